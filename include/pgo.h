@@ -1,0 +1,271 @@
+/*
+ * pgo.h — C-ABI of libpgo: the MI355X-native 6-DoF pose-graph Levenberg-Marquardt solver.
+ *
+ * This is the drop-in boundary for the ONE hot path of mpkuse/solve_keyframe_pose_graph:
+ * everything `PoseGraphSLAM::reinit_ceres_problem_onnewloopedge_optimize6DOF()` asks of Ceres
+ * (reference src/PoseGraphSLAM.cpp:1251-1950) plus the three cost functors of
+ * reference src/CeresResidues.h:19-222.  Each entry point below cites the reference
+ * interface it replaces.  Plain C: opaque handle, caller-owned arrays, fp64 + int32/int64.
+ * No torch types, no C++ types, never throws, never calls exit().
+ *
+ * Conventions (identical to the reference's storage, src/PoseGraphSLAM.h:153-175,
+ * src/utils/PoseManipUtils.cpp:61-98):
+ *   - node orientation: unit quaternion, 4 doubles per node in order x,y,z,w (Eigen coeffs order)
+ *   - node translation: 3 doubles per node
+ *   - one switch double per switchable edge, addressed by the caller-chosen switch index
+ *   - measurements are Eigen `Matrix4d` values, i.e. 16 doubles COLUMN-major, exactly what the
+ *     reference hands to `X::Create(const Matrix4d&, double)` (CeresResidues.h:72,129,204)
+ *   - tangent ordering inside the library (gradient output of pgo_evaluate):
+ *       [dtheta(3), dt(3)] per node, node-major, followed by one entry per switch variable.
+ *     dtheta is the Ceres `EigenQuaternionParameterization` increment: q <- [sin|d| d/|d|, cos|d|] (x) q.
+ *   - cost is the Ceres convention 0.5 * sum ||r||^2;  chi^2 = 2 * cost.
+ *
+ * Threading: a handle is single-caller (the reference drives Ceres from one thread, th_slam,
+ * src/keyframe_pose_graph_slam_node.cpp:475-477).  pgo_solve writes the caller's arrays exactly
+ * once, at the very end (the reference relies on this: src/PoseGraphSLAM.cpp:1894-1903).
+ */
+#ifndef PGO_H_
+#define PGO_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PGO_VERSION_MAJOR 0
+#define PGO_VERSION_MINOR 1
+
+typedef struct pgo_problem pgo_problem; /* opaque; replaces the persistent `ceres::Problem reint_problem`
+                                           (reference src/PoseGraphSLAM.h:197) */
+
+/* ---- error codes (0 = OK, negative = error).  Reference: asserts / exit(n) in the driver
+ *      (src/PoseGraphSLAM.cpp:201,207,274,1680,1711); Ceres reports through Summary. ---- */
+enum {
+    PGO_OK = 0,
+    PGO_ERR_INVALID_ARG = -1,    /* null pointer, negative count, index out of range */
+    PGO_ERR_NO_DEVICE = -2,      /* no HIP device / HIP runtime error at create */
+    PGO_ERR_HIP = -3,            /* a HIP call failed; pgo_last_error() has the text */
+    PGO_ERR_OUT_OF_MEMORY = -4,
+    PGO_ERR_STATE = -5,          /* call order violated (e.g. pgo_lm_step before pgo_solve_begin) */
+    PGO_ERR_COMM = -6,           /* RCCL failure */
+    PGO_ERR_NUMERIC = -7         /* non-finite cost/step at the initial point */
+};
+
+/* ---- termination types; same meaning as ceres::TerminationType as consumed at
+ *      src/PoseGraphSLAM.cpp:1905,1912 ---- */
+enum {
+    PGO_CONVERGENCE = 0,
+    PGO_NO_CONVERGENCE = 1,
+    PGO_FAILURE = 2
+};
+
+/* ---- linear solver for the LM normal equations (replaces SPARSE_NORMAL_CHOLESKY,
+ *      src/PoseGraphSLAM.cpp:1270) ---- */
+enum {
+    PGO_LINEAR_PCG_BLOCK_JACOBI = 0 /* device PCG on the Schur-reduced pose system, 6x6 block-Jacobi */
+};
+
+/* Options.  Defaults (pgo_options_init) are the Ceres defaults the reference runs with, plus
+ * max_num_iterations = 10 (src/PoseGraphSLAM.cpp:1268-1272).  See SURVEY.md Appendix B. */
+typedef struct pgo_options {
+    int32_t max_num_iterations;          /* 10   (PoseGraphSLAM.cpp:1272) */
+    int32_t linear_solver;               /* PGO_LINEAR_PCG_BLOCK_JACOBI */
+    int32_t jacobi_scaling;              /* 1    (Ceres default) */
+    int32_t max_num_consecutive_invalid_steps; /* 5 */
+    double initial_trust_region_radius;  /* 1e4  */
+    double max_trust_region_radius;      /* 1e16 */
+    double min_trust_region_radius;      /* 1e-32 */
+    double min_relative_decrease;        /* 1e-3 */
+    double min_lm_diagonal;              /* 1e-6 */
+    double max_lm_diagonal;              /* 1e32 */
+    double function_tolerance;           /* 1e-6 */
+    double gradient_tolerance;           /* 1e-10 */
+    double parameter_tolerance;          /* 1e-8 */
+    /* PCG controls (no Ceres counterpart: Ceres factorises exactly) */
+    int32_t cg_max_iterations;           /* 4000 */
+    int32_t cg_check_every;              /* 25: host polls the device convergence flag every this many iterations */
+    double cg_rel_tolerance;             /* 1e-10: stop when ||r||_{M^-1} <= tol * ||b||_{M^-1} */
+    /* device selection */
+    int32_t device_id;                   /* -1: use the current HIP device */
+    int32_t verbosity;                   /* 0 silent (minimizer_progress_to_stdout=false, :1271), 1 per-iteration line on stderr */
+} pgo_options;
+
+/* Per-iteration record; mirrors ceres::IterationSummary fields the BriefReport is built from. */
+typedef struct pgo_iteration {
+    int32_t iteration;
+    int32_t step_is_valid;
+    int32_t step_is_successful;
+    int32_t cg_iterations;
+    double cost;               /* cost after this iteration (Ceres convention, 0.5 sum r^2) */
+    double cost_change;
+    double model_cost_change;
+    double relative_decrease;
+    double gradient_max_norm;
+    double step_norm;
+    double trust_region_radius;
+    double cg_residual;        /* final relative preconditioned residual of the PCG solve */
+    double seconds;            /* wall seconds of this iteration (device-synchronised) */
+} pgo_iteration;
+
+#define PGO_MAX_ITERATION_LOG 256
+
+/* Replaces ceres::Solver::Summary as read at src/PoseGraphSLAM.cpp:1905,1912,1921. */
+typedef struct pgo_summary {
+    int32_t termination_type;        /* PGO_CONVERGENCE / PGO_NO_CONVERGENCE / PGO_FAILURE */
+    int32_t num_iterations;          /* LM iterations executed, NOT counting iteration 0 (Ceres' iterations.size()-1) */
+    int32_t num_successful_steps;
+    int32_t num_unsuccessful_steps;
+    int64_t cg_iterations;           /* total PCG iterations */
+    double initial_cost;
+    double final_cost;
+    double seconds_total;            /* whole pgo_solve, including H2D/D2H */
+    double seconds_device;           /* LM loop only (state resident in HBM) */
+    int32_t num_logged;              /* entries valid in iterations[] (entry 0 = iteration 0) */
+    int32_t reserved_;
+    pgo_iteration iterations[PGO_MAX_ITERATION_LOG];
+    char message[256];
+} pgo_summary;
+
+/* ------------------------------------------------------------------------------------------ */
+/* lifecycle                                                                                  */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Fills `o` with the defaults documented above. */
+void pgo_options_init(pgo_options* o);
+
+/* Creates a persistent problem bound to one HIP device (replaces constructing `reint_problem`,
+ * src/PoseGraphSLAM.h:197).  `opts` may be NULL (defaults).  Fails with PGO_ERR_NO_DEVICE when
+ * no GPU is usable: there is NO CPU fallback in this library. */
+int pgo_create(pgo_problem** out, const pgo_options* opts);
+int pgo_destroy(pgo_problem* p);
+
+/* Replaces the option assignments at src/PoseGraphSLAM.cpp:1268-1272. */
+int pgo_set_options(pgo_problem* p, const pgo_options* opts);
+
+/* Capacity hint (the reference pre-allocates 30000/30000, src/PoseGraphSLAM.cpp:17-25; here growable). */
+int pgo_reserve(pgo_problem* p, int64_t n_nodes, int64_t n_edges);
+
+/* ------------------------------------------------------------------------------------------ */
+/* problem construction (library copies edge data at add time, as Ceres owns cost functions)   */
+/* ------------------------------------------------------------------------------------------ */
+
+/* n x `AddResidualBlock(SixDOFError::Create(c1_T_c2, weight), NULL, q[c1], t[c1], q[c2], t[c2])`
+ * — reference src/PoseGraphSLAM.cpp:1629-1633 with functor src/CeresResidues.h:19-90.
+ * c1_T_c2: n x 16 doubles (column-major Matrix4d).  weight: n doubles. */
+int pgo_add_relpose_edges(pgo_problem* p, int64_t n, const int32_t* c1, const int32_t* c2,
+                          const double* c1_T_c2, const double* weight);
+
+/* n x `AddResidualBlock(SixDOFErrorWithSwitchingConstraints::Create(bTa, weight), NULL,
+ *                       q[c1], t[c1], q[c2], t[c2], &switch[switch_idx])`
+ * — reference src/PoseGraphSLAM.cpp:1550-1556 with functor src/CeresResidues.h:145-222.
+ * `weight` is accepted and IGNORED exactly as the reference functor ignores it (CeresResidues.h:198);
+ * it may be NULL.  Each switch index must be used by at most one edge (reference: switch e <-> loop edge e). */
+int pgo_add_switchable_edges(pgo_problem* p, int64_t n, const int32_t* c1, const int32_t* c2,
+                             const double* c1_T_c2, const double* weight, const int32_t* switch_idx);
+
+/* REPLACES the current regulariser set: `RemoveResidualBlock` of all previous ones followed by
+ * n x `AddResidualBlock(NodePoseRegularization::Create(target, weight), NULL, q[node], t[node])`
+ * — reference src/PoseGraphSLAM.cpp:1803-1807,1844-1849 with functor src/CeresResidues.h:96-141. */
+int pgo_set_node_regularizers(pgo_problem* p, int64_t n, const int32_t* node,
+                              const double* target, const double* weight);
+
+/* `SetParameterBlockConstant(q[node]); SetParameterBlockConstant(t[node])`
+ * — reference src/PoseGraphSLAM.cpp:143-144 (load_state path).  Cumulative. */
+int pgo_set_nodes_constant(pgo_problem* p, int64_t n, const int32_t* node);
+
+/* Introspection. */
+int pgo_num_relpose_edges(const pgo_problem* p, int64_t* n);
+int pgo_num_switchable_edges(const pgo_problem* p, int64_t* n);
+int pgo_num_regularizers(const pgo_problem* p, int64_t* n);
+
+/* ------------------------------------------------------------------------------------------ */
+/* solve                                                                                      */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Replaces `ceres::Solve(reint_options, &reint_problem, &reint_summary)` — src/PoseGraphSLAM.cpp:1903.
+ * In/out, in place: quat_xyzw[4*n_nodes], t[3*n_nodes], sw[n_switch].  Arrays are HOST pointers.
+ * On PGO_FAILURE the arrays are left unmodified (Ceres IsSolutionUsable semantics).
+ * Equivalent to pgo_solve_begin + pgo_lm_step until done + pgo_solve_end. */
+int pgo_solve(pgo_problem* p, double* quat_xyzw, double* t, double* sw,
+              int64_t n_nodes, int64_t n_switch, pgo_summary* summary);
+
+/* Stepping form of the same solve (used by bench.py to time exactly K LM iterations with the state
+ * resident in HBM).  begin: upload + (re)build device graph + iteration 0 (evaluate, Jacobi scaling,
+ * gradient).  step: ONE trust-region iteration; *done = 1 when a Ceres termination test fired
+ * (the step may still be called again when `ignore_termination` != 0).  end: final write-back. */
+int pgo_solve_begin(pgo_problem* p, const double* quat_xyzw, const double* t, const double* sw,
+                    int64_t n_nodes, int64_t n_switch);
+int pgo_lm_step(pgo_problem* p, int32_t ignore_termination, int32_t* done);
+int pgo_solve_end(pgo_problem* p, double* quat_xyzw, double* t, double* sw, pgo_summary* summary);
+
+/* Parity hook = `ceres::Problem::Evaluate` at the given point (all outputs optional, HOST pointers):
+ *   cost                      0.5 sum r^2 over all residual blocks
+ *   residuals                 concatenated in block order: relpose edges (6 each, add order),
+ *                             switchable edges (7 each, add order), regularisers (6 each)
+ *   gradient                  J^T r in the tangent layout documented at the top (6*n_nodes + n_switch)
+ * Runs K1 (+K2 when a gradient is asked for) on the device. */
+int pgo_evaluate(pgo_problem* p, const double* quat_xyzw, const double* t, const double* sw,
+                 int64_t n_nodes, int64_t n_switch,
+                 double* cost, double* residuals, double* gradient);
+
+/* Parity hook for the Jacobian blocks K1 produced at the last pgo_evaluate / pgo_solve_begin point.
+ * For edge kind k (0 relpose, 1 switchable, 2 regulariser) copies, for edges [first, first+count):
+ *   J1[count*36], J2[count*36]  row-major (rows = residual 0..5, cols = [dtheta(3), dt(3)] of c1 / c2;
+ *                               regularisers: J1 only, J2 may be NULL)
+ *   dr_ds[count*7]              switchable only: d r / d s   (NULL otherwise)
+ * These are the Ceres tangent-space blocks (autodiff 6x4 times the 4x3 parameterization Jacobian). */
+int pgo_get_jacobian_blocks(pgo_problem* p, int32_t kind, int64_t first, int64_t count,
+                            double* J1, double* J2, double* dr_ds);
+
+/* Parity hook for K2: the assembled (undamped, unscaled) normal matrix at the last linearisation.
+ *   diag[n_nodes*36]     H_ii row-major (pose part BEFORE switch elimination: sum J^T J)
+ *   grad[n_nodes*6]      g_i
+ *   offdiag[E*36]        J1^T J2 per edge in internal edge order: relpose (add order) then switchable
+ *   sw_c[E_s*12], sw_hss[E_s], sw_gs[E_s]   switch couplings [J1^T Js ; J2^T Js], Js^T Js, Js^T r
+ * Any pointer may be NULL. */
+int pgo_get_normal_blocks(pgo_problem* p, double* diag, double* grad, double* offdiag,
+                          double* sw_c, double* sw_hss, double* sw_gs);
+
+/* Parity hook for K3: y = (H_reduced + damping) * x on the device, x,y HOST arrays of 6*n_nodes,
+ * using the damping of the current trust-region radius.  Valid after pgo_solve_begin. */
+int pgo_apply_normal_operator(pgo_problem* p, const double* x, double* y);
+
+/* ------------------------------------------------------------------------------------------ */
+/* multi-GPU (edge sharding).  One process per GPU.                             */
+/* ------------------------------------------------------------------------------------------ */
+
+#define PGO_COMM_ID_BYTES 128
+
+/* Rank 0 produces an RCCL unique id (ncclGetUniqueId); the host (torch.distributed) broadcasts the
+ * bytes; every rank then calls pgo_comm_init.  After that the edges added on this rank are this
+ * rank's SHARD: K1/K2 run on the local shard, diagonal blocks + gradient are all-reduced once per
+ * linearisation and the CG matvec output (6*n_nodes doubles) once per CG iteration — a single
+ * ncclAllReduce(sum, fp64) over xGMI.  Pose/switch arrays are replicated; switch variables belong
+ * to the rank holding their edge (others pass through what they were given).  */
+int pgo_comm_get_unique_id(uint8_t id[PGO_COMM_ID_BYTES]);
+int pgo_comm_init(pgo_problem* p, int32_t rank, int32_t world_size, const uint8_t id[PGO_COMM_ID_BYTES]);
+int pgo_comm_destroy(pgo_problem* p);
+
+/* ------------------------------------------------------------------------------------------ */
+/* measurement helpers (bench.py): HIP-event timing of the dominant kernel on the library's stream */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Launches K1 (residual + Jacobian) `launches` times back-to-back on the library stream at the current
+ * device state (valid after pgo_solve_begin) bracketed by hipEvents; returns the average
+ * milliseconds per launch and the algorithmic bytes one launch moves (SURVEY.md §8d formula). */
+int pgo_time_linearize_kernel(pgo_problem* p, int32_t launches, double* avg_ms, double* algorithmic_bytes);
+
+/* Same for one PCG iteration (K3+K4) and the assembly (K2). which: 0 = K1, 1 = K2, 2 = one PCG iteration, 3 = K1 cost-only */
+int pgo_time_kernel(pgo_problem* p, int32_t which, int32_t launches, double* avg_ms, double* algorithmic_bytes);
+
+int pgo_device_synchronize(pgo_problem* p);
+
+const char* pgo_strerror(int code);
+/* Text of the last error on this handle (HIP/RCCL error string); never NULL. */
+const char* pgo_last_error(const pgo_problem* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PGO_H_ */

@@ -1,0 +1,52 @@
+"""In-tree native builds: libpgo.so (HIP, gfx950) and libpgo_graphgen.so (host).  No JIT cache: the built
+.so files live next to the sources so that they travel to the GPU box with the repo snapshot."""
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
+LIBPGO = os.path.join(_HERE, "libpgo.so")
+LIBGEN = os.path.join(_HERE, "libpgo_graphgen.so")
+
+HIP_SOURCES = ["pgo_kernels.hip", "pgo_solver.hip", "pgo_capi.cpp"]
+HIP_HEADERS = ["pgo_internal.hpp", "pgo_device_math.hpp"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def hipcc_path():
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: libpgo cannot be built (there is no CPU fallback)")
+
+
+def build_graphgen(force=False):
+    src = os.path.join(CSRC, "pgo_graphgen.cpp")
+    if force or _stale(LIBGEN, [src, os.path.join(INCLUDE, "pgo_graphgen.h")]):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", INCLUDE, "-o", LIBGEN, src])
+    return LIBGEN
+
+
+def build_libpgo(force=False, verbose=False):
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
+    deps = srcs + [os.path.join(CSRC, h) for h in HIP_HEADERS] + [os.path.join(INCLUDE, "pgo.h")]
+    if force or _stale(LIBPGO, deps):
+        cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=on",
+               "-I", INCLUDE, "-I", CSRC, "-x", "hip"] + srcs + ["-o", LIBPGO, "-ldl"]
+        if verbose:
+            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+        subprocess.check_call(cmd)
+    return LIBPGO
+
+
+def build_all(force=False):
+    build_graphgen(force)
+    build_libpgo(force)

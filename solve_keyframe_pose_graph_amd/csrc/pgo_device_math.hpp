@@ -1,0 +1,229 @@
+// pgo_device_math.hpp — closed-form residuals and tangent-space Jacobian blocks of the three cost
+// functors, as evaluated per lane by the K1 kernels.  fp64 throughout.
+//
+// What is replaced (reference file:line):
+//   SixDOFError::operator() + AutoDiff<6,4,3,4,3>                         src/CeresResidues.h:32-69,74
+//   SixDOFErrorWithSwitchingConstraints::operator() + AutoDiff<7,4,3,4,3,1> src/CeresResidues.h:158-201,206
+//   NodePoseRegularization::operator() + AutoDiff<6,4,3>                  src/CeresResidues.h:104-127,131
+//   ceres::EigenQuaternionParameterization::{Plus,ComputeJacobian}        src/PoseGraphSLAM.cpp:1276,1352
+// The reference differentiates with Jets and projects with the 4x3 parameterization Jacobian; here the
+// product (6x4)(4x3) is derived analytically — the left perturbation q <- (d,1) (x) q,
+// i.e. R <- (I + 2[d]x) R.  Tangent ordering per pose: [dtheta(3), dt(3)].
+//
+// Compiles for host too (PGO_HD empty) so the algebra can be checked against tests/golden without a GPU.
+#pragma once
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define PGO_HD __host__ __device__ __forceinline__
+#else
+#define PGO_HD inline
+#endif
+
+namespace pgo {
+
+struct Pose {            // w_T_c : unit quaternion (x,y,z,w as the reference stores it) + translation
+    double qx, qy, qz, qw, tx, ty, tz;
+};
+struct Meas {            // observed c1_T_c2 : quaternion from Eigen's Matrix3 -> Quaternion rule + translation, and the edge weight
+    double qx, qy, qz, qw, tx, ty, tz, w;
+};
+
+// R(q) — same polynomial as Eigen::toRotationMatrix (no normalisation), row-major
+PGO_HD void quat_to_rot(double x, double y, double z, double w, double* R) {
+    const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w;
+    const double txx = tx * x, txy = ty * x, txz = tz * x;
+    const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1.0 - (tyy + tzz); R[1] = txy - twz;         R[2] = txz + twy;
+    R[3] = txy + twz;         R[4] = 1.0 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;         R[7] = tyz + twx;         R[8] = 1.0 - (txx + tyy);
+}
+
+// Hamilton product (Eigen coefficient order x,y,z,w)
+PGO_HD void quat_mul(const double* a, const double* b, double* r) {
+    r[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+    r[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    r[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+    r[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+}
+
+// M(a,b) = d/dd [ vec( a (x) (d,0) (x) b ) ]  (3x3 row-major), a = (av,aw), b = (bv,bw):
+//   aw bw I - aw [bv]x - av bv^T + bw [av]x - [av]x [bv]x
+PGO_HD void quat_sandwich_jac(const double* a, const double* b, double* M) {
+    const double ax = a[0], ay = a[1], az = a[2], aw = a[3];
+    const double bx = b[0], by = b[1], bz = b[2], bw = b[3];
+    const double ab = ax * bx + ay * by + az * bz;          // av . bv
+    const double d = aw * bw + ab;                          // diagonal part: aw bw + (av.bv) from -[av]x[bv]x = (av.bv) I - bv av^T
+    // -[av]x[bv]x = (av.bv) I - bv av^T ;  total = (aw bw + av.bv) I - av bv^T - bv av^T + [bw av - aw bv]x
+    const double cx = bw * ax - aw * bx, cy = bw * ay - aw * by, cz = bw * az - aw * bz;
+    M[0] = d - 2.0 * ax * bx;          M[1] = -(ax * by + bx * ay) - cz;  M[2] = -(ax * bz + bx * az) + cy;
+    M[3] = -(ay * bx + by * ax) + cz;  M[4] = d - 2.0 * ay * by;          M[5] = -(ay * bz + by * az) - cx;
+    M[6] = -(az * bx + bz * ax) - cy;  M[7] = -(az * by + bz * ay) + cx;  M[8] = d - 2.0 * az * bz;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Relative-pose residual (SixDOFError) at weight w:
+//   a = R1 t_o ; v = p1 + a - p2 ; dt = R2^T v ; dq = q2* (x) q1 (x) q_o ; r = w [dt ; 2 dq.vec]
+//   dr/d(theta1) = w [ -2 R2^T [a]x ; 2 M ]      dr/d(p1) = w [ R2^T ; 0 ]
+//   dr/d(theta2) = w [  2 R2^T [v]x ; -2 M ]     dr/d(p2) = w [ -R2^T ; 0 ]        M = M(q2*, q1 (x) q_o)
+// Outputs: r[6]; J1[36], J2[36] row-major 6x6 (cols = [dtheta, dt]).  If !WANT_J only r is written.
+// ---------------------------------------------------------------------------------------------
+template <bool WANT_J>
+PGO_HD void relpose_residual(const Pose& c1, const Pose& c2, const Meas& m, double w, double* r, double* J1, double* J2) {
+    double R1[9], R2[9];
+    quat_to_rot(c1.qx, c1.qy, c1.qz, c1.qw, R1);
+    quat_to_rot(c2.qx, c2.qy, c2.qz, c2.qw, R2);
+    const double a0 = R1[0] * m.tx + R1[1] * m.ty + R1[2] * m.tz;
+    const double a1 = R1[3] * m.tx + R1[4] * m.ty + R1[5] * m.tz;
+    const double a2 = R1[6] * m.tx + R1[7] * m.ty + R1[8] * m.tz;
+    const double v0 = c1.tx + a0 - c2.tx, v1 = c1.ty + a1 - c2.ty, v2 = c1.tz + a2 - c2.tz;
+    // dt = R2^T v
+    const double d0 = R2[0] * v0 + R2[3] * v1 + R2[6] * v2;
+    const double d1 = R2[1] * v0 + R2[4] * v1 + R2[7] * v2;
+    const double d2 = R2[2] * v0 + R2[5] * v1 + R2[8] * v2;
+    const double q1[4] = {c1.qx, c1.qy, c1.qz, c1.qw};
+    const double qo[4] = {m.qx, m.qy, m.qz, m.qw};
+    const double q2c[4] = {-c2.qx, -c2.qy, -c2.qz, c2.qw};
+    double b[4], dq[4];
+    quat_mul(q1, qo, b);
+    quat_mul(q2c, b, dq);
+    r[0] = w * d0; r[1] = w * d1; r[2] = w * d2;
+    r[3] = w * 2.0 * dq[0]; r[4] = w * 2.0 * dq[1]; r[5] = w * 2.0 * dq[2];
+    if (WANT_J) {
+        // a' = R2^T a  ->  R2^T [a]x = [a']x R2^T ;  R2^T [v]x = [dt]x R2^T
+        const double p0 = R2[0] * a0 + R2[3] * a1 + R2[6] * a2;
+        const double p1 = R2[1] * a0 + R2[4] * a1 + R2[7] * a2;
+        const double p2 = R2[2] * a0 + R2[5] * a1 + R2[8] * a2;
+        double M[9];
+        quat_sandwich_jac(q2c, b, M);
+        const double w2 = 2.0 * w;
+        // rows 0..2 of [x]x R2^T :  row i = e_i^T [x]x R2^T ; ([x]x R2^T)(i,j) = sum_k [x]x(i,k) R2(j,k)
+#define PGO_CROSS_RT(X0, X1, X2, i, j) \
+        ((i) == 0 ? (-(X2) * R2[(j) * 3 + 1] + (X1) * R2[(j) * 3 + 2]) : (i) == 1 ? ((X2) * R2[(j) * 3 + 0] - (X0) * R2[(j) * 3 + 2]) : (-(X1) * R2[(j) * 3 + 0] + (X0) * R2[(j) * 3 + 1]))
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double rt = R2[j * 3 + i];                         // R2^T(i,j)
+                J1[i * 6 + j] = -w2 * PGO_CROSS_RT(p0, p1, p2, i, j);    // -2 w [a']x R2^T
+                J1[i * 6 + 3 + j] = w * rt;
+                J2[i * 6 + j] = w2 * PGO_CROSS_RT(d0, d1, d2, i, j);     //  2 w [dt]x R2^T
+                J2[i * 6 + 3 + j] = -w * rt;
+                J1[(3 + i) * 6 + j] = w2 * M[i * 3 + j];
+                J1[(3 + i) * 6 + 3 + j] = 0.0;
+                J2[(3 + i) * 6 + j] = -w2 * M[i * 3 + j];
+                J2[(3 + i) * 6 + 3 + j] = 0.0;
+            }
+        }
+#undef PGO_CROSS_RT
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Switchable residual (SixDOFErrorWithSwitchingConstraints): with r6, A1, A2 the relative-pose residual
+// and blocks at w = 1 (the edge weight is ignored exactly as CeresResidues.h:198 ignores it):
+//   r = [ s r6 ; s (1 - s) ]   J1 = s A1, J2 = s A2 (7th row zero, not stored)   dr/ds = [ r6 ; 1 - 2 s ]
+// ---------------------------------------------------------------------------------------------
+template <bool WANT_J>
+PGO_HD void switch_residual(const Pose& c1, const Pose& c2, const Meas& m, double s, double* r7, double* J1, double* J2, double* Js7) {
+    double r6[6];
+    relpose_residual<WANT_J>(c1, c2, m, 1.0, r6, J1, J2);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) r7[i] = s * r6[i];
+    r7[6] = s * (1.0 - s);
+    if (WANT_J) {
+#pragma unroll
+        for (int i = 0; i < 36; ++i) { J1[i] *= s; J2[i] *= s; }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) Js7[i] = r6[i];
+        Js7[6] = 1.0 - 2.0 * s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Node regulariser (NodePoseRegularization) with target f = (R_f, t_f) given as a rigid Matrix4d and
+// q_f = Eigen quaternion of R_f:   delta = f^-1 [R(q1) p1; 0 1]
+//   r = w [ R_f^T (p1 - t_f) ; 2 sigma (q_f* (x) q1).vec ],  sigma = sign chosen by Eigen's Matrix3->Quaternion
+//   branch rule applied to R_delta (w > 0 when trace > 0, else the largest-diagonal component > 0).
+//   dr/dp1 = w [ R_f^T ; 0 ]     dr/dtheta1 = w [ 0 ; 2 sigma M(q_f*, q1) ]
+// Rf is row-major 3x3.
+// ---------------------------------------------------------------------------------------------
+template <bool WANT_J>
+PGO_HD void prior_residual(const Pose& c1, const double* Rf, const double* tf, const double* qf, double w, double* r, double* J1) {
+    const double e0 = c1.tx - tf[0], e1 = c1.ty - tf[1], e2 = c1.tz - tf[2];
+    r[0] = w * (Rf[0] * e0 + Rf[3] * e1 + Rf[6] * e2);
+    r[1] = w * (Rf[1] * e0 + Rf[4] * e1 + Rf[7] * e2);
+    r[2] = w * (Rf[2] * e0 + Rf[5] * e1 + Rf[8] * e2);
+    const double qfc[4] = {-qf[0], -qf[1], -qf[2], qf[3]};
+    const double q1[4] = {c1.qx, c1.qy, c1.qz, c1.qw};
+    double dq[4];
+    quat_mul(qfc, q1, dq);
+    // Eigen branch rule on R_delta = R(dq): trace = 3 - 4 |v|^2 ; diag_i = 1 - 2 (|v|^2 - v_i^2)
+    const double xx = dq[0] * dq[0], yy = dq[1] * dq[1], zz = dq[2] * dq[2];
+    const double trace = 3.0 - 4.0 * (xx + yy + zz);
+    double sigma;
+    if (trace > 0.0) sigma = dq[3] >= 0.0 ? 1.0 : -1.0;
+    else {
+        const double m00 = 1.0 - 2.0 * (yy + zz), m11 = 1.0 - 2.0 * (xx + zz), m22 = 1.0 - 2.0 * (xx + yy);
+        int i = 0; double mii = m00;
+        if (m11 > m00) { i = 1; mii = m11; }
+        if (m22 > mii) { i = 2; }
+        sigma = dq[i] >= 0.0 ? 1.0 : -1.0;
+    }
+    const double w2 = 2.0 * w * sigma;
+    r[3] = w2 * dq[0]; r[4] = w2 * dq[1]; r[5] = w2 * dq[2];
+    if (WANT_J) {
+        double M[9];
+        quat_sandwich_jac(qfc, q1, M);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                J1[i * 6 + j] = 0.0;
+                J1[i * 6 + 3 + j] = w * Rf[j * 3 + i];
+                J1[(3 + i) * 6 + j] = w2 * M[i * 3 + j];
+                J1[(3 + i) * 6 + 3 + j] = 0.0;
+            }
+        }
+    }
+}
+
+// ceres::EigenQuaternionParameterization::Plus:  q+ = [sin|d| d/|d| ; cos|d|] (x) q
+PGO_HD void quat_plus(const double* q, const double* d, double* out) {
+    const double n = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    if (n > 0.0) {
+        const double sbd = sin(n) / n;
+        const double dq[4] = {sbd * d[0], sbd * d[1], sbd * d[2], cos(n)};
+        quat_mul(dq, q, out);
+    } else {
+        out[0] = q[0]; out[1] = q[1]; out[2] = q[2]; out[3] = q[3];
+    }
+}
+
+// Eigen's `Quaterniond(Matrix3d)` (CeresResidues.h:24,150): R row-major -> q (x,y,z,w).  Host-side use
+// when an edge is added; restated from Eigen's published algorithm (branch on trace / largest diagonal).
+inline void eigen_matrix_to_quat(const double* R, double* q) {
+    double t = R[0] + R[4] + R[8];
+    if (t > 0.0) {
+        t = sqrt(t + 1.0);
+        q[3] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (R[7] - R[5]) * t;
+        q[1] = (R[2] - R[6]) * t;
+        q[2] = (R[3] - R[1]) * t;
+    } else {
+        int i = 0;
+        if (R[4] > R[0]) i = 1;
+        if (R[8] > R[i * 3 + i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrt(R[i * 3 + i] - R[j * 3 + j] - R[k * 3 + k] + 1.0);
+        q[i] = 0.5 * t;
+        t = 0.5 / t;
+        q[3] = (R[k * 3 + j] - R[j * 3 + k]) * t;
+        q[j] = (R[j * 3 + i] + R[i * 3 + j]) * t;
+        q[k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
+    }
+}
+
+}  // namespace pgo
