@@ -10,7 +10,7 @@ INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIBPGO = os.path.join(_HERE, "libpgo.so")
 LIBGEN = os.path.join(_HERE, "libpgo_graphgen.so")
 
-HIP_SOURCES = ["pgo_kernels.hip", "pgo_solver.hip", "pgo_capi.cpp"]
+HIP_SOURCES = ["pgo_kernels.hip", "pgo_solver.hip"]
 HIP_HEADERS = ["pgo_internal.hpp", "pgo_device_math.hpp"]
 
 

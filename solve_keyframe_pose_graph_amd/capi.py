@@ -1,0 +1,281 @@
+"""ctypes binding of libpgo.so (include/pgo.h) — the drop-in boundary for the reference's Ceres path.
+
+The library is the product; this module only marshals numpy arrays across the C-ABI.  It fails loudly when
+libpgo.so cannot be built/loaded or when no HIP device is present: there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+
+PGO_MAX_ITERATION_LOG = 256
+PGO_COMM_ID_BYTES = 128
+CONVERGENCE, NO_CONVERGENCE, FAILURE = 0, 1, 2
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+
+class Options(C.Structure):
+    _fields_ = [("max_num_iterations", C.c_int32), ("linear_solver", C.c_int32), ("jacobi_scaling", C.c_int32),
+                ("max_num_consecutive_invalid_steps", C.c_int32),
+                ("initial_trust_region_radius", C.c_double), ("max_trust_region_radius", C.c_double), ("min_trust_region_radius", C.c_double),
+                ("min_relative_decrease", C.c_double), ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
+                ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
+                ("cg_max_iterations", C.c_int32), ("cg_check_every", C.c_int32), ("cg_rel_tolerance", C.c_double),
+                ("device_id", C.c_int32), ("verbosity", C.c_int32)]
+
+
+class Iteration(C.Structure):
+    _fields_ = [("iteration", C.c_int32), ("step_is_valid", C.c_int32), ("step_is_successful", C.c_int32), ("cg_iterations", C.c_int32),
+                ("cost", C.c_double), ("cost_change", C.c_double), ("model_cost_change", C.c_double), ("relative_decrease", C.c_double),
+                ("gradient_max_norm", C.c_double), ("step_norm", C.c_double), ("trust_region_radius", C.c_double), ("cg_residual", C.c_double),
+                ("seconds", C.c_double)]
+
+
+class Summary(C.Structure):
+    _fields_ = [("termination_type", C.c_int32), ("num_iterations", C.c_int32), ("num_successful_steps", C.c_int32), ("num_unsuccessful_steps", C.c_int32),
+                ("cg_iterations", C.c_int64), ("initial_cost", C.c_double), ("final_cost", C.c_double), ("seconds_total", C.c_double),
+                ("seconds_device", C.c_double), ("num_logged", C.c_int32), ("reserved_", C.c_int32),
+                ("iterations", Iteration * PGO_MAX_ITERATION_LOG), ("message", C.c_char * 256)]
+
+
+# every symbol include/pgo.h declares (checked by tests/test_capi_symbols.py against the header text)
+EXPORTS = [
+    "pgo_options_init", "pgo_create", "pgo_destroy", "pgo_set_options", "pgo_reserve",
+    "pgo_add_relpose_edges", "pgo_add_switchable_edges", "pgo_set_node_regularizers", "pgo_set_nodes_constant",
+    "pgo_num_relpose_edges", "pgo_num_switchable_edges", "pgo_num_regularizers",
+    "pgo_solve", "pgo_solve_begin", "pgo_lm_step", "pgo_solve_end", "pgo_evaluate",
+    "pgo_get_jacobian_blocks", "pgo_get_normal_blocks", "pgo_apply_normal_operator",
+    "pgo_comm_get_unique_id", "pgo_comm_init", "pgo_comm_destroy",
+    "pgo_time_linearize_kernel", "pgo_time_kernel", "pgo_device_synchronize", "pgo_strerror", "pgo_last_error",
+]
+
+_lib = None
+
+
+class PgoError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("libpgo error %d: %s" % (code, text))
+        self.code = code
+
+
+def load(build=True):
+    """Loads libpgo.so (building it in-tree with hipcc when stale).  Raises if that is impossible."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.build_libpgo() if build else _build.LIBPGO
+    if not os.path.exists(path):
+        raise RuntimeError("libpgo.so is missing (%s): the HIP library must be built; there is no CPU fallback" % path)
+    lib = C.CDLL(path)
+    lib.pgo_strerror.restype = C.c_char_p
+    lib.pgo_last_error.restype = C.c_char_p
+    lib.pgo_last_error.argtypes = [C.c_void_p]
+    lib.pgo_strerror.argtypes = [C.c_int]
+    for f in EXPORTS:
+        if not hasattr(lib, f):
+            raise RuntimeError("libpgo.so does not export %s" % f)
+    _lib = lib
+    return lib
+
+
+def default_options(**kw):
+    o = Options()
+    load().pgo_options_init(C.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise TypeError("unknown option %r" % k)
+        setattr(o, k, v)
+    return o
+
+
+def _d(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _pd(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+def _pi(a):
+    return a.ctypes.data_as(_ip) if a is not None else None
+
+
+class Problem:
+    """Persistent solver problem = the reference's `ceres::Problem reint_problem` + `ceres::Solve`."""
+
+    def __init__(self, options=None, **opt_kw):
+        self.lib = load()
+        self.h = C.c_void_p()
+        o = options if options is not None else default_options(**opt_kw)
+        rc = self.lib.pgo_create(C.byref(self.h), C.byref(o))
+        if rc != 0:
+            self.h = C.c_void_p()
+            raise PgoError(rc, self.lib.pgo_strerror(rc).decode())
+        self.options = o
+        self.n_rel = self.n_sw = self.n_reg = 0
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.lib.pgo_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise PgoError(rc, "%s — %s" % (self.lib.pgo_strerror(rc).decode(), self.lib.pgo_last_error(self.h).decode()))
+
+    def set_options(self, **kw):
+        for k, v in kw.items():
+            if not hasattr(self.options, k):
+                raise TypeError("unknown option %r" % k)
+            setattr(self.options, k, v)
+        self._check(self.lib.pgo_set_options(self.h, C.byref(self.options)))
+
+    # ---- problem construction ----
+    def add_relpose_edges(self, c1, c2, c1_T_c2, weight):
+        c1, c2, T, w = _i(c1), _i(c2), _d(c1_T_c2), _d(weight)
+        n = len(c1)
+        assert len(c2) == n and T.size == 16 * n and w.size == n
+        self._check(self.lib.pgo_add_relpose_edges(self.h, C.c_int64(n), _pi(c1), _pi(c2), _pd(T), _pd(w)))
+        self.n_rel += n
+
+    def add_switchable_edges(self, c1, c2, c1_T_c2, weight, switch_idx):
+        c1, c2, T, s = _i(c1), _i(c2), _d(c1_T_c2), _i(switch_idx)
+        n = len(c1)
+        w = _d(weight) if weight is not None else None
+        assert len(c2) == n and T.size == 16 * n and len(s) == n
+        self._check(self.lib.pgo_add_switchable_edges(self.h, C.c_int64(n), _pi(c1), _pi(c2), _pd(T), _pd(w), _pi(s)))
+        self.n_sw += n
+
+    def set_node_regularizers(self, node, target, weight):
+        node, T, w = _i(node), _d(target), _d(weight)
+        n = len(node)
+        assert T.size == 16 * n and w.size == n
+        self._check(self.lib.pgo_set_node_regularizers(self.h, C.c_int64(n), _pi(node), _pd(T), _pd(w)))
+        self.n_reg = n
+
+    def set_nodes_constant(self, node):
+        node = _i(node)
+        self._check(self.lib.pgo_set_nodes_constant(self.h, C.c_int64(len(node)), _pi(node)))
+
+    # ---- solve ----
+    @staticmethod
+    def _state(quat, t, sw):
+        q = np.array(quat, dtype=np.float64).reshape(-1).copy()
+        tt = np.array(t, dtype=np.float64).reshape(-1).copy()
+        s = np.array(sw, dtype=np.float64).reshape(-1).copy() if sw is not None else np.zeros(0)
+        assert q.size % 4 == 0 and tt.size == q.size // 4 * 3
+        return q, tt, s
+
+    def solve(self, quat, t, sw=None):
+        """= ceres::Solve.  Returns (quat, t, sw, Summary); the inputs are not modified."""
+        q, tt, s = self._state(quat, t, sw)
+        summ = Summary()
+        self._check(self.lib.pgo_solve(self.h, _pd(q), _pd(tt), _pd(s) if s.size else None, C.c_int64(q.size // 4), C.c_int64(s.size), C.byref(summ)))
+        return q, tt, s, summ
+
+    def solve_begin(self, quat, t, sw=None):
+        q, tt, s = self._state(quat, t, sw)
+        self._shape = (q.size // 4, s.size)
+        self._check(self.lib.pgo_solve_begin(self.h, _pd(q), _pd(tt), _pd(s) if s.size else None, C.c_int64(q.size // 4), C.c_int64(s.size)))
+
+    def lm_step(self, ignore_termination=False):
+        done = C.c_int32(0)
+        self._check(self.lib.pgo_lm_step(self.h, C.c_int32(1 if ignore_termination else 0), C.byref(done)))
+        return bool(done.value)
+
+    def solve_end(self):
+        N, S = self._shape
+        q, tt, s = np.zeros(4 * N), np.zeros(3 * N), np.zeros(S)
+        summ = Summary()
+        self._check(self.lib.pgo_solve_end(self.h, _pd(q), _pd(tt), _pd(s) if S else None, C.byref(summ)))
+        return q, tt, s, summ
+
+    def evaluate(self, quat, t, sw=None, want_residuals=True, want_gradient=True):
+        q, tt, s = self._state(quat, t, sw)
+        N, S = q.size // 4, s.size
+        cost = C.c_double(0)
+        res = np.zeros(6 * self.n_rel + 7 * self.n_sw + 6 * self.n_reg) if want_residuals else None
+        grad = np.zeros(6 * N + S) if want_gradient else None
+        self._check(self.lib.pgo_evaluate(self.h, _pd(q), _pd(tt), _pd(s) if S else None, C.c_int64(N), C.c_int64(S), C.byref(cost), _pd(res), _pd(grad)))
+        self._shape = (N, S)
+        return cost.value, res, grad
+
+    def jacobian_blocks(self, kind, first=0, count=None):
+        n = [self.n_rel, self.n_sw, self.n_reg][kind]
+        count = n - first if count is None else count
+        J1 = np.zeros((count, 6, 6)); J2 = np.zeros((count, 6, 6)); ds = np.zeros((count, 7))
+        self._check(self.lib.pgo_get_jacobian_blocks(self.h, C.c_int32(kind), C.c_int64(first), C.c_int64(count), _pd(J1), _pd(J2), _pd(ds)))
+        return J1, J2, ds
+
+    def normal_blocks(self):
+        N, _ = self._shape
+        E = self.n_rel + self.n_sw
+        diag = np.zeros((N, 6, 6)); grad = np.zeros((N, 6)); off = np.zeros((E, 6, 6))
+        c = np.zeros((self.n_sw, 12)); hss = np.zeros(self.n_sw); gs = np.zeros(self.n_sw)
+        self._check(self.lib.pgo_get_normal_blocks(self.h, _pd(diag), _pd(grad), _pd(off), _pd(c), _pd(hss), _pd(gs)))
+        return diag, grad, off, c, hss, gs
+
+    def apply_normal_operator(self, x):
+        x = _d(x).reshape(-1)
+        y = np.zeros_like(x)
+        self._check(self.lib.pgo_apply_normal_operator(self.h, _pd(x), _pd(y)))
+        return y
+
+    def time_kernel(self, which, launches=20):
+        ms = C.c_double(0); by = C.c_double(0)
+        self._check(self.lib.pgo_time_kernel(self.h, C.c_int32(which), C.c_int32(launches), C.byref(ms), C.byref(by)))
+        return ms.value, by.value
+
+    def synchronize(self):
+        self._check(self.lib.pgo_device_synchronize(self.h))
+
+    # ---- multi-GPU ----
+    @staticmethod
+    def comm_unique_id():
+        buf = (C.c_uint8 * PGO_COMM_ID_BYTES)()
+        rc = load().pgo_comm_get_unique_id(buf)
+        if rc != 0:
+            raise PgoError(rc, load().pgo_strerror(rc).decode())
+        return bytes(buf)
+
+    def comm_init(self, rank, world_size, unique_id):
+        buf = (C.c_uint8 * PGO_COMM_ID_BYTES).from_buffer_copy(unique_id)
+        self._check(self.lib.pgo_comm_init(self.h, C.c_int32(rank), C.c_int32(world_size), buf))
+
+    def comm_destroy(self):
+        self._check(self.lib.pgo_comm_destroy(self.h))
+
+
+def problem_from_graph(g, switchable=True, options=None, edge_slice=None, **opt_kw):
+    """Builds a Problem from a graphgen.PoseGraph the way the reference's trigger adds residual blocks
+    (odometry -> SixDOFError, loop closures -> switchable / plain, regularisers).  `edge_slice(kind, n)`
+    optionally returns the index subset this rank owns (edge sharding)."""
+    P = Problem(options, **opt_kw)
+    sel = (lambda kind, n: np.arange(n)) if edge_slice is None else edge_slice
+    io = sel("odom", g.n_odom)
+    if len(io):
+        P.add_relpose_edges(g.odom_c1[io], g.odom_c2[io], g.odom_T[io], g.odom_w[io])
+    il = sel("loop", g.n_loops)
+    if len(il):
+        if switchable:
+            P.add_switchable_edges(g.loop_c1[il], g.loop_c2[il], g.loop_T[il], g.loop_w[il], il.astype(np.int32))
+        else:
+            P.add_relpose_edges(g.loop_c1[il], g.loop_c2[il], g.loop_T[il], g.loop_w[il])
+    ir = sel("reg", len(g.reg_node))
+    if len(ir):
+        P.set_node_regularizers(g.reg_node[ir], g.reg_T[ir], g.reg_w[ir])
+    return P

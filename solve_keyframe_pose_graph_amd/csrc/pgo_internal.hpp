@@ -1,0 +1,114 @@
+// pgo_internal.hpp — device data layout and kernel launch interface shared by pgo_kernels.hip (device code)
+// and pgo_solver.hip (host LM controller + C-ABI).  gfx950 only.
+//
+// HBM layout (all fp64 unless noted; "tile" = 64 consecutive edges of one class = one wavefront of K1):
+//   pose8   [N][8]            qx qy qz qw tx ty tz pad — one 64-B record per keyframe (coalesced 16-B/lane loads,
+//                             LDS-staged per wavefront in K1).  The C-ABI keeps the reference's quat[4N]/t[3N] arrays.
+//   sw      [S]               switch variables
+//   edge inputs per class (relpose / switchable), SoA planes padded to a multiple of 64:
+//     c1,c2 [Epad] int32      endpoint keyframes           meas [8][Epad]  q_obs(4) t_obs(3) weight
+//     swidx [Epad] int32      (switchable only)            win  [tiles] int4 {lo1,n1,lo2,n2} pose windows for LDS staging
+//   K1 output per tile, AoSoA [tile][k/2][lane][2] so every store is 16 B/lane, 1 KiB/wave-instruction:
+//     relpose   78 doubles/edge: r[6]  J1[36] J2[36]                (row-major 6x6, cols [dtheta, dt])
+//     switch    86 doubles/edge: r[7]  Js[7]  J1[36] J2[36]         (J1,J2 rows 0..5; row 6 is identically 0)
+//   K2 outputs: Hd [N][36] (sum J^T J, incl. regularisers), g [N][6], Hoff [slot][36] = J1^T J2,
+//               c [Es][12] = [J1^T Js ; J2^T Js], hss [Es], gs [Es]
+//   LM system: BSR of the Schur-reduced damped normal matrix, one block row per keyframe:
+//     bsr_rowptr [N+1], bsr_col [nnzb] int32 (static per graph), bsr_val [nnzb][36] (rebuilt per LM iteration)
+//     Minv [N][36] block-Jacobi preconditioner, b [N][6] right-hand side, CG vectors [N][6]
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pgo_device_math.hpp"
+
+namespace pgo {
+
+constexpr int TILE = 64;
+constexpr int REL_DOUBLES = 78;    // r6 + J1 + J2
+constexpr int SW_DOUBLES = 86;     // r7 + Js7 + J1 + J2
+constexpr int K1_WAVES = 4;        // wavefronts (tiles) per K1 workgroup
+constexpr int WIN_MAX = 96;        // poses per LDS window
+constexpr int WIN_STRIDE = 80;     // bytes per staged pose record (64 B + 16 B pad: conflict-free ds_read_b128)
+constexpr int MAX_PARTIALS = 1024; // grid cap for kernels that emit per-block partial sums
+constexpr int PRIOR_DOUBLES = 42;  // r6 + J1
+
+struct PriorDev {        // NodePoseRegularization target (rigid), see prior_residual()
+    double Rf[9];
+    double tf[3];
+    double qf[4];
+    double w;
+    int32_t node;
+    int32_t pad_;
+};
+
+struct EdgeClassDev {
+    const int32_t* c1;
+    const int32_t* c2;
+    const double* meas;     // 8 planes x Epad
+    const int32_t* swidx;   // switchable only
+    const int4* win;        // per tile
+    double* J;              // tiles x DOUBLES x 64
+    int64_t E, Epad;
+    int32_t tiles;
+};
+
+struct GraphDev {
+    int64_t N, S;
+    EdgeClassDev rel, sw;
+    const PriorDev* prior; int32_t n_prior; double* Jp;   // Jp [n_prior][42]
+    // node -> incident (slot<<1 | side) CSR.  slot: relpose e -> e ; switch j -> rel.Epad + j ; prior k -> rel.Epad + sw.Epad + k
+    const int64_t* inc_rowptr; const int64_t* inc;  // inc entries are int64: (slot << 1) | side
+    const uint8_t* node_free;
+    // BSR structure
+    const int64_t* bsr_rowptr; const int32_t* bsr_col; int64_t nnzb;
+};
+
+struct LinDev {            // per-linearisation products
+    double* Hd; double* g; double* Hoff; double* c; double* hss; double* gs;
+};
+
+struct ScaleDev {
+    double* scale_p;  // [N][6]
+    double* scale_s;  // [Es]  (per switchable edge)
+    double* diag_p;   // [N][6] clamped squared column norms of the scaled Jacobian
+    double* diag_s;   // [Es]
+    double* a_inv;    // [Es]  1 / (hss + lambda_s)
+};
+
+struct CgDev {
+    double* val; double* Minv; double* Dtot; double* b;
+    double* x; double* r; double* r2; double* z; double* p; double* q;
+    double* part_pq;      // [MAX_PARTIALS]
+    double* part_rz;      // [2][MAX_PARTIALS]
+    double* scal;         // [0]=rz0 [1]=rz_last [2]=pq_last
+    int32_t* flags;       // [0]=done [1]=breakdown [2]=iterations
+};
+
+// ---- launchers (pgo_kernels.hip).  All asynchronous on `st`. ----
+void launch_k1(const GraphDev& G, const double* pose8, const double* sw, bool want_jacobian, double* partials /*[MAX_PARTIALS]*/, int* n_partials, hipStream_t st);
+void launch_prior(const GraphDev& G, const double* pose8, bool want_jacobian, double* partial_cost /*1 double*/, hipStream_t st);
+void launch_k2(const GraphDev& G, const LinDev& L, hipStream_t st);
+void launch_scale_init(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, int jacobi_scaling, hipStream_t st);
+void launch_lm_diag(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, double min_diag, double max_diag, hipStream_t st);
+void launch_build_rows(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, double radius, int add_lambda, hipStream_t st);
+void launch_invert_rows(const GraphDev& G, const CgDev& C, int32_t* fail_flag, hipStream_t st);
+void launch_cg_init(const GraphDev& G, const CgDev& C, hipStream_t st);
+void launch_cg_spmv(const GraphDev& G, const CgDev& C, hipStream_t st);
+void launch_cg_pq(const GraphDev& G, const CgDev& C, hipStream_t st);   // multi-GPU: recompute p.q after the all-reduce of q
+void launch_cg_update(const GraphDev& G, const CgDev& C, int parity, hipStream_t st);
+void launch_cg_direction(const GraphDev& G, const CgDev& C, int parity, double tol2, hipStream_t st);
+void launch_apply_operator(const GraphDev& G, const CgDev& C, const double* x, double* y, hipStream_t st);
+void launch_model_change(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const double* delta_p, double* delta_s, double* partials, int* n_partials, hipStream_t st);
+void launch_plus(const GraphDev& G, const double* pose8, const double* sw, const double* delta_p, const double* delta_s,
+                 double* pose8_out, double* sw_out, double* part_step2, double* part_sw_step2, int* n_partials, hipStream_t st);
+void launch_state_norms(const GraphDev& G, const LinDev& L, const double* pose8, const double* sw,
+                        double* part_xnorm2, double* part_sw_xnorm2, double* part_gmax, int* n_partials, hipStream_t st);
+void launch_reduce(const double* partials, int n, int op /*0 sum,1 max*/, double* out, hipStream_t st);
+void launch_pack_pose(const double* quat, const double* t, double* pose8, int64_t N, hipStream_t st);
+void launch_unpack_pose(const double* pose8, double* quat, double* t, int64_t N, hipStream_t st);
+void launch_unpack_k1(const GraphDev& G, int kind, int64_t first, int64_t count, double* r, double* J1, double* J2, double* Js, hipStream_t st);
+
+double k1_algorithmic_bytes(const GraphDev& G, bool want_jacobian);
+
+}  // namespace pgo

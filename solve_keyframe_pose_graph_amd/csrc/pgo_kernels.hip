@@ -1,0 +1,928 @@
+// pgo_kernels.hip — hand-written HIP kernels for gfx950 (MI355X, wave64).  fp64 VALU, HBM-bound; no MFMA
+// (6x6 blocks are not a dense contraction).  Layouts: pgo_internal.hpp.  Kernel inventory:
+//   K1  k1_edges_kernel<J>     per-edge residual (+ two 6x6 Jacobian blocks), every edge of every class in ONE launch,
+//                              one lane per edge, one wavefront per 64-edge tile, endpoint poses staged through LDS
+//   K2  k2_node_kernel         per-keyframe segmented reduction  Hd = sum J^T J, g = sum J^T r   (deterministic, no atomics)
+//       k2_edge_kernel         per-edge off-diagonal block J1^T J2 and switch couplings
+//   K3  cg_spmv_kernel         block-CSR (6x6) SpMV of the Schur-reduced damped normal matrix
+//   K4  cg_update/direction    fused PCG vector updates, block-Jacobi apply and dot products
+//   K5  plus_kernel            manifold Plus + step norms; k1 (J = false) evaluates the candidate cost
+#include "pgo_internal.hpp"
+
+namespace pgo {
+
+// ------------------------------------------------------------------------------------------------
+// reductions (fixed-shape trees: results are bitwise reproducible run to run)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+    return v;
+}
+// sum over the workgroup; valid in thread 0.  `buf` holds blockDim/64 doubles of LDS.
+__device__ __forceinline__ double block_sum(double v, double* buf) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) buf[wave] = v;
+    __syncthreads();
+    double s = 0.0;
+    if (threadIdx.x == 0) for (int i = 0; i < nw; ++i) s += buf[i];
+    return s;
+}
+// every thread gets sum(partials[0..n)); n <= a few thousand, read through L2
+__device__ __forceinline__ double block_total(const double* __restrict__ partials, int n, double* buf) {
+    double v = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) v += partials[i];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) buf[wave] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int i = 0; i < nw; ++i) s += buf[i];
+    return s;
+}
+
+__device__ __forceinline__ size_t tile_elem(int doubles_per_edge, int64_t e, int k) {
+    return (size_t)(e >> 6) * (size_t)(doubles_per_edge * TILE) + (size_t)(k >> 1) * (2 * TILE) + (size_t)(e & 63) * 2 + (k & 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1 — residual + Jacobian blocks for all edges, one launch
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ Pose load_pose_global(const double* __restrict__ pose8, int32_t c) {
+    const double2* g = reinterpret_cast<const double2*>(pose8 + (size_t)c * 8);
+    const double2 a = g[0], b = g[1], d = g[2], e = g[3];
+    return Pose{a.x, a.y, b.x, b.y, d.x, d.y, e.x};
+}
+__device__ __forceinline__ Pose load_pose_lds(const char* win, int rel) {
+    const double2* g = reinterpret_cast<const double2*>(win + rel * WIN_STRIDE);
+    const double2 a = g[0], b = g[1], d = g[2], e = g[3];
+    return Pose{a.x, a.y, b.x, b.y, d.x, d.y, e.x};
+}
+// one wavefront copies `n` 64-B pose records starting at keyframe `lo` into its LDS window (80-B stride)
+__device__ __forceinline__ void stage_window(const double* __restrict__ pose8, int lo, int n, char* win, int lane) {
+    const double2* src = reinterpret_cast<const double2*>(pose8 + (size_t)lo * 8);
+    for (int u = lane; u < n * 4; u += 64) {
+        const double2 v = src[u];                                   // 16 B/lane, 1 KiB per wave-instruction, fully coalesced
+        *reinterpret_cast<double2*>(win + (u >> 2) * WIN_STRIDE + (u & 3) * 16) = v;
+    }
+}
+
+template <bool WANT_J>
+__global__ __launch_bounds__(K1_WAVES * 64) void k1_edges_kernel(EdgeClassDev rel, EdgeClassDev sw, const double* __restrict__ pose8,
+                                                                  const double* __restrict__ swv, double* __restrict__ partials) {
+    __shared__ __attribute__((aligned(16))) char lds_win[K1_WAVES * 2 * WIN_MAX * WIN_STRIDE];
+    __shared__ double red[K1_WAVES];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tile_g = blockIdx.x * K1_WAVES + wave;
+    const bool active = tile_g < rel.tiles + sw.tiles;
+    const bool is_sw = tile_g >= rel.tiles;
+    const int tile = is_sw ? tile_g - rel.tiles : tile_g;
+    const EdgeClassDev& C = is_sw ? sw : rel;
+    char* win1 = lds_win + (wave * 2 + 0) * WIN_MAX * WIN_STRIDE;
+    char* win2 = lds_win + (wave * 2 + 1) * WIN_MAX * WIN_STRIDE;
+    int4 w = make_int4(0, 0, 0, 0);
+    if (active) {
+        w = C.win[tile];
+        if (w.y > 0) stage_window(pose8, w.x, w.y, win1, lane);
+        if (w.w > 0) stage_window(pose8, w.z, w.w, win2, lane);
+    }
+    __syncthreads();
+    double cost = 0.0;
+    if (active) {
+        const int64_t e = (int64_t)tile * TILE + lane;
+        const bool valid = e < C.E;
+        const int32_t c1 = C.c1[e], c2 = C.c2[e];          // padded entries are 0
+        const Pose P1 = w.y > 0 ? load_pose_lds(win1, c1 - w.x) : load_pose_global(pose8, c1);
+        const Pose P2 = w.w > 0 ? load_pose_lds(win2, c2 - w.z) : load_pose_global(pose8, c2);
+        const double* mp = C.meas + e;
+        const size_t ep = (size_t)C.Epad;
+        const Meas M{mp[0], mp[ep], mp[2 * ep], mp[3 * ep], mp[4 * ep], mp[5 * ep], mp[6 * ep], mp[7 * ep]};
+        if (!is_sw) {
+            double r[6], J1[36], J2[36];
+            relpose_residual<WANT_J>(P1, P2, M, M.w, r, J1, J2);
+            if (valid) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) cost += r[i] * r[i];
+            }
+            double2* out = reinterpret_cast<double2*>(C.J) + (size_t)tile * (REL_DOUBLES / 2 * TILE) + lane;
+            if (!valid) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) r[i] = 0.0;
+                if (WANT_J) {
+#pragma unroll
+                    for (int i = 0; i < 36; ++i) { J1[i] = 0.0; J2[i] = 0.0; }
+                }
+            }
+            if (WANT_J) {   // cost-only evaluation never touches the J buffers: the linearisation must survive a rejected step
+#pragma unroll
+                for (int kp = 0; kp < 3; ++kp) out[kp * TILE] = make_double2(r[2 * kp], r[2 * kp + 1]);
+#pragma unroll
+                for (int kp = 0; kp < 18; ++kp) out[(3 + kp) * TILE] = make_double2(J1[2 * kp], J1[2 * kp + 1]);
+#pragma unroll
+                for (int kp = 0; kp < 18; ++kp) out[(21 + kp) * TILE] = make_double2(J2[2 * kp], J2[2 * kp + 1]);
+            }
+        } else {
+            const double s = valid ? swv[C.swidx[e]] : 0.0;
+            double r[7], Js[7], J1[36], J2[36];
+            switch_residual<WANT_J>(P1, P2, M, s, r, J1, J2, Js);
+            if (valid) {
+#pragma unroll
+                for (int i = 0; i < 7; ++i) cost += r[i] * r[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 7; ++i) { r[i] = 0.0; Js[i] = 0.0; }
+            }
+            double2* out = reinterpret_cast<double2*>(C.J) + (size_t)tile * (SW_DOUBLES / 2 * TILE) + lane;
+            if (WANT_J) {
+                out[0 * TILE] = make_double2(r[0], r[1]);
+                out[1 * TILE] = make_double2(r[2], r[3]);
+                out[2 * TILE] = make_double2(r[4], r[5]);
+                out[3 * TILE] = make_double2(r[6], Js[0]);
+                out[4 * TILE] = make_double2(Js[1], Js[2]);
+                out[5 * TILE] = make_double2(Js[3], Js[4]);
+                out[6 * TILE] = make_double2(Js[5], Js[6]);
+#pragma unroll
+                for (int kp = 0; kp < 18; ++kp) out[(7 + kp) * TILE] = make_double2(J1[2 * kp], J1[2 * kp + 1]);
+#pragma unroll
+                for (int kp = 0; kp < 18; ++kp) out[(25 + kp) * TILE] = make_double2(J2[2 * kp], J2[2 * kp + 1]);
+            }
+        }
+    }
+    const double s = block_sum(cost, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+// regularisers: a handful of unary blocks, one lane each, single workgroup
+template <bool WANT_J>
+__global__ __launch_bounds__(256) void prior_kernel(const PriorDev* __restrict__ pr, int n, const double* __restrict__ pose8,
+                                                    double* __restrict__ Jp, double* __restrict__ cost_out) {
+    __shared__ double red[4];
+    double cost = 0.0;
+    for (int k = threadIdx.x; k < n; k += blockDim.x) {
+        const PriorDev P = pr[k];
+        const Pose X = load_pose_global(pose8, P.node);
+        double r[6], J1[36];
+        prior_residual<WANT_J>(X, P.Rf, P.tf, P.qf, P.w, r, J1);
+        for (int i = 0; i < 6; ++i) cost += r[i] * r[i];
+        if (WANT_J) {
+            for (int i = 0; i < 6; ++i) Jp[(size_t)k * PRIOR_DOUBLES + i] = r[i];
+            for (int i = 0; i < 36; ++i) Jp[(size_t)k * PRIOR_DOUBLES + 6 + i] = J1[i];
+        }
+    }
+    const double s = block_sum(cost, red);
+    if (threadIdx.x == 0) cost_out[0] = s;
+}
+
+void launch_k1(const GraphDev& G, const double* pose8, const double* sw, bool want_jacobian, double* partials, int* n_partials, hipStream_t st) {
+    const int tiles = G.rel.tiles + G.sw.tiles;
+    const int grid = (tiles + K1_WAVES - 1) / K1_WAVES;
+    *n_partials = grid;
+    if (grid == 0) return;
+    if (want_jacobian) hipLaunchKernelGGL(k1_edges_kernel<true>, dim3(grid), dim3(K1_WAVES * 64), 0, st, G.rel, G.sw, pose8, sw, partials);
+    else hipLaunchKernelGGL(k1_edges_kernel<false>, dim3(grid), dim3(K1_WAVES * 64), 0, st, G.rel, G.sw, pose8, sw, partials);
+}
+void launch_prior(const GraphDev& G, const double* pose8, bool want_jacobian, double* partial_cost, hipStream_t st) {
+    if (want_jacobian) hipLaunchKernelGGL(prior_kernel<true>, dim3(1), dim3(256), 0, st, G.prior, G.n_prior, pose8, G.Jp, partial_cost);
+    else hipLaunchKernelGGL(prior_kernel<false>, dim3(1), dim3(256), 0, st, G.prior, G.n_prior, pose8, G.Jp, partial_cost);
+}
+
+double k1_algorithmic_bytes(const GraphDev& G, bool want_jacobian) {
+    // in = 56 N + 8 E_s + 72 E + 68 E_g ; out = 624 E_r + 688 E_s + 336 E_g   (cost-only: inputs only)
+    const double N = (double)G.N, Er = (double)G.rel.E, Es = (double)G.sw.E, Eg = (double)G.n_prior;
+    double b = 56.0 * N + 8.0 * Es + 72.0 * (Er + Es) + 68.0 * Eg;
+    if (want_jacobian) b += 624.0 * Er + 688.0 * Es + 336.0 * Eg;
+    return b;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2 — normal-equation assembly
+// ------------------------------------------------------------------------------------------------
+// one lane per keyframe: walk its incident (edge, side) list in a fixed order and accumulate J^T J and J^T r
+__global__ __launch_bounds__(256) void k2_node_kernel(GraphDev G, LinDev L) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= G.N) return;
+    double H[21], g[6];
+#pragma unroll
+    for (int i = 0; i < 21; ++i) H[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) g[i] = 0.0;
+    const int64_t b = G.inc_rowptr[n], e = G.inc_rowptr[n + 1];
+    const int64_t slot_sw = G.rel.Epad, slot_pr = G.rel.Epad + G.sw.Epad;
+    for (int64_t k = b; k < e; ++k) {
+        const int64_t ent = G.inc[k];
+        const int64_t slot = ent >> 1;
+        const int side = (int)(ent & 1);
+        double r[6], J[36];
+        if (slot < slot_sw) {
+            const double2* base = reinterpret_cast<const double2*>(G.rel.J + tile_elem(REL_DOUBLES, slot, 0));
+#pragma unroll
+            for (int kp = 0; kp < 3; ++kp) { const double2 v = base[kp * TILE]; r[2 * kp] = v.x; r[2 * kp + 1] = v.y; }
+            const int o = side ? 21 : 3;
+#pragma unroll
+            for (int kp = 0; kp < 18; ++kp) { const double2 v = base[(o + kp) * TILE]; J[2 * kp] = v.x; J[2 * kp + 1] = v.y; }
+        } else if (slot < slot_pr) {
+            const double2* base = reinterpret_cast<const double2*>(G.sw.J + tile_elem(SW_DOUBLES, slot - slot_sw, 0));
+#pragma unroll
+            for (int kp = 0; kp < 3; ++kp) { const double2 v = base[kp * TILE]; r[2 * kp] = v.x; r[2 * kp + 1] = v.y; }
+            const int o = side ? 25 : 7;
+#pragma unroll
+            for (int kp = 0; kp < 18; ++kp) { const double2 v = base[(o + kp) * TILE]; J[2 * kp] = v.x; J[2 * kp + 1] = v.y; }
+        } else {
+            const double* base = G.Jp + (size_t)(slot - slot_pr) * PRIOR_DOUBLES;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) r[i] = base[i];
+#pragma unroll
+            for (int i = 0; i < 36; ++i) J[i] = base[6 + i];
+        }
+        int idx = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            double ga = 0.0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) ga += J[i * 6 + a] * r[i];
+            g[a] += ga;
+#pragma unroll
+            for (int c = a; c < 6; ++c) {
+                double s = 0.0;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) s += J[i * 6 + a] * J[i * 6 + c];
+                H[idx++] += s;
+            }
+        }
+    }
+    double* Hd = L.Hd + (size_t)n * 36;
+    int idx = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+        for (int c = a; c < 6; ++c) { Hd[a * 6 + c] = H[idx]; Hd[c * 6 + a] = H[idx]; ++idx; }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) L.g[(size_t)n * 6 + i] = g[i];
+}
+
+// one lane per edge: off-diagonal block J1^T J2 and, for switchable edges, [J1^T Js ; J2^T Js], Js^T Js, Js^T r
+__global__ __launch_bounds__(256) void k2_edge_kernel(GraphDev G, LinDev L) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nrel = G.rel.Epad;
+    if (gid >= nrel + G.sw.Epad) return;
+    const bool is_sw = gid >= nrel;
+    const int64_t e = is_sw ? gid - nrel : gid;
+    const EdgeClassDev& C = is_sw ? G.sw : G.rel;
+    if (e >= C.E) return;
+    double J1[36], J2[36];
+    const int D = is_sw ? SW_DOUBLES : REL_DOUBLES;
+    const double2* base = reinterpret_cast<const double2*>(C.J + tile_elem(D, e, 0));
+    const int o1 = is_sw ? 7 : 3, o2 = is_sw ? 25 : 21;
+#pragma unroll
+    for (int kp = 0; kp < 18; ++kp) { const double2 v = base[(o1 + kp) * TILE]; J1[2 * kp] = v.x; J1[2 * kp + 1] = v.y; }
+#pragma unroll
+    for (int kp = 0; kp < 18; ++kp) { const double2 v = base[(o2 + kp) * TILE]; J2[2 * kp] = v.x; J2[2 * kp + 1] = v.y; }
+    double* H = L.Hoff + (size_t)gid * 36;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) s += J1[i * 6 + a] * J2[i * 6 + c];
+            H[a * 6 + c] = s;
+        }
+    }
+    if (is_sw) {
+        double r[7], Js[7];
+        { double2 v;
+          v = base[0 * TILE]; r[0] = v.x; r[1] = v.y;  v = base[1 * TILE]; r[2] = v.x; r[3] = v.y;  v = base[2 * TILE]; r[4] = v.x; r[5] = v.y;
+          v = base[3 * TILE]; r[6] = v.x; Js[0] = v.y; v = base[4 * TILE]; Js[1] = v.x; Js[2] = v.y;
+          v = base[5 * TILE]; Js[3] = v.x; Js[4] = v.y; v = base[6 * TILE]; Js[5] = v.x; Js[6] = v.y; }
+        double hss = 0.0, gs = 0.0;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) { hss += Js[i] * Js[i]; gs += Js[i] * r[i]; }
+        double* c = L.c + (size_t)e * 12;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { s1 += J1[i * 6 + a] * Js[i]; s2 += J2[i * 6 + a] * Js[i]; }
+            c[a] = s1; c[6 + a] = s2;
+        }
+        L.hss[e] = hss; L.gs[e] = gs;
+    }
+}
+
+void launch_k2(const GraphDev& G, const LinDev& L, hipStream_t st) {
+    if (G.N > 0) hipLaunchKernelGGL(k2_node_kernel, dim3((unsigned)((G.N + 255) / 256)), dim3(256), 0, st, G, L);
+    const int64_t ne = G.rel.Epad + G.sw.Epad;
+    if (ne > 0) hipLaunchKernelGGL(k2_edge_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, G, L);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Jacobi scaling and LM diagonal (Ceres: scale = 1/(1+sqrt(col norm^2)) fixed at iteration 0;
+// D^2 = clamp(col norm^2 of the scaled Jacobian, min, max) / radius)
+// ------------------------------------------------------------------------------------------------
+__global__ void scale_init_kernel(GraphDev G, LinDev L, ScaleDev Sc, int jacobi_scaling) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t np = G.N * 6;
+    if (i < np) {
+        const int64_t n = i / 6; const int c = (int)(i % 6);
+        Sc.scale_p[i] = jacobi_scaling ? 1.0 / (1.0 + sqrt(L.Hd[(size_t)n * 36 + c * 6 + c])) : 1.0;
+    } else if (i < np + G.sw.E) {
+        const int64_t e = i - np;
+        Sc.scale_s[e] = jacobi_scaling ? 1.0 / (1.0 + sqrt(L.hss[e])) : 1.0;
+    }
+}
+__global__ void lm_diag_kernel(GraphDev G, LinDev L, ScaleDev Sc, double mn, double mx) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t np = G.N * 6;
+    if (i < np) {
+        const int64_t n = i / 6; const int c = (int)(i % 6);
+        const double s = Sc.scale_p[i];
+        Sc.diag_p[i] = fmin(fmax(s * s * L.Hd[(size_t)n * 36 + c * 6 + c], mn), mx);
+    } else if (i < np + G.sw.E) {
+        const int64_t e = i - np;
+        const double s = Sc.scale_s[e];
+        Sc.diag_s[e] = fmin(fmax(s * s * L.hss[e], mn), mx);
+    }
+}
+void launch_scale_init(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, int jacobi_scaling, hipStream_t st) {
+    const int64_t n = G.N * 6 + G.sw.E;
+    if (n > 0) hipLaunchKernelGGL(scale_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, G, L, Sc, jacobi_scaling);
+}
+void launch_lm_diag(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, double mn, double mx, hipStream_t st) {
+    const int64_t n = G.N * 6 + G.sw.E;
+    if (n > 0) hipLaunchKernelGGL(lm_diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, G, L, Sc, mn, mx);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LM system build: Schur-eliminate the switch variables edge by edge (each switch occurs in exactly one
+// residual block, reference src/PoseGraphSLAM.cpp:1555, so H_ss is diagonal), add the LM damping in the
+// unscaled space (lambda_j = D_j^2 / scale_j^2) and write the block-CSR rows.
+// ------------------------------------------------------------------------------------------------
+__global__ void sw_prepare_kernel(GraphDev G, LinDev L, ScaleDev Sc, double radius) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= G.sw.E) return;
+    const double s = Sc.scale_s[e];
+    Sc.a_inv[e] = 1.0 / (L.hss[e] + Sc.diag_s[e] / (radius * s * s));
+}
+
+__global__ __launch_bounds__(256) void build_rows_kernel(GraphDev G, LinDev L, ScaleDev Sc, CgDev C, double radius, int add_lambda) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= G.N) return;
+    const bool free_node = G.node_free[n] != 0;
+    double D[36], bv[6];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) D[i] = L.Hd[(size_t)n * 36 + i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) bv[i] = -L.g[(size_t)n * 6 + i];
+    const int64_t b = G.inc_rowptr[n], e = G.inc_rowptr[n + 1];
+    const int64_t slot_sw = G.rel.Epad, slot_pr = G.rel.Epad + G.sw.Epad;
+    const int64_t row0 = G.bsr_rowptr[n];
+    for (int64_t k = b; k < e; ++k) {
+        const int64_t ent = G.inc[k];
+        const int64_t slot = ent >> 1;
+        const int side = (int)(ent & 1);
+        if (slot >= slot_pr) break;   // regularisers come last in the list; they are already in Hd
+        double B[36];
+        const double* H = L.Hoff + (size_t)slot * 36;
+        if (side == 0) {
+#pragma unroll
+            for (int i = 0; i < 36; ++i) B[i] = H[i];
+        } else {
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int c = 0; c < 6; ++c) B[a * 6 + c] = H[c * 6 + a];
+        }
+        if (slot >= slot_sw) {
+            const int64_t es = slot - slot_sw;
+            const double ai = Sc.a_inv[es];
+            const double* cc = L.c + (size_t)es * 12;
+            double cs[6], co[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { cs[i] = cc[side * 6 + i]; co[i] = cc[(1 - side) * 6 + i]; }
+            const double gsa = L.gs[es] * ai;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                bv[a] += cs[a] * gsa;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) { D[a * 6 + c] -= cs[a] * cs[c] * ai; B[a * 6 + c] -= cs[a] * co[c] * ai; }
+            }
+        }
+        double* out = C.val + (size_t)(row0 + 1 + (k - b)) * 36;
+        if (!free_node) {
+#pragma unroll
+            for (int i = 0; i < 36; ++i) B[i] = 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < 36; ++i) out[i] = B[i];
+    }
+    if (add_lambda) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) { const double s = Sc.scale_p[(size_t)n * 6 + c]; D[c * 6 + c] += Sc.diag_p[(size_t)n * 6 + c] / (radius * s * s); }
+    }
+    if (!free_node) {
+#pragma unroll
+        for (int i = 0; i < 36; ++i) D[i] = 0.0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) { D[c * 6 + c] = add_lambda ? 1.0 : 0.0; bv[c] = 0.0; }
+    }
+#pragma unroll
+    for (int i = 0; i < 36; ++i) { C.val[(size_t)row0 * 36 + i] = D[i]; C.Dtot[(size_t)n * 36 + i] = D[i]; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) C.b[(size_t)n * 6 + i] = bv[i];
+}
+
+// 6x6 SPD inverse through Cholesky, fully unrolled in registers.  Returns false when not positive definite.
+__device__ __forceinline__ bool spd6_inverse(const double* A, double* Ai) {
+    double Lm[36];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double d = A[j * 6 + j];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) if (k < j) d -= Lm[j * 6 + k] * Lm[j * 6 + k];
+        ok = ok && (d > 0.0);
+        d = sqrt(d);
+        Lm[j * 6 + j] = d;
+        const double di = 1.0 / d;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) if (i > j) {
+            double s = A[i * 6 + j];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) if (k < j) s -= Lm[i * 6 + k] * Lm[j * 6 + k];
+            Lm[i * 6 + j] = s * di;
+        }
+    }
+    // Li = L^-1 (lower)
+    double Li[36];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) Li[i] = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        Li[c * 6 + c] = 1.0 / Lm[c * 6 + c];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) if (i > c) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) if (k >= c && k < i) s -= Lm[i * 6 + k] * Li[k * 6 + c];
+            Li[i * 6 + c] = s / Lm[i * 6 + i];
+        }
+    }
+    // A^-1 = Li^T Li
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) if (k >= a && k >= c) s += Li[k * 6 + a] * Li[k * 6 + c];
+            Ai[a * 6 + c] = s;
+        }
+    return ok;
+}
+
+__global__ __launch_bounds__(256) void invert_rows_kernel(GraphDev G, CgDev C, int32_t* fail) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= G.N) return;
+    double D[36], Di[36];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) D[i] = C.Dtot[(size_t)n * 36 + i];
+    if (!G.node_free[n]) {
+#pragma unroll
+        for (int i = 0; i < 36; ++i) D[i] = 0.0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) D[c * 6 + c] = 1.0;
+    }
+    const bool ok = spd6_inverse(D, Di);
+    if (!ok) atomicOr(fail, 1);
+#pragma unroll
+    for (int i = 0; i < 36; ++i) C.Minv[(size_t)n * 36 + i] = Di[i];
+}
+
+void launch_build_rows(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, double radius, int add_lambda, hipStream_t st) {
+    if (G.sw.E > 0) hipLaunchKernelGGL(sw_prepare_kernel, dim3((unsigned)((G.sw.E + 255) / 256)), dim3(256), 0, st, G, L, Sc, radius);
+    if (G.N > 0) hipLaunchKernelGGL(build_rows_kernel, dim3((unsigned)((G.N + 255) / 256)), dim3(256), 0, st, G, L, Sc, C, radius, add_lambda);
+}
+void launch_invert_rows(const GraphDev& G, const CgDev& C, int32_t* fail_flag, hipStream_t st) {
+    if (G.N > 0) hipLaunchKernelGGL(invert_rows_kernel, dim3((unsigned)((G.N + 255) / 256)), dim3(256), 0, st, G, C, fail_flag);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3/K4 — preconditioned conjugate gradients on the block-CSR system, block-Jacobi preconditioner.
+// One thread per (keyframe, row): 192-thread workgroups = 32 keyframes x 6 rows; each lane streams its 48-B row
+// of every block of its block-row (contiguous 288 B per block across the 6 lanes of a keyframe).
+// Dot products: per-workgroup partials (grid capped at MAX_PARTIALS), re-reduced in a fixed order by every
+// workgroup of the consuming kernel -> no atomics, bitwise reproducible.
+// ------------------------------------------------------------------------------------------------
+constexpr int CG_BLOCK = 192;
+
+// workgroup-uniform read of the convergence flag (it may be raised by workgroup 0 of cg_direction while other
+// workgroups of the same launch are starting: one lane reads, LDS broadcasts, nobody diverges around a barrier)
+__device__ __forceinline__ bool cg_done(const CgDev& C) {
+    __shared__ int s_done;
+    if (threadIdx.x == 0) s_done = C.flags[0];
+    __syncthreads();
+    return s_done != 0;
+}
+
+__device__ __forceinline__ double bsr_row_dot(const GraphDev& G, const double* __restrict__ val, const double* __restrict__ p, int64_t n, int r) {
+    double acc = 0.0;
+    const int64_t b = G.bsr_rowptr[n], e = G.bsr_rowptr[n + 1];
+    for (int64_t k = b; k < e; ++k) {
+        const int32_t col = G.bsr_col[k];
+        const double2* v = reinterpret_cast<const double2*>(val + (size_t)k * 36 + r * 6);
+        const double2* pc = reinterpret_cast<const double2*>(p + (size_t)col * 6);
+        const double2 v0 = v[0], v1 = v[1], v2 = v[2], p0 = pc[0], p1 = pc[1], p2 = pc[2];
+        acc += v0.x * p0.x + v0.y * p0.y + v1.x * p1.x + v1.y * p1.y + v2.x * p2.x + v2.y * p2.y;
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(CG_BLOCK) void cg_spmv_kernel(GraphDev G, CgDev C) {
+    __shared__ double red[CG_BLOCK / 64];
+    if (cg_done(C)) return;
+    const int64_t rows = G.N * 6;
+    double pq = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * CG_BLOCK + threadIdx.x; i < rows; i += (int64_t)gridDim.x * CG_BLOCK) {
+        const int64_t n = i / 6; const int r = (int)(i - n * 6);
+        const double acc = bsr_row_dot(G, C.val, C.p, n, r);
+        C.q[i] = acc;
+        pq += acc * C.p[i];
+    }
+    const double s = block_sum(pq, red);
+    if (threadIdx.x == 0) C.part_pq[blockIdx.x] = s;
+}
+
+// multi-GPU: after the RCCL all-reduce of q, recompute the p.q partials
+__global__ __launch_bounds__(CG_BLOCK) void cg_pq_kernel(GraphDev G, CgDev C) {
+    __shared__ double red[CG_BLOCK / 64];
+    if (cg_done(C)) return;
+    const int64_t rows = G.N * 6;
+    double pq = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * CG_BLOCK + threadIdx.x; i < rows; i += (int64_t)gridDim.x * CG_BLOCK) pq += C.q[i] * C.p[i];
+    const double s = block_sum(pq, red);
+    if (threadIdx.x == 0) C.part_pq[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(CG_BLOCK) void apply_operator_kernel(GraphDev G, CgDev C, const double* __restrict__ x, double* __restrict__ y) {
+    const int64_t rows = G.N * 6;
+    for (int64_t i = (int64_t)blockIdx.x * CG_BLOCK + threadIdx.x; i < rows; i += (int64_t)gridDim.x * CG_BLOCK) {
+        const int64_t n = i / 6; const int r = (int)(i - n * 6);
+        y[i] = bsr_row_dot(G, C.val, x, n, r);
+    }
+}
+
+// x = 0, r = b, z = Minv b, p = z, partial r.z -> part_rz[0]; flags cleared by the host memset before
+__global__ __launch_bounds__(CG_BLOCK) void cg_init_kernel(GraphDev G, CgDev C) {
+    __shared__ double red[CG_BLOCK / 64];
+    const int64_t rows = G.N * 6;
+    double rz = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * CG_BLOCK + threadIdx.x; i < rows; i += (int64_t)gridDim.x * CG_BLOCK) {
+        const int64_t n = i / 6; const int r = (int)(i - n * 6);
+        const double* bn = C.b + (size_t)n * 6;
+        const double* M = C.Minv + (size_t)n * 36 + r * 6;
+        double z = 0.0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) z += M[c] * bn[c];
+        const double bi = bn[r];
+        C.x[i] = 0.0; C.r[i] = bi; C.z[i] = z; C.p[i] = z;
+        rz += bi * z;
+    }
+    const double s = block_sum(rz, red);
+    if (threadIdx.x == 0) C.part_rz[blockIdx.x] = s;
+}
+__global__ void cg_scalars_init_kernel(CgDev C, int nparts) {
+    __shared__ double red[4];
+    const double rz0 = block_total(C.part_rz, nparts, red);
+    if (threadIdx.x == 0) { C.scal[0] = rz0; C.scal[1] = rz0; C.scal[2] = 0.0; C.flags[0] = (rz0 > 0.0) ? 0 : 1; C.flags[1] = 0; C.flags[2] = 0; }
+}
+
+// alpha = rz/pq ; x += alpha p ; r2 = r - alpha q ; z = Minv r2 ; partial r2.z -> part_rz[parity^1]
+__global__ __launch_bounds__(CG_BLOCK) void cg_update_kernel(GraphDev G, CgDev C, int parity, int nparts) {
+    __shared__ double red[CG_BLOCK / 64];
+    if (cg_done(C)) return;
+    const double pq = block_total(C.part_pq, nparts, red);
+    const double rz = block_total(C.part_rz + parity * MAX_PARTIALS, nparts, red);
+    if (!(pq > 0.0)) {   // breakdown: matrix not positive definite along p (or NaN)
+        if (blockIdx.x == 0 && threadIdx.x == 0) { C.flags[1] = 1; }
+        // leave x untouched; cg_direction raises done
+        double* out = C.part_rz + (parity ^ 1) * MAX_PARTIALS;
+        if (threadIdx.x == 0) out[blockIdx.x] = 0.0;
+        return;
+    }
+    const double alpha = rz / pq;
+    const int64_t rows = G.N * 6;
+    const double* rin = parity ? C.r2 : C.r;
+    double* rout = parity ? C.r : C.r2;
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * CG_BLOCK + threadIdx.x; i < rows; i += (int64_t)gridDim.x * CG_BLOCK) {
+        const int64_t n = i / 6; const int r = (int)(i - n * 6);
+        const double* rn = rin + (size_t)n * 6;
+        const double* qn = C.q + (size_t)n * 6;
+        const double* M = C.Minv + (size_t)n * 36 + r * 6;
+        double z = 0.0, rr = 0.0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const double rc = rn[c] - alpha * qn[c];
+            z += M[c] * rc;
+            if (c == r) rr = rc;
+        }
+        C.x[i] += alpha * C.p[i];
+        rout[i] = rr;
+        C.z[i] = z;
+        acc += rr * z;
+    }
+    const double s = block_sum(acc, red);
+    if (threadIdx.x == 0) C.part_rz[(parity ^ 1) * MAX_PARTIALS + blockIdx.x] = s;
+}
+
+// beta = rz_new/rz_old ; p = z + beta p ; convergence test on the preconditioned residual norm
+__global__ __launch_bounds__(CG_BLOCK) void cg_direction_kernel(GraphDev G, CgDev C, int parity, int nparts, double tol2) {
+    __shared__ double red[CG_BLOCK / 64];
+    if (cg_done(C)) return;
+    const double rz_old = block_total(C.part_rz + parity * MAX_PARTIALS, nparts, red);
+    const double rz_new = block_total(C.part_rz + (parity ^ 1) * MAX_PARTIALS, nparts, red);
+    const bool breakdown = C.flags[1] != 0;
+    const double beta = rz_new / rz_old;
+    const int64_t rows = G.N * 6;
+    if (!breakdown) {
+        for (int64_t i = (int64_t)blockIdx.x * CG_BLOCK + threadIdx.x; i < rows; i += (int64_t)gridDim.x * CG_BLOCK) C.p[i] = C.z[i] + beta * C.p[i];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (!breakdown) { C.flags[2] += 1; C.scal[1] = rz_new; }
+        if (breakdown || !(rz_new > tol2 * C.scal[0])) C.flags[0] = 1;
+    }
+}
+
+static inline int cg_grid(const GraphDev& G) {
+    const int64_t rows = G.N * 6;
+    int64_t g = (rows + CG_BLOCK - 1) / CG_BLOCK;
+    if (g > MAX_PARTIALS) g = MAX_PARTIALS;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+void launch_cg_init(const GraphDev& G, const CgDev& C, hipStream_t st) {
+    const int g = cg_grid(G);
+    hipLaunchKernelGGL(cg_init_kernel, dim3(g), dim3(CG_BLOCK), 0, st, G, C);
+    hipLaunchKernelGGL(cg_scalars_init_kernel, dim3(1), dim3(256), 0, st, C, g);
+}
+void launch_cg_spmv(const GraphDev& G, const CgDev& C, hipStream_t st) { hipLaunchKernelGGL(cg_spmv_kernel, dim3(cg_grid(G)), dim3(CG_BLOCK), 0, st, G, C); }
+void launch_cg_pq(const GraphDev& G, const CgDev& C, hipStream_t st) { hipLaunchKernelGGL(cg_pq_kernel, dim3(cg_grid(G)), dim3(CG_BLOCK), 0, st, G, C); }
+void launch_cg_update(const GraphDev& G, const CgDev& C, int parity, hipStream_t st) { const int g = cg_grid(G); hipLaunchKernelGGL(cg_update_kernel, dim3(g), dim3(CG_BLOCK), 0, st, G, C, parity, g); }
+void launch_cg_direction(const GraphDev& G, const CgDev& C, int parity, double tol2, hipStream_t st) { const int g = cg_grid(G); hipLaunchKernelGGL(cg_direction_kernel, dim3(g), dim3(CG_BLOCK), 0, st, G, C, parity, g, tol2); }
+void launch_apply_operator(const GraphDev& G, const CgDev& C, const double* x, double* y, hipStream_t st) { hipLaunchKernelGGL(apply_operator_kernel, dim3(cg_grid(G)), dim3(CG_BLOCK), 0, st, G, C, x, y); }
+
+// ------------------------------------------------------------------------------------------------
+// step finish: switch back-substitution  ds = -(gs + c1.d1 + c2.d2) a_inv  and
+// model_cost_change = - sum (J d)^T (r + J d / 2)    (trust_region_minimizer.cc)
+// one lane per edge, tiles as in K1
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void model_change_kernel(GraphDev G, LinDev L, ScaleDev Sc, const double* __restrict__ dp, double* __restrict__ ds_out, double* __restrict__ partials) {
+    __shared__ double red[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tile_g = blockIdx.x * 4 + wave;
+    const int ntile = G.rel.tiles + G.sw.tiles;
+    double mc = 0.0;
+    if (tile_g < ntile) {
+        const bool is_sw = tile_g >= G.rel.tiles;
+        const int tile = is_sw ? tile_g - G.rel.tiles : tile_g;
+        const EdgeClassDev& C = is_sw ? G.sw : G.rel;
+        const int64_t e = (int64_t)tile * TILE + lane;
+        if (e < C.E) {
+            const int32_t c1 = C.c1[e], c2 = C.c2[e];
+            double d1[6], d2[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { d1[i] = dp[(size_t)c1 * 6 + i]; d2[i] = dp[(size_t)c2 * 6 + i]; }
+            const int D = is_sw ? SW_DOUBLES : REL_DOUBLES;
+            const double2* base = reinterpret_cast<const double2*>(C.J + tile_elem(D, e, 0));
+            const int o1 = is_sw ? 7 : 3, o2 = is_sw ? 25 : 21;
+            double u[7];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) u[i] = 0.0;
+#pragma unroll
+            for (int row = 0; row < 6; ++row) {
+#pragma unroll
+                for (int kp = 0; kp < 3; ++kp) {
+                    const double2 a = base[(o1 + row * 3 + kp) * TILE], b = base[(o2 + row * 3 + kp) * TILE];
+                    u[row] += a.x * d1[2 * kp] + a.y * d1[2 * kp + 1] + b.x * d2[2 * kp] + b.y * d2[2 * kp + 1];
+                }
+            }
+            double r[7];
+            { double2 v; v = base[0]; r[0] = v.x; r[1] = v.y; v = base[TILE]; r[2] = v.x; r[3] = v.y; v = base[2 * TILE]; r[4] = v.x; r[5] = v.y; }
+            r[6] = 0.0;
+            if (is_sw) {
+                double Js[7];
+                { double2 v; v = base[3 * TILE]; r[6] = v.x; Js[0] = v.y; v = base[4 * TILE]; Js[1] = v.x; Js[2] = v.y;
+                  v = base[5 * TILE]; Js[3] = v.x; Js[4] = v.y; v = base[6 * TILE]; Js[5] = v.x; Js[6] = v.y; }
+                const double* cc = L.c + (size_t)e * 12;
+                double acc = L.gs[e];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) acc += cc[i] * d1[i] + cc[6 + i] * d2[i];
+                const double ds = -acc * Sc.a_inv[e];
+                ds_out[e] = ds;
+#pragma unroll
+                for (int i = 0; i < 7; ++i) u[i] += Js[i] * ds;
+            }
+#pragma unroll
+            for (int i = 0; i < 7; ++i) mc += u[i] * (r[i] + 0.5 * u[i]);
+        }
+    }
+    // regularisers: handled by the last workgroup's first lanes
+    if (blockIdx.x == gridDim.x - 1) {
+        for (int k = threadIdx.x; k < G.n_prior; k += blockDim.x) {
+            const double* base = G.Jp + (size_t)k * PRIOR_DOUBLES;
+            const int32_t node = G.prior[k].node;
+            for (int row = 0; row < 6; ++row) {
+                double u = 0.0;
+                for (int c = 0; c < 6; ++c) u += base[6 + row * 6 + c] * dp[(size_t)node * 6 + c];
+                mc += u * (base[row] + 0.5 * u);
+            }
+        }
+    }
+    const double s = block_sum(mc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+void launch_model_change(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const double* delta_p, double* delta_s, double* partials, int* n_partials, hipStream_t st) {
+    const int tiles = G.rel.tiles + G.sw.tiles;
+    int grid = (tiles + 3) / 4;
+    if (grid < 1) grid = 1;
+    *n_partials = grid;
+    hipLaunchKernelGGL(model_change_kernel, dim3(grid), dim3(256), 0, st, G, L, Sc, delta_p, delta_s, partials);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5 — candidate point x (+) delta and the ambient step norm || x - x_cand ||^2 (Ceres' step_norm)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void plus_kernel(GraphDev G, const double* __restrict__ pose8, const double* __restrict__ sw, const double* __restrict__ dp,
+                                                   const double* __restrict__ ds, double* __restrict__ pose8_out, double* __restrict__ sw_out,
+                                                   double* __restrict__ part_step2, double* __restrict__ part_sw_step2) {
+    __shared__ double red[4];
+    double s2 = 0.0, s2sw = 0.0;
+    const int64_t total = G.N + G.sw.E;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < G.N) {
+            const double2* g = reinterpret_cast<const double2*>(pose8 + (size_t)i * 8);
+            const double2 a = g[0], b = g[1], c = g[2], d = g[3];
+            double q[4] = {a.x, a.y, b.x, b.y}, t[3] = {c.x, c.y, d.x}, qn[4], tn[3];
+            if (G.node_free[i]) {
+                const double* di = dp + (size_t)i * 6;
+                quat_plus(q, di, qn);
+                tn[0] = t[0] + di[3]; tn[1] = t[1] + di[4]; tn[2] = t[2] + di[5];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s2 += (q[k] - qn[k]) * (q[k] - qn[k]);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) s2 += (t[k] - tn[k]) * (t[k] - tn[k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) qn[k] = q[k];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) tn[k] = t[k];
+            }
+            double2* o = reinterpret_cast<double2*>(pose8_out + (size_t)i * 8);
+            o[0] = make_double2(qn[0], qn[1]); o[1] = make_double2(qn[2], qn[3]); o[2] = make_double2(tn[0], tn[1]); o[3] = make_double2(tn[2], 0.0);
+        } else {
+            const int64_t e = i - G.N;
+            const int32_t si = G.sw.swidx[e];
+            const double d = ds[e];
+            sw_out[si] = sw[si] + d;
+            s2sw += d * d;
+        }
+    }
+    const double a = block_sum(s2, red);
+    const double b = block_sum(s2sw, red);
+    if (threadIdx.x == 0) { part_step2[blockIdx.x] = a; part_sw_step2[blockIdx.x] = b; }
+}
+static inline int capped_grid(int64_t n, int block) {
+    int64_t g = (n + block - 1) / block;
+    if (g > MAX_PARTIALS) g = MAX_PARTIALS;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+void launch_plus(const GraphDev& G, const double* pose8, const double* sw, const double* delta_p, const double* delta_s, double* pose8_out, double* sw_out,
+                 double* part_step2, double* part_sw_step2, int* n_partials, hipStream_t st) {
+    const int g = capped_grid(G.N + G.sw.E, 256);
+    *n_partials = g;
+    hipLaunchKernelGGL(plus_kernel, dim3(g), dim3(256), 0, st, G, pose8, sw, delta_p, delta_s, pose8_out, sw_out, part_step2, part_sw_step2);
+}
+
+// ||x||^2 over the free parameters (ambient: 4 + 3 per keyframe, 1 per switch) and the projected-gradient max norm
+// || Plus(x, -g) - x ||_inf  (trust_region_minimizer.cc)
+__global__ __launch_bounds__(256) void state_norms_kernel(GraphDev G, LinDev L, const double* __restrict__ pose8, const double* __restrict__ sw,
+                                                          double* __restrict__ part_x2, double* __restrict__ part_sw_x2, double* __restrict__ part_gmax) {
+    __shared__ double red[4];
+    double x2 = 0.0, x2sw = 0.0, gm = 0.0;
+    const int64_t total = G.N + G.sw.E;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < G.N) {
+            if (!G.node_free[i]) continue;
+            const double2* g = reinterpret_cast<const double2*>(pose8 + (size_t)i * 8);
+            const double2 a = g[0], b = g[1], c = g[2], d = g[3];
+            const double q[4] = {a.x, a.y, b.x, b.y};
+            x2 += a.x * a.x + a.y * a.y + b.x * b.x + b.y * b.y + c.x * c.x + c.y * c.y + d.x * d.x;
+            const double* gi = L.g + (size_t)i * 6;
+            const double ng[3] = {-gi[0], -gi[1], -gi[2]};
+            double qn[4];
+            quat_plus(q, ng, qn);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) gm = fmax(gm, fabs(qn[k] - q[k]));
+#pragma unroll
+            for (int k = 0; k < 3; ++k) gm = fmax(gm, fabs(gi[3 + k]));
+        } else {
+            const int64_t e = i - G.N;
+            const double s = sw[G.sw.swidx[e]];
+            x2sw += s * s;
+            gm = fmax(gm, fabs(L.gs[e]));
+        }
+    }
+    const double a = block_sum(x2, red);
+    const double b = block_sum(x2sw, red);
+    // max over the workgroup
+    gm = wave_max(gm);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = gm;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m = 0.0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) m = fmax(m, red[i]);
+        part_x2[blockIdx.x] = a; part_sw_x2[blockIdx.x] = b; part_gmax[blockIdx.x] = m;
+    }
+}
+void launch_state_norms(const GraphDev& G, const LinDev& L, const double* pose8, const double* sw, double* part_xnorm2, double* part_sw_xnorm2, double* part_gmax,
+                        int* n_partials, hipStream_t st) {
+    const int g = capped_grid(G.N + G.sw.E, 256);
+    *n_partials = g;
+    hipLaunchKernelGGL(state_norms_kernel, dim3(g), dim3(256), 0, st, G, L, pose8, sw, part_xnorm2, part_sw_xnorm2, part_gmax);
+}
+
+__global__ void reduce_kernel(const double* __restrict__ partials, int n, int op, double* __restrict__ out) {
+    __shared__ double red[4];
+    double v = 0.0;
+    if (op == 0) { for (int i = threadIdx.x; i < n; i += blockDim.x) v += partials[i]; v = wave_sum(v); }
+    else { for (int i = threadIdx.x; i < n; i += blockDim.x) v = fmax(v, partials[i]); v = wave_max(v); }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = red[0];
+        for (int i = 1; i < 4; ++i) s = op == 0 ? s + red[i] : fmax(s, red[i]);
+        out[0] = s;
+    }
+}
+void launch_reduce(const double* partials, int n, int op, double* out, hipStream_t st) { hipLaunchKernelGGL(reduce_kernel, dim3(1), dim3(256), 0, st, partials, n, op, out); }
+
+// ------------------------------------------------------------------------------------------------
+// layout conversion at the C-ABI boundary (reference layout: quat[4N] xyzw + t[3N], src/PoseGraphSLAM.h:153-175)
+// ------------------------------------------------------------------------------------------------
+__global__ void pack_pose_kernel(const double* __restrict__ quat, const double* __restrict__ t, double* __restrict__ pose8, int64_t N) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    double2* o = reinterpret_cast<double2*>(pose8 + (size_t)i * 8);
+    o[0] = make_double2(quat[4 * i], quat[4 * i + 1]); o[1] = make_double2(quat[4 * i + 2], quat[4 * i + 3]);
+    o[2] = make_double2(t[3 * i], t[3 * i + 1]); o[3] = make_double2(t[3 * i + 2], 0.0);
+}
+__global__ void unpack_pose_kernel(const double* __restrict__ pose8, double* __restrict__ quat, double* __restrict__ t, int64_t N) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const double* p = pose8 + (size_t)i * 8;
+    quat[4 * i] = p[0]; quat[4 * i + 1] = p[1]; quat[4 * i + 2] = p[2]; quat[4 * i + 3] = p[3];
+    t[3 * i] = p[4]; t[3 * i + 1] = p[5]; t[3 * i + 2] = p[6];
+}
+void launch_pack_pose(const double* quat, const double* t, double* pose8, int64_t N, hipStream_t st) {
+    if (N > 0) hipLaunchKernelGGL(pack_pose_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, quat, t, pose8, N);
+}
+void launch_unpack_pose(const double* pose8, double* quat, double* t, int64_t N, hipStream_t st) {
+    if (N > 0) hipLaunchKernelGGL(unpack_pose_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, pose8, quat, t, N);
+}
+
+// parity hooks: K1's tiled output -> plain row-major blocks
+__global__ void unpack_k1_kernel(GraphDev G, int kind, int64_t first, int64_t count, double* r, double* J1, double* J2, double* Js) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const int64_t e = first + i;
+    if (kind == 2) {
+        const double* base = G.Jp + (size_t)e * PRIOR_DOUBLES;
+        if (r) for (int k = 0; k < 6; ++k) r[i * 6 + k] = base[k];
+        if (J1) for (int k = 0; k < 36; ++k) J1[i * 36 + k] = base[6 + k];
+        return;
+    }
+    const bool is_sw = kind == 1;
+    const EdgeClassDev& C = is_sw ? G.sw : G.rel;
+    const int D = is_sw ? SW_DOUBLES : REL_DOUBLES;
+    const int nr = is_sw ? 7 : 6, o1 = is_sw ? 14 : 6, o2 = is_sw ? 50 : 42;
+    if (r) for (int k = 0; k < nr; ++k) r[i * nr + k] = C.J[tile_elem(D, e, k)];
+    if (J1) for (int k = 0; k < 36; ++k) J1[i * 36 + k] = C.J[tile_elem(D, e, o1 + k)];
+    if (J2) for (int k = 0; k < 36; ++k) J2[i * 36 + k] = C.J[tile_elem(D, e, o2 + k)];
+    if (Js && is_sw) for (int k = 0; k < 7; ++k) Js[i * 7 + k] = C.J[tile_elem(D, e, 7 + k)];
+}
+void launch_unpack_k1(const GraphDev& G, int kind, int64_t first, int64_t count, double* r, double* J1, double* J2, double* Js, hipStream_t st) {
+    if (count > 0) hipLaunchKernelGGL(unpack_k1_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, G, kind, first, count, r, J1, J2, Js);
+}
+
+}  // namespace pgo

@@ -1,0 +1,904 @@
+// pgo_solver.hip — host side of libpgo: persistent problem, device graph construction, the Ceres-compatible
+// Levenberg-Marquardt trust-region controller, PCG driver, optional RCCL edge sharding, and the C-ABI (include/pgo.h).
+//
+// What it replaces in the reference: the `ceres::Problem` bookkeeping calls of
+// PoseGraphSLAM::reinit_ceres_problem_onnewloopedge_optimize6DOF (src/PoseGraphSLAM.cpp:1340-1367,1550-1556,
+// 1629-1633,1803-1849) and `ceres::Solve` (:1903) with the options at :1268-1272.  The minimiser follows
+// Ceres' trust_region_minimizer.cc / levenberg_marquardt_strategy.cc control flow; the
+// linear solve is a device PCG instead of SPARSE_NORMAL_CHOLESKY.  There is NO CPU fallback: without a HIP
+// device pgo_create fails.
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pgo.h"
+#include "pgo_internal.hpp"
+
+using namespace pgo;
+
+namespace {
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+template <class T>
+struct DBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        const size_t want = n + n / 8 + 64;
+        hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct HostClass {
+    std::vector<int32_t> c1, c2, sw;
+    std::vector<double> meas;   // 8 per edge: q_obs(4) t_obs(3) w
+    int64_t size() const { return (int64_t)c1.size(); }
+};
+
+// scalar slots
+enum { S_COST = 0, S_PRIOR_COST = 1, S_MODEL = 2, S_SW_STEP2 = 3, S_SW_XNORM2 = 4, S_GMAX = 5, S_STEP2 = 6, S_XNORM2 = 7, S_N = 8 };
+
+// ---- RCCL through dlopen (only touched when pgo_comm_* is used) ----
+struct Rccl {
+    struct Uid { char b[128]; };   // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128), passed BY VALUE to ncclCommInitRank
+    void* h = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, Uid, int) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+
+}  // namespace
+
+struct pgo_problem {
+    pgo_options opt;
+    int device = 0;
+    hipStream_t st = nullptr;
+    std::string err;
+
+    HostClass rel, swe;
+    std::vector<PriorDev> priors;
+    std::vector<int32_t> constant_nodes;
+    bool graph_dirty = true, priors_dirty = true;
+
+    // device graph
+    int64_t N = 0, S = 0;
+    DBuf<int32_t> d_rc1, d_rc2, d_sc1, d_sc2, d_sidx, d_bsr_col;
+    DBuf<double> d_rmeas, d_smeas;
+    DBuf<int4> d_rwin, d_swin;
+    DBuf<PriorDev> d_prior;
+    DBuf<int64_t> d_inc_rowptr, d_inc, d_bsr_rowptr;
+    DBuf<uint8_t> d_node_free;
+    DBuf<double> d_Jr, d_Js, d_Jp;
+    DBuf<double> d_Hd_g;             // Hd [N][36] followed by g [N][6]  (contiguous: one all-reduce)
+    DBuf<double> d_Hoff, d_c, d_hss, d_gs;
+    DBuf<double> d_scale_p, d_scale_s, d_diag_p, d_diag_s, d_a_inv;
+    DBuf<double> d_val, d_Minv, d_Dtot_b;   // Dtot [N][36] followed by b [N][6]
+    DBuf<double> d_cgvec;            // x r r2 z p q  (6 x [N][6])
+    DBuf<double> d_part;             // partial-sum scratch: several arrays of n_part
+    DBuf<double> d_cgpart;           // part_pq [MAX] + part_rz [2][MAX] + scal[4]
+    DBuf<int32_t> d_flags;           // cg flags [4] + invert fail [1]
+    DBuf<double> d_scal;             // S_N doubles
+    DBuf<double> d_pose[2], d_swv[2], d_delta_s, d_io;   // state ping-pong, staging for quat/t
+    DBuf<double> d_tmp;
+    int cur = 0;
+    int64_t n_part = MAX_PARTIALS;
+    std::vector<uint8_t> h_node_free, h_sw_used;
+    int64_t nnzb = 0;
+
+    GraphDev G{};
+    LinDev L{};
+    ScaleDev Sc{};
+    CgDev C{};
+
+    // LM state
+    bool in_solve = false, scale_ready = false, terminated = false;
+    double radius = 0, decrease_factor = 2, x_cost = 0, x_norm = 0, gmax = 0;
+    bool reuse_diagonal = false;
+    int iteration = 0, invalid = 0;
+    double t_begin = 0, t_device0 = 0;
+    pgo_summary sum;
+
+    // comm
+    Rccl nccl; void* comm = nullptr; int rank = 0, world = 1;
+};
+
+namespace {
+
+#define HIPCHK(p, expr)                                                                            \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess) {                                                                   \
+            (p)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                         \
+            return e__ == hipErrorOutOfMemory ? PGO_ERR_OUT_OF_MEMORY : PGO_ERR_HIP;               \
+        }                                                                                          \
+    } while (0)
+
+int set_device(pgo_problem* p) { HIPCHK(p, hipSetDevice(p->device)); return PGO_OK; }
+
+// Matrix4d (column-major 16) -> Meas fields
+void meas_from_matrix(const double* T, double w, double* out8) {
+    double R[9];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R[r * 3 + c] = T[c * 4 + r];
+    double q[4];
+    eigen_matrix_to_quat(R, q);   // CeresResidues.h:24 / :150
+    out8[0] = q[0]; out8[1] = q[1]; out8[2] = q[2]; out8[3] = q[3];
+    out8[4] = T[12]; out8[5] = T[13]; out8[6] = T[14]; out8[7] = w;
+}
+
+int upload_class(pgo_problem* p, const HostClass& H, bool is_sw, DBuf<int32_t>& dc1, DBuf<int32_t>& dc2, DBuf<int32_t>& dsw, DBuf<double>& dmeas,
+                 DBuf<int4>& dwin, EdgeClassDev& out) {
+    const int64_t E = H.size();
+    const int64_t Epad = (E + TILE - 1) / TILE * TILE;
+    const int tiles = (int)(Epad / TILE);
+    std::vector<int32_t> c1(Epad), c2(Epad), sw(is_sw ? Epad : 0);
+    std::vector<double> meas((size_t)8 * Epad);
+    std::vector<int4> win(tiles);
+    for (int64_t e = 0; e < Epad; ++e) {
+        const int64_t s = e < E ? e : E - 1;   // padding lanes replicate the last edge (computed, never stored or counted)
+        c1[e] = H.c1[s]; c2[e] = H.c2[s];
+        if (is_sw) sw[e] = H.sw[s];
+        for (int k = 0; k < 8; ++k) meas[(size_t)k * Epad + e] = H.meas[(size_t)s * 8 + k];
+    }
+    for (int t = 0; t < tiles; ++t) {
+        int lo1 = INT32_MAX, hi1 = -1, lo2 = INT32_MAX, hi2 = -1;
+        for (int l = 0; l < TILE; ++l) {
+            const int64_t e = (int64_t)t * TILE + l;
+            lo1 = std::min(lo1, c1[e]); hi1 = std::max(hi1, c1[e]); lo2 = std::min(lo2, c2[e]); hi2 = std::max(hi2, c2[e]);
+        }
+        const int n1 = hi1 - lo1 + 1, n2 = hi2 - lo2 + 1;
+        win[t] = make_int4(lo1, n1 <= WIN_MAX ? n1 : 0, lo2, n2 <= WIN_MAX ? n2 : 0);
+    }
+    if (Epad > 0) {
+        HIPCHK(p, dc1.ensure(Epad)); HIPCHK(p, dc2.ensure(Epad)); HIPCHK(p, dmeas.ensure((size_t)8 * Epad)); HIPCHK(p, dwin.ensure(tiles));
+        HIPCHK(p, hipMemcpyAsync(dc1.p, c1.data(), Epad * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
+        HIPCHK(p, hipMemcpyAsync(dc2.p, c2.data(), Epad * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
+        HIPCHK(p, hipMemcpyAsync(dmeas.p, meas.data(), (size_t)8 * Epad * sizeof(double), hipMemcpyHostToDevice, p->st));
+        HIPCHK(p, hipMemcpyAsync(dwin.p, win.data(), tiles * sizeof(int4), hipMemcpyHostToDevice, p->st));
+        if (is_sw) { HIPCHK(p, dsw.ensure(Epad)); HIPCHK(p, hipMemcpyAsync(dsw.p, sw.data(), Epad * sizeof(int32_t), hipMemcpyHostToDevice, p->st)); }
+        HIPCHK(p, hipStreamSynchronize(p->st));   // host vectors die at scope exit
+    }
+    out.c1 = dc1.p; out.c2 = dc2.p; out.meas = dmeas.p; out.swidx = is_sw ? dsw.p : nullptr; out.win = dwin.p;
+    out.E = E; out.Epad = Epad; out.tiles = tiles; out.J = nullptr;
+    return PGO_OK;
+}
+
+int build_graph(pgo_problem* p, int64_t N, int64_t S) {
+    // ---- validate against the array sizes the caller solves with
+    for (const HostClass* H : {&p->rel, &p->swe})
+        for (int64_t e = 0; e < H->size(); ++e)
+            if (H->c1[e] < 0 || H->c1[e] >= N || H->c2[e] < 0 || H->c2[e] >= N) { p->err = "edge endpoint out of range for n_nodes"; return PGO_ERR_INVALID_ARG; }
+    p->h_sw_used.assign((size_t)S, 0);
+    for (int64_t e = 0; e < p->swe.size(); ++e) {
+        const int32_t si = p->swe.sw[e];
+        if (si < 0 || si >= S) { p->err = "switch index out of range for n_switch"; return PGO_ERR_INVALID_ARG; }
+        if (p->h_sw_used[si]) { p->err = "switch index used by more than one edge"; return PGO_ERR_INVALID_ARG; }
+        p->h_sw_used[si] = 1;
+    }
+    for (const PriorDev& pr : p->priors) if (pr.node < 0 || pr.node >= N) { p->err = "regulariser node out of range"; return PGO_ERR_INVALID_ARG; }
+    p->N = N; p->S = S;
+    GraphDev& G = p->G;
+    G = GraphDev{};
+    G.N = N; G.S = S;
+    int rc;
+    if ((rc = upload_class(p, p->rel, false, p->d_rc1, p->d_rc2, p->d_sidx /*unused*/, p->d_rmeas, p->d_rwin, G.rel)) != PGO_OK) return rc;
+    if ((rc = upload_class(p, p->swe, true, p->d_sc1, p->d_sc2, p->d_sidx, p->d_smeas, p->d_swin, G.sw)) != PGO_OK) return rc;
+    const int64_t Er = G.rel.E, Es = G.sw.E, Eg = (int64_t)p->priors.size();
+    // ---- node -> incident list (edges in slot order, then regularisers), BSR structure
+    std::vector<int64_t> rowptr(N + 1, 0), bsr_rowptr(N + 1, 0);
+    for (int64_t e = 0; e < Er; ++e) { rowptr[p->rel.c1[e] + 1]++; rowptr[p->rel.c2[e] + 1]++; }
+    for (int64_t e = 0; e < Es; ++e) { rowptr[p->swe.c1[e] + 1]++; rowptr[p->swe.c2[e] + 1]++; }
+    for (int64_t n = 0; n < N; ++n) bsr_rowptr[n + 1] = bsr_rowptr[n] + 1 + rowptr[n + 1];
+    for (int64_t k = 0; k < Eg; ++k) rowptr[p->priors[k].node + 1]++;
+    for (int64_t n = 0; n < N; ++n) rowptr[n + 1] += rowptr[n];
+    const int64_t ninc = rowptr[N];
+    p->nnzb = bsr_rowptr[N];
+    std::vector<int64_t> inc((size_t)ninc), fill(rowptr.begin(), rowptr.end() - 1);
+    std::vector<int32_t> bsr_col((size_t)p->nnzb);
+    std::vector<int64_t> bfill(N);
+    for (int64_t n = 0; n < N; ++n) { bsr_col[bsr_rowptr[n]] = (int32_t)n; bfill[n] = bsr_rowptr[n] + 1; }
+    auto add_edge = [&](int64_t slot, int32_t a, int32_t b) {
+        inc[fill[a]++] = (slot << 1) | 0; bsr_col[bfill[a]++] = b;
+        inc[fill[b]++] = (slot << 1) | 1; bsr_col[bfill[b]++] = a;
+    };
+    for (int64_t e = 0; e < Er; ++e) add_edge(e, p->rel.c1[e], p->rel.c2[e]);
+    for (int64_t e = 0; e < Es; ++e) add_edge(G.rel.Epad + e, p->swe.c1[e], p->swe.c2[e]);
+    for (int64_t k = 0; k < Eg; ++k) inc[fill[p->priors[k].node]++] = ((G.rel.Epad + G.sw.Epad + k) << 1);
+    p->h_node_free.assign((size_t)N, 0);
+    for (int64_t n = 0; n < N; ++n) p->h_node_free[n] = rowptr[n + 1] > rowptr[n] ? 1 : 0;
+    for (int32_t c : p->constant_nodes) if (c >= 0 && c < N) p->h_node_free[c] = 0;
+
+    HIPCHK(p, p->d_inc_rowptr.ensure(N + 1)); HIPCHK(p, p->d_bsr_rowptr.ensure(N + 1)); HIPCHK(p, p->d_inc.ensure(std::max<int64_t>(ninc, 1)));
+    HIPCHK(p, p->d_bsr_col.ensure(std::max<int64_t>(p->nnzb, 1))); HIPCHK(p, p->d_node_free.ensure(std::max<int64_t>(N, 1)));
+    HIPCHK(p, p->d_prior.ensure(std::max<int64_t>(Eg, 1)));
+    HIPCHK(p, hipMemcpyAsync(p->d_inc_rowptr.p, rowptr.data(), (N + 1) * sizeof(int64_t), hipMemcpyHostToDevice, p->st));
+    HIPCHK(p, hipMemcpyAsync(p->d_bsr_rowptr.p, bsr_rowptr.data(), (N + 1) * sizeof(int64_t), hipMemcpyHostToDevice, p->st));
+    if (ninc) HIPCHK(p, hipMemcpyAsync(p->d_inc.p, inc.data(), ninc * sizeof(int64_t), hipMemcpyHostToDevice, p->st));
+    if (p->nnzb) HIPCHK(p, hipMemcpyAsync(p->d_bsr_col.p, bsr_col.data(), p->nnzb * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
+    if (N) HIPCHK(p, hipMemcpyAsync(p->d_node_free.p, p->h_node_free.data(), N, hipMemcpyHostToDevice, p->st));
+    if (Eg) HIPCHK(p, hipMemcpyAsync(p->d_prior.p, p->priors.data(), Eg * sizeof(PriorDev), hipMemcpyHostToDevice, p->st));
+    HIPCHK(p, hipStreamSynchronize(p->st));
+
+    // ---- work buffers
+    const int64_t slots = G.rel.Epad + G.sw.Epad;
+    HIPCHK(p, p->d_Jr.ensure(std::max<int64_t>((int64_t)G.rel.tiles * REL_DOUBLES * TILE, 1)));
+    HIPCHK(p, p->d_Js.ensure(std::max<int64_t>((int64_t)G.sw.tiles * SW_DOUBLES * TILE, 1)));
+    HIPCHK(p, p->d_Jp.ensure(std::max<int64_t>(Eg * PRIOR_DOUBLES, 1)));
+    HIPCHK(p, p->d_Hd_g.ensure(std::max<int64_t>(N * 42, 1)));
+    HIPCHK(p, p->d_Hoff.ensure(std::max<int64_t>(slots * 36, 1)));
+    HIPCHK(p, p->d_c.ensure(std::max<int64_t>(Es * 12, 1))); HIPCHK(p, p->d_hss.ensure(std::max<int64_t>(Es, 1))); HIPCHK(p, p->d_gs.ensure(std::max<int64_t>(Es, 1)));
+    HIPCHK(p, p->d_scale_p.ensure(std::max<int64_t>(N * 6, 1))); HIPCHK(p, p->d_diag_p.ensure(std::max<int64_t>(N * 6, 1)));
+    HIPCHK(p, p->d_scale_s.ensure(std::max<int64_t>(Es, 1))); HIPCHK(p, p->d_diag_s.ensure(std::max<int64_t>(Es, 1))); HIPCHK(p, p->d_a_inv.ensure(std::max<int64_t>(Es, 1)));
+    HIPCHK(p, p->d_val.ensure(std::max<int64_t>(p->nnzb * 36, 1))); HIPCHK(p, p->d_Minv.ensure(std::max<int64_t>(N * 36, 1))); HIPCHK(p, p->d_Dtot_b.ensure(std::max<int64_t>(N * 42, 1)));
+    HIPCHK(p, p->d_cgvec.ensure(std::max<int64_t>(N * 36, 1)));
+    p->n_part = std::max<int64_t>(MAX_PARTIALS, (G.rel.tiles + G.sw.tiles + 3) / 4 + 1);
+    HIPCHK(p, p->d_part.ensure(p->n_part * 6));
+    HIPCHK(p, p->d_cgpart.ensure(3 * MAX_PARTIALS + 8));
+    HIPCHK(p, p->d_flags.ensure(8)); HIPCHK(p, p->d_scal.ensure(S_N));
+    for (int k = 0; k < 2; ++k) { HIPCHK(p, p->d_pose[k].ensure(std::max<int64_t>(N * 8, 1))); HIPCHK(p, p->d_swv[k].ensure(std::max<int64_t>(S, 1))); }
+    HIPCHK(p, p->d_delta_s.ensure(std::max<int64_t>(Es, 1))); HIPCHK(p, p->d_io.ensure(std::max<int64_t>(N * 7, 1)));
+
+    G.rel.J = p->d_Jr.p; G.sw.J = p->d_Js.p;
+    G.prior = p->d_prior.p; G.n_prior = (int32_t)Eg; G.Jp = p->d_Jp.p;
+    G.inc_rowptr = p->d_inc_rowptr.p; G.inc = p->d_inc.p; G.node_free = p->d_node_free.p;
+    G.bsr_rowptr = p->d_bsr_rowptr.p; G.bsr_col = p->d_bsr_col.p; G.nnzb = p->nnzb;
+    p->L = LinDev{p->d_Hd_g.p, p->d_Hd_g.p + (size_t)N * 36, p->d_Hoff.p, p->d_c.p, p->d_hss.p, p->d_gs.p};
+    p->Sc = ScaleDev{p->d_scale_p.p, p->d_scale_s.p, p->d_diag_p.p, p->d_diag_s.p, p->d_a_inv.p};
+    CgDev& C = p->C;
+    C.val = p->d_val.p; C.Minv = p->d_Minv.p; C.Dtot = p->d_Dtot_b.p; C.b = p->d_Dtot_b.p + (size_t)N * 36;
+    double* v = p->d_cgvec.p; const size_t n6 = (size_t)N * 6;
+    C.x = v; C.r = v + n6; C.r2 = v + 2 * n6; C.z = v + 3 * n6; C.p = v + 4 * n6; C.q = v + 5 * n6;
+    C.part_pq = p->d_cgpart.p; C.part_rz = p->d_cgpart.p + MAX_PARTIALS; C.scal = p->d_cgpart.p + 3 * MAX_PARTIALS;
+    C.flags = p->d_flags.p;
+    p->graph_dirty = false; p->priors_dirty = false;
+    return PGO_OK;
+}
+
+// ---- collectives (no-ops at world == 1) ----
+int allreduce(pgo_problem* p, double* buf, size_t n, int op /*0 sum, 2 max*/) {
+    if (p->world <= 1 || !p->comm) return PGO_OK;
+    const int rc = p->nccl.AllReduce(buf, buf, n, /*ncclDouble*/ 8, op, p->comm, p->st);
+    if (rc != 0) { p->err = std::string("ncclAllReduce: ") + (p->nccl.GetErrorString ? p->nccl.GetErrorString(rc) : "error"); return PGO_ERR_COMM; }
+    return PGO_OK;
+}
+
+double* part(pgo_problem* p, int k) { return p->d_part.p + (size_t)k * p->n_part; }
+
+// K1 (+ regularisers) at state `which`; cost lands in d_scal[S_COST], d_scal[S_PRIOR_COST]
+int run_k1(pgo_problem* p, int which, bool want_j) {
+    int np = 0;
+    launch_k1(p->G, p->d_pose[which].p, p->d_swv[which].p, want_j, part(p, 0), &np, p->st);
+    if (np > 0) launch_reduce(part(p, 0), np, 0, p->d_scal.p + S_COST, p->st);
+    else HIPCHK(p, hipMemsetAsync(p->d_scal.p + S_COST, 0, sizeof(double), p->st));
+    launch_prior(p->G, p->d_pose[which].p, want_j, p->d_scal.p + S_PRIOR_COST, p->st);
+    return PGO_OK;
+}
+
+int read_scalars(pgo_problem* p, double* h) {
+    // edge-local sums [S_COST..S_SW_XNORM2] are summed over ranks; the projected-gradient norm takes the max
+    int rc;
+    if ((rc = allreduce(p, p->d_scal.p, 5, 0)) != PGO_OK) return rc;
+    if ((rc = allreduce(p, p->d_scal.p + S_GMAX, 1, 2)) != PGO_OK) return rc;
+    HIPCHK(p, hipMemcpyAsync(h, p->d_scal.p, S_N * sizeof(double), hipMemcpyDeviceToHost, p->st));
+    HIPCHK(p, hipStreamSynchronize(p->st));
+    return PGO_OK;
+}
+
+// linearise at the current state: K1 + K2 (+ all-reduce of diagonal blocks and gradient), norms
+int linearize(pgo_problem* p, double* cost_out) {
+    int rc;
+    if ((rc = run_k1(p, p->cur, true)) != PGO_OK) return rc;
+    launch_k2(p->G, p->L, p->st);
+    if ((rc = allreduce(p, p->d_Hd_g.p, (size_t)p->N * 42, 0)) != PGO_OK) return rc;
+    if (!p->scale_ready) { launch_scale_init(p->G, p->L, p->Sc, p->opt.jacobi_scaling, p->st); p->scale_ready = true; }
+    int np = 0;
+    launch_state_norms(p->G, p->L, p->d_pose[p->cur].p, p->d_swv[p->cur].p, part(p, 1), part(p, 2), part(p, 3), &np, p->st);
+    launch_reduce(part(p, 1), np, 0, p->d_scal.p + S_XNORM2, p->st);
+    launch_reduce(part(p, 2), np, 0, p->d_scal.p + S_SW_XNORM2, p->st);
+    launch_reduce(part(p, 3), np, 1, p->d_scal.p + S_GMAX, p->st);
+    HIPCHK(p, hipMemsetAsync(p->d_scal.p + S_MODEL, 0, 2 * sizeof(double), p->st));
+    double h[S_N];
+    if ((rc = read_scalars(p, h)) != PGO_OK) return rc;
+    *cost_out = 0.5 * (h[S_COST] + h[S_PRIOR_COST]);
+    p->x_norm = std::sqrt(h[S_XNORM2] + h[S_SW_XNORM2]);
+    p->gmax = h[S_GMAX];
+    return PGO_OK;
+}
+
+struct CgResult { int iterations; bool breakdown; double rel_residual; };
+
+int run_pcg(pgo_problem* p, CgResult* res) {
+    const pgo_options& o = p->opt;
+    launch_cg_init(p->G, p->C, p->st);
+    const double tol2 = o.cg_rel_tolerance * o.cg_rel_tolerance;
+    int k = 0;
+    int32_t hflags[3] = {0, 0, 0};
+    double hscal[3] = {0, 0, 0};
+    const int every = std::max(1, o.cg_check_every);
+    int rc;
+    while (k < o.cg_max_iterations) {
+        const int chunk = std::min(every, o.cg_max_iterations - k);
+        for (int j = 0; j < chunk; ++j, ++k) {
+            launch_cg_spmv(p->G, p->C, p->st);
+            if (p->world > 1) {
+                if ((rc = allreduce(p, p->C.q, (size_t)p->N * 6, 0)) != PGO_OK) return rc;   // the one exchange per CG matvec
+                launch_cg_pq(p->G, p->C, p->st);
+            }
+            launch_cg_update(p->G, p->C, k & 1, p->st);
+            launch_cg_direction(p->G, p->C, k & 1, tol2, p->st);
+        }
+        HIPCHK(p, hipMemcpyAsync(hflags, p->C.flags, sizeof(hflags), hipMemcpyDeviceToHost, p->st));
+        HIPCHK(p, hipMemcpyAsync(hscal, p->C.scal, sizeof(hscal), hipMemcpyDeviceToHost, p->st));
+        HIPCHK(p, hipStreamSynchronize(p->st));
+        if (hflags[0]) break;
+    }
+    res->iterations = hflags[2];
+    res->breakdown = hflags[1] != 0;
+    res->rel_residual = hscal[0] > 0 ? std::sqrt(std::max(0.0, hscal[1]) / hscal[0]) : 0.0;
+    return PGO_OK;
+}
+
+int build_system(pgo_problem* p, bool* ok) {
+    int rc;
+    HIPCHK(p, hipMemsetAsync(p->d_flags.p + 4, 0, sizeof(int32_t), p->st));
+    launch_build_rows(p->G, p->L, p->Sc, p->C, p->radius, p->rank == 0 ? 1 : 0, p->st);
+    if ((rc = allreduce(p, p->d_Dtot_b.p, (size_t)p->N * 42, 0)) != PGO_OK) return rc;
+    launch_invert_rows(p->G, p->C, p->d_flags.p + 4, p->st);
+    int32_t fail = 0;
+    HIPCHK(p, hipMemcpyAsync(&fail, p->d_flags.p + 4, sizeof(int32_t), hipMemcpyDeviceToHost, p->st));
+    HIPCHK(p, hipStreamSynchronize(p->st));
+    *ok = fail == 0;
+    return PGO_OK;
+}
+
+void log_iter(pgo_problem* p, const pgo_iteration& it) {
+    if (p->sum.num_logged < PGO_MAX_ITERATION_LOG) p->sum.iterations[p->sum.num_logged++] = it;
+    if (p->opt.verbosity > 0)
+        std::fprintf(stderr, "[pgo] it %3d cost %.12e dcost %.3e rho %.3e |step| %.3e radius %.3e cg %d (%.1e) %s %.2f ms\n", it.iteration, it.cost, it.cost_change,
+                     it.relative_decrease, it.step_norm, it.trust_region_radius, it.cg_iterations, it.cg_residual, it.step_is_successful ? "ok" : (it.step_is_valid ? "REJ" : "INVALID"), it.seconds * 1e3);
+}
+
+void terminate(pgo_problem* p, int type, const char* msg) {
+    p->terminated = true;
+    p->sum.termination_type = type;
+    std::snprintf(p->sum.message, sizeof(p->sum.message), "%s", msg);
+}
+
+int solve_begin(pgo_problem* p, const double* quat, const double* t, const double* sw, int64_t N, int64_t S) {
+    if (!quat || !t || N <= 0 || S < 0 || (S > 0 && !sw)) { p->err = "null state array or bad size"; return PGO_ERR_INVALID_ARG; }
+    int rc;
+    if ((rc = set_device(p)) != PGO_OK) return rc;
+    p->t_begin = now_s();
+    if (p->graph_dirty || p->priors_dirty || N != p->N || S != p->S) if ((rc = build_graph(p, N, S)) != PGO_OK) return rc;
+    // upload in the reference layout, repack on the device
+    double* io = p->d_io.p;
+    HIPCHK(p, hipMemcpyAsync(io, quat, (size_t)N * 4 * sizeof(double), hipMemcpyHostToDevice, p->st));
+    HIPCHK(p, hipMemcpyAsync(io + (size_t)N * 4, t, (size_t)N * 3 * sizeof(double), hipMemcpyHostToDevice, p->st));
+    p->cur = 0;
+    launch_pack_pose(io, io + (size_t)N * 4, p->d_pose[0].p, N, p->st);
+    if (S > 0) {
+        HIPCHK(p, hipMemcpyAsync(p->d_swv[0].p, sw, (size_t)S * sizeof(double), hipMemcpyHostToDevice, p->st));
+        HIPCHK(p, hipMemcpyAsync(p->d_swv[1].p, p->d_swv[0].p, (size_t)S * sizeof(double), hipMemcpyDeviceToDevice, p->st));
+    }
+    HIPCHK(p, hipStreamSynchronize(p->st));
+    p->t_device0 = now_s();
+    std::memset(&p->sum, 0, sizeof(p->sum));
+    p->in_solve = true; p->terminated = false; p->scale_ready = false;
+    p->radius = p->opt.initial_trust_region_radius; p->decrease_factor = 2.0; p->reuse_diagonal = false; p->iteration = 0; p->invalid = 0;
+    p->sum.termination_type = PGO_NO_CONVERGENCE;
+    if ((rc = linearize(p, &p->x_cost)) != PGO_OK) return rc;
+    p->sum.initial_cost = p->x_cost;
+    p->sum.final_cost = p->x_cost;
+    if (!std::isfinite(p->x_cost)) { terminate(p, PGO_FAILURE, "initial cost is not finite"); return PGO_OK; }
+    pgo_iteration it{};
+    it.iteration = 0; it.step_is_valid = 1; it.step_is_successful = 1; it.cost = p->x_cost; it.gradient_max_norm = p->gmax; it.trust_region_radius = p->radius;
+    it.seconds = now_s() - p->t_device0;
+    log_iter(p, it);
+    return PGO_OK;
+}
+
+int lm_step(pgo_problem* p, int ignore_termination, int* done) {
+    if (!p->in_solve) { p->err = "pgo_lm_step before pgo_solve_begin"; return PGO_ERR_STATE; }
+    const pgo_options& o = p->opt;
+    int rc;
+    if ((rc = set_device(p)) != PGO_OK) return rc;
+    if (p->terminated && !ignore_termination) { if (done) *done = 1; return PGO_OK; }
+    if (p->sum.termination_type == PGO_FAILURE && p->terminated) { if (done) *done = 1; return PGO_OK; }
+    // FinalizeIterationAndCheckIfMinimizerCanContinue
+    if (!ignore_termination) {
+        if (p->iteration >= o.max_num_iterations) { terminate(p, PGO_NO_CONVERGENCE, "Maximum number of iterations reached."); if (done) *done = 1; return PGO_OK; }
+        if (p->gmax <= o.gradient_tolerance) { terminate(p, PGO_CONVERGENCE, "Gradient tolerance reached."); if (done) *done = 1; return PGO_OK; }
+        if (p->radius < o.min_trust_region_radius) { terminate(p, PGO_CONVERGENCE, "Minimum trust region radius reached."); if (done) *done = 1; return PGO_OK; }
+    }
+    const double t0 = now_s();
+    ++p->iteration;
+    pgo_iteration it{};
+    it.iteration = p->iteration; it.trust_region_radius = p->radius;
+    if (!p->reuse_diagonal) launch_lm_diag(p->G, p->L, p->Sc, o.min_lm_diagonal, o.max_lm_diagonal, p->st);
+    bool ok = true;
+    if ((rc = build_system(p, &ok)) != PGO_OK) return rc;
+    CgResult cg{0, false, 0.0};
+    if (ok) {
+        if ((rc = run_pcg(p, &cg)) != PGO_OK) return rc;
+        if (cg.breakdown) ok = false;
+    }
+    it.cg_iterations = cg.iterations; it.cg_residual = cg.rel_residual;
+    p->sum.cg_iterations += cg.iterations;
+    const int nxt = p->cur ^ 1;
+    double h[S_N] = {0};
+    if (ok) {
+        int np = 0, np2 = 0;
+        launch_model_change(p->G, p->L, p->Sc, p->C.x, p->d_delta_s.p, part(p, 4), &np, p->st);
+        launch_reduce(part(p, 4), np, 0, p->d_scal.p + S_MODEL, p->st);
+        launch_plus(p->G, p->d_pose[p->cur].p, p->d_swv[p->cur].p, p->C.x, p->d_delta_s.p, p->d_pose[nxt].p, p->d_swv[nxt].p, part(p, 1), part(p, 2), &np2, p->st);
+        launch_reduce(part(p, 1), np2, 0, p->d_scal.p + S_STEP2, p->st);
+        launch_reduce(part(p, 2), np2, 0, p->d_scal.p + S_SW_STEP2, p->st);
+        if ((rc = run_k1(p, nxt, false)) != PGO_OK) return rc;
+        HIPCHK(p, hipMemsetAsync(p->d_scal.p + S_SW_XNORM2, 0, 2 * sizeof(double), p->st));   // SW_XNORM2, GMAX unused here
+        if ((rc = read_scalars(p, h)) != PGO_OK) return rc;
+        it.model_cost_change = -h[S_MODEL];
+        if (!(it.model_cost_change > 0.0) || !std::isfinite(it.model_cost_change)) ok = false;
+    }
+    if (!ok) {
+        // HandleInvalidStep
+        it.step_is_valid = 0; it.cost = p->x_cost; it.gradient_max_norm = p->gmax;
+        ++p->invalid; ++p->sum.num_unsuccessful_steps;
+        if (p->invalid >= o.max_num_consecutive_invalid_steps && !ignore_termination) {
+            terminate(p, PGO_FAILURE, "Number of consecutive invalid steps more than max_num_consecutive_invalid_steps.");
+            it.seconds = now_s() - t0; log_iter(p, it);
+            if (done) *done = 1;
+            return PGO_OK;
+        }
+        p->radius *= 0.5; p->reuse_diagonal = true;   // LevenbergMarquardtStrategy::StepIsInvalid
+        it.seconds = now_s() - t0; log_iter(p, it);
+        if (done) *done = 0;
+        return PGO_OK;
+    }
+    p->invalid = 0;
+    it.step_is_valid = 1;
+    const double cand_cost = 0.5 * (h[S_COST] + h[S_PRIOR_COST]);
+    it.step_norm = std::sqrt(h[S_STEP2] + h[S_SW_STEP2]);
+    it.cost_change = p->x_cost - cand_cost;
+    it.relative_decrease = it.cost_change / it.model_cost_change;
+    bool stop = false;
+    if (!ignore_termination) {
+        if (it.step_norm <= o.parameter_tolerance * (p->x_norm + o.parameter_tolerance)) { terminate(p, PGO_CONVERGENCE, "Parameter tolerance reached."); stop = true; }
+        else if (std::fabs(it.cost_change) <= o.function_tolerance * p->x_cost) { terminate(p, PGO_CONVERGENCE, "Function tolerance reached."); stop = true; }
+    }
+    if (stop) {
+        it.cost = p->x_cost; it.gradient_max_norm = p->gmax; it.seconds = now_s() - t0; log_iter(p, it);
+        if (done) *done = 1;
+        return PGO_OK;
+    }
+    if (std::isfinite(cand_cost) && it.relative_decrease > o.min_relative_decrease) {
+        // HandleSuccessfulStep
+        p->cur = nxt;
+        double c = 0;
+        if ((rc = linearize(p, &c)) != PGO_OK) return rc;
+        p->x_cost = c;
+        it.step_is_successful = 1;
+        p->radius = p->radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * it.relative_decrease - 1.0, 3));   // StepAccepted
+        p->radius = std::min(o.max_trust_region_radius, p->radius);
+        p->decrease_factor = 2.0; p->reuse_diagonal = false;
+        ++p->sum.num_successful_steps;
+    } else {
+        p->radius = p->radius / p->decrease_factor; p->decrease_factor *= 2.0; p->reuse_diagonal = true;   // StepRejected
+        ++p->sum.num_unsuccessful_steps;
+    }
+    it.cost = p->x_cost; it.gradient_max_norm = p->gmax; it.seconds = now_s() - t0;
+    log_iter(p, it);
+    p->sum.final_cost = p->x_cost;
+    if (done) *done = 0;
+    return PGO_OK;
+}
+
+int solve_end(pgo_problem* p, double* quat, double* t, double* sw, pgo_summary* out) {
+    if (!p->in_solve) { p->err = "pgo_solve_end before pgo_solve_begin"; return PGO_ERR_STATE; }
+    int rc;
+    if ((rc = set_device(p)) != PGO_OK) return rc;
+    const double t_dev = now_s();
+    p->sum.num_iterations = p->iteration;
+    p->sum.final_cost = p->x_cost;
+    p->sum.seconds_device = t_dev - p->t_device0;
+    if (p->sum.termination_type != PGO_FAILURE && quat && t) {
+        // single write-back at the very end (reference relies on this: src/PoseGraphSLAM.cpp:1894-1903)
+        double* io = p->d_io.p;
+        launch_unpack_pose(p->d_pose[p->cur].p, io, io + (size_t)p->N * 4, p->N, p->st);
+        std::vector<double> hq((size_t)p->N * 4), ht((size_t)p->N * 3), hs((size_t)p->S);
+        HIPCHK(p, hipMemcpyAsync(hq.data(), io, hq.size() * sizeof(double), hipMemcpyDeviceToHost, p->st));
+        HIPCHK(p, hipMemcpyAsync(ht.data(), io + (size_t)p->N * 4, ht.size() * sizeof(double), hipMemcpyDeviceToHost, p->st));
+        if (p->S > 0) {
+            if (p->world > 1) {
+                // every switch is owned by the rank holding its edge: sum (owned ? value : 0) and the owner count
+                std::vector<double> own((size_t)p->S * 2, 0.0), cur((size_t)p->S);
+                HIPCHK(p, hipMemcpyAsync(cur.data(), p->d_swv[p->cur].p, (size_t)p->S * sizeof(double), hipMemcpyDeviceToHost, p->st));
+                HIPCHK(p, hipStreamSynchronize(p->st));
+                for (int64_t i = 0; i < p->S; ++i) if (p->h_sw_used[i]) { own[i] = cur[i]; own[p->S + i] = 1.0; }
+                HIPCHK(p, p->d_tmp.ensure((size_t)p->S * 2));
+                HIPCHK(p, hipMemcpyAsync(p->d_tmp.p, own.data(), own.size() * sizeof(double), hipMemcpyHostToDevice, p->st));
+                if ((rc = allreduce(p, p->d_tmp.p, own.size(), 0)) != PGO_OK) return rc;
+                HIPCHK(p, hipMemcpyAsync(own.data(), p->d_tmp.p, own.size() * sizeof(double), hipMemcpyDeviceToHost, p->st));
+                HIPCHK(p, hipStreamSynchronize(p->st));
+                for (int64_t i = 0; i < p->S; ++i) hs[i] = own[p->S + i] > 0.5 ? own[i] : (sw ? sw[i] : cur[i]);
+            } else {
+                HIPCHK(p, hipMemcpyAsync(hs.data(), p->d_swv[p->cur].p, (size_t)p->S * sizeof(double), hipMemcpyDeviceToHost, p->st));
+            }
+        }
+        HIPCHK(p, hipStreamSynchronize(p->st));
+        std::memcpy(quat, hq.data(), hq.size() * sizeof(double));
+        std::memcpy(t, ht.data(), ht.size() * sizeof(double));
+        if (sw && p->S > 0) std::memcpy(sw, hs.data(), hs.size() * sizeof(double));
+    }
+    p->sum.seconds_total = now_s() - p->t_begin;
+    if (out) *out = p->sum;
+    p->in_solve = false;
+    return PGO_OK;
+}
+
+int add_edges(pgo_problem* p, HostClass& H, int64_t n, const int32_t* c1, const int32_t* c2, const double* T, const double* w, const int32_t* sw) {
+    if (n < 0 || (n > 0 && (!c1 || !c2 || !T))) { p->err = "null edge array"; return PGO_ERR_INVALID_ARG; }
+    for (int64_t k = 0; k < n; ++k) if (c1[k] < 0 || c2[k] < 0 || c1[k] == c2[k] || (sw && sw[k] < 0)) { p->err = "negative index or self edge"; return PGO_ERR_INVALID_ARG; }
+    const size_t base = H.c1.size();
+    H.c1.insert(H.c1.end(), c1, c1 + n);
+    H.c2.insert(H.c2.end(), c2, c2 + n);
+    if (sw) H.sw.insert(H.sw.end(), sw, sw + n);
+    H.meas.resize((base + n) * 8);
+    for (int64_t k = 0; k < n; ++k) meas_from_matrix(T + 16 * k, w ? w[k] : 1.0, &H.meas[(base + k) * 8]);
+    p->graph_dirty = true;
+    return PGO_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+// C-ABI
+// ================================================================================================
+extern "C" {
+
+void pgo_options_init(pgo_options* o) {
+    if (!o) return;
+    std::memset(o, 0, sizeof(*o));
+    o->max_num_iterations = 10;          // src/PoseGraphSLAM.cpp:1272
+    o->linear_solver = PGO_LINEAR_PCG_BLOCK_JACOBI;
+    o->jacobi_scaling = 1;
+    o->max_num_consecutive_invalid_steps = 5;
+    o->initial_trust_region_radius = 1e4;
+    o->max_trust_region_radius = 1e16;
+    o->min_trust_region_radius = 1e-32;
+    o->min_relative_decrease = 1e-3;
+    o->min_lm_diagonal = 1e-6;
+    o->max_lm_diagonal = 1e32;
+    o->function_tolerance = 1e-6;
+    o->gradient_tolerance = 1e-10;
+    o->parameter_tolerance = 1e-8;
+    o->cg_max_iterations = 4000;
+    o->cg_check_every = 25;
+    o->cg_rel_tolerance = 1e-10;
+    o->device_id = -1;
+    o->verbosity = 0;
+}
+
+int pgo_create(pgo_problem** out, const pgo_options* opts) {
+    if (!out) return PGO_ERR_INVALID_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return PGO_ERR_NO_DEVICE;
+    pgo_problem* p = new (std::nothrow) pgo_problem();
+    if (!p) return PGO_ERR_OUT_OF_MEMORY;
+    if (opts) p->opt = *opts; else pgo_options_init(&p->opt);
+    int dev = p->opt.device_id;
+    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+    if (dev >= count) { delete p; return PGO_ERR_NO_DEVICE; }
+    p->device = dev;
+    if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&p->st, hipStreamNonBlocking) != hipSuccess) { delete p; return PGO_ERR_NO_DEVICE; }
+    std::memset(&p->sum, 0, sizeof(p->sum));
+    *out = p;
+    return PGO_OK;
+}
+
+int pgo_destroy(pgo_problem* p) {
+    if (!p) return PGO_ERR_INVALID_ARG;
+    (void)hipSetDevice(p->device);
+    if (p->comm && p->nccl.CommDestroy) p->nccl.CommDestroy(p->comm);
+    (void)hipStreamSynchronize(p->st);
+    p->d_rc1.release(); p->d_rc2.release(); p->d_sc1.release(); p->d_sc2.release(); p->d_sidx.release(); p->d_bsr_col.release();
+    p->d_rmeas.release(); p->d_smeas.release(); p->d_rwin.release(); p->d_swin.release(); p->d_prior.release();
+    p->d_inc_rowptr.release(); p->d_inc.release(); p->d_bsr_rowptr.release(); p->d_node_free.release();
+    p->d_Jr.release(); p->d_Js.release(); p->d_Jp.release(); p->d_Hd_g.release(); p->d_Hoff.release(); p->d_c.release(); p->d_hss.release(); p->d_gs.release();
+    p->d_scale_p.release(); p->d_scale_s.release(); p->d_diag_p.release(); p->d_diag_s.release(); p->d_a_inv.release();
+    p->d_val.release(); p->d_Minv.release(); p->d_Dtot_b.release(); p->d_cgvec.release(); p->d_part.release(); p->d_cgpart.release();
+    p->d_flags.release(); p->d_scal.release(); p->d_pose[0].release(); p->d_pose[1].release(); p->d_swv[0].release(); p->d_swv[1].release();
+    p->d_delta_s.release(); p->d_io.release(); p->d_tmp.release();
+    (void)hipStreamDestroy(p->st);
+    delete p;
+    return PGO_OK;
+}
+
+int pgo_set_options(pgo_problem* p, const pgo_options* o) {
+    if (!p || !o) return PGO_ERR_INVALID_ARG;
+    const int dev = p->opt.device_id;
+    p->opt = *o;
+    p->opt.device_id = dev;   // the device binding is fixed at create
+    return PGO_OK;
+}
+
+int pgo_reserve(pgo_problem* p, int64_t n_nodes, int64_t n_edges) {
+    if (!p || n_nodes < 0 || n_edges < 0) return PGO_ERR_INVALID_ARG;
+    p->rel.c1.reserve(n_edges); p->rel.c2.reserve(n_edges); p->rel.meas.reserve((size_t)n_edges * 8);
+    return PGO_OK;
+}
+
+int pgo_add_relpose_edges(pgo_problem* p, int64_t n, const int32_t* c1, const int32_t* c2, const double* T, const double* w) {
+    if (!p) return PGO_ERR_INVALID_ARG;
+    if (n > 0 && !w) { p->err = "weight array required for relative-pose edges"; return PGO_ERR_INVALID_ARG; }
+    return add_edges(p, p->rel, n, c1, c2, T, w, nullptr);
+}
+int pgo_add_switchable_edges(pgo_problem* p, int64_t n, const int32_t* c1, const int32_t* c2, const double* T, const double* w, const int32_t* sw) {
+    if (!p) return PGO_ERR_INVALID_ARG;
+    if (n > 0 && !sw) { p->err = "switch index array required"; return PGO_ERR_INVALID_ARG; }
+    return add_edges(p, p->swe, n, c1, c2, T, w, sw);
+}
+int pgo_set_node_regularizers(pgo_problem* p, int64_t n, const int32_t* node, const double* target, const double* weight) {
+    if (!p || n < 0 || (n > 0 && (!node || !target || !weight))) return PGO_ERR_INVALID_ARG;
+    std::vector<PriorDev> v((size_t)n);
+    for (int64_t k = 0; k < n; ++k) {
+        if (node[k] < 0) { p->err = "negative regulariser node"; return PGO_ERR_INVALID_ARG; }
+        const double* T = target + 16 * k;
+        PriorDev& P = v[k];
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) P.Rf[r * 3 + c] = T[c * 4 + r];
+        P.tf[0] = T[12]; P.tf[1] = T[13]; P.tf[2] = T[14];
+        eigen_matrix_to_quat(P.Rf, P.qf);
+        P.w = weight[k]; P.node = node[k]; P.pad_ = 0;
+    }
+    p->priors.swap(v);
+    p->priors_dirty = true;
+    return PGO_OK;
+}
+int pgo_set_nodes_constant(pgo_problem* p, int64_t n, const int32_t* node) {
+    if (!p || n < 0 || (n > 0 && !node)) return PGO_ERR_INVALID_ARG;
+    for (int64_t k = 0; k < n; ++k) if (node[k] < 0) return PGO_ERR_INVALID_ARG;
+    p->constant_nodes.insert(p->constant_nodes.end(), node, node + n);
+    p->graph_dirty = true;
+    return PGO_OK;
+}
+int pgo_num_relpose_edges(const pgo_problem* p, int64_t* n) { if (!p || !n) return PGO_ERR_INVALID_ARG; *n = p->rel.size(); return PGO_OK; }
+int pgo_num_switchable_edges(const pgo_problem* p, int64_t* n) { if (!p || !n) return PGO_ERR_INVALID_ARG; *n = p->swe.size(); return PGO_OK; }
+int pgo_num_regularizers(const pgo_problem* p, int64_t* n) { if (!p || !n) return PGO_ERR_INVALID_ARG; *n = (int64_t)p->priors.size(); return PGO_OK; }
+
+int pgo_solve_begin(pgo_problem* p, const double* q, const double* t, const double* sw, int64_t N, int64_t S) {
+    if (!p) return PGO_ERR_INVALID_ARG;
+    return solve_begin(p, q, t, sw, N, S);
+}
+int pgo_lm_step(pgo_problem* p, int32_t ignore_termination, int32_t* done) {
+    if (!p) return PGO_ERR_INVALID_ARG;
+    int d = 0;
+    const int rc = lm_step(p, ignore_termination, &d);
+    if (done) *done = d;
+    return rc;
+}
+int pgo_solve_end(pgo_problem* p, double* q, double* t, double* sw, pgo_summary* s) {
+    if (!p) return PGO_ERR_INVALID_ARG;
+    return solve_end(p, q, t, sw, s);
+}
+int pgo_solve(pgo_problem* p, double* q, double* t, double* sw, int64_t N, int64_t S, pgo_summary* s) {
+    if (!p) return PGO_ERR_INVALID_ARG;
+    int rc = solve_begin(p, q, t, sw, N, S);
+    if (rc != PGO_OK) return rc;
+    int done = p->terminated ? 1 : 0;
+    while (!done) { rc = lm_step(p, 0, &done); if (rc != PGO_OK) { p->in_solve = false; return rc; } }
+    return solve_end(p, q, t, sw, s);
+}
+
+int pgo_evaluate(pgo_problem* p, const double* q, const double* t, const double* sw, int64_t N, int64_t S, double* cost, double* residuals, double* gradient) {
+    if (!p) return PGO_ERR_INVALID_ARG;
+    const pgo_summary keep = p->sum;
+    int rc = solve_begin(p, q, t, sw, N, S);   // upload + K1 + K2 + norms at the given point
+    if (rc != PGO_OK) return rc;
+    p->in_solve = false;
+    if (cost) *cost = p->x_cost;
+    const int64_t Er = p->G.rel.E, Es = p->G.sw.E, Eg = p->G.n_prior;
+    if (residuals) {
+        const int64_t total = 6 * Er + 7 * Es + 6 * Eg;
+        HIPCHK(p, p->d_tmp.ensure(std::max<int64_t>(total, 1)));
+        launch_unpack_k1(p->G, 0, 0, Er, p->d_tmp.p, nullptr, nullptr, nullptr, p->st);
+        launch_unpack_k1(p->G, 1, 0, Es, p->d_tmp.p + 6 * Er, nullptr, nullptr, nullptr, p->st);
+        launch_unpack_k1(p->G, 2, 0, Eg, p->d_tmp.p + 6 * Er + 7 * Es, nullptr, nullptr, nullptr, p->st);
+        HIPCHK(p, hipMemcpyAsync(residuals, p->d_tmp.p, total * sizeof(double), hipMemcpyDeviceToHost, p->st));
+        HIPCHK(p, hipStreamSynchronize(p->st));
+    }
+    if (gradient) {
+        std::vector<double> gs((size_t)std::max<int64_t>(Es, 1));
+        HIPCHK(p, hipMemcpyAsync(gradient, p->L.g, (size_t)N * 6 * sizeof(double), hipMemcpyDeviceToHost, p->st));
+        if (Es) HIPCHK(p, hipMemcpyAsync(gs.data(), p->L.gs, Es * sizeof(double), hipMemcpyDeviceToHost, p->st));
+        HIPCHK(p, hipStreamSynchronize(p->st));
+        for (int64_t i = 0; i < S; ++i) gradient[6 * N + i] = 0.0;
+        for (int64_t e = 0; e < Es; ++e) gradient[6 * N + p->swe.sw[e]] = gs[e];
+        for (int64_t n = 0; n < N; ++n) if (!p->h_node_free[n]) for (int c = 0; c < 6; ++c) gradient[6 * n + c] = 0.0;
+    }
+    p->sum = keep;
+    return PGO_OK;
+}
+
+int pgo_get_jacobian_blocks(pgo_problem* p, int32_t kind, int64_t first, int64_t count, double* J1, double* J2, double* dr_ds) {
+    if (!p || kind < 0 || kind > 2 || first < 0 || count < 0) return PGO_ERR_INVALID_ARG;
+    if (p->graph_dirty) { p->err = "no linearisation available"; return PGO_ERR_STATE; }
+    const int64_t E = kind == 0 ? p->G.rel.E : kind == 1 ? p->G.sw.E : p->G.n_prior;
+    if (first + count > E) return PGO_ERR_INVALID_ARG;
+    if (count == 0) return PGO_OK;
+    int rc;
+    if ((rc = set_device(p)) != PGO_OK) return rc;
+    HIPCHK(p, p->d_tmp.ensure((size_t)count * 79));
+    double* d1 = p->d_tmp.p; double* d2 = d1 + count * 36; double* ds = d2 + count * 36;
+    launch_unpack_k1(p->G, kind, first, count, nullptr, d1, kind == 2 ? nullptr : d2, kind == 1 ? ds : nullptr, p->st);
+    if (J1) HIPCHK(p, hipMemcpyAsync(J1, d1, count * 36 * sizeof(double), hipMemcpyDeviceToHost, p->st));
+    if (J2 && kind != 2) HIPCHK(p, hipMemcpyAsync(J2, d2, count * 36 * sizeof(double), hipMemcpyDeviceToHost, p->st));
+    if (dr_ds && kind == 1) HIPCHK(p, hipMemcpyAsync(dr_ds, ds, count * 7 * sizeof(double), hipMemcpyDeviceToHost, p->st));
+    HIPCHK(p, hipStreamSynchronize(p->st));
+    return PGO_OK;
+}
+
+int pgo_get_normal_blocks(pgo_problem* p, double* diag, double* grad, double* offdiag, double* sw_c, double* sw_hss, double* sw_gs) {
+    if (!p) return PGO_ERR_INVALID_ARG;
+    if (p->graph_dirty) { p->err = "no linearisation available"; return PGO_ERR_STATE; }
+    int rc;
+    if ((rc = set_device(p)) != PGO_OK) return rc;
+    const int64_t N = p->N, Er = p->G.rel.E, Es = p->G.sw.E;
+    if (diag) HIPCHK(p, hipMemcpyAsync(diag, p->L.Hd, N * 36 * sizeof(double), hipMemcpyDeviceToHost, p->st));
+    if (grad) HIPCHK(p, hipMemcpyAsync(grad, p->L.g, N * 6 * sizeof(double), hipMemcpyDeviceToHost, p->st));
+    if (offdiag) {
+        if (Er) HIPCHK(p, hipMemcpyAsync(offdiag, p->L.Hoff, Er * 36 * sizeof(double), hipMemcpyDeviceToHost, p->st));
+        if (Es) HIPCHK(p, hipMemcpyAsync(offdiag + Er * 36, p->L.Hoff + (size_t)p->G.rel.Epad * 36, Es * 36 * sizeof(double), hipMemcpyDeviceToHost, p->st));
+    }
+    if (sw_c && Es) HIPCHK(p, hipMemcpyAsync(sw_c, p->L.c, Es * 12 * sizeof(double), hipMemcpyDeviceToHost, p->st));
+    if (sw_hss && Es) HIPCHK(p, hipMemcpyAsync(sw_hss, p->L.hss, Es * sizeof(double), hipMemcpyDeviceToHost, p->st));
+    if (sw_gs && Es) HIPCHK(p, hipMemcpyAsync(sw_gs, p->L.gs, Es * sizeof(double), hipMemcpyDeviceToHost, p->st));
+    HIPCHK(p, hipStreamSynchronize(p->st));
+    return PGO_OK;
+}
+
+int pgo_apply_normal_operator(pgo_problem* p, const double* x, double* y) {
+    if (!p || !x || !y) return PGO_ERR_INVALID_ARG;
+    if (!p->in_solve) { p->err = "pgo_apply_normal_operator needs an open solve (pgo_solve_begin)"; return PGO_ERR_STATE; }
+    int rc;
+    if ((rc = set_device(p)) != PGO_OK) return rc;
+    const pgo_options& o = p->opt;
+    if (!p->reuse_diagonal) launch_lm_diag(p->G, p->L, p->Sc, o.min_lm_diagonal, o.max_lm_diagonal, p->st);
+    bool ok = true;
+    if ((rc = build_system(p, &ok)) != PGO_OK) return rc;
+    HIPCHK(p, p->d_tmp.ensure((size_t)p->N * 12));
+    HIPCHK(p, hipMemcpyAsync(p->d_tmp.p, x, (size_t)p->N * 6 * sizeof(double), hipMemcpyHostToDevice, p->st));
+    launch_apply_operator(p->G, p->C, p->d_tmp.p, p->d_tmp.p + (size_t)p->N * 6, p->st);
+    if ((rc = allreduce(p, p->d_tmp.p + (size_t)p->N * 6, (size_t)p->N * 6, 0)) != PGO_OK) return rc;
+    HIPCHK(p, hipMemcpyAsync(y, p->d_tmp.p + (size_t)p->N * 6, (size_t)p->N * 6 * sizeof(double), hipMemcpyDeviceToHost, p->st));
+    HIPCHK(p, hipStreamSynchronize(p->st));
+    return PGO_OK;
+}
+
+// ---- multi-GPU ----
+static int load_rccl(Rccl& r, std::string& err) {
+    if (r.h) return PGO_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) { r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (r.h) break; }
+    if (!r.h) { err = std::string("dlopen(librccl): ") + dlerror(); return PGO_ERR_COMM; }
+    r.GetUniqueId = (int (*)(void*))dlsym(r.h, "ncclGetUniqueId");
+    r.CommInitRank = (int (*)(void**, int, Rccl::Uid, int))dlsym(r.h, "ncclCommInitRank");
+    r.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(r.h, "ncclAllReduce");
+    r.CommDestroy = (int (*)(void*))dlsym(r.h, "ncclCommDestroy");
+    r.GetErrorString = (const char* (*)(int))dlsym(r.h, "ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.AllReduce || !r.CommDestroy) { err = "librccl: missing symbols"; return PGO_ERR_COMM; }
+    return PGO_OK;
+}
+static Rccl g_rccl_for_id;
+
+int pgo_comm_get_unique_id(uint8_t id[PGO_COMM_ID_BYTES]) {
+    if (!id) return PGO_ERR_INVALID_ARG;
+    std::string err;
+    if (load_rccl(g_rccl_for_id, err) != PGO_OK) return PGO_ERR_COMM;
+    Rccl::Uid u;
+    if (g_rccl_for_id.GetUniqueId(&u) != 0) return PGO_ERR_COMM;
+    std::memcpy(id, u.b, PGO_COMM_ID_BYTES);
+    return PGO_OK;
+}
+int pgo_comm_init(pgo_problem* p, int32_t rank, int32_t world, const uint8_t id[PGO_COMM_ID_BYTES]) {
+    if (!p || !id || world < 1 || rank < 0 || rank >= world) return PGO_ERR_INVALID_ARG;
+    int rc;
+    if ((rc = set_device(p)) != PGO_OK) return rc;
+    if ((rc = load_rccl(p->nccl, p->err)) != PGO_OK) return rc;
+    Rccl::Uid u;
+    std::memcpy(u.b, id, PGO_COMM_ID_BYTES);
+    void* comm = nullptr;
+    const int nrc = p->nccl.CommInitRank(&comm, world, u, rank);
+    if (nrc != 0) { p->err = std::string("ncclCommInitRank: ") + (p->nccl.GetErrorString ? p->nccl.GetErrorString(nrc) : "error"); return PGO_ERR_COMM; }
+    p->comm = comm; p->rank = rank; p->world = world;
+    return PGO_OK;
+}
+int pgo_comm_destroy(pgo_problem* p) {
+    if (!p) return PGO_ERR_INVALID_ARG;
+    if (p->comm && p->nccl.CommDestroy) { (void)hipStreamSynchronize(p->st); p->nccl.CommDestroy(p->comm); }
+    p->comm = nullptr; p->rank = 0; p->world = 1;
+    return PGO_OK;
+}
+
+// ---- measurement helpers ----
+int pgo_time_kernel(pgo_problem* p, int32_t which, int32_t launches, double* avg_ms, double* algorithmic_bytes) {
+    if (!p || launches <= 0 || !avg_ms) return PGO_ERR_INVALID_ARG;
+    if (!p->in_solve) { p->err = "pgo_time_kernel needs an open solve (pgo_solve_begin)"; return PGO_ERR_STATE; }
+    int rc;
+    if ((rc = set_device(p)) != PGO_OK) return rc;
+    hipEvent_t e0, e1;
+    HIPCHK(p, hipEventCreate(&e0)); HIPCHK(p, hipEventCreate(&e1));
+    int np = 0;
+    const int nxt = p->cur ^ 1;
+    const GraphDev& G = p->G;
+    double bytes = 0;
+    if (which == 2) {   // a live PCG state to iterate on (tolerance 0: never converges during the timed launches)
+        const pgo_options& o = p->opt;
+        if (!p->reuse_diagonal) launch_lm_diag(p->G, p->L, p->Sc, o.min_lm_diagonal, o.max_lm_diagonal, p->st);
+        bool ok = true;
+        if ((rc = build_system(p, &ok)) != PGO_OK) return rc;
+        launch_cg_init(p->G, p->C, p->st);
+    }
+    const double N = (double)G.N, E = (double)(G.rel.E + G.sw.E), Es = (double)G.sw.E;
+    // one untimed launch first (instruction cache, TLB)
+    for (int rep = 0; rep < 2; ++rep) {
+        const int n = rep == 0 ? 1 : launches;
+        if (rep == 1) HIPCHK(p, hipEventRecord(e0, p->st));
+        for (int i = 0; i < n; ++i) {
+            switch (which) {
+                case 0: launch_k1(G, p->d_pose[p->cur].p, p->d_swv[p->cur].p, true, part(p, 0), &np, p->st); bytes = k1_algorithmic_bytes(G, true); break;
+                case 1: launch_k2(G, p->L, p->st); bytes = (624.0 * G.rel.E + 688.0 * Es) + 288.0 * E + 336.0 * N + 112.0 * Es; break;
+                case 2: launch_cg_spmv(G, p->C, p->st); launch_cg_update(G, p->C, i & 1, p->st); launch_cg_direction(G, p->C, i & 1, 0.0, p->st);
+                        bytes = 288.0 * (N + E) + 104.0 * Es + 288.0 * N + 80.0 * (6.0 * N + Es); break;
+                case 3: launch_k1(G, p->d_pose[nxt].p, p->d_swv[nxt].p, false, part(p, 5), &np, p->st); bytes = k1_algorithmic_bytes(G, false); break;
+                default: (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return PGO_ERR_INVALID_ARG;
+            }
+        }
+        if (rep == 1) HIPCHK(p, hipEventRecord(e1, p->st));
+        HIPCHK(p, hipStreamSynchronize(p->st));
+    }
+    float ms = 0;
+    HIPCHK(p, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *avg_ms = (double)ms / launches;
+    if (algorithmic_bytes) *algorithmic_bytes = bytes;
+    return PGO_OK;
+}
+int pgo_time_linearize_kernel(pgo_problem* p, int32_t launches, double* avg_ms, double* bytes) { return pgo_time_kernel(p, 0, launches, avg_ms, bytes); }
+
+int pgo_device_synchronize(pgo_problem* p) {
+    if (!p) return PGO_ERR_INVALID_ARG;
+    int rc;
+    if ((rc = set_device(p)) != PGO_OK) return rc;
+    HIPCHK(p, hipStreamSynchronize(p->st));
+    return PGO_OK;
+}
+
+const char* pgo_strerror(int code) {
+    switch (code) {
+        case PGO_OK: return "ok";
+        case PGO_ERR_INVALID_ARG: return "invalid argument";
+        case PGO_ERR_NO_DEVICE: return "no usable HIP device (libpgo has no CPU fallback)";
+        case PGO_ERR_HIP: return "HIP runtime error";
+        case PGO_ERR_OUT_OF_MEMORY: return "out of device memory";
+        case PGO_ERR_STATE: return "call order violated";
+        case PGO_ERR_COMM: return "RCCL error";
+        case PGO_ERR_NUMERIC: return "non-finite value";
+        default: return "unknown error";
+    }
+}
+const char* pgo_last_error(const pgo_problem* p) { return p ? p->err.c_str() : ""; }
+
+}  // extern "C"

@@ -1,0 +1,174 @@
+"""GPU parity tests proper: libpgo (HIP, through the C-ABI) against the CPU oracle on the same seeded inputs.
+
+Tolerances (fp64, stated per test): the kernels use closed-form Jacobians while the oracle differentiates with
+Jets, so entries agree to a few ulp of their magnitude, not bitwise.
+"""
+import numpy as np
+import pytest
+
+from solve_keyframe_pose_graph_amd import capi, graphgen
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(g, switchable=True, **opt):
+    return util.oracle_problem(g, switchable), util.pgo_problem(g, switchable, **opt)
+
+
+@pytest.mark.parametrize("name,switchable", [("C1", True), ("C1F5", True), ("C2", False)])
+def test_evaluate_matches_oracle(name, switchable):
+    g = graphgen.config(name)
+    O, P = _both(g, switchable)
+    q, t, s = util.initial_state(g, switchable, perturb=0.01, seed=3)
+    co, ro, go = O.evaluate(q, t, s)
+    cp, rp, gp = P.evaluate(q, t, s)
+    assert abs(cp - co) <= 1e-12 * max(1.0, abs(co))
+    assert np.abs(rp - ro).max() <= 1e-12 * max(1.0, np.abs(ro).max())
+    assert np.abs(gp - go).max() <= 1e-11 * max(1.0, np.abs(go).max())
+
+
+def test_jacobian_blocks_match_oracle():
+    g = util.small_graph(400, 60, f=3, seed=5)
+    O, P = _both(g, True)
+    q, t, s = util.initial_state(g, True, perturb=0.05, seed=4)
+    P.evaluate(q, t, s)
+    for kind in (0, 1, 2):
+        J1o, J2o, dso = O.jacobian_blocks(q, t, s, kind)
+        J1p, J2p, dsp = P.jacobian_blocks(kind)
+        scale = max(1.0, np.abs(J1o).max())
+        assert np.abs(J1p - J1o).max() <= 1e-12 * scale
+        if kind != 2:
+            assert np.abs(J2p - J2o).max() <= 1e-12 * scale
+        if kind == 1:
+            assert np.abs(dsp - dso).max() <= 1e-12 * max(1.0, np.abs(dso).max())
+
+
+def test_normal_matrix_matches_oracle():
+    """K2: assembled J^T J / J^T r against the oracle's dense normal matrix (SURVEY.md §8c golden (4))."""
+    g = util.small_graph(120, 25, f=2, seed=9)
+    O, P = _both(g, True)
+    q, t, s = util.initial_state(g, True, perturb=0.02, seed=1)
+    N, S = g.n_poses, g.n_loops
+    H = O.dense_normal_matrix(q, t, s)
+    _, _, go = O.evaluate(q, t, s)
+    P.evaluate(q, t, s)
+    diag, grad, off, c, hss, gs = P.normal_blocks()
+    tol = 1e-11 * max(1.0, np.abs(H).max())
+    for n in range(N):
+        assert np.abs(diag[n] - H[6 * n:6 * n + 6, 6 * n:6 * n + 6]).max() <= tol
+    assert np.abs(grad.reshape(-1) - go[:6 * N]).max() <= 1e-11 * max(1.0, np.abs(go).max())
+    # off-diagonal blocks: the oracle's dense matrix holds the SUM over parallel edges; compare that sum
+    acc = {}
+    c1 = np.concatenate([g.odom_c1, g.loop_c1]); c2 = np.concatenate([g.odom_c2, g.loop_c2])
+    for e in range(len(c1)):
+        acc.setdefault((c1[e], c2[e]), np.zeros((6, 6)))
+        acc[(c1[e], c2[e])] += off[e]
+    for (a, b), blk in acc.items():
+        ref = H[6 * a:6 * a + 6, 6 * b:6 * b + 6]
+        if (b, a) in acc:
+            blk = blk + acc[(b, a)].T
+        assert np.abs(blk - ref).max() <= tol
+    for e in range(S):
+        a, b = g.loop_c1[e], g.loop_c2[e]
+        assert np.abs(c[e, :6] - H[6 * a:6 * a + 6, 6 * N + e]).max() <= tol
+        assert np.abs(c[e, 6:] - H[6 * b:6 * b + 6, 6 * N + e]).max() <= tol
+        assert abs(hss[e] - H[6 * N + e, 6 * N + e]) <= tol
+        assert abs(gs[e] - go[6 * N + e]) <= 1e-11 * max(1.0, np.abs(go).max())
+
+
+def test_normal_operator_is_schur_complement():
+    """K3: (H_reduced + damping) x from the device BSR against the dense Schur complement built from the oracle's H."""
+    g = util.small_graph(100, 20, f=2, seed=2)
+    O, P = _both(g, True)
+    q, t, s = util.initial_state(g, True, perturb=0.02, seed=6)
+    N, S = g.n_poses, g.n_loops
+    H = O.dense_normal_matrix(q, t, s)
+    P.solve_begin(q, t, s)
+    radius = 1e4
+    scale = 1.0 / (1.0 + np.sqrt(np.diag(H)))
+    D2 = np.clip(scale ** 2 * np.diag(H), 1e-6, 1e32) / radius
+    lam = D2 / scale ** 2
+    Hd = H + np.diag(lam)
+    A = Hd[:6 * N, :6 * N] - Hd[:6 * N, 6 * N:] @ np.linalg.solve(Hd[6 * N:, 6 * N:], Hd[6 * N:, :6 * N])
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=6 * N)
+    y = P.apply_normal_operator(x)
+    P.solve_end()
+    assert np.abs(y - A @ x).max() <= 1e-10 * np.abs(A @ x).max()
+
+
+@pytest.mark.parametrize("name,switchable", [("C1", True), ("C1F5", True), ("C2", False)])
+def test_solve_matches_oracle_at_convergence(name, switchable):
+    """Final chi^2 within 1e-6 relative (BASELINE.json north_star) and per-node pose agreement, both solvers
+    run to convergence (function tolerance) from the same initial guess."""
+    g = graphgen.config(name)
+    O, P = _both(g, switchable, max_num_iterations=100, function_tolerance=1e-10, cg_rel_tolerance=1e-12, cg_max_iterations=20000)
+    q, t, s = util.initial_state(g, switchable)
+    from oracle import binding as ob
+    qo, to, so, sumo = O.solve(q, t, s, ob.default_options(max_num_iterations=100, function_tolerance=1e-10))
+    qp, tp, sp, sump = P.solve(q, t, s)
+    assert sumo.termination_type == 0 and sump.termination_type == capi.CONVERGENCE
+    assert abs(sump.final_cost - sumo.final_cost) <= 1e-6 * sumo.final_cost
+    dt = np.linalg.norm(tp.reshape(-1, 3) - to.reshape(-1, 3), axis=1).max()
+    dr = util.rot_angle(qp.reshape(-1, 4), qo.reshape(-1, 4)).max()
+    # per-node pose tolerance: 1e-3 m / 1e-3 rad on the 200-keyframe graphs; C2 (10k keyframes, f=1 chain + 1k loops) has
+    # nearly flat directions (curvature ~1e-5) along which a 1e-10 cost difference already moves poses by millimetres -> 2e-2 m
+    tol_t = 2e-2 if name == "C2" else 1e-3
+    assert dt <= tol_t and dr <= 1e-3, (dt, dr)
+    if switchable:
+        assert np.abs(sp - so).max() <= 1e-3
+
+
+def test_first_iterations_track_oracle():
+    """With a tight PCG tolerance the device LM reproduces the oracle's (exact Cholesky) iterates: same accept/reject
+    sequence and the same costs for the reference's 10-iteration budget (src/PoseGraphSLAM.cpp:1272)."""
+    g = graphgen.config("C1")
+    O, P = _both(g, True, cg_rel_tolerance=1e-13, cg_max_iterations=20000)
+    q, t, s = util.initial_state(g, True)
+    _, _, _, sumo = O.solve(q, t, s)
+    _, _, _, sump = P.solve(q, t, s)
+    assert sump.num_iterations == sumo.num_iterations
+    for k in range(min(sumo.num_logged, sump.num_logged)):
+        a, b = sumo.iterations[k], sump.iterations[k]
+        assert a.step_is_successful == b.step_is_successful
+        assert abs(a.cost - b.cost) <= 1e-8 * max(a.cost, 1e-12), (k, a.cost, b.cost)
+
+
+def test_constant_nodes_and_unused_switch():
+    g = util.small_graph(150, 20, f=1, seed=4)
+    O, P = _both(g, True, max_num_iterations=50, function_tolerance=1e-10, cg_rel_tolerance=1e-12)
+    O.set_nodes_constant([0, 1, 2, 77]); P.set_nodes_constant([0, 1, 2, 77])
+    q, t, s = util.initial_state(g, True)
+    s = np.concatenate([s, [0.5, 0.25]])   # two switch slots no edge refers to: must pass through untouched
+    from oracle import binding as ob
+    qo, to, so, sumo = O.solve(q, t, s, ob.default_options(max_num_iterations=50, function_tolerance=1e-10))
+    qp, tp, sp, sump = P.solve(q, t, s)
+    assert np.array_equal(qp.reshape(-1, 4)[[0, 1, 2, 77]], q[[0, 1, 2, 77]])
+    assert np.array_equal(tp.reshape(-1, 3)[[0, 1, 2, 77]], t[[0, 1, 2, 77]])
+    assert sp[-2] == 0.5 and sp[-1] == 0.25
+    assert abs(sump.final_cost - sumo.final_cost) <= 1e-6 * sumo.final_cost
+
+
+def test_cost_only_does_not_clobber_linearisation():
+    """A rejected step must leave J/H intact: evaluate, take LM steps, the rejected ones keep the same cost."""
+    g = graphgen.config("C1")
+    P = util.pgo_problem(g, True, initial_trust_region_radius=1e12)
+    q, t, s = util.initial_state(g, True, perturb=0.2, seed=8)
+    P.solve_begin(q, t, s)
+    for _ in range(6):
+        P.lm_step(ignore_termination=True)
+    _, _, _, summ = P.solve_end()
+    costs = [summ.iterations[k].cost for k in range(summ.num_logged)]
+    assert all(costs[k + 1] <= costs[k] * (1 + 1e-12) for k in range(len(costs) - 1))
+
+
+def test_error_paths():
+    P = capi.Problem()
+    with pytest.raises(capi.PgoError):
+        P.add_relpose_edges([0], [0], np.eye(4).reshape(1, 16), [1.0])      # self edge
+    P.add_relpose_edges([1], [0], np.eye(4).reshape(1, 16), [1.0])
+    with pytest.raises(capi.PgoError):
+        P.solve(np.tile([0, 0, 0, 1.0], (1, 1)), np.zeros((1, 3)))          # endpoint out of range for n_nodes = 1
+    with pytest.raises(capi.PgoError):
+        P.lm_step()                                                          # no open solve

@@ -1,0 +1,48 @@
+"""Shared helpers for the parity tests: build the same problem on the oracle (CPU checker) and on libpgo (HIP)."""
+import numpy as np
+
+from oracle import binding as ob
+from solve_keyframe_pose_graph_amd import capi, graphgen
+
+
+def oracle_problem(g, switchable=True):
+    P = ob.OracleProblem()
+    P.add_relpose_edges(g.odom_c1, g.odom_c2, g.odom_T, g.odom_w)
+    if g.n_loops:
+        if switchable:
+            P.add_switchable_edges(g.loop_c1, g.loop_c2, g.loop_T, g.loop_w, np.arange(g.n_loops))
+        else:
+            P.add_relpose_edges(g.loop_c1, g.loop_c2, g.loop_T, g.loop_w)
+    if len(g.reg_node):
+        P.set_node_regularizers(g.reg_node, g.reg_T, g.reg_w)
+    return P
+
+
+def pgo_problem(g, switchable=True, **opt):
+    return capi.problem_from_graph(g, switchable=switchable, **opt)
+
+
+def initial_state(g, switchable=True, perturb=0.0, seed=0):
+    q = g.init_q.copy()
+    t = g.init_t.copy()
+    s = np.full(g.n_loops if switchable else 0, 0.99)   # reference src/PoseGraphSLAM.cpp:353
+    if perturb > 0:
+        rng = np.random.default_rng(seed)
+        q = q + rng.normal(size=q.shape) * perturb
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+        t = t + rng.normal(size=t.shape) * perturb
+        if s.size:
+            s = s + rng.normal(size=s.shape) * perturb
+    return q, t, s
+
+
+def rot_angle(qa, qb):
+    """Rotation angle between unit quaternions (rows), sign-invariant."""
+    d = np.abs(np.sum(qa * qb, axis=1)).clip(0, 1)
+    return 2 * np.arccos(d)
+
+
+def small_graph(n=300, loops=40, f=2, seed=11, **kw):
+    opts = dict(box_scale=1.0, turn_deg_per_keyframe=15.0, straight_min=2, straight_max=6, min_loop_gap=20, odom_sigma_r=0.002, odom_sigma_t=0.01)
+    opts.update(kw)
+    return graphgen.generate(n, loops, odom_f_max=f, seed=seed, **opts)
