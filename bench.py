@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the hot path (BASELINE.json): Levenberg-Marquardt iterations/s of the
+MI355X-native pose-graph solver on the synthetic 100k-pose / 300k-edge switchable-constraint SE(3) graph (C3).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+A "step" is ONE trust-region LM iteration of pgo_lm_step: lm-diagonal, Schur-reduced system build, block-Jacobi PCG
+solve, model-cost change, candidate Plus, candidate cost (K1 cost-only) and — when the step is accepted —
+re-linearisation (K1 + K2).  Inputs are resident in HBM when the timed region starts (pgo_solve_begin is outside it).
+N GPUs: weak scaling — the graph is N x C3 (N*100k poses / N*300k edges), edges sharded contiguously across ranks,
+one RCCL all-reduce per CG matvec inside libpgo; `value` = LM iterations/s x N (C3-sized graph-iterations per second).
+
+Extra JSON objects: `roofline` (K1, HIP events on the library's own stream) and `cpu_baseline` (the CPU oracle = a
+restatement of the reference's Ceres path, timed on the host cores on a bounded sample; rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+C3_POSES, C3_LOOPS, C3_EDGES = 100000, 100003, 300000
+
+
+def cpu_baseline(sample_poses, max_iters, budget_s):
+    """Times the oracle (oracle/pgo_oracle.cpp: Jet autodiff + Ceres-style LM + exact block-sparse Cholesky, 1 thread —
+    the reference never sets num_threads, Ceres default 1) on a C3-structured sample that fits the time budget."""
+    from oracle import binding as ob
+    from solve_keyframe_pose_graph_amd import graphgen
+    from tests import util
+    g = graphgen.generate(sample_poses, sample_poses, odom_f_max=2, seed=3)
+    O = util.oracle_problem(g, True)
+    q, t, s = util.initial_state(g, True)
+    t0 = time.time()
+    # no early stop: the same fixed iteration budget the GPU leg times
+    opt = ob.default_options(max_num_iterations=max_iters, function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0)
+    _, _, _, sm = O.solve(q, t, s, opt)
+    wall = time.time() - t0
+    edges = g.n_odom + g.n_loops
+    iters = max(1, sm.num_iterations)
+    ips_sample = iters / sm.seconds_total
+    return {
+        "value": ips_sample * edges / C3_EDGES,   # LINEAR edge scaling to C3 size: optimistic for the CPU (sparse Cholesky is super-linear)
+        "unit": "LM iters/s (C3-equivalent)",
+        "cores": 1,
+        "kind": "port",
+        "sample": "%d LM iterations of the oracle on a C3-structured %d-pose / %d-edge graph (same generator, seed 3): %.3f LM iters/s on the sample "
+                  "(%.2f s, linear solver %.2f s, Jacobians %.2f s, Cholesky fill %d blocks), scaled linearly by edge count to 300k edges"
+                  % (iters, g.n_poses, edges, ips_sample, wall, sm.seconds_linear_solver, sm.seconds_jacobian, sm.chol_nnz_blocks),
+        "sample_iters_per_s": ips_sample,
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)     # the reference's LM budget per trigger: max_num_iterations = 10
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--cg-tol", type=float, default=None, help="PCG relative tolerance (default: library default)")
+    ap.add_argument("--cg-max", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-poses", type=int, default=20000)
+    ap.add_argument("--cpu-iters", type=int, default=6)
+    ap.add_argument("--poses-per-gpu", type=int, default=C3_POSES)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(0)
+
+    from solve_keyframe_pose_graph_amd import capi, graphgen
+    capi.load()   # raises if libpgo.so is missing: no CPU fallback
+
+    # ---- workload: N x C3, generated identically on every rank (deterministic), edges sharded contiguously
+    scale = args.gpus
+    n_poses = args.poses_per_gpu * scale
+    n_loops = int(round(C3_LOOPS * (args.poses_per_gpu / C3_POSES))) * scale if scale > 1 or args.poses_per_gpu != C3_POSES else C3_LOOPS
+    g = graphgen.generate(n_poses, n_loops, odom_f_max=2, seed=3)
+    n_edges = g.n_odom + g.n_loops
+
+    from solve_keyframe_pose_graph_amd.sharding import edge_slice
+    shard = edge_slice(rank, world)
+
+    opt = {}
+    if args.cg_tol is not None:
+        opt["cg_rel_tolerance"] = args.cg_tol
+    if args.cg_max is not None:
+        opt["cg_max_iterations"] = args.cg_max
+    P = capi.problem_from_graph(g, switchable=True, edge_slice=shard if world > 1 else None, device_id=local_rank, max_num_iterations=10 ** 6, **opt)
+    if world > 1:
+        uid = [capi.Problem.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        P.comm_init(rank, world, uid[0])
+
+    q0, t0_, s0 = g.init_q, g.init_t, np.full(g.n_loops, 0.99)
+
+    def sync():
+        P.synchronize()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    # ---- warmup (untimed): W LM iterations from the initial guess, then reset the state
+    P.solve_begin(q0, t0_, s0)
+    for _ in range(args.warmup):
+        P.lm_step(ignore_termination=True)
+    P.solve_end()
+
+    # ---- timed: exactly K LM iterations from the odometry initial guess, state resident in HBM
+    P.solve_begin(q0, t0_, s0)
+    barrier(); sync()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        P.lm_step(ignore_termination=True)
+    sync(); barrier()
+    elapsed = time.perf_counter() - t_start
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- roofline of the dominant data-parallel kernel (K1), measured live with HIP events on the library stream
+    k1_ms, k1_bytes = P.time_kernel(0, 50)
+    k2_ms, k2_bytes = P.time_kernel(1, 20)
+    cg_ms, cg_bytes = P.time_kernel(2, 50)
+    k1c_ms, k1c_bytes = P.time_kernel(3, 50)
+    qf, tf, sf, summ = P.solve_end()
+
+    traffic = None
+    try:   # HBM bytes per K1 launch from the rocprofv3 PMC passes (profiles/k1_pmc_rNN.json, written by scripts/profile_k1.sh)
+        with open(os.path.join(ROOT, "profiles", "k1_pmc_latest.json")) as f:
+            traffic = json.load(f).get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+
+    out = None
+    if rank == 0:
+        ips = args.steps / elapsed
+        its = [summ.iterations[k] for k in range(summ.num_logged)]
+        out = {
+            "metric": "LM iters/sec + final chi2 vs Ceres, 100k-pose/300k-edge SE(3) graph",
+            "value": ips * scale,
+            "unit": "LM iters/s" if scale == 1 else "LM iters/s x N (C3-sized graph-iterations/s)",
+            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C3 x %d: synthetic 3D Manhattan graph, %d poses / %d edges (%d odometry f=1,2 + %d switchable loop closures, 10%% outliers) + %d regulariser(s)"
+                                   % (scale, g.n_poses, n_edges, g.n_odom, g.n_loops, len(g.reg_node)),
+                       "poses": g.n_poses, "edges": n_edges, "sharding": "edges, contiguous per rank; 1 RCCL all-reduce per CG matvec" if world > 1 else "single GPU",
+                       "linear_solver": "PCG block-Jacobi on the Schur-reduced pose system", "cg_rel_tolerance": P.options.cg_rel_tolerance,
+                       "cg_max_iterations": P.options.cg_max_iterations},
+            "lm_iters_per_s_raw": ips,
+            "chi2_initial": 2.0 * summ.initial_cost, "chi2_final": 2.0 * summ.final_cost,
+            "lm_successful_steps": summ.num_successful_steps, "cg_iterations_total": int(summ.cg_iterations),
+            "cg_iterations_per_step": [it.cg_iterations for it in its[1:]],
+            "roofline": {"bound": "hbm", "kernel": "k1_edges_kernel<true> (residual + Jacobian blocks, all edges, one launch)",
+                         "achieved": k1_bytes / (k1_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": k1_bytes / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": k1_bytes, "avg_launch_ms": k1_ms},
+            "other_kernels": {"k2_assembly": {"ms": k2_ms, "GBps": k2_bytes / k2_ms / 1e6}, "pcg_iteration": {"ms": cg_ms, "GBps": cg_bytes / cg_ms / 1e6},
+                              "k1_cost_only": {"ms": k1c_ms, "GBps": k1c_bytes / k1c_ms / 1e6}},
+        }
+        if scale == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.cpu_sample_poses, args.cpu_iters, 30.0)
+            except Exception as e:   # the baseline is reported, never required for the GPU number
+                out["cpu_baseline"] = {"value": None, "unit": "LM iters/s (C3-equivalent)", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
+        print(json.dumps(out))
+    if world > 1:
+        P.comm_destroy()
+        dist.destroy_process_group()
+    P.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,278 @@
+"""Research probe (CPU, scipy): PCG iteration counts on the Schur-reduced damped LM system of a C3-structured graph with
+  (a) 6x6 block-Jacobi, (b) two-level: block-Jacobi smoother + chain-aggregate coarse space with rigid-body-mode prolongation,
+  (c) multilevel version of (b).  Uses the oracle only to linearise.  Not part of the product or the tests."""
+import sys, time
+sys.path.insert(0, '/root/repo')
+import numpy as np, scipy.sparse as sp, scipy.sparse.linalg as spla
+from solve_keyframe_pose_graph_amd import graphgen
+from tests import util
+
+def build_system(g, q, t, s, radius):
+    O = util.oracle_problem(g, True)
+    N, S = g.n_poses, g.n_loops
+    J1r, J2r, _ = O.jacobian_blocks(q, t, s, 0)
+    J1s, J2s, dss = O.jacobian_blocks(q, t, s, 1)
+    J1p, _, _ = O.jacobian_blocks(q, t, s, 2)
+    cost, res, grad = O.evaluate(q, t, s)
+    rows, cols, blks = [], [], []
+    Hd = np.zeros((N, 6, 6))
+    def add(c1, c2, J1, J2):
+        np.add.at(Hd, c1, np.einsum('eia,eib->eab', J1, J1)); np.add.at(Hd, c2, np.einsum('eia,eib->eab', J2, J2))
+        return np.einsum('eia,eib->eab', J1, J2)
+    Hoff_r = add(g.odom_c1, g.odom_c2, J1r, J2r)
+    Hoff_s = add(g.loop_c1, g.loop_c2, J1s, J2s)
+    np.add.at(Hd, g.reg_node, np.einsum('eia,eib->eab', J1p, J1p))
+    c1v = np.einsum('eia,ei->ea', J1s, dss[:, :6]); c2v = np.einsum('eia,ei->ea', J2s, dss[:, :6])
+    hss = (dss ** 2).sum(1)
+    diag = np.einsum('naa->na', Hd).copy()
+    sc_p = 1 / (1 + np.sqrt(diag)); sc_s = 1 / (1 + np.sqrt(hss))
+    lam_p = np.clip(sc_p ** 2 * diag, 1e-6, 1e32) / (radius * sc_p ** 2)
+    lam_s = np.clip(sc_s ** 2 * hss, 1e-6, 1e32) / (radius * sc_s ** 2)
+    a = hss + lam_s
+    Hoff_s = Hoff_s - np.einsum('ea,eb->eab', c1v, c2v) / a[:, None, None]
+    np.add.at(Hd, g.loop_c1, -np.einsum('ea,eb->eab', c1v, c1v) / a[:, None, None])
+    np.add.at(Hd, g.loop_c2, -np.einsum('ea,eb->eab', c2v, c2v) / a[:, None, None])
+    Hd[np.arange(N)[:, None], np.arange(6), np.arange(6)] += lam_p
+    r_ = np.concatenate([np.arange(N), g.odom_c1, g.odom_c2, g.loop_c1, g.loop_c2])
+    c_ = np.concatenate([np.arange(N), g.odom_c2, g.odom_c1, g.loop_c2, g.loop_c1])
+    b_ = np.concatenate([Hd, Hoff_r, Hoff_r.transpose(0, 2, 1), Hoff_s, Hoff_s.transpose(0, 2, 1)])
+    # COO of blocks -> BSR (duplicates summed)
+    ii = (r_[:, None, None] * 6 + np.arange(6)[None, :, None]) + 0 * np.arange(6)[None, None, :]
+    jj = (c_[:, None, None] * 6 + np.arange(6)[None, None, :]) + 0 * np.arange(6)[None, :, None]
+    A = sp.coo_matrix((b_.ravel(), (ii.ravel(), jj.ravel())), shape=(6 * N, 6 * N)).tocsr()
+    gs = np.einsum('ei,ei->e', dss, res[6 * g.n_odom:6 * g.n_odom + 7 * S].reshape(S, 7))
+    b = -grad[:6 * N].copy()
+    np.add.at(b.reshape(N, 6), g.loop_c1, c1v * (gs / a)[:, None]); np.add.at(b.reshape(N, 6), g.loop_c2, c2v * (gs / a)[:, None])
+    return A, b
+
+def block_diag_inv(A, N):
+    D = np.zeros((N, 6, 6))
+    Ab = A.tobsr(blocksize=(6, 6))
+    for n in range(N):
+        for k in range(Ab.indptr[n], Ab.indptr[n + 1]):
+            if Ab.indices[k] == n: D[n] = Ab.data[k]
+    Di = np.linalg.inv(D)
+    return sp.block_diag(list(Di), format='csr') if N < 30000 else sp.bsr_matrix((Di, np.arange(N), np.arange(N + 1)), shape=(6 * N, 6 * N)).tocsr()
+
+def prolongation(t, agg, rigid=True):
+    """P: fine (dtheta_i, dt_i) <- coarse (dtheta_a, dt_a):  dtheta_i = dtheta_a ; dt_i = dt_a + 2 dtheta_a x (t_i - c_a)"""
+    N = len(agg); na = agg.max() + 1
+    cen = np.zeros((na, 3)); cnt = np.bincount(agg, minlength=na)
+    np.add.at(cen, agg, t); cen /= cnt[:, None]
+    blocks = np.zeros((N, 6, 6)); blocks[:, np.arange(6), np.arange(6)] = 1
+    if rigid:
+        d = t - cen[agg]
+        # dt_i = 2 * (dtheta x d) = -2 [d]x dtheta
+        X = np.zeros((N, 3, 3)); X[:, 0, 1] = -d[:, 2]; X[:, 0, 2] = d[:, 1]; X[:, 1, 0] = d[:, 2]; X[:, 1, 2] = -d[:, 0]; X[:, 2, 0] = -d[:, 1]; X[:, 2, 1] = d[:, 0]
+        blocks[:, 3:, :3] = -2 * X
+    P = sp.bsr_matrix((blocks, agg, np.arange(N + 1)), shape=(6 * N, 6 * na)).tocsr()
+    return P, cen
+
+def pcg(A, b, M, tol, maxit=20000):
+    x = np.zeros_like(b); r = b.copy(); z = M(r); p = z.copy(); rz = r @ z; rz0 = rz; k = 0
+    while k < maxit:
+        q = A @ p; al = rz / (p @ q); x += al * p; r -= al * q; z = M(r); rzn = r @ z; k += 1
+        if rzn <= tol * tol * rz0: break
+        p = z + (rzn / rz) * p; rz = rzn
+    return x, k
+
+class MG:
+    def __init__(self, A, t, m, rigid=True, min_coarse=400, nu=1, omega=1.0):
+        self.levels = []
+        N = A.shape[0] // 6
+        while True:
+            Dinv = block_diag_inv(A, N)
+            if N <= min_coarse:
+                self.levels.append(dict(A=A, lu=spla.splu(A.tocsc())))
+                break
+            agg = np.arange(N) // m
+            P, cen = prolongation(t, agg, rigid)
+            Ac = (P.T @ A @ P).tocsr()
+            self.levels.append(dict(A=A, Dinv=Dinv, P=P))
+            A, t, N = Ac, cen, agg.max() + 1
+        self.nu = nu; self.omega = omega
+        print('   MG levels:', [(l['A'].shape[0] // 6, l['A'].nnz // 36) for l in self.levels])
+    def vcycle(self, lvl, r):
+        L = self.levels[lvl]
+        if 'lu' in L: return L['lu'].solve(r)
+        x = self.omega * (L['Dinv'] @ r)
+        for _ in range(self.nu - 1): x += self.omega * (L['Dinv'] @ (r - L['A'] @ x))
+        rc = L['P'].T @ (r - L['A'] @ x)
+        x += L['P'] @ self.vcycle(lvl + 1, rc)
+        for _ in range(self.nu): x += self.omega * (L['Dinv'] @ (r - L['A'] @ x))
+        return x
+    def __call__(self, r): return self.vcycle(0, r)
+
+if __name__ == '__main__':
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+    g = graphgen.generate(n, n, odom_f_max=2, seed=3)
+    q, t, s = util.initial_state(g, True)
+    for radius in [1e4, 1e6, 1e9]:
+        t0 = time.time(); A, b = build_system(g, q, t, s, radius); print('radius', radius, 'build', time.time() - t0)
+        N = g.n_poses
+        Dinv = block_diag_inv(A, N)
+        x, k = pcg(A, b, lambda r: Dinv @ r, 1e-8); print('  block-Jacobi            its', k)
+        for m in (4, 8, 16):
+            for rigid in (False, True):
+                M = MG(A, t, m, rigid=rigid)
+                x2, k2 = pcg(A, b, M, 1e-8); print('  MG m=%d rigid=%d nu=1       its' % (m, rigid), k2, 'err', np.abs(x2 - x).max() / np.abs(x).max())
+
+
+class MGAdd(MG):
+    """additive multilevel (no residual SpMVs): z = D0^-1 r + P (recursive)(P^T r)"""
+    def vcycle(self, lvl, r):
+        L = self.levels[lvl]
+        if 'lu' in L: return L['lu'].solve(r)
+        return L['Dinv'] @ r + L['P'] @ self.vcycle(lvl + 1, L['P'].T @ r)
+
+
+class MGW(MG):
+    gamma = 2
+    def vcycle(self, lvl, r):
+        L = self.levels[lvl]
+        if 'lu' in L: return L['lu'].solve(r)
+        x = self.omega * (L['Dinv'] @ r)
+        for _ in range(self.gamma if lvl >= 1 else 1):
+            rc = L['P'].T @ (r - L['A'] @ x)
+            x += L['P'] @ self.vcycle(lvl + 1, rc)
+        x += self.omega * (L['Dinv'] @ (r - L['A'] @ x))
+        return x
+
+
+def probe2(n, radii, m_list, min_coarse):
+    g = graphgen.generate(n, n, odom_f_max=2, seed=3)
+    q, t, s = util.initial_state(g, True)
+    for radius in radii:
+        A, b = build_system(g, q, t, s, radius)
+        N = g.n_poses
+        Dinv = block_diag_inv(A, N)
+        t0 = time.time(); x, k = pcg(A, b, lambda r: Dinv @ r, 1e-8, maxit=30000); print('radius %g  block-Jacobi its %d (%.1fs)' % (radius, k, time.time() - t0), flush=True)
+        for m in m_list:
+            for cls in (MG, MGAdd, MGW):
+                M = cls(A, t, m, rigid=True, min_coarse=min_coarse)
+                t0 = time.time(); x2, k2 = pcg(A, b, M, 1e-8, maxit=5000)
+                print('  %s m=%d its %d (%.1fs) err %.1e' % (cls.__name__, m, k2, time.time() - t0, np.abs(x2 - x).max() / np.abs(x).max()), flush=True)
+
+
+class MGList(MG):
+    """V-cycle with a per-level aggregate size list; last level solved exactly."""
+    def __init__(self, A, t, ms, nu=1, omega=1.0, post_only=False):
+        self.levels = []
+        N = A.shape[0] // 6
+        for m in ms:
+            Dinv = block_diag_inv(A, N)
+            agg = np.arange(N) // m
+            P, cen = prolongation(t, agg, True)
+            Ac = (P.T @ A @ P).tocsr()
+            self.levels.append(dict(A=A, Dinv=Dinv, P=P))
+            A, t, N = Ac, cen, agg.max() + 1
+        self.levels.append(dict(A=A, lu=spla.splu(A.tocsc())))
+        self.nu = nu; self.omega = omega
+        print('   levels:', [(l['A'].shape[0] // 6, l['A'].nnz // 36) for l in self.levels], flush=True)
+
+
+def probe3(n, radii, configs):
+    g = graphgen.generate(n, n, odom_f_max=2, seed=3)
+    q, t, s = util.initial_state(g, True)
+    for radius in radii:
+        A, b = build_system(g, q, t, s, radius)
+        xref = None
+        for ms in configs:
+            M = MGList(A, t, ms)
+            t0 = time.time(); x2, k2 = pcg(A, b, M, 1e-8, maxit=5000)
+            if xref is None: xref = x2
+            print('radius %g  ms=%s its %d (%.1fs) diff %.1e' % (radius, ms, k2, time.time() - t0, np.abs(x2 - xref).max() / np.abs(xref).max()), flush=True)
+
+
+class SegTwoLevel:
+    """smoother = exact solve of the diagonal super-blocks of `mseg` consecutive keyframes (non-overlapping additive Schwarz
+    along the odometry chain); coarse space = rigid-body modes of aggregates of `magg` consecutive keyframes, solved exactly."""
+    def __init__(self, A, t, mseg, magg, sym=True):
+        N = A.shape[0] // 6
+        seg = (np.arange(6 * N) // 6) // mseg
+        Ac = A.tocoo()
+        keep = seg[Ac.row] == seg[Ac.col]
+        B = sp.coo_matrix((Ac.data[keep], (Ac.row[keep], Ac.col[keep])), shape=A.shape).tocsc()
+        self.S = spla.splu(B)
+        self.A = A
+        if magg:
+            self.P, _ = prolongation(t, np.arange(N) // magg, True)
+            self.C = spla.splu((self.P.T @ A @ self.P).tocsc())
+        else:
+            self.P = None
+        self.sym = sym
+    def __call__(self, r):
+        x = self.S.solve(r)
+        if self.P is not None:
+            x = x + self.P @ self.C.solve(self.P.T @ (r - self.A @ x))
+            if self.sym:
+                x = x + self.S.solve(r - self.A @ x)
+        return x
+
+
+def probe4(n, radii, configs):
+    g = graphgen.generate(n, n, odom_f_max=2, seed=3)
+    q, t, s = util.initial_state(g, True)
+    for radius in radii:
+        A, b = build_system(g, q, t, s, radius)
+        xref = None
+        for (mseg, magg) in configs:
+            M = SegTwoLevel(A, t, mseg, magg)
+            t0 = time.time(); x2, k2 = pcg(A, b, M, 1e-8, maxit=5000)
+            if xref is None: xref = x2
+            print('radius %g  seg=%d agg=%s its %d (%.1fs) diff %.1e' % (radius, mseg, magg, k2, time.time() - t0, np.abs(x2 - xref).max() / np.abs(xref).max()), flush=True)
+
+
+class MGK(MGList):
+    """K-cycle (Notay): the coarse problem of every level is solved by `kit` steps of flexible CG preconditioned by the next level."""
+    kit = 2
+    def vcycle(self, lvl, r):
+        L = self.levels[lvl]
+        if 'lu' in L: return L['lu'].solve(r)
+        x = self.omega * (L['Dinv'] @ r)
+        rc = L['P'].T @ (r - L['A'] @ x)
+        x += L['P'] @ self.coarse_solve(lvl + 1, rc)
+        x += self.omega * (L['Dinv'] @ (r - L['A'] @ x))
+        return x
+    def coarse_solve(self, lvl, b):
+        L = self.levels[lvl]
+        if 'lu' in L: return L['lu'].solve(b)
+        A = L['A']
+        # flexible CG, kit iterations, preconditioner = vcycle(lvl)
+        x = np.zeros_like(b); r = b.copy(); ps = []; qs = []
+        for it in range(self.kit):
+            z = self.vcycle(lvl, r)
+            p = z.copy()
+            for (pp_, qq_) in zip(ps, qs): p -= (z @ qq_) / (pp_ @ qq_) * pp_
+            q = A @ p
+            al = (p @ r) / (p @ q)
+            x += al * p; r -= al * q
+            ps.append(p); qs.append(q)
+        return x
+
+
+def fpcg(A, b, M, tol, maxit=5000, trunc=1):
+    """flexible PCG (needed when M is a K-cycle = nonlinear)"""
+    x = np.zeros_like(b); r = b.copy(); k = 0; ps = []; qs = []; rz0 = None
+    while k < maxit:
+        z = M(r); rz = r @ z
+        if rz0 is None: rz0 = rz
+        if rz <= tol * tol * rz0: break
+        p = z.copy()
+        for (pp_, qq_) in zip(ps[-trunc:], qs[-trunc:]): p -= (z @ qq_) / (pp_ @ qq_) * pp_
+        q = A @ p; al = (p @ r) / (p @ q); x += al * p; r -= al * q; ps.append(p); qs.append(q); k += 1
+        ps = ps[-trunc:]; qs = qs[-trunc:]
+    return x, k
+
+
+def probe5(n, radii, configs):
+    g = graphgen.generate(n, n, odom_f_max=2, seed=3)
+    q, t, s = util.initial_state(g, True)
+    for radius in radii:
+        A, b = build_system(g, q, t, s, radius)
+        xref = None
+        for ms in configs:
+            M = MGK(A, t, ms)
+            t0 = time.time(); x2, k2 = fpcg(A, b, M, 1e-8)
+            if xref is None: xref = x2
+            print('radius %g  K-cycle ms=%s its %d (%.1fs) diff %.1e' % (radius, ms, k2, time.time() - t0, np.abs(x2 - xref).max() / np.abs(xref).max()), flush=True)

@@ -5,4 +5,4 @@ PoseGraphSLAM::reinit_ceres_problem_onnewloopedge_optimize6DOF, reference src/Po
 with the cost functors of src/CeresResidues.h).  The product is the C-ABI library libpgo.so
 (include/pgo.h, hand-written HIP for gfx950); this package is the thin host side above it.
 """
-__all__ = ["capi", "graphgen"]
+__all__ = ["capi", "graphgen", "sharding"]

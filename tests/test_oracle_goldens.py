@@ -1,0 +1,93 @@
+"""CPU: the oracle (Jet autodiff restatement of the reference functors) against the committed golden vectors
+(tests/golden/functor_goldens.json, 50-digit mpmath + finite differences; generator committed beside it) and against
+known answers readable from the reference code."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import binding as ob
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def golden():
+    with open(os.path.join(HERE, "golden", "functor_goldens.json")) as f:
+        return json.load(f)
+
+
+def test_functor_values_and_jacobians(golden):
+    n = {"relpose": 0, "switch": 0, "prior": 0}
+    for c in golden["cases"]:
+        k = c["kind"]
+        n[k] += 1
+        if k == "relpose":
+            r, Ja, J1, J2 = ob.eval_relpose(c["q1"], c["t1"], c["q2"], c["t2"], c["T"], c["w"])
+            got = [r, J1, J2]; want = [c["r"], c["J1"], c["J2"]]
+        elif k == "switch":
+            r, Ja, J1, J2, Js = ob.eval_switch(c["q1"], c["t1"], c["q2"], c["t2"], c["s"], c["T"], c["w"])
+            got = [r, J1, J2, Js]; want = [c["r"], c["J1"], c["J2"], c["Js"]]
+        else:
+            r, Ja, J1 = ob.eval_prior(c["q1"], c["t1"], c["T"], c["w"])
+            got = [r, J1]; want = [c["r"], c["J1"]]
+        for a, b in zip(got, want):
+            b = np.array(b)
+            assert np.abs(a - b).max() <= 2e-13 * max(1.0, np.abs(b).max())
+    assert n["relpose"] >= 100 and n["switch"] >= 80 and n["prior"] >= 40
+
+
+def test_plus_and_its_jacobian(golden):
+    for p in golden["plus"]:
+        assert np.abs(ob.quat_plus(p["q"], p["delta"]) - p["q_plus"]).max() <= 1e-15
+        assert np.abs(ob.quat_plus_jacobian(p["q"]) - np.array(p["jac0"])).max() <= 1e-15
+
+
+def test_eigen_matrix_to_quaternion_branches(golden):
+    for m in golden["mat_to_quat"]:
+        assert np.abs(ob.mat_to_quat(m["T"]) - m["q"]).max() <= 1e-15, m["name"]
+
+
+def test_switch_prior_value_at_initial_switch():
+    # r7 = s (1 - s) = 0.0099 at s = 0.99 (reference src/CeresResidues.h:189,197-198; init 0.99 at PoseGraphSLAM.cpp:353)
+    I = np.eye(4).flatten(order="F")
+    r, _, _, _, _ = ob.eval_switch([0, 0, 0, 1], [0, 0, 0], [0, 0, 0, 1], [0, 0, 0], 0.99, I, 1.0)
+    assert abs(r[6] - 0.0099) < 1e-15 and np.abs(r[:6]).max() == 0.0
+
+
+def test_switch_functor_ignores_edge_weight():
+    # reference src/CeresResidues.h:198 `residuals *= s; //* T(weight)`
+    rng = np.random.default_rng(0)
+    q1, q2 = rng.normal(size=4), rng.normal(size=4)
+    q1 /= np.linalg.norm(q1); q2 /= np.linalg.norm(q2)
+    T = np.eye(4); T[:3, 3] = [0.3, -0.2, 0.1]
+    a = ob.eval_switch(q1, [1, 2, 3], q2, [0, 1, 0], 0.7, T.flatten(order="F"), 1.0)[0]
+    b = ob.eval_switch(q1, [1, 2, 3], q2, [0, 1, 0], 0.7, T.flatten(order="F"), 0.123)[0]
+    assert np.array_equal(a, b)
+
+
+def test_gauge_invariance_of_edge_residuals():
+    # left-multiplying both poses by one SE(3) leaves the relative-pose residual unchanged
+    from tests.golden.make_functor_goldens import quat_to_R_np, rand_unit_quat
+    rng = np.random.default_rng(1)
+    q1, q2, qg, qo = (rand_unit_quat(rng) for _ in range(4))
+    t1, t2, tg, to = (rng.normal(size=3) for _ in range(4))
+    T = np.eye(4); T[:3, :3] = quat_to_R_np(qo); T[:3, 3] = to
+
+    def qmul(a, b):
+        ax, ay, az, aw = a; bx, by, bz, bw = b
+        return np.array([aw * bx + ax * bw + ay * bz - az * by, aw * by + ay * bw + az * bx - ax * bz, aw * bz + az * bw + ax * by - ay * bx, aw * bw - ax * bx - ay * by - az * bz])
+    Rg = quat_to_R_np(qg)
+    r0 = ob.eval_relpose(q1, t1, q2, t2, T.flatten(order="F"), 0.9)[0]
+    r1 = ob.eval_relpose(qmul(qg, q1), Rg @ t1 + tg, qmul(qg, q2), Rg @ t2 + tg, T.flatten(order="F"), 0.9)[0]
+    assert np.abs(r0 - r1).max() <= 1e-13
+
+
+def test_reference_weight_tables():
+    # odometry weight 0.9^f * exp(-yaw_deg^2 / 6)  (reference src/PoseGraphSLAM.cpp:1604-1606)
+    for yaw, want in [(0, 0.9), (1, 0.762), (2, 0.462), (5, 0.0140), (10, 5.2e-8), (90, 0.0)]:
+        w = 0.9 * np.exp(-yaw * yaw / 6.0)
+        assert abs(w - want) <= 0.006 * max(want, 1e-9) + 1e-12
+    # regulariser weight max(1.1, ln(1 + end - start) / 2) (:1839): 5.4099 for a 50k-node world
+    assert abs(max(1.1, np.log(1 + 49999) / 2) - 5.4099) < 1e-4
