@@ -85,7 +85,7 @@ typedef struct pgo_options {
     /* PCG controls (no Ceres counterpart: Ceres factorises exactly) */
     int32_t cg_max_iterations;           /* 4000 */
     int32_t cg_check_every;              /* 25: host polls the device convergence flag every this many iterations */
-    double cg_rel_tolerance;             /* 1e-10: stop when ||r||_{M^-1} <= tol * ||b||_{M^-1} */
+    double cg_rel_tolerance;             /* 1e-9: stop when ||r||_{M^-1} <= tol * ||b||_{M^-1} */
     /* device selection */
     int32_t device_id;                   /* -1: use the current HIP device */
     int32_t verbosity;                   /* 0 silent (minimizer_progress_to_stdout=false, :1271), 1 per-iteration line on stderr */

@@ -78,7 +78,7 @@ struct ScaleDev {
 
 struct CgDev {
     double* val; double* Minv; double* Dtot; double* b;
-    double* x; double* r; double* r2; double* z; double* p; double* q;
+    double* x; double* r; double* r2; double* z; double* p; double* p2; double* q;   // r/r2 and p/p2 ping-pong by iteration parity
     double* part_pq;      // [MAX_PARTIALS]
     double* part_rz;      // [2][MAX_PARTIALS]
     double* scal;         // [0]=rz0 [1]=rz_last [2]=pq_last
@@ -94,10 +94,9 @@ void launch_lm_diag(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, doub
 void launch_build_rows(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, double radius, int add_lambda, hipStream_t st);
 void launch_invert_rows(const GraphDev& G, const CgDev& C, int32_t* fail_flag, hipStream_t st);
 void launch_cg_init(const GraphDev& G, const CgDev& C, hipStream_t st);
-void launch_cg_spmv(const GraphDev& G, const CgDev& C, hipStream_t st);
-void launch_cg_pq(const GraphDev& G, const CgDev& C, hipStream_t st);   // multi-GPU: recompute p.q after the all-reduce of q
-void launch_cg_update(const GraphDev& G, const CgDev& C, int parity, hipStream_t st);
-void launch_cg_direction(const GraphDev& G, const CgDev& C, int parity, double tol2, hipStream_t st);
+void launch_cg_spmv(const GraphDev& G, const CgDev& C, int k, double tol2, hipStream_t st);   // iteration k: direction + matvec (+ convergence test)
+void launch_cg_pq(const GraphDev& G, const CgDev& C, int k, hipStream_t st);   // multi-GPU: recompute p.q after the all-reduce of q
+void launch_cg_update(const GraphDev& G, const CgDev& C, int k, hipStream_t st);
 void launch_apply_operator(const GraphDev& G, const CgDev& C, const double* x, double* y, hipStream_t st);
 void launch_model_change(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const double* delta_p, double* delta_s, double* partials, int* n_partials, hipStream_t st);
 void launch_plus(const GraphDev& G, const double* pose8, const double* sw, const double* delta_p, const double* delta_s,

@@ -49,6 +49,10 @@ __device__ __forceinline__ double block_total(const double* __restrict__ partial
     return s;
 }
 
+// 6x6 blocks of the BSR matrix and of the preconditioner are stored PAIR-MAJOR: element (r, c) lives at (c/2)*12 + r*2 + (c&1),
+// so the 6 lanes (rows) of one keyframe read consecutive 16-B words: every SpMV load is a contiguous 96-B run per keyframe.
+__device__ __forceinline__ int pm(int r, int c) { return (c >> 1) * 12 + r * 2 + (c & 1); }
+
 __device__ __forceinline__ size_t tile_elem(int doubles_per_edge, int64_t e, int k) {
     return (size_t)(e >> 6) * (size_t)(doubles_per_edge * TILE) + (size_t)(k >> 1) * (2 * TILE) + (size_t)(e & 63) * 2 + (k & 1);
 }
@@ -422,7 +426,9 @@ __global__ __launch_bounds__(256) void build_rows_kernel(GraphDev G, LinDev L, S
             for (int i = 0; i < 36; ++i) B[i] = 0.0;
         }
 #pragma unroll
-        for (int i = 0; i < 36; ++i) out[i] = B[i];
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) out[pm(c, a)] = B[a * 6 + c];   // BSR blocks: COLUMN-pair-major (lane = column)
     }
     if (add_lambda) {
 #pragma unroll
@@ -435,7 +441,9 @@ __global__ __launch_bounds__(256) void build_rows_kernel(GraphDev G, LinDev L, S
         for (int c = 0; c < 6; ++c) { D[c * 6 + c] = add_lambda ? 1.0 : 0.0; bv[c] = 0.0; }
     }
 #pragma unroll
-    for (int i = 0; i < 36; ++i) { C.val[(size_t)row0 * 36 + i] = D[i]; C.Dtot[(size_t)n * 36 + i] = D[i]; }
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) { C.val[(size_t)row0 * 36 + pm(c, a)] = D[a * 6 + c]; C.Dtot[(size_t)n * 36 + a * 6 + c] = D[a * 6 + c]; }
 #pragma unroll
     for (int i = 0; i < 6; ++i) C.b[(size_t)n * 6 + i] = bv[i];
 }
@@ -504,7 +512,9 @@ __global__ __launch_bounds__(256) void invert_rows_kernel(GraphDev G, CgDev C, i
     const bool ok = spd6_inverse(D, Di);
     if (!ok) atomicOr(fail, 1);
 #pragma unroll
-    for (int i = 0; i < 36; ++i) C.Minv[(size_t)n * 36 + i] = Di[i];
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) C.Minv[(size_t)n * 36 + pm(a, c)] = Di[a * 6 + c];
 }
 
 void launch_build_rows(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, double radius, int add_lambda, hipStream_t st) {
@@ -517,15 +527,18 @@ void launch_invert_rows(const GraphDev& G, const CgDev& C, int32_t* fail_flag, h
 
 // ------------------------------------------------------------------------------------------------
 // K3/K4 — preconditioned conjugate gradients on the block-CSR system, block-Jacobi preconditioner.
-// One thread per (keyframe, row): 192-thread workgroups = 32 keyframes x 6 rows; each lane streams its 48-B row
-// of every block of its block-row (contiguous 288 B per block across the 6 lanes of a keyframe).
-// Dot products: per-workgroup partials (grid capped at MAX_PARTIALS), re-reduced in a fixed order by every
-// workgroup of the consuming kernel -> no atomics, bitwise reproducible.
+// TWO kernels per iteration:
+//   cg_spmv_kernel   beta = rz_k / rz_{k-1};  p_k = z + beta p_{k-1} (own row written to the ping-pong buffer, neighbours'
+//                    rows recomputed on the fly from z and p_{k-1});  q = A p_k;  partial p.q
+//   cg_update_kernel alpha = rz_k / p.q;  x += alpha p_k;  r' = r - alpha q;  z = Minv r';  partial r'.z
+// One thread per (keyframe, row): 192-thread workgroups = 32 keyframes x 6 rows; blocks are pair-major so each load
+// instruction reads a contiguous 96-B run per keyframe.  Dot products: per-workgroup partials (grid capped at MAX_PARTIALS),
+// re-reduced in a fixed order by every workgroup of the consuming kernel -> no atomics, bitwise reproducible.
 // ------------------------------------------------------------------------------------------------
-constexpr int CG_BLOCK = 192;
+constexpr int CG_BLOCK = 192;   // 32 keyframes x 6 lanes = 3 wavefronts
 
-// workgroup-uniform read of the convergence flag (it may be raised by workgroup 0 of cg_direction while other
-// workgroups of the same launch are starting: one lane reads, LDS broadcasts, nobody diverges around a barrier)
+// workgroup-uniform read of the convergence flag (it may be raised by workgroup 0 of cg_spmv while other workgroups of the
+// same launch are starting: one lane reads, LDS broadcasts, nobody diverges around a barrier)
 __device__ __forceinline__ bool cg_done(const CgDev& C) {
     __shared__ int s_done;
     if (threadIdx.x == 0) s_done = C.flags[0];
@@ -533,67 +546,150 @@ __device__ __forceinline__ bool cg_done(const CgDev& C) {
     return s_done != 0;
 }
 
-__device__ __forceinline__ double bsr_row_dot(const GraphDev& G, const double* __restrict__ val, const double* __restrict__ p, int64_t n, int r) {
-    double acc = 0.0;
-    const int64_t b = G.bsr_rowptr[n], e = G.bsr_rowptr[n + 1];
-    for (int64_t k = b; k < e; ++k) {
-        const int32_t col = G.bsr_col[k];
-        const double2* v = reinterpret_cast<const double2*>(val + (size_t)k * 36 + r * 6);
-        const double2* pc = reinterpret_cast<const double2*>(p + (size_t)col * 6);
-        const double2 v0 = v[0], v1 = v[1], v2 = v[2], p0 = pc[0], p1 = pc[1], p2 = pc[2];
-        acc += v0.x * p0.x + v0.y * p0.y + v1.x * p1.x + v1.y * p1.y + v2.x * p2.x + v2.y * p2.y;
+// One lane per (keyframe, COLUMN c): it streams column c of every block of the block-row (3 x 16 B, contiguous 96-B runs across the
+// 6 lanes of a keyframe), needs ONE entry of the input vector per block (8-B gather instead of 48 B), and accumulates a private
+// 6-vector of row partials.  The 6 lanes of a keyframe reduce once per row through LDS.  U blocks per step with every load issued
+// before the first use (col -> gather is a dependent chain; the block columns do not depend on col at all).
+template <int U, bool FUSED>
+__device__ __forceinline__ void spmv_chunk(const int32_t* __restrict__ colp, const double* __restrict__ valp, int c, const double* __restrict__ z,
+                                           const double* __restrict__ pprev, double beta, double* acc) {
+    int32_t col[U];
+    double2 v[U][3];
+    double zz[U], pp[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) col[u] = colp[u];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const double2* vp = reinterpret_cast<const double2*>(valp + (size_t)u * 36) + c;
+        v[u][0] = vp[0]; v[u][1] = vp[6]; v[u][2] = vp[12];
     }
-    return acc;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        zz[u] = z[(size_t)col[u] * 6 + c];
+        pp[u] = FUSED ? pprev[(size_t)col[u] * 6 + c] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const double x = FUSED ? zz[u] + beta * pp[u] : zz[u];
+        acc[0] += v[u][0].x * x; acc[1] += v[u][0].y * x; acc[2] += v[u][1].x * x; acc[3] += v[u][1].y * x; acc[4] += v[u][2].x * x; acc[5] += v[u][2].y * x;
+    }
 }
 
-__global__ __launch_bounds__(CG_BLOCK) void cg_spmv_kernel(GraphDev G, CgDev C) {
+template <bool FUSED>
+__device__ __forceinline__ void bsr_row_accumulate(const GraphDev& G, const double* __restrict__ val, const double* __restrict__ z,
+                                                   const double* __restrict__ pprev, double beta, int64_t n, int c, double* acc) {
+    const int64_t b = G.bsr_rowptr[n], e = G.bsr_rowptr[n + 1];
+    int64_t k = b;
+    for (; k + 4 <= e; k += 4) spmv_chunk<4, FUSED>(G.bsr_col + k, val + (size_t)k * 36, c, z, pprev, beta, acc);
+    if (k + 2 <= e) { spmv_chunk<2, FUSED>(G.bsr_col + k, val + (size_t)k * 36, c, z, pprev, beta, acc); k += 2; }
+    if (k < e) spmv_chunk<1, FUSED>(G.bsr_col + k, val + (size_t)k * 36, c, z, pprev, beta, acc);
+}
+
+// q = A (z + beta p_prev), p_cur = z + beta p_prev
+__global__ __launch_bounds__(CG_BLOCK) void cg_spmv_kernel(GraphDev G, CgDev C, int parity, int first, int nparts, double tol2) {
     __shared__ double red[CG_BLOCK / 64];
+    __shared__ double xch[CG_BLOCK * 7];   // [keyframe-in-group][c][r], padded to 7 to spread LDS banks
     if (cg_done(C)) return;
+    double beta = 0.0;
+    if (!first) {
+        const double rz_new = block_total(C.part_rz + parity * MAX_PARTIALS, nparts, red);
+        const double rz_old = block_total(C.part_rz + (parity ^ 1) * MAX_PARTIALS, nparts, red);
+        const bool breakdown = C.flags[1] != 0;
+        // convergence on the preconditioned residual norm: every workgroup evaluates the same numbers -> uniform exit
+        if (breakdown || !(rz_new > tol2 * C.scal[0])) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) { C.flags[0] = 1; if (!breakdown) C.scal[1] = rz_new; }
+            return;
+        }
+        beta = rz_new / rz_old;
+        if (blockIdx.x == 0 && threadIdx.x == 0) C.scal[1] = rz_new;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) C.flags[2] += 1;
+    const double* __restrict__ pprev = parity ? C.p : C.p2;
+    double* __restrict__ pcur = parity ? C.p2 : C.p;
+    const double* __restrict__ z = C.z;
     const int64_t rows = G.N * 6;
+    const int64_t stride = (int64_t)gridDim.x * CG_BLOCK;
     double pq = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * CG_BLOCK + threadIdx.x; i < rows; i += (int64_t)gridDim.x * CG_BLOCK) {
-        const int64_t n = i / 6; const int r = (int)(i - n * 6);
-        const double acc = bsr_row_dot(G, C.val, C.p, n, r);
-        C.q[i] = acc;
-        pq += acc * C.p[i];
+    // all threads of the workgroup run the same number of trips (barriers inside)
+    const int64_t trips = (rows + stride - 1) / stride;
+    for (int64_t it = 0; it < trips; ++it) {
+        const int64_t i = it * stride + (int64_t)blockIdx.x * CG_BLOCK + threadIdx.x;
+        const bool live = i < rows;
+        const int64_t n = live ? i / 6 : 0; const int c = live ? (int)(i - n * 6) : 0;
+        double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (live) bsr_row_accumulate<true>(G, C.val, z, pprev, beta, n, c, acc);
+        __syncthreads();
+        double* mine = xch + (size_t)threadIdx.x * 7;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) mine[r] = acc[r];
+        __syncthreads();
+        if (live) {
+            // lane (n, c) now plays row r = c: sum the c-th partial of the keyframe's 6 lanes
+            const double* grp = xch + (size_t)(threadIdx.x - c) * 7;
+            double q = 0.0;
+#pragma unroll
+            for (int cc = 0; cc < 6; ++cc) q += grp[cc * 7 + c];
+            const double pi = z[i] + beta * pprev[i];
+            pcur[i] = pi;
+            C.q[i] = q;
+            pq += q * pi;
+        }
     }
     const double s = block_sum(pq, red);
     if (threadIdx.x == 0) C.part_pq[blockIdx.x] = s;
 }
 
 // multi-GPU: after the RCCL all-reduce of q, recompute the p.q partials
-__global__ __launch_bounds__(CG_BLOCK) void cg_pq_kernel(GraphDev G, CgDev C) {
+__global__ __launch_bounds__(CG_BLOCK) void cg_pq_kernel(GraphDev G, CgDev C, int parity) {
     __shared__ double red[CG_BLOCK / 64];
     if (cg_done(C)) return;
+    const double* __restrict__ pcur = parity ? C.p2 : C.p;
     const int64_t rows = G.N * 6;
     double pq = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * CG_BLOCK + threadIdx.x; i < rows; i += (int64_t)gridDim.x * CG_BLOCK) pq += C.q[i] * C.p[i];
+    for (int64_t i = (int64_t)blockIdx.x * CG_BLOCK + threadIdx.x; i < rows; i += (int64_t)gridDim.x * CG_BLOCK) pq += C.q[i] * pcur[i];
     const double s = block_sum(pq, red);
     if (threadIdx.x == 0) C.part_pq[blockIdx.x] = s;
 }
 
 __global__ __launch_bounds__(CG_BLOCK) void apply_operator_kernel(GraphDev G, CgDev C, const double* __restrict__ x, double* __restrict__ y) {
+    __shared__ double xch[CG_BLOCK * 7];
     const int64_t rows = G.N * 6;
-    for (int64_t i = (int64_t)blockIdx.x * CG_BLOCK + threadIdx.x; i < rows; i += (int64_t)gridDim.x * CG_BLOCK) {
-        const int64_t n = i / 6; const int r = (int)(i - n * 6);
-        y[i] = bsr_row_dot(G, C.val, x, n, r);
+    const int64_t stride = (int64_t)gridDim.x * CG_BLOCK;
+    const int64_t trips = (rows + stride - 1) / stride;
+    for (int64_t it = 0; it < trips; ++it) {
+        const int64_t i = it * stride + (int64_t)blockIdx.x * CG_BLOCK + threadIdx.x;
+        const bool live = i < rows;
+        const int64_t n = live ? i / 6 : 0; const int c = live ? (int)(i - n * 6) : 0;
+        double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (live) bsr_row_accumulate<false>(G, C.val, x, nullptr, 0.0, n, c, acc);
+        __syncthreads();
+        double* mine = xch + (size_t)threadIdx.x * 7;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) mine[r] = acc[r];
+        __syncthreads();
+        if (live) {
+            const double* grp = xch + (size_t)(threadIdx.x - c) * 7;
+            double q = 0.0;
+#pragma unroll
+            for (int cc = 0; cc < 6; ++cc) q += grp[cc * 7 + c];
+            y[i] = q;
+        }
     }
 }
 
-// x = 0, r = b, z = Minv b, p = z, partial r.z -> part_rz[0]; flags cleared by the host memset before
+// x = 0, r = b, z = Minv b, partial r.z -> part_rz[0]
 __global__ __launch_bounds__(CG_BLOCK) void cg_init_kernel(GraphDev G, CgDev C) {
     __shared__ double red[CG_BLOCK / 64];
     const int64_t rows = G.N * 6;
     double rz = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * CG_BLOCK + threadIdx.x; i < rows; i += (int64_t)gridDim.x * CG_BLOCK) {
         const int64_t n = i / 6; const int r = (int)(i - n * 6);
-        const double* bn = C.b + (size_t)n * 6;
-        const double* M = C.Minv + (size_t)n * 36 + r * 6;
-        double z = 0.0;
-#pragma unroll
-        for (int c = 0; c < 6; ++c) z += M[c] * bn[c];
-        const double bi = bn[r];
-        C.x[i] = 0.0; C.r[i] = bi; C.z[i] = z; C.p[i] = z;
+        const double2* bn = reinterpret_cast<const double2*>(C.b + (size_t)n * 6);
+        const double2* M = reinterpret_cast<const double2*>(C.Minv + (size_t)n * 36) + r;
+        const double2 m0 = M[0], m1 = M[6], m2 = M[12], b0 = bn[0], b1 = bn[1], b2 = bn[2];
+        const double z = m0.x * b0.x + m0.y * b0.y + m1.x * b1.x + m1.y * b1.y + m2.x * b2.x + m2.y * b2.y;
+        const double bi = C.b[i];
+        C.x[i] = 0.0; C.r[i] = bi; C.z[i] = z; C.p[i] = 0.0; C.p2[i] = 0.0;   // p buffers zeroed: iteration 0 multiplies them by beta = 0
         rz += bi * z;
     }
     const double s = block_sum(rz, red);
@@ -605,37 +701,34 @@ __global__ void cg_scalars_init_kernel(CgDev C, int nparts) {
     if (threadIdx.x == 0) { C.scal[0] = rz0; C.scal[1] = rz0; C.scal[2] = 0.0; C.flags[0] = (rz0 > 0.0) ? 0 : 1; C.flags[1] = 0; C.flags[2] = 0; }
 }
 
-// alpha = rz/pq ; x += alpha p ; r2 = r - alpha q ; z = Minv r2 ; partial r2.z -> part_rz[parity^1]
+// alpha = rz/pq ; x += alpha p ; r' = r - alpha q ; z = Minv r' ; partial r'.z -> part_rz[parity^1]
 __global__ __launch_bounds__(CG_BLOCK) void cg_update_kernel(GraphDev G, CgDev C, int parity, int nparts) {
     __shared__ double red[CG_BLOCK / 64];
     if (cg_done(C)) return;
     const double pq = block_total(C.part_pq, nparts, red);
     const double rz = block_total(C.part_rz + parity * MAX_PARTIALS, nparts, red);
-    if (!(pq > 0.0)) {   // breakdown: matrix not positive definite along p (or NaN)
-        if (blockIdx.x == 0 && threadIdx.x == 0) { C.flags[1] = 1; }
-        // leave x untouched; cg_direction raises done
-        double* out = C.part_rz + (parity ^ 1) * MAX_PARTIALS;
-        if (threadIdx.x == 0) out[blockIdx.x] = 0.0;
+    if (!(pq > 0.0)) {   // breakdown: matrix not positive definite along p (or NaN); x is left untouched, the next spmv raises done
+        if (blockIdx.x == 0 && threadIdx.x == 0) C.flags[1] = 1;
+        if (threadIdx.x == 0) C.part_rz[(parity ^ 1) * MAX_PARTIALS + blockIdx.x] = 0.0;
         return;
     }
     const double alpha = rz / pq;
     const int64_t rows = G.N * 6;
-    const double* rin = parity ? C.r2 : C.r;
-    double* rout = parity ? C.r : C.r2;
+    const double* __restrict__ rin = parity ? C.r2 : C.r;
+    double* __restrict__ rout = parity ? C.r : C.r2;
+    const double* __restrict__ pcur = parity ? C.p2 : C.p;
     double acc = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * CG_BLOCK + threadIdx.x; i < rows; i += (int64_t)gridDim.x * CG_BLOCK) {
         const int64_t n = i / 6; const int r = (int)(i - n * 6);
-        const double* rn = rin + (size_t)n * 6;
-        const double* qn = C.q + (size_t)n * 6;
-        const double* M = C.Minv + (size_t)n * 36 + r * 6;
-        double z = 0.0, rr = 0.0;
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            const double rc = rn[c] - alpha * qn[c];
-            z += M[c] * rc;
-            if (c == r) rr = rc;
-        }
-        C.x[i] += alpha * C.p[i];
+        const double2* rn = reinterpret_cast<const double2*>(rin + (size_t)n * 6);
+        const double2* qn = reinterpret_cast<const double2*>(C.q + (size_t)n * 6);
+        const double2* M = reinterpret_cast<const double2*>(C.Minv + (size_t)n * 36) + r;
+        const double2 m0 = M[0], m1 = M[6], m2 = M[12];
+        const double2 r0 = rn[0], r1 = rn[1], r2 = rn[2], q0 = qn[0], q1 = qn[1], q2 = qn[2];
+        const double a0 = r0.x - alpha * q0.x, a1 = r0.y - alpha * q0.y, a2 = r1.x - alpha * q1.x, a3 = r1.y - alpha * q1.y, a4 = r2.x - alpha * q2.x, a5 = r2.y - alpha * q2.y;
+        const double z = m0.x * a0 + m0.y * a1 + m1.x * a2 + m1.y * a3 + m2.x * a4 + m2.y * a5;
+        const double rr = r == 0 ? a0 : r == 1 ? a1 : r == 2 ? a2 : r == 3 ? a3 : r == 4 ? a4 : a5;
+        C.x[i] += alpha * pcur[i];
         rout[i] = rr;
         C.z[i] = z;
         acc += rr * z;
@@ -644,24 +737,8 @@ __global__ __launch_bounds__(CG_BLOCK) void cg_update_kernel(GraphDev G, CgDev C
     if (threadIdx.x == 0) C.part_rz[(parity ^ 1) * MAX_PARTIALS + blockIdx.x] = s;
 }
 
-// beta = rz_new/rz_old ; p = z + beta p ; convergence test on the preconditioned residual norm
-__global__ __launch_bounds__(CG_BLOCK) void cg_direction_kernel(GraphDev G, CgDev C, int parity, int nparts, double tol2) {
-    __shared__ double red[CG_BLOCK / 64];
-    if (cg_done(C)) return;
-    const double rz_old = block_total(C.part_rz + parity * MAX_PARTIALS, nparts, red);
-    const double rz_new = block_total(C.part_rz + (parity ^ 1) * MAX_PARTIALS, nparts, red);
-    const bool breakdown = C.flags[1] != 0;
-    const double beta = rz_new / rz_old;
-    const int64_t rows = G.N * 6;
-    if (!breakdown) {
-        for (int64_t i = (int64_t)blockIdx.x * CG_BLOCK + threadIdx.x; i < rows; i += (int64_t)gridDim.x * CG_BLOCK) C.p[i] = C.z[i] + beta * C.p[i];
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (!breakdown) { C.flags[2] += 1; C.scal[1] = rz_new; }
-        if (breakdown || !(rz_new > tol2 * C.scal[0])) C.flags[0] = 1;
-    }
-}
-
+// grid capped at MAX_PARTIALS workgroups (grid-stride beyond).  Measured on C3 (3125 workgroups of work): the ragged 1024-workgroup
+// grid (68 us / PCG iteration) beats both a balanced 782 x 4 trips (76 us) and 384-thread workgroups with 1563 partials (80 us).
 static inline int cg_grid(const GraphDev& G) {
     const int64_t rows = G.N * 6;
     int64_t g = (rows + CG_BLOCK - 1) / CG_BLOCK;
@@ -674,10 +751,12 @@ void launch_cg_init(const GraphDev& G, const CgDev& C, hipStream_t st) {
     hipLaunchKernelGGL(cg_init_kernel, dim3(g), dim3(CG_BLOCK), 0, st, G, C);
     hipLaunchKernelGGL(cg_scalars_init_kernel, dim3(1), dim3(256), 0, st, C, g);
 }
-void launch_cg_spmv(const GraphDev& G, const CgDev& C, hipStream_t st) { hipLaunchKernelGGL(cg_spmv_kernel, dim3(cg_grid(G)), dim3(CG_BLOCK), 0, st, G, C); }
-void launch_cg_pq(const GraphDev& G, const CgDev& C, hipStream_t st) { hipLaunchKernelGGL(cg_pq_kernel, dim3(cg_grid(G)), dim3(CG_BLOCK), 0, st, G, C); }
-void launch_cg_update(const GraphDev& G, const CgDev& C, int parity, hipStream_t st) { const int g = cg_grid(G); hipLaunchKernelGGL(cg_update_kernel, dim3(g), dim3(CG_BLOCK), 0, st, G, C, parity, g); }
-void launch_cg_direction(const GraphDev& G, const CgDev& C, int parity, double tol2, hipStream_t st) { const int g = cg_grid(G); hipLaunchKernelGGL(cg_direction_kernel, dim3(g), dim3(CG_BLOCK), 0, st, G, C, parity, g, tol2); }
+void launch_cg_spmv(const GraphDev& G, const CgDev& C, int k, double tol2, hipStream_t st) {
+    const int g = cg_grid(G);
+    hipLaunchKernelGGL(cg_spmv_kernel, dim3(g), dim3(CG_BLOCK), 0, st, G, C, k & 1, k == 0 ? 1 : 0, g, tol2);
+}
+void launch_cg_pq(const GraphDev& G, const CgDev& C, int k, hipStream_t st) { hipLaunchKernelGGL(cg_pq_kernel, dim3(cg_grid(G)), dim3(CG_BLOCK), 0, st, G, C, k & 1); }
+void launch_cg_update(const GraphDev& G, const CgDev& C, int k, hipStream_t st) { const int g = cg_grid(G); hipLaunchKernelGGL(cg_update_kernel, dim3(g), dim3(CG_BLOCK), 0, st, G, C, k & 1, g); }
 void launch_apply_operator(const GraphDev& G, const CgDev& C, const double* x, double* y, hipStream_t st) { hipLaunchKernelGGL(apply_operator_kernel, dim3(cg_grid(G)), dim3(CG_BLOCK), 0, st, G, C, x, y); }
 
 // ------------------------------------------------------------------------------------------------
