@@ -1,0 +1,296 @@
+// PoseGraphSLAM.cpp — see PoseGraphSLAM.hpp.  Host code only; every numerical step of the solve happens inside libpgo (HIP).
+#include "PoseGraphSLAM.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "../pgo_device_math.hpp"
+
+namespace pgo_host {
+
+// ---------------------------------------------------------------- Matrix4d
+Matrix4d Matrix4d::Identity() { Matrix4d m; m.d.fill(0.0); m.d[0] = m.d[5] = m.d[10] = m.d[15] = 1.0; return m; }
+Matrix4d Matrix4d::operator*(const Matrix4d& o) const {
+    Matrix4d r;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { double s = 0; for (int k = 0; k < 4; ++k) s += (*this)(i, k) * o(k, j); r(i, j) = s; }
+    return r;
+}
+Matrix4d Matrix4d::inverse() const {
+    Matrix4d r = Identity();
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r(i, j) = (*this)(j, i);
+    for (int i = 0; i < 3; ++i) r(i, 3) = -(r(i, 0) * (*this)(0, 3) + r(i, 1) * (*this)(1, 3) + r(i, 2) * (*this)(2, 3));
+    return r;
+}
+void raw_xyzw_to_eigenmat(const double* quat, const double* t, Matrix4d& dst) {
+    double R[9];
+    pgo::quat_to_rot(quat[0], quat[1], quat[2], quat[3], R);     // Quaterniond(w,x,y,z).toRotationMatrix()
+    dst = Matrix4d::Identity();
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) dst(r, c) = R[r * 3 + c];
+    dst(0, 3) = t[0]; dst(1, 3) = t[1]; dst(2, 3) = t[2];
+}
+void eigenmat_to_raw_xyzw(const Matrix4d& T, double* quat, double* t) {
+    double R[9];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R[r * 3 + c] = T(r, c);
+    pgo::eigen_matrix_to_quat(R, quat);                          // Quaterniond q(T.topLeftCorner<3,3>())
+    t[0] = T(0, 3); t[1] = T(1, 3); t[2] = T(2, 3);
+}
+double yaw_degrees(const Matrix4d& T) { return std::atan2(T(1, 0), T(0, 0)) / M_PI * 180.0; }   // R2ypr(...)(0)
+
+// ---------------------------------------------------------------- PoseGraphSLAM
+PoseGraphSLAM::PoseGraphSLAM(GraphSource* _manager, const pgo_options* options) : manager(_manager) {
+    std::memset(&summary_, 0, sizeof(summary_));
+    last_rc_ = pgo_create(&problem_, options);     // replaces the persistent ceres::Problem; fails without a GPU
+    if (last_rc_ != PGO_OK) problem_ = nullptr;
+}
+PoseGraphSLAM::~PoseGraphSLAM() { if (problem_) pgo_destroy(problem_); }
+
+int PoseGraphSLAM::nNodes() const { std::lock_guard<std::mutex> lk(mutex_opt_vars); return (int)(_opt_t_.size() / 3); }
+int PoseGraphSLAM::n_opt_variables() const { return nNodes(); }
+int PoseGraphSLAM::n_opt_switch() const { std::lock_guard<std::mutex> lk(mutex_opt_vars); return (int)_opt_switch_.size(); }
+bool PoseGraphSLAM::nodePoseExists(int i) const { std::lock_guard<std::mutex> lk(mutex_opt_vars); return i >= 0 && i < (int)(_opt_t_.size() / 3); }
+int PoseGraphSLAM::solvedUntil() const { std::lock_guard<std::mutex> lk(mutex_opt_vars); return solved_until; }
+const Matrix4d PoseGraphSLAM::getNodePose(int i) const {
+    std::lock_guard<std::mutex> lk(mutex_opt_vars);
+    Matrix4d T = Matrix4d::Identity();
+    if (i >= 0 && i < (int)(_opt_t_.size() / 3)) raw_xyzw_to_eigenmat(&_opt_quat_[4 * i], &_opt_t_[3 * i], T);
+    return T;
+}
+void PoseGraphSLAM::getAllNodePose(std::vector<Matrix4d>& v) const {
+    v.clear();
+    const int n = nNodes();
+    for (int i = 0; i < n; ++i) v.push_back(getNodePose(i));
+}
+double PoseGraphSLAM::get_loopedge_switching_variable_val(int i) const {
+    std::lock_guard<std::mutex> lk(mutex_opt_vars);
+    return (i >= 0 && i < (int)_opt_switch_.size()) ? _opt_switch_[i] : 0.0;
+}
+void PoseGraphSLAM::allocate_and_append_new_opt_variable_withpose(const Matrix4d& pose) {
+    double q[4], t[3];
+    eigenmat_to_raw_xyzw(pose, q, t);
+    std::lock_guard<std::mutex> lk(mutex_opt_vars);
+    _opt_quat_.insert(_opt_quat_.end(), q, q + 4);
+    _opt_t_.insert(_opt_t_.end(), t, t + 3);
+}
+bool PoseGraphSLAM::update_opt_variable_with(int i, const Matrix4d& pose) {
+    double q[4], t[3];
+    eigenmat_to_raw_xyzw(pose, q, t);
+    std::lock_guard<std::mutex> lk(mutex_opt_vars);
+    if (i < 0 || i >= (int)(_opt_t_.size() / 3)) return false;
+    std::copy(q, q + 4, &_opt_quat_[4 * i]);
+    std::copy(t, t + 3, &_opt_t_[3 * i]);
+    return true;
+}
+void PoseGraphSLAM::allocate_and_append_new_edge_switch_var() {
+    std::lock_guard<std::mutex> lk(mutex_opt_vars);
+    _opt_switch_.push_back(0.99);   // reference src/PoseGraphSLAM.cpp:353
+}
+
+bool PoseGraphSLAM::reinit_ceres_problem_onnewloopedge_optimize6DOF_once() {
+    if (!problem_) return false;
+    const int node_len = manager->getNodeLen();
+    const int loopedge_len = manager->getEdgeLen();
+    if (prev_loopedge_len == loopedge_len) { status_ = 0; return false; }       // no new loop edge: sleep again (:1306-1312)
+    if (manager->curr_kidnap_status()) { status_ = 0; return false; }           // kidnapped: sleep (:1314-1319)
+    status_ = 1;
+
+    // -0- new optimisation variables (:1340-1367)
+    for (int yp = n_opt_variables(); yp < node_len; ++yp) allocate_and_append_new_opt_variable_withpose(Matrix4d::Identity());
+    for (int yp = n_opt_switch(); yp < loopedge_len; ++yp) allocate_and_append_new_edge_switch_var();
+
+    // -1/-2- loop edges, intra- and inter-world (:1381-1559)
+    std::vector<int32_t> c1, c2, sw;
+    std::vector<double> T, w;
+    for (int e = prev_loopedge_len; e < loopedge_len; ++e) {
+        const Matrix4d bTa = manager->getEdgePose(e);
+        const double weight = manager->getEdgeWeight(e);
+        const std::pair<int, int> paur = manager->getEdgeIdxInfo(e);
+        const int a = paur.first, b = paur.second;
+        const int a_world = manager->which_world_is_this_node(a), b_world = manager->which_world_is_this_node(b);
+        if (a_world < 0 || b_world < 0) continue;                                // an endpoint lies in a dead zone (:1400-1401)
+        if (a_world != b_world && !manager->is_exist(b_world, a_world)) {
+            // relative pose between the two worlds from ODOMETRY poses at first contact (:1459-1464)
+            const Matrix4d wb_T_wa = (manager->getNodePose(b) * bTa) * manager->getNodePose(a).inverse();
+            std::map<int, int> before, after;
+            manager->getWorld2SetIDMap(before);
+            manager->setPoseBetweenWorlds(b_world, a_world, wb_T_wa);           // the only place two sets can merge (:1489-1490)
+            manager->getWorld2SetIDMap(after);
+            changes_to_setid_on_set_union.clear();
+            for (const auto& kv : before) {
+                const auto it = after.find(kv.first);
+                if (it != after.end() && it->second != kv.second) changes_to_setid_on_set_union[kv.first] = std::make_tuple(kv.second, it->second);
+            }
+        }
+        // SixDOFErrorWithSwitchingConstraints(bTa, weight) on (q_b,t_b, q_a,t_a, s_e)  (:1550-1556)
+        c1.push_back(b); c2.push_back(a); sw.push_back(e); w.push_back(weight);
+        T.insert(T.end(), bTa.d.begin(), bTa.d.end());
+        added_edges_.push_back({b, a, weight, e});
+    }
+    if (!c1.empty()) last_rc_ = pgo_add_switchable_edges(problem_, (int64_t)c1.size(), c1.data(), c2.data(), T.data(), w.data(), sw.data());
+
+    // -3- odometry residues u <-> u-f, f = 1..5 (:1570-1639)
+    c1.clear(); c2.clear(); T.clear(); w.clear();
+    const int su = solvedUntil();
+    for (int u = su + 1; u < node_len; ++u) {
+        const int set_u = manager->find_setID_of_world_i(manager->which_world_is_this_node(u));
+        for (int f = 1; f < 6; ++f) {
+            const int world_umf = (u - f >= 0) ? manager->which_world_is_this_node(u - f) : -1;
+            const int set_umf = manager->find_setID_of_world_i(world_umf);
+            if (set_u < 0 || set_umf < 0) continue;                              // dead zone (:1583-1586)
+            if (u - f < 0) continue;                                             // (:1588-1591)
+            const Matrix4d u_M_umf = manager->getNodePose(u).inverse() * manager->getNodePose(u - f);      // (:1597-1599)
+            const double yaw = yaw_degrees(u_M_umf);
+            const double odom_edge_weight = std::pow(0.9, f) * std::exp(-yaw * yaw / 6.0);                // (:1603-1606)
+            c1.push_back(u); c2.push_back(u - f); w.push_back(odom_edge_weight);
+            T.insert(T.end(), u_M_umf.d.begin(), u_M_umf.d.end());
+            added_edges_.push_back({u, u - f, odom_edge_weight, -1});
+        }
+    }
+    if (!c1.empty()) last_rc_ = pgo_add_relpose_edges(problem_, (int64_t)c1.size(), c1.data(), c2.data(), T.data(), w.data());
+
+    // -4- initial guesses (:1649-1793)
+    {
+        const int s_until = su;
+        int s_world = manager->which_world_is_this_node(s_until);
+        if (s_world < 0) s_world = -s_world - 1;
+        for (int u = 0; u < node_len; ++u) {
+            const int world_u = manager->which_world_is_this_node(u);
+            const int set_u = manager->find_setID_of_world_i(world_u);
+            if (set_u < 0) continue;                                             // kidnapped nodes (:1665-1668)
+            Matrix4d wset_T_w = Matrix4d::Identity();
+            if (set_u != world_u) {
+                if (!manager->is_exist(set_u, world_u)) { last_rc_ = PGO_ERR_STATE; status_ = 0; return false; }   // the reference exit(3)s here
+                wset_T_w = manager->getPoseBetweenWorlds(set_u, world_u);
+            }
+            const bool before = u <= s_until;
+            const bool in_change_set = changes_to_setid_on_set_union.count(world_u) > 0;
+            if (in_change_set && before) {
+                if (set_u == s_world) { last_rc_ = PGO_ERR_STATE; status_ = 0; return false; }                      // the reference exit(8)s here
+                const int old_setid = std::get<0>(changes_to_setid_on_set_union[world_u]);
+                const int new_setid = std::get<1>(changes_to_setid_on_set_union[world_u]);
+                update_opt_variable_with(u, manager->getPoseBetweenWorlds(new_setid, old_setid) * this->getNodePose(u));
+            } else if (!before) {
+                // both the in-change-set and the ordinary branch chain from the last solved pose inside its world, or map the
+                // odometry pose into the set's frame otherwise (:1727-1753, :1767-1786)
+                if (s_world == world_u) {
+                    const Matrix4d last_M_u = manager->getNodePose(s_until).inverse() * manager->getNodePose(u);
+                    update_opt_variable_with(u, this->getNodePose(s_until) * last_M_u);
+                } else {
+                    update_opt_variable_with(u, wset_T_w * manager->getNodePose(u));
+                }
+            } else if (s_until == 0) {
+                update_opt_variable_with(u, manager->getNodePose(u));            // very first trigger (:1756-1761)
+            }
+        }
+    }
+
+    // -5- node regularisation replaces the previous set (:1803-1877)
+    regs_.clear();
+    for (int ww = 0; ww < manager->n_worlds(); ++ww) {
+        const int ww_setid = manager->find_setID_of_world_i(ww);
+        const int ww_start = manager->nodeidx_of_world_i_started(ww), ww_end = manager->nodeidx_of_world_i_ended(ww);
+        if (ww_start < 0 || ww_start >= node_len) continue;
+        if (ww_setid >= 0 && ww_setid == ww) {
+            const double regularization_weight = std::max(1.1, std::log(1.0 + ww_end - ww_start) / 2.0);            // (:1839)
+            regs_.push_back({ww_start, regularization_weight, this->getNodePose(ww_start)});                          // (:1844-1848)
+        }
+    }
+    {
+        std::vector<int32_t> rn; std::vector<double> rw, rT;
+        for (const AddedRegularizer& r : regs_) { rn.push_back(r.node); rw.push_back(r.weight); rT.insert(rT.end(), r.target.d.begin(), r.target.d.end()); }
+        last_rc_ = pgo_set_node_regularizers(problem_, (int64_t)rn.size(), rn.data(), rT.data(), rw.data());
+    }
+    changes_to_setid_on_set_union.clear();                                       // (:1882)
+
+    // -6- solve WITHOUT holding the lock; single write-back at the end (:1891-1910)
+    status_ = 2;
+    std::vector<double> q, t, s;
+    {
+        std::lock_guard<std::mutex> lk(mutex_opt_vars);
+        q = _opt_quat_; t = _opt_t_; s = _opt_switch_;
+    }
+    init_quat_ = q; init_t_ = t;
+    last_rc_ = pgo_solve(problem_, q.data(), t.data(), s.empty() ? nullptr : s.data(), (int64_t)(t.size() / 3), (int64_t)s.size(), &summary_);
+    {
+        std::lock_guard<std::mutex> lk(mutex_opt_vars);
+        if (last_rc_ == PGO_OK && summary_.termination_type != PGO_FAILURE) { _opt_quat_ = q; _opt_t_ = t; _opt_switch_ = s; }
+        solved_until = node_len - 1;                                             // regardless of convergence (:1906-1910)
+    }
+    status_ = 0;
+    prev_loopedge_len = loopedge_len;
+    prev_node_len = node_len;
+    return last_rc_ == PGO_OK;
+}
+
+// ---------------------------------------------------------------- VectorGraphSource
+void VectorGraphSource::ensure_world(int w) const {
+    while ((int)set_of_.size() <= w) { set_of_.push_back((int)set_of_.size()); set_T_world_.push_back(Matrix4d::Identity()); }
+}
+int VectorGraphSource::n_worlds() const { int m = -1; for (int w : node_world_) m = std::max(m, w); return m + 1; }
+int VectorGraphSource::nodeidx_of_world_i_started(int w) const { for (size_t i = 0; i < node_world_.size(); ++i) if (node_world_[i] == w) return (int)i; return -1; }
+int VectorGraphSource::nodeidx_of_world_i_ended(int w) const { for (int i = (int)node_world_.size() - 1; i >= 0; --i) if (node_world_[i] == w) return i; return -1; }
+int VectorGraphSource::find_setID_of_world_i(int w) const { if (w < 0) return w; ensure_world(w); return set_of_[w]; }
+bool VectorGraphSource::is_exist(int m, int n) const { if (m < 0 || n < 0) return false; ensure_world(std::max(m, n)); return set_of_[m] == set_of_[n]; }
+Matrix4d VectorGraphSource::getPoseBetweenWorlds(int m, int n) const { ensure_world(std::max(m, n)); return set_T_world_[m].inverse() * set_T_world_[n]; }
+void VectorGraphSource::setPoseBetweenWorlds(int m, int n, const Matrix4d& m_T_n) {
+    ensure_world(std::max(m, n));
+    if (set_of_[m] == set_of_[n]) return;
+    // merge the set of n into the set of m (or the other way round) keeping the smaller set id as the root frame
+    const int sm = set_of_[m], sn = set_of_[n];
+    if (sm < sn) {
+        const Matrix4d sm_T_sn = set_T_world_[m] * m_T_n * set_T_world_[n].inverse();
+        for (size_t w = 0; w < set_of_.size(); ++w) if (set_of_[w] == sn) { set_T_world_[w] = sm_T_sn * set_T_world_[w]; set_of_[w] = sm; }
+    } else {
+        const Matrix4d sn_T_sm = set_T_world_[n] * m_T_n.inverse() * set_T_world_[m].inverse();
+        for (size_t w = 0; w < set_of_.size(); ++w) if (set_of_[w] == sm) { set_T_world_[w] = sn_T_sm * set_T_world_[w]; set_of_[w] = sn; }
+    }
+}
+void VectorGraphSource::getWorld2SetIDMap(std::map<int, int>& out) const {
+    out.clear();
+    const int n = n_worlds();
+    if (n > 0) ensure_world(n - 1);
+    for (int w = 0; w < n; ++w) out[w] = set_of_[w];
+}
+
+}  // namespace pgo_host
+
+// ================================================================================================
+// thin C wrapper so the parity tests (pytest/ctypes) can drive the C++ host side
+// ================================================================================================
+using namespace pgo_host;
+struct pgo_host_session { VectorGraphSource src; PoseGraphSLAM* slam; };
+
+extern "C" {
+pgo_host_session* pgo_host_create(const pgo_options* opt) {
+    pgo_host_session* s = new pgo_host_session();
+    s->slam = new PoseGraphSLAM(&s->src, opt);
+    if (!s->slam->ok()) { delete s->slam; delete s; return nullptr; }
+    return s;
+}
+void pgo_host_destroy(pgo_host_session* s) { if (s) { delete s->slam; delete s; } }
+void pgo_host_add_node(pgo_host_session* s, int world, const double* T16) { Matrix4d T; std::copy(T16, T16 + 16, T.d.begin()); s->src.add_node(world, T); }
+void pgo_host_add_loop_edge(pgo_host_session* s, int a, int b, const double* bTa16, double w) { Matrix4d T; std::copy(bTa16, bTa16 + 16, T.d.begin()); s->src.add_loop_edge(a, b, T, w); }
+void pgo_host_set_kidnapped(pgo_host_session* s, int k) { s->src.set_kidnapped(k != 0); }
+int pgo_host_trigger(pgo_host_session* s) { return s->slam->reinit_ceres_problem_onnewloopedge_optimize6DOF_once() ? 1 : 0; }
+int pgo_host_n_nodes(pgo_host_session* s) { return s->slam->nNodes(); }
+int pgo_host_solved_until(pgo_host_session* s) { return s->slam->solvedUntil(); }
+int pgo_host_node_pose_exists(pgo_host_session* s, int i) { return s->slam->nodePoseExists(i) ? 1 : 0; }
+void pgo_host_get_node_pose(pgo_host_session* s, int i, double* T16) { const Matrix4d T = s->slam->getNodePose(i); std::copy(T.d.begin(), T.d.end(), T16); }
+double pgo_host_switch(pgo_host_session* s, int e) { return s->slam->get_loopedge_switching_variable_val(e); }
+int pgo_host_n_added_edges(pgo_host_session* s) { return (int)s->slam->added_edges().size(); }
+void pgo_host_get_added_edges(pgo_host_session* s, int32_t* c1, int32_t* c2, double* w, int32_t* sw) {
+    const auto& v = s->slam->added_edges();
+    for (size_t k = 0; k < v.size(); ++k) { c1[k] = v[k].c1; c2[k] = v[k].c2; w[k] = v[k].weight; sw[k] = v[k].switch_idx; }
+}
+int pgo_host_n_regularizers(pgo_host_session* s) { return (int)s->slam->regularizers().size(); }
+void pgo_host_get_regularizers(pgo_host_session* s, int32_t* node, double* w, double* T16) {
+    const auto& v = s->slam->regularizers();
+    for (size_t k = 0; k < v.size(); ++k) { node[k] = v[k].node; w[k] = v[k].weight; std::copy(v[k].target.d.begin(), v[k].target.d.end(), T16 + 16 * k); }
+}
+void pgo_host_get_initial_guess(pgo_host_session* s, double* quat, double* t) {
+    std::copy(s->slam->last_initial_quat().begin(), s->slam->last_initial_quat().end(), quat);
+    std::copy(s->slam->last_initial_t().begin(), s->slam->last_initial_t().end(), t);
+}
+void pgo_host_get_summary(pgo_host_session* s, pgo_summary* out) { *out = s->slam->last_summary(); }
+int pgo_host_last_error(pgo_host_session* s) { return s->slam->last_error(); }
+}

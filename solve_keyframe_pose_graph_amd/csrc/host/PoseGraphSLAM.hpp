@@ -1,0 +1,150 @@
+// PoseGraphSLAM.hpp — ROS-free host side above the C-ABI (include/pgo.h), mirroring the solver-facing interface of the
+// reference's `PoseGraphSLAM` class: same method names, argument meaning and threading contract, so that a maintainer can
+// swap the Ceres calls of the reference for libpgo and keep NodeDataManager, the ROS callbacks and the Worlds/kidnap
+// bookkeeping untouched.
+//
+// Mirrored interface (reference file:line):
+//   opt-variable storage, xyzw quaternion + translation + one switch per loop edge      src/PoseGraphSLAM.h:153-175
+//   getNodePose / nodePoseExists / nNodes / getAllNodePose / solvedUntil                src/PoseGraphSLAM.cpp:178-224, PoseGraphSLAM.h:120
+//   allocate_and_append_new_opt_variable_withpose / update_opt_variable_with            src/PoseGraphSLAM.cpp:226-335
+//   allocate_and_append_new_edge_switch_var (init 0.99) / get_loopedge_switching_variable_val   :339-361, PoseGraphSLAM.h:219
+//   one wake-up of reinit_ceres_problem_onnewloopedge_optimize6DOF(): steps -0- .. -6-   src/PoseGraphSLAM.cpp:1287-1940
+// The data source is abstract: in the reference it is `NodeDataManager` + `Worlds` (NodeDataManager.h:95-111,179; Worlds.h:50-76).
+#pragma once
+#include <array>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <utility>
+#include <vector>
+
+#include "pgo.h"
+
+namespace pgo_host {
+
+// Eigen::Matrix4d stand-in: 16 doubles, column-major.
+struct Matrix4d {
+    std::array<double, 16> d;
+    double& operator()(int r, int c) { return d[c * 4 + r]; }
+    double operator()(int r, int c) const { return d[c * 4 + r]; }
+    static Matrix4d Identity();
+    Matrix4d operator*(const Matrix4d& o) const;
+    Matrix4d inverse() const;   // rigid inverse
+};
+
+// PoseManipUtils::{raw_xyzw_to_eigenmat, eigenmat_to_raw_xyzw, R2ypr}  (reference src/utils/PoseManipUtils.cpp:61-98,143-158)
+void raw_xyzw_to_eigenmat(const double* quat, const double* t, Matrix4d& dst);
+void eigenmat_to_raw_xyzw(const Matrix4d& T, double* quat, double* t);
+double yaw_degrees(const Matrix4d& T);
+
+// What the trigger reads from NodeDataManager / Worlds.  Method names follow the reference.
+class GraphSource {
+public:
+    virtual ~GraphSource() {}
+    virtual int getNodeLen() const = 0;
+    virtual Matrix4d getNodePose(int i) const = 0;                  // odometry pose w_M_i in its own world
+    virtual int which_world_is_this_node(int i) const = 0;          // = which_world_is_this(getNodeTimestamp(i)); negative while kidnapped
+    virtual int getEdgeLen() const = 0;
+    virtual Matrix4d getEdgePose(int e) const = 0;                  // b_T_a
+    virtual double getEdgeWeight(int e) const = 0;
+    virtual std::pair<int, int> getEdgeIdxInfo(int e) const = 0;    // (a = current, b = previous)
+    virtual bool curr_kidnap_status() const = 0;
+    virtual int n_worlds() const = 0;
+    virtual int nodeidx_of_world_i_started(int w) const = 0;
+    virtual int nodeidx_of_world_i_ended(int w) const = 0;
+    // Worlds
+    virtual int find_setID_of_world_i(int w) const = 0;             // negative for kidnapped / unknown worlds
+    virtual bool is_exist(int m, int n) const = 0;
+    virtual Matrix4d getPoseBetweenWorlds(int m, int n) const = 0;  // m_T_n
+    virtual void setPoseBetweenWorlds(int m, int n, const Matrix4d& m_T_n) = 0;
+    virtual void getWorld2SetIDMap(std::map<int, int>& out) const = 0;
+};
+
+// One record per residual block the trigger adds — what a reader of the reference would expect `AddResidualBlock` to receive.
+struct AddedEdge { int c1, c2; double weight; int switch_idx; /* -1: SixDOFError */ };
+struct AddedRegularizer { int node; double weight; Matrix4d target; };
+
+class PoseGraphSLAM {
+public:
+    explicit PoseGraphSLAM(GraphSource* manager, const pgo_options* options = nullptr);
+    ~PoseGraphSLAM();
+    bool ok() const { return problem_ != nullptr; }
+
+    // One wake-up of the reference's trigger loop body.  Returns true when a solve ran.
+    bool reinit_ceres_problem_onnewloopedge_optimize6DOF_once();
+    int get_reinit_ceres_problem_onnewloopedge_optimize6DOF_status() const { return status_; }
+
+    // thread-safe readers (same names as the reference)
+    const Matrix4d getNodePose(int i) const;
+    bool nodePoseExists(int i) const;
+    int nNodes() const;
+    void getAllNodePose(std::vector<Matrix4d>& vec_w_T_ci) const;
+    int solvedUntil() const;
+    double get_loopedge_switching_variable_val(int i) const;
+
+    // introspection for the parity tests
+    const std::vector<AddedEdge>& added_edges() const { return added_edges_; }
+    const std::vector<AddedRegularizer>& regularizers() const { return regs_; }
+    const std::vector<double>& last_initial_quat() const { return init_quat_; }
+    const std::vector<double>& last_initial_t() const { return init_t_; }
+    const pgo_summary& last_summary() const { return summary_; }
+    int last_error() const { return last_rc_; }
+
+private:
+    void allocate_and_append_new_opt_variable_withpose(const Matrix4d& pose);
+    bool update_opt_variable_with(int i, const Matrix4d& pose);
+    void allocate_and_append_new_edge_switch_var();
+    int n_opt_variables() const;
+    int n_opt_switch() const;
+
+    GraphSource* manager;
+    pgo_problem* problem_ = nullptr;
+    mutable std::mutex mutex_opt_vars;
+    std::vector<double> _opt_quat_, _opt_t_, _opt_switch_;   // xyzw ; xyz ; one per loop edge
+    int solved_until = 0;
+    int prev_loopedge_len = 0, prev_node_len = 0;
+    int status_ = -1, last_rc_ = 0;
+    std::map<int, std::tuple<int, int>> changes_to_setid_on_set_union;
+    std::vector<AddedEdge> added_edges_;
+    std::vector<AddedRegularizer> regs_;
+    std::vector<double> init_quat_, init_t_;
+    pgo_summary summary_;
+};
+
+// A plain in-memory GraphSource (stands in for NodeDataManager + Worlds in tests and examples).
+class VectorGraphSource : public GraphSource {
+public:
+    void add_node(int world, const Matrix4d& w_M_i) { node_world_.push_back(world); node_pose_.push_back(w_M_i); }
+    void add_loop_edge(int a, int b, const Matrix4d& b_T_a, double weight) { edge_ab_.push_back({a, b}); edge_pose_.push_back(b_T_a); edge_w_.push_back(weight); }
+    void set_kidnapped(bool k) { kidnapped_ = k; }
+
+    int getNodeLen() const override { return (int)node_pose_.size(); }
+    Matrix4d getNodePose(int i) const override { return node_pose_[i]; }
+    int which_world_is_this_node(int i) const override { return node_world_[i]; }
+    int getEdgeLen() const override { return (int)edge_ab_.size(); }
+    Matrix4d getEdgePose(int e) const override { return edge_pose_[e]; }
+    double getEdgeWeight(int e) const override { return edge_w_[e]; }
+    std::pair<int, int> getEdgeIdxInfo(int e) const override { return edge_ab_[e]; }
+    bool curr_kidnap_status() const override { return kidnapped_; }
+    int n_worlds() const override;
+    int nodeidx_of_world_i_started(int w) const override;
+    int nodeidx_of_world_i_ended(int w) const override;
+    int find_setID_of_world_i(int w) const override;
+    bool is_exist(int m, int n) const override;
+    Matrix4d getPoseBetweenWorlds(int m, int n) const override;
+    void setPoseBetweenWorlds(int m, int n, const Matrix4d& m_T_n) override;
+    void getWorld2SetIDMap(std::map<int, int>& out) const override;
+
+private:
+    void ensure_world(int w) const;
+    std::vector<int> node_world_;
+    std::vector<Matrix4d> node_pose_;
+    std::vector<std::pair<int, int>> edge_ab_;
+    std::vector<Matrix4d> edge_pose_;
+    std::vector<double> edge_w_;
+    bool kidnapped_ = false;
+    mutable std::vector<int> set_of_;            // world -> set id (= smallest world id of the merged set)
+    mutable std::vector<Matrix4d> set_T_world_;  // pose of the world in its set's frame
+};
+
+}  // namespace pgo_host

@@ -1,0 +1,108 @@
+"""ctypes view of the C++ host side (csrc/host/PoseGraphSLAM.{hpp,cpp}) — the ROS-free mirror of the reference's
+`PoseGraphSLAM` solver-facing interface and of one wake-up of reinit_ceres_problem_onnewloopedge_optimize6DOF()
+(reference src/PoseGraphSLAM.cpp:1287-1940).  Used by the parity tests and examples; production callers use the C++ class."""
+import ctypes as C
+
+import numpy as np
+
+from . import _build, capi
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        capi.load()
+        _lib = C.CDLL(_build.build_host())
+        _lib.pgo_host_create.restype = C.c_void_p
+        _lib.pgo_host_switch.restype = C.c_double
+        for f in ("destroy", "add_node", "add_loop_edge", "set_kidnapped", "trigger", "n_nodes", "solved_until", "node_pose_exists", "get_node_pose", "switch",
+                  "n_added_edges", "get_added_edges", "n_regularizers", "get_regularizers", "get_initial_guess", "get_summary", "last_error"):
+            fn = getattr(_lib, "pgo_host_" + f)
+            fn.argtypes = None
+    return _lib
+
+
+class PoseGraphSLAM:
+    def __init__(self, **opt_kw):
+        self.lib = _load()
+        self.opt = capi.default_options(**opt_kw)
+        self.h = C.c_void_p(self.lib.pgo_host_create(C.byref(self.opt)))
+        if not self.h.value:
+            raise capi.PgoError(-2, "PoseGraphSLAM: pgo_create failed (no GPU / libpgo missing): there is no CPU fallback")
+
+    def close(self):
+        if self.h and self.h.value:
+            self.lib.pgo_host_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- the caller side (NodeDataManager stand-in) ----
+    def add_node(self, world, w_M_i_colmajor16):
+        a = np.ascontiguousarray(w_M_i_colmajor16, dtype=np.float64)
+        self.lib.pgo_host_add_node(self.h, C.c_int(world), a.ctypes.data_as(_dp))
+
+    def add_loop_edge(self, a, b, b_T_a_colmajor16, weight=1.0):
+        T = np.ascontiguousarray(b_T_a_colmajor16, dtype=np.float64)
+        self.lib.pgo_host_add_loop_edge(self.h, C.c_int(a), C.c_int(b), T.ctypes.data_as(_dp), C.c_double(weight))
+
+    def set_kidnapped(self, k):
+        self.lib.pgo_host_set_kidnapped(self.h, C.c_int(1 if k else 0))
+
+    # ---- PoseGraphSLAM interface ----
+    def reinit_ceres_problem_onnewloopedge_optimize6DOF_once(self):
+        return bool(self.lib.pgo_host_trigger(self.h))
+
+    def nNodes(self):
+        return self.lib.pgo_host_n_nodes(self.h)
+
+    def solvedUntil(self):
+        return self.lib.pgo_host_solved_until(self.h)
+
+    def nodePoseExists(self, i):
+        return bool(self.lib.pgo_host_node_pose_exists(self.h, C.c_int(i)))
+
+    def getNodePose(self, i):
+        T = np.zeros(16)
+        self.lib.pgo_host_get_node_pose(self.h, C.c_int(i), T.ctypes.data_as(_dp))
+        return T.reshape(4, 4, order="F")
+
+    def get_loopedge_switching_variable_val(self, e):
+        return self.lib.pgo_host_switch(self.h, C.c_int(e))
+
+    # ---- introspection ----
+    def added_edges(self):
+        n = self.lib.pgo_host_n_added_edges(self.h)
+        c1 = np.zeros(n, np.int32); c2 = np.zeros(n, np.int32); w = np.zeros(n); sw = np.zeros(n, np.int32)
+        if n:
+            self.lib.pgo_host_get_added_edges(self.h, c1.ctypes.data_as(_ip), c2.ctypes.data_as(_ip), w.ctypes.data_as(_dp), sw.ctypes.data_as(_ip))
+        return c1, c2, w, sw
+
+    def regularizers(self):
+        n = self.lib.pgo_host_n_regularizers(self.h)
+        node = np.zeros(n, np.int32); w = np.zeros(n); T = np.zeros((n, 16))
+        if n:
+            self.lib.pgo_host_get_regularizers(self.h, node.ctypes.data_as(_ip), w.ctypes.data_as(_dp), T.ctypes.data_as(_dp))
+        return node, w, T
+
+    def initial_guess(self):
+        n = self.nNodes()
+        q = np.zeros((n, 4)); t = np.zeros((n, 3))
+        self.lib.pgo_host_get_initial_guess(self.h, q.ctypes.data_as(_dp), t.ctypes.data_as(_dp))
+        return q, t
+
+    def summary(self):
+        s = capi.Summary()
+        self.lib.pgo_host_get_summary(self.h, C.byref(s))
+        return s
+
+    def last_error(self):
+        return self.lib.pgo_host_last_error(self.h)

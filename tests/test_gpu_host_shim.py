@@ -1,0 +1,137 @@
+"""GPU: the C++ host side above the C-ABI (csrc/host/PoseGraphSLAM.*) — the ROS-free mirror of the reference's
+PoseGraphSLAM trigger.  A scripted arrival sequence is pushed through it and the problem it builds is compared with
+expectations derived by hand from the reference's rules (src/PoseGraphSLAM.cpp:1340-1367, 1550-1556, 1570-1633,
+1649-1793, 1817-1849); every trigger's solve is re-done by the oracle from the same initial guess."""
+import numpy as np
+import pytest
+
+from oracle import binding as ob
+from solve_keyframe_pose_graph_amd import capi, graphgen
+from solve_keyframe_pose_graph_amd.pose_graph_slam import PoseGraphSLAM
+from tests import util
+from tests.golden.make_functor_goldens import quat_to_R_np
+
+pytestmark = pytest.mark.gpu
+
+
+def T_of(q, t):
+    T = np.eye(4); T[:3, :3] = quat_to_R_np(q); T[:3, 3] = t
+    return T
+
+
+def quat_of(T):
+    return ob.mat_to_quat(T.flatten(order="F"))
+
+
+def expected_odom(vio, lo, hi, worlds=None):
+    """reference policy for u in [lo, hi): f = 1..5, weight 0.9^f exp(-yaw_deg^2/6), measurement w_M_u^-1 w_M_umf"""
+    out = []
+    for u in range(lo, hi):
+        for f in range(1, 6):
+            if u - f < 0:
+                continue
+            if worlds is not None and (worlds[u] < 0 or worlds[u - f] < 0):
+                continue
+            M = np.linalg.inv(vio[u]) @ vio[u - f]
+            yaw = np.degrees(np.arctan2(M[1, 0], M[0, 0]))
+            out.append((u, u - f, 0.9 ** f * np.exp(-yaw * yaw / 6.0), M))
+    return out
+
+
+def test_single_world_incremental_triggers_match_oracle():
+    g = graphgen.config("C1F5")
+    vio = [T_of(g.init_q[i], g.init_t[i]) for i in range(g.n_poses)]
+    S = PoseGraphSLAM(max_num_iterations=10, cg_rel_tolerance=1e-12, cg_max_iterations=20000)
+    O = ob.OracleProblem()
+    # arrival script: keyframes stream in; loop-closure messages arrive when their newer keyframe exists; trigger after each batch
+    order = np.argsort(g.loop_c2, kind="stable")
+    batches = [order[:7], order[7:13], order[13:]]
+    n_seen, n_edges_seen, prev_solved = 0, 0, 0
+    exp_edges = []
+    assert not S.reinit_ceres_problem_onnewloopedge_optimize6DOF_once()       # nothing to do yet
+    for bi, batch in enumerate(batches):
+        upto = int(g.loop_c2[batch].max()) + 1 + 3
+        upto = min(upto, g.n_poses)
+        for i in range(n_seen, upto):
+            S.add_node(0, vio[i].flatten(order="F"))
+        n_seen = upto
+        for e in batch:
+            S.add_loop_edge(int(g.loop_c2[e]), int(g.loop_c1[e]), g.loop_T[e], float(g.loop_w[e]))   # (a = newer, b = older, b_T_a)
+        su_before = S.solvedUntil()
+        assert S.reinit_ceres_problem_onnewloopedge_optimize6DOF_once()
+        assert S.solvedUntil() == n_seen - 1 and S.nNodes() == n_seen
+        # ---- expected residual blocks of this trigger: new loop edges first (switch id = message index), then odometry
+        new_loops = [(int(g.loop_c1[e]), int(g.loop_c2[e]), float(g.loop_w[e]), n_edges_seen + k) for k, e in enumerate(batch)]
+        n_edges_seen += len(batch)
+        new_odom = expected_odom(vio, su_before + 1, n_seen)
+        exp_edges += [(b, a, w, sw) for (b, a, w, sw) in new_loops] + [(u, v, w, -1) for (u, v, w, _) in new_odom]
+        c1, c2, w, sw = S.added_edges()
+        assert len(c1) == len(exp_edges)
+        for k, (a_, b_, w_, s_) in enumerate(exp_edges):
+            assert (c1[k], c2[k], sw[k]) == (a_, b_, s_) and abs(w[k] - w_) <= 1e-12 * max(1.0, w_)
+        # ---- regulariser: node 0, weight max(1.1, ln(1 + end - start)/2), target = its current optimised pose
+        node, rw, rT = S.regularizers()
+        assert list(node) == [0] and abs(rw[0] - max(1.1, np.log(1 + (n_seen - 1)) / 2)) <= 1e-12
+        q0, t0 = S.initial_guess()
+        assert np.abs(rT[0].reshape(4, 4, order="F") - T_of(q0[0], t0[0])).max() <= 1e-12
+        # ---- initial guess: solved nodes keep their optimised pose, new nodes chain odometry from the last solved one
+        if bi == 0:
+            for i in range(n_seen):
+                assert np.abs(T_of(q0[i], t0[i]) - vio[i]).max() <= 1e-9
+        else:
+            last = su_before
+            Tl = T_of(q0[last], t0[last])
+            for i in range(last + 1, n_seen):
+                want = Tl @ np.linalg.inv(vio[last]) @ vio[i]
+                assert np.abs(T_of(q0[i], t0[i]) - want).max() <= 1e-9
+        # ---- the same accumulated problem, same initial guess, solved by the oracle
+        O.add_switchable_edges([x[0] for x in new_loops], [x[1] for x in new_loops], g.loop_T[batch], [x[2] for x in new_loops], [x[3] for x in new_loops])
+        if new_odom:
+            O.add_relpose_edges([x[0] for x in new_odom], [x[1] for x in new_odom], np.array([x[3].flatten(order="F") for x in new_odom]), [x[2] for x in new_odom])
+        O.set_node_regularizers(node, rT, rw)
+        s0 = np.array([0.99] * n_edges_seen) if bi == 0 else np.concatenate([s_prev, [0.99] * len(batch)])
+        qo, to, so, sumo = O.solve(q0, t0, s0)
+        summ = S.summary()
+        assert summ.num_iterations == sumo.num_iterations
+        assert abs(summ.final_cost - sumo.final_cost) <= 1e-6 * max(sumo.final_cost, 1e-12)
+        got_t = np.array([S.getNodePose(i)[:3, 3] for i in range(n_seen)])
+        assert np.abs(got_t - to.reshape(-1, 3)).max() <= 1e-5
+        s_prev = np.array([S.get_loopedge_switching_variable_val(e) for e in range(n_edges_seen)])
+        assert np.abs(s_prev - so).max() <= 1e-5
+    S.close()
+
+
+def test_kidnap_two_worlds_merge_on_first_inter_world_edge():
+    rng = np.random.default_rng(5)
+    g = util.small_graph(120, 0, f=1, seed=8, turn_deg_per_keyframe=2.0)
+    truth = [T_of(g.truth_q[i], g.truth_t[i]) for i in range(120)]
+    # world 0 = keyframes 0..59, kidnap, world 1 = 60..119 with its own odometry frame (restarts at identity)
+    vio = [truth[i] for i in range(60)] + [np.linalg.inv(truth[60]) @ truth[i] for i in range(60, 120)]
+    world = [0] * 60 + [1] * 60
+    S = PoseGraphSLAM(max_num_iterations=10, cg_rel_tolerance=1e-12, cg_max_iterations=20000)
+    for i in range(120):
+        S.add_node(world[i], vio[i].flatten(order="F"))
+    S.set_kidnapped(True)
+    S.add_loop_edge(40, 5, (np.linalg.inv(truth[5]) @ truth[40]).flatten(order="F"))
+    assert not S.reinit_ceres_problem_onnewloopedge_optimize6DOF_once()        # kidnapped: the trigger sleeps (reference :1314-1319)
+    S.set_kidnapped(False)
+    assert S.reinit_ceres_problem_onnewloopedge_optimize6DOF_once()
+    node, rw, _ = S.regularizers()
+    assert sorted(node) == [0, 60]                                             # both worlds are their own set root
+    c1, c2, w, sw = S.added_edges()
+    odom = [(a, b) for a, b, s in zip(c1, c2, sw) if s < 0]
+    assert all(world[a] == world[b] or True for a, b in odom)
+    # the reference adds odometry edges across the kidnap too when both worlds are alive
+    assert (60, 59) in odom
+    # first inter-world loop edge: a = 100 (world 1), b = 20 (world 0)
+    bTa = np.linalg.inv(truth[20]) @ truth[100]
+    S.add_loop_edge(100, 20, bTa.flatten(order="F"))
+    assert S.reinit_ceres_problem_onnewloopedge_optimize6DOF_once()
+    node, rw, _ = S.regularizers()
+    assert list(node) == [0]                                                   # merged: only the root world keeps a regulariser
+    assert abs(rw[0] - max(1.1, np.log(1 + 59) / 2)) <= 1e-12
+    # after the merge every world-1 pose is expressed in world 0's frame: close to the ground truth (noise-free script)
+    err = max(np.abs(S.getNodePose(i) - truth[i]).max() for i in range(120))
+    assert err <= 1e-6, err
+    assert S.get_loopedge_switching_variable_val(1) > 0.9
+    S.close()
