@@ -63,14 +63,15 @@ enum {
 /* ---- linear solver for the LM normal equations (replaces SPARSE_NORMAL_CHOLESKY,
  *      src/PoseGraphSLAM.cpp:1270) ---- */
 enum {
-    PGO_LINEAR_PCG_BLOCK_JACOBI = 0 /* device PCG on the Schur-reduced pose system, 6x6 block-Jacobi */
+    PGO_LINEAR_PCG_BLOCK_JACOBI = 0, /* device PCG on the Schur-reduced pose system, 6x6 block-Jacobi, assembled block-CSR matrix */
+    PGO_LINEAR_PCG_MATRIX_FREE = 1   /* same PCG, the matvec evaluated matrix-free from one compact record per edge side (default) */
 };
 
 /* Options.  Defaults (pgo_options_init) are the Ceres defaults the reference runs with, plus
  * max_num_iterations = 10 (src/PoseGraphSLAM.cpp:1268-1272).  See SURVEY.md Appendix B. */
 typedef struct pgo_options {
     int32_t max_num_iterations;          /* 10   (PoseGraphSLAM.cpp:1272) */
-    int32_t linear_solver;               /* PGO_LINEAR_PCG_BLOCK_JACOBI */
+    int32_t linear_solver;               /* PGO_LINEAR_PCG_MATRIX_FREE */
     int32_t jacobi_scaling;              /* 1    (Ceres default) */
     int32_t max_num_consecutive_invalid_steps; /* 5 */
     double initial_trust_region_radius;  /* 1e4  */

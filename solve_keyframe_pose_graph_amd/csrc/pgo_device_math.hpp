@@ -189,6 +189,91 @@ PGO_HD void prior_residual(const Pose& c1, const double* Rf, const double* tf, c
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Matrix-free normal-equation operator.  The two Jacobian blocks of an edge are functions of 15 numbers:
+//   q2 (4), b = q1 (x) q_o (4), a' = R2^T R1 t_o (3), dt = R2^T v (3, unweighted), ws (edge weight w, or the switch value s)
+//   J1 = ws [ -2 [a']x R2^T , R2^T ; 2 M , 0 ]      J2 = ws [ 2 [dt]x R2^T , -R2^T ; -2 M , 0 ]      M = M(q2*, b)
+// (+ r6 = [dt ; 2 (q2* (x) b).vec] for switchable edges, whose Schur term is  u <- u - k (k.u),  k = r6 sqrt(1/(Js^T Js + lambda_s))).
+// compact_apply returns this edge's contribution to (J^T J p) at ONE endpoint: y = J_side^T (J1 p1 + J2 p2).
+// ---------------------------------------------------------------------------------------------
+constexpr int COMPACT_DOUBLES = 22;   // q2[4] b[4] ap[3] dt[3] ws r6[6] pad
+
+PGO_HD void edge_compact(const Pose& c1, const Pose& c2, const Meas& m, double ws, bool want_r6, double* rec) {
+    double R1[9], R2[9];
+    quat_to_rot(c1.qx, c1.qy, c1.qz, c1.qw, R1);
+    quat_to_rot(c2.qx, c2.qy, c2.qz, c2.qw, R2);
+    const double a0 = R1[0] * m.tx + R1[1] * m.ty + R1[2] * m.tz;
+    const double a1 = R1[3] * m.tx + R1[4] * m.ty + R1[5] * m.tz;
+    const double a2 = R1[6] * m.tx + R1[7] * m.ty + R1[8] * m.tz;
+    const double v0 = c1.tx + a0 - c2.tx, v1 = c1.ty + a1 - c2.ty, v2 = c1.tz + a2 - c2.tz;
+    const double q1[4] = {c1.qx, c1.qy, c1.qz, c1.qw};
+    const double qo[4] = {m.qx, m.qy, m.qz, m.qw};
+    double b[4];
+    quat_mul(q1, qo, b);
+    rec[0] = c2.qx; rec[1] = c2.qy; rec[2] = c2.qz; rec[3] = c2.qw;
+    rec[4] = b[0]; rec[5] = b[1]; rec[6] = b[2]; rec[7] = b[3];
+    rec[8] = R2[0] * a0 + R2[3] * a1 + R2[6] * a2;
+    rec[9] = R2[1] * a0 + R2[4] * a1 + R2[7] * a2;
+    rec[10] = R2[2] * a0 + R2[5] * a1 + R2[8] * a2;
+    rec[11] = R2[0] * v0 + R2[3] * v1 + R2[6] * v2;
+    rec[12] = R2[1] * v0 + R2[4] * v1 + R2[7] * v2;
+    rec[13] = R2[2] * v0 + R2[5] * v1 + R2[8] * v2;
+    rec[14] = ws;
+    if (want_r6) {
+        const double q2c[4] = {-c2.qx, -c2.qy, -c2.qz, c2.qw};
+        double dq[4];
+        quat_mul(q2c, b, dq);
+        rec[15] = rec[11]; rec[16] = rec[12]; rec[17] = rec[13];
+        rec[18] = 2.0 * dq[0]; rec[19] = 2.0 * dq[1]; rec[20] = 2.0 * dq[2];
+    } else {
+        rec[15] = 0.0; rec[16] = 0.0; rec[17] = 0.0; rec[18] = 0.0; rec[19] = 0.0; rec[20] = 0.0;
+    }
+    rec[21] = 0.0;
+}
+
+// side 0: own = c1, other = c2.  side 1: own = c2, other = c1.  kscale = sqrt(a_inv) for switchable edges, 0 otherwise.
+PGO_HD void compact_apply(const double* rec, int side, const double* p_own, const double* p_other, double kscale, double* y) {
+    const double* p1 = side ? p_other : p_own;
+    const double* p2 = side ? p_own : p_other;
+    double R2[9], M[9];
+    quat_to_rot(rec[0], rec[1], rec[2], rec[3], R2);
+    const double q2c[4] = {-rec[0], -rec[1], -rec[2], rec[3]};
+    quat_sandwich_jac(q2c, rec + 4, M);
+    const double ap0 = rec[8], ap1 = rec[9], ap2 = rec[10], d0 = rec[11], d1 = rec[12], d2 = rec[13], ws = rec[14];
+    // g1 = R2^T theta1, g2 = R2^T theta2, f = R2^T (tau1 - tau2)
+    const double g10 = R2[0] * p1[0] + R2[3] * p1[1] + R2[6] * p1[2], g11 = R2[1] * p1[0] + R2[4] * p1[1] + R2[7] * p1[2], g12 = R2[2] * p1[0] + R2[5] * p1[1] + R2[8] * p1[2];
+    const double g20 = R2[0] * p2[0] + R2[3] * p2[1] + R2[6] * p2[2], g21 = R2[1] * p2[0] + R2[4] * p2[1] + R2[7] * p2[2], g22 = R2[2] * p2[0] + R2[5] * p2[1] + R2[8] * p2[2];
+    const double t0 = p1[3] - p2[3], t1 = p1[4] - p2[4], t2 = p1[5] - p2[5];
+    const double f0 = R2[0] * t0 + R2[3] * t1 + R2[6] * t2, f1 = R2[1] * t0 + R2[4] * t1 + R2[7] * t2, f2 = R2[2] * t0 + R2[5] * t1 + R2[8] * t2;
+    // u_t = ws ( f + 2 (dt x g2 - a' x g1) ),  u_q = 2 ws M (theta1 - theta2)
+    double u[6];
+    u[0] = ws * (f0 + 2.0 * ((d1 * g22 - d2 * g21) - (ap1 * g12 - ap2 * g11)));
+    u[1] = ws * (f1 + 2.0 * ((d2 * g20 - d0 * g22) - (ap2 * g10 - ap0 * g12)));
+    u[2] = ws * (f2 + 2.0 * ((d0 * g21 - d1 * g20) - (ap0 * g11 - ap1 * g10)));
+    const double e0 = p1[0] - p2[0], e1 = p1[1] - p2[1], e2 = p1[2] - p2[2];
+    u[3] = 2.0 * ws * (M[0] * e0 + M[1] * e1 + M[2] * e2);
+    u[4] = 2.0 * ws * (M[3] * e0 + M[4] * e1 + M[5] * e2);
+    u[5] = 2.0 * ws * (M[6] * e0 + M[7] * e1 + M[8] * e2);
+    if (kscale != 0.0) {
+        double k[6], d = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { k[i] = rec[15 + i] * kscale; d += k[i] * u[i]; }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) u[i] -= k[i] * d;
+    }
+    // x = (a' or dt) x u_t ; w3 = R2 x + M^T u_q
+    const double c0 = side ? d0 : ap0, c1 = side ? d1 : ap1, c2 = side ? d2 : ap2;
+    const double x0 = c1 * u[2] - c2 * u[1], x1 = c2 * u[0] - c0 * u[2], x2 = c0 * u[1] - c1 * u[0];
+    const double m0 = M[0] * u[3] + M[3] * u[4] + M[6] * u[5], m1 = M[1] * u[3] + M[4] * u[4] + M[7] * u[5], m2 = M[2] * u[3] + M[5] * u[4] + M[8] * u[5];
+    const double sg = side ? -ws : ws;
+    y[0] = 2.0 * sg * (R2[0] * x0 + R2[1] * x1 + R2[2] * x2 + m0);
+    y[1] = 2.0 * sg * (R2[3] * x0 + R2[4] * x1 + R2[5] * x2 + m1);
+    y[2] = 2.0 * sg * (R2[6] * x0 + R2[7] * x1 + R2[8] * x2 + m2);
+    y[3] = sg * (R2[0] * u[0] + R2[1] * u[1] + R2[2] * u[2]);
+    y[4] = sg * (R2[3] * u[0] + R2[4] * u[1] + R2[5] * u[2]);
+    y[5] = sg * (R2[6] * u[0] + R2[7] * u[1] + R2[8] * u[2]);
+}
+
 // ceres::EigenQuaternionParameterization::Plus:  q+ = [sin|d| d/|d| ; cos|d|] (x) q
 PGO_HD void quat_plus(const double* q, const double* d, double* out) {
     const double n = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);

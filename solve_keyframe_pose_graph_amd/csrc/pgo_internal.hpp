@@ -32,6 +32,10 @@ constexpr int WIN_MAX = 96;        // poses per LDS window
 constexpr int WIN_STRIDE = 80;     // bytes per staged pose record (64 B + 16 B pad: conflict-free ds_read_b128)
 constexpr int MAX_PARTIALS = 1024; // grid cap for kernels that emit per-block partial sums
 constexpr int PRIOR_DOUBLES = 42;  // r6 + J1
+constexpr int MF_BLOCK = 512;      // lanes (edge-sides) per workgroup tile of the matrix-free operator
+constexpr int MF_MAX_NODES = 85;   // keyframes per tile (85 * 6 rows <= 512 lanes in the row phase)
+constexpr int MF_MAX_GRID = 1024;  // cap on matvec workgroups = p.q partial sums (measured: 1024 capped 50.8 us/iteration vs one workgroup per tile 54.5 us)
+constexpr int MF_PLANES = 11;      // COMPACT_DOUBLES / 2 double2 planes
 
 struct PriorDev {        // NodePoseRegularization target (rigid), see prior_residual()
     double Rf[9];
@@ -64,6 +68,22 @@ struct GraphDev {
     const int64_t* bsr_rowptr; const int32_t* bsr_col; int64_t nnzb;
 };
 
+// Matrix-free operator (PGO_LINEAR_PCG_MATRIX_FREE): one compact record per edge-side in keyframe-major ("incident") order,
+// stored as 11 double2 planes [plane][ninc_pad] so a workgroup tile reads 512 consecutive records with 1-KiB wave loads.
+struct MfDev {
+    const int64_t* einc;         // [ninc]  (slot << 1) | side, edges only, keyframe-major
+    const int32_t* einc_own;     // [ninc]  keyframe this edge-side belongs to
+    const int32_t* einc_other;   // [ninc]  the other endpoint
+    const int64_t* einc_rowptr;  // [N+1]
+    const int64_t* tile_inc0;    // [tiles+1] first edge-side of each workgroup tile (whole keyframes per tile, <= MF_BLOCK sides)
+    const int32_t* tile_node0;   // [tiles+1]
+    const int32_t* node_prior;   // [N] regulariser index or -1
+    double2* rec;                // [MF_PLANES][ninc_pad]
+    double* lam;                 // [N][6] LM damping in the unscaled space (identity rows for fixed keyframes)
+    int64_t ninc, ninc_pad;
+    int32_t tiles;
+};
+
 struct LinDev {            // per-linearisation products
     double* Hd; double* g; double* Hoff; double* c; double* hss; double* gs;
 };
@@ -88,15 +108,20 @@ struct CgDev {
 // ---- launchers (pgo_kernels.hip).  All asynchronous on `st`. ----
 void launch_k1(const GraphDev& G, const double* pose8, const double* sw, bool want_jacobian, double* partials /*[MAX_PARTIALS]*/, int* n_partials, hipStream_t st);
 void launch_prior(const GraphDev& G, const double* pose8, bool want_jacobian, double* partial_cost /*1 double*/, hipStream_t st);
-void launch_k2(const GraphDev& G, const LinDev& L, hipStream_t st);
+void launch_k2(const GraphDev& G, const LinDev& L, bool want_offdiag, hipStream_t st);
 void launch_scale_init(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, int jacobi_scaling, hipStream_t st);
 void launch_lm_diag(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, double min_diag, double max_diag, hipStream_t st);
-void launch_build_rows(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, double radius, int add_lambda, hipStream_t st);
+void launch_build_rows(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, double radius, int add_lambda, double* lam_out /*null: write BSR blocks*/, hipStream_t st);
+void launch_mf_compact(const GraphDev& G, const MfDev& F, const double* pose8, const double* sw, hipStream_t st);
+void launch_mf_spmv(const GraphDev& G, const MfDev& F, const ScaleDev& Sc, const CgDev& C, int k, double tol2, hipStream_t st);
+void launch_mf_apply(const GraphDev& G, const MfDev& F, const ScaleDev& Sc, const CgDev& C, const double* x, double* y, hipStream_t st);
 void launch_invert_rows(const GraphDev& G, const CgDev& C, int32_t* fail_flag, hipStream_t st);
 void launch_cg_init(const GraphDev& G, const CgDev& C, hipStream_t st);
 void launch_cg_spmv(const GraphDev& G, const CgDev& C, int k, double tol2, hipStream_t st);   // iteration k: direction + matvec (+ convergence test)
 void launch_cg_pq(const GraphDev& G, const CgDev& C, int k, hipStream_t st);   // multi-GPU: recompute p.q after the all-reduce of q
-void launch_cg_update(const GraphDev& G, const CgDev& C, int k, hipStream_t st);
+void launch_cg_update(const GraphDev& G, const CgDev& C, int k, int n_pq_partials, hipStream_t st);
+int cg_grid_size(const GraphDev& G);
+int mf_grid_size(const MfDev& F);
 void launch_apply_operator(const GraphDev& G, const CgDev& C, const double* x, double* y, hipStream_t st);
 void launch_model_change(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const double* delta_p, double* delta_s, double* partials, int* n_partials, hipStream_t st);
 void launch_plus(const GraphDev& G, const double* pose8, const double* sw, const double* delta_p, const double* delta_s,

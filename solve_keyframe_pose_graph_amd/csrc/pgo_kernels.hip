@@ -274,9 +274,9 @@ __global__ __launch_bounds__(256) void k2_node_kernel(GraphDev G, LinDev L) {
 }
 
 // one lane per edge: off-diagonal block J1^T J2 and, for switchable edges, [J1^T Js ; J2^T Js], Js^T Js, Js^T r
-__global__ __launch_bounds__(256) void k2_edge_kernel(GraphDev G, LinDev L) {
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void k2_edge_kernel(GraphDev G, LinDev L, int want_offdiag) {
     const int64_t nrel = G.rel.Epad;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + (want_offdiag ? 0 : nrel);
     if (gid >= nrel + G.sw.Epad) return;
     const bool is_sw = gid >= nrel;
     const int64_t e = is_sw ? gid - nrel : gid;
@@ -290,15 +290,17 @@ __global__ __launch_bounds__(256) void k2_edge_kernel(GraphDev G, LinDev L) {
     for (int kp = 0; kp < 18; ++kp) { const double2 v = base[(o1 + kp) * TILE]; J1[2 * kp] = v.x; J1[2 * kp + 1] = v.y; }
 #pragma unroll
     for (int kp = 0; kp < 18; ++kp) { const double2 v = base[(o2 + kp) * TILE]; J2[2 * kp] = v.x; J2[2 * kp + 1] = v.y; }
-    double* H = L.Hoff + (size_t)gid * 36;
+    if (want_offdiag) {
+        double* H = L.Hoff + (size_t)gid * 36;
 #pragma unroll
-    for (int a = 0; a < 6; ++a) {
+        for (int a = 0; a < 6; ++a) {
 #pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            double s = 0.0;
+            for (int c = 0; c < 6; ++c) {
+                double s = 0.0;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) s += J1[i * 6 + a] * J2[i * 6 + c];
-            H[a * 6 + c] = s;
+                for (int i = 0; i < 6; ++i) s += J1[i * 6 + a] * J2[i * 6 + c];
+                H[a * 6 + c] = s;
+            }
         }
     }
     if (is_sw) {
@@ -322,10 +324,12 @@ __global__ __launch_bounds__(256) void k2_edge_kernel(GraphDev G, LinDev L) {
     }
 }
 
-void launch_k2(const GraphDev& G, const LinDev& L, hipStream_t st) {
+void launch_k2(const GraphDev& G, const LinDev& L, bool want_offdiag, hipStream_t st) {
     if (G.N > 0) hipLaunchKernelGGL(k2_node_kernel, dim3((unsigned)((G.N + 255) / 256)), dim3(256), 0, st, G, L);
-    const int64_t ne = G.rel.Epad + G.sw.Epad;
-    if (ne > 0) hipLaunchKernelGGL(k2_edge_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, G, L);
+    // the matrix-free operator needs only the switch couplings: skip the relpose part of the edge range entirely
+    const int64_t first = want_offdiag ? 0 : G.rel.Epad;
+    const int64_t ne = G.rel.Epad + G.sw.Epad - first;
+    if (ne > 0) hipLaunchKernelGGL(k2_edge_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, G, L, want_offdiag ? 1 : 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -377,7 +381,8 @@ __global__ void sw_prepare_kernel(GraphDev G, LinDev L, ScaleDev Sc, double radi
     Sc.a_inv[e] = 1.0 / (L.hss[e] + Sc.diag_s[e] / (radius * s * s));
 }
 
-__global__ __launch_bounds__(256) void build_rows_kernel(GraphDev G, LinDev L, ScaleDev Sc, CgDev C, double radius, int add_lambda) {
+__global__ __launch_bounds__(256) void build_rows_kernel(GraphDev G, LinDev L, ScaleDev Sc, CgDev C, double radius, int add_lambda, double* __restrict__ lam_out) {
+    const bool write_val = lam_out == nullptr;
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= G.N) return;
     const bool free_node = G.node_free[n] != 0;
@@ -396,7 +401,10 @@ __global__ __launch_bounds__(256) void build_rows_kernel(GraphDev G, LinDev L, S
         if (slot >= slot_pr) break;   // regularisers come last in the list; they are already in Hd
         double B[36];
         const double* H = L.Hoff + (size_t)slot * 36;
-        if (side == 0) {
+        if (!write_val) {
+#pragma unroll
+            for (int i = 0; i < 36; ++i) B[i] = 0.0;
+        } else if (side == 0) {
 #pragma unroll
             for (int i = 0; i < 36; ++i) B[i] = H[i];
         } else {
@@ -420,6 +428,7 @@ __global__ __launch_bounds__(256) void build_rows_kernel(GraphDev G, LinDev L, S
                 for (int c = 0; c < 6; ++c) { D[a * 6 + c] -= cs[a] * cs[c] * ai; B[a * 6 + c] -= cs[a] * co[c] * ai; }
             }
         }
+        if (!write_val) continue;
         double* out = C.val + (size_t)(row0 + 1 + (k - b)) * 36;
         if (!free_node) {
 #pragma unroll
@@ -430,9 +439,14 @@ __global__ __launch_bounds__(256) void build_rows_kernel(GraphDev G, LinDev L, S
 #pragma unroll
             for (int c = 0; c < 6; ++c) out[pm(c, a)] = B[a * 6 + c];   // BSR blocks: COLUMN-pair-major (lane = column)
     }
+    double lam[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     if (add_lambda) {
 #pragma unroll
-        for (int c = 0; c < 6; ++c) { const double s = Sc.scale_p[(size_t)n * 6 + c]; D[c * 6 + c] += Sc.diag_p[(size_t)n * 6 + c] / (radius * s * s); }
+        for (int c = 0; c < 6; ++c) { const double s = Sc.scale_p[(size_t)n * 6 + c]; lam[c] = Sc.diag_p[(size_t)n * 6 + c] / (radius * s * s); D[c * 6 + c] += lam[c]; }
+    }
+    if (lam_out) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) lam_out[(size_t)n * 6 + c] = free_node ? lam[c] : (add_lambda ? 1.0 : 0.0);   // fixed keyframes: identity row
     }
     if (!free_node) {
 #pragma unroll
@@ -443,7 +457,7 @@ __global__ __launch_bounds__(256) void build_rows_kernel(GraphDev G, LinDev L, S
 #pragma unroll
     for (int a = 0; a < 6; ++a)
 #pragma unroll
-        for (int c = 0; c < 6; ++c) { C.val[(size_t)row0 * 36 + pm(c, a)] = D[a * 6 + c]; C.Dtot[(size_t)n * 36 + a * 6 + c] = D[a * 6 + c]; }
+        for (int c = 0; c < 6; ++c) { if (write_val) C.val[(size_t)row0 * 36 + pm(c, a)] = D[a * 6 + c]; C.Dtot[(size_t)n * 36 + a * 6 + c] = D[a * 6 + c]; }
 #pragma unroll
     for (int i = 0; i < 6; ++i) C.b[(size_t)n * 6 + i] = bv[i];
 }
@@ -517,9 +531,9 @@ __global__ __launch_bounds__(256) void invert_rows_kernel(GraphDev G, CgDev C, i
         for (int c = 0; c < 6; ++c) C.Minv[(size_t)n * 36 + pm(a, c)] = Di[a * 6 + c];
 }
 
-void launch_build_rows(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, double radius, int add_lambda, hipStream_t st) {
+void launch_build_rows(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, double radius, int add_lambda, double* lam_out, hipStream_t st) {
     if (G.sw.E > 0) hipLaunchKernelGGL(sw_prepare_kernel, dim3((unsigned)((G.sw.E + 255) / 256)), dim3(256), 0, st, G, L, Sc, radius);
-    if (G.N > 0) hipLaunchKernelGGL(build_rows_kernel, dim3((unsigned)((G.N + 255) / 256)), dim3(256), 0, st, G, L, Sc, C, radius, add_lambda);
+    if (G.N > 0) hipLaunchKernelGGL(build_rows_kernel, dim3((unsigned)((G.N + 255) / 256)), dim3(256), 0, st, G, L, Sc, C, radius, add_lambda, lam_out);
 }
 void launch_invert_rows(const GraphDev& G, const CgDev& C, int32_t* fail_flag, hipStream_t st) {
     if (G.N > 0) hipLaunchKernelGGL(invert_rows_kernel, dim3((unsigned)((G.N + 255) / 256)), dim3(256), 0, st, G, C, fail_flag);
@@ -702,10 +716,10 @@ __global__ void cg_scalars_init_kernel(CgDev C, int nparts) {
 }
 
 // alpha = rz/pq ; x += alpha p ; r' = r - alpha q ; z = Minv r' ; partial r'.z -> part_rz[parity^1]
-__global__ __launch_bounds__(CG_BLOCK) void cg_update_kernel(GraphDev G, CgDev C, int parity, int nparts) {
+__global__ __launch_bounds__(CG_BLOCK) void cg_update_kernel(GraphDev G, CgDev C, int parity, int nparts_pq, int nparts) {
     __shared__ double red[CG_BLOCK / 64];
     if (cg_done(C)) return;
-    const double pq = block_total(C.part_pq, nparts, red);
+    const double pq = block_total(C.part_pq, nparts_pq, red);   // produced by the matvec kernel (its own grid size)
     const double rz = block_total(C.part_rz + parity * MAX_PARTIALS, nparts, red);
     if (!(pq > 0.0)) {   // breakdown: matrix not positive definite along p (or NaN); x is left untouched, the next spmv raises done
         if (blockIdx.x == 0 && threadIdx.x == 0) C.flags[1] = 1;
@@ -756,8 +770,157 @@ void launch_cg_spmv(const GraphDev& G, const CgDev& C, int k, double tol2, hipSt
     hipLaunchKernelGGL(cg_spmv_kernel, dim3(g), dim3(CG_BLOCK), 0, st, G, C, k & 1, k == 0 ? 1 : 0, g, tol2);
 }
 void launch_cg_pq(const GraphDev& G, const CgDev& C, int k, hipStream_t st) { hipLaunchKernelGGL(cg_pq_kernel, dim3(cg_grid(G)), dim3(CG_BLOCK), 0, st, G, C, k & 1); }
-void launch_cg_update(const GraphDev& G, const CgDev& C, int k, hipStream_t st) { const int g = cg_grid(G); hipLaunchKernelGGL(cg_update_kernel, dim3(g), dim3(CG_BLOCK), 0, st, G, C, k & 1, g); }
+void launch_cg_update(const GraphDev& G, const CgDev& C, int k, int n_pq_partials, hipStream_t st) { const int g = cg_grid(G); hipLaunchKernelGGL(cg_update_kernel, dim3(g), dim3(CG_BLOCK), 0, st, G, C, k & 1, n_pq_partials, g); }
+int cg_grid_size(const GraphDev& G) { return cg_grid(G); }
 void launch_apply_operator(const GraphDev& G, const CgDev& C, const double* x, double* y, hipStream_t st) { hipLaunchKernelGGL(apply_operator_kernel, dim3(cg_grid(G)), dim3(CG_BLOCK), 0, st, G, C, x, y); }
+
+// ------------------------------------------------------------------------------------------------
+// K3 (matrix-free) — the PCG matvec without an assembled matrix.  Per edge-side one compact record of 22 doubles
+// (q2, q1 (x) q_o, a', dt, w|s, r6: pgo_device_math.hpp) instead of a 288-B block; the diagonal blocks need no storage at all
+// (sum_e J_i^T J_i p_i falls out of the per-edge products).  Bytes per PCG matvec on C3: 600k x 176 B = 106 MB instead of 202 MB.
+//   phase A  one lane per edge-side of the workgroup's keyframes: y_e = J_side^T (I - k k^T)(J1 p1 + J2 p2)  -> LDS
+//   phase B  one lane per (keyframe, row): sum of the keyframe's edge-sides in list order (deterministic) + damping + regulariser
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mf_compact_kernel(GraphDev G, MfDev F, const double* __restrict__ pose8, const double* __restrict__ swv) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= F.ninc) return;
+    const int64_t slot = F.einc[i] >> 1;
+    const bool is_sw = slot >= G.rel.Epad;
+    const EdgeClassDev& C = is_sw ? G.sw : G.rel;
+    const int64_t e = is_sw ? slot - G.rel.Epad : slot;
+    const Pose P1 = load_pose_global(pose8, C.c1[e]);
+    const Pose P2 = load_pose_global(pose8, C.c2[e]);
+    const double* mp = C.meas + e;
+    const size_t ep = (size_t)C.Epad;
+    const Meas M{mp[0], mp[ep], mp[2 * ep], mp[3 * ep], mp[4 * ep], mp[5 * ep], mp[6 * ep], mp[7 * ep]};
+    const double ws = is_sw ? swv[C.swidx[e]] : M.w;
+    double rec[COMPACT_DOUBLES];
+    edge_compact(P1, P2, M, ws, is_sw, rec);
+#pragma unroll
+    for (int pl = 0; pl < MF_PLANES; ++pl) F.rec[(size_t)pl * F.ninc_pad + i] = make_double2(rec[2 * pl], rec[2 * pl + 1]);
+}
+
+template <bool FUSED>
+__global__ __launch_bounds__(MF_BLOCK) void mf_spmv_kernel(GraphDev G, MfDev F, ScaleDev Sc, CgDev C, const double* __restrict__ xin, double* __restrict__ yout,
+                                                           int parity, int first, int nparts, double tol2) {
+    __shared__ double contrib[MF_BLOCK * 7];
+    __shared__ double pwin[MF_BLOCK];
+    __shared__ double red[MF_BLOCK / 64];
+    double beta = 0.0;
+    if (FUSED) {
+        if (cg_done(C)) return;
+        if (!first) {
+            const double rz_new = block_total(C.part_rz + parity * MAX_PARTIALS, nparts, red);
+            const double rz_old = block_total(C.part_rz + (parity ^ 1) * MAX_PARTIALS, nparts, red);
+            const bool breakdown = C.flags[1] != 0;
+            if (breakdown || !(rz_new > tol2 * C.scal[0])) {
+                if (blockIdx.x == 0 && threadIdx.x == 0) { C.flags[0] = 1; if (!breakdown) C.scal[1] = rz_new; }
+                return;
+            }
+            beta = rz_new / rz_old;
+            if (blockIdx.x == 0 && threadIdx.x == 0) C.scal[1] = rz_new;
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) C.flags[2] += 1;
+    }
+    const double* __restrict__ pprev = FUSED ? (parity ? C.p : C.p2) : xin;
+    double* __restrict__ pcur = parity ? C.p2 : C.p;
+    const double* __restrict__ z = FUSED ? C.z : xin;
+    const int64_t slot_sw = G.rel.Epad;
+    const int l = threadIdx.x;
+    double pq = 0.0;
+    for (int tile = blockIdx.x; tile < F.tiles; tile += gridDim.x) {
+        const int64_t i0 = F.tile_inc0[tile], i1 = F.tile_inc0[tile + 1];
+        const int32_t n0 = F.tile_node0[tile], n1 = F.tile_node0[tile + 1];
+        const int64_t i = i0 + l;
+        const int nn = n1 - n0;
+        // phase 0: the tile's own keyframes' input vector p = z + beta p_prev, once, into LDS (every edge-side of a keyframe needs it,
+        // and odometry neighbours are inside the same window): only far endpoints of loop closures gather from global memory
+        if (l < nn * 6) {
+            const size_t vi = (size_t)n0 * 6 + l;
+            double v = z[vi];
+            if (FUSED) v += beta * pprev[vi];
+            pwin[l] = v;
+        }
+        __syncthreads();
+        if (i < i1) {
+            const int64_t ent = F.einc[i];
+            const int64_t slot = ent >> 1;
+            const int side = (int)(ent & 1);
+            const int32_t own = F.einc_own[i], other = F.einc_other[i];
+            double rec[COMPACT_DOUBLES];
+#pragma unroll
+            for (int pl = 0; pl < MF_PLANES; ++pl) { const double2 v = F.rec[(size_t)pl * F.ninc_pad + i]; rec[2 * pl] = v.x; rec[2 * pl + 1] = v.y; }
+            double po[6], pt[6];
+            {
+                const double* a = pwin + (own - n0) * 6;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) po[c] = a[c];
+            }
+            if (other >= n0 && other < n1) {
+                const double* b = pwin + (other - n0) * 6;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) pt[c] = b[c];
+            } else {
+                const double2* b = reinterpret_cast<const double2*>(z + (size_t)other * 6);
+                const double2 b0 = b[0], b1 = b[1], b2 = b[2];
+                pt[0] = b0.x; pt[1] = b0.y; pt[2] = b1.x; pt[3] = b1.y; pt[4] = b2.x; pt[5] = b2.y;
+                if (FUSED) {
+                    const double2* c = reinterpret_cast<const double2*>(pprev + (size_t)other * 6);
+                    const double2 c0 = c[0], c1 = c[1], c2 = c[2];
+                    pt[0] += beta * c0.x; pt[1] += beta * c0.y; pt[2] += beta * c1.x; pt[3] += beta * c1.y; pt[4] += beta * c2.x; pt[5] += beta * c2.y;
+                }
+            }
+            const double kscale = slot >= slot_sw ? sqrt(Sc.a_inv[slot - slot_sw]) : 0.0;
+            double y[6];
+            compact_apply(rec, side, po, pt, kscale, y);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) contrib[l * 7 + r] = y[r];
+        }
+        __syncthreads();
+        if (l < nn * 6) {
+            const int nl = l / 6, r = l - nl * 6;
+            const int64_t node = (int64_t)n0 + nl;
+            const int b = (int)(F.einc_rowptr[node] - i0), e = (int)(F.einc_rowptr[node + 1] - i0);
+            const size_t vi = (size_t)node * 6 + r;
+            const double pr = pwin[l];
+            double acc = F.lam[vi] * pr;
+            if (G.node_free[node]) {
+                for (int j = b; j < e; ++j) acc += contrib[j * 7 + r];
+                const int32_t pk = F.node_prior[node];
+                if (pk >= 0) {   // regulariser: J^T J p of a unary block (a handful per graph)
+                    const double* Jp = G.Jp + (size_t)pk * PRIOR_DOUBLES + 6;
+                    double pn[6];
+                    for (int c = 0; c < 6; ++c) pn[c] = pwin[nl * 6 + c];
+                    double s = 0.0;
+                    for (int ii = 0; ii < 6; ++ii) { double t = 0.0; for (int c = 0; c < 6; ++c) t += Jp[ii * 6 + c] * pn[c]; s += Jp[ii * 6 + r] * t; }
+                    acc += s;
+                }
+            }
+            if (FUSED) { pcur[vi] = pr; C.q[vi] = acc; pq += acc * pr; }
+            else yout[vi] = acc;
+        }
+        __syncthreads();
+    }
+    if (FUSED) {
+        const double s = block_sum(pq, red);
+        if (threadIdx.x == 0) C.part_pq[blockIdx.x] = s;
+    }
+}
+
+// one workgroup per tile up to MF_MAX_GRID (its p.q partials are consumed by cg_update only); beyond that an even number of trips
+static inline int mf_grid(const MfDev& F) { const int g = F.tiles < MF_MAX_GRID ? F.tiles : MF_MAX_GRID; return g < 1 ? 1 : g; }
+int mf_grid_size(const MfDev& F) { return mf_grid(F); }
+void launch_mf_compact(const GraphDev& G, const MfDev& F, const double* pose8, const double* sw, hipStream_t st) {
+    if (F.ninc > 0) hipLaunchKernelGGL(mf_compact_kernel, dim3((unsigned)((F.ninc + 255) / 256)), dim3(256), 0, st, G, F, pose8, sw);
+}
+void launch_mf_spmv(const GraphDev& G, const MfDev& F, const ScaleDev& Sc, const CgDev& C, int k, double tol2, hipStream_t st) {
+    const int g = mf_grid(F);
+    // the partial-sum count consumed here is the one cg_init / cg_update produced (cg_grid); the one produced is mf_grid
+    hipLaunchKernelGGL(mf_spmv_kernel<true>, dim3(g), dim3(MF_BLOCK), 0, st, G, F, Sc, C, (const double*)nullptr, (double*)nullptr, k & 1, k == 0 ? 1 : 0, cg_grid(G), tol2);
+}
+void launch_mf_apply(const GraphDev& G, const MfDev& F, const ScaleDev& Sc, const CgDev& C, const double* x, double* y, hipStream_t st) {
+    hipLaunchKernelGGL(mf_spmv_kernel<false>, dim3(mf_grid(F)), dim3(MF_BLOCK), 0, st, G, F, Sc, C, x, y, 0, 1, 0, 0.0);
+}
 
 // ------------------------------------------------------------------------------------------------
 // step finish: switch back-substitution  ds = -(gs + c1.d1 + c2.d2) a_inv  and

@@ -94,6 +94,13 @@ struct pgo_problem {
     DBuf<double> d_scal;             // S_N doubles
     DBuf<double> d_pose[2], d_swv[2], d_delta_s, d_io;   // state ping-pong, staging for quat/t
     DBuf<double> d_tmp;
+    // matrix-free operator
+    DBuf<int64_t> d_einc, d_einc_rowptr, d_tile_inc0;
+    DBuf<int32_t> d_einc_own, d_einc_other, d_tile_node0, d_node_prior;
+    DBuf<double2> d_rec;
+    DBuf<double> d_lam;
+    MfDev F{};
+    bool built_mf = false;
     int cur = 0;
     int64_t n_part = MAX_PARTIALS;
     std::vector<uint8_t> h_node_free, h_sw_used;
@@ -232,21 +239,73 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S) {
     if (Eg) HIPCHK(p, hipMemcpyAsync(p->d_prior.p, p->priors.data(), Eg * sizeof(PriorDev), hipMemcpyHostToDevice, p->st));
     HIPCHK(p, hipStreamSynchronize(p->st));
 
+    // ---- matrix-free operator: edge-sides in keyframe-major order, packed into workgroup tiles of whole keyframes
+    const bool mf = p->opt.linear_solver == PGO_LINEAR_PCG_MATRIX_FREE;
+    p->built_mf = mf;
+    p->F = MfDev{};
+    if (mf) {
+        std::vector<int64_t> erow(N + 1, 0), einc; std::vector<int32_t> eown, eoth, node_prior(N, -1);
+        einc.reserve((size_t)2 * (Er + Es)); eown.reserve(einc.capacity()); eoth.reserve(einc.capacity());
+        const int64_t slot_pr = G.rel.Epad + G.sw.Epad;
+        for (int64_t n = 0; n < N; ++n) {
+            for (int64_t k = rowptr[n]; k < rowptr[n + 1]; ++k) {
+                const int64_t slot = inc[k] >> 1; const int side = (int)(inc[k] & 1);
+                if (slot >= slot_pr) {
+                    if (node_prior[n] >= 0) { p->err = "matrix-free operator: more than one regulariser on a keyframe"; return PGO_ERR_INVALID_ARG; }
+                    node_prior[n] = (int32_t)(slot - slot_pr);
+                    continue;
+                }
+                const bool is_sw = slot >= G.rel.Epad;
+                const int64_t e = is_sw ? slot - G.rel.Epad : slot;
+                const int32_t a = is_sw ? p->swe.c1[e] : p->rel.c1[e], b = is_sw ? p->swe.c2[e] : p->rel.c2[e];
+                einc.push_back(inc[k]); eown.push_back((int32_t)n); eoth.push_back(side == 0 ? b : a);
+            }
+            erow[n + 1] = (int64_t)einc.size();
+        }
+        std::vector<int64_t> tile_inc0; std::vector<int32_t> tile_node0;
+        tile_inc0.push_back(0); tile_node0.push_back(0);
+        int64_t cur = 0; int cur_nodes = 0;
+        for (int64_t n = 0; n < N; ++n) {
+            const int64_t d = erow[n + 1] - erow[n];
+            if (d > MF_BLOCK) { p->err = "matrix-free operator: a keyframe with more than 512 incident edges (use PGO_LINEAR_PCG_BLOCK_JACOBI)"; return PGO_ERR_INVALID_ARG; }
+            if (cur + d > MF_BLOCK || cur_nodes >= MF_MAX_NODES) { tile_inc0.push_back(erow[n]); tile_node0.push_back((int32_t)n); cur = 0; cur_nodes = 0; }
+            cur += d; ++cur_nodes;
+        }
+        tile_inc0.push_back(erow[N]); tile_node0.push_back((int32_t)N);
+        const int64_t ninc_e = (int64_t)einc.size();
+        const int64_t ninc_pad = (ninc_e + 63) / 64 * 64 + 64;
+        const int tiles = (int)tile_node0.size() - 1;
+        HIPCHK(p, p->d_einc.ensure(std::max<int64_t>(ninc_e, 1))); HIPCHK(p, p->d_einc_own.ensure(std::max<int64_t>(ninc_e, 1))); HIPCHK(p, p->d_einc_other.ensure(std::max<int64_t>(ninc_e, 1)));
+        HIPCHK(p, p->d_einc_rowptr.ensure(N + 1)); HIPCHK(p, p->d_tile_inc0.ensure(tiles + 1)); HIPCHK(p, p->d_tile_node0.ensure(tiles + 1)); HIPCHK(p, p->d_node_prior.ensure(std::max<int64_t>(N, 1)));
+        HIPCHK(p, p->d_rec.ensure((size_t)MF_PLANES * ninc_pad)); HIPCHK(p, p->d_lam.ensure(std::max<int64_t>(N * 6, 1)));
+        if (ninc_e) {
+            HIPCHK(p, hipMemcpyAsync(p->d_einc.p, einc.data(), ninc_e * sizeof(int64_t), hipMemcpyHostToDevice, p->st));
+            HIPCHK(p, hipMemcpyAsync(p->d_einc_own.p, eown.data(), ninc_e * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
+            HIPCHK(p, hipMemcpyAsync(p->d_einc_other.p, eoth.data(), ninc_e * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
+        }
+        HIPCHK(p, hipMemcpyAsync(p->d_einc_rowptr.p, erow.data(), (N + 1) * sizeof(int64_t), hipMemcpyHostToDevice, p->st));
+        HIPCHK(p, hipMemcpyAsync(p->d_tile_inc0.p, tile_inc0.data(), (tiles + 1) * sizeof(int64_t), hipMemcpyHostToDevice, p->st));
+        HIPCHK(p, hipMemcpyAsync(p->d_tile_node0.p, tile_node0.data(), (tiles + 1) * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
+        HIPCHK(p, hipMemcpyAsync(p->d_node_prior.p, node_prior.data(), N * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
+        HIPCHK(p, hipStreamSynchronize(p->st));
+        p->F = MfDev{p->d_einc.p, p->d_einc_own.p, p->d_einc_other.p, p->d_einc_rowptr.p, p->d_tile_inc0.p, p->d_tile_node0.p, p->d_node_prior.p,
+                     p->d_rec.p, p->d_lam.p, ninc_e, ninc_pad, tiles};
+    }
     // ---- work buffers
     const int64_t slots = G.rel.Epad + G.sw.Epad;
     HIPCHK(p, p->d_Jr.ensure(std::max<int64_t>((int64_t)G.rel.tiles * REL_DOUBLES * TILE, 1)));
     HIPCHK(p, p->d_Js.ensure(std::max<int64_t>((int64_t)G.sw.tiles * SW_DOUBLES * TILE, 1)));
     HIPCHK(p, p->d_Jp.ensure(std::max<int64_t>(Eg * PRIOR_DOUBLES, 1)));
     HIPCHK(p, p->d_Hd_g.ensure(std::max<int64_t>(N * 42, 1)));
-    HIPCHK(p, p->d_Hoff.ensure(std::max<int64_t>(slots * 36, 1)));
+    HIPCHK(p, p->d_Hoff.ensure(mf ? 1 : std::max<int64_t>(slots * 36, 1)));
     HIPCHK(p, p->d_c.ensure(std::max<int64_t>(Es * 12, 1))); HIPCHK(p, p->d_hss.ensure(std::max<int64_t>(Es, 1))); HIPCHK(p, p->d_gs.ensure(std::max<int64_t>(Es, 1)));
     HIPCHK(p, p->d_scale_p.ensure(std::max<int64_t>(N * 6, 1))); HIPCHK(p, p->d_diag_p.ensure(std::max<int64_t>(N * 6, 1)));
     HIPCHK(p, p->d_scale_s.ensure(std::max<int64_t>(Es, 1))); HIPCHK(p, p->d_diag_s.ensure(std::max<int64_t>(Es, 1))); HIPCHK(p, p->d_a_inv.ensure(std::max<int64_t>(Es, 1)));
-    HIPCHK(p, p->d_val.ensure(std::max<int64_t>(p->nnzb * 36, 1))); HIPCHK(p, p->d_Minv.ensure(std::max<int64_t>(N * 36, 1))); HIPCHK(p, p->d_Dtot_b.ensure(std::max<int64_t>(N * 42, 1)));
+    HIPCHK(p, p->d_val.ensure(mf ? 1 : std::max<int64_t>(p->nnzb * 36, 1))); HIPCHK(p, p->d_Minv.ensure(std::max<int64_t>(N * 36, 1))); HIPCHK(p, p->d_Dtot_b.ensure(std::max<int64_t>(N * 42, 1)));
     HIPCHK(p, p->d_cgvec.ensure(std::max<int64_t>(N * 42, 1)));
     p->n_part = std::max<int64_t>(MAX_PARTIALS, (G.rel.tiles + G.sw.tiles + 3) / 4 + 1);
     HIPCHK(p, p->d_part.ensure(p->n_part * 6));
-    HIPCHK(p, p->d_cgpart.ensure(3 * MAX_PARTIALS + 8));
+    HIPCHK(p, p->d_cgpart.ensure(MF_MAX_GRID + 2 * MAX_PARTIALS + 8));
     HIPCHK(p, p->d_flags.ensure(8)); HIPCHK(p, p->d_scal.ensure(S_N));
     for (int k = 0; k < 2; ++k) { HIPCHK(p, p->d_pose[k].ensure(std::max<int64_t>(N * 8, 1))); HIPCHK(p, p->d_swv[k].ensure(std::max<int64_t>(S, 1))); }
     HIPCHK(p, p->d_delta_s.ensure(std::max<int64_t>(Es, 1))); HIPCHK(p, p->d_io.ensure(std::max<int64_t>(N * 7, 1)));
@@ -261,7 +320,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S) {
     C.val = p->d_val.p; C.Minv = p->d_Minv.p; C.Dtot = p->d_Dtot_b.p; C.b = p->d_Dtot_b.p + (size_t)N * 36;
     double* v = p->d_cgvec.p; const size_t n6 = (size_t)N * 6;
     C.x = v; C.r = v + n6; C.r2 = v + 2 * n6; C.z = v + 3 * n6; C.p = v + 4 * n6; C.p2 = v + 5 * n6; C.q = v + 6 * n6;
-    C.part_pq = p->d_cgpart.p; C.part_rz = p->d_cgpart.p + MAX_PARTIALS; C.scal = p->d_cgpart.p + 3 * MAX_PARTIALS;
+    C.part_pq = p->d_cgpart.p; C.part_rz = p->d_cgpart.p + MF_MAX_GRID; C.scal = p->d_cgpart.p + MF_MAX_GRID + 2 * MAX_PARTIALS;
     C.flags = p->d_flags.p;
     p->graph_dirty = false; p->priors_dirty = false;
     return PGO_OK;
@@ -301,7 +360,8 @@ int read_scalars(pgo_problem* p, double* h) {
 int linearize(pgo_problem* p, double* cost_out) {
     int rc;
     if ((rc = run_k1(p, p->cur, true)) != PGO_OK) return rc;
-    launch_k2(p->G, p->L, p->st);
+    launch_k2(p->G, p->L, !p->built_mf, p->st);
+    if (p->built_mf) launch_mf_compact(p->G, p->F, p->d_pose[p->cur].p, p->d_swv[p->cur].p, p->st);
     if ((rc = allreduce(p, p->d_Hd_g.p, (size_t)p->N * 42, 0)) != PGO_OK) return rc;
     if (!p->scale_ready) { launch_scale_init(p->G, p->L, p->Sc, p->opt.jacobi_scaling, p->st); p->scale_ready = true; }
     int np = 0;
@@ -332,12 +392,15 @@ int run_pcg(pgo_problem* p, CgResult* res) {
     while (k < o.cg_max_iterations) {
         const int chunk = std::min(every, o.cg_max_iterations - k);
         for (int j = 0; j < chunk; ++j, ++k) {
-            launch_cg_spmv(p->G, p->C, k, tol2, p->st);
+            int n_pq = cg_grid_size(p->G);
+            if (p->built_mf) { launch_mf_spmv(p->G, p->F, p->Sc, p->C, k, tol2, p->st); n_pq = mf_grid_size(p->F); }
+            else launch_cg_spmv(p->G, p->C, k, tol2, p->st);
             if (p->world > 1) {
                 if ((rc = allreduce(p, p->C.q, (size_t)p->N * 6, 0)) != PGO_OK) return rc;   // the one exchange per CG matvec
                 launch_cg_pq(p->G, p->C, k, p->st);
+                n_pq = cg_grid_size(p->G);
             }
-            launch_cg_update(p->G, p->C, k, p->st);
+            launch_cg_update(p->G, p->C, k, n_pq, p->st);
         }
         HIPCHK(p, hipMemcpyAsync(hflags, p->C.flags, sizeof(hflags), hipMemcpyDeviceToHost, p->st));
         HIPCHK(p, hipMemcpyAsync(hscal, p->C.scal, sizeof(hscal), hipMemcpyDeviceToHost, p->st));
@@ -345,7 +408,8 @@ int run_pcg(pgo_problem* p, CgResult* res) {
         if (hflags[0]) break;
     }
     if (!hflags[0]) {   // iteration cap reached: one more convergence test so that scal[1] holds the last r.z (x is already final)
-        launch_cg_spmv(p->G, p->C, k, 1e300, p->st);
+        if (p->built_mf) launch_mf_spmv(p->G, p->F, p->Sc, p->C, k, 1e300, p->st);
+        else launch_cg_spmv(p->G, p->C, k, 1e300, p->st);
         HIPCHK(p, hipMemcpyAsync(hflags, p->C.flags, sizeof(hflags), hipMemcpyDeviceToHost, p->st));
         HIPCHK(p, hipMemcpyAsync(hscal, p->C.scal, sizeof(hscal), hipMemcpyDeviceToHost, p->st));
         HIPCHK(p, hipStreamSynchronize(p->st));
@@ -359,7 +423,7 @@ int run_pcg(pgo_problem* p, CgResult* res) {
 int build_system(pgo_problem* p, bool* ok) {
     int rc;
     HIPCHK(p, hipMemsetAsync(p->d_flags.p + 4, 0, sizeof(int32_t), p->st));
-    launch_build_rows(p->G, p->L, p->Sc, p->C, p->radius, p->rank == 0 ? 1 : 0, p->st);
+    launch_build_rows(p->G, p->L, p->Sc, p->C, p->radius, p->rank == 0 ? 1 : 0, p->built_mf ? p->d_lam.p : nullptr, p->st);
     if ((rc = allreduce(p, p->d_Dtot_b.p, (size_t)p->N * 42, 0)) != PGO_OK) return rc;
     launch_invert_rows(p->G, p->C, p->d_flags.p + 4, p->st);
     int32_t fail = 0;
@@ -577,7 +641,7 @@ void pgo_options_init(pgo_options* o) {
     if (!o) return;
     std::memset(o, 0, sizeof(*o));
     o->max_num_iterations = 10;          // src/PoseGraphSLAM.cpp:1272
-    o->linear_solver = PGO_LINEAR_PCG_BLOCK_JACOBI;
+    o->linear_solver = PGO_LINEAR_PCG_MATRIX_FREE;
     o->jacobi_scaling = 1;
     o->max_num_consecutive_invalid_steps = 5;
     o->initial_trust_region_radius = 1e4;
@@ -627,6 +691,8 @@ int pgo_destroy(pgo_problem* p) {
     p->d_val.release(); p->d_Minv.release(); p->d_Dtot_b.release(); p->d_cgvec.release(); p->d_part.release(); p->d_cgpart.release();
     p->d_flags.release(); p->d_scal.release(); p->d_pose[0].release(); p->d_pose[1].release(); p->d_swv[0].release(); p->d_swv[1].release();
     p->d_delta_s.release(); p->d_io.release(); p->d_tmp.release();
+    p->d_einc.release(); p->d_einc_rowptr.release(); p->d_tile_inc0.release(); p->d_einc_own.release(); p->d_einc_other.release();
+    p->d_tile_node0.release(); p->d_node_prior.release(); p->d_rec.release(); p->d_lam.release();
     (void)hipStreamDestroy(p->st);
     delete p;
     return PGO_OK;
@@ -635,6 +701,7 @@ int pgo_destroy(pgo_problem* p) {
 int pgo_set_options(pgo_problem* p, const pgo_options* o) {
     if (!p || !o) return PGO_ERR_INVALID_ARG;
     const int dev = p->opt.device_id;
+    if (o->linear_solver != p->opt.linear_solver) p->graph_dirty = true;
     p->opt = *o;
     p->opt.device_id = dev;   // the device binding is fixed at create
     return PGO_OK;
@@ -763,6 +830,11 @@ int pgo_get_normal_blocks(pgo_problem* p, double* diag, double* grad, double* of
     const int64_t N = p->N, Er = p->G.rel.E, Es = p->G.sw.E;
     if (diag) HIPCHK(p, hipMemcpyAsync(diag, p->L.Hd, N * 36 * sizeof(double), hipMemcpyDeviceToHost, p->st));
     if (grad) HIPCHK(p, hipMemcpyAsync(grad, p->L.g, N * 6 * sizeof(double), hipMemcpyDeviceToHost, p->st));
+    if (offdiag && p->built_mf) {   // the matrix-free solver never forms J1^T J2: compute it for the parity hook only
+        HIPCHK(p, p->d_Hoff.ensure((size_t)(p->G.rel.Epad + p->G.sw.Epad) * 36));
+        p->L.Hoff = p->d_Hoff.p;
+        launch_k2(p->G, p->L, true, p->st);
+    }
     if (offdiag) {
         if (Er) HIPCHK(p, hipMemcpyAsync(offdiag, p->L.Hoff, Er * 36 * sizeof(double), hipMemcpyDeviceToHost, p->st));
         if (Es) HIPCHK(p, hipMemcpyAsync(offdiag + Er * 36, p->L.Hoff + (size_t)p->G.rel.Epad * 36, Es * 36 * sizeof(double), hipMemcpyDeviceToHost, p->st));
@@ -785,7 +857,8 @@ int pgo_apply_normal_operator(pgo_problem* p, const double* x, double* y) {
     if ((rc = build_system(p, &ok)) != PGO_OK) return rc;
     HIPCHK(p, p->d_tmp.ensure((size_t)p->N * 12));
     HIPCHK(p, hipMemcpyAsync(p->d_tmp.p, x, (size_t)p->N * 6 * sizeof(double), hipMemcpyHostToDevice, p->st));
-    launch_apply_operator(p->G, p->C, p->d_tmp.p, p->d_tmp.p + (size_t)p->N * 6, p->st);
+    if (p->built_mf) launch_mf_apply(p->G, p->F, p->Sc, p->C, p->d_tmp.p, p->d_tmp.p + (size_t)p->N * 6, p->st);
+    else launch_apply_operator(p->G, p->C, p->d_tmp.p, p->d_tmp.p + (size_t)p->N * 6, p->st);
     if ((rc = allreduce(p, p->d_tmp.p + (size_t)p->N * 6, (size_t)p->N * 6, 0)) != PGO_OK) return rc;
     HIPCHK(p, hipMemcpyAsync(y, p->d_tmp.p + (size_t)p->N * 6, (size_t)p->N * 6 * sizeof(double), hipMemcpyDeviceToHost, p->st));
     HIPCHK(p, hipStreamSynchronize(p->st));
@@ -864,9 +937,11 @@ int pgo_time_kernel(pgo_problem* p, int32_t which, int32_t launches, double* avg
         for (int i = 0; i < n; ++i) {
             switch (which) {
                 case 0: launch_k1(G, p->d_pose[p->cur].p, p->d_swv[p->cur].p, true, part(p, 0), &np, p->st); bytes = k1_algorithmic_bytes(G, true); break;
-                case 1: launch_k2(G, p->L, p->st); bytes = (624.0 * G.rel.E + 688.0 * Es) + 288.0 * E + 336.0 * N + 112.0 * Es; break;
-                case 2: launch_cg_spmv(G, p->C, rep == 0 ? 0 : i + 1, 0.0, p->st); launch_cg_update(G, p->C, rep == 0 ? 0 : i + 1, p->st);
-                        bytes = 288.0 * (N + E) + 104.0 * Es + 288.0 * N + 80.0 * (6.0 * N + Es); break;
+                case 1: launch_k2(G, p->L, !p->built_mf, p->st); bytes = (624.0 * G.rel.E + 688.0 * Es) + 288.0 * E + 336.0 * N + 112.0 * Es; break;
+                case 2: { const int kk = rep == 0 ? 0 : i + 1;
+                          if (p->built_mf) { launch_mf_spmv(G, p->F, p->Sc, p->C, kk, 0.0, p->st); launch_cg_update(G, p->C, kk, mf_grid_size(p->F), p->st); }
+                          else { launch_cg_spmv(G, p->C, kk, 0.0, p->st); launch_cg_update(G, p->C, kk, cg_grid_size(G), p->st); } }
+                        bytes = 288.0 * (N + E) + 104.0 * Es + 288.0 * N + 80.0 * (6.0 * N + Es); break;   // SURVEY.md §8d figure for the assembled form
                 case 3: launch_k1(G, p->d_pose[nxt].p, p->d_swv[nxt].p, false, part(p, 5), &np, p->st); bytes = k1_algorithmic_bytes(G, false); break;
                 default: (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return PGO_ERR_INVALID_ARG;
             }

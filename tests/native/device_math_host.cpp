@@ -29,6 +29,15 @@ void dm_prior(const double* q1, const double* t1, const double* T16, double w, d
     eigen_matrix_to_quat(R, q);
     prior_residual<true>(mk(q1, t1), R, t, q, w, r, J1);
 }
+// matrix-free operator: contribution of one edge to (J^T J p) at both endpoints, from the compact record
+void dm_compact_apply(const double* q1, const double* t1, const double* q2, const double* t2, const double* T16, double ws, int is_switch, double kscale,
+                      const double* p1, const double* p2, double* y1, double* y2) {
+    Meas m = mkm(T16, ws);
+    double rec[COMPACT_DOUBLES];
+    edge_compact(mk(q1, t1), mk(q2, t2), m, ws, is_switch != 0, rec);
+    compact_apply(rec, 0, p1, p2, kscale, y1);
+    compact_apply(rec, 1, p2, p1, kscale, y2);
+}
 void dm_plus(const double* q, const double* d, double* out) { quat_plus(q, d, out); }
 void dm_mat_to_quat(const double* T16, double* q) {
     double R[9];

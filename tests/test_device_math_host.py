@@ -68,3 +68,36 @@ def test_analytic_blocks_match_goldens(shim):
         o = np.zeros(4)
         shim.dm_mat_to_quat(P(A(m["T"])), P(o))
         assert np.abs(o - m["q"]).max() <= 1e-15
+
+
+def test_matrix_free_edge_operator_equals_jtj(shim):
+    """compact_apply (the per-edge-side body of the matrix-free PCG matvec) == J_side^T (J1 p1 + J2 p2), incl. the switch Schur term."""
+    rng = np.random.default_rng(7)
+    for trial in range(60):
+        q1, q2, qo = (rng.normal(size=4) for _ in range(3))
+        q1 /= np.linalg.norm(q1); q2 /= np.linalg.norm(q2); qo /= np.linalg.norm(qo)
+        t1, t2, to = rng.normal(size=3) * 3, rng.normal(size=3) * 3, rng.normal(size=3)
+        from tests.golden.make_functor_goldens import make_T
+        T = A(make_T(qo, to))
+        p1, p2 = rng.normal(size=6), rng.normal(size=6)
+        is_sw = trial % 2
+        if not is_sw:
+            w = rng.uniform(0.1, 1.5)
+            r, J1, J2 = np.zeros(6), np.zeros((6, 6)), np.zeros((6, 6))
+            shim.dm_relpose(P(A(q1)), P(A(t1)), P(A(q2)), P(A(t2)), P(T), C.c_double(w), P(r), P(J1), P(J2))
+            u = J1 @ p1 + J2 @ p2
+            want1, want2 = J1.T @ u, J2.T @ u
+            ws, kscale = w, 0.0
+        else:
+            s = rng.uniform(0.05, 1.2)
+            r, J1, J2, Js = np.zeros(7), np.zeros((6, 6)), np.zeros((6, 6)), np.zeros(7)
+            shim.dm_switch(P(A(q1)), P(A(t1)), P(A(q2)), P(A(t2)), C.c_double(s), P(T), P(r), P(J1), P(J2), P(Js))
+            a_inv = 1.0 / (Js @ Js + rng.uniform(0, 0.1))
+            u = J1 @ p1 + J2 @ p2
+            u = u - Js[:6] * (Js[:6] @ u) * a_inv          # Schur complement of the switch column
+            want1, want2 = J1.T @ u, J2.T @ u
+            ws, kscale = s, np.sqrt(a_inv)
+        y1, y2 = np.zeros(6), np.zeros(6)
+        shim.dm_compact_apply(P(A(q1)), P(A(t1)), P(A(q2)), P(A(t2)), P(T), C.c_double(ws), C.c_int(is_sw), C.c_double(kscale), P(A(p1)), P(A(p2)), P(y1), P(y2))
+        sc = max(1.0, np.abs(want1).max(), np.abs(want2).max())
+        assert np.abs(y1 - want1).max() <= 1e-12 * sc and np.abs(y2 - want2).max() <= 1e-12 * sc

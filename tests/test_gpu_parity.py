@@ -77,10 +77,11 @@ def test_normal_matrix_matches_oracle():
         assert abs(gs[e] - go[6 * N + e]) <= 1e-11 * max(1.0, np.abs(go).max())
 
 
-def test_normal_operator_is_schur_complement():
-    """K3: (H_reduced + damping) x from the device BSR against the dense Schur complement built from the oracle's H."""
+@pytest.mark.parametrize("linear_solver", [0, 1])   # 0: assembled block-CSR, 1: matrix-free (default)
+def test_normal_operator_is_schur_complement(linear_solver):
+    """K3: (H_reduced + damping) x on the device (both matvec forms) against the dense Schur complement built from the oracle's H."""
     g = util.small_graph(100, 20, f=2, seed=2)
-    O, P = _both(g, True)
+    O, P = _both(g, True, linear_solver=linear_solver)
     q, t, s = util.initial_state(g, True, perturb=0.02, seed=6)
     N, S = g.n_poses, g.n_loops
     H = O.dense_normal_matrix(q, t, s)
@@ -98,12 +99,13 @@ def test_normal_operator_is_schur_complement():
     assert np.abs(y - A @ x).max() <= 1e-10 * np.abs(A @ x).max()
 
 
+@pytest.mark.parametrize("linear_solver", [0, 1])
 @pytest.mark.parametrize("name,switchable", [("C1", True), ("C1F5", True), ("C2", False)])
-def test_solve_matches_oracle_at_convergence(name, switchable):
+def test_solve_matches_oracle_at_convergence(name, switchable, linear_solver):
     """Final chi^2 within 1e-6 relative (BASELINE.json north_star) and per-node pose agreement, both solvers
     run to convergence (function tolerance) from the same initial guess."""
     g = graphgen.config(name)
-    O, P = _both(g, switchable, max_num_iterations=100, function_tolerance=1e-10, cg_rel_tolerance=1e-12, cg_max_iterations=20000)
+    O, P = _both(g, switchable, max_num_iterations=100, function_tolerance=1e-10, cg_rel_tolerance=1e-12, cg_max_iterations=20000, linear_solver=linear_solver)
     q, t, s = util.initial_state(g, switchable)
     from oracle import binding as ob
     qo, to, so, sumo = O.solve(q, t, s, ob.default_options(max_num_iterations=100, function_tolerance=1e-10))
@@ -120,11 +122,12 @@ def test_solve_matches_oracle_at_convergence(name, switchable):
         assert np.abs(sp - so).max() <= 1e-3
 
 
-def test_first_iterations_track_oracle():
+@pytest.mark.parametrize("linear_solver", [0, 1])
+def test_first_iterations_track_oracle(linear_solver):
     """With a tight PCG tolerance the device LM reproduces the oracle's (exact Cholesky) iterates: same accept/reject
     sequence and the same costs for the reference's 10-iteration budget (src/PoseGraphSLAM.cpp:1272)."""
     g = graphgen.config("C1")
-    O, P = _both(g, True, cg_rel_tolerance=1e-13, cg_max_iterations=20000)
+    O, P = _both(g, True, cg_rel_tolerance=1e-13, cg_max_iterations=20000, linear_solver=linear_solver)
     q, t, s = util.initial_state(g, True)
     _, _, _, sumo = O.solve(q, t, s)
     _, _, _, sump = P.solve(q, t, s)
