@@ -172,7 +172,7 @@ def main():
             "config": {"workload": "C3 x %d: synthetic 3D Manhattan graph, %d poses / %d edges (%d odometry f=1,2 + %d switchable loop closures, 10%% outliers) + %d regulariser(s)"
                                    % (scale, g.n_poses, n_edges, g.n_odom, g.n_loops, len(g.reg_node)),
                        "poses": g.n_poses, "edges": n_edges, "sharding": "edges, contiguous per rank; 1 RCCL all-reduce per CG matvec" if world > 1 else "single GPU",
-                       "linear_solver": "PCG block-Jacobi on the Schur-reduced pose system", "cg_rel_tolerance": P.options.cg_rel_tolerance,
+                       "linear_solver": "PCG, 6x6 block-Jacobi, Schur-reduced pose system, %s matvec" % ("matrix-free" if P.options.linear_solver == 1 else "block-CSR"), "cg_rel_tolerance": P.options.cg_rel_tolerance,
                        "cg_max_iterations": P.options.cg_max_iterations},
             "lm_iters_per_s_raw": ips,
             "chi2_initial": 2.0 * summ.initial_cost, "chi2_final": 2.0 * summ.final_cost,
