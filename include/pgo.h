@@ -248,6 +248,13 @@ int pgo_comm_get_unique_id(uint8_t id[PGO_COMM_ID_BYTES]);
 int pgo_comm_init(pgo_problem* p, int32_t rank, int32_t world_size, const uint8_t id[PGO_COMM_ID_BYTES]);
 int pgo_comm_destroy(pgo_problem* p);
 
+/* Bring-your-own collective (e.g. torch.distributed, MPI, or an in-process test harness): `fn` must all-reduce `count` doubles in
+ * DEVICE memory in place across the `world_size` ranks (op 0 = sum, 2 = max; work enqueued before the call on `hip_stream` must be
+ * honoured, and the result must be visible to work enqueued on it afterwards) and return 0 on success.  Replaces the RCCL
+ * communicator of pgo_comm_init; same sharding contract. */
+typedef int (*pgo_allreduce_fn)(void* ctx, double* device_buf, int64_t count, int32_t op, void* hip_stream);
+int pgo_comm_init_custom(pgo_problem* p, int32_t rank, int32_t world_size, pgo_allreduce_fn fn, void* ctx);
+
 /* ------------------------------------------------------------------------------------------ */
 /* measurement helpers (bench.py): HIP-event timing of the dominant kernel on the library's stream */
 /* ------------------------------------------------------------------------------------------ */

@@ -49,7 +49,7 @@ EXPORTS = [
     "pgo_num_relpose_edges", "pgo_num_switchable_edges", "pgo_num_regularizers",
     "pgo_solve", "pgo_solve_begin", "pgo_lm_step", "pgo_solve_end", "pgo_evaluate",
     "pgo_get_jacobian_blocks", "pgo_get_normal_blocks", "pgo_apply_normal_operator",
-    "pgo_comm_get_unique_id", "pgo_comm_init", "pgo_comm_destroy",
+    "pgo_comm_get_unique_id", "pgo_comm_init", "pgo_comm_destroy", "pgo_comm_init_custom",
     "pgo_time_linearize_kernel", "pgo_time_kernel", "pgo_device_synchronize", "pgo_strerror", "pgo_last_error",
 ]
 
@@ -255,6 +255,20 @@ class Problem:
     def comm_init(self, rank, world_size, unique_id):
         buf = (C.c_uint8 * PGO_COMM_ID_BYTES).from_buffer_copy(unique_id)
         self._check(self.lib.pgo_comm_init(self.h, C.c_int32(rank), C.c_int32(world_size), buf))
+
+    def comm_init_custom(self, rank, world_size, fn):
+        """fn(device_ptr:int, count:int, op:int, stream:int) -> 0 on success; all-reduces `count` doubles in device memory in place."""
+        CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p)
+
+        def tramp(ctx, buf, count, op, stream):
+            try:
+                return int(fn(buf, count, op, stream))
+            except Exception:   # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._custom_cb = CB(tramp)   # keep alive
+        self._check(self.lib.pgo_comm_init_custom(self.h, C.c_int32(rank), C.c_int32(world_size), self._custom_cb, None))
 
     def comm_destroy(self):
         self._check(self.lib.pgo_comm_destroy(self.h))

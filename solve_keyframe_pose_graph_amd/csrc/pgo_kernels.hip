@@ -402,11 +402,13 @@ __global__ __launch_bounds__(256) void build_rows_kernel(GraphDev G, LinDev L, S
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= G.N) return;
     const bool free_node = G.node_free[n] != 0;
+    // `add_lambda` marks the LEAD rank (rank 0, or the only rank): Hd and g are already summed over ranks (all-reduced after K2), so
+    // exactly one rank may put them — and the damping — into the system; the others contribute only their local switch Schur terms.
     double D[36], bv[6];
 #pragma unroll
-    for (int i = 0; i < 36; ++i) D[i] = L.Hd[(size_t)n * 36 + i];
+    for (int i = 0; i < 36; ++i) D[i] = add_lambda ? L.Hd[(size_t)n * 36 + i] : 0.0;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) bv[i] = -L.g[(size_t)n * 6 + i];
+    for (int i = 0; i < 6; ++i) bv[i] = add_lambda ? -L.g[(size_t)n * 6 + i] : 0.0;
     const int64_t b = G.inc_rowptr[n], e = G.inc_rowptr[n + 1];
     const int64_t slot_sw = G.rel.Epad, slot_pr = G.rel.Epad + G.sw.Epad;
     const int64_t row0 = G.bsr_rowptr[n];

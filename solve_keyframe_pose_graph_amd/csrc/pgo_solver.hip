@@ -121,6 +121,7 @@ struct pgo_problem {
 
     // comm
     Rccl nccl; void* comm = nullptr; int rank = 0, world = 1;
+    pgo_allreduce_fn custom_allreduce = nullptr; void* custom_ctx = nullptr;
 };
 
 namespace {
@@ -183,6 +184,8 @@ int upload_class(pgo_problem* p, const HostClass& H, bool is_sw, DBuf<int32_t>& 
     return PGO_OK;
 }
 
+int allreduce(pgo_problem* p, double* buf, size_t n, int op);
+
 int build_graph(pgo_problem* p, int64_t N, int64_t S) {
     // ---- validate against the array sizes the caller solves with
     for (const HostClass* H : {&p->rel, &p->swe})
@@ -226,6 +229,18 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S) {
     for (int64_t k = 0; k < Eg; ++k) inc[fill[p->priors[k].node]++] = ((G.rel.Epad + G.sw.Epad + k) << 1);
     p->h_node_free.assign((size_t)N, 0);
     for (int64_t n = 0; n < N; ++n) p->h_node_free[n] = rowptr[n + 1] > rowptr[n] ? 1 : 0;
+    if (p->world > 1 && (p->comm || p->custom_allreduce)) {
+        // edge sharding: a keyframe is part of the program when ANY rank holds a residual block on it -> union over ranks
+        std::vector<double> flags((size_t)N);
+        for (int64_t n = 0; n < N; ++n) flags[n] = p->h_node_free[n];
+        HIPCHK(p, p->d_tmp.ensure((size_t)N));
+        HIPCHK(p, hipMemcpyAsync(p->d_tmp.p, flags.data(), N * sizeof(double), hipMemcpyHostToDevice, p->st));
+        int rc2 = allreduce(p, p->d_tmp.p, (size_t)N, 2 /*ncclMax*/);
+        if (rc2 != PGO_OK) return rc2;
+        HIPCHK(p, hipMemcpyAsync(flags.data(), p->d_tmp.p, N * sizeof(double), hipMemcpyDeviceToHost, p->st));
+        HIPCHK(p, hipStreamSynchronize(p->st));
+        for (int64_t n = 0; n < N; ++n) p->h_node_free[n] = flags[n] > 0.5 ? 1 : 0;
+    }
     for (int32_t c : p->constant_nodes) if (c >= 0 && c < N) p->h_node_free[c] = 0;
 
     HIPCHK(p, p->d_inc_rowptr.ensure(N + 1)); HIPCHK(p, p->d_bsr_rowptr.ensure(N + 1)); HIPCHK(p, p->d_inc.ensure(std::max<int64_t>(ninc, 1)));
@@ -328,7 +343,13 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S) {
 
 // ---- collectives (no-ops at world == 1) ----
 int allreduce(pgo_problem* p, double* buf, size_t n, int op /*0 sum, 2 max*/) {
-    if (p->world <= 1 || !p->comm) return PGO_OK;
+    if (p->world <= 1) return PGO_OK;
+    if (p->custom_allreduce) {
+        const int rc = p->custom_allreduce(p->custom_ctx, buf, (int64_t)n, op, (void*)p->st);
+        if (rc != 0) { p->err = "custom all-reduce callback failed"; return PGO_ERR_COMM; }
+        return PGO_OK;
+    }
+    if (!p->comm) return PGO_OK;
     const int rc = p->nccl.AllReduce(buf, buf, n, /*ncclDouble*/ 8, op, p->comm, p->st);
     if (rc != 0) { p->err = std::string("ncclAllReduce: ") + (p->nccl.GetErrorString ? p->nccl.GetErrorString(rc) : "error"); return PGO_ERR_COMM; }
     return PGO_OK;
@@ -901,12 +922,21 @@ int pgo_comm_init(pgo_problem* p, int32_t rank, int32_t world, const uint8_t id[
     const int nrc = p->nccl.CommInitRank(&comm, world, u, rank);
     if (nrc != 0) { p->err = std::string("ncclCommInitRank: ") + (p->nccl.GetErrorString ? p->nccl.GetErrorString(nrc) : "error"); return PGO_ERR_COMM; }
     p->comm = comm; p->rank = rank; p->world = world;
+    p->graph_dirty = true;   // keyframe participation is the union over ranks
+    return PGO_OK;
+}
+int pgo_comm_init_custom(pgo_problem* p, int32_t rank, int32_t world, pgo_allreduce_fn fn, void* ctx) {
+    if (!p || !fn || world < 1 || rank < 0 || rank >= world) return PGO_ERR_INVALID_ARG;
+    p->custom_allreduce = fn; p->custom_ctx = ctx; p->rank = rank; p->world = world;
+    p->graph_dirty = true;
     return PGO_OK;
 }
 int pgo_comm_destroy(pgo_problem* p) {
     if (!p) return PGO_ERR_INVALID_ARG;
+    p->custom_allreduce = nullptr; p->custom_ctx = nullptr;
     if (p->comm && p->nccl.CommDestroy) { (void)hipStreamSynchronize(p->st); p->nccl.CommDestroy(p->comm); }
     p->comm = nullptr; p->rank = 0; p->world = 1;
+    p->graph_dirty = true;
     return PGO_OK;
 }
 

@@ -57,6 +57,14 @@ def _worker(rank, world, port, out):
     P, owned = _local_problem(g, rank, world)
     cost, _, grad = P.evaluate(q, t, s, want_residuals=False)
     H = P.dense_normal_matrix(q, t, s)
+    # keyframe participation = union over ranks of 'has a local residual block' (libpgo all-reduces these flags with max)
+    deg = np.zeros(N)
+    sel = edge_slice(rank, world)
+    for arr, n in ((g.odom_c1, g.n_odom), (g.odom_c2, g.n_odom), (g.loop_c1, g.n_loops), (g.loop_c2, g.n_loops)):
+        idx = sel('odom' if n == g.n_odom else 'loop', n)
+        deg[arr[idx]] = 1
+    tf = torch.from_numpy(deg.copy()); dist.all_reduce(tf, op=dist.ReduceOp.MAX)
+    assert tf.min().item() == 1.0 and deg.min() == 0.0   # every keyframe participates globally, but not on every rank
     # collectives: cost (scalar sum), diagonal blocks + gradient (one all-reduce per linearisation)
     tc = torch.tensor([cost]); dist.all_reduce(tc)
     diag = torch.from_numpy(np.diag(H)[:6 * N].copy()); dist.all_reduce(diag)
