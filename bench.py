@@ -70,6 +70,9 @@ def main():
     ap.add_argument("--cpu-sample-poses", type=int, default=20000)
     ap.add_argument("--cpu-iters", type=int, default=6)
     ap.add_argument("--poses-per-gpu", type=int, default=C3_POSES)
+    ap.add_argument("--collective", choices=["rccl", "gloo"], default="rccl",
+                    help="rccl: libpgo's own RCCL communicator over xGMI (default).  gloo: torch.distributed gloo through pgo_comm_init_custom "
+                         "(host staging; lets several ranks share one GPU to validate the multi-rank path on a 1-GPU box)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -82,12 +85,19 @@ def main():
 
     import torch
     dist = None
+    device_index = local_rank
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.collective == "rccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            device_index = local_rank % max(1, torch.cuda.device_count())
+            torch.cuda.set_device(device_index)
+            dist.init_process_group(backend="gloo")
     elif torch.cuda.is_available():
         torch.cuda.set_device(0)
+        device_index = 0
 
     from solve_keyframe_pose_graph_amd import capi, graphgen
     capi.load()   # raises if libpgo.so is missing: no CPU fallback
@@ -107,11 +117,25 @@ def main():
         opt["cg_rel_tolerance"] = args.cg_tol
     if args.cg_max is not None:
         opt["cg_max_iterations"] = args.cg_max
-    P = capi.problem_from_graph(g, switchable=True, edge_slice=shard if world > 1 else None, device_id=local_rank, max_num_iterations=10 ** 6, **opt)
-    if world > 1:
+    P = capi.problem_from_graph(g, switchable=True, edge_slice=shard if world > 1 else None, device_id=device_index, max_num_iterations=10 ** 6, **opt)
+    if world > 1 and args.collective == "rccl":
         uid = [capi.Problem.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         P.comm_init(rank, world, uid[0])
+    elif world > 1:
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+
+        def gloo_allreduce(buf, count, op, stream):
+            hip.hipStreamSynchronize(stream)
+            host = torch.empty(count, dtype=torch.float64)
+            hip.hipMemcpy(host.data_ptr(), buf, count * 8, 2)
+            dist.all_reduce(host, op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX)
+            hip.hipMemcpy(buf, host.data_ptr(), count * 8, 1)
+            return 0
+        P.comm_init_custom(rank, world, gloo_allreduce)
 
     q0, t0_, s0 = g.init_q, g.init_t, np.full(g.n_loops, 0.99)
 
@@ -139,7 +163,7 @@ def main():
     sync(); barrier()
     elapsed = time.perf_counter() - t_start
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.collective == "rccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -151,7 +175,9 @@ def main():
     qf, tf, sf, summ = P.solve_end()
 
     traffic = None
-    try:   # HBM bytes per K1 launch from the rocprofv3 PMC passes (profiles/k1_pmc_rNN.json, written by scripts/profile_k1.sh)
+    try:
+        if not (scale == 1 and args.poses_per_gpu == C3_POSES):
+            raise KeyError("the PMC passes were taken on C3 x 1 only")   # HBM bytes per K1 launch from the rocprofv3 PMC passes (profiles/k1_pmc_rNN.json, written by scripts/profile_k1.sh)
         with open(os.path.join(ROOT, "profiles", "k1_pmc_latest.json")) as f:
             traffic = json.load(f).get("hbm_bytes_per_launch")
     except Exception:
@@ -171,7 +197,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "C3 x %d: synthetic 3D Manhattan graph, %d poses / %d edges (%d odometry f=1,2 + %d switchable loop closures, 10%% outliers) + %d regulariser(s)"
                                    % (scale, g.n_poses, n_edges, g.n_odom, g.n_loops, len(g.reg_node)),
-                       "poses": g.n_poses, "edges": n_edges, "sharding": "edges, contiguous per rank; 1 RCCL all-reduce per CG matvec" if world > 1 else "single GPU",
+                       "poses": g.n_poses, "edges": n_edges, "sharding": ("edges, contiguous per rank; 1 %s all-reduce per CG matvec" % args.collective) if world > 1 else "single GPU",
                        "linear_solver": "PCG, 6x6 block-Jacobi, Schur-reduced pose system, %s matvec" % ("matrix-free" if P.options.linear_solver == 1 else "block-CSR"), "cg_rel_tolerance": P.options.cg_rel_tolerance,
                        "cg_max_iterations": P.options.cg_max_iterations},
             "lm_iters_per_s_raw": ips,

@@ -87,6 +87,8 @@ typedef struct pgo_options {
     int32_t cg_max_iterations;           /* 4000 */
     int32_t cg_check_every;              /* 25: host polls the device convergence flag every this many iterations */
     double cg_rel_tolerance;             /* 1e-9: stop when ||r||_{M^-1} <= tol * ||b||_{M^-1} */
+    int32_t cg_warm_start;               /* 1: after a rejected step start the PCG from the previous step (same H, larger damping) */
+    int32_t cg_use_graph;                /* 1: replay each `cg_check_every`-iteration chunk of the PCG loop as one hipGraph (single GPU) */
     /* device selection */
     int32_t device_id;                   /* -1: use the current HIP device */
     int32_t verbosity;                   /* 0 silent (minimizer_progress_to_stdout=false, :1271), 1 per-iteration line on stderr */

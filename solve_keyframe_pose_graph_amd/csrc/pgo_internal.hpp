@@ -116,7 +116,7 @@ void launch_mf_compact(const GraphDev& G, const MfDev& F, const double* pose8, c
 void launch_mf_spmv(const GraphDev& G, const MfDev& F, const ScaleDev& Sc, const CgDev& C, int k, double tol2, hipStream_t st);
 void launch_mf_apply(const GraphDev& G, const MfDev& F, const ScaleDev& Sc, const CgDev& C, const double* x, double* y, hipStream_t st);
 void launch_invert_rows(const GraphDev& G, const CgDev& C, int32_t* fail_flag, hipStream_t st);
-void launch_cg_init(const GraphDev& G, const CgDev& C, hipStream_t st);
+void launch_cg_init(const GraphDev& G, const CgDev& C, int warm /*x holds a previous solution, q = A x*/, hipStream_t st);
 void launch_cg_spmv(const GraphDev& G, const CgDev& C, int k, double tol2, hipStream_t st);   // iteration k: direction + matvec (+ convergence test)
 void launch_cg_pq(const GraphDev& G, const CgDev& C, int k, hipStream_t st);   // multi-GPU: recompute p.q after the all-reduce of q
 void launch_cg_update(const GraphDev& G, const CgDev& C, int k, int n_pq_partials, hipStream_t st);

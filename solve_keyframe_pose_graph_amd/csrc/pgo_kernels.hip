@@ -53,6 +53,20 @@ __device__ __forceinline__ double block_total(const double* __restrict__ partial
 // so the 6 lanes (rows) of one keyframe read consecutive 16-B words: every SpMV load is a contiguous 96-B run per keyframe.
 __device__ __forceinline__ int pm(int r, int c) { return (c >> 1) * 12 + r * 2 + (c & 1); }
 
+// two totals in one pass (one barrier pair instead of two): every PCG kernel starts by re-reducing two partial arrays
+__device__ __forceinline__ void block_total2(const double* __restrict__ pa, int na, const double* __restrict__ pb, int nb, double* buf /*2 x nwaves*/, double& sa, double& sb) {
+    double va = 0.0, vb = 0.0;
+    for (int i = threadIdx.x; i < na; i += blockDim.x) va += pa[i];
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) vb += pb[i];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    va = wave_sum(va); vb = wave_sum(vb);
+    __syncthreads();
+    if (lane == 0) { buf[wave] = va; buf[nw + wave] = vb; }
+    __syncthreads();
+    sa = 0.0; sb = 0.0;
+    for (int i = 0; i < nw; ++i) { sa += buf[i]; sb += buf[nw + i]; }
+}
+
 __device__ __forceinline__ size_t tile_elem(int doubles_per_edge, int64_t e, int k) {
     return (size_t)(e >> 6) * (size_t)(doubles_per_edge * TILE) + (size_t)(k >> 1) * (2 * TILE) + (size_t)(e & 63) * 2 + (k & 1);
 }
@@ -619,13 +633,13 @@ __device__ __forceinline__ void bsr_row_accumulate(const GraphDev& G, const doub
 
 // q = A (z + beta p_prev), p_cur = z + beta p_prev
 __global__ __launch_bounds__(CG_BLOCK) void cg_spmv_kernel(GraphDev G, CgDev C, int parity, int first, int nparts, double tol2) {
-    __shared__ double red[CG_BLOCK / 64];
+    __shared__ double red[2 * (CG_BLOCK / 64)];
     __shared__ double xch[CG_BLOCK * 7];   // [keyframe-in-group][c][r], padded to 7 to spread LDS banks
     if (cg_done(C)) return;
     double beta = 0.0;
     if (!first) {
-        const double rz_new = block_total(C.part_rz + parity * MAX_PARTIALS, nparts, red);
-        const double rz_old = block_total(C.part_rz + (parity ^ 1) * MAX_PARTIALS, nparts, red);
+        double rz_new, rz_old;
+        block_total2(C.part_rz + parity * MAX_PARTIALS, nparts, C.part_rz + (parity ^ 1) * MAX_PARTIALS, nparts, red, rz_new, rz_old);
         const bool breakdown = C.flags[1] != 0;
         // convergence on the preconditioned residual norm: every workgroup evaluates the same numbers -> uniform exit
         if (breakdown || !(rz_new > tol2 * C.scal[0])) {
@@ -709,36 +723,52 @@ __global__ __launch_bounds__(CG_BLOCK) void apply_operator_kernel(GraphDev G, Cg
     }
 }
 
-// x = 0, r = b, z = Minv b, partial r.z -> part_rz[0]
-__global__ __launch_bounds__(CG_BLOCK) void cg_init_kernel(GraphDev G, CgDev C) {
+// cold: x = 0, r = b.   warm (after a rejected step: same H, larger damping): x keeps the previous solution, r = b - A x (A x is in q).
+// z = Minv r, partial r.z -> part_rz[0]; the convergence reference stays ||b||_{Minv} (partials -> part_pq) in both cases.
+__global__ __launch_bounds__(CG_BLOCK) void cg_init_kernel(GraphDev G, CgDev C, int warm) {
     __shared__ double red[CG_BLOCK / 64];
     const int64_t rows = G.N * 6;
-    double rz = 0.0;
+    double rz = 0.0, bb = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * CG_BLOCK + threadIdx.x; i < rows; i += (int64_t)gridDim.x * CG_BLOCK) {
         const int64_t n = i / 6; const int r = (int)(i - n * 6);
         const double2* bn = reinterpret_cast<const double2*>(C.b + (size_t)n * 6);
         const double2* M = reinterpret_cast<const double2*>(C.Minv + (size_t)n * 36) + r;
         const double2 m0 = M[0], m1 = M[6], m2 = M[12], b0 = bn[0], b1 = bn[1], b2 = bn[2];
-        const double z = m0.x * b0.x + m0.y * b0.y + m1.x * b1.x + m1.y * b1.y + m2.x * b2.x + m2.y * b2.y;
+        const double zb = m0.x * b0.x + m0.y * b0.y + m1.x * b1.x + m1.y * b1.y + m2.x * b2.x + m2.y * b2.y;
         const double bi = C.b[i];
-        C.x[i] = 0.0; C.r[i] = bi; C.z[i] = z; C.p[i] = 0.0; C.p2[i] = 0.0;   // p buffers zeroed: iteration 0 multiplies them by beta = 0
-        rz += bi * z;
+        bb += bi * zb;
+        double ri = bi, z = zb;
+        if (warm) {
+            const double2* qn = reinterpret_cast<const double2*>(C.q + (size_t)n * 6);
+            const double2 q0 = qn[0], q1 = qn[1], q2 = qn[2];
+            z = m0.x * (b0.x - q0.x) + m0.y * (b0.y - q0.y) + m1.x * (b1.x - q1.x) + m1.y * (b1.y - q1.y) + m2.x * (b2.x - q2.x) + m2.y * (b2.y - q2.y);
+            ri = bi - C.q[i];
+        } else {
+            C.x[i] = 0.0;
+        }
+        C.r[i] = ri; C.z[i] = z; C.p[i] = 0.0; C.p2[i] = 0.0;   // p buffers zeroed: iteration 0 multiplies them by beta = 0
+        rz += ri * z;
     }
     const double s = block_sum(rz, red);
-    if (threadIdx.x == 0) C.part_rz[blockIdx.x] = s;
+    const double sb = block_sum(bb, red);
+    if (threadIdx.x == 0) { C.part_rz[blockIdx.x] = s; C.part_pq[blockIdx.x] = sb; }
 }
 __global__ void cg_scalars_init_kernel(CgDev C, int nparts) {
     __shared__ double red[4];
     const double rz0 = block_total(C.part_rz, nparts, red);
-    if (threadIdx.x == 0) { C.scal[0] = rz0; C.scal[1] = rz0; C.scal[2] = 0.0; C.flags[0] = (rz0 > 0.0) ? 0 : 1; C.flags[1] = 0; C.flags[2] = 0; }
+    const double bb = block_total(C.part_pq, nparts, red);
+    if (threadIdx.x == 0) {
+        C.scal[0] = bb; C.scal[1] = rz0; C.scal[2] = 0.0;
+        C.flags[0] = (bb > 0.0 && rz0 > 0.0) ? 0 : 1; C.flags[1] = 0; C.flags[2] = 0;
+    }
 }
 
 // alpha = rz/pq ; x += alpha p ; r' = r - alpha q ; z = Minv r' ; partial r'.z -> part_rz[parity^1]
 __global__ __launch_bounds__(CG_BLOCK) void cg_update_kernel(GraphDev G, CgDev C, int parity, int nparts_pq, int nparts) {
-    __shared__ double red[CG_BLOCK / 64];
+    __shared__ double red[2 * (CG_BLOCK / 64)];
     if (cg_done(C)) return;
-    const double pq = block_total(C.part_pq, nparts_pq, red);   // produced by the matvec kernel (its own grid size)
-    const double rz = block_total(C.part_rz + parity * MAX_PARTIALS, nparts, red);
+    double pq, rz;   // pq partials are produced by the matvec kernel (its own grid size)
+    block_total2(C.part_pq, nparts_pq, C.part_rz + parity * MAX_PARTIALS, nparts, red, pq, rz);
     if (!(pq > 0.0)) {   // breakdown: matrix not positive definite along p (or NaN); x is left untouched, the next spmv raises done
         if (blockIdx.x == 0 && threadIdx.x == 0) C.flags[1] = 1;
         if (threadIdx.x == 0) C.part_rz[(parity ^ 1) * MAX_PARTIALS + blockIdx.x] = 0.0;
@@ -778,9 +808,9 @@ static inline int cg_grid(const GraphDev& G) {
     if (g < 1) g = 1;
     return (int)g;
 }
-void launch_cg_init(const GraphDev& G, const CgDev& C, hipStream_t st) {
+void launch_cg_init(const GraphDev& G, const CgDev& C, int warm, hipStream_t st) {
     const int g = cg_grid(G);
-    hipLaunchKernelGGL(cg_init_kernel, dim3(g), dim3(CG_BLOCK), 0, st, G, C);
+    hipLaunchKernelGGL(cg_init_kernel, dim3(g), dim3(CG_BLOCK), 0, st, G, C, warm);
     hipLaunchKernelGGL(cg_scalars_init_kernel, dim3(1), dim3(256), 0, st, C, g);
 }
 void launch_cg_spmv(const GraphDev& G, const CgDev& C, int k, double tol2, hipStream_t st) {
@@ -823,13 +853,13 @@ __global__ __launch_bounds__(MF_BLOCK) void mf_spmv_kernel(GraphDev G, MfDev F, 
                                                            int parity, int first, int nparts, double tol2) {
     __shared__ double contrib[MF_BLOCK * 7];
     __shared__ double pwin[MF_BLOCK];
-    __shared__ double red[MF_BLOCK / 64];
+    __shared__ double red[2 * (MF_BLOCK / 64)];
     double beta = 0.0;
     if (FUSED) {
         if (cg_done(C)) return;
         if (!first) {
-            const double rz_new = block_total(C.part_rz + parity * MAX_PARTIALS, nparts, red);
-            const double rz_old = block_total(C.part_rz + (parity ^ 1) * MAX_PARTIALS, nparts, red);
+            double rz_new, rz_old;
+            block_total2(C.part_rz + parity * MAX_PARTIALS, nparts, C.part_rz + (parity ^ 1) * MAX_PARTIALS, nparts, red, rz_new, rz_old);
             const bool breakdown = C.flags[1] != 0;
             if (breakdown || !(rz_new > tol2 * C.scal[0])) {
                 if (blockIdx.x == 0 && threadIdx.x == 0) { C.flags[0] = 1; if (!breakdown) C.scal[1] = rz_new; }

@@ -112,7 +112,7 @@ struct pgo_problem {
     CgDev C{};
 
     // LM state
-    bool in_solve = false, scale_ready = false, terminated = false;
+    bool in_solve = false, scale_ready = false, terminated = false, have_prev_step = false;
     double radius = 0, decrease_factor = 2, x_cost = 0, x_norm = 0, gmax = 0;
     bool reuse_diagonal = false;
     int iteration = 0, invalid = 0;
@@ -122,6 +122,9 @@ struct pgo_problem {
     // comm
     Rccl nccl; void* comm = nullptr; int rank = 0, world = 1;
     pgo_allreduce_fn custom_allreduce = nullptr; void* custom_ctx = nullptr;
+
+    // hipGraph of one PCG chunk (launch-bound inner loop); valid for (graph build epoch, tolerance, chunk length, solver)
+    hipGraphExec_t cg_graph = nullptr; int cg_graph_len = 0; double cg_graph_tol2 = -1; uint64_t cg_graph_epoch = 0, build_epoch = 1; bool cg_graph_failed = false;
 };
 
 namespace {
@@ -338,6 +341,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S) {
     C.part_pq = p->d_cgpart.p; C.part_rz = p->d_cgpart.p + MF_MAX_GRID; C.scal = p->d_cgpart.p + MF_MAX_GRID + 2 * MAX_PARTIALS;
     C.flags = p->d_flags.p;
     p->graph_dirty = false; p->priors_dirty = false;
+    ++p->build_epoch;   // invalidates the captured PCG graph (kernel arguments hold device pointers / sizes)
     return PGO_OK;
 }
 
@@ -401,27 +405,59 @@ int linearize(pgo_problem* p, double* cost_out) {
 
 struct CgResult { int iterations; bool breakdown; double rel_residual; };
 
-int run_pcg(pgo_problem* p, CgResult* res) {
+int run_pcg(pgo_problem* p, CgResult* res, bool warm) {
     const pgo_options& o = p->opt;
-    launch_cg_init(p->G, p->C, p->st);
+    int rc0;
+    if (warm) {
+        // after a rejected step the system keeps H and only the damping grows: start from the previous solution (q = A x first)
+        if (p->built_mf) launch_mf_apply(p->G, p->F, p->Sc, p->C, p->C.x, p->C.q, p->st);
+        else launch_apply_operator(p->G, p->C, p->C.x, p->C.q, p->st);
+        if ((rc0 = allreduce(p, p->C.q, (size_t)p->N * 6, 0)) != PGO_OK) return rc0;
+    }
+    launch_cg_init(p->G, p->C, warm ? 1 : 0, p->st);
     const double tol2 = o.cg_rel_tolerance * o.cg_rel_tolerance;
     int k = 0;
     int32_t hflags[3] = {0, 0, 0};
     double hscal[3] = {0, 0, 0};
-    const int every = std::max(1, o.cg_check_every);
+    int every = std::max(2, o.cg_check_every) & ~1;   // even: the r/p ping-pong parity repeats from chunk to chunk
     int rc;
+    auto one_iteration = [&](int kk) -> int {
+        int n_pq = cg_grid_size(p->G);
+        if (p->built_mf) { launch_mf_spmv(p->G, p->F, p->Sc, p->C, kk, tol2, p->st); n_pq = mf_grid_size(p->F); }
+        else launch_cg_spmv(p->G, p->C, kk, tol2, p->st);
+        if (p->world > 1) {
+            int r2 = allreduce(p, p->C.q, (size_t)p->N * 6, 0);   // the one exchange per CG matvec
+            if (r2 != PGO_OK) return r2;
+            launch_cg_pq(p->G, p->C, kk, p->st);
+            n_pq = cg_grid_size(p->G);
+        }
+        launch_cg_update(p->G, p->C, kk, n_pq, p->st);
+        return PGO_OK;
+    };
+    // hipGraph: capture one chunk (iterations 2 .. 2+every-1: no `first` kernel, even start) once per graph build and replay it
+    const bool want_graph = o.cg_use_graph && p->world == 1 && !p->cg_graph_failed;
+    if (want_graph && (p->cg_graph == nullptr || p->cg_graph_epoch != p->build_epoch || p->cg_graph_len != every || p->cg_graph_tol2 != tol2)) {
+        if (p->cg_graph) { (void)hipGraphExecDestroy(p->cg_graph); p->cg_graph = nullptr; }
+        hipGraph_t gr = nullptr;
+        bool ok = hipStreamBeginCapture(p->st, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (ok) {
+            for (int j = 0; j < every; ++j) (void)one_iteration(2 + j);
+            ok = hipStreamEndCapture(p->st, &gr) == hipSuccess && gr != nullptr;
+        }
+        if (ok) ok = hipGraphInstantiate(&p->cg_graph, gr, nullptr, nullptr, 0) == hipSuccess;
+        if (gr) (void)hipGraphDestroy(gr);
+        if (!ok) { p->cg_graph = nullptr; p->cg_graph_failed = true; (void)hipGetLastError(); }
+        else { p->cg_graph_epoch = p->build_epoch; p->cg_graph_len = every; p->cg_graph_tol2 = tol2; }
+    }
     while (k < o.cg_max_iterations) {
         const int chunk = std::min(every, o.cg_max_iterations - k);
-        for (int j = 0; j < chunk; ++j, ++k) {
-            int n_pq = cg_grid_size(p->G);
-            if (p->built_mf) { launch_mf_spmv(p->G, p->F, p->Sc, p->C, k, tol2, p->st); n_pq = mf_grid_size(p->F); }
-            else launch_cg_spmv(p->G, p->C, k, tol2, p->st);
-            if (p->world > 1) {
-                if ((rc = allreduce(p, p->C.q, (size_t)p->N * 6, 0)) != PGO_OK) return rc;   // the one exchange per CG matvec
-                launch_cg_pq(p->G, p->C, k, p->st);
-                n_pq = cg_grid_size(p->G);
-            }
-            launch_cg_update(p->G, p->C, k, n_pq, p->st);
+        if (k >= 2 && chunk == every && want_graph && p->cg_graph && (k & 1) == 0) {
+            HIPCHK(p, hipGraphLaunch(p->cg_graph, p->st));
+            k += every;
+        } else {
+            const int n = k == 0 ? std::min(2, chunk) : chunk;   // iterations 0,1 run eagerly (iteration 0 has its own kernel arguments)
+            for (int j = 0; j < n; ++j, ++k) if ((rc = one_iteration(k)) != PGO_OK) return rc;
+            if (k == 2 && o.cg_max_iterations > 2) continue;      // no host poll after the two start-up iterations
         }
         HIPCHK(p, hipMemcpyAsync(hflags, p->C.flags, sizeof(hflags), hipMemcpyDeviceToHost, p->st));
         HIPCHK(p, hipMemcpyAsync(hscal, p->C.scal, sizeof(hscal), hipMemcpyDeviceToHost, p->st));
@@ -486,7 +522,7 @@ int solve_begin(pgo_problem* p, const double* quat, const double* t, const doubl
     HIPCHK(p, hipStreamSynchronize(p->st));
     p->t_device0 = now_s();
     std::memset(&p->sum, 0, sizeof(p->sum));
-    p->in_solve = true; p->terminated = false; p->scale_ready = false;
+    p->in_solve = true; p->terminated = false; p->scale_ready = false; p->have_prev_step = false;
     p->radius = p->opt.initial_trust_region_radius; p->decrease_factor = 2.0; p->reuse_diagonal = false; p->iteration = 0; p->invalid = 0;
     p->sum.termination_type = PGO_NO_CONVERGENCE;
     if ((rc = linearize(p, &p->x_cost)) != PGO_OK) return rc;
@@ -522,7 +558,8 @@ int lm_step(pgo_problem* p, int ignore_termination, int* done) {
     if ((rc = build_system(p, &ok)) != PGO_OK) return rc;
     CgResult cg{0, false, 0.0};
     if (ok) {
-        if ((rc = run_pcg(p, &cg)) != PGO_OK) return rc;
+        if ((rc = run_pcg(p, &cg, p->opt.cg_warm_start != 0 && p->have_prev_step && p->reuse_diagonal)) != PGO_OK) return rc;
+        p->have_prev_step = !cg.breakdown;
         if (cg.breakdown) ok = false;
     }
     it.cg_iterations = cg.iterations; it.cg_residual = cg.rel_residual;
@@ -676,6 +713,8 @@ void pgo_options_init(pgo_options* o) {
     o->parameter_tolerance = 1e-8;
     o->cg_max_iterations = 4000;
     o->cg_check_every = 25;
+    o->cg_warm_start = 1;
+    o->cg_use_graph = 1;
     o->cg_rel_tolerance = 1e-9;     // loosest decade that keeps the 10-iteration chi^2 of C3 within 1e-8 of the 1e-13 solve
     o->device_id = -1;
     o->verbosity = 0;
@@ -704,6 +743,7 @@ int pgo_destroy(pgo_problem* p) {
     (void)hipSetDevice(p->device);
     if (p->comm && p->nccl.CommDestroy) p->nccl.CommDestroy(p->comm);
     (void)hipStreamSynchronize(p->st);
+    if (p->cg_graph) (void)hipGraphExecDestroy(p->cg_graph);
     p->d_rc1.release(); p->d_rc2.release(); p->d_sc1.release(); p->d_sc2.release(); p->d_sidx.release(); p->d_bsr_col.release();
     p->d_rmeas.release(); p->d_smeas.release(); p->d_rwin.release(); p->d_swin.release(); p->d_prior.release();
     p->d_inc_rowptr.release(); p->d_inc.release(); p->d_bsr_rowptr.release(); p->d_node_free.release();
@@ -957,7 +997,7 @@ int pgo_time_kernel(pgo_problem* p, int32_t which, int32_t launches, double* avg
         if (!p->reuse_diagonal) launch_lm_diag(p->G, p->L, p->Sc, o.min_lm_diagonal, o.max_lm_diagonal, p->st);
         bool ok = true;
         if ((rc = build_system(p, &ok)) != PGO_OK) return rc;
-        launch_cg_init(p->G, p->C, p->st);
+        launch_cg_init(p->G, p->C, 0, p->st);
     }
     const double N = (double)G.N, E = (double)(G.rel.E + G.sw.E), Es = (double)G.sw.E;
     // one untimed launch first (instruction cache, TLB)
