@@ -196,7 +196,7 @@ PGO_HD void prior_residual(const Pose& c1, const double* Rf, const double* tf, c
 // (+ r6 = [dt ; 2 (q2* (x) b).vec] for switchable edges, whose Schur term is  u <- u - k (k.u),  k = r6 sqrt(1/(Js^T Js + lambda_s))).
 // compact_apply returns this edge's contribution to (J^T J p) at ONE endpoint: y = J_side^T (J1 p1 + J2 p2).
 // ---------------------------------------------------------------------------------------------
-constexpr int COMPACT_DOUBLES = 22;   // q2[4] b[4] ap[3] dt[3] ws r6[6] pad
+constexpr int COMPACT_DOUBLES = 22;   // q2[4] b[4] ap[3] dt[3] | ws pad | r6[6]   (rec[14] = ws, rec[16..21] = r6)
 
 PGO_HD void edge_compact(const Pose& c1, const Pose& c2, const Meas& m, double ws, bool want_r6, double* rec) {
     double R1[9], R2[9];
@@ -223,12 +223,12 @@ PGO_HD void edge_compact(const Pose& c1, const Pose& c2, const Meas& m, double w
         const double q2c[4] = {-c2.qx, -c2.qy, -c2.qz, c2.qw};
         double dq[4];
         quat_mul(q2c, b, dq);
-        rec[15] = rec[11]; rec[16] = rec[12]; rec[17] = rec[13];
-        rec[18] = 2.0 * dq[0]; rec[19] = 2.0 * dq[1]; rec[20] = 2.0 * dq[2];
+        rec[16] = rec[11]; rec[17] = rec[12]; rec[18] = rec[13];
+        rec[19] = 2.0 * dq[0]; rec[20] = 2.0 * dq[1]; rec[21] = 2.0 * dq[2];
     } else {
-        rec[15] = 0.0; rec[16] = 0.0; rec[17] = 0.0; rec[18] = 0.0; rec[19] = 0.0; rec[20] = 0.0;
+        rec[16] = 0.0; rec[17] = 0.0; rec[18] = 0.0; rec[19] = 0.0; rec[20] = 0.0; rec[21] = 0.0;
     }
-    rec[21] = 0.0;
+    rec[15] = 0.0;
 }
 
 // side 0: own = c1, other = c2.  side 1: own = c2, other = c1.  kscale = sqrt(a_inv) for switchable edges, 0 otherwise.
@@ -257,7 +257,7 @@ PGO_HD void compact_apply(const double* rec, int side, const double* p_own, cons
     if (kscale != 0.0) {
         double k[6], d = 0.0;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) { k[i] = rec[15 + i] * kscale; d += k[i] * u[i]; }
+        for (int i = 0; i < 6; ++i) { k[i] = rec[16 + i] * kscale; d += k[i] * u[i]; }
 #pragma unroll
         for (int i = 0; i < 6; ++i) u[i] -= k[i] * d;
     }

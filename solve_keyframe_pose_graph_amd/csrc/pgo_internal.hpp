@@ -71,14 +71,17 @@ struct GraphDev {
 // Matrix-free operator (PGO_LINEAR_PCG_MATRIX_FREE): one compact record per edge-side in keyframe-major ("incident") order,
 // stored as 11 double2 planes [plane][ninc_pad] so a workgroup tile reads 512 consecutive records with 1-KiB wave loads.
 struct MfDev {
-    const int64_t* einc;         // [ninc]  (slot << 1) | side, edges only, keyframe-major
-    const int32_t* einc_own;     // [ninc]  keyframe this edge-side belongs to
+    // per edge side ("incident"), tile-major; inside a tile: all relative-pose sides of its keyframes (keyframe order), then all
+    // switchable sides (keyframe order) — so only the tail wavefronts of a tile touch the r6 planes
+    const uint32_t* einc;        // [ninc]  bit31 = switchable, bits 30..1 = edge index inside its class, bit0 = side
     const int32_t* einc_other;   // [ninc]  the other endpoint
-    const int64_t* einc_rowptr;  // [N+1]
-    const int64_t* tile_inc0;    // [tiles+1] first edge-side of each workgroup tile (whole keyframes per tile, <= MF_BLOCK sides)
+    const uint8_t* einc_ownl;    // [ninc]  own keyframe, tile-local (0..84)
+    const int64_t* tile_inc0;    // [tiles+1] first edge side of each workgroup tile (whole keyframes per tile, <= MF_BLOCK sides)
+    const int32_t* tile_sw0;     // [tiles]   tile-local index of the first switchable side
     const int32_t* tile_node0;   // [tiles+1]
+    const ushort4* node_rng;     // [N] tile-local {rel_begin, rel_end, sw_begin, sw_end} of the keyframe's sides
     const int32_t* node_prior;   // [N] regulariser index or -1
-    double2* rec;                // [MF_PLANES][ninc_pad]
+    double2* rec;                // [MF_PLANES][ninc_pad]: planes 0-6 q2 b a' dt, plane 7 (w|s, -), planes 8-10 r6 (switchable only)
     double* lam;                 // [N][6] LM damping in the unscaled space (identity rows for fixed keyframes)
     int64_t ninc, ninc_pad;
     int32_t tiles;

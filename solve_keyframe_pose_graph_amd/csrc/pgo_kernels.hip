@@ -779,21 +779,29 @@ __global__ __launch_bounds__(CG_BLOCK) void cg_update_kernel(GraphDev G, CgDev C
     const double* __restrict__ rin = parity ? C.r2 : C.r;
     double* __restrict__ rout = parity ? C.r : C.r2;
     const double* __restrict__ pcur = parity ? C.p2 : C.p;
+    __shared__ double rnew[CG_BLOCK];
     double acc = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * CG_BLOCK + threadIdx.x; i < rows; i += (int64_t)gridDim.x * CG_BLOCK) {
-        const int64_t n = i / 6; const int r = (int)(i - n * 6);
-        const double2* rn = reinterpret_cast<const double2*>(rin + (size_t)n * 6);
-        const double2* qn = reinterpret_cast<const double2*>(C.q + (size_t)n * 6);
-        const double2* M = reinterpret_cast<const double2*>(C.Minv + (size_t)n * 36) + r;
-        const double2 m0 = M[0], m1 = M[6], m2 = M[12];
-        const double2 r0 = rn[0], r1 = rn[1], r2 = rn[2], q0 = qn[0], q1 = qn[1], q2 = qn[2];
-        const double a0 = r0.x - alpha * q0.x, a1 = r0.y - alpha * q0.y, a2 = r1.x - alpha * q1.x, a3 = r1.y - alpha * q1.y, a4 = r2.x - alpha * q2.x, a5 = r2.y - alpha * q2.y;
-        const double z = m0.x * a0 + m0.y * a1 + m1.x * a2 + m1.y * a3 + m2.x * a4 + m2.y * a5;
-        const double rr = r == 0 ? a0 : r == 1 ? a1 : r == 2 ? a2 : r == 3 ? a3 : r == 4 ? a4 : a5;
-        C.x[i] += alpha * pcur[i];
-        rout[i] = rr;
-        C.z[i] = z;
-        acc += rr * z;
+    const int64_t stride = (int64_t)gridDim.x * CG_BLOCK;
+    const int64_t trips = (rows + stride - 1) / stride;
+    for (int64_t it = 0; it < trips; ++it) {
+        const int64_t i = it * stride + (int64_t)blockIdx.x * CG_BLOCK + threadIdx.x;
+        const bool live = i < rows;
+        // each lane forms ITS entry of r' = r - alpha q once (coalesced 8-B loads) and shares it through LDS with the 5 other rows
+        // of its keyframe, instead of every lane re-reading the keyframe's whole r and q
+        double rr = 0.0;
+        if (live) { rr = rin[i] - alpha * C.q[i]; rout[i] = rr; C.x[i] += alpha * pcur[i]; }
+        __syncthreads();
+        rnew[threadIdx.x] = rr;
+        __syncthreads();
+        if (live) {
+            const int64_t n = i / 6; const int r = (int)(i - n * 6);
+            const double* a = rnew + (threadIdx.x - r);
+            const double2* M = reinterpret_cast<const double2*>(C.Minv + (size_t)n * 36) + r;
+            const double2 m0 = M[0], m1 = M[6], m2 = M[12];
+            const double z = m0.x * a[0] + m0.y * a[1] + m1.x * a[2] + m1.y * a[3] + m2.x * a[4] + m2.y * a[5];
+            C.z[i] = z;
+            acc += rr * z;
+        }
     }
     const double s = block_sum(acc, red);
     if (threadIdx.x == 0) C.part_rz[(parity ^ 1) * MAX_PARTIALS + blockIdx.x] = s;
@@ -832,10 +840,10 @@ void launch_apply_operator(const GraphDev& G, const CgDev& C, const double* x, d
 __global__ __launch_bounds__(256) void mf_compact_kernel(GraphDev G, MfDev F, const double* __restrict__ pose8, const double* __restrict__ swv) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= F.ninc) return;
-    const int64_t slot = F.einc[i] >> 1;
-    const bool is_sw = slot >= G.rel.Epad;
+    const uint32_t ent = F.einc[i];
+    const bool is_sw = (ent >> 31) != 0;
+    const int64_t e = (ent & 0x7fffffffu) >> 1;
     const EdgeClassDev& C = is_sw ? G.sw : G.rel;
-    const int64_t e = is_sw ? slot - G.rel.Epad : slot;
     const Pose P1 = load_pose_global(pose8, C.c1[e]);
     const Pose P2 = load_pose_global(pose8, C.c2[e]);
     const double* mp = C.meas + e;
@@ -844,8 +852,8 @@ __global__ __launch_bounds__(256) void mf_compact_kernel(GraphDev G, MfDev F, co
     const double ws = is_sw ? swv[C.swidx[e]] : M.w;
     double rec[COMPACT_DOUBLES];
     edge_compact(P1, P2, M, ws, is_sw, rec);
-#pragma unroll
-    for (int pl = 0; pl < MF_PLANES; ++pl) F.rec[(size_t)pl * F.ninc_pad + i] = make_double2(rec[2 * pl], rec[2 * pl + 1]);
+    const int np = is_sw ? MF_PLANES : 8;
+    for (int pl = 0; pl < np; ++pl) F.rec[(size_t)pl * F.ninc_pad + i] = make_double2(rec[2 * pl], rec[2 * pl + 1]);
 }
 
 template <bool FUSED>
@@ -873,15 +881,15 @@ __global__ __launch_bounds__(MF_BLOCK) void mf_spmv_kernel(GraphDev G, MfDev F, 
     const double* __restrict__ pprev = FUSED ? (parity ? C.p : C.p2) : xin;
     double* __restrict__ pcur = parity ? C.p2 : C.p;
     const double* __restrict__ z = FUSED ? C.z : xin;
-    const int64_t slot_sw = G.rel.Epad;
     const int l = threadIdx.x;
     double pq = 0.0;
     for (int tile = blockIdx.x; tile < F.tiles; tile += gridDim.x) {
         const int64_t i0 = F.tile_inc0[tile], i1 = F.tile_inc0[tile + 1];
         const int32_t n0 = F.tile_node0[tile], n1 = F.tile_node0[tile + 1];
+        const int sw0 = F.tile_sw0[tile];
         const int64_t i = i0 + l;
         const int nn = n1 - n0;
-        // phase 0: the tile's own keyframes' input vector p = z + beta p_prev, once, into LDS (every edge-side of a keyframe needs it,
+        // phase 0: the tile's own keyframes' input vector p = z + beta p_prev, once, into LDS (every edge side of a keyframe needs it,
         // and odometry neighbours are inside the same window): only far endpoints of loop closures gather from global memory
         if (l < nn * 6) {
             const size_t vi = (size_t)n0 * 6 + l;
@@ -891,16 +899,26 @@ __global__ __launch_bounds__(MF_BLOCK) void mf_spmv_kernel(GraphDev G, MfDev F, 
         }
         __syncthreads();
         if (i < i1) {
-            const int64_t ent = F.einc[i];
-            const int64_t slot = ent >> 1;
-            const int side = (int)(ent & 1);
-            const int32_t own = F.einc_own[i], other = F.einc_other[i];
+            const uint32_t ent = F.einc[i];
+            const bool is_sw = l >= sw0;
+            const int side = (int)(ent & 1u);
+            const int32_t other = F.einc_other[i];
+            const int ownl = F.einc_ownl[i];
             double rec[COMPACT_DOUBLES];
 #pragma unroll
-            for (int pl = 0; pl < MF_PLANES; ++pl) { const double2 v = F.rec[(size_t)pl * F.ninc_pad + i]; rec[2 * pl] = v.x; rec[2 * pl + 1] = v.y; }
+            for (int pl = 0; pl < 8; ++pl) { const double2 v = F.rec[(size_t)pl * F.ninc_pad + i]; rec[2 * pl] = v.x; rec[2 * pl + 1] = v.y; }
+            double kscale = 0.0;
+            if (is_sw) {   // tail wavefronts of the tile only
+#pragma unroll
+                for (int pl = 8; pl < MF_PLANES; ++pl) { const double2 v = F.rec[(size_t)pl * F.ninc_pad + i]; rec[2 * pl] = v.x; rec[2 * pl + 1] = v.y; }
+                kscale = sqrt(Sc.a_inv[(ent & 0x7fffffffu) >> 1]);
+            } else {
+#pragma unroll
+                for (int k = 16; k < COMPACT_DOUBLES; ++k) rec[k] = 0.0;
+            }
             double po[6], pt[6];
             {
-                const double* a = pwin + (own - n0) * 6;
+                const double* a = pwin + ownl * 6;
 #pragma unroll
                 for (int c = 0; c < 6; ++c) po[c] = a[c];
             }
@@ -918,7 +936,6 @@ __global__ __launch_bounds__(MF_BLOCK) void mf_spmv_kernel(GraphDev G, MfDev F, 
                     pt[0] += beta * c0.x; pt[1] += beta * c0.y; pt[2] += beta * c1.x; pt[3] += beta * c1.y; pt[4] += beta * c2.x; pt[5] += beta * c2.y;
                 }
             }
-            const double kscale = slot >= slot_sw ? sqrt(Sc.a_inv[slot - slot_sw]) : 0.0;
             double y[6];
             compact_apply(rec, side, po, pt, kscale, y);
 #pragma unroll
@@ -928,12 +945,13 @@ __global__ __launch_bounds__(MF_BLOCK) void mf_spmv_kernel(GraphDev G, MfDev F, 
         if (l < nn * 6) {
             const int nl = l / 6, r = l - nl * 6;
             const int64_t node = (int64_t)n0 + nl;
-            const int b = (int)(F.einc_rowptr[node] - i0), e = (int)(F.einc_rowptr[node + 1] - i0);
             const size_t vi = (size_t)node * 6 + r;
             const double pr = pwin[l];
             double acc = F.lam[vi] * pr;
             if (G.node_free[node]) {
-                for (int j = b; j < e; ++j) acc += contrib[j * 7 + r];
+                const ushort4 rg = F.node_rng[node];
+                for (int j = rg.x; j < rg.y; ++j) acc += contrib[j * 7 + r];    // relative-pose sides, then switchable sides: the same
+                for (int j = rg.z; j < rg.w; ++j) acc += contrib[j * 7 + r];    // fixed order as the incident list -> deterministic
                 const int32_t pk = F.node_prior[node];
                 if (pk >= 0) {   // regulariser: J^T J p of a unary block (a handful per graph)
                     const double* Jp = G.Jp + (size_t)pk * PRIOR_DOUBLES + 6;

@@ -95,8 +95,11 @@ struct pgo_problem {
     DBuf<double> d_pose[2], d_swv[2], d_delta_s, d_io;   // state ping-pong, staging for quat/t
     DBuf<double> d_tmp;
     // matrix-free operator
-    DBuf<int64_t> d_einc, d_einc_rowptr, d_tile_inc0;
-    DBuf<int32_t> d_einc_own, d_einc_other, d_tile_node0, d_node_prior;
+    DBuf<uint32_t> d_einc;
+    DBuf<uint8_t> d_einc_ownl;
+    DBuf<ushort4> d_node_rng;
+    DBuf<int64_t> d_tile_inc0;
+    DBuf<int32_t> d_einc_other, d_tile_node0, d_tile_sw0, d_node_prior;
     DBuf<double2> d_rec;
     DBuf<double> d_lam;
     MfDev F{};
@@ -262,51 +265,76 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S) {
     p->built_mf = mf;
     p->F = MfDev{};
     if (mf) {
-        std::vector<int64_t> erow(N + 1, 0), einc; std::vector<int32_t> eown, eoth, node_prior(N, -1);
-        einc.reserve((size_t)2 * (Er + Es)); eown.reserve(einc.capacity()); eoth.reserve(einc.capacity());
+        // per keyframe: its relative-pose sides and its switchable sides (both in incident-list order), regulariser index
+        std::vector<int32_t> node_prior(N, -1), deg_rel(N, 0), deg_sw(N, 0);
         const int64_t slot_pr = G.rel.Epad + G.sw.Epad;
         for (int64_t n = 0; n < N; ++n) {
             for (int64_t k = rowptr[n]; k < rowptr[n + 1]; ++k) {
-                const int64_t slot = inc[k] >> 1; const int side = (int)(inc[k] & 1);
+                const int64_t slot = inc[k] >> 1;
                 if (slot >= slot_pr) {
                     if (node_prior[n] >= 0) { p->err = "matrix-free operator: more than one regulariser on a keyframe"; return PGO_ERR_INVALID_ARG; }
                     node_prior[n] = (int32_t)(slot - slot_pr);
-                    continue;
-                }
-                const bool is_sw = slot >= G.rel.Epad;
-                const int64_t e = is_sw ? slot - G.rel.Epad : slot;
-                const int32_t a = is_sw ? p->swe.c1[e] : p->rel.c1[e], b = is_sw ? p->swe.c2[e] : p->rel.c2[e];
-                einc.push_back(inc[k]); eown.push_back((int32_t)n); eoth.push_back(side == 0 ? b : a);
+                } else if (slot >= G.rel.Epad) ++deg_sw[n]; else ++deg_rel[n];
             }
-            erow[n + 1] = (int64_t)einc.size();
+            if (deg_rel[n] + deg_sw[n] > MF_BLOCK) { p->err = "matrix-free operator: a keyframe with more than 512 incident edges (use PGO_LINEAR_PCG_BLOCK_JACOBI)"; return PGO_ERR_INVALID_ARG; }
         }
-        std::vector<int64_t> tile_inc0; std::vector<int32_t> tile_node0;
-        tile_inc0.push_back(0); tile_node0.push_back(0);
-        int64_t cur = 0; int cur_nodes = 0;
-        for (int64_t n = 0; n < N; ++n) {
-            const int64_t d = erow[n + 1] - erow[n];
-            if (d > MF_BLOCK) { p->err = "matrix-free operator: a keyframe with more than 512 incident edges (use PGO_LINEAR_PCG_BLOCK_JACOBI)"; return PGO_ERR_INVALID_ARG; }
-            if (cur + d > MF_BLOCK || cur_nodes >= MF_MAX_NODES) { tile_inc0.push_back(erow[n]); tile_node0.push_back((int32_t)n); cur = 0; cur_nodes = 0; }
-            cur += d; ++cur_nodes;
+        if ((int64_t)std::max(G.rel.E, G.sw.E) >= (1ll << 30)) { p->err = "matrix-free operator: more than 2^30 edges in one class"; return PGO_ERR_INVALID_ARG; }
+        // pack whole keyframes into workgroup tiles
+        std::vector<int32_t> tile_node0; tile_node0.push_back(0);
+        { int64_t cur = 0; int cur_nodes = 0;
+          for (int64_t n = 0; n < N; ++n) {
+              const int64_t d = deg_rel[n] + deg_sw[n];
+              if (cur + d > MF_BLOCK || cur_nodes >= MF_MAX_NODES) { tile_node0.push_back((int32_t)n); cur = 0; cur_nodes = 0; }
+              cur += d; ++cur_nodes;
+          }
+          tile_node0.push_back((int32_t)N); }
+        const int tiles = (int)tile_node0.size() - 1;
+        std::vector<int64_t> tile_inc0(tiles + 1, 0);
+        std::vector<int32_t> tile_sw0(std::max(tiles, 1), 0);
+        std::vector<uint32_t> einc; std::vector<int32_t> eoth; std::vector<uint8_t> eown; std::vector<ushort4> node_rng(std::max<int64_t>(N, 1));
+        einc.reserve((size_t)2 * (Er + Es)); eoth.reserve(einc.capacity()); eown.reserve(einc.capacity());
+        for (int t = 0; t < tiles; ++t) {
+            const int32_t n0 = tile_node0[t], n1 = tile_node0[t + 1];
+            tile_inc0[t] = (int64_t)einc.size();
+            for (int pass = 0; pass < 2; ++pass) {          // pass 0: relative-pose sides, pass 1: switchable sides
+                if (pass == 1) tile_sw0[t] = (int32_t)((int64_t)einc.size() - tile_inc0[t]);
+                for (int32_t n = n0; n < n1; ++n) {
+                    const unsigned short begin = (unsigned short)((int64_t)einc.size() - tile_inc0[t]);
+                    for (int64_t k = rowptr[n]; k < rowptr[n + 1]; ++k) {
+                        const int64_t slot = inc[k] >> 1; const int side = (int)(inc[k] & 1);
+                        if (slot >= slot_pr) continue;
+                        const bool is_sw = slot >= G.rel.Epad;
+                        if ((int)is_sw != pass) continue;
+                        const int64_t e = is_sw ? slot - G.rel.Epad : slot;
+                        const int32_t a = is_sw ? p->swe.c1[e] : p->rel.c1[e], b = is_sw ? p->swe.c2[e] : p->rel.c2[e];
+                        einc.push_back((is_sw ? 0x80000000u : 0u) | (uint32_t)(e << 1) | (uint32_t)side);
+                        eoth.push_back(side == 0 ? b : a);
+                        eown.push_back((uint8_t)(n - n0));
+                    }
+                    const unsigned short end = (unsigned short)((int64_t)einc.size() - tile_inc0[t]);
+                    if (pass == 0) { node_rng[n].x = begin; node_rng[n].y = end; } else { node_rng[n].z = begin; node_rng[n].w = end; }
+                }
+            }
         }
-        tile_inc0.push_back(erow[N]); tile_node0.push_back((int32_t)N);
+        tile_inc0[tiles] = (int64_t)einc.size();
         const int64_t ninc_e = (int64_t)einc.size();
         const int64_t ninc_pad = (ninc_e + 63) / 64 * 64 + 64;
-        const int tiles = (int)tile_node0.size() - 1;
-        HIPCHK(p, p->d_einc.ensure(std::max<int64_t>(ninc_e, 1))); HIPCHK(p, p->d_einc_own.ensure(std::max<int64_t>(ninc_e, 1))); HIPCHK(p, p->d_einc_other.ensure(std::max<int64_t>(ninc_e, 1)));
-        HIPCHK(p, p->d_einc_rowptr.ensure(N + 1)); HIPCHK(p, p->d_tile_inc0.ensure(tiles + 1)); HIPCHK(p, p->d_tile_node0.ensure(tiles + 1)); HIPCHK(p, p->d_node_prior.ensure(std::max<int64_t>(N, 1)));
+        HIPCHK(p, p->d_einc.ensure(std::max<int64_t>(ninc_e, 1))); HIPCHK(p, p->d_einc_ownl.ensure(std::max<int64_t>(ninc_e, 1))); HIPCHK(p, p->d_einc_other.ensure(std::max<int64_t>(ninc_e, 1)));
+        HIPCHK(p, p->d_node_rng.ensure(std::max<int64_t>(N, 1))); HIPCHK(p, p->d_tile_inc0.ensure(tiles + 1)); HIPCHK(p, p->d_tile_node0.ensure(tiles + 1));
+        HIPCHK(p, p->d_tile_sw0.ensure(std::max(tiles, 1))); HIPCHK(p, p->d_node_prior.ensure(std::max<int64_t>(N, 1)));
         HIPCHK(p, p->d_rec.ensure((size_t)MF_PLANES * ninc_pad)); HIPCHK(p, p->d_lam.ensure(std::max<int64_t>(N * 6, 1)));
         if (ninc_e) {
-            HIPCHK(p, hipMemcpyAsync(p->d_einc.p, einc.data(), ninc_e * sizeof(int64_t), hipMemcpyHostToDevice, p->st));
-            HIPCHK(p, hipMemcpyAsync(p->d_einc_own.p, eown.data(), ninc_e * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
+            HIPCHK(p, hipMemcpyAsync(p->d_einc.p, einc.data(), ninc_e * sizeof(uint32_t), hipMemcpyHostToDevice, p->st));
+            HIPCHK(p, hipMemcpyAsync(p->d_einc_ownl.p, eown.data(), ninc_e * sizeof(uint8_t), hipMemcpyHostToDevice, p->st));
             HIPCHK(p, hipMemcpyAsync(p->d_einc_other.p, eoth.data(), ninc_e * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
         }
-        HIPCHK(p, hipMemcpyAsync(p->d_einc_rowptr.p, erow.data(), (N + 1) * sizeof(int64_t), hipMemcpyHostToDevice, p->st));
+        HIPCHK(p, hipMemcpyAsync(p->d_node_rng.p, node_rng.data(), N * sizeof(ushort4), hipMemcpyHostToDevice, p->st));
         HIPCHK(p, hipMemcpyAsync(p->d_tile_inc0.p, tile_inc0.data(), (tiles + 1) * sizeof(int64_t), hipMemcpyHostToDevice, p->st));
         HIPCHK(p, hipMemcpyAsync(p->d_tile_node0.p, tile_node0.data(), (tiles + 1) * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
+        if (tiles) HIPCHK(p, hipMemcpyAsync(p->d_tile_sw0.p, tile_sw0.data(), tiles * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
         HIPCHK(p, hipMemcpyAsync(p->d_node_prior.p, node_prior.data(), N * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
         HIPCHK(p, hipStreamSynchronize(p->st));
-        p->F = MfDev{p->d_einc.p, p->d_einc_own.p, p->d_einc_other.p, p->d_einc_rowptr.p, p->d_tile_inc0.p, p->d_tile_node0.p, p->d_node_prior.p,
+        p->F = MfDev{p->d_einc.p, p->d_einc_other.p, p->d_einc_ownl.p, p->d_tile_inc0.p, p->d_tile_sw0.p, p->d_tile_node0.p, p->d_node_rng.p, p->d_node_prior.p,
                      p->d_rec.p, p->d_lam.p, ninc_e, ninc_pad, tiles};
     }
     // ---- work buffers
@@ -752,8 +780,8 @@ int pgo_destroy(pgo_problem* p) {
     p->d_val.release(); p->d_Minv.release(); p->d_Dtot_b.release(); p->d_cgvec.release(); p->d_part.release(); p->d_cgpart.release();
     p->d_flags.release(); p->d_scal.release(); p->d_pose[0].release(); p->d_pose[1].release(); p->d_swv[0].release(); p->d_swv[1].release();
     p->d_delta_s.release(); p->d_io.release(); p->d_tmp.release();
-    p->d_einc.release(); p->d_einc_rowptr.release(); p->d_tile_inc0.release(); p->d_einc_own.release(); p->d_einc_other.release();
-    p->d_tile_node0.release(); p->d_node_prior.release(); p->d_rec.release(); p->d_lam.release();
+    p->d_einc.release(); p->d_einc_ownl.release(); p->d_node_rng.release(); p->d_tile_inc0.release(); p->d_einc_other.release();
+    p->d_tile_node0.release(); p->d_tile_sw0.release(); p->d_node_prior.release(); p->d_rec.release(); p->d_lam.release();
     (void)hipStreamDestroy(p->st);
     delete p;
     return PGO_OK;
