@@ -28,7 +28,7 @@ constexpr int TILE = 64;
 constexpr int REL_DOUBLES = 78;    // r6 + J1 + J2
 constexpr int SW_DOUBLES = 86;     // r7 + Js7 + J1 + J2
 constexpr int K1_WAVES = 4;        // wavefronts (tiles) per K1 workgroup
-constexpr int WIN_MAX = 96;        // poses per LDS window
+constexpr int WIN_MAX = 72;        // poses per LDS window: 46 KB of LDS per workgroup -> 3 workgroups/CU (measured 34.3 us; 96 poses / 2 per CU: 36.0 us)
 constexpr int WIN_STRIDE = 80;     // bytes per staged pose record (64 B + 16 B pad: conflict-free ds_read_b128)
 constexpr int MAX_PARTIALS = 1024; // grid cap for kernels that emit per-block partial sums
 constexpr int PRIOR_DOUBLES = 42;  // r6 + J1
