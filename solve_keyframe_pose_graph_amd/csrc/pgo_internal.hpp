@@ -15,7 +15,7 @@
 //               c [Es][12] = [J1^T Js ; J2^T Js], hss [Es], gs [Es]
 //   LM system: BSR of the Schur-reduced damped normal matrix, one block row per keyframe:
 //     bsr_rowptr [N+1], bsr_col [nnzb] int32 (static per graph), bsr_val [nnzb][36] (rebuilt per LM iteration)
-//     Minv [N][36] block-Jacobi preconditioner, b [N][6] right-hand side, CG vectors [N][6]
+//     Lf [N][24] block-Jacobi preconditioner (packed fp32 Cholesky factors), b [N][6] right-hand side, CG vectors [N][6]
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -100,7 +100,7 @@ struct ScaleDev {
 };
 
 struct CgDev {
-    double* val; double* Minv; double* Dtot; double* b;
+    double* val; float* Lf; double* Dtot; double* b;   // Lf [N][24]: packed fp32 Cholesky factor of the block-Jacobi blocks
     double* x; double* r; double* r2; double* z; double* p; double* p2; double* q;   // r/r2 and p/p2 ping-pong by iteration parity
     double* part_pq;      // [MAX_PARTIALS]
     double* part_rz;      // [2][MAX_PARTIALS]

@@ -494,59 +494,16 @@ __global__ __launch_bounds__(256) void build_rows_kernel(GraphDev G, LinDev L, S
     for (int i = 0; i < 6; ++i) C.b[(size_t)n * 6 + i] = bv[i];
 }
 
-// 6x6 SPD inverse through Cholesky, fully unrolled in registers.  Returns false when not positive definite.
-__device__ __forceinline__ bool spd6_inverse(const double* A, double* Ai) {
-    double Lm[36];
-    bool ok = true;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        double d = A[j * 6 + j];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) if (k < j) d -= Lm[j * 6 + k] * Lm[j * 6 + k];
-        ok = ok && (d > 0.0);
-        d = sqrt(d);
-        Lm[j * 6 + j] = d;
-        const double di = 1.0 / d;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) if (i > j) {
-            double s = A[i * 6 + j];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) if (k < j) s -= Lm[i * 6 + k] * Lm[j * 6 + k];
-            Lm[i * 6 + j] = s * di;
-        }
-    }
-    // Li = L^-1 (lower)
-    double Li[36];
-#pragma unroll
-    for (int i = 0; i < 36; ++i) Li[i] = 0.0;
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {
-        Li[c * 6 + c] = 1.0 / Lm[c * 6 + c];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) if (i > c) {
-            double s = 0.0;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) if (k >= c && k < i) s -= Lm[i * 6 + k] * Li[k * 6 + c];
-            Li[i * 6 + c] = s / Lm[i * 6 + i];
-        }
-    }
-    // A^-1 = Li^T Li
-#pragma unroll
-    for (int a = 0; a < 6; ++a)
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            double s = 0.0;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) if (k >= a && k >= c) s += Li[k * 6 + a] * Li[k * 6 + c];
-            Ai[a * 6 + c] = s;
-        }
-    return ok;
-}
+// Block-Jacobi preconditioner in FACTORED form: the lower Cholesky factor L of every (Schur-reduced, damped) 6x6 diagonal block, packed
+// (21 entries, diagonal stored as 1/L_ii) and rounded to fp32 — 96 B per keyframe instead of 288 B for an fp64 inverse.  M = L~ L~^T
+// is symmetric positive definite whatever the rounding did, so PCG stays valid; the arithmetic applying it is fp64.
+constexpr int LF_STRIDE = 24;   // floats per keyframe (21 used): 6 x 16-B loads
+__device__ __forceinline__ int lf_idx(int i, int j) { return i * (i + 1) / 2 + j; }   // i >= j
 
 __global__ __launch_bounds__(256) void invert_rows_kernel(GraphDev G, CgDev C, int32_t* fail) {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= G.N) return;
-    double D[36], Di[36];
+    double D[36], Lm[36];
 #pragma unroll
     for (int i = 0; i < 36; ++i) D[i] = C.Dtot[(size_t)n * 36 + i];
     if (!G.node_free[n]) {
@@ -555,12 +512,89 @@ __global__ __launch_bounds__(256) void invert_rows_kernel(GraphDev G, CgDev C, i
 #pragma unroll
         for (int c = 0; c < 6; ++c) D[c * 6 + c] = 1.0;
     }
-    const bool ok = spd6_inverse(D, Di);
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double d = D[j * 6 + j];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) if (k < j) d -= Lm[j * 6 + k] * Lm[j * 6 + k];
+        ok = ok && (d > 0.0);
+        d = sqrt(d);
+        Lm[j * 6 + j] = d;
+        const double di = 1.0 / d;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) if (i > j) {
+            double sacc = D[i * 6 + j];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) if (k < j) sacc -= Lm[i * 6 + k] * Lm[j * 6 + k];
+            Lm[i * 6 + j] = sacc * di;
+        }
+    }
     if (!ok) atomicOr(fail, 1);
+    float out[LF_STRIDE];
 #pragma unroll
-    for (int a = 0; a < 6; ++a)
+    for (int i = 0; i < LF_STRIDE; ++i) out[i] = 0.0f;
 #pragma unroll
-        for (int c = 0; c < 6; ++c) C.Minv[(size_t)n * 36 + pm(a, c)] = Di[a * 6 + c];
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) if (j <= i) out[lf_idx(i, j)] = (float)(i == j ? 1.0 / Lm[i * 6 + i] : Lm[i * 6 + j]);
+    float4* dst = reinterpret_cast<float4*>(C.Lf + (size_t)n * LF_STRIDE);
+#pragma unroll
+    for (int k = 0; k < LF_STRIDE / 4; ++k) dst[k] = make_float4(out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]);
+}
+
+// z_r = (L L^T)^-1 a, component r, from the packed factor in LDS (diagonal inverted) and the keyframe's 6-vector a
+__device__ __forceinline__ double lf_apply_row(const float* __restrict__ Lf, const double* __restrict__ a, int r) {
+    double y[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double sacc = a[i];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) if (j < i) sacc -= (double)Lf[lf_idx(i, j)] * y[j];
+        y[i] = sacc * (double)Lf[lf_idx(i, i)];
+    }
+    double zz[6];
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double sacc = y[i];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) if (j > i) sacc -= (double)Lf[lf_idx(j, i)] * zz[j];
+        zz[i] = sacc * (double)Lf[lf_idx(i, i)];
+    }
+    double out = zz[0];
+#pragma unroll
+    for (int i = 1; i < 6; ++i) out = (r == i) ? zz[i] : out;
+    return out;
+}
+// the workgroup's CG_BLOCK/6 keyframes' factors -> LDS: exactly one coalesced 16-B load per lane
+template <int KEYFRAMES>
+__device__ __forceinline__ void lf_stage(const float* __restrict__ Lf_global, int64_t first_node, int64_t n_nodes_total, float* lds) {
+    for (int f4 = threadIdx.x; f4 < KEYFRAMES * 6; f4 += blockDim.x) {   // 6 float4 per keyframe, consecutive lanes -> consecutive 16 B
+        const int64_t node = first_node + f4 / 6;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (node < n_nodes_total) v = reinterpret_cast<const float4*>(Lf_global + (size_t)first_node * LF_STRIDE)[f4];
+        reinterpret_cast<float4*>(lds)[f4] = v;
+    }
+}
+// both rows (2j, 2j+1) of z = (L L^T)^-1 a for the lane owning row pair j
+__device__ __forceinline__ double2 lf_apply_pair(const float* __restrict__ Lf, const double* __restrict__ a, int j) {
+    double y[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double sacc = a[i];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) if (k < i) sacc -= (double)Lf[lf_idx(i, k)] * y[k];
+        y[i] = sacc * (double)Lf[lf_idx(i, i)];
+    }
+    double zz[6];
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double sacc = y[i];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) if (k > i) sacc -= (double)Lf[lf_idx(k, i)] * zz[k];
+        zz[i] = sacc * (double)Lf[lf_idx(i, i)];
+    }
+    return j == 0 ? make_double2(zz[0], zz[1]) : j == 1 ? make_double2(zz[2], zz[3]) : make_double2(zz[4], zz[5]);
 }
 
 void launch_build_rows(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, double radius, int add_lambda, double* lam_out, hipStream_t st) {
@@ -724,30 +758,34 @@ __global__ __launch_bounds__(CG_BLOCK) void apply_operator_kernel(GraphDev G, Cg
 }
 
 // cold: x = 0, r = b.   warm (after a rejected step: same H, larger damping): x keeps the previous solution, r = b - A x (A x is in q).
-// z = Minv r, partial r.z -> part_rz[0]; the convergence reference stays ||b||_{Minv} (partials -> part_pq) in both cases.
+// z = M^-1 r, partial r.z -> part_rz[0]; the convergence reference stays ||b||_{M^-1} (partials -> part_pq) in both cases.
 __global__ __launch_bounds__(CG_BLOCK) void cg_init_kernel(GraphDev G, CgDev C, int warm) {
     __shared__ double red[CG_BLOCK / 64];
+    __shared__ __attribute__((aligned(16))) float lfs[CG_BLOCK / 6 * LF_STRIDE];
+    __shared__ double av[CG_BLOCK], bv[CG_BLOCK];
     const int64_t rows = G.N * 6;
+    const int64_t stride = (int64_t)gridDim.x * CG_BLOCK;
+    const int64_t trips = (rows + stride - 1) / stride;
     double rz = 0.0, bb = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * CG_BLOCK + threadIdx.x; i < rows; i += (int64_t)gridDim.x * CG_BLOCK) {
-        const int64_t n = i / 6; const int r = (int)(i - n * 6);
-        const double2* bn = reinterpret_cast<const double2*>(C.b + (size_t)n * 6);
-        const double2* M = reinterpret_cast<const double2*>(C.Minv + (size_t)n * 36) + r;
-        const double2 m0 = M[0], m1 = M[6], m2 = M[12], b0 = bn[0], b1 = bn[1], b2 = bn[2];
-        const double zb = m0.x * b0.x + m0.y * b0.y + m1.x * b1.x + m1.y * b1.y + m2.x * b2.x + m2.y * b2.y;
-        const double bi = C.b[i];
-        bb += bi * zb;
-        double ri = bi, z = zb;
-        if (warm) {
-            const double2* qn = reinterpret_cast<const double2*>(C.q + (size_t)n * 6);
-            const double2 q0 = qn[0], q1 = qn[1], q2 = qn[2];
-            z = m0.x * (b0.x - q0.x) + m0.y * (b0.y - q0.y) + m1.x * (b1.x - q1.x) + m1.y * (b1.y - q1.y) + m2.x * (b2.x - q2.x) + m2.y * (b2.y - q2.y);
-            ri = bi - C.q[i];
-        } else {
-            C.x[i] = 0.0;
+    for (int64_t it = 0; it < trips; ++it) {
+        const int64_t base = it * stride + (int64_t)blockIdx.x * CG_BLOCK;
+        const int64_t i = base + threadIdx.x;
+        const bool live = i < rows;
+        const double bi = live ? C.b[i] : 0.0;
+        const double ri = live ? (warm ? bi - C.q[i] : bi) : 0.0;
+        __syncthreads();
+        lf_stage<CG_BLOCK / 6>(C.Lf, base / 6, G.N, lfs);
+        av[threadIdx.x] = ri; bv[threadIdx.x] = bi;
+        __syncthreads();
+        if (live) {
+            const int r = (int)(i % 6);
+            const float* Lf = lfs + (threadIdx.x / 6) * LF_STRIDE;
+            const double z = lf_apply_row(Lf, av + (threadIdx.x - r), r);
+            const double zb = warm ? lf_apply_row(Lf, bv + (threadIdx.x - r), r) : z;
+            if (!warm) C.x[i] = 0.0;
+            C.r[i] = ri; C.z[i] = z; C.p[i] = 0.0; C.p2[i] = 0.0;   // p buffers zeroed: iteration 0 multiplies them by beta = 0
+            rz += ri * z; bb += bi * zb;
         }
-        C.r[i] = ri; C.z[i] = z; C.p[i] = 0.0; C.p2[i] = 0.0;   // p buffers zeroed: iteration 0 multiplies them by beta = 0
-        rz += ri * z;
     }
     const double s = block_sum(rz, red);
     const double sb = block_sum(bb, red);
@@ -767,6 +805,23 @@ __global__ void cg_scalars_init_kernel(CgDev C, int nparts) {
 __global__ __launch_bounds__(CG_BLOCK) void cg_update_kernel(GraphDev G, CgDev C, int parity, int nparts_pq, int nparts) {
     __shared__ double red[2 * (CG_BLOCK / 64)];
     if (cg_done(C)) return;
+    const double2* __restrict__ rin = reinterpret_cast<const double2*>(parity ? C.r2 : C.r);
+    double2* __restrict__ rout = reinterpret_cast<double2*>(parity ? C.r : C.r2);
+    const double2* __restrict__ pcur = reinterpret_cast<const double2*>(parity ? C.p2 : C.p);
+    const double2* __restrict__ qv = reinterpret_cast<const double2*>(C.q);
+    double2* __restrict__ xv = reinterpret_cast<double2*>(C.x);
+    double2* __restrict__ zv = reinterpret_cast<double2*>(C.z);
+    // one lane per (keyframe, ROW PAIR): every vector access is 16 B/lane (8-B accesses reach only ~0.6x of the streaming rate);
+    // a workgroup covers CG_BLOCK/3 = 64 keyframes per trip
+    constexpr int KF = CG_BLOCK / 3;
+    const int64_t pairs = G.N * 3;
+    const int64_t stride = (int64_t)gridDim.x * CG_BLOCK;
+    const int64_t trips = (pairs + stride - 1) / stride;
+    // the first trip's operands do not depend on alpha: issue their loads BEFORE the partial-sum re-reduction so that its ~2 us of
+    // dependent L2 round trips overlap with the streaming loads
+    const int64_t i_first = (int64_t)blockIdx.x * CG_BLOCK + threadIdx.x;
+    double2 r0 = make_double2(0.0, 0.0), q0 = r0, p0 = r0, x0 = r0;
+    if (i_first < pairs) { r0 = rin[i_first]; q0 = qv[i_first]; p0 = pcur[i_first]; x0 = xv[i_first]; }
     double pq, rz;   // pq partials are produced by the matvec kernel (its own grid size)
     block_total2(C.part_pq, nparts_pq, C.part_rz + parity * MAX_PARTIALS, nparts, red, pq, rz);
     if (!(pq > 0.0)) {   // breakdown: matrix not positive definite along p (or NaN); x is left untouched, the next spmv raises done
@@ -775,32 +830,29 @@ __global__ __launch_bounds__(CG_BLOCK) void cg_update_kernel(GraphDev G, CgDev C
         return;
     }
     const double alpha = rz / pq;
-    const int64_t rows = G.N * 6;
-    const double* __restrict__ rin = parity ? C.r2 : C.r;
-    double* __restrict__ rout = parity ? C.r : C.r2;
-    const double* __restrict__ pcur = parity ? C.p2 : C.p;
-    __shared__ double rnew[CG_BLOCK];
+    __shared__ double2 rnew[CG_BLOCK];
+    __shared__ __attribute__((aligned(16))) float lfs[KF * LF_STRIDE];
     double acc = 0.0;
-    const int64_t stride = (int64_t)gridDim.x * CG_BLOCK;
-    const int64_t trips = (rows + stride - 1) / stride;
     for (int64_t it = 0; it < trips; ++it) {
-        const int64_t i = it * stride + (int64_t)blockIdx.x * CG_BLOCK + threadIdx.x;
-        const bool live = i < rows;
-        // each lane forms ITS entry of r' = r - alpha q once (coalesced 8-B loads) and shares it through LDS with the 5 other rows
-        // of its keyframe, instead of every lane re-reading the keyframe's whole r and q
-        double rr = 0.0;
-        if (live) { rr = rin[i] - alpha * C.q[i]; rout[i] = rr; C.x[i] += alpha * pcur[i]; }
+        const int64_t base = it * stride + (int64_t)blockIdx.x * CG_BLOCK;
+        const int64_t i = base + threadIdx.x;
+        const bool live = i < pairs;
+        double2 rr = make_double2(0.0, 0.0);
+        if (live) {
+            if (it > 0) { r0 = rin[i]; q0 = qv[i]; p0 = pcur[i]; x0 = xv[i]; }
+            rr = make_double2(r0.x - alpha * q0.x, r0.y - alpha * q0.y);
+            x0.x += alpha * p0.x; x0.y += alpha * p0.y;
+            rout[i] = rr; xv[i] = x0;
+        }
         __syncthreads();
+        lf_stage<KF>(C.Lf, base / 3, G.N, lfs);
         rnew[threadIdx.x] = rr;
         __syncthreads();
         if (live) {
-            const int64_t n = i / 6; const int r = (int)(i - n * 6);
-            const double* a = rnew + (threadIdx.x - r);
-            const double2* M = reinterpret_cast<const double2*>(C.Minv + (size_t)n * 36) + r;
-            const double2 m0 = M[0], m1 = M[6], m2 = M[12];
-            const double z = m0.x * a[0] + m0.y * a[1] + m1.x * a[2] + m1.y * a[3] + m2.x * a[4] + m2.y * a[5];
-            C.z[i] = z;
-            acc += rr * z;
+            const int j = (int)(i % 3);
+            const double2 z = lf_apply_pair(lfs + (threadIdx.x / 3) * LF_STRIDE, reinterpret_cast<const double*>(rnew + (threadIdx.x - j)), j);
+            zv[i] = z;
+            acc += rr.x * z.x + rr.y * z.y;
         }
     }
     const double s = block_sum(acc, red);
@@ -862,6 +914,7 @@ __global__ __launch_bounds__(MF_BLOCK) void mf_spmv_kernel(GraphDev G, MfDev F, 
     __shared__ double contrib[MF_BLOCK * 7];
     __shared__ double pwin[MF_BLOCK];
     __shared__ double red[2 * (MF_BLOCK / 64)];
+    const int l = threadIdx.x;
     double beta = 0.0;
     if (FUSED) {
         if (cg_done(C)) return;
@@ -881,7 +934,6 @@ __global__ __launch_bounds__(MF_BLOCK) void mf_spmv_kernel(GraphDev G, MfDev F, 
     const double* __restrict__ pprev = FUSED ? (parity ? C.p : C.p2) : xin;
     double* __restrict__ pcur = parity ? C.p2 : C.p;
     const double* __restrict__ z = FUSED ? C.z : xin;
-    const int l = threadIdx.x;
     double pq = 0.0;
     for (int tile = blockIdx.x; tile < F.tiles; tile += gridDim.x) {
         const int64_t i0 = F.tile_inc0[tile], i1 = F.tile_inc0[tile + 1];

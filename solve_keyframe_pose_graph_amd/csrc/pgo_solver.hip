@@ -86,7 +86,8 @@ struct pgo_problem {
     DBuf<double> d_Hd_g;             // Hd [N][36] followed by g [N][6]  (contiguous: one all-reduce)
     DBuf<double> d_Hoff, d_c, d_hss, d_gs;
     DBuf<double> d_scale_p, d_scale_s, d_diag_p, d_diag_s, d_a_inv;
-    DBuf<double> d_val, d_Minv, d_Dtot_b;   // Dtot [N][36] followed by b [N][6]
+    DBuf<double> d_val, d_Dtot_b;   // Dtot [N][36] followed by b [N][6]
+    DBuf<float> d_Lf;
     DBuf<double> d_cgvec;            // x r r2 z p p2 q  (7 x [N][6])
     DBuf<double> d_part;             // partial-sum scratch: several arrays of n_part
     DBuf<double> d_cgpart;           // part_pq [MAX] + part_rz [2][MAX] + scal[4]
@@ -261,7 +262,17 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S) {
     HIPCHK(p, hipStreamSynchronize(p->st));
 
     // ---- matrix-free operator: edge-sides in keyframe-major order, packed into workgroup tiles of whole keyframes
-    const bool mf = p->opt.linear_solver == PGO_LINEAR_PCG_MATRIX_FREE;
+    bool mf = p->opt.linear_solver == PGO_LINEAR_PCG_MATRIX_FREE;
+    if (mf) {
+        // a keyframe with more edge sides than a workgroup tile holds (a hub revisited hundreds of times), or with several regularisers,
+        // is served by the assembled block-CSR operator instead
+        const int64_t slot_pr0 = G.rel.Epad + G.sw.Epad;
+        for (int64_t n = 0; n < N && mf; ++n) {
+            int64_t deg = 0, npri = 0;
+            for (int64_t k = rowptr[n]; k < rowptr[n + 1]; ++k) { if ((inc[k] >> 1) >= slot_pr0) ++npri; else ++deg; }
+            if (deg > MF_BLOCK || npri > 1) mf = false;
+        }
+    }
     p->built_mf = mf;
     p->F = MfDev{};
     if (mf) {
@@ -347,7 +358,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S) {
     HIPCHK(p, p->d_c.ensure(std::max<int64_t>(Es * 12, 1))); HIPCHK(p, p->d_hss.ensure(std::max<int64_t>(Es, 1))); HIPCHK(p, p->d_gs.ensure(std::max<int64_t>(Es, 1)));
     HIPCHK(p, p->d_scale_p.ensure(std::max<int64_t>(N * 6, 1))); HIPCHK(p, p->d_diag_p.ensure(std::max<int64_t>(N * 6, 1)));
     HIPCHK(p, p->d_scale_s.ensure(std::max<int64_t>(Es, 1))); HIPCHK(p, p->d_diag_s.ensure(std::max<int64_t>(Es, 1))); HIPCHK(p, p->d_a_inv.ensure(std::max<int64_t>(Es, 1)));
-    HIPCHK(p, p->d_val.ensure(mf ? 1 : std::max<int64_t>(p->nnzb * 36, 1))); HIPCHK(p, p->d_Minv.ensure(std::max<int64_t>(N * 36, 1))); HIPCHK(p, p->d_Dtot_b.ensure(std::max<int64_t>(N * 42, 1)));
+    HIPCHK(p, p->d_val.ensure(mf ? 1 : std::max<int64_t>(p->nnzb * 36, 1))); HIPCHK(p, p->d_Lf.ensure(std::max<int64_t>(N * 24 + 64 * 24, 1))); HIPCHK(p, p->d_Dtot_b.ensure(std::max<int64_t>(N * 42, 1)));
     HIPCHK(p, p->d_cgvec.ensure(std::max<int64_t>(N * 42, 1)));
     p->n_part = std::max<int64_t>(MAX_PARTIALS, (G.rel.tiles + G.sw.tiles + 3) / 4 + 1);
     HIPCHK(p, p->d_part.ensure(p->n_part * 6));
@@ -363,7 +374,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S) {
     p->L = LinDev{p->d_Hd_g.p, p->d_Hd_g.p + (size_t)N * 36, p->d_Hoff.p, p->d_c.p, p->d_hss.p, p->d_gs.p};
     p->Sc = ScaleDev{p->d_scale_p.p, p->d_scale_s.p, p->d_diag_p.p, p->d_diag_s.p, p->d_a_inv.p};
     CgDev& C = p->C;
-    C.val = p->d_val.p; C.Minv = p->d_Minv.p; C.Dtot = p->d_Dtot_b.p; C.b = p->d_Dtot_b.p + (size_t)N * 36;
+    C.val = p->d_val.p; C.Lf = p->d_Lf.p; C.Dtot = p->d_Dtot_b.p; C.b = p->d_Dtot_b.p + (size_t)N * 36;
     double* v = p->d_cgvec.p; const size_t n6 = (size_t)N * 6;
     C.x = v; C.r = v + n6; C.r2 = v + 2 * n6; C.z = v + 3 * n6; C.p = v + 4 * n6; C.p2 = v + 5 * n6; C.q = v + 6 * n6;
     C.part_pq = p->d_cgpart.p; C.part_rz = p->d_cgpart.p + MF_MAX_GRID; C.scal = p->d_cgpart.p + MF_MAX_GRID + 2 * MAX_PARTIALS;
@@ -777,7 +788,7 @@ int pgo_destroy(pgo_problem* p) {
     p->d_inc_rowptr.release(); p->d_inc.release(); p->d_bsr_rowptr.release(); p->d_node_free.release();
     p->d_Jr.release(); p->d_Js.release(); p->d_Jp.release(); p->d_Hd_g.release(); p->d_Hoff.release(); p->d_c.release(); p->d_hss.release(); p->d_gs.release();
     p->d_scale_p.release(); p->d_scale_s.release(); p->d_diag_p.release(); p->d_diag_s.release(); p->d_a_inv.release();
-    p->d_val.release(); p->d_Minv.release(); p->d_Dtot_b.release(); p->d_cgvec.release(); p->d_part.release(); p->d_cgpart.release();
+    p->d_val.release(); p->d_Lf.release(); p->d_Dtot_b.release(); p->d_cgvec.release(); p->d_part.release(); p->d_cgpart.release();
     p->d_flags.release(); p->d_scal.release(); p->d_pose[0].release(); p->d_pose[1].release(); p->d_swv[0].release(); p->d_swv[1].release();
     p->d_delta_s.release(); p->d_io.release(); p->d_tmp.release();
     p->d_einc.release(); p->d_einc_ownl.release(); p->d_node_rng.release(); p->d_tile_inc0.release(); p->d_einc_other.release();

@@ -175,3 +175,33 @@ def test_error_paths():
         P.solve(np.tile([0, 0, 0, 1.0], (1, 1)), np.zeros((1, 3)))          # endpoint out of range for n_nodes = 1
     with pytest.raises(capi.PgoError):
         P.lm_step()                                                          # no open solve
+
+
+def test_unreferenced_keyframes_and_hub_fallback():
+    """Keyframes no residual block refers to pass through untouched (Ceres drops unreferenced parameter blocks from the program); a hub
+    keyframe with more edge sides than a matrix-free tile holds makes the library fall back to the assembled operator — same answer."""
+    g = util.small_graph(200, 30, f=1, seed=21)
+    q, t, s = util.initial_state(g, True)
+    # 5 extra keyframes nobody refers to
+    q2 = np.vstack([q, np.tile([0.1, 0.2, 0.3, np.sqrt(1 - 0.14)], (5, 1))]); t2 = np.vstack([t, np.arange(15.0).reshape(5, 3)])
+    O, P = _both(g, True, max_num_iterations=50, function_tolerance=1e-10, cg_rel_tolerance=1e-12)
+    from oracle import binding as ob
+    qo, to, so, sumo = O.solve(q2, t2, s, ob.default_options(max_num_iterations=50, function_tolerance=1e-10))
+    qp, tp, sp, sump = P.solve(q2, t2, s)
+    assert np.array_equal(qp.reshape(-1, 4)[200:], q2[200:]) and np.array_equal(tp.reshape(-1, 3)[200:], t2[200:])
+    assert abs(sump.final_cost - sumo.final_cost) <= 1e-6 * sumo.final_cost
+    # hub: keyframe 0 gets 600 extra (consistent) relative-pose edges to spread keyframes
+    rng = np.random.default_rng(3)
+    others = rng.integers(1, 200, size=600).astype(np.int32)
+    from tests.golden.make_functor_goldens import quat_to_R_np
+    T = np.zeros((600, 16))
+    for k, o in enumerate(others):
+        A = np.eye(4); A[:3, :3] = quat_to_R_np(g.truth_q[0]); A[:3, 3] = g.truth_t[0]
+        B = np.eye(4); B[:3, :3] = quat_to_R_np(g.truth_q[o]); B[:3, 3] = g.truth_t[o]
+        T[k] = (np.linalg.inv(A) @ B).flatten(order="F")
+    O.add_relpose_edges(np.zeros(600, np.int32), others, T, np.full(600, 0.5))
+    P.add_relpose_edges(np.zeros(600, np.int32), others, T, np.full(600, 0.5))
+    qo, to, so, sumo = O.solve(q, t, s, ob.default_options(max_num_iterations=50, function_tolerance=1e-10))
+    qp, tp, sp, sump = P.solve(q, t, s)
+    assert abs(sump.final_cost - sumo.final_cost) <= 1e-6 * sumo.final_cost
+    assert np.abs(tp - to).max() <= 1e-3
