@@ -46,6 +46,14 @@ def cpu_baseline(sample_poses, max_iters, budget_s):
     edges = g.n_odom + g.n_loops
     iters = max(1, sm.num_iterations)
     ips_sample = iters / sm.seconds_total
+    # kernel-level companion number on the FULL C3 graph: one residual + Jacobian evaluation of all 300k edges by the oracle's Jet
+    # autodiff (what Ceres' evaluator does per linearisation) — the CPU counterpart of K1, no linear algebra involved
+    g3 = graphgen.config("C3")
+    O3 = util.oracle_problem(g3, True)
+    q3, t3, s3 = util.initial_state(g3, True)
+    tj = time.time()
+    O3.evaluate(q3, t3, s3, want_residuals=False, want_gradient=True)
+    jac_ms = 1e3 * (time.time() - tj)
     return {
         "value": ips_sample * edges / C3_EDGES,   # LINEAR edge scaling to C3 size: optimistic for the CPU (sparse Cholesky is super-linear)
         "unit": "LM iters/s (C3-equivalent)",
@@ -55,6 +63,7 @@ def cpu_baseline(sample_poses, max_iters, budget_s):
                   "(%.2f s, linear solver %.2f s, Jacobians %.2f s, Cholesky fill %d blocks), scaled linearly by edge count to 300k edges"
                   % (iters, g.n_poses, edges, ips_sample, wall, sm.seconds_linear_solver, sm.seconds_jacobian, sm.chol_nnz_blocks),
         "sample_iters_per_s": ips_sample,
+        "c3_jacobian_evaluation_ms": jac_ms,   # CPU (1 thread) residuals + autodiff Jacobians + J^T r of all 300k C3 edges; GPU: roofline.avg_launch_ms
         "host_cpus": os.cpu_count(),
     }
 
