@@ -3,7 +3,9 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
+#include <string>
 
 #include "../pgo_device_math.hpp"
 
@@ -222,6 +224,50 @@ bool PoseGraphSLAM::reinit_ceres_problem_onnewloopedge_optimize6DOF_once() {
     return last_rc_ == PGO_OK;
 }
 
+// ---------------------------------------------------------------- saveAsJSON (reference src/PoseGraphSLAM.cpp:1111-1207)
+static std::string csv_matrix(const Matrix4d& M) {   // Eigen IOFormat(FullPrecision, DontAlignCols, ",", ";")
+    std::string out; char buf[40];
+    for (int r = 0; r < 4; ++r) {
+        for (int c = 0; c < 4; ++c) { std::snprintf(buf, sizeof(buf), "%.17g", M(r, c)); out += buf; if (c < 3) out += ","; }
+        if (r < 3) out += ";";
+    }
+    return out;
+}
+static std::string prettyprintMatrix4d(const Matrix4d& M) {   // PoseManipUtils.cpp:206-215: yaw,pitch,roll in degrees + translation
+    const double nx = M(0, 0), ny = M(1, 0), nz = M(2, 0), ox = M(0, 1), oy = M(1, 1), ax = M(0, 2), ay = M(1, 2);
+    const double y = std::atan2(ny, nx);
+    const double pch = std::atan2(-nz, nx * std::cos(y) + ny * std::sin(y));
+    const double rl = std::atan2(ax * std::sin(y) - ay * std::cos(y), -ox * std::sin(y) + oy * std::cos(y));
+    char buf[200];
+    std::snprintf(buf, sizeof(buf), ":YPR(deg)=(%4.3f,%4.3f,%4.3f)  :TxTyTz=(%4.3f,%4.3f,%4.3f)", y / M_PI * 180.0, pch / M_PI * 180.0, rl / M_PI * 180.0, M(0, 3), M(1, 3), M(2, 3));
+    return buf;
+}
+bool PoseGraphSLAM::saveAsJSON(const std::string& base_path) const {
+    FILE* f = std::fopen((base_path + "/log_optimized_poses.json").c_str(), "w");
+    if (!f) return false;
+    const int n = nNodes();
+    std::fprintf(f, "{\n    \"meta_data\": {\"nNodes\": %d},\n    \"PoseGraphSLAM_nodes\": [", n);
+    for (int i = 0; i < n; ++i) {
+        const Matrix4d opt = getNodePose(i), odom = manager->getNodePose(i);
+        std::fprintf(f, "%s\n        {\"node_i\": %d, \"wTc_opt\": \"%s\", \"wTc_opt_prettyprint\": \"%s\", \"w_T_c_odom\": \"%s\", \"w_T_c_odom_prettyprint\": \"%s\"}",
+                     i ? "," : "", i, csv_matrix(opt).c_str(), prettyprintMatrix4d(opt).c_str(), csv_matrix(odom).c_str(), prettyprintMatrix4d(odom).c_str());
+    }
+    std::fprintf(f, "\n    ],\n    \"PoseGraphSLAM_loopedgeinfo\": [");
+    const int ne = manager->getEdgeLen();
+    for (int e = 0; e < ne; ++e) {
+        const std::pair<int, int> ab = manager->getEdgeIdxInfo(e);
+        const int a = ab.first, b = ab.second;
+        std::fprintf(f, "%s\n        {\"getEdge_i\": %d, \"a\": %d, \"b\": %d, \"world_of_a\": %d, \"world_of_b\": %d, \"weight\": %.17g, \"getEdgePose\": \"%s\"",
+                     e ? "," : "", e, a, b, manager->which_world_is_this_node(a), manager->which_world_is_this_node(b), manager->getEdgeWeight(e), prettyprintMatrix4d(manager->getEdgePose(e)).c_str());
+        if (a < n && b < n) std::fprintf(f, ", \"getEdgePose_after_opt\": \"%s\"", prettyprintMatrix4d(getNodePose(b).inverse() * getNodePose(a)).c_str());
+        if (e < n_opt_switch()) std::fprintf(f, ", \"switching_var_after_opt\": %.17g", get_loopedge_switching_variable_val(e));
+        std::fprintf(f, "}");
+    }
+    std::fprintf(f, "\n    ]\n}\n");
+    std::fclose(f);
+    return true;
+}
+
 // ---------------------------------------------------------------- VectorGraphSource
 void VectorGraphSource::ensure_world(int w) const {
     while ((int)set_of_.size() <= w) { set_of_.push_back((int)set_of_.size()); set_T_world_.push_back(Matrix4d::Identity()); }
@@ -293,4 +339,5 @@ void pgo_host_get_initial_guess(pgo_host_session* s, double* quat, double* t) {
 }
 void pgo_host_get_summary(pgo_host_session* s, pgo_summary* out) { *out = s->slam->last_summary(); }
 int pgo_host_last_error(pgo_host_session* s) { return s->slam->last_error(); }
+int pgo_host_save_as_json(pgo_host_session* s, const char* base_path) { return s->slam->saveAsJSON(base_path) ? 1 : 0; }
 }

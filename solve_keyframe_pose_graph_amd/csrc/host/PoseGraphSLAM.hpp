@@ -14,6 +14,7 @@
 #include <array>
 #include <map>
 #include <mutex>
+#include <string>
 #include <tuple>
 #include <utility>
 #include <vector>
@@ -81,6 +82,10 @@ public:
     void getAllNodePose(std::vector<Matrix4d>& vec_w_T_ci) const;
     int solvedUntil() const;
     double get_loopedge_switching_variable_val(int i) const;
+    // writes base_path + "/log_optimized_poses.json" with the keys of the reference's saveAsJSON (src/PoseGraphSLAM.cpp:1111-1207):
+    // meta_data.nNodes, PoseGraphSLAM_nodes[{node_i, wTc_opt, w_T_c_odom (+ _prettyprint)}], PoseGraphSLAM_loopedgeinfo[{getEdge_i, a, b,
+    // world_of_a, world_of_b, weight, getEdgePose, getEdgePose_after_opt, switching_var_after_opt}]; matrices as Eigen CSVFormat strings
+    bool saveAsJSON(const std::string& base_path) const;
 
     // introspection for the parity tests
     const std::vector<AddedEdge>& added_edges() const { return added_edges_; }

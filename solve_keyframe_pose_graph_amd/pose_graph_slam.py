@@ -104,5 +104,30 @@ class PoseGraphSLAM:
         self.lib.pgo_host_get_summary(self.h, C.byref(s))
         return s
 
+    def saveAsJSON(self, base_path):
+        return bool(self.lib.pgo_host_save_as_json(self.h, str(base_path).encode()))
+
     def last_error(self):
         return self.lib.pgo_host_last_error(self.h)
+
+
+def read_log_optimized_poses(path):
+    """Reader for the reference's `log_optimized_poses.json` (PoseGraphSLAM::saveAsJSON, reference src/PoseGraphSLAM.cpp:1111-1207;
+    matrices are Eigen CSVFormat strings "r0c0,r0c1,..;r1c0,.." — RawFileIO.h:90-101).  Returns a dict of numpy arrays."""
+    import json
+
+    def mat(sv):
+        return np.array([[float(x) for x in row.split(",")] for row in sv.split(";")])
+    with open(path) as f:
+        d = json.load(f)
+    nodes = sorted(d.get("PoseGraphSLAM_nodes", []), key=lambda x: x["node_i"])
+    edges = sorted(d.get("PoseGraphSLAM_loopedgeinfo", []), key=lambda x: x["getEdge_i"])
+    return {
+        "nNodes": d["meta_data"]["nNodes"],
+        "wTc_opt": np.array([mat(n["wTc_opt"]) for n in nodes]).reshape(-1, 4, 4),
+        "w_T_c_odom": np.array([mat(n["w_T_c_odom"]) for n in nodes]).reshape(-1, 4, 4),
+        "edge_a": np.array([e["a"] for e in edges], dtype=np.int32), "edge_b": np.array([e["b"] for e in edges], dtype=np.int32),
+        "edge_weight": np.array([e["weight"] for e in edges]),
+        "edge_world_of_a": np.array([e["world_of_a"] for e in edges], dtype=np.int32), "edge_world_of_b": np.array([e["world_of_b"] for e in edges], dtype=np.int32),
+        "switching_var_after_opt": np.array([e.get("switching_var_after_opt", np.nan) for e in edges]),
+    }

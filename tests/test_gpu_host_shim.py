@@ -135,3 +135,26 @@ def test_kidnap_two_worlds_merge_on_first_inter_world_edge():
     assert err <= 1e-6, err
     assert S.get_loopedge_switching_variable_val(1) > 0.9
     S.close()
+
+
+def test_save_as_json_round_trip(tmp_path):
+    """log_optimized_poses.json with the reference's keys (src/PoseGraphSLAM.cpp:1111-1207) and a lossless CSV matrix encoding."""
+    from solve_keyframe_pose_graph_amd.pose_graph_slam import read_log_optimized_poses
+    g = graphgen.config("C1")
+    vio = [T_of(g.init_q[i], g.init_t[i]) for i in range(g.n_poses)]
+    S = PoseGraphSLAM()
+    for i in range(g.n_poses):
+        S.add_node(0, vio[i].flatten(order="F"))
+    for e in range(g.n_loops):
+        S.add_loop_edge(int(g.loop_c2[e]), int(g.loop_c1[e]), g.loop_T[e], 1.0)
+    assert S.reinit_ceres_problem_onnewloopedge_optimize6DOF_once()
+    assert S.saveAsJSON(tmp_path)
+    d = read_log_optimized_poses(tmp_path / "log_optimized_poses.json")
+    assert d["nNodes"] == g.n_poses and d["wTc_opt"].shape == (g.n_poses, 4, 4)
+    for i in (0, 7, 199):
+        assert np.array_equal(d["wTc_opt"][i], S.getNodePose(i))            # %.17g round-trips doubles exactly
+        assert np.abs(d["w_T_c_odom"][i] - vio[i]).max() == 0.0
+    assert np.array_equal(d["edge_a"], g.loop_c2) and np.array_equal(d["edge_b"], g.loop_c1)
+    sw = np.array([S.get_loopedge_switching_variable_val(e) for e in range(g.n_loops)])
+    assert np.array_equal(d["switching_var_after_opt"], sw)
+    S.close()
