@@ -89,6 +89,8 @@ typedef struct pgo_options {
     double cg_rel_tolerance;             /* 1e-9: stop when ||r||_{M^-1} <= tol * ||b||_{M^-1} */
     int32_t cg_warm_start;               /* 1: after a rejected step start the PCG from the previous step (same H, larger damping) */
     int32_t cg_use_graph;                /* 1: replay each `cg_check_every`-iteration chunk of the PCG loop as one hipGraph (single GPU) */
+    double cg_early_tolerance;           /* 1e-4: first PCG phase; the candidate is evaluated there and a clearly bad step is rejected at once */
+    double cg_early_reject_rho;          /* -0.5: reject after the first phase when relative_decrease < this (0 disables: set cg_early_tolerance = 0) */
     /* device selection */
     int32_t device_id;                   /* -1: use the current HIP device */
     int32_t verbosity;                   /* 0 silent (minimizer_progress_to_stdout=false, :1271), 1 per-iteration line on stderr */

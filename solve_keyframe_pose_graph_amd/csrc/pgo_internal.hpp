@@ -104,7 +104,7 @@ struct CgDev {
     double* x; double* r; double* r2; double* z; double* p; double* p2; double* q;   // r/r2 and p/p2 ping-pong by iteration parity
     double* part_pq;      // [MAX_PARTIALS]
     double* part_rz;      // [2][MAX_PARTIALS]
-    double* scal;         // [0]=rz0 [1]=rz_last [2]=pq_last
+    double* scal;         // [0]=||b||^2_{M^-1} [1]=last r.z [2]=unused [3]=squared relative tolerance
     int32_t* flags;       // [0]=done [1]=breakdown [2]=iterations
 };
 
@@ -119,7 +119,8 @@ void launch_mf_compact(const GraphDev& G, const MfDev& F, const double* pose8, c
 void launch_mf_spmv(const GraphDev& G, const MfDev& F, const ScaleDev& Sc, const CgDev& C, int k, double tol2, hipStream_t st);
 void launch_mf_apply(const GraphDev& G, const MfDev& F, const ScaleDev& Sc, const CgDev& C, const double* x, double* y, hipStream_t st);
 void launch_invert_rows(const GraphDev& G, const CgDev& C, int32_t* fail_flag, hipStream_t st);
-void launch_cg_init(const GraphDev& G, const CgDev& C, int warm /*x holds a previous solution, q = A x*/, hipStream_t st);
+void launch_cg_init(const GraphDev& G, const CgDev& C, int warm /*x holds a previous solution, q = A x*/, double tol2, hipStream_t st);
+void launch_cg_set_tolerance(const CgDev& C, double tol2, hipStream_t st);
 void launch_cg_spmv(const GraphDev& G, const CgDev& C, int k, double tol2, hipStream_t st);   // iteration k: direction + matvec (+ convergence test)
 void launch_cg_pq(const GraphDev& G, const CgDev& C, int k, hipStream_t st);   // multi-GPU: recompute p.q after the all-reduce of q
 void launch_cg_update(const GraphDev& G, const CgDev& C, int k, int n_pq_partials, hipStream_t st);

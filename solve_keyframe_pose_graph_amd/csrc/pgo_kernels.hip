@@ -676,7 +676,7 @@ __global__ __launch_bounds__(CG_BLOCK) void cg_spmv_kernel(GraphDev G, CgDev C, 
         block_total2(C.part_rz + parity * MAX_PARTIALS, nparts, C.part_rz + (parity ^ 1) * MAX_PARTIALS, nparts, red, rz_new, rz_old);
         const bool breakdown = C.flags[1] != 0;
         // convergence on the preconditioned residual norm: every workgroup evaluates the same numbers -> uniform exit
-        if (breakdown || !(rz_new > tol2 * C.scal[0])) {
+        if (breakdown || !(rz_new > C.scal[3] * C.scal[0])) {
             if (blockIdx.x == 0 && threadIdx.x == 0) { C.flags[0] = 1; if (!breakdown) C.scal[1] = rz_new; }
             return;
         }
@@ -791,12 +791,12 @@ __global__ __launch_bounds__(CG_BLOCK) void cg_init_kernel(GraphDev G, CgDev C, 
     const double sb = block_sum(bb, red);
     if (threadIdx.x == 0) { C.part_rz[blockIdx.x] = s; C.part_pq[blockIdx.x] = sb; }
 }
-__global__ void cg_scalars_init_kernel(CgDev C, int nparts) {
+__global__ void cg_scalars_init_kernel(CgDev C, int nparts, double tol2) {
     __shared__ double red[4];
     const double rz0 = block_total(C.part_rz, nparts, red);
     const double bb = block_total(C.part_pq, nparts, red);
     if (threadIdx.x == 0) {
-        C.scal[0] = bb; C.scal[1] = rz0; C.scal[2] = 0.0;
+        C.scal[0] = bb; C.scal[1] = rz0; C.scal[2] = 0.0; C.scal[3] = tol2;
         C.flags[0] = (bb > 0.0 && rz0 > 0.0) ? 0 : 1; C.flags[1] = 0; C.flags[2] = 0;
     }
 }
@@ -868,10 +868,16 @@ static inline int cg_grid(const GraphDev& G) {
     if (g < 1) g = 1;
     return (int)g;
 }
-void launch_cg_init(const GraphDev& G, const CgDev& C, int warm, hipStream_t st) {
+// resume a stopped PCG with a tighter tolerance: new squared tolerance, convergence flag cleared (a breakdown stays)
+__global__ void cg_set_tolerance_kernel(CgDev C, double tol2) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { C.scal[3] = tol2; if (!C.flags[1]) C.flags[0] = 0; }
+}
+void launch_cg_set_tolerance(const CgDev& C, double tol2, hipStream_t st) { hipLaunchKernelGGL(cg_set_tolerance_kernel, dim3(1), dim3(64), 0, st, C, tol2); }
+
+void launch_cg_init(const GraphDev& G, const CgDev& C, int warm, double tol2, hipStream_t st) {
     const int g = cg_grid(G);
     hipLaunchKernelGGL(cg_init_kernel, dim3(g), dim3(CG_BLOCK), 0, st, G, C, warm);
-    hipLaunchKernelGGL(cg_scalars_init_kernel, dim3(1), dim3(256), 0, st, C, g);
+    hipLaunchKernelGGL(cg_scalars_init_kernel, dim3(1), dim3(256), 0, st, C, g, tol2);
 }
 void launch_cg_spmv(const GraphDev& G, const CgDev& C, int k, double tol2, hipStream_t st) {
     const int g = cg_grid(G);
@@ -922,7 +928,7 @@ __global__ __launch_bounds__(MF_BLOCK) void mf_spmv_kernel(GraphDev G, MfDev F, 
             double rz_new, rz_old;
             block_total2(C.part_rz + parity * MAX_PARTIALS, nparts, C.part_rz + (parity ^ 1) * MAX_PARTIALS, nparts, red, rz_new, rz_old);
             const bool breakdown = C.flags[1] != 0;
-            if (breakdown || !(rz_new > tol2 * C.scal[0])) {
+            if (breakdown || !(rz_new > C.scal[3] * C.scal[0])) {
                 if (blockIdx.x == 0 && threadIdx.x == 0) { C.flags[0] = 1; if (!breakdown) C.scal[1] = rz_new; }
                 return;
             }

@@ -444,18 +444,22 @@ int linearize(pgo_problem* p, double* cost_out) {
 
 struct CgResult { int iterations; bool breakdown; double rel_residual; };
 
-int run_pcg(pgo_problem* p, CgResult* res, bool warm) {
+// rel_tol: relative tolerance of this phase.  resume_from >= 0: continue the stopped PCG at that iteration index with the new tolerance
+// (device state x, r, z, p and the partial sums are those of `resume_from` completed iterations).
+int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume_from) {
     const pgo_options& o = p->opt;
     int rc0;
-    if (warm) {
+    const double tol2 = rel_tol * rel_tol;
+    if (resume_from >= 0) {
+        launch_cg_set_tolerance(p->C, tol2, p->st);
+    } else if (warm) {
         // after a rejected step the system keeps H and only the damping grows: start from the previous solution (q = A x first)
         if (p->built_mf) launch_mf_apply(p->G, p->F, p->Sc, p->C, p->C.x, p->C.q, p->st);
         else launch_apply_operator(p->G, p->C, p->C.x, p->C.q, p->st);
         if ((rc0 = allreduce(p, p->C.q, (size_t)p->N * 6, 0)) != PGO_OK) return rc0;
     }
-    launch_cg_init(p->G, p->C, warm ? 1 : 0, p->st);
-    const double tol2 = o.cg_rel_tolerance * o.cg_rel_tolerance;
-    int k = 0;
+    if (resume_from < 0) launch_cg_init(p->G, p->C, warm ? 1 : 0, tol2, p->st);
+    int k = resume_from >= 0 ? resume_from : 0;
     int32_t hflags[3] = {0, 0, 0};
     double hscal[3] = {0, 0, 0};
     int every = std::max(2, o.cg_check_every) & ~1;   // even: the r/p ping-pong parity repeats from chunk to chunk
@@ -475,7 +479,7 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm) {
     };
     // hipGraph: capture one chunk (iterations 2 .. 2+every-1: no `first` kernel, even start) once per graph build and replay it
     const bool want_graph = o.cg_use_graph && p->world == 1 && !p->cg_graph_failed;
-    if (want_graph && (p->cg_graph == nullptr || p->cg_graph_epoch != p->build_epoch || p->cg_graph_len != every || p->cg_graph_tol2 != tol2)) {
+    if (want_graph && (p->cg_graph == nullptr || p->cg_graph_epoch != p->build_epoch || p->cg_graph_len != every)) {
         if (p->cg_graph) { (void)hipGraphExecDestroy(p->cg_graph); p->cg_graph = nullptr; }
         hipGraph_t gr = nullptr;
         bool ok = hipStreamBeginCapture(p->st, hipStreamCaptureModeThreadLocal) == hipSuccess;
@@ -486,7 +490,7 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm) {
         if (ok) ok = hipGraphInstantiate(&p->cg_graph, gr, nullptr, nullptr, 0) == hipSuccess;
         if (gr) (void)hipGraphDestroy(gr);
         if (!ok) { p->cg_graph = nullptr; p->cg_graph_failed = true; (void)hipGetLastError(); }
-        else { p->cg_graph_epoch = p->build_epoch; p->cg_graph_len = every; p->cg_graph_tol2 = tol2; }
+        else { p->cg_graph_epoch = p->build_epoch; p->cg_graph_len = every; }
     }
     while (k < o.cg_max_iterations) {
         const int chunk = std::min(every, o.cg_max_iterations - k);
@@ -494,9 +498,11 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm) {
             HIPCHK(p, hipGraphLaunch(p->cg_graph, p->st));
             k += every;
         } else {
-            const int n = k == 0 ? std::min(2, chunk) : chunk;   // iterations 0,1 run eagerly (iteration 0 has its own kernel arguments)
+            // iterations 0,1 run eagerly (iteration 0 has its own kernel arguments); an odd resume index takes one eager iteration to realign
+            const int n = k == 0 ? std::min(2, chunk) : ((k & 1) ? 1 : chunk);
+            const bool startup = k == 0 || (k & 1);
             for (int j = 0; j < n; ++j, ++k) if ((rc = one_iteration(k)) != PGO_OK) return rc;
-            if (k == 2 && o.cg_max_iterations > 2) continue;      // no host poll after the two start-up iterations
+            if (startup && k < o.cg_max_iterations) continue;     // no host poll after the start-up iterations
         }
         HIPCHK(p, hipMemcpyAsync(hflags, p->C.flags, sizeof(hflags), hipMemcpyDeviceToHost, p->st));
         HIPCHK(p, hipMemcpyAsync(hscal, p->C.scal, sizeof(hscal), hipMemcpyDeviceToHost, p->st));
@@ -504,6 +510,7 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm) {
         if (hflags[0]) break;
     }
     if (!hflags[0]) {   // iteration cap reached: one more convergence test so that scal[1] holds the last r.z (x is already final)
+        launch_cg_set_tolerance(p->C, 1e300, p->st);
         if (p->built_mf) launch_mf_spmv(p->G, p->F, p->Sc, p->C, k, 1e300, p->st);
         else launch_cg_spmv(p->G, p->C, k, 1e300, p->st);
         HIPCHK(p, hipMemcpyAsync(hflags, p->C.flags, sizeof(hflags), hipMemcpyDeviceToHost, p->st));
@@ -596,25 +603,46 @@ int lm_step(pgo_problem* p, int ignore_termination, int* done) {
     bool ok = true;
     if ((rc = build_system(p, &ok)) != PGO_OK) return rc;
     CgResult cg{0, false, 0.0};
-    if (ok) {
-        if ((rc = run_pcg(p, &cg, p->opt.cg_warm_start != 0 && p->have_prev_step && p->reuse_diagonal)) != PGO_OK) return rc;
-        p->have_prev_step = !cg.breakdown;
-        if (cg.breakdown) ok = false;
-    }
-    it.cg_iterations = cg.iterations; it.cg_residual = cg.rel_residual;
-    p->sum.cg_iterations += cg.iterations;
     const int nxt = p->cur ^ 1;
     double h[S_N] = {0};
-    if (ok) {
-        int np = 0, np2 = 0;
+    // candidate point x (+) delta, its cost, the model cost change and the step norms -> h[]
+    auto evaluate_candidate = [&]() -> int {
+        int np = 0, np2 = 0, r2;
         launch_model_change(p->G, p->L, p->Sc, p->C.x, p->d_delta_s.p, part(p, 4), &np, p->st);
         launch_reduce(part(p, 4), np, 0, p->d_scal.p + S_MODEL, p->st);
         launch_plus(p->G, p->d_pose[p->cur].p, p->d_swv[p->cur].p, p->C.x, p->d_delta_s.p, p->d_pose[nxt].p, p->d_swv[nxt].p, part(p, 1), part(p, 2), &np2, p->st);
         launch_reduce(part(p, 1), np2, 0, p->d_scal.p + S_STEP2, p->st);
         launch_reduce(part(p, 2), np2, 0, p->d_scal.p + S_SW_STEP2, p->st);
-        if ((rc = run_k1(p, nxt, false)) != PGO_OK) return rc;
+        if ((r2 = run_k1(p, nxt, false)) != PGO_OK) return r2;
         HIPCHK(p, hipMemsetAsync(p->d_scal.p + S_SW_XNORM2, 0, 2 * sizeof(double), p->st));   // SW_XNORM2, GMAX unused here
-        if ((rc = read_scalars(p, h)) != PGO_OK) return rc;
+        return read_scalars(p, h);
+    };
+    bool evaluated = false;
+    if (ok) {
+        // phase 1 of the PCG stops at cg_early_tolerance: a rejected step only changes the trust-region radius (Ceres StepRejected), so a
+        // step that is clearly bad there (relative_decrease < cg_early_reject_rho, far from min_relative_decrease, and neither
+        // convergence test would fire) is rejected without paying for the remaining decades; otherwise the same PCG resumes to cg_rel_tolerance
+        const bool early = o.cg_early_tolerance > o.cg_rel_tolerance;
+        const bool warm = o.cg_warm_start != 0 && p->have_prev_step && p->reuse_diagonal;
+        if ((rc = run_pcg(p, &cg, warm, early ? o.cg_early_tolerance : o.cg_rel_tolerance, -1)) != PGO_OK) return rc;
+        if (early && !cg.breakdown) {
+            if ((rc = evaluate_candidate()) != PGO_OK) return rc;
+            const double mc = -h[S_MODEL];
+            const double cand = 0.5 * (h[S_COST] + h[S_PRIOR_COST]);
+            const double dc = p->x_cost - cand;
+            const double sn = std::sqrt(h[S_STEP2] + h[S_SW_STEP2]);
+            const bool clear_reject = mc > 0.0 && std::isfinite(mc) && std::isfinite(cand) && dc / mc < o.cg_early_reject_rho &&
+                                      sn > o.parameter_tolerance * (p->x_norm + o.parameter_tolerance) && std::fabs(dc) > o.function_tolerance * p->x_cost;
+            if (clear_reject) evaluated = true;
+            else if ((rc = run_pcg(p, &cg, false, o.cg_rel_tolerance, cg.iterations)) != PGO_OK) return rc;
+        }
+        p->have_prev_step = !cg.breakdown;
+        if (cg.breakdown) ok = false;
+    }
+    it.cg_iterations = cg.iterations; it.cg_residual = cg.rel_residual;
+    p->sum.cg_iterations += cg.iterations;
+    if (ok) {
+        if (!evaluated && (rc = evaluate_candidate()) != PGO_OK) return rc;
         it.model_cost_change = -h[S_MODEL];
         if (!(it.model_cost_change > 0.0) || !std::isfinite(it.model_cost_change)) ok = false;
     }
@@ -754,6 +782,8 @@ void pgo_options_init(pgo_options* o) {
     o->cg_check_every = 25;
     o->cg_warm_start = 1;
     o->cg_use_graph = 1;
+    o->cg_early_tolerance = 1e-4;
+    o->cg_early_reject_rho = -0.5;
     o->cg_rel_tolerance = 1e-9;     // loosest decade that keeps the 10-iteration chi^2 of C3 within 1e-8 of the 1e-13 solve
     o->device_id = -1;
     o->verbosity = 0;
@@ -1036,7 +1066,7 @@ int pgo_time_kernel(pgo_problem* p, int32_t which, int32_t launches, double* avg
         if (!p->reuse_diagonal) launch_lm_diag(p->G, p->L, p->Sc, o.min_lm_diagonal, o.max_lm_diagonal, p->st);
         bool ok = true;
         if ((rc = build_system(p, &ok)) != PGO_OK) return rc;
-        launch_cg_init(p->G, p->C, 0, p->st);
+        launch_cg_init(p->G, p->C, 0, 0.0, p->st);
     }
     const double N = (double)G.N, E = (double)(G.rel.E + G.sw.E), Es = (double)G.sw.E;
     // one untimed launch first (instruction cache, TLB)

@@ -117,3 +117,20 @@ def test_rccl_world_size_one_matches_single_gpu():
     assert sum1.num_iterations == sum0.num_iterations
     assert abs(sum1.final_cost - sum0.final_cost) <= 1e-12 * sum0.final_cost
     assert np.abs(t1 - t0).max() <= 1e-10 and np.abs(s1 - s0).max() <= 1e-10
+
+
+def test_c3_early_rejection_does_not_change_the_iterates(c3):
+    """A rejected LM step only shrinks the trust region (Ceres StepRejected), so libpgo stops the PCG of a clearly bad step at
+    cg_early_tolerance.  The accepted iterates must be exactly those of the full-accuracy run, with markedly fewer CG iterations."""
+    g = c3
+    q, t, s = util.initial_state(g, True)
+    Pf = util.pgo_problem(g, True, cg_early_tolerance=0.0)
+    _, tf, sf, sumf = Pf.solve(q, t, s)
+    Pf.close()
+    Pe = util.pgo_problem(g, True)           # defaults: early phase at 1e-4, reject when relative_decrease < -0.5
+    _, te, se, sume = Pe.solve(q, t, s)
+    Pe.close()
+    assert [sume.iterations[k].step_is_successful for k in range(sume.num_logged)] == [sumf.iterations[k].step_is_successful for k in range(sumf.num_logged)]
+    assert abs(sume.final_cost - sumf.final_cost) <= 1e-10 * sumf.final_cost
+    assert np.abs(te - tf).max() <= 1e-8 and np.abs(se - sf).max() <= 1e-8
+    assert sume.num_unsuccessful_steps >= 3 and sume.cg_iterations < 0.75 * sumf.cg_iterations
