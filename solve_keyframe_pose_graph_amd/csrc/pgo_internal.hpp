@@ -32,8 +32,9 @@ constexpr int WIN_MAX = 72;        // poses per LDS window: 46 KB of LDS per wor
 constexpr int WIN_STRIDE = 80;     // bytes per staged pose record (64 B + 16 B pad: conflict-free ds_read_b128)
 constexpr int MAX_PARTIALS = 1024; // grid cap for kernels that emit per-block partial sums
 constexpr int PRIOR_DOUBLES = 42;  // r6 + J1
-constexpr int MF_BLOCK = 512;      // lanes (edge-sides) per workgroup tile of the matrix-free operator
-constexpr int MF_MAX_NODES = 85;   // keyframes per tile (85 * 6 rows <= 512 lanes in the row phase)
+constexpr int MF_BLOCK = 256;      // lanes (edge sides) per workgroup tile of the matrix-free operator (measured per PCG iteration on C3:
+                                   // 128 -> 49.2 us, 256 -> 42.8 us, 512 -> 44.4 us, 1024 -> 51.7 us)
+constexpr int MF_MAX_NODES = 42;   // keyframes per tile (42 * 6 rows <= 256 lanes in the row phase)
 constexpr int MF_MAX_GRID = 1024;  // cap on matvec workgroups = p.q partial sums (measured: 1024 capped 50.8 us/iteration vs one workgroup per tile 54.5 us)
 constexpr int MF_PLANES = 11;      // COMPACT_DOUBLES / 2 double2 planes
 
@@ -75,7 +76,7 @@ struct MfDev {
     // switchable sides (keyframe order) — so only the tail wavefronts of a tile touch the r6 planes
     const uint32_t* einc;        // [ninc]  bit31 = switchable, bits 30..1 = edge index inside its class, bit0 = side
     const int32_t* einc_other;   // [ninc]  the other endpoint
-    const uint8_t* einc_ownl;    // [ninc]  own keyframe, tile-local (0..84)
+    const uint8_t* einc_ownl;    // [ninc]  own keyframe, tile-local (0..41)
     const int64_t* tile_inc0;    // [tiles+1] first edge side of each workgroup tile (whole keyframes per tile, <= MF_BLOCK sides)
     const int32_t* tile_sw0;     // [tiles]   tile-local index of the first switchable side
     const int32_t* tile_node0;   // [tiles+1]

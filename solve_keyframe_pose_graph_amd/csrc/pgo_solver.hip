@@ -287,7 +287,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S) {
                     node_prior[n] = (int32_t)(slot - slot_pr);
                 } else if (slot >= G.rel.Epad) ++deg_sw[n]; else ++deg_rel[n];
             }
-            if (deg_rel[n] + deg_sw[n] > MF_BLOCK) { p->err = "matrix-free operator: a keyframe with more than 512 incident edges (use PGO_LINEAR_PCG_BLOCK_JACOBI)"; return PGO_ERR_INVALID_ARG; }
+            if (deg_rel[n] + deg_sw[n] > MF_BLOCK) { p->err = "matrix-free operator: a keyframe with more incident edges than a matrix-free tile holds (use PGO_LINEAR_PCG_BLOCK_JACOBI)"; return PGO_ERR_INVALID_ARG; }
         }
         if ((int64_t)std::max(G.rel.E, G.sw.E) >= (1ll << 30)) { p->err = "matrix-free operator: more than 2^30 edges in one class"; return PGO_ERR_INVALID_ARG; }
         // pack whole keyframes into workgroup tiles
