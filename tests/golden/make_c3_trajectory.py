@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/c3_ten_iterations.json — an INDEPENDENT CPU trajectory of the reference's 10-iteration solve on the full C3
+graph (100 000 keyframes / 300 000 edges), used by the GPU suite as the full-size parity anchor.
+
+The oracle's exact block Cholesky cannot factor the C3 normal matrix in reasonable time (fill > 2e7 blocks), so the linear systems
+are solved here with scipy's conjugate gradients to a relative residual of 1e-12 — the same mathematical step as SPARSE_NORMAL_CHOLESKY
+to ~1e-12 — on a matrix assembled in scipy from the ORACLE's Jet-autodiff Jacobian blocks.  The trust-region logic is the Python
+restatement of oracle/pgo_oracle.cpp (Ceres trust_region_minimizer.cc / levenberg_marquardt_strategy.cc).  Nothing of libpgo is used.
+
+Run (about 30-60 min, one core):  python tests/golden/make_c3_trajectory.py [n_iterations]
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import binding as ob  # noqa: E402
+from solve_keyframe_pose_graph_amd import graphgen  # noqa: E402
+from tests import util  # noqa: E402
+
+
+def linearize(O, g, q, t, s):
+    N, S = g.n_poses, g.n_loops
+    J1r, J2r, _ = O.jacobian_blocks(q, t, s, 0)
+    J1s, J2s, dss = O.jacobian_blocks(q, t, s, 1)
+    J1p, _, _ = O.jacobian_blocks(q, t, s, 2)
+    cost, res, grad = O.evaluate(q, t, s)
+    Hd = np.zeros((N, 6, 6))
+    np.add.at(Hd, g.odom_c1, np.einsum('eia,eib->eab', J1r, J1r)); np.add.at(Hd, g.odom_c2, np.einsum('eia,eib->eab', J2r, J2r))
+    np.add.at(Hd, g.loop_c1, np.einsum('eia,eib->eab', J1s, J1s)); np.add.at(Hd, g.loop_c2, np.einsum('eia,eib->eab', J2s, J2s))
+    np.add.at(Hd, g.reg_node, np.einsum('eia,eib->eab', J1p, J1p))
+    Hoff_r = np.einsum('eia,eib->eab', J1r, J2r)
+    Hoff_s = np.einsum('eia,eib->eab', J1s, J2s)
+    c1v = np.einsum('eia,ei->ea', J1s, dss[:, :6]); c2v = np.einsum('eia,ei->ea', J2s, dss[:, :6])
+    hss = (dss ** 2).sum(1)
+    rs = res[6 * g.n_odom:6 * g.n_odom + 7 * S].reshape(S, 7)
+    gs = np.einsum('ei,ei->e', dss, rs)
+    return dict(cost=cost, grad=grad, Hd=Hd, Hoff_r=Hoff_r, Hoff_s=Hoff_s, c1=c1v, c2=c2v, hss=hss, gs=gs,
+                J=(J1r, J2r, J1s, J2s, dss, J1p), r=(res[:6 * g.n_odom].reshape(-1, 6), rs, res[6 * g.n_odom + 7 * S:].reshape(-1, 6)))
+
+
+def solve_step(g, L, scale_p, scale_s, diag_p, diag_s, radius):
+    N, S = g.n_poses, g.n_loops
+    lam_p = diag_p / (radius * scale_p ** 2)
+    lam_s = diag_s / (radius * scale_s ** 2)
+    a = L['hss'] + lam_s
+    Hd = L['Hd'].copy()
+    Hoff_s = L['Hoff_s'] - np.einsum('ea,eb->eab', L['c1'], L['c2']) / a[:, None, None]
+    np.add.at(Hd, g.loop_c1, -np.einsum('ea,eb->eab', L['c1'], L['c1']) / a[:, None, None])
+    np.add.at(Hd, g.loop_c2, -np.einsum('ea,eb->eab', L['c2'], L['c2']) / a[:, None, None])
+    Hd[np.arange(N)[:, None], np.arange(6), np.arange(6)] += lam_p.reshape(N, 6)
+    r_ = np.concatenate([np.arange(N), g.odom_c1, g.odom_c2, g.loop_c1, g.loop_c2])
+    c_ = np.concatenate([np.arange(N), g.odom_c2, g.odom_c1, g.loop_c2, g.loop_c1])
+    b_ = np.concatenate([Hd, L['Hoff_r'], L['Hoff_r'].transpose(0, 2, 1), Hoff_s, Hoff_s.transpose(0, 2, 1)])
+    ii = (r_[:, None, None] * 6 + np.arange(6)[None, :, None]) + 0 * np.arange(6)[None, None, :]
+    jj = (c_[:, None, None] * 6 + np.arange(6)[None, None, :]) + 0 * np.arange(6)[None, :, None]
+    A = sp.coo_matrix((b_.ravel(), (ii.ravel(), jj.ravel())), shape=(6 * N, 6 * N)).tocsr()
+    b = -L['grad'][:6 * N].copy()
+    np.add.at(b.reshape(N, 6), g.loop_c1, L['c1'] * (L['gs'] / a)[:, None]); np.add.at(b.reshape(N, 6), g.loop_c2, L['c2'] * (L['gs'] / a)[:, None])
+    Di = np.linalg.inv(Hd)
+    M = spla.LinearOperator((6 * N, 6 * N), matvec=lambda v: np.einsum('nab,nb->na', Di, v.reshape(N, 6)).ravel())
+    it = [0]
+    x, info = spla.cg(A, b, rtol=1e-12, atol=0.0, maxiter=100000, M=M, callback=lambda xk: it.__setitem__(0, it[0] + 1))
+    dp = x.reshape(N, 6)
+    ds = -(L['gs'] + np.einsum('ea,ea->e', L['c1'], dp[g.loop_c1]) + np.einsum('ea,ea->e', L['c2'], dp[g.loop_c2])) / a
+    return dp, ds, it[0], info
+
+
+def model_change(g, L, dp, ds):
+    J1r, J2r, J1s, J2s, dss, J1p = L['J']
+    rr, rs, rp = L['r']
+    u = np.einsum('eia,ea->ei', J1r, dp[g.odom_c1]) + np.einsum('eia,ea->ei', J2r, dp[g.odom_c2])
+    mc = np.sum(u * (rr + 0.5 * u))
+    u6 = np.einsum('eia,ea->ei', J1s, dp[g.loop_c1]) + np.einsum('eia,ea->ei', J2s, dp[g.loop_c2])
+    u7 = np.concatenate([u6, np.zeros((len(u6), 1))], axis=1) + dss * ds[:, None]
+    mc += np.sum(u7 * (rs + 0.5 * u7))
+    up = np.einsum('eia,ea->ei', J1p, dp[g.reg_node])
+    mc += np.sum(up * (rp + 0.5 * up))
+    return -mc
+
+
+def plus(q, t, s, dp, ds):
+    n = np.linalg.norm(dp[:, :3], axis=1)
+    sbd = np.where(n > 0, np.sin(n) / np.where(n > 0, n, 1), 1.0)
+    dq = np.concatenate([dp[:, :3] * sbd[:, None], np.cos(n)[:, None]], axis=1)
+    ax, ay, az, aw = dq.T; bx, by, bz, bw = q.T
+    qn = np.stack([aw * bx + ax * bw + ay * bz - az * by, aw * by + ay * bw + az * bx - ax * bz, aw * bz + az * bw + ax * by - ay * bx, aw * bw - ax * bx - ay * by - az * bz], axis=1)
+    return qn, t + dp[:, 3:], s + ds
+
+
+def main():
+    n_iter = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+    name = sys.argv[2] if len(sys.argv) > 2 else "C3"
+    g = graphgen.config(name)
+    O = util.oracle_problem(g, True)
+    q, t, s = util.initial_state(g, True)
+    L = linearize(O, g, q, t, s)
+    N, S = g.n_poses, g.n_loops
+    diagH = np.einsum('naa->na', L['Hd']).reshape(-1)
+    scale_p = 1.0 / (1.0 + np.sqrt(diagH)); scale_s = 1.0 / (1.0 + np.sqrt(L['hss']))
+    radius, decrease = 1e4, 2.0
+    x_cost = L['cost']
+    log = [dict(iteration=0, cost=x_cost, successful=1, radius=radius)]
+    reuse = False
+    t00 = time.time()
+    for it in range(1, n_iter + 1):
+        if not reuse:
+            diag_p = np.clip(scale_p ** 2 * np.einsum('naa->na', L['Hd']).reshape(-1), 1e-6, 1e32)
+            diag_s = np.clip(scale_s ** 2 * L['hss'], 1e-6, 1e32)
+        t0 = time.time()
+        dp, ds, cgit, info = solve_step(g, L, scale_p, scale_s, diag_p, diag_s, radius)
+        mc = model_change(g, L, dp, ds)
+        qc, tc, sc = plus(q, t, s, dp, ds)
+        cand = O.evaluate(qc, tc, sc, want_residuals=False, want_gradient=False)[0]
+        rho = (x_cost - cand) / mc
+        rec = dict(iteration=it, radius=radius, model_cost_change=mc, candidate_cost=cand, relative_decrease=rho, cg_iterations=cgit)
+        if rho > 1e-3:
+            q, t, s = qc, tc, sc
+            L = linearize(O, g, q, t, s)
+            x_cost = L['cost']
+            radius = min(1e16, radius / max(1.0 / 3.0, 1.0 - (2.0 * rho - 1.0) ** 3)); decrease = 2.0; reuse = False
+            rec['successful'] = 1
+        else:
+            radius /= decrease; decrease *= 2.0; reuse = True
+            rec['successful'] = 0
+        rec['cost'] = x_cost
+        log.append(rec)
+        print('it %2d cost %.12e rho %.3e cg %d (%s) %.0fs' % (it, x_cost, rho, cgit, 'ok' if rec['successful'] else 'REJ', time.time() - t0), flush=True)
+    out = dict(note="generated by tests/golden/make_c3_trajectory.py: oracle Jacobians + scipy CG (rtol 1e-12) + Python restatement of the Ceres LM loop",
+               config=name, n_poses=N, n_edges=g.n_odom + g.n_loops, iterations=log, seconds=time.time() - t00,
+               final_t_sample=t[::997].tolist(), final_s_sample=s[::997].tolist())
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "%s_ten_iterations.json" % name.lower())
+    with open(path, "w") as f:
+        json.dump(out, f)
+    print("wrote", path)
+
+
+if __name__ == "__main__":
+    main()

@@ -134,3 +134,23 @@ def test_c3_early_rejection_does_not_change_the_iterates(c3):
     assert abs(sume.final_cost - sumf.final_cost) <= 1e-10 * sumf.final_cost
     assert np.abs(te - tf).max() <= 1e-8 and np.abs(se - sf).max() <= 1e-8
     assert sume.num_unsuccessful_steps >= 3 and sume.cg_iterations < 0.75 * sumf.cg_iterations
+
+
+def test_c3_structured_20k_ten_iterations_match_oracle_exact_cholesky():
+    """The largest C3-structured graph whose normal matrix the oracle's exact block Cholesky factors in seconds (20 000 keyframes /
+    59 997 edges, same generator and seed as C3): libpgo with its DEFAULT settings against the oracle for the reference's 10-iteration
+    budget — same accept/reject sequence, per-iteration costs to 1e-6 relative, final chi^2 within 1e-6 (BASELINE.json's bar)."""
+    from oracle import binding as ob
+    g = graphgen.generate(20000, 20000, odom_f_max=2, seed=3)
+    O, P = util.oracle_problem(g, True), util.pgo_problem(g, True)
+    q, t, s = util.initial_state(g, True)
+    qo, to, so, sumo = O.solve(q, t, s)
+    qp, tp, sp, sump = P.solve(q, t, s)
+    assert sump.num_iterations == sumo.num_iterations == 10
+    for k in range(11):
+        a, b = sumo.iterations[k], sump.iterations[k]
+        assert a.step_is_successful == b.step_is_successful, k
+        assert abs(a.cost - b.cost) <= 1e-6 * a.cost, (k, a.cost, b.cost)
+    assert abs(sump.final_cost - sumo.final_cost) <= 1e-6 * sumo.final_cost
+    assert np.linalg.norm(tp.reshape(-1, 3) - to.reshape(-1, 3), axis=1).max() <= 1e-3
+    assert np.abs(sp - so).max() <= 1e-3
