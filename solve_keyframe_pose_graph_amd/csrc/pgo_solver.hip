@@ -127,6 +127,10 @@ struct pgo_problem {
     Rccl nccl; void* comm = nullptr; int rank = 0, world = 1;
     pgo_allreduce_fn custom_allreduce = nullptr; void* custom_ctx = nullptr;
 
+    // pipelined convergence polling: pinned host copies of {flags[4], scal[4]} for two chunks in flight
+    struct Poll { int32_t flags[4]; double scal[4]; };
+    Poll* poll = nullptr; hipEvent_t poll_ev[2] = {nullptr, nullptr};
+
     // hipGraph of one PCG chunk (launch-bound inner loop); valid for (graph build epoch, tolerance, chunk length, solver)
     hipGraphExec_t cg_graph = nullptr; int cg_graph_len = 0; double cg_graph_tol2 = -1; uint64_t cg_graph_epoch = 0, build_epoch = 1; bool cg_graph_failed = false;
 };
@@ -492,7 +496,17 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
         if (!ok) { p->cg_graph = nullptr; p->cg_graph_failed = true; (void)hipGetLastError(); }
         else { p->cg_graph_epoch = p->build_epoch; p->cg_graph_len = every; }
     }
-    while (k < o.cg_max_iterations) {
+    // Chunks of `every` iterations; the convergence flag of chunk j is read (pinned memory + event) only AFTER chunk j+1 has been
+    // enqueued, so the GPU never drains while the host polls.  A chunk enqueued after convergence is a string of early-exit kernels.
+    int n_chunks = 0, waited = -1;
+    bool done = false;
+    auto enqueue_poll = [&](int slot) -> int {
+        HIPCHK(p, hipMemcpyAsync(p->poll[slot].flags, p->C.flags, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, p->st));
+        HIPCHK(p, hipMemcpyAsync(p->poll[slot].scal, p->C.scal, 3 * sizeof(double), hipMemcpyDeviceToHost, p->st));
+        HIPCHK(p, hipEventRecord(p->poll_ev[slot], p->st));
+        return PGO_OK;
+    };
+    while (k < o.cg_max_iterations && !done) {
         const int chunk = std::min(every, o.cg_max_iterations - k);
         if (k >= 2 && chunk == every && want_graph && p->cg_graph && (k & 1) == 0) {
             HIPCHK(p, hipGraphLaunch(p->cg_graph, p->st));
@@ -504,10 +518,24 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
             for (int j = 0; j < n; ++j, ++k) if ((rc = one_iteration(k)) != PGO_OK) return rc;
             if (startup && k < o.cg_max_iterations) continue;     // no host poll after the start-up iterations
         }
+        if ((rc = enqueue_poll(n_chunks & 1)) != PGO_OK) return rc;
+        // the first two chunks are polled immediately (short solves finish there); afterwards one chunk stays in flight
+        const int check = n_chunks < 2 ? n_chunks : n_chunks - 1;
+        if (check > waited) {
+            HIPCHK(p, hipEventSynchronize(p->poll_ev[check & 1]));
+            waited = check;
+            if (p->poll[check & 1].flags[0]) done = true;
+        }
+        ++n_chunks;
+    }
+    if (n_chunks > 0) {   // the state after the LAST enqueued chunk is the final one (kernels past convergence do nothing)
+        HIPCHK(p, hipEventSynchronize(p->poll_ev[(n_chunks - 1) & 1]));
+        std::memcpy(hflags, p->poll[(n_chunks - 1) & 1].flags, sizeof(hflags));
+        std::memcpy(hscal, p->poll[(n_chunks - 1) & 1].scal, sizeof(hscal));
+    } else {
         HIPCHK(p, hipMemcpyAsync(hflags, p->C.flags, sizeof(hflags), hipMemcpyDeviceToHost, p->st));
         HIPCHK(p, hipMemcpyAsync(hscal, p->C.scal, sizeof(hscal), hipMemcpyDeviceToHost, p->st));
         HIPCHK(p, hipStreamSynchronize(p->st));
-        if (hflags[0]) break;
     }
     if (!hflags[0]) {   // iteration cap reached: one more convergence test so that scal[1] holds the last r.z (x is already final)
         launch_cg_set_tolerance(p->C, 1e300, p->st);
@@ -803,6 +831,9 @@ int pgo_create(pgo_problem** out, const pgo_options* opts) {
     p->device = dev;
     if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&p->st, hipStreamNonBlocking) != hipSuccess) { delete p; return PGO_ERR_NO_DEVICE; }
     std::memset(&p->sum, 0, sizeof(p->sum));
+    if (hipHostMalloc((void**)&p->poll, 2 * sizeof(pgo_problem::Poll), hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&p->poll_ev[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&p->poll_ev[1], hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(p->st); delete p; return PGO_ERR_OUT_OF_MEMORY; }
+    std::memset(p->poll, 0, 2 * sizeof(pgo_problem::Poll));
     *out = p;
     return PGO_OK;
 }
@@ -813,6 +844,8 @@ int pgo_destroy(pgo_problem* p) {
     if (p->comm && p->nccl.CommDestroy) p->nccl.CommDestroy(p->comm);
     (void)hipStreamSynchronize(p->st);
     if (p->cg_graph) (void)hipGraphExecDestroy(p->cg_graph);
+    if (p->poll) (void)hipHostFree(p->poll);
+    for (int i = 0; i < 2; ++i) if (p->poll_ev[i]) (void)hipEventDestroy(p->poll_ev[i]);
     p->d_rc1.release(); p->d_rc2.release(); p->d_sc1.release(); p->d_sc2.release(); p->d_sidx.release(); p->d_bsr_col.release();
     p->d_rmeas.release(); p->d_smeas.release(); p->d_rwin.release(); p->d_swin.release(); p->d_prior.release();
     p->d_inc_rowptr.release(); p->d_inc.release(); p->d_bsr_rowptr.release(); p->d_node_free.release();

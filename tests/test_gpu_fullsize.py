@@ -154,3 +154,30 @@ def test_c3_structured_20k_ten_iterations_match_oracle_exact_cholesky():
     assert abs(sump.final_cost - sumo.final_cost) <= 1e-6 * sumo.final_cost
     assert np.linalg.norm(tp.reshape(-1, 3) - to.reshape(-1, 3), axis=1).max() <= 1e-3
     assert np.abs(sp - so).max() <= 1e-3
+
+
+def test_c3_ten_iterations_match_the_independent_cpu_trajectory(c3):
+    """Full-size anchor for BASELINE.json's headline config: the per-iteration costs and accept/reject decisions of libpgo (default
+    settings) against tests/golden/c3_ten_iterations.json — a CPU trajectory computed without libpgo (oracle Jet Jacobians, scipy
+    CG to 1e-12, Python restatement of the Ceres LM loop; generator: tests/golden/make_c3_trajectory.py)."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c3_ten_iterations.json")
+    with open(path) as f:
+        gold = json.load(f)
+    g = c3
+    assert gold["n_poses"] == g.n_poses and gold["n_edges"] == g.n_odom + g.n_loops
+    P = util.pgo_problem(g, True)
+    q, t, s = util.initial_state(g, True)
+    qp, tp, sp, summ = P.solve(q, t, s)
+    its = gold["iterations"]
+    assert summ.num_iterations == len(its) - 1 == 10
+    for k, rec in enumerate(its):
+        mine = summ.iterations[k]
+        assert mine.step_is_successful == rec["successful"], k
+        assert abs(mine.cost - rec["cost"]) <= 1e-6 * rec["cost"], (k, mine.cost, rec["cost"])     # chi^2 within 1e-6 relative at EVERY iteration
+        if k > 0:
+            assert abs(mine.relative_decrease - rec["relative_decrease"]) <= 1e-3 * max(1.0, abs(rec["relative_decrease"]))
+    tt = tp.reshape(-1, 3)[::997]
+    assert np.abs(tt - np.array(gold["final_t_sample"])).max() <= 1e-3
+    assert np.abs(sp[::997] - np.array(gold["final_s_sample"])).max() <= 1e-3
