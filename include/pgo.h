@@ -260,6 +260,41 @@ typedef int (*pgo_allreduce_fn)(void* ctx, double* device_buf, int64_t count, in
 int pgo_comm_init_custom(pgo_problem* p, int32_t rank, int32_t world_size, pgo_allreduce_fn fn, void* ctx);
 
 /* ------------------------------------------------------------------------------------------ */
+/* graph construction on the device from the raw VIO poses                   */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Device-resident copy of the odometry poses `manager->getNodePose(i)` (w_M_i in its own world,
+ * NodeDataManager.h:95; n x 16 doubles, column-major Matrix4d).  Append-only in the reference (poses are
+ * never revised once published), so a trigger sends only the new ones: poses [first, first+n) with
+ * first <= pgo_num_vio_poses (rewriting earlier entries is allowed). */
+int pgo_set_vio_poses(pgo_problem* p, int64_t first, int64_t n, const double* w_M);
+int pgo_num_vio_poses(const pgo_problem* p, int64_t* n);
+
+/* The odometry-residue loop of the trigger, src/PoseGraphSLAM.cpp:1570-1639, for u in [u_begin, u_end) and
+ * f = 1..f_max (reference: 5): skips u-f < 0 (:1588) and pairs with an endpoint whose set id is negative
+ * (dead zone, :1583); measurement u_M_umf = w_M_u^-1 * w_M_umf (:1597-1599), weight 0.9^f * exp(-yaw^2/6) with
+ * yaw = R2ypr(u_M_umf)(0) in degrees (:1603-1606; use_yaw_weight = 0 keeps 0.9^f only), all computed by one
+ * kernel from the resident VIO poses, appended as `SixDOFError` blocks on (u, u-f) in the reference's order
+ * (u outer, f inner).  node_set_id: one int per VIO pose (find_setID_of_world_i(which_world_is_this(u))), or
+ * NULL = every keyframe usable.  n_added (optional) receives the number of edges appended. */
+int pgo_add_odometry_edges_from_vio(pgo_problem* p, const int32_t* node_set_id, int64_t u_begin, int64_t u_end,
+                                    int32_t f_max, int32_t use_yaw_weight, int64_t* n_added);
+
+/* Initial guesses of the trigger, src/PoseGraphSLAM.cpp:1727-1786: for u in [u_begin, u_end),
+ * pose_u = left[left_of_node[u - u_begin]] * w_M_u written as (xyzw, t) the way update_opt_variable_with
+ * stores it (PoseManipUtils.cpp:87-98); `left` is a small table of Matrix4d (n_left x 16): w_T_last * w_M_last^-1
+ * for keyframes chained from the last solved pose (:1770-1775) or wset_T_w for other worlds (:1777-1780);
+ * a negative selector leaves quat/t of that keyframe untouched.  quat/t are the caller's FULL arrays
+ * (entries u_begin.. are written). */
+int pgo_initial_guess_from_vio(pgo_problem* p, int64_t n_left, const double* left, const int32_t* left_of_node,
+                               int64_t u_begin, int64_t u_end, double* quat_xyzw, double* t);
+
+/* Parity hook: the stored records of relative-pose edges [first, first+n) as the kernels consume them —
+ * c1, c2 and (q_obs xyzw, t_obs, weight) = 8 doubles per edge, i.e. what SixDOFError's constructor keeps
+ * (CeresResidues.h:22-28).  Any output may be NULL. */
+int pgo_get_relpose_edge_records(const pgo_problem* p, int64_t first, int64_t n, int32_t* c1, int32_t* c2, double* record8);
+
+/* ------------------------------------------------------------------------------------------ */
 /* measurement helpers (bench.py): HIP-event timing of the dominant kernel on the library's stream */
 /* ------------------------------------------------------------------------------------------ */
 
@@ -270,6 +305,10 @@ int pgo_time_linearize_kernel(pgo_problem* p, int32_t launches, double* avg_ms, 
 
 /* Same for one PCG iteration (K3+K4) and the assembly (K2). which: 0 = K1, 1 = K2, 2 = one PCG iteration, 3 = K1 cost-only */
 int pgo_time_kernel(pgo_problem* p, int32_t which, int32_t launches, double* avg_ms, double* algorithmic_bytes);
+
+/* K0 (odometry records from the resident VIO poses, f = 1..f_max over ALL resident poses): HIP-event average per launch and the
+ * algorithmic bytes 128 B x poses + (8 + 64) B x edges. */
+int pgo_time_vio_odometry_kernel(pgo_problem* p, int32_t f_max, int32_t launches, double* avg_ms, double* algorithmic_bytes);
 
 int pgo_device_synchronize(pgo_problem* p);
 

@@ -58,6 +58,7 @@ def lib():
         _lib.orc_destroy.argtypes = [C.c_void_p]
         _lib.orc_sizeof_summary.restype = C.c_size_t
         _lib.orc_sizeof_options.restype = C.c_size_t
+        _lib.orc_odometry_edges_from_vio.restype = C.c_int64
         assert _lib.orc_sizeof_summary() == C.sizeof(Summary), (_lib.orc_sizeof_summary(), C.sizeof(Summary))
         assert _lib.orc_sizeof_options() == C.sizeof(Options), (_lib.orc_sizeof_options(), C.sizeof(Options))
     return _lib
@@ -120,6 +121,29 @@ def quat_plus_jacobian(q):
     o = np.zeros((4, 3))
     lib().orc_quat_plus_jacobian(_d(q)[1], o.ctypes.data_as(_dp))
     return o
+
+
+def odometry_edges_from_vio(w_M, set_id, u_begin, u_end, f_max=5, use_yaw=True):
+    """The reference's odometry-residue loop (src/PoseGraphSLAM.cpp:1570-1639) -> (c1, c2, T[n,16], weight)."""
+    w_M = np.ascontiguousarray(w_M, dtype=np.float64).reshape(-1, 16)
+    cap = max(0, (u_end - u_begin) * f_max)
+    c1 = np.zeros(cap, np.int32); c2 = np.zeros(cap, np.int32); T = np.zeros((cap, 16)); w = np.zeros(cap)
+    sid = None if set_id is None else np.ascontiguousarray(set_id, dtype=np.int32)
+    n = lib().orc_odometry_edges_from_vio(C.c_int64(len(w_M)), w_M.ctypes.data_as(_dp), None if sid is None else sid.ctypes.data_as(_ip),
+                                          C.c_int64(u_begin), C.c_int64(u_end), C.c_int(f_max), C.c_int(1 if use_yaw else 0),
+                                          c1.ctypes.data_as(_ip), c2.ctypes.data_as(_ip), T.ctypes.data_as(_dp), w.ctypes.data_as(_dp))
+    return c1[:n].copy(), c2[:n].copy(), T[:n].copy(), w[:n].copy()
+
+
+def initial_guess_from_vio(left, left_of_node, w_M, u_begin, u_end, quat, t):
+    """Initial guesses (src/PoseGraphSLAM.cpp:1770-1786): quat/t (full arrays) updated in place for u in [u_begin, u_end)."""
+    left = np.ascontiguousarray(left, dtype=np.float64).reshape(-1, 16)
+    w_M = np.ascontiguousarray(w_M, dtype=np.float64).reshape(-1, 16)
+    sel = np.ascontiguousarray(left_of_node, dtype=np.int32)
+    rc = lib().orc_initial_guess_from_vio(C.c_int64(len(left)), left.ctypes.data_as(_dp), sel.ctypes.data_as(_ip), w_M.ctypes.data_as(_dp),
+                                          C.c_int64(u_begin), C.c_int64(u_end), quat.ctypes.data_as(_dp), t.ctypes.data_as(_dp))
+    assert rc == 0
+    return quat, t
 
 
 class OracleProblem:

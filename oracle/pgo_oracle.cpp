@@ -545,6 +545,56 @@ int orc_quat_to_mat(const double* q_xyzw, double* R9_rowmajor) {
 int orc_quat_plus(const double* q, const double* delta3, double* q_out) { eigen_quaternion_plus(q, delta3, q_out); return 0; }
 int orc_quat_plus_jacobian(const double* q, double* jac_4x3) { eigen_quaternion_plus_jacobian(q, jac_4x3); return 0; }
 
+// --- graph construction from raw VIO poses (restates src/PoseGraphSLAM.cpp:1570-1639 and :1770-1786; test infrastructure) ---
+static Mat4d mul4(const Mat4d& A, const Mat4d& B) {
+    Mat4d C;
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { double a = 0; for (int k = 0; k < 4; ++k) a += A(r, k) * B(k, c); C(r, c) = a; }
+    return C;
+}
+// PoseManipUtils::R2ypr (src/utils/PoseManipUtils.cpp:143-158), first component only, degrees
+static double r2ypr_yaw_deg(const Mat4d& T) { return std::atan2(T(1, 0), T(0, 0)) / M_PI * 180.0; }
+
+// The odometry-residue loop.  Outputs sized for (u_end-u_begin)*f_max entries; returns the number of edges written.
+// T_out holds the Matrix4d handed to SixDOFError::Create (:1620), w_out the weight (:1603-1606).
+int64_t orc_odometry_edges_from_vio(int64_t n_vio, const double* w_M, const int32_t* set_id, int64_t u_begin, int64_t u_end, int f_max, int use_yaw,
+                                    int32_t* c1, int32_t* c2, double* T_out, double* w_out) {
+    int64_t n = 0;
+    for (int64_t u = u_begin; u < u_end && u < n_vio; ++u) {
+        for (int f = 1; f <= f_max; ++f) {
+            if (u - f < 0) continue;                                               // :1588-1591
+            if (set_id && (set_id[u] < 0 || set_id[u - f] < 0)) continue;          // :1583-1586
+            Mat4d w_M_u, w_M_umf;
+            std::memcpy(w_M_u.d, w_M + 16 * u, sizeof(w_M_u.d));
+            std::memcpy(w_M_umf.d, w_M + 16 * (u - f), sizeof(w_M_umf.d));
+            const Mat4d u_M_umf = mul4(inverse4(w_M_u), w_M_umf);                 // :1597-1599
+            double odom_edge_weight = 1.0;
+            odom_edge_weight *= std::pow(0.9, f);                                  // :1604
+            if (use_yaw) { const double yaw = r2ypr_yaw_deg(u_M_umf); odom_edge_weight *= std::exp(-yaw * yaw / 6.); }   // :1605-1606
+            c1[n] = (int32_t)u; c2[n] = (int32_t)(u - f);
+            std::memcpy(T_out + 16 * n, u_M_umf.d, sizeof(u_M_umf.d));
+            w_out[n] = odom_edge_weight;
+            ++n;
+        }
+    }
+    return n;
+}
+
+// Initial guess of keyframe u: left * w_M_u stored as (xyzw, t) (update_opt_variable_with -> eigenmat_to_raw_xyzw, PoseManipUtils.cpp:87-98)
+int orc_initial_guess_from_vio(int64_t n_left, const double* left, const int32_t* left_of_node, const double* w_M, int64_t u_begin, int64_t u_end,
+                               double* quat, double* t) {
+    for (int64_t u = u_begin; u < u_end; ++u) {
+        const int sel = left_of_node[u - u_begin];
+        if (sel < 0) continue;
+        if (sel >= n_left) return -1;
+        Mat4d L, M;
+        std::memcpy(L.d, left + 16 * sel, sizeof(L.d)); std::memcpy(M.d, w_M + 16 * u, sizeof(M.d));
+        const Mat4d P = mul4(L, M);
+        orc_mat_to_quat(P.d, quat + 4 * u);
+        t[3 * u] = P(0, 3); t[3 * u + 1] = P(1, 3); t[3 * u + 2] = P(2, 3);
+    }
+    return 0;
+}
+
 // --- problem ---
 void* orc_create() { return new Problem(); }
 void orc_destroy(void* h) { delete (Problem*)h; }

@@ -276,3 +276,50 @@ def probe5(n, radii, configs):
             t0 = time.time(); x2, k2 = fpcg(A, b, M, 1e-8)
             if xref is None: xref = x2
             print('radius %g  K-cycle ms=%s its %d (%.1fs) diff %.1e' % (radius, ms, k2, time.time() - t0, np.abs(x2 - xref).max() / np.abs(xref).max()), flush=True)
+
+
+class TwoLevel:
+    """block-Jacobi + ONE coarse space of rigid-body modes of large aggregates, coarse problem solved exactly (on the GPU: a dense
+    explicit inverse).  mode 'add': z = D^-1 r + P Ac^-1 P^T r ; 'mult': Jacobi, coarse correction, Jacobi (2 extra matvecs)."""
+    def __init__(self, A, t, agg, Dinv, mode):
+        self.A, self.Dinv, self.mode = A, Dinv, mode
+        self.P, _ = prolongation(t, agg, True)
+        Ac = (self.P.T @ A @ self.P).tocsc()
+        self.C = spla.splu(Ac)
+        self.nc = Ac.shape[0]
+    def __call__(self, r):
+        if self.mode == 'add':
+            return self.Dinv @ r + self.P @ self.C.solve(self.P.T @ r)
+        if self.mode == 'coarse_first':       # z = Pc r + D^-1 (r - A Pc r) ... unsymmetric, for flexible CG only
+            x = self.P @ self.C.solve(self.P.T @ r)
+            return x + self.Dinv @ (r - self.A @ x)
+        x = self.Dinv @ r
+        x = x + self.P @ self.C.solve(self.P.T @ (r - self.A @ x))
+        return x + self.Dinv @ (r - self.A @ x)
+
+
+def spatial_aggregates(t, n_agg, seed=0):
+    """k-means-like clustering of keyframe positions (a few Lloyd iterations)"""
+    from scipy.cluster.vq import kmeans2
+    rng = np.random.default_rng(seed)
+    cen = t[rng.choice(len(t), n_agg, replace=False)]
+    _, lab = kmeans2(t, cen, iter=8, minit='matrix')
+    _, lab = np.unique(lab, return_inverse=True)
+    return lab
+
+
+def probe6(n, radii, n_aggs, loops=None):
+    g = graphgen.generate(n, loops if loops is not None else n, odom_f_max=2, seed=3)
+    q, t, s = util.initial_state(g, True)
+    N = g.n_poses
+    for radius in radii:
+        A, b = build_system(g, q, t, s, radius)
+        Dinv = block_diag_inv(A, N)
+        t0 = time.time(); x, k = pcg(A, b, lambda r: Dinv @ r, 1e-8, maxit=30000); print('radius %g  block-Jacobi its %d (%.1fs)' % (radius, k, time.time() - t0), flush=True)
+        for na in n_aggs:
+            for kind in ('chain', 'spatial'):
+                agg = (np.arange(N) // int(np.ceil(N / na))) if kind == 'chain' else spatial_aggregates(t, na)
+                for mode in ('add', 'mult'):
+                    M = TwoLevel(A, t, agg, Dinv, mode)
+                    t0 = time.time(); x2, k2 = pcg(A, b, M, 1e-8, maxit=4000)
+                    print('  n_agg %5d %-7s %-4s coarse dim %5d: its %4d (%.1fs) err %.1e' % (na, kind, mode, M.nc, k2, time.time() - t0, np.abs(x2 - x).max() / np.abs(x).max()), flush=True)

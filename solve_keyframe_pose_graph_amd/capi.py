@@ -48,10 +48,11 @@ EXPORTS = [
     "pgo_options_init", "pgo_create", "pgo_destroy", "pgo_set_options", "pgo_reserve",
     "pgo_add_relpose_edges", "pgo_add_switchable_edges", "pgo_set_node_regularizers", "pgo_set_nodes_constant",
     "pgo_num_relpose_edges", "pgo_num_switchable_edges", "pgo_num_regularizers",
+    "pgo_set_vio_poses", "pgo_num_vio_poses", "pgo_add_odometry_edges_from_vio", "pgo_initial_guess_from_vio", "pgo_get_relpose_edge_records",
     "pgo_solve", "pgo_solve_begin", "pgo_lm_step", "pgo_solve_end", "pgo_evaluate",
     "pgo_get_jacobian_blocks", "pgo_get_normal_blocks", "pgo_apply_normal_operator",
     "pgo_comm_get_unique_id", "pgo_comm_init", "pgo_comm_destroy", "pgo_comm_init_custom",
-    "pgo_time_linearize_kernel", "pgo_time_kernel", "pgo_device_synchronize", "pgo_strerror", "pgo_last_error",
+    "pgo_time_linearize_kernel", "pgo_time_kernel", "pgo_time_vio_odometry_kernel", "pgo_device_synchronize", "pgo_strerror", "pgo_last_error",
 ]
 
 _lib = None
@@ -172,6 +173,35 @@ class Problem:
         node = _i(node)
         self._check(self.lib.pgo_set_nodes_constant(self.h, C.c_int64(len(node)), _pi(node)))
 
+    # ---- graph construction on the device from raw VIO poses ----
+    def set_vio_poses(self, first, w_M):
+        M = _d(w_M).reshape(-1, 16)
+        self._check(self.lib.pgo_set_vio_poses(self.h, C.c_int64(first), C.c_int64(len(M)), _pd(M)))
+
+    def num_vio_poses(self):
+        n = C.c_int64()
+        self._check(self.lib.pgo_num_vio_poses(self.h, C.byref(n)))
+        return n.value
+
+    def add_odometry_edges_from_vio(self, node_set_id, u_begin, u_end, f_max=5, use_yaw_weight=True):
+        sid = _i(node_set_id) if node_set_id is not None else None
+        n = C.c_int64()
+        self._check(self.lib.pgo_add_odometry_edges_from_vio(self.h, _pi(sid), C.c_int64(u_begin), C.c_int64(u_end), C.c_int32(f_max),
+                                                              C.c_int32(1 if use_yaw_weight else 0), C.byref(n)))
+        self.n_rel += n.value
+        return n.value
+
+    def initial_guess_from_vio(self, left, left_of_node, u_begin, u_end, quat, t):
+        L = _d(left).reshape(-1, 16)
+        sel = _i(left_of_node)
+        assert quat.dtype == np.float64 and t.dtype == np.float64 and quat.flags.c_contiguous and t.flags.c_contiguous
+        self._check(self.lib.pgo_initial_guess_from_vio(self.h, C.c_int64(len(L)), _pd(L), _pi(sel), C.c_int64(u_begin), C.c_int64(u_end), _pd(quat), _pd(t)))
+
+    def relpose_edge_records(self, first, n):
+        c1 = np.zeros(n, np.int32); c2 = np.zeros(n, np.int32); rec = np.zeros((n, 8))
+        self._check(self.lib.pgo_get_relpose_edge_records(self.h, C.c_int64(first), C.c_int64(n), _pi(c1), _pi(c2), _pd(rec)))
+        return c1, c2, rec
+
     # ---- solve ----
     @staticmethod
     def _state(quat, t, sw):
@@ -239,6 +269,11 @@ class Problem:
     def time_kernel(self, which, launches=20):
         ms = C.c_double(0); by = C.c_double(0)
         self._check(self.lib.pgo_time_kernel(self.h, C.c_int32(which), C.c_int32(launches), C.byref(ms), C.byref(by)))
+        return ms.value, by.value
+
+    def time_vio_odometry_kernel(self, f_max=5, launches=20):
+        ms = C.c_double(0); by = C.c_double(0)
+        self._check(self.lib.pgo_time_vio_odometry_kernel(self.h, C.c_int32(f_max), C.c_int32(launches), C.byref(ms), C.byref(by)))
         return ms.value, by.value
 
     def synchronize(self):

@@ -131,30 +131,72 @@ bool PoseGraphSLAM::reinit_ceres_problem_onnewloopedge_optimize6DOF_once() {
     if (!c1.empty()) last_rc_ = pgo_add_switchable_edges(problem_, (int64_t)c1.size(), c1.data(), c2.data(), T.data(), w.data(), sw.data());
 
     // -3- odometry residues u <-> u-f, f = 1..5 (:1570-1639)
-    c1.clear(); c2.clear(); T.clear(); w.clear();
     const int su = solvedUntil();
-    for (int u = su + 1; u < node_len; ++u) {
-        const int set_u = manager->find_setID_of_world_i(manager->which_world_is_this_node(u));
-        for (int f = 1; f < 6; ++f) {
-            const int world_umf = (u - f >= 0) ? manager->which_world_is_this_node(u - f) : -1;
-            const int set_umf = manager->find_setID_of_world_i(world_umf);
-            if (set_u < 0 || set_umf < 0) continue;                              // dead zone (:1583-1586)
-            if (u - f < 0) continue;                                             // (:1588-1591)
-            const Matrix4d u_M_umf = manager->getNodePose(u).inverse() * manager->getNodePose(u - f);      // (:1597-1599)
-            const double yaw = yaw_degrees(u_M_umf);
-            const double odom_edge_weight = std::pow(0.9, f) * std::exp(-yaw * yaw / 6.0);                // (:1603-1606)
-            c1.push_back(u); c2.push_back(u - f); w.push_back(odom_edge_weight);
-            T.insert(T.end(), u_M_umf.d.begin(), u_M_umf.d.end());
-            added_edges_.push_back({u, u - f, odom_edge_weight, -1});
+    if (device_graph_construction_) {
+        // K0 on the device: only the new raw VIO poses travel; measurement, quaternion and yaw weight are computed there
+        int64_t resident = 0;
+        last_rc_ = pgo_num_vio_poses(problem_, &resident);
+        if (last_rc_ == PGO_OK && resident < node_len) {
+            std::vector<double> fresh;
+            fresh.reserve((size_t)(node_len - resident) * 16);
+            for (int u = (int)resident; u < node_len; ++u) { const Matrix4d M = manager->getNodePose(u); fresh.insert(fresh.end(), M.d.begin(), M.d.end()); }
+            last_rc_ = pgo_set_vio_poses(problem_, resident, node_len - resident, fresh.data());
         }
+        std::vector<int32_t> set_id((size_t)node_len, 0);
+        for (int u = std::max(0, su + 1 - 5); u < node_len; ++u) set_id[u] = manager->find_setID_of_world_i(manager->which_world_is_this_node(u));
+        int64_t before = 0, added = 0;
+        if (last_rc_ == PGO_OK) last_rc_ = pgo_num_relpose_edges(problem_, &before);
+        if (last_rc_ == PGO_OK) last_rc_ = pgo_add_odometry_edges_from_vio(problem_, set_id.data(), su + 1, node_len, 5, 1, &added);
+        if (last_rc_ == PGO_OK && added > 0) {
+            std::vector<int32_t> a1((size_t)added), a2((size_t)added);
+            std::vector<double> rec((size_t)added * 8);
+            last_rc_ = pgo_get_relpose_edge_records(problem_, before, added, a1.data(), a2.data(), rec.data());
+            for (int64_t k = 0; k < added; ++k) added_edges_.push_back({a1[k], a2[k], rec[k * 8 + 7], -1});
+        }
+    } else {
+        c1.clear(); c2.clear(); T.clear(); w.clear();
+        for (int u = su + 1; u < node_len; ++u) {
+            const int set_u = manager->find_setID_of_world_i(manager->which_world_is_this_node(u));
+            for (int f = 1; f < 6; ++f) {
+                const int world_umf = (u - f >= 0) ? manager->which_world_is_this_node(u - f) : -1;
+                const int set_umf = manager->find_setID_of_world_i(world_umf);
+                if (set_u < 0 || set_umf < 0) continue;                              // dead zone (:1583-1586)
+                if (u - f < 0) continue;                                             // (:1588-1591)
+                const Matrix4d u_M_umf = manager->getNodePose(u).inverse() * manager->getNodePose(u - f);      // (:1597-1599)
+                const double yaw = yaw_degrees(u_M_umf);
+                const double odom_edge_weight = std::pow(0.9, f) * std::exp(-yaw * yaw / 6.0);                // (:1603-1606)
+                c1.push_back(u); c2.push_back(u - f); w.push_back(odom_edge_weight);
+                T.insert(T.end(), u_M_umf.d.begin(), u_M_umf.d.end());
+                added_edges_.push_back({u, u - f, odom_edge_weight, -1});
+            }
+        }
+        if (!c1.empty()) last_rc_ = pgo_add_relpose_edges(problem_, (int64_t)c1.size(), c1.data(), c2.data(), T.data(), w.data());
     }
-    if (!c1.empty()) last_rc_ = pgo_add_relpose_edges(problem_, (int64_t)c1.size(), c1.data(), c2.data(), T.data(), w.data());
 
     // -4- initial guesses (:1649-1793)
     {
         const int s_until = su;
         int s_world = manager->which_world_is_this_node(s_until);
         if (s_world < 0) s_world = -s_world - 1;
+        // device path: pose_u = left[sel] * w_M_u for the keyframes that take their guess from the VIO pose; table entry 0 = chaining
+        // from the last solved pose (w_T_last * w_M_last^-1, :1770-1775), 1 = identity (:1756-1761), 2+k = k-th distinct wset_T_w (:1777-1780)
+        std::vector<double> left;
+        std::vector<int32_t> sel((size_t)node_len, -1);
+        std::map<int, int> left_of_world;
+        if (device_graph_construction_ && node_len > 0) {
+            const Matrix4d I = Matrix4d::Identity();
+            left.insert(left.end(), I.d.begin(), I.d.end());                     // entry 0 is filled in after the loop
+            left.insert(left.end(), I.d.begin(), I.d.end());
+        }
+        auto guess_from_vio = [&](int u, int which, const Matrix4d& L, int world_u) {
+            if (!device_graph_construction_) { update_opt_variable_with(u, L * manager->getNodePose(u)); return; }
+            if (which == 2) {
+                auto it = left_of_world.find(world_u);
+                if (it == left_of_world.end()) { it = left_of_world.emplace(world_u, (int)(left.size() / 16)).first; left.insert(left.end(), L.d.begin(), L.d.end()); }
+                which = it->second;
+            }
+            sel[u] = which;
+        };
         for (int u = 0; u < node_len; ++u) {
             const int world_u = manager->which_world_is_this_node(u);
             const int set_u = manager->find_setID_of_world_i(world_u);
@@ -170,19 +212,30 @@ bool PoseGraphSLAM::reinit_ceres_problem_onnewloopedge_optimize6DOF_once() {
                 if (set_u == s_world) { last_rc_ = PGO_ERR_STATE; status_ = 0; return false; }                      // the reference exit(8)s here
                 const int old_setid = std::get<0>(changes_to_setid_on_set_union[world_u]);
                 const int new_setid = std::get<1>(changes_to_setid_on_set_union[world_u]);
+                // re-expresses an already OPTIMISED pose in the merged set's frame: host (rare, world merges only)
                 update_opt_variable_with(u, manager->getPoseBetweenWorlds(new_setid, old_setid) * this->getNodePose(u));
             } else if (!before) {
                 // both the in-change-set and the ordinary branch chain from the last solved pose inside its world, or map the
                 // odometry pose into the set's frame otherwise (:1727-1753, :1767-1786)
                 if (s_world == world_u) {
-                    const Matrix4d last_M_u = manager->getNodePose(s_until).inverse() * manager->getNodePose(u);
-                    update_opt_variable_with(u, this->getNodePose(s_until) * last_M_u);
+                    if (device_graph_construction_) sel[u] = 0;
+                    else {
+                        const Matrix4d last_M_u = manager->getNodePose(s_until).inverse() * manager->getNodePose(u);
+                        update_opt_variable_with(u, this->getNodePose(s_until) * last_M_u);
+                    }
                 } else {
-                    update_opt_variable_with(u, wset_T_w * manager->getNodePose(u));
+                    guess_from_vio(u, 2, wset_T_w, world_u);
                 }
             } else if (s_until == 0) {
-                update_opt_variable_with(u, manager->getNodePose(u));            // very first trigger (:1756-1761)
+                guess_from_vio(u, 1, Matrix4d::Identity(), world_u);            // very first trigger (:1756-1761)
             }
+        }
+        if (device_graph_construction_ && node_len > 0 && last_rc_ == PGO_OK) {
+            // every keyframe <= s_until was handled above, so the anchor pose is final here exactly as in the sequential host loop
+            const Matrix4d chain = this->getNodePose(s_until) * manager->getNodePose(s_until).inverse();
+            std::copy(chain.d.begin(), chain.d.end(), left.begin());
+            std::lock_guard<std::mutex> lk(mutex_opt_vars);
+            last_rc_ = pgo_initial_guess_from_vio(problem_, (int64_t)(left.size() / 16), left.data(), sel.data(), 0, node_len, _opt_quat_.data(), _opt_t_.data());
         }
     }
 
@@ -317,6 +370,7 @@ void pgo_host_destroy(pgo_host_session* s) { if (s) { delete s->slam; delete s; 
 void pgo_host_add_node(pgo_host_session* s, int world, const double* T16) { Matrix4d T; std::copy(T16, T16 + 16, T.d.begin()); s->src.add_node(world, T); }
 void pgo_host_add_loop_edge(pgo_host_session* s, int a, int b, const double* bTa16, double w) { Matrix4d T; std::copy(bTa16, bTa16 + 16, T.d.begin()); s->src.add_loop_edge(a, b, T, w); }
 void pgo_host_set_kidnapped(pgo_host_session* s, int k) { s->src.set_kidnapped(k != 0); }
+void pgo_host_set_device_graph_construction(pgo_host_session* s, int on) { s->slam->set_device_graph_construction(on != 0); }
 int pgo_host_trigger(pgo_host_session* s) { return s->slam->reinit_ceres_problem_onnewloopedge_optimize6DOF_once() ? 1 : 0; }
 int pgo_host_n_nodes(pgo_host_session* s) { return s->slam->nNodes(); }
 int pgo_host_solved_until(pgo_host_session* s) { return s->slam->solvedUntil(); }

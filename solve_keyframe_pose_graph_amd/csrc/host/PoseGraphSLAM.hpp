@@ -70,6 +70,9 @@ public:
     explicit PoseGraphSLAM(GraphSource* manager, const pgo_options* options = nullptr);
     ~PoseGraphSLAM();
     bool ok() const { return problem_ != nullptr; }
+    // Steps -3-/-4- (odometry measurements, yaw weights, VIO-derived initial guesses) run as device kernels from the resident raw VIO
+    // poses by default; `false` computes them on the host thread like the reference — kept for the parity tests.
+    void set_device_graph_construction(bool on) { device_graph_construction_ = on; }
 
     // One wake-up of the reference's trigger loop body.  Returns true when a solve ran.
     bool reinit_ceres_problem_onnewloopedge_optimize6DOF_once();
@@ -109,6 +112,7 @@ private:
     int solved_until = 0;
     int prev_loopedge_len = 0, prev_node_len = 0;
     int status_ = -1, last_rc_ = 0;
+    bool device_graph_construction_ = true;
     std::map<int, std::tuple<int, int>> changes_to_setid_on_set_union;
     std::vector<AddedEdge> added_edges_;
     std::vector<AddedRegularizer> regs_;

@@ -286,9 +286,10 @@ PGO_HD void quat_plus(const double* q, const double* d, double* out) {
     }
 }
 
-// Eigen's `Quaterniond(Matrix3d)` (CeresResidues.h:24,150): R row-major -> q (x,y,z,w).  Host-side use
-// when an edge is added; restated from Eigen's published algorithm (branch on trace / largest diagonal).
-inline void eigen_matrix_to_quat(const double* R, double* q) {
+// Eigen's `Quaterniond(Matrix3d)` (CeresResidues.h:24,150; PoseManipUtils.cpp:87-98): R row-major -> q (x,y,z,w).  Restated from
+// Eigen's published algorithm (branch on trace / largest diagonal); the three non-trace cases are written out so that device code
+// needs no dynamically indexed registers.
+PGO_HD void eigen_matrix_to_quat(const double* R, double* q) {
     double t = R[0] + R[4] + R[8];
     if (t > 0.0) {
         t = sqrt(t + 1.0);
@@ -297,18 +298,78 @@ inline void eigen_matrix_to_quat(const double* R, double* q) {
         q[0] = (R[7] - R[5]) * t;
         q[1] = (R[2] - R[6]) * t;
         q[2] = (R[3] - R[1]) * t;
-    } else {
-        int i = 0;
-        if (R[4] > R[0]) i = 1;
-        if (R[8] > R[i * 3 + i]) i = 2;
-        const int j = (i + 1) % 3, k = (j + 1) % 3;
-        t = sqrt(R[i * 3 + i] - R[j * 3 + j] - R[k * 3 + k] + 1.0);
-        q[i] = 0.5 * t;
+    } else if (R[0] >= R[4] && R[0] >= R[8]) {          // i=0, j=1, k=2   (Eigen: i=1 only if R11 > R00; i=2 only if R22 > R[i][i])
+        t = sqrt(R[0] - R[4] - R[8] + 1.0);
+        q[0] = 0.5 * t;
         t = 0.5 / t;
-        q[3] = (R[k * 3 + j] - R[j * 3 + k]) * t;
-        q[j] = (R[j * 3 + i] + R[i * 3 + j]) * t;
-        q[k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
+        q[3] = (R[7] - R[5]) * t;
+        q[1] = (R[3] + R[1]) * t;
+        q[2] = (R[6] + R[2]) * t;
+    } else if (R[4] > R[0] && R[4] >= R[8]) {           // i=1, j=2, k=0
+        t = sqrt(R[4] - R[8] - R[0] + 1.0);
+        q[1] = 0.5 * t;
+        t = 0.5 / t;
+        q[3] = (R[2] - R[6]) * t;
+        q[2] = (R[7] + R[5]) * t;
+        q[0] = (R[1] + R[3]) * t;
+    } else {                                            // i=2, j=0, k=1
+        t = sqrt(R[8] - R[0] - R[4] + 1.0);
+        q[2] = 0.5 * t;
+        t = 0.5 / t;
+        q[3] = (R[3] - R[1]) * t;
+        q[0] = (R[2] + R[6]) * t;
+        q[1] = (R[5] + R[7]) * t;
     }
+}
+
+// ---- graph construction from raw VIO poses (reference src/PoseGraphSLAM.cpp:1597-1606, :1770-1778) ----
+// Matrix4d inputs are column-major 16 doubles with bottom row (0,0,0,1), as Eigen stores them.
+
+// u_M_umf = w_M_u^-1 * w_M_umf  (:1597-1599).  The reference calls the general Matrix4d::inverse(); for an affine matrix that is
+// [A^-1, -A^-1 t], with A^-1 by cofactors as Eigen's fixed-size inverse computes it — also right for a not-quite-orthonormal A.
+// Outputs R (row-major 3x3) and t of the product.
+PGO_HD void vio_relative_pose(const double* Mu, const double* Mm, double* R, double* t) {
+    const double a00 = Mu[0], a10 = Mu[1], a20 = Mu[2], a01 = Mu[4], a11 = Mu[5], a21 = Mu[6], a02 = Mu[8], a12 = Mu[9], a22 = Mu[10];
+    const double c00 = a11 * a22 - a12 * a21, c01 = a02 * a21 - a01 * a22, c02 = a01 * a12 - a02 * a11;
+    const double c10 = a12 * a20 - a10 * a22, c11 = a00 * a22 - a02 * a20, c12 = a02 * a10 - a00 * a12;
+    const double c20 = a10 * a21 - a11 * a20, c21 = a01 * a20 - a00 * a21, c22 = a00 * a11 - a01 * a10;
+    const double idet = 1.0 / (a00 * c00 + a01 * c10 + a02 * c20);
+    const double I[9] = {c00 * idet, c01 * idet, c02 * idet, c10 * idet, c11 * idet, c12 * idet, c20 * idet, c21 * idet, c22 * idet};   // A^-1 row-major
+    const double d0 = Mm[12] - Mu[12], d1 = Mm[13] - Mu[13], d2 = Mm[14] - Mu[14];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) R[r * 3 + c] = I[r * 3] * Mm[c * 4] + I[r * 3 + 1] * Mm[c * 4 + 1] + I[r * 3 + 2] * Mm[c * 4 + 2];
+        t[r] = I[r * 3] * d0 + I[r * 3 + 1] * d1 + I[r * 3 + 2] * d2;
+    }
+}
+
+// odometry edge record (q_obs xyzw, t_obs, weight): weight = 0.9^f * exp(-yaw^2/6), yaw = R2ypr(R)(0) in DEGREES
+// (:1603-1606; PoseManipUtils.cpp:143-158: y = atan2(n(1), n(0)) with n = R.col(0))
+PGO_HD void vio_odometry_record(const double* Mu, const double* Mm, int f, bool yaw_weight, double* out8) {
+    double R[9], t[3];
+    vio_relative_pose(Mu, Mm, R, t);
+    eigen_matrix_to_quat(R, out8);
+    out8[4] = t[0]; out8[5] = t[1]; out8[6] = t[2];
+    double w = pow(0.9, (double)f);
+    if (yaw_weight) {
+        const double yaw = atan2(R[3], R[0]) / 3.14159265358979323846 * 180.0;
+        w *= exp(-yaw * yaw / 6.0);
+    }
+    out8[7] = w;
+}
+
+// initial guess of a not-yet-solved keyframe (:1770-1778): pose = L * w_M_u with L = w_T_last * w_M_last^-1 (or wset_T_w), stored as
+// (xyzw, t) the way update_opt_variable_with -> eigenmat_to_raw_xyzw does
+PGO_HD void vio_left_compose(const double* L, const double* Mu, double* q, double* t) {
+    double R[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) R[r * 3 + c] = L[r] * Mu[c * 4] + L[4 + r] * Mu[c * 4 + 1] + L[8 + r] * Mu[c * 4 + 2];
+        t[r] = L[r] * Mu[12] + L[4 + r] * Mu[13] + L[8 + r] * Mu[14] + L[12 + r];
+    }
+    eigen_matrix_to_quat(R, q);
 }
 
 }  // namespace pgo

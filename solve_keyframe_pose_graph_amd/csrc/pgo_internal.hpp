@@ -137,6 +137,9 @@ void launch_reduce(const double* partials, int n, int op /*0 sum,1 max*/, double
 void launch_pack_pose(const double* quat, const double* t, double* pose8, int64_t N, hipStream_t st);
 void launch_unpack_pose(const double* pose8, double* quat, double* t, int64_t N, hipStream_t st);
 void launch_unpack_k1(const GraphDev& G, int kind, int64_t first, int64_t count, double* r, double* J1, double* J2, double* Js, hipStream_t st);
+// K0: graph construction from raw VIO poses
+void launch_vio_odometry(int64_t n, const int32_t* c1, const int32_t* c2, const double* vio, int yaw_weight, double* meas8, hipStream_t st);
+void launch_vio_initial_guess(int64_t u_begin, int64_t count, const double* left, const int32_t* left_of_node, const double* vio, double* quat, double* t, hipStream_t st);
 
 double k1_algorithmic_bytes(const GraphDev& G, bool want_jacobian);
 

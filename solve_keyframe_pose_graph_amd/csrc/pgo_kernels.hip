@@ -1291,4 +1291,49 @@ void launch_unpack_k1(const GraphDev& G, int kind, int64_t first, int64_t count,
     if (count > 0) hipLaunchKernelGGL(unpack_k1_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, G, kind, first, count, r, J1, J2, Js);
 }
 
+// ---- K0: graph construction from the device-resident raw VIO pose array ----
+// K0a: one lane per odometry edge (u = c1, u-f = c2): record = (q_obs, t_obs, 0.9^f exp(-yaw^2/6)) of u_M_umf = w_M_u^-1 w_M_umf
+// (reference src/PoseGraphSLAM.cpp:1597-1606).  Reads 2 x 128 B (neighbouring lanes share poses through L1/L2), writes 64 B.
+__global__ void __launch_bounds__(256) vio_odometry_kernel(int64_t n, const int32_t* __restrict__ c1, const int32_t* __restrict__ c2,
+                                                           const double* __restrict__ vio, int yaw_weight, double* __restrict__ meas8) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int u = c1[e], m = c2[e];
+    double Mu[16], Mm[16];
+    const double2* pu = reinterpret_cast<const double2*>(vio + (size_t)u * 16);
+    const double2* pm = reinterpret_cast<const double2*>(vio + (size_t)m * 16);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const double2 a = pu[k], b = pm[k]; Mu[2 * k] = a.x; Mu[2 * k + 1] = a.y; Mm[2 * k] = b.x; Mm[2 * k + 1] = b.y; }
+    double out[8];
+    vio_odometry_record(Mu, Mm, u - m, yaw_weight != 0, out);
+    double2* po = reinterpret_cast<double2*>(meas8 + (size_t)e * 8);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) po[k] = make_double2(out[2 * k], out[2 * k + 1]);
+}
+void launch_vio_odometry(int64_t n, const int32_t* c1, const int32_t* c2, const double* vio, int yaw_weight, double* meas8, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(vio_odometry_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, c1, c2, vio, yaw_weight, meas8);
+}
+
+// K0b: initial guesses (reference :1770-1778): pose[u] = left[left_of_node[u - u_begin]] * w_M_u as (xyzw, t); negative selector = skip
+__global__ void __launch_bounds__(256) vio_initial_guess_kernel(int64_t u_begin, int64_t count, const double* __restrict__ left, const int32_t* __restrict__ left_of_node,
+                                                                const double* __restrict__ vio, double* __restrict__ quat, double* __restrict__ t) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const int sel = left_of_node[i];
+    if (sel < 0) return;
+    const int64_t u = u_begin + i;
+    double L[16], Mu[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { L[k] = left[(size_t)sel * 16 + k]; Mu[k] = vio[(size_t)u * 16 + k]; }
+    double q[4], tt[3];
+    vio_left_compose(L, Mu, q, tt);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) quat[i * 4 + k] = q[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) t[i * 3 + k] = tt[k];
+}
+void launch_vio_initial_guess(int64_t u_begin, int64_t count, const double* left, const int32_t* left_of_node, const double* vio, double* quat, double* t, hipStream_t st) {
+    if (count > 0) hipLaunchKernelGGL(vio_initial_guess_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, u_begin, count, left, left_of_node, vio, quat, t);
+}
+
 }  // namespace pgo

@@ -41,6 +41,10 @@ struct DBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+// function-local device scratch (freed at scope exit; DBuf members of pgo_problem are released by pgo_destroy)
+template <class T>
+struct ScopedBuf : DBuf<T> { ~ScopedBuf() { this->release(); } };
+
 struct HostClass {
     std::vector<int32_t> c1, c2, sw;
     std::vector<double> meas;   // 8 per edge: q_obs(4) t_obs(3) w
@@ -95,6 +99,8 @@ struct pgo_problem {
     DBuf<double> d_scal;             // S_N doubles
     DBuf<double> d_pose[2], d_swv[2], d_delta_s, d_io;   // state ping-pong, staging for quat/t
     DBuf<double> d_tmp;
+    DBuf<double> d_vio;              // raw VIO poses [n_vio][16] (graph construction, K0)
+    int64_t n_vio = 0;
     // matrix-free operator
     DBuf<uint32_t> d_einc;
     DBuf<uint8_t> d_einc_ownl;
@@ -853,7 +859,7 @@ int pgo_destroy(pgo_problem* p) {
     p->d_scale_p.release(); p->d_scale_s.release(); p->d_diag_p.release(); p->d_diag_s.release(); p->d_a_inv.release();
     p->d_val.release(); p->d_Lf.release(); p->d_Dtot_b.release(); p->d_cgvec.release(); p->d_part.release(); p->d_cgpart.release();
     p->d_flags.release(); p->d_scal.release(); p->d_pose[0].release(); p->d_pose[1].release(); p->d_swv[0].release(); p->d_swv[1].release();
-    p->d_delta_s.release(); p->d_io.release(); p->d_tmp.release();
+    p->d_delta_s.release(); p->d_io.release(); p->d_tmp.release(); p->d_vio.release();
     p->d_einc.release(); p->d_einc_ownl.release(); p->d_node_rng.release(); p->d_tile_inc0.release(); p->d_einc_other.release();
     p->d_tile_node0.release(); p->d_tile_sw0.release(); p->d_node_prior.release(); p->d_rec.release(); p->d_lam.release();
     (void)hipStreamDestroy(p->st);
@@ -907,6 +913,96 @@ int pgo_set_nodes_constant(pgo_problem* p, int64_t n, const int32_t* node) {
     for (int64_t k = 0; k < n; ++k) if (node[k] < 0) return PGO_ERR_INVALID_ARG;
     p->constant_nodes.insert(p->constant_nodes.end(), node, node + n);
     p->graph_dirty = true;
+    return PGO_OK;
+}
+// ---- graph construction from the resident VIO poses (K0) ----
+int pgo_set_vio_poses(pgo_problem* p, int64_t first, int64_t n, const double* w_M) {
+    if (!p || first < 0 || n < 0 || (n > 0 && !w_M)) return PGO_ERR_INVALID_ARG;
+    if (first > p->n_vio) { p->err = "VIO poses must be appended contiguously"; return PGO_ERR_INVALID_ARG; }
+    if (n == 0) return PGO_OK;
+    HIPCHK(p, hipSetDevice(p->device));
+    const int64_t need = first + n;
+    if ((size_t)need * 16 > p->d_vio.cap) {       // grow geometrically, keep the old poses
+        ScopedBuf<double> bigger;
+        HIPCHK(p, bigger.ensure((size_t)std::max<int64_t>(need + need / 2, 1024) * 16));
+        if (p->n_vio > 0) HIPCHK(p, hipMemcpyAsync(bigger.p, p->d_vio.p, (size_t)p->n_vio * 16 * sizeof(double), hipMemcpyDeviceToDevice, p->st));
+        HIPCHK(p, hipStreamSynchronize(p->st));
+        std::swap(p->d_vio.p, bigger.p); std::swap(p->d_vio.cap, bigger.cap);
+    }
+    HIPCHK(p, hipMemcpyAsync(p->d_vio.p + (size_t)first * 16, w_M, (size_t)n * 16 * sizeof(double), hipMemcpyHostToDevice, p->st));
+    HIPCHK(p, hipStreamSynchronize(p->st));
+    p->n_vio = std::max(p->n_vio, need);
+    return PGO_OK;
+}
+int pgo_num_vio_poses(const pgo_problem* p, int64_t* n) { if (!p || !n) return PGO_ERR_INVALID_ARG; *n = p->n_vio; return PGO_OK; }
+
+int pgo_add_odometry_edges_from_vio(pgo_problem* p, const int32_t* set_id, int64_t u_begin, int64_t u_end, int32_t f_max, int32_t use_yaw_weight, int64_t* n_added) {
+    if (!p || u_begin < 0 || u_end < u_begin || f_max < 1) return PGO_ERR_INVALID_ARG;
+    if (u_end > p->n_vio) { p->err = "odometry edges requested beyond the resident VIO poses"; return PGO_ERR_INVALID_ARG; }
+    if (p->in_solve) { p->err = "graph construction inside a solve"; return PGO_ERR_STATE; }
+    std::vector<int32_t> c1, c2;
+    c1.reserve((size_t)(u_end - u_begin) * f_max); c2.reserve(c1.capacity());
+    for (int64_t u = u_begin; u < u_end; ++u)
+        for (int f = 1; f <= f_max; ++f) {
+            if (u - f < 0) continue;                                           // (:1588-1591)
+            if (set_id && (set_id[u] < 0 || set_id[u - f] < 0)) continue;      // dead zone (:1583-1586)
+            c1.push_back((int32_t)u); c2.push_back((int32_t)(u - f));
+        }
+    const int64_t n = (int64_t)c1.size();
+    if (n_added) *n_added = n;
+    if (n == 0) return PGO_OK;
+    HIPCHK(p, hipSetDevice(p->device));
+    ScopedBuf<int32_t> d_c;                       // c1 then c2
+    ScopedBuf<double> d_meas;
+    HIPCHK(p, d_c.ensure((size_t)2 * n)); HIPCHK(p, d_meas.ensure((size_t)8 * n));
+    HIPCHK(p, hipMemcpyAsync(d_c.p, c1.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
+    HIPCHK(p, hipMemcpyAsync(d_c.p + n, c2.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
+    launch_vio_odometry(n, d_c.p, d_c.p + n, p->d_vio.p, use_yaw_weight, d_meas.p, p->st);
+    HostClass& H = p->rel;
+    const size_t base = H.c1.size();
+    H.meas.resize((base + n) * 8);
+    HIPCHK(p, hipMemcpyAsync(&H.meas[base * 8], d_meas.p, (size_t)8 * n * sizeof(double), hipMemcpyDeviceToHost, p->st));
+    const hipError_t e = hipStreamSynchronize(p->st);
+    if (e != hipSuccess) { H.meas.resize(base * 8); p->err = hipGetErrorString(e); return PGO_ERR_HIP; }
+    H.c1.insert(H.c1.end(), c1.begin(), c1.end());
+    H.c2.insert(H.c2.end(), c2.begin(), c2.end());
+    p->graph_dirty = true;
+    return PGO_OK;
+}
+
+int pgo_initial_guess_from_vio(pgo_problem* p, int64_t n_left, const double* left, const int32_t* left_of_node, int64_t u_begin, int64_t u_end, double* quat, double* t) {
+    if (!p || n_left < 0 || u_begin < 0 || u_end < u_begin) return PGO_ERR_INVALID_ARG;
+    const int64_t cnt = u_end - u_begin;
+    if (cnt == 0) return PGO_OK;
+    if (!left_of_node || !quat || !t || (n_left > 0 && !left)) return PGO_ERR_INVALID_ARG;
+    if (u_end > p->n_vio) { p->err = "initial guesses requested beyond the resident VIO poses"; return PGO_ERR_INVALID_ARG; }
+    bool any = false;
+    for (int64_t i = 0; i < cnt; ++i) {
+        if (left_of_node[i] >= n_left) { p->err = "left-matrix selector out of range"; return PGO_ERR_INVALID_ARG; }
+        any |= left_of_node[i] >= 0;
+    }
+    if (!any) return PGO_OK;
+    HIPCHK(p, hipSetDevice(p->device));
+    ScopedBuf<double> d_left, d_q, d_t;
+    ScopedBuf<int32_t> d_sel;
+    HIPCHK(p, d_left.ensure((size_t)n_left * 16)); HIPCHK(p, d_q.ensure((size_t)cnt * 4)); HIPCHK(p, d_t.ensure((size_t)cnt * 3)); HIPCHK(p, d_sel.ensure((size_t)cnt));
+    HIPCHK(p, hipMemcpyAsync(d_left.p, left, (size_t)n_left * 16 * sizeof(double), hipMemcpyHostToDevice, p->st));
+    HIPCHK(p, hipMemcpyAsync(d_sel.p, left_of_node, (size_t)cnt * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
+    // untouched keyframes keep the caller's values: seed the staging buffers with them
+    HIPCHK(p, hipMemcpyAsync(d_q.p, quat + u_begin * 4, (size_t)cnt * 4 * sizeof(double), hipMemcpyHostToDevice, p->st));
+    HIPCHK(p, hipMemcpyAsync(d_t.p, t + u_begin * 3, (size_t)cnt * 3 * sizeof(double), hipMemcpyHostToDevice, p->st));
+    launch_vio_initial_guess(u_begin, cnt, d_left.p, d_sel.p, p->d_vio.p, d_q.p, d_t.p, p->st);
+    HIPCHK(p, hipMemcpyAsync(quat + u_begin * 4, d_q.p, (size_t)cnt * 4 * sizeof(double), hipMemcpyDeviceToHost, p->st));
+    HIPCHK(p, hipMemcpyAsync(t + u_begin * 3, d_t.p, (size_t)cnt * 3 * sizeof(double), hipMemcpyDeviceToHost, p->st));
+    HIPCHK(p, hipStreamSynchronize(p->st));
+    return PGO_OK;
+}
+
+int pgo_get_relpose_edge_records(const pgo_problem* p, int64_t first, int64_t n, int32_t* c1, int32_t* c2, double* record8) {
+    if (!p || first < 0 || n < 0 || first + n > p->rel.size()) return PGO_ERR_INVALID_ARG;
+    if (c1) std::copy(p->rel.c1.begin() + first, p->rel.c1.begin() + first + n, c1);
+    if (c2) std::copy(p->rel.c2.begin() + first, p->rel.c2.begin() + first + n, c2);
+    if (record8) std::copy(p->rel.meas.begin() + first * 8, p->rel.meas.begin() + (first + n) * 8, record8);
     return PGO_OK;
 }
 int pgo_num_relpose_edges(const pgo_problem* p, int64_t* n) { if (!p || !n) return PGO_ERR_INVALID_ARG; *n = p->rel.size(); return PGO_OK; }
@@ -1129,6 +1225,33 @@ int pgo_time_kernel(pgo_problem* p, int32_t which, int32_t launches, double* avg
     return PGO_OK;
 }
 int pgo_time_linearize_kernel(pgo_problem* p, int32_t launches, double* avg_ms, double* bytes) { return pgo_time_kernel(p, 0, launches, avg_ms, bytes); }
+
+int pgo_time_vio_odometry_kernel(pgo_problem* p, int32_t f_max, int32_t launches, double* avg_ms, double* algorithmic_bytes) {
+    if (!p || launches <= 0 || !avg_ms || f_max < 1) return PGO_ERR_INVALID_ARG;
+    if (p->n_vio < 2) { p->err = "no resident VIO poses"; return PGO_ERR_STATE; }
+    int rc;
+    if ((rc = set_device(p)) != PGO_OK) return rc;
+    std::vector<int32_t> c;
+    for (int64_t u = 0; u < p->n_vio; ++u) for (int f = 1; f <= f_max; ++f) if (u - f >= 0) c.push_back((int32_t)u);
+    const int64_t n = (int64_t)c.size();
+    for (int64_t u = 0; u < p->n_vio; ++u) for (int f = 1; f <= f_max; ++f) if (u - f >= 0) c.push_back((int32_t)(u - f));
+    ScopedBuf<int32_t> d_c; ScopedBuf<double> d_meas;
+    HIPCHK(p, d_c.ensure((size_t)2 * n)); HIPCHK(p, d_meas.ensure((size_t)8 * n));
+    HIPCHK(p, hipMemcpyAsync(d_c.p, c.data(), (size_t)2 * n * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
+    hipEvent_t e0, e1;
+    HIPCHK(p, hipEventCreate(&e0)); HIPCHK(p, hipEventCreate(&e1));
+    launch_vio_odometry(n, d_c.p, d_c.p + n, p->d_vio.p, 1, d_meas.p, p->st);
+    HIPCHK(p, hipEventRecord(e0, p->st));
+    for (int i = 0; i < launches; ++i) launch_vio_odometry(n, d_c.p, d_c.p + n, p->d_vio.p, 1, d_meas.p, p->st);
+    HIPCHK(p, hipEventRecord(e1, p->st));
+    HIPCHK(p, hipStreamSynchronize(p->st));
+    float ms = 0;
+    HIPCHK(p, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *avg_ms = (double)ms / launches;
+    if (algorithmic_bytes) *algorithmic_bytes = 128.0 * (double)p->n_vio + (8.0 + 64.0) * (double)n;   // each pose once + 2 indices + one record per edge
+    return PGO_OK;
+}
 
 int pgo_device_synchronize(pgo_problem* p) {
     if (!p) return PGO_ERR_INVALID_ARG;

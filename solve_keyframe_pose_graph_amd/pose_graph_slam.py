@@ -57,6 +57,10 @@ class PoseGraphSLAM:
     def set_kidnapped(self, k):
         self.lib.pgo_host_set_kidnapped(self.h, C.c_int(1 if k else 0))
 
+    def set_device_graph_construction(self, on):
+        """Steps -3-/-4- of the trigger (odometry measurements, yaw weights, VIO-derived guesses) as device kernels (default) or on the host."""
+        self.lib.pgo_host_set_device_graph_construction(self.h, C.c_int(1 if on else 0))
+
     # ---- PoseGraphSLAM interface ----
     def reinit_ceres_problem_onnewloopedge_optimize6DOF_once(self):
         return bool(self.lib.pgo_host_trigger(self.h))

@@ -44,4 +44,6 @@ void dm_mat_to_quat(const double* T16, double* q) {
     for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R[r * 3 + c] = T16[c * 4 + r];
     eigen_matrix_to_quat(R, q);
 }
+void dm_vio_odometry_record(const double* Mu, const double* Mm, int f, int yaw_weight, double* out8) { vio_odometry_record(Mu, Mm, f, yaw_weight != 0, out8); }
+void dm_vio_left_compose(const double* L, const double* Mu, double* q, double* t) { vio_left_compose(L, Mu, q, t); }
 }

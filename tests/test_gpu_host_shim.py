@@ -38,10 +38,12 @@ def expected_odom(vio, lo, hi, worlds=None):
     return out
 
 
-def test_single_world_incremental_triggers_match_oracle():
+@pytest.mark.parametrize("device_k0", [True, False], ids=["k0_on_device", "k0_on_host"])
+def test_single_world_incremental_triggers_match_oracle(device_k0):
     g = graphgen.config("C1F5")
     vio = [T_of(g.init_q[i], g.init_t[i]) for i in range(g.n_poses)]
     S = PoseGraphSLAM(max_num_iterations=10, cg_rel_tolerance=1e-12, cg_max_iterations=20000)
+    S.set_device_graph_construction(device_k0)      # steps -3-/-4- as K0 kernels (default) or on the host thread
     O = ob.OracleProblem()
     # arrival script: keyframes stream in; loop-closure messages arrive when their newer keyframe exists; trigger after each batch
     order = np.argsort(g.loop_c2, kind="stable")
@@ -101,7 +103,8 @@ def test_single_world_incremental_triggers_match_oracle():
     S.close()
 
 
-def test_kidnap_two_worlds_merge_on_first_inter_world_edge():
+@pytest.mark.parametrize("device_k0", [True, False], ids=["k0_on_device", "k0_on_host"])
+def test_kidnap_two_worlds_merge_on_first_inter_world_edge(device_k0):
     rng = np.random.default_rng(5)
     g = util.small_graph(120, 0, f=1, seed=8, turn_deg_per_keyframe=2.0)
     truth = [T_of(g.truth_q[i], g.truth_t[i]) for i in range(120)]
@@ -109,6 +112,7 @@ def test_kidnap_two_worlds_merge_on_first_inter_world_edge():
     vio = [truth[i] for i in range(60)] + [np.linalg.inv(truth[60]) @ truth[i] for i in range(60, 120)]
     world = [0] * 60 + [1] * 60
     S = PoseGraphSLAM(max_num_iterations=10, cg_rel_tolerance=1e-12, cg_max_iterations=20000)
+    S.set_device_graph_construction(device_k0)
     for i in range(120):
         S.add_node(world[i], vio[i].flatten(order="F"))
     S.set_kidnapped(True)

@@ -1,0 +1,93 @@
+"""GPU: the K0 graph-construction kernels through the C-ABI (pgo_set_vio_poses / pgo_add_odometry_edges_from_vio /
+pgo_initial_guess_from_vio) against the oracle's restatement of src/PoseGraphSLAM.cpp:1570-1639 and :1770-1786."""
+import numpy as np
+import pytest
+
+from oracle import binding as orc
+from solve_keyframe_pose_graph_amd import capi, graphgen
+from tests import util
+from tests.test_vio_construction import random_poses
+
+pytestmark = pytest.mark.gpu
+
+
+def expected_records(T, w):
+    rec = np.zeros((len(T), 8))
+    for k in range(len(T)):
+        rec[k, :4] = orc.mat_to_quat(T[k])
+    rec[:, 4:7] = T[:, 12:15]
+    rec[:, 7] = w
+    return rec
+
+
+def test_odometry_edges_from_vio_match_the_reference_loop():
+    rng = np.random.default_rng(11)
+    n = 3000
+    w_M = random_poses(n, rng)
+    w_M[::13, :12] *= 1.0 + 1e-4                        # slightly non-orthonormal rotation blocks
+    set_id = np.zeros(n, np.int32)
+    set_id[1000:1010] = -1
+    set_id[1010:] = 2
+    P = capi.Problem()
+    # poses arrive in three batches, edges in two triggers — as the reference appends (:1340-1367, :1570)
+    P.set_vio_poses(0, w_M[:500])
+    P.set_vio_poses(500, w_M[500:2000])
+    assert P.num_vio_poses() == 2000
+    n1 = P.add_odometry_edges_from_vio(set_id, 0, 1200)
+    P.set_vio_poses(2000, w_M[2000:])
+    n2 = P.add_odometry_edges_from_vio(set_id, 1200, n)
+    c1, c2, T, w = orc.odometry_edges_from_vio(w_M, set_id, 0, n, 5, True)
+    assert n1 + n2 == len(c1)
+    g1, g2, rec = P.relpose_edge_records(0, n1 + n2)
+    assert np.array_equal(g1, c1) and np.array_equal(g2, c2)
+    exp = expected_records(T, w)
+    assert np.abs(rec[:, :4] - exp[:, :4]).max() < 1e-12
+    assert (np.abs(rec[:, 4:7] - exp[:, 4:7]) / np.maximum(1.0, np.abs(exp[:, 4:7]))).max() < 1e-12
+    assert np.abs(rec[:, 7] - exp[:, 7]).max() < 1e-14
+    # without the yaw term
+    P2 = capi.Problem()
+    P2.set_vio_poses(0, w_M)
+    P2.add_odometry_edges_from_vio(None, 0, n, f_max=2, use_yaw_weight=False)
+    a1, a2, r2 = P2.relpose_edge_records(0, P2.n_rel)
+    assert set((a1 - a2).tolist()) == {1, 2}
+    assert set(np.round(r2[:, 7], 12)) == {0.9, 0.81}
+    # errors: beyond the resident poses, non-contiguous append
+    with pytest.raises(capi.PgoError):
+        P2.add_odometry_edges_from_vio(None, 0, n + 1)
+    with pytest.raises(capi.PgoError):
+        P2.set_vio_poses(n + 5, w_M[:1])
+
+
+def test_initial_guess_from_vio_matches_the_reference_chaining():
+    rng = np.random.default_rng(12)
+    n = 2500
+    w_M = random_poses(n, rng)
+    left = random_poses(4, rng, walk=False)
+    sel = rng.integers(-1, 4, n - 700).astype(np.int32)
+    q = rng.normal(size=(n, 4))
+    t = rng.normal(size=(n, 3))
+    qo, to = q.copy(), t.copy()
+    orc.initial_guess_from_vio(left, sel, w_M, 700, n, qo, to)
+    P = capi.Problem()
+    P.set_vio_poses(0, w_M)
+    P.initial_guess_from_vio(left, sel, 700, n, q, t)
+    assert np.abs(q - qo).max() < 1e-12
+    assert (np.abs(t - to) / np.maximum(1.0, np.abs(to))).max() < 1e-12
+    assert np.array_equal(q[:700], qo[:700])
+
+
+def test_graph_built_on_the_device_solves_like_the_host_built_one():
+    """C4-style graph (f = 1..5, yaw weights): odometry edges built by K0 from the VIO chain vs handed over as matrices."""
+    g = graphgen.generate(4000, 400, odom_f_max=5, apply_yaw_weight=1, seed=9, **graphgen._SMALL)
+    q, t, s = util.initial_state(g, True)
+    Pa = util.pgo_problem(g, True)
+    qa, ta, sa, suma = Pa.solve(q, t, s)
+    Pb = capi.Problem()
+    Pb.set_vio_poses(0, util.poses_to_matrices(g.init_q, g.init_t))
+    assert Pb.add_odometry_edges_from_vio(None, 0, g.n_poses) == g.n_odom
+    Pb.add_switchable_edges(g.loop_c1, g.loop_c2, g.loop_T, g.loop_w, np.arange(g.n_loops))
+    Pb.set_node_regularizers(g.reg_node, g.reg_T, g.reg_w)
+    qb, tb, sb, sumb = Pb.solve(q, t, s)
+    assert sumb.num_iterations == suma.num_iterations
+    assert abs(sumb.final_cost - suma.final_cost) <= 1e-8 * suma.final_cost
+    assert np.abs(tb - ta).max() < 1e-6 and np.abs(sb - sa).max() < 1e-6

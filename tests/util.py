@@ -46,3 +46,18 @@ def small_graph(n=300, loops=40, f=2, seed=11, **kw):
     opts = dict(box_scale=1.0, turn_deg_per_keyframe=15.0, straight_min=2, straight_max=6, min_loop_gap=20, odom_sigma_r=0.002, odom_sigma_t=0.01)
     opts.update(kw)
     return graphgen.generate(n, loops, odom_f_max=f, seed=seed, **opts)
+
+
+def poses_to_matrices(q, t):
+    """(xyzw, t) rows -> n x 16 column-major Matrix4d (the layout `manager->getNodePose(i)` hands the trigger)"""
+    q = np.asarray(q, dtype=np.float64)
+    x, y, z, w = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = np.empty((len(q), 3, 3))
+    R[:, 0, 0] = 1 - 2 * (y * y + z * z); R[:, 0, 1] = 2 * (x * y - z * w); R[:, 0, 2] = 2 * (x * z + y * w)
+    R[:, 1, 0] = 2 * (x * y + z * w); R[:, 1, 1] = 1 - 2 * (x * x + z * z); R[:, 1, 2] = 2 * (y * z - x * w)
+    R[:, 2, 0] = 2 * (x * z - y * w); R[:, 2, 1] = 2 * (y * z + x * w); R[:, 2, 2] = 1 - 2 * (x * x + y * y)
+    M = np.zeros((len(q), 4, 4))
+    M[:, :3, :3] = R
+    M[:, :3, 3] = t
+    M[:, 3, 3] = 1
+    return np.ascontiguousarray(M.transpose(0, 2, 1)).reshape(len(q), 16)
