@@ -323,3 +323,58 @@ def probe6(n, radii, n_aggs, loops=None):
                     M = TwoLevel(A, t, agg, Dinv, mode)
                     t0 = time.time(); x2, k2 = pcg(A, b, M, 1e-8, maxit=4000)
                     print('  n_agg %5d %-7s %-4s coarse dim %5d: its %4d (%.1fs) err %.1e' % (na, kind, mode, M.nc, k2, time.time() - t0, np.abs(x2 - x).max() / np.abs(x).max()), flush=True)
+
+
+class ChainTridiag:
+    """M = block-tridiagonal part of A along the keyframe chain (diagonal blocks of A + the (i,i+1) blocks), solved exactly.
+    SPD because every edge's contribution is PSD and dropping a PSD edge's off-diagonal blocks keeps its diagonal blocks."""
+    def __init__(self, A, N, band=1):
+        Ab = A.tobsr(blocksize=(6, 6))
+        rows = np.repeat(np.arange(N), np.diff(Ab.indptr))
+        keep = np.abs(rows - Ab.indices) <= band
+        indptr = np.concatenate([[0], np.cumsum(np.bincount(rows[keep], minlength=N))])
+        M = sp.bsr_matrix((Ab.data[keep], Ab.indices[keep], indptr), shape=A.shape)
+        self.lu = spla.splu(M.tocsc(), permc_spec='NATURAL', diag_pivot_thresh=0.0)
+    def __call__(self, r): return self.lu.solve(r)
+
+
+def probe7(n, loops, f, switchable, radii, bands=(1, 2)):
+    g = graphgen.generate(n, loops, odom_f_max=f, seed=3)
+    q, t, s = util.initial_state(g, switchable)
+    N = g.n_poses
+    for radius in radii:
+        if switchable:
+            A, b = build_system(g, q, t, s, radius)
+        else:
+            A, b = build_system_plain(g, q, t, radius)
+        Dinv = block_diag_inv(A, N)
+        t0 = time.time(); x, k = pcg(A, b, lambda r: Dinv @ r, 1e-8, maxit=60000); print('n %d loops %d f %d radius %g  block-Jacobi its %d (%.1fs)' % (n, loops, f, radius, k, time.time() - t0), flush=True)
+        for band in bands:
+            M = ChainTridiag(A, N, band)
+            t0 = time.time(); x2, k2 = pcg(A, b, M, 1e-8, maxit=20000)
+            print('   chain band %d: its %d (%.1fs) err %.1e' % (band, k2, time.time() - t0, np.abs(x2 - x).max() / np.abs(x).max()), flush=True)
+
+
+def build_system_plain(g, q, t, radius):
+    """all edges as plain relative-pose edges (C2 style)"""
+    O = util.oracle_problem(g, False)
+    N = g.n_poses
+    s = np.zeros(0)
+    J1r, J2r, _ = O.jacobian_blocks(q, t, s, 0)
+    J1p, _, _ = O.jacobian_blocks(q, t, s, 2)
+    cost, res, grad = O.evaluate(q, t, s)
+    c1 = np.concatenate([g.odom_c1, g.loop_c1]); c2 = np.concatenate([g.odom_c2, g.loop_c2])
+    Hd = np.zeros((N, 6, 6))
+    np.add.at(Hd, c1, np.einsum('eia,eib->eab', J1r, J1r)); np.add.at(Hd, c2, np.einsum('eia,eib->eab', J2r, J2r))
+    Hoff = np.einsum('eia,eib->eab', J1r, J2r)
+    np.add.at(Hd, g.reg_node, np.einsum('eia,eib->eab', J1p, J1p))
+    diag = np.einsum('naa->na', Hd).copy()
+    sc = 1 / (1 + np.sqrt(diag))
+    lam = np.clip(sc ** 2 * diag, 1e-6, 1e32) / (radius * sc ** 2)
+    Hd[np.arange(N)[:, None], np.arange(6), np.arange(6)] += lam
+    r_ = np.concatenate([np.arange(N), c1, c2]); c_ = np.concatenate([np.arange(N), c2, c1])
+    b_ = np.concatenate([Hd, Hoff, Hoff.transpose(0, 2, 1)])
+    ii = (r_[:, None, None] * 6 + np.arange(6)[None, :, None]) + 0 * np.arange(6)[None, None, :]
+    jj = (c_[:, None, None] * 6 + np.arange(6)[None, None, :]) + 0 * np.arange(6)[None, :, None]
+    A = sp.coo_matrix((b_.ravel(), (ii.ravel(), jj.ravel())), shape=(6 * N, 6 * N)).tocsr()
+    return A, -grad[:6 * N].copy()

@@ -53,8 +53,8 @@ LIBHOST = os.path.join(_HERE, "libpgo_host.so")
 def build_host(force=False):
     """C++ host side above the C-ABI (csrc/host/PoseGraphSLAM.*): plain g++, links libpgo.so next to it."""
     build_libpgo(force)
-    srcs = [os.path.join(CSRC, "host", "PoseGraphSLAM.cpp")]
-    deps = srcs + [os.path.join(CSRC, "host", "PoseGraphSLAM.hpp"), os.path.join(CSRC, "pgo_device_math.hpp"), os.path.join(INCLUDE, "pgo.h"), LIBPGO]
+    srcs = [os.path.join(CSRC, "host", "PoseGraphSLAM.cpp"), os.path.join(CSRC, "host", "GraphFormats.cpp")]
+    deps = srcs + [os.path.join(CSRC, "host", "PoseGraphSLAM.hpp"), os.path.join(CSRC, "host", "GraphFormats.hpp"), os.path.join(CSRC, "pgo_device_math.hpp"), os.path.join(INCLUDE, "pgo.h"), LIBPGO]
     if force or _stale(LIBHOST, deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", INCLUDE, "-I", CSRC, "-o", LIBHOST] + srcs +
                               ["-L", _HERE, "-l:libpgo.so", "-Wl,-rpath,$ORIGIN"])

@@ -1,5 +1,6 @@
 // PoseGraphSLAM.cpp — see PoseGraphSLAM.hpp.  Host code only; every numerical step of the solve happens inside libpgo (HIP).
 #include "PoseGraphSLAM.hpp"
+#include "GraphFormats.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -278,23 +279,8 @@ bool PoseGraphSLAM::reinit_ceres_problem_onnewloopedge_optimize6DOF_once() {
 }
 
 // ---------------------------------------------------------------- saveAsJSON (reference src/PoseGraphSLAM.cpp:1111-1207)
-static std::string csv_matrix(const Matrix4d& M) {   // Eigen IOFormat(FullPrecision, DontAlignCols, ",", ";")
-    std::string out; char buf[40];
-    for (int r = 0; r < 4; ++r) {
-        for (int c = 0; c < 4; ++c) { std::snprintf(buf, sizeof(buf), "%.17g", M(r, c)); out += buf; if (c < 3) out += ","; }
-        if (r < 3) out += ";";
-    }
-    return out;
-}
-static std::string prettyprintMatrix4d(const Matrix4d& M) {   // PoseManipUtils.cpp:206-215: yaw,pitch,roll in degrees + translation
-    const double nx = M(0, 0), ny = M(1, 0), nz = M(2, 0), ox = M(0, 1), oy = M(1, 1), ax = M(0, 2), ay = M(1, 2);
-    const double y = std::atan2(ny, nx);
-    const double pch = std::atan2(-nz, nx * std::cos(y) + ny * std::sin(y));
-    const double rl = std::atan2(ax * std::sin(y) - ay * std::cos(y), -ox * std::sin(y) + oy * std::cos(y));
-    char buf[200];
-    std::snprintf(buf, sizeof(buf), ":YPR(deg)=(%4.3f,%4.3f,%4.3f)  :TxTyTz=(%4.3f,%4.3f,%4.3f)", y / M_PI * 180.0, pch / M_PI * 180.0, rl / M_PI * 180.0, M(0, 3), M(1, 3), M(2, 3));
-    return buf;
-}
+static std::string csv_matrix(const Matrix4d& M) { return matrix4d_to_csv(M); }            // shared with log_posegraph.json (GraphFormats.cpp)
+static std::string prettyprintMatrix4d(const Matrix4d& M) { return prettyprint_matrix4d(M); }
 bool PoseGraphSLAM::saveAsJSON(const std::string& base_path) const {
     FILE* f = std::fopen((base_path + "/log_optimized_poses.json").c_str(), "w");
     if (!f) return false;
@@ -366,7 +352,61 @@ pgo_host_session* pgo_host_create(const pgo_options* opt) {
     if (!s->slam->ok()) { delete s->slam; delete s; return nullptr; }
     return s;
 }
-void pgo_host_destroy(pgo_host_session* s) { if (s) { delete s->slam; delete s; } }
+// A session that only holds the data source (no solver, no GPU): file-format work
+pgo_host_session* pgo_host_create_source_only() { pgo_host_session* s = new pgo_host_session(); s->slam = nullptr; return s; }
+// Attaches the solver to a source-only session (e.g. after pgo_host_load_posegraph_json); 1 on success
+int pgo_host_attach_solver(pgo_host_session* s, const pgo_options* opt) {
+    if (s->slam) return 1;
+    s->slam = new PoseGraphSLAM(&s->src, opt);
+    if (!s->slam->ok()) { delete s->slam; s->slam = nullptr; return 0; }
+    return 1;
+}
+int pgo_host_source_n_nodes(pgo_host_session* s) { return s->src.getNodeLen(); }
+int pgo_host_source_n_edges(pgo_host_session* s) { return s->src.getEdgeLen(); }
+void pgo_host_source_get_node(pgo_host_session* s, int i, int* world, double* stamp, double* T16) {
+    *world = s->src.which_world_is_this_node(i); *stamp = s->src.getNodeTimestamp(i);
+    const Matrix4d T = s->src.getNodePose(i); std::copy(T.d.begin(), T.d.end(), T16);
+}
+void pgo_host_source_get_edge(pgo_host_session* s, int e, int* a, int* b, double* weight, double* bTa16, char* description, int description_cap) {
+    const std::pair<int, int> p = s->src.getEdgeIdxInfo(e);
+    *a = p.first; *b = p.second; *weight = s->src.getEdgeWeight(e);
+    const Matrix4d T = s->src.getEdgePose(e); std::copy(T.d.begin(), T.d.end(), bTa16);
+    if (description && description_cap > 0) { std::strncpy(description, s->src.getEdgeDescriptionString(e).c_str(), (size_t)description_cap - 1); description[description_cap - 1] = 0; }
+}
+void pgo_host_add_node_stamped(pgo_host_session* s, int world, const double* T16, double stamp) { Matrix4d T; std::copy(T16, T16 + 16, T.d.begin()); s->src.add_node(world, T, stamp); }
+void pgo_host_add_loop_edge_described(pgo_host_session* s, int a, int b, const double* bTa16, double w, const char* description) {
+    Matrix4d T; std::copy(bTa16, bTa16 + 16, T.d.begin()); s->src.add_loop_edge(a, b, T, w, description ? description : "");
+}
+// log_posegraph.json (NodeDataManager::saveAsJSON / loadFromJSON, reference src/NodeDataManager.cpp:503-754)
+int pgo_host_save_posegraph_json(pgo_host_session* s, const char* base_path) { return save_posegraph_json(s->src, base_path) ? 1 : 0; }
+int pgo_host_load_posegraph_json(pgo_host_session* s, const char* base_path, const uint8_t* edge_mask, int n_mask, char* err, int err_cap) {
+    if (s->slam) { if (err && err_cap > 0) std::snprintf(err, (size_t)err_cap, "load into a source-only session, then attach the solver"); return 0; }
+    std::vector<bool> mask;
+    for (int i = 0; i < n_mask; ++i) mask.push_back(edge_mask[i] != 0);
+    std::string e;
+    const bool ok = load_posegraph_json(s->src, base_path, mask, &e);
+    if (!ok && err && err_cap > 0) std::snprintf(err, (size_t)err_cap, "%s", e.c_str());
+    return ok ? 1 : 0;
+}
+// g2o export: keyframe poses = optimised when `optimized` and a solver is attached, else the VIO poses; edges = loop edges (b -> a, b_T_a,
+// unit weight: the switchable functor ignores its weight, CeresResidues.h:198) followed by the odometry edges of the reference policy
+// (f = 1..f_max, weight 0.9^f exp(-yaw^2/6)) for pairs whose endpoints are in live worlds
+int pgo_host_export_g2o(pgo_host_session* s, const char* path, int optimized, int f_max) {
+    const int n = s->src.getNodeLen();
+    std::vector<Matrix4d> poses;
+    for (int i = 0; i < n; ++i) poses.push_back((optimized && s->slam && s->slam->nodePoseExists(i)) ? s->slam->getNodePose(i) : s->src.getNodePose(i));
+    std::vector<G2oEdge> edges;
+    for (int e = 0; e < s->src.getEdgeLen(); ++e) { const std::pair<int, int> p = s->src.getEdgeIdxInfo(e); edges.push_back({p.second, p.first, s->src.getEdgePose(e), 1.0}); }
+    for (int u = 0; u < n; ++u)
+        for (int f = 1; f <= f_max; ++f) {
+            if (u - f < 0 || s->src.find_setID_of_world_i(s->src.which_world_is_this_node(u)) < 0 || s->src.find_setID_of_world_i(s->src.which_world_is_this_node(u - f)) < 0) continue;
+            const Matrix4d M = s->src.getNodePose(u).inverse() * s->src.getNodePose(u - f);
+            const double yaw = yaw_degrees(M);
+            edges.push_back({u, u - f, M, std::pow(0.9, f) * std::exp(-yaw * yaw / 6.0)});
+        }
+    return export_g2o(path, poses, edges) ? 1 : 0;
+}
+void pgo_host_destroy(pgo_host_session* s) { if (s) { delete s->slam; delete s; } }   // slam may be null (source-only)
 void pgo_host_add_node(pgo_host_session* s, int world, const double* T16) { Matrix4d T; std::copy(T16, T16 + 16, T.d.begin()); s->src.add_node(world, T); }
 void pgo_host_add_loop_edge(pgo_host_session* s, int a, int b, const double* bTa16, double w) { Matrix4d T; std::copy(bTa16, bTa16 + 16, T.d.begin()); s->src.add_loop_edge(a, b, T, w); }
 void pgo_host_set_kidnapped(pgo_host_session* s, int k) { s->src.set_kidnapped(k != 0); }

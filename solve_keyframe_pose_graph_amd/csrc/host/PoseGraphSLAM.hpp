@@ -123,9 +123,19 @@ private:
 // A plain in-memory GraphSource (stands in for NodeDataManager + Worlds in tests and examples).
 class VectorGraphSource : public GraphSource {
 public:
-    void add_node(int world, const Matrix4d& w_M_i) { node_world_.push_back(world); node_pose_.push_back(w_M_i); }
-    void add_loop_edge(int a, int b, const Matrix4d& b_T_a, double weight) { edge_ab_.push_back({a, b}); edge_pose_.push_back(b_T_a); edge_w_.push_back(weight); }
+    // stamp < 0: keyframes are stamped idx * 0.1 s (the reference stores ros::Time; only equality and order matter here)
+    void add_node(int world, const Matrix4d& w_M_i, double stamp = -1.0) {
+        node_stamp_.push_back(stamp >= 0 ? stamp : 0.1 * (double)node_pose_.size());
+        node_world_.push_back(world); node_pose_.push_back(w_M_i);
+    }
+    void add_loop_edge(int a, int b, const Matrix4d& b_T_a, double weight, const std::string& description = std::string()) {
+        edge_ab_.push_back({a, b}); edge_pose_.push_back(b_T_a); edge_w_.push_back(weight); edge_desc_.push_back(description);
+    }
     void set_kidnapped(bool k) { kidnapped_ = k; }
+    void reset() { node_world_.clear(); node_pose_.clear(); node_stamp_.clear(); edge_ab_.clear(); edge_pose_.clear(); edge_w_.clear(); edge_desc_.clear(); set_of_.clear(); set_T_world_.clear(); kidnapped_ = false; }
+    double getNodeTimestamp(int i) const { return node_stamp_[i]; }
+    const std::string& getEdgeDescriptionString(int e) const { return edge_desc_[e]; }
+    std::string disjoint_set_status() const;      // Worlds::disjoint_set_status (reference src/Worlds.cpp:333-370)
 
     int getNodeLen() const override { return (int)node_pose_.size(); }
     Matrix4d getNodePose(int i) const override { return node_pose_[i]; }
@@ -150,7 +160,8 @@ private:
     std::vector<Matrix4d> node_pose_;
     std::vector<std::pair<int, int>> edge_ab_;
     std::vector<Matrix4d> edge_pose_;
-    std::vector<double> edge_w_;
+    std::vector<double> edge_w_, node_stamp_;
+    std::vector<std::string> edge_desc_;
     bool kidnapped_ = false;
     mutable std::vector<int> set_of_;            // world -> set id (= smallest world id of the merged set)
     mutable std::vector<Matrix4d> set_T_world_;  // pose of the world in its set's frame

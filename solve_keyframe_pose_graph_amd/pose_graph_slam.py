@@ -18,12 +18,83 @@ def _load():
         capi.load()
         _lib = C.CDLL(_build.build_host())
         _lib.pgo_host_create.restype = C.c_void_p
+        _lib.pgo_host_create_source_only.restype = C.c_void_p
         _lib.pgo_host_switch.restype = C.c_double
         for f in ("destroy", "add_node", "add_loop_edge", "set_kidnapped", "trigger", "n_nodes", "solved_until", "node_pose_exists", "get_node_pose", "switch",
                   "n_added_edges", "get_added_edges", "n_regularizers", "get_regularizers", "get_initial_guess", "get_summary", "last_error"):
             fn = getattr(_lib, "pgo_host_" + f)
             fn.argtypes = None
     return _lib
+
+
+class GraphSource:
+    """The data-source half of a host session (NodeDataManager + Worlds stand-in) without a solver: needs no GPU.  Reads and writes
+    the reference's `log_posegraph.json` (NodeDataManager::saveAsJSON / loadFromJSON, reference src/NodeDataManager.cpp:503-754) and
+    exports .g2o; `attach_solver()` turns it into a PoseGraphSLAM session over the same data."""
+
+    def __init__(self):
+        self.lib = _load()
+        self.h = C.c_void_p(self.lib.pgo_host_create_source_only())
+        self._owned = True
+
+    def close(self):
+        if self._owned and self.h and self.h.value:
+            self.lib.pgo_host_destroy(self.h)
+        self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add_node(self, world, w_M_i_colmajor16, stamp=-1.0):
+        a = np.ascontiguousarray(w_M_i_colmajor16, dtype=np.float64)
+        self.lib.pgo_host_add_node_stamped(self.h, C.c_int(world), a.ctypes.data_as(_dp), C.c_double(stamp))
+
+    def add_loop_edge(self, a, b, b_T_a_colmajor16, weight=1.0, description=""):
+        T = np.ascontiguousarray(b_T_a_colmajor16, dtype=np.float64)
+        self.lib.pgo_host_add_loop_edge_described(self.h, C.c_int(a), C.c_int(b), T.ctypes.data_as(_dp), C.c_double(weight), description.encode())
+
+    def n_nodes(self):
+        return self.lib.pgo_host_source_n_nodes(self.h)
+
+    def n_edges(self):
+        return self.lib.pgo_host_source_n_edges(self.h)
+
+    def node(self, i):
+        w = C.c_int(); st = C.c_double(); T = np.zeros(16)
+        self.lib.pgo_host_source_get_node(self.h, C.c_int(i), C.byref(w), C.byref(st), T.ctypes.data_as(_dp))
+        return w.value, st.value, T
+
+    def edge(self, e):
+        a = C.c_int(); b = C.c_int(); w = C.c_double(); T = np.zeros(16); buf = C.create_string_buffer(512)
+        self.lib.pgo_host_source_get_edge(self.h, C.c_int(e), C.byref(a), C.byref(b), C.byref(w), T.ctypes.data_as(_dp), buf, C.c_int(512))
+        return a.value, b.value, w.value, T, buf.value.decode()
+
+    def save_posegraph_json(self, base_path):
+        return bool(self.lib.pgo_host_save_posegraph_json(self.h, str(base_path).encode()))
+
+    def load_posegraph_json(self, base_path, edge_mask=None):
+        m = np.ascontiguousarray(edge_mask, dtype=np.uint8) if edge_mask is not None else np.zeros(0, np.uint8)
+        err = C.create_string_buffer(512)
+        ok = self.lib.pgo_host_load_posegraph_json(self.h, str(base_path).encode(), m.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_int(len(m)), err, C.c_int(512))
+        if not ok:
+            raise ValueError("log_posegraph.json: " + err.value.decode())
+        return self
+
+    def export_g2o(self, path, optimized=False, f_max=5):
+        return bool(self.lib.pgo_host_export_g2o(self.h, str(path).encode(), C.c_int(1 if optimized else 0), C.c_int(f_max)))
+
+    def attach_solver(self, **opt_kw):
+        """-> PoseGraphSLAM over this source (needs a GPU).  The returned object owns the session."""
+        opt = capi.default_options(**opt_kw)
+        if not self.lib.pgo_host_attach_solver(self.h, C.byref(opt)):
+            raise capi.PgoError(-2, "PoseGraphSLAM: pgo_create failed (no GPU / libpgo missing): there is no CPU fallback")
+        S = PoseGraphSLAM.__new__(PoseGraphSLAM)
+        S.lib, S.opt, S.h = self.lib, opt, self.h
+        self._owned = False
+        return S
 
 
 class PoseGraphSLAM:
@@ -46,13 +117,13 @@ class PoseGraphSLAM:
             pass
 
     # ---- the caller side (NodeDataManager stand-in) ----
-    def add_node(self, world, w_M_i_colmajor16):
+    def add_node(self, world, w_M_i_colmajor16, stamp=-1.0):
         a = np.ascontiguousarray(w_M_i_colmajor16, dtype=np.float64)
-        self.lib.pgo_host_add_node(self.h, C.c_int(world), a.ctypes.data_as(_dp))
+        self.lib.pgo_host_add_node_stamped(self.h, C.c_int(world), a.ctypes.data_as(_dp), C.c_double(stamp))
 
-    def add_loop_edge(self, a, b, b_T_a_colmajor16, weight=1.0):
+    def add_loop_edge(self, a, b, b_T_a_colmajor16, weight=1.0, description=""):
         T = np.ascontiguousarray(b_T_a_colmajor16, dtype=np.float64)
-        self.lib.pgo_host_add_loop_edge(self.h, C.c_int(a), C.c_int(b), T.ctypes.data_as(_dp), C.c_double(weight))
+        self.lib.pgo_host_add_loop_edge_described(self.h, C.c_int(a), C.c_int(b), T.ctypes.data_as(_dp), C.c_double(weight), description.encode())
 
     def set_kidnapped(self, k):
         self.lib.pgo_host_set_kidnapped(self.h, C.c_int(1 if k else 0))
@@ -110,6 +181,12 @@ class PoseGraphSLAM:
 
     def saveAsJSON(self, base_path):
         return bool(self.lib.pgo_host_save_as_json(self.h, str(base_path).encode()))
+
+    def save_posegraph_json(self, base_path):
+        return bool(self.lib.pgo_host_save_posegraph_json(self.h, str(base_path).encode()))
+
+    def export_g2o(self, path, optimized=True, f_max=5):
+        return bool(self.lib.pgo_host_export_g2o(self.h, str(path).encode(), C.c_int(1 if optimized else 0), C.c_int(f_max)))
 
     def last_error(self):
         return self.lib.pgo_host_last_error(self.h)

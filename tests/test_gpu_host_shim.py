@@ -162,3 +162,36 @@ def test_save_as_json_round_trip(tmp_path):
     sw = np.array([S.get_loopedge_switching_variable_val(e) for e in range(g.n_loops)])
     assert np.array_equal(d["switching_var_after_opt"], sw)
     S.close()
+
+
+def test_replay_of_a_recorded_session_from_log_posegraph_json(tmp_path):
+    """a session written in the reference's log_posegraph.json format is replayed through the trigger (incremental
+    solves), and the optimised trajectory written as log_optimized_poses.json equals a direct solve of the same final problem."""
+    from solve_keyframe_pose_graph_amd import replay
+    from solve_keyframe_pose_graph_amd.pose_graph_slam import GraphSource, read_log_optimized_poses
+    g = util.small_graph(400, 60, f=1, seed=31)
+    w_M = util.poses_to_matrices(g.init_q, g.init_t)
+    rec = GraphSource()
+    for i in range(g.n_poses):
+        rec.add_node(0, w_M[i])
+    for e in range(g.n_loops):
+        rec.add_loop_edge(int(g.loop_c2[e]), int(g.loop_c1[e]), g.loop_T[e], 1.0, "synthetic")
+    (tmp_path / "in").mkdir()
+    assert rec.save_posegraph_json(tmp_path / "in")
+    assert replay.main([str(tmp_path / "in"), "--out", str(tmp_path / "out"), "--every", "80"]) == 0
+    out = read_log_optimized_poses(tmp_path / "out" / "log_optimized_poses.json")
+    assert out["nNodes"] == g.n_poses and len(out["edge_a"]) == g.n_loops
+    assert np.abs(out["w_T_c_odom"].reshape(-1, 4, 4).transpose(0, 2, 1).reshape(-1, 16) - w_M).max() < 1e-12
+    assert (tmp_path / "out" / "optimized.g2o").exists() and (tmp_path / "out" / "log_posegraph.json").exists()
+    # the last trigger solved the complete graph: its cost is a local minimum of the same objective the oracle sees
+    src = GraphSource().load_posegraph_json(tmp_path / "out")
+    S, log = replay.replay(src, every=80, max_num_iterations=10)
+    assert len(log) >= 3 and all(r["final_cost"] <= r["initial_cost"] for r in log)
+    assert log[-1]["keyframes"] == g.n_poses and log[-1]["loop_edges"] == g.n_loops
+    got = np.array([S.getNodePose(i) for i in range(g.n_poses)])
+    assert np.abs(got - out["wTc_opt"]).max() < 1e-9                          # the replay is deterministic
+    inl = g.loop_is_outlier == 0
+    order = np.argsort(np.maximum(g.loop_c1, g.loop_c2), kind="stable")       # arrival order = switch index
+    s_fin = np.array([S.get_loopedge_switching_variable_val(k) for k in range(g.n_loops)])
+    assert (s_fin[np.argsort(order)][inl] > 0.5).mean() > 0.9                 # inlier loop closures stay switched on
+    S.close()
