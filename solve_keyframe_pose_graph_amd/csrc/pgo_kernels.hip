@@ -416,8 +416,9 @@ __global__ __launch_bounds__(256) void build_rows_kernel(GraphDev G, LinDev L, S
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= G.N) return;
     const bool free_node = G.node_free[n] != 0;
-    // `add_lambda` marks the LEAD rank (rank 0, or the only rank): Hd and g are already summed over ranks (all-reduced after K2), so
-    // exactly one rank may put them — and the damping — into the system; the others contribute only their local switch Schur terms.
+    // Multi-GPU: Hd and g are already summed over the ranks sharing the keyframe (exchanged after K2), so exactly one rank — the
+    // keyframe's OWNER — may put them and the damping into the system; the others contribute only their local switch Schur terms.
+    if (G.own) add_lambda = G.own[n] != 0.0 ? 1 : 0;
     double D[36], bv[6];
 #pragma unroll
     for (int i = 0; i < 36; ++i) D[i] = add_lambda ? L.Hd[(size_t)n * 36 + i] : 0.0;
@@ -719,18 +720,6 @@ __global__ __launch_bounds__(CG_BLOCK) void cg_spmv_kernel(GraphDev G, CgDev C, 
     if (threadIdx.x == 0) C.part_pq[blockIdx.x] = s;
 }
 
-// multi-GPU: after the RCCL all-reduce of q, recompute the p.q partials
-__global__ __launch_bounds__(CG_BLOCK) void cg_pq_kernel(GraphDev G, CgDev C, int parity) {
-    __shared__ double red[CG_BLOCK / 64];
-    if (cg_done(C)) return;
-    const double* __restrict__ pcur = parity ? C.p2 : C.p;
-    const int64_t rows = G.N * 6;
-    double pq = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * CG_BLOCK + threadIdx.x; i < rows; i += (int64_t)gridDim.x * CG_BLOCK) pq += C.q[i] * pcur[i];
-    const double s = block_sum(pq, red);
-    if (threadIdx.x == 0) C.part_pq[blockIdx.x] = s;
-}
-
 __global__ __launch_bounds__(CG_BLOCK) void apply_operator_kernel(GraphDev G, CgDev C, const double* __restrict__ x, double* __restrict__ y) {
     __shared__ double xch[CG_BLOCK * 7];
     const int64_t rows = G.N * 6;
@@ -784,7 +773,8 @@ __global__ __launch_bounds__(CG_BLOCK) void cg_init_kernel(GraphDev G, CgDev C, 
             const double zb = warm ? lf_apply_row(Lf, bv + (threadIdx.x - r), r) : z;
             if (!warm) C.x[i] = 0.0;
             C.r[i] = ri; C.z[i] = z; C.p[i] = 0.0; C.p2[i] = 0.0;   // p buffers zeroed: iteration 0 multiplies them by beta = 0
-            rz += ri * z; bb += bi * zb;
+            const double w = G.own ? G.own[i / 6] : 1.0;
+            rz += w * ri * z; bb += w * bi * zb;
         }
     }
     const double s = block_sum(rz, red);
@@ -852,7 +842,8 @@ __global__ __launch_bounds__(CG_BLOCK) void cg_update_kernel(GraphDev G, CgDev C
             const int j = (int)(i % 3);
             const double2 z = lf_apply_pair(lfs + (threadIdx.x / 3) * LF_STRIDE, reinterpret_cast<const double*>(rnew + (threadIdx.x - j)), j);
             zv[i] = z;
-            acc += rr.x * z.x + rr.y * z.y;
+            const double w = G.own ? G.own[i / 3] : 1.0;
+            acc += w * (rr.x * z.x + rr.y * z.y);
         }
     }
     const double s = block_sum(acc, red);
@@ -879,12 +870,22 @@ void launch_cg_init(const GraphDev& G, const CgDev& C, int warm, double tol2, hi
     hipLaunchKernelGGL(cg_init_kernel, dim3(g), dim3(CG_BLOCK), 0, st, G, C, warm);
     hipLaunchKernelGGL(cg_scalars_init_kernel, dim3(1), dim3(256), 0, st, C, g, tol2);
 }
-void launch_cg_spmv(const GraphDev& G, const CgDev& C, int k, double tol2, hipStream_t st) {
+int launch_cg_init_vectors(const GraphDev& G, const CgDev& C, int warm, hipStream_t st) {
     const int g = cg_grid(G);
-    hipLaunchKernelGGL(cg_spmv_kernel, dim3(g), dim3(CG_BLOCK), 0, st, G, C, k & 1, k == 0 ? 1 : 0, g, tol2);
+    hipLaunchKernelGGL(cg_init_kernel, dim3(g), dim3(CG_BLOCK), 0, st, G, C, warm);
+    return g;
 }
-void launch_cg_pq(const GraphDev& G, const CgDev& C, int k, hipStream_t st) { hipLaunchKernelGGL(cg_pq_kernel, dim3(cg_grid(G)), dim3(CG_BLOCK), 0, st, G, C, k & 1); }
-void launch_cg_update(const GraphDev& G, const CgDev& C, int k, int n_pq_partials, hipStream_t st) { const int g = cg_grid(G); hipLaunchKernelGGL(cg_update_kernel, dim3(g), dim3(CG_BLOCK), 0, st, G, C, k & 1, n_pq_partials, g); }
+void launch_cg_init_scalars(const CgDev& C, int nparts, double tol2, hipStream_t st) { hipLaunchKernelGGL(cg_scalars_init_kernel, dim3(1), dim3(256), 0, st, C, nparts, tol2); }
+// n_rz_partials: how many r.z partial sums the consumers re-reduce (0 = one per cg_update workgroup; multi-GPU passes 1: the partials
+// were summed over workgroups AND ranks into slot 0)
+void launch_cg_spmv(const GraphDev& G, const CgDev& C, int k, double tol2, hipStream_t st, int n_rz_partials) {
+    const int g = cg_grid(G);
+    hipLaunchKernelGGL(cg_spmv_kernel, dim3(g), dim3(CG_BLOCK), 0, st, G, C, k & 1, k == 0 ? 1 : 0, n_rz_partials > 0 ? n_rz_partials : g, tol2);
+}
+void launch_cg_update(const GraphDev& G, const CgDev& C, int k, int n_pq_partials, hipStream_t st, int n_rz_partials) {
+    const int g = cg_grid(G);
+    hipLaunchKernelGGL(cg_update_kernel, dim3(g), dim3(CG_BLOCK), 0, st, G, C, k & 1, n_pq_partials, n_rz_partials > 0 ? n_rz_partials : g);
+}
 int cg_grid_size(const GraphDev& G) { return cg_grid(G); }
 void launch_apply_operator(const GraphDev& G, const CgDev& C, const double* x, double* y, hipStream_t st) { hipLaunchKernelGGL(apply_operator_kernel, dim3(cg_grid(G)), dim3(CG_BLOCK), 0, st, G, C, x, y); }
 
@@ -1037,10 +1038,11 @@ int mf_grid_size(const MfDev& F) { return mf_grid(F); }
 void launch_mf_compact(const GraphDev& G, const MfDev& F, const double* pose8, const double* sw, hipStream_t st) {
     if (F.ninc > 0) hipLaunchKernelGGL(mf_compact_kernel, dim3((unsigned)((F.ninc + 255) / 256)), dim3(256), 0, st, G, F, pose8, sw);
 }
-void launch_mf_spmv(const GraphDev& G, const MfDev& F, const ScaleDev& Sc, const CgDev& C, int k, double tol2, hipStream_t st) {
+void launch_mf_spmv(const GraphDev& G, const MfDev& F, const ScaleDev& Sc, const CgDev& C, int k, double tol2, hipStream_t st, int n_rz_partials) {
     const int g = mf_grid(F);
     // the partial-sum count consumed here is the one cg_init / cg_update produced (cg_grid); the one produced is mf_grid
-    hipLaunchKernelGGL(mf_spmv_kernel<true>, dim3(g), dim3(MF_BLOCK), 0, st, G, F, Sc, C, (const double*)nullptr, (double*)nullptr, k & 1, k == 0 ? 1 : 0, cg_grid(G), tol2);
+    hipLaunchKernelGGL(mf_spmv_kernel<true>, dim3(g), dim3(MF_BLOCK), 0, st, G, F, Sc, C, (const double*)nullptr, (double*)nullptr, k & 1, k == 0 ? 1 : 0,
+                       n_rz_partials > 0 ? n_rz_partials : cg_grid(G), tol2);
 }
 void launch_mf_apply(const GraphDev& G, const MfDev& F, const ScaleDev& Sc, const CgDev& C, const double* x, double* y, hipStream_t st) {
     hipLaunchKernelGGL(mf_spmv_kernel<false>, dim3(mf_grid(F)), dim3(MF_BLOCK), 0, st, G, F, Sc, C, x, y, 0, 1, 0, 0.0);
@@ -1142,10 +1144,12 @@ __global__ __launch_bounds__(256) void plus_kernel(GraphDev G, const double* __r
                 const double* di = dp + (size_t)i * 6;
                 quat_plus(q, di, qn);
                 tn[0] = t[0] + di[3]; tn[1] = t[1] + di[4]; tn[2] = t[2] + di[5];
+                double d2 = 0.0;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) s2 += (q[k] - qn[k]) * (q[k] - qn[k]);
+                for (int k = 0; k < 4; ++k) d2 += (q[k] - qn[k]) * (q[k] - qn[k]);
 #pragma unroll
-                for (int k = 0; k < 3; ++k) s2 += (t[k] - tn[k]) * (t[k] - tn[k]);
+                for (int k = 0; k < 3; ++k) d2 += (t[k] - tn[k]) * (t[k] - tn[k]);
+                s2 += G.own ? G.own[i] * d2 : d2;
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) qn[k] = q[k];
@@ -1192,7 +1196,8 @@ __global__ __launch_bounds__(256) void state_norms_kernel(GraphDev G, LinDev L, 
             const double2* g = reinterpret_cast<const double2*>(pose8 + (size_t)i * 8);
             const double2 a = g[0], b = g[1], c = g[2], d = g[3];
             const double q[4] = {a.x, a.y, b.x, b.y};
-            x2 += a.x * a.x + a.y * a.y + b.x * b.x + b.y * b.y + c.x * c.x + c.y * c.y + d.x * d.x;
+            const double n2 = a.x * a.x + a.y * a.y + b.x * b.x + b.y * b.y + c.x * c.x + c.y * c.y + d.x * d.x;
+            x2 += G.own ? G.own[i] * n2 : n2;
             const double* gi = L.g + (size_t)i * 6;
             const double ng[3] = {-gi[0], -gi[1], -gi[2]};
             double qn[4];
@@ -1334,6 +1339,60 @@ __global__ void __launch_bounds__(256) vio_initial_guess_kernel(int64_t u_begin,
 }
 void launch_vio_initial_guess(int64_t u_begin, int64_t count, const double* left, const int32_t* left_of_node, const double* vio, double* quat, double* t, hipStream_t st) {
     if (count > 0) hipLaunchKernelGGL(vio_initial_guess_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, u_begin, count, left, left_of_node, vio, quat, t);
+}
+
+// ---- multi-GPU: exchange of the keyframes shared between ranks ----
+// All ranks hold the same ordered list of shared keyframes (touched by >= 2 ranks); the exchange buffer has one row of K doubles per
+// list entry.  A rank packs the rows of the shared keyframes IT touches (the rest of the zero-initialised buffer stays 0), the
+// buffer is all-reduced, and the rank reads its rows back.
+__global__ void pack_rows_kernel(double* __restrict__ buf, int K, int off, const double* __restrict__ src, int k, int64_t n, const int32_t* __restrict__ loc,
+                                 const int32_t* __restrict__ pos) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * k) return;
+    const int64_t j = i / k; const int c = (int)(i - j * k);
+    buf[(size_t)pos[j] * K + off + c] = src[(size_t)loc[j] * k + c];
+}
+__global__ void unpack_rows_kernel(const double* __restrict__ buf, int K, int off, double* __restrict__ dst, int k, int64_t n, const int32_t* __restrict__ loc,
+                                   const int32_t* __restrict__ pos, const int32_t* __restrict__ stop) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * k || (stop && *stop)) return;   // a stopped PCG keeps its state bit for bit (it may be resumed with a tighter tolerance)
+    const int64_t j = i / k; const int c = (int)(i - j * k);
+    dst[(size_t)loc[j] * k + c] = buf[(size_t)pos[j] * K + off + c];
+}
+void launch_pack_rows(double* buf, int K, int off, const double* src, int k, int64_t n, const int32_t* loc, const int32_t* pos, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((n * k + 255) / 256)), dim3(256), 0, st, buf, K, off, src, k, n, loc, pos);
+}
+void launch_unpack_rows(const double* buf, int K, int off, double* dst, int k, int64_t n, const int32_t* loc, const int32_t* pos, const int32_t* stop, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(unpack_rows_kernel, dim3((unsigned)((n * k + 255) / 256)), dim3(256), 0, st, buf, K, off, dst, k, n, loc, pos, stop);
+}
+// PCG scalars across ranks: partial sums -> one scalar in scratch (skipped once the PCG has stopped), all-reduce of the scratch, then the
+// total is committed to slot 0 of the partial array the consumers re-reduce — again only while the PCG is live, so that a stopped PCG
+// keeps the sums of its last completed iteration.
+__global__ void cg_reduce_live_kernel(CgDev C, const double* __restrict__ partials, int n, double* __restrict__ out) {
+    __shared__ double red[4];
+    const bool stopped = C.flags[0] != 0;
+    double v = 0.0;
+    if (!stopped) for (int i = threadIdx.x; i < n; i += blockDim.x) v += partials[i];
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = stopped ? 0.0 : red[0] + red[1] + red[2] + red[3];
+}
+__global__ void cg_commit_live_kernel(CgDev C, const double* __restrict__ src, double* __restrict__ dst) {
+    if (threadIdx.x == 0 && C.flags[0] == 0) dst[0] = src[0];
+}
+void launch_cg_reduce_live(const CgDev& C, const double* partials, int n, double* out, hipStream_t st) { hipLaunchKernelGGL(cg_reduce_live_kernel, dim3(1), dim3(256), 0, st, C, partials, n, out); }
+void launch_cg_commit_live(const CgDev& C, const double* src, double* dst, hipStream_t st) { hipLaunchKernelGGL(cg_commit_live_kernel, dim3(1), dim3(64), 0, st, C, src, dst); }
+__global__ void scatter_owned_pose_kernel(const double* __restrict__ quat, const double* __restrict__ t, int64_t n, const int32_t* __restrict__ l2g,
+                                          const double* __restrict__ own, double* __restrict__ gquat, double* __restrict__ gt) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || own[i] == 0.0) return;
+    const int64_t g = l2g[i];
+    for (int k = 0; k < 4; ++k) gquat[g * 4 + k] = quat[i * 4 + k];
+    for (int k = 0; k < 3; ++k) gt[g * 3 + k] = t[i * 3 + k];
+}
+void launch_scatter_owned_pose(const double* quat, const double* t, int64_t n, const int32_t* l2g, const double* own, double* gquat, double* gt, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(scatter_owned_pose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, quat, t, n, l2g, own, gquat, gt);
 }
 
 }  // namespace pgo

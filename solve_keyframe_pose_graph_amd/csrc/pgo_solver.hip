@@ -78,8 +78,16 @@ struct pgo_problem {
     std::vector<int32_t> constant_nodes;
     bool graph_dirty = true, priors_dirty = true;
 
-    // device graph
-    int64_t N = 0, S = 0;
+    // device graph.  N = keyframes this handle works on: all of the caller's (one GPU), or — multi-GPU — only those touched by the
+    // rank's own residual blocks, renumbered densely in ascending global order ("rank-local subgraph"); N_global = the caller's count.
+    int64_t N = 0, S = 0, N_global = 0;
+    bool local_ids = false;
+    std::vector<int32_t> l2g, g2l;            // local -> global, global -> local (-1: not touched by this rank)
+    std::vector<uint8_t> h_touched_any;       // [N_global] some rank holds a residual block on the keyframe
+    std::vector<double> h_own;                // [N] 1.0 where this rank is the keyframe's owner (lowest rank touching it)
+    DBuf<int32_t> d_l2g, d_sh_loc, d_sh_pos;  // shared keyframes touched here: local id, position in the global shared list
+    DBuf<double> d_own, d_xbuf;               // owner weights; exchange buffer
+    int64_t n_sh_mine = 0, n_sh_global = 0;
     DBuf<int32_t> d_rc1, d_rc2, d_sc1, d_sc2, d_sidx, d_bsr_col;
     DBuf<double> d_rmeas, d_smeas;
     DBuf<int4> d_rwin, d_swin;
@@ -166,6 +174,7 @@ void meas_from_matrix(const double* T, double w, double* out8) {
 
 int upload_class(pgo_problem* p, const HostClass& H, bool is_sw, DBuf<int32_t>& dc1, DBuf<int32_t>& dc2, DBuf<int32_t>& dsw, DBuf<double>& dmeas,
                  DBuf<int4>& dwin, EdgeClassDev& out) {
+    const int32_t* g2l = p->local_ids ? p->g2l.data() : nullptr;
     const int64_t E = H.size();
     const int64_t Epad = (E + TILE - 1) / TILE * TILE;
     const int tiles = (int)(Epad / TILE);
@@ -174,7 +183,7 @@ int upload_class(pgo_problem* p, const HostClass& H, bool is_sw, DBuf<int32_t>& 
     std::vector<int4> win(tiles);
     for (int64_t e = 0; e < Epad; ++e) {
         const int64_t s = e < E ? e : E - 1;   // padding lanes replicate the last edge (computed, never stored or counted)
-        c1[e] = H.c1[s]; c2[e] = H.c2[s];
+        c1[e] = g2l ? g2l[H.c1[s]] : H.c1[s]; c2[e] = g2l ? g2l[H.c2[s]] : H.c2[s];
         if (is_sw) sw[e] = H.sw[s];
         for (int k = 0; k < 8; ++k) meas[(size_t)k * Epad + e] = H.meas[(size_t)s * 8 + k];
     }
@@ -216,20 +225,77 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S) {
         p->h_sw_used[si] = 1;
     }
     for (const PriorDev& pr : p->priors) if (pr.node < 0 || pr.node >= N) { p->err = "regulariser node out of range"; return PGO_ERR_INVALID_ARG; }
-    p->N = N; p->S = S;
+    p->S = S; p->N_global = N;
     GraphDev& G = p->G;
     G = GraphDev{};
+    // ---- multi-GPU: rank-local subgraph.  This rank works on the keyframes its own residual blocks touch, renumbered densely; keyframes
+    // touched by >= 2 ranks are "shared" (their rows are summed over ranks by exchange_rows), the lowest touching rank is the owner.
+    const int64_t Ng = N;
+    p->local_ids = p->world > 1 && (p->comm || p->custom_allreduce);
+    p->n_sh_mine = p->n_sh_global = 0;
+    if (p->local_ids) {
+        std::vector<uint8_t> touched((size_t)Ng, 0);
+        for (const HostClass* H : {&p->rel, &p->swe}) for (int64_t e = 0; e < H->size(); ++e) { touched[H->c1[e]] = 1; touched[H->c2[e]] = 1; }
+        for (const PriorDev& pr : p->priors) touched[pr.node] = 1;
+        bool any = false;
+        for (int64_t g = 0; g < Ng && !any; ++g) any = touched[g] != 0;
+        if (!any) touched[0] = 1;   // a rank without residual blocks still takes part in every collective: give it one (zero-contribution) keyframe
+        // two all-reduces of Ng doubles, once per graph build: how many ranks touch each keyframe, and the lowest of them
+        std::vector<double> buf((size_t)2 * Ng);
+        for (int64_t g = 0; g < Ng; ++g) { buf[g] = touched[g] ? 1.0 : 0.0; buf[Ng + g] = touched[g] ? (double)(p->world - p->rank) : 0.0; }
+        HIPCHK(p, p->d_tmp.ensure((size_t)2 * Ng));
+        HIPCHK(p, hipMemcpyAsync(p->d_tmp.p, buf.data(), (size_t)2 * Ng * sizeof(double), hipMemcpyHostToDevice, p->st));
+        int rc2;
+        if ((rc2 = allreduce(p, p->d_tmp.p, (size_t)Ng, 0)) != PGO_OK) return rc2;
+        if ((rc2 = allreduce(p, p->d_tmp.p + Ng, (size_t)Ng, 2 /*max*/)) != PGO_OK) return rc2;
+        HIPCHK(p, hipMemcpyAsync(buf.data(), p->d_tmp.p, (size_t)2 * Ng * sizeof(double), hipMemcpyDeviceToHost, p->st));
+        HIPCHK(p, hipStreamSynchronize(p->st));
+        p->l2g.clear(); p->g2l.assign((size_t)Ng, -1); p->h_own.clear(); p->h_touched_any.assign((size_t)Ng, 0);
+        std::vector<int32_t> sh_loc, sh_pos;
+        int64_t pos = 0;
+        for (int64_t g = 0; g < Ng; ++g) {
+            const int cnt = (int)(buf[g] + 0.5);
+            p->h_touched_any[g] = cnt > 0;
+            if (touched[g]) {
+                const int owner = p->world - (int)(buf[Ng + g] + 0.5);
+                p->g2l[g] = (int32_t)p->l2g.size();
+                if (cnt >= 2) { sh_loc.push_back((int32_t)p->l2g.size()); sh_pos.push_back((int32_t)pos); }
+                p->l2g.push_back((int32_t)g);
+                p->h_own.push_back(owner == p->rank ? 1.0 : 0.0);
+            }
+            if (cnt >= 2) ++pos;
+        }
+        p->n_sh_global = pos; p->n_sh_mine = (int64_t)sh_loc.size();
+        N = (int64_t)p->l2g.size();
+        HIPCHK(p, p->d_l2g.ensure(N)); HIPCHK(p, p->d_own.ensure(N)); HIPCHK(p, p->d_sh_loc.ensure(std::max<int64_t>(p->n_sh_mine, 1))); HIPCHK(p, p->d_sh_pos.ensure(std::max<int64_t>(p->n_sh_mine, 1)));
+        HIPCHK(p, hipMemcpyAsync(p->d_l2g.p, p->l2g.data(), N * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
+        HIPCHK(p, hipMemcpyAsync(p->d_own.p, p->h_own.data(), N * sizeof(double), hipMemcpyHostToDevice, p->st));
+        if (p->n_sh_mine) {
+            HIPCHK(p, hipMemcpyAsync(p->d_sh_loc.p, sh_loc.data(), p->n_sh_mine * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
+            HIPCHK(p, hipMemcpyAsync(p->d_sh_pos.p, sh_pos.data(), p->n_sh_mine * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
+        }
+        HIPCHK(p, hipStreamSynchronize(p->st));
+        G.own = p->d_own.p;
+    } else {
+        p->l2g.clear(); p->g2l.clear(); p->h_own.clear(); p->h_touched_any.clear();
+        G.own = nullptr;
+    }
+    p->N = N;
+    const int32_t* g2l = p->local_ids ? p->g2l.data() : nullptr;
+    auto L = [g2l](int32_t g) -> int32_t { return g2l ? g2l[g] : g; };
     G.N = N; G.S = S;
     int rc;
     if ((rc = upload_class(p, p->rel, false, p->d_rc1, p->d_rc2, p->d_sidx /*unused*/, p->d_rmeas, p->d_rwin, G.rel)) != PGO_OK) return rc;
     if ((rc = upload_class(p, p->swe, true, p->d_sc1, p->d_sc2, p->d_sidx, p->d_smeas, p->d_swin, G.sw)) != PGO_OK) return rc;
     const int64_t Er = G.rel.E, Es = G.sw.E, Eg = (int64_t)p->priors.size();
+    std::vector<PriorDev> pri = p->priors;
+    for (PriorDev& x : pri) x.node = L(x.node);
     // ---- node -> incident list (edges in slot order, then regularisers), BSR structure
     std::vector<int64_t> rowptr(N + 1, 0), bsr_rowptr(N + 1, 0);
-    for (int64_t e = 0; e < Er; ++e) { rowptr[p->rel.c1[e] + 1]++; rowptr[p->rel.c2[e] + 1]++; }
-    for (int64_t e = 0; e < Es; ++e) { rowptr[p->swe.c1[e] + 1]++; rowptr[p->swe.c2[e] + 1]++; }
+    for (int64_t e = 0; e < Er; ++e) { rowptr[L(p->rel.c1[e]) + 1]++; rowptr[L(p->rel.c2[e]) + 1]++; }
+    for (int64_t e = 0; e < Es; ++e) { rowptr[L(p->swe.c1[e]) + 1]++; rowptr[L(p->swe.c2[e]) + 1]++; }
     for (int64_t n = 0; n < N; ++n) bsr_rowptr[n + 1] = bsr_rowptr[n] + 1 + rowptr[n + 1];
-    for (int64_t k = 0; k < Eg; ++k) rowptr[p->priors[k].node + 1]++;
+    for (int64_t k = 0; k < Eg; ++k) rowptr[pri[k].node + 1]++;
     for (int64_t n = 0; n < N; ++n) rowptr[n + 1] += rowptr[n];
     const int64_t ninc = rowptr[N];
     p->nnzb = bsr_rowptr[N];
@@ -241,24 +307,14 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S) {
         inc[fill[a]++] = (slot << 1) | 0; bsr_col[bfill[a]++] = b;
         inc[fill[b]++] = (slot << 1) | 1; bsr_col[bfill[b]++] = a;
     };
-    for (int64_t e = 0; e < Er; ++e) add_edge(e, p->rel.c1[e], p->rel.c2[e]);
-    for (int64_t e = 0; e < Es; ++e) add_edge(G.rel.Epad + e, p->swe.c1[e], p->swe.c2[e]);
-    for (int64_t k = 0; k < Eg; ++k) inc[fill[p->priors[k].node]++] = ((G.rel.Epad + G.sw.Epad + k) << 1);
+    for (int64_t e = 0; e < Er; ++e) add_edge(e, L(p->rel.c1[e]), L(p->rel.c2[e]));
+    for (int64_t e = 0; e < Es; ++e) add_edge(G.rel.Epad + e, L(p->swe.c1[e]), L(p->swe.c2[e]));
+    for (int64_t k = 0; k < Eg; ++k) inc[fill[pri[k].node]++] = ((G.rel.Epad + G.sw.Epad + k) << 1);
+    // a keyframe is part of the program when a residual block touches it: on one GPU that is a non-empty incident list; in a rank-local
+    // subgraph every keyframe is touched by construction (by this rank or, for the stand-in keyframe of an idle rank, possibly by none)
     p->h_node_free.assign((size_t)N, 0);
-    for (int64_t n = 0; n < N; ++n) p->h_node_free[n] = rowptr[n + 1] > rowptr[n] ? 1 : 0;
-    if (p->world > 1 && (p->comm || p->custom_allreduce)) {
-        // edge sharding: a keyframe is part of the program when ANY rank holds a residual block on it -> union over ranks
-        std::vector<double> flags((size_t)N);
-        for (int64_t n = 0; n < N; ++n) flags[n] = p->h_node_free[n];
-        HIPCHK(p, p->d_tmp.ensure((size_t)N));
-        HIPCHK(p, hipMemcpyAsync(p->d_tmp.p, flags.data(), N * sizeof(double), hipMemcpyHostToDevice, p->st));
-        int rc2 = allreduce(p, p->d_tmp.p, (size_t)N, 2 /*ncclMax*/);
-        if (rc2 != PGO_OK) return rc2;
-        HIPCHK(p, hipMemcpyAsync(flags.data(), p->d_tmp.p, N * sizeof(double), hipMemcpyDeviceToHost, p->st));
-        HIPCHK(p, hipStreamSynchronize(p->st));
-        for (int64_t n = 0; n < N; ++n) p->h_node_free[n] = flags[n] > 0.5 ? 1 : 0;
-    }
-    for (int32_t c : p->constant_nodes) if (c >= 0 && c < N) p->h_node_free[c] = 0;
+    for (int64_t n = 0; n < N; ++n) p->h_node_free[n] = (rowptr[n + 1] > rowptr[n] || (p->local_ids && p->h_touched_any[p->l2g[n]])) ? 1 : 0;
+    for (int32_t c : p->constant_nodes) if (c >= 0 && c < Ng && L(c) >= 0) p->h_node_free[L(c)] = 0;
 
     HIPCHK(p, p->d_inc_rowptr.ensure(N + 1)); HIPCHK(p, p->d_bsr_rowptr.ensure(N + 1)); HIPCHK(p, p->d_inc.ensure(std::max<int64_t>(ninc, 1)));
     HIPCHK(p, p->d_bsr_col.ensure(std::max<int64_t>(p->nnzb, 1))); HIPCHK(p, p->d_node_free.ensure(std::max<int64_t>(N, 1)));
@@ -268,7 +324,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S) {
     if (ninc) HIPCHK(p, hipMemcpyAsync(p->d_inc.p, inc.data(), ninc * sizeof(int64_t), hipMemcpyHostToDevice, p->st));
     if (p->nnzb) HIPCHK(p, hipMemcpyAsync(p->d_bsr_col.p, bsr_col.data(), p->nnzb * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
     if (N) HIPCHK(p, hipMemcpyAsync(p->d_node_free.p, p->h_node_free.data(), N, hipMemcpyHostToDevice, p->st));
-    if (Eg) HIPCHK(p, hipMemcpyAsync(p->d_prior.p, p->priors.data(), Eg * sizeof(PriorDev), hipMemcpyHostToDevice, p->st));
+    if (Eg) HIPCHK(p, hipMemcpyAsync(p->d_prior.p, pri.data(), Eg * sizeof(PriorDev), hipMemcpyHostToDevice, p->st));
     HIPCHK(p, hipStreamSynchronize(p->st));
 
     // ---- matrix-free operator: edge-sides in keyframe-major order, packed into workgroup tiles of whole keyframes
@@ -327,7 +383,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S) {
                         const bool is_sw = slot >= G.rel.Epad;
                         if ((int)is_sw != pass) continue;
                         const int64_t e = is_sw ? slot - G.rel.Epad : slot;
-                        const int32_t a = is_sw ? p->swe.c1[e] : p->rel.c1[e], b = is_sw ? p->swe.c2[e] : p->rel.c2[e];
+                        const int32_t a = L(is_sw ? p->swe.c1[e] : p->rel.c1[e]), b = L(is_sw ? p->swe.c2[e] : p->rel.c2[e]);
                         einc.push_back((is_sw ? 0x80000000u : 0u) | (uint32_t)(e << 1) | (uint32_t)side);
                         eoth.push_back(side == 0 ? b : a);
                         eown.push_back((uint8_t)(n - n0));
@@ -408,6 +464,61 @@ int allreduce(pgo_problem* p, double* buf, size_t n, int op /*0 sum, 2 max*/) {
     return PGO_OK;
 }
 
+// Multi-GPU exchange: sums, over the ranks sharing them, the rows of one or two keyframe-indexed device arrays (k1 + k2 doubles per
+// keyframe) and `n_extra` scalars (summed over ALL ranks, in place at `extra`) with ONE all-reduce of n_shared*(k1+k2) + n_extra doubles.
+// Keyframes touched by a single rank never travel.
+int exchange_rows(pgo_problem* p, double* a1, int k1, double* a2, int k2, double* extra, int n_extra, const int32_t* stop = nullptr) {
+    if (!p->local_ids) return PGO_OK;
+    const int K = k1 + k2;
+    const size_t n = (size_t)p->n_sh_global * K;
+    if (n + n_extra == 0) return PGO_OK;
+    HIPCHK(p, p->d_xbuf.ensure(n + n_extra));
+    if (n) HIPCHK(p, hipMemsetAsync(p->d_xbuf.p, 0, n * sizeof(double), p->st));
+    launch_pack_rows(p->d_xbuf.p, K, 0, a1, k1, p->n_sh_mine, p->d_sh_loc.p, p->d_sh_pos.p, p->st);
+    if (a2) launch_pack_rows(p->d_xbuf.p, K, k1, a2, k2, p->n_sh_mine, p->d_sh_loc.p, p->d_sh_pos.p, p->st);
+    if (n_extra) HIPCHK(p, hipMemcpyAsync(p->d_xbuf.p + n, extra, n_extra * sizeof(double), hipMemcpyDeviceToDevice, p->st));
+    int rc;
+    if ((rc = allreduce(p, p->d_xbuf.p, n + n_extra, 0)) != PGO_OK) return rc;
+    launch_unpack_rows(p->d_xbuf.p, K, 0, a1, k1, p->n_sh_mine, p->d_sh_loc.p, p->d_sh_pos.p, stop, p->st);
+    if (a2) launch_unpack_rows(p->d_xbuf.p, K, k1, a2, k2, p->n_sh_mine, p->d_sh_loc.p, p->d_sh_pos.p, stop, p->st);
+    if (n_extra) HIPCHK(p, hipMemcpyAsync(extra, p->d_xbuf.p + n, n_extra * sizeof(double), hipMemcpyDeviceToDevice, p->st));
+    return PGO_OK;
+}
+
+// keyframe-indexed device array of this handle (k doubles per keyframe) -> the caller's array over ALL keyframes, complete on every rank
+// (multi-GPU: each keyframe is contributed by its owner; keyframes no rank touches come back as zeros)
+int nodes_to_global(pgo_problem* p, const double* dev, int k, double* host_global) {
+    if (!p->local_ids) {
+        HIPCHK(p, hipMemcpyAsync(host_global, dev, (size_t)p->N * k * sizeof(double), hipMemcpyDeviceToHost, p->st));
+        HIPCHK(p, hipStreamSynchronize(p->st));
+        return PGO_OK;
+    }
+    std::vector<double> loc((size_t)p->N * k), glob((size_t)p->N_global * k, 0.0);
+    HIPCHK(p, hipMemcpyAsync(loc.data(), dev, loc.size() * sizeof(double), hipMemcpyDeviceToHost, p->st));
+    HIPCHK(p, hipStreamSynchronize(p->st));
+    for (int64_t l = 0; l < p->N; ++l) if (p->h_own[l] != 0.0) std::copy(loc.begin() + l * k, loc.begin() + (l + 1) * k, glob.begin() + (size_t)p->l2g[l] * k);
+    HIPCHK(p, p->d_tmp.ensure(glob.size()));
+    HIPCHK(p, hipMemcpyAsync(p->d_tmp.p, glob.data(), glob.size() * sizeof(double), hipMemcpyHostToDevice, p->st));
+    int rc;
+    if ((rc = allreduce(p, p->d_tmp.p, glob.size(), 0)) != PGO_OK) return rc;
+    HIPCHK(p, hipMemcpyAsync(host_global, p->d_tmp.p, glob.size() * sizeof(double), hipMemcpyDeviceToHost, p->st));
+    HIPCHK(p, hipStreamSynchronize(p->st));
+    return PGO_OK;
+}
+// the caller's array over all keyframes -> this handle's keyframes on the device
+int nodes_from_global(pgo_problem* p, const double* host_global, int k, double* dev) {
+    if (!p->local_ids) {
+        HIPCHK(p, hipMemcpyAsync(dev, host_global, (size_t)p->N * k * sizeof(double), hipMemcpyHostToDevice, p->st));
+        HIPCHK(p, hipStreamSynchronize(p->st));
+        return PGO_OK;
+    }
+    std::vector<double> loc((size_t)p->N * k);
+    for (int64_t l = 0; l < p->N; ++l) std::copy(host_global + (size_t)p->l2g[l] * k, host_global + (size_t)(p->l2g[l] + 1) * k, loc.begin() + l * k);
+    HIPCHK(p, hipMemcpyAsync(dev, loc.data(), loc.size() * sizeof(double), hipMemcpyHostToDevice, p->st));
+    HIPCHK(p, hipStreamSynchronize(p->st));
+    return PGO_OK;
+}
+
 double* part(pgo_problem* p, int k) { return p->d_part.p + (size_t)k * p->n_part; }
 
 // K1 (+ regularisers) at state `which`; cost lands in d_scal[S_COST], d_scal[S_PRIOR_COST]
@@ -422,9 +533,11 @@ int run_k1(pgo_problem* p, int which, bool want_j) {
 
 int read_scalars(pgo_problem* p, double* h) {
     // edge-local sums [S_COST..S_SW_XNORM2] are summed over ranks; the projected-gradient norm takes the max
+    // (max), the keyframe sums S_STEP2 / S_XNORM2 are owner-weighted partial sums on every rank
     int rc;
     if ((rc = allreduce(p, p->d_scal.p, 5, 0)) != PGO_OK) return rc;
     if ((rc = allreduce(p, p->d_scal.p + S_GMAX, 1, 2)) != PGO_OK) return rc;
+    if ((rc = allreduce(p, p->d_scal.p + S_STEP2, 2, 0)) != PGO_OK) return rc;
     HIPCHK(p, hipMemcpyAsync(h, p->d_scal.p, S_N * sizeof(double), hipMemcpyDeviceToHost, p->st));
     HIPCHK(p, hipStreamSynchronize(p->st));
     return PGO_OK;
@@ -436,7 +549,7 @@ int linearize(pgo_problem* p, double* cost_out) {
     if ((rc = run_k1(p, p->cur, true)) != PGO_OK) return rc;
     launch_k2(p->G, p->L, !p->built_mf, p->st);
     if (p->built_mf) launch_mf_compact(p->G, p->F, p->d_pose[p->cur].p, p->d_swv[p->cur].p, p->st);
-    if ((rc = allreduce(p, p->d_Hd_g.p, (size_t)p->N * 42, 0)) != PGO_OK) return rc;
+    if ((rc = exchange_rows(p, p->L.Hd, 36, p->L.g, 6, nullptr, 0)) != PGO_OK) return rc;   // diagonal blocks + gradient of shared keyframes
     if (!p->scale_ready) { launch_scale_init(p->G, p->L, p->Sc, p->opt.jacobi_scaling, p->st); p->scale_ready = true; }
     int np = 0;
     launch_state_norms(p->G, p->L, p->d_pose[p->cur].p, p->d_swv[p->cur].p, part(p, 1), part(p, 2), part(p, 3), &np, p->st);
@@ -444,6 +557,7 @@ int linearize(pgo_problem* p, double* cost_out) {
     launch_reduce(part(p, 2), np, 0, p->d_scal.p + S_SW_XNORM2, p->st);
     launch_reduce(part(p, 3), np, 1, p->d_scal.p + S_GMAX, p->st);
     HIPCHK(p, hipMemsetAsync(p->d_scal.p + S_MODEL, 0, 2 * sizeof(double), p->st));
+    HIPCHK(p, hipMemsetAsync(p->d_scal.p + S_STEP2, 0, sizeof(double), p->st));   // not produced here; keeps the summed slot finite
     double h[S_N];
     if ((rc = read_scalars(p, h)) != PGO_OK) return rc;
     *cost_out = 0.5 * (h[S_COST] + h[S_PRIOR_COST]);
@@ -466,9 +580,25 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
         // after a rejected step the system keeps H and only the damping grows: start from the previous solution (q = A x first)
         if (p->built_mf) launch_mf_apply(p->G, p->F, p->Sc, p->C, p->C.x, p->C.q, p->st);
         else launch_apply_operator(p->G, p->C, p->C.x, p->C.q, p->st);
-        if ((rc0 = allreduce(p, p->C.q, (size_t)p->N * 6, 0)) != PGO_OK) return rc0;
+        if ((rc0 = exchange_rows(p, p->C.q, 6, nullptr, 0, nullptr, 0)) != PGO_OK) return rc0;
     }
-    if (resume_from < 0) launch_cg_init(p->G, p->C, warm ? 1 : 0, tol2, p->st);
+    // Multi-GPU: every dot product is an owner-weighted (r.z) or rank-local (p.A_r p) partial sum; it is reduced over the workgroups into
+    // slot 0 of its partial array, summed over ranks, and the consumers re-reduce ONE partial.
+    const bool multi = p->local_ids;
+    const int n_rz = multi ? 1 : 0;
+    if (resume_from < 0) {
+        if (!multi) launch_cg_init(p->G, p->C, warm ? 1 : 0, tol2, p->st);
+        else {
+            const int g = launch_cg_init_vectors(p->G, p->C, warm ? 1 : 0, p->st);
+            double* two = p->C.scal + 4;                      // scratch behind the four PCG scalars
+            launch_reduce(p->C.part_rz, g, 0, two, p->st);
+            launch_reduce(p->C.part_pq, g, 0, two + 1, p->st);
+            if ((rc0 = allreduce(p, two, 2, 0)) != PGO_OK) return rc0;
+            HIPCHK(p, hipMemcpyAsync(p->C.part_rz, two, sizeof(double), hipMemcpyDeviceToDevice, p->st));
+            HIPCHK(p, hipMemcpyAsync(p->C.part_pq, two + 1, sizeof(double), hipMemcpyDeviceToDevice, p->st));
+            launch_cg_init_scalars(p->C, 1, tol2, p->st);
+        }
+    }
     int k = resume_from >= 0 ? resume_from : 0;
     int32_t hflags[3] = {0, 0, 0};
     double hscal[3] = {0, 0, 0};
@@ -476,15 +606,26 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
     int rc;
     auto one_iteration = [&](int kk) -> int {
         int n_pq = cg_grid_size(p->G);
-        if (p->built_mf) { launch_mf_spmv(p->G, p->F, p->Sc, p->C, kk, tol2, p->st); n_pq = mf_grid_size(p->F); }
-        else launch_cg_spmv(p->G, p->C, kk, tol2, p->st);
-        if (p->world > 1) {
-            int r2 = allreduce(p, p->C.q, (size_t)p->N * 6, 0);   // the one exchange per CG matvec
+        if (p->built_mf) { launch_mf_spmv(p->G, p->F, p->Sc, p->C, kk, tol2, p->st, n_rz); n_pq = mf_grid_size(p->F); }
+        else launch_cg_spmv(p->G, p->C, kk, tol2, p->st, n_rz);
+        if (multi) {
+            // the ONE exchange per CG matvec: q = sum over ranks of A_r p on the shared keyframes, with p.Ap = sum_r p.(A_r p) riding along
+            double* tmp = p->C.scal + 6;
+            launch_cg_reduce_live(p->C, p->C.part_pq, n_pq, tmp, p->st);
+            int r2 = exchange_rows(p, p->C.q, 6, nullptr, 0, tmp, 1, p->C.flags);
             if (r2 != PGO_OK) return r2;
-            launch_cg_pq(p->G, p->C, kk, p->st);
-            n_pq = cg_grid_size(p->G);
+            launch_cg_commit_live(p->C, tmp, p->C.part_pq, p->st);
+            n_pq = 1;
         }
-        launch_cg_update(p->G, p->C, kk, n_pq, p->st);
+        launch_cg_update(p->G, p->C, kk, n_pq, p->st, n_rz);
+        if (multi) {   // r.z of the new residual: owner-weighted partials -> one scalar over ranks
+            double* rz = p->C.part_rz + (size_t)((kk & 1) ^ 1) * MAX_PARTIALS;
+            double* tmp = p->C.scal + 7;
+            launch_cg_reduce_live(p->C, rz, cg_grid_size(p->G), tmp, p->st);
+            int r2 = allreduce(p, tmp, 1, 0);
+            if (r2 != PGO_OK) return r2;
+            launch_cg_commit_live(p->C, tmp, rz, p->st);
+        }
         return PGO_OK;
     };
     // hipGraph: capture one chunk (iterations 2 .. 2+every-1: no `first` kernel, even start) once per graph build and replay it
@@ -545,8 +686,8 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
     }
     if (!hflags[0]) {   // iteration cap reached: one more convergence test so that scal[1] holds the last r.z (x is already final)
         launch_cg_set_tolerance(p->C, 1e300, p->st);
-        if (p->built_mf) launch_mf_spmv(p->G, p->F, p->Sc, p->C, k, 1e300, p->st);
-        else launch_cg_spmv(p->G, p->C, k, 1e300, p->st);
+        if (p->built_mf) launch_mf_spmv(p->G, p->F, p->Sc, p->C, k, 1e300, p->st, n_rz);
+        else launch_cg_spmv(p->G, p->C, k, 1e300, p->st, n_rz);
         HIPCHK(p, hipMemcpyAsync(hflags, p->C.flags, sizeof(hflags), hipMemcpyDeviceToHost, p->st));
         HIPCHK(p, hipMemcpyAsync(hscal, p->C.scal, sizeof(hscal), hipMemcpyDeviceToHost, p->st));
         HIPCHK(p, hipStreamSynchronize(p->st));
@@ -560,8 +701,8 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
 int build_system(pgo_problem* p, bool* ok) {
     int rc;
     HIPCHK(p, hipMemsetAsync(p->d_flags.p + 4, 0, sizeof(int32_t), p->st));
-    launch_build_rows(p->G, p->L, p->Sc, p->C, p->radius, p->rank == 0 ? 1 : 0, p->built_mf ? p->d_lam.p : nullptr, p->st);
-    if ((rc = allreduce(p, p->d_Dtot_b.p, (size_t)p->N * 42, 0)) != PGO_OK) return rc;
+    launch_build_rows(p->G, p->L, p->Sc, p->C, p->radius, 1 /*one GPU: this handle adds Hd, g and the damping; multi-GPU: the keyframe's owner (G.own)*/, p->built_mf ? p->d_lam.p : nullptr, p->st);
+    if ((rc = exchange_rows(p, p->C.Dtot, 36, p->C.b, 6, nullptr, 0)) != PGO_OK) return rc;   // reduced diagonal + rhs of shared keyframes
     launch_invert_rows(p->G, p->C, p->d_flags.p + 4, p->st);
     int32_t fail = 0;
     HIPCHK(p, hipMemcpyAsync(&fail, p->d_flags.p + 4, sizeof(int32_t), hipMemcpyDeviceToHost, p->st));
@@ -588,13 +729,14 @@ int solve_begin(pgo_problem* p, const double* quat, const double* t, const doubl
     int rc;
     if ((rc = set_device(p)) != PGO_OK) return rc;
     p->t_begin = now_s();
-    if (p->graph_dirty || p->priors_dirty || N != p->N || S != p->S) if ((rc = build_graph(p, N, S)) != PGO_OK) return rc;
-    // upload in the reference layout, repack on the device
+    if (p->graph_dirty || p->priors_dirty || N != p->N_global || S != p->S) if ((rc = build_graph(p, N, S)) != PGO_OK) return rc;
+    // upload in the reference layout (multi-GPU: only this rank's keyframes), repack on the device
     double* io = p->d_io.p;
-    HIPCHK(p, hipMemcpyAsync(io, quat, (size_t)N * 4 * sizeof(double), hipMemcpyHostToDevice, p->st));
-    HIPCHK(p, hipMemcpyAsync(io + (size_t)N * 4, t, (size_t)N * 3 * sizeof(double), hipMemcpyHostToDevice, p->st));
+    const int64_t Nl = p->N;
+    if ((rc = nodes_from_global(p, quat, 4, io)) != PGO_OK) return rc;
+    if ((rc = nodes_from_global(p, t, 3, io + (size_t)Nl * 4)) != PGO_OK) return rc;
     p->cur = 0;
-    launch_pack_pose(io, io + (size_t)N * 4, p->d_pose[0].p, N, p->st);
+    launch_pack_pose(io, io + (size_t)Nl * 4, p->d_pose[0].p, Nl, p->st);
     if (S > 0) {
         HIPCHK(p, hipMemcpyAsync(p->d_swv[0].p, sw, (size_t)S * sizeof(double), hipMemcpyHostToDevice, p->st));
         HIPCHK(p, hipMemcpyAsync(p->d_swv[1].p, p->d_swv[0].p, (size_t)S * sizeof(double), hipMemcpyDeviceToDevice, p->st));
@@ -649,6 +791,7 @@ int lm_step(pgo_problem* p, int ignore_termination, int* done) {
         launch_reduce(part(p, 2), np2, 0, p->d_scal.p + S_SW_STEP2, p->st);
         if ((r2 = run_k1(p, nxt, false)) != PGO_OK) return r2;
         HIPCHK(p, hipMemsetAsync(p->d_scal.p + S_SW_XNORM2, 0, 2 * sizeof(double), p->st));   // SW_XNORM2, GMAX unused here
+        HIPCHK(p, hipMemsetAsync(p->d_scal.p + S_XNORM2, 0, sizeof(double), p->st));
         return read_scalars(p, h);
     };
     bool evaluated = false;
@@ -745,9 +888,24 @@ int solve_end(pgo_problem* p, double* quat, double* t, double* sw, pgo_summary* 
         // single write-back at the very end (reference relies on this: src/PoseGraphSLAM.cpp:1894-1903)
         double* io = p->d_io.p;
         launch_unpack_pose(p->d_pose[p->cur].p, io, io + (size_t)p->N * 4, p->N, p->st);
-        std::vector<double> hq((size_t)p->N * 4), ht((size_t)p->N * 3), hs((size_t)p->S);
-        HIPCHK(p, hipMemcpyAsync(hq.data(), io, hq.size() * sizeof(double), hipMemcpyDeviceToHost, p->st));
-        HIPCHK(p, hipMemcpyAsync(ht.data(), io + (size_t)p->N * 4, ht.size() * sizeof(double), hipMemcpyDeviceToHost, p->st));
+        const int64_t Ng = p->N_global;
+        std::vector<double> hq((size_t)Ng * 4), ht((size_t)Ng * 3), hs((size_t)p->S);
+        if (!p->local_ids) {
+            HIPCHK(p, hipMemcpyAsync(hq.data(), io, hq.size() * sizeof(double), hipMemcpyDeviceToHost, p->st));
+            HIPCHK(p, hipMemcpyAsync(ht.data(), io + (size_t)p->N * 4, ht.size() * sizeof(double), hipMemcpyDeviceToHost, p->st));
+        } else {
+            // every keyframe is written by its owner into a zeroed array over all keyframes; one all-reduce replicates the result
+            HIPCHK(p, p->d_tmp.ensure((size_t)Ng * 7));
+            HIPCHK(p, hipMemsetAsync(p->d_tmp.p, 0, (size_t)Ng * 7 * sizeof(double), p->st));
+            launch_scatter_owned_pose(io, io + (size_t)p->N * 4, p->N, p->d_l2g.p, p->d_own.p, p->d_tmp.p, p->d_tmp.p + (size_t)Ng * 4, p->st);
+            if ((rc = allreduce(p, p->d_tmp.p, (size_t)Ng * 7, 0)) != PGO_OK) return rc;
+            HIPCHK(p, hipMemcpyAsync(hq.data(), p->d_tmp.p, hq.size() * sizeof(double), hipMemcpyDeviceToHost, p->st));
+            HIPCHK(p, hipMemcpyAsync(ht.data(), p->d_tmp.p + (size_t)Ng * 4, ht.size() * sizeof(double), hipMemcpyDeviceToHost, p->st));
+            HIPCHK(p, hipStreamSynchronize(p->st));
+            for (int64_t g = 0; g < Ng; ++g) if (!p->h_touched_any[g]) {   // keyframes without any residual block keep the caller's values
+                std::copy(quat + g * 4, quat + g * 4 + 4, hq.begin() + g * 4); std::copy(t + g * 3, t + g * 3 + 3, ht.begin() + g * 3);
+            }
+        }
         if (p->S > 0) {
             if (p->world > 1) {
                 // every switch is owned by the rank holding its edge: sum (owned ? value : 0) and the owner count
@@ -860,6 +1018,7 @@ int pgo_destroy(pgo_problem* p) {
     p->d_val.release(); p->d_Lf.release(); p->d_Dtot_b.release(); p->d_cgvec.release(); p->d_part.release(); p->d_cgpart.release();
     p->d_flags.release(); p->d_scal.release(); p->d_pose[0].release(); p->d_pose[1].release(); p->d_swv[0].release(); p->d_swv[1].release();
     p->d_delta_s.release(); p->d_io.release(); p->d_tmp.release(); p->d_vio.release();
+    p->d_l2g.release(); p->d_sh_loc.release(); p->d_sh_pos.release(); p->d_own.release(); p->d_xbuf.release();
     p->d_einc.release(); p->d_einc_ownl.release(); p->d_node_rng.release(); p->d_tile_inc0.release(); p->d_einc_other.release();
     p->d_tile_node0.release(); p->d_tile_sw0.release(); p->d_node_prior.release(); p->d_rec.release(); p->d_lam.release();
     (void)hipStreamDestroy(p->st);
@@ -1052,12 +1211,17 @@ int pgo_evaluate(pgo_problem* p, const double* q, const double* t, const double*
     }
     if (gradient) {
         std::vector<double> gs((size_t)std::max<int64_t>(Es, 1));
-        HIPCHK(p, hipMemcpyAsync(gradient, p->L.g, (size_t)N * 6 * sizeof(double), hipMemcpyDeviceToHost, p->st));
+        // constant keyframes have no gradient entry; zero them on the device copy before it is spread over all keyframes
+        std::vector<double> gl((size_t)p->N * 6);
+        HIPCHK(p, hipMemcpyAsync(gl.data(), p->L.g, gl.size() * sizeof(double), hipMemcpyDeviceToHost, p->st));
         if (Es) HIPCHK(p, hipMemcpyAsync(gs.data(), p->L.gs, Es * sizeof(double), hipMemcpyDeviceToHost, p->st));
         HIPCHK(p, hipStreamSynchronize(p->st));
+        for (int64_t n = 0; n < p->N; ++n) if (!p->h_node_free[n]) for (int c = 0; c < 6; ++c) gl[6 * n + c] = 0.0;
+        HIPCHK(p, p->d_io.ensure(gl.size()));
+        HIPCHK(p, hipMemcpyAsync(p->d_io.p, gl.data(), gl.size() * sizeof(double), hipMemcpyHostToDevice, p->st));
+        if ((rc = nodes_to_global(p, p->d_io.p, 6, gradient)) != PGO_OK) return rc;
         for (int64_t i = 0; i < S; ++i) gradient[6 * N + i] = 0.0;
-        for (int64_t e = 0; e < Es; ++e) gradient[6 * N + p->swe.sw[e]] = gs[e];
-        for (int64_t n = 0; n < N; ++n) if (!p->h_node_free[n]) for (int c = 0; c < 6; ++c) gradient[6 * n + c] = 0.0;
+        for (int64_t e = 0; e < Es; ++e) gradient[6 * N + p->swe.sw[e]] = gs[e];   // multi-GPU: each rank reports the switches of its own edges
     }
     p->sum = keep;
     return PGO_OK;
@@ -1086,9 +1250,9 @@ int pgo_get_normal_blocks(pgo_problem* p, double* diag, double* grad, double* of
     if (p->graph_dirty) { p->err = "no linearisation available"; return PGO_ERR_STATE; }
     int rc;
     if ((rc = set_device(p)) != PGO_OK) return rc;
-    const int64_t N = p->N, Er = p->G.rel.E, Es = p->G.sw.E;
-    if (diag) HIPCHK(p, hipMemcpyAsync(diag, p->L.Hd, N * 36 * sizeof(double), hipMemcpyDeviceToHost, p->st));
-    if (grad) HIPCHK(p, hipMemcpyAsync(grad, p->L.g, N * 6 * sizeof(double), hipMemcpyDeviceToHost, p->st));
+    const int64_t Er = p->G.rel.E, Es = p->G.sw.E;
+    if (diag && (rc = nodes_to_global(p, p->L.Hd, 36, diag)) != PGO_OK) return rc;
+    if (grad && (rc = nodes_to_global(p, p->L.g, 6, grad)) != PGO_OK) return rc;
     if (offdiag && p->built_mf) {   // the matrix-free solver never forms J1^T J2: compute it for the parity hook only
         HIPCHK(p, p->d_Hoff.ensure((size_t)(p->G.rel.Epad + p->G.sw.Epad) * 36));
         p->L.Hoff = p->d_Hoff.p;
@@ -1114,14 +1278,14 @@ int pgo_apply_normal_operator(pgo_problem* p, const double* x, double* y) {
     if (!p->reuse_diagonal) launch_lm_diag(p->G, p->L, p->Sc, o.min_lm_diagonal, o.max_lm_diagonal, p->st);
     bool ok = true;
     if ((rc = build_system(p, &ok)) != PGO_OK) return rc;
-    HIPCHK(p, p->d_tmp.ensure((size_t)p->N * 12));
-    HIPCHK(p, hipMemcpyAsync(p->d_tmp.p, x, (size_t)p->N * 6 * sizeof(double), hipMemcpyHostToDevice, p->st));
-    if (p->built_mf) launch_mf_apply(p->G, p->F, p->Sc, p->C, p->d_tmp.p, p->d_tmp.p + (size_t)p->N * 6, p->st);
-    else launch_apply_operator(p->G, p->C, p->d_tmp.p, p->d_tmp.p + (size_t)p->N * 6, p->st);
-    if ((rc = allreduce(p, p->d_tmp.p + (size_t)p->N * 6, (size_t)p->N * 6, 0)) != PGO_OK) return rc;
-    HIPCHK(p, hipMemcpyAsync(y, p->d_tmp.p + (size_t)p->N * 6, (size_t)p->N * 6 * sizeof(double), hipMemcpyDeviceToHost, p->st));
-    HIPCHK(p, hipStreamSynchronize(p->st));
-    return PGO_OK;
+    // x and y are arrays over ALL keyframes (multi-GPU: this rank applies its part to its keyframes, shared rows are summed)
+    HIPCHK(p, p->d_io.ensure((size_t)p->N * 12));
+    double* xin = p->d_io.p; double* yout = p->d_io.p + (size_t)p->N * 6;
+    if ((rc = nodes_from_global(p, x, 6, xin)) != PGO_OK) return rc;
+    if (p->built_mf) launch_mf_apply(p->G, p->F, p->Sc, p->C, xin, yout, p->st);
+    else launch_apply_operator(p->G, p->C, xin, yout, p->st);
+    if ((rc = exchange_rows(p, yout, 6, nullptr, 0, nullptr, 0)) != PGO_OK) return rc;
+    return nodes_to_global(p, yout, 6, y);
 }
 
 // ---- multi-GPU ----
