@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--collective", choices=["rccl", "gloo"], default="rccl",
                     help="rccl: libpgo's own RCCL communicator over xGMI (default).  gloo: torch.distributed gloo through pgo_comm_init_custom "
                          "(host staging; lets several ranks share one GPU to validate the multi-rank path on a 1-GPU box)")
+    ap.add_argument("--partition", choices=["spatial", "chain", "contiguous"], default="spatial", help="how edges are dealt out to the ranks (solve_keyframe_pose_graph_amd/sharding.py)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -111,15 +112,20 @@ def main():
     from solve_keyframe_pose_graph_amd import capi, graphgen
     capi.load()   # raises if libpgo.so is missing: no CPU fallback
 
-    # ---- workload: N x C3, generated identically on every rank (deterministic), edges sharded contiguously
+    # ---- workload: N x C3, generated identically on every rank (deterministic); edges dealt out by the `--partition` policy
     scale = args.gpus
     n_poses = args.poses_per_gpu * scale
     n_loops = int(round(C3_LOOPS * (args.poses_per_gpu / C3_POSES))) * scale if scale > 1 or args.poses_per_gpu != C3_POSES else C3_LOOPS
     g = graphgen.generate(n_poses, n_loops, odom_f_max=2, seed=3)
     n_edges = g.n_odom + g.n_loops
 
-    from solve_keyframe_pose_graph_amd.sharding import edge_slice
-    shard = edge_slice(rank, world)
+    from solve_keyframe_pose_graph_amd import sharding
+    shard, shard_stats = None, None
+    if world > 1:
+        parts = sharding.partition(g, world, args.partition)
+        shard = parts[rank]
+        if rank == 0:
+            shard_stats = sharding.partition_stats(g, parts)
 
     opt = {}
     if args.cg_tol is not None:
@@ -206,7 +212,9 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "C3 x %d: synthetic 3D Manhattan graph, %d poses / %d edges (%d odometry f=1,2 + %d switchable loop closures, 10%% outliers) + %d regulariser(s)"
                                    % (scale, g.n_poses, n_edges, g.n_odom, g.n_loops, len(g.reg_node)),
-                       "poses": g.n_poses, "edges": n_edges, "sharding": ("edges, contiguous per rank; 1 %s all-reduce per CG matvec" % args.collective) if world > 1 else "single GPU",
+                       "poses": g.n_poses, "edges": n_edges, "sharding": ("edges by the '%s' policy (sharding.py): %d..%d edges and %d..%d keyframes per rank, %d of %d keyframes shared between ranks; one %s all-reduce of 6 x shared + 1 doubles per CG matvec, one scalar per CG iteration"
+                                                                       % (args.partition, min(shard_stats["edges_per_rank"]), max(shard_stats["edges_per_rank"]), min(shard_stats["keyframes_per_rank"]), max(shard_stats["keyframes_per_rank"]),
+                                                                          shard_stats["shared_keyframes"], g.n_poses, args.collective)) if world > 1 else "single GPU",
                        "linear_solver": "PCG, 6x6 block-Jacobi, Schur-reduced pose system, %s matvec" % ("matrix-free" if P.options.linear_solver == 1 else "block-CSR"), "cg_rel_tolerance": P.options.cg_rel_tolerance,
                        "cg_max_iterations": P.options.cg_max_iterations},
             "lm_iters_per_s_raw": ips,

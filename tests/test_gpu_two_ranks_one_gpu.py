@@ -1,8 +1,10 @@
-"""GPU: the multi-GPU LM logic with TWO ranks on ONE MI355X.  Each rank is a libpgo handle in its own thread owning a contiguous
-slice of the edges (sharding.edge_slice); the collective is supplied through pgo_comm_init_custom by an in-process harness that
-sums / maxes the two ranks' device buffers.  Everything the 8-GPU run does except RCCL itself is exercised: keyframe-participation
-union, all-reduced diagonal blocks + gradient, the lead rank owning damping / regularisers, the all-reduce per CG matvec, scalar
-reductions, switch ownership merge.  (RCCL itself: test_gpu_fullsize.py::test_rccl_world_size_one_matches_single_gpu.)"""
+"""GPU: the multi-GPU LM logic with SEVERAL ranks on ONE MI355X.  Each rank is a libpgo handle in its own thread owning a subset of
+the edges (sharding.partition: contiguous / chain / spatial); the collective is supplied through pgo_comm_init_custom by an
+in-process harness that sums / maxes the ranks' device buffers.  Everything the 8-GPU run does except RCCL itself is exercised:
+rank-local subgraphs (each rank works on the keyframes its edges touch), shared-keyframe discovery and ownership, the exchange of
+shared rows of the diagonal blocks / gradient / reduced system / CG matvec output, owner-weighted dot products and norms, the
+stopped-PCG-keeps-its-state rule behind early rejection, an idle rank, the owner-wise write-back and the switch ownership merge.
+(RCCL itself: test_gpu_fullsize.py::test_rccl_world_size_one_matches_single_gpu.)"""
 import ctypes as C
 import threading
 
@@ -10,7 +12,7 @@ import numpy as np
 import pytest
 
 from solve_keyframe_pose_graph_amd import capi
-from solve_keyframe_pose_graph_amd.sharding import edge_slice
+from solve_keyframe_pose_graph_amd import sharding
 from tests import util
 
 pytestmark = pytest.mark.gpu
@@ -42,28 +44,39 @@ class InProcessAllReduce:
         return fn
 
 
-@pytest.mark.parametrize("linear_solver", [1, 0])
-def test_two_ranks_reproduce_the_single_rank_solve(linear_solver):
+def idle_last_rank(g, world):
+    """world-1 working ranks (spatial cells) + one rank without a single residual block"""
+    return sharding.partition(g, world - 1, "spatial") + [lambda kind, n: np.arange(0)]
+
+
+@pytest.mark.parametrize("world,policy,linear_solver", [(2, "contiguous", 1), (2, "contiguous", 0), (3, "spatial", 1), (3, "chain", 0), (4, "spatial", 1), (3, "idle", 1)])
+def test_ranks_reproduce_the_single_rank_solve(world, policy, linear_solver):
     g = util.small_graph(500, 70, f=2, seed=17)
     q, t, s = util.initial_state(g, True)
     opts = dict(cg_rel_tolerance=1e-12, cg_max_iterations=20000, linear_solver=linear_solver)
     P = util.pgo_problem(g, True, **opts)
     q1, t1, s1, sum1 = P.solve(q, t, s)
+    c_ref, r_ref, g_ref = P.evaluate(q, t, s)
     P.close()
 
-    world = 2
+    parts = idle_last_rank(g, world) if policy == "idle" else sharding.partition(g, world, policy)
+    st = sharding.partition_stats(g, parts)
+    assert sum(st["edges_per_rank"]) == g.n_odom + g.n_loops and 0 < st["shared_keyframes"] < g.n_poses
     ar = InProcessAllReduce(world)
     out = [None] * world
+    grads = [None] * world
     err = []
 
     def run(rank):
         try:
-            Pr = capi.problem_from_graph(g, switchable=True, edge_slice=edge_slice(rank, world), **opts)
+            Pr = capi.problem_from_graph(g, switchable=True, edge_slice=parts[rank], **opts)
             Pr.comm_init_custom(rank, world, ar.make(rank))
+            c, _, gr = Pr.evaluate(q, t, s)                                  # parity hook through the exchange: cost + full gradient
+            grads[rank] = (c, gr)
             out[rank] = Pr.solve(q, t, s)
             Pr.comm_destroy()
             Pr.close()
-        except Exception as e:   # make a failing rank release the other one
+        except Exception as e:   # make a failing rank release the others
             err.append(e)
             ar.barrier.abort()
     th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
@@ -73,11 +86,58 @@ def test_two_ranks_reproduce_the_single_rank_solve(linear_solver):
         x.join(timeout=600)
     assert not err, err
     assert ar.calls > 100                                        # one exchange per CG matvec happened
+    # gradient over ALL keyframes on every rank; the switch part holds the rank's own switches
+    for r in range(world):
+        c, gr = grads[r]
+        assert abs(c - c_ref) <= 1e-12 * c_ref
+        assert np.abs(gr[:6 * g.n_poses] - g_ref[:6 * g.n_poses]).max() <= 1e-10 * np.abs(g_ref).max()
+    gs = np.sum([grads[r][1][6 * g.n_poses:] for r in range(world)], axis=0)
+    assert np.abs(gs - g_ref[6 * g.n_poses:]).max() <= 1e-10 * np.abs(g_ref).max()
     for r in range(world):
         qr, tr, sr, sumr = out[r]
         assert sumr.num_iterations == sum1.num_iterations
         assert [sumr.iterations[k].step_is_successful for k in range(sumr.num_logged)] == [sum1.iterations[k].step_is_successful for k in range(sum1.num_logged)]
         assert abs(sumr.final_cost - sum1.final_cost) <= 1e-9 * sum1.final_cost
         assert np.abs(tr - t1).max() <= 1e-7 and np.abs(sr - s1).max() <= 1e-7
-    # both ranks hold the same replicated result, including the switches owned by the other rank
-    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+        for k in range(sumr.num_logged):
+            assert abs(sumr.iterations[k].step_norm - sum1.iterations[k].step_norm) <= 1e-7 * max(1.0, sum1.iterations[k].step_norm)   # owner-weighted norms
+    # every rank returns the same complete result, including keyframes and switches it never touched
+    for r in range(1, world):
+        assert np.array_equal(out[0][0], out[r][0]) and np.array_equal(out[0][1], out[r][1]) and np.array_equal(out[0][2], out[r][2])
+
+
+def test_default_tolerances_with_early_rejection_across_ranks():
+    """Library defaults (two-phase PCG with early rejection: a stopped PCG is evaluated, then resumed) on a graph whose solve rejects
+    steps: three ranks follow the single-rank accept/reject sequence."""
+    g = util.small_graph(1500, 300, f=2, seed=23, outlier_frac=0.3)
+    q, t, s = util.initial_state(g, True)
+    P = util.pgo_problem(g, True)
+    q1, t1, s1, sum1 = P.solve(q, t, s)
+    P.close()
+    world = 3
+    parts = sharding.partition(g, world, "spatial")
+    ar = InProcessAllReduce(world)
+    out = [None] * world
+    err = []
+
+    def run(rank):
+        try:
+            Pr = capi.problem_from_graph(g, switchable=True, edge_slice=parts[rank])
+            Pr.comm_init_custom(rank, world, ar.make(rank))
+            out[rank] = Pr.solve(q, t, s)
+            Pr.comm_destroy()
+            Pr.close()
+        except Exception as e:
+            err.append(e)
+            ar.barrier.abort()
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join(timeout=600)
+    assert not err, err
+    seq1 = [sum1.iterations[k].step_is_successful for k in range(sum1.num_logged)]
+    for r in range(world):
+        sumr = out[r][3]
+        assert [sumr.iterations[k].step_is_successful for k in range(sumr.num_logged)] == seq1
+        assert abs(sumr.final_cost - sum1.final_cost) <= 1e-6 * sum1.final_cost
