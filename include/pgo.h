@@ -244,10 +244,17 @@ int pgo_apply_normal_operator(pgo_problem* p, const double* x, double* y);
 
 /* Rank 0 produces an RCCL unique id (ncclGetUniqueId); the host (torch.distributed) broadcasts the
  * bytes; every rank then calls pgo_comm_init.  After that the edges added on this rank are this
- * rank's SHARD: K1/K2 run on the local shard, diagonal blocks + gradient are all-reduced once per
- * linearisation and the CG matvec output (6*n_nodes doubles) once per CG iteration — a single
- * ncclAllReduce(sum, fp64) over xGMI.  Pose/switch arrays are replicated; switch variables belong
- * to the rank holding their edge (others pass through what they were given).  */
+ * rank's SHARD and the handle works on the keyframes those edges touch (a rank-local subgraph).
+ * Keyframes touched by two or more ranks are shared: only THEIR rows travel — diagonal blocks +
+ * gradient once per linearisation, the CG matvec output (6 doubles per shared keyframe, plus the
+ * p.Ap partial) once per CG iteration in a single ncclAllReduce(sum, fp64) over xGMI, and one
+ * scalar all-reduce per CG iteration for r.z.  Deal the edges out with locality (sharding.py:
+ * `spatial`) to keep the shared set small.  The contract on every rank: the same n_nodes / n_switch,
+ * the same initial arrays, the same constant keyframes, every switch index on exactly one rank; a
+ * rank without edges is fine.  pgo_solve returns the COMPLETE solution on every rank (each
+ * keyframe from its owner, each switch from the rank holding its edge).  Calls that issue
+ * collectives (solve*, evaluate, get_normal_blocks, apply_normal_operator, time_kernel) must be
+ * made by all ranks in the same order. */
 int pgo_comm_get_unique_id(uint8_t id[PGO_COMM_ID_BYTES]);
 int pgo_comm_init(pgo_problem* p, int32_t rank, int32_t world_size, const uint8_t id[PGO_COMM_ID_BYTES]);
 int pgo_comm_destroy(pgo_problem* p);

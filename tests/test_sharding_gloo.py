@@ -1,8 +1,9 @@
-"""CPU, world_size 2 over gloo: the N > 1 path's construction.  Each rank owns a contiguous slice of the edges
-(sharding.edge_slice, the selector bench.py and libpgo's multi-GPU mode use); summing the per-rank quantities with an
-all-reduce must reproduce the single-rank cost, gradient, diagonal blocks and the Schur-reduced damped operator applied to a
-vector — exactly the collectives libpgo issues through RCCL (one per CG matvec, one per linearisation).  The oracle stands
-in for the kernels here (no GPU in this container)."""
+"""CPU, world_size 2 and 3 over gloo: the construction of the N > 1 path.  Each rank owns the edges a sharding.partition policy deals
+it and works on the keyframes those edges touch (rank-local subgraph); keyframes touched by >= 2 ranks are shared and ONLY their rows
+travel.  With the oracle standing in for the kernels (no GPU in this container) the test replays the collectives libpgo issues —
+touch counts (sum) and lowest touching rank (max) at graph build, shared rows of diagonal + gradient per linearisation, shared rows
+of the CG matvec output with the rank-local p.Ap partial riding along, owner-weighted scalar sums, owner-wise write-back — and
+checks every rank ends up with the single-rank numbers on ITS keyframes."""
 import os
 import socket
 
@@ -12,6 +13,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+from solve_keyframe_pose_graph_amd import sharding
 from solve_keyframe_pose_graph_amd.sharding import edge_slice
 from tests import util
 
@@ -21,9 +23,8 @@ def _free_port():
     return p
 
 
-def _local_problem(g, rank, world):
+def _local_problem(g, sel):
     from oracle import binding as ob
-    sel = edge_slice(rank, world)
     P = ob.OracleProblem()
     io, il, ir = sel("odom", g.n_odom), sel("loop", g.n_loops), sel("reg", len(g.reg_node))
     if len(io):
@@ -32,11 +33,14 @@ def _local_problem(g, rank, world):
         P.add_switchable_edges(g.loop_c1[il], g.loop_c2[il], g.loop_T[il], g.loop_w[il], il)
     if len(ir):
         P.set_node_regularizers(g.reg_node[ir], g.reg_T[ir], g.reg_w[ir])
-    return P, il
+    touched = np.zeros(g.n_poses, bool)
+    for a in (g.odom_c1[io], g.odom_c2[io], g.loop_c1[il], g.loop_c2[il], g.reg_node[ir]):
+        touched[a] = True
+    return P, il, touched
 
 
-def _reduced_operator(H, N, owned_sw, lam_p, radius, x):
-    """(H_pp_local - sum_{owned switches} c c^T / a) x ; the damping lam_p is added once (rank 0) by the caller."""
+def _reduced_operator(H, N, owned_sw, radius, x):
+    """(H_pp_local - sum_{owned switches} c c^T / a) x : the rank's part A_r x of the Schur-reduced operator, without the damping"""
     Hpp = H[:6 * N, :6 * N]
     y = Hpp @ x
     for e in owned_sw:
@@ -48,62 +52,116 @@ def _reduced_operator(H, N, owned_sw, lam_p, radius, x):
     return y
 
 
-def _worker(rank, world, port, out):
+def _exchange_rows(rows_mine, shared_pos_of_mine, n_shared, k, extra=None):
+    """libpgo's exchange_rows: zero buffer of n_shared x k (+ scalars), this rank's shared rows packed in, ONE all-reduce, rows read back"""
+    n_extra = 0 if extra is None else len(extra)
+    buf = torch.zeros(n_shared * k + n_extra, dtype=torch.float64)
+    view = buf[:n_shared * k].view(n_shared, k)
+    view[shared_pos_of_mine] = torch.from_numpy(np.ascontiguousarray(rows_mine))
+    if n_extra:
+        buf[n_shared * k:] = torch.from_numpy(np.asarray(extra, dtype=np.float64))
+    dist.all_reduce(buf)
+    return view[shared_pos_of_mine].numpy().copy(), buf[n_shared * k:].numpy().copy()
+
+
+def _worker(rank, world, port, policy, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     g = util.small_graph(90, 18, f=2, seed=6)
     q, t, s = util.initial_state(g, True, perturb=0.02, seed=3)
     N, S = g.n_poses, g.n_loops
-    P, owned = _local_problem(g, rank, world)
+    P, owned_sw, touched = _local_problem(g, sharding.partition(g, world, policy)[rank])
     cost, _, grad = P.evaluate(q, t, s, want_residuals=False)
     H = P.dense_normal_matrix(q, t, s)
-    # keyframe participation = union over ranks of 'has a local residual block' (libpgo all-reduces these flags with max)
-    deg = np.zeros(N)
-    sel = edge_slice(rank, world)
-    for arr, n in ((g.odom_c1, g.n_odom), (g.odom_c2, g.n_odom), (g.loop_c1, g.n_loops), (g.loop_c2, g.n_loops)):
-        idx = sel('odom' if n == g.n_odom else 'loop', n)
-        deg[arr[idx]] = 1
-    tf = torch.from_numpy(deg.copy()); dist.all_reduce(tf, op=dist.ReduceOp.MAX)
-    assert tf.min().item() == 1.0 and deg.min() == 0.0   # every keyframe participates globally, but not on every rank
-    # collectives: cost (scalar sum), diagonal blocks + gradient (one all-reduce per linearisation)
-    tc = torch.tensor([cost]); dist.all_reduce(tc)
-    diag = torch.from_numpy(np.diag(H)[:6 * N].copy()); dist.all_reduce(diag)
-    tg = torch.from_numpy(grad[:6 * N].copy()); dist.all_reduce(tg)
+    # ---- graph build: how many ranks touch each keyframe (sum) and the lowest of them (max of world - rank)
+    cnt = torch.from_numpy(touched.astype(np.float64)); dist.all_reduce(cnt)
+    low = torch.from_numpy(np.where(touched, float(world - rank), 0.0)); dist.all_reduce(low, op=dist.ReduceOp.MAX)
+    cnt = cnt.numpy().astype(int); owner = world - low.numpy().astype(int)
+    assert cnt.min() >= 1 and not touched.all()                  # every keyframe is somebody's, nobody holds them all
+    shared = np.nonzero(cnt >= 2)[0]                              # the same ordered list on every rank
+    pos_of = -np.ones(N, int); pos_of[shared] = np.arange(len(shared))
+    mine = np.nonzero(touched)[0]                                 # rank-local keyframes (ascending global order = local numbering)
+    mine_shared = mine[cnt[mine] >= 2]
+    own_w = (owner[mine] == rank).astype(np.float64)              # owner weights over the local keyframes
+    rows = lambda v, k: v.reshape(N, k)                           # noqa: E731
+    # ---- linearisation: cost (scalar sum), diagonal + gradient rows of the SHARED keyframes only
+    tc = torch.tensor([cost], dtype=torch.float64); dist.all_reduce(tc)
+    dg = np.concatenate([rows(np.diag(H)[:6 * N].copy(), 6), rows(grad[:6 * N].copy(), 6)], axis=1)    # [N][12]
+    got, _ = _exchange_rows(dg[mine_shared], pos_of[mine_shared], len(shared), 12)
+    dg[mine_shared] = got
+    diag_l, grad_l = dg[mine, :6], dg[mine, 6:]                   # complete on this rank's keyframes
+    # ---- damped operator: the OWNER adds the damping once; shared rows of y summed, x.(A_r x) rides along
     radius = 1e4
-    sc = 1.0 / (1.0 + np.sqrt(diag.numpy()))
-    lam_p = np.clip(sc ** 2 * diag.numpy(), 1e-6, 1e32) / (radius * sc ** 2)
+    full_diag = np.zeros((N, 6)); full_diag[mine] = diag_l
+    sc = 1.0 / (1.0 + np.sqrt(full_diag[mine]))
+    lam = np.clip(sc ** 2 * full_diag[mine], 1e-6, 1e32) / (radius * sc ** 2)
     x = np.random.default_rng(0).normal(size=6 * N)
-    y = _reduced_operator(H, N, owned, lam_p, radius, x)
-    if rank == 0:
-        y = y + lam_p * x
-    ty = torch.from_numpy(y); dist.all_reduce(ty)          # the one exchange per CG matvec
-    if rank == 0:
-        np.savez(out, cost=tc.numpy(), grad=tg.numpy(), y=ty.numpy(), diag=diag.numpy())
+    x_l = np.zeros(6 * N); rows(x_l, 6)[mine] = rows(x, 6)[mine]  # a rank only ever holds x on its keyframes
+    y = rows(_reduced_operator(H, N, owned_sw, radius, x_l), 6)
+    y[mine] += own_w[:, None] * lam * rows(x, 6)[mine]
+    assert np.abs(np.delete(y, mine, axis=0)).max(initial=0.0) == 0.0     # A_r only reaches the rank's own keyframes
+    pAp_local = float((rows(x, 6)[mine] * y[mine]).sum())
+    got, extra = _exchange_rows(y[mine_shared], pos_of[mine_shared], len(shared), 6, [pAp_local])
+    y[mine_shared] = got
+    # ---- owner-weighted scalar (r.z, norms): one more scalar all-reduce
+    xx = torch.tensor([float((own_w[:, None] * rows(x, 6)[mine] ** 2).sum())], dtype=torch.float64); dist.all_reduce(xx)
+    # ---- write-back: owners scatter their keyframes into a zeroed global array, one all-reduce replicates it
+    wb = torch.zeros(N, 6, dtype=torch.float64)
+    wb[mine[own_w > 0]] = torch.from_numpy(y[mine[own_w > 0]])
+    dist.all_reduce(wb)
+    np.savez(out % rank, cost=tc.numpy(), mine=mine, grad=grad_l, diag=diag_l, y=y[mine], pAp=extra, xx=xx.numpy(), y_all=wb.numpy(), n_shared=len(shared))
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
-def test_edge_sharding_reproduces_the_full_system(tmp_path):
-    world = 2
-    out = str(tmp_path / "sharded.npz")
-    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
-    r = np.load(out)
+@pytest.mark.parametrize("world,policy", [(2, "contiguous"), (3, "spatial"), (2, "chain")])
+def test_rank_local_subgraphs_reproduce_the_full_system(tmp_path, world, policy):
+    out = str(tmp_path / "rank%d.npz")
+    mp.spawn(_worker, args=(world, _free_port(), policy, out), nprocs=world, join=True)
     g = util.small_graph(90, 18, f=2, seed=6)
     q, t, s = util.initial_state(g, True, perturb=0.02, seed=3)
     N, S = g.n_poses, g.n_loops
     O = util.oracle_problem(g, True)
     cost, _, grad = O.evaluate(q, t, s, want_residuals=False)
     H = O.dense_normal_matrix(q, t, s)
-    assert abs(r["cost"][0] - cost) <= 1e-12 * cost
-    assert np.abs(r["grad"] - grad[:6 * N]).max() <= 1e-11 * np.abs(grad).max()
-    assert np.abs(r["diag"] - np.diag(H)[:6 * N]).max() <= 1e-11 * np.diag(H).max()
     radius = 1e4
     scale = 1.0 / (1.0 + np.sqrt(np.diag(H)))
     lam = np.clip(scale ** 2 * np.diag(H), 1e-6, 1e32) / (radius * scale ** 2)
     Hd = H + np.diag(lam)
     A = Hd[:6 * N, :6 * N] - Hd[:6 * N, 6 * N:] @ np.linalg.solve(Hd[6 * N:, 6 * N:], Hd[6 * N:, :6 * N])
     x = np.random.default_rng(0).normal(size=6 * N)
-    assert np.abs(r["y"] - A @ x).max() <= 1e-10 * np.abs(A @ x).max()
+    Ax = (A @ x).reshape(N, 6)
+    for rank in range(world):
+        r = np.load(out % rank)
+        mine = r["mine"]
+        assert 0 < r["n_shared"] < N and len(mine) < N
+        assert abs(r["cost"][0] - cost) <= 1e-12 * cost
+        assert np.abs(r["grad"] - grad[:6 * N].reshape(N, 6)[mine]).max() <= 1e-11 * np.abs(grad).max()
+        assert np.abs(r["diag"] - np.diag(H)[:6 * N].reshape(N, 6)[mine]).max() <= 1e-11 * np.diag(H).max()
+        assert np.abs(r["y"] - Ax[mine]).max() <= 1e-10 * np.abs(Ax).max()          # complete on the rank's keyframes after ONE exchange
+        assert abs(r["pAp"][0] - x @ (A @ x)) <= 1e-10 * abs(x @ (A @ x))           # sum over ranks of the rank-local partials
+        assert abs(r["xx"][0] - x @ x) <= 1e-12 * (x @ x)                             # every keyframe counted once
+        assert np.abs(r["y_all"] - Ax).max() <= 1e-10 * np.abs(Ax).max()             # owner-wise write-back
+
+
+def test_policies_deal_out_every_edge_exactly_once():
+    g = util.small_graph(300, 40, f=2, seed=11)
+    for world in (1, 2, 3, 8):
+        for policy in ("contiguous", "chain", "spatial"):
+            parts = sharding.partition(g, world, policy)
+            for kind, n in (("odom", g.n_odom), ("loop", g.n_loops), ("reg", len(g.reg_node))):
+                got = np.sort(np.concatenate([parts[r](kind, n) for r in range(world)]))
+                assert np.array_equal(got, np.arange(n)), (world, policy, kind)
+            st = sharding.partition_stats(g, parts)
+            assert sum(st["edges_per_rank"]) == g.n_odom + g.n_loops
+            if policy != "contiguous" and world > 1:
+                assert max(st["edges_per_rank"]) <= 1.5 * (g.n_odom + g.n_loops) / world + 8      # balanced by edge load
+    # locality on the benchmark's graph family (C3 structure: loop closures tie places that are close in space, far apart in time):
+    # spatial cells share fewer keyframes than index ranges, which share fewer than dealing out edge-index ranges
+    from solve_keyframe_pose_graph_amd import graphgen
+    g = graphgen.generate(40000, 40000, odom_f_max=2, seed=3)
+    sh = {pol: sharding.partition_stats(g, sharding.partition(g, 4, pol))["shared_keyframes"] for pol in ("contiguous", "chain", "spatial")}
+    assert sh["spatial"] < 0.7 * sh["chain"] and sh["chain"] < sh["contiguous"], sh
 
 
 def test_slices_partition_every_edge_class():
