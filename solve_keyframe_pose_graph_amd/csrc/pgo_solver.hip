@@ -231,7 +231,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S) {
     // ---- multi-GPU: rank-local subgraph.  This rank works on the keyframes its own residual blocks touch, renumbered densely; keyframes
     // touched by >= 2 ranks are "shared" (their rows are summed over ranks by exchange_rows), the lowest touching rank is the owner.
     const int64_t Ng = N;
-    p->local_ids = p->world > 1 && (p->comm || p->custom_allreduce);
+    p->local_ids = p->comm != nullptr || p->custom_allreduce != nullptr;   // also with a 1-rank communicator: the same code path, every collective issued
     p->n_sh_mine = p->n_sh_global = 0;
     if (p->local_ids) {
         std::vector<uint8_t> touched((size_t)Ng, 0);
@@ -450,9 +450,8 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S) {
     return PGO_OK;
 }
 
-// ---- collectives (no-ops at world == 1) ----
+// ---- collectives (no-ops without a communicator; a 1-rank communicator still issues every call) ----
 int allreduce(pgo_problem* p, double* buf, size_t n, int op /*0 sum, 2 max*/) {
-    if (p->world <= 1) return PGO_OK;
     if (p->custom_allreduce) {
         const int rc = p->custom_allreduce(p->custom_ctx, buf, (int64_t)n, op, (void*)p->st);
         if (rc != 0) { p->err = "custom all-reduce callback failed"; return PGO_ERR_COMM; }
@@ -629,7 +628,7 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
         return PGO_OK;
     };
     // hipGraph: capture one chunk (iterations 2 .. 2+every-1: no `first` kernel, even start) once per graph build and replay it
-    const bool want_graph = o.cg_use_graph && p->world == 1 && !p->cg_graph_failed;
+    const bool want_graph = o.cg_use_graph && !p->local_ids && !p->cg_graph_failed;
     if (want_graph && (p->cg_graph == nullptr || p->cg_graph_epoch != p->build_epoch || p->cg_graph_len != every)) {
         if (p->cg_graph) { (void)hipGraphExecDestroy(p->cg_graph); p->cg_graph = nullptr; }
         hipGraph_t gr = nullptr;
@@ -907,7 +906,7 @@ int solve_end(pgo_problem* p, double* quat, double* t, double* sw, pgo_summary* 
             }
         }
         if (p->S > 0) {
-            if (p->world > 1) {
+            if (p->local_ids) {
                 // every switch is owned by the rank holding its edge: sum (owned ? value : 0) and the owner count
                 std::vector<double> own((size_t)p->S * 2, 0.0), cur((size_t)p->S);
                 HIPCHK(p, hipMemcpyAsync(cur.data(), p->d_swv[p->cur].p, (size_t)p->S * sizeof(double), hipMemcpyDeviceToHost, p->st));

@@ -104,8 +104,9 @@ def test_c4_small_variant_matches_oracle_solve():
 
 
 def test_rccl_world_size_one_matches_single_gpu():
-    """Exercises the multi-GPU code path (ncclCommInitRank, the all-reduce per CG matvec / per linearisation, the scalar
-    all-reduces, the switch ownership merge) with a 1-rank communicator."""
+    """Exercises the multi-GPU code path THROUGH RCCL with a 1-rank communicator: ncclCommInitRank, and — because a handle with a
+    communicator always runs the rank-local machinery — every ncclAllReduce the N-rank run issues (touch counts / owners at graph
+    build, exchange per CG matvec with the p.Ap scalar, r.z scalar, per-linearisation rows, scalar readbacks, write-back, switch merge)."""
     g = util.small_graph(600, 80, f=2, seed=13)
     q, t, s = util.initial_state(g, True)
     P0 = util.pgo_problem(g, True)
