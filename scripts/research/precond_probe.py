@@ -378,3 +378,73 @@ def build_system_plain(g, q, t, radius):
     jj = (c_[:, None, None] * 6 + np.arange(6)[None, None, :]) + 0 * np.arange(6)[None, :, None]
     A = sp.coo_matrix((b_.ravel(), (ii.ravel(), jj.ravel())), shape=(6 * N, 6 * N)).tocsr()
     return A, -grad[:6 * N].copy()
+
+
+class ChainBlocks:
+    """block-Jacobi with blocks of `m` consecutive keyframes (6m x 6m), solved exactly"""
+    def __init__(self, A, N, m):
+        seg = (np.arange(6 * N) // 6) // m
+        Ac = A.tocoo()
+        keep = seg[Ac.row] == seg[Ac.col]
+        B = sp.coo_matrix((Ac.data[keep], (Ac.row[keep], Ac.col[keep])), shape=A.shape).tocsc()
+        self.lu = spla.splu(B, permc_spec='NATURAL', diag_pivot_thresh=0.0)
+    def __call__(self, r): return self.lu.solve(r)
+
+
+def probe8(n, radii, ms=(2, 4, 8, 16)):
+    g = graphgen.generate(n, n, odom_f_max=2, seed=3)
+    q, t, s = util.initial_state(g, True)
+    N = g.n_poses
+    for radius in radii:
+        A, b = build_system(g, q, t, s, radius)
+        Dinv = block_diag_inv(A, N)
+        x, k = pcg(A, b, lambda r: Dinv @ r, 1e-8, maxit=60000); print('n %d radius %g  block-Jacobi its %d' % (n, radius, k), flush=True)
+        for m in ms:
+            M = ChainBlocks(A, N, m)
+            x2, k2 = pcg(A, b, M, 1e-8, maxit=20000)
+            print('   %d-keyframe blocks: its %d' % (m, k2), flush=True)
+
+
+class ClusterBlocks:
+    """block-Jacobi whose blocks are arbitrary keyframe clusters (labels), each solved exactly"""
+    def __init__(self, A, N, labels):
+        lab = np.repeat(labels, 6)
+        Ac = A.tocoo()
+        keep = lab[Ac.row] == lab[Ac.col]
+        B = sp.coo_matrix((Ac.data[keep], (Ac.row[keep], Ac.col[keep])), shape=A.shape).tocsc()
+        self.lu = spla.splu(B)
+    def __call__(self, r): return self.lu.solve(r)
+
+
+def graph_clusters(g, m, seed=0):
+    """greedy clusters of <= m keyframes grown along the heaviest connections (odometry + loop edges): BFS from unassigned seeds"""
+    N = g.n_poses
+    adj = [[] for _ in range(N)]
+    for a, b in zip(np.concatenate([g.odom_c1, g.loop_c1]), np.concatenate([g.odom_c2, g.loop_c2])):
+        adj[a].append(b); adj[b].append(a)
+    lab = -np.ones(N, int); c = 0
+    for s0 in range(N):
+        if lab[s0] >= 0: continue
+        grp = [s0]; lab[s0] = c; head = 0
+        while head < len(grp) and len(grp) < m:
+            u = grp[head]; head += 1
+            for v in adj[u]:
+                if lab[v] < 0 and len(grp) < m:
+                    lab[v] = c; grp.append(v)
+        c += 1
+    return lab
+
+
+def probe9(n, radii, ms=(4, 8, 16, 32)):
+    g = graphgen.generate(n, n, odom_f_max=2, seed=3)
+    q, t, s = util.initial_state(g, True)
+    N = g.n_poses
+    for radius in radii:
+        A, b = build_system(g, q, t, s, radius)
+        Dinv = block_diag_inv(A, N)
+        x, k = pcg(A, b, lambda r: Dinv @ r, 1e-8, maxit=60000); print('n %d radius %g  block-Jacobi its %d' % (n, radius, k), flush=True)
+        for m in ms:
+            lab = graph_clusters(g, m)
+            M = ClusterBlocks(A, N, lab)
+            x2, k2 = pcg(A, b, M, 1e-8, maxit=20000)
+            print('   graph clusters <= %d keyframes (%d clusters): its %d' % (m, lab.max() + 1, k2), flush=True)

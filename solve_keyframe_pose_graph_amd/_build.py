@@ -61,7 +61,21 @@ def build_host(force=False):
     return LIBHOST
 
 
+EXAMPLE_REPLAY = os.path.join(os.path.dirname(_HERE), "examples", "replay_session")
+
+
+def build_examples(force=False):
+    """examples/replay_session.cpp: the C++ host classes used directly (what a maintainer's code looks like)."""
+    build_host(force)
+    src = EXAMPLE_REPLAY + ".cpp"
+    if force or _stale(EXAMPLE_REPLAY, [src, LIBHOST, os.path.join(CSRC, "host", "PoseGraphSLAM.hpp"), os.path.join(CSRC, "host", "GraphFormats.hpp")]):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", INCLUDE, "-I", CSRC, "-o", EXAMPLE_REPLAY, src, "-L", _HERE, "-l:libpgo_host.so", "-l:libpgo.so",
+                               "-Wl,-rpath," + _HERE])
+    return EXAMPLE_REPLAY
+
+
 def build_all(force=False):
     build_graphgen(force)
     build_libpgo(force)
     build_host(force)
+    build_examples(force)

@@ -195,3 +195,29 @@ def test_replay_of_a_recorded_session_from_log_posegraph_json(tmp_path):
     s_fin = np.array([S.get_loopedge_switching_variable_val(k) for k in range(g.n_loops)])
     assert (s_fin[np.argsort(order)][inl] > 0.5).mean() > 0.9                 # inlier loop closures stay switched on
     S.close()
+
+
+def test_cpp_example_replays_a_session_like_the_python_tool(tmp_path):
+    """examples/replay_session.cpp drives the C++ host classes directly (PoseGraphSLAM + GraphFormats): same session, same trajectory."""
+    import subprocess
+    from solve_keyframe_pose_graph_amd import _build, replay
+    from solve_keyframe_pose_graph_amd.pose_graph_slam import GraphSource, read_log_optimized_poses
+    exe = _build.build_examples()
+    g = util.small_graph(300, 40, f=1, seed=33)
+    w_M = util.poses_to_matrices(g.init_q, g.init_t)
+    rec = GraphSource()
+    for i in range(g.n_poses):
+        rec.add_node(0, w_M[i])
+    for e in range(g.n_loops):
+        rec.add_loop_edge(int(g.loop_c2[e]), int(g.loop_c1[e]), g.loop_T[e], 1.0)
+    (tmp_path / "in").mkdir(); (tmp_path / "cpp").mkdir()
+    assert rec.save_posegraph_json(tmp_path / "in")
+    r = subprocess.run([exe, str(tmp_path / "in"), str(tmp_path / "cpp"), "60"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "LM iterations" in r.stdout
+    assert replay.main([str(tmp_path / "in"), "--out", str(tmp_path / "py"), "--every", "60"]) == 0
+    a = read_log_optimized_poses(tmp_path / "cpp" / "log_optimized_poses.json")
+    b = read_log_optimized_poses(tmp_path / "py" / "log_optimized_poses.json")
+    assert a["nNodes"] == b["nNodes"] == g.n_poses
+    assert np.abs(a["wTc_opt"] - b["wTc_opt"]).max() < 1e-9
+    assert np.abs(a["switching_var_after_opt"] - b["switching_var_after_opt"]).max() < 1e-9
