@@ -89,8 +89,13 @@ typedef struct pgo_options {
     double cg_rel_tolerance;             /* 1e-9: stop when ||r||_{M^-1} <= tol * ||b||_{M^-1} */
     int32_t cg_warm_start;               /* 1: after a rejected step start the PCG from the previous step (same H, larger damping) */
     int32_t cg_use_graph;                /* 1: replay each `cg_check_every`-iteration chunk of the PCG loop as one hipGraph (single GPU) */
-    double cg_early_tolerance;           /* 1e-4: first PCG phase; the candidate is evaluated there and a clearly bad step is rejected at once */
-    double cg_early_reject_rho;          /* -0.5: reject after the first phase when relative_decrease < this (0 disables: set cg_early_tolerance = 0) */
+    /* Early rejection: a rejected LM step only shrinks the trust region, so the PCG pauses at up to two intermediate tolerances, the
+     * candidate is evaluated there, and a step whose relative_decrease is already below the stage's threshold (and which would trip
+     * neither convergence test) is rejected without paying for the remaining decades; otherwise the SAME PCG resumes. */
+    double cg_early_tolerance;           /* 1e-2: first stage (0 disables the stage) */
+    double cg_early_reject_rho;          /* -0.5: threshold of the first stage — far below min_relative_decrease because the step is still crude */
+    double cg_mid_tolerance;             /* 1e-4: second stage (0 disables the stage) */
+    double cg_mid_reject_rho;            /* -0.05: threshold of the second stage — the step is within ~1e-4 of the final one there */
     /* device selection */
     int32_t device_id;                   /* -1: use the current HIP device */
     int32_t verbosity;                   /* 0 silent (minimizer_progress_to_stdout=false, :1271), 1 per-iteration line on stderr */

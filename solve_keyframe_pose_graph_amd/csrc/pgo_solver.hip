@@ -795,22 +795,26 @@ int lm_step(pgo_problem* p, int ignore_termination, int* done) {
     };
     bool evaluated = false;
     if (ok) {
-        // phase 1 of the PCG stops at cg_early_tolerance: a rejected step only changes the trust-region radius (Ceres StepRejected), so a
-        // step that is clearly bad there (relative_decrease < cg_early_reject_rho, far from min_relative_decrease, and neither
-        // convergence test would fire) is rejected without paying for the remaining decades; otherwise the same PCG resumes to cg_rel_tolerance
-        const bool early = o.cg_early_tolerance > o.cg_rel_tolerance;
+        // The PCG pauses at up to two intermediate tolerances (cg_early_tolerance > cg_mid_tolerance > cg_rel_tolerance).  A rejected step
+        // only changes the trust-region radius (Ceres StepRejected), so a step that is already clearly bad at a pause
+        // (relative_decrease below the stage's threshold, and neither convergence test would fire) is rejected without paying for the
+        // remaining decades; otherwise the same PCG resumes towards the next tolerance.
+        struct Stage { double tol, reject_rho; };
+        Stage stages[2]; int n_stages = 0;
+        if (o.cg_early_tolerance > o.cg_rel_tolerance) stages[n_stages++] = Stage{o.cg_early_tolerance, o.cg_early_reject_rho};
+        if (o.cg_mid_tolerance > o.cg_rel_tolerance && (n_stages == 0 || o.cg_mid_tolerance < stages[0].tol)) stages[n_stages++] = Stage{o.cg_mid_tolerance, o.cg_mid_reject_rho};
         const bool warm = o.cg_warm_start != 0 && p->have_prev_step && p->reuse_diagonal;
-        if ((rc = run_pcg(p, &cg, warm, early ? o.cg_early_tolerance : o.cg_rel_tolerance, -1)) != PGO_OK) return rc;
-        if (early && !cg.breakdown) {
+        if ((rc = run_pcg(p, &cg, warm, n_stages ? stages[0].tol : o.cg_rel_tolerance, -1)) != PGO_OK) return rc;
+        for (int sidx = 0; sidx < n_stages && !cg.breakdown && !evaluated; ++sidx) {
             if ((rc = evaluate_candidate()) != PGO_OK) return rc;
             const double mc = -h[S_MODEL];
             const double cand = 0.5 * (h[S_COST] + h[S_PRIOR_COST]);
             const double dc = p->x_cost - cand;
             const double sn = std::sqrt(h[S_STEP2] + h[S_SW_STEP2]);
-            const bool clear_reject = mc > 0.0 && std::isfinite(mc) && std::isfinite(cand) && dc / mc < o.cg_early_reject_rho &&
+            const bool clear_reject = mc > 0.0 && std::isfinite(mc) && std::isfinite(cand) && dc / mc < stages[sidx].reject_rho &&
                                       sn > o.parameter_tolerance * (p->x_norm + o.parameter_tolerance) && std::fabs(dc) > o.function_tolerance * p->x_cost;
             if (clear_reject) evaluated = true;
-            else if ((rc = run_pcg(p, &cg, false, o.cg_rel_tolerance, cg.iterations)) != PGO_OK) return rc;
+            else if ((rc = run_pcg(p, &cg, false, sidx + 1 < n_stages ? stages[sidx + 1].tol : o.cg_rel_tolerance, cg.iterations)) != PGO_OK) return rc;
         }
         p->have_prev_step = !cg.breakdown;
         if (cg.breakdown) ok = false;
@@ -973,8 +977,10 @@ void pgo_options_init(pgo_options* o) {
     o->cg_check_every = 25;
     o->cg_warm_start = 1;
     o->cg_use_graph = 1;
-    o->cg_early_tolerance = 1e-4;
+    o->cg_early_tolerance = 1e-2;
     o->cg_early_reject_rho = -0.5;
+    o->cg_mid_tolerance = 1e-4;
+    o->cg_mid_reject_rho = -0.05;
     o->cg_rel_tolerance = 1e-9;     // loosest decade that keeps the 10-iteration chi^2 of C3 within 1e-8 of the 1e-13 solve
     o->device_id = -1;
     o->verbosity = 0;
