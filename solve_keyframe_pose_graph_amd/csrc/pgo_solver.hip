@@ -85,6 +85,7 @@ struct pgo_problem {
     std::vector<int32_t> l2g, g2l;            // local -> global, global -> local (-1: not touched by this rank)
     std::vector<uint8_t> h_touched_any;       // [N_global] some rank holds a residual block on the keyframe
     std::vector<double> h_own;                // [N] 1.0 where this rank is the keyframe's owner (lowest rank touching it)
+    std::vector<double> h_init_q, h_init_t;   // multi-GPU: the caller's state at solve_begin (keyframes no rank touches are returned as given)
     DBuf<int32_t> d_l2g, d_sh_loc, d_sh_pos;  // shared keyframes touched here: local id, position in the global shared list
     DBuf<double> d_own, d_xbuf;               // owner weights; exchange buffer
     int64_t n_sh_mine = 0, n_sh_global = 0;
@@ -732,6 +733,7 @@ int solve_begin(pgo_problem* p, const double* quat, const double* t, const doubl
     // upload in the reference layout (multi-GPU: only this rank's keyframes), repack on the device
     double* io = p->d_io.p;
     const int64_t Nl = p->N;
+    if (p->local_ids) { p->h_init_q.assign(quat, quat + (size_t)N * 4); p->h_init_t.assign(t, t + (size_t)N * 3); }
     if ((rc = nodes_from_global(p, quat, 4, io)) != PGO_OK) return rc;
     if ((rc = nodes_from_global(p, t, 3, io + (size_t)Nl * 4)) != PGO_OK) return rc;
     p->cur = 0;
@@ -905,8 +907,8 @@ int solve_end(pgo_problem* p, double* quat, double* t, double* sw, pgo_summary* 
             HIPCHK(p, hipMemcpyAsync(hq.data(), p->d_tmp.p, hq.size() * sizeof(double), hipMemcpyDeviceToHost, p->st));
             HIPCHK(p, hipMemcpyAsync(ht.data(), p->d_tmp.p + (size_t)Ng * 4, ht.size() * sizeof(double), hipMemcpyDeviceToHost, p->st));
             HIPCHK(p, hipStreamSynchronize(p->st));
-            for (int64_t g = 0; g < Ng; ++g) if (!p->h_touched_any[g]) {   // keyframes without any residual block keep the caller's values
-                std::copy(quat + g * 4, quat + g * 4 + 4, hq.begin() + g * 4); std::copy(t + g * 3, t + g * 3 + 3, ht.begin() + g * 3);
+            for (int64_t g = 0; g < Ng; ++g) if (!p->h_touched_any[g]) {   // keyframes without any residual block: the values given to solve_begin
+                std::copy(p->h_init_q.begin() + g * 4, p->h_init_q.begin() + g * 4 + 4, hq.begin() + g * 4); std::copy(p->h_init_t.begin() + g * 3, p->h_init_t.begin() + g * 3 + 3, ht.begin() + g * 3);
             }
         }
         if (p->S > 0) {

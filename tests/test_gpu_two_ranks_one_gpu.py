@@ -141,3 +141,42 @@ def test_default_tolerances_with_early_rejection_across_ranks():
         sumr = out[r][3]
         assert [sumr.iterations[k].step_is_successful for k in range(sumr.num_logged)] == seq1
         assert abs(sumr.final_cost - sum1.final_cost) <= 1e-6 * sum1.final_cost
+
+
+def test_keyframes_without_residual_blocks_come_back_as_given_on_every_rank():
+    g = util.small_graph(300, 40, f=2, seed=19)
+    q, t, s = util.initial_state(g, True)
+    rng = np.random.default_rng(1)
+    extra_q = rng.normal(size=(4, 4)); extra_q /= np.linalg.norm(extra_q, axis=1, keepdims=True)
+    q = np.concatenate([q, extra_q]); t = np.concatenate([t, rng.normal(size=(4, 3))])       # four keyframes no edge refers to
+    opts = dict(cg_rel_tolerance=1e-12, cg_max_iterations=20000)
+    P = util.pgo_problem(g, True, **opts)
+    q1, t1, s1, sum1 = P.solve(q, t, s)
+    P.close()
+    assert np.array_equal(q1.reshape(-1, 4)[-4:], q[-4:]) and np.array_equal(t1.reshape(-1, 3)[-4:], t[-4:])
+    world = 2
+    parts = sharding.partition(g, world, "chain")
+    ar = InProcessAllReduce(world)
+    out = [None] * world
+    err = []
+
+    def run(rank):
+        try:
+            Pr = capi.problem_from_graph(g, switchable=True, edge_slice=parts[rank], **opts)
+            Pr.comm_init_custom(rank, world, ar.make(rank))
+            out[rank] = Pr.solve(q, t, s)
+            Pr.comm_destroy()
+            Pr.close()
+        except Exception as e:
+            err.append(e)
+            ar.barrier.abort()
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join(timeout=600)
+    assert not err, err
+    for r in range(world):
+        qr, tr, sr, sumr = out[r]
+        assert np.array_equal(qr.reshape(-1, 4)[-4:], q[-4:]) and np.array_equal(tr.reshape(-1, 3)[-4:], t[-4:])
+        assert np.abs(tr - t1).max() <= 1e-7 and abs(sumr.final_cost - sum1.final_cost) <= 1e-9 * sum1.final_cost
