@@ -185,3 +185,22 @@ def test_c3_ten_iterations_match_the_independent_cpu_trajectory(c3):
     tt = tp.reshape(-1, 3)[::997]
     assert np.abs(tt - np.array(gold["final_t_sample"])).max() <= 1e-3
     assert np.abs(sp[::997] - np.array(gold["final_s_sample"])).max() <= 1e-3
+
+
+def test_c3_structured_5k_to_convergence_matches_oracle():
+    """final chi^2 against the CPU oracle run TO CONVERGENCE (not the 10-iteration budget) on a C3-structured graph
+    the oracle's exact Cholesky handles quickly.  With Ceres' function_tolerance 1e-6 both minimisers stop after the same 10 iterations
+    with chi^2 equal to 1e-7 but up to 5 cm apart at the far end of the trajectory (a flat valley: the cost no longer sees it); run to
+    function_tolerance 1e-12 they agree to 1e-12 in chi^2 and 1.4e-4 m in every keyframe — the per-keyframe bar needs a converged solve."""
+    from oracle import binding as ob
+    g = graphgen.generate(5000, 5000, odom_f_max=2, seed=3)
+    q, t, s = util.initial_state(g, True)
+    for ftol, cost_bar, pose_bar in ((1e-6, 1e-6, 0.1), (1e-12, 1e-10, 1e-3)):
+        O, P = util.oracle_problem(g, True), util.pgo_problem(g, True, max_num_iterations=200, function_tolerance=ftol)
+        qo, to, so, sumo = O.solve(q, t, s, ob.default_options(max_num_iterations=200, function_tolerance=ftol))
+        qp, tp, sp, sump = P.solve(q, t, s)
+        P.close()
+        assert sumo.termination_type == 0 and sump.termination_type == 0          # CONVERGENCE on both sides, by their own tests
+        assert abs(sump.final_cost - sumo.final_cost) <= cost_bar * sumo.final_cost, (ftol, sump.final_cost, sumo.final_cost)
+        assert np.linalg.norm(tp.reshape(-1, 3) - to.reshape(-1, 3), axis=1).max() <= pose_bar
+        assert np.abs(sp - so).max() <= 1e-3
