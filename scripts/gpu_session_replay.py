@@ -1,0 +1,53 @@
+"""The reference's REAL workload: a session streamed through the trigger (csrc/host/PoseGraphSLAM.cpp), one solve per wake-up with a new
+loop edge, each limited to 10 LM iterations and warm-started from the previous solution.  Per trigger: libpgo wall time (graph rebuild +
+upload + solve + write-back) next to the CPU oracle solving the SAME accumulated problem from the SAME initial guess."""
+import json, sys, time
+sys.path.insert(0, '/root/repo')
+import numpy as np
+from oracle import binding as ob
+from solve_keyframe_pose_graph_amd import graphgen
+from solve_keyframe_pose_graph_amd.pose_graph_slam import PoseGraphSLAM
+from tests import util
+
+n, loops, every = (int(sys.argv[1]) if len(sys.argv) > 1 else 3000), (int(sys.argv[2]) if len(sys.argv) > 2 else 600), (int(sys.argv[3]) if len(sys.argv) > 3 else 100)
+g = graphgen.generate(n, loops, odom_f_max=5, apply_yaw_weight=1, seed=5, **graphgen._SMALL)
+w_M = util.poses_to_matrices(g.init_q, g.init_t)
+order = np.argsort(np.maximum(g.loop_c1, g.loop_c2), kind="stable")
+S = PoseGraphSLAM()
+O = ob.OracleProblem()
+k, rows, n_edges_prev = 0, [], 0
+for i in range(n):
+    S.add_node(0, w_M[i])
+    while k < len(order) and max(g.loop_c1[order[k]], g.loop_c2[order[k]]) <= i:
+        e = order[k]
+        S.add_loop_edge(int(g.loop_c2[e]), int(g.loop_c1[e]), g.loop_T[e], 1.0)
+        k += 1
+    if (i + 1) % every == 0 or i == n - 1:
+        t0 = time.perf_counter()
+        if not S.reinit_ceres_problem_onnewloopedge_optimize6DOF_once():
+            continue
+        gpu_ms = (time.perf_counter() - t0) * 1e3
+        sm = S.summary()
+        # the same accumulated problem for the oracle: the residual blocks the trigger added since the last solve
+        c1, c2, w, sw = S.added_edges()
+        new = slice(n_edges_prev, len(c1)); n_edges_prev = len(c1)
+        lo = [j for j in range(new.start, new.stop) if sw[j] >= 0]
+        od = [j for j in range(new.start, new.stop) if sw[j] < 0]
+        if lo:
+            O.add_switchable_edges(c1[lo], c2[lo], g.loop_T[order[[sw[j] for j in lo]]], w[lo], sw[lo])
+        if od:
+            T = np.array([(np.linalg.inv(w_M[c1[j]].reshape(4, 4).T) @ w_M[c2[j]].reshape(4, 4).T).flatten(order="F") for j in od])
+            O.add_relpose_edges(c1[od], c2[od], T, w[od])
+        node, rw, rT = S.regularizers()
+        O.set_node_regularizers(node, rT, rw)
+        q0, t0_ = S.initial_guess()
+        s0 = np.full(k, 0.99) if not rows else np.concatenate([s_prev, np.full(k - len(s_prev), 0.99)])
+        t1 = time.perf_counter()
+        qo, to, so, sumo = O.solve(q0, t0_, s0)
+        cpu_ms = (time.perf_counter() - t1) * 1e3
+        s_prev = np.array([S.get_loopedge_switching_variable_val(e) for e in range(k)])
+        rows.append({"keyframes": i + 1, "loop_edges": k, "edges": len(c1), "gpu_ms": gpu_ms, "gpu_lm": sm.num_iterations, "gpu_cg": int(sm.cg_iterations), "cpu_ms": cpu_ms,
+                     "cpu_lm": sumo.num_iterations, "gpu_cost": sm.final_cost, "cpu_cost": sumo.final_cost})
+        print(json.dumps(rows[-1]), flush=True)
+print(json.dumps({"triggers": len(rows), "gpu_total_ms": sum(r["gpu_ms"] for r in rows), "cpu_total_ms": sum(r["cpu_ms"] for r in rows),
+                  "max_rel_cost_diff": max(abs(r["gpu_cost"] - r["cpu_cost"]) / max(r["cpu_cost"], 1e-12) for r in rows)}))
