@@ -212,7 +212,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "C3 x %d: synthetic 3D Manhattan graph, %d poses / %d edges (%d odometry f=1,2 + %d switchable loop closures, 10%% outliers) + %d regulariser(s)"
                                    % (scale, g.n_poses, n_edges, g.n_odom, g.n_loops, len(g.reg_node)),
-                       "poses": g.n_poses, "edges": n_edges, "sharding": ("edges by the '%s' policy (sharding.py): %d..%d edges and %d..%d keyframes per rank, %d of %d keyframes shared between ranks; one %s all-reduce of 6 x shared + 1 doubles per CG matvec, one scalar per CG iteration"
+                       "poses": g.n_poses, "edges": n_edges, "sharding": ("edges by the '%s' policy (sharding.py): %d..%d edges and %d..%d keyframes per rank, %d of %d keyframes shared between ranks; one %s all-reduce of 6 x shared + 2 doubles per CG iteration"
                                                                        % (args.partition, min(shard_stats["edges_per_rank"]), max(shard_stats["edges_per_rank"]), min(shard_stats["keyframes_per_rank"]), max(shard_stats["keyframes_per_rank"]),
                                                                           shard_stats["shared_keyframes"], g.n_poses, args.collective)) if world > 1 else "single GPU",
                        "linear_solver": "PCG, 6x6 block-Jacobi, Schur-reduced pose system, %s matvec" % ("matrix-free" if P.options.linear_solver == 1 else "block-CSR"), "cg_rel_tolerance": P.options.cg_rel_tolerance,

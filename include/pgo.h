@@ -251,9 +251,9 @@ int pgo_apply_normal_operator(pgo_problem* p, const double* x, double* y);
  * bytes; every rank then calls pgo_comm_init.  After that the edges added on this rank are this
  * rank's SHARD and the handle works on the keyframes those edges touch (a rank-local subgraph).
  * Keyframes touched by two or more ranks are shared: only THEIR rows travel — diagonal blocks +
- * gradient once per linearisation, the CG matvec output (6 doubles per shared keyframe, plus the
- * p.Ap partial) once per CG iteration in a single ncclAllReduce(sum, fp64) over xGMI, and one
- * scalar all-reduce per CG iteration for r.z.  Deal the edges out with locality (sharding.py:
+ * gradient once per linearisation, and per CG iteration the matvec output (6 doubles per shared
+ * keyframe) with both dot products of the iteration riding along, in a single
+ * ncclAllReduce(sum, fp64) over xGMI (the PCG runs in Chronopoulos-Gear form on several ranks).  Deal the edges out with locality (sharding.py:
  * `spatial`) to keep the shared set small.  The contract on every rank: the same n_nodes / n_switch,
  * the same initial arrays, the same constant keyframes, every switch index on exactly one rank; a
  * rank without edges is fine.  pgo_solve returns the COMPLETE solution on every rank (each

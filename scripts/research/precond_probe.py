@@ -448,3 +448,33 @@ def probe9(n, radii, ms=(4, 8, 16, 32)):
             M = ClusterBlocks(A, N, lab)
             x2, k2 = pcg(A, b, M, 1e-8, maxit=20000)
             print('   graph clusters <= %d keyframes (%d clusters): its %d' % (m, lab.max() + 1, k2), flush=True)
+
+
+def pcg_cg(A, b, M, tol, maxit=20000):
+    """Chronopoulos-Gear PCG: ONE synchronisation point per iteration (both dot products right after the matvec)"""
+    x = np.zeros_like(b); r = b.copy(); u = M(r); w = A @ u
+    gam = r @ u; dlt = w @ u; gam0 = gam
+    p = np.zeros_like(b); s = np.zeros_like(b); al = gam / dlt; be = 0.0; k = 0
+    while k < maxit:
+        p = u + be * p; s = w + be * s
+        x += al * p; r -= al * s
+        u = M(r); w = A @ u
+        gam_new = r @ u; dlt = w @ u; k += 1
+        if gam_new <= tol * tol * gam0: break
+        be = gam_new / gam; al = gam_new / (dlt - be * gam_new / al); gam = gam_new
+    return x, k, np.linalg.norm(b - A @ x) / np.linalg.norm(b)
+
+
+def probe10(n, radii):
+    g = graphgen.generate(n, n, odom_f_max=2, seed=3)
+    q, t, s = util.initial_state(g, True)
+    N = g.n_poses
+    for radius in radii:
+        A, b = build_system(g, q, t, s, radius)
+        Dinv = block_diag_inv(A, N)
+        M = lambda r: Dinv @ r
+        for tol in (1e-9, 1e-12):
+            x, k = pcg(A, b, M, tol, maxit=60000)
+            x2, k2, res2 = pcg_cg(A, b, M, tol, maxit=60000)
+            print('radius %g tol %g: PCG its %d true res %.1e | CG-CG its %d true res %.1e  dx %.1e' % (radius, tol, k, np.linalg.norm(b - A @ x) / np.linalg.norm(b), k2, res2,
+                  np.abs(x2 - x).max() / np.abs(x).max()), flush=True)

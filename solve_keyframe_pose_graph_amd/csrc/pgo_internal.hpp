@@ -120,16 +120,15 @@ void launch_scale_init(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, i
 void launch_lm_diag(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, double min_diag, double max_diag, hipStream_t st);
 void launch_build_rows(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, double radius, int add_lambda, double* lam_out /*null: write BSR blocks*/, hipStream_t st);
 void launch_mf_compact(const GraphDev& G, const MfDev& F, const double* pose8, const double* sw, hipStream_t st);
-void launch_mf_spmv(const GraphDev& G, const MfDev& F, const ScaleDev& Sc, const CgDev& C, int k, double tol2, hipStream_t st, int n_rz_partials = 0);
+void launch_mf_spmv(const GraphDev& G, const MfDev& F, const ScaleDev& Sc, const CgDev& C, int k, double tol2, hipStream_t st);
 void launch_mf_apply(const GraphDev& G, const MfDev& F, const ScaleDev& Sc, const CgDev& C, const double* x, double* y, hipStream_t st);
 void launch_invert_rows(const GraphDev& G, const CgDev& C, int32_t* fail_flag, hipStream_t st);
 void launch_cg_init(const GraphDev& G, const CgDev& C, int warm /*x holds a previous solution, q = A x*/, double tol2, hipStream_t st);
-// multi-GPU: the two halves of cg_init, so that the owner-weighted partial sums can be summed over ranks in between
-int launch_cg_init_vectors(const GraphDev& G, const CgDev& C, int warm, hipStream_t st);   // returns the number of partials written to part_rz / part_pq
-void launch_cg_init_scalars(const CgDev& C, int nparts, double tol2, hipStream_t st);
+// multi-GPU: the vector half of cg_init (owner-weighted partials of r.u in part_rz and of b.M^-1 b in part_pq); returns their count
+int launch_cg_init_vectors(const GraphDev& G, const CgDev& C, int warm, hipStream_t st);
 void launch_cg_set_tolerance(const CgDev& C, double tol2, hipStream_t st);
-void launch_cg_spmv(const GraphDev& G, const CgDev& C, int k, double tol2, hipStream_t st, int n_rz_partials = 0);   // iteration k: direction + matvec (+ convergence test)
-void launch_cg_update(const GraphDev& G, const CgDev& C, int k, int n_pq_partials, hipStream_t st, int n_rz_partials = 0);
+void launch_cg_spmv(const GraphDev& G, const CgDev& C, int k, double tol2, hipStream_t st);   // iteration k: direction + matvec (+ convergence test)
+void launch_cg_update(const GraphDev& G, const CgDev& C, int k, int n_pq_partials, hipStream_t st);
 int cg_grid_size(const GraphDev& G);
 int mf_grid_size(const MfDev& F);
 void launch_apply_operator(const GraphDev& G, const CgDev& C, const double* x, double* y, hipStream_t st);
@@ -145,8 +144,11 @@ void launch_unpack_k1(const GraphDev& G, int kind, int64_t first, int64_t count,
 // multi-GPU exchange of the keyframes shared between ranks: buf[pos[j]*K + off + c] <-> src[loc[j]*k + c], c < k
 void launch_pack_rows(double* buf, int K, int off, const double* src, int k, int64_t n, const int32_t* loc, const int32_t* pos, hipStream_t st);
 void launch_unpack_rows(const double* buf, int K, int off, double* dst, int k, int64_t n, const int32_t* loc, const int32_t* pos, const int32_t* stop /*nullable device flag: skip when set*/, hipStream_t st);
-void launch_cg_reduce_live(const CgDev& C, const double* partials, int n, double* out, hipStream_t st);
-void launch_cg_commit_live(const CgDev& C, const double* src, double* dst, hipStream_t st);
+// multi-GPU PCG in Chronopoulos-Gear form (one collective per iteration): see pgo_kernels.hip
+void launch_cgcg_dots(const GraphDev& G, const CgDev& C, hipStream_t st);                                     // part_pq[block] = partial of u.w
+void launch_cg_reduce2_live(const CgDev& C, const double* pa, int na, const double* pb, int nb, double* out, hipStream_t st);
+void launch_cgcg_update(const GraphDev& G, const CgDev& C, int k, int first, hipStream_t st);
+void launch_cgcg_scalars_init(const CgDev& C, const double* bb_src, double tol2, hipStream_t st);
 // write-back: owned keyframes of the rank-local (quat[n][4], t[n][3]) into zero-initialised global arrays
 void launch_scatter_owned_pose(const double* quat, const double* t, int64_t n, const int32_t* l2g, const double* own, double* gquat, double* gt, hipStream_t st);
 // K0: graph construction from raw VIO poses

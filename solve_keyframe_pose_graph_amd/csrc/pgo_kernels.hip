@@ -850,6 +850,106 @@ __global__ __launch_bounds__(CG_BLOCK) void cg_update_kernel(GraphDev G, CgDev C
     if (threadIdx.x == 0) C.part_rz[(parity ^ 1) * MAX_PARTIALS + blockIdx.x] = s;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Multi-GPU PCG: Chronopoulos-Gear form of the same block-Jacobi PCG.  Both dot products of an iteration — gamma = r.u (u = M^-1 r,
+// owner-weighted partials left by the previous update) and delta = u.(A u) = sum over ranks of u.(A_r u) (rank-local partials) — are
+// available right after the matvec, so they ride on the ONE all-reduce that sums the shared rows of w = A u:
+//     w = A u ; [gamma, delta, shared rows of w] summed over ranks ;
+//     beta = gamma/gamma_prev ; alpha = gamma / (delta - beta gamma / alpha_prev) ; p = u + beta p ; s = w + beta s ;
+//     x += alpha p ; r -= alpha s ; u = M^-1 r
+// Same iterates as the standard recurrence in exact arithmetic; measured on the C3-structured 20k system: same iteration counts and
+// true residuals down to 1e-12 (scripts/research/precond_probe.py::probe10).  Scalars live in C.scal[8..15]:
+//     [8 + 2*parity] gamma, [9 + 2*parity] alpha of the iteration with that parity ; [12] delta, [13] gamma as exchanged.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(CG_BLOCK) void cgcg_dots_kernel(GraphDev G, CgDev C) {
+    __shared__ double red[CG_BLOCK / 64];
+    const int64_t rows = G.N * 6;
+    double d = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * CG_BLOCK + threadIdx.x; i < rows; i += (int64_t)gridDim.x * CG_BLOCK) d += C.z[i] * C.q[i];
+    const double s = block_sum(d, red);
+    if (threadIdx.x == 0) C.part_pq[blockIdx.x] = s;
+}
+// out[0] = sum pa, out[1] = sum pb — or zeros once the PCG has stopped (a stopped PCG keeps its state; the exchanged scalars are scratch)
+__global__ void cg_reduce2_live_kernel(CgDev C, const double* __restrict__ pa, int na, const double* __restrict__ pb, int nb, double* __restrict__ out) {
+    __shared__ double red[8];
+    const bool stopped = C.flags[0] != 0;
+    double a = 0.0, b = 0.0;
+    if (!stopped) block_total2(pa, na, pb, nb, red, a, b);
+    if (threadIdx.x == 0) { out[0] = a; out[1] = b; }
+}
+__global__ __launch_bounds__(CG_BLOCK) void cgcg_update_kernel(GraphDev G, CgDev C, int parity, int first) {
+    if (cg_done(C)) return;
+    const double delta = C.scal[12], gamma = C.scal[13];
+    double beta = 0.0, den = delta;
+    const bool breakdown = C.flags[1] != 0;
+    if (breakdown || !(gamma > C.scal[3] * C.scal[0])) {   // converged (or broken down): the state stays that of the last completed update
+        if (blockIdx.x == 0 && threadIdx.x == 0) { C.flags[0] = 1; if (!breakdown) C.scal[1] = gamma; }
+        return;
+    }
+    if (!first) {
+        const double gamma_prev = C.scal[8 + 2 * (parity ^ 1)], alpha_prev = C.scal[9 + 2 * (parity ^ 1)];
+        beta = gamma / gamma_prev;
+        den = delta - beta * gamma / alpha_prev;
+    }
+    if (!(den > 0.0)) {   // not positive definite along the direction (or NaN)
+        if (blockIdx.x == 0 && threadIdx.x == 0) { C.flags[1] = 1; C.flags[0] = 1; }
+        return;
+    }
+    const double alpha = gamma / den;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { C.scal[8 + 2 * parity] = gamma; C.scal[9 + 2 * parity] = alpha; C.scal[1] = gamma; C.flags[2] += 1; }
+    __shared__ double red[CG_BLOCK / 64];
+    constexpr int KF = CG_BLOCK / 3;
+    __shared__ double2 rnew[CG_BLOCK];
+    __shared__ __attribute__((aligned(16))) float lfs[KF * LF_STRIDE];
+    double2* __restrict__ rv = reinterpret_cast<double2*>(C.r);
+    double2* __restrict__ pv = reinterpret_cast<double2*>(C.p);
+    double2* __restrict__ sv = reinterpret_cast<double2*>(C.p2);    // the standard form's second direction buffer holds s = A p here
+    const double2* __restrict__ wv = reinterpret_cast<const double2*>(C.q);
+    double2* __restrict__ xv = reinterpret_cast<double2*>(C.x);
+    double2* __restrict__ uv = reinterpret_cast<double2*>(C.z);
+    const int64_t pairs = G.N * 3;
+    const int64_t stride = (int64_t)gridDim.x * CG_BLOCK;
+    const int64_t trips = (pairs + stride - 1) / stride;
+    double acc = 0.0;
+    for (int64_t it = 0; it < trips; ++it) {
+        const int64_t base = it * stride + (int64_t)blockIdx.x * CG_BLOCK;
+        const int64_t i = base + threadIdx.x;
+        const bool live = i < pairs;
+        double2 rr = make_double2(0.0, 0.0);
+        if (live) {
+            const double2 u = uv[i], w = wv[i];
+            double2 pp = pv[i], ss = sv[i], xx = xv[i];
+            rr = rv[i];
+            pp.x = u.x + beta * pp.x; pp.y = u.y + beta * pp.y;
+            ss.x = w.x + beta * ss.x; ss.y = w.y + beta * ss.y;
+            xx.x += alpha * pp.x; xx.y += alpha * pp.y;
+            rr.x -= alpha * ss.x; rr.y -= alpha * ss.y;
+            pv[i] = pp; sv[i] = ss; xv[i] = xx; rv[i] = rr;
+        }
+        __syncthreads();
+        lf_stage<KF>(C.Lf, base / 3, G.N, lfs);
+        rnew[threadIdx.x] = rr;
+        __syncthreads();
+        if (live) {
+            const int j = (int)(i % 3);
+            const double2 u = lf_apply_pair(lfs + (threadIdx.x / 3) * LF_STRIDE, reinterpret_cast<const double*>(rnew + (threadIdx.x - j)), j);
+            uv[i] = u;
+            const double wgt = G.own ? G.own[i / 3] : 1.0;
+            acc += wgt * (rr.x * u.x + rr.y * u.y);
+        }
+    }
+    const double sum = block_sum(acc, red);
+    if (threadIdx.x == 0) C.part_rz[blockIdx.x] = sum;
+}
+// bb = b.M^-1 b (already summed over ranks at src[0]) -> scal[0]; tolerance, flags
+__global__ void cgcg_scalars_init_kernel(CgDev C, const double* __restrict__ bb_src, double tol2) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const double bb = bb_src[0];
+        C.scal[0] = bb; C.scal[1] = 0.0; C.scal[2] = 0.0; C.scal[3] = tol2;
+        C.flags[0] = bb > 0.0 ? 0 : 1; C.flags[1] = 0; C.flags[2] = 0;
+    }
+}
+
 // grid capped at MAX_PARTIALS workgroups (grid-stride beyond).  Measured on C3 (3125 workgroups of work): the ragged 1024-workgroup
 // grid (68 us / PCG iteration) beats both a balanced 782 x 4 trips (76 us) and 384-thread workgroups with 1563 partials (80 us).
 static inline int cg_grid(const GraphDev& G) {
@@ -875,17 +975,20 @@ int launch_cg_init_vectors(const GraphDev& G, const CgDev& C, int warm, hipStrea
     hipLaunchKernelGGL(cg_init_kernel, dim3(g), dim3(CG_BLOCK), 0, st, G, C, warm);
     return g;
 }
-void launch_cg_init_scalars(const CgDev& C, int nparts, double tol2, hipStream_t st) { hipLaunchKernelGGL(cg_scalars_init_kernel, dim3(1), dim3(256), 0, st, C, nparts, tol2); }
-// n_rz_partials: how many r.z partial sums the consumers re-reduce (0 = one per cg_update workgroup; multi-GPU passes 1: the partials
-// were summed over workgroups AND ranks into slot 0)
-void launch_cg_spmv(const GraphDev& G, const CgDev& C, int k, double tol2, hipStream_t st, int n_rz_partials) {
+void launch_cg_spmv(const GraphDev& G, const CgDev& C, int k, double tol2, hipStream_t st) {
     const int g = cg_grid(G);
-    hipLaunchKernelGGL(cg_spmv_kernel, dim3(g), dim3(CG_BLOCK), 0, st, G, C, k & 1, k == 0 ? 1 : 0, n_rz_partials > 0 ? n_rz_partials : g, tol2);
+    hipLaunchKernelGGL(cg_spmv_kernel, dim3(g), dim3(CG_BLOCK), 0, st, G, C, k & 1, k == 0 ? 1 : 0, g, tol2);
 }
-void launch_cg_update(const GraphDev& G, const CgDev& C, int k, int n_pq_partials, hipStream_t st, int n_rz_partials) {
+void launch_cg_update(const GraphDev& G, const CgDev& C, int k, int n_pq_partials, hipStream_t st) {
     const int g = cg_grid(G);
-    hipLaunchKernelGGL(cg_update_kernel, dim3(g), dim3(CG_BLOCK), 0, st, G, C, k & 1, n_pq_partials, n_rz_partials > 0 ? n_rz_partials : g);
+    hipLaunchKernelGGL(cg_update_kernel, dim3(g), dim3(CG_BLOCK), 0, st, G, C, k & 1, n_pq_partials, g);
 }
+void launch_cgcg_dots(const GraphDev& G, const CgDev& C, hipStream_t st) { hipLaunchKernelGGL(cgcg_dots_kernel, dim3(cg_grid(G)), dim3(CG_BLOCK), 0, st, G, C); }
+void launch_cg_reduce2_live(const CgDev& C, const double* pa, int na, const double* pb, int nb, double* out, hipStream_t st) {
+    hipLaunchKernelGGL(cg_reduce2_live_kernel, dim3(1), dim3(256), 0, st, C, pa, na, pb, nb, out);
+}
+void launch_cgcg_update(const GraphDev& G, const CgDev& C, int k, int first, hipStream_t st) { hipLaunchKernelGGL(cgcg_update_kernel, dim3(cg_grid(G)), dim3(CG_BLOCK), 0, st, G, C, k & 1, first); }
+void launch_cgcg_scalars_init(const CgDev& C, const double* bb_src, double tol2, hipStream_t st) { hipLaunchKernelGGL(cgcg_scalars_init_kernel, dim3(1), dim3(64), 0, st, C, bb_src, tol2); }
 int cg_grid_size(const GraphDev& G) { return cg_grid(G); }
 void launch_apply_operator(const GraphDev& G, const CgDev& C, const double* x, double* y, hipStream_t st) { hipLaunchKernelGGL(apply_operator_kernel, dim3(cg_grid(G)), dim3(CG_BLOCK), 0, st, G, C, x, y); }
 
@@ -1038,11 +1141,10 @@ int mf_grid_size(const MfDev& F) { return mf_grid(F); }
 void launch_mf_compact(const GraphDev& G, const MfDev& F, const double* pose8, const double* sw, hipStream_t st) {
     if (F.ninc > 0) hipLaunchKernelGGL(mf_compact_kernel, dim3((unsigned)((F.ninc + 255) / 256)), dim3(256), 0, st, G, F, pose8, sw);
 }
-void launch_mf_spmv(const GraphDev& G, const MfDev& F, const ScaleDev& Sc, const CgDev& C, int k, double tol2, hipStream_t st, int n_rz_partials) {
+void launch_mf_spmv(const GraphDev& G, const MfDev& F, const ScaleDev& Sc, const CgDev& C, int k, double tol2, hipStream_t st) {
     const int g = mf_grid(F);
     // the partial-sum count consumed here is the one cg_init / cg_update produced (cg_grid); the one produced is mf_grid
-    hipLaunchKernelGGL(mf_spmv_kernel<true>, dim3(g), dim3(MF_BLOCK), 0, st, G, F, Sc, C, (const double*)nullptr, (double*)nullptr, k & 1, k == 0 ? 1 : 0,
-                       n_rz_partials > 0 ? n_rz_partials : cg_grid(G), tol2);
+    hipLaunchKernelGGL(mf_spmv_kernel<true>, dim3(g), dim3(MF_BLOCK), 0, st, G, F, Sc, C, (const double*)nullptr, (double*)nullptr, k & 1, k == 0 ? 1 : 0, cg_grid(G), tol2);
 }
 void launch_mf_apply(const GraphDev& G, const MfDev& F, const ScaleDev& Sc, const CgDev& C, const double* x, double* y, hipStream_t st) {
     hipLaunchKernelGGL(mf_spmv_kernel<false>, dim3(mf_grid(F)), dim3(MF_BLOCK), 0, st, G, F, Sc, C, x, y, 0, 1, 0, 0.0);
@@ -1365,24 +1467,6 @@ void launch_pack_rows(double* buf, int K, int off, const double* src, int k, int
 void launch_unpack_rows(const double* buf, int K, int off, double* dst, int k, int64_t n, const int32_t* loc, const int32_t* pos, const int32_t* stop, hipStream_t st) {
     if (n > 0) hipLaunchKernelGGL(unpack_rows_kernel, dim3((unsigned)((n * k + 255) / 256)), dim3(256), 0, st, buf, K, off, dst, k, n, loc, pos, stop);
 }
-// PCG scalars across ranks: partial sums -> one scalar in scratch (skipped once the PCG has stopped), all-reduce of the scratch, then the
-// total is committed to slot 0 of the partial array the consumers re-reduce — again only while the PCG is live, so that a stopped PCG
-// keeps the sums of its last completed iteration.
-__global__ void cg_reduce_live_kernel(CgDev C, const double* __restrict__ partials, int n, double* __restrict__ out) {
-    __shared__ double red[4];
-    const bool stopped = C.flags[0] != 0;
-    double v = 0.0;
-    if (!stopped) for (int i = threadIdx.x; i < n; i += blockDim.x) v += partials[i];
-    v = wave_sum(v);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) out[0] = stopped ? 0.0 : red[0] + red[1] + red[2] + red[3];
-}
-__global__ void cg_commit_live_kernel(CgDev C, const double* __restrict__ src, double* __restrict__ dst) {
-    if (threadIdx.x == 0 && C.flags[0] == 0) dst[0] = src[0];
-}
-void launch_cg_reduce_live(const CgDev& C, const double* partials, int n, double* out, hipStream_t st) { hipLaunchKernelGGL(cg_reduce_live_kernel, dim3(1), dim3(256), 0, st, C, partials, n, out); }
-void launch_cg_commit_live(const CgDev& C, const double* src, double* dst, hipStream_t st) { hipLaunchKernelGGL(cg_commit_live_kernel, dim3(1), dim3(64), 0, st, C, src, dst); }
 __global__ void scatter_owned_pose_kernel(const double* __restrict__ quat, const double* __restrict__ t, int64_t n, const int32_t* __restrict__ l2g,
                                           const double* __restrict__ own, double* __restrict__ gquat, double* __restrict__ gt) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -429,7 +429,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S) {
     HIPCHK(p, p->d_cgvec.ensure(std::max<int64_t>(N * 42, 1)));
     p->n_part = std::max<int64_t>(MAX_PARTIALS, (G.rel.tiles + G.sw.tiles + 3) / 4 + 1);
     HIPCHK(p, p->d_part.ensure(p->n_part * 6));
-    HIPCHK(p, p->d_cgpart.ensure(MF_MAX_GRID + 2 * MAX_PARTIALS + 8));
+    HIPCHK(p, p->d_cgpart.ensure(MF_MAX_GRID + 2 * MAX_PARTIALS + 16));   // partial sums + 16 PCG scalars (C.scal)
     HIPCHK(p, p->d_flags.ensure(8)); HIPCHK(p, p->d_scal.ensure(S_N));
     for (int k = 0; k < 2; ++k) { HIPCHK(p, p->d_pose[k].ensure(std::max<int64_t>(N * 8, 1))); HIPCHK(p, p->d_swv[k].ensure(std::max<int64_t>(S, 1))); }
     HIPCHK(p, p->d_delta_s.ensure(std::max<int64_t>(Es, 1))); HIPCHK(p, p->d_io.ensure(std::max<int64_t>(N * 7, 1)));
@@ -582,21 +582,19 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
         else launch_apply_operator(p->G, p->C, p->C.x, p->C.q, p->st);
         if ((rc0 = exchange_rows(p, p->C.q, 6, nullptr, 0, nullptr, 0)) != PGO_OK) return rc0;
     }
-    // Multi-GPU: every dot product is an owner-weighted (r.z) or rank-local (p.A_r p) partial sum; it is reduced over the workgroups into
-    // slot 0 of its partial array, summed over ranks, and the consumers re-reduce ONE partial.
+    // Multi-GPU: the PCG runs in Chronopoulos-Gear form (pgo_kernels.hip): per iteration ONE all-reduce carries the shared rows of
+    // w = A u together with gamma = r.u (owner-weighted partials of the previous update) and delta = u.A u (rank-local partials).
     const bool multi = p->local_ids;
-    const int n_rz = multi ? 1 : 0;
     if (resume_from < 0) {
         if (!multi) launch_cg_init(p->G, p->C, warm ? 1 : 0, tol2, p->st);
         else {
+            // r = b (- A x), u = M^-1 r, p = s = 0; part_rz <- owner-weighted partials of gamma_0 (they travel with the first exchange),
+            // part_pq <- partials of b.M^-1 b, summed over ranks here once: the reference norm of the stopping test
             const int g = launch_cg_init_vectors(p->G, p->C, warm ? 1 : 0, p->st);
-            double* two = p->C.scal + 4;                      // scratch behind the four PCG scalars
-            launch_reduce(p->C.part_rz, g, 0, two, p->st);
-            launch_reduce(p->C.part_pq, g, 0, two + 1, p->st);
-            if ((rc0 = allreduce(p, two, 2, 0)) != PGO_OK) return rc0;
-            HIPCHK(p, hipMemcpyAsync(p->C.part_rz, two, sizeof(double), hipMemcpyDeviceToDevice, p->st));
-            HIPCHK(p, hipMemcpyAsync(p->C.part_pq, two + 1, sizeof(double), hipMemcpyDeviceToDevice, p->st));
-            launch_cg_init_scalars(p->C, 1, tol2, p->st);
+            double* bb = p->C.scal + 12;
+            launch_reduce(p->C.part_pq, g, 0, bb, p->st);
+            if ((rc0 = allreduce(p, bb, 1, 0)) != PGO_OK) return rc0;
+            launch_cgcg_scalars_init(p->C, bb, tol2, p->st);
         }
     }
     int k = resume_from >= 0 ? resume_from : 0;
@@ -604,28 +602,24 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
     double hscal[3] = {0, 0, 0};
     int every = std::max(2, o.cg_check_every) & ~1;   // even: the r/p ping-pong parity repeats from chunk to chunk
     int rc;
+    const bool fresh = resume_from < 0;
     auto one_iteration = [&](int kk) -> int {
-        int n_pq = cg_grid_size(p->G);
-        if (p->built_mf) { launch_mf_spmv(p->G, p->F, p->Sc, p->C, kk, tol2, p->st, n_rz); n_pq = mf_grid_size(p->F); }
-        else launch_cg_spmv(p->G, p->C, kk, tol2, p->st, n_rz);
         if (multi) {
-            // the ONE exchange per CG matvec: q = sum over ranks of A_r p on the shared keyframes, with p.Ap = sum_r p.(A_r p) riding along
-            double* tmp = p->C.scal + 6;
-            launch_cg_reduce_live(p->C, p->C.part_pq, n_pq, tmp, p->st);
-            int r2 = exchange_rows(p, p->C.q, 6, nullptr, 0, tmp, 1, p->C.flags);
+            if (p->built_mf) launch_mf_apply(p->G, p->F, p->Sc, p->C, p->C.z, p->C.q, p->st);
+            else launch_apply_operator(p->G, p->C, p->C.z, p->C.q, p->st);
+            launch_cgcg_dots(p->G, p->C, p->st);
+            const int g = cg_grid_size(p->G);
+            double* two = p->C.scal + 12;                                  // [delta, gamma]
+            launch_cg_reduce2_live(p->C, p->C.part_pq, g, p->C.part_rz, g, two, p->st);
+            int r2 = exchange_rows(p, p->C.q, 6, nullptr, 0, two, 2, p->C.flags);   // the ONE exchange per CG iteration
             if (r2 != PGO_OK) return r2;
-            launch_cg_commit_live(p->C, tmp, p->C.part_pq, p->st);
-            n_pq = 1;
+            launch_cgcg_update(p->G, p->C, kk, fresh && kk == 0 ? 1 : 0, p->st);
+            return PGO_OK;
         }
-        launch_cg_update(p->G, p->C, kk, n_pq, p->st, n_rz);
-        if (multi) {   // r.z of the new residual: owner-weighted partials -> one scalar over ranks
-            double* rz = p->C.part_rz + (size_t)((kk & 1) ^ 1) * MAX_PARTIALS;
-            double* tmp = p->C.scal + 7;
-            launch_cg_reduce_live(p->C, rz, cg_grid_size(p->G), tmp, p->st);
-            int r2 = allreduce(p, tmp, 1, 0);
-            if (r2 != PGO_OK) return r2;
-            launch_cg_commit_live(p->C, tmp, rz, p->st);
-        }
+        int n_pq = cg_grid_size(p->G);
+        if (p->built_mf) { launch_mf_spmv(p->G, p->F, p->Sc, p->C, kk, tol2, p->st); n_pq = mf_grid_size(p->F); }
+        else launch_cg_spmv(p->G, p->C, kk, tol2, p->st);
+        launch_cg_update(p->G, p->C, kk, n_pq, p->st);
         return PGO_OK;
     };
     // hipGraph: capture one chunk (iterations 2 .. 2+every-1: no `first` kernel, even start) once per graph build and replay it
@@ -684,10 +678,10 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
         HIPCHK(p, hipMemcpyAsync(hscal, p->C.scal, sizeof(hscal), hipMemcpyDeviceToHost, p->st));
         HIPCHK(p, hipStreamSynchronize(p->st));
     }
-    if (!hflags[0]) {   // iteration cap reached: one more convergence test so that scal[1] holds the last r.z (x is already final)
+    if (!hflags[0] && !multi) {   // iteration cap reached: one more convergence test so that scal[1] holds the last r.z (x is already final)
         launch_cg_set_tolerance(p->C, 1e300, p->st);
-        if (p->built_mf) launch_mf_spmv(p->G, p->F, p->Sc, p->C, k, 1e300, p->st, n_rz);
-        else launch_cg_spmv(p->G, p->C, k, 1e300, p->st, n_rz);
+        if (p->built_mf) launch_mf_spmv(p->G, p->F, p->Sc, p->C, k, 1e300, p->st);
+        else launch_cg_spmv(p->G, p->C, k, 1e300, p->st);
         HIPCHK(p, hipMemcpyAsync(hflags, p->C.flags, sizeof(hflags), hipMemcpyDeviceToHost, p->st));
         HIPCHK(p, hipMemcpyAsync(hscal, p->C.scal, sizeof(hscal), hipMemcpyDeviceToHost, p->st));
         HIPCHK(p, hipStreamSynchronize(p->st));

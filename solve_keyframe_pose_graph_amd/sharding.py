@@ -1,7 +1,7 @@
 """Edge sharding for multi-GPU solves.  Residual blocks are the independent units: every rank adds a subset of the
 edges to its own libpgo handle.  Inside libpgo a rank then works on the keyframes ITS edges touch (a rank-local subgraph); keyframes
-touched by two or more ranks are "shared" and only their rows travel: one all-reduce of 6 x n_shared (+1) doubles per CG matvec, one
-scalar per CG iteration for r.z, 42 x n_shared twice per LM iteration.  How the edges are dealt out therefore decides the exchange
+touched by two or more ranks are "shared" and only their rows travel: ONE all-reduce of 6 x n_shared + 2 doubles per CG iteration
+(both dot products ride along), 42 x n_shared twice per LM iteration.  How the edges are dealt out therefore decides the exchange
 volume — the policies here differ only in that:
 
   contiguous   a contiguous index range of every edge class per rank (what a caller gets without thinking; loop closures land on

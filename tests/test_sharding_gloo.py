@@ -2,8 +2,9 @@
 it and works on the keyframes those edges touch (rank-local subgraph); keyframes touched by >= 2 ranks are shared and ONLY their rows
 travel.  With the oracle standing in for the kernels (no GPU in this container) the test replays the collectives libpgo issues —
 touch counts (sum) and lowest touching rank (max) at graph build, shared rows of diagonal + gradient per linearisation, shared rows
-of the CG matvec output with the rank-local p.Ap partial riding along, owner-weighted scalar sums, owner-wise write-back — and
-checks every rank ends up with the single-rank numbers on ITS keyframes."""
+of the CG matvec output with BOTH dot products of the iteration riding along (the rank-local partial of u.Au and the owner-weighted
+partial of r.u: the Chronopoulos-Gear form needs no other collective), owner-wise write-back — and checks every rank ends up with the
+single-rank numbers on ITS keyframes."""
 import os
 import socket
 
@@ -100,16 +101,15 @@ def _worker(rank, world, port, policy, out):
     y = rows(_reduced_operator(H, N, owned_sw, radius, x_l), 6)
     y[mine] += own_w[:, None] * lam * rows(x, 6)[mine]
     assert np.abs(np.delete(y, mine, axis=0)).max(initial=0.0) == 0.0     # A_r only reaches the rank's own keyframes
-    pAp_local = float((rows(x, 6)[mine] * y[mine]).sum())
-    got, extra = _exchange_rows(y[mine_shared], pos_of[mine_shared], len(shared), 6, [pAp_local])
+    pAp_local = float((rows(x, 6)[mine] * y[mine]).sum())                       # rank-local partial: sum over ranks = x.Ax
+    xx_local = float((own_w[:, None] * rows(x, 6)[mine] ** 2).sum())           # owner-weighted partial: every keyframe counted once
+    got, extra = _exchange_rows(y[mine_shared], pos_of[mine_shared], len(shared), 6, [pAp_local, xx_local])   # ONE all-reduce
     y[mine_shared] = got
-    # ---- owner-weighted scalar (r.z, norms): one more scalar all-reduce
-    xx = torch.tensor([float((own_w[:, None] * rows(x, 6)[mine] ** 2).sum())], dtype=torch.float64); dist.all_reduce(xx)
     # ---- write-back: owners scatter their keyframes into a zeroed global array, one all-reduce replicates it
     wb = torch.zeros(N, 6, dtype=torch.float64)
     wb[mine[own_w > 0]] = torch.from_numpy(y[mine[own_w > 0]])
     dist.all_reduce(wb)
-    np.savez(out % rank, cost=tc.numpy(), mine=mine, grad=grad_l, diag=diag_l, y=y[mine], pAp=extra, xx=xx.numpy(), y_all=wb.numpy(), n_shared=len(shared))
+    np.savez(out % rank, cost=tc.numpy(), mine=mine, grad=grad_l, diag=diag_l, y=y[mine], pAp=extra[:1], xx=extra[1:], y_all=wb.numpy(), n_shared=len(shared))
     dist.destroy_process_group()
 
 
