@@ -1026,6 +1026,22 @@ __global__ __launch_bounds__(MF_BLOCK) void mf_spmv_kernel(GraphDev G, MfDev F, 
     __shared__ double red[2 * (MF_BLOCK / 64)];
     const int l = threadIdx.x;
     double beta = 0.0;
+    const double* __restrict__ pprev = FUSED ? (parity ? C.p : C.p2) : xin;
+    const double* __restrict__ z = FUSED ? C.z : xin;
+    // the first tile's bounds and phase-0 operands do not depend on beta: request them BEFORE the partial-sum re-reduction so that its
+    // dependent L2 round trips overlap with theirs (two registers; the records stay behind the reduction — hoisting them spills)
+    double v0_first = 0.0, v1_first = 0.0;
+    {
+        const int tile = blockIdx.x;
+        if (tile < F.tiles) {
+            const int32_t n0 = F.tile_node0[tile], n1 = F.tile_node0[tile + 1];
+            if (l < (n1 - n0) * 6) {
+                const size_t vi = (size_t)n0 * 6 + l;
+                v0_first = z[vi];
+                if (FUSED) v1_first = pprev[vi];
+            }
+        }
+    }
     if (FUSED) {
         if (cg_done(C)) return;
         if (!first) {
@@ -1041,9 +1057,7 @@ __global__ __launch_bounds__(MF_BLOCK) void mf_spmv_kernel(GraphDev G, MfDev F, 
         }
         if (blockIdx.x == 0 && threadIdx.x == 0) C.flags[2] += 1;
     }
-    const double* __restrict__ pprev = FUSED ? (parity ? C.p : C.p2) : xin;
     double* __restrict__ pcur = parity ? C.p2 : C.p;
-    const double* __restrict__ z = FUSED ? C.z : xin;
     double pq = 0.0;
     for (int tile = blockIdx.x; tile < F.tiles; tile += gridDim.x) {
         const int64_t i0 = F.tile_inc0[tile], i1 = F.tile_inc0[tile + 1];
@@ -1054,9 +1068,13 @@ __global__ __launch_bounds__(MF_BLOCK) void mf_spmv_kernel(GraphDev G, MfDev F, 
         // phase 0: the tile's own keyframes' input vector p = z + beta p_prev, once, into LDS (every edge side of a keyframe needs it,
         // and odometry neighbours are inside the same window): only far endpoints of loop closures gather from global memory
         if (l < nn * 6) {
-            const size_t vi = (size_t)n0 * 6 + l;
-            double v = z[vi];
-            if (FUSED) v += beta * pprev[vi];
+            double v;
+            if (tile == (int)blockIdx.x) v = FUSED ? v0_first + beta * v1_first : v0_first;
+            else {
+                const size_t vi = (size_t)n0 * 6 + l;
+                v = z[vi];
+                if (FUSED) v += beta * pprev[vi];
+            }
             pwin[l] = v;
         }
         __syncthreads();
