@@ -205,3 +205,25 @@ def test_unreferenced_keyframes_and_hub_fallback():
     qp, tp, sp, sump = P.solve(q, t, s)
     assert abs(sump.final_cost - sumo.final_cost) <= 1e-6 * sumo.final_cost
     assert np.abs(tp - to).max() <= 1e-3
+
+
+def test_full_graph_cost_and_gradient_match_the_independent_goldens():
+    """libpgo's evaluate (K1 + K2 through the C-ABI) against tests/golden/graph_goldens.json — whole-graph cost and sampled gradient rows
+    computed at 50 digits without the oracle (generator: tests/golden/make_graph_goldens.py)."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "graph_goldens.json")) as f:
+        gold = json.load(f)
+    for c in gold["graphs"]:
+        g = graphgen.config(c["config"])
+        q, t, s = util.initial_state(g, True, perturb=c["perturb"], seed=c["seed"])
+        P = util.pgo_problem(g, True)
+        cost, res, grad = P.evaluate(q, t, s)
+        P.close()
+        assert len(res) == c["n_residuals"]
+        assert abs(cost - c["cost"]) <= 1e-13 * c["cost"]
+        scale = np.abs(grad).max()
+        for n, row in zip(c["nodes"], c["node_gradient"]):
+            assert np.abs(grad[6 * n:6 * n + 6] - np.array(row)).max() <= 1e-12 * scale, (c["config"], n)
+        for k, v in zip(c["switches"], c["switch_gradient"]):
+            assert abs(grad[6 * g.n_poses + k] - v) <= 1e-12 * scale, (c["config"], k)

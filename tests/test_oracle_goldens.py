@@ -91,3 +91,25 @@ def test_reference_weight_tables():
         assert abs(w - want) <= 0.006 * max(want, 1e-9) + 1e-12
     # regulariser weight max(1.1, ln(1 + end - start) / 2) (:1839): 5.4099 for a 50k-node world
     assert abs(max(1.1, np.log(1 + 49999) / 2) - 5.4099) < 1e-4
+
+
+def test_oracle_full_graph_cost_and_gradient_match_the_independent_goldens():
+    """tests/golden/graph_goldens.json: whole-graph cost (50-digit closed forms) and sampled gradient rows (50-digit central differences
+    through Plus) for C1 and its f = 1..5 variant at a perturbed state — pins the oracle's evaluate() beyond single residual blocks."""
+    import json
+    import os
+    from solve_keyframe_pose_graph_amd import graphgen
+    from tests import util
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "graph_goldens.json")) as f:
+        gold = json.load(f)
+    for c in gold["graphs"]:
+        g = graphgen.config(c["config"])
+        q, t, s = util.initial_state(g, True, perturb=c["perturb"], seed=c["seed"])
+        cost, res, grad = util.oracle_problem(g, True).evaluate(q, t, s)
+        assert len(res) == c["n_residuals"]
+        assert abs(cost - c["cost"]) <= 1e-13 * c["cost"]
+        scale = np.abs(grad).max()
+        for n, row in zip(c["nodes"], c["node_gradient"]):
+            assert np.abs(grad[6 * n:6 * n + 6] - np.array(row)).max() <= 1e-12 * scale, (c["config"], n)
+        for k, v in zip(c["switches"], c["switch_gradient"]):
+            assert abs(grad[6 * g.n_poses + k] - v) <= 1e-12 * scale, (c["config"], k)
