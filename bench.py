@@ -93,6 +93,12 @@ def main():
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
         args.gpus = world
 
+    # stdout carries exactly ONE line, the JSON of rank 0.  Native libraries print on stdout behind Python's back (librccl a version
+    # banner at exit, gloo its connection report), so file descriptor 1 is pointed at stderr for the whole run and the result line is
+    # written to a private duplicate of the original stdout.
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     dist = None
     device_index = local_rank
@@ -233,7 +239,7 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args.cpu_sample_poses, args.cpu_iters, 30.0)
             except Exception as e:   # the baseline is reported, never required for the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "LM iters/s (C3-equivalent)", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
-        print(json.dumps(out))
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         P.comm_destroy()
         dist.destroy_process_group()
