@@ -221,3 +221,49 @@ def test_cpp_example_replays_a_session_like_the_python_tool(tmp_path):
     assert a["nNodes"] == b["nNodes"] == g.n_poses
     assert np.abs(a["wTc_opt"] - b["wTc_opt"]).max() < 1e-9
     assert np.abs(a["switching_var_after_opt"] - b["switching_var_after_opt"]).max() < 1e-9
+
+
+def test_readers_run_concurrently_with_the_trigger_thread():
+    """The reference's threading contract: one thread runs the trigger, others read getNodePose / nNodes / solvedUntil /
+    get_loopedge_switching_variable_val under mutex_opt_vars at any time; the solve itself holds no lock and writes back once."""
+    import threading
+    g = util.small_graph(1500, 200, f=2, seed=41)
+    w_M = util.poses_to_matrices(g.init_q, g.init_t)
+    S = PoseGraphSLAM(max_num_iterations=10)
+    order = np.argsort(np.maximum(g.loop_c1, g.loop_c2), kind="stable")
+    stop = threading.Event()
+    seen = {"reads": 0, "bad": 0, "max_solved": -1}
+
+    def reader():
+        rng = np.random.default_rng(0)
+        while not stop.is_set():
+            n = S.nNodes()
+            su = S.solvedUntil()
+            seen["max_solved"] = max(seen["max_solved"], su)
+            if n > 0:
+                i = int(rng.integers(0, n))
+                if S.nodePoseExists(i):
+                    T = S.getNodePose(i)
+                    ok = np.isfinite(T).all() and abs(np.linalg.det(T[:3, :3]) - 1.0) < 1e-6 and np.array_equal(T[3], [0, 0, 0, 1])
+                    seen["bad"] += 0 if ok else 1
+                    seen["reads"] += 1
+            S.get_loopedge_switching_variable_val(0)
+    th = [threading.Thread(target=reader) for _ in range(3)]
+    for x in th:
+        x.start()
+    k = 0
+    try:
+        for i in range(g.n_poses):
+            S.add_node(0, w_M[i])
+            while k < len(order) and max(g.loop_c1[order[k]], g.loop_c2[order[k]]) <= i:
+                e = order[k]
+                S.add_loop_edge(int(g.loop_c2[e]), int(g.loop_c1[e]), g.loop_T[e], 1.0)
+                k += 1
+            if (i + 1) % 250 == 0:
+                S.reinit_ceres_problem_onnewloopedge_optimize6DOF_once()
+    finally:
+        stop.set()
+        for x in th:
+            x.join(timeout=60)
+    assert seen["reads"] > 100 and seen["bad"] == 0 and seen["max_solved"] == g.n_poses - 1
+    S.close()
