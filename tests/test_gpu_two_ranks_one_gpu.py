@@ -226,3 +226,50 @@ def test_c3_four_ranks_on_one_gpu_follow_the_single_rank_trajectory():
         assert abs(sumr.cg_iterations - sum1.cg_iterations) <= 0.02 * sum1.cg_iterations
         assert np.abs(tr - t1).max() <= 1e-4 and np.abs(sr - s1).max() <= 1e-4
     assert np.array_equal(out[0][1], out[3][1])
+
+
+@pytest.mark.parametrize("switchable", [True, False])
+def test_constant_keyframes_and_unused_switches_across_ranks(switchable):
+    """load_state semantics (SetParameterBlockConstant, reference src/PoseGraphSLAM.cpp:143-144) on three ranks: the constant keyframes
+    are shared between ranks here, stay bit-exact, and the solve equals the single-rank one; unused switch slots pass through."""
+    g = util.small_graph(400, 60, f=2, seed=29)
+    q, t, s = util.initial_state(g, switchable)
+    if switchable:
+        s = np.concatenate([s, [0.5, 0.25]])
+    const = [0, 1, 150, 151, 399]
+    opts = dict(cg_rel_tolerance=1e-12, cg_max_iterations=20000, max_num_iterations=30, function_tolerance=1e-10)
+    P = util.pgo_problem(g, switchable, **opts)
+    P.set_nodes_constant(const)
+    q1, t1, s1, sum1 = P.solve(q, t, s)
+    P.close()
+    world = 3
+    parts = sharding.partition(g, world, "chain")
+    ar = InProcessAllReduce(world)
+    out = [None] * world
+    err = []
+
+    def run(rank):
+        try:
+            Pr = capi.problem_from_graph(g, switchable=switchable, edge_slice=parts[rank], **opts)
+            Pr.set_nodes_constant(const)                       # the same list on every rank
+            Pr.comm_init_custom(rank, world, ar.make(rank))
+            out[rank] = Pr.solve(q, t, s)
+            Pr.comm_destroy()
+            Pr.close()
+        except Exception as e:
+            err.append(e)
+            ar.barrier.abort()
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join(timeout=600)
+    assert not err, err
+    for r in range(world):
+        qr, tr, sr, sumr = out[r]
+        assert np.array_equal(qr.reshape(-1, 4)[const], q[const]) and np.array_equal(tr.reshape(-1, 3)[const], t[const])
+        assert sumr.num_iterations == sum1.num_iterations
+        assert abs(sumr.final_cost - sum1.final_cost) <= 1e-9 * sum1.final_cost
+        assert np.abs(tr - t1).max() <= 1e-7
+        if switchable:
+            assert sr[-2] == 0.5 and sr[-1] == 0.25 and np.abs(sr - s1).max() <= 1e-7
