@@ -478,3 +478,18 @@ def probe10(n, radii):
             x2, k2, res2 = pcg_cg(A, b, M, tol, maxit=60000)
             print('radius %g tol %g: PCG its %d true res %.1e | CG-CG its %d true res %.1e  dx %.1e' % (radius, tol, k, np.linalg.norm(b - A @ x) / np.linalg.norm(b), k2, res2,
                   np.abs(x2 - x).max() / np.abs(x).max()), flush=True)
+
+
+def probe11(n, radii, ms=(4, 4, 4, 4, 4)):
+    """V / W / K cycles at full size (the three heavy steps of the C3 trajectory run at radius 1e4, 3e4, 9e4)"""
+    g = graphgen.generate(n, n, odom_f_max=2, seed=3)
+    q, t, s = util.initial_state(g, True)
+    N = g.n_poses
+    for radius in radii:
+        A, b = build_system(g, q, t, s, radius)
+        Dinv = block_diag_inv(A, N)
+        t0 = time.time(); x, k = pcg(A, b, lambda r: Dinv @ r, 1e-9, maxit=60000); print('n %d radius %g  block-Jacobi its %d (%.0fs)' % (n, radius, k, time.time() - t0), flush=True)
+        M = MGList(A, t, list(ms))
+        t0 = time.time(); x2, k2 = pcg(A, b, M, 1e-9, maxit=5000); print('   V(1,1) ms=%s: its %d (%.0fs) err %.1e' % (list(ms), k2, time.time() - t0, np.abs(x2 - x).max() / np.abs(x).max()), flush=True)
+        M = MGK(A, t, list(ms))
+        t0 = time.time(); x3, k3 = fpcg(A, b, M, 1e-9); print('   K-cycle: its %d (%.0fs) err %.1e' % (k3, time.time() - t0, np.abs(x3 - x).max() / np.abs(x).max()), flush=True)
