@@ -602,7 +602,6 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
     double hscal[3] = {0, 0, 0};
     int every = std::max(2, o.cg_check_every) & ~1;   // even: the r/p ping-pong parity repeats from chunk to chunk
     int rc;
-    const bool fresh = resume_from < 0;
     auto one_iteration = [&](int kk) -> int {
         if (multi) {
             if (p->built_mf) launch_mf_apply(p->G, p->F, p->Sc, p->C, p->C.z, p->C.q, p->st);
@@ -613,7 +612,7 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
             launch_cg_reduce2_live(p->C, p->C.part_pq, g, p->C.part_rz, g, two, p->st);
             int r2 = exchange_rows(p, p->C.q, 6, nullptr, 0, two, 2, p->C.flags);   // the ONE exchange per CG iteration
             if (r2 != PGO_OK) return r2;
-            launch_cgcg_update(p->G, p->C, kk, fresh && kk == 0 ? 1 : 0, p->st);
+            launch_cgcg_update(p->G, p->C, kk, kk == 0 ? 1 : 0, p->st);   // also when a PCG that stopped before its first update is resumed: p = s = 0 still
             return PGO_OK;
         }
         int n_pq = cg_grid_size(p->G);
