@@ -195,6 +195,16 @@ def main():
     k1c_ms, k1c_bytes = P.time_kernel(3, 50)
     qf, tf, sf, summ = P.solve_end()
 
+    # ---- the same K iterations once more INCLUDING the host<->device transfers and the write-back; never `value`
+    barrier(); sync()
+    t_incl = time.perf_counter()
+    P.solve_begin(q0, t0_, s0)
+    for _ in range(args.steps):
+        P.lm_step(ignore_termination=True)
+    P.solve_end()
+    sync(); barrier()
+    elapsed_incl = time.perf_counter() - t_incl
+
     traffic = None
     try:
         if not (scale == 1 and args.poses_per_gpu == C3_POSES):
@@ -224,6 +234,7 @@ def main():
                        "linear_solver": "PCG, 6x6 block-Jacobi, Schur-reduced pose system, %s matvec" % ("matrix-free" if P.options.linear_solver == 1 else "block-CSR"), "cg_rel_tolerance": P.options.cg_rel_tolerance,
                        "cg_max_iterations": P.options.cg_max_iterations},
             "lm_iters_per_s_raw": ips,
+            "lm_iters_per_s_including_transfers": args.steps / elapsed_incl * scale,   # upload of the state, K iterations, write-back (rank 0's clock)
             "chi2_initial": 2.0 * summ.initial_cost, "chi2_final": 2.0 * summ.final_cost,
             "lm_successful_steps": summ.num_successful_steps, "cg_iterations_total": int(summ.cg_iterations),
             "cg_iterations_per_step": [it.cg_iterations for it in its[1:]],
