@@ -953,8 +953,8 @@ __global__ void cgcg_scalars_init_kernel(CgDev C, const double* __restrict__ bb_
 // grid capped at MAX_PARTIALS workgroups (grid-stride beyond).  Measured on C3 (3125 workgroups of work): the ragged 1024-workgroup
 // grid (68 us / PCG iteration) beats both a balanced 782 x 4 trips (76 us) and 384-thread workgroups with 1563 partials (80 us).
 static inline int cg_grid(const GraphDev& G) {
-    const int64_t rows = G.N * 6;
-    int64_t g = (rows + CG_BLOCK - 1) / CG_BLOCK;
+    const int64_t pairs = G.N * 3;       // cg_update: one lane per row pair -> one trip per workgroup up to MAX_PARTIALS * CG_BLOCK / 3 keyframes
+    int64_t g = (pairs + CG_BLOCK - 1) / CG_BLOCK;
     if (g > MAX_PARTIALS) g = MAX_PARTIALS;
     if (g < 1) g = 1;
     return (int)g;
