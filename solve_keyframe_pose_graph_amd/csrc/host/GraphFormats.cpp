@@ -290,6 +290,113 @@ bool load_posegraph_json(VectorGraphSource& src, const std::string& base_path, c
     return true;
 }
 
+// ------------------------------------------------------------------------------------------------ solved_posegraph.json
+namespace {
+std::string matrix_json(const Matrix4d& M) {   // RawFileIO::eigen_matrix_to_json: rows/cols/data with IOFormat(FullPrecision, DontAlignCols, ", ", "\n")
+    std::string data;
+    for (int r = 0; r < 4; ++r) {
+        for (int c = 0; c < 4; ++c) { data += num(M(r, c)); if (c < 3) data += ", "; }
+        if (r < 3) data += "\n";
+    }
+    return "{\"rows\": 4, \"cols\": 4, \"data\": \"" + json_escape(data) + "\", \"data_pretty\": \"" + json_escape(prettyprint_matrix4d(M)) + "\"}";
+}
+bool matrix_from_json(const JsonValue& v, Matrix4d& M) {   // RawFileIO::read_eigen_matrix4d_fromjson (src/utils/RawFileIO.cpp:372-409)
+    if (v.at("rows").as_int(0) != 4 || v.at("cols").as_int(0) != 4) return false;
+    const std::vector<std::string> rows = split(v.at("data").as_string(), '\n');
+    if (rows.size() != 4) return false;
+    for (int r = 0; r < 4; ++r) {
+        const std::vector<std::string> cols = split(rows[r], ',');
+        if (cols.size() != 4) return false;
+        for (int c = 0; c < 4; ++c) { char* e = nullptr; M(r, c) = std::strtod(cols[c].c_str(), &e); if (e == cols[c].c_str()) return false; }
+    }
+    return true;
+}
+long long to_nsec(double stamp_s) { return (long long)std::llround(stamp_s * 1e9); }
+}  // namespace
+
+bool save_solved_posegraph_json(const VectorGraphSource& src, const std::vector<Matrix4d>& w_T_c, const std::string& base_path) {
+    const int N = src.getNodeLen(), W = src.n_worlds();
+    if ((int)w_T_c.size() != N) return false;
+    std::ofstream f(base_path + "/solved_posegraph.json");
+    if (!f.is_open()) return false;
+    f << "{\n    \"SolvedPoseGraph\": [";
+    for (int i = 0; i < N; ++i) {
+        const int w = src.which_world_is_this_node(i);
+        f << (i ? ",\n" : "\n") << "        {\"w_T_c\": " << matrix_json(w_T_c[i]) << ", \"worldID\": " << w << ", \"setID_of_worldID\": " << src.find_setID_of_world_i(w)
+          << ", \"stampNSec\": " << to_nsec(src.getNodeTimestamp(i)) << ", \"seq\": " << i << "}";
+    }
+    f << "\n    ],\n    \"KidnapTimestamps\": {\"kidnap_starts\": [";
+    for (int w = 0; w + 1 < W; ++w) { const int a = src.nodeidx_of_world_i_ended(w); f << (w ? ", " : "") << "{\"stampNSec\": " << to_nsec(a >= 0 ? src.getNodeTimestamp(a) : 0.0) << "}"; }
+    f << "], \"kidnap_ends\": [";
+    for (int w = 0; w + 1 < W; ++w) { const int b = src.nodeidx_of_world_i_started(w + 1); f << (w ? ", " : "") << "{\"stampNSec\": " << to_nsec(b >= 0 ? src.getNodeTimestamp(b) : 0.0) << "}"; }
+    f << "]},\n    \"WorldsData\": {\n        \"rel_pose_between_worlds__wb_T_wa\": [";
+    std::string log, debug;
+    bool first = true;
+    for (int w = 0; w < W; ++w) { log += "add_element:" + std::to_string(w) + ";"; debug += "\t\t\tadd_element( " + std::to_string(w) + ")\n"; }
+    for (int w = 0; w < W; ++w) {
+        const int root = src.find_setID_of_world_i(w);
+        if (root < 0 || root == w) continue;
+        f << (first ? "\n" : ",\n") << "            {\"node_b\": " << root << ", \"node_a\": " << w << ", \"wb_T_wa\": " << matrix_json(src.getPoseBetweenWorlds(root, w))
+          << ", \"info_wb_T_wa\": \"merged\"}";
+        first = false;
+        log += "union_sets:" + std::to_string(std::max(w, root)) + "," + std::to_string(std::min(w, root)) + ";";
+        debug += "\t\t\tunion_sets( " + std::to_string(std::max(w, root)) + "," + std::to_string(std::min(w, root)) + ")\n";
+    }
+    f << (first ? "" : "\n        ") << "],\n        \"vec_world_starts\": [";
+    for (int w = 0; w < W; ++w) { const int a = src.nodeidx_of_world_i_started(w); f << (w ? ", " : "") << "{\"stampNSec\": " << to_nsec(a >= 0 ? src.getNodeTimestamp(a) : 0.0) << "}"; }
+    f << "],\n        \"vec_world_ends\": [";
+    for (int w = 0; w < W; ++w) { const int a = src.nodeidx_of_world_i_ended(w); f << (w ? ", " : "") << "{\"stampNSec\": " << to_nsec(a >= 0 ? src.getNodeTimestamp(a) : 0.0) << "}"; }
+    f << "],\n        \"disjoint_set\": {\"debug_string\": \"" << json_escape(debug) << "\", \"log_string\": \"" << json_escape(log) << "\"}\n    }\n}\n";
+    return f.good();
+}
+
+bool load_solved_posegraph_json(VectorGraphSource& src, std::vector<Matrix4d>& w_T_c, const std::string& base_path, std::string* err) {
+    std::string dummy;
+    std::string& e = err ? *err : dummy;
+    std::ifstream f(base_path + "/solved_posegraph.json");
+    if (!f.is_open()) { e = "cannot open " + base_path + "/solved_posegraph.json"; return false; }
+    std::stringstream ss;
+    ss << f.rdbuf();
+    JsonValue all;
+    if (!json_parse(ss.str(), all, &e)) return false;
+    const JsonValue& nodes = all.at("SolvedPoseGraph");
+    if (nodes.kind != JsonValue::Array) { e = "SolvedPoseGraph missing"; return false; }
+    src.reset();
+    w_T_c.clear();
+    for (size_t i = 0; i < nodes.size(); ++i) {
+        const JsonValue& n = nodes.at(i);
+        Matrix4d T;
+        if (!matrix_from_json(n.at("w_T_c"), T)) { e = "SolvedPoseGraph[" + std::to_string(i) + "].w_T_c is not a 4x4 matrix"; src.reset(); w_T_c.clear(); return false; }
+        if (n.at("seq").as_int((int)i) != (int)i) { e = "SolvedPoseGraph is not in seq order"; src.reset(); w_T_c.clear(); return false; }
+        src.add_node(n.at("worldID").as_int(0), T, n.at("stampNSec").as_double(0.0) * 1e-9);
+        w_T_c.push_back(T);
+    }
+    // world merges: replay the union log with the stored relative poses (Worlds::loadStateFromDisk, reference src/Worlds.cpp:519-667)
+    const JsonValue& wd = all.at("WorldsData");
+    const JsonValue& rel = wd.at("rel_pose_between_worlds__wb_T_wa");
+    std::map<std::pair<int, int>, Matrix4d> poses;
+    for (size_t k = 0; k < rel.size(); ++k) {
+        Matrix4d T;
+        if (!matrix_from_json(rel.at(k).at("wb_T_wa"), T)) { e = "rel_pose_between_worlds__wb_T_wa[" + std::to_string(k) + "] is not a 4x4 matrix"; src.reset(); w_T_c.clear(); return false; }
+        poses[{rel.at(k).at("node_b").as_int(-1), rel.at(k).at("node_a").as_int(-1)}] = T;
+    }
+    for (const std::string& cmd : split(wd.at("disjoint_set").at("log_string").as_string(), ';')) {
+        if (cmd.size() < 4) continue;
+        const std::vector<std::string> sp = split(cmd, ':');
+        if (sp.size() != 2 || (sp[0] != "add_element" && sp[0] != "union_sets")) { e = "unknown disjoint-set command `" + cmd + "`"; src.reset(); w_T_c.clear(); return false; }
+        if (sp[0] == "add_element") continue;                  // worlds exist as soon as a keyframe names them
+        const std::vector<std::string> ops = split(sp[1], ',');
+        if (ops.size() != 2) { e = "union_sets needs two operands: `" + cmd + "`"; src.reset(); w_T_c.clear(); return false; }
+        const int x = std::atoi(ops[0].c_str()), y = std::atoi(ops[1].c_str());
+        const int b = std::min(x, y), a = std::max(x, y);
+        auto it = poses.find({b, a});
+        if (it != poses.end()) src.setPoseBetweenWorlds(b, a, it->second);
+        else if ((it = poses.find({a, b})) != poses.end()) src.setPoseBetweenWorlds(a, b, it->second);
+        else { e = "no relative pose stored for the merged worlds " + std::to_string(b) + " and " + std::to_string(a); src.reset(); w_T_c.clear(); return false; }
+    }
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------------ g2o
 bool export_g2o(const std::string& path, const std::vector<Matrix4d>& poses, const std::vector<G2oEdge>& edges) {
     std::FILE* f = std::fopen(path.c_str(), "w");

@@ -49,6 +49,20 @@ bool save_posegraph_json(const VectorGraphSource& src, const std::string& base_p
 // the edge timestamps against the node timestamps like the reference (:659-666, :736-747) — returning false instead of exit(1).
 bool load_posegraph_json(VectorGraphSource& src, const std::string& base_path, const std::vector<bool>& edge_mask, std::string* err);
 
+// solved_posegraph.json — the saved state of a finished session that the reference writes in Composer::saveStateToDisk and reads back in
+// Composer::loadStateFromDisk to continue on top of a previous map (reference src/Composer.cpp:952-1177, src/Worlds.cpp:449-667):
+//   SolvedPoseGraph[{w_T_c{rows, cols, data, data_pretty}, worldID, setID_of_worldID, stampNSec, seq}]  corrected keyframe poses
+//   KidnapTimestamps{kidnap_starts[{stampNSec}], kidnap_ends[{stampNSec}]}
+//   WorldsData{rel_pose_between_worlds__wb_T_wa[{node_b, node_a, wb_T_wa{rows, cols, data, data_pretty}, info_wb_T_wa}],
+//              vec_world_starts[{stampNSec}], vec_world_ends[{stampNSec}], disjoint_set{debug_string, log_string}}
+// Matrices use RawFileIO::eigen_matrix_to_json's layout (entries ", "-separated, rows "\n"-separated); the disjoint set travels as the
+// replayable command log "add_element:k;union_sets:max,min;" the reference parses (Worlds.cpp:560-640).
+bool save_solved_posegraph_json(const VectorGraphSource& src, const std::vector<Matrix4d>& w_T_c, const std::string& base_path);
+// Rebuilds a source from the file: one keyframe per SolvedPoseGraph entry (its corrected pose stands in for the odometry pose of the
+// loaded map, its world and stamp restored), the world merges replayed from WorldsData; w_T_c receives the corrected poses — the
+// caller marks those keyframes constant like PoseGraphSLAM::load_state (reference src/PoseGraphSLAM.cpp:143-144 -> pgo_set_nodes_constant).
+bool load_solved_posegraph_json(VectorGraphSource& src, std::vector<Matrix4d>& w_T_c, const std::string& base_path, std::string* err);
+
 // g2o export of a solved or unsolved graph: one VERTEX_SE3:QUAT per pose (x y z qx qy qz qw), one EDGE_SE3:QUAT per edge (c1 -> c2
 // with the measurement c1_T_c2) and the 21 upper-triangular entries of the information matrix of (dt, dq.vec): w^2 on translation,
 // 4 w^2 on the quaternion vector part (the reference residual is [dt; 2 dq.vec]·w, g2o's is [dt; dq.vec]).

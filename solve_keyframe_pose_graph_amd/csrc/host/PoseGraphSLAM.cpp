@@ -89,6 +89,31 @@ void PoseGraphSLAM::allocate_and_append_new_edge_switch_var() {
     _opt_switch_.push_back(0.99);   // reference src/PoseGraphSLAM.cpp:353
 }
 
+bool PoseGraphSLAM::load_state(bool optimization_variable_as_constants) {
+    if (!problem_) return false;
+    if (!optimization_variable_as_constants) return true;          // the solver thread picks such keyframes up by itself (:60-63)
+    const int node_len = manager->getNodeLen();
+    std::vector<int32_t> constant;
+    for (int yp = n_opt_variables(); yp < node_len; ++yp) {
+        const int world = manager->which_world_is_this_node(yp);
+        const int set_id = manager->find_setID_of_world_i(world);
+        Matrix4d ws_T_w = Matrix4d::Identity();
+        if (world >= 0 && world != set_id) {
+            if (!manager->is_exist(set_id, world)) { last_rc_ = PGO_ERR_STATE; return false; }   // the reference exit(1)s here (:96-101)
+            ws_T_w = manager->getPoseBetweenWorlds(set_id, world);
+        }
+        allocate_and_append_new_opt_variable_withpose(ws_T_w * manager->getNodePose(yp));            // (:103-114)
+        constant.push_back(yp);
+    }
+    if (!constant.empty()) last_rc_ = pgo_set_nodes_constant(problem_, (int64_t)constant.size(), constant.data());   // (:143-144)
+    {
+        std::lock_guard<std::mutex> lk(mutex_opt_vars);
+        solved_until = node_len - 1;                                                                  // (:158)
+    }
+    prev_node_len = node_len;
+    return last_rc_ == PGO_OK;
+}
+
 bool PoseGraphSLAM::reinit_ceres_problem_onnewloopedge_optimize6DOF_once() {
     if (!problem_) return false;
     const int node_len = manager->getNodeLen();
@@ -343,7 +368,7 @@ void VectorGraphSource::getWorld2SetIDMap(std::map<int, int>& out) const {
 // thin C wrapper so the parity tests (pytest/ctypes) can drive the C++ host side
 // ================================================================================================
 using namespace pgo_host;
-struct pgo_host_session { VectorGraphSource src; PoseGraphSLAM* slam; };
+struct pgo_host_session { VectorGraphSource src; PoseGraphSLAM* slam; std::vector<Matrix4d> loaded_w_T_c; };
 
 extern "C" {
 pgo_host_session* pgo_host_create(const pgo_options* opt) {
@@ -388,6 +413,25 @@ int pgo_host_load_posegraph_json(pgo_host_session* s, const char* base_path, con
     if (!ok && err && err_cap > 0) std::snprintf(err, (size_t)err_cap, "%s", e.c_str());
     return ok ? 1 : 0;
 }
+// solved_posegraph.json (Composer::saveStateToDisk / loadStateFromDisk, reference src/Composer.cpp:952-1177): corrected poses = the
+// optimised ones when a solver is attached and has them, else the odometry poses
+int pgo_host_save_solved_posegraph_json(pgo_host_session* s, const char* base_path) {
+    std::vector<Matrix4d> poses;
+    for (int i = 0; i < s->src.getNodeLen(); ++i) poses.push_back((s->slam && s->slam->nodePoseExists(i)) ? s->slam->getNodePose(i) : s->src.getNodePose(i));
+    return save_solved_posegraph_json(s->src, poses, base_path) ? 1 : 0;
+}
+int pgo_host_load_solved_posegraph_json(pgo_host_session* s, const char* base_path, char* err, int err_cap) {
+    if (s->slam) { if (err && err_cap > 0) std::snprintf(err, (size_t)err_cap, "load into a source-only session, then attach the solver"); return 0; }
+    std::string e;
+    const bool ok = load_solved_posegraph_json(s->src, s->loaded_w_T_c, base_path, &e);
+    if (!ok && err && err_cap > 0) std::snprintf(err, (size_t)err_cap, "%s", e.c_str());
+    return ok ? 1 : 0;
+}
+int pgo_host_n_loaded_poses(pgo_host_session* s) { return (int)s->loaded_w_T_c.size(); }
+void pgo_host_get_loaded_pose(pgo_host_session* s, int i, double* T16) { std::copy(s->loaded_w_T_c[i].d.begin(), s->loaded_w_T_c[i].d.end(), T16); }
+int pgo_host_source_set_id_of_world(pgo_host_session* s, int w) { return s->src.find_setID_of_world_i(w); }
+void pgo_host_source_pose_between_worlds(pgo_host_session* s, int m, int n, double* T16) { const Matrix4d T = s->src.getPoseBetweenWorlds(m, n); std::copy(T.d.begin(), T.d.end(), T16); }
+void pgo_host_source_merge_worlds(pgo_host_session* s, int m, int n, const double* m_T_n16) { Matrix4d T; std::copy(m_T_n16, m_T_n16 + 16, T.d.begin()); s->src.setPoseBetweenWorlds(m, n, T); }
 // g2o export: keyframe poses = optimised when `optimized` and a solver is attached, else the VIO poses; edges = loop edges (b -> a, b_T_a,
 // unit weight: the switchable functor ignores its weight, CeresResidues.h:198) followed by the odometry edges of the reference policy
 // (f = 1..f_max, weight 0.9^f exp(-yaw^2/6)) for pairs whose endpoints are in live worlds
@@ -411,6 +455,7 @@ void pgo_host_add_node(pgo_host_session* s, int world, const double* T16) { Matr
 void pgo_host_add_loop_edge(pgo_host_session* s, int a, int b, const double* bTa16, double w) { Matrix4d T; std::copy(bTa16, bTa16 + 16, T.d.begin()); s->src.add_loop_edge(a, b, T, w); }
 void pgo_host_set_kidnapped(pgo_host_session* s, int k) { s->src.set_kidnapped(k != 0); }
 void pgo_host_set_device_graph_construction(pgo_host_session* s, int on) { s->slam->set_device_graph_construction(on != 0); }
+int pgo_host_load_state(pgo_host_session* s, int as_constants) { return (s->slam && s->slam->load_state(as_constants != 0)) ? 1 : 0; }
 int pgo_host_trigger(pgo_host_session* s) { return s->slam->reinit_ceres_problem_onnewloopedge_optimize6DOF_once() ? 1 : 0; }
 int pgo_host_n_nodes(pgo_host_session* s) { return s->slam->nNodes(); }
 int pgo_host_solved_until(pgo_host_session* s) { return s->slam->solvedUntil(); }

@@ -74,6 +74,13 @@ public:
     // poses by default; `false` computes them on the host thread like the reference — kept for the parity tests.
     void set_device_graph_construction(bool on) { device_graph_construction_ = on; }
 
+    // PoseGraphSLAM::load_state (reference src/PoseGraphSLAM.cpp:30-165): the keyframes the data source holds beyond the current
+    // optimisation variables are a previously solved map (e.g. from solved_posegraph.json).  Each becomes an optimisation variable at
+    // its pose in its world-set's frame (ws_T_w * w_T_c), marked constant when `optimization_variable_as_constants` (the reference's
+    // SetParameterBlockConstant, :143-144), and solved_until moves to the last of them — so the trigger adds no odometry residues among
+    // them and later loop closures localise new keyframes against the fixed map.
+    bool load_state(bool optimization_variable_as_constants = true);
+
     // One wake-up of the reference's trigger loop body.  Returns true when a solve ran.
     bool reinit_ceres_problem_onnewloopedge_optimize6DOF_once();
     int get_reinit_ceres_problem_onnewloopedge_optimize6DOF_status() const { return status_; }

@@ -86,6 +86,36 @@ class GraphSource:
     def export_g2o(self, path, optimized=False, f_max=5):
         return bool(self.lib.pgo_host_export_g2o(self.h, str(path).encode(), C.c_int(1 if optimized else 0), C.c_int(f_max)))
 
+    # ---- solved_posegraph.json: the saved state of a finished session (Composer::saveStateToDisk / loadStateFromDisk) ----
+    def save_solved_posegraph_json(self, base_path):
+        return bool(self.lib.pgo_host_save_solved_posegraph_json(self.h, str(base_path).encode()))
+
+    def load_solved_posegraph_json(self, base_path):
+        err = C.create_string_buffer(512)
+        if not self.lib.pgo_host_load_solved_posegraph_json(self.h, str(base_path).encode(), err, C.c_int(512)):
+            raise ValueError("solved_posegraph.json: " + err.value.decode())
+        return self
+
+    def loaded_poses(self):
+        """corrected poses w_T_c of the loaded map, n x 16 column-major (the keyframes a caller then marks constant)"""
+        n = self.lib.pgo_host_n_loaded_poses(self.h)
+        out = np.zeros((n, 16))
+        for i in range(n):
+            self.lib.pgo_host_get_loaded_pose(self.h, C.c_int(i), out[i].ctypes.data_as(_dp))
+        return out
+
+    def set_id_of_world(self, w):
+        return self.lib.pgo_host_source_set_id_of_world(self.h, C.c_int(w))
+
+    def pose_between_worlds(self, m, n):
+        T = np.zeros(16)
+        self.lib.pgo_host_source_pose_between_worlds(self.h, C.c_int(m), C.c_int(n), T.ctypes.data_as(_dp))
+        return T
+
+    def merge_worlds(self, m, n, m_T_n_colmajor16):
+        T = np.ascontiguousarray(m_T_n_colmajor16, dtype=np.float64)
+        self.lib.pgo_host_source_merge_worlds(self.h, C.c_int(m), C.c_int(n), T.ctypes.data_as(_dp))
+
     def attach_solver(self, **opt_kw):
         """-> PoseGraphSLAM over this source (needs a GPU).  The returned object owns the session."""
         opt = capi.default_options(**opt_kw)
@@ -133,6 +163,10 @@ class PoseGraphSLAM:
         self.lib.pgo_host_set_device_graph_construction(self.h, C.c_int(1 if on else 0))
 
     # ---- PoseGraphSLAM interface ----
+    def load_state(self, optimization_variable_as_constants=True):
+        """PoseGraphSLAM::load_state: the keyframes already in the data source are a previously solved map (kept constant)."""
+        return bool(self.lib.pgo_host_load_state(self.h, C.c_int(1 if optimization_variable_as_constants else 0)))
+
     def reinit_ceres_problem_onnewloopedge_optimize6DOF_once(self):
         return bool(self.lib.pgo_host_trigger(self.h))
 
@@ -184,6 +218,10 @@ class PoseGraphSLAM:
 
     def save_posegraph_json(self, base_path):
         return bool(self.lib.pgo_host_save_posegraph_json(self.h, str(base_path).encode()))
+
+    def save_solved_posegraph_json(self, base_path):
+        """Composer::saveStateToDisk's solved_posegraph.json with the optimised poses of this session"""
+        return bool(self.lib.pgo_host_save_solved_posegraph_json(self.h, str(base_path).encode()))
 
     def export_g2o(self, path, optimized=True, f_max=5):
         return bool(self.lib.pgo_host_export_g2o(self.h, str(path).encode(), C.c_int(1 if optimized else 0), C.c_int(f_max)))

@@ -267,3 +267,50 @@ def test_readers_run_concurrently_with_the_trigger_thread():
             x.join(timeout=60)
     assert seen["reads"] > 100 and seen["bad"] == 0 and seen["max_solved"] == g.n_poses - 1
     S.close()
+
+
+def test_continue_on_top_of_a_saved_map_load_state(tmp_path):
+    """The reference's relocalisation-in-a-previous-map flow: session A is solved and saved as solved_posegraph.json
+    (Composer::saveStateToDisk); session B loads it (loadStateFromDisk + PoseGraphSLAM::load_state: the old keyframes become CONSTANT
+    optimisation variables), drives on in a new world with its own odometry frame, and the first loop closures into the old map
+    merge the worlds and place the new keyframes in the old map's frame while the map itself stays bit-exact."""
+    from solve_keyframe_pose_graph_amd.pose_graph_slam import GraphSource
+    g = util.small_graph(160, 0, f=1, seed=8, turn_deg_per_keyframe=2.0)
+    truth = [T_of(g.truth_q[i], g.truth_t[i]) for i in range(160)]
+    # ---- session A: keyframes 0..79 with two loop closures, solved, saved
+    A = PoseGraphSLAM(max_num_iterations=20, cg_rel_tolerance=1e-12, cg_max_iterations=20000)
+    for i in range(80):
+        A.add_node(0, truth[i].flatten(order="F"))
+    A.add_loop_edge(70, 10, (np.linalg.inv(truth[10]) @ truth[70]).flatten(order="F"))
+    A.add_loop_edge(60, 25, (np.linalg.inv(truth[25]) @ truth[60]).flatten(order="F"))
+    assert A.reinit_ceres_problem_onnewloopedge_optimize6DOF_once()
+    old_map = np.array([A.getNodePose(i) for i in range(80)])
+    assert A.save_solved_posegraph_json(tmp_path)
+    A.close()
+    # ---- session B: load the map, continue in world 1 (odometry restarts at identity)
+    src = GraphSource().load_solved_posegraph_json(tmp_path)
+    assert src.n_nodes() == 80 and np.abs(src.loaded_poses().reshape(80, 4, 4).transpose(0, 2, 1) - old_map).max() < 1e-12
+    B = src.attach_solver(max_num_iterations=20, cg_rel_tolerance=1e-12, cg_max_iterations=20000)
+    assert B.load_state(True)
+    assert B.solvedUntil() == 79 and B.nNodes() == 80
+    as_loaded = np.array([B.getNodePose(i) for i in range(80)])
+    assert np.abs(as_loaded - old_map).max() < 1e-12           # matrix -> (xyzw, t) -> matrix round trip of the storage
+    for i in range(80, 160):
+        B.add_node(1, (np.linalg.inv(truth[80]) @ truth[i]).flatten(order="F"))
+    # loop closures from the new drive into the old map: a = new keyframe, b = old keyframe, b_T_a
+    for a, b in ((100, 20), (130, 50), (150, 75)):
+        B.add_loop_edge(a, b, (np.linalg.inv(truth[b]) @ truth[a]).flatten(order="F"))
+    assert B.reinit_ceres_problem_onnewloopedge_optimize6DOF_once()
+    # the loaded map is constant: bit-exact
+    now = np.array([B.getNodePose(i) for i in range(80)])
+    assert np.array_equal(now, as_loaded)
+    # no odometry residue was added among or onto the map's keyframes except the reference's u <-> u-f across the boundary
+    c1, c2, w, sw = B.added_edges()
+    odom = [(a, b) for a, b, s_ in zip(c1, c2, sw) if s_ < 0]
+    assert all(a >= 80 for a, b in odom) and min(a for a, b in odom) == 80
+    # the new keyframes land in the old map's frame (noise-free script -> close to the ground truth expressed in the map frame)
+    err = max(np.abs(B.getNodePose(i) - truth[i]).max() for i in range(80, 160))
+    assert err <= 1e-5, err
+    node, rw, _ = B.regularizers()
+    assert list(node) == [0]                      # merged into world 0's set: one regulariser, on the (constant) root keyframe
+    B.close()

@@ -118,3 +118,53 @@ def test_g2o_export_of_the_unsolved_graph(tmp_path):
     M = np.linalg.inv(w_M[int(eo[1])].reshape(4, 4).T) @ w_M[int(eo[2])].reshape(4, 4).T
     yaw = np.degrees(np.arctan2(M[1, 0], M[0, 0]))
     assert float(eo[10]) == pytest.approx((0.81 * np.exp(-yaw * yaw / 6)) ** 2, rel=1e-12)
+
+
+def test_solved_posegraph_json_has_the_reference_layout_and_restores_worlds(tmp_path):
+    """solved_posegraph.json (Composer::saveStateToDisk / loadStateFromDisk, reference src/Composer.cpp:952-1177, src/Worlds.cpp:449-667):
+    keys, the RawFileIO matrix layout, the replayable disjoint-set log, and a load that restores poses, stamps, worlds and merges."""
+    g, w_M, S = two_world_source()
+    # merge world 1 into world 0 the way the first inter-world loop edge does
+    w0_T_w1 = np.eye(4); w0_T_w1[:3, 3] = [1.5, -2.0, 0.25]; w0_T_w1[:3, :3] = [[0, -1, 0], [1, 0, 0], [0, 0, 1]]
+    S.merge_worlds(0, 1, w0_T_w1.flatten(order="F"))
+    assert S.set_id_of_world(1) == 0
+    assert S.save_solved_posegraph_json(tmp_path)
+    d = json.load(open(tmp_path / "solved_posegraph.json"))
+    assert set(d) == {"SolvedPoseGraph", "KidnapTimestamps", "WorldsData"}
+    n9 = d["SolvedPoseGraph"][9]
+    assert set(n9) == {"w_T_c", "worldID", "setID_of_worldID", "stampNSec", "seq"} and n9["seq"] == 9 and n9["worldID"] == 0
+    assert n9["stampNSec"] == int(round((100.0 + 0.25 * 9) * 1e9)) and d["SolvedPoseGraph"][60]["worldID"] == 1 and d["SolvedPoseGraph"][60]["setID_of_worldID"] == 0
+    m = n9["w_T_c"]
+    assert m["rows"] == 4 and m["cols"] == 4 and m["data"].count("\n") == 3 and ", " in m["data"]
+    got = np.array([[float(x) for x in row.split(",")] for row in m["data"].split("\n")])
+    assert np.array_equal(got, w_M[9].reshape(4, 4).T)                      # a source without a solver saves its odometry poses
+    wd = d["WorldsData"]
+    assert wd["disjoint_set"]["log_string"] == "add_element:0;add_element:1;union_sets:1,0;"
+    rel = wd["rel_pose_between_worlds__wb_T_wa"]
+    assert len(rel) == 1 and (rel[0]["node_b"], rel[0]["node_a"]) == (0, 1)
+    got = np.array([[float(x) for x in row.split(",")] for row in rel[0]["wb_T_wa"]["data"].split("\n")])
+    assert np.abs(got - w0_T_w1).max() < 1e-15
+    assert len(wd["vec_world_starts"]) == len(wd["vec_world_ends"]) == 2 and len(d["KidnapTimestamps"]["kidnap_starts"]) == 1
+    assert d["KidnapTimestamps"]["kidnap_starts"][0]["stampNSec"] == int(round((100.0 + 0.25 * 49) * 1e9))
+    # ---- load
+    L = GraphSource().load_solved_posegraph_json(tmp_path)
+    assert L.n_nodes() == g.n_poses and L.n_edges() == 0
+    P = L.loaded_poses()
+    assert np.array_equal(P, w_M)
+    for i in (0, 49, 50, 89):
+        w, st, T = L.node(i)
+        assert w == (0 if i < 50 else 1) and abs(st - (100.0 + 0.25 * i)) < 1e-9 and np.array_equal(T, w_M[i])
+    assert L.set_id_of_world(1) == 0 and np.abs(L.pose_between_worlds(0, 1).reshape(4, 4).T - w0_T_w1).max() < 1e-15
+    # ---- rejected inputs
+    bad = json.loads(json.dumps(d)); bad["WorldsData"]["disjoint_set"]["log_string"] = "add_element:0;frobnicate:1;"
+    (tmp_path / "bad").mkdir(); json.dump(bad, open(tmp_path / "bad" / "solved_posegraph.json", "w"))
+    with pytest.raises(ValueError, match="unknown disjoint-set command"):
+        GraphSource().load_solved_posegraph_json(tmp_path / "bad")
+    bad = json.loads(json.dumps(d)); bad["WorldsData"]["rel_pose_between_worlds__wb_T_wa"] = []
+    (tmp_path / "bad2").mkdir(); json.dump(bad, open(tmp_path / "bad2" / "solved_posegraph.json", "w"))
+    with pytest.raises(ValueError, match="no relative pose stored"):
+        GraphSource().load_solved_posegraph_json(tmp_path / "bad2")
+    bad = json.loads(json.dumps(d)); bad["SolvedPoseGraph"][3]["w_T_c"]["rows"] = 3
+    (tmp_path / "bad3").mkdir(); json.dump(bad, open(tmp_path / "bad3" / "solved_posegraph.json", "w"))
+    with pytest.raises(ValueError, match="not a 4x4"):
+        GraphSource().load_solved_posegraph_json(tmp_path / "bad3")
