@@ -968,7 +968,7 @@ void pgo_options_init(pgo_options* o) {
     o->function_tolerance = 1e-6;
     o->gradient_tolerance = 1e-10;
     o->parameter_tolerance = 1e-8;
-    o->cg_max_iterations = 4000;
+    o->cg_max_iterations = 50000;   // chain-like graphs need 5-15k iterations per step at large trust regions; capping them costs parity
     o->cg_check_every = 25;
     o->cg_warm_start = 1;
     o->cg_use_graph = 1;
