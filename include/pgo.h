@@ -96,6 +96,15 @@ typedef struct pgo_options {
     double cg_early_reject_rho;          /* -0.5: threshold of the first stage — far below min_relative_decrease because the step is still crude */
     double cg_mid_tolerance;             /* 1e-4: second stage (0 disables the stage) */
     double cg_mid_reject_rho;            /* -0.05: threshold of the second stage — the step is within ~1e-4 of the final one there */
+    /* Two-level preconditioner for large trust regions: block-Jacobi plus the rigid-body modes of `coarse_aggregates` aggregates of
+     * consecutive keyframes, the coarse operator formed and inverted densely (blocked Gauss-Jordan kernels) once per LM iteration.  It is used when the
+     * aggregates hold <= 64 keyframes each (small and mid-size graphs: 3-20x fewer PCG iterations at every radius) and otherwise for LM
+     * iterations whose trust-region radius is >= coarse_min_radius (aggregates up to 1024 keyframes), where the slow modes are the long
+     * wavelengths the coarse space removes (10-60x fewer iterations); with large aggregates at small radii it does not pay.  The solution of each step is the
+     * same to the PCG tolerance.  Single GPU only. */
+    int32_t coarse_aggregates;           /* 512 (coarse dimension 3072, 75 MB dense inverse); 0 disables */
+    int32_t reserved2_;
+    double coarse_min_radius;            /* 1e6 */
     /* device selection */
     int32_t device_id;                   /* -1: use the current HIP device */
     int32_t verbosity;                   /* 0 silent (minimizer_progress_to_stdout=false, :1271), 1 per-iteration line on stderr */

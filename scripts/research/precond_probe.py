@@ -493,3 +493,21 @@ def probe11(n, radii, ms=(4, 4, 4, 4, 4)):
         t0 = time.time(); x2, k2 = pcg(A, b, M, 1e-9, maxit=5000); print('   V(1,1) ms=%s: its %d (%.0fs) err %.1e' % (list(ms), k2, time.time() - t0, np.abs(x2 - x).max() / np.abs(x).max()), flush=True)
         M = MGK(A, t, list(ms))
         t0 = time.time(); x3, k3 = fpcg(A, b, M, 1e-9); print('   K-cycle: its %d (%.0fs) err %.1e' % (k3, time.time() - t0, np.abs(x3 - x).max() / np.abs(x).max()), flush=True)
+
+
+def probe12(n, radii, n_aggs=(128, 512, 2048)):
+    """two-level (block-Jacobi + one rigid-body coarse space solved exactly) at LARGE trust regions, where the slow modes are the long
+    wavelengths: does a coarse space small enough for a dense inverse pay there?"""
+    g = graphgen.generate(n, n, odom_f_max=2, seed=3)
+    q, t, s = util.initial_state(g, True)
+    N = g.n_poses
+    for radius in radii:
+        A, b = build_system(g, q, t, s, radius)
+        Dinv = block_diag_inv(A, N)
+        t0 = time.time(); x, k = pcg(A, b, lambda r: Dinv @ r, 1e-9, maxit=200000); print('n %d radius %g  block-Jacobi its %d (%.0fs)' % (n, radius, k, time.time() - t0), flush=True)
+        for na in n_aggs:
+            agg = np.arange(N) // int(np.ceil(N / na))
+            for mode in ('add', 'mult'):
+                M = TwoLevel(A, t, agg, Dinv, mode)
+                t0 = time.time(); x2, k2 = pcg(A, b, M, 1e-9, maxit=50000)
+                print('   chain aggregates %5d (coarse dim %5d) %-4s: its %5d (%.0fs) err %.1e' % (na, M.nc, mode, k2, time.time() - t0, np.abs(x2 - x).max() / np.abs(x).max()), flush=True)

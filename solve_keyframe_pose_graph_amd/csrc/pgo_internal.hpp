@@ -103,6 +103,24 @@ struct ScaleDev {
     double* a_inv;    // [Es]  1 / (hss + lambda_s)
 };
 
+// Two-level preconditioner (large trust regions): block-Jacobi PLUS one coarse space — the rigid-body modes of `n_agg` aggregates of
+// consecutive keyframes, z = D^-1 r + P Ac^-1 P^T r with Ac = P^T A P formed and inverted densely once per LM iteration.  Keyframe i
+// of aggregate a moves with the aggregate: dtheta_i = dtheta_a, dt_i = dt_a - 2 [d_i]x dtheta_a, d_i = t_i - centroid_a.
+struct CoarseDev {
+    int32_t n_agg, nc;            // aggregates, coarse unknowns (6 per aggregate)
+    int32_t m;                    // keyframes per aggregate: agg(i) = i / m
+    int32_t n_blk;                // coarse 6x6 blocks (a <= b) that receive contributions
+    double* cen;                  // [n_agg][3] centroid of the FREE keyframes of the aggregate
+    double* d;                    // [N][3]     t_i - centroid
+    double* Ac;                   // [nc][nc]   P^T A P, then its inverse (symmetric, full storage)
+    double* rc;                   // [nc]       P^T r
+    double* yc;                   // [nc]       Ac^-1 P^T r
+    const int64_t* blk_ptr;       // [n_blk+1]  contribution list of each coarse block
+    const int32_t* blk_ab;        // [n_blk][2] (a, b), a <= b
+    const int64_t* contrib;       // (index << 3) | kind : 0 keyframe diagonal block, 1/2 relative-pose edge forward/transposed, 3/4 switchable edge
+    const int32_t* agg_free;      // [n_agg] free keyframes in the aggregate (0: identity block)
+};
+
 struct CgDev {
     double* val; float* Lf; double* Dtot; double* b;   // Lf [N][24]: packed fp32 Cholesky factor of the block-Jacobi blocks
     double* x; double* r; double* r2; double* z; double* p; double* p2; double* q;   // r/r2 and p/p2 ping-pong by iteration parity
@@ -126,6 +144,7 @@ void launch_invert_rows(const GraphDev& G, const CgDev& C, int32_t* fail_flag, h
 void launch_cg_init(const GraphDev& G, const CgDev& C, int warm /*x holds a previous solution, q = A x*/, double tol2, hipStream_t st);
 // multi-GPU: the vector half of cg_init (owner-weighted partials of r.u in part_rz and of b.M^-1 b in part_pq); returns their count
 int launch_cg_init_vectors(const GraphDev& G, const CgDev& C, int warm, hipStream_t st);
+void launch_cg_init_scalars(const CgDev& C, int nparts, double tol2, hipStream_t st);   // scal[0] = b.M^-1 b, scal[1] = r.z from the partial sums; flags reset
 void launch_cg_set_tolerance(const CgDev& C, double tol2, hipStream_t st);
 void launch_cg_spmv(const GraphDev& G, const CgDev& C, int k, double tol2, hipStream_t st);   // iteration k: direction + matvec (+ convergence test)
 void launch_cg_update(const GraphDev& G, const CgDev& C, int k, int n_pq_partials, hipStream_t st);
@@ -144,6 +163,14 @@ void launch_unpack_k1(const GraphDev& G, int kind, int64_t first, int64_t count,
 // multi-GPU exchange of the keyframes shared between ranks: buf[pos[j]*K + off + c] <-> src[loc[j]*k + c], c < k
 void launch_pack_rows(double* buf, int K, int off, const double* src, int k, int64_t n, const int32_t* loc, const int32_t* pos, hipStream_t st);
 void launch_unpack_rows(const double* buf, int K, int off, double* dst, int k, int64_t n, const int32_t* loc, const int32_t* pos, const int32_t* stop /*nullable device flag: skip when set*/, hipStream_t st);
+// two-level preconditioner (CoarseDev)
+void launch_coarse_geometry(const GraphDev& G, const CoarseDev& K, const double* pose8, hipStream_t st);       // centroids + d
+void launch_coarse_assemble(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, const CoarseDev& K, hipStream_t st);   // Ac = P^T A P (deterministic)
+void launch_coarse_symmetrize(const CoarseDev& K, hipStream_t st);                                             // mirror one triangle
+void launch_coarse_shift(const CoarseDev& K, double eps, hipStream_t st);   // Ac_ii *= 1 + eps
+void launch_coarse_invert(const CoarseDev& K, double* scratch /* nc x 32 + 1024 doubles */, int32_t* fail, hipStream_t st);   // Ac -> Ac^-1 (blocked Gauss-Jordan)
+// z += P Ac^-1 P^T r for the vectors of the PCG (r of the given parity), r.z partials updated in place (same workgroup -> slot mapping as cg_update)
+void launch_coarse_apply(const GraphDev& G, const CgDev& C, const CoarseDev& K, const double* r, double* z, double* part_rz, bool inside_iteration, hipStream_t st);
 // multi-GPU PCG in Chronopoulos-Gear form (one collective per iteration): see pgo_kernels.hip
 void launch_cgcg_dots(const GraphDev& G, const CgDev& C, hipStream_t st);                                     // part_pq[block] = partial of u.w
 void launch_cg_reduce2_live(const CgDev& C, const double* pa, int na, const double* pb, int nb, double* out, hipStream_t st);

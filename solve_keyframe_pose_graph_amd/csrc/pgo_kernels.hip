@@ -970,6 +970,7 @@ void launch_cg_init(const GraphDev& G, const CgDev& C, int warm, double tol2, hi
     hipLaunchKernelGGL(cg_init_kernel, dim3(g), dim3(CG_BLOCK), 0, st, G, C, warm);
     hipLaunchKernelGGL(cg_scalars_init_kernel, dim3(1), dim3(256), 0, st, C, g, tol2);
 }
+void launch_cg_init_scalars(const CgDev& C, int nparts, double tol2, hipStream_t st) { hipLaunchKernelGGL(cg_scalars_init_kernel, dim3(1), dim3(256), 0, st, C, nparts, tol2); }
 int launch_cg_init_vectors(const GraphDev& G, const CgDev& C, int warm, hipStream_t st) {
     const int g = cg_grid(G);
     hipLaunchKernelGGL(cg_init_kernel, dim3(g), dim3(CG_BLOCK), 0, st, G, C, warm);
@@ -1495,6 +1496,333 @@ __global__ void scatter_owned_pose_kernel(const double* __restrict__ quat, const
 }
 void launch_scatter_owned_pose(const double* quat, const double* t, int64_t n, const int32_t* l2g, const double* own, double* gquat, double* gt, hipStream_t st) {
     if (n > 0) hipLaunchKernelGGL(scatter_owned_pose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, quat, t, n, l2g, own, gquat, gt);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Two-level preconditioner: the coarse space of rigid-body modes of keyframe aggregates (CoarseDev, pgo_internal.hpp)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_bcast0(double v) { return __shfl(v, 0, 64); }
+
+// one wavefront per aggregate: centroid of its free keyframes, then d_i = t_i - centroid for every member
+__global__ __launch_bounds__(256) void coarse_geometry_kernel(GraphDev G, CoarseDev K, const double* __restrict__ pose8) {
+    const int a = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int lane = threadIdx.x & 63;
+    if (a >= K.n_agg) return;
+    const int64_t i0 = (int64_t)a * K.m, i1 = i0 + K.m < G.N ? i0 + K.m : G.N;
+    double sx = 0.0, sy = 0.0, sz = 0.0, cnt = 0.0;
+    for (int64_t i = i0 + lane; i < i1; i += 64) {
+        if (!G.node_free[i]) continue;
+        const double* t = pose8 + (size_t)i * 8 + 4;
+        sx += t[0]; sy += t[1]; sz += t[2]; cnt += 1.0;
+    }
+    sx = wave_bcast0(wave_sum(sx)); sy = wave_bcast0(wave_sum(sy)); sz = wave_bcast0(wave_sum(sz)); cnt = wave_bcast0(wave_sum(cnt));
+    const double inv = cnt > 0.0 ? 1.0 / cnt : 0.0;
+    const double cx = sx * inv, cy = sy * inv, cz = sz * inv;
+    if (lane == 0) { K.cen[a * 3] = cx; K.cen[a * 3 + 1] = cy; K.cen[a * 3 + 2] = cz; }
+    for (int64_t i = i0 + lane; i < i1; i += 64) {
+        const double* t = pose8 + (size_t)i * 8 + 4;
+        K.d[i * 3] = t[0] - cx; K.d[i * 3 + 1] = t[1] - cy; K.d[i * 3 + 2] = t[2] - cz;
+    }
+}
+void launch_coarse_geometry(const GraphDev& G, const CoarseDev& K, const double* pose8, hipStream_t st) {
+    hipLaunchKernelGGL(coarse_geometry_kernel, dim3((unsigned)((K.n_agg + 3) / 4)), dim3(256), 0, st, G, K, pose8);
+}
+
+// entry (r, c) of B_i^T H B_j with B = [[I, 0], [X, I]], X = -2 [d]x ; H (6x6 row-major) read from LDS
+__device__ __forceinline__ double coarse_xentry(const double* d, int q, int c) {   // X[q][c] = -2 skew(d)[q][c]
+    // skew(d) = [[0, -dz, dy], [dz, 0, -dx], [-dy, dx, 0]]
+    if (q == c) return 0.0;
+    const int k = 3 - q - c;                        // the remaining axis
+    const double sgn = ((c - q + 3) % 3 == 1) ? -1.0 : 1.0;   // (q,c) = (0,1),(1,2),(2,0) -> -d_k ; reversed -> +d_k
+    return -2.0 * sgn * d[k];
+}
+__device__ __forceinline__ double coarse_t(const double* H, const double* dj, int p, int c) {   // T = H B_j
+    double t = H[p * 6 + c];
+    if (c < 3) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) t += H[p * 6 + 3 + q] * coarse_xentry(dj, q, c);
+    }
+    return t;
+}
+__device__ __forceinline__ double coarse_entry(const double* H, const double* di, const double* dj, int r, int c) {
+    double v = coarse_t(H, dj, r, c);
+    if (r < 3) {
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp) v += coarse_xentry(di, pp, r) * coarse_t(H, dj, 3 + pp, c);
+    }
+    return v;
+}
+
+// Ac = P^T A P: one wavefront per coarse block (a <= b), lane l < 36 owns entry (l / 6, l % 6); the block's contributions are summed in
+// list order (deterministic, no atomics).  Fine blocks come from the data the LM iteration already has: the reduced diagonal blocks
+// (C.Dtot: J^T J + damping - switch Schur terms + regularisers) and, per edge, J1^T J2 - c1 c2^T / a recomputed from K1's Jacobians.
+__global__ __launch_bounds__(256) void coarse_assemble_kernel(GraphDev G, LinDev L, ScaleDev Sc, CgDev C, CoarseDev K) {
+    __shared__ double Hs[4][36];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int blk = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (blk >= K.n_blk) return;                       // whole wavefronts leave together; no workgroup barrier below
+    const int a = K.blk_ab[blk * 2], b = K.blk_ab[blk * 2 + 1];
+    const int r = lane / 6, c = lane - r * 6;
+    const bool own = lane < 36;
+    double acc = 0.0;
+    for (int64_t k = K.blk_ptr[blk]; k < K.blk_ptr[blk + 1]; ++k) {
+        const int64_t ent = K.contrib[k];
+        const int kind = (int)(ent & 7);
+        const int64_t idx = ent >> 3;
+        int64_t ni, nj;
+        double h = 0.0;
+        if (kind == 0) {
+            ni = nj = idx;
+            if (own) h = C.Dtot[(size_t)idx * 36 + lane];
+        } else {
+            const bool is_sw = kind >= 3;
+            const bool transposed = kind == 2 || kind == 4;
+            const EdgeClassDev& E = is_sw ? G.sw : G.rel;
+            const int D = is_sw ? SW_DOUBLES : REL_DOUBLES;
+            const int o1 = is_sw ? 14 : 6, o2 = is_sw ? 50 : 42;
+            const int32_t c1 = E.c1[idx], c2 = E.c2[idx];
+            ni = transposed ? c2 : c1; nj = transposed ? c1 : c2;
+            if (own) {
+                const int oa = transposed ? o2 : o1, ob = transposed ? o1 : o2;   // H[r][c] = sum_k Ja[k][r] Jb[k][c]
+#pragma unroll
+                for (int kk = 0; kk < 6; ++kk) h += E.J[tile_elem(D, idx, oa + kk * 6 + r)] * E.J[tile_elem(D, idx, ob + kk * 6 + c)];
+                if (is_sw) {
+                    const double* cc = L.c + (size_t)idx * 12;
+                    h -= cc[(transposed ? 6 : 0) + r] * cc[(transposed ? 0 : 6) + c] * Sc.a_inv[idx];
+                }
+            }
+        }
+        if (own) Hs[wv][lane] = h;
+        __builtin_amdgcn_wave_barrier();
+        if (own) acc += coarse_entry(Hs[wv], K.d + (size_t)ni * 3, K.d + (size_t)nj * 3, r, c);
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (!own) return;
+    if (a == b && K.agg_free[a] == 0) acc = r == c ? 1.0 : 0.0;        // an aggregate without free keyframes: identity block
+    K.Ac[(size_t)(a * 6 + r) * K.nc + b * 6 + c] = acc;
+    if (a != b) K.Ac[(size_t)(b * 6 + c) * K.nc + a * 6 + r] = acc;
+}
+__global__ void coarse_pad_identity_kernel(CoarseDev K);
+void launch_coarse_assemble(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, const CoarseDev& K, hipStream_t st) {
+    (void)hipMemsetAsync(K.Ac, 0, (size_t)K.nc * K.nc * sizeof(double), st);
+    if (K.nc > 6 * K.n_agg) hipLaunchKernelGGL(coarse_pad_identity_kernel, dim3((unsigned)((K.nc - 6 * K.n_agg + 63) / 64)), dim3(64), 0, st, K);
+    if (K.n_blk > 0) hipLaunchKernelGGL(coarse_assemble_kernel, dim3((unsigned)((K.n_blk + 3) / 4)), dim3(256), 0, st, G, L, Sc, C, K);
+}
+
+// the computed inverse is symmetric only up to rounding; PCG needs an exactly symmetric preconditioner: mirror one triangle
+__global__ void coarse_symmetrize_kernel(CoarseDev K) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = K.nc;
+    if (t >= n * n) return;
+    const int64_t i = t / n, j = t - i * n;           // column-major element (i, j) lives at Ac[i + j n]
+    if (i < j) K.Ac[i + j * n] = K.Ac[j + i * n];     // upper <- lower
+}
+void launch_coarse_symmetrize(const CoarseDev& K, hipStream_t st) {
+    const int64_t n2 = (int64_t)K.nc * K.nc;
+    hipLaunchKernelGGL(coarse_symmetrize_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, K);
+}
+
+// rc = P^T r: one wavefront per aggregate;  B_i^T r_i = [r_theta + 2 d_i x r_t ; r_t]
+__global__ __launch_bounds__(256) void coarse_restrict_kernel(GraphDev G, CoarseDev K, const double* __restrict__ rv, const int32_t* __restrict__ stop) {
+    if (stop && *stop) return;   // a stopped PCG keeps z and its partial sums (it may be resumed)
+    const int a = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int lane = threadIdx.x & 63;
+    if (a >= K.n_agg) return;
+    const int64_t i0 = (int64_t)a * K.m, i1 = i0 + K.m < G.N ? i0 + K.m : G.N;
+    double s[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int64_t i = i0 + lane; i < i1; i += 64) {
+        if (!G.node_free[i]) continue;
+        const double* r = rv + (size_t)i * 6;
+        const double* d = K.d + (size_t)i * 3;
+        s[0] += r[0] + 2.0 * (d[1] * r[5] - d[2] * r[4]);
+        s[1] += r[1] + 2.0 * (d[2] * r[3] - d[0] * r[5]);
+        s[2] += r[2] + 2.0 * (d[0] * r[4] - d[1] * r[3]);
+        s[3] += r[3]; s[4] += r[4]; s[5] += r[5];
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s[k] = wave_sum(s[k]);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) K.rc[a * 6 + k] = s[k];
+    }
+}
+// yc = Ac^-1 rc: one wavefront per row of the dense inverse
+__global__ __launch_bounds__(256) void coarse_solve_kernel(CoarseDev K, const int32_t* __restrict__ stop) {
+    if (stop && *stop) return;
+    const int row = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= K.nc) return;
+    const double* A = K.Ac + (size_t)row * K.nc;
+    double s = 0.0;
+    for (int j = lane; j < K.nc; j += 64) s += A[j] * K.rc[j];
+    s = wave_sum(s);
+    if (lane == 0) K.yc[row] = s;
+}
+// z_i += B_i y_a  (dtheta_i = dtheta_a ; dt_i = dt_a - 2 d_i x dtheta_a) and r.z += r.(P y): the cg_update lane / workgroup mapping, so
+// that workgroup b adds its partial to the same slot b the update kernel wrote
+__global__ __launch_bounds__(CG_BLOCK) void coarse_prolong_kernel(GraphDev G, CoarseDev K, const double* __restrict__ rv, double* __restrict__ zv, double* __restrict__ part_rz,
+                                                                   const int32_t* __restrict__ stop) {
+    __shared__ double red[CG_BLOCK / 64];
+    if (stop && *stop) return;
+    const int64_t pairs = G.N * 3;
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * CG_BLOCK + threadIdx.x; i < pairs; i += (int64_t)gridDim.x * CG_BLOCK) {
+        const int64_t n = i / 3;
+        const int j = (int)(i - n * 3);
+        if (!G.node_free[n]) continue;
+        const double* y = K.yc + (size_t)(n / K.m) * 6;
+        const double* d = K.d + (size_t)n * 3;
+        const double add[6] = {y[0], y[1], y[2], y[3] - 2.0 * (d[1] * y[2] - d[2] * y[1]), y[4] - 2.0 * (d[2] * y[0] - d[0] * y[2]), y[5] - 2.0 * (d[0] * y[1] - d[1] * y[0])};
+        const double a0 = j == 0 ? add[0] : (j == 1 ? add[2] : add[4]), a1 = j == 0 ? add[1] : (j == 1 ? add[3] : add[5]);
+        double2* zp = reinterpret_cast<double2*>(zv) + i;
+        const double2 r = reinterpret_cast<const double2*>(rv)[i];
+        double2 z = *zp;
+        z.x += a0; z.y += a1;
+        *zp = z;
+        const double w = G.own ? G.own[n] : 1.0;
+        acc += w * (r.x * a0 + r.y * a1);
+    }
+    const double s = block_sum(acc, red);
+    if (threadIdx.x == 0) part_rz[blockIdx.x] += s;
+}
+void launch_coarse_apply(const GraphDev& G, const CgDev& C, const CoarseDev& K, const double* r, double* z, double* part_rz, bool inside_iteration, hipStream_t st) {
+    const int32_t* stop = inside_iteration ? C.flags : nullptr;     // at PCG start the flag still belongs to the previous solve
+    hipLaunchKernelGGL(coarse_restrict_kernel, dim3((unsigned)((K.n_agg + 3) / 4)), dim3(256), 0, st, G, K, r, stop);
+    hipLaunchKernelGGL(coarse_solve_kernel, dim3((unsigned)((K.nc + 3) / 4)), dim3(256), 0, st, K, stop);
+    hipLaunchKernelGGL(coarse_prolong_kernel, dim3(cg_grid(G)), dim3(CG_BLOCK), 0, st, G, K, r, z, part_rz, stop);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dense inverse of the (symmetric positive definite) coarse operator, in place: blocked Gauss-Jordan without pivoting, block size 32.
+// Per pivot block k:  P = A_kk^-1 ; A_kj <- P A_kj (j != k) ; A_ij <- A_ij - A_ik A_kj (i, j != k, old A_ik) ; A_ik <- -A_ik P ; A_kk <- P.
+// Three launches per block (pivot / panels / trailing update); n is a multiple of 64 (padded with an identity block).  2 n^3 flops, the
+// matrix (<= 75 MB) stays in L2 / Infinity Cache.  Written here instead of calling rocSOLVER: the first rocBLAS handle of a process costs
+// seconds to minutes of library loading on a cold box.
+// ------------------------------------------------------------------------------------------------
+constexpr int GJ_NB = 32;
+
+__global__ __launch_bounds__(1024) void gj_pivot_kernel(const double* __restrict__ A, int n, int k0, double* __restrict__ Pinv, int32_t* __restrict__ fail) {
+    __shared__ double a[GJ_NB][GJ_NB + 1];
+    const int r = threadIdx.x / GJ_NB, c = threadIdx.x % GJ_NB;
+    a[r][c] = A[(size_t)(k0 + r) * n + k0 + c];
+    __syncthreads();
+    for (int p = 0; p < GJ_NB; ++p) {
+        const double piv = a[p][p], arp = a[r][p], apc = a[p][c], arc = a[r][c];
+        __syncthreads();
+        double v;
+        if (r == p) v = c == p ? 1.0 / piv : apc / piv;
+        else v = c == p ? -arp / piv : arc - arp * apc / piv;
+        a[r][c] = v;
+        if (threadIdx.x == 0 && !(piv > 0.0)) *fail = 1;     // not positive definite (or NaN)
+        __syncthreads();
+    }
+    Pinv[r * GJ_NB + c] = a[r][c];
+}
+
+// threads [0, n): row i — save the old column panel, write the new one (or the pivot block's inverse);
+// threads [n, 2n): column j outside the pivot block — new row panel P A_kj
+__global__ __launch_bounds__(256) void gj_panels_kernel(double* __restrict__ A, int n, int k0, const double* __restrict__ Pinv, double* __restrict__ Cold) {
+    __shared__ double P[GJ_NB][GJ_NB + 1];
+    for (int t = threadIdx.x; t < GJ_NB * GJ_NB; t += blockDim.x) P[t / GJ_NB][t % GJ_NB] = Pinv[t];
+    __syncthreads();
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) {
+        const int i = t;
+        double old[GJ_NB];
+        double* row = A + (size_t)i * n + k0;
+#pragma unroll
+        for (int c = 0; c < GJ_NB; ++c) old[c] = row[c];
+#pragma unroll
+        for (int c = 0; c < GJ_NB; ++c) Cold[(size_t)i * GJ_NB + c] = old[c];
+        if (i >= k0 && i < k0 + GJ_NB) {
+#pragma unroll
+            for (int c = 0; c < GJ_NB; ++c) row[c] = P[i - k0][c];
+        } else {
+            for (int cc = 0; cc < GJ_NB; ++cc) {
+                double s = 0.0;
+#pragma unroll
+                for (int c = 0; c < GJ_NB; ++c) s += old[c] * P[c][cc];
+                row[cc] = -s;
+            }
+        }
+    } else if (t < 2 * n) {
+        const int j = t - n;
+        if (j >= k0 && j < k0 + GJ_NB) return;
+        double col[GJ_NB];
+#pragma unroll
+        for (int c = 0; c < GJ_NB; ++c) col[c] = A[(size_t)(k0 + c) * n + j];
+        for (int r = 0; r < GJ_NB; ++r) {
+            double s = 0.0;
+#pragma unroll
+            for (int c = 0; c < GJ_NB; ++c) s += P[r][c] * col[c];
+            A[(size_t)(k0 + r) * n + j] = s;
+        }
+    }
+}
+
+// trailing update: 64 x 64 tile per workgroup, 4 x 4 per thread; rows and columns of the pivot block are left alone
+__global__ __launch_bounds__(256) void gj_update_kernel(double* __restrict__ A, int n, int k0, const double* __restrict__ Cold) {
+    __shared__ double Cs[64][GJ_NB + 1];
+    __shared__ double Rs[GJ_NB][64 + 1];
+    const int ti = blockIdx.y * 64, tj = blockIdx.x * 64;
+    for (int t = threadIdx.x; t < 64 * GJ_NB; t += 256) {
+        const int r = t / GJ_NB, c = t % GJ_NB;
+        Cs[r][c] = Cold[(size_t)(ti + r) * GJ_NB + c];
+        const int rr = t / 64, cc = t % 64;
+        Rs[rr][cc] = A[(size_t)(k0 + rr) * n + tj + cc];
+    }
+    __syncthreads();
+    const int r0 = (threadIdx.x / 16) * 4, c0 = (threadIdx.x % 16) * 4;
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+#pragma unroll 8
+    for (int k = 0; k < GJ_NB; ++k) {
+        double cv[4], rv[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { cv[a] = Cs[r0 + a][k]; rv[a] = Rs[k][c0 + a]; }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] += cv[a] * rv[b];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int i = ti + r0 + a;
+        if (i >= k0 && i < k0 + GJ_NB) continue;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int j = tj + c0 + b;
+            if (j >= k0 && j < k0 + GJ_NB) continue;
+            A[(size_t)i * n + j] -= acc[a][b];
+        }
+    }
+}
+
+__global__ void coarse_pad_identity_kernel(CoarseDev K) {    // rows/columns beyond 6 n_agg: a decoupled identity block
+    const int i = 6 * K.n_agg + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < K.nc) K.Ac[(size_t)i * K.nc + i] = 1.0;
+}
+
+__global__ void coarse_shift_kernel(CoarseDev K, double eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < K.nc) K.Ac[(size_t)i * K.nc + i] *= 1.0 + eps;
+}
+void launch_coarse_shift(const CoarseDev& K, double eps, hipStream_t st) { hipLaunchKernelGGL(coarse_shift_kernel, dim3((unsigned)((K.nc + 255) / 256)), dim3(256), 0, st, K, eps); }
+
+// Ac (assembled, padded) -> Ac^-1, exactly symmetric; *fail != 0 when a pivot was not positive
+void launch_coarse_invert(const CoarseDev& K, double* scratch /* nc x 32 + 1024 doubles */, int32_t* fail, hipStream_t st) {
+    const int n = K.nc;
+    double* Cold = scratch;
+    double* Pinv = scratch + (size_t)n * GJ_NB;
+    for (int k0 = 0; k0 < n; k0 += GJ_NB) {
+        hipLaunchKernelGGL(gj_pivot_kernel, dim3(1), dim3(GJ_NB * GJ_NB), 0, st, K.Ac, n, k0, Pinv, fail);
+        hipLaunchKernelGGL(gj_panels_kernel, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), 0, st, K.Ac, n, k0, Pinv, Cold);
+        hipLaunchKernelGGL(gj_update_kernel, dim3((unsigned)(n / 64), (unsigned)(n / 64)), dim3(256), 0, st, K.Ac, n, k0, Cold);
+    }
+    launch_coarse_symmetrize(K, st);
 }
 
 }  // namespace pgo

@@ -109,6 +109,15 @@ struct pgo_problem {
     DBuf<double> d_pose[2], d_swv[2], d_delta_s, d_io;   // state ping-pong, staging for quat/t
     DBuf<double> d_tmp;
     DBuf<double> d_vio;              // raw VIO poses [n_vio][16] (graph construction, K0)
+    // two-level preconditioner (CoarseDev)
+    DBuf<double> d_ccen, d_cd, d_cAc, d_crc, d_cscr;
+    DBuf<int64_t> d_cblk_ptr, d_ccontrib;
+    DBuf<int32_t> d_cblk_ab, d_cagg_free, d_cinfo;
+    CoarseDev K{};
+    bool coarse_built = false, coarse_active = false;
+    int coarse_mode = 0;             // per solve: 0 not yet compared with plain block-Jacobi, 1 keep, 2 dropped (it did not pay on this graph)
+    int coarse_backoff = 0, coarse_skip = 0;   // a handle that keeps dropping it (incremental triggers on the same kind of graph) retests ever more rarely
+    uint64_t coarse_geometry_epoch = 0, lin_epoch = 0;   // lin_epoch counts linearisations (the centroids follow the poses)
     int64_t n_vio = 0;
     // matrix-free operator
     DBuf<uint32_t> d_einc;
@@ -147,7 +156,7 @@ struct pgo_problem {
     Poll* poll = nullptr; hipEvent_t poll_ev[2] = {nullptr, nullptr};
 
     // hipGraph of one PCG chunk (launch-bound inner loop); valid for (graph build epoch, tolerance, chunk length, solver)
-    hipGraphExec_t cg_graph = nullptr; int cg_graph_len = 0; double cg_graph_tol2 = -1; uint64_t cg_graph_epoch = 0, build_epoch = 1; bool cg_graph_failed = false;
+    hipGraphExec_t cg_graph = nullptr; int cg_graph_len = 0; double cg_graph_tol2 = -1; uint64_t cg_graph_epoch = 0, build_epoch = 1; bool cg_graph_failed = false; bool cg_graph_coarse = false;
 };
 
 namespace {
@@ -446,6 +455,54 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S) {
     C.x = v; C.r = v + n6; C.r2 = v + 2 * n6; C.z = v + 3 * n6; C.p = v + 4 * n6; C.p2 = v + 5 * n6; C.q = v + 6 * n6;
     C.part_pq = p->d_cgpart.p; C.part_rz = p->d_cgpart.p + MF_MAX_GRID; C.scal = p->d_cgpart.p + MF_MAX_GRID + 2 * MAX_PARTIALS;
     C.flags = p->d_flags.p;
+    // ---- two-level preconditioner: aggregates of consecutive keyframes and, per coarse 6x6 block (a <= b), the ordered list of fine
+    // blocks that project onto it (single GPU; enough keyframes per aggregate to be worth it)
+    p->coarse_built = false; p->coarse_active = false; p->K = CoarseDev{};
+    {
+        int n_agg = p->opt.coarse_aggregates;
+        if (n_agg > N / 8) n_agg = (int)(N / 8);
+        if (n_agg >= 2 && !p->local_ids) {
+            const int m = (int)((N + n_agg - 1) / n_agg);
+            n_agg = (int)((N + m - 1) / m);
+            std::vector<int32_t> agg_free((size_t)n_agg, 0);
+            for (int64_t n = 0; n < N; ++n) if (p->h_node_free[n]) agg_free[n / m]++;
+            // (block key, entry) pairs; key = a * n_agg + b with a <= b
+            std::vector<std::pair<int64_t, int64_t>> ent;
+            ent.reserve((size_t)N + 2 * (size_t)(Er + Es));
+            for (int64_t n = 0; n < N; ++n) if (p->h_node_free[n]) ent.push_back({(int64_t)(n / m) * n_agg + n / m, (n << 3) | 0});
+            auto edge = [&](int64_t e, int32_t c1, int32_t c2, int kind_fwd) {
+                if (!p->h_node_free[c1] || !p->h_node_free[c2]) return;       // rows and columns of fixed keyframes are not part of the system
+                const int64_t a = c1 / m, b = c2 / m;
+                if (a < b) ent.push_back({a * n_agg + b, (e << 3) | kind_fwd});
+                else if (a > b) ent.push_back({b * n_agg + a, (e << 3) | (kind_fwd + 1)});
+                else { ent.push_back({a * n_agg + a, (e << 3) | kind_fwd}); ent.push_back({a * n_agg + a, (e << 3) | (kind_fwd + 1)}); }
+            };
+            for (int64_t e = 0; e < Er; ++e) edge(e, L(p->rel.c1[e]), L(p->rel.c2[e]), 1);
+            for (int64_t e = 0; e < Es; ++e) edge(e, L(p->swe.c1[e]), L(p->swe.c2[e]), 3);
+            for (int a = 0; a < n_agg; ++a) if (agg_free[a] == 0) ent.push_back({(int64_t)a * n_agg + a, -1});   // identity block: listed, no contribution
+            std::stable_sort(ent.begin(), ent.end(), [](const std::pair<int64_t, int64_t>& x, const std::pair<int64_t, int64_t>& y) { return x.first < y.first; });
+            std::vector<int64_t> blk_ptr, contrib;
+            std::vector<int32_t> blk_ab;
+            int64_t prev = -1;
+            for (const auto& kv : ent) {
+                if (kv.first != prev) { blk_ptr.push_back((int64_t)contrib.size()); blk_ab.push_back((int32_t)(kv.first / n_agg)); blk_ab.push_back((int32_t)(kv.first % n_agg)); prev = kv.first; }
+                if (kv.second >= 0) contrib.push_back(kv.second);
+            }
+            blk_ptr.push_back((int64_t)contrib.size());
+            const int n_blk = (int)blk_ab.size() / 2;
+            const int nc = (6 * n_agg + 63) / 64 * 64;      // padded with a decoupled identity block (the dense kernels work on 64-wide tiles)
+            HIPCHK(p, p->d_ccen.ensure((size_t)n_agg * 3)); HIPCHK(p, p->d_cd.ensure((size_t)N * 3)); HIPCHK(p, p->d_cAc.ensure((size_t)nc * nc));
+            HIPCHK(p, p->d_crc.ensure((size_t)nc * 2)); HIPCHK(p, p->d_cscr.ensure((size_t)nc * 32 + 1024)); HIPCHK(p, hipMemsetAsync(p->d_crc.p, 0, (size_t)nc * 2 * sizeof(double), p->st)); HIPCHK(p, p->d_cblk_ptr.ensure(blk_ptr.size())); HIPCHK(p, p->d_ccontrib.ensure(std::max<size_t>(contrib.size(), 1)));
+            HIPCHK(p, p->d_cblk_ab.ensure(blk_ab.size())); HIPCHK(p, p->d_cagg_free.ensure(n_agg)); HIPCHK(p, p->d_cinfo.ensure(4));
+            HIPCHK(p, hipMemcpyAsync(p->d_cblk_ptr.p, blk_ptr.data(), blk_ptr.size() * sizeof(int64_t), hipMemcpyHostToDevice, p->st));
+            if (!contrib.empty()) HIPCHK(p, hipMemcpyAsync(p->d_ccontrib.p, contrib.data(), contrib.size() * sizeof(int64_t), hipMemcpyHostToDevice, p->st));
+            HIPCHK(p, hipMemcpyAsync(p->d_cblk_ab.p, blk_ab.data(), blk_ab.size() * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
+            HIPCHK(p, hipMemcpyAsync(p->d_cagg_free.p, agg_free.data(), n_agg * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
+            HIPCHK(p, hipStreamSynchronize(p->st));
+            p->K = CoarseDev{n_agg, nc, m, n_blk, p->d_ccen.p, p->d_cd.p, p->d_cAc.p, p->d_crc.p, p->d_crc.p + nc, p->d_cblk_ptr.p, p->d_cblk_ab.p, p->d_ccontrib.p, p->d_cagg_free.p};
+            p->coarse_built = true;
+        }
+    }
     p->graph_dirty = false; p->priors_dirty = false;
     ++p->build_epoch;   // invalidates the captured PCG graph (kernel arguments hold device pointers / sizes)
     return PGO_OK;
@@ -548,6 +605,7 @@ int linearize(pgo_problem* p, double* cost_out) {
     int rc;
     if ((rc = run_k1(p, p->cur, true)) != PGO_OK) return rc;
     launch_k2(p->G, p->L, !p->built_mf, p->st);
+    ++p->lin_epoch;
     if (p->built_mf) launch_mf_compact(p->G, p->F, p->d_pose[p->cur].p, p->d_swv[p->cur].p, p->st);
     if ((rc = exchange_rows(p, p->L.Hd, 36, p->L.g, 6, nullptr, 0)) != PGO_OK) return rc;   // diagonal blocks + gradient of shared keyframes
     if (!p->scale_ready) { launch_scale_init(p->G, p->L, p->Sc, p->opt.jacobi_scaling, p->st); p->scale_ready = true; }
@@ -566,7 +624,7 @@ int linearize(pgo_problem* p, double* cost_out) {
     return PGO_OK;
 }
 
-struct CgResult { int iterations; bool breakdown; double rel_residual; };
+struct CgResult { int iterations; bool breakdown; double rel_residual; bool converged; };
 
 // rel_tol: relative tolerance of this phase.  resume_from >= 0: continue the stopped PCG at that iteration index with the new tolerance
 // (device state x, r, z, p and the partial sums are those of `resume_from` completed iterations).
@@ -586,7 +644,12 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
     // w = A u together with gamma = r.u (owner-weighted partials of the previous update) and delta = u.A u (rank-local partials).
     const bool multi = p->local_ids;
     if (resume_from < 0) {
-        if (!multi) launch_cg_init(p->G, p->C, warm ? 1 : 0, tol2, p->st);
+        if (!multi && p->coarse_active) {
+            // z = D^-1 r + P Ac^-1 P^T r: the coarse term is added to z and to the r.z partials before the scalars are formed
+            const int g = launch_cg_init_vectors(p->G, p->C, warm ? 1 : 0, p->st);
+            launch_coarse_apply(p->G, p->C, p->K, p->C.r, p->C.z, p->C.part_rz, false, p->st);
+            launch_cg_init_scalars(p->C, g, tol2, p->st);
+        } else if (!multi) launch_cg_init(p->G, p->C, warm ? 1 : 0, tol2, p->st);
         else {
             // r = b (- A x), u = M^-1 r, p = s = 0; part_rz <- owner-weighted partials of gamma_0 (they travel with the first exchange),
             // part_pq <- partials of b.M^-1 b, summed over ranks here once: the reference norm of the stopping test
@@ -619,11 +682,13 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
         if (p->built_mf) { launch_mf_spmv(p->G, p->F, p->Sc, p->C, kk, tol2, p->st); n_pq = mf_grid_size(p->F); }
         else launch_cg_spmv(p->G, p->C, kk, tol2, p->st);
         launch_cg_update(p->G, p->C, kk, n_pq, p->st);
+        if (p->coarse_active)   // the new residual is in the OTHER r buffer, its r.z partials in the other parity's slots
+            launch_coarse_apply(p->G, p->C, p->K, (kk & 1) ? p->C.r : p->C.r2, p->C.z, p->C.part_rz + (size_t)((kk & 1) ^ 1) * MAX_PARTIALS, true, p->st);
         return PGO_OK;
     };
     // hipGraph: capture one chunk (iterations 2 .. 2+every-1: no `first` kernel, even start) once per graph build and replay it
     const bool want_graph = o.cg_use_graph && !p->local_ids && !p->cg_graph_failed;
-    if (want_graph && (p->cg_graph == nullptr || p->cg_graph_epoch != p->build_epoch || p->cg_graph_len != every)) {
+    if (want_graph && (p->cg_graph == nullptr || p->cg_graph_epoch != p->build_epoch || p->cg_graph_len != every || p->cg_graph_coarse != p->coarse_active)) {
         if (p->cg_graph) { (void)hipGraphExecDestroy(p->cg_graph); p->cg_graph = nullptr; }
         hipGraph_t gr = nullptr;
         bool ok = hipStreamBeginCapture(p->st, hipStreamCaptureModeThreadLocal) == hipSuccess;
@@ -634,7 +699,7 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
         if (ok) ok = hipGraphInstantiate(&p->cg_graph, gr, nullptr, nullptr, 0) == hipSuccess;
         if (gr) (void)hipGraphDestroy(gr);
         if (!ok) { p->cg_graph = nullptr; p->cg_graph_failed = true; (void)hipGetLastError(); }
-        else { p->cg_graph_epoch = p->build_epoch; p->cg_graph_len = every; }
+        else { p->cg_graph_epoch = p->build_epoch; p->cg_graph_len = every; p->cg_graph_coarse = p->coarse_active; }
     }
     // Chunks of `every` iterations; the convergence flag of chunk j is read (pinned memory + event) only AFTER chunk j+1 has been
     // enqueued, so the GPU never drains while the host polls.  A chunk enqueued after convergence is a string of early-exit kernels.
@@ -677,6 +742,7 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
         HIPCHK(p, hipMemcpyAsync(hscal, p->C.scal, sizeof(hscal), hipMemcpyDeviceToHost, p->st));
         HIPCHK(p, hipStreamSynchronize(p->st));
     }
+    res->converged = hflags[0] != 0 && hflags[1] == 0;
     if (!hflags[0] && !multi) {   // iteration cap reached: one more convergence test so that scal[1] holds the last r.z (x is already final)
         launch_cg_set_tolerance(p->C, 1e300, p->st);
         if (p->built_mf) launch_mf_spmv(p->G, p->F, p->Sc, p->C, k, 1e300, p->st);
@@ -691,6 +757,30 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
     return PGO_OK;
 }
 
+// Coarse operator of the two-level preconditioner for the system just built: Ac = P^T A P (deterministic assembly) and its dense inverse
+// (blocked Gauss-Jordan kernels).  A coarse operator that is not numerically positive definite leaves the coarse space off for this iteration.
+static int build_coarse(pgo_problem* p) {
+    p->coarse_active = false;
+    // Where it pays: always when the aggregates are small (the coarse space is then a sizeable fraction of the problem: graphs up to
+    // ~64 x coarse_aggregates keyframes), otherwise only at large trust regions, where the slow modes are the long wavelengths
+    // (measured: scripts/gpu_coarse_ab.py).
+    if (!p->coarse_built || p->opt.coarse_aggregates <= 0 || p->coarse_mode == 2) return PGO_OK;
+    if (!(p->K.m <= 64 || (p->radius >= p->opt.coarse_min_radius && p->K.m <= 1024))) return PGO_OK;   // aggregates of thousands of keyframes are too coarse to help
+    if (p->coarse_geometry_epoch != p->lin_epoch) {          // the aggregates' centroids follow the poses of the current linearisation
+        launch_coarse_geometry(p->G, p->K, p->d_pose[p->cur].p, p->st);
+        p->coarse_geometry_epoch = p->lin_epoch;
+    }
+    launch_coarse_assemble(p->G, p->L, p->Sc, p->C, p->K, p->st);
+    int32_t* fail = p->d_cinfo.p;
+    HIPCHK(p, hipMemsetAsync(fail, 0, sizeof(int32_t), p->st));
+    launch_coarse_invert(p->K, p->d_cscr.p, fail, p->st);
+    int32_t h = 1;
+    HIPCHK(p, hipMemcpyAsync(&h, fail, sizeof(h), hipMemcpyDeviceToHost, p->st));
+    HIPCHK(p, hipStreamSynchronize(p->st));
+    p->coarse_active = h == 0;
+    return PGO_OK;
+}
+
 int build_system(pgo_problem* p, bool* ok) {
     int rc;
     HIPCHK(p, hipMemsetAsync(p->d_flags.p + 4, 0, sizeof(int32_t), p->st));
@@ -701,6 +791,7 @@ int build_system(pgo_problem* p, bool* ok) {
     HIPCHK(p, hipMemcpyAsync(&fail, p->d_flags.p + 4, sizeof(int32_t), hipMemcpyDeviceToHost, p->st));
     HIPCHK(p, hipStreamSynchronize(p->st));
     *ok = fail == 0;
+    if (*ok && (rc = build_coarse(p)) != PGO_OK) return rc;
     return PGO_OK;
 }
 
@@ -739,6 +830,7 @@ int solve_begin(pgo_problem* p, const double* quat, const double* t, const doubl
     p->t_device0 = now_s();
     std::memset(&p->sum, 0, sizeof(p->sum));
     p->in_solve = true; p->terminated = false; p->scale_ready = false; p->have_prev_step = false;
+    if (p->coarse_skip > 0) { p->coarse_mode = 2; --p->coarse_skip; } else p->coarse_mode = 0;
     p->radius = p->opt.initial_trust_region_radius; p->decrease_factor = 2.0; p->reuse_diagonal = false; p->iteration = 0; p->invalid = 0;
     p->sum.termination_type = PGO_NO_CONVERGENCE;
     if ((rc = linearize(p, &p->x_cost)) != PGO_OK) return rc;
@@ -772,7 +864,7 @@ int lm_step(pgo_problem* p, int ignore_termination, int* done) {
     if (!p->reuse_diagonal) launch_lm_diag(p->G, p->L, p->Sc, o.min_lm_diagonal, o.max_lm_diagonal, p->st);
     bool ok = true;
     if ((rc = build_system(p, &ok)) != PGO_OK) return rc;
-    CgResult cg{0, false, 0.0};
+    CgResult cg{0, false, 0.0, false};
     const int nxt = p->cur ^ 1;
     double h[S_N] = {0};
     // candidate point x (+) delta, its cost, the model cost change and the step norms -> h[]
@@ -810,6 +902,30 @@ int lm_step(pgo_problem* p, int ignore_termination, int* done) {
                                       sn > o.parameter_tolerance * (p->x_norm + o.parameter_tolerance) && std::fabs(dc) > o.function_tolerance * p->x_cost;
             if (clear_reject) evaluated = true;
             else if ((rc = run_pcg(p, &cg, false, sidx + 1 < n_stages ? stages[sidx + 1].tol : o.cg_rel_tolerance, cg.iterations)) != PGO_OK) return rc;
+        }
+        // The coarse space pays by a large factor or not at all (it can even cost iterations on chains that odometry weights cut into
+        // many loose pieces), so once per solve — at the first full-accuracy step that used it — plain block-Jacobi gets the SAME
+        // iteration budget on the same system: if it does not converge within it the coarse space stays for the rest of
+        // the solve, otherwise it is dropped.  The test costs at most as many iterations as the coarse run took.
+        if (p->coarse_active && p->coarse_mode == 0 && !evaluated && !cg.breakdown && cg.converged) {
+            HIPCHK(p, p->d_tmp.ensure((size_t)p->N * 6));
+            HIPCHK(p, hipMemcpyAsync(p->d_tmp.p, p->C.x, (size_t)p->N * 6 * sizeof(double), hipMemcpyDeviceToDevice, p->st));
+            const int saved_cap = p->opt.cg_max_iterations;
+            p->opt.cg_max_iterations = std::max(cg.iterations, 2 * (std::max(2, p->opt.cg_check_every) & ~1));
+            p->coarse_active = false;
+            CgResult plain{0, false, 0.0, false};
+            rc = run_pcg(p, &plain, false, o.cg_rel_tolerance, -1);
+            p->opt.cg_max_iterations = saved_cap;
+            if (rc != PGO_OK) return rc;
+            if (plain.converged && !plain.breakdown) {      // block-Jacobi alone is at least as fast here
+                p->coarse_mode = 2; cg.iterations += plain.iterations;
+                p->coarse_backoff = std::min(2 * p->coarse_backoff + 1, 15); p->coarse_skip = p->coarse_backoff;
+            }
+            else {
+                p->coarse_mode = 1; p->coarse_active = true; p->coarse_backoff = 0;
+                HIPCHK(p, hipMemcpyAsync(p->C.x, p->d_tmp.p, (size_t)p->N * 6 * sizeof(double), hipMemcpyDeviceToDevice, p->st));
+                cg.iterations += plain.iterations;
+            }
         }
         p->have_prev_step = !cg.breakdown;
         if (cg.breakdown) ok = false;
@@ -976,6 +1092,8 @@ void pgo_options_init(pgo_options* o) {
     o->cg_early_reject_rho = -0.5;
     o->cg_mid_tolerance = 1e-4;
     o->cg_mid_reject_rho = -0.05;
+    o->coarse_aggregates = 512;
+    o->coarse_min_radius = 1e6;
     o->cg_rel_tolerance = 1e-9;     // loosest decade that keeps the 10-iteration chi^2 of C3 within 1e-8 of the 1e-13 solve
     o->device_id = -1;
     o->verbosity = 0;
@@ -1018,6 +1136,7 @@ int pgo_destroy(pgo_problem* p) {
     p->d_val.release(); p->d_Lf.release(); p->d_Dtot_b.release(); p->d_cgvec.release(); p->d_part.release(); p->d_cgpart.release();
     p->d_flags.release(); p->d_scal.release(); p->d_pose[0].release(); p->d_pose[1].release(); p->d_swv[0].release(); p->d_swv[1].release();
     p->d_delta_s.release(); p->d_io.release(); p->d_tmp.release(); p->d_vio.release();
+    p->d_ccen.release(); p->d_cd.release(); p->d_cAc.release(); p->d_crc.release(); p->d_cblk_ptr.release(); p->d_ccontrib.release(); p->d_cblk_ab.release(); p->d_cagg_free.release(); p->d_cinfo.release(); p->d_cscr.release();
     p->d_l2g.release(); p->d_sh_loc.release(); p->d_sh_pos.release(); p->d_own.release(); p->d_xbuf.release();
     p->d_einc.release(); p->d_einc_ownl.release(); p->d_node_rng.release(); p->d_tile_inc0.release(); p->d_einc_other.release();
     p->d_tile_node0.release(); p->d_tile_sw0.release(); p->d_node_prior.release(); p->d_rec.release(); p->d_lam.release();

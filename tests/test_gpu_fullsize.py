@@ -116,8 +116,9 @@ def test_rccl_world_size_one_matches_single_gpu():
     q1, t1, s1, sum1 = P1.solve(q, t, s)
     P1.comm_destroy()
     assert sum1.num_iterations == sum0.num_iterations
-    assert abs(sum1.final_cost - sum0.final_cost) <= 1e-12 * sum0.final_cost
-    assert np.abs(t1 - t0).max() <= 1e-10 and np.abs(s1 - s0).max() <= 1e-10
+    # the two runs use different (both exact-to-tolerance) PCG variants: two-level preconditioner vs Chronopoulos-Gear block-Jacobi
+    assert abs(sum1.final_cost - sum0.final_cost) <= 1e-9 * sum0.final_cost
+    assert np.abs(t1 - t0).max() <= 1e-7 and np.abs(s1 - s0).max() <= 1e-7
 
 
 def test_c3_early_rejection_does_not_change_the_iterates(c3):
