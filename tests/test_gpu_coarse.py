@@ -1,0 +1,93 @@
+"""GPU: the two-level preconditioner (block-Jacobi + rigid-body modes of keyframe aggregates; pgo_options.coarse_aggregates).  A
+preconditioner does not change what the PCG converges to, so the checks are: same LM trajectory as with plain block-Jacobi and as
+the oracle's exact solve, far fewer PCG iterations where it pays, and the once-per-solve comparison dropping it where it does not."""
+import numpy as np
+import pytest
+
+from solve_keyframe_pose_graph_amd import graphgen
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def run(g, switchable=True, **kw):
+    q, t, s = util.initial_state(g, switchable)
+    P = util.pgo_problem(g, switchable, **kw)
+    out = P.solve(q, t, s)
+    P.close()
+    return out
+
+
+@pytest.mark.parametrize("name,switchable", [("C1", True), ("C1F5", True), ("C2", False)])
+def test_same_trajectory_far_fewer_iterations_on_the_small_configs(name, switchable):
+    g = graphgen.config(name)
+    _, t0, s0, off = run(g, switchable, coarse_aggregates=0, cg_max_iterations=200000)
+    _, t1, s1, on = run(g, switchable)
+    assert on.num_iterations == off.num_iterations
+    for k in range(off.num_logged):
+        a, b = off.iterations[k], on.iterations[k]
+        assert a.step_is_successful == b.step_is_successful
+        assert abs(a.cost - b.cost) <= 1e-7 * max(a.cost, 1e-12), (k, a.cost, b.cost)
+    assert np.abs(t1 - t0).max() <= 1e-5
+    assert on.cg_iterations * 5 < off.cg_iterations, (on.cg_iterations, off.cg_iterations)
+
+
+def test_mid_size_graph_matches_the_oracle_with_the_coarse_space_on_at_every_radius():
+    """8k keyframes, every step accepted, the trust region grows to 2e8: plain block-Jacobi needs > 10^5 iterations, two levels a few 10^3;
+    per-iteration costs against the oracle's exact Cholesky."""
+    g = graphgen.generate(8000, 5000, odom_f_max=2, seed=21, outlier_frac=0.1)
+    q, t, s = util.initial_state(g, True)
+    qo, to, so, sumo = util.oracle_problem(g, True).solve(q, t, s)
+    _, tp, sp, sump = run(g, True)
+    assert [sump.iterations[k].step_is_successful for k in range(sump.num_logged)] == [sumo.iterations[k].step_is_successful for k in range(sumo.num_logged)]
+    for k in range(sumo.num_logged):
+        assert abs(sumo.iterations[k].cost - sump.iterations[k].cost) <= 1e-6 * sumo.iterations[k].cost, k
+    assert sump.cg_iterations < 12000
+    assert np.abs(sp - so).max() <= 1e-3
+
+
+def test_large_aggregates_switch_on_only_at_large_radius_and_the_headline_graph_is_untouched(c3=None):
+    """100k keyframes / 512 aggregates = 196 keyframes each (> 64): the coarse space waits for radius >= coarse_min_radius, which the
+    10-iteration C3 trajectory never reaches — identical iteration counts with and without it."""
+    g = graphgen.config("C3")
+    _, _, _, off = run(g, True, coarse_aggregates=0)
+    _, _, _, on = run(g, True)
+    assert [on.iterations[k].cg_iterations for k in range(on.num_logged)] == [off.iterations[k].cg_iterations for k in range(off.num_logged)]
+    assert on.final_cost == off.final_cost
+    # forced on from the start (coarse_min_radius = 0) it still converges to the same trajectory
+    _, _, _, forced = run(g, True, coarse_min_radius=0.0)
+    assert [forced.iterations[k].step_is_successful for k in range(forced.num_logged)] == [off.iterations[k].step_is_successful for k in range(off.num_logged)]
+    assert abs(forced.final_cost - off.final_cost) <= 1e-6 * off.final_cost
+
+
+def test_dropped_where_it_does_not_pay():
+    """A chain that the reference's yaw weights cut into hundreds of loose pieces (15 degrees per keyframe: odometry weights ~1e-17 across
+    every turn): the aggregates' rigid-body modes are not the slow modes there and the coarse space costs iterations.  The once-per-solve
+    comparison notices at the first step and the rest of the solve runs plain block-Jacobi: same trajectory, bounded overhead."""
+    g = graphgen.generate(2000, 400, odom_f_max=5, apply_yaw_weight=1, seed=5, **graphgen._SMALL)
+    _, t0, _, off = run(g, True, coarse_aggregates=0)
+    _, t1, _, on = run(g, True)
+    assert [on.iterations[k].step_is_successful for k in range(on.num_logged)] == [off.iterations[k].step_is_successful for k in range(off.num_logged)]
+    assert abs(on.final_cost - off.final_cost) <= 1e-7 * off.final_cost
+    its_off = [off.iterations[k].cg_iterations for k in range(1, off.num_logged)]
+    its_on = [on.iterations[k].cg_iterations for k in range(1, on.num_logged)]
+    # once the comparison has run (at the first step solved to full accuracy with the coarse space) the solve is plain block-Jacobi
+    assert all(abs(a - b) <= 0.01 * b + 2 for a, b in zip(its_on[-4:], its_off[-4:])) or on.cg_iterations < off.cg_iterations
+    assert on.cg_iterations <= 1.35 * off.cg_iterations, (its_on, its_off)
+
+
+def test_constant_and_unreferenced_keyframes_with_the_coarse_space():
+    g = util.small_graph(700, 90, f=2, seed=37)
+    q, t, s = util.initial_state(g, True)
+    q = np.vstack([q, [[0.0, 0.0, 0.0, 1.0]] * 3]); t = np.vstack([t, np.arange(9.0).reshape(3, 3)])     # three keyframes nobody refers to
+    const = [0, 1, 2, 350, 351, 699]
+    from oracle import binding as ob
+    O = util.oracle_problem(g, True); O.set_nodes_constant(const)
+    qo, to, so, sumo = O.solve(q, t, s, ob.default_options(max_num_iterations=30, function_tolerance=1e-10))
+    P = util.pgo_problem(g, True, max_num_iterations=30, function_tolerance=1e-10)
+    P.set_nodes_constant(const)
+    qp, tp, sp, sump = P.solve(q, t, s)
+    P.close()
+    assert np.array_equal(tp.reshape(-1, 3)[const], t[const]) and np.array_equal(tp.reshape(-1, 3)[-3:], t[-3:])
+    assert abs(sump.final_cost - sumo.final_cost) <= 1e-6 * sumo.final_cost
+    assert sump.num_iterations == sumo.num_iterations
