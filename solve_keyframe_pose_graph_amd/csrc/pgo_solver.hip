@@ -911,7 +911,8 @@ int lm_step(pgo_problem* p, int ignore_termination, int* done) {
             HIPCHK(p, p->d_tmp.ensure((size_t)p->N * 6));
             HIPCHK(p, hipMemcpyAsync(p->d_tmp.p, p->C.x, (size_t)p->N * 6 * sizeof(double), hipMemcpyDeviceToDevice, p->st));
             const int saved_cap = p->opt.cg_max_iterations;
-            p->opt.cg_max_iterations = std::max(cg.iterations, 2 * (std::max(2, p->opt.cg_check_every) & ~1));
+            // an iteration with the coarse space costs about twice a plain one (three more kernels at the latency floor): equal TIME budgets
+            p->opt.cg_max_iterations = std::max(2 * cg.iterations, 2 * (std::max(2, p->opt.cg_check_every) & ~1));
             p->coarse_active = false;
             CgResult plain{0, false, 0.0, false};
             rc = run_pcg(p, &plain, false, o.cg_rel_tolerance, -1);
