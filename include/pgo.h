@@ -100,11 +100,12 @@ typedef struct pgo_options {
      * consecutive keyframes, the coarse operator formed and inverted densely (blocked Gauss-Jordan kernels) once per LM iteration.  It is used when the
      * aggregates hold <= 64 keyframes each (small and mid-size graphs: 3-20x fewer PCG iterations at every radius) and otherwise for LM
      * iterations whose trust-region radius is >= coarse_min_radius (aggregates up to 1024 keyframes), where the slow modes are the long
-     * wavelengths the coarse space removes (10-60x fewer iterations); with large aggregates at small radii it does not pay.  The solution of each step is the
-     * same to the PCG tolerance.  Single GPU only. */
+     * wavelengths the coarse space removes (10-60x fewer iterations); with large aggregates at small radii it does not pay.  Once per solve (and once more when a coarse space dropped
+     * at a small radius becomes eligible at coarse_min_radius) plain block-Jacobi gets the same time budget on the same system; the
+     * loser is not used for the rest of the solve.  The solution of each step is the same to the PCG tolerance.  Single GPU only. */
     int32_t coarse_aggregates;           /* 512 (coarse dimension 3072, 75 MB dense inverse); 0 disables */
     int32_t reserved2_;
-    double coarse_min_radius;            /* 1e6 */
+    double coarse_min_radius;            /* 1e5 */
     /* device selection */
     int32_t device_id;                   /* -1: use the current HIP device */
     int32_t verbosity;                   /* 0 silent (minimizer_progress_to_stdout=false, :1271), 1 per-iteration line on stderr */

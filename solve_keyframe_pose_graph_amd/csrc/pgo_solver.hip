@@ -116,6 +116,7 @@ struct pgo_problem {
     CoarseDev K{};
     bool coarse_built = false, coarse_active = false;
     int coarse_mode = 0;             // per solve: 0 not yet compared with plain block-Jacobi, 1 keep, 2 dropped (it did not pay on this graph)
+    int coarse_retests = 0; bool coarse_skip_all = false; double coarse_drop_radius = 0.0;   // dropped at a small radius: one more comparison once the radius reaches coarse_min_radius
     int coarse_backoff = 0, coarse_skip = 0;   // a handle that keeps dropping it (incremental triggers on the same kind of graph) retests ever more rarely
     uint64_t coarse_geometry_epoch = 0, lin_epoch = 0;   // lin_epoch counts linearisations (the centroids follow the poses)
     int64_t n_vio = 0;
@@ -764,7 +765,13 @@ static int build_coarse(pgo_problem* p) {
     // Where it pays: always when the aggregates are small (the coarse space is then a sizeable fraction of the problem: graphs up to
     // ~64 x coarse_aggregates keyframes), otherwise only at large trust regions, where the slow modes are the long wavelengths
     // (measured: scripts/gpu_coarse_ab.py).
-    if (!p->coarse_built || p->opt.coarse_aggregates <= 0 || p->coarse_mode == 2) return PGO_OK;
+    if (!p->coarse_built || p->opt.coarse_aggregates <= 0) return PGO_OK;
+    if (p->coarse_mode == 2) {
+        // dropped at a smaller trust region: the long wavelengths it removes dominate more and more as the radius grows, so it gets another
+        // comparison once the radius is 9x (two accepted steps) beyond the one it lost at — at most twice per solve
+        if (p->coarse_retests >= 2 || p->coarse_skip_all || !(p->radius >= 9.0 * p->coarse_drop_radius && p->radius >= p->opt.coarse_min_radius)) return PGO_OK;
+        ++p->coarse_retests; p->coarse_mode = 0;
+    }
     if (!(p->K.m <= 64 || (p->radius >= p->opt.coarse_min_radius && p->K.m <= 1024))) return PGO_OK;   // aggregates of thousands of keyframes are too coarse to help
     if (p->coarse_geometry_epoch != p->lin_epoch) {          // the aggregates' centroids follow the poses of the current linearisation
         launch_coarse_geometry(p->G, p->K, p->d_pose[p->cur].p, p->st);
@@ -778,6 +785,7 @@ static int build_coarse(pgo_problem* p) {
     HIPCHK(p, hipMemcpyAsync(&h, fail, sizeof(h), hipMemcpyDeviceToHost, p->st));
     HIPCHK(p, hipStreamSynchronize(p->st));
     p->coarse_active = h == 0;
+    if (p->opt.verbosity > 0) std::fprintf(stderr, "[pgo] coarse space: %d aggregates of %d keyframes, %d blocks, radius %.1e: %s\n", p->K.n_agg, p->K.m, p->K.n_blk, p->radius, h == 0 ? "on" : "coarse operator not positive definite -> off");
     return PGO_OK;
 }
 
@@ -830,7 +838,8 @@ int solve_begin(pgo_problem* p, const double* quat, const double* t, const doubl
     p->t_device0 = now_s();
     std::memset(&p->sum, 0, sizeof(p->sum));
     p->in_solve = true; p->terminated = false; p->scale_ready = false; p->have_prev_step = false;
-    if (p->coarse_skip > 0) { p->coarse_mode = 2; --p->coarse_skip; } else p->coarse_mode = 0;
+    p->coarse_retests = 0; p->coarse_drop_radius = 0.0;
+    if (p->coarse_skip > 0) { p->coarse_mode = 2; p->coarse_skip_all = true; --p->coarse_skip; } else { p->coarse_mode = 0; p->coarse_skip_all = false; }
     p->radius = p->opt.initial_trust_region_radius; p->decrease_factor = 2.0; p->reuse_diagonal = false; p->iteration = 0; p->invalid = 0;
     p->sum.termination_type = PGO_NO_CONVERGENCE;
     if ((rc = linearize(p, &p->x_cost)) != PGO_OK) return rc;
@@ -911,16 +920,16 @@ int lm_step(pgo_problem* p, int ignore_termination, int* done) {
             HIPCHK(p, p->d_tmp.ensure((size_t)p->N * 6));
             HIPCHK(p, hipMemcpyAsync(p->d_tmp.p, p->C.x, (size_t)p->N * 6 * sizeof(double), hipMemcpyDeviceToDevice, p->st));
             const int saved_cap = p->opt.cg_max_iterations;
-            // an iteration with the coarse space costs about twice a plain one (three more kernels at the latency floor): equal TIME budgets
-            p->opt.cg_max_iterations = std::max(2 * cg.iterations, 2 * (std::max(2, p->opt.cg_check_every) & ~1));
+            // an iteration with the coarse space costs 2.6-2.8x a plain one (three more kernels at the latency floor, measured from 200 to
+            // 20k keyframes): equal TIME budgets
+            p->opt.cg_max_iterations = std::max(3 * cg.iterations, 2 * (std::max(2, p->opt.cg_check_every) & ~1));
             p->coarse_active = false;
             CgResult plain{0, false, 0.0, false};
             rc = run_pcg(p, &plain, false, o.cg_rel_tolerance, -1);
             p->opt.cg_max_iterations = saved_cap;
             if (rc != PGO_OK) return rc;
             if (plain.converged && !plain.breakdown) {      // block-Jacobi alone is at least as fast here
-                p->coarse_mode = 2; cg.iterations += plain.iterations;
-                p->coarse_backoff = std::min(2 * p->coarse_backoff + 1, 15); p->coarse_skip = p->coarse_backoff;
+                p->coarse_mode = 2; cg.iterations += plain.iterations; p->coarse_drop_radius = p->radius;
             }
             else {
                 p->coarse_mode = 1; p->coarse_active = true; p->coarse_backoff = 0;
@@ -1043,6 +1052,9 @@ int solve_end(pgo_problem* p, double* quat, double* t, double* sw, pgo_summary* 
         std::memcpy(t, ht.data(), ht.size() * sizeof(double));
         if (sw && p->S > 0) std::memcpy(sw, hs.data(), hs.size() * sizeof(double));
     }
+    // a solve in which the coarse space lost every comparison: the following solves of this handle (incremental triggers on the same kind
+    // of graph) skip it, 1, 3, 7, 15 solves at a time, before comparing again; one win resets the back-off
+    if (p->coarse_mode == 2 && !p->coarse_skip_all) { p->coarse_backoff = std::min(2 * p->coarse_backoff + 1, 15); p->coarse_skip = p->coarse_backoff; }
     p->sum.seconds_total = now_s() - p->t_begin;
     if (out) *out = p->sum;
     p->in_solve = false;
@@ -1094,7 +1106,7 @@ void pgo_options_init(pgo_options* o) {
     o->cg_mid_tolerance = 1e-4;
     o->cg_mid_reject_rho = -0.05;
     o->coarse_aggregates = 512;
-    o->coarse_min_radius = 1e6;
+    o->coarse_min_radius = 1e5;
     o->cg_rel_tolerance = 1e-9;     // loosest decade that keeps the 10-iteration chi^2 of C3 within 1e-8 of the 1e-13 solve
     o->device_id = -1;
     o->verbosity = 0;
