@@ -511,3 +511,25 @@ def probe12(n, radii, n_aggs=(128, 512, 2048)):
                 M = TwoLevel(A, t, agg, Dinv, mode)
                 t0 = time.time(); x2, k2 = pcg(A, b, M, 1e-9, maxit=50000)
                 print('   chain aggregates %5d (coarse dim %5d) %-4s: its %5d (%.0fs) err %.1e' % (na, M.nc, mode, k2, time.time() - t0, np.abs(x2 - x).max() / np.abs(x).max()), flush=True)
+
+
+class MGAddList(MGList):
+    """additive multilevel (BPX-like): z = D0^-1 r + P1 (D1^-1 + P2 (... exact)) P1^T r — no residual matvecs, symmetric"""
+    def vcycle(self, lvl, r):
+        L = self.levels[lvl]
+        if 'lu' in L: return L['lu'].solve(r)
+        return L['Dinv'] @ r + L['P'] @ self.vcycle(lvl + 1, L['P'].T @ r)
+
+
+def probe13(n, radii, configs):
+    g = graphgen.generate(n, n, odom_f_max=2, seed=3)
+    q, t, s = util.initial_state(g, True)
+    N = g.n_poses
+    for radius in radii:
+        A, b = build_system(g, q, t, s, radius)
+        Dinv = block_diag_inv(A, N)
+        t0 = time.time(); x, k = pcg(A, b, lambda r: Dinv @ r, 1e-9, maxit=60000); print('n %d radius %g  block-Jacobi its %d (%.0fs)' % (n, radius, k, time.time() - t0), flush=True)
+        for ms in configs:
+            M = MGAddList(A, t, list(ms))
+            t0 = time.time(); x2, k2 = pcg(A, b, M, 1e-9, maxit=20000)
+            print('   additive multilevel ms=%s: its %d (%.0fs) err %.1e' % (list(ms), k2, time.time() - t0, np.abs(x2 - x).max() / np.abs(x).max()), flush=True)
