@@ -462,7 +462,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S) {
     {
         int n_agg = p->opt.coarse_aggregates;
         if (n_agg > N / 8) n_agg = (int)(N / 8);
-        if (n_agg >= 2 && !p->local_ids) {
+        if (n_agg >= 2 && !p->local_ids && (N + n_agg - 1) / n_agg <= 1024) {    // aggregates of thousands of keyframes are never used (build_coarse)
             const int m = (int)((N + n_agg - 1) / n_agg);
             n_agg = (int)((N + m - 1) / m);
             std::vector<int32_t> agg_free((size_t)n_agg, 0);
