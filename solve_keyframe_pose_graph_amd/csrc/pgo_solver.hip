@@ -769,7 +769,7 @@ static int build_coarse(pgo_problem* p) {
     if (p->coarse_mode == 2) {
         // dropped at a smaller trust region: the long wavelengths it removes dominate more and more as the radius grows, so it gets another
         // comparison once the radius is 9x (two accepted steps) beyond the one it lost at — at most twice per solve
-        if (p->coarse_retests >= 2 || p->coarse_skip_all || !(p->radius >= 9.0 * p->coarse_drop_radius && p->radius >= p->opt.coarse_min_radius)) return PGO_OK;
+        if (p->coarse_retests >= 2 || p->coarse_skip_all || !(p->radius >= 9.0 * p->coarse_drop_radius)) return PGO_OK;   // (eligibility by aggregate size / coarse_min_radius is checked below)
         ++p->coarse_retests; p->coarse_mode = 0;
     }
     if (!(p->K.m <= 64 || (p->radius >= p->opt.coarse_min_radius && p->K.m <= 1024))) return PGO_OK;   // aggregates of thousands of keyframes are too coarse to help
@@ -929,6 +929,9 @@ int lm_step(pgo_problem* p, int ignore_termination, int* done) {
             p->opt.cg_max_iterations = saved_cap;
             if (rc != PGO_OK) return rc;
             if (plain.converged && !plain.breakdown) {      // block-Jacobi alone is at least as fast here
+                // lost although it needed clearly fewer iterations: worth another comparison at a larger radius; lost without even that
+                // (the aggregates' rigid modes are not this graph's slow modes): no more comparisons in this solve
+                if ((double)plain.iterations < 1.2 * (double)cg.iterations) p->coarse_retests = 2;
                 p->coarse_mode = 2; cg.iterations += plain.iterations; p->coarse_drop_radius = p->radius;
             }
             else {
