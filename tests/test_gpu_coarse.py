@@ -91,3 +91,17 @@ def test_constant_and_unreferenced_keyframes_with_the_coarse_space():
     assert np.array_equal(tp.reshape(-1, 3)[const], t[const]) and np.array_equal(tp.reshape(-1, 3)[-3:], t[-3:])
     assert abs(sump.final_cost - sumo.final_cost) <= 1e-6 * sumo.final_cost
     assert sump.num_iterations == sumo.num_iterations
+
+
+def test_two_runs_are_bitwise_identical_with_the_coarse_space():
+    """Galerkin assembly in list order, Gauss-Jordan, wavefront reductions: no atomics anywhere, so two solves give the same bits."""
+    g = graphgen.generate(6000, 4000, odom_f_max=2, seed=77, outlier_frac=0.1)
+    q, t, s = util.initial_state(g, True)
+    outs = []
+    for _ in range(2):
+        P = util.pgo_problem(g, True)
+        outs.append(P.solve(q, t, s))
+        P.close()
+    (qa, ta, sa, suma), (qb, tb, sb, sumb) = outs
+    assert suma.cg_iterations == sumb.cg_iterations and suma.cg_iterations < 20000
+    assert np.array_equal(qa, qb) and np.array_equal(ta, tb) and np.array_equal(sa, sb) and suma.final_cost == sumb.final_cost
