@@ -332,6 +332,11 @@ int pgo_time_kernel(pgo_problem* p, int32_t which, int32_t launches, double* avg
  * algorithmic bytes 128 B x poses + (8 + 64) B x edges. */
 int pgo_time_vio_odometry_kernel(pgo_problem* p, int32_t f_max, int32_t launches, double* avg_ms, double* algorithmic_bytes);
 
+/* K6's dense inverse on its own (test and measurement hook): inverts the symmetric positive definite n x n matrix `a` (row-major, host)
+ * with the blocked Gauss-Jordan kernels the two-level preconditioner uses for its coarse operator, `launches` times; `a_inv` (host) gets
+ * the result, *avg_ms (may be NULL) the HIP-event average of one inversion.  PGO_ERR_NUMERIC when a pivot is not positive. */
+int pgo_dense_spd_inverse(pgo_problem* p, int32_t n, const double* a, double* a_inv, int32_t launches, double* avg_ms);
+
 int pgo_device_synchronize(pgo_problem* p);
 
 const char* pgo_strerror(int code);

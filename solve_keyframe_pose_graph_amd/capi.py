@@ -52,7 +52,7 @@ EXPORTS = [
     "pgo_solve", "pgo_solve_begin", "pgo_lm_step", "pgo_solve_end", "pgo_evaluate",
     "pgo_get_jacobian_blocks", "pgo_get_normal_blocks", "pgo_apply_normal_operator",
     "pgo_comm_get_unique_id", "pgo_comm_init", "pgo_comm_destroy", "pgo_comm_init_custom",
-    "pgo_time_linearize_kernel", "pgo_time_kernel", "pgo_time_vio_odometry_kernel", "pgo_device_synchronize", "pgo_strerror", "pgo_last_error",
+    "pgo_time_linearize_kernel", "pgo_time_kernel", "pgo_time_vio_odometry_kernel", "pgo_dense_spd_inverse", "pgo_device_synchronize", "pgo_strerror", "pgo_last_error",
 ]
 
 _lib = None
@@ -275,6 +275,14 @@ class Problem:
         ms = C.c_double(0); by = C.c_double(0)
         self._check(self.lib.pgo_time_vio_odometry_kernel(self.h, C.c_int32(f_max), C.c_int32(launches), C.byref(ms), C.byref(by)))
         return ms.value, by.value
+
+    def dense_spd_inverse(self, a, launches=1):
+        """K6's blocked Gauss-Jordan inverse of a symmetric positive definite matrix; returns (inverse, average milliseconds)."""
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        n = a.shape[0]
+        out = np.empty_like(a); ms = C.c_double(0)
+        self._check(self.lib.pgo_dense_spd_inverse(self.h, C.c_int32(n), _pd(a), _pd(out), C.c_int32(launches), C.byref(ms)))
+        return out, ms.value
 
     def synchronize(self):
         self._check(self.lib.pgo_device_synchronize(self.h))

@@ -1693,112 +1693,158 @@ void launch_coarse_apply(const GraphDev& G, const CgDev& C, const CoarseDev& K, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Dense inverse of the (symmetric positive definite) coarse operator, in place: blocked Gauss-Jordan without pivoting, block size 32.
-// Per pivot block k:  P = A_kk^-1 ; A_kj <- P A_kj (j != k) ; A_ij <- A_ij - A_ik A_kj (i, j != k, old A_ik) ; A_ik <- -A_ik P ; A_kk <- P.
-// Three launches per block (pivot / panels / trailing update); n is a multiple of 64 (padded with an identity block).  2 n^3 flops, the
-// matrix (<= 75 MB) stays in L2 / Infinity Cache.  Written here instead of calling rocSOLVER: the first rocBLAS handle of a process costs
+// Dense inverse of the (symmetric positive definite) coarse operator, in place: blocked Gauss-Jordan without pivoting, block size 32,
+// working on the (row-major) UPPER triangle only.  After the blocks before k0 have been swept the full Gauss-Jordan matrix M satisfies
+// M_ij = M_ji when i and j are on the same side of k0 and M_ij = -M_ji otherwise, so with
+//     u_x = the old coupling of index x to the pivot block (row x of the column panel for x < k0, column x of the row panel for x > k),
+//     v_x = P u_x,  P = A_kk^-1,  s_x = -1 for x < k0 and +1 beyond the pivot block,
+// one step is:  panels  A[x][k] = -v_x (x < k0),  A[k][x] = v_x (x > k),  A_kk = P ;  trailing update  A_ij -= u_i . (s_j v_j)  for i <= j.
+// Two launches per block: `gj_panels` (V^T = P U^T on the fp64 MFMA, one wavefront per 16 indices; writes the new panels and U^T, s V^T in
+// k-major scratch) and `gj_update` (64 x 64 tile per workgroup on or above the diagonal, 32 x 32 per wavefront as 2 x 2 MFMA 16x16x4 tiles
+// over K = 32, operands straight from the L2-resident scratch).  The workgroup that owns the NEXT pivot block inverts it in LDS right after
+// updating it, so the pivot inverse never sits on the critical path.  Rows and columns of the pivot block carry u = v = 0 and so pass
+// through the update unchanged.  n is a multiple of 64 (padded with an identity block).  n^3 flops on half the matrix per step; the matrix
+// (<= 75 MB) streams from the Infinity Cache.  Written here instead of calling rocSOLVER: the first rocBLAS handle of a process costs
 // seconds to minutes of library loading on a cold box.
+// v_mfma_f64_16x16x4_f64 operand maps: A[l & 15][k = l >> 4], B[k = l >> 4][l & 15], D[row = (l >> 4) + 4 reg][col = l & 15].
 // ------------------------------------------------------------------------------------------------
 constexpr int GJ_NB = 32;
+typedef double gj_d4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(1024) void gj_pivot_kernel(const double* __restrict__ A, int n, int k0, double* __restrict__ Pinv, int32_t* __restrict__ fail) {
-    __shared__ double a[GJ_NB][GJ_NB + 1];
-    const int r = threadIdx.x / GJ_NB, c = threadIdx.x % GJ_NB;
-    a[r][c] = A[(size_t)(k0 + r) * n + k0 + c];
-    __syncthreads();
+// 32 x 32 Gauss-Jordan in LDS by the 256 threads of a workgroup; `a` holds the symmetric block.  Writes the symmetrised inverse to Pinv.
+__device__ inline void gj_block_inverse(double (*a)[GJ_NB + 1], double* __restrict__ Pinv, int32_t* __restrict__ fail) {
+    const int tid = threadIdx.x, r = tid >> 3, c0 = (tid & 7) * 4;
     for (int p = 0; p < GJ_NB; ++p) {
-        const double piv = a[p][p], arp = a[r][p], apc = a[p][c], arc = a[r][c];
+        const double piv = a[p][p], arp = a[r][p];
+        double apc[4], arc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { apc[q] = a[p][c0 + q]; arc[q] = a[r][c0 + q]; }
         __syncthreads();
-        double v;
-        if (r == p) v = c == p ? 1.0 / piv : apc / piv;
-        else v = c == p ? -arp / piv : arc - arp * apc / piv;
-        a[r][c] = v;
-        if (threadIdx.x == 0 && !(piv > 0.0)) *fail = 1;     // not positive definite (or NaN)
+        const double inv = 1.0 / piv, f = arp * inv;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = c0 + q;
+            double v;
+            if (r == p) v = c == p ? inv : apc[q] * inv;
+            else v = c == p ? -f : arc[q] - f * apc[q];
+            a[r][c] = v;
+        }
+        if (tid == 0 && !(piv > 0.0)) *fail = 1;     // not positive definite (or NaN)
         __syncthreads();
     }
-    Pinv[r * GJ_NB + c] = a[r][c];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Pinv[r * GJ_NB + c0 + q] = 0.5 * (a[r][c0 + q] + a[c0 + q][r]);
 }
 
-// threads [0, n): row i — save the old column panel, write the new one (or the pivot block's inverse);
-// threads [n, 2n): column j outside the pivot block — new row panel P A_kj
-__global__ __launch_bounds__(256) void gj_panels_kernel(double* __restrict__ A, int n, int k0, const double* __restrict__ Pinv, double* __restrict__ Cold) {
-    __shared__ double P[GJ_NB][GJ_NB + 1];
-    for (int t = threadIdx.x; t < GJ_NB * GJ_NB; t += blockDim.x) P[t / GJ_NB][t % GJ_NB] = Pinv[t];
-    __syncthreads();
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n) {
-        const int i = t;
-        double old[GJ_NB];
-        double* row = A + (size_t)i * n + k0;
+// the first pivot block (the later ones are inverted by gj_update_kernel one step ahead)
+__global__ __launch_bounds__(256) void gj_pivot_kernel(const double* __restrict__ A, int n, int k0, double* __restrict__ Pinv, int32_t* __restrict__ fail) {
+    __shared__ double a[GJ_NB][GJ_NB + 1];
+    const int r = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 4;
 #pragma unroll
-        for (int c = 0; c < GJ_NB; ++c) old[c] = row[c];
-#pragma unroll
-        for (int c = 0; c < GJ_NB; ++c) Cold[(size_t)i * GJ_NB + c] = old[c];
-        if (i >= k0 && i < k0 + GJ_NB) {
-#pragma unroll
-            for (int c = 0; c < GJ_NB; ++c) row[c] = P[i - k0][c];
-        } else {
-            for (int cc = 0; cc < GJ_NB; ++cc) {
-                double s = 0.0;
-#pragma unroll
-                for (int c = 0; c < GJ_NB; ++c) s += old[c] * P[c][cc];
-                row[cc] = -s;
-            }
-        }
-    } else if (t < 2 * n) {
-        const int j = t - n;
-        if (j >= k0 && j < k0 + GJ_NB) return;
-        double col[GJ_NB];
-#pragma unroll
-        for (int c = 0; c < GJ_NB; ++c) col[c] = A[(size_t)(k0 + c) * n + j];
-        for (int r = 0; r < GJ_NB; ++r) {
-            double s = 0.0;
-#pragma unroll
-            for (int c = 0; c < GJ_NB; ++c) s += P[r][c] * col[c];
-            A[(size_t)(k0 + r) * n + j] = s;
-        }
+    for (int q = 0; q < 4; ++q) {
+        const int c = c0 + q, lo = r < c ? r : c, hi = r < c ? c : r;
+        a[r][c] = A[(size_t)(k0 + lo) * n + k0 + hi];
     }
+    __syncthreads();
+    gj_block_inverse(a, Pinv, fail);
 }
 
-// trailing update: 64 x 64 tile per workgroup, 4 x 4 per thread; rows and columns of the pivot block are left alone
-__global__ __launch_bounds__(256) void gj_update_kernel(double* __restrict__ A, int n, int k0, const double* __restrict__ Cold) {
-    __shared__ double Cs[64][GJ_NB + 1];
-    __shared__ double Rs[GJ_NB][64 + 1];
-    const int ti = blockIdx.y * 64, tj = blockIdx.x * 64;
-    for (int t = threadIdx.x; t < 64 * GJ_NB; t += 256) {
-        const int r = t / GJ_NB, c = t % GJ_NB;
-        Cs[r][c] = Cold[(size_t)(ti + r) * GJ_NB + c];
-        const int rr = t / 64, cc = t % 64;
-        Rs[rr][cc] = A[(size_t)(k0 + rr) * n + tj + cc];
-    }
-    __syncthreads();
-    const int r0 = (threadIdx.x / 16) * 4, c0 = (threadIdx.x % 16) * 4;
-    double acc[4][4];
+// one wavefront per 16 consecutive indices x
+__global__ __launch_bounds__(256) void gj_panels_kernel(double* __restrict__ A, int n, int k0, const double* __restrict__ Pinv, double* __restrict__ UT, double* __restrict__ VT) {
+    const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+    const int x0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    if (x0 >= n) return;
+    if (x0 >= k0 && x0 < k0 + GJ_NB) {           // pivot rows: the block becomes P; zero coupling keeps them out of the trailing update
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-#pragma unroll 8
-    for (int k = 0; k < GJ_NB; ++k) {
-        double cv[4], rv[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) { cv[a] = Cs[r0 + a][k]; rv[a] = Rs[k][c0 + a]; }
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] += cv[a] * rv[b];
-    }
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const int i = ti + r0 + a;
-        if (i >= k0 && i < k0 + GJ_NB) continue;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int j = tj + c0 + b;
-            if (j >= k0 && j < k0 + GJ_NB) continue;
-            A[(size_t)i * n + j] -= acc[a][b];
+        for (int kk = 0; kk < GJ_NB / 4; ++kk) {
+            const int k = kk * 4 + lk;
+            UT[(size_t)k * n + x0 + lr] = 0.0; VT[(size_t)k * n + x0 + lr] = 0.0;
+            A[(size_t)(x0 + lr) * n + k0 + k] = Pinv[(x0 - k0 + lr) * GJ_NB + k];
         }
+        return;
     }
+    const bool before = x0 < k0;
+    double u[GJ_NB / 4];
+#pragma unroll
+    for (int kk = 0; kk < GJ_NB / 4; ++kk) {
+        const int k = kk * 4 + lk;
+        u[kk] = before ? A[(size_t)(x0 + lr) * n + k0 + k] : A[(size_t)(k0 + k) * n + x0 + lr];
+    }
+    gj_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < GJ_NB / 4; ++kk) {
+        const int k = kk * 4 + lk;
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Pinv[lr * GJ_NB + k], u[kk], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Pinv[(16 + lr) * GJ_NB + k], u[kk], acc1, 0, 0, 0);
+    }
+    const double sgn = before ? -1.0 : 1.0;
+#pragma unroll
+    for (int kk = 0; kk < GJ_NB / 4; ++kk) UT[(size_t)(kk * 4 + lk) * n + x0 + lr] = u[kk];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int c = h * 16 + lk + 4 * reg;                       // D row -> index inside the pivot block, D column lr -> x
+            const double w = sgn * (h == 0 ? acc0[reg] : acc1[reg]);
+            VT[(size_t)c * n + x0 + lr] = w;
+            if (before) A[(size_t)(x0 + lr) * n + k0 + c] = w;
+            else A[(size_t)(k0 + c) * n + x0 + lr] = w;
+        }
+}
+
+// trailing update of the tiles on or above the diagonal; the owner of the next pivot block also inverts it (into Pinv)
+__global__ __launch_bounds__(256) void gj_update_kernel(double* __restrict__ A, int n, int k0, const double* __restrict__ UT, const double* __restrict__ VT, double* __restrict__ Pinv, int32_t* __restrict__ fail) {
+    __shared__ double a[GJ_NB][GJ_NB + 1];
+    const int k1 = k0 + GJ_NB, kt = k1 < n ? k1 / 64 : 0;
+    int bi = blockIdx.y, bj = blockIdx.x;
+    if (bi == 0 && bj == 0) bi = bj = kt;                             // the tile of the next pivot block is dispatched first: its
+    else if (bi == kt && bj == kt) bi = bj = 0;                       // in-LDS inversion overlaps with the other tiles
+    if (bj < bi) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int i0 = bi * 64 + wr * 32, j0 = bj * 64 + wc * 32;
+    const bool ahead = k1 < n && bi == bj && bi == kt;                // this workgroup owns the next pivot block
+    if (!(bi == bj && wr == 1 && wc == 0)) {                          // (that quadrant lies below the diagonal)
+        gj_d4 acc[2][2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[s][t] = gj_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < GJ_NB / 4; ++kk) {
+            const size_t row = (size_t)(kk * 4 + lk) * n;
+            const double a0 = UT[row + i0 + lr], a1 = UT[row + i0 + 16 + lr], b0 = VT[row + j0 + lr], b1 = VT[row + j0 + 16 + lr];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        const bool mine = ahead && i0 == k1 && j0 == k1;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int i = i0 + s * 16 + lk + 4 * reg, j = j0 + t * 16 + lr;
+                    const double v = A[(size_t)i * n + j] - acc[s][t][reg];
+                    A[(size_t)i * n + j] = v;
+                    if (mine) a[i - k1][j - k1] = v;
+                }
+    }
+    if (!ahead) return;
+    __syncthreads();
+    {   // only the upper triangle of the block is maintained: mirror it
+        const int r = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 4;
+        double m[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int c = c0 + q; m[q] = r <= c ? a[r][c] : a[c][r]; }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[r][c0 + q] = m[q];
+        __syncthreads();
+    }
+    gj_block_inverse(a, Pinv, fail);
 }
 
 __global__ void coarse_pad_identity_kernel(CoarseDev K) {    // rows/columns beyond 6 n_agg: a decoupled identity block
@@ -1813,16 +1859,17 @@ __global__ void coarse_shift_kernel(CoarseDev K, double eps) {
 void launch_coarse_shift(const CoarseDev& K, double eps, hipStream_t st) { hipLaunchKernelGGL(coarse_shift_kernel, dim3((unsigned)((K.nc + 255) / 256)), dim3(256), 0, st, K, eps); }
 
 // Ac (assembled, padded) -> Ac^-1, exactly symmetric; *fail != 0 when a pivot was not positive
-void launch_coarse_invert(const CoarseDev& K, double* scratch /* nc x 32 + 1024 doubles */, int32_t* fail, hipStream_t st) {
+void launch_coarse_invert(const CoarseDev& K, double* scratch /* 64 nc + 1024 doubles */, int32_t* fail, hipStream_t st) {
     const int n = K.nc;
-    double* Cold = scratch;
-    double* Pinv = scratch + (size_t)n * GJ_NB;
+    double* UT = scratch;
+    double* VT = scratch + (size_t)n * GJ_NB;
+    double* Pinv = scratch + (size_t)n * GJ_NB * 2;
+    hipLaunchKernelGGL(gj_pivot_kernel, dim3(1), dim3(256), 0, st, K.Ac, n, 0, Pinv, fail);
     for (int k0 = 0; k0 < n; k0 += GJ_NB) {
-        hipLaunchKernelGGL(gj_pivot_kernel, dim3(1), dim3(GJ_NB * GJ_NB), 0, st, K.Ac, n, k0, Pinv, fail);
-        hipLaunchKernelGGL(gj_panels_kernel, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), 0, st, K.Ac, n, k0, Pinv, Cold);
-        hipLaunchKernelGGL(gj_update_kernel, dim3((unsigned)(n / 64), (unsigned)(n / 64)), dim3(256), 0, st, K.Ac, n, k0, Cold);
+        hipLaunchKernelGGL(gj_panels_kernel, dim3((unsigned)((n / 16 + 3) / 4)), dim3(256), 0, st, K.Ac, n, k0, Pinv, UT, VT);
+        hipLaunchKernelGGL(gj_update_kernel, dim3((unsigned)(n / 64), (unsigned)(n / 64)), dim3(256), 0, st, K.Ac, n, k0, UT, VT, Pinv, fail);
     }
-    launch_coarse_symmetrize(K, st);
+    launch_coarse_symmetrize(K, st);     // lower <- upper
 }
 
 }  // namespace pgo

@@ -493,7 +493,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S) {
             const int n_blk = (int)blk_ab.size() / 2;
             const int nc = (6 * n_agg + 63) / 64 * 64;      // padded with a decoupled identity block (the dense kernels work on 64-wide tiles)
             HIPCHK(p, p->d_ccen.ensure((size_t)n_agg * 3)); HIPCHK(p, p->d_cd.ensure((size_t)N * 3)); HIPCHK(p, p->d_cAc.ensure((size_t)nc * nc));
-            HIPCHK(p, p->d_crc.ensure((size_t)nc * 2)); HIPCHK(p, p->d_cscr.ensure((size_t)nc * 32 + 1024)); HIPCHK(p, hipMemsetAsync(p->d_crc.p, 0, (size_t)nc * 2 * sizeof(double), p->st)); HIPCHK(p, p->d_cblk_ptr.ensure(blk_ptr.size())); HIPCHK(p, p->d_ccontrib.ensure(std::max<size_t>(contrib.size(), 1)));
+            HIPCHK(p, p->d_crc.ensure((size_t)nc * 2)); HIPCHK(p, p->d_cscr.ensure((size_t)nc * 64 + 1024)); HIPCHK(p, hipMemsetAsync(p->d_crc.p, 0, (size_t)nc * 2 * sizeof(double), p->st)); HIPCHK(p, p->d_cblk_ptr.ensure(blk_ptr.size())); HIPCHK(p, p->d_ccontrib.ensure(std::max<size_t>(contrib.size(), 1)));
             HIPCHK(p, p->d_cblk_ab.ensure(blk_ab.size())); HIPCHK(p, p->d_cagg_free.ensure(n_agg)); HIPCHK(p, p->d_cinfo.ensure(4));
             HIPCHK(p, hipMemcpyAsync(p->d_cblk_ptr.p, blk_ptr.data(), blk_ptr.size() * sizeof(int64_t), hipMemcpyHostToDevice, p->st));
             if (!contrib.empty()) HIPCHK(p, hipMemcpyAsync(p->d_ccontrib.p, contrib.data(), contrib.size() * sizeof(int64_t), hipMemcpyHostToDevice, p->st));
@@ -1549,6 +1549,43 @@ int pgo_time_vio_odometry_kernel(pgo_problem* p, int32_t f_max, int32_t launches
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     *avg_ms = (double)ms / launches;
     if (algorithmic_bytes) *algorithmic_bytes = 128.0 * (double)p->n_vio + (8.0 + 64.0) * (double)n;   // each pose once + 2 indices + one record per edge
+    return PGO_OK;
+}
+
+int pgo_dense_spd_inverse(pgo_problem* p, int32_t n, const double* a, double* a_inv, int32_t launches, double* avg_ms) {
+    if (!p || n <= 0 || !a || !a_inv || launches < 1) return PGO_ERR_INVALID_ARG;
+    int rc;
+    if ((rc = set_device(p)) != PGO_OK) return rc;
+    const int nc = (n + 63) / 64 * 64;
+    std::vector<double> h((size_t)nc * nc, 0.0);
+    for (int i = 0; i < nc; ++i) {
+        if (i < n) std::memcpy(&h[(size_t)i * nc], a + (size_t)i * n, (size_t)n * sizeof(double));
+        else h[(size_t)i * nc + i] = 1.0;
+    }
+    ScopedBuf<double> d_a, d_scr; ScopedBuf<int32_t> d_fail;
+    HIPCHK(p, d_a.ensure((size_t)nc * nc)); HIPCHK(p, d_scr.ensure((size_t)nc * 64 + 1024)); HIPCHK(p, d_fail.ensure(1));
+    CoarseDev K{}; K.nc = nc; K.Ac = d_a.p;
+    hipEvent_t e0, e1;
+    HIPCHK(p, hipEventCreate(&e0)); HIPCHK(p, hipEventCreate(&e1));
+    float total = 0;
+    for (int l = 0; l < launches; ++l) {
+        HIPCHK(p, hipMemcpyAsync(d_a.p, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, p->st));
+        HIPCHK(p, hipMemsetAsync(d_fail.p, 0, sizeof(int32_t), p->st));
+        HIPCHK(p, hipEventRecord(e0, p->st));
+        launch_coarse_invert(K, d_scr.p, d_fail.p, p->st);
+        HIPCHK(p, hipEventRecord(e1, p->st));
+        HIPCHK(p, hipStreamSynchronize(p->st));
+        float ms = 0;
+        HIPCHK(p, hipEventElapsedTime(&ms, e0, e1));
+        total += ms;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    int32_t fail = 1;
+    HIPCHK(p, hipMemcpy(&fail, d_fail.p, sizeof(fail), hipMemcpyDeviceToHost));
+    HIPCHK(p, hipMemcpy(h.data(), d_a.p, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) std::memcpy(a_inv + (size_t)i * n, &h[(size_t)i * nc], (size_t)n * sizeof(double));
+    if (avg_ms) *avg_ms = (double)total / launches;
+    if (fail) { p->err = "matrix is not numerically positive definite"; return PGO_ERR_NUMERIC; }
     return PGO_OK;
 }
 

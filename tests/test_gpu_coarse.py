@@ -4,7 +4,7 @@ the oracle's exact solve, far fewer PCG iterations where it pays, and the once-p
 import numpy as np
 import pytest
 
-from solve_keyframe_pose_graph_amd import graphgen
+from solve_keyframe_pose_graph_amd import capi, graphgen
 from tests import util
 
 pytestmark = pytest.mark.gpu
@@ -105,3 +105,30 @@ def test_two_runs_are_bitwise_identical_with_the_coarse_space():
     (qa, ta, sa, suma), (qb, tb, sb, sumb) = outs
     assert suma.cg_iterations == sumb.cg_iterations and suma.cg_iterations < 20000
     assert np.array_equal(qa, qb) and np.array_equal(ta, tb) and np.array_equal(sa, sb) and suma.final_cost == sumb.final_cost
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [64, 96, 200, 1024, 3072])
+def test_dense_inverse_against_numpy(n):
+    """K6's blocked Gauss-Jordan (upper triangle, fp64 MFMA) against numpy on symmetric positive definite matrices whose conditioning
+    resembles a coarse operator's (a graph Laplacian-like stiff part plus a small damping on the diagonal)."""
+    rng = np.random.default_rng(n)
+    B = rng.standard_normal((n, max(8, n // 2)))
+    A = B @ B.T + np.diag(rng.uniform(1e-3, 1.0, n))
+    A = 0.5 * (A + A.T)
+    P = capi.Problem()
+    inv, ms = P.dense_spd_inverse(A)
+    P.close()
+    assert np.array_equal(inv, inv.T)
+    ref = np.linalg.inv(A)
+    assert np.abs(inv - ref).max() <= 1e-9 * np.abs(ref).max() * max(1.0, np.linalg.cond(A) * 1e-6)
+    assert np.abs(inv @ A - np.eye(n)).max() < 1e-7
+
+
+@pytest.mark.gpu
+def test_dense_inverse_reports_an_indefinite_matrix():
+    A = np.eye(128); A[70, 70] = -1.0
+    P = capi.Problem()
+    with pytest.raises(capi.PgoError):
+        P.dense_spd_inverse(A)
+    P.close()
