@@ -118,6 +118,7 @@ struct pgo_problem {
     int coarse_mode = 0;             // per solve: 0 not yet compared with plain block-Jacobi, 1 keep, 2 dropped (it did not pay on this graph)
     int coarse_retests = 0; bool coarse_skip_all = false; double coarse_drop_radius = 0.0;   // dropped at a small radius: one more comparison once the radius reaches coarse_min_radius
     int coarse_backoff = 0, coarse_skip = 0;   // a handle that keeps dropping it (incremental triggers on the same kind of graph) retests ever more rarely
+    int coarse_keep_streak = 0;      // consecutive solves that kept it: the comparison is then repeated only every 4th solve
     uint64_t coarse_geometry_epoch = 0, lin_epoch = 0;   // lin_epoch counts linearisations (the centroids follow the poses)
     int64_t n_vio = 0;
     // matrix-free operator
@@ -839,7 +840,8 @@ int solve_begin(pgo_problem* p, const double* quat, const double* t, const doubl
     std::memset(&p->sum, 0, sizeof(p->sum));
     p->in_solve = true; p->terminated = false; p->scale_ready = false; p->have_prev_step = false;
     p->coarse_retests = 0; p->coarse_drop_radius = 0.0;
-    if (p->coarse_skip > 0) { p->coarse_mode = 2; p->coarse_skip_all = true; --p->coarse_skip; } else { p->coarse_mode = 0; p->coarse_skip_all = false; }
+    if (p->coarse_skip > 0) { p->coarse_mode = 2; p->coarse_skip_all = true; --p->coarse_skip; }
+    else { p->coarse_mode = (p->coarse_keep_streak % 4 != 0) ? 1 : 0; p->coarse_skip_all = false; }
     p->radius = p->opt.initial_trust_region_radius; p->decrease_factor = 2.0; p->reuse_diagonal = false; p->iteration = 0; p->invalid = 0;
     p->sum.termination_type = PGO_NO_CONVERGENCE;
     if ((rc = linearize(p, &p->x_cost)) != PGO_OK) return rc;
@@ -1055,9 +1057,11 @@ int solve_end(pgo_problem* p, double* quat, double* t, double* sw, pgo_summary* 
         std::memcpy(t, ht.data(), ht.size() * sizeof(double));
         if (sw && p->S > 0) std::memcpy(sw, hs.data(), hs.size() * sizeof(double));
     }
+    // (a solve that kept it: the next three solves of this handle use it without the comparison)
     // a solve in which the coarse space lost every comparison: the following solves of this handle (incremental triggers on the same kind
     // of graph) skip it, 1, 3, 7, 15 solves at a time, before comparing again; one win resets the back-off
     if (p->coarse_mode == 2 && !p->coarse_skip_all) { p->coarse_backoff = std::min(2 * p->coarse_backoff + 1, 15); p->coarse_skip = p->coarse_backoff; }
+    if (p->coarse_mode == 1) ++p->coarse_keep_streak; else if (p->coarse_mode == 2 && !p->coarse_skip_all) p->coarse_keep_streak = 0;
     p->sum.seconds_total = now_s() - p->t_begin;
     if (out) *out = p->sum;
     p->in_solve = false;

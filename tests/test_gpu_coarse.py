@@ -108,6 +108,21 @@ def test_two_runs_are_bitwise_identical_with_the_coarse_space():
 
 
 @pytest.mark.gpu
+def test_a_handle_that_kept_it_skips_the_comparison_in_its_next_solves():
+    """Incremental triggers solve the same kind of graph again and again: after a solve in which the coarse space won its comparison the
+    next three solves of the handle use it without paying for the plain block-Jacobi run; the fifth compares again."""
+    g = graphgen.generate(6918, 1382, odom_f_max=3, seed=12, outlier_frac=0.3)
+    q, t, s = util.initial_state(g, True)
+    P = util.pgo_problem(g, True)
+    runs = [P.solve(q, t, s)[3] for _ in range(5)]
+    P.close()
+    cg = [r.cg_iterations for r in runs]
+    assert cg[1] == cg[2] == cg[3] and cg[1] < cg[0] and cg[4] == cg[0]
+    for r in runs[1:]:
+        assert r.num_iterations == runs[0].num_iterations and abs(r.final_cost - runs[0].final_cost) <= 1e-12 * runs[0].final_cost
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n", [64, 96, 200, 1024, 3072])
 def test_dense_inverse_against_numpy(n):
     """K6's blocked Gauss-Jordan (upper triangle, fp64 MFMA) against numpy on symmetric positive definite matrices whose conditioning
