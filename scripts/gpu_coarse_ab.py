@@ -15,7 +15,7 @@ def cases():
 for name, g, sw in cases():
     q, t, s = util.initial_state(g, sw)
     ref = None
-    for label, kw in (("off", dict(coarse_aggregates=0)), ("default", dict()), ("always", dict(coarse_min_radius=0.0)), ("512 aggs", dict(coarse_aggregates=512))):
+    for label, kw in (("off", dict(coarse_aggregates=0)), ("default", dict()), ("always", dict(coarse_min_radius=0.0)), ("256 aggs", dict(coarse_aggregates=256))):
         P = util.pgo_problem(g, sw, **kw)
         P.solve(q, t, s)
         _, tt, ss, sm = P.solve(q, t, s)

@@ -10,7 +10,8 @@ from solve_keyframe_pose_graph_amd.pose_graph_slam import PoseGraphSLAM
 from tests import util
 
 n, loops, every = (int(sys.argv[1]) if len(sys.argv) > 1 else 3000), (int(sys.argv[2]) if len(sys.argv) > 2 else 600), (int(sys.argv[3]) if len(sys.argv) > 3 else 100)
-g = graphgen.generate(n, loops, odom_f_max=5, apply_yaw_weight=1, seed=5, **graphgen._SMALL)
+turn = float(sys.argv[4]) if len(sys.argv) > 4 else 15.0      # degrees per keyframe in the turns: 15 cuts the yaw-weighted chain into loose pieces, 2 keeps it connected
+g = graphgen.generate(n, loops, odom_f_max=5, apply_yaw_weight=1, seed=5, **dict(graphgen._SMALL, turn_deg_per_keyframe=turn))
 w_M = util.poses_to_matrices(g.init_q, g.init_t)
 order = np.argsort(np.maximum(g.loop_c1, g.loop_c2), kind="stable")
 S = PoseGraphSLAM()

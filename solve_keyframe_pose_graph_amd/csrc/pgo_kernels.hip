@@ -1665,6 +1665,7 @@ __global__ __launch_bounds__(CG_BLOCK) void coarse_prolong_kernel(GraphDev G, Co
     __shared__ double red[CG_BLOCK / 64];
     if (stop && *stop) return;
     const int64_t pairs = G.N * 3;
+    const bool direct = K.m == 1;      // one aggregate per keyframe: P = I and Ac^-1 is the inverse of the system itself, z = Ac^-1 r replaces the block-Jacobi z
     double acc = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * CG_BLOCK + threadIdx.x; i < pairs; i += (int64_t)gridDim.x * CG_BLOCK) {
         const int64_t n = i / 3;
@@ -1677,13 +1678,13 @@ __global__ __launch_bounds__(CG_BLOCK) void coarse_prolong_kernel(GraphDev G, Co
         double2* zp = reinterpret_cast<double2*>(zv) + i;
         const double2 r = reinterpret_cast<const double2*>(rv)[i];
         double2 z = *zp;
-        z.x += a0; z.y += a1;
+        if (direct) { z.x = a0; z.y = a1; } else { z.x += a0; z.y += a1; }
         *zp = z;
         const double w = G.own ? G.own[n] : 1.0;
         acc += w * (r.x * a0 + r.y * a1);
     }
     const double s = block_sum(acc, red);
-    if (threadIdx.x == 0) part_rz[blockIdx.x] += s;
+    if (threadIdx.x == 0) { if (direct) part_rz[blockIdx.x] = s; else part_rz[blockIdx.x] += s; }
 }
 void launch_coarse_apply(const GraphDev& G, const CgDev& C, const CoarseDev& K, const double* r, double* z, double* part_rz, bool inside_iteration, hipStream_t st) {
     const int32_t* stop = inside_iteration ? C.flags : nullptr;     // at PCG start the flag still belongs to the previous solve

@@ -462,7 +462,11 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S) {
     p->coarse_built = false; p->coarse_active = false; p->K = CoarseDev{};
     {
         int n_agg = p->opt.coarse_aggregates;
-        if (n_agg > N / 8) n_agg = (int)(N / 8);
+        // a graph with no more keyframes than HALF the configured aggregates gets one aggregate per keyframe: the coarse operator IS the reduced system and the
+        // "preconditioner" its dense inverse (a direct solve; the PCG around it only refines); larger graphs: at least 8 keyframes per aggregate, but not fewer than half the
+        // configured number of aggregates: the dense inverse (cubic in the aggregates) is what small graphs pay for (scripts/gpu_small_graphs.py)
+        if (N <= n_agg / 2) n_agg = (int)N;
+        else n_agg = (int)std::min<int64_t>(n_agg, std::max<int64_t>(N / 8, n_agg / 2));
         if (n_agg >= 2 && !p->local_ids && (N + n_agg - 1) / n_agg <= 1024) {    // aggregates of thousands of keyframes are never used (build_coarse)
             const int m = (int)((N + n_agg - 1) / n_agg);
             n_agg = (int)((N + m - 1) / m);
