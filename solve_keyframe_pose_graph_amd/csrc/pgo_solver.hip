@@ -670,6 +670,9 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
     int32_t hflags[3] = {0, 0, 0};
     double hscal[3] = {0, 0, 0};
     int every = std::max(2, o.cg_check_every) & ~1;   // even: the r/p ping-pong parity repeats from chunk to chunk
+    // five kernels per iteration with the coarse space: chunks of 12 keep a captured chunk at 60 kernel nodes (rocprofv3 7.2 crashes while a
+    // graph of 120 nodes is captured under --kernel-trace; 80 are fine) and halve the early-exit launches after convergence
+    if (p->coarse_active && !multi) every = std::min(every, 12);
     int rc;
     auto one_iteration = [&](int kk) -> int {
         if (multi) {
