@@ -85,7 +85,7 @@ typedef struct pgo_options {
     double parameter_tolerance;          /* 1e-8 */
     /* PCG controls (no Ceres counterpart: Ceres factorises exactly) */
     int32_t cg_max_iterations;           /* 50000: a safety net, not a budget — a capped PCG is an inexact LM step and leaves the exact-solve path */
-    int32_t cg_check_every;              /* 25: host polls the device convergence flag every this many iterations */
+    int32_t cg_check_every;              /* 25: host polls the device convergence flag every this many iterations (rounded down to even; 12 while the two-level preconditioner is on) */
     double cg_rel_tolerance;             /* 1e-9: stop when ||r||_{M^-1} <= tol * ||b||_{M^-1} */
     int32_t cg_warm_start;               /* 1: after a rejected step start the PCG from the previous step (same H, larger damping) */
     int32_t cg_use_graph;                /* 1: replay each `cg_check_every`-iteration chunk of the PCG loop as one hipGraph (single GPU) */
