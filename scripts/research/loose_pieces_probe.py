@@ -49,3 +49,63 @@ for radius in (1e4, 1e6, 1e8):
     two_level(ag, 'pieces (cut at links < 1e-6 max)')
     two_level(merged(ag, 512), 'pieces merged to <= 512')
     two_level(merged(ag, 256), 'pieces merged to <= 256')
+
+# ---- piece-aligned block-Jacobi: every strongly connected run of keyframes is one dense diagonal block ----
+def piece_block_jacobi(A, agg):
+    Ad = A.tocsr()
+    blocks, idx = [], []
+    for a in range(agg.max() + 1):
+        ks = np.flatnonzero(agg == a)
+        ii = (ks[:, None] * 6 + np.arange(6)[None, :]).ravel()
+        blocks.append(np.linalg.inv(Ad[ii][:, ii].toarray())); idx.append(ii)
+    def M(r):
+        z = np.empty_like(r)
+        for B, ii in zip(blocks, idx): z[ii] = B @ r[ii]
+        return z
+    return M
+
+print('piece-aligned block-Jacobi')
+for radius in (1e4, 1e6, 1e8):
+    A, b = build_system(g, q, t, s, radius)
+    for theta in (1e-6, 1e-2):
+        ag = pieces(theta)
+        x, k = pcg(A, b, piece_block_jacobi(A, ag), 1e-9, maxit=60000)
+        print('   radius %.0e  cut at %.0e: %d blocks (largest %d keyframes)  its %d' % (radius, theta, ag.max() + 1, np.bincount(ag).max(), k), flush=True)
+
+def capped(agg, cap):
+    """split pieces longer than `cap` keyframes into consecutive runs of at most `cap`"""
+    out = np.zeros_like(agg); a = -1; run = 0
+    for i in range(len(agg)):
+        if i == 0 or agg[i] != agg[i - 1] or run == cap: a += 1; run = 0
+        out[i] = a; run += 1
+    return out
+
+print('capped piece blocks, alone and with the rigid modes of the (uncapped) pieces as coarse space')
+for radius in (1e4, 1e6, 1e8):
+    A, b = build_system(g, q, t, s, radius)
+    ag = pieces(1e-6)
+    P, _ = prolongation(np.asarray(t).reshape(-1, 3), ag, True)
+    Aci = np.linalg.inv((P.T @ A @ P).toarray())
+    for cap in (2, 4, 8, 1000):
+        Mb = piece_block_jacobi(A, capped(ag, cap))
+        x, k = pcg(A, b, Mb, 1e-9, maxit=60000)
+        x, k2 = pcg(A, b, lambda r: Mb(r) + P @ (Aci @ (P.T @ r)), 1e-9, maxit=60000)
+        print('   radius %.0e  cap %4d: %4d blocks  its %5d   + piece rigid modes %5d' % (radius, cap, capped(ag, cap).max() + 1, k, k2), flush=True)
+
+print('6x6 block-Jacobi + rigid modes of runs of <= m keyframes INSIDE pieces (boundaries forced at weak links); singletons with / without coarse unknowns')
+for radius in (1e4, 1e6, 1e8):
+    A, b = build_system(g, q, t, s, radius)
+    Dinv = block_diag_inv(A, N)
+    ag0 = pieces(1e-6)
+    for m in (4, 8, 16, 32):
+        ag = capped(ag0, m)
+        P, _ = prolongation(np.asarray(t).reshape(-1, 3), ag, True)
+        sizes = np.bincount(ag)
+        for drop_single in (False, True):
+            Pm = P
+            if drop_single:
+                keep = np.repeat(sizes > 1, 6)
+                Pm = P[:, np.flatnonzero(keep)]
+            Aci = np.linalg.inv((Pm.T @ A @ Pm).toarray())
+            x, k = pcg(A, b, lambda r: Dinv @ r + Pm @ (Aci @ (Pm.T @ r)), 1e-9, maxit=60000)
+            print('   radius %.0e  m %2d  singletons %s: coarse unknowns %5d  its %5d' % (radius, m, 'dropped' if drop_single else 'kept   ', Pm.shape[1], k), flush=True)
