@@ -1652,9 +1652,12 @@ __global__ __launch_bounds__(256) void coarse_solve_kernel(CoarseDev K, const in
     const int row = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= K.nc) return;
-    const double* A = K.Ac + (size_t)row * K.nc;
+    const double2* __restrict__ A = reinterpret_cast<const double2*>(K.Ac + (size_t)row * K.nc);    // nc is a multiple of 64: rows are 16-B aligned
+    const double2* __restrict__ x = reinterpret_cast<const double2*>(K.rc);
     double s = 0.0;
-    for (int j = lane; j < K.nc; j += 64) s += A[j] * K.rc[j];
+    const int n2 = K.nc >> 1;
+#pragma unroll 4
+    for (int j = lane; j < n2; j += 64) { const double2 a = A[j], b = x[j]; s += a.x * b.x + a.y * b.y; }
     s = wave_sum(s);
     if (lane == 0) K.yc[row] = s;
 }
