@@ -261,6 +261,11 @@ def test_readers_run_concurrently_with_the_trigger_thread():
                 k += 1
             if (i + 1) % 250 == 0:
                 S.reinit_ceres_problem_onnewloopedge_optimize6DOF_once()
+        # the readers get a moment to observe the state after the last trigger (they only run between its return and stop.set())
+        import time
+        deadline = time.time() + 5.0
+        while seen["max_solved"] < g.n_poses - 1 and time.time() < deadline:
+            time.sleep(0.01)
     finally:
         stop.set()
         for x in th:
