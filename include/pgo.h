@@ -102,7 +102,11 @@ typedef struct pgo_options {
      * iterations whose trust-region radius is >= coarse_min_radius (aggregates up to 1024 keyframes), where the slow modes are the long
      * wavelengths the coarse space removes (10-60x fewer iterations); with large aggregates at small radii it does not pay.  Once per solve (and once more when a coarse space dropped
      * at a small radius becomes eligible at coarse_min_radius) plain block-Jacobi gets the same time budget on the same system; the
-     * loser is not used for the rest of the solve.  The solution of each step is the same to the PCG tolerance.  Single GPU only. */
+     * loser is not used for the rest of the solve; a handle that kept it skips the comparison in its next three solves, one that dropped
+     * it skips the coarse space for its next 1, 3, 7, 15 solves.  Aggregate count: `coarse_aggregates`, at least 8 keyframes each but not fewer
+     * than half that number on small graphs; a graph of <= coarse_aggregates / 2 keyframes gets one aggregate per keyframe, which makes the
+     * coarse inverse the inverse of the reduced system itself (a direct solve refined by the PCG).  The solution of each step is the same
+     * to the PCG tolerance.  Single GPU only. */
     int32_t coarse_aggregates;           /* 512 (coarse dimension 3072, 75 MB dense inverse); 0 disables */
     int32_t reserved2_;
     double coarse_min_radius;            /* 1e5 */
