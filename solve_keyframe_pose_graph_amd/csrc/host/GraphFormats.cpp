@@ -273,13 +273,18 @@ bool load_posegraph_json(VectorGraphSource& src, const std::string& base_path, c
         const JsonValue& n = nodes.at(i);
         Matrix4d wTc;
         if (!csv_to_matrix4d(n.at("wTc").as_string(), wTc)) { e = "node " + std::to_string(i) + ": wTc is not a 4x4 matrix string"; src.reset(); return false; }
-        src.add_node(n.has("world_id") ? n.at("world_id").as_int(0) : 0, wTc, n.at("timestamp").as_double((double)i * 0.1));
+        // worlds are numbered in order of appearance (one more per kidnap): an id beyond the keyframe count cannot come from a recorded
+        // session, and the world tables grow with the largest id
+        const int world_id = n.has("world_id") ? n.at("world_id").as_int(0) : 0;
+        if (world_id > (int)nodes.size() || world_id < -(int)nodes.size() - 1) { e = "node " + std::to_string(i) + ": world_id out of range"; src.reset(); return false; }
+        src.add_node(world_id, wTc, n.at("timestamp").as_double((double)i * 0.1));
     }
     for (size_t k = 0; k < edges.size(); ++k) {
         if (!edge_mask.empty() && (k >= edge_mask.size() || !edge_mask[k])) continue;                                       // reference :700-701
         const JsonValue& ed = edges.at(k);
         const int idx0 = ed.at("idx0").as_int(-1), idx1 = ed.at("idx1").as_int(-1);
         if (idx0 < 0 || idx1 < 0 || idx0 >= (int)nodes.size() || idx1 >= (int)nodes.size()) { e = "loop edge " + std::to_string(k) + ": endpoint out of range"; src.reset(); return false; }
+        if (idx0 == idx1) { e = "loop edge " + std::to_string(k) + ": both endpoints are keyframe " + std::to_string(idx0); src.reset(); return false; }
         // the claimed stamps must be the stamps of the keyframes (reference :736-747 exit(1)s otherwise)
         if (ed.has("timestamp0") && ed.at("timestamp0").as_double() != src.getNodeTimestamp(idx0)) { e = "loop edge " + std::to_string(k) + ": timestamp0 differs from its keyframe's"; src.reset(); return false; }
         if (ed.has("timestamp1") && ed.at("timestamp1").as_double() != src.getNodeTimestamp(idx1)) { e = "loop edge " + std::to_string(k) + ": timestamp1 differs from its keyframe's"; src.reset(); return false; }
@@ -368,7 +373,9 @@ bool load_solved_posegraph_json(VectorGraphSource& src, std::vector<Matrix4d>& w
         Matrix4d T;
         if (!matrix_from_json(n.at("w_T_c"), T)) { e = "SolvedPoseGraph[" + std::to_string(i) + "].w_T_c is not a 4x4 matrix"; src.reset(); w_T_c.clear(); return false; }
         if (n.at("seq").as_int((int)i) != (int)i) { e = "SolvedPoseGraph is not in seq order"; src.reset(); w_T_c.clear(); return false; }
-        src.add_node(n.at("worldID").as_int(0), T, n.at("stampNSec").as_double(0.0) * 1e-9);
+        const int world_id = n.at("worldID").as_int(0);
+        if (world_id > (int)nodes.size() || world_id < -(int)nodes.size() - 1) { e = "SolvedPoseGraph[" + std::to_string(i) + "]: worldID out of range"; src.reset(); w_T_c.clear(); return false; }
+        src.add_node(world_id, T, n.at("stampNSec").as_double(0.0) * 1e-9);
         w_T_c.push_back(T);
     }
     // world merges: replay the union log with the stored relative poses (Worlds::loadStateFromDisk, reference src/Worlds.cpp:519-667)

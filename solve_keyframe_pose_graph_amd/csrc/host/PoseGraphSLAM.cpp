@@ -19,10 +19,21 @@ Matrix4d Matrix4d::operator*(const Matrix4d& o) const {
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { double s = 0; for (int k = 0; k < 4; ++k) s += (*this)(i, k) * o(k, j); r(i, j) = s; }
     return r;
 }
+// The reference calls Eigen's general Matrix4d::inverse() (src/PoseGraphSLAM.cpp:1463,1599,1770), which for a pose [A t; 0 1] is
+// [A^-1, -A^-1 t] with A^-1 by cofactors — also for a not-quite-orthonormal A (VIO poses are only orthonormal to ~1e-7).  Same algebra
+// as the K0 device path (pgo_device_math.hpp: vio_relative_pose), so the host and device paths of the trigger agree.
 Matrix4d Matrix4d::inverse() const {
+    const Matrix4d& M = *this;
+    const double a00 = M(0, 0), a01 = M(0, 1), a02 = M(0, 2), a10 = M(1, 0), a11 = M(1, 1), a12 = M(1, 2), a20 = M(2, 0), a21 = M(2, 1), a22 = M(2, 2);
+    const double c00 = a11 * a22 - a12 * a21, c01 = a02 * a21 - a01 * a22, c02 = a01 * a12 - a02 * a11;
+    const double c10 = a12 * a20 - a10 * a22, c11 = a00 * a22 - a02 * a20, c12 = a02 * a10 - a00 * a12;
+    const double c20 = a10 * a21 - a11 * a20, c21 = a01 * a20 - a00 * a21, c22 = a00 * a11 - a01 * a10;
+    const double idet = 1.0 / (a00 * c00 + a01 * c10 + a02 * c20);
     Matrix4d r = Identity();
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r(i, j) = (*this)(j, i);
-    for (int i = 0; i < 3; ++i) r(i, 3) = -(r(i, 0) * (*this)(0, 3) + r(i, 1) * (*this)(1, 3) + r(i, 2) * (*this)(2, 3));
+    r(0, 0) = c00 * idet; r(0, 1) = c01 * idet; r(0, 2) = c02 * idet;
+    r(1, 0) = c10 * idet; r(1, 1) = c11 * idet; r(1, 2) = c12 * idet;
+    r(2, 0) = c20 * idet; r(2, 1) = c21 * idet; r(2, 2) = c22 * idet;
+    for (int i = 0; i < 3; ++i) r(i, 3) = -(r(i, 0) * M(0, 3) + r(i, 1) * M(1, 3) + r(i, 2) * M(2, 3));
     return r;
 }
 void raw_xyzw_to_eigenmat(const double* quat, const double* t, Matrix4d& dst) {
@@ -111,6 +122,7 @@ bool PoseGraphSLAM::load_state(bool optimization_variable_as_constants) {
         solved_until = node_len - 1;                                                                  // (:158)
     }
     prev_node_len = node_len;
+    odom_until_ = std::max(odom_until_, node_len);
     return last_rc_ == PGO_OK;
 }
 
@@ -121,6 +133,10 @@ bool PoseGraphSLAM::reinit_ceres_problem_onnewloopedge_optimize6DOF_once() {
     if (prev_loopedge_len == loopedge_len) { status_ = 0; return false; }       // no new loop edge: sleep again (:1306-1312)
     if (manager->curr_kidnap_status()) { status_ = 0; return false; }           // kidnapped: sleep (:1314-1319)
     status_ = 1;
+    last_rc_ = PGO_OK;
+    // A failed pgo_* call ends the wake-up at once: nothing after it runs, and the progress markers only move past what libpgo has
+    // accepted (loop edges: prev_loopedge_len; odometry residues: odom_until_), so the next wake-up neither repeats nor loses blocks.
+    auto failed = [this]() { status_ = 0; return false; };
 
     // -0- new optimisation variables (:1340-1367)
     for (int yp = n_opt_variables(); yp < node_len; ++yp) allocate_and_append_new_opt_variable_withpose(Matrix4d::Identity());
@@ -129,11 +145,13 @@ bool PoseGraphSLAM::reinit_ceres_problem_onnewloopedge_optimize6DOF_once() {
     // -1/-2- loop edges, intra- and inter-world (:1381-1559)
     std::vector<int32_t> c1, c2, sw;
     std::vector<double> T, w;
+    std::vector<AddedEdge> pending;
     for (int e = prev_loopedge_len; e < loopedge_len; ++e) {
         const Matrix4d bTa = manager->getEdgePose(e);
         const double weight = manager->getEdgeWeight(e);
         const std::pair<int, int> paur = manager->getEdgeIdxInfo(e);
         const int a = paur.first, b = paur.second;
+        if (a == b || a < 0 || b < 0 || a >= node_len || b >= node_len) continue;   // not a residual block Ceres could hold (one parameter block twice): dropped alone, not with its batch
         const int a_world = manager->which_world_is_this_node(a), b_world = manager->which_world_is_this_node(b);
         if (a_world < 0 || b_world < 0) continue;                                // an endpoint lies in a dead zone (:1400-1401)
         if (a_world != b_world && !manager->is_exist(b_world, a_world)) {
@@ -152,36 +170,45 @@ bool PoseGraphSLAM::reinit_ceres_problem_onnewloopedge_optimize6DOF_once() {
         // SixDOFErrorWithSwitchingConstraints(bTa, weight) on (q_b,t_b, q_a,t_a, s_e)  (:1550-1556)
         c1.push_back(b); c2.push_back(a); sw.push_back(e); w.push_back(weight);
         T.insert(T.end(), bTa.d.begin(), bTa.d.end());
-        added_edges_.push_back({b, a, weight, e});
+        pending.push_back({b, a, weight, e});
     }
-    if (!c1.empty()) last_rc_ = pgo_add_switchable_edges(problem_, (int64_t)c1.size(), c1.data(), c2.data(), T.data(), w.data(), sw.data());
+    if (!c1.empty()) {
+        last_rc_ = pgo_add_switchable_edges(problem_, (int64_t)c1.size(), c1.data(), c2.data(), T.data(), w.data(), sw.data());
+        if (last_rc_ != PGO_OK) return failed();
+    }
+    added_edges_.insert(added_edges_.end(), pending.begin(), pending.end());
+    prev_loopedge_len = loopedge_len;
 
     // -3- odometry residues u <-> u-f, f = 1..5 (:1570-1639)
     const int su = solvedUntil();
+    const int u_first = std::max(su + 1, odom_until_);     // = su + 1 unless an earlier wake-up failed after adding its odometry residues
     if (device_graph_construction_) {
         // K0 on the device: only the new raw VIO poses travel; measurement, quaternion and yaw weight are computed there
         int64_t resident = 0;
         last_rc_ = pgo_num_vio_poses(problem_, &resident);
-        if (last_rc_ == PGO_OK && resident < node_len) {
+        if (last_rc_ != PGO_OK) return failed();
+        if (resident < node_len) {
             std::vector<double> fresh;
             fresh.reserve((size_t)(node_len - resident) * 16);
             for (int u = (int)resident; u < node_len; ++u) { const Matrix4d M = manager->getNodePose(u); fresh.insert(fresh.end(), M.d.begin(), M.d.end()); }
             last_rc_ = pgo_set_vio_poses(problem_, resident, node_len - resident, fresh.data());
+            if (last_rc_ != PGO_OK) return failed();
         }
         std::vector<int32_t> set_id((size_t)node_len, 0);
-        for (int u = std::max(0, su + 1 - 5); u < node_len; ++u) set_id[u] = manager->find_setID_of_world_i(manager->which_world_is_this_node(u));
+        for (int u = std::max(0, u_first - 5); u < node_len; ++u) set_id[u] = manager->find_setID_of_world_i(manager->which_world_is_this_node(u));
         int64_t before = 0, added = 0;
-        if (last_rc_ == PGO_OK) last_rc_ = pgo_num_relpose_edges(problem_, &before);
-        if (last_rc_ == PGO_OK) last_rc_ = pgo_add_odometry_edges_from_vio(problem_, set_id.data(), su + 1, node_len, 5, 1, &added);
-        if (last_rc_ == PGO_OK && added > 0) {
+        if ((last_rc_ = pgo_num_relpose_edges(problem_, &before)) != PGO_OK) return failed();
+        if (u_first < node_len && (last_rc_ = pgo_add_odometry_edges_from_vio(problem_, set_id.data(), u_first, node_len, 5, 1, &added)) != PGO_OK) return failed();
+        odom_until_ = std::max(odom_until_, node_len);
+        if (added > 0) {
             std::vector<int32_t> a1((size_t)added), a2((size_t)added);
             std::vector<double> rec((size_t)added * 8);
-            last_rc_ = pgo_get_relpose_edge_records(problem_, before, added, a1.data(), a2.data(), rec.data());
+            if ((last_rc_ = pgo_get_relpose_edge_records(problem_, before, added, a1.data(), a2.data(), rec.data())) != PGO_OK) return failed();
             for (int64_t k = 0; k < added; ++k) added_edges_.push_back({a1[k], a2[k], rec[k * 8 + 7], -1});
         }
     } else {
-        c1.clear(); c2.clear(); T.clear(); w.clear();
-        for (int u = su + 1; u < node_len; ++u) {
+        c1.clear(); c2.clear(); T.clear(); w.clear(); pending.clear();
+        for (int u = u_first; u < node_len; ++u) {
             const int set_u = manager->find_setID_of_world_i(manager->which_world_is_this_node(u));
             for (int f = 1; f < 6; ++f) {
                 const int world_umf = (u - f >= 0) ? manager->which_world_is_this_node(u - f) : -1;
@@ -193,10 +220,12 @@ bool PoseGraphSLAM::reinit_ceres_problem_onnewloopedge_optimize6DOF_once() {
                 const double odom_edge_weight = std::pow(0.9, f) * std::exp(-yaw * yaw / 6.0);                // (:1603-1606)
                 c1.push_back(u); c2.push_back(u - f); w.push_back(odom_edge_weight);
                 T.insert(T.end(), u_M_umf.d.begin(), u_M_umf.d.end());
-                added_edges_.push_back({u, u - f, odom_edge_weight, -1});
+                pending.push_back({u, u - f, odom_edge_weight, -1});
             }
         }
-        if (!c1.empty()) last_rc_ = pgo_add_relpose_edges(problem_, (int64_t)c1.size(), c1.data(), c2.data(), T.data(), w.data());
+        if (!c1.empty() && (last_rc_ = pgo_add_relpose_edges(problem_, (int64_t)c1.size(), c1.data(), c2.data(), T.data(), w.data())) != PGO_OK) return failed();
+        added_edges_.insert(added_edges_.end(), pending.begin(), pending.end());
+        odom_until_ = std::max(odom_until_, node_len);
     }
 
     // -4- initial guesses (:1649-1793)
@@ -256,13 +285,25 @@ bool PoseGraphSLAM::reinit_ceres_problem_onnewloopedge_optimize6DOF_once() {
                 guess_from_vio(u, 1, Matrix4d::Identity(), world_u);            // very first trigger (:1756-1761)
             }
         }
-        if (device_graph_construction_ && node_len > 0 && last_rc_ == PGO_OK) {
-            // every keyframe <= s_until was handled above, so the anchor pose is final here exactly as in the sequential host loop
-            const Matrix4d chain = this->getNodePose(s_until) * manager->getNodePose(s_until).inverse();
+        if (device_graph_construction_ && node_len > 0) {
+            // The chain anchor w_T_last must be the pose the sequential host loop would read at this point.  Keyframes <= s_until that
+            // were re-expressed above are final already; on the very first trigger (s_until == 0) keyframe 0's own guess w_M_0 is still
+            // deferred to the kernel (sel = 1), so it is resolved here — through the same (xyzw, t) round trip update_opt_variable_with
+            // + getNodePose perform — instead of reading the Identity the variable was allocated with.
+            Matrix4d w_T_last = this->getNodePose(s_until);
+            if (s_until >= 0 && s_until < node_len && sel[s_until] >= 0) {
+                Matrix4d L;
+                std::copy(left.begin() + (size_t)sel[s_until] * 16, left.begin() + (size_t)sel[s_until] * 16 + 16, L.d.begin());
+                double q[4], t3[3];
+                eigenmat_to_raw_xyzw(L * manager->getNodePose(s_until), q, t3);
+                raw_xyzw_to_eigenmat(q, t3, w_T_last);
+            }
+            const Matrix4d chain = w_T_last * manager->getNodePose(s_until).inverse();
             std::copy(chain.d.begin(), chain.d.end(), left.begin());
             std::lock_guard<std::mutex> lk(mutex_opt_vars);
             last_rc_ = pgo_initial_guess_from_vio(problem_, (int64_t)(left.size() / 16), left.data(), sel.data(), 0, node_len, _opt_quat_.data(), _opt_t_.data());
         }
+        if (last_rc_ != PGO_OK) return failed();
     }
 
     // -5- node regularisation replaces the previous set (:1803-1877)
@@ -279,7 +320,7 @@ bool PoseGraphSLAM::reinit_ceres_problem_onnewloopedge_optimize6DOF_once() {
     {
         std::vector<int32_t> rn; std::vector<double> rw, rT;
         for (const AddedRegularizer& r : regs_) { rn.push_back(r.node); rw.push_back(r.weight); rT.insert(rT.end(), r.target.d.begin(), r.target.d.end()); }
-        last_rc_ = pgo_set_node_regularizers(problem_, (int64_t)rn.size(), rn.data(), rT.data(), rw.data());
+        if ((last_rc_ = pgo_set_node_regularizers(problem_, (int64_t)rn.size(), rn.data(), rT.data(), rw.data())) != PGO_OK) return failed();
     }
     changes_to_setid_on_set_union.clear();                                       // (:1882)
 
@@ -292,15 +333,15 @@ bool PoseGraphSLAM::reinit_ceres_problem_onnewloopedge_optimize6DOF_once() {
     }
     init_quat_ = q; init_t_ = t;
     last_rc_ = pgo_solve(problem_, q.data(), t.data(), s.empty() ? nullptr : s.data(), (int64_t)(t.size() / 3), (int64_t)s.size(), &summary_);
+    if (last_rc_ != PGO_OK) return failed();     // a library error (not a Ceres-style FAILURE): no write-back, solved_until stays
     {
         std::lock_guard<std::mutex> lk(mutex_opt_vars);
-        if (last_rc_ == PGO_OK && summary_.termination_type != PGO_FAILURE) { _opt_quat_ = q; _opt_t_ = t; _opt_switch_ = s; }
+        if (summary_.termination_type != PGO_FAILURE) { _opt_quat_ = q; _opt_t_ = t; _opt_switch_ = s; }
         solved_until = node_len - 1;                                             // regardless of convergence (:1906-1910)
     }
     status_ = 0;
-    prev_loopedge_len = loopedge_len;
     prev_node_len = node_len;
-    return last_rc_ == PGO_OK;
+    return true;
 }
 
 // ---------------------------------------------------------------- saveAsJSON (reference src/PoseGraphSLAM.cpp:1111-1207)
@@ -336,9 +377,9 @@ bool PoseGraphSLAM::saveAsJSON(const std::string& base_path) const {
 void VectorGraphSource::ensure_world(int w) const {
     while ((int)set_of_.size() <= w) { set_of_.push_back((int)set_of_.size()); set_T_world_.push_back(Matrix4d::Identity()); }
 }
-int VectorGraphSource::n_worlds() const { int m = -1; for (int w : node_world_) m = std::max(m, w); return m + 1; }
-int VectorGraphSource::nodeidx_of_world_i_started(int w) const { for (size_t i = 0; i < node_world_.size(); ++i) if (node_world_[i] == w) return (int)i; return -1; }
-int VectorGraphSource::nodeidx_of_world_i_ended(int w) const { for (int i = (int)node_world_.size() - 1; i >= 0; --i) if (node_world_[i] == w) return i; return -1; }
+int VectorGraphSource::n_worlds() const { return (int)world_first_.size(); }
+int VectorGraphSource::nodeidx_of_world_i_started(int w) const { return (w >= 0 && (size_t)w < world_first_.size()) ? world_first_[w] : -1; }
+int VectorGraphSource::nodeidx_of_world_i_ended(int w) const { return (w >= 0 && (size_t)w < world_last_.size()) ? world_last_[w] : -1; }
 int VectorGraphSource::find_setID_of_world_i(int w) const { if (w < 0) return w; ensure_world(w); return set_of_[w]; }
 bool VectorGraphSource::is_exist(int m, int n) const { if (m < 0 || n < 0) return false; ensure_world(std::max(m, n)); return set_of_[m] == set_of_[n]; }
 Matrix4d VectorGraphSource::getPoseBetweenWorlds(int m, int n) const { ensure_world(std::max(m, n)); return set_T_world_[m].inverse() * set_T_world_[n]; }

@@ -30,7 +30,7 @@ struct Matrix4d {
     double operator()(int r, int c) const { return d[c * 4 + r]; }
     static Matrix4d Identity();
     Matrix4d operator*(const Matrix4d& o) const;
-    Matrix4d inverse() const;   // rigid inverse
+    Matrix4d inverse() const;   // affine inverse [A^-1, -A^-1 t], A^-1 by cofactors (what Eigen's general inverse() gives for a pose)
 };
 
 // PoseManipUtils::{raw_xyzw_to_eigenmat, eigenmat_to_raw_xyzw, R2ypr}  (reference src/utils/PoseManipUtils.cpp:61-98,143-158)
@@ -118,6 +118,7 @@ private:
     std::vector<double> _opt_quat_, _opt_t_, _opt_switch_;   // xyzw ; xyz ; one per loop edge
     int solved_until = 0;
     int prev_loopedge_len = 0, prev_node_len = 0;
+    int odom_until_ = 0;                 // odometry residues exist for every keyframe below this index
     int status_ = -1, last_rc_ = 0;
     bool device_graph_construction_ = true;
     std::map<int, std::tuple<int, int>> changes_to_setid_on_set_union;
@@ -133,13 +134,18 @@ public:
     // stamp < 0: keyframes are stamped idx * 0.1 s (the reference stores ros::Time; only equality and order matter here)
     void add_node(int world, const Matrix4d& w_M_i, double stamp = -1.0) {
         node_stamp_.push_back(stamp >= 0 ? stamp : 0.1 * (double)node_pose_.size());
+        if (world >= 0) {   // first / last keyframe of every world, kept incrementally (the trigger asks per world, per wake-up)
+            if ((size_t)world >= world_first_.size()) { world_first_.resize((size_t)world + 1, -1); world_last_.resize((size_t)world + 1, -1); }
+            if (world_first_[world] < 0) world_first_[world] = (int)node_pose_.size();
+            world_last_[world] = (int)node_pose_.size();
+        }
         node_world_.push_back(world); node_pose_.push_back(w_M_i);
     }
     void add_loop_edge(int a, int b, const Matrix4d& b_T_a, double weight, const std::string& description = std::string()) {
         edge_ab_.push_back({a, b}); edge_pose_.push_back(b_T_a); edge_w_.push_back(weight); edge_desc_.push_back(description);
     }
     void set_kidnapped(bool k) { kidnapped_ = k; }
-    void reset() { node_world_.clear(); node_pose_.clear(); node_stamp_.clear(); edge_ab_.clear(); edge_pose_.clear(); edge_w_.clear(); edge_desc_.clear(); set_of_.clear(); set_T_world_.clear(); kidnapped_ = false; }
+    void reset() { node_world_.clear(); node_pose_.clear(); node_stamp_.clear(); edge_ab_.clear(); edge_pose_.clear(); edge_w_.clear(); edge_desc_.clear(); set_of_.clear(); set_T_world_.clear(); world_first_.clear(); world_last_.clear(); kidnapped_ = false; }
     double getNodeTimestamp(int i) const { return node_stamp_[i]; }
     const std::string& getEdgeDescriptionString(int e) const { return edge_desc_[e]; }
     std::string disjoint_set_status() const;      // Worlds::disjoint_set_status (reference src/Worlds.cpp:333-370)
@@ -163,7 +169,7 @@ public:
 
 private:
     void ensure_world(int w) const;
-    std::vector<int> node_world_;
+    std::vector<int> node_world_, world_first_, world_last_;
     std::vector<Matrix4d> node_pose_;
     std::vector<std::pair<int, int>> edge_ab_;
     std::vector<Matrix4d> edge_pose_;

@@ -319,3 +319,108 @@ def test_continue_on_top_of_a_saved_map_load_state(tmp_path):
     node, rw, _ = B.regularizers()
     assert list(node) == [0]                      # merged into world 0's set: one regulariser, on the (constant) root keyframe
     B.close()
+
+
+def _generic_se3(seed):
+    rng = np.random.default_rng(seed)
+    q = rng.normal(size=4); q /= np.linalg.norm(q)
+    return T_of(q, rng.normal(size=3) * 3.0)
+
+
+@pytest.mark.parametrize("device_k0", [True, False], ids=["k0_on_device", "k0_on_host"])
+def test_first_trigger_when_the_first_vio_pose_is_not_identity(device_k0):
+    """Real VINS sessions do not start at identity.  On the very first trigger (solvedUntil == 0) the reference gives keyframe 0 the
+    guess w_M_0 (src/PoseGraphSLAM.cpp:1756-1761) and chains the rest from it: w_T_0 * (w_M_0^-1 w_M_u) = w_M_u (:1767-1775)."""
+    g = graphgen.config("C1F5")
+    G = _generic_se3(3)
+    vio = [G @ T_of(g.init_q[i], g.init_t[i]) for i in range(g.n_poses)]
+    S = PoseGraphSLAM(max_num_iterations=10, cg_rel_tolerance=1e-12, cg_max_iterations=20000)
+    S.set_device_graph_construction(device_k0)
+    for i in range(g.n_poses):
+        S.add_node(0, vio[i].flatten(order="F"))
+    for e in range(g.n_loops):
+        S.add_loop_edge(int(g.loop_c2[e]), int(g.loop_c1[e]), g.loop_T[e], 1.0)
+    assert S.reinit_ceres_problem_onnewloopedge_optimize6DOF_once()
+    q0, t0 = S.initial_guess()
+    for i in range(g.n_poses):
+        assert np.abs(T_of(q0[i], t0[i]) - vio[i]).max() <= 1e-9, i
+    node, rw, rT = S.regularizers()
+    assert list(node) == [0] and np.abs(rT[0].reshape(4, 4, order="F") - vio[0]).max() <= 1e-9
+    # gauge: the same session started at identity converges to the same trajectory moved by G
+    S2 = PoseGraphSLAM(max_num_iterations=10, cg_rel_tolerance=1e-12, cg_max_iterations=20000)
+    S2.set_device_graph_construction(device_k0)
+    for i in range(g.n_poses):
+        S2.add_node(0, T_of(g.init_q[i], g.init_t[i]).flatten(order="F"))
+    for e in range(g.n_loops):
+        S2.add_loop_edge(int(g.loop_c2[e]), int(g.loop_c1[e]), g.loop_T[e], 1.0)
+    assert S2.reinit_ceres_problem_onnewloopedge_optimize6DOF_once()
+    assert abs(S.summary().final_cost - S2.summary().final_cost) <= 1e-7 * S2.summary().final_cost
+    err = max(np.abs(S.getNodePose(i) - G @ S2.getNodePose(i)).max() for i in range(g.n_poses))
+    assert err <= 1e-5, err
+    S.close(); S2.close()
+
+
+def test_host_and_device_construction_agree_on_not_quite_orthonormal_vio_poses():
+    """VIO poses are orthonormal only to ~1e-7.  The reference inverts them with Eigen's general Matrix4d::inverse()
+    (src/PoseGraphSLAM.cpp:1599, :1463): the host path, the K0 device path and numpy's general inverse must agree on such input —
+    odometry records, weights, initial guesses, and the world-to-world pose at first contact."""
+    rng = np.random.default_rng(12)
+    g = util.small_graph(90, 0, f=1, seed=9, turn_deg_per_keyframe=2.0)
+    G = _generic_se3(4)
+    truth = [T_of(g.truth_q[i], g.truth_t[i]) for i in range(90)]
+    def rough(T):
+        T = T.copy(); T[:3, :3] += rng.normal(size=(3, 3)) * 1e-6
+        return T
+    vio = [rough(G @ truth[i]) for i in range(50)] + [rough(np.linalg.inv(truth[50]) @ truth[i]) for i in range(50, 90)]
+    world = [0] * 50 + [1] * 40
+    bTa1 = np.linalg.inv(truth[5]) @ truth[40]
+    bTa2 = np.linalg.inv(truth[20]) @ truth[70]
+    sessions = []
+    for device_k0 in (True, False):
+        S = PoseGraphSLAM(max_num_iterations=3, cg_rel_tolerance=1e-12, cg_max_iterations=20000)
+        S.set_device_graph_construction(device_k0)
+        for i in range(90):
+            S.add_node(world[i], vio[i].flatten(order="F"))
+        S.add_loop_edge(40, 5, bTa1.flatten(order="F"))
+        assert S.reinit_ceres_problem_onnewloopedge_optimize6DOF_once()
+        first = (S.added_edges(), S.initial_guess())
+        S.add_loop_edge(70, 20, bTa2.flatten(order="F"))               # first inter-world edge: worlds merge (:1459-1464)
+        assert S.reinit_ceres_problem_onnewloopedge_optimize6DOF_once()
+        sessions.append((S, first, S.initial_guess()))
+    (Sd, fd, gd), (Sh, fh, gh) = sessions
+    (c1d, c2d, wd, swd), (q0d, t0d) = fd
+    (c1h, c2h, wh, swh), (q0h, t0h) = fh
+    assert np.array_equal(c1d, c1h) and np.array_equal(c2d, c2h) and np.array_equal(swd, swh)
+    assert np.abs(np.array(wd) - np.array(wh)).max() <= 1e-13
+    assert np.abs(q0d - q0h).max() <= 1e-12 and np.abs(t0d - t0h).max() <= 1e-11
+    # against the general inverse: weights of the reference policy
+    want = expected_odom(vio, 1, 90, world)
+    got_w = [w for w, s_ in zip(wh, swh) if s_ < 0]
+    assert len(got_w) == len(want) and max(abs(a - b[2]) for a, b in zip(got_w, want)) <= 1e-12
+    # after the merge: world-1 keyframes are re-expressed with wb_T_wa = w_M_b * bTa * (w_M_a)^-1 from the ODOMETRY poses
+    wb_T_wa = vio[20] @ bTa2 @ np.linalg.inv(vio[70])
+    for (q0, t0) in (gd, gh):
+        for i in (50, 60, 89):
+            want_i = wb_T_wa @ vio[i]
+            R = want_i[:3, :3]
+            # stored through the (xyzw, t) round trip: compare translations exactly and rotations to the non-orthonormality
+            assert np.abs(t0[i] - want_i[:3, 3]).max() <= 1e-10
+            assert np.abs(T_of(q0[i], t0[i])[:3, :3] - R).max() <= 1e-5
+    assert np.abs(gd[0] - gh[0]).max() <= 1e-12 and np.abs(gd[1] - gh[1]).max() <= 1e-10
+    Sd.close(); Sh.close()
+
+
+def test_a_bad_loop_edge_is_dropped_alone_and_a_library_error_does_not_advance_the_trigger():
+    g = graphgen.config("C1")
+    S = PoseGraphSLAM(max_num_iterations=5)
+    for i in range(g.n_poses):
+        S.add_node(0, T_of(g.init_q[i], g.init_t[i]).flatten(order="F"))
+    S.add_loop_edge(30, 30, np.eye(4).flatten(order="F"))          # a == b: no residual block can hold one parameter block twice
+    for e in range(5):
+        S.add_loop_edge(int(g.loop_c2[e]), int(g.loop_c1[e]), g.loop_T[e], 1.0)
+    assert S.reinit_ceres_problem_onnewloopedge_optimize6DOF_once()
+    c1, c2, w, sw = S.added_edges()
+    loops = [(a, b, s_) for a, b, s_ in zip(c1, c2, sw) if s_ >= 0]
+    assert [s_ for _, _, s_ in loops] == [1, 2, 3, 4, 5]           # switch index = message index; message 0 was dropped alone
+    assert S.last_error() == 0 and S.solvedUntil() == g.n_poses - 1
+    S.close()

@@ -83,6 +83,12 @@ def test_loader_rejects_what_the_reference_rejects(tmp_path):
     attempt(lambda x: x["loopedges"][2].__setitem__("timestamp0", 1.0), "timestamp0 differs")            # :736-741
     attempt(lambda x: x["loopedges"][2].__setitem__("idx1", 4000), "out of range")
     attempt(lambda x: x["nodes"][3].__setitem__("wTc", "1,2,3;4,5,6"), "not a 4x4")
+    # a loop edge from a keyframe to itself is no residual block (Ceres refuses one parameter block twice); a world id far beyond the
+    # keyframe count cannot come from a recorded session and would size the world tables
+    def self_loop(x):
+        x["loopedges"][1]["idx1"] = x["loopedges"][1]["idx0"]; x["loopedges"][1]["timestamp1"] = x["loopedges"][1]["timestamp0"]
+    attempt(self_loop, "both endpoints")
+    attempt(lambda x: x["nodes"][7].__setitem__("world_id", 2000000000), "world_id out of range")
     with pytest.raises(ValueError, match="cannot open"):
         GraphSource().load_posegraph_json(tmp_path / "nowhere")
     (tmp_path / "broken").mkdir()
