@@ -108,8 +108,24 @@ typedef struct pgo_options {
      * coarse inverse the inverse of the reduced system itself (a direct solve refined by the PCG).  The solution of each step is the same
      * to the PCG tolerance.  Single GPU only. */
     int32_t coarse_aggregates;           /* 512 (coarse dimension 3072, 75 MB dense inverse); 0 disables */
-    int32_t reserved2_;
+    /* Aggregation multigrid for large graphs (single GPU): z = D^-1 r + P V(P^T r) — block-Jacobi on the keyframes plus one V(1,1)
+     * cycle over a hierarchy of rigid aggregates that follow the GRAPH (heavy-edge matching over odometry and loop-closure edges;
+     * 2^mg_first_passes keyframes per level-1 aggregate, 2^mg_passes nodes per aggregate above), block-Jacobi smoothing with damping
+     * mg_omega on every level, every coarse correction scaled by mg_correction_scale (aggregation without prolongation smoothing
+     * under-corrects; the factor keeps the cycle symmetric positive definite), the coarsest level (<= mg_dense_max_nodes) inverted densely.  The operators are the Galerkin products of the
+     * current LM system, rebuilt every LM iteration.  Used instead of the two-level preconditioner above for graphs of at least
+     * mg_min_keyframes keyframes (0 disables); no comparisons, no per-handle history: what runs depends on the system alone.  Like every preconditioner it
+     * changes the iteration count of the PCG, not the solution of a step beyond cg_rel_tolerance. */
+    int32_t mg_min_keyframes;            /* 0 */
     double coarse_min_radius;            /* 1e5 */
+    double mg_omega;                     /* 0.9 */
+    double mg_correction_scale;          /* 1.6 */
+    int32_t mg_first_passes;             /* 3 */
+    int32_t mg_passes;                   /* 2 */
+    int32_t mg_dense_max_nodes;          /* 512 (dense coarsest operator of <= 3072 unknowns) */
+    int32_t mg_switch_iterations;        /* 400: every PCG starts with plain block-Jacobi (most LM systems — small trust regions, steps about to be
+                                          *      rejected — need a few hundred cheap iterations); one that has not converged after this many iterations
+                                          *      is restarted from its current iterate with the multigrid.  0: multigrid from the first iteration. */
     /* device selection */
     int32_t device_id;                   /* -1: use the current HIP device */
     int32_t verbosity;                   /* 0 silent (minimizer_progress_to_stdout=false, :1271), 1 per-iteration line on stderr */

@@ -86,7 +86,8 @@ class Hier:
 
 class Cycle:
     """cycle: 'V', 'W', 'K' ; smoother: ('jac', omega) or ('cheb', degree)"""
-    def __init__(self, H, cycle='V', smoother=('jac', 0.8), nu=1, kit=2, fine_additive=False):
+    def __init__(self, H, cycle='V', smoother=('jac', 0.8), nu=1, kit=2, fine_additive=False, alpha=1.0, alpha0=1.0):
+        self.alpha, self.alpha0 = alpha, alpha0
         self.H, self.cycle, self.smoother, self.nu, self.kit = H, cycle, smoother, nu, kit
         self.fine_additive = fine_additive
         self.work = 0.0    # in fine-matvec units (blocks touched / fine blocks)
@@ -124,10 +125,10 @@ class Cycle:
         L = self.H.levels[lvl]
         if 'lu' in L: self.syncs += 1; return L['lu'].solve(r)
         if lvl == 0 and self.fine_additive:
-            return L['Dinv'] @ r + L['P'] @ self.coarse(lvl + 1, L['P'].T @ r)
+            return L['Dinv'] @ r + self.alpha0 * (L['P'] @ self.coarse(lvl + 1, L['P'].T @ r))
         x = self.smooth(lvl, None, r, True)
         rc = L['P'].T @ (r - self.mv(lvl, x)); self.syncs += 1
-        x = x + L['P'] @ self.coarse(lvl + 1, rc); self.syncs += 1
+        x = x + self.alpha * (L['P'] @ self.coarse(lvl + 1, rc)); self.syncs += 1
         x = self.smooth(lvl, x, r, False)
         return x
     def coarse(self, lvl, b):

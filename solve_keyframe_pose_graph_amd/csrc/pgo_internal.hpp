@@ -121,6 +121,29 @@ struct CoarseDev {
     const int32_t* agg_free;      // [n_agg] free keyframes in the aggregate (0: identity block)
 };
 
+// Aggregation multigrid (large graphs): z = D^-1 r + P V(P^T r), V = one V(1,1) cycle (block-Jacobi smoothing) over coarse levels 1..n_sparse
+// of ever larger rigid aggregates (pgo_mg_host.hpp), the level above them solved densely.  All coarse levels are block-CSR with 6x6 blocks in
+// the column-pair-major layout of the block-CSR PCG (element (row, col) at (row/2)*12 + col*2 + (row&1)), the diagonal block first in its row.
+constexpr int MG_MAX_LEVELS = 12;
+constexpr int MG_TILE_ROWS = 32;         // rows per workgroup tile of the level kernels (192 lanes = 32 rows x 6)
+struct MgLevelDev {
+    int32_t n, n_next, tiles, pad_;
+    int64_t nnzb;
+    const int64_t* rowptr; const int32_t* col; double* val;      // block-CSR
+    const int64_t* g_ptr; const int64_t* g_ent;                  // Galerkin contribution lists of the blocks
+    double* Dinv;                                                // [n][36] row-major: omega x inverse of the diagonal block
+    double* pos; double* d;                                      // [n][3] position (centroid of the aggregate); offset to the parent's
+    const int32_t* parent; const int32_t* agg_ptr; const int32_t* tile_agg0;   // nodes of level l+1: members contiguous
+    double* r; double* x; double* xt; double* xf;                // [n][6] restricted residual, pre-smoothed x, x + P x_next, final x
+};
+struct MgDev {
+    int32_t n_levels;                    // levels 1..n_levels; the last one is dense (CoarseDev: Ac, rc = its residual, yc = its solution)
+    int32_t n1;                          // nodes of level 1
+    const int32_t* agg0;                 // [N] level-1 node of each keyframe (-1: not part of the system)
+    const int32_t* mem0_ptr; const int32_t* mem0;   // level-1 node -> keyframes
+    double* d0;                          // [N][3] t_i - pos_1[agg0[i]]
+};
+
 struct CgDev {
     double* val; float* Lf; double* Dtot; double* b;   // Lf [N][24]: packed fp32 Cholesky factor of the block-Jacobi blocks
     double* x; double* r; double* r2; double* z; double* p; double* p2; double* q;   // r/r2 and p/p2 ping-pong by iteration parity
@@ -181,6 +204,14 @@ void launch_scatter_owned_pose(const double* quat, const double* t, int64_t n, c
 // K0: graph construction from raw VIO poses
 void launch_vio_odometry(int64_t n, const int32_t* c1, const int32_t* c2, const double* vio, int yaw_weight, double* meas8, hipStream_t st);
 void launch_vio_initial_guess(int64_t u_begin, int64_t count, const double* left, const int32_t* left_of_node, const double* vio, double* quat, double* t, hipStream_t st);
+
+// aggregation multigrid (MgDev / MgLevelDev); levels[0] = level 1
+void launch_mg_geometry(const GraphDev& G, const MgDev& M, const MgLevelDev* levels, const double* pose8, hipStream_t st);
+// numeric Galerkin products of the current LM system, level by level, block-Jacobi inverses of the sparse levels, the dense coarsest operator
+// into K.Ac (K.nc padded), which is then inverted by launch_coarse_invert; *fail != 0: some diagonal block was not positive definite
+void launch_mg_assemble(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, double omega, int32_t* fail, hipStream_t st);
+// z += scale P V(P^T r) (every coarse correction inside V scaled alike), r.z partials updated in place (cg_update's workgroup -> slot mapping)
+void launch_mg_apply(const GraphDev& G, const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, const double* r, double* z, double* part_rz, double scale, bool inside_iteration, hipStream_t st);
 
 double k1_algorithmic_bytes(const GraphDev& G, bool want_jacobian);
 

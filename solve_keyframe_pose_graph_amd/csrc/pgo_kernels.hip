@@ -1906,4 +1906,6 @@ void launch_coarse_invert(const CoarseDev& K, double* scratch /* 64 nc + 1024 do
     launch_coarse_symmetrize(K, st);     // lower <- upper
 }
 
+#include "pgo_mg_kernels.hpp"
+
 }  // namespace pgo

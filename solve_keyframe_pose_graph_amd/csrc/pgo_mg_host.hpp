@@ -1,0 +1,235 @@
+// pgo_mg_host.hpp — host side of the aggregation-multigrid preconditioner: builds, once per graph, the level hierarchy the device
+// kernels of pgo_mg_kernels.hpp work on.  Included by pgo_solver.hip only.
+//
+// What it replaces in the reference: nothing one-to-one — Ceres factorises the normal equations exactly
+// (SPARSE_NORMAL_CHOLESKY, reference src/PoseGraphSLAM.cpp:1270); here the PCG that stands in for that factorisation is
+// preconditioned by  z = D^-1 r + P V(P^T r):  block-Jacobi on the keyframes plus one V(1,1) cycle over a hierarchy of ever coarser
+// "keyframes", each the rigid-body motion of an aggregate of the level below (dtheta_i = dtheta_a, dt_i = dt_a - 2 [d_i]x dtheta_a,
+// d_i = position_i - centroid_a), the coarsest level (<= dense_max nodes) solved densely.  Aggregates follow the GRAPH (odometry and
+// loop-closure edges alike: heavy-edge pairwise matching, `passes` rounds per level -> aggregates of up to 2^passes nodes), because
+// on revisited places loop closures tie keyframes as strongly as odometry does; chain-only aggregates need ~2x the iterations
+// (scripts/research/amg_probe.py).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <numeric>
+#include <utility>
+#include <vector>
+
+namespace pgo_mg {
+
+struct HostLevel {                       // level l >= 1
+    int32_t n = 0;                       // nodes
+    std::vector<int64_t> rowptr;         // [n+1] block rows, the diagonal block first
+    std::vector<int32_t> col;            // [nnzb]
+    std::vector<int64_t> g_ptr;          // [nnzb+1] contributions of the level below to each block
+    std::vector<int64_t> g_ent;          // level 1: (index << 3) | kind — 0 keyframe diagonal block, 1/2 relative-pose edge forward/transposed, 3/4 switchable edge;
+                                         // level >= 2: (row << 32) | block slot of the level below
+    std::vector<int32_t> parent;         // [n] node of level l+1 (empty on the coarsest level); members of a parent are CONTIGUOUS
+    std::vector<int32_t> agg_ptr;        // [n_next+1] first member of each parent
+    std::vector<int32_t> tile_agg0;      // [tiles+1] workgroup tiles of whole aggregates, <= tile_rows rows
+};
+
+struct Hierarchy {
+    std::vector<HostLevel> L;            // L[0] = level 1
+    std::vector<int32_t> agg0;           // [N] level-1 node of each keyframe, -1 for keyframes outside the system (fixed)
+    std::vector<int32_t> mem0_ptr, mem0; // level-1 node -> its keyframes
+};
+
+struct WEdge { int32_t u, v; double w; };
+
+// `passes` rounds of greedy heavy-edge matching.  edges: undirected, u != v, duplicates allowed (their weights add up).  Returns the
+// aggregate of every node (ids in order of first appearance), n_agg through the reference.  `skip[i]` nodes get -1.
+inline std::vector<int32_t> match_passes(int32_t n, std::vector<WEdge> edges, int passes, const std::vector<uint8_t>* skip, int32_t& n_agg) {
+    std::vector<int32_t> agg(n);
+    std::iota(agg.begin(), agg.end(), 0);
+    int32_t cur_n = n;
+    for (int p = 0; p < passes; ++p) {
+        // merge parallel edges
+        for (WEdge& e : edges) if (e.u > e.v) std::swap(e.u, e.v);
+        std::sort(edges.begin(), edges.end(), [](const WEdge& a, const WEdge& b) { return a.u != b.u ? a.u < b.u : a.v < b.v; });
+        size_t m = 0;
+        for (size_t k = 0; k < edges.size(); ++k) {
+            if (m > 0 && edges[m - 1].u == edges[k].u && edges[m - 1].v == edges[k].v) edges[m - 1].w += edges[k].w;
+            else edges[m++] = edges[k];
+        }
+        edges.resize(m);
+        // strength of a coupling relative to what else its endpoints are tied to: w_ij / sqrt(W_i W_j), W = weighted degree (the analogue of
+        // |a_ij| / sqrt(a_ii a_jj)).  Raw summed weights would let the aggregates that have already merged the most keep pairing up with each
+        // other while light nodes stay single for ever, and the coarse graphs degenerate into stars.
+        std::vector<double> W(cur_n, 0.0);
+        for (const WEdge& e : edges) { W[e.u] += e.w; W[e.v] += e.w; }
+        std::vector<double> strength(edges.size());
+        for (size_t k = 0; k < edges.size(); ++k) strength[k] = edges[k].w / std::sqrt(W[edges[k].u] * W[edges[k].v]);
+        std::vector<uint32_t> order(edges.size());
+        std::iota(order.begin(), order.end(), 0u);
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return strength[a] > strength[b]; });
+        std::vector<int32_t> mate(cur_n, -1);
+        for (uint32_t k : order) {
+            const WEdge& e = edges[k];
+            if (mate[e.u] >= 0 || mate[e.v] >= 0) continue;
+            mate[e.u] = e.v; mate[e.v] = e.u;
+        }
+        std::vector<int32_t> a2(cur_n, -1);
+        int32_t na = 0;
+        for (int32_t i = 0; i < cur_n; ++i) {
+            if (a2[i] >= 0) continue;
+            a2[i] = na;
+            if (mate[i] >= 0) a2[mate[i]] = na;
+            ++na;
+        }
+        for (int32_t i = 0; i < n; ++i) agg[i] = a2[agg[i]];
+        size_t m2 = 0;
+        for (size_t k = 0; k < edges.size(); ++k) {
+            const int32_t u = a2[edges[k].u], v = a2[edges[k].v];
+            if (u != v) edges[m2++] = WEdge{u, v, edges[k].w};
+        }
+        edges.resize(m2);
+        cur_n = na;
+    }
+    // skipped nodes are not part of any aggregate: renumber the rest in order of first appearance
+    std::vector<int32_t> remap(cur_n, -1);
+    int32_t na = 0;
+    for (int32_t i = 0; i < n; ++i) {
+        if (skip && (*skip)[i]) { agg[i] = -1; continue; }
+        if (remap[agg[i]] < 0) remap[agg[i]] = na++;
+        agg[i] = remap[agg[i]];
+    }
+    n_agg = na;
+    return agg;
+}
+
+// block structure of a level from (row node, column node, entry) triples: rows sorted, the diagonal block first in each row
+inline void build_blocks(int32_t n, std::vector<std::pair<int64_t, int64_t>>& trip /* (row * n + col, entry) */, HostLevel& out) {
+    // diagonal first: key' = row * (n+1) + (col == row ? 0 : col + 1)
+    for (auto& t : trip) { const int64_t r = t.first / n, c = t.first % n; t.first = r * ((int64_t)n + 1) + (c == r ? 0 : c + 1); }
+    std::stable_sort(trip.begin(), trip.end(), [](const std::pair<int64_t, int64_t>& a, const std::pair<int64_t, int64_t>& b) { return a.first < b.first; });
+    out.rowptr.assign((size_t)n + 1, 0);
+    out.col.clear(); out.g_ptr.clear(); out.g_ent.clear();
+    int64_t prev = -1;
+    for (const auto& t : trip) {
+        if (t.first != prev) {
+            const int64_t r = t.first / ((int64_t)n + 1), cc = t.first % ((int64_t)n + 1);
+            out.col.push_back((int32_t)(cc == 0 ? r : cc - 1));
+            out.g_ptr.push_back((int64_t)out.g_ent.size());
+            out.rowptr[(size_t)r + 1]++;
+            prev = t.first;
+        }
+        if (t.second >= 0) out.g_ent.push_back(t.second);
+    }
+    out.g_ptr.push_back((int64_t)out.g_ent.size());
+    for (int32_t r = 0; r < n; ++r) out.rowptr[(size_t)r + 1] += out.rowptr[r];
+}
+
+// N keyframes, node_free[N]; edge lists of both classes (endpoints in the handle's local numbering, weights of the relative-pose class).
+// passes0: matching rounds keyframes -> level 1, passes: for the levels above.  Returns false when the graph does not coarsen down to
+// dense_max nodes (e.g. mostly isolated keyframes): the caller then runs without the multigrid.
+inline bool build_hierarchy(int64_t N, const std::vector<uint8_t>& node_free, const std::vector<int32_t>& rc1, const std::vector<int32_t>& rc2, const double* rmeas8 /* weight at [8 e + 7] */,
+                            const std::vector<int32_t>& sc1, const std::vector<int32_t>& sc2, int passes0, int passes, int dense_max, int tile_rows, int max_levels, Hierarchy& H) {
+    H = Hierarchy{};
+    const int64_t Er = (int64_t)rc1.size(), Es = (int64_t)sc1.size();
+    std::vector<WEdge> edges;
+    edges.reserve((size_t)(Er + Es));
+    for (int64_t e = 0; e < Er; ++e) if (node_free[rc1[e]] && node_free[rc2[e]]) {
+        const double w = rmeas8[8 * e + 7];
+        if (w * w > 1e-8) edges.push_back({rc1[e], rc2[e], w * w});       // an odometry edge the yaw policy has (all but) switched off ties nothing together
+    }
+    for (int64_t e = 0; e < Es; ++e) if (node_free[sc1[e]] && node_free[sc2[e]]) edges.push_back({sc1[e], sc2[e], 1.0});    // the switchable functor ignores its weight (CeresResidues.h:198)
+    std::vector<uint8_t> skip((size_t)N);
+    for (int64_t i = 0; i < N; ++i) skip[i] = node_free[i] ? 0 : 1;
+    int32_t n1 = 0;
+    H.agg0 = match_passes((int32_t)N, edges, passes0, &skip, n1);
+    if (n1 < 1) return false;
+    // level-1 edge list
+    auto collapse = [](const std::vector<WEdge>& in, const std::vector<int32_t>& par) {
+        std::vector<WEdge> out;
+        out.reserve(in.size());
+        for (const WEdge& e : in) { const int32_t u = par[e.u], v = par[e.v]; if (u >= 0 && v >= 0 && u != v) out.push_back({u, v, e.w}); }
+        return out;
+    };
+    std::vector<WEdge> cur = collapse(edges, H.agg0);
+    // pass 1: aggregate level by level in provisional numbering; par[l] maps level l+1 (index l) to the level above
+    std::vector<std::vector<int32_t>> par;
+    std::vector<int32_t> n_of{n1};
+    for (int lvl = 1;; ++lvl) {
+        const int32_t n = n_of.back();
+        if (n <= dense_max) break;                     // coarsest level: solved densely
+        if (lvl >= max_levels) return false;
+        int32_t n_next = 0;
+        par.push_back(match_passes(n, cur, passes, nullptr, n_next));
+        if ((double)n_next > 0.85 * (double)n) return false;          // coarsening stalls
+        cur = collapse(cur, par.back());
+        n_of.push_back(n_next);
+    }
+    // pass 2, top down: number every level so that the members of a parent are contiguous and parents ascend
+    const int nl = (int)n_of.size();
+    H.L.resize((size_t)nl);
+    std::vector<int32_t> newid_above;                  // final id of each provisional node of the level above (identity on the coarsest level)
+    for (int l = nl - 1; l >= 0; --l) {
+        HostLevel& Lv = H.L[l];
+        const int32_t n = n_of[l];
+        Lv.n = n;
+        std::vector<int32_t> newid(n);
+        if (l == nl - 1) std::iota(newid.begin(), newid.end(), 0);
+        else {
+            const std::vector<int32_t>& pr = par[l];
+            std::vector<int32_t> fpar(n), order(n);
+            for (int32_t i = 0; i < n; ++i) fpar[i] = newid_above[pr[i]];
+            std::iota(order.begin(), order.end(), 0);
+            std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return fpar[a] < fpar[b]; });
+            Lv.parent.resize(n);
+            for (int32_t k = 0; k < n; ++k) { newid[order[k]] = k; Lv.parent[k] = fpar[order[k]]; }
+            const int32_t n_next = n_of[l + 1];
+            Lv.agg_ptr.assign((size_t)n_next + 1, 0);
+            for (int32_t k = 0; k < n; ++k) Lv.agg_ptr[(size_t)Lv.parent[k] + 1]++;
+            for (int32_t a = 0; a < n_next; ++a) Lv.agg_ptr[(size_t)a + 1] += Lv.agg_ptr[a];
+            // workgroup tiles: whole aggregates, <= tile_rows rows
+            Lv.tile_agg0.push_back(0);
+            int rows = 0;
+            for (int32_t a = 0; a < n_next; ++a) {
+                const int sz = Lv.agg_ptr[(size_t)a + 1] - Lv.agg_ptr[a];
+                if (rows + sz > tile_rows) { Lv.tile_agg0.push_back(a); rows = 0; }
+                rows += sz;
+            }
+            Lv.tile_agg0.push_back(n_next);
+        }
+        newid_above.swap(newid);
+    }
+    for (int32_t& a : H.agg0) if (a >= 0) a = newid_above[a];
+    // level-1 membership lists (after the renumbering of level 1)
+    H.mem0_ptr.assign((size_t)n1 + 1, 0);
+    for (int64_t i = 0; i < N; ++i) if (H.agg0[i] >= 0) H.mem0_ptr[(size_t)H.agg0[i] + 1]++;
+    for (int32_t a = 0; a < n1; ++a) H.mem0_ptr[(size_t)a + 1] += H.mem0_ptr[a];
+    H.mem0.resize((size_t)H.mem0_ptr[n1]);
+    { std::vector<int32_t> fill(H.mem0_ptr.begin(), H.mem0_ptr.end() - 1);
+      for (int64_t i = 0; i < N; ++i) if (H.agg0[i] >= 0) H.mem0[(size_t)fill[H.agg0[i]]++] = (int32_t)i; }
+    // block structures and Galerkin contribution lists, bottom up
+    {
+        std::vector<std::pair<int64_t, int64_t>> trip;
+        trip.reserve((size_t)N + 2 * (size_t)(Er + Es));
+        for (int64_t i = 0; i < N; ++i) if (H.agg0[i] >= 0) trip.push_back({(int64_t)H.agg0[i] * n1 + H.agg0[i], (i << 3) | 0});
+        auto edge = [&](int64_t e, int32_t c1, int32_t c2, int kind_fwd) {
+            const int32_t a = H.agg0[c1], b = H.agg0[c2];
+            if (a < 0 || b < 0) return;                     // rows and columns of fixed keyframes are not part of the system
+            trip.push_back({(int64_t)a * n1 + b, (e << 3) | kind_fwd});
+            trip.push_back({(int64_t)b * n1 + a, (e << 3) | (kind_fwd + 1)});
+        };
+        for (int64_t e = 0; e < Er; ++e) edge(e, rc1[e], rc2[e], 1);
+        for (int64_t e = 0; e < Es; ++e) edge(e, sc1[e], sc2[e], 3);
+        build_blocks(n1, trip, H.L[0]);
+    }
+    for (size_t l = 0; l + 1 < H.L.size(); ++l) {
+        const HostLevel& A = H.L[l];
+        HostLevel& B = H.L[l + 1];
+        std::vector<std::pair<int64_t, int64_t>> trip;
+        trip.reserve(A.col.size());
+        for (int32_t r = 0; r < A.n; ++r)
+            for (int64_t k = A.rowptr[r]; k < A.rowptr[(size_t)r + 1]; ++k)
+                trip.push_back({(int64_t)A.parent[r] * B.n + A.parent[A.col[k]], ((int64_t)r << 32) | k});
+        build_blocks(B.n, trip, B);
+    }
+    return true;
+}
+
+}  // namespace pgo_mg

@@ -1,0 +1,388 @@
+// pgo_mg_kernels.hpp — device side of the aggregation-multigrid preconditioner (MgDev / MgLevelDev, pgo_internal.hpp; hierarchy:
+// pgo_mg_host.hpp).  Included at the end of pgo_kernels.hip, inside namespace pgo (it uses that file's reductions, the block-CSR row
+// product and the rigid-mode Galerkin entry).  gfx950, fp64 VALU.
+//
+// Per PCG iteration, after cg_update has left the new residual r and z = D^-1 r:
+//   restrict0   r_1 = P_0^T r (gather over the keyframes of every level-1 aggregate), x_1 = w D_1^-1 r_1
+//   down(l)     t = r_l - A_l x_l ; r_{l+1} = P_l^T t ; x_{l+1} = w D_{l+1}^-1 r_{l+1}          l = 1 .. n_levels-1 (one kernel per level)
+//   dense       x_top = A_top^-1 r_top (explicit inverse) ; xt = x + s P x_top on the level below   (s = mg_correction_scale)
+//   up(l)       x_l = xt_l + w D_l^-1 (r_l - A_l xt_l) ; xt_{l-1} = x_{l-1} + P x_l                  l = n_levels-1 .. 1
+//   prolong0    z += P_0 x_1, r.z partials updated in cg_update's slots
+// i.e. 2 n_levels + 1 small kernels; every sum runs in a fixed order (bitwise reproducible).  The level kernels work on workgroup tiles
+// of whole aggregates (<= 32 rows, members of an aggregate are contiguous by construction), so restriction and prolongation never leave
+// the workgroup.  All of it is latency-bound (the levels hold 17 %, 6 %, 2 % ... of the keyframes): what counts is the kernel count.
+
+__device__ __forceinline__ int bsr_idx(int row, int col) { return (row >> 1) * 12 + col * 2 + (row & 1); }
+
+__device__ __forceinline__ void mg_row_accumulate(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, const double* __restrict__ val,
+                                                  const double* __restrict__ x, int64_t n, int c, double* acc) {
+    const int64_t b = rowptr[n], e = rowptr[n + 1];
+    int64_t k = b;
+    for (; k + 4 <= e; k += 4) spmv_chunk<4, false>(col + k, val + (size_t)k * 36, c, x, nullptr, 0.0, acc);
+    if (k + 2 <= e) { spmv_chunk<2, false>(col + k, val + (size_t)k * 36, c, x, nullptr, 0.0, acc); k += 2; }
+    if (k < e) spmv_chunk<1, false>(col + k, val + (size_t)k * 36, c, x, nullptr, 0.0, acc);
+}
+
+// (P_i y)[k]:  dtheta_i = y_theta ; dt_i = y_t - 2 d_i x y_theta
+__device__ __forceinline__ double mg_prolong_comp(const double* y, const double* d, int k) {
+    if (k < 3) return y[k];
+    const int a = k - 3, b = a == 2 ? 0 : a + 1, c = b == 2 ? 0 : b + 1;
+    return y[k] - 2.0 * (d[b] * y[c] - d[c] * y[b]);
+}
+// (P_i^T t)[k]:  [t_theta + 2 d_i x t_t ; t_t]
+__device__ __forceinline__ double mg_restrict_comp(const double* t, const double* d, int k) {
+    if (k >= 3) return t[k];
+    const int b = k == 2 ? 0 : k + 1, c = b == 2 ? 0 : b + 1;
+    return t[k] + 2.0 * (d[b] * t[3 + c] - d[c] * t[3 + b]);
+}
+
+// ---- geometry: positions of the coarse nodes (centroids) and the offsets d of every node to its parent ----
+__global__ __launch_bounds__(256) void mg_geometry0_kernel(MgDev M, MgLevelDev A1, const double* __restrict__ pose8) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= M.n1) return;
+    const int m0 = M.mem0_ptr[a], m1 = M.mem0_ptr[a + 1];
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    for (int m = m0; m < m1; ++m) { const double* t = pose8 + (size_t)M.mem0[m] * 8 + 4; sx += t[0]; sy += t[1]; sz += t[2]; }
+    const double inv = 1.0 / (double)(m1 - m0);
+    sx *= inv; sy *= inv; sz *= inv;
+    A1.pos[a * 3] = sx; A1.pos[a * 3 + 1] = sy; A1.pos[a * 3 + 2] = sz;
+    for (int m = m0; m < m1; ++m) {
+        const int i = M.mem0[m];
+        const double* t = pose8 + (size_t)i * 8 + 4;
+        M.d0[(size_t)i * 3] = t[0] - sx; M.d0[(size_t)i * 3 + 1] = t[1] - sy; M.d0[(size_t)i * 3 + 2] = t[2] - sz;
+    }
+}
+__global__ __launch_bounds__(256) void mg_geometry_kernel(MgLevelDev A, double* __restrict__ pos_next) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= A.n_next) return;
+    const int m0 = A.agg_ptr[a], m1 = A.agg_ptr[a + 1];
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    for (int m = m0; m < m1; ++m) { sx += A.pos[m * 3]; sy += A.pos[m * 3 + 1]; sz += A.pos[m * 3 + 2]; }
+    const double inv = 1.0 / (double)(m1 - m0);
+    sx *= inv; sy *= inv; sz *= inv;
+    pos_next[a * 3] = sx; pos_next[a * 3 + 1] = sy; pos_next[a * 3 + 2] = sz;
+    for (int m = m0; m < m1; ++m) { A.d[m * 3] = A.pos[m * 3] - sx; A.d[m * 3 + 1] = A.pos[m * 3 + 1] - sy; A.d[m * 3 + 2] = A.pos[m * 3 + 2] - sz; }
+}
+void launch_mg_geometry(const GraphDev& G, const MgDev& M, const MgLevelDev* levels, const double* pose8, hipStream_t st) {
+    (void)G;
+    hipLaunchKernelGGL(mg_geometry0_kernel, dim3((unsigned)((M.n1 + 255) / 256)), dim3(256), 0, st, M, levels[0], pose8);
+    for (int l = 0; l + 1 < M.n_levels; ++l)
+        hipLaunchKernelGGL(mg_geometry_kernel, dim3((unsigned)((levels[l].n_next + 255) / 256)), dim3(256), 0, st, levels[l], levels[l + 1].pos);
+}
+
+// ---- Galerkin products ----
+// level 1 from the keyframe system: one wavefront per block; contributions as in coarse_assemble_kernel (reduced diagonal blocks C.Dtot and,
+// per edge, J1^T J2 - c1 c2^T / a recomputed from K1's Jacobians), summed in list order
+__global__ __launch_bounds__(256) void mg_galerkin0_kernel(GraphDev G, LinDev L, ScaleDev Sc, CgDev C, MgDev M, MgLevelDev A) {
+    __shared__ double Hs[4][36];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t slot = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (slot >= A.nnzb) return;
+    const int r = lane / 6, c = lane - r * 6;
+    const bool own = lane < 36;
+    double acc = 0.0;
+    for (int64_t k = A.g_ptr[slot]; k < A.g_ptr[slot + 1]; ++k) {
+        const int64_t ent = A.g_ent[k];
+        const int kind = (int)(ent & 7);
+        const int64_t idx = ent >> 3;
+        int64_t ni, nj;
+        double h = 0.0;
+        if (kind == 0) {
+            ni = nj = idx;
+            if (own) h = C.Dtot[(size_t)idx * 36 + lane];
+        } else {
+            const bool is_sw = kind >= 3;
+            const bool transposed = kind == 2 || kind == 4;
+            const EdgeClassDev& E = is_sw ? G.sw : G.rel;
+            const int D = is_sw ? SW_DOUBLES : REL_DOUBLES;
+            const int o1 = is_sw ? 14 : 6, o2 = is_sw ? 50 : 42;
+            const int32_t c1 = E.c1[idx], c2 = E.c2[idx];
+            ni = transposed ? c2 : c1; nj = transposed ? c1 : c2;
+            if (own) {
+                const int oa = transposed ? o2 : o1, ob = transposed ? o1 : o2;
+#pragma unroll
+                for (int kk = 0; kk < 6; ++kk) h += E.J[tile_elem(D, idx, oa + kk * 6 + r)] * E.J[tile_elem(D, idx, ob + kk * 6 + c)];
+                if (is_sw) {
+                    const double* cc = L.c + (size_t)idx * 12;
+                    h -= cc[(transposed ? 6 : 0) + r] * cc[(transposed ? 0 : 6) + c] * Sc.a_inv[idx];
+                }
+            }
+        }
+        if (own) Hs[wv][lane] = h;
+        __builtin_amdgcn_wave_barrier();
+        if (own) acc += coarse_entry(Hs[wv], M.d0 + (size_t)ni * 3, M.d0 + (size_t)nj * 3, r, c);
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (own) A.val[(size_t)slot * 36 + bsr_idx(r, c)] = acc;
+}
+// level l+1 (B) from level l (A): contributions are blocks of A, entry = (row << 32) | slot
+__global__ __launch_bounds__(256) void mg_galerkin_kernel(MgLevelDev A, MgLevelDev B) {
+    __shared__ double Hs[4][36];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t slot = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (slot >= B.nnzb) return;
+    const int r = lane / 6, c = lane - r * 6;
+    const bool own = lane < 36;
+    // storage offset `lane` of a block holds element (row, col) with row = 2 (lane / 12) + (lane & 1), col = (lane % 12) / 2
+    const int srow = 2 * (lane / 12) + (lane & 1), scol = (lane % 12) >> 1;
+    double acc = 0.0;
+    for (int64_t k = B.g_ptr[slot]; k < B.g_ptr[slot + 1]; ++k) {
+        const int64_t ent = B.g_ent[k];
+        const int64_t fs = ent & 0xffffffffll;
+        const int64_t ni = ent >> 32, nj = A.col[fs];
+        if (own) Hs[wv][srow * 6 + scol] = A.val[(size_t)fs * 36 + lane];
+        __builtin_amdgcn_wave_barrier();
+        if (own) acc += coarse_entry(Hs[wv], A.d + (size_t)ni * 3, A.d + (size_t)nj * 3, r, c);
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (own) B.val[(size_t)slot * 36 + bsr_idx(r, c)] = acc;
+}
+// omega x inverse of every diagonal block (Cholesky; a block that is not positive definite raises *fail)
+__global__ __launch_bounds__(256) void mg_dinv_kernel(MgLevelDev A, double omega, int32_t* __restrict__ fail) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.n) return;
+    const double* v = A.val + (size_t)A.rowptr[i] * 36;
+    double Lm[36];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double d = v[bsr_idx(j, j)];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) if (k < j) d -= Lm[j * 6 + k] * Lm[j * 6 + k];
+        ok = ok && (d > 0.0);
+        d = sqrt(d);
+        Lm[j * 6 + j] = 1.0 / d;                      // the diagonal is kept inverted
+#pragma unroll
+        for (int r = 0; r < 6; ++r) if (r > j) {
+            double s = v[bsr_idx(r, j)];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) if (k < j) s -= Lm[r * 6 + k] * Lm[j * 6 + k];
+            Lm[r * 6 + j] = s * Lm[j * 6 + j];
+        }
+    }
+    if (!ok) atomicOr(fail, 1);
+    double* out = A.Dinv + (size_t)i * 36;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {                     // column e of the inverse: L L^T z = unit vector e
+        double y[6], z[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            double s = r == e ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) if (k < r) s -= Lm[r * 6 + k] * y[k];
+            y[r] = s * Lm[r * 6 + r];
+        }
+#pragma unroll
+        for (int r = 5; r >= 0; --r) {
+            double s = y[r];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) if (k > r) s -= Lm[k * 6 + r] * z[k];
+            z[r] = s * Lm[r * 6 + r];
+        }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) out[r * 6 + e] = omega * z[r];
+    }
+}
+// coarsest level: its blocks into the dense operator (zeroed, identity-padded by the launcher)
+__global__ __launch_bounds__(256) void mg_dense_scatter_kernel(MgLevelDev A, CoarseDev K) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)A.n * 36) return;
+    const int i = (int)(t / 36), l = (int)(t - (int64_t)i * 36);
+    const int row = 2 * (l / 12) + (l & 1), col = (l % 12) >> 1;
+    for (int64_t k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k)
+        K.Ac[(size_t)(i * 6 + row) * K.nc + (size_t)A.col[k] * 6 + col] = A.val[(size_t)k * 36 + l];
+}
+void launch_mg_assemble(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, double omega, int32_t* fail, hipStream_t st) {
+    hipLaunchKernelGGL(mg_galerkin0_kernel, dim3((unsigned)((levels[0].nnzb + 3) / 4)), dim3(256), 0, st, G, L, Sc, C, M, levels[0]);
+    for (int l = 1; l < M.n_levels; ++l)
+        hipLaunchKernelGGL(mg_galerkin_kernel, dim3((unsigned)((levels[l].nnzb + 3) / 4)), dim3(256), 0, st, levels[l - 1], levels[l]);
+    for (int l = 0; l + 1 < M.n_levels; ++l)
+        hipLaunchKernelGGL(mg_dinv_kernel, dim3((unsigned)((levels[l].n + 255) / 256)), dim3(256), 0, st, levels[l], omega, fail);
+    const MgLevelDev& T = levels[M.n_levels - 1];
+    (void)hipMemsetAsync(K.Ac, 0, (size_t)K.nc * K.nc * sizeof(double), st);
+    if (K.nc > 6 * K.n_agg) hipLaunchKernelGGL(coarse_pad_identity_kernel, dim3((unsigned)((K.nc - 6 * K.n_agg + 63) / 64)), dim3(64), 0, st, K);
+    hipLaunchKernelGGL(mg_dense_scatter_kernel, dim3((unsigned)(((int64_t)T.n * 36 + 255) / 256)), dim3(256), 0, st, T, K);
+}
+
+// ---- the cycle ----
+// r_1 = P_0^T r over the keyframes of each level-1 aggregate; x_1 = Dinv_1 r_1 (skipped when level 1 is the dense level)
+__global__ __launch_bounds__(CG_BLOCK) void mg_restrict0_kernel(MgDev M, const double* __restrict__ rv, double* __restrict__ r_out, double* __restrict__ x_out,
+                                                                 const double* __restrict__ Dinv, const int32_t* __restrict__ stop) {
+    __shared__ double rb[CG_BLOCK];
+    if (stop && *stop) return;
+    const int a = blockIdx.x * MG_TILE_ROWS + threadIdx.x / 6, k = threadIdx.x % 6;
+    const bool live = a < M.n1;
+    double s = 0.0;
+    if (live) {
+        for (int m = M.mem0_ptr[a]; m < M.mem0_ptr[a + 1]; ++m) { const int i = M.mem0[m]; s += mg_restrict_comp(rv + (size_t)i * 6, M.d0 + (size_t)i * 3, k); }
+        r_out[(size_t)a * 6 + k] = s;
+    }
+    if (!x_out) return;
+    rb[threadIdx.x] = s;
+    __syncthreads();
+    if (live) {
+        const double* Dk = Dinv + (size_t)a * 36 + k * 6;
+        const double* ra = rb + (threadIdx.x - k);
+        double x = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) x += Dk[j] * ra[j];
+        x_out[(size_t)a * 6 + k] = x;
+    }
+}
+// t = r - A x on the rows of a tile of whole aggregates; r_next = P^T t; x_next = Dinv_next r_next (when the next level is a sparse one)
+__global__ __launch_bounds__(CG_BLOCK) void mg_down_kernel(MgLevelDev A, double* __restrict__ r_next, double* __restrict__ x_next, const double* __restrict__ Dinv_next,
+                                                            const int32_t* __restrict__ stop) {
+    __shared__ double xch[CG_BLOCK * 7];
+    __shared__ double tb[CG_BLOCK];
+    __shared__ double rb[CG_BLOCK];
+    if (stop && *stop) return;
+    const int a0 = A.tile_agg0[blockIdx.x], a1 = A.tile_agg0[blockIdx.x + 1];
+    const int i0 = A.agg_ptr[a0], i1 = A.agg_ptr[a1];
+    const int li = threadIdx.x / 6, c = threadIdx.x % 6;
+    const int row = i0 + li;
+    const bool live = row < i1;
+    double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (live) mg_row_accumulate(A.rowptr, A.col, A.val, A.x, row, c, acc);
+    double* mine = xch + (size_t)threadIdx.x * 7;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) mine[q] = acc[q];
+    __syncthreads();
+    if (live) {
+        const double* grp = xch + (size_t)(threadIdx.x - c) * 7;
+        double q = 0.0;
+#pragma unroll
+        for (int cc = 0; cc < 6; ++cc) q += grp[cc * 7 + c];
+        tb[threadIdx.x] = A.r[(size_t)row * 6 + c] - q;
+    }
+    __syncthreads();
+    const int na = a1 - a0;
+    const bool lagg = threadIdx.x < na * 6;
+    double s = 0.0;
+    const int a = a0 + li;
+    if (lagg) {
+        for (int m = A.agg_ptr[a]; m < A.agg_ptr[a + 1]; ++m) s += mg_restrict_comp(tb + (size_t)(m - i0) * 6, A.d + (size_t)m * 3, c);
+        r_next[(size_t)a * 6 + c] = s;
+    }
+    if (!x_next) return;
+    rb[threadIdx.x] = s;
+    __syncthreads();
+    if (lagg) {
+        const double* Dk = Dinv_next + (size_t)a * 36 + c * 6;
+        const double* ra = rb + (threadIdx.x - c);
+        double x = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) x += Dk[j] * ra[j];
+        x_next[(size_t)a * 6 + c] = x;
+    }
+}
+// dense level: one workgroup of 6 wavefronts per node — wavefront q takes row 6 a + q of the explicit inverse (one wavefront per node leaves
+// the 58 MB of a 2688-wide inverse to 440 wavefronts: 21 us; one per row: 2640 wavefronts) — then x + s P y on the node's members below
+__global__ __launch_bounds__(384) void mg_dense_solve_kernel(CoarseDev K, MgLevelDev Below, int has_below, double scale, const int32_t* __restrict__ stop) {
+    __shared__ double ys[6];
+    if (stop && *stop) return;
+    const int a = blockIdx.x;
+    const int q = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const double2* __restrict__ x = reinterpret_cast<const double2*>(K.rc);
+    const double2* __restrict__ Ar = reinterpret_cast<const double2*>(K.Ac + (size_t)(a * 6 + q) * K.nc);
+    const int n2 = K.nc >> 1;
+    double s = 0.0;
+#pragma unroll 4
+    for (int j = lane; j < n2; j += 64) { const double2 u = Ar[j], v = x[j]; s += u.x * v.x + u.y * v.y; }
+    s = wave_sum(s);
+    if (lane == 0) { ys[q] = s; K.yc[a * 6 + q] = s; }
+    if (!has_below) return;
+    __syncthreads();
+    double y[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) y[k] = ys[k];
+    const int c0 = Below.agg_ptr[a], c1 = Below.agg_ptr[a + 1];
+    for (int idx = threadIdx.x; idx < (c1 - c0) * 6; idx += 384) {
+        const int i = c0 + idx / 6, k = idx % 6;
+        Below.xt[(size_t)i * 6 + k] = Below.x[(size_t)i * 6 + k] + scale * mg_prolong_comp(y, Below.d + (size_t)i * 3, k);
+    }
+}
+// x = xt + Dinv (r - A xt) on a tile; then xt = x + P x on the members (level below) of the tile's rows
+__global__ __launch_bounds__(CG_BLOCK) void mg_up_kernel(MgLevelDev A, MgLevelDev Below, int has_below, double scale, const int32_t* __restrict__ stop) {
+    __shared__ double xch[CG_BLOCK * 7];
+    __shared__ double tb[CG_BLOCK];
+    __shared__ double xb[CG_BLOCK];
+    if (stop && *stop) return;
+    const int a0 = A.tile_agg0[blockIdx.x], a1 = A.tile_agg0[blockIdx.x + 1];
+    const int i0 = A.agg_ptr[a0], i1 = A.agg_ptr[a1];
+    const int li = threadIdx.x / 6, c = threadIdx.x % 6;
+    const int row = i0 + li;
+    const bool live = row < i1;
+    double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (live) mg_row_accumulate(A.rowptr, A.col, A.val, A.xt, row, c, acc);
+    double* mine = xch + (size_t)threadIdx.x * 7;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) mine[q] = acc[q];
+    __syncthreads();
+    if (live) {
+        const double* grp = xch + (size_t)(threadIdx.x - c) * 7;
+        double q = 0.0;
+#pragma unroll
+        for (int cc = 0; cc < 6; ++cc) q += grp[cc * 7 + c];
+        tb[threadIdx.x] = A.r[(size_t)row * 6 + c] - q;
+    }
+    __syncthreads();
+    if (live) {
+        const double* Dk = A.Dinv + (size_t)row * 36 + c * 6;
+        const double* ta = tb + (threadIdx.x - c);
+        double x = A.xt[(size_t)row * 6 + c];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) x += Dk[j] * ta[j];
+        A.xf[(size_t)row * 6 + c] = x;
+        xb[threadIdx.x] = x;
+    }
+    if (!has_below) return;
+    __syncthreads();
+    const int c0 = Below.agg_ptr[i0], c1 = Below.agg_ptr[i1];
+    for (int idx = threadIdx.x; idx < (c1 - c0) * 6; idx += CG_BLOCK) {
+        const int i = c0 + idx / 6, k = idx % 6;
+        const double* y = xb + (size_t)(Below.parent[i] - i0) * 6;
+        Below.xt[(size_t)i * 6 + k] = Below.x[(size_t)i * 6 + k] + scale * mg_prolong_comp(y, Below.d + (size_t)i * 3, k);
+    }
+}
+// z_i += P_i y_{agg0(i)} and r.z += r.(P y), in cg_update's lane / workgroup mapping (same partial-sum slots)
+__global__ __launch_bounds__(CG_BLOCK) void mg_prolong0_kernel(GraphDev G, MgDev M, const double* __restrict__ y1, const double* __restrict__ rv, double* __restrict__ zv,
+                                                                double* __restrict__ part_rz, double scale, const int32_t* __restrict__ stop) {
+    __shared__ double red[CG_BLOCK / 64];
+    if (stop && *stop) return;
+    const int64_t pairs = G.N * 3;
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * CG_BLOCK + threadIdx.x; i < pairs; i += (int64_t)gridDim.x * CG_BLOCK) {
+        const int64_t n = i / 3;
+        const int j = (int)(i - n * 3);
+        const int a = M.agg0[n];
+        if (a < 0) continue;
+        const double* y = y1 + (size_t)a * 6;
+        const double* d = M.d0 + (size_t)n * 3;
+        const double a0 = scale * mg_prolong_comp(y, d, 2 * j), a1 = scale * mg_prolong_comp(y, d, 2 * j + 1);
+        double2* zp = reinterpret_cast<double2*>(zv) + i;
+        const double2 r = reinterpret_cast<const double2*>(rv)[i];
+        double2 z = *zp;
+        z.x += a0; z.y += a1;
+        *zp = z;
+        acc += r.x * a0 + r.y * a1;
+    }
+    const double s = block_sum(acc, red);
+    if (threadIdx.x == 0) part_rz[blockIdx.x] += s;
+}
+
+void launch_mg_apply(const GraphDev& G, const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, const double* r, double* z, double* part_rz, double scale, bool inside_iteration, hipStream_t st) {
+    const int32_t* stop = inside_iteration ? C.flags : nullptr;     // at PCG start the flag still belongs to the previous solve
+    const int nl = M.n_levels;
+    const unsigned g1 = (unsigned)((M.n1 + MG_TILE_ROWS - 1) / MG_TILE_ROWS);
+    if (nl == 1) hipLaunchKernelGGL(mg_restrict0_kernel, dim3(g1), dim3(CG_BLOCK), 0, st, M, r, K.rc, (double*)nullptr, (const double*)nullptr, stop);
+    else hipLaunchKernelGGL(mg_restrict0_kernel, dim3(g1), dim3(CG_BLOCK), 0, st, M, r, levels[0].r, levels[0].x, (const double*)levels[0].Dinv, stop);
+    for (int l = 1; l < nl; ++l) {                     // sparse level l -> level l+1
+        const MgLevelDev& A = levels[l - 1];
+        if (l + 1 == nl) hipLaunchKernelGGL(mg_down_kernel, dim3((unsigned)A.tiles), dim3(CG_BLOCK), 0, st, A, K.rc, (double*)nullptr, (const double*)nullptr, stop);
+        else hipLaunchKernelGGL(mg_down_kernel, dim3((unsigned)A.tiles), dim3(CG_BLOCK), 0, st, A, levels[l].r, levels[l].x, (const double*)levels[l].Dinv, stop);
+    }
+    hipLaunchKernelGGL(mg_dense_solve_kernel, dim3((unsigned)K.n_agg), dim3(384), 0, st, K, nl >= 2 ? levels[nl - 2] : levels[0], nl >= 2 ? 1 : 0, scale, stop);
+    for (int l = nl - 1; l >= 1; --l)
+        hipLaunchKernelGGL(mg_up_kernel, dim3((unsigned)levels[l - 1].tiles), dim3(CG_BLOCK), 0, st, levels[l - 1], l >= 2 ? levels[l - 2] : levels[0], l >= 2 ? 1 : 0, scale, stop);
+    hipLaunchKernelGGL(mg_prolong0_kernel, dim3(cg_grid(G)), dim3(CG_BLOCK), 0, st, G, M, (const double*)(nl == 1 ? K.yc : levels[0].xf), r, z, part_rz, scale, stop);
+}

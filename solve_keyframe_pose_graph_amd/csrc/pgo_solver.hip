@@ -19,6 +19,7 @@
 
 #include "pgo.h"
 #include "pgo_internal.hpp"
+#include "pgo_mg_host.hpp"
 
 using namespace pgo;
 
@@ -120,6 +121,11 @@ struct pgo_problem {
     int coarse_backoff = 0, coarse_skip = 0;   // a handle that keeps dropping it (incremental triggers on the same kind of graph) retests ever more rarely
     int coarse_keep_streak = 0;      // consecutive solves that kept it: the comparison is then repeated only every 4th solve
     uint64_t coarse_geometry_epoch = 0, lin_epoch = 0;   // lin_epoch counts linearisations (the centroids follow the poses)
+    // aggregation multigrid (MgDev): hierarchy arrays live in three pooled buffers
+    DBuf<double> d_mg_f64; DBuf<int32_t> d_mg_i32; DBuf<int64_t> d_mg_i64;
+    MgDev M{}; MgLevelDev mg_levels[MG_MAX_LEVELS];
+    bool mg_built = false, mg_active = false;
+    uint64_t mg_geometry_epoch = 0;
     int64_t n_vio = 0;
     // matrix-free operator
     DBuf<uint32_t> d_einc;
@@ -158,7 +164,13 @@ struct pgo_problem {
     Poll* poll = nullptr; hipEvent_t poll_ev[2] = {nullptr, nullptr};
 
     // hipGraph of one PCG chunk (launch-bound inner loop); valid for (graph build epoch, tolerance, chunk length, solver)
-    hipGraphExec_t cg_graph = nullptr; int cg_graph_len = 0; double cg_graph_tol2 = -1; uint64_t cg_graph_epoch = 0, build_epoch = 1; bool cg_graph_failed = false; bool cg_graph_coarse = false;
+    // one captured chunk per preconditioner (0 block-Jacobi, 1 two-level, 2 multigrid): the hybrid policy changes between them inside a solve
+    struct CapturedChunk { hipGraphExec_t exec = nullptr; int len = 0; uint64_t epoch = 0; };
+    CapturedChunk cg_chunk[3];
+    hipGraphExec_t cg_graph = nullptr;   // the one in use (not owned)
+    uint64_t build_epoch = 1; bool cg_graph_failed = false;
+    int cg_extra = 0;                    // PCG iterations of the current LM step spent before a change of preconditioner
+    bool mg_failed = false;              // the multigrid operators of the current system could not be built
 };
 
 namespace {
@@ -509,6 +521,66 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S) {
             p->coarse_built = true;
         }
     }
+    // ---- aggregation multigrid for large graphs (single GPU): hierarchy of graph-following rigid aggregates, pgo_mg_host.hpp
+    p->mg_built = false; p->mg_active = false; p->M = MgDev{}; p->mg_geometry_epoch = 0;
+    if (!p->local_ids && p->opt.mg_min_keyframes > 0 && N >= p->opt.mg_min_keyframes) {
+        pgo_mg::Hierarchy H;
+        const int dense_max = std::max(1, std::min(p->opt.mg_dense_max_nodes, 512));
+        const bool ok = pgo_mg::build_hierarchy(N, p->h_node_free, p->rel.c1, p->rel.c2, p->rel.meas.data(), p->swe.c1, p->swe.c2, std::max(1, std::min(p->opt.mg_first_passes, 3)),
+                                                std::max(1, std::min(p->opt.mg_passes, 3)), dense_max, MG_TILE_ROWS, MG_MAX_LEVELS, H);
+        if (ok) {
+            const int nl = (int)H.L.size();
+            // pooled arrays: (offset, count) per array; doubles rounded up to even counts (16-B loads)
+            std::vector<int32_t> pi32; std::vector<int64_t> pi64;
+            auto put32 = [&](const std::vector<int32_t>& v) { const size_t o = pi32.size(); pi32.insert(pi32.end(), v.begin(), v.end()); return o; };
+            auto put64 = [&](const std::vector<int64_t>& v) { const size_t o = pi64.size(); pi64.insert(pi64.end(), v.begin(), v.end()); return o; };
+            size_t nf64 = 0;
+            auto take = [&](size_t cnt) { const size_t o = nf64; nf64 += (cnt + 1) & ~(size_t)1; return o; };
+            struct Off { size_t col, parent, agg_ptr, tile, rowptr, g_ptr, g_ent, val, Dinv, pos, d, r, x, xt, xf; };
+            std::vector<Off> off((size_t)nl);
+            const size_t o_agg0 = put32(H.agg0), o_mem0_ptr = put32(H.mem0_ptr), o_mem0 = put32(H.mem0);
+            const size_t o_d0 = take((size_t)N * 3);
+            for (int l = 0; l < nl; ++l) {
+                const pgo_mg::HostLevel& A = H.L[l];
+                Off& o = off[l];
+                o.col = put32(A.col); o.parent = put32(A.parent); o.agg_ptr = put32(A.agg_ptr); o.tile = put32(A.tile_agg0);
+                o.rowptr = put64(A.rowptr); o.g_ptr = put64(A.g_ptr); o.g_ent = put64(A.g_ent);
+                o.val = take(A.col.size() * 36); o.Dinv = take((size_t)A.n * 36); o.pos = take((size_t)A.n * 3); o.d = take((size_t)A.n * 3);
+                o.r = take((size_t)A.n * 6); o.x = take((size_t)A.n * 6); o.xt = take((size_t)A.n * 6); o.xf = take((size_t)A.n * 6);
+            }
+            const int n_top = H.L[nl - 1].n;
+            const int nc = (6 * n_top + 63) / 64 * 64;
+            HIPCHK(p, p->d_mg_i32.ensure(std::max<size_t>(pi32.size(), 1))); HIPCHK(p, p->d_mg_i64.ensure(std::max<size_t>(pi64.size(), 1))); HIPCHK(p, p->d_mg_f64.ensure(std::max<size_t>(nf64, 2)));
+            HIPCHK(p, p->d_cAc.ensure((size_t)nc * nc)); HIPCHK(p, p->d_crc.ensure((size_t)nc * 2)); HIPCHK(p, p->d_cscr.ensure((size_t)nc * 64 + 1024)); HIPCHK(p, p->d_cinfo.ensure(4));
+            HIPCHK(p, hipMemcpyAsync(p->d_mg_i32.p, pi32.data(), pi32.size() * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
+            HIPCHK(p, hipMemcpyAsync(p->d_mg_i64.p, pi64.data(), pi64.size() * sizeof(int64_t), hipMemcpyHostToDevice, p->st));
+            HIPCHK(p, hipMemsetAsync(p->d_mg_f64.p, 0, nf64 * sizeof(double), p->st));
+            HIPCHK(p, hipMemsetAsync(p->d_crc.p, 0, (size_t)nc * 2 * sizeof(double), p->st));
+            HIPCHK(p, hipStreamSynchronize(p->st));
+            const int32_t* b32 = p->d_mg_i32.p; const int64_t* b64 = p->d_mg_i64.p; double* bf = p->d_mg_f64.p;
+            p->M = MgDev{nl, H.L[0].n, b32 + o_agg0, b32 + o_mem0_ptr, b32 + o_mem0, bf + o_d0};
+            for (int l = 0; l < nl; ++l) {
+                const pgo_mg::HostLevel& A = H.L[l];
+                const Off& o = off[l];
+                MgLevelDev& D = p->mg_levels[l];
+                D = MgLevelDev{};
+                D.n = A.n; D.n_next = l + 1 < nl ? H.L[l + 1].n : 0; D.tiles = A.tile_agg0.empty() ? 0 : (int32_t)A.tile_agg0.size() - 1; D.nnzb = (int64_t)A.col.size();
+                D.rowptr = b64 + o.rowptr; D.col = b32 + o.col; D.val = bf + o.val; D.g_ptr = b64 + o.g_ptr; D.g_ent = b64 + o.g_ent;
+                D.Dinv = bf + o.Dinv; D.pos = bf + o.pos; D.d = bf + o.d; D.parent = b32 + o.parent; D.agg_ptr = b32 + o.agg_ptr; D.tile_agg0 = b32 + o.tile;
+                D.r = bf + o.r; D.x = bf + o.x; D.xt = bf + o.xt; D.xf = bf + o.xf;
+            }
+            // the dense coarsest level shares the buffers of the two-level preconditioner, which the multigrid replaces on this graph
+            p->coarse_built = false;
+            p->K = CoarseDev{};
+            p->K.n_agg = n_top; p->K.nc = nc; p->K.Ac = p->d_cAc.p; p->K.rc = p->d_crc.p; p->K.yc = p->d_crc.p + nc;
+            p->mg_built = true;
+            if (p->opt.verbosity > 0) {
+                std::fprintf(stderr, "[pgo] multigrid: %lld keyframes", (long long)N);
+                for (int l = 0; l < nl; ++l) std::fprintf(stderr, " -> %d (%lld blocks)", H.L[l].n, (long long)H.L[l].col.size());
+                std::fprintf(stderr, ", coarsest dense %d\n", nc);
+            }
+        } else if (p->opt.verbosity > 0) std::fprintf(stderr, "[pgo] multigrid: the graph does not coarsen (isolated keyframes?) -> off\n");
+    }
     p->graph_dirty = false; p->priors_dirty = false;
     ++p->build_epoch;   // invalidates the captured PCG graph (kernel arguments hold device pointers / sizes)
     return PGO_OK;
@@ -630,6 +702,9 @@ int linearize(pgo_problem* p, double* cost_out) {
     return PGO_OK;
 }
 
+static int build_mg(pgo_problem* p);
+double mg_scale(const pgo_problem* p) { return p->opt.mg_correction_scale >= 1.0 && p->opt.mg_correction_scale <= 4.0 ? p->opt.mg_correction_scale : 1.0; }
+
 struct CgResult { int iterations; bool breakdown; double rel_residual; bool converged; };
 
 // rel_tol: relative tolerance of this phase.  resume_from >= 0: continue the stopped PCG at that iteration index with the new tolerance
@@ -650,10 +725,11 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
     // w = A u together with gamma = r.u (owner-weighted partials of the previous update) and delta = u.A u (rank-local partials).
     const bool multi = p->local_ids;
     if (resume_from < 0) {
-        if (!multi && p->coarse_active) {
-            // z = D^-1 r + P Ac^-1 P^T r: the coarse term is added to z and to the r.z partials before the scalars are formed
+        if (!multi && (p->coarse_active || p->mg_active)) {
+            // z = D^-1 r + P Ac^-1 P^T r (or the multigrid cycle): the coarse term is added to z and to the r.z partials before the scalars are formed
             const int g = launch_cg_init_vectors(p->G, p->C, warm ? 1 : 0, p->st);
-            launch_coarse_apply(p->G, p->C, p->K, p->C.r, p->C.z, p->C.part_rz, false, p->st);
+            if (p->mg_active) launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz, mg_scale(p), false, p->st);
+            else launch_coarse_apply(p->G, p->C, p->K, p->C.r, p->C.z, p->C.part_rz, false, p->st);
             launch_cg_init_scalars(p->C, g, tol2, p->st);
         } else if (!multi) launch_cg_init(p->G, p->C, warm ? 1 : 0, tol2, p->st);
         else {
@@ -669,10 +745,16 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
     int k = resume_from >= 0 ? resume_from : 0;
     int32_t hflags[3] = {0, 0, 0};
     double hscal[3] = {0, 0, 0};
-    int every = std::max(2, o.cg_check_every) & ~1;   // even: the r/p ping-pong parity repeats from chunk to chunk
-    // five kernels per iteration with the coarse space: chunks of 12 keep a captured chunk at 60 kernel nodes (rocprofv3 7.2 crashes while a
-    // graph of 120 nodes is captured under --kernel-trace; 80 are fine) and halve the early-exit launches after convergence
-    if (p->coarse_active && !multi) every = std::min(every, 12);
+    int every = 2;
+    auto chunk_length = [&]() {
+        int e = std::max(2, o.cg_check_every) & ~1;   // even: the r/p ping-pong parity repeats from chunk to chunk
+        // five kernels per iteration with the coarse space: chunks of 12 keep a captured chunk at 60 kernel nodes (rocprofv3 7.2 crashes while a
+        // graph of 120 nodes is captured under --kernel-trace; 80 are fine) and halve the early-exit launches after convergence
+        if (p->coarse_active && !multi) e = std::min(e, 12);
+        if (p->mg_active && !multi) e = std::max(2, (72 / (2 * p->M.n_levels + 3)) & ~1);   // 2 n_levels + 1 cycle kernels + matvec + update per iteration
+        return e;
+    };
+    every = chunk_length();
     int rc;
     auto one_iteration = [&](int kk) -> int {
         if (multi) {
@@ -691,25 +773,32 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
         if (p->built_mf) { launch_mf_spmv(p->G, p->F, p->Sc, p->C, kk, tol2, p->st); n_pq = mf_grid_size(p->F); }
         else launch_cg_spmv(p->G, p->C, kk, tol2, p->st);
         launch_cg_update(p->G, p->C, kk, n_pq, p->st);
-        if (p->coarse_active)   // the new residual is in the OTHER r buffer, its r.z partials in the other parity's slots
+        // the new residual is in the OTHER r buffer, its r.z partials in the other parity's slots
+        if (p->mg_active) launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, (kk & 1) ? p->C.r : p->C.r2, p->C.z, p->C.part_rz + (size_t)((kk & 1) ^ 1) * MAX_PARTIALS, mg_scale(p), true, p->st);
+        else if (p->coarse_active)
             launch_coarse_apply(p->G, p->C, p->K, (kk & 1) ? p->C.r : p->C.r2, p->C.z, p->C.part_rz + (size_t)((kk & 1) ^ 1) * MAX_PARTIALS, true, p->st);
         return PGO_OK;
     };
-    // hipGraph: capture one chunk (iterations 2 .. 2+every-1: no `first` kernel, even start) once per graph build and replay it
+    // hipGraph: capture one chunk (iterations 2 .. 2+every-1: no `first` kernel, even start) once per graph build and preconditioner, and replay it
     const bool want_graph = o.cg_use_graph && !p->local_ids && !p->cg_graph_failed;
-    if (want_graph && (p->cg_graph == nullptr || p->cg_graph_epoch != p->build_epoch || p->cg_graph_len != every || p->cg_graph_coarse != p->coarse_active)) {
-        if (p->cg_graph) { (void)hipGraphExecDestroy(p->cg_graph); p->cg_graph = nullptr; }
+    auto ensure_graph = [&]() {
+        const int mode = p->mg_active ? 2 : p->coarse_active ? 1 : 0;
+        pgo_problem::CapturedChunk& cc = p->cg_chunk[mode];
+        if (!want_graph || (cc.exec != nullptr && cc.epoch == p->build_epoch && cc.len == every)) { p->cg_graph = want_graph ? cc.exec : nullptr; return; }
+        if (cc.exec) { (void)hipGraphExecDestroy(cc.exec); cc.exec = nullptr; }
         hipGraph_t gr = nullptr;
         bool ok = hipStreamBeginCapture(p->st, hipStreamCaptureModeThreadLocal) == hipSuccess;
         if (ok) {
             for (int j = 0; j < every; ++j) (void)one_iteration(2 + j);
             ok = hipStreamEndCapture(p->st, &gr) == hipSuccess && gr != nullptr;
         }
-        if (ok) ok = hipGraphInstantiate(&p->cg_graph, gr, nullptr, nullptr, 0) == hipSuccess;
+        if (ok) ok = hipGraphInstantiate(&cc.exec, gr, nullptr, nullptr, 0) == hipSuccess;
         if (gr) (void)hipGraphDestroy(gr);
-        if (!ok) { p->cg_graph = nullptr; p->cg_graph_failed = true; (void)hipGetLastError(); }
-        else { p->cg_graph_epoch = p->build_epoch; p->cg_graph_len = every; p->cg_graph_coarse = p->coarse_active; }
-    }
+        if (!ok) { cc.exec = nullptr; p->cg_graph_failed = true; (void)hipGetLastError(); }
+        else { cc.epoch = p->build_epoch; cc.len = every; }
+        p->cg_graph = cc.exec;
+    };
+    ensure_graph();
     // Chunks of `every` iterations; the convergence flag of chunk j is read (pinned memory + event) only AFTER chunk j+1 has been
     // enqueued, so the GPU never drains while the host polls.  A chunk enqueued after convergence is a string of early-exit kernels.
     int n_chunks = 0, waited = -1;
@@ -741,6 +830,25 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
             if (p->poll[check & 1].flags[0]) done = true;
         }
         ++n_chunks;
+        // Hybrid preconditioning: most LM systems (small trust regions, steps about to be rejected) are solved by block-Jacobi in a few
+        // hundred cheap iterations; one that is not done after mg_switch_iterations is a hard one, and from there the multigrid (4x fewer
+        // iterations or better at ~3x the price) takes over: operators built now, PCG restarted from the current iterate.
+        if (!done && !multi && p->mg_built && !p->mg_active && !p->mg_failed && k >= p->opt.mg_switch_iterations && k < o.cg_max_iterations) {
+            HIPCHK(p, hipMemcpyAsync(hflags, p->C.flags, sizeof(hflags), hipMemcpyDeviceToHost, p->st));
+            HIPCHK(p, hipStreamSynchronize(p->st));
+            if (hflags[0]) { done = true; (void)enqueue_poll(n_chunks & 1); ++n_chunks; break; }
+            if ((rc = build_mg(p)) != PGO_OK) return rc;
+            if (!p->mg_active) { p->mg_failed = true; continue; }
+            p->cg_extra += hflags[2];
+            if (p->built_mf) launch_mf_apply(p->G, p->F, p->Sc, p->C, p->C.x, p->C.q, p->st);
+            else launch_apply_operator(p->G, p->C, p->C.x, p->C.q, p->st);
+            const int g = launch_cg_init_vectors(p->G, p->C, 1, p->st);
+            launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz, mg_scale(p), false, p->st);
+            launch_cg_init_scalars(p->C, g, tol2, p->st);
+            k = 0; n_chunks = 0; waited = -1;
+            every = chunk_length();
+            ensure_graph();
+        }
     }
     if (n_chunks > 0) {   // the state after the LAST enqueued chunk is the final one (kernels past convergence do nothing)
         HIPCHK(p, hipEventSynchronize(p->poll_ev[(n_chunks - 1) & 1]));
@@ -797,6 +905,27 @@ static int build_coarse(pgo_problem* p) {
     return PGO_OK;
 }
 
+// Multigrid operators of the system just built: Galerkin products level by level, block-Jacobi inverses, dense inverse of the coarsest level.
+// A block that is not numerically positive definite leaves the multigrid off for this LM iteration (plain block-Jacobi).
+static int build_mg(pgo_problem* p) {
+    p->mg_active = false;
+    if (!p->mg_built) return PGO_OK;
+    if (p->mg_geometry_epoch != p->lin_epoch) {              // the aggregates' centroids follow the poses of the current linearisation
+        launch_mg_geometry(p->G, p->M, p->mg_levels, p->d_pose[p->cur].p, p->st);
+        p->mg_geometry_epoch = p->lin_epoch;
+    }
+    int32_t* fail = p->d_cinfo.p;
+    HIPCHK(p, hipMemsetAsync(fail, 0, sizeof(int32_t), p->st));
+    launch_mg_assemble(p->G, p->L, p->Sc, p->C, p->M, p->mg_levels, p->K, p->opt.mg_omega > 0.0 && p->opt.mg_omega <= 1.0 ? p->opt.mg_omega : 0.9, fail, p->st);
+    launch_coarse_invert(p->K, p->d_cscr.p, fail, p->st);
+    int32_t h = 1;
+    HIPCHK(p, hipMemcpyAsync(&h, fail, sizeof(h), hipMemcpyDeviceToHost, p->st));
+    HIPCHK(p, hipStreamSynchronize(p->st));
+    p->mg_active = h == 0;
+    if (p->opt.verbosity > 0 && h != 0) std::fprintf(stderr, "[pgo] multigrid: a coarse block is not positive definite at radius %.1e -> off for this iteration\n", p->radius);
+    return PGO_OK;
+}
+
 int build_system(pgo_problem* p, bool* ok) {
     int rc;
     HIPCHK(p, hipMemsetAsync(p->d_flags.p + 4, 0, sizeof(int32_t), p->st));
@@ -807,7 +936,9 @@ int build_system(pgo_problem* p, bool* ok) {
     HIPCHK(p, hipMemcpyAsync(&fail, p->d_flags.p + 4, sizeof(int32_t), hipMemcpyDeviceToHost, p->st));
     HIPCHK(p, hipStreamSynchronize(p->st));
     *ok = fail == 0;
-    if (*ok && (rc = build_coarse(p)) != PGO_OK) return rc;
+    p->mg_active = false; p->mg_failed = false;
+    if (*ok && p->mg_built) { if (p->opt.mg_switch_iterations <= 0 && (rc = build_mg(p)) != PGO_OK) return rc; }
+    else if (*ok && (rc = build_coarse(p)) != PGO_OK) return rc;
     return PGO_OK;
 }
 
@@ -883,6 +1014,7 @@ int lm_step(pgo_problem* p, int ignore_termination, int* done) {
     bool ok = true;
     if ((rc = build_system(p, &ok)) != PGO_OK) return rc;
     CgResult cg{0, false, 0.0, false};
+    p->cg_extra = 0;
     const int nxt = p->cur ^ 1;
     double h[S_N] = {0};
     // candidate point x (+) delta, its cost, the model cost change and the step norms -> h[]
@@ -952,8 +1084,8 @@ int lm_step(pgo_problem* p, int ignore_termination, int* done) {
         p->have_prev_step = !cg.breakdown;
         if (cg.breakdown) ok = false;
     }
-    it.cg_iterations = cg.iterations; it.cg_residual = cg.rel_residual;
-    p->sum.cg_iterations += cg.iterations;
+    it.cg_iterations = cg.iterations + p->cg_extra; it.cg_residual = cg.rel_residual;
+    p->sum.cg_iterations += cg.iterations + p->cg_extra;
     if (ok) {
         if (!evaluated && (rc = evaluate_candidate()) != PGO_OK) return rc;
         it.model_cost_change = -h[S_MODEL];
@@ -1121,6 +1253,13 @@ void pgo_options_init(pgo_options* o) {
     o->cg_mid_reject_rho = -0.05;
     o->coarse_aggregates = 512;
     o->coarse_min_radius = 1e5;
+    o->mg_min_keyframes = 0;
+    o->mg_omega = 0.9;
+    o->mg_correction_scale = 1.6;
+    o->mg_first_passes = 3;
+    o->mg_passes = 2;
+    o->mg_dense_max_nodes = 512;
+    o->mg_switch_iterations = 400;
     o->cg_rel_tolerance = 1e-9;     // loosest decade that keeps the 10-iteration chi^2 of C3 within 1e-8 of the 1e-13 solve
     o->device_id = -1;
     o->verbosity = 0;
@@ -1152,7 +1291,7 @@ int pgo_destroy(pgo_problem* p) {
     (void)hipSetDevice(p->device);
     if (p->comm && p->nccl.CommDestroy) p->nccl.CommDestroy(p->comm);
     (void)hipStreamSynchronize(p->st);
-    if (p->cg_graph) (void)hipGraphExecDestroy(p->cg_graph);
+    for (auto& cc : p->cg_chunk) if (cc.exec) (void)hipGraphExecDestroy(cc.exec);
     if (p->poll) (void)hipHostFree(p->poll);
     for (int i = 0; i < 2; ++i) if (p->poll_ev[i]) (void)hipEventDestroy(p->poll_ev[i]);
     p->d_rc1.release(); p->d_rc2.release(); p->d_sc1.release(); p->d_sc2.release(); p->d_sidx.release(); p->d_bsr_col.release();
@@ -1163,6 +1302,7 @@ int pgo_destroy(pgo_problem* p) {
     p->d_val.release(); p->d_Lf.release(); p->d_Dtot_b.release(); p->d_cgvec.release(); p->d_part.release(); p->d_cgpart.release();
     p->d_flags.release(); p->d_scal.release(); p->d_pose[0].release(); p->d_pose[1].release(); p->d_swv[0].release(); p->d_swv[1].release();
     p->d_delta_s.release(); p->d_io.release(); p->d_tmp.release(); p->d_vio.release();
+    p->d_mg_f64.release(); p->d_mg_i32.release(); p->d_mg_i64.release();
     p->d_ccen.release(); p->d_cd.release(); p->d_cAc.release(); p->d_crc.release(); p->d_cblk_ptr.release(); p->d_ccontrib.release(); p->d_cblk_ab.release(); p->d_cagg_free.release(); p->d_cinfo.release(); p->d_cscr.release();
     p->d_l2g.release(); p->d_sh_loc.release(); p->d_sh_pos.release(); p->d_own.release(); p->d_xbuf.release();
     p->d_einc.release(); p->d_einc_ownl.release(); p->d_node_rng.release(); p->d_tile_inc0.release(); p->d_einc_other.release();

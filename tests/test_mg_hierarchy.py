@@ -1,0 +1,157 @@
+"""CPU: the host-side hierarchy of the aggregation multigrid (csrc/pgo_mg_host.hpp: graph-following aggregates by heavy-edge matching,
+contiguous renumbering, block structures, Galerkin contribution lists) checked for its invariants through tests/native/mg_host.cpp.
+Host logic coverage; the cycle runs in HIP kernels (tests/test_gpu_multigrid.py)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from solve_keyframe_pose_graph_amd import graphgen
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+@pytest.fixture(scope="module")
+def shim():
+    so = os.path.join(HERE, "native", "libmg_host.so")
+    src = os.path.join(HERE, "native", "mg_host.cpp")
+    hdr = os.path.join(ROOT, "solve_keyframe_pose_graph_amd", "csrc", "pgo_mg_host.hpp")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", os.path.dirname(hdr), "-o", so, src])
+    lib = C.CDLL(so)
+    lib.mgh_build.restype = C.c_void_p
+    return lib
+
+
+def I32(x): return np.ascontiguousarray(x, dtype=np.int32)
+def ptr(a, t): return a.ctypes.data_as(C.POINTER(t))
+
+
+def build(lib, g, free=None, passes0=3, passes=2, dense_max=64, tile_rows=32, max_levels=12):
+    N = g.n_poses
+    nf = np.ones(N, np.uint8) if free is None else np.ascontiguousarray(free, dtype=np.uint8)
+    rc1, rc2, sc1, sc2 = I32(g.odom_c1), I32(g.odom_c2), I32(g.loop_c1), I32(g.loop_c2)
+    rw = np.ascontiguousarray(g.odom_w, dtype=np.float64)
+    h = lib.mgh_build(C.c_longlong(N), ptr(nf, C.c_ubyte), C.c_longlong(len(rc1)), ptr(rc1, C.c_int), ptr(rc2, C.c_int), ptr(rw, C.c_double), C.c_longlong(len(sc1)), ptr(sc1, C.c_int),
+                      ptr(sc2, C.c_int), passes0, passes, dense_max, tile_rows, max_levels)
+    if not h:
+        return None
+    h = C.c_void_p(h)
+    levels = []
+    for l in range(lib.mgh_levels(h)):
+        sz = np.zeros(6, np.int64)
+        lib.mgh_sizes(h, l, ptr(sz, C.c_longlong))
+        n, nnzb, nent, npar, nagg, ntile = [int(x) for x in sz]
+        L = dict(n=n, rowptr=np.zeros(n + 1, np.int64), col=np.zeros(nnzb, np.int32), g_ptr=np.zeros(nnzb + 1, np.int64), g_ent=np.zeros(nent, np.int64),
+                 parent=np.zeros(npar, np.int32), agg_ptr=np.zeros(nagg, np.int32), tile_agg0=np.zeros(ntile, np.int32))
+        lib.mgh_level(h, l, ptr(L["rowptr"], C.c_longlong), ptr(L["col"], C.c_int), ptr(L["g_ptr"], C.c_longlong), ptr(L["g_ent"], C.c_longlong), ptr(L["parent"], C.c_int),
+                      ptr(L["agg_ptr"], C.c_int), ptr(L["tile_agg0"], C.c_int))
+        levels.append(L)
+    n1 = levels[0]["n"]
+    agg0 = np.zeros(N, np.int32); mem0_ptr = np.zeros(n1 + 1, np.int32)
+    nmem = int((nf != 0).sum())
+    mem0 = np.zeros(nmem, np.int32)
+    lib.mgh_level0(h, ptr(agg0, C.c_int), ptr(mem0_ptr, C.c_int), ptr(mem0, C.c_int))
+    lib.mgh_free(h)
+    return dict(levels=levels, agg0=agg0, mem0_ptr=mem0_ptr, mem0=mem0)
+
+
+def check(g, H, free, passes0, passes, dense_max):
+    N = g.n_poses
+    L = H["levels"]
+    agg0 = H["agg0"]
+    n1 = L[0]["n"]
+    # every free keyframe in exactly one level-1 aggregate of <= 2^passes0 keyframes; fixed ones in none
+    assert np.array_equal(agg0 >= 0, free.astype(bool))
+    assert set(agg0[agg0 >= 0]) == set(range(n1))
+    sizes = np.bincount(agg0[agg0 >= 0], minlength=n1)
+    assert sizes.min() >= 1 and sizes.max() <= 2 ** passes0
+    for a in range(n1):
+        mem = H["mem0"][H["mem0_ptr"][a]:H["mem0_ptr"][a + 1]]
+        assert len(mem) == sizes[a] and np.all(agg0[mem] == a)
+    # aggregates are connected through the graph (matching only ever merges across an edge)
+    nbr = [set() for _ in range(N)]
+    for c1, c2 in list(zip(g.odom_c1, g.odom_c2)) + list(zip(g.loop_c1, g.loop_c2)):
+        nbr[c1].add(c2); nbr[c2].add(c1)
+    for a in range(0, n1, max(1, n1 // 200)):
+        mem = set(H["mem0"][H["mem0_ptr"][a]:H["mem0_ptr"][a + 1]].tolist())
+        seen, todo = set(), [next(iter(mem))]
+        while todo:
+            x = todo.pop()
+            if x in seen: continue
+            seen.add(x); todo += [y for y in nbr[x] if y in mem and y not in seen]
+        assert seen == mem
+    # level 1 blocks: exactly the aggregate pairs the free-free edges connect, diagonal first, both triangles; every contribution listed once
+    fe = [(e, c1, c2, 1) for e, (c1, c2) in enumerate(zip(g.odom_c1, g.odom_c2))] + [(e, c1, c2, 3) for e, (c1, c2) in enumerate(zip(g.loop_c1, g.loop_c2))]
+    want = {(a, a) for a in range(n1)}
+    want_ent = {}
+    for i in range(N):
+        if agg0[i] >= 0: want_ent.setdefault((agg0[i], agg0[i]), []).append((i << 3) | 0)
+    for e, c1, c2, kind in fe:
+        a, b = agg0[c1], agg0[c2]
+        if a < 0 or b < 0: continue
+        want.add((a, b)); want.add((b, a))
+        want_ent.setdefault((a, b), []).append((e << 3) | kind); want_ent.setdefault((b, a), []).append((e << 3) | (kind + 1))
+    A = L[0]
+    got = set()
+    for r in range(n1):
+        cols = A["col"][A["rowptr"][r]:A["rowptr"][r + 1]]
+        assert cols[0] == r and len(set(cols.tolist())) == len(cols)
+        for k in range(A["rowptr"][r], A["rowptr"][r + 1]):
+            got.add((r, int(A["col"][k])))
+            ent = A["g_ent"][A["g_ptr"][k]:A["g_ptr"][k + 1]].tolist()
+            assert sorted(ent) == sorted(want_ent[(r, int(A["col"][k]))])
+    assert got == want
+    # coarser levels
+    for l in range(len(L) - 1):
+        A, B = L[l], L[l + 1]
+        par, ap = A["parent"], A["agg_ptr"]
+        assert len(par) == A["n"] and len(ap) == B["n"] + 1 and ap[0] == 0 and ap[-1] == A["n"]
+        assert np.all(np.diff(par) >= 0) and par[0] == 0 and par[-1] == B["n"] - 1            # members contiguous, parents ascending
+        assert np.all(np.diff(ap) >= 1) and np.all(np.diff(ap) <= 2 ** passes)
+        for a in range(B["n"]):
+            assert np.all(par[ap[a]:ap[a + 1]] == a)
+        t = A["tile_agg0"]
+        assert t[0] == 0 and t[-1] == B["n"] and np.all(np.diff(t) >= 1)
+        assert all(ap[t[k + 1]] - ap[t[k]] <= 32 for k in range(len(t) - 1))
+        rows = np.repeat(np.arange(A["n"]), np.diff(A["rowptr"]))
+        wantB = {}
+        for k in range(len(A["col"])):
+            wantB.setdefault((int(par[rows[k]]), int(par[A["col"][k]])), []).append((int(rows[k]) << 32) | k)
+        gotB = {}
+        for r in range(B["n"]):
+            cols = B["col"][B["rowptr"][r]:B["rowptr"][r + 1]]
+            assert cols[0] == r
+            for k in range(B["rowptr"][r], B["rowptr"][r + 1]):
+                gotB[(r, int(B["col"][k]))] = B["g_ent"][B["g_ptr"][k]:B["g_ptr"][k + 1]].tolist()
+        assert set(gotB) == set(wantB)
+        for key in wantB:
+            assert sorted(gotB[key]) == sorted(wantB[key])
+        assert all((b, a) in gotB for (a, b) in gotB)                                             # structurally symmetric
+    assert L[-1]["n"] <= dense_max and len(L[-1]["parent"]) == 0
+    assert all(L[l + 1]["n"] < L[l]["n"] for l in range(len(L) - 1))
+
+
+@pytest.mark.parametrize("n,loops,f,passes0,passes,dense_max", [(1500, 1500, 2, 3, 2, 64), (4000, 2500, 2, 2, 2, 100), (900, 100, 1, 3, 3, 16), (2500, 2500, 5, 1, 1, 200)])
+def test_hierarchy_invariants(shim, n, loops, f, passes0, passes, dense_max):
+    g = graphgen.generate(n, loops, odom_f_max=f, seed=n)
+    free = np.ones(n, np.uint8)
+    H = build(shim, g, free, passes0, passes, dense_max)
+    assert H is not None and len(H["levels"]) >= 2
+    check(g, H, free, passes0, passes, dense_max)
+
+
+def test_fixed_keyframes_stay_outside_and_isolated_graphs_are_refused(shim):
+    g = graphgen.generate(1200, 600, odom_f_max=2, seed=4)
+    free = np.ones(1200, np.uint8); free[:300] = 0; free[700] = 0
+    H = build(shim, g, free, 3, 2, 64)
+    assert H is not None
+    check(g, H, free, 3, 2, 64)
+    # a "graph" without edges cannot coarsen: the builder says so instead of returning a useless hierarchy
+    class E: pass
+    e = E(); e.n_poses = 1000
+    e.odom_c1 = e.odom_c2 = e.loop_c1 = e.loop_c2 = np.zeros(0, np.int32); e.odom_w = np.zeros(0)
+    assert build(shim, e, np.ones(1000, np.uint8), 3, 2, 64) is None
