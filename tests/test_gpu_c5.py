@@ -1,0 +1,86 @@
+"""GPU: BASELINE.json config 5 — 1M keyframes / 3M edges (1 999 997 odometry f=1,2 + 1 000 003 switchable loop closures) — at full size on ONE
+MI355X: (a) the single-handle path (non-temporal K1 stores above the Infinity-Cache size, 32-bit index headroom at 6M edge sides) against
+the oracle's O(E) evaluation and through three LM iterations; (b) the same graph dealt out to four and to eight in-process ranks (edge sharding,
+rank-local subgraphs, one exchange per CG iteration) against the single-rank trajectory."""
+import threading
+
+import numpy as np
+import pytest
+
+from solve_keyframe_pose_graph_amd import capi, graphgen, sharding
+from tests import util
+from tests.test_gpu_two_ranks_one_gpu import InProcessAllReduce
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def c5():
+    g = graphgen.config("C5")
+    assert g.n_poses == 1000000 and g.n_odom == 1999997 and g.n_loops == 1000003
+    return g
+
+
+def test_c5_objective_gradient_and_three_lm_iterations_on_one_gpu(c5):
+    g = c5
+    O = util.oracle_problem(g, True)
+    P = util.pgo_problem(g, True, max_num_iterations=3)
+    q, t, s = util.initial_state(g, True)
+    c0, r0, g0 = O.evaluate(q, t, s)
+    cp, rp, gp = P.evaluate(q, t, s)                     # K1 with non-temporal stores (2.2 GB of Jacobian blocks) + K2
+    assert abs(cp - c0) <= 1e-10 * c0
+    assert np.abs(rp - r0).max() <= 1e-11 * max(1.0, np.abs(r0).max())
+    assert np.abs(gp - g0).max() <= 1e-10 * max(1.0, np.abs(g0).max())
+    # a perturbed state as well (the initial one has exact odometry residuals of zero along the chain)
+    q2, t2, s2 = util.initial_state(g, True, perturb=0.01, seed=5)
+    c2 = O.evaluate(q2, t2, s2, want_residuals=False, want_gradient=False)[0]
+    assert abs(P.evaluate(q2, t2, s2)[0] - c2) <= 1e-10 * c2
+    qf, tf, sf, summ = P.solve(q, t, s)
+    assert summ.num_iterations == 3 and summ.num_successful_steps >= 2
+    costs = [summ.iterations[k].cost for k in range(summ.num_logged)]
+    assert all(b <= a for a, b in zip(costs, costs[1:])) and costs[-1] < 0.1 * costs[0]
+    c1 = O.evaluate(qf, tf, sf, want_residuals=False, want_gradient=False)[0]
+    assert abs(c1 - summ.final_cost) <= 1e-10 * max(c1, 1e-12)
+    # the write-back is complete: every keyframe moved off the odometry guess or stayed finite, quaternions unit
+    assert np.isfinite(tf).all() and np.abs(np.linalg.norm(qf.reshape(-1, 4), axis=1) - 1.0).max() <= 1e-12
+    P.close()
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_c5_ranks_on_one_gpu_follow_the_single_rank_trajectory(c5, world):
+    g = c5
+    q, t, s = util.initial_state(g, True)
+    P = util.pgo_problem(g, True, max_num_iterations=2)
+    q1, t1, s1, sum1 = P.solve(q, t, s)
+    P.close()
+    parts = sharding.partition(g, world, "spatial")
+    st = sharding.partition_stats(g, parts)
+    assert 1000 < st["shared_keyframes"] < 0.2 * g.n_poses
+    ar = InProcessAllReduce(world)
+    out, err = [None] * world, []
+
+    def run(rank):
+        try:
+            Pr = capi.problem_from_graph(g, switchable=True, edge_slice=parts[rank], max_num_iterations=2)
+            Pr.comm_init_custom(rank, world, ar.make(rank))
+            out[rank] = Pr.solve(q, t, s)
+            Pr.comm_destroy()
+            Pr.close()
+        except Exception as e:
+            err.append(e)
+            ar.barrier.abort()
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join(timeout=1200)
+    assert not err, err
+    for r in range(world):
+        qr, tr, sr, sumr = out[r]
+        assert sumr.num_iterations == sum1.num_iterations == 2
+        for k in range(sum1.num_logged):
+            a, b = sum1.iterations[k], sumr.iterations[k]
+            assert a.step_is_successful == b.step_is_successful, k
+            assert abs(a.cost - b.cost) <= 1e-6 * a.cost, (k, a.cost, b.cost)
+        assert np.abs(tr - t1).max() <= 1e-4 and np.abs(sr - s1).max() <= 1e-4
+    assert np.array_equal(out[0][1], out[world - 1][1])          # every rank returns the complete, identical solution
