@@ -92,6 +92,11 @@ typedef struct pgo_options {
     /* Early rejection: a rejected LM step only shrinks the trust region, so the PCG pauses at up to two intermediate tolerances, the
      * candidate is evaluated there, and a step whose relative_decrease is already below the stage's threshold (and which would trip
      * neither convergence test) is rejected without paying for the remaining decades; otherwise the SAME PCG resumes. */
+    /* NOT a Ceres rule: with an exact solve Ceres always evaluates the full step.  A step whose relative_decrease at the pause is below the
+     * stage's threshold while the converged step would have cleared min_relative_decrease would be rejected here and accepted by Ceres; the
+     * thresholds are far enough from min_relative_decrease that no such step has been seen (tests/test_gpu_fuzz.py compares the sequences
+     * with the stages on and off over hundreds of graphs), but a caller that wants Ceres' exact decision rule sets both tolerances to 0.
+     * The `relative_decrease`, `cost_change` and `step_norm` logged for an early-rejected step are the values at the pause. */
     double cg_early_tolerance;           /* 1e-2: first stage (0 disables the stage) */
     double cg_early_reject_rho;          /* -0.5: threshold of the first stage — far below min_relative_decrease because the step is still crude */
     double cg_mid_tolerance;             /* 1e-4: second stage (0 disables the stage) */
@@ -267,6 +272,12 @@ int pgo_get_jacobian_blocks(pgo_problem* p, int32_t kind, int64_t first, int64_t
 int pgo_get_normal_blocks(pgo_problem* p, double* diag, double* grad, double* offdiag,
                           double* sw_c, double* sw_hss, double* sw_gs);
 
+/* Parity hook for the manifold step (a4): `ceres::EigenQuaternionParameterization::Plus` (reference src/PoseGraphSLAM.cpp:1276,1352) of n
+ * keyframes on the device, with the same device function the solver's candidate step uses:
+ *   quat_out[i] = [sin|d_i| d_i/|d_i| ; cos|d_i|] (x) quat[i],   t_out[i] = t[i] + dt[i]        (delta: 6 doubles per keyframe, [dtheta, dt])
+ * HOST arrays; t / t_out may be NULL. */
+int pgo_manifold_plus(pgo_problem* p, int64_t n, const double* quat_xyzw, const double* t, const double* delta, double* quat_out, double* t_out);
+
 /* Parity hook for K3: y = (H_reduced + damping) * x on the device, x,y HOST arrays of 6*n_nodes,
  * using the damping of the current trust-region radius.  Valid after pgo_solve_begin. */
 int pgo_apply_normal_operator(pgo_problem* p, const double* x, double* y);
@@ -345,7 +356,10 @@ int pgo_get_relpose_edge_records(const pgo_problem* p, int64_t first, int64_t n,
  * milliseconds per launch and the algorithmic bytes one launch moves (SURVEY.md §8d formula). */
 int pgo_time_linearize_kernel(pgo_problem* p, int32_t launches, double* avg_ms, double* algorithmic_bytes);
 
-/* Same for one PCG iteration (K3+K4) and the assembly (K2). which: 0 = K1, 1 = K2, 2 = one PCG iteration, 3 = K1 cost-only */
+/* Same for one PCG iteration (K3+K4) and the assembly (K2). which: 0 = K1, 1 = K2, 2 = one block-Jacobi PCG iteration (matvec + update),
+ * 3 = K1 cost-only, 4 = the matvec of the iteration alone, 5 = its vector update alone.  algorithmic_bytes of 2/4/5: what THIS design moves
+ * per iteration with every array counted once (matrix-free: compact edge-side records + index data + vectors + the fp32 block-Jacobi
+ * factors; block-CSR: SURVEY.md 8d's assembled form). */
 int pgo_time_kernel(pgo_problem* p, int32_t which, int32_t launches, double* avg_ms, double* algorithmic_bytes);
 
 /* K0 (odometry records from the resident VIO poses, f = 1..f_max over ALL resident poses): HIP-event average per launch and the

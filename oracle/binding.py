@@ -43,7 +43,7 @@ class Options(C.Structure):
     _fields_ = [("max_num_iterations", C.c_int), ("jacobi_scaling", C.c_int), ("max_num_consecutive_invalid_steps", C.c_int),
                 ("initial_trust_region_radius", C.c_double), ("max_trust_region_radius", C.c_double), ("min_trust_region_radius", C.c_double),
                 ("min_relative_decrease", C.c_double), ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
-                ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double), ("verbosity", C.c_int)]
+                ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double), ("verbosity", C.c_int), ("num_threads", C.c_int)]
 
 
 _lib = None

@@ -148,14 +148,18 @@ static double evaluate_cost(const Problem& P, const State& x, double* residuals 
     return 0.5 * cost;
 }
 
-static double linearize(const Problem& P, const State& x, std::vector<Lin>& rel, std::vector<Lin>& swe, std::vector<Lin>& pri) {
+// num_threads > 1: the residual blocks are evaluated by that many OpenMP threads (what Ceres' `num_threads` does for the Jacobian evaluation;
+// the reference leaves it at 1).  Used by bench.py's all-cores baseline only: the summation order of the cost then differs from the serial one.
+static double linearize(const Problem& P, const State& x, std::vector<Lin>& rel, std::vector<Lin>& swe, std::vector<Lin>& pri, int num_threads = 1) {
     rel.resize(P.rel.size()); swe.resize(P.swe.size()); pri.resize(P.pri.size());
     double cost = 0;
+#pragma omp parallel for num_threads(num_threads) reduction(+ : cost) schedule(static) if (num_threads > 1)
     for (size_t k = 0; k < P.rel.size(); ++k) {
         const RelEdge& e = P.rel[k]; Lin& L = rel[k];
         eval_relpose(e, &x.q[4 * e.c1], &x.t[3 * e.c1], &x.q[4 * e.c2], &x.t[3 * e.c2], L.r, nullptr, L.J1, L.J2);
         for (int i = 0; i < 6; ++i) cost += L.r[i] * L.r[i];
     }
+#pragma omp parallel for num_threads(num_threads) reduction(+ : cost) schedule(static) if (num_threads > 1)
     for (size_t k = 0; k < P.swe.size(); ++k) {
         const SwEdge& e = P.swe[k]; Lin& L = swe[k];
         eval_switch(e, &x.q[4 * e.c1], &x.t[3 * e.c1], &x.q[4 * e.c2], &x.t[3 * e.c2], &x.s[e.sw], L.r, nullptr, L.J1, L.J2, L.Js);
@@ -215,6 +219,7 @@ struct Options {
     double gradient_tolerance = 1e-10;
     double parameter_tolerance = 1e-8;
     int verbosity = 0;
+    int num_threads = 1;   // Ceres default, which the reference keeps
 };
 
 struct IterLog {
@@ -375,7 +380,7 @@ static int solve(const Problem& P, const Options& opt, State& x, int N, int S, S
 
     // ---- iteration 0
     double tj = now_s();
-    double x_cost = linearize(P, x, rel, swe, pri);
+    double x_cost = linearize(P, x, rel, swe, pri, opt.num_threads);
     gradient_and_colnorms(P, N, S, rel, swe, pri, node_free, g, cn);
     sum.seconds_jacobian += now_s() - tj;
     if (!std::isfinite(x_cost)) { sum.termination_type = 2; std::snprintf(sum.message, sizeof(sum.message), "initial cost not finite"); return 0; }
@@ -462,7 +467,7 @@ static int solve(const Problem& P, const Options& opt, State& x, int N, int S, S
             // HandleSuccessfulStep
             x = cand; x_cost = cand_cost; x_norm = x_norm_of(x);
             tj = now_s();
-            linearize(P, x, rel, swe, pri);
+            linearize(P, x, rel, swe, pri, opt.num_threads);
             gradient_and_colnorms(P, N, S, rel, swe, pri, node_free, g, cn);
             sum.seconds_jacobian += now_s() - tj;
             gmax = gradient_max_norm_of(x);

@@ -51,7 +51,7 @@ EXPORTS = [
     "pgo_num_relpose_edges", "pgo_num_switchable_edges", "pgo_num_regularizers",
     "pgo_set_vio_poses", "pgo_num_vio_poses", "pgo_add_odometry_edges_from_vio", "pgo_initial_guess_from_vio", "pgo_get_relpose_edge_records",
     "pgo_solve", "pgo_solve_begin", "pgo_lm_step", "pgo_solve_end", "pgo_evaluate",
-    "pgo_get_jacobian_blocks", "pgo_get_normal_blocks", "pgo_apply_normal_operator",
+    "pgo_get_jacobian_blocks", "pgo_get_normal_blocks", "pgo_apply_normal_operator", "pgo_manifold_plus",
     "pgo_comm_get_unique_id", "pgo_comm_init", "pgo_comm_destroy", "pgo_comm_init_custom",
     "pgo_time_linearize_kernel", "pgo_time_kernel", "pgo_time_vio_odometry_kernel", "pgo_dense_spd_inverse", "pgo_device_synchronize", "pgo_strerror", "pgo_last_error",
 ]
@@ -266,6 +266,14 @@ class Problem:
         y = np.zeros_like(x)
         self._check(self.lib.pgo_apply_normal_operator(self.h, _pd(x), _pd(y)))
         return y
+
+    def manifold_plus(self, quat, t, delta):
+        """EigenQuaternionParameterization::Plus of every keyframe on the device (parity hook): returns (quat_out, t_out)"""
+        q = _d(quat).reshape(-1); tt = _d(t).reshape(-1); d = _d(delta).reshape(-1)
+        n = q.size // 4
+        qo = np.zeros_like(q); to = np.zeros_like(tt)
+        self._check(self.lib.pgo_manifold_plus(self.h, C.c_int64(n), _pd(q), _pd(tt), _pd(d), _pd(qo), _pd(to)))
+        return qo.reshape(n, 4), to.reshape(n, 3)
 
     def time_kernel(self, which, launches=20):
         ms = C.c_double(0); by = C.c_double(0)

@@ -180,6 +180,7 @@ void launch_plus(const GraphDev& G, const double* pose8, const double* sw, const
 void launch_state_norms(const GraphDev& G, const LinDev& L, const double* pose8, const double* sw,
                         double* part_xnorm2, double* part_sw_xnorm2, double* part_gmax, int* n_partials, hipStream_t st);
 void launch_reduce(const double* partials, int n, int op /*0 sum,1 max*/, double* out, hipStream_t st);
+void launch_manifold_plus(int64_t n, const double* quat, const double* t, const double* delta, double* quat_out, double* t_out, hipStream_t st);   // parity hook
 void launch_pack_pose(const double* quat, const double* t, double* pose8, int64_t N, hipStream_t st);
 void launch_unpack_pose(const double* pose8, double* quat, double* t, int64_t N, hipStream_t st);
 void launch_unpack_k1(const GraphDev& G, int kind, int64_t first, int64_t count, double* r, double* J1, double* J2, double* Js, hipStream_t st);

@@ -1293,6 +1293,21 @@ __global__ __launch_bounds__(256) void plus_kernel(GraphDev G, const double* __r
     const double b = block_sum(s2sw, red);
     if (threadIdx.x == 0) { part_step2[blockIdx.x] = a; part_sw_step2[blockIdx.x] = b; }
 }
+// parity hook: the manifold step alone on caller-supplied keyframes (reference layout)
+__global__ void manifold_plus_kernel(int64_t n, const double* __restrict__ quat, const double* __restrict__ t, const double* __restrict__ delta,
+                                     double* __restrict__ quat_out, double* __restrict__ t_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double q[4] = {quat[4 * i], quat[4 * i + 1], quat[4 * i + 2], quat[4 * i + 3]}, qn[4];
+    quat_plus(q, delta + 6 * i, qn);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) quat_out[4 * i + k] = qn[k];
+    if (t && t_out) for (int k = 0; k < 3; ++k) t_out[3 * i + k] = t[3 * i + k] + delta[6 * i + 3 + k];
+}
+void launch_manifold_plus(int64_t n, const double* quat, const double* t, const double* delta, double* quat_out, double* t_out, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(manifold_plus_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, quat, t, delta, quat_out, t_out);
+}
+
 static inline int capped_grid(int64_t n, int block) {
     int64_t g = (n + block - 1) / block;
     if (g > MAX_PARTIALS) g = MAX_PARTIALS;

@@ -1555,6 +1555,25 @@ int pgo_get_normal_blocks(pgo_problem* p, double* diag, double* grad, double* of
     return PGO_OK;
 }
 
+int pgo_manifold_plus(pgo_problem* p, int64_t n, const double* quat, const double* t, const double* delta, double* quat_out, double* t_out) {
+    if (!p || n < 0 || (n > 0 && (!quat || !delta || !quat_out))) return PGO_ERR_INVALID_ARG;
+    if (n == 0) return PGO_OK;
+    int rc;
+    if ((rc = set_device(p)) != PGO_OK) return rc;
+    const bool with_t = t != nullptr && t_out != nullptr;
+    ScopedBuf<double> d;
+    HIPCHK(p, d.ensure((size_t)n * 20));
+    double* dq = d.p; double* dd = dq + 4 * n; double* dqo = dd + 6 * n; double* dt = dqo + 4 * n; double* dto = dt + 3 * n;
+    HIPCHK(p, hipMemcpyAsync(dq, quat, (size_t)n * 4 * sizeof(double), hipMemcpyHostToDevice, p->st));
+    HIPCHK(p, hipMemcpyAsync(dd, delta, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice, p->st));
+    if (with_t) HIPCHK(p, hipMemcpyAsync(dt, t, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, p->st));
+    launch_manifold_plus(n, dq, with_t ? dt : nullptr, dd, dqo, with_t ? dto : nullptr, p->st);
+    HIPCHK(p, hipMemcpyAsync(quat_out, dqo, (size_t)n * 4 * sizeof(double), hipMemcpyDeviceToHost, p->st));
+    if (with_t) HIPCHK(p, hipMemcpyAsync(t_out, dto, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, p->st));
+    HIPCHK(p, hipStreamSynchronize(p->st));
+    return PGO_OK;
+}
+
 int pgo_apply_normal_operator(pgo_problem* p, const double* x, double* y) {
     if (!p || !x || !y) return PGO_ERR_INVALID_ARG;
     if (!p->in_solve) { p->err = "pgo_apply_normal_operator needs an open solve (pgo_solve_begin)"; return PGO_ERR_STATE; }
@@ -1640,7 +1659,7 @@ int pgo_time_kernel(pgo_problem* p, int32_t which, int32_t launches, double* avg
     const int nxt = p->cur ^ 1;
     const GraphDev& G = p->G;
     double bytes = 0;
-    if (which == 2) {   // a live PCG state to iterate on (tolerance 0: never converges during the timed launches)
+    if (which == 2 || which == 4 || which == 5) {   // a live PCG state to iterate on (tolerance 0: never converges during the timed launches)
         const pgo_options& o = p->opt;
         if (!p->reuse_diagonal) launch_lm_diag(p->G, p->L, p->Sc, o.min_lm_diagonal, o.max_lm_diagonal, p->st);
         bool ok = true;
@@ -1656,10 +1675,20 @@ int pgo_time_kernel(pgo_problem* p, int32_t which, int32_t launches, double* avg
             switch (which) {
                 case 0: launch_k1(G, p->d_pose[p->cur].p, p->d_swv[p->cur].p, true, part(p, 0), &np, p->st); bytes = k1_algorithmic_bytes(G, true); break;
                 case 1: launch_k2(G, p->L, !p->built_mf, p->st); bytes = (624.0 * G.rel.E + 688.0 * Es) + 288.0 * E + 336.0 * N + 112.0 * Es; break;
-                case 2: { const int kk = rep == 0 ? 0 : i + 1;
-                          if (p->built_mf) { launch_mf_spmv(G, p->F, p->Sc, p->C, kk, 0.0, p->st); launch_cg_update(G, p->C, kk, mf_grid_size(p->F), p->st); }
-                          else { launch_cg_spmv(G, p->C, kk, 0.0, p->st); launch_cg_update(G, p->C, kk, cg_grid_size(G), p->st); } }
-                        bytes = 288.0 * (N + E) + 104.0 * Es + 288.0 * N + 80.0 * (6.0 * N + Es); break;   // SURVEY.md §8d figure for the assembled form
+                case 2: case 4: case 5: {   // one PCG iteration (2), its matvec alone (4), its vector update alone (5)
+                          const int kk = rep == 0 ? 0 : i + 1;
+                          if (which != 5) { if (p->built_mf) launch_mf_spmv(G, p->F, p->Sc, p->C, kk, 0.0, p->st); else launch_cg_spmv(G, p->C, kk, 0.0, p->st); }
+                          if (which != 4) launch_cg_update(G, p->C, kk, p->built_mf ? mf_grid_size(p->F) : cg_grid_size(G), p->st);
+                          // Bytes this design moves per iteration, each array once.  Matrix-free matvec: per edge side the compact record (8 double2
+                          // planes; 11 for switchable sides) + 9 B of index data (+ a_inv for switchable sides); per keyframe z and p_prev read,
+                          // p and q written (4 x 48), damping 48, side ranges / regulariser index / free flag 13.  Update: r, q, p, x read, r, x, z
+                          // written (7 x 48), the fp32 block-Jacobi factor 96.  Block-CSR matvec: SURVEY.md 8d's assembled form.
+                          const double sides_rel = 2.0 * (double)G.rel.E, sides_sw = 2.0 * (double)G.sw.E;
+                          const double mv = p->built_mf ? sides_rel * (128.0 + 9.0) + sides_sw * (176.0 + 9.0 + 8.0) + N * (4.0 * 48.0 + 48.0 + 13.0)
+                                                        : 288.0 * (N + 2.0 * E) + 4.0 * (N + 2.0 * E) + N * 4.0 * 48.0;
+                          const double up = N * (7.0 * 48.0 + 96.0);
+                          bytes = which == 2 ? mv + up : which == 4 ? mv : up;
+                          break; }
                 case 3: launch_k1(G, p->d_pose[nxt].p, p->d_swv[nxt].p, false, part(p, 5), &np, p->st); bytes = k1_algorithmic_bytes(G, false); break;
                 default: (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return PGO_ERR_INVALID_ARG;
             }

@@ -7,7 +7,10 @@ are solved here with scipy's conjugate gradients to a relative residual of 1e-12
 to ~1e-12 — on a matrix assembled in scipy from the ORACLE's Jet-autodiff Jacobian blocks.  The trust-region logic is the Python
 restatement of oracle/pgo_oracle.cpp (Ceres trust_region_minimizer.cc / levenberg_marquardt_strategy.cc).  Nothing of libpgo is used.
 
-Run (about 30-60 min, one core):  python tests/golden/make_c3_trajectory.py [n_iterations]
+Run (about 30-60 min, one core):  python tests/golden/make_c3_trajectory.py [n_iterations] [config] [output name] [preconditioner]
+The optional preconditioner "mg" (an aggregation-multigrid V-cycle in scipy, scripts/research/amg_probe.py) only shortens the CG runs of the
+long trajectories (20 iterations: the trust region grows to 1e6 and block-Jacobi needs ~10^4 iterations per step); the steps are the same
+to the CG tolerance of 1e-12.
 """
 import json
 import os
@@ -45,7 +48,7 @@ def linearize(O, g, q, t, s):
                 J=(J1r, J2r, J1s, J2s, dss, J1p), r=(res[:6 * g.n_odom].reshape(-1, 6), rs, res[6 * g.n_odom + 7 * S:].reshape(-1, 6)))
 
 
-def solve_step(g, L, scale_p, scale_s, diag_p, diag_s, radius):
+def solve_step(g, L, scale_p, scale_s, diag_p, diag_s, radius, precond='bj', t_now=None):
     N, S = g.n_poses, g.n_loops
     lam_p = diag_p / (radius * scale_p ** 2)
     lam_s = diag_s / (radius * scale_s ** 2)
@@ -65,6 +68,11 @@ def solve_step(g, L, scale_p, scale_s, diag_p, diag_s, radius):
     np.add.at(b.reshape(N, 6), g.loop_c1, L['c1'] * (L['gs'] / a)[:, None]); np.add.at(b.reshape(N, 6), g.loop_c2, L['c2'] * (L['gs'] / a)[:, None])
     Di = np.linalg.inv(Hd)
     M = spla.LinearOperator((6 * N, 6 * N), matvec=lambda v: np.einsum('nab,nb->na', Di, v.reshape(N, 6)).ravel())
+    if precond == 'mg':
+        from scripts.research import amg_probe as mg
+        H = mg.Hier(A, t_now, lambda A_, N_, lvl: mg.graph_aggregates(A_, N_, 3 if lvl == 0 else 2), min_coarse=500, verbose=False)
+        cyc = mg.Cycle(H, 'V', ('jac', 0.9), fine_additive=True)
+        M = spla.LinearOperator((6 * N, 6 * N), matvec=lambda v: cyc(v))
     it = [0]
     x, info = spla.cg(A, b, rtol=1e-12, atol=0.0, maxiter=100000, M=M, callback=lambda xk: it.__setitem__(0, it[0] + 1))
     dp = x.reshape(N, 6)
@@ -97,6 +105,8 @@ def plus(q, t, s, dp, ds):
 def main():
     n_iter = int(sys.argv[1]) if len(sys.argv) > 1 else 10
     name = sys.argv[2] if len(sys.argv) > 2 else "C3"
+    out_name = sys.argv[3] if len(sys.argv) > 3 else "%s_ten_iterations.json" % name.lower()
+    precond = sys.argv[4] if len(sys.argv) > 4 else "bj"
     g = graphgen.config(name)
     O = util.oracle_problem(g, True)
     q, t, s = util.initial_state(g, True)
@@ -114,7 +124,7 @@ def main():
             diag_p = np.clip(scale_p ** 2 * np.einsum('naa->na', L['Hd']).reshape(-1), 1e-6, 1e32)
             diag_s = np.clip(scale_s ** 2 * L['hss'], 1e-6, 1e32)
         t0 = time.time()
-        dp, ds, cgit, info = solve_step(g, L, scale_p, scale_s, diag_p, diag_s, radius)
+        dp, ds, cgit, info = solve_step(g, L, scale_p, scale_s, diag_p, diag_s, radius, precond, t)
         mc = model_change(g, L, dp, ds)
         qc, tc, sc = plus(q, t, s, dp, ds)
         cand = O.evaluate(qc, tc, sc, want_residuals=False, want_gradient=False)[0]
@@ -132,10 +142,10 @@ def main():
         rec['cost'] = x_cost
         log.append(rec)
         print('it %2d cost %.12e rho %.3e cg %d (%s) %.0fs' % (it, x_cost, rho, cgit, 'ok' if rec['successful'] else 'REJ', time.time() - t0), flush=True)
-    out = dict(note="generated by tests/golden/make_c3_trajectory.py: oracle Jacobians + scipy CG (rtol 1e-12) + Python restatement of the Ceres LM loop",
+    out = dict(note="generated by tests/golden/make_c3_trajectory.py: oracle Jacobians + scipy CG (rtol 1e-12, preconditioner %s) + Python restatement of the Ceres LM loop" % precond,
                config=name, n_poses=N, n_edges=g.n_odom + g.n_loops, iterations=log, seconds=time.time() - t00,
                final_t_sample=t[::997].tolist(), final_s_sample=s[::997].tolist())
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "%s_ten_iterations.json" % name.lower())
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), out_name)
     with open(path, "w") as f:
         json.dump(out, f)
     print("wrote", path)

@@ -90,3 +90,35 @@ def test_random_graph_matches_oracle(case):
             if const:
                 assert np.array_equal(tp.reshape(-1, 3)[const], t0[const])
         P.close()
+
+
+def test_early_rejection_never_changes_the_accept_reject_sequence():
+    """Two-stage early rejection (pgo.h: cg_early_tolerance / cg_mid_tolerance) is not a Ceres rule, so it must be invisible: over 240 random
+    session-sized graphs with 0-40 % outlier loop closures (the distribution of scripts/gpu_fuzz_soak.py, hundreds of rejected steps) the
+    accept/reject sequence and every accepted iterate's cost are those of the run without the stages, with markedly fewer PCG iterations."""
+    rng = np.random.default_rng(2025)
+    n_graphs, rejected, cg_on, cg_off, fired = 0, 0, 0, 0, 0
+    while n_graphs < 240:
+        n = int(rng.integers(80, 900)); loops = int(rng.integers(5, max(6, n // 3))); f = int(rng.integers(1, 6))
+        out = float(rng.choice([0.0, 0.1, 0.2, 0.4])); seed = int(rng.integers(1, 10 ** 6))
+        g = util.small_graph(n, loops, f=f, seed=seed, outlier_frac=out, min_loop_gap=int(rng.integers(5, 30)))
+        if g.n_loops == 0:
+            continue
+        n_graphs += 1
+        q, t, s = util.initial_state(g, True)
+        res = []
+        for kw in (dict(cg_early_tolerance=0.0, cg_mid_tolerance=0.0), dict()):
+            P = util.pgo_problem(g, True, **kw)
+            res.append(P.solve(q, t, s)[3])
+            P.close()
+        off, on = res
+        seq_off = [off.iterations[i].step_is_successful for i in range(off.num_logged)]
+        seq_on = [on.iterations[i].step_is_successful for i in range(on.num_logged)]
+        assert seq_on == seq_off, (n, loops, f, out, seed, seq_on, seq_off)
+        for i in range(off.num_logged):
+            assert abs(on.iterations[i].cost - off.iterations[i].cost) <= 1e-9 * max(off.iterations[i].cost, 1e-12), (n, loops, f, out, seed, i)
+        rejected += seq_off.count(0)
+        cg_on += on.cg_iterations; cg_off += off.cg_iterations
+        fired += sum(1 for i in range(1, on.num_logged) if not seq_on[i] and on.iterations[i].cg_iterations < off.iterations[i].cg_iterations)
+    assert rejected >= 100 and fired >= 50, (rejected, fired)
+    assert cg_on < cg_off
