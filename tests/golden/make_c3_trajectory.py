@@ -142,12 +142,16 @@ def main():
         rec['cost'] = x_cost
         log.append(rec)
         print('it %2d cost %.12e rho %.3e cg %d (%s) %.0fs' % (it, x_cost, rho, cgit, 'ok' if rec['successful'] else 'REJ', time.time() - t0), flush=True)
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), out_name + '.partial'), "w") as f:   # a long run survives an interruption
+            json.dump(dict(config=name, iterations=log), f)
     out = dict(note="generated by tests/golden/make_c3_trajectory.py: oracle Jacobians + scipy CG (rtol 1e-12, preconditioner %s) + Python restatement of the Ceres LM loop" % precond,
                config=name, n_poses=N, n_edges=g.n_odom + g.n_loops, iterations=log, seconds=time.time() - t00,
                final_t_sample=t[::997].tolist(), final_s_sample=s[::997].tolist())
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), out_name)
     with open(path, "w") as f:
         json.dump(out, f)
+    if os.path.exists(path + '.partial'):
+        os.remove(path + '.partial')
     print("wrote", path)
 
 
