@@ -70,7 +70,7 @@ def load(build=True):
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.build_libpgo() if build else _build.LIBPGO
+    path = os.environ.get("PGO_LIBPGO_OVERRIDE") or (_build.build_libpgo() if build else _build.LIBPGO)   # override: kernel A/B experiments (scripts/) load a variant build
     if not os.path.exists(path):
         raise RuntimeError("libpgo.so is missing (%s): the HIP library must be built; there is no CPU fallback" % path)
     lib = C.CDLL(path)
