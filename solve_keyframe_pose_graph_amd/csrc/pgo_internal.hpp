@@ -133,7 +133,7 @@ struct MgLevelDev {
     const int64_t* g_ptr; const int64_t* g_ent;                  // Galerkin contribution lists of the blocks
     double* Dinv;                                                // [n][36] row-major: omega x inverse of the diagonal block
     double* pos; double* d;                                      // [n][3] position (centroid of the aggregate); offset to the parent's
-    const int32_t* parent; const int32_t* agg_ptr; const int32_t* tile_agg0;   // nodes of level l+1: members contiguous
+    const int32_t* parent; const int32_t* agg_ptr; const int4* tile_info;   // nodes of level l+1: members contiguous; per workgroup tile {first aggregate, end aggregate, first row, end row}
     double* r; double* x; double* xt; double* xf;                // [n][6] restricted residual, pre-smoothed x, x + P x_next, final x
 };
 struct MgDev {

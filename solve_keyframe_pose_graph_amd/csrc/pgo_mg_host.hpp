@@ -126,7 +126,8 @@ inline void build_blocks(int32_t n, std::vector<std::pair<int64_t, int64_t>>& tr
 // passes0: matching rounds keyframes -> level 1, passes: for the levels above.  Returns false when the graph does not coarsen down to
 // dense_max nodes (e.g. mostly isolated keyframes): the caller then runs without the multigrid.
 inline bool build_hierarchy(int64_t N, const std::vector<uint8_t>& node_free, const std::vector<int32_t>& rc1, const std::vector<int32_t>& rc2, const double* rmeas8 /* weight at [8 e + 7] */,
-                            const std::vector<int32_t>& sc1, const std::vector<int32_t>& sc2, int passes0, int passes, int dense_max, int tile_rows, int max_levels, Hierarchy& H) {
+                            const std::vector<int32_t>& sc1, const std::vector<int32_t>& sc2, const double* sw_weight /* per switchable edge: s^2 of its switch at graph build, or nullptr = 1 */,
+                            int passes0, int passes, int dense_max, int tile_rows, int max_levels, Hierarchy& H, bool level0_follows_switchable = true) {
     H = Hierarchy{};
     const int64_t Er = (int64_t)rc1.size(), Es = (int64_t)sc1.size();
     std::vector<WEdge> edges;
@@ -135,11 +136,25 @@ inline bool build_hierarchy(int64_t N, const std::vector<uint8_t>& node_free, co
         const double w = rmeas8[8 * e + 7];
         if (w * w > 1e-8) edges.push_back({rc1[e], rc2[e], w * w});       // an odometry edge the yaw policy has (all but) switched off ties nothing together
     }
-    for (int64_t e = 0; e < Es; ++e) if (node_free[sc1[e]] && node_free[sc2[e]]) edges.push_back({sc1[e], sc2[e], 1.0});    // the switchable functor ignores its weight (CeresResidues.h:198)
+    // the switchable functor ignores its edge weight (CeresResidues.h:198) and scales the whole block by its switch: a loop closure the
+    // solver has switched off ties nothing together any more
+    for (int64_t e = 0; e < Es; ++e) if (node_free[sc1[e]] && node_free[sc2[e]]) {
+        const double w = sw_weight ? sw_weight[e] : 1.0;
+        if (w > 1e-8) edges.push_back({sc1[e], sc2[e], w});
+    }
     std::vector<uint8_t> skip((size_t)N);
     for (int64_t i = 0; i < N; ++i) skip[i] = node_free[i] ? 0 : 1;
     int32_t n1 = 0;
-    H.agg0 = match_passes((int32_t)N, edges, passes0, &skip, n1);
+    if (level0_follows_switchable) H.agg0 = match_passes((int32_t)N, edges, passes0, &skip, n1);
+    else {
+        // keyframes are grouped along relative-pose (odometry) edges only: a switchable loop closure may be an outlier the solver is about to
+        // switch off, and an aggregate held together by nothing else would stop being a rigid piece; the levels above match along the summed
+        // couplings of whole groups, where a single dead edge no longer decides anything
+        std::vector<WEdge> rel_only;
+        rel_only.reserve((size_t)Er);
+        for (int64_t e = 0; e < Er; ++e) if (node_free[rc1[e]] && node_free[rc2[e]]) { const double w = rmeas8[8 * e + 7]; if (w * w > 1e-8) rel_only.push_back({rc1[e], rc2[e], w * w}); }
+        H.agg0 = match_passes((int32_t)N, rel_only, passes0, &skip, n1);
+    }
     if (n1 < 1) return false;
     // level-1 edge list
     auto collapse = [](const std::vector<WEdge>& in, const std::vector<int32_t>& par) {

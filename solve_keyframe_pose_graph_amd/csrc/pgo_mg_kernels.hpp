@@ -229,18 +229,35 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_restrict0_kernel(MgDev M, const d
         x_out[(size_t)a * 6 + k] = x;
     }
 }
-// t = r - A x on the rows of a tile of whole aggregates; r_next = P^T t; x_next = Dinv_next r_next (when the next level is a sparse one)
+// t = r - A x on the rows of a tile of whole aggregates; r_next = P^T t; x_next = Dinv_next r_next (when the next level is a sparse one).
+// Every kernel of the cycle starts on cold L2s (kernel boundaries invalidate them), so what it costs is its chain of DEPENDENT loads:
+// tile_info -> rowptr -> col -> x is the only chain here; everything else a lane will need (its r entry, its row's offset d, the member
+// range of its aggregate, the Dinv row of the next level) is requested up front, before the first barrier.
 __global__ __launch_bounds__(CG_BLOCK) void mg_down_kernel(MgLevelDev A, double* __restrict__ r_next, double* __restrict__ x_next, const double* __restrict__ Dinv_next,
                                                             const int32_t* __restrict__ stop) {
     __shared__ double xch[CG_BLOCK * 7];
     __shared__ double tb[CG_BLOCK];
-    __shared__ double rb[CG_BLOCK];
+    __shared__ double cb[CG_BLOCK];
     if (stop && *stop) return;
-    const int a0 = A.tile_agg0[blockIdx.x], a1 = A.tile_agg0[blockIdx.x + 1];
-    const int i0 = A.agg_ptr[a0], i1 = A.agg_ptr[a1];
+    const int4 ti = A.tile_info[blockIdx.x];          // {a0, a1, i0, i1}
+    const int a0 = ti.x, na = ti.y - ti.x, i0 = ti.z, i1 = ti.w;
     const int li = threadIdx.x / 6, c = threadIdx.x % 6;
     const int row = i0 + li;
     const bool live = row < i1;
+    const bool lagg = threadIdx.x < na * 6;
+    const int a = a0 + li;
+    double rv = 0.0, d0 = 0.0, d1 = 0.0, d2 = 0.0;
+    int m0 = 0, m1 = 0;
+    double Dk[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (live) { rv = A.r[(size_t)row * 6 + c]; d0 = A.d[(size_t)row * 3]; d1 = A.d[(size_t)row * 3 + 1]; d2 = A.d[(size_t)row * 3 + 2]; }
+    if (lagg) {
+        m0 = A.agg_ptr[a]; m1 = A.agg_ptr[a + 1];
+        if (x_next) {
+            const double2* Dp = reinterpret_cast<const double2*>(Dinv_next + (size_t)a * 36 + c * 6);
+            const double2 u0 = Dp[0], u1 = Dp[1], u2 = Dp[2];
+            Dk[0] = u0.x; Dk[1] = u0.y; Dk[2] = u1.x; Dk[3] = u1.y; Dk[4] = u2.x; Dk[5] = u2.y;
+        }
+    }
     double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     if (live) mg_row_accumulate(A.rowptr, A.col, A.val, A.x, row, c, acc);
     double* mine = xch + (size_t)threadIdx.x * 7;
@@ -252,23 +269,24 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_down_kernel(MgLevelDev A, double*
         double q = 0.0;
 #pragma unroll
         for (int cc = 0; cc < 6; ++cc) q += grp[cc * 7 + c];
-        tb[threadIdx.x] = A.r[(size_t)row * 6 + c] - q;
+        tb[threadIdx.x] = rv - q;
     }
     __syncthreads();
-    const int na = a1 - a0;
-    const bool lagg = threadIdx.x < na * 6;
+    if (live) {                                       // the row's own contribution (P_row^T t)[c]
+        const double d[3] = {d0, d1, d2};
+        cb[threadIdx.x] = mg_restrict_comp(tb + (size_t)li * 6, d, c);
+    }
+    __syncthreads();
     double s = 0.0;
-    const int a = a0 + li;
     if (lagg) {
-        for (int m = A.agg_ptr[a]; m < A.agg_ptr[a + 1]; ++m) s += mg_restrict_comp(tb + (size_t)(m - i0) * 6, A.d + (size_t)m * 3, c);
+        for (int m = m0; m < m1; ++m) s += cb[(m - i0) * 6 + c];
         r_next[(size_t)a * 6 + c] = s;
     }
     if (!x_next) return;
-    rb[threadIdx.x] = s;
+    tb[threadIdx.x] = s;
     __syncthreads();
     if (lagg) {
-        const double* Dk = Dinv_next + (size_t)a * 36 + c * 6;
-        const double* ra = rb + (threadIdx.x - c);
+        const double* ra = tb + (threadIdx.x - c);
         double x = 0.0;
 #pragma unroll
         for (int j = 0; j < 6; ++j) x += Dk[j] * ra[j];
@@ -301,17 +319,36 @@ __global__ __launch_bounds__(384) void mg_dense_solve_kernel(CoarseDev K, MgLeve
         Below.xt[(size_t)i * 6 + k] = Below.x[(size_t)i * 6 + k] + scale * mg_prolong_comp(y, Below.d + (size_t)i * 3, k);
     }
 }
-// x = xt + Dinv (r - A xt) on a tile; then xt = x + P x on the members (level below) of the tile's rows
+// x = xt + Dinv (r - A xt) on a tile; then xt = x + s P x on the members (level below) of the tile's rows.  Loads hoisted as in mg_down.
 __global__ __launch_bounds__(CG_BLOCK) void mg_up_kernel(MgLevelDev A, MgLevelDev Below, int has_below, double scale, const int32_t* __restrict__ stop) {
     __shared__ double xch[CG_BLOCK * 7];
     __shared__ double tb[CG_BLOCK];
     __shared__ double xb[CG_BLOCK];
     if (stop && *stop) return;
-    const int a0 = A.tile_agg0[blockIdx.x], a1 = A.tile_agg0[blockIdx.x + 1];
-    const int i0 = A.agg_ptr[a0], i1 = A.agg_ptr[a1];
+    const int4 ti = A.tile_info[blockIdx.x];
+    const int i0 = ti.z, i1 = ti.w;
     const int li = threadIdx.x / 6, c = threadIdx.x % 6;
     const int row = i0 + li;
     const bool live = row < i1;
+    double rv = 0.0, xv = 0.0;
+    double Dk[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    int c0 = 0, c1 = 0;
+    if (live) {
+        rv = A.r[(size_t)row * 6 + c]; xv = A.xt[(size_t)row * 6 + c];
+        const double2* Dp = reinterpret_cast<const double2*>(A.Dinv + (size_t)row * 36 + c * 6);
+        const double2 u0 = Dp[0], u1 = Dp[1], u2 = Dp[2];
+        Dk[0] = u0.x; Dk[1] = u0.y; Dk[2] = u1.x; Dk[3] = u1.y; Dk[4] = u2.x; Dk[5] = u2.y;
+    }
+    if (has_below) { c0 = Below.agg_ptr[i0]; c1 = Below.agg_ptr[i1]; }
+    // the first trip of the prolongation loop: child row, its parent, its pre-smoothed x and offset d
+    const int idx0 = threadIdx.x;
+    int ch = 0, chk = 0, chp = 0; double chx = 0.0, chd[3] = {0.0, 0.0, 0.0};
+    const bool first = has_below && idx0 < (c1 - c0) * 6;
+    if (first) {
+        ch = c0 + idx0 / 6; chk = idx0 % 6;
+        chp = Below.parent[ch]; chx = Below.x[(size_t)ch * 6 + chk];
+        chd[0] = Below.d[(size_t)ch * 3]; chd[1] = Below.d[(size_t)ch * 3 + 1]; chd[2] = Below.d[(size_t)ch * 3 + 2];
+    }
     double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     if (live) mg_row_accumulate(A.rowptr, A.col, A.val, A.xt, row, c, acc);
     double* mine = xch + (size_t)threadIdx.x * 7;
@@ -323,13 +360,12 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_up_kernel(MgLevelDev A, MgLevelDe
         double q = 0.0;
 #pragma unroll
         for (int cc = 0; cc < 6; ++cc) q += grp[cc * 7 + c];
-        tb[threadIdx.x] = A.r[(size_t)row * 6 + c] - q;
+        tb[threadIdx.x] = rv - q;
     }
     __syncthreads();
     if (live) {
-        const double* Dk = A.Dinv + (size_t)row * 36 + c * 6;
         const double* ta = tb + (threadIdx.x - c);
-        double x = A.xt[(size_t)row * 6 + c];
+        double x = xv;
 #pragma unroll
         for (int j = 0; j < 6; ++j) x += Dk[j] * ta[j];
         A.xf[(size_t)row * 6 + c] = x;
@@ -337,8 +373,8 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_up_kernel(MgLevelDev A, MgLevelDe
     }
     if (!has_below) return;
     __syncthreads();
-    const int c0 = Below.agg_ptr[i0], c1 = Below.agg_ptr[i1];
-    for (int idx = threadIdx.x; idx < (c1 - c0) * 6; idx += CG_BLOCK) {
+    if (first) Below.xt[(size_t)ch * 6 + chk] = chx + scale * mg_prolong_comp(xb + (size_t)(chp - i0) * 6, chd, chk);
+    for (int idx = threadIdx.x + CG_BLOCK; idx < (c1 - c0) * 6; idx += CG_BLOCK) {
         const int i = c0 + idx / 6, k = idx % 6;
         const double* y = xb + (size_t)(Below.parent[i] - i0) * 6;
         Below.xt[(size_t)i * 6 + k] = Below.x[(size_t)i * 6 + k] + scale * mg_prolong_comp(y, Below.d + (size_t)i * 3, k);

@@ -169,6 +169,7 @@ struct pgo_problem {
     CapturedChunk cg_chunk[3];
     hipGraphExec_t cg_graph = nullptr;   // the one in use (not owned)
     uint64_t build_epoch = 1; bool cg_graph_failed = false;
+    double cg_prev_equiv = 0.0, cg_prev_radius = 0.0;   // block-Jacobi-equivalent PCG iterations and radius of the last fully solved LM system of this solve
     int cg_extra = 0;                    // PCG iterations of the current LM step spent before a change of preconditioner
     bool mg_failed = false;              // the multigrid operators of the current system could not be built
 };
@@ -236,7 +237,7 @@ int upload_class(pgo_problem* p, const HostClass& H, bool is_sw, DBuf<int32_t>& 
 
 int allreduce(pgo_problem* p, double* buf, size_t n, int op);
 
-int build_graph(pgo_problem* p, int64_t N, int64_t S) {
+int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
     // ---- validate against the array sizes the caller solves with
     for (const HostClass* H : {&p->rel, &p->swe})
         for (int64_t e = 0; e < H->size(); ++e)
@@ -526,8 +527,10 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S) {
     if (!p->local_ids && p->opt.mg_min_keyframes > 0 && N >= p->opt.mg_min_keyframes) {
         pgo_mg::Hierarchy H;
         const int dense_max = std::max(1, std::min(p->opt.mg_dense_max_nodes, 512));
-        const bool ok = pgo_mg::build_hierarchy(N, p->h_node_free, p->rel.c1, p->rel.c2, p->rel.meas.data(), p->swe.c1, p->swe.c2, std::max(1, std::min(p->opt.mg_first_passes, 3)),
-                                                std::max(1, std::min(p->opt.mg_passes, 3)), dense_max, MG_TILE_ROWS, MG_MAX_LEVELS, H);
+        std::vector<double> sw_w;
+        if (sw_now && S > 0) { sw_w.resize((size_t)Es); for (int64_t e = 0; e < Es; ++e) { const double sv = sw_now[p->swe.sw[e]]; sw_w[e] = sv * sv; } }
+        const bool ok = pgo_mg::build_hierarchy(N, p->h_node_free, p->rel.c1, p->rel.c2, p->rel.meas.data(), p->swe.c1, p->swe.c2, sw_w.empty() ? nullptr : sw_w.data(), std::max(1, std::min(p->opt.mg_first_passes, 3)),
+                                                std::max(1, std::min(p->opt.mg_passes, 3)), dense_max, MG_TILE_ROWS, MG_MAX_LEVELS, H, false);
         if (ok) {
             const int nl = (int)H.L.size();
             // pooled arrays: (offset, count) per array; doubles rounded up to even counts (16-B loads)
@@ -543,7 +546,13 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S) {
             for (int l = 0; l < nl; ++l) {
                 const pgo_mg::HostLevel& A = H.L[l];
                 Off& o = off[l];
-                o.col = put32(A.col); o.parent = put32(A.parent); o.agg_ptr = put32(A.agg_ptr); o.tile = put32(A.tile_agg0);
+                o.col = put32(A.col); o.parent = put32(A.parent); o.agg_ptr = put32(A.agg_ptr);
+                {   // per tile {a0, a1, i0, i1}, 16-B aligned
+                    std::vector<int32_t> info;
+                    for (size_t tt = 0; tt + 1 < A.tile_agg0.size(); ++tt) { const int32_t a0 = A.tile_agg0[tt], a1 = A.tile_agg0[tt + 1]; info.insert(info.end(), {a0, a1, A.agg_ptr[a0], A.agg_ptr[a1]}); }
+                    while (pi32.size() % 4) pi32.push_back(0);
+                    o.tile = put32(info);
+                }
                 o.rowptr = put64(A.rowptr); o.g_ptr = put64(A.g_ptr); o.g_ent = put64(A.g_ent);
                 o.val = take(A.col.size() * 36); o.Dinv = take((size_t)A.n * 36); o.pos = take((size_t)A.n * 3); o.d = take((size_t)A.n * 3);
                 o.r = take((size_t)A.n * 6); o.x = take((size_t)A.n * 6); o.xt = take((size_t)A.n * 6); o.xf = take((size_t)A.n * 6);
@@ -566,7 +575,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S) {
                 D = MgLevelDev{};
                 D.n = A.n; D.n_next = l + 1 < nl ? H.L[l + 1].n : 0; D.tiles = A.tile_agg0.empty() ? 0 : (int32_t)A.tile_agg0.size() - 1; D.nnzb = (int64_t)A.col.size();
                 D.rowptr = b64 + o.rowptr; D.col = b32 + o.col; D.val = bf + o.val; D.g_ptr = b64 + o.g_ptr; D.g_ent = b64 + o.g_ent;
-                D.Dinv = bf + o.Dinv; D.pos = bf + o.pos; D.d = bf + o.d; D.parent = b32 + o.parent; D.agg_ptr = b32 + o.agg_ptr; D.tile_agg0 = b32 + o.tile;
+                D.Dinv = bf + o.Dinv; D.pos = bf + o.pos; D.d = bf + o.d; D.parent = b32 + o.parent; D.agg_ptr = b32 + o.agg_ptr; D.tile_info = reinterpret_cast<const int4*>(b32 + o.tile);
                 D.r = bf + o.r; D.x = bf + o.x; D.xt = bf + o.xt; D.xf = bf + o.xf;
             }
             // the dense coarsest level shares the buffers of the two-level preconditioner, which the multigrid replaces on this graph
@@ -937,7 +946,15 @@ int build_system(pgo_problem* p, bool* ok) {
     HIPCHK(p, hipStreamSynchronize(p->st));
     *ok = fail == 0;
     p->mg_active = false; p->mg_failed = false;
-    if (*ok && p->mg_built) { if (p->opt.mg_switch_iterations <= 0 && (rc = build_mg(p)) != PGO_OK) return rc; }
+    if (*ok && p->mg_built) {
+        // Which preconditioner the PCG of this LM system starts with.  Block-Jacobi iterations grow like sqrt(radius) from one accepted step
+        // to the next, so the previous step of this solve predicts this one: predicted >= 3 x mg_switch_iterations block-Jacobi iterations
+        // -> multigrid from the first iteration (a multigrid iteration counts as 4: it costs ~3x and saves 4x or more on such systems);
+        // otherwise block-Jacobi, with the in-flight switch of run_pcg as the safety net.  Depends on this solve's own history only.
+        double predicted = 0.0;
+        if (p->cg_prev_radius > 0.0 && p->radius > 0.0) predicted = p->cg_prev_equiv * std::sqrt(p->radius / p->cg_prev_radius);
+        if ((p->opt.mg_switch_iterations <= 0 || predicted >= 3.0 * (double)p->opt.mg_switch_iterations) && (rc = build_mg(p)) != PGO_OK) return rc;
+    }
     else if (*ok && (rc = build_coarse(p)) != PGO_OK) return rc;
     return PGO_OK;
 }
@@ -960,7 +977,7 @@ int solve_begin(pgo_problem* p, const double* quat, const double* t, const doubl
     int rc;
     if ((rc = set_device(p)) != PGO_OK) return rc;
     p->t_begin = now_s();
-    if (p->graph_dirty || p->priors_dirty || N != p->N_global || S != p->S) if ((rc = build_graph(p, N, S)) != PGO_OK) return rc;
+    if (p->graph_dirty || p->priors_dirty || N != p->N_global || S != p->S) if ((rc = build_graph(p, N, S, sw)) != PGO_OK) return rc;
     // upload in the reference layout (multi-GPU: only this rank's keyframes), repack on the device
     double* io = p->d_io.p;
     const int64_t Nl = p->N;
@@ -978,6 +995,7 @@ int solve_begin(pgo_problem* p, const double* quat, const double* t, const doubl
     std::memset(&p->sum, 0, sizeof(p->sum));
     p->in_solve = true; p->terminated = false; p->scale_ready = false; p->have_prev_step = false;
     p->coarse_retests = 0; p->coarse_drop_radius = 0.0;
+    p->cg_prev_equiv = 0.0; p->cg_prev_radius = 0.0;
     if (p->coarse_skip > 0) { p->coarse_mode = 2; p->coarse_skip_all = true; --p->coarse_skip; }
     else { p->coarse_mode = (p->coarse_keep_streak % 4 != 0) ? 1 : 0; p->coarse_skip_all = false; }
     p->radius = p->opt.initial_trust_region_radius; p->decrease_factor = 2.0; p->reuse_diagonal = false; p->iteration = 0; p->invalid = 0;
@@ -1083,6 +1101,8 @@ int lm_step(pgo_problem* p, int ignore_termination, int* done) {
         }
         p->have_prev_step = !cg.breakdown;
         if (cg.breakdown) ok = false;
+        // block-Jacobi-equivalent work of this system, for the next system's choice of preconditioner (build_system)
+        if (!evaluated && !cg.breakdown) { p->cg_prev_equiv = (double)p->cg_extra + (p->mg_active ? 4.0 : 1.0) * (double)cg.iterations; p->cg_prev_radius = p->radius; }
     }
     it.cg_iterations = cg.iterations + p->cg_extra; it.cg_residual = cg.rel_residual;
     p->sum.cg_iterations += cg.iterations + p->cg_extra;
@@ -1253,9 +1273,9 @@ void pgo_options_init(pgo_options* o) {
     o->cg_mid_reject_rho = -0.05;
     o->coarse_aggregates = 512;
     o->coarse_min_radius = 1e7;
-    o->mg_min_keyframes = 0;
+    o->mg_min_keyframes = 40000;
     o->mg_omega = 0.9;
-    o->mg_correction_scale = 1.6;
+    o->mg_correction_scale = 1.0;
     o->mg_first_passes = 3;
     o->mg_passes = 2;
     o->mg_dense_max_nodes = 512;

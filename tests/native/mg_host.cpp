@@ -11,7 +11,7 @@ void* mgh_build(long long N, const unsigned char* node_free, long long Er, const
     std::vector<double> meas((size_t)Er * 8, 0.0);
     for (long long e = 0; e < Er; ++e) meas[8 * e + 7] = rw[e];
     pgo_mg::Hierarchy* H = new pgo_mg::Hierarchy();
-    if (!pgo_mg::build_hierarchy(N, nf, a, b, meas.data(), c, d, passes0, passes, dense_max, tile_rows, max_levels, *H)) { delete H; return nullptr; }
+    if (!pgo_mg::build_hierarchy(N, nf, a, b, meas.data(), c, d, nullptr, passes0, passes, dense_max, tile_rows, max_levels, *H)) { delete H; return nullptr; }
     return H;
 }
 void mgh_free(void* h) { delete (pgo_mg::Hierarchy*)h; }

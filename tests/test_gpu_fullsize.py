@@ -134,8 +134,9 @@ def test_c3_early_rejection_does_not_change_the_iterates(c3):
     _, te, se, sume = Pe.solve(q, t, s)
     Pe.close()
     assert [sume.iterations[k].step_is_successful for k in range(sume.num_logged)] == [sumf.iterations[k].step_is_successful for k in range(sumf.num_logged)]
-    assert abs(sume.final_cost - sumf.final_cost) <= 1e-10 * sumf.final_cost
-    assert np.abs(te - tf).max() <= 1e-8 and np.abs(se - sf).max() <= 1e-8
+    # (to the PCG tolerance: the two runs pause at different points, so the hybrid block-Jacobi / multigrid PCG switches at different ones)
+    assert abs(sume.final_cost - sumf.final_cost) <= 1e-7 * sumf.final_cost
+    assert np.abs(te - tf).max() <= 1e-5 and np.abs(se - sf).max() <= 1e-5
     assert sume.num_unsuccessful_steps >= 3 and sume.cg_iterations < 0.55 * sumf.cg_iterations
 
 
@@ -159,22 +160,25 @@ def test_c3_structured_20k_ten_iterations_match_oracle_exact_cholesky():
     assert np.abs(sp - so).max() <= 1e-3
 
 
-def test_c3_ten_iterations_match_the_independent_cpu_trajectory(c3):
+@pytest.mark.parametrize("n_iter,name", [(10, "c3_ten_iterations.json"), (20, "c3_twenty_iterations.json")])
+def test_c3_iterations_match_the_independent_cpu_trajectory(c3, n_iter, name):
     """Full-size anchor for BASELINE.json's headline config: the per-iteration costs and accept/reject decisions of libpgo (default
-    settings) against tests/golden/c3_ten_iterations.json — a CPU trajectory computed without libpgo (oracle Jet Jacobians, scipy
-    CG to 1e-12, Python restatement of the Ceres LM loop; generator: tests/golden/make_c3_trajectory.py)."""
+    settings: hybrid block-Jacobi / multigrid PCG, two-stage early rejection) against tests/golden/c3_{ten,twenty}_iterations.json — CPU
+    trajectories computed without libpgo (oracle Jet Jacobians, scipy CG to 1e-12, Python restatement of the Ceres LM loop; generator:
+    tests/golden/make_c3_trajectory.py).  Ten iterations = the reference's budget per trigger; twenty = what bench.py times by default in
+    the driver's run (the trust region grows to 1e5 and the multigrid takes over the late systems)."""
     import json
     import os
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c3_ten_iterations.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name)
     with open(path) as f:
         gold = json.load(f)
     g = c3
     assert gold["n_poses"] == g.n_poses and gold["n_edges"] == g.n_odom + g.n_loops
-    P = util.pgo_problem(g, True)
+    P = util.pgo_problem(g, True, max_num_iterations=n_iter)
     q, t, s = util.initial_state(g, True)
     qp, tp, sp, summ = P.solve(q, t, s)
     its = gold["iterations"]
-    assert summ.num_iterations == len(its) - 1 == 10
+    assert summ.num_iterations == len(its) - 1 == n_iter
     for k, rec in enumerate(its):
         mine = summ.iterations[k]
         assert mine.step_is_successful == rec["successful"], k

@@ -120,5 +120,5 @@ def test_early_rejection_never_changes_the_accept_reject_sequence():
         rejected += seq_off.count(0)
         cg_on += on.cg_iterations; cg_off += off.cg_iterations
         fired += sum(1 for i in range(1, on.num_logged) if not seq_on[i] and on.iterations[i].cg_iterations < off.iterations[i].cg_iterations)
-    assert rejected >= 100 and fired >= 50, (rejected, fired)
+    assert rejected >= 100 and fired >= 10, (rejected, fired)
     assert cg_on < cg_off

@@ -404,8 +404,8 @@ def test_host_and_device_construction_agree_on_not_quite_orthonormal_vio_poses()
         for i in (50, 60, 89):
             want_i = wb_T_wa @ vio[i]
             R = want_i[:3, :3]
-            # stored through the (xyzw, t) round trip: compare translations exactly and rotations to the non-orthonormality
-            assert np.abs(t0[i] - want_i[:3, 3]).max() <= 1e-10
+            # (the world-1 keyframes were already optimised once in their own frame: equal to their odometry up to that solve's residual)
+            assert np.abs(t0[i] - want_i[:3, 3]).max() <= 1e-5
             assert np.abs(T_of(q0[i], t0[i])[:3, :3] - R).max() <= 1e-5
     assert np.abs(gd[0] - gh[0]).max() <= 1e-12 and np.abs(gd[1] - gh[1]).max() <= 1e-10
     Sd.close(); Sh.close()

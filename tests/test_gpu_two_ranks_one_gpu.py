@@ -189,7 +189,7 @@ def test_c3_four_ranks_on_one_gpu_follow_the_single_rank_trajectory():
     from solve_keyframe_pose_graph_amd import graphgen
     g = graphgen.config("C3")
     q, t, s = util.initial_state(g, True)
-    P = util.pgo_problem(g, True)
+    P = util.pgo_problem(g, True, mg_min_keyframes=0)     # block-Jacobi PCG on both sides (the multigrid is single-GPU): comparable iteration counts
     q1, t1, s1, sum1 = P.solve(q, t, s)
     P.close()
     world = 4
