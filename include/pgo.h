@@ -114,14 +114,18 @@ typedef struct pgo_options {
      * to the PCG tolerance.  Single GPU only. */
     int32_t coarse_aggregates;           /* 512 (coarse dimension 3072, 75 MB dense inverse); 0 disables */
     /* Aggregation multigrid for large graphs (single GPU): z = D^-1 r + P V(P^T r) — block-Jacobi on the keyframes plus one V(1,1)
-     * cycle over a hierarchy of rigid aggregates that follow the GRAPH (heavy-edge matching over odometry and loop-closure edges;
-     * 2^mg_first_passes keyframes per level-1 aggregate, 2^mg_passes nodes per aggregate above), block-Jacobi smoothing with damping
-     * mg_omega on every level, every coarse correction scaled by mg_correction_scale (aggregation without prolongation smoothing
-     * under-corrects; the factor keeps the cycle symmetric positive definite), the coarsest level (<= mg_dense_max_nodes) inverted densely.  The operators are the Galerkin products of the
-     * current LM system, rebuilt every LM iteration.  Used instead of the two-level preconditioner above for graphs of at least
-     * mg_min_keyframes keyframes (0 disables); no comparisons, no per-handle history: what runs depends on the system alone.  Like every preconditioner it
-     * changes the iteration count of the PCG, not the solution of a step beyond cg_rel_tolerance. */
-    int32_t mg_min_keyframes;            /* 40000 */
+     * cycle over a hierarchy of rigid aggregates (dtheta_i = dtheta_a, dt_i = dt_a - 2 [d_i]x dtheta_a).  Level 1 groups up to
+     * 2^mg_first_passes keyframes along RELATIVE-POSE (odometry) edges only — a switchable loop closure may be an outlier the solver is about
+     * to switch off, and aggregates held together by such an edge cost 2-3x the iterations once it is off (measured on C3); the levels above
+     * match whole groups along their summed couplings, odometry and loop closures alike (heavy-edge matching, 2^mg_passes nodes per
+     * aggregate).  Block-Jacobi smoothing with damping mg_omega on every level, every coarse correction scaled by mg_correction_scale,
+     * the coarsest level (<= mg_dense_max_nodes) inverted densely.  The operators are the Galerkin products of the current LM system,
+     * rebuilt for every LM system that uses them.  Replaces the two-level preconditioner above on graphs of at least mg_min_keyframes
+     * keyframes (0 disables).  No comparison runs and no per-handle history: what runs depends on the solve alone (mg_switch_iterations).
+     * Like every preconditioner it changes the iteration count of the PCG, not the solution of a step beyond cg_rel_tolerance. */
+    int32_t mg_min_keyframes;            /* 32000: where the two-level preconditioner's aggregates exceed 64 keyframes.  Measured (20 LM steps): 20k keyframes
+                                          *      0.66 -> 0.50 s, 100k (C3) 0.70 -> 0.54 s, 200k (C4) 8.8 -> 4.6 s, 1M (C5, 10 steps) 15.8 -> 10.9 s; a 10k-keyframe
+                                          *      chain with few loops (C2) is better off with the two-level method (0.32 vs 0.42 s) */
     double coarse_min_radius;            /* 1e7 (measured on the 100k-keyframe benchmark graph, 196 keyframes per aggregate: at radius 1e5..1e6 the coarse space saves 1.3x
                                           *      iterations at 2.7x the cost per iteration — and its comparison run doubled the cost of that LM step) */
     double mg_omega;                     /* 0.9 */
@@ -131,7 +135,9 @@ typedef struct pgo_options {
     int32_t mg_dense_max_nodes;          /* 512 (dense coarsest operator of <= 3072 unknowns) */
     int32_t mg_switch_iterations;        /* 400: every PCG starts with plain block-Jacobi (most LM systems — small trust regions, steps about to be
                                           *      rejected — need a few hundred cheap iterations); one that has not converged after this many iterations
-                                          *      is restarted from its current iterate with the multigrid.  0: multigrid from the first iteration. */
+                                          *      is restarted from its current iterate with the multigrid; a system predicted (from the previous LM step of the same
+                                          *      solve, block-Jacobi iterations growing like sqrt(radius)) to need >= 3x this many starts with it.
+                                          *      0: multigrid from the first iteration of every system. */
     /* device selection */
     int32_t device_id;                   /* -1: use the current HIP device */
     int32_t verbosity;                   /* 0 silent (minimizer_progress_to_stdout=false, :1271), 1 per-iteration line on stderr */

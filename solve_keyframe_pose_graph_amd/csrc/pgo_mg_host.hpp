@@ -5,10 +5,12 @@
 // (SPARSE_NORMAL_CHOLESKY, reference src/PoseGraphSLAM.cpp:1270); here the PCG that stands in for that factorisation is
 // preconditioned by  z = D^-1 r + P V(P^T r):  block-Jacobi on the keyframes plus one V(1,1) cycle over a hierarchy of ever coarser
 // "keyframes", each the rigid-body motion of an aggregate of the level below (dtheta_i = dtheta_a, dt_i = dt_a - 2 [d_i]x dtheta_a,
-// d_i = position_i - centroid_a), the coarsest level (<= dense_max nodes) solved densely.  Aggregates follow the GRAPH (odometry and
-// loop-closure edges alike: heavy-edge pairwise matching, `passes` rounds per level -> aggregates of up to 2^passes nodes), because
-// on revisited places loop closures tie keyframes as strongly as odometry does; chain-only aggregates need ~2x the iterations
-// (scripts/research/amg_probe.py).
+// d_i = position_i - centroid_a), the coarsest level (<= dense_max nodes) solved densely.  Aggregates follow the GRAPH by heavy-edge pairwise
+// matching (`passes` rounds per level -> up to 2^passes nodes each).  Level 1 matches keyframes along relative-pose (odometry) edges only:
+// a switchable loop closure can be an outlier that the solver switches off a few LM steps later, and an aggregate held together by nothing
+// else then stops being a rigid piece (measured on C3: 2-3x the PCG iterations from then on).  From level 1 up whole groups are matched
+// along ALL their summed couplings — on revisited places loop closures tie groups as strongly as odometry does, and one dead edge among
+// several no longer decides anything; chain-only aggregates on every level need ~2x the iterations (scripts/research/amg_probe.py).
 #pragma once
 #include <algorithm>
 #include <cmath>

@@ -5,13 +5,13 @@
 
 extern "C" {
 void* mgh_build(long long N, const unsigned char* node_free, long long Er, const int* rc1, const int* rc2, const double* rw, long long Es, const int* sc1, const int* sc2,
-                int passes0, int passes, int dense_max, int tile_rows, int max_levels) {
+                int passes0, int passes, int dense_max, int tile_rows, int max_levels, int level0_follows_switchable) {
     std::vector<uint8_t> nf(node_free, node_free + N);
     std::vector<int32_t> a(rc1, rc1 + Er), b(rc2, rc2 + Er), c(sc1, sc1 + Es), d(sc2, sc2 + Es);
     std::vector<double> meas((size_t)Er * 8, 0.0);
     for (long long e = 0; e < Er; ++e) meas[8 * e + 7] = rw[e];
     pgo_mg::Hierarchy* H = new pgo_mg::Hierarchy();
-    if (!pgo_mg::build_hierarchy(N, nf, a, b, meas.data(), c, d, nullptr, passes0, passes, dense_max, tile_rows, max_levels, *H)) { delete H; return nullptr; }
+    if (!pgo_mg::build_hierarchy(N, nf, a, b, meas.data(), c, d, nullptr, passes0, passes, dense_max, tile_rows, max_levels, *H, level0_follows_switchable != 0)) { delete H; return nullptr; }
     return H;
 }
 void mgh_free(void* h) { delete (pgo_mg::Hierarchy*)h; }

@@ -30,13 +30,13 @@ def I32(x): return np.ascontiguousarray(x, dtype=np.int32)
 def ptr(a, t): return a.ctypes.data_as(C.POINTER(t))
 
 
-def build(lib, g, free=None, passes0=3, passes=2, dense_max=64, tile_rows=32, max_levels=12):
+def build(lib, g, free=None, passes0=3, passes=2, dense_max=64, tile_rows=32, max_levels=12, level0_loops=True):
     N = g.n_poses
     nf = np.ones(N, np.uint8) if free is None else np.ascontiguousarray(free, dtype=np.uint8)
     rc1, rc2, sc1, sc2 = I32(g.odom_c1), I32(g.odom_c2), I32(g.loop_c1), I32(g.loop_c2)
     rw = np.ascontiguousarray(g.odom_w, dtype=np.float64)
     h = lib.mgh_build(C.c_longlong(N), ptr(nf, C.c_ubyte), C.c_longlong(len(rc1)), ptr(rc1, C.c_int), ptr(rc2, C.c_int), ptr(rw, C.c_double), C.c_longlong(len(sc1)), ptr(sc1, C.c_int),
-                      ptr(sc2, C.c_int), passes0, passes, dense_max, tile_rows, max_levels)
+                      ptr(sc2, C.c_int), passes0, passes, dense_max, tile_rows, max_levels, 1 if level0_loops else 0)
     if not h:
         return None
     h = C.c_void_p(h)
@@ -59,7 +59,7 @@ def build(lib, g, free=None, passes0=3, passes=2, dense_max=64, tile_rows=32, ma
     return dict(levels=levels, agg0=agg0, mem0_ptr=mem0_ptr, mem0=mem0)
 
 
-def check(g, H, free, passes0, passes, dense_max):
+def check(g, H, free, passes0, passes, dense_max, level0_loops=True):
     N = g.n_poses
     L = H["levels"]
     agg0 = H["agg0"]
@@ -74,7 +74,7 @@ def check(g, H, free, passes0, passes, dense_max):
         assert len(mem) == sizes[a] and np.all(agg0[mem] == a)
     # aggregates are connected through the graph (matching only ever merges across an edge)
     nbr = [set() for _ in range(N)]
-    for c1, c2 in list(zip(g.odom_c1, g.odom_c2)) + list(zip(g.loop_c1, g.loop_c2)):
+    for c1, c2 in list(zip(g.odom_c1, g.odom_c2)) + (list(zip(g.loop_c1, g.loop_c2)) if level0_loops else []):   # the library's level 1 follows odometry edges only
         nbr[c1].add(c2); nbr[c2].add(c1)
     for a in range(0, n1, max(1, n1 // 200)):
         mem = set(H["mem0"][H["mem0_ptr"][a]:H["mem0_ptr"][a + 1]].tolist())
@@ -135,21 +135,22 @@ def check(g, H, free, passes0, passes, dense_max):
     assert all(L[l + 1]["n"] < L[l]["n"] for l in range(len(L) - 1))
 
 
+@pytest.mark.parametrize("level0_loops", [False, True], ids=["level1_along_odometry", "level1_along_all_edges"])
 @pytest.mark.parametrize("n,loops,f,passes0,passes,dense_max", [(1500, 1500, 2, 3, 2, 64), (4000, 2500, 2, 2, 2, 100), (900, 100, 1, 3, 3, 16), (2500, 2500, 5, 1, 1, 200)])
-def test_hierarchy_invariants(shim, n, loops, f, passes0, passes, dense_max):
+def test_hierarchy_invariants(shim, n, loops, f, passes0, passes, dense_max, level0_loops):
     g = graphgen.generate(n, loops, odom_f_max=f, seed=n)
     free = np.ones(n, np.uint8)
-    H = build(shim, g, free, passes0, passes, dense_max)
+    H = build(shim, g, free, passes0, passes, dense_max, level0_loops=level0_loops)
     assert H is not None and len(H["levels"]) >= 2
-    check(g, H, free, passes0, passes, dense_max)
+    check(g, H, free, passes0, passes, dense_max, level0_loops)
 
 
 def test_fixed_keyframes_stay_outside_and_isolated_graphs_are_refused(shim):
     g = graphgen.generate(1200, 600, odom_f_max=2, seed=4)
     free = np.ones(1200, np.uint8); free[:300] = 0; free[700] = 0
-    H = build(shim, g, free, 3, 2, 64)
+    H = build(shim, g, free, 3, 2, 64, level0_loops=False)
     assert H is not None
-    check(g, H, free, 3, 2, 64)
+    check(g, H, free, 3, 2, 64, False)
     # a "graph" without edges cannot coarsen: the builder says so instead of returning a useless hierarchy
     class E: pass
     e = E(); e.n_poses = 1000
