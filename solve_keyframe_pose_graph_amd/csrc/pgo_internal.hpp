@@ -31,6 +31,7 @@ constexpr int K1_WAVES = 4;        // wavefronts (tiles) per K1 workgroup
 constexpr int WIN_MAX = 72;        // poses per LDS window: 46 KB of LDS per workgroup -> 3 workgroups/CU (measured 34.3 us; 96 poses / 2 per CU: 36.0 us)
 constexpr int WIN_STRIDE = 80;     // bytes per staged pose record (64 B + 16 B pad: conflict-free ds_read_b128)
 constexpr int MAX_PARTIALS = 1024; // grid cap for kernels that emit per-block partial sums
+constexpr int RZ_STRIDE = 2 * MAX_PARTIALS;   // one parity of the r.z partials: the update kernel's slots, then up to MAX_PARTIALS slots of the multigrid's fine prolongation
 constexpr int PRIOR_DOUBLES = 42;  // r6 + J1
 constexpr int MF_BLOCK = 256;      // lanes (edge sides) per workgroup tile of the matrix-free operator (measured per PCG iteration on C3:
                                    // 128 -> 49.2 us, 256 -> 42.8 us, 512 -> 44.4 us, 1024 -> 51.7 us)
@@ -133,7 +134,7 @@ struct MgLevelDev {
     const int64_t* g_ptr; const int64_t* g_ent;                  // Galerkin contribution lists of the blocks
     double* Dinv;                                                // [n][36] row-major: omega x inverse of the diagonal block
     double* pos; double* d;                                      // [n][3] position (centroid of the aggregate); offset to the parent's
-    const int32_t* parent; const int32_t* agg_ptr; const int4* tile_info;   // nodes of level l+1: members contiguous; per workgroup tile {first aggregate, end aggregate, first row, end row}
+    const int32_t* parent; const int32_t* agg_ptr; const int4* tile_info; const int2* tile_rows;   // tile_rows [tile][MG_TILE_ROWS]: block range of each row of the tile (no dependent tile_info -> rowptr load);   // nodes of level l+1: members contiguous; per workgroup tile {first aggregate, end aggregate, first row, end row}
     double* r; double* x; double* xt; double* xf;                // [n][6] restricted residual, pre-smoothed x, x + P x_next, final x
 };
 struct MgDev {
@@ -148,7 +149,9 @@ struct CgDev {
     double* val; float* Lf; double* Dtot; double* b;   // Lf [N][24]: packed fp32 Cholesky factor of the block-Jacobi blocks
     double* x; double* r; double* r2; double* z; double* p; double* p2; double* q;   // r/r2 and p/p2 ping-pong by iteration parity
     double* part_pq;      // [MAX_PARTIALS]
-    double* part_rz;      // [2][MAX_PARTIALS]
+    double* part_rz;      // [2][RZ_STRIDE]
+    int32_t extra_rz;     // r.z partial slots that follow the update kernel's (written by the multigrid's level-1 kernel: the fine prolongation is fused into it)
+    int32_t pad_;
     double* scal;         // [0]=||b||^2_{M^-1} [1]=last r.z [2]=unused [3]=squared relative tolerance
     int32_t* flags;       // [0]=done [1]=breakdown [2]=iterations
 };

@@ -674,7 +674,7 @@ __global__ __launch_bounds__(CG_BLOCK) void cg_spmv_kernel(GraphDev G, CgDev C, 
     double beta = 0.0;
     if (!first) {
         double rz_new, rz_old;
-        block_total2(C.part_rz + parity * MAX_PARTIALS, nparts, C.part_rz + (parity ^ 1) * MAX_PARTIALS, nparts, red, rz_new, rz_old);
+        block_total2(C.part_rz + parity * RZ_STRIDE, nparts + C.extra_rz, C.part_rz + (parity ^ 1) * RZ_STRIDE, nparts + C.extra_rz, red, rz_new, rz_old);
         const bool breakdown = C.flags[1] != 0;
         // convergence on the preconditioned residual norm: every workgroup evaluates the same numbers -> uniform exit
         if (breakdown || !(rz_new > C.scal[3] * C.scal[0])) {
@@ -783,7 +783,7 @@ __global__ __launch_bounds__(CG_BLOCK) void cg_init_kernel(GraphDev G, CgDev C, 
 }
 __global__ void cg_scalars_init_kernel(CgDev C, int nparts, double tol2) {
     __shared__ double red[4];
-    const double rz0 = block_total(C.part_rz, nparts, red);
+    const double rz0 = block_total(C.part_rz, nparts + C.extra_rz, red);
     const double bb = block_total(C.part_pq, nparts, red);
     if (threadIdx.x == 0) {
         C.scal[0] = bb; C.scal[1] = rz0; C.scal[2] = 0.0; C.scal[3] = tol2;
@@ -813,10 +813,10 @@ __global__ __launch_bounds__(CG_BLOCK) void cg_update_kernel(GraphDev G, CgDev C
     double2 r0 = make_double2(0.0, 0.0), q0 = r0, p0 = r0, x0 = r0;
     if (i_first < pairs) { r0 = rin[i_first]; q0 = qv[i_first]; p0 = pcur[i_first]; x0 = xv[i_first]; }
     double pq, rz;   // pq partials are produced by the matvec kernel (its own grid size)
-    block_total2(C.part_pq, nparts_pq, C.part_rz + parity * MAX_PARTIALS, nparts, red, pq, rz);
+    block_total2(C.part_pq, nparts_pq, C.part_rz + parity * RZ_STRIDE, nparts + C.extra_rz, red, pq, rz);
     if (!(pq > 0.0)) {   // breakdown: matrix not positive definite along p (or NaN); x is left untouched, the next spmv raises done
         if (blockIdx.x == 0 && threadIdx.x == 0) C.flags[1] = 1;
-        if (threadIdx.x == 0) C.part_rz[(parity ^ 1) * MAX_PARTIALS + blockIdx.x] = 0.0;
+        if (threadIdx.x == 0) C.part_rz[(parity ^ 1) * RZ_STRIDE + blockIdx.x] = 0.0;
         return;
     }
     const double alpha = rz / pq;
@@ -847,7 +847,7 @@ __global__ __launch_bounds__(CG_BLOCK) void cg_update_kernel(GraphDev G, CgDev C
         }
     }
     const double s = block_sum(acc, red);
-    if (threadIdx.x == 0) C.part_rz[(parity ^ 1) * MAX_PARTIALS + blockIdx.x] = s;
+    if (threadIdx.x == 0) C.part_rz[(parity ^ 1) * RZ_STRIDE + blockIdx.x] = s;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1049,7 +1049,7 @@ __global__ __launch_bounds__(MF_BLOCK) void mf_spmv_kernel(GraphDev G, MfDev F, 
         if (cg_done(C)) return;
         if (!first) {
             double rz_new, rz_old;
-            block_total2(C.part_rz + parity * MAX_PARTIALS, nparts, C.part_rz + (parity ^ 1) * MAX_PARTIALS, nparts, red, rz_new, rz_old);
+            block_total2(C.part_rz + parity * RZ_STRIDE, nparts + C.extra_rz, C.part_rz + (parity ^ 1) * RZ_STRIDE, nparts + C.extra_rz, red, rz_new, rz_old);
             const bool breakdown = C.flags[1] != 0;
             if (breakdown || !(rz_new > C.scal[3] * C.scal[0])) {
                 if (blockIdx.x == 0 && threadIdx.x == 0) { C.flags[0] = 1; if (!breakdown) C.scal[1] = rz_new; }

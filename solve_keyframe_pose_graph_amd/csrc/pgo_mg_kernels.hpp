@@ -14,9 +14,8 @@
 
 __device__ __forceinline__ int bsr_idx(int row, int col) { return (row >> 1) * 12 + col * 2 + (row & 1); }
 
-__device__ __forceinline__ void mg_row_accumulate(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, const double* __restrict__ val,
-                                                  const double* __restrict__ x, int64_t n, int c, double* acc) {
-    const int64_t b = rowptr[n], e = rowptr[n + 1];
+__device__ __forceinline__ void mg_row_accumulate(int64_t b, int64_t e, const int32_t* __restrict__ col, const double* __restrict__ val,
+                                                  const double* __restrict__ x, int c, double* acc) {
     int64_t k = b;
     for (; k + 4 <= e; k += 4) spmv_chunk<4, false>(col + k, val + (size_t)k * 36, c, x, nullptr, 0.0, acc);
     if (k + 2 <= e) { spmv_chunk<2, false>(col + k, val + (size_t)k * 36, c, x, nullptr, 0.0, acc); k += 2; }
@@ -239,9 +238,10 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_down_kernel(MgLevelDev A, double*
     __shared__ double tb[CG_BLOCK];
     __shared__ double cb[CG_BLOCK];
     if (stop && *stop) return;
-    const int4 ti = A.tile_info[blockIdx.x];          // {a0, a1, i0, i1}
-    const int a0 = ti.x, na = ti.y - ti.x, i0 = ti.z, i1 = ti.w;
     const int li = threadIdx.x / 6, c = threadIdx.x % 6;
+    const int4 ti = A.tile_info[blockIdx.x];          // {a0, a1, i0, i1}
+    const int2 rb = A.tile_rows[blockIdx.x * MG_TILE_ROWS + li];   // this lane's row: its block range (independent of tile_info)
+    const int a0 = ti.x, na = ti.y - ti.x, i0 = ti.z, i1 = ti.w;
     const int row = i0 + li;
     const bool live = row < i1;
     const bool lagg = threadIdx.x < na * 6;
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_down_kernel(MgLevelDev A, double*
         }
     }
     double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    if (live) mg_row_accumulate(A.rowptr, A.col, A.val, A.x, row, c, acc);
+    if (live) mg_row_accumulate(rb.x, rb.y, A.col, A.val, A.x, c, acc);
     double* mine = xch + (size_t)threadIdx.x * 7;
 #pragma unroll
     for (int q = 0; q < 6; ++q) mine[q] = acc[q];
@@ -320,14 +320,19 @@ __global__ __launch_bounds__(384) void mg_dense_solve_kernel(CoarseDev K, MgLeve
     }
 }
 // x = xt + Dinv (r - A xt) on a tile; then xt = x + s P x on the members (level below) of the tile's rows.  Loads hoisted as in mg_down.
-__global__ __launch_bounds__(CG_BLOCK) void mg_up_kernel(MgLevelDev A, MgLevelDev Below, int has_below, double scale, const int32_t* __restrict__ stop) {
+// FINE (level 1 only): the prolongation to the KEYFRAMES is done here too — z_i += s P_i x_1[agg0(i)] over the keyframes of the tile's rows
+// (mem0 lists) with this workgroup's share of r.(P x_1) going to its own partial-sum slot after the update kernel's (CgDev::extra_rz).
+template <bool FINE>
+__global__ __launch_bounds__(CG_BLOCK) void mg_up_kernel(MgLevelDev A, MgLevelDev Below, int has_below, double scale, const int32_t* __restrict__ stop,
+                                                          MgDev M, const double* __restrict__ rfine, double* __restrict__ zfine, double* __restrict__ part_extra) {
     __shared__ double xch[CG_BLOCK * 7];
     __shared__ double tb[CG_BLOCK];
     __shared__ double xb[CG_BLOCK];
     if (stop && *stop) return;
-    const int4 ti = A.tile_info[blockIdx.x];
-    const int i0 = ti.z, i1 = ti.w;
     const int li = threadIdx.x / 6, c = threadIdx.x % 6;
+    const int4 ti = A.tile_info[blockIdx.x];
+    const int2 rb = A.tile_rows[blockIdx.x * MG_TILE_ROWS + li];
+    const int i0 = ti.z, i1 = ti.w;
     const int row = i0 + li;
     const bool live = row < i1;
     double rv = 0.0, xv = 0.0;
@@ -349,8 +354,29 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_up_kernel(MgLevelDev A, MgLevelDe
         chp = Below.parent[ch]; chx = Below.x[(size_t)ch * 6 + chk];
         chd[0] = Below.d[(size_t)ch * 3]; chd[1] = Below.d[(size_t)ch * 3 + 1]; chd[2] = Below.d[(size_t)ch * 3 + 2];
     }
+    // FINE: everything the fine prolongation will need is requested now — keyframe, its aggregate's tile-local row, offset d, r and z of up to
+    // four (keyframe, row pair) items per lane (<= 32 rows x 8 keyframes x 3 pairs per tile) — so that this chain runs beside the smoothing's
+    constexpr int FT = FINE ? (MG_TILE_ROWS * 8 * 3 + CG_BLOCK - 1) / CG_BLOCK : 1;
+    int fn[FT], fa[FT]; double fd[FT][3]; double2 fr[FT], fz[FT];
+    int fcnt = 0;
+    if (FINE) {
+        const int e0 = M.mem0_ptr[i0];
+        fcnt = (M.mem0_ptr[i1] - e0) * 3;
+#pragma unroll
+        for (int tt = 0; tt < FT; ++tt) {
+            const int idx = threadIdx.x + tt * CG_BLOCK;
+            fn[tt] = -1;
+            if (idx < fcnt) {
+                const int n = M.mem0[e0 + idx / 3], j = idx % 3;
+                fn[tt] = n * 3 + j; fa[tt] = M.agg0[n] - i0;
+                fd[tt][0] = M.d0[(size_t)n * 3]; fd[tt][1] = M.d0[(size_t)n * 3 + 1]; fd[tt][2] = M.d0[(size_t)n * 3 + 2];
+                fr[tt] = reinterpret_cast<const double2*>(rfine)[(size_t)n * 3 + j];
+                fz[tt] = reinterpret_cast<const double2*>(zfine)[(size_t)n * 3 + j];
+            }
+        }
+    }
     double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    if (live) mg_row_accumulate(A.rowptr, A.col, A.val, A.xt, row, c, acc);
+    if (live) mg_row_accumulate(rb.x, rb.y, A.col, A.val, A.xt, c, acc);
     double* mine = xch + (size_t)threadIdx.x * 7;
 #pragma unroll
     for (int q = 0; q < 6; ++q) mine[q] = acc[q];
@@ -370,6 +396,23 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_up_kernel(MgLevelDev A, MgLevelDe
         for (int j = 0; j < 6; ++j) x += Dk[j] * ta[j];
         A.xf[(size_t)row * 6 + c] = x;
         xb[threadIdx.x] = x;
+    }
+    if (FINE) {
+        __shared__ double red[CG_BLOCK / 64];
+        __syncthreads();
+        double acc2 = 0.0;
+#pragma unroll
+        for (int tt = 0; tt < FT; ++tt) {
+            if (fn[tt] < 0) continue;
+            const int j = fn[tt] % 3;
+            const double* y = xb + (size_t)fa[tt] * 6;
+            const double b0 = scale * mg_prolong_comp(y, fd[tt], 2 * j), b1 = scale * mg_prolong_comp(y, fd[tt], 2 * j + 1);
+            reinterpret_cast<double2*>(zfine)[fn[tt]] = make_double2(fz[tt].x + b0, fz[tt].y + b1);
+            acc2 += fr[tt].x * b0 + fr[tt].y * b1;
+        }
+        const double s2 = block_sum(acc2, red);
+        if (threadIdx.x == 0) part_extra[blockIdx.x] = s2;
+        return;
     }
     if (!has_below) return;
     __syncthreads();
@@ -418,7 +461,11 @@ void launch_mg_apply(const GraphDev& G, const CgDev& C, const MgDev& M, const Mg
         else hipLaunchKernelGGL(mg_down_kernel, dim3((unsigned)A.tiles), dim3(CG_BLOCK), 0, st, A, levels[l].r, levels[l].x, (const double*)levels[l].Dinv, stop);
     }
     hipLaunchKernelGGL(mg_dense_solve_kernel, dim3((unsigned)K.n_agg), dim3(384), 0, st, K, nl >= 2 ? levels[nl - 2] : levels[0], nl >= 2 ? 1 : 0, scale, stop);
-    for (int l = nl - 1; l >= 1; --l)
-        hipLaunchKernelGGL(mg_up_kernel, dim3((unsigned)levels[l - 1].tiles), dim3(CG_BLOCK), 0, st, levels[l - 1], l >= 2 ? levels[l - 2] : levels[0], l >= 2 ? 1 : 0, scale, stop);
-    hipLaunchKernelGGL(mg_prolong0_kernel, dim3(cg_grid(G)), dim3(CG_BLOCK), 0, st, G, M, (const double*)(nl == 1 ? K.yc : levels[0].xf), r, z, part_rz, scale, stop);
+    const bool fused = C.extra_rz > 0;     // level 1's kernel prolongs to the keyframes itself (the solver sets extra_rz = its tile count when that fits the partial-sum slots)
+    const unsigned g0 = (unsigned)cg_grid(G);
+    for (int l = nl - 1; l >= 1; --l) {
+        if (l == 1 && fused) hipLaunchKernelGGL(mg_up_kernel<true>, dim3((unsigned)levels[0].tiles), dim3(CG_BLOCK), 0, st, levels[0], levels[0], 0, scale, stop, M, r, z, part_rz + g0);
+        else hipLaunchKernelGGL(mg_up_kernel<false>, dim3((unsigned)levels[l - 1].tiles), dim3(CG_BLOCK), 0, st, levels[l - 1], l >= 2 ? levels[l - 2] : levels[0], l >= 2 ? 1 : 0, scale, stop, M, r, z, part_rz);
+    }
+    if (!fused) hipLaunchKernelGGL(mg_prolong0_kernel, dim3(g0), dim3(CG_BLOCK), 0, st, G, M, (const double*)(nl == 1 ? K.yc : levels[0].xf), r, z, part_rz, scale, stop);
 }

@@ -453,7 +453,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
     HIPCHK(p, p->d_cgvec.ensure(std::max<int64_t>(N * 42, 1)));
     p->n_part = std::max<int64_t>(MAX_PARTIALS, (G.rel.tiles + G.sw.tiles + 3) / 4 + 1);
     HIPCHK(p, p->d_part.ensure(p->n_part * 6));
-    HIPCHK(p, p->d_cgpart.ensure(MF_MAX_GRID + 2 * MAX_PARTIALS + 16));   // partial sums + 16 PCG scalars (C.scal)
+    HIPCHK(p, p->d_cgpart.ensure(MF_MAX_GRID + 2 * RZ_STRIDE + 16));   // partial sums + 16 PCG scalars (C.scal)
     HIPCHK(p, p->d_flags.ensure(8)); HIPCHK(p, p->d_scal.ensure(S_N));
     for (int k = 0; k < 2; ++k) { HIPCHK(p, p->d_pose[k].ensure(std::max<int64_t>(N * 8, 1))); HIPCHK(p, p->d_swv[k].ensure(std::max<int64_t>(S, 1))); }
     HIPCHK(p, p->d_delta_s.ensure(std::max<int64_t>(Es, 1))); HIPCHK(p, p->d_io.ensure(std::max<int64_t>(N * 7, 1)));
@@ -468,7 +468,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
     C.val = p->d_val.p; C.Lf = p->d_Lf.p; C.Dtot = p->d_Dtot_b.p; C.b = p->d_Dtot_b.p + (size_t)N * 36;
     double* v = p->d_cgvec.p; const size_t n6 = (size_t)N * 6;
     C.x = v; C.r = v + n6; C.r2 = v + 2 * n6; C.z = v + 3 * n6; C.p = v + 4 * n6; C.p2 = v + 5 * n6; C.q = v + 6 * n6;
-    C.part_pq = p->d_cgpart.p; C.part_rz = p->d_cgpart.p + MF_MAX_GRID; C.scal = p->d_cgpart.p + MF_MAX_GRID + 2 * MAX_PARTIALS;
+    C.part_pq = p->d_cgpart.p; C.part_rz = p->d_cgpart.p + MF_MAX_GRID; C.scal = p->d_cgpart.p + MF_MAX_GRID + 2 * RZ_STRIDE; C.extra_rz = 0;
     C.flags = p->d_flags.p;
     // ---- two-level preconditioner: aggregates of consecutive keyframes and, per coarse 6x6 block (a <= b), the ordered list of fine
     // blocks that project onto it (single GPU; enough keyframes per aggregate to be worth it)
@@ -539,7 +539,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
             auto put64 = [&](const std::vector<int64_t>& v) { const size_t o = pi64.size(); pi64.insert(pi64.end(), v.begin(), v.end()); return o; };
             size_t nf64 = 0;
             auto take = [&](size_t cnt) { const size_t o = nf64; nf64 += (cnt + 1) & ~(size_t)1; return o; };
-            struct Off { size_t col, parent, agg_ptr, tile, rowptr, g_ptr, g_ent, val, Dinv, pos, d, r, x, xt, xf; };
+            struct Off { size_t col, parent, agg_ptr, tile, tile_rows, rowptr, g_ptr, g_ent, val, Dinv, pos, d, r, x, xt, xf; };
             std::vector<Off> off((size_t)nl);
             const size_t o_agg0 = put32(H.agg0), o_mem0_ptr = put32(H.mem0_ptr), o_mem0 = put32(H.mem0);
             const size_t o_d0 = take((size_t)N * 3);
@@ -552,6 +552,12 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
                     for (size_t tt = 0; tt + 1 < A.tile_agg0.size(); ++tt) { const int32_t a0 = A.tile_agg0[tt], a1 = A.tile_agg0[tt + 1]; info.insert(info.end(), {a0, a1, A.agg_ptr[a0], A.agg_ptr[a1]}); }
                     while (pi32.size() % 4) pi32.push_back(0);
                     o.tile = put32(info);
+                    std::vector<int32_t> rows;      // [tile][MG_TILE_ROWS] {first block, end block} of each row of the tile
+                    for (size_t tt = 0; tt + 1 < A.tile_agg0.size(); ++tt) {
+                        const int32_t i0 = A.agg_ptr[A.tile_agg0[tt]], i1 = A.agg_ptr[A.tile_agg0[tt + 1]];
+                        for (int li = 0; li < MG_TILE_ROWS; ++li) { const int32_t r = i0 + li; rows.push_back(r < i1 ? (int32_t)A.rowptr[r] : 0); rows.push_back(r < i1 ? (int32_t)A.rowptr[r + 1] : 0); }
+                    }
+                    o.tile_rows = put32(rows);
                 }
                 o.rowptr = put64(A.rowptr); o.g_ptr = put64(A.g_ptr); o.g_ent = put64(A.g_ent);
                 o.val = take(A.col.size() * 36); o.Dinv = take((size_t)A.n * 36); o.pos = take((size_t)A.n * 3); o.d = take((size_t)A.n * 3);
@@ -575,7 +581,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
                 D = MgLevelDev{};
                 D.n = A.n; D.n_next = l + 1 < nl ? H.L[l + 1].n : 0; D.tiles = A.tile_agg0.empty() ? 0 : (int32_t)A.tile_agg0.size() - 1; D.nnzb = (int64_t)A.col.size();
                 D.rowptr = b64 + o.rowptr; D.col = b32 + o.col; D.val = bf + o.val; D.g_ptr = b64 + o.g_ptr; D.g_ent = b64 + o.g_ent;
-                D.Dinv = bf + o.Dinv; D.pos = bf + o.pos; D.d = bf + o.d; D.parent = b32 + o.parent; D.agg_ptr = b32 + o.agg_ptr; D.tile_info = reinterpret_cast<const int4*>(b32 + o.tile);
+                D.Dinv = bf + o.Dinv; D.pos = bf + o.pos; D.d = bf + o.d; D.parent = b32 + o.parent; D.agg_ptr = b32 + o.agg_ptr; D.tile_info = reinterpret_cast<const int4*>(b32 + o.tile); D.tile_rows = reinterpret_cast<const int2*>(b32 + o.tile_rows);
                 D.r = bf + o.r; D.x = bf + o.x; D.xt = bf + o.xt; D.xf = bf + o.xf;
             }
             // the dense coarsest level shares the buffers of the two-level preconditioner, which the multigrid replaces on this graph
@@ -783,9 +789,9 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
         else launch_cg_spmv(p->G, p->C, kk, tol2, p->st);
         launch_cg_update(p->G, p->C, kk, n_pq, p->st);
         // the new residual is in the OTHER r buffer, its r.z partials in the other parity's slots
-        if (p->mg_active) launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, (kk & 1) ? p->C.r : p->C.r2, p->C.z, p->C.part_rz + (size_t)((kk & 1) ^ 1) * MAX_PARTIALS, mg_scale(p), true, p->st);
+        if (p->mg_active) launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, (kk & 1) ? p->C.r : p->C.r2, p->C.z, p->C.part_rz + (size_t)((kk & 1) ^ 1) * RZ_STRIDE, mg_scale(p), true, p->st);
         else if (p->coarse_active)
-            launch_coarse_apply(p->G, p->C, p->K, (kk & 1) ? p->C.r : p->C.r2, p->C.z, p->C.part_rz + (size_t)((kk & 1) ^ 1) * MAX_PARTIALS, true, p->st);
+            launch_coarse_apply(p->G, p->C, p->K, (kk & 1) ? p->C.r : p->C.r2, p->C.z, p->C.part_rz + (size_t)((kk & 1) ^ 1) * RZ_STRIDE, true, p->st);
         return PGO_OK;
     };
     // hipGraph: capture one chunk (iterations 2 .. 2+every-1: no `first` kernel, even start) once per graph build and preconditioner, and replay it
@@ -931,6 +937,8 @@ static int build_mg(pgo_problem* p) {
     HIPCHK(p, hipMemcpyAsync(&h, fail, sizeof(h), hipMemcpyDeviceToHost, p->st));
     HIPCHK(p, hipStreamSynchronize(p->st));
     p->mg_active = h == 0;
+    // level 1's up-sweep kernel also prolongs to the keyframes when its per-workgroup r.z partials fit behind the update kernel's
+    p->C.extra_rz = (p->mg_active && p->M.n_levels >= 2 && p->mg_levels[0].tiles <= MAX_PARTIALS) ? p->mg_levels[0].tiles : 0;
     if (p->opt.verbosity > 0 && h != 0) std::fprintf(stderr, "[pgo] multigrid: a coarse block is not positive definite at radius %.1e -> off for this iteration\n", p->radius);
     return PGO_OK;
 }
@@ -945,7 +953,7 @@ int build_system(pgo_problem* p, bool* ok) {
     HIPCHK(p, hipMemcpyAsync(&fail, p->d_flags.p + 4, sizeof(int32_t), hipMemcpyDeviceToHost, p->st));
     HIPCHK(p, hipStreamSynchronize(p->st));
     *ok = fail == 0;
-    p->mg_active = false; p->mg_failed = false;
+    p->mg_active = false; p->mg_failed = false; p->C.extra_rz = 0;
     if (*ok && p->mg_built) {
         // Which preconditioner the PCG of this LM system starts with.  Block-Jacobi iterations grow like sqrt(radius) from one accepted step
         // to the next, so the previous step of this solve predicts this one: predicted >= 3 x mg_switch_iterations block-Jacobi iterations
