@@ -207,11 +207,14 @@ def main():
     for _ in range(args.warmup):
         P.lm_step(ignore_termination=True)
     P.solve_end()
-    drop_problem(P)
+    fresh = world == 1     # several ranks: ONE handle and ONE communicator for all legs (the multi-rank PCG keeps no history between solves)
+    if fresh:
+        drop_problem(P)
 
     # ---- timed: exactly K LM iterations from the odometry initial guess, state resident in HBM (fresh handle; upload, device graph build and
     # iteration 0 happen in solve_begin, outside the timed region)
-    P = make_problem()
+    if fresh:
+        P = make_problem()
     P.solve_begin(q0, t0_, s0)
     barrier(); sync()
     t_start = time.perf_counter()
@@ -234,10 +237,12 @@ def main():
     qf, tf, sf, summ = P.solve_end()
     P_linear_solver, P_cg_tol, P_cg_max = P.options.linear_solver, P.options.cg_rel_tolerance, P.options.cg_max_iterations
     summ_cg_total = int(summ.cg_iterations)
-    drop_problem(P)
+    if fresh:
+        drop_problem(P)
 
     # ---- the same K iterations once more INCLUDING the host<->device transfers and the write-back; never `value`
-    P = make_problem()       # cold handle: the edge upload and the device graph build of a first solve are part of this figure
+    if fresh:
+        P = make_problem()   # cold handle: the edge upload and the device graph build of a first solve are part of this figure
     barrier(); sync()
     t_incl = time.perf_counter()
     P.solve_begin(q0, t0_, s0)
