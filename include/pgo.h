@@ -86,7 +86,8 @@ typedef struct pgo_options {
     /* PCG controls (no Ceres counterpart: Ceres factorises exactly) */
     int32_t cg_max_iterations;           /* 50000: a safety net, not a budget — a capped PCG is an inexact LM step and leaves the exact-solve path */
     int32_t cg_check_every;              /* 25: host polls the device convergence flag every this many iterations (rounded down to even; 12 while the two-level preconditioner is on) */
-    double cg_rel_tolerance;             /* 1e-9: stop when ||r||_{M^-1} <= tol * ||b||_{M^-1} */
+    double cg_rel_tolerance;             /* 1e-9: stop when ||r||_{M^-1} <= tol * ||b||_{D^-1} (D = block-Jacobi).  The block-Jacobi factors are stored rounded
+                                          *       to fp32 (a preconditioner may be anything symmetric positive definite; the arithmetic applying them is fp64). */
     int32_t cg_warm_start;               /* 1: after a rejected step start the PCG from the previous step (same H, larger damping) */
     int32_t cg_use_graph;                /* 1: replay each `cg_check_every`-iteration chunk of the PCG loop as one hipGraph (single GPU) */
     /* Early rejection: a rejected LM step only shrinks the trust region, so the PCG pauses at up to two intermediate tolerances, the
@@ -160,6 +161,8 @@ typedef struct pgo_iteration {
     double seconds;            /* wall seconds of this iteration (device-synchronised) */
 } pgo_iteration;
 
+/* pgo_summary.iterations[] keeps the first PGO_MAX_ITERATION_LOG records (iteration 0 included); a stepping run that goes on longer
+ * (pgo_lm_step with ignore_termination) still counts every iteration in num_iterations / cg_iterations — compare num_logged. */
 #define PGO_MAX_ITERATION_LOG 256
 
 /* Replaces ceres::Solver::Summary as read at src/PoseGraphSLAM.cpp:1905,1912,1921. */
