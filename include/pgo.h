@@ -124,7 +124,8 @@ typedef struct pgo_options {
      * rebuilt for every LM system that uses them.  Replaces the two-level preconditioner above on graphs of at least mg_min_keyframes
      * keyframes (0 disables).  No comparison runs and no per-handle history: what runs depends on the solve alone (mg_switch_iterations).
      * Like every preconditioner it changes the iteration count of the PCG, not the solution of a step beyond cg_rel_tolerance. */
-    int32_t mg_min_keyframes;            /* 32000: where the two-level preconditioner's aggregates exceed 64 keyframes.  Measured (20 LM steps): 20k keyframes
+    int32_t mg_min_keyframes;            /* 24000.  Measured (20 LM steps) on four graph types at 8k / 15k / 25k keyframes the two-level method wins 3:1 / 3:1 / 1:3
+                                          *      against the multigrid (which costs ~3x per iteration); C3-structured 20k keyframes
                                           *      0.66 -> 0.50 s, 100k (C3) 0.70 -> 0.54 s, 200k (C4) 8.8 -> 4.6 s, 1M (C5, 10 steps) 15.8 -> 10.9 s; a 10k-keyframe
                                           *      chain with few loops (C2) is better off with the two-level method (0.32 vs 0.42 s) */
     double coarse_min_radius;            /* 1e7 (measured on the 100k-keyframe benchmark graph, 196 keyframes per aggregate: at radius 1e5..1e6 the coarse space saves 1.3x

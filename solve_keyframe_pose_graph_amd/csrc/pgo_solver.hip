@@ -1281,7 +1281,7 @@ void pgo_options_init(pgo_options* o) {
     o->cg_mid_reject_rho = -0.05;
     o->coarse_aggregates = 512;
     o->coarse_min_radius = 1e7;
-    o->mg_min_keyframes = 32000;
+    o->mg_min_keyframes = 24000;
     o->mg_omega = 0.9;
     o->mg_correction_scale = 1.0;
     o->mg_first_passes = 3;
