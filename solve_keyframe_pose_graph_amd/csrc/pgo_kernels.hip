@@ -794,7 +794,6 @@ __global__ void cg_scalars_init_kernel(CgDev C, int nparts, double tol2) {
 // alpha = rz/pq ; x += alpha p ; r' = r - alpha q ; z = Minv r' ; partial r'.z -> part_rz[parity^1]
 __global__ __launch_bounds__(CG_BLOCK) void cg_update_kernel(GraphDev G, CgDev C, int parity, int nparts_pq, int nparts) {
     __shared__ double red[2 * (CG_BLOCK / 64)];
-    if (cg_done(C)) return;
     const double2* __restrict__ rin = reinterpret_cast<const double2*>(parity ? C.r2 : C.r);
     double2* __restrict__ rout = reinterpret_cast<double2*>(parity ? C.r : C.r2);
     const double2* __restrict__ pcur = reinterpret_cast<const double2*>(parity ? C.p2 : C.p);
@@ -812,6 +811,7 @@ __global__ __launch_bounds__(CG_BLOCK) void cg_update_kernel(GraphDev G, CgDev C
     const int64_t i_first = (int64_t)blockIdx.x * CG_BLOCK + threadIdx.x;
     double2 r0 = make_double2(0.0, 0.0), q0 = r0, p0 = r0, x0 = r0;
     if (i_first < pairs) { r0 = rin[i_first]; q0 = qv[i_first]; p0 = pcur[i_first]; x0 = xv[i_first]; }
+    if (cg_done(C)) return;     // after the first trip's loads are in flight: the flag's round trip overlaps with theirs
     double pq, rz;   // pq partials are produced by the matvec kernel (its own grid size)
     block_total2(C.part_pq, nparts_pq, C.part_rz + parity * RZ_STRIDE, nparts + C.extra_rz, red, pq, rz);
     if (!(pq > 0.0)) {   // breakdown: matrix not positive definite along p (or NaN); x is left untouched, the next spmv raises done

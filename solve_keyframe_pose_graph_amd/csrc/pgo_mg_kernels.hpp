@@ -14,6 +14,9 @@
 
 __device__ __forceinline__ int bsr_idx(int row, int col) { return (row >> 1) * 12 + col * 2 + (row & 1); }
 
+// One block row times x for the lane owning column c (the block-CSR PCG's row product).  Measured alternatives that changed nothing (a level
+// kernel stays at 8-10 us whatever its size: 40 or 400 workgroups): taking up to 8 blocks at once with every load in flight before the first
+// use (one col -> x round trip per row instead of three: 9.0 -> 9.2 us at 164 VGPRs), testing the stop flag only after the first loads.
 __device__ __forceinline__ void mg_row_accumulate(int64_t b, int64_t e, const int32_t* __restrict__ col, const double* __restrict__ val,
                                                   const double* __restrict__ x, int c, double* acc) {
     int64_t k = b;
@@ -208,12 +211,15 @@ void launch_mg_assemble(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, 
 __global__ __launch_bounds__(CG_BLOCK) void mg_restrict0_kernel(MgDev M, const double* __restrict__ rv, double* __restrict__ r_out, double* __restrict__ x_out,
                                                                  const double* __restrict__ Dinv, const int32_t* __restrict__ stop) {
     __shared__ double rb[CG_BLOCK];
-    if (stop && *stop) return;
+    const int stopped = stop ? *stop : 0;        // requested together with the first data loads, tested when they are needed: no round trip of its own
     const int a = blockIdx.x * MG_TILE_ROWS + threadIdx.x / 6, k = threadIdx.x % 6;
     const bool live = a < M.n1;
+    int m0 = 0, m1 = 0;
+    if (live) { m0 = M.mem0_ptr[a]; m1 = M.mem0_ptr[a + 1]; }
+    if (stopped) return;
     double s = 0.0;
     if (live) {
-        for (int m = M.mem0_ptr[a]; m < M.mem0_ptr[a + 1]; ++m) { const int i = M.mem0[m]; s += mg_restrict_comp(rv + (size_t)i * 6, M.d0 + (size_t)i * 3, k); }
+        for (int m = m0; m < m1; ++m) { const int i = M.mem0[m]; s += mg_restrict_comp(rv + (size_t)i * 6, M.d0 + (size_t)i * 3, k); }
         r_out[(size_t)a * 6 + k] = s;
     }
     if (!x_out) return;
@@ -237,10 +243,11 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_down_kernel(MgLevelDev A, double*
     __shared__ double xch[CG_BLOCK * 7];
     __shared__ double tb[CG_BLOCK];
     __shared__ double cb[CG_BLOCK];
-    if (stop && *stop) return;
+    const int stopped = stop ? *stop : 0;
     const int li = threadIdx.x / 6, c = threadIdx.x % 6;
     const int4 ti = A.tile_info[blockIdx.x];          // {a0, a1, i0, i1}
     const int2 rb = A.tile_rows[blockIdx.x * MG_TILE_ROWS + li];   // this lane's row: its block range (independent of tile_info)
+    if (stopped) return;
     const int a0 = ti.x, na = ti.y - ti.x, i0 = ti.z, i1 = ti.w;
     const int row = i0 + li;
     const bool live = row < i1;
@@ -297,15 +304,17 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_down_kernel(MgLevelDev A, double*
 // the 58 MB of a 2688-wide inverse to 440 wavefronts: 21 us; one per row: 2640 wavefronts) — then x + s P y on the node's members below
 __global__ __launch_bounds__(384) void mg_dense_solve_kernel(CoarseDev K, MgLevelDev Below, int has_below, double scale, const int32_t* __restrict__ stop) {
     __shared__ double ys[6];
-    if (stop && *stop) return;
+    const int stopped = stop ? *stop : 0;
     const int a = blockIdx.x;
     const int q = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const double2* __restrict__ x = reinterpret_cast<const double2*>(K.rc);
     const double2* __restrict__ Ar = reinterpret_cast<const double2*>(K.Ac + (size_t)(a * 6 + q) * K.nc);
     const int n2 = K.nc >> 1;
     double s = 0.0;
+    if (lane < n2) { const double2 u = Ar[lane], v = x[lane]; s = u.x * v.x + u.y * v.y; }      // first trip issued before the flag is needed
+    if (stopped) return;
 #pragma unroll 4
-    for (int j = lane; j < n2; j += 64) { const double2 u = Ar[j], v = x[j]; s += u.x * v.x + u.y * v.y; }
+    for (int j = lane + 64; j < n2; j += 64) { const double2 u = Ar[j], v = x[j]; s += u.x * v.x + u.y * v.y; }
     s = wave_sum(s);
     if (lane == 0) { ys[q] = s; K.yc[a * 6 + q] = s; }
     if (!has_below) return;
@@ -328,10 +337,11 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_up_kernel(MgLevelDev A, MgLevelDe
     __shared__ double xch[CG_BLOCK * 7];
     __shared__ double tb[CG_BLOCK];
     __shared__ double xb[CG_BLOCK];
-    if (stop && *stop) return;
+    const int stopped = stop ? *stop : 0;
     const int li = threadIdx.x / 6, c = threadIdx.x % 6;
     const int4 ti = A.tile_info[blockIdx.x];
     const int2 rb = A.tile_rows[blockIdx.x * MG_TILE_ROWS + li];
+    if (stopped) return;
     const int i0 = ti.z, i1 = ti.w;
     const int row = i0 + li;
     const bool live = row < i1;
