@@ -1285,7 +1285,7 @@ void pgo_options_init(pgo_options* o) {
     o->mg_omega = 0.9;
     o->mg_correction_scale = 1.0;
     o->mg_first_passes = 3;
-    o->mg_passes = 2;
+    o->mg_passes = 3;
     o->mg_dense_max_nodes = 512;
     o->mg_switch_iterations = 400;
     o->cg_rel_tolerance = 1e-9;     // loosest decade that keeps the 10-iteration chi^2 of C3 within 1e-8 of the 1e-13 solve

@@ -40,7 +40,7 @@ def test_oracle_trajectory_with_every_hierarchy_depth(dense_max, first, passes):
 
 
 def test_mid_size_graph_hybrid_start_and_multigrid_from_the_first_iteration():
-    """20k keyframes: levels 20000 -> 2500 -> ~800 -> ~250 (dense).  From the first iteration the multigrid needs ~6x fewer PCG iterations than
+    """20k keyframes: levels 20000 -> 2500 -> ~430 (dense).  From the first iteration the multigrid needs 3-8x fewer PCG iterations than
     block-Jacobi on the hard (large-radius) systems.  The default start is hybrid: block-Jacobi first, the multigrid takes over a system that
     is not solved after mg_switch_iterations, and a system predicted hard from the previous step of the solve starts with it; easy systems
     never build it.  Same LM trajectory either way."""
@@ -54,7 +54,7 @@ def test_mid_size_graph_hybrid_start_and_multigrid_from_the_first_iteration():
     hard = [k for k in range(1, plain.num_logged) if plain.iterations[k].cg_iterations > 1000]
     assert len(hard) >= 3
     for k in hard:
-        assert mg.iterations[k].cg_iterations * 4 < plain.iterations[k].cg_iterations, (k, mg.iterations[k].cg_iterations, plain.iterations[k].cg_iterations)
+        assert mg.iterations[k].cg_iterations * 3 < plain.iterations[k].cg_iterations, (k, mg.iterations[k].cg_iterations, plain.iterations[k].cg_iterations)
         assert hyb.iterations[k].cg_iterations < plain.iterations[k].cg_iterations
     assert 400 <= hyb.iterations[hard[0]].cg_iterations                       # first hard system: switched in flight after 400 block-Jacobi iterations
     assert any(hyb.iterations[k].cg_iterations < 400 for k in hard[1:])       # later ones: predicted hard, multigrid from the first iteration
