@@ -1344,6 +1344,9 @@ int pgo_set_options(pgo_problem* p, const pgo_options* o) {
     if (!p || !o) return PGO_ERR_INVALID_ARG;
     const int dev = p->opt.device_id;
     if (o->linear_solver != p->opt.linear_solver) p->graph_dirty = true;
+    // the preconditioner hierarchies are part of the device graph build
+    if (o->mg_min_keyframes != p->opt.mg_min_keyframes || o->mg_first_passes != p->opt.mg_first_passes || o->mg_passes != p->opt.mg_passes ||
+        o->mg_dense_max_nodes != p->opt.mg_dense_max_nodes || o->coarse_aggregates != p->opt.coarse_aggregates) p->graph_dirty = true;
     p->opt = *o;
     p->opt.device_id = dev;   // the device binding is fixed at create
     return PGO_OK;
