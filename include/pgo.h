@@ -138,7 +138,8 @@ typedef struct pgo_options {
     int32_t mg_switch_iterations;        /* 400: every PCG starts with plain block-Jacobi (most LM systems — small trust regions, steps about to be
                                           *      rejected — need a few hundred cheap iterations); one that has not converged after this many iterations
                                           *      is restarted from its current iterate with the multigrid; a system predicted (from the previous LM step of the same
-                                          *      solve, block-Jacobi iterations growing like sqrt(radius)) to need >= 3x this many starts with it.
+                                          *      solve, block-Jacobi iterations growing like sqrt(radius)) to need >= 2.25x this many starts with it, and one
+                                          *      predicted easier than that switches only after twice its prediction.
                                           *      0: multigrid from the first iteration of every system. */
     /* device selection */
     int32_t device_id;                   /* -1: use the current HIP device */

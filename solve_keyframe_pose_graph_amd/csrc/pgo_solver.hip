@@ -170,6 +170,7 @@ struct pgo_problem {
     hipGraphExec_t cg_graph = nullptr;   // the one in use (not owned)
     uint64_t build_epoch = 1; bool cg_graph_failed = false;
     double cg_prev_equiv = 0.0, cg_prev_radius = 0.0;   // block-Jacobi-equivalent PCG iterations and radius of the last fully solved LM system of this solve
+    int mg_switch_at = 400;              // in-flight switch point of the current LM system (build_system)
     int cg_extra = 0;                    // PCG iterations of the current LM step spent before a change of preconditioner
     bool mg_failed = false;              // the multigrid operators of the current system could not be built
 };
@@ -848,7 +849,7 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
         // Hybrid preconditioning: most LM systems (small trust regions, steps about to be rejected) are solved by block-Jacobi in a few
         // hundred cheap iterations; one that is not done after mg_switch_iterations is a hard one, and from there the multigrid (4x fewer
         // iterations or better at ~3x the price) takes over: operators built now, PCG restarted from the current iterate.
-        if (!done && !multi && p->mg_built && !p->mg_active && !p->mg_failed && k >= p->opt.mg_switch_iterations && k < o.cg_max_iterations) {
+        if (!done && !multi && p->mg_built && !p->mg_active && !p->mg_failed && k >= p->mg_switch_at && k < o.cg_max_iterations) {
             HIPCHK(p, hipMemcpyAsync(hflags, p->C.flags, sizeof(hflags), hipMemcpyDeviceToHost, p->st));
             HIPCHK(p, hipStreamSynchronize(p->st));
             if (hflags[0]) { done = true; (void)enqueue_poll(n_chunks & 1); ++n_chunks; break; }
@@ -956,12 +957,16 @@ int build_system(pgo_problem* p, bool* ok) {
     p->mg_active = false; p->mg_failed = false; p->C.extra_rz = 0;
     if (*ok && p->mg_built) {
         // Which preconditioner the PCG of this LM system starts with.  Block-Jacobi iterations grow like sqrt(radius) from one accepted step
-        // to the next, so the previous step of this solve predicts this one: predicted >= 3 x mg_switch_iterations block-Jacobi iterations
-        // -> multigrid from the first iteration (a multigrid iteration counts as 4: it costs ~3x and saves 4x or more on such systems);
-        // otherwise block-Jacobi, with the in-flight switch of run_pcg as the safety net.  Depends on this solve's own history only.
+        // to the next, so the previous step of this solve predicts this one (a multigrid iteration counts as 4 block-Jacobi ones: it costs
+        // ~2.5x and saves 4x or more on hard systems):  predicted >= 2.25 x mg_switch_iterations -> multigrid from the first iteration;
+        // predicted easier than that -> block-Jacobi, and the in-flight switch of run_pcg waits for twice the prediction (switching 400
+        // iterations into a system that needs 520 throws the work away); no prediction (first step, after a rejected one) -> block-Jacobi with
+        // the switch at mg_switch_iterations.  Depends on this solve's own history only.
         double predicted = 0.0;
         if (p->cg_prev_radius > 0.0 && p->radius > 0.0) predicted = p->cg_prev_equiv * std::sqrt(p->radius / p->cg_prev_radius);
-        if ((p->opt.mg_switch_iterations <= 0 || predicted >= 3.0 * (double)p->opt.mg_switch_iterations) && (rc = build_mg(p)) != PGO_OK) return rc;
+        p->mg_switch_at = p->opt.mg_switch_iterations;
+        if (predicted > 0.0 && predicted < 2.25 * (double)p->opt.mg_switch_iterations) p->mg_switch_at = std::max(p->opt.mg_switch_iterations, (int)(2.0 * predicted));
+        if ((p->opt.mg_switch_iterations <= 0 || predicted >= 2.25 * (double)p->opt.mg_switch_iterations) && (rc = build_mg(p)) != PGO_OK) return rc;
     }
     else if (*ok && (rc = build_coarse(p)) != PGO_OK) return rc;
     return PGO_OK;
