@@ -141,6 +141,12 @@ typedef struct pgo_options {
                                           *      solve, block-Jacobi iterations growing like sqrt(radius)) to need >= 2.25x this many starts with it, and one
                                           *      predicted easier than that switches only after twice its prediction.
                                           *      0: multigrid from the first iteration of every system. */
+    int32_t resident_max_keyframes;      /* 0 (off).  Graphs up to this many keyframes run their plain block-Jacobi PCG as ONE resident kernel per chunk of iterations on
+                                          *      the 32 CUs of one XCD, the two dot products of an iteration being exchanges through that XCD's L2 (1.5-2 us each) instead
+                                          *      of kernel boundaries.  Correct, and measured SLOWER than the two-kernel form (14-16 vs 12 us per iteration at 400-3000
+                                          *      keyframes: the matrix-free operator is compute-bound on 32 CUs, an L2 load that must bypass the CU's L1 costs ~1 us) -
+                                          *      and these graphs need the two-level preconditioner anyway (40x fewer iterations), whose dense solve does not fit one
+                                          *      XCD's L2.  Kept as a measured experiment. */
     /* device selection */
     int32_t device_id;                   /* -1: use the current HIP device */
     int32_t verbosity;                   /* 0 silent (minimizer_progress_to_stdout=false, :1271), 1 per-iteration line on stderr */

@@ -48,7 +48,7 @@ for i in range(n):
         cpu_ms = (time.perf_counter() - t1) * 1e3
         s_prev = np.array([S.get_loopedge_switching_variable_val(e) for e in range(k)])
         rows.append({"keyframes": i + 1, "loop_edges": k, "edges": len(c1), "gpu_ms": gpu_ms, "gpu_lm": sm.num_iterations, "gpu_cg": int(sm.cg_iterations), "cpu_ms": cpu_ms,
-                     "cpu_lm": sumo.num_iterations, "gpu_cost": sm.final_cost, "cpu_cost": sumo.final_cost})
+                     "cpu_lm": sumo.num_iterations, "gpu_solve_ms": sm.seconds_total * 1e3, "gpu_device_ms": sm.seconds_device * 1e3, "gpu_cost": sm.final_cost, "cpu_cost": sumo.final_cost})
         print(json.dumps(rows[-1]), flush=True)
 print(json.dumps({"triggers": len(rows), "gpu_total_ms": sum(r["gpu_ms"] for r in rows), "cpu_total_ms": sum(r["cpu_ms"] for r in rows),
                   "max_rel_cost_diff": max(abs(r["gpu_cost"] - r["cpu_cost"]) / max(r["cpu_cost"], 1e-12) for r in rows)}))

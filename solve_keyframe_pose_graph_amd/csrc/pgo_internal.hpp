@@ -120,6 +120,7 @@ struct CoarseDev {
     const int32_t* blk_ab;        // [n_blk][2] (a, b), a <= b
     const int64_t* contrib;       // (index << 3) | kind : 0 keyframe diagonal block, 1/2 relative-pose edge forward/transposed, 3/4 switchable edge
     const int32_t* agg_free;      // [n_agg] free keyframes in the aggregate (0: identity block)
+    float* Acf;                   // [nc][nc]   the inverse rounded to fp32 (what the per-iteration solves stream: half the bytes; a preconditioner needs no more); null: not kept
 };
 
 // Aggregation multigrid (large graphs): z = D^-1 r + P V(P^T r), V = one V(1,1) cycle (block-Jacobi smoothing) over coarse levels 1..n_sparse
@@ -156,7 +157,17 @@ struct CgDev {
     int32_t* flags;       // [0]=done [1]=breakdown [2]=iterations
 };
 
+// Resident PCG of session-sized graphs (pgo_resident_kernels.hpp): launch bookkeeping and the slot rows of the two per-iteration exchanges.
+constexpr int RES_MAX_PART = 64;                       // participants (workgroups on one XCD) at most
+constexpr unsigned long long RES_EMPTY = ~0ull;        // an empty slot (a NaN pattern no arithmetic produces)
+struct ResDev {
+    uint32_t* ctl;                 // [0] workgroups arrived, [1] participants   (zeroed before every launch)
+    unsigned long long* slots;     // [2 exchanges][2 parities][RES_MAX_PART]    (RES_EMPTY before every launch)
+};
+
 // ---- launchers (pgo_kernels.hip).  All asynchronous on `st`. ----
+// iterations k0 .. k0+len-1 of the matrix-free block-Jacobi PCG in one resident kernel (same entry/exit state as launch_mf_spmv + launch_cg_update)
+void launch_pcg_resident(const GraphDev& G, const MfDev& F, const ScaleDev& Sc, const CgDev& C, const ResDev& R, int k0, int len, hipStream_t st);
 void launch_k1(const GraphDev& G, const double* pose8, const double* sw, bool want_jacobian, double* partials /*[MAX_PARTIALS]*/, int* n_partials, hipStream_t st);
 void launch_prior(const GraphDev& G, const double* pose8, bool want_jacobian, double* partial_cost /*1 double*/, hipStream_t st);
 void launch_k2(const GraphDev& G, const LinDev& L, bool want_offdiag, hipStream_t st);
@@ -198,6 +209,13 @@ void launch_coarse_shift(const CoarseDev& K, double eps, hipStream_t st);   // A
 void launch_coarse_invert(const CoarseDev& K, double* scratch /* 64 nc + 1024 doubles */, int32_t* fail, hipStream_t st);   // Ac -> Ac^-1 (blocked Gauss-Jordan)
 // z += P Ac^-1 P^T r for the vectors of the PCG (r of the given parity), r.z partials updated in place (same workgroup -> slot mapping as cg_update)
 void launch_coarse_apply(const GraphDev& G, const CgDev& C, const CoarseDev& K, const double* r, double* z, double* part_rz, bool inside_iteration, hipStream_t st);
+// the same preconditioner inside the PCG iteration in THREE kernels (matrix-free operator, aggregates of <= 64 keyframes; pgo_kernels.hip):
+int coarse_group_keyframes(const CoarseDev& K);                 // keyframes per workgroup trip of the update kernel (whole aggregates); 0: not available
+int coarse_update_grid(const GraphDev& G, const CoarseDev& K);  // its workgroups = its r.z partial slots
+int coarse_solve_grid(const CoarseDev& K);                      // workgroups of the dense solve = the coarse r.z partial slots that follow them
+void launch_mf_spmv_coarse(const GraphDev& G, const MfDev& F, const ScaleDev& Sc, const CgDev& C, const CoarseDev& K, int k, double tol2, int nparts, int pending, hipStream_t st);
+void launch_cg_update_restrict(const GraphDev& G, const CgDev& C, const CoarseDev& K, int k, int n_pq_partials, hipStream_t st);
+void launch_coarse_solve_dot(const CoarseDev& K, const int32_t* stop, double* part, hipStream_t st);
 // multi-GPU PCG in Chronopoulos-Gear form (one collective per iteration): see pgo_kernels.hip
 void launch_cgcg_dots(const GraphDev& G, const CgDev& C, hipStream_t st);                                     // part_pq[block] = partial of u.w
 void launch_cg_reduce2_live(const CgDev& C, const double* pa, int na, const double* pb, int nb, double* out, hipStream_t st);

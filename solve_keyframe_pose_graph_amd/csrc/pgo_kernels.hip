@@ -1021,9 +1021,23 @@ __global__ __launch_bounds__(256) void mf_compact_kernel(GraphDev G, MfDev F, co
     for (int pl = 0; pl < np; ++pl) F.rec[(size_t)pl * F.ninc_pad + i] = make_double2(rec[2 * pl], rec[2 * pl + 1]);
 }
 
-template <bool FUSED>
+// component r of B_i y_a, the pending coarse correction of keyframe i (dtheta_i = dtheta_a ; dt_i = dt_a - 2 d_i x dtheta_a); 0 for fixed keyframes
+__device__ __forceinline__ double coarse_pending(const CoarseDev& K, const uint8_t* __restrict__ node_free, int64_t node, int r) {
+    // every load is issued unconditionally (no load depends on another one's value): one round trip
+    const double fr = node_free[node] ? 1.0 : 0.0;
+    const double* y = K.yc + (size_t)(node / K.m) * 6;
+    const double* d = K.d + (size_t)node * 3;
+    const int c = r < 3 ? r : r - 3, c1 = c == 2 ? 0 : c + 1, c2 = c == 0 ? 2 : c - 1;
+    const double yr = y[r], ya = y[c1], yb = y[c2], da = d[c1], db = d[c2];
+    return fr * (r < 3 ? yr : yr - 2.0 * (da * yb - db * ya));
+}
+
+// COARSE (two-level preconditioner, fused form): the preconditioned residual is z = z_bj + P y with z_bj in C.z (block-Jacobi part, written by
+// cg_update_restrict_kernel) and y = Ac^-1 P^T r in K.yc (coarse_solve_dot_kernel): the prolongation happens HERE, where z is consumed, instead
+// of in a kernel of its own; `pending` = 0 right after the PCG start, when C.z is already complete.  K.m == 1: z = y alone (direct inverse).
+template <bool FUSED, bool COARSE = false>
 __global__ __launch_bounds__(MF_BLOCK) void mf_spmv_kernel(GraphDev G, MfDev F, ScaleDev Sc, CgDev C, const double* __restrict__ xin, double* __restrict__ yout,
-                                                           int parity, int first, int nparts, double tol2) {
+                                                           int parity, int first, int nparts, double tol2, CoarseDev K = CoarseDev{}, int pending = 0) {
     __shared__ double contrib[MF_BLOCK * 7];
     __shared__ double pwin[MF_BLOCK];
     __shared__ double red[2 * (MF_BLOCK / 64)];
@@ -1042,6 +1056,7 @@ __global__ __launch_bounds__(MF_BLOCK) void mf_spmv_kernel(GraphDev G, MfDev F, 
                 const size_t vi = (size_t)n0 * 6 + l;
                 v0_first = z[vi];
                 if (FUSED) v1_first = pprev[vi];
+                if (COARSE && pending) { const double cp = coarse_pending(K, G.node_free, (int64_t)n0 + l / 6, l % 6); v0_first = K.m == 1 ? cp : v0_first + cp; }
             }
         }
     }
@@ -1072,7 +1087,15 @@ __global__ __launch_bounds__(MF_BLOCK) void mf_spmv_kernel(GraphDev G, MfDev F, 
         // and odometry neighbours are inside the same window): only far endpoints of loop closures gather from global memory
         if (l < nn * 6) {
             double v;
-            if (tile == (int)blockIdx.x) v = FUSED ? v0_first + beta * v1_first : v0_first;
+            if (COARSE) {
+                const size_t vi = (size_t)n0 * 6 + l;
+                double zf = v0_first;
+                if (tile != (int)blockIdx.x) {
+                    zf = z[vi];
+                    if (pending) { const double cp = coarse_pending(K, G.node_free, (int64_t)n0 + l / 6, l % 6); zf = K.m == 1 ? cp : zf + cp; }
+                }
+                v = zf + beta * (tile == (int)blockIdx.x ? v1_first : pprev[vi]);
+            } else if (tile == (int)blockIdx.x) v = FUSED ? v0_first + beta * v1_first : v0_first;
             else {
                 const size_t vi = (size_t)n0 * 6 + l;
                 v = z[vi];
@@ -1113,6 +1136,22 @@ __global__ __launch_bounds__(MF_BLOCK) void mf_spmv_kernel(GraphDev G, MfDev F, 
                 const double2* b = reinterpret_cast<const double2*>(z + (size_t)other * 6);
                 const double2 b0 = b[0], b1 = b[1], b2 = b[2];
                 pt[0] = b0.x; pt[1] = b0.y; pt[2] = b1.x; pt[3] = b1.y; pt[4] = b2.x; pt[5] = b2.y;
+                if (COARSE && pending) {
+                    if (K.m == 1) {
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) pt[c] = 0.0;
+                    }
+                    {   // unconditional loads (a fixed keyframe's correction is multiplied by 0): nothing here waits for another load
+                        const double fr = G.node_free[other] ? 1.0 : 0.0;
+                        const double* yy = K.yc + (size_t)(other / K.m) * 6;
+                        const double* dd = K.d + (size_t)other * 3;
+                        const double y0 = yy[0], y1 = yy[1], y2 = yy[2], y3 = yy[3], y4 = yy[4], y5 = yy[5], d0 = dd[0], d1 = dd[1], d2 = dd[2];
+                        pt[0] += fr * y0; pt[1] += fr * y1; pt[2] += fr * y2;
+                        pt[3] += fr * (y3 - 2.0 * (d1 * y2 - d2 * y1));
+                        pt[4] += fr * (y4 - 2.0 * (d2 * y0 - d0 * y2));
+                        pt[5] += fr * (y5 - 2.0 * (d0 * y1 - d1 * y0));
+                    }
+                }
                 if (FUSED) {
                     const double2* c = reinterpret_cast<const double2*>(pprev + (size_t)other * 6);
                     const double2 c0 = c[0], c1 = c[1], c2 = c[2];
@@ -1165,10 +1204,14 @@ void launch_mf_compact(const GraphDev& G, const MfDev& F, const double* pose8, c
 void launch_mf_spmv(const GraphDev& G, const MfDev& F, const ScaleDev& Sc, const CgDev& C, int k, double tol2, hipStream_t st) {
     const int g = mf_grid(F);
     // the partial-sum count consumed here is the one cg_init / cg_update produced (cg_grid); the one produced is mf_grid
-    hipLaunchKernelGGL(mf_spmv_kernel<true>, dim3(g), dim3(MF_BLOCK), 0, st, G, F, Sc, C, (const double*)nullptr, (double*)nullptr, k & 1, k == 0 ? 1 : 0, cg_grid(G), tol2);
+    hipLaunchKernelGGL((mf_spmv_kernel<true, false>), dim3(g), dim3(MF_BLOCK), 0, st, G, F, Sc, C, (const double*)nullptr, (double*)nullptr, k & 1, k == 0 ? 1 : 0, cg_grid(G), tol2);
+}
+// two-level preconditioner, fused form (3 kernels per iteration): nparts = r.z partial slots of the update kernel (coarse_update_grid)
+void launch_mf_spmv_coarse(const GraphDev& G, const MfDev& F, const ScaleDev& Sc, const CgDev& C, const CoarseDev& K, int k, double tol2, int nparts, int pending, hipStream_t st) {
+    hipLaunchKernelGGL((mf_spmv_kernel<true, true>), dim3(mf_grid(F)), dim3(MF_BLOCK), 0, st, G, F, Sc, C, (const double*)nullptr, (double*)nullptr, k & 1, k == 0 ? 1 : 0, nparts, tol2, K, pending);
 }
 void launch_mf_apply(const GraphDev& G, const MfDev& F, const ScaleDev& Sc, const CgDev& C, const double* x, double* y, hipStream_t st) {
-    hipLaunchKernelGGL(mf_spmv_kernel<false>, dim3(mf_grid(F)), dim3(MF_BLOCK), 0, st, G, F, Sc, C, x, y, 0, 1, 0, 0.0);
+    hipLaunchKernelGGL((mf_spmv_kernel<false, false>), dim3(mf_grid(F)), dim3(MF_BLOCK), 0, st, G, F, Sc, C, x, y, 0, 1, 0, 0.0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1632,7 +1675,19 @@ __global__ void coarse_symmetrize_kernel(CoarseDev K) {
     const int64_t n = K.nc;
     if (t >= n * n) return;
     const int64_t i = t / n, j = t - i * n;           // column-major element (i, j) lives at Ac[i + j n]
-    if (i < j) K.Ac[i + j * n] = K.Ac[j + i * n];     // upper <- lower
+    const double v = i < j ? K.Ac[j + i * n] : K.Ac[i + j * n];
+    if (i < j) K.Ac[i + j * n] = v;                   // upper <- lower
+    if (K.Acf) K.Acf[i + j * n] = (float)v;           // both mirror images round the same fp64 value: the fp32 copy is exactly symmetric too
+}
+// one row of the fp32 inverse times the fp64 vector, lanes of one wavefront striding over it (n a multiple of 64: rows are 16-B aligned)
+__device__ __forceinline__ double dense_row_dot(const float* __restrict__ Arow, const double* __restrict__ x, int n, int lane) {
+    const float4* __restrict__ A4 = reinterpret_cast<const float4*>(Arow);
+    const double2* __restrict__ x2 = reinterpret_cast<const double2*>(x);
+    double s = 0.0;
+    const int n4 = n >> 2;
+#pragma unroll 4
+    for (int j = lane; j < n4; j += 64) { const float4 a = A4[j]; const double2 u = x2[2 * j], v = x2[2 * j + 1]; s += (double)a.x * u.x + (double)a.y * u.y + (double)a.z * v.x + (double)a.w * v.y; }
+    return s;
 }
 void launch_coarse_symmetrize(const CoarseDev& K, hipStream_t st) {
     const int64_t n2 = (int64_t)K.nc * K.nc;
@@ -1669,13 +1724,7 @@ __global__ __launch_bounds__(256) void coarse_solve_kernel(CoarseDev K, const in
     const int row = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= K.nc) return;
-    const double2* __restrict__ A = reinterpret_cast<const double2*>(K.Ac + (size_t)row * K.nc);    // nc is a multiple of 64: rows are 16-B aligned
-    const double2* __restrict__ x = reinterpret_cast<const double2*>(K.rc);
-    double s = 0.0;
-    const int n2 = K.nc >> 1;
-#pragma unroll 4
-    for (int j = lane; j < n2; j += 64) { const double2 a = A[j], b = x[j]; s += a.x * b.x + a.y * b.y; }
-    s = wave_sum(s);
+    const double s = wave_sum(dense_row_dot(K.Acf + (size_t)row * K.nc, K.rc, K.nc, lane));
     if (lane == 0) K.yc[row] = s;
 }
 // z_i += B_i y_a  (dtheta_i = dtheta_a ; dt_i = dt_a - 2 d_i x dtheta_a) and r.z += r.(P y): the cg_update lane / workgroup mapping, so
@@ -1705,6 +1754,132 @@ __global__ __launch_bounds__(CG_BLOCK) void coarse_prolong_kernel(GraphDev G, Co
     }
     const double s = block_sum(acc, red);
     if (threadIdx.x == 0) { if (direct) part_rz[blockIdx.x] = s; else part_rz[blockIdx.x] += s; }
+}
+// ---- fused form of the two-level iteration (matrix-free operator, aggregates of <= 64 keyframes): THREE kernels instead of five ----
+//   mf_spmv_kernel<true, true>    prolongs the pending coarse correction while it forms p (above)
+//   cg_update_restrict_kernel     cg_update_kernel + rc = P^T r' : a workgroup trip covers `kft` keyframes = WHOLE aggregates (kft = (64 / m) m)
+//   coarse_solve_dot_kernel       y = Ac^-1 rc and the partial sums of rc.y = r'.(P y), the coarse part of r.z, behind the update kernel's partials
+__global__ __launch_bounds__(CG_BLOCK) void cg_update_restrict_kernel(GraphDev G, CgDev C, CoarseDev K, int parity, int nparts_pq, int nparts, int kft) {
+    __shared__ double red[2 * (CG_BLOCK / 64)];
+    const double2* __restrict__ rin = reinterpret_cast<const double2*>(parity ? C.r2 : C.r);
+    double2* __restrict__ rout = reinterpret_cast<double2*>(parity ? C.r : C.r2);
+    const double2* __restrict__ pcur = reinterpret_cast<const double2*>(parity ? C.p2 : C.p);
+    const double2* __restrict__ qv = reinterpret_cast<const double2*>(C.q);
+    double2* __restrict__ xv = reinterpret_cast<double2*>(C.x);
+    double2* __restrict__ zv = reinterpret_cast<double2*>(C.z);
+    const int t = threadIdx.x;
+    const int64_t groups = (G.N + kft - 1) / kft;
+    const int64_t kf_first = (int64_t)blockIdx.x * kft + t / 3;
+    const bool live_first = t < kft * 3 && kf_first < G.N;
+    const int64_t i_first = (int64_t)blockIdx.x * kft * 3 + t;
+    double2 r0 = make_double2(0.0, 0.0), q0 = r0, p0 = r0, x0 = r0;
+    double d0 = 0.0, d1 = 0.0, d2 = 0.0, fr = 0.0;      // the lane's keyframe: offset from its aggregate's centroid, free flag
+    if (live_first) {
+        r0 = rin[i_first]; q0 = qv[i_first]; p0 = pcur[i_first]; x0 = xv[i_first];
+        const double* d = K.d + (size_t)kf_first * 3; d0 = d[0]; d1 = d[1]; d2 = d[2]; fr = G.node_free[kf_first] ? 1.0 : 0.0;
+    }
+    if (cg_done(C)) return;
+    double pq, rz;
+    block_total2(C.part_pq, nparts_pq, C.part_rz + parity * RZ_STRIDE, nparts + C.extra_rz, red, pq, rz);
+    if (!(pq > 0.0)) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) C.flags[1] = 1;
+        if (threadIdx.x == 0) C.part_rz[(parity ^ 1) * RZ_STRIDE + blockIdx.x] = 0.0;
+        return;
+    }
+    const double alpha = rz / pq;
+    const bool direct = K.m == 1;
+    __shared__ double2 btr[CG_BLOCK];       // B_i^T r'_i, row pair j of keyframe t / 3 at [t]
+    __shared__ double2 rnew[CG_BLOCK];
+    __shared__ __attribute__((aligned(16))) float lfs[(CG_BLOCK / 3) * LF_STRIDE];
+    double acc = 0.0;
+    for (int64_t g = blockIdx.x; g < groups; g += gridDim.x) {
+        const int64_t base = g * kft;                       // first keyframe of the group: a multiple of m
+        const int64_t i = base * 3 + t;
+        const bool live = t < kft * 3 && base + t / 3 < G.N;
+        double2 rr = make_double2(0.0, 0.0);
+        if (live) {
+            if (g != (int64_t)blockIdx.x) {
+                r0 = rin[i]; q0 = qv[i]; p0 = pcur[i]; x0 = xv[i];
+                const double* d = K.d + (size_t)(base + t / 3) * 3; d0 = d[0]; d1 = d[1]; d2 = d[2]; fr = G.node_free[base + t / 3] ? 1.0 : 0.0;
+            }
+            rr = make_double2(r0.x - alpha * q0.x, r0.y - alpha * q0.y);
+            x0.x += alpha * p0.x; x0.y += alpha * p0.y;
+            rout[i] = rr; xv[i] = x0;
+        }
+        __syncthreads();
+        for (int f4 = t; f4 < kft * 6; f4 += CG_BLOCK) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (base + f4 / 6 < G.N) v = reinterpret_cast<const float4*>(C.Lf + (size_t)base * LF_STRIDE)[f4];
+            reinterpret_cast<float4*>(lfs)[f4] = v;
+        }
+        rnew[t] = rr;
+        __syncthreads();
+        if (live) {
+            const int j = t % 3;
+            const double2 z = lf_apply_pair(lfs + (t / 3) * LF_STRIDE, reinterpret_cast<const double*>(rnew + (t - j)), j);
+            zv[i] = z;
+            if (!direct) acc += rr.x * z.x + rr.y * z.y;
+        }
+        // rc = P^T r' for the aggregates of this group: B_i^T r'_i = [r_theta + 2 d_i x r_t ; r_t] per keyframe (its three lanes, operands from LDS),
+        // then a fixed-order sum over each aggregate's keyframes (deterministic)
+        {
+            double2 b = make_double2(0.0, 0.0);
+            if (live) {
+                const int j = t % 3;
+                const double* r6 = reinterpret_cast<const double*>(rnew + (t - j));
+                if (j == 0) b = make_double2(r6[0] + 2.0 * (d1 * r6[5] - d2 * r6[4]), r6[1] + 2.0 * (d2 * r6[3] - d0 * r6[5]));
+                else if (j == 1) b = make_double2(r6[2] + 2.0 * (d0 * r6[4] - d1 * r6[3]), r6[3]);
+                else b = make_double2(r6[4], r6[5]);
+                b.x *= fr; b.y *= fr;
+            }
+            btr[t] = b;
+        }
+        __syncthreads();
+        const int64_t left = G.N - base < kft ? G.N - base : kft;
+        const int n_ag = (int)((left + K.m - 1) / K.m);
+        for (int u = t; u < n_ag * 6; u += CG_BLOCK) {
+            const int la = u / 6, c = u - la * 6;
+            const double* col = reinterpret_cast<const double*>(btr) + (size_t)la * K.m * 6 + c;
+            const int cnt = (int)(left - (int64_t)la * K.m < K.m ? left - (int64_t)la * K.m : K.m);
+            double sum = 0.0;
+            for (int j = 0; j < cnt; ++j) sum += col[j * 6];
+            K.rc[(size_t)(base / K.m + la) * 6 + c] = sum;
+        }
+        __syncthreads();
+    }
+    const double s = block_sum(acc, red);
+    if (threadIdx.x == 0) C.part_rz[(parity ^ 1) * RZ_STRIDE + blockIdx.x] = s;
+}
+constexpr int CSOLVE_ROWS = 8;      // rows of the dense inverse per workgroup (one wavefront each)
+__global__ __launch_bounds__(CSOLVE_ROWS * 64) void coarse_solve_dot_kernel(CoarseDev K, const int32_t* __restrict__ stop, double* __restrict__ part) {
+    __shared__ double ws[CSOLVE_ROWS];
+    if (stop && *stop) return;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * CSOLVE_ROWS + wv;
+    double s = 0.0, rc_row = 0.0;
+    if (row < K.nc) {
+        rc_row = K.rc[row];
+        s = wave_sum(dense_row_dot(K.Acf + (size_t)row * K.nc, K.rc, K.nc, lane));
+        if (lane == 0) K.yc[row] = s;
+    }
+    if (lane == 0) ws[wv] = s * rc_row;
+    __syncthreads();
+    if (threadIdx.x == 0) { double tsum = 0.0; for (int i = 0; i < CSOLVE_ROWS; ++i) tsum += ws[i]; part[blockIdx.x] = tsum; }
+}
+int coarse_group_keyframes(const CoarseDev& K) { return K.m >= 1 && K.m <= CG_BLOCK / 3 ? (CG_BLOCK / 3 / K.m) * K.m : 0; }   // 0: aggregates too large for the fused form
+int coarse_update_grid(const GraphDev& G, const CoarseDev& K) {
+    const int kft = coarse_group_keyframes(K);
+    int64_t g = kft > 0 ? (G.N + kft - 1) / kft : 1;
+    if (g > MAX_PARTIALS) g = MAX_PARTIALS;
+    return (int)(g < 1 ? 1 : g);
+}
+int coarse_solve_grid(const CoarseDev& K) { return (K.nc + CSOLVE_ROWS - 1) / CSOLVE_ROWS; }
+void launch_cg_update_restrict(const GraphDev& G, const CgDev& C, const CoarseDev& K, int k, int n_pq_partials, hipStream_t st) {
+    const int g = coarse_update_grid(G, K);
+    hipLaunchKernelGGL(cg_update_restrict_kernel, dim3(g), dim3(CG_BLOCK), 0, st, G, C, K, k & 1, n_pq_partials, g, coarse_group_keyframes(K));
+}
+void launch_coarse_solve_dot(const CoarseDev& K, const int32_t* stop, double* part, hipStream_t st) {
+    hipLaunchKernelGGL(coarse_solve_dot_kernel, dim3(coarse_solve_grid(K)), dim3(CSOLVE_ROWS * 64), 0, st, K, stop, part);
 }
 void launch_coarse_apply(const GraphDev& G, const CgDev& C, const CoarseDev& K, const double* r, double* z, double* part_rz, bool inside_iteration, hipStream_t st) {
     const int32_t* stop = inside_iteration ? C.flags : nullptr;     // at PCG start the flag still belongs to the previous solve
@@ -1922,5 +2097,6 @@ void launch_coarse_invert(const CoarseDev& K, double* scratch /* 64 nc + 1024 do
 }
 
 #include "pgo_mg_kernels.hpp"
+#include "pgo_resident_kernels.hpp"
 
 }  // namespace pgo

@@ -308,13 +308,13 @@ __global__ __launch_bounds__(384) void mg_dense_solve_kernel(CoarseDev K, MgLeve
     const int a = blockIdx.x;
     const int q = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const double2* __restrict__ x = reinterpret_cast<const double2*>(K.rc);
-    const double2* __restrict__ Ar = reinterpret_cast<const double2*>(K.Ac + (size_t)(a * 6 + q) * K.nc);
-    const int n2 = K.nc >> 1;
+    const float4* __restrict__ Ar = reinterpret_cast<const float4*>(K.Acf + (size_t)(a * 6 + q) * K.nc);     // the inverse in fp32: half the bytes of the dominant stream
+    const int n4 = K.nc >> 2;
     double s = 0.0;
-    if (lane < n2) { const double2 u = Ar[lane], v = x[lane]; s = u.x * v.x + u.y * v.y; }      // first trip issued before the flag is needed
+    if (lane < n4) { const float4 u = Ar[lane]; const double2 v = x[2 * lane], w = x[2 * lane + 1]; s = (double)u.x * v.x + (double)u.y * v.y + (double)u.z * w.x + (double)u.w * w.y; }   // first trip issued before the flag is needed
     if (stopped) return;
 #pragma unroll 4
-    for (int j = lane + 64; j < n2; j += 64) { const double2 u = Ar[j], v = x[j]; s += u.x * v.x + u.y * v.y; }
+    for (int j = lane + 64; j < n4; j += 64) { const float4 u = Ar[j]; const double2 v = x[2 * j], w = x[2 * j + 1]; s += (double)u.x * v.x + (double)u.y * v.y + (double)u.z * w.x + (double)u.w * w.y; }
     s = wave_sum(s);
     if (lane == 0) { ys[q] = s; K.yc[a * 6 + q] = s; }
     if (!has_below) return;

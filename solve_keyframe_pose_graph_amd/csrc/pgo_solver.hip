@@ -106,12 +106,15 @@ struct pgo_problem {
     DBuf<double> d_part;             // partial-sum scratch: several arrays of n_part
     DBuf<double> d_cgpart;           // part_pq [MAX] + part_rz [2][MAX] + scal[4]
     DBuf<int32_t> d_flags;           // cg flags [4] + invert fail [1]
+    DBuf<unsigned long long> d_res;  // resident PCG: ctl (as the first 8 bytes) + slot rows
+    ResDev R{};
     DBuf<double> d_scal;             // S_N doubles
     DBuf<double> d_pose[2], d_swv[2], d_delta_s, d_io;   // state ping-pong, staging for quat/t
     DBuf<double> d_tmp;
     DBuf<double> d_vio;              // raw VIO poses [n_vio][16] (graph construction, K0)
     // two-level preconditioner (CoarseDev)
     DBuf<double> d_ccen, d_cd, d_cAc, d_crc, d_cscr;
+    DBuf<float> d_cAcf;              // the dense inverse rounded to fp32
     DBuf<int64_t> d_cblk_ptr, d_ccontrib;
     DBuf<int32_t> d_cblk_ab, d_cagg_free, d_cinfo;
     CoarseDev K{};
@@ -454,7 +457,9 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
     HIPCHK(p, p->d_cgvec.ensure(std::max<int64_t>(N * 42, 1)));
     p->n_part = std::max<int64_t>(MAX_PARTIALS, (G.rel.tiles + G.sw.tiles + 3) / 4 + 1);
     HIPCHK(p, p->d_part.ensure(p->n_part * 6));
-    HIPCHK(p, p->d_cgpart.ensure(MF_MAX_GRID + 2 * RZ_STRIDE + 16));   // partial sums + 16 PCG scalars (C.scal)
+    HIPCHK(p, p->d_cgpart.ensure(MF_MAX_GRID + 2 * RZ_STRIDE + 16));
+    HIPCHK(p, p->d_res.ensure(8 + 4 * RES_MAX_PART));
+    p->R.ctl = reinterpret_cast<uint32_t*>(p->d_res.p); p->R.slots = p->d_res.p + 8;   // partial sums + 16 PCG scalars (C.scal)
     HIPCHK(p, p->d_flags.ensure(8)); HIPCHK(p, p->d_scal.ensure(S_N));
     for (int k = 0; k < 2; ++k) { HIPCHK(p, p->d_pose[k].ensure(std::max<int64_t>(N * 8, 1))); HIPCHK(p, p->d_swv[k].ensure(std::max<int64_t>(S, 1))); }
     HIPCHK(p, p->d_delta_s.ensure(std::max<int64_t>(Es, 1))); HIPCHK(p, p->d_io.ensure(std::max<int64_t>(N * 7, 1)));
@@ -511,7 +516,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
             blk_ptr.push_back((int64_t)contrib.size());
             const int n_blk = (int)blk_ab.size() / 2;
             const int nc = (6 * n_agg + 63) / 64 * 64;      // padded with a decoupled identity block (the dense kernels work on 64-wide tiles)
-            HIPCHK(p, p->d_ccen.ensure((size_t)n_agg * 3)); HIPCHK(p, p->d_cd.ensure((size_t)N * 3)); HIPCHK(p, p->d_cAc.ensure((size_t)nc * nc));
+            HIPCHK(p, p->d_ccen.ensure((size_t)n_agg * 3)); HIPCHK(p, p->d_cd.ensure((size_t)N * 3)); HIPCHK(p, p->d_cAc.ensure((size_t)nc * nc)); HIPCHK(p, p->d_cAcf.ensure((size_t)nc * nc));
             HIPCHK(p, p->d_crc.ensure((size_t)nc * 2)); HIPCHK(p, p->d_cscr.ensure((size_t)nc * 64 + 1024)); HIPCHK(p, hipMemsetAsync(p->d_crc.p, 0, (size_t)nc * 2 * sizeof(double), p->st)); HIPCHK(p, p->d_cblk_ptr.ensure(blk_ptr.size())); HIPCHK(p, p->d_ccontrib.ensure(std::max<size_t>(contrib.size(), 1)));
             HIPCHK(p, p->d_cblk_ab.ensure(blk_ab.size())); HIPCHK(p, p->d_cagg_free.ensure(n_agg)); HIPCHK(p, p->d_cinfo.ensure(4));
             HIPCHK(p, hipMemcpyAsync(p->d_cblk_ptr.p, blk_ptr.data(), blk_ptr.size() * sizeof(int64_t), hipMemcpyHostToDevice, p->st));
@@ -519,7 +524,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
             HIPCHK(p, hipMemcpyAsync(p->d_cblk_ab.p, blk_ab.data(), blk_ab.size() * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
             HIPCHK(p, hipMemcpyAsync(p->d_cagg_free.p, agg_free.data(), n_agg * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
             HIPCHK(p, hipStreamSynchronize(p->st));
-            p->K = CoarseDev{n_agg, nc, m, n_blk, p->d_ccen.p, p->d_cd.p, p->d_cAc.p, p->d_crc.p, p->d_crc.p + nc, p->d_cblk_ptr.p, p->d_cblk_ab.p, p->d_ccontrib.p, p->d_cagg_free.p};
+            p->K = CoarseDev{n_agg, nc, m, n_blk, p->d_ccen.p, p->d_cd.p, p->d_cAc.p, p->d_crc.p, p->d_crc.p + nc, p->d_cblk_ptr.p, p->d_cblk_ab.p, p->d_ccontrib.p, p->d_cagg_free.p, p->d_cAcf.p};
             p->coarse_built = true;
         }
     }
@@ -567,7 +572,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
             const int n_top = H.L[nl - 1].n;
             const int nc = (6 * n_top + 63) / 64 * 64;
             HIPCHK(p, p->d_mg_i32.ensure(std::max<size_t>(pi32.size(), 1))); HIPCHK(p, p->d_mg_i64.ensure(std::max<size_t>(pi64.size(), 1))); HIPCHK(p, p->d_mg_f64.ensure(std::max<size_t>(nf64, 2)));
-            HIPCHK(p, p->d_cAc.ensure((size_t)nc * nc)); HIPCHK(p, p->d_crc.ensure((size_t)nc * 2)); HIPCHK(p, p->d_cscr.ensure((size_t)nc * 64 + 1024)); HIPCHK(p, p->d_cinfo.ensure(4));
+            HIPCHK(p, p->d_cAc.ensure((size_t)nc * nc)); HIPCHK(p, p->d_cAcf.ensure((size_t)nc * nc)); HIPCHK(p, p->d_crc.ensure((size_t)nc * 2)); HIPCHK(p, p->d_cscr.ensure((size_t)nc * 64 + 1024)); HIPCHK(p, p->d_cinfo.ensure(4));
             HIPCHK(p, hipMemcpyAsync(p->d_mg_i32.p, pi32.data(), pi32.size() * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
             HIPCHK(p, hipMemcpyAsync(p->d_mg_i64.p, pi64.data(), pi64.size() * sizeof(int64_t), hipMemcpyHostToDevice, p->st));
             HIPCHK(p, hipMemsetAsync(p->d_mg_f64.p, 0, nf64 * sizeof(double), p->st));
@@ -588,7 +593,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
             // the dense coarsest level shares the buffers of the two-level preconditioner, which the multigrid replaces on this graph
             p->coarse_built = false;
             p->K = CoarseDev{};
-            p->K.n_agg = n_top; p->K.nc = nc; p->K.Ac = p->d_cAc.p; p->K.rc = p->d_crc.p; p->K.yc = p->d_crc.p + nc;
+            p->K.n_agg = n_top; p->K.nc = nc; p->K.Ac = p->d_cAc.p; p->K.Acf = p->d_cAcf.p; p->K.rc = p->d_crc.p; p->K.yc = p->d_crc.p + nc;
             p->mg_built = true;
             if (p->opt.verbosity > 0) {
                 std::fprintf(stderr, "[pgo] multigrid: %lld keyframes", (long long)N);
@@ -740,12 +745,22 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
     // Multi-GPU: the PCG runs in Chronopoulos-Gear form (pgo_kernels.hip): per iteration ONE all-reduce carries the shared rows of
     // w = A u together with gamma = r.u (owner-weighted partials of the previous update) and delta = u.A u (rank-local partials).
     const bool multi = p->local_ids;
+    // two-level preconditioner in three kernels per iteration (prolongation inside the matvec, restriction inside the update, r.(P y) from the dense solve):
+    // the update kernel's r.z partials take `fused_parts` slots, the solve's C.extra_rz slots behind them
+    const bool fused_coarse = !multi && p->coarse_active && !p->mg_active && p->built_mf && coarse_group_keyframes(p->K) > 0;
+    const int fused_parts = fused_coarse ? coarse_update_grid(p->G, p->K) : 0;
+    if (fused_coarse) p->C.extra_rz = coarse_solve_grid(p->K);
+    else if (!p->mg_active) p->C.extra_rz = 0;
     if (resume_from < 0) {
         if (!multi && (p->coarse_active || p->mg_active)) {
             // z = D^-1 r + P Ac^-1 P^T r (or the multigrid cycle): the coarse term is added to z and to the r.z partials before the scalars are formed
-            const int g = launch_cg_init_vectors(p->G, p->C, warm ? 1 : 0, p->st);
+            int g = launch_cg_init_vectors(p->G, p->C, warm ? 1 : 0, p->st);
             if (p->mg_active) launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz, mg_scale(p), false, p->st);
             else launch_coarse_apply(p->G, p->C, p->K, p->C.r, p->C.z, p->C.part_rz, false, p->st);
+            if (fused_coarse) {    // z is complete here: the slots the fused kernels will use beyond the start-up kernels' stay zero for this parity
+                HIPCHK(p, hipMemsetAsync(p->C.part_rz + g, 0, (size_t)(fused_parts + p->C.extra_rz - g) * sizeof(double), p->st));
+                g = fused_parts;
+            }
             launch_cg_init_scalars(p->C, g, tol2, p->st);
         } else if (!multi) launch_cg_init(p->G, p->C, warm ? 1 : 0, tol2, p->st);
         else {
@@ -766,7 +781,7 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
         int e = std::max(2, o.cg_check_every) & ~1;   // even: the r/p ping-pong parity repeats from chunk to chunk
         // five kernels per iteration with the coarse space: chunks of 12 keep a captured chunk at 60 kernel nodes (rocprofv3 7.2 crashes while a
         // graph of 120 nodes is captured under --kernel-trace; 80 are fine) and halve the early-exit launches after convergence
-        if (p->coarse_active && !multi) e = std::min(e, 12);
+        if (p->coarse_active && !multi) e = std::min(e, fused_coarse ? 24 : 12);
         if (p->mg_active && !multi) e = std::max(2, (72 / (2 * p->M.n_levels + 3)) & ~1);   // 2 n_levels + 1 cycle kernels + matvec + update per iteration
         return e;
     };
@@ -785,6 +800,12 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
             launch_cgcg_update(p->G, p->C, kk, kk == 0 ? 1 : 0, p->st);   // also when a PCG that stopped before its first update is resumed: p = s = 0 still
             return PGO_OK;
         }
+        if (fused_coarse) {
+            launch_mf_spmv_coarse(p->G, p->F, p->Sc, p->C, p->K, kk, tol2, fused_parts, kk > 0 ? 1 : 0, p->st);
+            launch_cg_update_restrict(p->G, p->C, p->K, kk, mf_grid_size(p->F), p->st);
+            launch_coarse_solve_dot(p->K, p->C.flags, p->C.part_rz + (size_t)((kk & 1) ^ 1) * RZ_STRIDE + fused_parts, p->st);
+            return PGO_OK;
+        }
         int n_pq = cg_grid_size(p->G);
         if (p->built_mf) { launch_mf_spmv(p->G, p->F, p->Sc, p->C, kk, tol2, p->st); n_pq = mf_grid_size(p->F); }
         else launch_cg_spmv(p->G, p->C, kk, tol2, p->st);
@@ -797,6 +818,9 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
     };
     // hipGraph: capture one chunk (iterations 2 .. 2+every-1: no `first` kernel, even start) once per graph build and preconditioner, and replay it
     const bool want_graph = o.cg_use_graph && !p->local_ids && !p->cg_graph_failed;
+    // session-sized graphs: whole chunks of block-Jacobi iterations inside one resident kernel (pgo_resident_kernels.hpp)
+    const bool resident = !multi && p->built_mf && !p->coarse_active && !p->mg_active && o.resident_max_keyframes > 0 && p->N <= o.resident_max_keyframes;
+    const int resident_chunk = 256;
     auto ensure_graph = [&]() {
         const int mode = p->mg_active ? 2 : p->coarse_active ? 1 : 0;
         pgo_problem::CapturedChunk& cc = p->cg_chunk[mode];
@@ -826,8 +850,12 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
         return PGO_OK;
     };
     while (k < o.cg_max_iterations && !done) {
-        const int chunk = std::min(every, o.cg_max_iterations - k);
-        if (k >= 2 && chunk == every && want_graph && p->cg_graph && (k & 1) == 0) {
+        int chunk = std::min(every, o.cg_max_iterations - k);
+        if (resident && !p->coarse_active && !p->mg_active) {
+            chunk = std::min(resident_chunk, o.cg_max_iterations - k);
+            launch_pcg_resident(p->G, p->F, p->Sc, p->C, p->R, k, chunk, p->st);
+            k += chunk;
+        } else if (k >= 2 && chunk == every && want_graph && p->cg_graph && (k & 1) == 0) {
             HIPCHK(p, hipGraphLaunch(p->cg_graph, p->st));
             k += every;
         } else {
@@ -878,7 +906,8 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
     res->converged = hflags[0] != 0 && hflags[1] == 0;
     if (!hflags[0] && !multi) {   // iteration cap reached: one more convergence test so that scal[1] holds the last r.z (x is already final)
         launch_cg_set_tolerance(p->C, 1e300, p->st);
-        if (p->built_mf) launch_mf_spmv(p->G, p->F, p->Sc, p->C, k, 1e300, p->st);
+        if (fused_coarse) launch_mf_spmv_coarse(p->G, p->F, p->Sc, p->C, p->K, k, 1e300, fused_parts, k > 0 ? 1 : 0, p->st);
+        else if (p->built_mf) launch_mf_spmv(p->G, p->F, p->Sc, p->C, k, 1e300, p->st);
         else launch_cg_spmv(p->G, p->C, k, 1e300, p->st);
         HIPCHK(p, hipMemcpyAsync(hflags, p->C.flags, sizeof(hflags), hipMemcpyDeviceToHost, p->st));
         HIPCHK(p, hipMemcpyAsync(hscal, p->C.scal, sizeof(hscal), hipMemcpyDeviceToHost, p->st));
@@ -1293,6 +1322,7 @@ void pgo_options_init(pgo_options* o) {
     o->mg_passes = 3;
     o->mg_dense_max_nodes = 512;
     o->mg_switch_iterations = 400;
+    o->resident_max_keyframes = 0;
     o->cg_rel_tolerance = 1e-9;     // loosest decade that keeps the 10-iteration chi^2 of C3 within 1e-8 of the 1e-13 solve
     o->device_id = -1;
     o->verbosity = 0;
@@ -1336,7 +1366,7 @@ int pgo_destroy(pgo_problem* p) {
     p->d_flags.release(); p->d_scal.release(); p->d_pose[0].release(); p->d_pose[1].release(); p->d_swv[0].release(); p->d_swv[1].release();
     p->d_delta_s.release(); p->d_io.release(); p->d_tmp.release(); p->d_vio.release();
     p->d_mg_f64.release(); p->d_mg_i32.release(); p->d_mg_i64.release();
-    p->d_ccen.release(); p->d_cd.release(); p->d_cAc.release(); p->d_crc.release(); p->d_cblk_ptr.release(); p->d_ccontrib.release(); p->d_cblk_ab.release(); p->d_cagg_free.release(); p->d_cinfo.release(); p->d_cscr.release();
+    p->d_ccen.release(); p->d_cd.release(); p->d_cAc.release(); p->d_crc.release(); p->d_cblk_ptr.release(); p->d_ccontrib.release(); p->d_cblk_ab.release(); p->d_cagg_free.release(); p->d_cinfo.release(); p->d_cscr.release(); p->d_res.release(); p->d_cAcf.release();
     p->d_l2g.release(); p->d_sh_loc.release(); p->d_sh_pos.release(); p->d_own.release(); p->d_xbuf.release();
     p->d_einc.release(); p->d_einc_ownl.release(); p->d_node_rng.release(); p->d_tile_inc0.release(); p->d_einc_other.release();
     p->d_tile_node0.release(); p->d_tile_sw0.release(); p->d_node_prior.release(); p->d_rec.release(); p->d_lam.release();
