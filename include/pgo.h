@@ -109,11 +109,12 @@ typedef struct pgo_options {
      * wavelengths the coarse space removes (10-60x fewer iterations); with large aggregates at small radii it does not pay.  Once per solve (and once more when a coarse space dropped
      * at a small radius becomes eligible at coarse_min_radius) plain block-Jacobi gets the same time budget on the same system; the
      * loser is not used for the rest of the solve; a handle that kept it skips the comparison in its next three solves, one that dropped
-     * it skips the coarse space for its next 1, 3, 7, 15 solves.  Aggregate count: `coarse_aggregates`, at least 8 keyframes each but not fewer
-     * than half that number on small graphs; a graph of <= coarse_aggregates / 2 keyframes gets one aggregate per keyframe, which makes the
-     * coarse inverse the inverse of the reduced system itself (a direct solve refined by the PCG).  The solution of each step is the same
-     * to the PCG tolerance.  Single GPU only. */
-    int32_t coarse_aggregates;           /* 512 (coarse dimension 3072, 75 MB dense inverse); 0 disables */
+     * it skips the coarse space for its next 1, 3, 7, 15 solves.  Aggregate count: at most `coarse_aggregates`, at least 8 keyframes each but not fewer
+     * than min(coarse_aggregates / 2, 256) on small graphs; a graph of no more keyframes than that gets one aggregate per keyframe, which makes the
+     * coarse inverse the inverse of the reduced system itself (a direct solve refined by the PCG).  Inside the PCG the preconditioner costs one
+     * kernel on top of block-Jacobi's two: the restriction rides in the vector update, the prolongation in the next matvec, and the dense solve
+     * (its inverse streamed in fp32) also yields the coarse part of r.z.  The solution of each step is the same to the PCG tolerance.  Single GPU only. */
+    int32_t coarse_aggregates;           /* 768 (coarse dimension <= 4608: 170 MB dense inverse + its fp32 copy; graphs up to 4096 keyframes use <= 512); 0 disables */
     /* Aggregation multigrid for large graphs (single GPU): z = D^-1 r + P V(P^T r) — block-Jacobi on the keyframes plus one V(1,1)
      * cycle over a hierarchy of rigid aggregates (dtheta_i = dtheta_a, dt_i = dt_a - 2 [d_i]x dtheta_a).  Level 1 groups up to
      * 2^mg_first_passes keyframes along RELATIVE-POSE (odometry) edges only — a switchable loop closure may be an outlier the solver is about
@@ -141,12 +142,6 @@ typedef struct pgo_options {
                                           *      solve, block-Jacobi iterations growing like sqrt(radius)) to need >= 2.25x this many starts with it, and one
                                           *      predicted easier than that switches only after twice its prediction.
                                           *      0: multigrid from the first iteration of every system. */
-    int32_t resident_max_keyframes;      /* 0 (off).  Graphs up to this many keyframes run their plain block-Jacobi PCG as ONE resident kernel per chunk of iterations on
-                                          *      the 32 CUs of one XCD, the two dot products of an iteration being exchanges through that XCD's L2 (1.5-2 us each) instead
-                                          *      of kernel boundaries.  Correct, and measured SLOWER than the two-kernel form (14-16 vs 12 us per iteration at 400-3000
-                                          *      keyframes: the matrix-free operator is compute-bound on 32 CUs, an L2 load that must bypass the CU's L1 costs ~1 us) -
-                                          *      and these graphs need the two-level preconditioner anyway (40x fewer iterations), whose dense solve does not fit one
-                                          *      XCD's L2.  Kept as a measured experiment. */
     /* device selection */
     int32_t device_id;                   /* -1: use the current HIP device */
     int32_t verbosity;                   /* 0 silent (minimizer_progress_to_stdout=false, :1271), 1 per-iteration line on stderr */

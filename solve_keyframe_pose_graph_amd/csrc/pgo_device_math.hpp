@@ -248,9 +248,8 @@ PGO_HD void rot_fwd(const double* q, double v0, double v1, double v2, double& o0
     o1 = v1 + q[3] * t1 + (q[2] * t0 - q[0] * t2);
     o2 = v2 + q[3] * t2 + (q[0] * t1 - q[1] * t0);
 }
-PGO_HD void compact_apply(const double* rec, int side, const double* p_own, const double* p_other, double kscale, double* y) {
-    const double* p1 = side ? p_other : p_own;
-    const double* p2 = side ? p_own : p_other;
+// u = W (J1 p1 + J2 p2) (+ the switch Schur term): the part of an edge's product that both endpoints share
+PGO_HD void compact_u(const double* rec, const double* p1, const double* p2, double kscale, double* u) {
     const double* q2 = rec;          // (x, y, z, w)
     const double* b = rec + 4;
     const double ap0 = rec[8], ap1 = rec[9], ap2 = rec[10], d0 = rec[11], d1 = rec[12], d2 = rec[13], ws = rec[14];
@@ -260,7 +259,6 @@ PGO_HD void compact_apply(const double* rec, int side, const double* p_own, cons
     rot_conj(q2, p2[0], p2[1], p2[2], g20, g21, g22);
     rot_conj(q2, p1[3] - p2[3], p1[4] - p2[4], p1[5] - p2[5], f0, f1, f2);
     // u_t = ws ( f + 2 (dt x g2 - a' x g1) ),  u_q = 2 ws M (theta1 - theta2)
-    double u[6];
     u[0] = ws * (f0 + 2.0 * ((d1 * g22 - d2 * g21) - (ap1 * g12 - ap2 * g11)));
     u[1] = ws * (f1 + 2.0 * ((d2 * g20 - d0 * g22) - (ap2 * g10 - ap0 * g12)));
     u[2] = ws * (f2 + 2.0 * ((d0 * g21 - d1 * g20) - (ap0 * g11 - ap1 * g10)));
@@ -283,6 +281,15 @@ PGO_HD void compact_apply(const double* rec, int side, const double* p_own, cons
 #pragma unroll
         for (int i = 0; i < 6; ++i) u[i] -= k[i] * d;
     }
+}
+// y = J_side^T u
+PGO_HD void compact_side(const double* rec, const double* u, int side, double* y) {
+    const double* q2 = rec;
+    const double* b = rec + 4;
+    const double ap0 = rec[8], ap1 = rec[9], ap2 = rec[10], d0 = rec[11], d1 = rec[12], d2 = rec[13], ws = rec[14];
+    const double av0 = -q2[0], av1 = -q2[1], av2 = -q2[2], aw = q2[3];
+    const double dd = aw * b[3] + (av0 * b[0] + av1 * b[1] + av2 * b[2]);
+    const double c0 = b[3] * av0 - aw * b[0], c1 = b[3] * av1 - aw * b[1], c2 = b[3] * av2 - aw * b[2];
     // x = (a' or dt) x u_t ; w3 = R2 x + M^T u_q ;  M^T u = dd u - bv (av.u) - av (bv.u) - c x u
     const double s0 = side ? d0 : ap0, s1 = side ? d1 : ap1, s2 = side ? d2 : ap2;
     const double x0 = s1 * u[2] - s2 * u[1], x1 = s2 * u[0] - s0 * u[2], x2 = s0 * u[1] - s1 * u[0];
@@ -300,6 +307,19 @@ PGO_HD void compact_apply(const double* rec, int side, const double* p_own, cons
     y[3] = sg * ru0;
     y[4] = sg * ru1;
     y[5] = sg * ru2;
+}
+PGO_HD void compact_apply(const double* rec, int side, const double* p_own, const double* p_other, double kscale, double* y) {
+    double u[6];
+    compact_u(rec, side ? p_other : p_own, side ? p_own : p_other, kscale, u);
+    compact_side(rec, u, side, y);
+}
+// both endpoints of one edge from ONE evaluation of u (the lane of an edge whose two keyframes sit in the same matvec tile): the same
+// expressions as two compact_apply calls, so the results are bit-identical to them; what the two sides share (M^T u_q, R2 u_t) is computed once
+PGO_HD void compact_apply_both(const double* rec, const double* p1, const double* p2, double kscale, double* y1, double* y2) {
+    double u[6];
+    compact_u(rec, p1, p2, kscale, u);
+    compact_side(rec, u, 0, y1);
+    compact_side(rec, u, 1, y2);
 }
 
 // ceres::EigenQuaternionParameterization::Plus:  q+ = [sin|d| d/|d| ; cos|d|] (x) q

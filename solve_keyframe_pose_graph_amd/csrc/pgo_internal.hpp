@@ -35,7 +35,8 @@ constexpr int RZ_STRIDE = 2 * MAX_PARTIALS;   // one parity of the r.z partials:
 constexpr int PRIOR_DOUBLES = 42;  // r6 + J1
 constexpr int MF_BLOCK = 256;      // lanes (edge sides) per workgroup tile of the matrix-free operator (measured per PCG iteration on C3:
                                    // 128 -> 49.2 us, 256 -> 42.8 us, 512 -> 44.4 us, 1024 -> 51.7 us)
-constexpr int MF_MAX_NODES = 42;   // keyframes per tile (42 * 6 rows <= 256 lanes in the row phase)
+constexpr int MF_MAX_NODES = 42;   // keyframes per tile (42 * 6 rows <= 256 lanes in the row phase; tiles of 60 keyframes with a second row pass measured slower: 43.5 vs 41.9 us per iteration on C3)
+constexpr int MF_SLOTS = 384;      // edge SIDES per tile (LDS contribution slots): a lane that serves both sides of an in-tile edge fills two
 constexpr int MF_MAX_GRID = 1024;  // cap on matvec workgroups = p.q partial sums (measured: 1024 capped 50.8 us/iteration vs one workgroup per tile 54.5 us)
 constexpr int MF_PLANES = 11;      // COMPACT_DOUBLES / 2 double2 planes
 
@@ -76,15 +77,19 @@ struct GraphDev {
 // Matrix-free operator (PGO_LINEAR_PCG_MATRIX_FREE): one compact record per edge-side in keyframe-major ("incident") order,
 // stored as 11 double2 planes [plane][ninc_pad] so a workgroup tile reads 512 consecutive records with 1-KiB wave loads.
 struct MfDev {
-    // per edge side ("incident"), tile-major; inside a tile: all relative-pose sides of its keyframes (keyframe order), then all
-    // switchable sides (keyframe order) — so only the tail wavefronts of a tile touch the r6 planes
-    const uint32_t* einc;        // [ninc]  bit31 = switchable, bits 30..1 = edge index inside its class, bit0 = side
+    // per LANE, tile-major.  A tile is a run of whole keyframes; its lanes are, in this order:
+    //   pairs   relative-pose edges with BOTH keyframes in the tile: one lane reads the record once and produces both sides' contributions
+    //   sides   relative-pose edge sides whose other keyframe lies outside the tile (its vector rows are gathered from global memory)
+    //   sides   switchable edge sides (loop closures: the other keyframe is almost never in the tile) — so only the tail wavefronts touch r6
+    // Contributions go to per-SIDE slots in LDS, ordered as the keyframes' incident lists (relative-pose sides by keyframe, then switchable
+    // sides by keyframe): the per-keyframe sums run over the same terms in the same order whichever lane produced them.
+    const uint32_t* einc;        // [ninc]  bit31 = switchable, bits 30..1 = edge index inside its class, bit0 = side of the OWN keyframe (pairs: 0)
     const int32_t* einc_other;   // [ninc]  the other endpoint
-    const uint8_t* einc_ownl;    // [ninc]  own keyframe, tile-local (0..41)
+    const uint32_t* einc_slot;   // [ninc]  bits 0-8 slot of the own side, 9-17 slot of the other side (511: none), 18-23 own keyframe, tile-local
     const int64_t* tile_inc0;    // [tiles+1] first edge side of each workgroup tile (whole keyframes per tile, <= MF_BLOCK sides)
-    const int32_t* tile_sw0;     // [tiles]   tile-local index of the first switchable side
+    const int32_t* tile_sw0;     // [tiles]   bits 0-15 tile-local index of the first switchable lane, bits 16-31 number of pair lanes
     const int32_t* tile_node0;   // [tiles+1]
-    const ushort4* node_rng;     // [N] tile-local {rel_begin, rel_end, sw_begin, sw_end} of the keyframe's sides
+    const ushort4* node_rng;     // [N] tile-local SLOT ranges {rel_begin, rel_end, sw_begin, sw_end} of the keyframe's sides
     const int32_t* node_prior;   // [N] regulariser index or -1
     double2* rec;                // [MF_PLANES][ninc_pad]: planes 0-6 q2 b a' dt, plane 7 (w|s, -), planes 8-10 r6 (switchable only)
     double* lam;                 // [N][6] LM damping in the unscaled space (identity rows for fixed keyframes)
@@ -157,17 +162,7 @@ struct CgDev {
     int32_t* flags;       // [0]=done [1]=breakdown [2]=iterations
 };
 
-// Resident PCG of session-sized graphs (pgo_resident_kernels.hpp): launch bookkeeping and the slot rows of the two per-iteration exchanges.
-constexpr int RES_MAX_PART = 64;                       // participants (workgroups on one XCD) at most
-constexpr unsigned long long RES_EMPTY = ~0ull;        // an empty slot (a NaN pattern no arithmetic produces)
-struct ResDev {
-    uint32_t* ctl;                 // [0] workgroups arrived, [1] participants   (zeroed before every launch)
-    unsigned long long* slots;     // [2 exchanges][2 parities][RES_MAX_PART]    (RES_EMPTY before every launch)
-};
-
 // ---- launchers (pgo_kernels.hip).  All asynchronous on `st`. ----
-// iterations k0 .. k0+len-1 of the matrix-free block-Jacobi PCG in one resident kernel (same entry/exit state as launch_mf_spmv + launch_cg_update)
-void launch_pcg_resident(const GraphDev& G, const MfDev& F, const ScaleDev& Sc, const CgDev& C, const ResDev& R, int k0, int len, hipStream_t st);
 void launch_k1(const GraphDev& G, const double* pose8, const double* sw, bool want_jacobian, double* partials /*[MAX_PARTIALS]*/, int* n_partials, hipStream_t st);
 void launch_prior(const GraphDev& G, const double* pose8, bool want_jacobian, double* partial_cost /*1 double*/, hipStream_t st);
 void launch_k2(const GraphDev& G, const LinDev& L, bool want_offdiag, hipStream_t st);

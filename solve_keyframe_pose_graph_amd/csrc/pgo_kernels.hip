@@ -1038,7 +1038,7 @@ __device__ __forceinline__ double coarse_pending(const CoarseDev& K, const uint8
 template <bool FUSED, bool COARSE = false>
 __global__ __launch_bounds__(MF_BLOCK) void mf_spmv_kernel(GraphDev G, MfDev F, ScaleDev Sc, CgDev C, const double* __restrict__ xin, double* __restrict__ yout,
                                                            int parity, int first, int nparts, double tol2, CoarseDev K = CoarseDev{}, int pending = 0) {
-    __shared__ double contrib[MF_BLOCK * 7];
+    __shared__ double contrib[MF_SLOTS * 7];
     __shared__ double pwin[MF_BLOCK];
     __shared__ double red[2 * (MF_BLOCK / 64)];
     const int l = threadIdx.x;
@@ -1080,7 +1080,7 @@ __global__ __launch_bounds__(MF_BLOCK) void mf_spmv_kernel(GraphDev G, MfDev F, 
     for (int tile = blockIdx.x; tile < F.tiles; tile += gridDim.x) {
         const int64_t i0 = F.tile_inc0[tile], i1 = F.tile_inc0[tile + 1];
         const int32_t n0 = F.tile_node0[tile], n1 = F.tile_node0[tile + 1];
-        const int sw0 = F.tile_sw0[tile];
+        const int sw0 = F.tile_sw0[tile] & 0xffff, pair1 = (int)((uint32_t)F.tile_sw0[tile] >> 16);
         const int64_t i = i0 + l;
         const int nn = n1 - n0;
         // phase 0: the tile's own keyframes' input vector p = z + beta p_prev, once, into LDS (every edge side of a keyframe needs it,
@@ -1109,7 +1109,8 @@ __global__ __launch_bounds__(MF_BLOCK) void mf_spmv_kernel(GraphDev G, MfDev F, 
             const bool is_sw = l >= sw0;
             const int side = (int)(ent & 1u);
             const int32_t other = F.einc_other[i];
-            const int ownl = F.einc_ownl[i];
+            const uint32_t sl = F.einc_slot[i];
+            const int ownl = (int)(sl >> 18), slot_a = (int)(sl & 511u), slot_b = (int)((sl >> 9) & 511u);
             double rec[COMPACT_DOUBLES];
 #pragma unroll
             for (int pl = 0; pl < 8; ++pl) { const double2 v = F.rec[(size_t)pl * F.ninc_pad + i]; rec[2 * pl] = v.x; rec[2 * pl + 1] = v.y; }
@@ -1159,9 +1160,14 @@ __global__ __launch_bounds__(MF_BLOCK) void mf_spmv_kernel(GraphDev G, MfDev F, 
                 }
             }
             double y[6];
-            compact_apply(rec, side, po, pt, kscale, y);
+            if (l < pair1) {       // both keyframes of the edge are in this tile: the record is read once, the shared part computed once
+                double y2[6];
+                compact_apply_both(rec, po, pt, 0.0, y, y2);
 #pragma unroll
-            for (int r = 0; r < 6; ++r) contrib[l * 7 + r] = y[r];
+                for (int r = 0; r < 6; ++r) contrib[slot_b * 7 + r] = y2[r];
+            } else compact_apply(rec, side, po, pt, kscale, y);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) contrib[slot_a * 7 + r] = y[r];
         }
         __syncthreads();
         if (l < nn * 6) {
@@ -2097,6 +2103,5 @@ void launch_coarse_invert(const CoarseDev& K, double* scratch /* 64 nc + 1024 do
 }
 
 #include "pgo_mg_kernels.hpp"
-#include "pgo_resident_kernels.hpp"
 
 }  // namespace pgo

@@ -106,8 +106,6 @@ struct pgo_problem {
     DBuf<double> d_part;             // partial-sum scratch: several arrays of n_part
     DBuf<double> d_cgpart;           // part_pq [MAX] + part_rz [2][MAX] + scal[4]
     DBuf<int32_t> d_flags;           // cg flags [4] + invert fail [1]
-    DBuf<unsigned long long> d_res;  // resident PCG: ctl (as the first 8 bytes) + slot rows
-    ResDev R{};
     DBuf<double> d_scal;             // S_N doubles
     DBuf<double> d_pose[2], d_swv[2], d_delta_s, d_io;   // state ping-pong, staging for quat/t
     DBuf<double> d_tmp;
@@ -132,7 +130,7 @@ struct pgo_problem {
     int64_t n_vio = 0;
     // matrix-free operator
     DBuf<uint32_t> d_einc;
-    DBuf<uint8_t> d_einc_ownl;
+    DBuf<uint32_t> d_einc_slot;
     DBuf<ushort4> d_node_rng;
     DBuf<int64_t> d_tile_inc0;
     DBuf<int32_t> d_einc_other, d_tile_node0, d_tile_sw0, d_node_prior;
@@ -140,6 +138,7 @@ struct pgo_problem {
     DBuf<double> d_lam;
     MfDev F{};
     bool built_mf = false;
+    int64_t mf_pair_lanes = 0, mf_rel_side_lanes = 0, mf_sw_lanes = 0;   // lanes of the matrix-free operator by kind (pgo_time_kernel's bytes)
     int cur = 0;
     int64_t n_part = MAX_PARTIALS;
     std::vector<uint8_t> h_node_free, h_sw_used;
@@ -385,53 +384,92 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
             if (deg_rel[n] + deg_sw[n] > MF_BLOCK) { p->err = "matrix-free operator: a keyframe with more incident edges than a matrix-free tile holds (use PGO_LINEAR_PCG_BLOCK_JACOBI)"; return PGO_ERR_INVALID_ARG; }
         }
         if ((int64_t)std::max(G.rel.E, G.sw.E) >= (1ll << 30)) { p->err = "matrix-free operator: more than 2^30 edges in one class"; return PGO_ERR_INVALID_ARG; }
-        // pack whole keyframes into workgroup tiles
+        // pack whole keyframes into workgroup tiles: <= MF_SLOTS edge sides, <= MF_BLOCK lanes (a relative-pose edge with both keyframes in
+        // the tile takes ONE lane for its two sides), <= MF_MAX_NODES keyframes
+        auto rel_other_of = [&](int64_t k) -> int32_t {      // incident entry k of a relative-pose side: the other keyframe, or -1
+            const int64_t slot = inc[k] >> 1; const int side = (int)(inc[k] & 1);
+            if (slot >= G.rel.Epad) return -1;
+            const int32_t a = L(p->rel.c1[slot]), b = L(p->rel.c2[slot]);
+            return a == b ? -1 : (side == 0 ? b : a);
+        };
         std::vector<int32_t> tile_node0; tile_node0.push_back(0);
-        { int64_t cur = 0; int cur_nodes = 0;
+        { int64_t sides = 0, pairs = 0; int cur_nodes = 0; int32_t start = 0;
           for (int64_t n = 0; n < N; ++n) {
               const int64_t d = deg_rel[n] + deg_sw[n];
-              if (cur + d > MF_BLOCK || cur_nodes >= MF_MAX_NODES) { tile_node0.push_back((int32_t)n); cur = 0; cur_nodes = 0; }
-              cur += d; ++cur_nodes;
+              auto pairs_with = [&](int32_t lo) { int64_t c = 0; for (int64_t k = rowptr[n]; k < rowptr[n + 1]; ++k) { const int32_t o = rel_other_of(k); if (o >= lo && o < (int32_t)n) ++c; } return c; };
+              int64_t np = pairs_with(start);
+              if (sides + d > MF_SLOTS || sides + d - (pairs + np) > MF_BLOCK || cur_nodes >= MF_MAX_NODES) {
+                  tile_node0.push_back((int32_t)n); sides = 0; pairs = 0; cur_nodes = 0; start = (int32_t)n; np = 0;
+              }
+              sides += d; pairs += np; ++cur_nodes;
           }
           tile_node0.push_back((int32_t)N); }
         const int tiles = (int)tile_node0.size() - 1;
         std::vector<int64_t> tile_inc0(tiles + 1, 0);
         std::vector<int32_t> tile_sw0(std::max(tiles, 1), 0);
-        std::vector<uint32_t> einc; std::vector<int32_t> eoth; std::vector<uint8_t> eown; std::vector<ushort4> node_rng(std::max<int64_t>(N, 1));
-        einc.reserve((size_t)2 * (Er + Es)); eoth.reserve(einc.capacity()); eown.reserve(einc.capacity());
+        std::vector<uint32_t> einc, eslot; std::vector<int32_t> eoth; std::vector<ushort4> node_rng(std::max<int64_t>(N, 1));
+        einc.reserve((size_t)(Er + 2 * Es) + 64); eoth.reserve(einc.capacity()); eslot.reserve(einc.capacity());
+        std::vector<uint16_t> side_slot((size_t)(rowptr[N]), 0);       // slot of incident entry k inside its tile
+        std::vector<uint16_t> rel_slot1((size_t)std::max<int64_t>(Er, 1), 0);   // per relative-pose edge: slot of its side 1 (own = c2)
         for (int t = 0; t < tiles; ++t) {
             const int32_t n0 = tile_node0[t], n1 = tile_node0[t + 1];
             tile_inc0[t] = (int64_t)einc.size();
-            for (int pass = 0; pass < 2; ++pass) {          // pass 0: relative-pose sides, pass 1: switchable sides
-                if (pass == 1) tile_sw0[t] = (int32_t)((int64_t)einc.size() - tile_inc0[t]);
+            // slots: the keyframes' relative-pose sides, then their switchable sides, each in incident-list order
+            int slot_n = 0;
+            for (int pass = 0; pass < 2; ++pass)
                 for (int32_t n = n0; n < n1; ++n) {
-                    const unsigned short begin = (unsigned short)((int64_t)einc.size() - tile_inc0[t]);
+                    const unsigned short begin = (unsigned short)slot_n;
+                    for (int64_t k = rowptr[n]; k < rowptr[n + 1]; ++k) {
+                        const int64_t slot = inc[k] >> 1;
+                        if (slot >= slot_pr || (int)(slot >= G.rel.Epad) != pass) continue;
+                        side_slot[k] = (uint16_t)slot_n;
+                        if (pass == 0 && (inc[k] & 1)) rel_slot1[slot] = (uint16_t)slot_n;
+                        ++slot_n;
+                    }
+                    if (pass == 0) { node_rng[n].x = begin; node_rng[n].y = (unsigned short)slot_n; } else { node_rng[n].z = begin; node_rng[n].w = (unsigned short)slot_n; }
+                }
+            // lanes: pairs, then the other relative-pose sides, then the switchable sides
+            int n_pairs = 0;
+            for (int group = 0; group < 3; ++group) {
+                if (group == 2) tile_sw0[t] = (int32_t)(((int64_t)einc.size() - tile_inc0[t]) | ((int64_t)n_pairs << 16));
+                for (int32_t n = n0; n < n1; ++n)
                     for (int64_t k = rowptr[n]; k < rowptr[n + 1]; ++k) {
                         const int64_t slot = inc[k] >> 1; const int side = (int)(inc[k] & 1);
                         if (slot >= slot_pr) continue;
                         const bool is_sw = slot >= G.rel.Epad;
-                        if ((int)is_sw != pass) continue;
+                        if (is_sw != (group == 2)) continue;
                         const int64_t e = is_sw ? slot - G.rel.Epad : slot;
                         const int32_t a = L(is_sw ? p->swe.c1[e] : p->rel.c1[e]), b = L(is_sw ? p->swe.c2[e] : p->rel.c2[e]);
-                        einc.push_back((is_sw ? 0x80000000u : 0u) | (uint32_t)(e << 1) | (uint32_t)side);
-                        eoth.push_back(side == 0 ? b : a);
-                        eown.push_back((uint8_t)(n - n0));
+                        const int32_t other = side == 0 ? b : a;
+                        const bool paired = !is_sw && a != b && other >= n0 && other < n1;
+                        if (group == 0) {
+                            if (!paired || side != 0) continue;          // the pair's lane stands at side 0 (own = c1)
+                            einc.push_back((uint32_t)(e << 1));
+                            eoth.push_back(b);
+                            eslot.push_back((uint32_t)side_slot[k] | ((uint32_t)rel_slot1[e] << 9) | ((uint32_t)(n - n0) << 18));
+                            ++n_pairs;
+                        } else {
+                            if (group == 1 && paired) continue;
+                            einc.push_back((is_sw ? 0x80000000u : 0u) | (uint32_t)(e << 1) | (uint32_t)side);
+                            eoth.push_back(other);
+                            eslot.push_back((uint32_t)side_slot[k] | (511u << 9) | ((uint32_t)(n - n0) << 18));
+                        }
                     }
-                    const unsigned short end = (unsigned short)((int64_t)einc.size() - tile_inc0[t]);
-                    if (pass == 0) { node_rng[n].x = begin; node_rng[n].y = end; } else { node_rng[n].z = begin; node_rng[n].w = end; }
-                }
             }
         }
         tile_inc0[tiles] = (int64_t)einc.size();
+        p->mf_pair_lanes = 0; p->mf_sw_lanes = 0;
+        for (int t = 0; t < tiles; ++t) { p->mf_pair_lanes += (uint32_t)tile_sw0[t] >> 16; p->mf_sw_lanes += (tile_inc0[t + 1] - tile_inc0[t]) - (tile_sw0[t] & 0xffff); }
+        p->mf_rel_side_lanes = (int64_t)einc.size() - p->mf_pair_lanes - p->mf_sw_lanes;
         const int64_t ninc_e = (int64_t)einc.size();
         const int64_t ninc_pad = (ninc_e + 63) / 64 * 64 + 64;
-        HIPCHK(p, p->d_einc.ensure(std::max<int64_t>(ninc_e, 1))); HIPCHK(p, p->d_einc_ownl.ensure(std::max<int64_t>(ninc_e, 1))); HIPCHK(p, p->d_einc_other.ensure(std::max<int64_t>(ninc_e, 1)));
+        HIPCHK(p, p->d_einc.ensure(std::max<int64_t>(ninc_e, 1))); HIPCHK(p, p->d_einc_slot.ensure(std::max<int64_t>(ninc_e, 1))); HIPCHK(p, p->d_einc_other.ensure(std::max<int64_t>(ninc_e, 1)));
         HIPCHK(p, p->d_node_rng.ensure(std::max<int64_t>(N, 1))); HIPCHK(p, p->d_tile_inc0.ensure(tiles + 1)); HIPCHK(p, p->d_tile_node0.ensure(tiles + 1));
         HIPCHK(p, p->d_tile_sw0.ensure(std::max(tiles, 1))); HIPCHK(p, p->d_node_prior.ensure(std::max<int64_t>(N, 1)));
         HIPCHK(p, p->d_rec.ensure((size_t)MF_PLANES * ninc_pad)); HIPCHK(p, p->d_lam.ensure(std::max<int64_t>(N * 6, 1)));
         if (ninc_e) {
             HIPCHK(p, hipMemcpyAsync(p->d_einc.p, einc.data(), ninc_e * sizeof(uint32_t), hipMemcpyHostToDevice, p->st));
-            HIPCHK(p, hipMemcpyAsync(p->d_einc_ownl.p, eown.data(), ninc_e * sizeof(uint8_t), hipMemcpyHostToDevice, p->st));
+            HIPCHK(p, hipMemcpyAsync(p->d_einc_slot.p, eslot.data(), ninc_e * sizeof(uint32_t), hipMemcpyHostToDevice, p->st));
             HIPCHK(p, hipMemcpyAsync(p->d_einc_other.p, eoth.data(), ninc_e * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
         }
         HIPCHK(p, hipMemcpyAsync(p->d_node_rng.p, node_rng.data(), N * sizeof(ushort4), hipMemcpyHostToDevice, p->st));
@@ -440,7 +478,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
         if (tiles) HIPCHK(p, hipMemcpyAsync(p->d_tile_sw0.p, tile_sw0.data(), tiles * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
         HIPCHK(p, hipMemcpyAsync(p->d_node_prior.p, node_prior.data(), N * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
         HIPCHK(p, hipStreamSynchronize(p->st));
-        p->F = MfDev{p->d_einc.p, p->d_einc_other.p, p->d_einc_ownl.p, p->d_tile_inc0.p, p->d_tile_sw0.p, p->d_tile_node0.p, p->d_node_rng.p, p->d_node_prior.p,
+        p->F = MfDev{p->d_einc.p, p->d_einc_other.p, p->d_einc_slot.p, p->d_tile_inc0.p, p->d_tile_sw0.p, p->d_tile_node0.p, p->d_node_rng.p, p->d_node_prior.p,
                      p->d_rec.p, p->d_lam.p, ninc_e, ninc_pad, tiles};
     }
     // ---- work buffers
@@ -457,9 +495,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
     HIPCHK(p, p->d_cgvec.ensure(std::max<int64_t>(N * 42, 1)));
     p->n_part = std::max<int64_t>(MAX_PARTIALS, (G.rel.tiles + G.sw.tiles + 3) / 4 + 1);
     HIPCHK(p, p->d_part.ensure(p->n_part * 6));
-    HIPCHK(p, p->d_cgpart.ensure(MF_MAX_GRID + 2 * RZ_STRIDE + 16));
-    HIPCHK(p, p->d_res.ensure(8 + 4 * RES_MAX_PART));
-    p->R.ctl = reinterpret_cast<uint32_t*>(p->d_res.p); p->R.slots = p->d_res.p + 8;   // partial sums + 16 PCG scalars (C.scal)
+    HIPCHK(p, p->d_cgpart.ensure(MF_MAX_GRID + 2 * RZ_STRIDE + 16));   // partial sums + 16 PCG scalars (C.scal)
     HIPCHK(p, p->d_flags.ensure(8)); HIPCHK(p, p->d_scal.ensure(S_N));
     for (int k = 0; k < 2; ++k) { HIPCHK(p, p->d_pose[k].ensure(std::max<int64_t>(N * 8, 1))); HIPCHK(p, p->d_swv[k].ensure(std::max<int64_t>(S, 1))); }
     HIPCHK(p, p->d_delta_s.ensure(std::max<int64_t>(Es, 1))); HIPCHK(p, p->d_io.ensure(std::max<int64_t>(N * 7, 1)));
@@ -481,11 +517,13 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
     p->coarse_built = false; p->coarse_active = false; p->K = CoarseDev{};
     {
         int n_agg = p->opt.coarse_aggregates;
-        // a graph with no more keyframes than HALF the configured aggregates gets one aggregate per keyframe: the coarse operator IS the reduced system and the
-        // "preconditioner" its dense inverse (a direct solve; the PCG around it only refines); larger graphs: at least 8 keyframes per aggregate, but not fewer than half the
-        // configured number of aggregates: the dense inverse (cubic in the aggregates) is what small graphs pay for (scripts/gpu_small_graphs.py)
-        if (N <= n_agg / 2) n_agg = (int)N;
-        else n_agg = (int)std::min<int64_t>(n_agg, std::max<int64_t>(N / 8, n_agg / 2));
+        // a graph with no more keyframes than `half` (256 by default) gets one aggregate per keyframe: the coarse operator IS the reduced system and the "preconditioner"
+        // its dense inverse (a direct solve; the PCG around it only refines); larger graphs: at least 8 keyframes per aggregate, but not fewer than `half` aggregates — the
+        // dense inverse (cubic in the aggregates) is what small graphs pay for (scripts/gpu_small_graphs.py) — and at most coarse_aggregates (768: measured on
+        // chain-like session graphs of 6 000 - 23 000 keyframes, scripts/gpu_session_aggregates.py: 768 beats 512 by 3 - 45 %, 1024 and 1536 lose to the cubic inverse)
+        const int half = std::min(n_agg / 2, 256);
+        if (N <= half) n_agg = (int)N;
+        else n_agg = (int)std::min<int64_t>(n_agg, std::max<int64_t>(N / 8, half));
         if (n_agg >= 2 && !p->local_ids && (N + n_agg - 1) / n_agg <= 1024) {    // aggregates of thousands of keyframes are never used (build_coarse)
             const int m = (int)((N + n_agg - 1) / n_agg);
             n_agg = (int)((N + m - 1) / m);
@@ -818,9 +856,6 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
     };
     // hipGraph: capture one chunk (iterations 2 .. 2+every-1: no `first` kernel, even start) once per graph build and preconditioner, and replay it
     const bool want_graph = o.cg_use_graph && !p->local_ids && !p->cg_graph_failed;
-    // session-sized graphs: whole chunks of block-Jacobi iterations inside one resident kernel (pgo_resident_kernels.hpp)
-    const bool resident = !multi && p->built_mf && !p->coarse_active && !p->mg_active && o.resident_max_keyframes > 0 && p->N <= o.resident_max_keyframes;
-    const int resident_chunk = 256;
     auto ensure_graph = [&]() {
         const int mode = p->mg_active ? 2 : p->coarse_active ? 1 : 0;
         pgo_problem::CapturedChunk& cc = p->cg_chunk[mode];
@@ -850,12 +885,8 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
         return PGO_OK;
     };
     while (k < o.cg_max_iterations && !done) {
-        int chunk = std::min(every, o.cg_max_iterations - k);
-        if (resident && !p->coarse_active && !p->mg_active) {
-            chunk = std::min(resident_chunk, o.cg_max_iterations - k);
-            launch_pcg_resident(p->G, p->F, p->Sc, p->C, p->R, k, chunk, p->st);
-            k += chunk;
-        } else if (k >= 2 && chunk == every && want_graph && p->cg_graph && (k & 1) == 0) {
+        const int chunk = std::min(every, o.cg_max_iterations - k);
+        if (k >= 2 && chunk == every && want_graph && p->cg_graph && (k & 1) == 0) {
             HIPCHK(p, hipGraphLaunch(p->cg_graph, p->st));
             k += every;
         } else {
@@ -1313,7 +1344,7 @@ void pgo_options_init(pgo_options* o) {
     o->cg_early_reject_rho = -0.5;
     o->cg_mid_tolerance = 1e-4;
     o->cg_mid_reject_rho = -0.05;
-    o->coarse_aggregates = 512;
+    o->coarse_aggregates = 768;
     o->coarse_min_radius = 1e7;
     o->mg_min_keyframes = 24000;
     o->mg_omega = 0.9;
@@ -1322,7 +1353,6 @@ void pgo_options_init(pgo_options* o) {
     o->mg_passes = 3;
     o->mg_dense_max_nodes = 512;
     o->mg_switch_iterations = 400;
-    o->resident_max_keyframes = 0;
     o->cg_rel_tolerance = 1e-9;     // loosest decade that keeps the 10-iteration chi^2 of C3 within 1e-8 of the 1e-13 solve
     o->device_id = -1;
     o->verbosity = 0;
@@ -1366,9 +1396,9 @@ int pgo_destroy(pgo_problem* p) {
     p->d_flags.release(); p->d_scal.release(); p->d_pose[0].release(); p->d_pose[1].release(); p->d_swv[0].release(); p->d_swv[1].release();
     p->d_delta_s.release(); p->d_io.release(); p->d_tmp.release(); p->d_vio.release();
     p->d_mg_f64.release(); p->d_mg_i32.release(); p->d_mg_i64.release();
-    p->d_ccen.release(); p->d_cd.release(); p->d_cAc.release(); p->d_crc.release(); p->d_cblk_ptr.release(); p->d_ccontrib.release(); p->d_cblk_ab.release(); p->d_cagg_free.release(); p->d_cinfo.release(); p->d_cscr.release(); p->d_res.release(); p->d_cAcf.release();
+    p->d_ccen.release(); p->d_cd.release(); p->d_cAc.release(); p->d_crc.release(); p->d_cblk_ptr.release(); p->d_ccontrib.release(); p->d_cblk_ab.release(); p->d_cagg_free.release(); p->d_cinfo.release(); p->d_cscr.release(); p->d_cAcf.release();
     p->d_l2g.release(); p->d_sh_loc.release(); p->d_sh_pos.release(); p->d_own.release(); p->d_xbuf.release();
-    p->d_einc.release(); p->d_einc_ownl.release(); p->d_node_rng.release(); p->d_tile_inc0.release(); p->d_einc_other.release();
+    p->d_einc.release(); p->d_einc_slot.release(); p->d_node_rng.release(); p->d_tile_inc0.release(); p->d_einc_other.release();
     p->d_tile_node0.release(); p->d_tile_sw0.release(); p->d_node_prior.release(); p->d_rec.release(); p->d_lam.release();
     (void)hipStreamDestroy(p->st);
     delete p;
@@ -1745,12 +1775,13 @@ int pgo_time_kernel(pgo_problem* p, int32_t which, int32_t launches, double* avg
                           const int kk = rep == 0 ? 0 : i + 1;
                           if (which != 5) { if (p->built_mf) launch_mf_spmv(G, p->F, p->Sc, p->C, kk, 0.0, p->st); else launch_cg_spmv(G, p->C, kk, 0.0, p->st); }
                           if (which != 4) launch_cg_update(G, p->C, kk, p->built_mf ? mf_grid_size(p->F) : cg_grid_size(G), p->st);
-                          // Bytes this design moves per iteration, each array once.  Matrix-free matvec: per edge side the compact record (8 double2
-                          // planes; 11 for switchable sides) + 9 B of index data (+ a_inv for switchable sides); per keyframe z and p_prev read,
-                          // p and q written (4 x 48), damping 48, side ranges / regulariser index / free flag 13.  Update: r, q, p, x read, r, x, z
-                          // written (7 x 48), the fp32 block-Jacobi factor 96.  Block-CSR matvec: SURVEY.md 8d's assembled form.
-                          const double sides_rel = 2.0 * (double)G.rel.E, sides_sw = 2.0 * (double)G.sw.E;
-                          const double mv = p->built_mf ? sides_rel * (128.0 + 9.0) + sides_sw * (176.0 + 9.0 + 8.0) + N * (4.0 * 48.0 + 48.0 + 13.0)
+                          // Bytes this design moves per iteration, each array once.  Matrix-free matvec: per LANE (a relative-pose edge with both
+                          // keyframes in one tile is one lane, every other edge side its own) the compact record (8 double2 planes; 11 for switchable
+                          // sides) + 12 B of index data (+ a_inv for switchable sides); per keyframe z and p_prev read, p and q written (4 x 48),
+                          // damping 48, side ranges / regulariser index / free flag 13.  Update: r, q, p, x read, r, x, z written (7 x 48), the fp32
+                          // block-Jacobi factor 96.  Block-CSR matvec: SURVEY.md 8d's assembled form.
+                          const double lanes_rel = (double)(p->mf_pair_lanes + p->mf_rel_side_lanes), lanes_sw = (double)p->mf_sw_lanes;
+                          const double mv = p->built_mf ? lanes_rel * (128.0 + 12.0) + lanes_sw * (176.0 + 12.0 + 8.0) + N * (4.0 * 48.0 + 48.0 + 13.0)
                                                         : 288.0 * (N + 2.0 * E) + 4.0 * (N + 2.0 * E) + N * 4.0 * 48.0;
                           const double up = N * (7.0 * 48.0 + 96.0);
                           bytes = which == 2 ? mv + up : which == 4 ? mv : up;
