@@ -31,7 +31,9 @@ constexpr int K1_WAVES = 4;        // wavefronts (tiles) per K1 workgroup
 constexpr int WIN_MAX = 72;        // poses per LDS window: 46 KB of LDS per workgroup -> 3 workgroups/CU (measured 34.3 us; 96 poses / 2 per CU: 36.0 us)
 constexpr int WIN_STRIDE = 80;     // bytes per staged pose record (64 B + 16 B pad: conflict-free ds_read_b128)
 constexpr int MAX_PARTIALS = 1024; // grid cap for kernels that emit per-block partial sums
-constexpr int RZ_STRIDE = 2 * MAX_PARTIALS;   // one parity of the r.z partials: the update kernel's slots, then up to MAX_PARTIALS slots of the multigrid's fine prolongation
+constexpr int CG_MAX_GRID = 1024;   // cap on the PCG vector kernels' workgroups (= their r.z partial slots); 2048 (one trip per workgroup on C3) measured 46.5 vs 41.9 us per iteration
+constexpr int RZ_STRIDE = CG_MAX_GRID + MAX_PARTIALS;   // one parity of the r.z partials: the update kernel's slots, then up to MAX_PARTIALS slots of the multigrid's fine prolongation / the two-level solve
+constexpr int PQ_SLOTS = CG_MAX_GRID;   // p.q partial slots: the matvec's workgroups (MF_MAX_GRID matrix-free, the vector kernels' grid for block-CSR)
 constexpr int PRIOR_DOUBLES = 42;  // r6 + J1
 constexpr int MF_BLOCK = 256;      // lanes (edge sides) per workgroup tile of the matrix-free operator (measured per PCG iteration on C3:
                                    // 128 -> 49.2 us, 256 -> 42.8 us, 512 -> 44.4 us, 1024 -> 51.7 us)
@@ -142,6 +144,7 @@ struct MgLevelDev {
     double* pos; double* d;                                      // [n][3] position (centroid of the aggregate); offset to the parent's
     const int32_t* parent; const int32_t* agg_ptr; const int4* tile_info; const int2* tile_rows;   // tile_rows [tile][MG_TILE_ROWS]: block range of each row of the tile (no dependent tile_info -> rowptr load);   // nodes of level l+1: members contiguous; per workgroup tile {first aggregate, end aggregate, first row, end row}
     double* r; double* x; double* xt; double* xf;                // [n][6] restricted residual, pre-smoothed x, x + P x_next, final x
+    float* valf;                                                 // the blocks rounded to fp32, exactly symmetric: what the cycle streams
 };
 struct MgDev {
     int32_t n_levels;                    // levels 1..n_levels; the last one is dense (CoarseDev: Ac, rc = its residual, yc = its solution)
@@ -154,7 +157,7 @@ struct MgDev {
 struct CgDev {
     double* val; float* Lf; double* Dtot; double* b;   // Lf [N][24]: packed fp32 Cholesky factor of the block-Jacobi blocks
     double* x; double* r; double* r2; double* z; double* p; double* p2; double* q;   // r/r2 and p/p2 ping-pong by iteration parity
-    double* part_pq;      // [MAX_PARTIALS]
+    double* part_pq;      // [PQ_SLOTS]
     double* part_rz;      // [2][RZ_STRIDE]
     int32_t extra_rz;     // r.z partial slots that follow the update kernel's (written by the multigrid's level-1 kernel: the fine prolongation is fused into it)
     int32_t pad_;

@@ -957,7 +957,7 @@ __global__ void cgcg_scalars_init_kernel(CgDev C, const double* __restrict__ bb_
 static inline int cg_grid(const GraphDev& G) {
     const int64_t pairs = G.N * 3;       // cg_update: one lane per row pair -> one trip per workgroup up to MAX_PARTIALS * CG_BLOCK / 3 keyframes
     int64_t g = (pairs + CG_BLOCK - 1) / CG_BLOCK;
-    if (g > MAX_PARTIALS) g = MAX_PARTIALS;
+    if (g > CG_MAX_GRID) g = CG_MAX_GRID;
     if (g < 1) g = 1;
     return (int)g;
 }

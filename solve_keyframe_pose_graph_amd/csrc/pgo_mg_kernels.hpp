@@ -25,6 +25,56 @@ __device__ __forceinline__ void mg_row_accumulate(int64_t b, int64_t e, const in
     if (k < e) spmv_chunk<1, false>(col + k, val + (size_t)k * 36, c, x, nullptr, 0.0, acc);
 }
 
+// The cycle streams the level matrices in fp32 (valf: half the bytes of its dominant stream; a preconditioner needs no more), accumulating in fp64.
+template <int U>
+__device__ __forceinline__ void mg_chunk_f32(const int32_t* __restrict__ colp, const float* __restrict__ valp, int c, const double* __restrict__ x, double* acc) {
+    int32_t col[U];
+    float2 v[U][3];
+    double xx[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) col[u] = colp[u];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const float2* vp = reinterpret_cast<const float2*>(valp + (size_t)u * 36) + c;
+        v[u][0] = vp[0]; v[u][1] = vp[6]; v[u][2] = vp[12];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) xx[u] = x[(size_t)col[u] * 6 + c];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        acc[0] += (double)v[u][0].x * xx[u]; acc[1] += (double)v[u][0].y * xx[u]; acc[2] += (double)v[u][1].x * xx[u];
+        acc[3] += (double)v[u][1].y * xx[u]; acc[4] += (double)v[u][2].x * xx[u]; acc[5] += (double)v[u][2].y * xx[u];
+    }
+}
+__device__ __forceinline__ void mg_row_accumulate_f32(int64_t b, int64_t e, const int32_t* __restrict__ col, const float* __restrict__ val,
+                                                      const double* __restrict__ x, int c, double* acc) {
+    int64_t k = b;
+    for (; k + 4 <= e; k += 4) mg_chunk_f32<4>(col + k, val + (size_t)k * 36, c, x, acc);
+    if (k + 2 <= e) { mg_chunk_f32<2>(col + k, val + (size_t)k * 36, c, x, acc); k += 2; }
+    if (k < e) mg_chunk_f32<1>(col + k, val + (size_t)k * 36, c, x, acc);
+}
+// valf <- val, EXACTLY symmetric: a block below the diagonal is the transpose of the rounded block above it, a diagonal block takes its upper
+// triangle.  One wavefront per block row, lane l < 36 owns element l of a block (column-pair-major: (row, col) at (row/2)*12 + col*2 + (row&1)).
+__global__ __launch_bounds__(256) void mg_val_f32_kernel(MgLevelDev A) {
+    const int i = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+    if (i >= A.n || lane >= 36) return;
+    const int pr = lane / 12, rem = lane - pr * 12, col = rem >> 1, row = pr * 2 + (rem & 1);      // element (row, col) of the block
+    const int tr = bsr_idx(col, row);                                                               // where (col, row) lives
+    for (int64_t k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k) {
+        const int j = A.col[k];
+        double v;
+        if (j > i) v = A.val[(size_t)k * 36 + lane];
+        else if (j == i) v = row <= col ? A.val[(size_t)k * 36 + lane] : A.val[(size_t)k * 36 + tr];
+        else {
+            int64_t kt = A.rowptr[j];
+            const int64_t et = A.rowptr[j + 1];
+            while (kt < et && A.col[kt] != i) ++kt;
+            v = kt < et ? A.val[(size_t)kt * 36 + tr] : A.val[(size_t)k * 36 + lane];
+        }
+        A.valf[(size_t)k * 36 + lane] = (float)v;
+    }
+}
+
 // (P_i y)[k]:  dtheta_i = y_theta ; dt_i = y_t - 2 d_i x y_theta
 __device__ __forceinline__ double mg_prolong_comp(const double* y, const double* d, int k) {
     if (k < 3) return y[k];
@@ -200,6 +250,8 @@ void launch_mg_assemble(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, 
         hipLaunchKernelGGL(mg_galerkin_kernel, dim3((unsigned)((levels[l].nnzb + 3) / 4)), dim3(256), 0, st, levels[l - 1], levels[l]);
     for (int l = 0; l + 1 < M.n_levels; ++l)
         hipLaunchKernelGGL(mg_dinv_kernel, dim3((unsigned)((levels[l].n + 255) / 256)), dim3(256), 0, st, levels[l], omega, fail);
+    for (int l = 0; l + 1 < M.n_levels; ++l)
+        hipLaunchKernelGGL(mg_val_f32_kernel, dim3((unsigned)((levels[l].n + 3) / 4)), dim3(256), 0, st, levels[l]);
     const MgLevelDev& T = levels[M.n_levels - 1];
     (void)hipMemsetAsync(K.Ac, 0, (size_t)K.nc * K.nc * sizeof(double), st);
     if (K.nc > 6 * K.n_agg) hipLaunchKernelGGL(coarse_pad_identity_kernel, dim3((unsigned)((K.nc - 6 * K.n_agg + 63) / 64)), dim3(64), 0, st, K);
@@ -266,7 +318,7 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_down_kernel(MgLevelDev A, double*
         }
     }
     double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    if (live) mg_row_accumulate(rb.x, rb.y, A.col, A.val, A.x, c, acc);
+    if (live) mg_row_accumulate_f32(rb.x, rb.y, A.col, A.valf, A.x, c, acc);
     double* mine = xch + (size_t)threadIdx.x * 7;
 #pragma unroll
     for (int q = 0; q < 6; ++q) mine[q] = acc[q];
@@ -386,7 +438,7 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_up_kernel(MgLevelDev A, MgLevelDe
         }
     }
     double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    if (live) mg_row_accumulate(rb.x, rb.y, A.col, A.val, A.xt, c, acc);
+    if (live) mg_row_accumulate_f32(rb.x, rb.y, A.col, A.valf, A.xt, c, acc);
     double* mine = xch + (size_t)threadIdx.x * 7;
 #pragma unroll
     for (int q = 0; q < 6; ++q) mine[q] = acc[q];

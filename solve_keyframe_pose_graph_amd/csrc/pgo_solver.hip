@@ -495,7 +495,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
     HIPCHK(p, p->d_cgvec.ensure(std::max<int64_t>(N * 42, 1)));
     p->n_part = std::max<int64_t>(MAX_PARTIALS, (G.rel.tiles + G.sw.tiles + 3) / 4 + 1);
     HIPCHK(p, p->d_part.ensure(p->n_part * 6));
-    HIPCHK(p, p->d_cgpart.ensure(MF_MAX_GRID + 2 * RZ_STRIDE + 16));   // partial sums + 16 PCG scalars (C.scal)
+    HIPCHK(p, p->d_cgpart.ensure(PQ_SLOTS + 2 * RZ_STRIDE + 16));   // partial sums + 16 PCG scalars (C.scal)
     HIPCHK(p, p->d_flags.ensure(8)); HIPCHK(p, p->d_scal.ensure(S_N));
     for (int k = 0; k < 2; ++k) { HIPCHK(p, p->d_pose[k].ensure(std::max<int64_t>(N * 8, 1))); HIPCHK(p, p->d_swv[k].ensure(std::max<int64_t>(S, 1))); }
     HIPCHK(p, p->d_delta_s.ensure(std::max<int64_t>(Es, 1))); HIPCHK(p, p->d_io.ensure(std::max<int64_t>(N * 7, 1)));
@@ -510,7 +510,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
     C.val = p->d_val.p; C.Lf = p->d_Lf.p; C.Dtot = p->d_Dtot_b.p; C.b = p->d_Dtot_b.p + (size_t)N * 36;
     double* v = p->d_cgvec.p; const size_t n6 = (size_t)N * 6;
     C.x = v; C.r = v + n6; C.r2 = v + 2 * n6; C.z = v + 3 * n6; C.p = v + 4 * n6; C.p2 = v + 5 * n6; C.q = v + 6 * n6;
-    C.part_pq = p->d_cgpart.p; C.part_rz = p->d_cgpart.p + MF_MAX_GRID; C.scal = p->d_cgpart.p + MF_MAX_GRID + 2 * RZ_STRIDE; C.extra_rz = 0;
+    C.part_pq = p->d_cgpart.p; C.part_rz = p->d_cgpart.p + PQ_SLOTS; C.scal = p->d_cgpart.p + PQ_SLOTS + 2 * RZ_STRIDE; C.extra_rz = 0;
     C.flags = p->d_flags.p;
     // ---- two-level preconditioner: aggregates of consecutive keyframes and, per coarse 6x6 block (a <= b), the ordered list of fine
     // blocks that project onto it (single GPU; enough keyframes per aggregate to be worth it)
@@ -583,7 +583,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
             auto put64 = [&](const std::vector<int64_t>& v) { const size_t o = pi64.size(); pi64.insert(pi64.end(), v.begin(), v.end()); return o; };
             size_t nf64 = 0;
             auto take = [&](size_t cnt) { const size_t o = nf64; nf64 += (cnt + 1) & ~(size_t)1; return o; };
-            struct Off { size_t col, parent, agg_ptr, tile, tile_rows, rowptr, g_ptr, g_ent, val, Dinv, pos, d, r, x, xt, xf; };
+            struct Off { size_t col, parent, agg_ptr, tile, tile_rows, rowptr, g_ptr, g_ent, val, Dinv, pos, d, r, x, xt, xf, valf; };
             std::vector<Off> off((size_t)nl);
             const size_t o_agg0 = put32(H.agg0), o_mem0_ptr = put32(H.mem0_ptr), o_mem0 = put32(H.mem0);
             const size_t o_d0 = take((size_t)N * 3);
@@ -606,6 +606,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
                 o.rowptr = put64(A.rowptr); o.g_ptr = put64(A.g_ptr); o.g_ent = put64(A.g_ent);
                 o.val = take(A.col.size() * 36); o.Dinv = take((size_t)A.n * 36); o.pos = take((size_t)A.n * 3); o.d = take((size_t)A.n * 3);
                 o.r = take((size_t)A.n * 6); o.x = take((size_t)A.n * 6); o.xt = take((size_t)A.n * 6); o.xf = take((size_t)A.n * 6);
+                o.valf = take((A.col.size() * 36 + 1) / 2);      // fp32 copy of the blocks, carved out of the fp64 pool
             }
             const int n_top = H.L[nl - 1].n;
             const int nc = (6 * n_top + 63) / 64 * 64;
@@ -626,7 +627,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
                 D.n = A.n; D.n_next = l + 1 < nl ? H.L[l + 1].n : 0; D.tiles = A.tile_agg0.empty() ? 0 : (int32_t)A.tile_agg0.size() - 1; D.nnzb = (int64_t)A.col.size();
                 D.rowptr = b64 + o.rowptr; D.col = b32 + o.col; D.val = bf + o.val; D.g_ptr = b64 + o.g_ptr; D.g_ent = b64 + o.g_ent;
                 D.Dinv = bf + o.Dinv; D.pos = bf + o.pos; D.d = bf + o.d; D.parent = b32 + o.parent; D.agg_ptr = b32 + o.agg_ptr; D.tile_info = reinterpret_cast<const int4*>(b32 + o.tile); D.tile_rows = reinterpret_cast<const int2*>(b32 + o.tile_rows);
-                D.r = bf + o.r; D.x = bf + o.x; D.xt = bf + o.xt; D.xf = bf + o.xf;
+                D.r = bf + o.r; D.x = bf + o.x; D.xt = bf + o.xt; D.xf = bf + o.xf; D.valf = reinterpret_cast<float*>(bf + o.valf);
             }
             // the dense coarsest level shares the buffers of the two-level preconditioner, which the multigrid replaces on this graph
             p->coarse_built = false;
