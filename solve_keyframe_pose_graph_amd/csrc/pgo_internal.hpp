@@ -152,7 +152,11 @@ struct MgDev {
     const int32_t* agg0;                 // [N] level-1 node of each keyframe (-1: not part of the system)
     const int32_t* mem0_ptr; const int32_t* mem0;   // level-1 node -> keyframes
     double* d0;                          // [N][3] t_i - pos_1[agg0[i]]
+    // restriction inside the PCG's vector update: per run of MG_BLOCK0 consecutive keyframes (one workgroup trip of cg_update) the level-1 aggregates it holds,
+    // MG_BLOCK0 slots of {aggregate or -1, 8 member keyframes as run-local bytes (0xff: none)} — aggregates never cross a run boundary (pgo_mg_host.hpp)
+    const int4* blk_tab;                 // [runs][MG_BLOCK0] {aggregate, members 0-3, members 4-7, unused}; null: restriction by its own kernel
 };
+constexpr int MG_BLOCK0 = 64;
 
 struct CgDev {
     double* val; float* Lf; double* Dtot; double* b;   // Lf [N][24]: packed fp32 Cholesky factor of the block-Jacobi blocks
@@ -231,7 +235,10 @@ void launch_mg_geometry(const GraphDev& G, const MgDev& M, const MgLevelDev* lev
 // into K.Ac (K.nc padded), which is then inverted by launch_coarse_invert; *fail != 0: some diagonal block was not positive definite
 void launch_mg_assemble(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, double omega, int32_t* fail, hipStream_t st);
 // z += scale P V(P^T r) (every coarse correction inside V scaled alike), r.z partials updated in place (cg_update's workgroup -> slot mapping)
-void launch_mg_apply(const GraphDev& G, const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, const double* r, double* z, double* part_rz, double scale, bool inside_iteration, hipStream_t st);
+void launch_mg_apply(const GraphDev& G, const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, const double* r, double* z, double* part_rz, double scale, bool inside_iteration, hipStream_t st,
+                     bool restricted = false /* r_1 (and x_1) already formed by launch_cg_update_mg */);
+// cg_update + r_1 = P_0^T r', x_1 = w D_1^-1 r_1 of the multigrid (M.blk_tab)
+void launch_cg_update_mg(const GraphDev& G, const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, int k, int n_pq_partials, hipStream_t st);
 
 double k1_algorithmic_bytes(const GraphDev& G, bool want_jacobian);
 

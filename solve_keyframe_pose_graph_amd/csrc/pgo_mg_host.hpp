@@ -129,7 +129,7 @@ inline void build_blocks(int32_t n, std::vector<std::pair<int64_t, int64_t>>& tr
 // dense_max nodes (e.g. mostly isolated keyframes): the caller then runs without the multigrid.
 inline bool build_hierarchy(int64_t N, const std::vector<uint8_t>& node_free, const std::vector<int32_t>& rc1, const std::vector<int32_t>& rc2, const double* rmeas8 /* weight at [8 e + 7] */,
                             const std::vector<int32_t>& sc1, const std::vector<int32_t>& sc2, const double* sw_weight /* per switchable edge: s^2 of its switch at graph build, or nullptr = 1 */,
-                            int passes0, int passes, int dense_max, int tile_rows, int max_levels, Hierarchy& H, bool level0_follows_switchable = true) {
+                            int passes0, int passes, int dense_max, int tile_rows, int max_levels, Hierarchy& H, bool level0_follows_switchable = true, int level0_block = 0) {
     H = Hierarchy{};
     const int64_t Er = (int64_t)rc1.size(), Es = (int64_t)sc1.size();
     std::vector<WEdge> edges;
@@ -147,15 +147,32 @@ inline bool build_hierarchy(int64_t N, const std::vector<uint8_t>& node_free, co
     std::vector<uint8_t> skip((size_t)N);
     for (int64_t i = 0; i < N; ++i) skip[i] = node_free[i] ? 0 : 1;
     int32_t n1 = 0;
-    if (level0_follows_switchable) H.agg0 = match_passes((int32_t)N, edges, passes0, &skip, n1);
-    else {
+    std::vector<WEdge> rel_only;
+    if (!level0_follows_switchable) {
         // keyframes are grouped along relative-pose (odometry) edges only: a switchable loop closure may be an outlier the solver is about to
         // switch off, and an aggregate held together by nothing else would stop being a rigid piece; the levels above match along the summed
         // couplings of whole groups, where a single dead edge no longer decides anything
-        std::vector<WEdge> rel_only;
         rel_only.reserve((size_t)Er);
         for (int64_t e = 0; e < Er; ++e) if (node_free[rc1[e]] && node_free[rc2[e]]) { const double w = rmeas8[8 * e + 7]; if (w * w > 1e-8) rel_only.push_back({rc1[e], rc2[e], w * w}); }
-        H.agg0 = match_passes((int32_t)N, rel_only, passes0, &skip, n1);
+    }
+    H.agg0 = match_passes((int32_t)N, level0_follows_switchable ? edges : rel_only, passes0, &skip, n1);
+    if (level0_block > 0 && n1 >= 1) {
+        // The PCG's vector-update kernel works on consecutive runs of level0_block keyframes and restricts the new residual to the level-1 aggregates a run
+        // holds COMPLETELY (no restriction kernel of its own: -5 us per iteration).  Regular odometry chains match into such aggregates by themselves; an
+        // aggregate that does straddle a run boundary is cut there (one more, smaller aggregate per boundary at most).  Matching restricted to the runs from the
+        // start was measured instead and dropped: on the 4-world benchmark graph it changed the whole greedy matching and cost 12 % more PCG iterations.
+        std::vector<int64_t> first_run((size_t)n1, -1);
+        std::vector<std::pair<int64_t, int32_t>> extra;       // (aggregate * runs + run) -> new id, for the parts beyond an aggregate's first run
+        const int64_t runs = (N + level0_block - 1) / level0_block;
+        std::vector<std::pair<int64_t, int64_t>> parts;       // (aggregate * runs + run, keyframe) of keyframes outside their aggregate's first run
+        for (int64_t i = 0; i < N; ++i) if (H.agg0[i] >= 0) {
+            const int64_t r = i / level0_block; const int32_t a = H.agg0[i];
+            if (first_run[a] < 0) first_run[a] = r;
+            else if (first_run[a] != r) parts.push_back({(int64_t)a * runs + r, i});
+        }
+        std::sort(parts.begin(), parts.end());
+        int64_t prev = -1;
+        for (const auto& pr : parts) { if (pr.first != prev) { prev = pr.first; ++n1; } H.agg0[pr.second] = n1 - 1; }
     }
     if (n1 < 1) return false;
     // level-1 edge list

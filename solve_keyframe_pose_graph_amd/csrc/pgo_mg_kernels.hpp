@@ -511,11 +511,135 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_prolong0_kernel(GraphDev G, MgDev
     if (threadIdx.x == 0) part_rz[blockIdx.x] += s;
 }
 
-void launch_mg_apply(const GraphDev& G, const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, const double* r, double* z, double* part_rz, double scale, bool inside_iteration, hipStream_t st) {
+// cg_update_kernel + the multigrid's restriction to level 1.  A workgroup trip covers one run of MG_BLOCK0 keyframes; the level-1 aggregates never cross
+// a run boundary, so r_1 = P_0^T r' of the run's aggregates is formed from the new residual while it is still in LDS (members in list order, the
+// same sums as mg_restrict0_kernel) — and with it x_1 = w D_1^-1 r_1.  The slot table entries a lane needs are requested before the partial-sum
+// re-reduction, together with the vector operands.
+__global__ __launch_bounds__(CG_BLOCK) void cg_update_mg_kernel(GraphDev G, CgDev C, MgDev M, double* __restrict__ r1_out, double* __restrict__ x1_out, const double* __restrict__ Dinv1,
+                                                                 int parity, int nparts_pq, int nparts) {
+    static_assert(CG_BLOCK / 3 == MG_BLOCK0, "one workgroup trip of the vector update = one run of the slot table");
+    __shared__ double red[2 * (CG_BLOCK / 64)];
+    const double2* __restrict__ rin = reinterpret_cast<const double2*>(parity ? C.r2 : C.r);
+    double2* __restrict__ rout = reinterpret_cast<double2*>(parity ? C.r : C.r2);
+    const double2* __restrict__ pcur = reinterpret_cast<const double2*>(parity ? C.p2 : C.p);
+    const double2* __restrict__ qv = reinterpret_cast<const double2*>(C.q);
+    double2* __restrict__ xv = reinterpret_cast<double2*>(C.x);
+    double2* __restrict__ zv = reinterpret_cast<double2*>(C.z);
+    constexpr int KF = CG_BLOCK / 3;
+    const int t = threadIdx.x;
+    const int64_t pairs = G.N * 3;
+    const int64_t stride = (int64_t)gridDim.x * CG_BLOCK;
+    const int64_t trips = (pairs + stride - 1) / stride;
+    const int64_t i_first = (int64_t)blockIdx.x * CG_BLOCK + t;
+    double2 r0 = make_double2(0.0, 0.0), q0 = r0, p0 = r0, x0 = r0;
+    double d0 = 0.0, d1 = 0.0, d2 = 0.0;
+    int4 tab0 = make_int4(-1, -1, -1, 0), tab1 = tab0;
+    if (i_first < pairs) {
+        r0 = rin[i_first]; q0 = qv[i_first]; p0 = pcur[i_first]; x0 = xv[i_first];
+        const double* d = M.d0 + (size_t)(i_first / 3) * 3; d0 = d[0]; d1 = d[1]; d2 = d[2];
+    }
+    if ((int64_t)blockIdx.x * CG_BLOCK < pairs) {     // the run exists: its slots are served by all lanes, also those beyond the last keyframe
+        tab0 = M.blk_tab[(size_t)blockIdx.x * MG_BLOCK0 + t / 6];
+        tab1 = M.blk_tab[(size_t)blockIdx.x * MG_BLOCK0 + (t + CG_BLOCK) / 6];
+    }
+    if (cg_done(C)) return;
+    double pq, rz;
+    block_total2(C.part_pq, nparts_pq, C.part_rz + parity * RZ_STRIDE, nparts + C.extra_rz, red, pq, rz);
+    if (!(pq > 0.0)) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) C.flags[1] = 1;
+        if (threadIdx.x == 0) C.part_rz[(parity ^ 1) * RZ_STRIDE + blockIdx.x] = 0.0;
+        return;
+    }
+    const double alpha = rz / pq;
+    __shared__ double2 rnew[CG_BLOCK];
+    __shared__ double2 btr[CG_BLOCK];
+    __shared__ double rs[CG_BLOCK];
+    __shared__ __attribute__((aligned(16))) float lfs[KF * LF_STRIDE];
+    double acc = 0.0;
+    for (int64_t it = 0; it < trips; ++it) {
+        const int64_t run = it * gridDim.x + blockIdx.x;
+        const int64_t base = run * CG_BLOCK;
+        const int64_t i = base + t;
+        const bool live = i < pairs;
+        double2 rr = make_double2(0.0, 0.0);
+        if (live) {
+            if (it > 0) {
+                r0 = rin[i]; q0 = qv[i]; p0 = pcur[i]; x0 = xv[i];
+                const double* d = M.d0 + (size_t)(i / 3) * 3; d0 = d[0]; d1 = d[1]; d2 = d[2];
+            }
+            rr = make_double2(r0.x - alpha * q0.x, r0.y - alpha * q0.y);
+            x0.x += alpha * p0.x; x0.y += alpha * p0.y;
+            rout[i] = rr; xv[i] = x0;
+        }
+        if (it > 0) {
+            tab0.x = -1; tab1.x = -1;
+            if (base < pairs) { tab0 = M.blk_tab[(size_t)run * MG_BLOCK0 + t / 6]; tab1 = M.blk_tab[(size_t)run * MG_BLOCK0 + (t + CG_BLOCK) / 6]; }
+        }
+        __syncthreads();
+        lf_stage<KF>(C.Lf, base / 3, G.N, lfs);
+        rnew[t] = rr;
+        __syncthreads();
+        {
+            const int j = t % 3;
+            const double* r6 = reinterpret_cast<const double*>(rnew + (t - j));
+            double2 b;
+            if (j == 0) b = make_double2(r6[0] + 2.0 * (d1 * r6[5] - d2 * r6[4]), r6[1] + 2.0 * (d2 * r6[3] - d0 * r6[5]));
+            else if (j == 1) b = make_double2(r6[2] + 2.0 * (d0 * r6[4] - d1 * r6[3]), r6[3]);
+            else b = make_double2(r6[4], r6[5]);
+            btr[t] = b;
+            if (live) {
+                const double2 z = lf_apply_pair(lfs + (t / 3) * LF_STRIDE, r6, j);
+                zv[i] = z;
+                acc += rr.x * z.x + rr.y * z.y;
+            }
+        }
+        __syncthreads();
+        // r_1 of the run's aggregates: slot u / 6, component u % 6 (two rounds of the workgroup cover the MG_BLOCK0 slots)
+#pragma unroll
+        for (int round = 0; round < 2; ++round) {
+            const int4 tb = round ? tab1 : tab0;
+            const int c = (t + round * CG_BLOCK) % 6;
+            double sum = 0.0;
+            if (tb.x >= 0) {
+                const double* col = reinterpret_cast<const double*>(btr) + c;
+                const uint32_t lo = (uint32_t)tb.y, hi = (uint32_t)tb.z;
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const uint32_t kf = ((m < 4 ? lo >> (8 * m) : hi >> (8 * (m - 4))) & 0xffu);
+                    if (kf != 0xffu) sum += col[kf * 6];
+                }
+                r1_out[(size_t)tb.x * 6 + c] = sum;
+            }
+            if (x1_out) {
+                rs[t] = sum;
+                __syncthreads();
+                if (tb.x >= 0) {
+                    const double* Dk = Dinv1 + (size_t)tb.x * 36 + c * 6;
+                    const double* ra = rs + (t - c);
+                    double x = 0.0;
+#pragma unroll
+                    for (int jj = 0; jj < 6; ++jj) x += Dk[jj] * ra[jj];
+                    x1_out[(size_t)tb.x * 6 + c] = x;
+                }
+                __syncthreads();
+            }
+        }
+    }
+    const double s = block_sum(acc, red);
+    if (threadIdx.x == 0) C.part_rz[(parity ^ 1) * RZ_STRIDE + blockIdx.x] = s;
+}
+void launch_cg_update_mg(const GraphDev& G, const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, int k, int n_pq_partials, hipStream_t st) {
+    const int g = cg_grid(G);
+    if (M.n_levels == 1) hipLaunchKernelGGL(cg_update_mg_kernel, dim3(g), dim3(CG_BLOCK), 0, st, G, C, M, K.rc, (double*)nullptr, (const double*)nullptr, k & 1, n_pq_partials, g);
+    else hipLaunchKernelGGL(cg_update_mg_kernel, dim3(g), dim3(CG_BLOCK), 0, st, G, C, M, levels[0].r, levels[0].x, (const double*)levels[0].Dinv, k & 1, n_pq_partials, g);
+}
+void launch_mg_apply(const GraphDev& G, const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, const double* r, double* z, double* part_rz, double scale, bool inside_iteration, hipStream_t st,
+                     bool restricted) {
     const int32_t* stop = inside_iteration ? C.flags : nullptr;     // at PCG start the flag still belongs to the previous solve
     const int nl = M.n_levels;
     const unsigned g1 = (unsigned)((M.n1 + MG_TILE_ROWS - 1) / MG_TILE_ROWS);
-    if (nl == 1) hipLaunchKernelGGL(mg_restrict0_kernel, dim3(g1), dim3(CG_BLOCK), 0, st, M, r, K.rc, (double*)nullptr, (const double*)nullptr, stop);
+    if (restricted) {}
+    else if (nl == 1) hipLaunchKernelGGL(mg_restrict0_kernel, dim3(g1), dim3(CG_BLOCK), 0, st, M, r, K.rc, (double*)nullptr, (const double*)nullptr, stop);
     else hipLaunchKernelGGL(mg_restrict0_kernel, dim3(g1), dim3(CG_BLOCK), 0, st, M, r, levels[0].r, levels[0].x, (const double*)levels[0].Dinv, stop);
     for (int l = 1; l < nl; ++l) {                     // sparse level l -> level l+1
         const MgLevelDev& A = levels[l - 1];

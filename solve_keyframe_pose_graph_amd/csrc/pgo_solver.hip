@@ -574,7 +574,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
         std::vector<double> sw_w;
         if (sw_now && S > 0) { sw_w.resize((size_t)Es); for (int64_t e = 0; e < Es; ++e) { const double sv = sw_now[p->swe.sw[e]]; sw_w[e] = sv * sv; } }
         const bool ok = pgo_mg::build_hierarchy(N, p->h_node_free, p->rel.c1, p->rel.c2, p->rel.meas.data(), p->swe.c1, p->swe.c2, sw_w.empty() ? nullptr : sw_w.data(), std::max(1, std::min(p->opt.mg_first_passes, 3)),
-                                                std::max(1, std::min(p->opt.mg_passes, 3)), dense_max, MG_TILE_ROWS, MG_MAX_LEVELS, H, false);
+                                                std::max(1, std::min(p->opt.mg_passes, 3)), dense_max, MG_TILE_ROWS, MG_MAX_LEVELS, H, false, MG_BLOCK0);
         if (ok) {
             const int nl = (int)H.L.size();
             // pooled arrays: (offset, count) per array; doubles rounded up to even counts (16-B loads)
@@ -586,6 +586,30 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
             struct Off { size_t col, parent, agg_ptr, tile, tile_rows, rowptr, g_ptr, g_ent, val, Dinv, pos, d, r, x, xt, xf, valf; };
             std::vector<Off> off((size_t)nl);
             const size_t o_agg0 = put32(H.agg0), o_mem0_ptr = put32(H.mem0_ptr), o_mem0 = put32(H.mem0);
+            // slot table of the restriction inside the vector update: per run of MG_BLOCK0 keyframes its aggregates {id, 8 members as run-local bytes}
+            size_t o_blk_tab = 0; bool have_tab = true;
+            {
+                const int64_t runs = (N + MG_BLOCK0 - 1) / MG_BLOCK0;
+                std::vector<int32_t> tab((size_t)runs * MG_BLOCK0 * 4);
+                for (size_t k = 0; k < tab.size(); k += 4) { tab[k] = -1; tab[k + 1] = -1; tab[k + 2] = -1; tab[k + 3] = 0; }
+                std::vector<int> fill((size_t)runs, 0);
+                const int32_t n1h = (int32_t)H.mem0_ptr.size() - 1;
+                for (int32_t a = 0; a < n1h && have_tab; ++a) {
+                    const int32_t m0 = H.mem0_ptr[a], m1 = H.mem0_ptr[a + 1];
+                    if (m1 <= m0) continue;
+                    const int64_t run = H.mem0[m0] / MG_BLOCK0;
+                    if (m1 - m0 > 8 || fill[run] >= MG_BLOCK0) { have_tab = false; break; }
+                    uint32_t w[2] = {0xffffffffu, 0xffffffffu};
+                    for (int32_t m = m0; m < m1; ++m) {
+                        if (H.mem0[m] / MG_BLOCK0 != run) { have_tab = false; break; }
+                        const int j = m - m0;
+                        w[j >> 2] = (w[j >> 2] & ~(0xffu << (8 * (j & 3)))) | ((uint32_t)(H.mem0[m] - run * MG_BLOCK0) << (8 * (j & 3)));
+                    }
+                    int32_t* e = &tab[((size_t)run * MG_BLOCK0 + fill[run]++) * 4];
+                    e[0] = a; e[1] = (int32_t)w[0]; e[2] = (int32_t)w[1];
+                }
+                if (have_tab) { while (pi32.size() % 4) pi32.push_back(0); o_blk_tab = put32(tab); }
+            }
             const size_t o_d0 = take((size_t)N * 3);
             for (int l = 0; l < nl; ++l) {
                 const pgo_mg::HostLevel& A = H.L[l];
@@ -618,7 +642,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
             HIPCHK(p, hipMemsetAsync(p->d_crc.p, 0, (size_t)nc * 2 * sizeof(double), p->st));
             HIPCHK(p, hipStreamSynchronize(p->st));
             const int32_t* b32 = p->d_mg_i32.p; const int64_t* b64 = p->d_mg_i64.p; double* bf = p->d_mg_f64.p;
-            p->M = MgDev{nl, H.L[0].n, b32 + o_agg0, b32 + o_mem0_ptr, b32 + o_mem0, bf + o_d0};
+            p->M = MgDev{nl, H.L[0].n, b32 + o_agg0, b32 + o_mem0_ptr, b32 + o_mem0, bf + o_d0, have_tab ? reinterpret_cast<const int4*>(b32 + o_blk_tab) : nullptr};
             for (int l = 0; l < nl; ++l) {
                 const pgo_mg::HostLevel& A = H.L[l];
                 const Off& o = off[l];
@@ -848,9 +872,11 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
         int n_pq = cg_grid_size(p->G);
         if (p->built_mf) { launch_mf_spmv(p->G, p->F, p->Sc, p->C, kk, tol2, p->st); n_pq = mf_grid_size(p->F); }
         else launch_cg_spmv(p->G, p->C, kk, tol2, p->st);
-        launch_cg_update(p->G, p->C, kk, n_pq, p->st);
+        const bool mg_restrict_fused = p->mg_active && p->M.blk_tab != nullptr;      // the vector update also restricts the new residual to level 1
+        if (mg_restrict_fused) launch_cg_update_mg(p->G, p->C, p->M, p->mg_levels, p->K, kk, n_pq, p->st);
+        else launch_cg_update(p->G, p->C, kk, n_pq, p->st);
         // the new residual is in the OTHER r buffer, its r.z partials in the other parity's slots
-        if (p->mg_active) launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, (kk & 1) ? p->C.r : p->C.r2, p->C.z, p->C.part_rz + (size_t)((kk & 1) ^ 1) * RZ_STRIDE, mg_scale(p), true, p->st);
+        if (p->mg_active) launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, (kk & 1) ? p->C.r : p->C.r2, p->C.z, p->C.part_rz + (size_t)((kk & 1) ^ 1) * RZ_STRIDE, mg_scale(p), true, p->st, mg_restrict_fused);
         else if (p->coarse_active)
             launch_coarse_apply(p->G, p->C, p->K, (kk & 1) ? p->C.r : p->C.r2, p->C.z, p->C.part_rz + (size_t)((kk & 1) ^ 1) * RZ_STRIDE, true, p->st);
         return PGO_OK;
