@@ -419,7 +419,7 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_up_kernel(MgLevelDev A, MgLevelDe
     // FINE: everything the fine prolongation will need is requested now — keyframe, its aggregate's tile-local row, offset d, r and z of up to
     // four (keyframe, row pair) items per lane (<= 32 rows x 8 keyframes x 3 pairs per tile) — so that this chain runs beside the smoothing's
     constexpr int FT = FINE ? (MG_TILE_ROWS * 8 * 3 + CG_BLOCK - 1) / CG_BLOCK : 1;
-    int fn[FT], fa[FT]; double fd[FT][3]; double2 fr[FT], fz[FT];
+    int fn[FT], fa[FT]; double fd[FT][3]; double2 fz[FT];
     int fcnt = 0;
     if (FINE) {
         const int e0 = M.mem0_ptr[i0];
@@ -432,7 +432,6 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_up_kernel(MgLevelDev A, MgLevelDe
                 const int n = M.mem0[e0 + idx / 3], j = idx % 3;
                 fn[tt] = n * 3 + j; fa[tt] = M.agg0[n] - i0;
                 fd[tt][0] = M.d0[(size_t)n * 3]; fd[tt][1] = M.d0[(size_t)n * 3 + 1]; fd[tt][2] = M.d0[(size_t)n * 3 + 2];
-                fr[tt] = reinterpret_cast<const double2*>(rfine)[(size_t)n * 3 + j];
                 fz[tt] = reinterpret_cast<const double2*>(zfine)[(size_t)n * 3 + j];
             }
         }
@@ -462,7 +461,8 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_up_kernel(MgLevelDev A, MgLevelDe
     if (FINE) {
         __shared__ double red[CG_BLOCK / 64];
         __syncthreads();
-        double acc2 = 0.0;
+        // r.(P_0 x_1) = (P_0^T r).x_1 = r_1.x_1: the coarse part of r.z from this level's own vectors (the keyframes' r is not read again)
+        double acc2 = live ? scale * rv * xb[threadIdx.x] : 0.0;
 #pragma unroll
         for (int tt = 0; tt < FT; ++tt) {
             if (fn[tt] < 0) continue;
@@ -470,7 +470,6 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_up_kernel(MgLevelDev A, MgLevelDe
             const double* y = xb + (size_t)fa[tt] * 6;
             const double b0 = scale * mg_prolong_comp(y, fd[tt], 2 * j), b1 = scale * mg_prolong_comp(y, fd[tt], 2 * j + 1);
             reinterpret_cast<double2*>(zfine)[fn[tt]] = make_double2(fz[tt].x + b0, fz[tt].y + b1);
-            acc2 += fr[tt].x * b0 + fr[tt].y * b1;
         }
         const double s2 = block_sum(acc2, red);
         if (threadIdx.x == 0) part_extra[blockIdx.x] = s2;

@@ -883,10 +883,15 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
     };
     // hipGraph: capture one chunk (iterations 2 .. 2+every-1: no `first` kernel, even start) once per graph build and preconditioner, and replay it
     const bool want_graph = o.cg_use_graph && !p->local_ids && !p->cg_graph_failed;
-    auto ensure_graph = [&]() {
+    // Capture + instantiation cost about a millisecond: a PCG pays it only once it has run `graph_after` iterations eagerly (a graph that is rebuilt for every
+    // solve — the reference's sessions: one new loop edge, one solve — and converges in a few hundred iterations never does; eager launches keep up with
+    // 5-8 us kernels: measured 18.5 vs 19.4 ms at 300 keyframes, 64.0 vs 64.6 ms at 3000)
+    const int graph_after = 192;
+    auto ensure_graph = [&](bool may_capture) {
         const int mode = p->mg_active ? 2 : p->coarse_active ? 1 : 0;
         pgo_problem::CapturedChunk& cc = p->cg_chunk[mode];
         if (!want_graph || (cc.exec != nullptr && cc.epoch == p->build_epoch && cc.len == every)) { p->cg_graph = want_graph ? cc.exec : nullptr; return; }
+        if (!may_capture) { p->cg_graph = nullptr; return; }
         if (cc.exec) { (void)hipGraphExecDestroy(cc.exec); cc.exec = nullptr; }
         hipGraph_t gr = nullptr;
         bool ok = hipStreamBeginCapture(p->st, hipStreamCaptureModeThreadLocal) == hipSuccess;
@@ -900,7 +905,7 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
         else { cc.epoch = p->build_epoch; cc.len = every; }
         p->cg_graph = cc.exec;
     };
-    ensure_graph();
+    ensure_graph(k >= graph_after);
     // Chunks of `every` iterations; the convergence flag of chunk j is read (pinned memory + event) only AFTER chunk j+1 has been
     // enqueued, so the GPU never drains while the host polls.  A chunk enqueued after convergence is a string of early-exit kernels.
     int n_chunks = 0, waited = -1;
@@ -913,6 +918,7 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
     };
     while (k < o.cg_max_iterations && !done) {
         const int chunk = std::min(every, o.cg_max_iterations - k);
+        if (want_graph && !p->cg_graph && k >= graph_after && (k & 1) == 0) ensure_graph(true);
         if (k >= 2 && chunk == every && want_graph && p->cg_graph && (k & 1) == 0) {
             HIPCHK(p, hipGraphLaunch(p->cg_graph, p->st));
             k += every;
@@ -949,7 +955,7 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
             launch_cg_init_scalars(p->C, g, tol2, p->st);
             k = 0; n_chunks = 0; waited = -1;
             every = chunk_length();
-            ensure_graph();
+            ensure_graph(true);      // a system that needed the switch is a long one
         }
     }
     if (n_chunks > 0) {   // the state after the LAST enqueued chunk is the final one (kernels past convergence do nothing)
