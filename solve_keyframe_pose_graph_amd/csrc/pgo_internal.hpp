@@ -37,6 +37,7 @@ constexpr int PQ_SLOTS = CG_MAX_GRID;   // p.q partial slots: the matvec's workg
 constexpr int PRIOR_DOUBLES = 42;  // r6 + J1
 constexpr int MF_BLOCK = 256;      // lanes (edge sides) per workgroup tile of the matrix-free operator (measured per PCG iteration on C3:
                                    // 128 -> 49.2 us, 256 -> 42.8 us, 512 -> 44.4 us, 1024 -> 51.7 us)
+                                   // with one lane per in-tile edge (~4.2 lanes per keyframe on C3 instead of 6): 192 lanes -> 32.4 us per matvec, 256 -> 27.3 us
 constexpr int MF_MAX_NODES = 42;   // keyframes per tile (42 * 6 rows <= 256 lanes in the row phase; tiles of 60 keyframes with a second row pass measured slower: 43.5 vs 41.9 us per iteration on C3)
 constexpr int MF_SLOTS = 384;      // edge SIDES per tile (LDS contribution slots): a lane that serves both sides of an in-tile edge fills two
 constexpr int MF_MAX_GRID = 1024;  // cap on matvec workgroups = p.q partial sums (measured: 1024 capped 50.8 us/iteration vs one workgroup per tile 54.5 us)

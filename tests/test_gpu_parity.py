@@ -77,10 +77,12 @@ def test_normal_matrix_matches_oracle():
         assert abs(gs[e] - go[6 * N + e]) <= 1e-11 * max(1.0, np.abs(go).max())
 
 
+@pytest.mark.parametrize("shape", [(100, 20, 2), (260, 60, 5)])   # the second: f = 1..5 over 7 matvec tiles — edges served by one lane for both sides (both keyframes
+                                                                   # in a tile), edge sides whose other keyframe is in the neighbouring tile, loop closures far away
 @pytest.mark.parametrize("linear_solver", [0, 1])   # 0: assembled block-CSR, 1: matrix-free (default)
-def test_normal_operator_is_schur_complement(linear_solver):
+def test_normal_operator_is_schur_complement(linear_solver, shape):
     """K3: (H_reduced + damping) x on the device (both matvec forms) against the dense Schur complement built from the oracle's H."""
-    g = util.small_graph(100, 20, f=2, seed=2)
+    g = util.small_graph(shape[0], shape[1], f=shape[2], seed=2)
     O, P = _both(g, True, linear_solver=linear_solver)
     q, t, s = util.initial_state(g, True, perturb=0.02, seed=6)
     N, S = g.n_poses, g.n_loops
