@@ -11,7 +11,7 @@ g = graphgen.config("C3")
 q, t, s = util.initial_state(g, True)
 out = {}
 for name in ("plain", "rccl_1rank"):
-    P = util.pgo_problem(g, True)
+    P = util.pgo_problem(g, True, mg_min_keyframes=0, coarse_aggregates=0)     # block-Jacobi on both sides: the multi-rank PCG has no coarse levels
     if name != "plain":
         P.comm_init(0, 1, capi.Problem.comm_unique_id())
     P.solve(q, t, s)                      # warm-up (graph build, hipGraph capture)
@@ -22,4 +22,5 @@ for name in ("plain", "rccl_1rank"):
         P.comm_destroy()
     P.close()
 out["extra_us_per_cg_iteration"] = out["rccl_1rank"]["us_per_cg_iteration"] - out["plain"]["us_per_cg_iteration"]
-print(json.dumps(out, indent=1))
+print(json.dumps(out, indent=1), flush=True)
+open('gpurun_out/multi_overhead.json', 'w').write(json.dumps(out, indent=1))

@@ -180,6 +180,7 @@ void launch_build_rows(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, c
 void launch_mf_compact(const GraphDev& G, const MfDev& F, const double* pose8, const double* sw, hipStream_t st);
 void launch_mf_spmv(const GraphDev& G, const MfDev& F, const ScaleDev& Sc, const CgDev& C, int k, double tol2, hipStream_t st);
 void launch_mf_apply(const GraphDev& G, const MfDev& F, const ScaleDev& Sc, const CgDev& C, const double* x, double* y, hipStream_t st);
+void launch_mf_apply_dot(const GraphDev& G, const MfDev& F, const ScaleDev& Sc, const CgDev& C, const double* x, double* y, hipStream_t st);   // + partial sums of x.y in C.part_pq[0 .. mf_grid_size)
 void launch_invert_rows(const GraphDev& G, const CgDev& C, int32_t* fail_flag, hipStream_t st);
 void launch_cg_init(const GraphDev& G, const CgDev& C, int warm /*x holds a previous solution, q = A x*/, double tol2, hipStream_t st);
 // multi-GPU: the vector half of cg_init (owner-weighted partials of r.u in part_rz and of b.M^-1 b in part_pq); returns their count

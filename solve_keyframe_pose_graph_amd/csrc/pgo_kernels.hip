@@ -1191,11 +1191,11 @@ __global__ __launch_bounds__(MF_BLOCK) void mf_spmv_kernel(GraphDev G, MfDev F, 
                 }
             }
             if (FUSED) { pcur[vi] = pr; C.q[vi] = acc; pq += acc * pr; }
-            else yout[vi] = acc;
+            else { yout[vi] = acc; pq += acc * pr; }
         }
         __syncthreads();
     }
-    if (FUSED) {
+    if (FUSED || first == 2) {     // plain y = A x with first == 2: the partial sums of x.y as well (the multi-rank PCG's u.(A_r u))
         const double s = block_sum(pq, red);
         if (threadIdx.x == 0) C.part_pq[blockIdx.x] = s;
     }
@@ -1215,6 +1215,10 @@ void launch_mf_spmv(const GraphDev& G, const MfDev& F, const ScaleDev& Sc, const
 // two-level preconditioner, fused form (3 kernels per iteration): nparts = r.z partial slots of the update kernel (coarse_update_grid)
 void launch_mf_spmv_coarse(const GraphDev& G, const MfDev& F, const ScaleDev& Sc, const CgDev& C, const CoarseDev& K, int k, double tol2, int nparts, int pending, hipStream_t st) {
     hipLaunchKernelGGL((mf_spmv_kernel<true, true>), dim3(mf_grid(F)), dim3(MF_BLOCK), 0, st, G, F, Sc, C, (const double*)nullptr, (double*)nullptr, k & 1, k == 0 ? 1 : 0, nparts, tol2, K, pending);
+}
+// y = A x and the per-workgroup partial sums of x.y in C.part_pq[0 .. mf_grid_size): the multi-rank PCG's matvec and its u.(A_r u) in one kernel
+void launch_mf_apply_dot(const GraphDev& G, const MfDev& F, const ScaleDev& Sc, const CgDev& C, const double* x, double* y, hipStream_t st) {
+    hipLaunchKernelGGL((mf_spmv_kernel<false, false>), dim3(mf_grid(F)), dim3(MF_BLOCK), 0, st, G, F, Sc, C, x, y, 0, 2, 0, 0.0);
 }
 void launch_mf_apply(const GraphDev& G, const MfDev& F, const ScaleDev& Sc, const CgDev& C, const double* x, double* y, hipStream_t st) {
     hipLaunchKernelGGL((mf_spmv_kernel<false, false>), dim3(mf_grid(F)), dim3(MF_BLOCK), 0, st, G, F, Sc, C, x, y, 0, 1, 0, 0.0);

@@ -852,12 +852,12 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
     int rc;
     auto one_iteration = [&](int kk) -> int {
         if (multi) {
-            if (p->built_mf) launch_mf_apply(p->G, p->F, p->Sc, p->C, p->C.z, p->C.q, p->st);
-            else launch_apply_operator(p->G, p->C, p->C.z, p->C.q, p->st);
-            launch_cgcg_dots(p->G, p->C, p->st);
             const int g = cg_grid_size(p->G);
+            int g_pq = g;
+            if (p->built_mf) { launch_mf_apply_dot(p->G, p->F, p->Sc, p->C, p->C.z, p->C.q, p->st); g_pq = mf_grid_size(p->F); }   // w = A_r u and the partials of u.w in one kernel
+            else { launch_apply_operator(p->G, p->C, p->C.z, p->C.q, p->st); launch_cgcg_dots(p->G, p->C, p->st); }
             double* two = p->C.scal + 12;                                  // [delta, gamma]
-            launch_cg_reduce2_live(p->C, p->C.part_pq, g, p->C.part_rz, g, two, p->st);
+            launch_cg_reduce2_live(p->C, p->C.part_pq, g_pq, p->C.part_rz, g, two, p->st);
             int r2 = exchange_rows(p, p->C.q, 6, nullptr, 0, two, 2, p->C.flags);   // the ONE exchange per CG iteration
             if (r2 != PGO_OK) return r2;
             launch_cgcg_update(p->G, p->C, kk, kk == 0 ? 1 : 0, p->st);   // also when a PCG that stopped before its first update is resumed: p = s = 0 still
