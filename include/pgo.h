@@ -131,7 +131,9 @@ typedef struct pgo_options {
                                           *      chain with few loops (C2) is better off with the two-level method (0.32 vs 0.42 s) */
     double coarse_min_radius;            /* 1e7 (measured on the 100k-keyframe benchmark graph, 196 keyframes per aggregate: at radius 1e5..1e6 the coarse space saves 1.3x
                                           *      iterations at 2.7x the cost per iteration — and its comparison run doubled the cost of that LM step) */
-    double mg_omega;                     /* 0.9 */
+    double mg_omega;                     /* 0.9 (block-Jacobi damping of the level smoothers; values in (0, 1] are accepted.  Measured on C3 / C4, 20 steps: 0.7 0.490 / 3.70 s,
+                                          *      0.8 0.478 / 3.57, 0.9 0.469 / 3.48, 1.0 0.465 / 3.46; from 1.1 on the smoother diverges on some level — the cycle is no longer
+                                          *      positive definite, the PCG breaks down and the LM iterates leave the exact-solve path — so 1.0 has no margin and 0.9 stays) */
     double mg_correction_scale;          /* 1.0 (1.6 saves 15-25 % of the iterations on the first linearisation at radius >= 1e6 and costs 5-10 % on later ones) */
     int32_t mg_first_passes;             /* 3 */
     int32_t mg_passes;                   /* 3 (one level less than with 2 at +6 % iterations: 3 % faster on C3 and C4, each level costs two ~10-us kernels) */
