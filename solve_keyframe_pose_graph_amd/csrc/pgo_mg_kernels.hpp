@@ -125,45 +125,65 @@ void launch_mg_geometry(const GraphDev& G, const MgDev& M, const MgLevelDev* lev
 // ---- Galerkin products ----
 // level 1 from the keyframe system: one wavefront per block; contributions as in coarse_assemble_kernel (reduced diagonal blocks C.Dtot and,
 // per edge, J1^T J2 - c1 c2^T / a recomputed from K1's Jacobians), summed in list order
+// one contribution of the keyframe system to a level-1 block: the fine 6x6 block (lane's element) and the two keyframes it couples
+__device__ __forceinline__ double mg_fine_block(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, int64_t ent, int lane, int r, int c, bool own, int64_t& ni, int64_t& nj) {
+    const int kind = (int)(ent & 7);
+    const int64_t idx = ent >> 3;
+    double h = 0.0;
+    if (kind == 0) {
+        ni = nj = idx;
+        if (own) h = C.Dtot[(size_t)idx * 36 + lane];
+    } else {
+        const bool is_sw = kind >= 3;
+        const bool transposed = kind == 2 || kind == 4;
+        const EdgeClassDev& E = is_sw ? G.sw : G.rel;
+        const int D = is_sw ? SW_DOUBLES : REL_DOUBLES;
+        const int o1 = is_sw ? 14 : 6, o2 = is_sw ? 50 : 42;
+        const int32_t c1 = E.c1[idx], c2 = E.c2[idx];
+        ni = transposed ? c2 : c1; nj = transposed ? c1 : c2;
+        if (own) {
+            const int oa = transposed ? o2 : o1, ob = transposed ? o1 : o2;
+#pragma unroll
+            for (int kk = 0; kk < 6; ++kk) h += E.J[tile_elem(D, idx, oa + kk * 6 + r)] * E.J[tile_elem(D, idx, ob + kk * 6 + c)];
+            if (is_sw) {
+                const double* cc = L.c + (size_t)idx * 12;
+                h -= cc[(transposed ? 6 : 0) + r] * cc[(transposed ? 0 : 6) + c] * Sc.a_inv[idx];
+            }
+        }
+    }
+    return h;
+}
+// Two contributions are fetched together (their entry -> endpoints -> Jacobian load chains overlap) and then projected one after the other, in
+// list order: the sums are those of the one-at-a-time loop.
 __global__ __launch_bounds__(256) void mg_galerkin0_kernel(GraphDev G, LinDev L, ScaleDev Sc, CgDev C, MgDev M, MgLevelDev A) {
-    __shared__ double Hs[4][36];
+    __shared__ double Hs[4][2][36];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t slot = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (slot >= A.nnzb) return;
     const int r = lane / 6, c = lane - r * 6;
     const bool own = lane < 36;
     double acc = 0.0;
-    for (int64_t k = A.g_ptr[slot]; k < A.g_ptr[slot + 1]; ++k) {
-        const int64_t ent = A.g_ent[k];
-        const int kind = (int)(ent & 7);
-        const int64_t idx = ent >> 3;
-        int64_t ni, nj;
-        double h = 0.0;
-        if (kind == 0) {
-            ni = nj = idx;
-            if (own) h = C.Dtot[(size_t)idx * 36 + lane];
-        } else {
-            const bool is_sw = kind >= 3;
-            const bool transposed = kind == 2 || kind == 4;
-            const EdgeClassDev& E = is_sw ? G.sw : G.rel;
-            const int D = is_sw ? SW_DOUBLES : REL_DOUBLES;
-            const int o1 = is_sw ? 14 : 6, o2 = is_sw ? 50 : 42;
-            const int32_t c1 = E.c1[idx], c2 = E.c2[idx];
-            ni = transposed ? c2 : c1; nj = transposed ? c1 : c2;
-            if (own) {
-                const int oa = transposed ? o2 : o1, ob = transposed ? o1 : o2;
-#pragma unroll
-                for (int kk = 0; kk < 6; ++kk) h += E.J[tile_elem(D, idx, oa + kk * 6 + r)] * E.J[tile_elem(D, idx, ob + kk * 6 + c)];
-                if (is_sw) {
-                    const double* cc = L.c + (size_t)idx * 12;
-                    h -= cc[(transposed ? 6 : 0) + r] * cc[(transposed ? 0 : 6) + c] * Sc.a_inv[idx];
-                }
-            }
+    const int64_t k1 = A.g_ptr[slot + 1];
+    int64_t k = A.g_ptr[slot];
+    for (; k + 2 <= k1; k += 2) {
+        const int64_t e0 = A.g_ent[k], e1 = A.g_ent[k + 1];
+        int64_t ni0, nj0, ni1, nj1;
+        const double h0 = mg_fine_block(G, L, Sc, C, e0, lane, r, c, own, ni0, nj0);
+        const double h1 = mg_fine_block(G, L, Sc, C, e1, lane, r, c, own, ni1, nj1);
+        if (own) { Hs[wv][0][lane] = h0; Hs[wv][1][lane] = h1; }
+        __builtin_amdgcn_wave_barrier();
+        if (own) {
+            acc += coarse_entry(Hs[wv][0], M.d0 + (size_t)ni0 * 3, M.d0 + (size_t)nj0 * 3, r, c);
+            acc += coarse_entry(Hs[wv][1], M.d0 + (size_t)ni1 * 3, M.d0 + (size_t)nj1 * 3, r, c);
         }
-        if (own) Hs[wv][lane] = h;
         __builtin_amdgcn_wave_barrier();
-        if (own) acc += coarse_entry(Hs[wv], M.d0 + (size_t)ni * 3, M.d0 + (size_t)nj * 3, r, c);
+    }
+    if (k < k1) {
+        int64_t ni, nj;
+        const double h = mg_fine_block(G, L, Sc, C, A.g_ent[k], lane, r, c, own, ni, nj);
+        if (own) Hs[wv][0][lane] = h;
         __builtin_amdgcn_wave_barrier();
+        if (own) acc += coarse_entry(Hs[wv][0], M.d0 + (size_t)ni * 3, M.d0 + (size_t)nj * 3, r, c);
     }
     if (own) A.val[(size_t)slot * 36 + bsr_idx(r, c)] = acc;
 }
