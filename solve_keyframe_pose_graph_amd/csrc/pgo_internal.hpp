@@ -173,7 +173,7 @@ struct CgDev {
 // ---- launchers (pgo_kernels.hip).  All asynchronous on `st`. ----
 void launch_k1(const GraphDev& G, const double* pose8, const double* sw, bool want_jacobian, double* partials /*[MAX_PARTIALS]*/, int* n_partials, hipStream_t st);
 void launch_prior(const GraphDev& G, const double* pose8, bool want_jacobian, double* partial_cost /*1 double*/, hipStream_t st);
-void launch_k2(const GraphDev& G, const LinDev& L, bool want_offdiag, hipStream_t st);
+void launch_k2(const GraphDev& G, const LinDev& L, bool want_offdiag, hipStream_t st, const MfDev* F = nullptr /* matrix-free tiles: the per-keyframe sums run on them */);
 void launch_scale_init(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, int jacobi_scaling, hipStream_t st);
 void launch_lm_diag(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, double min_diag, double max_diag, hipStream_t st);
 void launch_build_rows(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, double radius, int add_lambda, double* lam_out /*null: write BSR blocks*/, hipStream_t st);

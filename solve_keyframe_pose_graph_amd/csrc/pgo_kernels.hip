@@ -354,8 +354,111 @@ __global__ __launch_bounds__(256) void k2_edge_kernel(GraphDev G, LinDev L, int 
     }
 }
 
-void launch_k2(const GraphDev& G, const LinDev& L, bool want_offdiag, hipStream_t st) {
-    if (G.N > 0) hipLaunchKernelGGL(k2_node_kernel, dim3((unsigned)((G.N + 255) / 256)), dim3(256), 0, st, G, L);
+// K2 on the matrix-free operator's tiles (round 2): one lane per matvec lane — an edge side, or BOTH sides of an edge whose keyframes share the tile —
+// loads the side's 6 x 6 Jacobian block and r6 from K1's output (21 or 39 double2 in flight per lane before the first use: consecutive lanes are
+// consecutive edges of a few interleaved streams, so the loads coalesce into 256-B runs) and writes the 21 + 6 numbers of J^T J (upper triangle) and
+// J^T r into the side's LDS slot (two rounds of 14 and 13 outputs: 43 KB of LDS, so that a CU holds three workgroups in different phases; with all 27 at
+// once, 83 KB and one workgroup per CU, the kernel measured 90 us on C3); then one lane per (keyframe, output) sums the keyframe's slots in incident-list
+// order — the order of the lane-per-keyframe kernel above, so the sums are bit-identical to it — adds the regulariser and stores Hd (both triangles) and g.
+constexpr int K2_OUT = 27, K2_HALF = 14;      // outputs per keyframe: 21 of the upper triangle + 6 of g; done in two rounds of <= 14 so that two to three workgroups share a CU's LDS
+template <int LO, int HI>
+__device__ __forceinline__ void k2_side_products(const double* J, const double* r, double* out /* LDS slot, K2_HALF doubles */) {
+    int idx = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+        for (int c = a; c < 6; ++c) {
+            if (idx >= LO && idx < HI) {
+                double sum = 0.0;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) sum += J[i * 6 + a] * J[i * 6 + c];
+                out[idx - LO] = sum;
+            }
+            ++idx;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        if (21 + a >= LO && 21 + a < HI) {
+            double ga = 0.0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) ga += J[i * 6 + a] * r[i];
+            out[21 + a - LO] = ga;
+        }
+    }
+}
+template <int LO, int HI>
+__device__ __forceinline__ void k2_reduce_round(const GraphDev& G, const LinDev& L, const MfDev& F, const double* sl, int n0, int nn, int l) {
+    constexpr int W = HI - LO;
+    for (int t = l; t < nn * W; t += MF_BLOCK) {
+        const int nl = t / W, j = LO + (t - nl * W);
+        const int64_t node = (int64_t)n0 + nl;
+        const ushort4 rg = F.node_rng[node];
+        double acc = 0.0;
+        for (int q = rg.x; q < rg.y; ++q) acc += sl[q * K2_HALF + (j - LO)];
+        for (int q = rg.z; q < rg.w; ++q) acc += sl[q * K2_HALF + (j - LO)];
+        // which output this is: j < 21 -> (a, c) of the upper triangle in row-major order, else g[j - 21]
+        int a = 0, c = j;
+        if (j < 21) { int left = j; while (left >= 6 - a) { left -= 6 - a; ++a; } c = a + left; }
+        const int32_t pk = F.node_prior[node];
+        if (pk >= 0) {
+            const double* base = G.Jp + (size_t)pk * PRIOR_DOUBLES;
+            double sum = 0.0;
+            if (j < 21) { for (int ii = 0; ii < 6; ++ii) sum += base[6 + ii * 6 + a] * base[6 + ii * 6 + c]; }
+            else { for (int ii = 0; ii < 6; ++ii) sum += base[6 + ii * 6 + (j - 21)] * base[ii]; }
+            acc += sum;
+        }
+        if (j < 21) { L.Hd[(size_t)node * 36 + a * 6 + c] = acc; L.Hd[(size_t)node * 36 + c * 6 + a] = acc; }
+        else L.g[(size_t)node * 6 + (j - 21)] = acc;
+    }
+}
+__global__ __launch_bounds__(MF_BLOCK) void k2_tiles_kernel(GraphDev G, LinDev L, MfDev F) {
+    __shared__ double sl[MF_SLOTS * K2_HALF];
+    const int tile = blockIdx.x, l = threadIdx.x;
+    const int64_t i0 = F.tile_inc0[tile], i1 = F.tile_inc0[tile + 1];
+    const int32_t n0 = F.tile_node0[tile], n1 = F.tile_node0[tile + 1];
+    const int sw0 = F.tile_sw0[tile] & 0xffff, pair1 = (int)((uint32_t)F.tile_sw0[tile] >> 16);
+    const int64_t i = i0 + l;
+    const bool have = i < i1;
+    const bool pair = have && l < pair1;
+    int slot_a = 0, slot_b = 0;
+    double r[6], Ja[36], Jb[36];
+    if (have) {
+        const uint32_t ent = F.einc[i];
+        const uint32_t slw = F.einc_slot[i];
+        slot_a = (int)(slw & 511u); slot_b = (int)((slw >> 9) & 511u);
+        const bool is_sw = l >= sw0;
+        const int side = (int)(ent & 1u);
+        const int64_t e = (int64_t)((ent & 0x7fffffffu) >> 1);
+        const double2* base = reinterpret_cast<const double2*>((is_sw ? G.sw.J : G.rel.J) + tile_elem(is_sw ? SW_DOUBLES : REL_DOUBLES, e, 0));
+        const int o1 = is_sw ? 7 : 3, o2 = is_sw ? 25 : 21;
+#pragma unroll
+        for (int kp = 0; kp < 3; ++kp) { const double2 v = base[kp * TILE]; r[2 * kp] = v.x; r[2 * kp + 1] = v.y; }
+        const int oa = side ? o2 : o1;
+#pragma unroll
+        for (int kp = 0; kp < 18; ++kp) { const double2 v = base[(oa + kp) * TILE]; Ja[2 * kp] = v.x; Ja[2 * kp + 1] = v.y; }
+        if (pair) {
+#pragma unroll
+            for (int kp = 0; kp < 18; ++kp) { const double2 v = base[(o2 + kp) * TILE]; Jb[2 * kp] = v.x; Jb[2 * kp + 1] = v.y; }
+        }
+        k2_side_products<0, K2_HALF>(Ja, r, sl + slot_a * K2_HALF);
+        if (pair) k2_side_products<0, K2_HALF>(Jb, r, sl + slot_b * K2_HALF);
+    }
+    __syncthreads();
+    const int nn = n1 - n0;
+    k2_reduce_round<0, K2_HALF>(G, L, F, sl, n0, nn, l);
+    __syncthreads();
+    if (have) {
+        k2_side_products<K2_HALF, K2_OUT>(Ja, r, sl + slot_a * K2_HALF);
+        if (pair) k2_side_products<K2_HALF, K2_OUT>(Jb, r, sl + slot_b * K2_HALF);
+    }
+    __syncthreads();
+    k2_reduce_round<K2_HALF, K2_OUT>(G, L, F, sl, n0, nn, l);
+}
+
+void launch_k2(const GraphDev& G, const LinDev& L, bool want_offdiag, hipStream_t st, const MfDev* F) {
+    if (F && F->tiles > 0) hipLaunchKernelGGL(k2_tiles_kernel, dim3((unsigned)F->tiles), dim3(MF_BLOCK), 0, st, G, L, *F);
+    else if (G.N > 0) hipLaunchKernelGGL(k2_node_kernel, dim3((unsigned)((G.N + 255) / 256)), dim3(256), 0, st, G, L);
     // the matrix-free operator needs only the switch couplings: skip the relpose part of the edge range entirely
     const int64_t first = want_offdiag ? 0 : G.rel.Epad;
     const int64_t ne = G.rel.Epad + G.sw.Epad - first;

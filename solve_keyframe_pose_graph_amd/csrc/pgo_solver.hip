@@ -766,7 +766,7 @@ int read_scalars(pgo_problem* p, double* h) {
 int linearize(pgo_problem* p, double* cost_out) {
     int rc;
     if ((rc = run_k1(p, p->cur, true)) != PGO_OK) return rc;
-    launch_k2(p->G, p->L, !p->built_mf, p->st);
+    launch_k2(p->G, p->L, !p->built_mf, p->st, p->built_mf ? &p->F : nullptr);
     ++p->lin_epoch;
     if (p->built_mf) launch_mf_compact(p->G, p->F, p->d_pose[p->cur].p, p->d_swv[p->cur].p, p->st);
     if ((rc = exchange_rows(p, p->L.Hd, 36, p->L.g, 6, nullptr, 0)) != PGO_OK) return rc;   // diagonal blocks + gradient of shared keyframes
@@ -1803,7 +1803,7 @@ int pgo_time_kernel(pgo_problem* p, int32_t which, int32_t launches, double* avg
         for (int i = 0; i < n; ++i) {
             switch (which) {
                 case 0: launch_k1(G, p->d_pose[p->cur].p, p->d_swv[p->cur].p, true, part(p, 0), &np, p->st); bytes = k1_algorithmic_bytes(G, true); break;
-                case 1: launch_k2(G, p->L, !p->built_mf, p->st); bytes = (624.0 * G.rel.E + 688.0 * Es) + 288.0 * E + 336.0 * N + 112.0 * Es; break;
+                case 1: launch_k2(G, p->L, !p->built_mf, p->st, p->built_mf ? &p->F : nullptr); bytes = (624.0 * G.rel.E + 688.0 * Es) + 288.0 * E + 336.0 * N + 112.0 * Es; break;
                 case 2: case 4: case 5: {   // one PCG iteration (2), its matvec alone (4), its vector update alone (5)
                           const int kk = rep == 0 ? 0 : i + 1;
                           if (which != 5) { if (p->built_mf) launch_mf_spmv(G, p->F, p->Sc, p->C, kk, 0.0, p->st); else launch_cg_spmv(G, p->C, kk, 0.0, p->st); }
