@@ -136,7 +136,7 @@ typedef struct pgo_options {
                                           *      positive definite, the PCG breaks down and the LM iterates leave the exact-solve path — so 1.0 has no margin and 0.9 stays) */
     double mg_correction_scale;          /* 1.0 (1.6 saves 15-25 % of the iterations on the first linearisation at radius >= 1e6 and costs 5-10 % on later ones) */
     int32_t mg_first_passes;             /* 3 */
-    int32_t mg_passes;                   /* 3 (one level less than with 2 at +6 % iterations: 3 % faster on C3 and C4, each level costs two ~10-us kernels) */
+    int32_t mg_passes;                   /* 3; values 1..3 (measured with up to 5 on the final build, C3 / C4 20 steps: 3: 0.467 / 3.46 s, 4: 0.514 / 4.36 s, 5: 0.621 / 4.81 s) (one level less than with 2 at +6 % iterations: 3 % faster on C3 and C4, each level costs two ~10-us kernels) */
     int32_t mg_dense_max_nodes;          /* 512 (dense coarsest operator of <= 3072 unknowns) */
     int32_t mg_switch_iterations;        /* 400: every PCG starts with plain block-Jacobi (most LM systems — small trust regions, steps about to be
                                           *      rejected — need a few hundred cheap iterations); one that has not converged after this many iterations
