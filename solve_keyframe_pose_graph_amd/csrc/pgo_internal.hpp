@@ -40,7 +40,8 @@ constexpr int MF_BLOCK = 256;      // lanes (edge sides) per workgroup tile of t
                                    // with one lane per in-tile edge (~4.2 lanes per keyframe on C3 instead of 6): 192 lanes -> 32.4 us per matvec, 256 -> 27.3 us
 constexpr int MF_MAX_NODES = 42;   // keyframes per tile (42 * 6 rows <= 256 lanes in the row phase; tiles of 60 keyframes with a second row pass measured slower: 43.5 vs 41.9 us per iteration on C3)
 constexpr int MF_SLOTS = 384;      // edge SIDES per tile (LDS contribution slots): a lane that serves both sides of an in-tile edge fills two
-constexpr int MF_MAX_GRID = 1024;  // cap on matvec workgroups = p.q partial sums (measured: 1024 capped 50.8 us/iteration vs one workgroup per tile 54.5 us)
+constexpr int MF_MAX_GRID = 1024;  // cap on matvec workgroups = p.q partial sums = what 256 CUs hold at 4 workgroups each (measured per matvec on C3 / C4 with the round-2 lanes:
+                                   // 512: 34.1 / 57.2 us, 768: 29.2 / 49.4, 896: 28.9 / 49.5, 1024: 27.3 / 45.3, 1536: 30.4 / 52.1, 2560: 34.6 / 51.8)
 constexpr int MF_PLANES = 11;      // COMPACT_DOUBLES / 2 double2 planes
 
 struct PriorDev {        // NodePoseRegularization target (rigid), see prior_residual()
