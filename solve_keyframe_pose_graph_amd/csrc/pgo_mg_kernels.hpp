@@ -8,7 +8,8 @@
 //   dense       x_top = A_top^-1 r_top (explicit inverse) ; xt = x + s P x_top on the level below   (s = mg_correction_scale)
 //   up(l)       x_l = xt_l + w D_l^-1 (r_l - A_l xt_l) ; xt_{l-1} = x_{l-1} + P x_l                  l = n_levels-1 .. 1
 //   prolong0    z += P_0 x_1, r.z partials updated in cg_update's slots
-// i.e. 2 n_levels + 1 small kernels; every sum runs in a fixed order (bitwise reproducible).  The level kernels work on workgroup tiles
+// i.e. 2 n_levels + 1 small kernels — 2 n_levels - 1 in the product's default form: restrict0 rides in the PCG's vector update (cg_update_mg_kernel) and prolong0 in
+// level 1's up-sweep; every sum runs in a fixed order (bitwise reproducible).  The level kernels work on workgroup tiles
 // of whole aggregates (<= 32 rows, members of an aggregate are contiguous by construction), so restriction and prolongation never leave
 // the workgroup.  All of it is latency-bound (the levels hold 17 %, 6 %, 2 % ... of the keyframes): what counts is the kernel count.
 

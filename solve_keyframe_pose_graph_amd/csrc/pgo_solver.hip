@@ -842,10 +842,10 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
     int every = 2;
     auto chunk_length = [&]() {
         int e = std::max(2, o.cg_check_every) & ~1;   // even: the r/p ping-pong parity repeats from chunk to chunk
-        // five kernels per iteration with the coarse space: chunks of 12 keep a captured chunk at 60 kernel nodes (rocprofv3 7.2 crashes while a
-        // graph of 120 nodes is captured under --kernel-trace; 80 are fine) and halve the early-exit launches after convergence
+        // captured chunks stay at <= 72 kernel nodes (rocprofv3 7.2 crashes while a graph of 120 nodes is captured under --kernel-trace; 80 are fine): five kernels
+        // per iteration with the coarse space in its unfused form -> 12 iterations, three in the fused form -> 24
         if (p->coarse_active && !multi) e = std::min(e, fused_coarse ? 24 : 12);
-        if (p->mg_active && !multi) e = std::max(2, (72 / (2 * p->M.n_levels + 3)) & ~1);   // 2 n_levels + 1 cycle kernels + matvec + update per iteration
+        if (p->mg_active && !multi) e = std::max(2, (72 / (2 * p->M.n_levels + 3)) & ~1);   // at most 2 n_levels + 1 cycle kernels + matvec + update per iteration (one less with the restriction inside the update)
         return e;
     };
     every = chunk_length();
