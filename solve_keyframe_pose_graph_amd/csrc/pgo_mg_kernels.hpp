@@ -412,8 +412,11 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_up_kernel(MgLevelDev A, MgLevelDe
     __shared__ double xb[CG_BLOCK];
     const int stopped = stop ? *stop : 0;
     const int li = threadIdx.x / 6, c = threadIdx.x % 6;
-    const int4 ti = A.tile_info[blockIdx.x];
-    const int2 rb = A.tile_rows[blockIdx.x * MG_TILE_ROWS + li];
+    double acc2 = 0.0;      // FINE: this workgroup's share of r.(P x_1), over all its tiles
+    // FINE: the grid is capped at MAX_PARTIALS workgroups (one r.z partial slot each), a workgroup takes every gridDim-th tile; otherwise one tile per workgroup
+    for (int tile = blockIdx.x; tile < A.tiles; tile += gridDim.x) {
+    const int4 ti = A.tile_info[tile];
+    const int2 rb = A.tile_rows[tile * MG_TILE_ROWS + li];
     if (stopped) return;
     const int i0 = ti.z, i1 = ti.w;
     const int row = i0 + li;
@@ -480,10 +483,9 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_up_kernel(MgLevelDev A, MgLevelDe
         xb[threadIdx.x] = x;
     }
     if (FINE) {
-        __shared__ double red[CG_BLOCK / 64];
         __syncthreads();
         // r.(P_0 x_1) = (P_0^T r).x_1 = r_1.x_1: the coarse part of r.z from this level's own vectors (the keyframes' r is not read again)
-        double acc2 = live ? scale * rv * xb[threadIdx.x] : 0.0;
+        if (live) acc2 += scale * rv * xb[threadIdx.x];
 #pragma unroll
         for (int tt = 0; tt < FT; ++tt) {
             if (fn[tt] < 0) continue;
@@ -492,9 +494,8 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_up_kernel(MgLevelDev A, MgLevelDe
             const double b0 = scale * mg_prolong_comp(y, fd[tt], 2 * j), b1 = scale * mg_prolong_comp(y, fd[tt], 2 * j + 1);
             reinterpret_cast<double2*>(zfine)[fn[tt]] = make_double2(fz[tt].x + b0, fz[tt].y + b1);
         }
-        const double s2 = block_sum(acc2, red);
-        if (threadIdx.x == 0) part_extra[blockIdx.x] = s2;
-        return;
+        __syncthreads();      // the LDS buffers are reused by the next tile
+        continue;
     }
     if (!has_below) return;
     __syncthreads();
@@ -503,6 +504,12 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_up_kernel(MgLevelDev A, MgLevelDe
         const int i = c0 + idx / 6, k = idx % 6;
         const double* y = xb + (size_t)(Below.parent[i] - i0) * 6;
         Below.xt[(size_t)i * 6 + k] = Below.x[(size_t)i * 6 + k] + scale * mg_prolong_comp(y, Below.d + (size_t)i * 3, k);
+    }
+    }
+    if (FINE) {
+        __shared__ double red[CG_BLOCK / 64];
+        const double s2 = block_sum(acc2, red);
+        if (threadIdx.x == 0) part_extra[blockIdx.x] = s2;
     }
 }
 // z_i += P_i y_{agg0(i)} and r.z += r.(P y), in cg_update's lane / workgroup mapping (same partial-sum slots)
@@ -670,7 +677,7 @@ void launch_mg_apply(const GraphDev& G, const CgDev& C, const MgDev& M, const Mg
     const bool fused = C.extra_rz > 0;     // level 1's kernel prolongs to the keyframes itself (the solver sets extra_rz = its tile count when that fits the partial-sum slots)
     const unsigned g0 = (unsigned)cg_grid(G);
     for (int l = nl - 1; l >= 1; --l) {
-        if (l == 1 && fused) hipLaunchKernelGGL(mg_up_kernel<true>, dim3((unsigned)levels[0].tiles), dim3(CG_BLOCK), 0, st, levels[0], levels[0], 0, scale, stop, M, r, z, part_rz + g0);
+        if (l == 1 && fused) hipLaunchKernelGGL(mg_up_kernel<true>, dim3((unsigned)(levels[0].tiles < MAX_PARTIALS ? levels[0].tiles : MAX_PARTIALS)), dim3(CG_BLOCK), 0, st, levels[0], levels[0], 0, scale, stop, M, r, z, part_rz + g0);
         else hipLaunchKernelGGL(mg_up_kernel<false>, dim3((unsigned)levels[l - 1].tiles), dim3(CG_BLOCK), 0, st, levels[l - 1], l >= 2 ? levels[l - 2] : levels[0], l >= 2 ? 1 : 0, scale, stop, M, r, z, part_rz);
     }
     if (!fused) hipLaunchKernelGGL(mg_prolong0_kernel, dim3(g0), dim3(CG_BLOCK), 0, st, G, M, (const double*)(nl == 1 ? K.yc : levels[0].xf), r, z, part_rz, scale, stop);
