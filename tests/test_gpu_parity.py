@@ -44,9 +44,10 @@ def test_jacobian_blocks_match_oracle():
             assert np.abs(dsp - dso).max() <= 1e-12 * max(1.0, np.abs(dso).max())
 
 
-def test_normal_matrix_matches_oracle():
+@pytest.mark.parametrize("shape", [(120, 25, 2), (260, 60, 5)])     # the second: 7 matvec tiles, on which K2's per-keyframe sums run (k2_tiles_kernel)
+def test_normal_matrix_matches_oracle(shape):
     """K2: assembled J^T J / J^T r against the oracle's dense normal matrix (SURVEY.md §8c golden (4))."""
-    g = util.small_graph(120, 25, f=2, seed=9)
+    g = util.small_graph(shape[0], shape[1], f=shape[2], seed=9)
     O, P = _both(g, True)
     q, t, s = util.initial_state(g, True, perturb=0.02, seed=1)
     N, S = g.n_poses, g.n_loops
