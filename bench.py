@@ -291,6 +291,14 @@ def main():
     except Exception:
         pass
 
+    pcg_traffic = None
+    try:
+        if scale == 1 and args.poses_per_gpu == C3_POSES:
+            with open(os.path.join(ROOT, "profiles", "pcg_pmc_latest.json")) as f:
+                pj = json.load(f)
+            pcg_traffic = pj["matvec"]["hbm_bytes_per_launch"] + pj["update"]["hbm_bytes_per_launch"]
+    except Exception:
+        pass
     out = None
     if rank == 0:
         ips = args.steps / elapsed
@@ -326,7 +334,8 @@ def main():
             # where the solve spends its time: one block-Jacobi PCG iteration = matvec + vector update, bytes = what this design moves per iteration
             "roofline_pcg": {"bound": "hbm", "kernel": "%s + cg_update_kernel (one PCG iteration)" % ("mf_spmv_kernel<true>" if P_linear_solver == 1 else "cg_spmv_kernel"),
                              "achieved": cg_bytes / (cg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cg_bytes / (cg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             "algorithmic_bytes_per_iteration": cg_bytes, "avg_iteration_ms": cg_ms,
+                             "algorithmic_bytes_per_iteration": cg_bytes, "avg_iteration_ms": cg_ms, "traffic": pcg_traffic,
+                             "traffic_source": "static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the two kernels on C3 (profiles/pcg_pmc_latest.json), not measured in this run",
                              "matvec": {"ms": mv_ms, "bytes": mv_bytes, "GBps": mv_bytes / mv_ms / 1e6}, "update": {"ms": up_ms, "bytes": up_bytes, "GBps": up_bytes / up_ms / 1e6},
                              "share_of_timed_region": summ_cg_total * cg_ms * 1e-3 / elapsed},
             "other_kernels": {"k2_assembly": {"ms": k2_ms, "GBps": k2_bytes / k2_ms / 1e6}, "pcg_iteration": {"ms": cg_ms, "GBps": cg_bytes / cg_ms / 1e6},

@@ -21,6 +21,12 @@ for title, pre, sub in (('mf_spmv_kernel<true, false>', 'pcg_spmv_', 'mf_spmv_ke
             'TCC_HIT_sum %.0f  TCC_MISS_sum %.0f  -> L2 hit rate %.1f %%' % (h, m, 100 * h / (h + m)),
             'SQ_WAVE_CYCLES %.3g  SQ_WAIT_ANY %.3g  -> %.0f %% of resident wave-cycles waiting;  SQ_BUSY_CYCLES %.3g  SQ_ACTIVE_INST_VALU %.3g' % (wc, wa, 100 * wa / wc, bc, va), '']
 open('profiles/r02_pcg_pmc.txt', 'w').write('\n'.join(out))
+pcg = {}
+for key, pre, sub in (('matvec', 'pcg_spmv_', 'mf_spmv_kernel<true, false>'), ('update', 'pcg_update_', 'cg_update_kernel')):
+    f, w = mean_of(pre + 'FETCH_SIZE.json', sub), mean_of(pre + 'WRITE_SIZE.json', sub)
+    pcg[key] = {'FETCH_SIZE_KiB': f, 'WRITE_SIZE_KiB': w, 'hbm_bytes_per_launch': (2 * f + w) * 1024}
+pcg['workload'] = 'C3'; pcg['fetch_correction'] = 'x2 (gfx950 FETCH_SIZE counts 128-B requests as 64 B for 16-B/lane streams, MI355X_MICROARCH.md)'
+json.dump(pcg, open('profiles/pcg_pmc_latest.json', 'w'), indent=1)
 kf, kw = mean_of('k1_FETCH_SIZE.json', 'k1_edges_kernel<true'), mean_of('k1_WRITE_SIZE.json', 'k1_edges_kernel<true')
 old = json.load(open('profiles/k1_pmc_r02.json'))
 old.update({'FETCH_SIZE_KiB': kf, 'WRITE_SIZE_KiB': kw, 'hbm_bytes_per_launch': (2 * kf + kw) * 1024})
