@@ -185,6 +185,7 @@ typedef struct pgo_summary {
     int32_t reserved_;
     pgo_iteration iterations[PGO_MAX_ITERATION_LOG];
     char message[256];
+    int64_t cg_iterations_multigrid; /* of cg_iterations: those preconditioned by the aggregation multigrid (the rest: block-Jacobi / two-level) */
 } pgo_summary;
 
 /* ------------------------------------------------------------------------------------------ */
@@ -372,7 +373,8 @@ int pgo_get_relpose_edge_records(const pgo_problem* p, int64_t first, int64_t n,
 int pgo_time_linearize_kernel(pgo_problem* p, int32_t launches, double* avg_ms, double* algorithmic_bytes);
 
 /* Same for one PCG iteration (K3+K4) and the assembly (K2). which: 0 = K1, 1 = K2, 2 = one block-Jacobi PCG iteration (matvec + update),
- * 3 = K1 cost-only, 4 = the matvec of the iteration alone, 5 = its vector update alone.  algorithmic_bytes of 2/4/5: what THIS design moves
+ * 3 = K1 cost-only, 4 = the matvec of the iteration alone, 5 = its vector update alone, 6 = one MULTIGRID-preconditioned PCG iteration (matvec + update with
+ * the restriction + every level kernel; graphs with a hierarchy only), 7 = its level kernels alone.  algorithmic_bytes of 2/4/5/6/7: what THIS design moves
  * per iteration with every array counted once (matrix-free: compact edge-side records + index data + vectors + the fp32 block-Jacobi
  * factors; block-CSR: SURVEY.md 8d's assembled form). */
 int pgo_time_kernel(pgo_problem* p, int32_t which, int32_t launches, double* avg_ms, double* algorithmic_bytes);

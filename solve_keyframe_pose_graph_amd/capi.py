@@ -41,7 +41,7 @@ class Summary(C.Structure):
     _fields_ = [("termination_type", C.c_int32), ("num_iterations", C.c_int32), ("num_successful_steps", C.c_int32), ("num_unsuccessful_steps", C.c_int32),
                 ("cg_iterations", C.c_int64), ("initial_cost", C.c_double), ("final_cost", C.c_double), ("seconds_total", C.c_double),
                 ("seconds_device", C.c_double), ("num_logged", C.c_int32), ("reserved_", C.c_int32),
-                ("iterations", Iteration * PGO_MAX_ITERATION_LOG), ("message", C.c_char * 256)]
+                ("iterations", Iteration * PGO_MAX_ITERATION_LOG), ("message", C.c_char * 256), ("cg_iterations_multigrid", C.c_int64)]
 
 
 # every symbol include/pgo.h declares (checked by tests/test_capi_symbols.py against the header text)

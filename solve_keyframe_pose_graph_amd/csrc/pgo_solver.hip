@@ -167,7 +167,7 @@ struct pgo_problem {
 
     // hipGraph of one PCG chunk (launch-bound inner loop); valid for (graph build epoch, tolerance, chunk length, solver)
     // one captured chunk per preconditioner (0 block-Jacobi, 1 two-level, 2 multigrid): the hybrid policy changes between them inside a solve
-    struct CapturedChunk { hipGraphExec_t exec = nullptr; int len = 0; uint64_t epoch = 0; };
+    struct CapturedChunk { hipGraphExec_t exec = nullptr; int len = 0; uint64_t epoch = 0; double scale = 0.0; };   // scale: mg_correction_scale is a by-value kernel argument of the captured cycle
     CapturedChunk cg_chunk[3];
     hipGraphExec_t cg_graph = nullptr;   // the one in use (not owned)
     uint64_t build_epoch = 1; bool cg_graph_failed = false;
@@ -890,7 +890,7 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
     auto ensure_graph = [&](bool may_capture) {
         const int mode = p->mg_active ? 2 : p->coarse_active ? 1 : 0;
         pgo_problem::CapturedChunk& cc = p->cg_chunk[mode];
-        if (!want_graph || (cc.exec != nullptr && cc.epoch == p->build_epoch && cc.len == every)) { p->cg_graph = want_graph ? cc.exec : nullptr; return; }
+        if (!want_graph || p->cg_graph_failed || (cc.exec != nullptr && cc.epoch == p->build_epoch && cc.len == every && cc.scale == mg_scale(p))) { p->cg_graph = want_graph && !p->cg_graph_failed ? cc.exec : nullptr; return; }
         if (!may_capture) { p->cg_graph = nullptr; return; }
         if (cc.exec) { (void)hipGraphExecDestroy(cc.exec); cc.exec = nullptr; }
         hipGraph_t gr = nullptr;
@@ -902,7 +902,7 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
         if (ok) ok = hipGraphInstantiate(&cc.exec, gr, nullptr, nullptr, 0) == hipSuccess;
         if (gr) (void)hipGraphDestroy(gr);
         if (!ok) { cc.exec = nullptr; p->cg_graph_failed = true; (void)hipGetLastError(); }
-        else { cc.epoch = p->build_epoch; cc.len = every; }
+        else { cc.epoch = p->build_epoch; cc.len = every; cc.scale = mg_scale(p); }
         p->cg_graph = cc.exec;
     };
     ensure_graph(k >= graph_after);
@@ -918,7 +918,7 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
     };
     while (k < o.cg_max_iterations && !done) {
         const int chunk = std::min(every, o.cg_max_iterations - k);
-        if (want_graph && !p->cg_graph && k >= graph_after && (k & 1) == 0) ensure_graph(true);
+        if (want_graph && !p->cg_graph_failed && !p->cg_graph && k >= graph_after && (k & 1) == 0) ensure_graph(true);
         if (k >= 2 && chunk == every && want_graph && p->cg_graph && (k & 1) == 0) {
             HIPCHK(p, hipGraphLaunch(p->cg_graph, p->st));
             k += every;
@@ -1214,6 +1214,7 @@ int lm_step(pgo_problem* p, int ignore_termination, int* done) {
     }
     it.cg_iterations = cg.iterations + p->cg_extra; it.cg_residual = cg.rel_residual;
     p->sum.cg_iterations += cg.iterations + p->cg_extra;
+    if (p->mg_active) p->sum.cg_iterations_multigrid += cg.iterations;     // iterations before an in-flight switch (cg_extra) ran with block-Jacobi
     if (ok) {
         if (!evaluated && (rc = evaluate_candidate()) != PGO_OK) return rc;
         it.model_cost_change = -h[S_MODEL];
@@ -1790,11 +1791,24 @@ int pgo_time_kernel(pgo_problem* p, int32_t which, int32_t launches, double* avg
     const int nxt = p->cur ^ 1;
     const GraphDev& G = p->G;
     double bytes = 0;
+    if (which == 6 || which == 7) {   // one multigrid-preconditioned PCG iteration (6) / its level kernels alone (7), on the current LM system
+        if (!p->mg_built || !p->built_mf) { p->err = "pgo_time_kernel: this graph has no multigrid hierarchy (mg_min_keyframes)"; (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return PGO_ERR_STATE; }
+        const pgo_options& o = p->opt;
+        if (!p->reuse_diagonal) launch_lm_diag(p->G, p->L, p->Sc, o.min_lm_diagonal, o.max_lm_diagonal, p->st);
+        bool ok = true;
+        if ((rc = build_system(p, &ok)) != PGO_OK) return rc;
+        if (!p->mg_active && (rc = build_mg(p)) != PGO_OK) return rc;
+        if (!p->mg_active) { p->err = "pgo_time_kernel: the multigrid operators of this system are not positive definite"; (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return PGO_ERR_NUMERIC; }
+        const int g = launch_cg_init_vectors(p->G, p->C, 0, p->st);
+        launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz, mg_scale(p), false, p->st);
+        launch_cg_init_scalars(p->C, g, 0.0, p->st);
+    }
     if (which == 2 || which == 4 || which == 5) {   // a live PCG state to iterate on (tolerance 0: never converges during the timed launches)
         const pgo_options& o = p->opt;
         if (!p->reuse_diagonal) launch_lm_diag(p->G, p->L, p->Sc, o.min_lm_diagonal, o.max_lm_diagonal, p->st);
         bool ok = true;
         if ((rc = build_system(p, &ok)) != PGO_OK) return rc;
+        p->mg_active = false; p->coarse_active = false; p->C.extra_rz = 0;   // the timed iteration is the plain block-Jacobi one: no partial-sum slots of a multigrid / two-level solve
         launch_cg_init(p->G, p->C, 0, 0.0, p->st);
     }
     const double N = (double)G.N, E = (double)(G.rel.E + G.sw.E), Es = (double)G.sw.E;
@@ -1822,6 +1836,28 @@ int pgo_time_kernel(pgo_problem* p, int32_t which, int32_t launches, double* avg
                           bytes = which == 2 ? mv + up : which == 4 ? mv : up;
                           break; }
                 case 3: launch_k1(G, p->d_pose[nxt].p, p->d_swv[nxt].p, false, part(p, 5), &np, p->st); bytes = k1_algorithmic_bytes(G, false); break;
+                case 6: case 7: {
+                          const int kk = rep == 0 ? 0 : i + 1;
+                          const bool fused = p->M.blk_tab != nullptr;
+                          if (which == 6) {
+                              launch_mf_spmv(G, p->F, p->Sc, p->C, kk, 0.0, p->st);
+                              if (fused) launch_cg_update_mg(G, p->C, p->M, p->mg_levels, p->K, kk, mf_grid_size(p->F), p->st);
+                              else launch_cg_update(G, p->C, kk, mf_grid_size(p->F), p->st);
+                          }
+                          launch_mg_apply(G, p->C, p->M, p->mg_levels, p->K, (kk & 1) ? p->C.r : p->C.r2, p->C.z, p->C.part_rz + (size_t)((kk & 1) ^ 1) * RZ_STRIDE, mg_scale(p), true, p->st, which == 6 && fused);
+                          // Bytes of this design, each array once per kernel that streams it.  Fine level as in case 2 (+ the restriction's per-keyframe offsets and slot table,
+                          // the prolongation's read-modify-write of z, offsets and aggregate index); every sparse coarse level: its fp32 blocks and column indices twice
+                          // (down- and up-sweep), Dinv, positions/offsets and its four vectors; the dense level: the fp32 inverse once.
+                          const double lanes_rel = (double)(p->mf_pair_lanes + p->mf_rel_side_lanes), lanes_sw = (double)p->mf_sw_lanes;
+                          const double fine = lanes_rel * (128.0 + 12.0) + lanes_sw * (176.0 + 12.0 + 8.0) + N * (4.0 * 48.0 + 48.0 + 13.0) + N * (7.0 * 48.0 + 96.0);
+                          double cyc = N * (24.0 + 16.0 / 8.0 * 8.0) /* d0 + slot table (restriction) */ + N * (2.0 * 48.0 + 24.0 + 4.0 + 4.0) /* z read + write, d0, agg0, member list (prolongation) */;
+                          for (int l = 0; l + 1 < p->M.n_levels; ++l) {
+                              const MgLevelDev& A = p->mg_levels[l];
+                              cyc += 2.0 * (double)A.nnzb * (144.0 + 4.0) + (double)A.n * (2.0 * 288.0 /* Dinv: pre- and post-smoothing */ + 24.0 + 10.0 * 48.0 + 16.0);
+                          }
+                          cyc += (double)p->K.nc * (double)p->K.nc * 4.0 + (double)p->K.nc * 16.0;
+                          bytes = which == 6 ? fine + cyc : cyc;
+                          break; }
                 default: (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return PGO_ERR_INVALID_ARG;
             }
         }
