@@ -363,6 +363,18 @@ int pgo_initial_guess_from_vio(pgo_problem* p, int64_t n_left, const double* lef
  * (CeresResidues.h:22-28).  Any output may be NULL. */
 int pgo_get_relpose_edge_records(const pgo_problem* p, int64_t first, int64_t n, int32_t* c1, int32_t* c2, double* record8);
 
+/* Edge sharding policies behind the C-ABI (host only: no handle, no device): which rank gets which residual block.  A C++ caller deals its edges out with this
+ * and then calls pgo_add_*_edges on every rank's handle with that rank's share.  What the policy decides is the number of keyframes shared between ranks, i.e. the
+ * rows every exchange carries:
+ *   PGO_PARTITION_CONTIGUOUS  a contiguous index range of every edge class per rank
+ *   PGO_PARTITION_CHAIN       keyframes in `world` consecutive index ranges balanced by edge load; an edge follows its LATER endpoint
+ *   PGO_PARTITION_SPATIAL     recursive coordinate bisection of the keyframe positions `t_xyz` into `world` cells of equal edge load; an edge follows its later endpoint
+ * node_part [n_nodes] (may be NULL; contiguous: not written) receives the part of every keyframe — a regulariser goes to its keyframe's part (contiguous: rank 0) —,
+ * rel_rank [n_rel] / sw_rank [n_sw] the rank of every edge.  Same results as solve_keyframe_pose_graph_amd/sharding.py (tests/test_partition_capi.py). */
+enum { PGO_PARTITION_CONTIGUOUS = 0, PGO_PARTITION_CHAIN = 1, PGO_PARTITION_SPATIAL = 2 };
+int pgo_partition_edges(int32_t policy, int32_t world, int64_t n_nodes, const double* t_xyz, int64_t n_rel, const int32_t* rel_c1, const int32_t* rel_c2,
+                        int64_t n_sw, const int32_t* sw_c1, const int32_t* sw_c2, int32_t* node_part, int32_t* rel_rank, int32_t* sw_rank);
+
 /* ------------------------------------------------------------------------------------------ */
 /* measurement helpers (bench.py): HIP-event timing of the dominant kernel on the library's stream */
 /* ------------------------------------------------------------------------------------------ */

@@ -52,8 +52,9 @@ class Cycle:
     """fine: 'add' (z = D^-1 r + P C(P^T r)) or 'mult' (V(1,1) on the fine level too)
     kcyc: set of levels whose system is solved by `kit` FCG steps preconditioned by the cycle from that level (K-cycle there); others: one cycle visit
     exact_from: level index from which the system is solved by LU (two-level exact = 1)"""
-    def __init__(self, H, fine='add', omega=0.9, kcyc=(), kit=2, exact_from=None, wcyc=(), alpha=1.0):
+    def __init__(self, H, fine='add', omega=0.9, kcyc=(), kit=2, exact_from=None, wcyc=(), alpha=1.0, alpha0=None):
         self.H, self.fine, self.omega, self.kcyc, self.kit, self.wcyc, self.alpha = H, fine, omega, set(kcyc), kit, set(wcyc), alpha
+        self.alpha0 = alpha if alpha0 is None else alpha0
         self.visits = [0] * len(H.levels); self.mvs = [0] * len(H.levels)
         self.lu = {}
         if exact_from is not None:
@@ -67,7 +68,7 @@ class Cycle:
         if lvl in self.lu: return self.lu[lvl].solve(r)
         om = self.omega
         if lvl == 0 and self.fine == 'add':
-            return L['Dinv'] @ r + self.alpha * (L['P'] @ self.coarse(1, L['P'].T @ r))
+            return L['Dinv'] @ r + self.alpha0 * (L['P'] @ self.coarse(1, L['P'].T @ r))
         x = om * (L['Dinv'] @ r)
         rc = L['P'].T @ (r - self.mv(lvl, x))
         x = x + self.alpha * (L['P'] @ self.coarse(lvl + 1, rc))
@@ -95,7 +96,12 @@ if __name__ == '__main__':
     g, t, A, b, s = load(path, radius)
     N = len(t)
     Dinv = block_diag_inv(A, N)
-    t0 = time.time(); xbj, kbj = pcg(A, b, lambda r: Dinv @ r, 1e-9, maxit=60000); print('radius %g: block-Jacobi %d its (%.0fs)' % (radius, kbj, time.time() - t0), flush=True)
+    import os
+    cache = path + ".xbj_%g.npy" % radius
+    if os.path.exists(cache): xbj = np.load(cache); kbj = -1
+    else:
+        xbj, kbj = pcg(A, b, lambda r: Dinv @ r, 1e-9, maxit=60000); np.save(cache, xbj)
+    print("radius %g: block-Jacobi %d its" % (radius, kbj), flush=True)
     def report(name, H, M, flexible=False):
         t0 = time.time()
         x2, k2 = (fpcg if flexible else pcg)(A, b, M, 1e-9, maxit=3000)
@@ -159,3 +165,11 @@ if __name__ == '__main__':
             report('aggregate-block smoother, V add', H, Cycle(H))
             report('aggregate-block smoother, exact two-level add', H, Cycle(H, exact_from=1))
             report('aggregate-block smoother, K level 1 kit 2', H, Cycle(H, kcyc=(1,)), True)
+
+    for w in which:
+        if w == 'alpha':
+            H = Hier(A, t, agg_product(g, 3, 3))
+            for (a0, a) in ((1.0, 1.0), (1.0, 1.3), (1.0, 1.6), (1.0, 2.0), (1.5, 1.0), (1.5, 1.5), (2.0, 1.0), (0.7, 1.0)):
+                report('alpha0 %.1f alpha %.1f V add' % (a0, a), H, Cycle(H, alpha=a, alpha0=a0))
+            for om in (0.7, 1.0):
+                report('omega %.1f V add' % om, H, Cycle(H, omega=om))

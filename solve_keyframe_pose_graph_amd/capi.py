@@ -52,7 +52,7 @@ EXPORTS = [
     "pgo_set_vio_poses", "pgo_num_vio_poses", "pgo_add_odometry_edges_from_vio", "pgo_initial_guess_from_vio", "pgo_get_relpose_edge_records",
     "pgo_solve", "pgo_solve_begin", "pgo_lm_step", "pgo_solve_end", "pgo_evaluate",
     "pgo_get_jacobian_blocks", "pgo_get_normal_blocks", "pgo_apply_normal_operator", "pgo_manifold_plus",
-    "pgo_comm_get_unique_id", "pgo_comm_init", "pgo_comm_destroy", "pgo_comm_init_custom",
+    "pgo_comm_get_unique_id", "pgo_comm_init", "pgo_comm_destroy", "pgo_comm_init_custom", "pgo_partition_edges",
     "pgo_time_linearize_kernel", "pgo_time_kernel", "pgo_time_vio_odometry_kernel", "pgo_dense_spd_inverse", "pgo_device_synchronize", "pgo_strerror", "pgo_last_error",
 ]
 
@@ -325,6 +325,22 @@ class Problem:
 
     def comm_destroy(self):
         self._check(self.lib.pgo_comm_destroy(self.h))
+
+
+PARTITION = {"contiguous": 0, "chain": 1, "spatial": 2}
+
+
+def partition_edges(policy, world, positions, rel_c1, rel_c2, sw_c1, sw_c2):
+    """pgo_partition_edges (host only): -> (node_part [n_nodes], rel_rank [n_rel], sw_rank [n_sw]); the policies of sharding.py behind the C-ABI."""
+    lib = load()
+    pos = _d(positions).reshape(-1, 3)
+    rc1, rc2, sc1, sc2 = _i(rel_c1), _i(rel_c2), _i(sw_c1), _i(sw_c2)
+    part = np.zeros(len(pos), np.int32); rr = np.zeros(len(rc1), np.int32); sr = np.zeros(len(sc1), np.int32)
+    rc = lib.pgo_partition_edges(C.c_int32(PARTITION[policy]), C.c_int32(world), C.c_int64(len(pos)), _pd(pos), C.c_int64(len(rc1)), _pi(rc1), _pi(rc2),
+                                 C.c_int64(len(sc1)), _pi(sc1), _pi(sc2), _pi(part), _pi(rr), _pi(sr))
+    if rc != 0:
+        raise PgoError(rc, lib.pgo_strerror(rc).decode())
+    return part, rr, sr
 
 
 def problem_from_graph(g, switchable=True, options=None, edge_slice=None, **opt_kw):

@@ -157,6 +157,9 @@ struct MgDev {
     // restriction inside the PCG's vector update: per run of MG_BLOCK0 consecutive keyframes (one workgroup trip of cg_update) the level-1 aggregates it holds,
     // MG_BLOCK0 slots of {aggregate or -1, 8 member keyframes as run-local bytes (0xff: none)} — aggregates never cross a run boundary (pgo_mg_host.hpp)
     const int4* blk_tab;                 // [runs][MG_BLOCK0] {aggregate, members 0-3, members 4-7, unused}; null: restriction by its own kernel
+    // several ranks (edge sharding): the keyframe arrays above are the rank's LOCAL keyframes, the level-1 ids GLOBAL (levels 1.. are replicated on every rank)
+    const double* inv_cnt;               // [n1] 1 / (members of the level-1 node over all ranks); null on one GPU
+    double* q1; double* s1;              // [n1][6] level-1 companions of the Chronopoulos-Gear recurrence: q1 = P0^T (A u) as exchanged, s1 = P0^T s
 };
 constexpr int MG_BLOCK0 = 64;
 
@@ -224,7 +227,9 @@ void launch_coarse_solve_dot(const CoarseDev& K, const int32_t* stop, double* pa
 // multi-GPU PCG in Chronopoulos-Gear form (one collective per iteration): see pgo_kernels.hip
 void launch_cgcg_dots(const GraphDev& G, const CgDev& C, hipStream_t st);                                     // part_pq[block] = partial of u.w
 void launch_cg_reduce2_live(const CgDev& C, const double* pa, int na, const double* pb, int nb, double* out, hipStream_t st);
-void launch_cgcg_update(const GraphDev& G, const CgDev& C, int k, int first, hipStream_t st);
+void launch_cgcg_update(const GraphDev& G, const CgDev& C, int k, int first, hipStream_t st, const double* xq = nullptr, const int32_t* sh_of = nullptr, const double* two = nullptr);
+// the iteration's exchange buffer in one kernel: [rows of w of the global shared list (zeros where this rank does not touch the keyframe) | sum pa | sum pb]
+void launch_cgcg_pack(const CgDev& C, const int32_t* sh_src, int64_t n_sh, const double* w, double* buf, const double* pa, int na, const double* pb, int nb, hipStream_t st);
 void launch_cgcg_scalars_init(const CgDev& C, const double* bb_src, double tol2, hipStream_t st);
 // write-back: owned keyframes of the rank-local (quat[n][4], t[n][3]) into zero-initialised global arrays
 void launch_scatter_owned_pose(const double* quat, const double* t, int64_t n, const int32_t* l2g, const double* own, double* gquat, double* gt, hipStream_t st);
@@ -234,9 +239,19 @@ void launch_vio_initial_guess(int64_t u_begin, int64_t count, const double* left
 
 // aggregation multigrid (MgDev / MgLevelDev); levels[0] = level 1
 void launch_mg_geometry(const GraphDev& G, const MgDev& M, const MgLevelDev* levels, const double* pose8, hipStream_t st);
+// several ranks: level 1's positions are the centroids over the members on ALL ranks: owner-weighted partial sums into levels[0].pos (all-reduced by the caller), then the rest
+void launch_mg_geometry0_sum(const GraphDev& G, const MgDev& M, const MgLevelDev* levels, const double* pose8, hipStream_t st);
+void launch_mg_geometry_finish(const GraphDev& G, const MgDev& M, const MgLevelDev* levels, const double* pose8, hipStream_t st);
 // numeric Galerkin products of the current LM system, level by level, block-Jacobi inverses of the sparse levels, the dense coarsest operator
 // into K.Ac (K.nc padded), which is then inverted by launch_coarse_invert; *fail != 0: some diagonal block was not positive definite
 void launch_mg_assemble(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, double omega, int32_t* fail, hipStream_t st);
+// its two halves: level 1 from the keyframe system (several ranks: this rank's contributions; the caller all-reduces levels[0].val), then everything above
+void launch_mg_galerkin0(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, const MgDev& M, const MgLevelDev* levels, hipStream_t st);
+void launch_mg_assemble_rest(const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, double omega, int32_t* fail, hipStream_t st);
+// out[n1][6] = P0^T v over the handle's keyframes (own_weighted: every keyframe counted by its owner only — several ranks)
+void launch_mg_restrict0(const GraphDev& G, const MgDev& M, const double* v, double* out, bool own_weighted, hipStream_t st);
+// several ranks: level-1 residual by the PCG's recurrence (mode 0: s1 = q1 + beta s1, r1 -= alpha s1 with the scalars cgcg_update left; mode 1, PCG start: s1 = 0) and x1 = w D1^-1 r1
+void launch_mg_level1_update(const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, int k, int first, int mode, hipStream_t st);
 // z += scale P V(P^T r) (every coarse correction inside V scaled alike), r.z partials updated in place (cg_update's workgroup -> slot mapping)
 void launch_mg_apply(const GraphDev& G, const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, const double* r, double* z, double* part_rz, double scale, bool inside_iteration, hipStream_t st,
                      bool restricted = false /* r_1 (and x_1) already formed by launch_cg_update_mg */);

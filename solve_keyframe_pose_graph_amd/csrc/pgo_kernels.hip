@@ -982,9 +982,33 @@ __global__ void cg_reduce2_live_kernel(CgDev C, const double* __restrict__ pa, i
     if (!stopped) block_total2(pa, na, pb, nb, red, a, b);
     if (threadIdx.x == 0) { out[0] = a; out[1] = b; }
 }
-__global__ __launch_bounds__(CG_BLOCK) void cgcg_update_kernel(GraphDev G, CgDev C, int parity, int first) {
+// Packs the iteration's exchange buffer in ONE kernel (no memset, no copies): workgroup 0 reduces the two dot products' partial sums into buf[6 n_sh], buf[6 n_sh + 1]
+// (zeros once the PCG has stopped); the others write, for every keyframe of the GLOBAL shared list, this rank's row of w = A_r u or zeros when it does not touch the keyframe.
+__global__ __launch_bounds__(256) void cgcg_pack_kernel(CgDev C, const int32_t* __restrict__ sh_src, int64_t n_sh, const double* __restrict__ w, double* __restrict__ buf,
+                                                         const double* __restrict__ pa, int na, const double* __restrict__ pb, int nb) {
+    if (blockIdx.x == 0) {
+        __shared__ double red[8];
+        const bool stopped = C.flags[0] != 0;
+        double a = 0.0, b = 0.0;
+        if (!stopped) block_total2(pa, na, pb, nb, red, a, b);
+        if (threadIdx.x == 0) { buf[n_sh * 6] = a; buf[n_sh * 6 + 1] = b; }
+        return;
+    }
+    const int64_t i = (int64_t)(blockIdx.x - 1) * blockDim.x + threadIdx.x;
+    if (i >= n_sh * 6) return;
+    const int64_t j = i / 6; const int c = (int)(i - j * 6);
+    const int32_t src = sh_src[j];
+    buf[i] = src >= 0 ? w[(size_t)src * 6 + c] : 0.0;
+}
+void launch_cgcg_pack(const CgDev& C, const int32_t* sh_src, int64_t n_sh, const double* w, double* buf, const double* pa, int na, const double* pb, int nb, hipStream_t st) {
+    hipLaunchKernelGGL(cgcg_pack_kernel, dim3((unsigned)((n_sh * 6 + 255) / 256 + 1)), dim3(256), 0, st, C, sh_src, n_sh, w, buf, pa, na, pb, nb);
+}
+// xq / sh_of / two (fused exchange): the summed rows of w for shared keyframes are read straight from the exchange buffer (sh_of[keyframe] = its position there, or -1)
+// and [delta, gamma] from its tail — no unpack kernel, no copies; null: w complete in C.q, scalars in C.scal[12..13]
+__global__ __launch_bounds__(CG_BLOCK) void cgcg_update_kernel(GraphDev G, CgDev C, int parity, int first, const double* __restrict__ xq = nullptr, const int32_t* __restrict__ sh_of = nullptr,
+                                                               const double* __restrict__ two = nullptr) {
     if (cg_done(C)) return;
-    const double delta = C.scal[12], gamma = C.scal[13];
+    const double delta = two ? two[0] : C.scal[12], gamma = two ? two[1] : C.scal[13];
     double beta = 0.0, den = delta;
     const bool breakdown = C.flags[1] != 0;
     if (breakdown || !(gamma > C.scal[3] * C.scal[0])) {   // converged (or broken down): the state stays that of the last completed update
@@ -1022,7 +1046,9 @@ __global__ __launch_bounds__(CG_BLOCK) void cgcg_update_kernel(GraphDev G, CgDev
         const bool live = i < pairs;
         double2 rr = make_double2(0.0, 0.0);
         if (live) {
-            const double2 u = uv[i], w = wv[i];
+            const double2 u = uv[i];
+            double2 w = wv[i];
+            if (xq) { const int32_t pos = sh_of[i / 3]; if (pos >= 0) w = reinterpret_cast<const double2*>(xq)[(size_t)pos * 3 + (i % 3)]; }
             double2 pp = pv[i], ss = sv[i], xx = xv[i];
             rr = rv[i];
             pp.x = u.x + beta * pp.x; pp.y = u.y + beta * pp.y;
@@ -1093,7 +1119,9 @@ void launch_cgcg_dots(const GraphDev& G, const CgDev& C, hipStream_t st) { hipLa
 void launch_cg_reduce2_live(const CgDev& C, const double* pa, int na, const double* pb, int nb, double* out, hipStream_t st) {
     hipLaunchKernelGGL(cg_reduce2_live_kernel, dim3(1), dim3(256), 0, st, C, pa, na, pb, nb, out);
 }
-void launch_cgcg_update(const GraphDev& G, const CgDev& C, int k, int first, hipStream_t st) { hipLaunchKernelGGL(cgcg_update_kernel, dim3(cg_grid(G)), dim3(CG_BLOCK), 0, st, G, C, k & 1, first); }
+void launch_cgcg_update(const GraphDev& G, const CgDev& C, int k, int first, hipStream_t st, const double* xq, const int32_t* sh_of, const double* two) {
+    hipLaunchKernelGGL(cgcg_update_kernel, dim3(cg_grid(G)), dim3(CG_BLOCK), 0, st, G, C, k & 1, first, xq, sh_of, two);
+}
 void launch_cgcg_scalars_init(const CgDev& C, const double* bb_src, double tol2, hipStream_t st) { hipLaunchKernelGGL(cgcg_scalars_init_kernel, dim3(1), dim3(64), 0, st, C, bb_src, tol2); }
 int cg_grid_size(const GraphDev& G) { return cg_grid(G); }
 void launch_apply_operator(const GraphDev& G, const CgDev& C, const double* x, double* y, hipStream_t st) { hipLaunchKernelGGL(apply_operator_kernel, dim3(cg_grid(G)), dim3(CG_BLOCK), 0, st, G, C, x, y); }

@@ -124,18 +124,31 @@ inline void build_blocks(int32_t n, std::vector<std::pair<int64_t, int64_t>>& tr
     for (int32_t r = 0; r < n; ++r) out.rowptr[(size_t)r + 1] += out.rowptr[r];
 }
 
-// N keyframes, node_free[N]; edge lists of both classes (endpoints in the handle's local numbering, weights of the relative-pose class).
+// Several ranks (edge sharding): the hierarchy is built from the GLOBAL graph — every rank gathers the endpoints and weights of all edges and builds the
+// same levels — while the contributions a rank adds to level 1's Galerkin product are its OWN: the diagonal blocks of the keyframes it owns and its own
+// edges, both in the handle's rank-local numbering (the device kernel indexes the rank-local arrays).  The ranks' partial level-1 blocks are summed by an
+// all-reduce; everything above level 1 is replicated.
+struct LocalContrib {
+    const std::vector<int32_t>* l2g;          // local keyframe -> global keyframe
+    const std::vector<double>* own;           // [N_local] 1.0 where this rank contributes the keyframe's (already summed) diagonal block
+    const std::vector<int32_t>* rc1; const std::vector<int32_t>* rc2;     // the rank's relative-pose edges (GLOBAL endpoints), in its own edge order
+    const std::vector<int32_t>* sc1; const std::vector<int32_t>* sc2;     // the rank's switchable edges
+};
+
+// N keyframes, node_free[N]; edge lists of both classes (endpoints in the handle's local numbering — the global one with several ranks —, weights of the
+// relative-pose class at rel_w[rel_w_stride * e]).
 // passes0: matching rounds keyframes -> level 1, passes: for the levels above.  Returns false when the graph does not coarsen down to
 // dense_max nodes (e.g. mostly isolated keyframes): the caller then runs without the multigrid.
-inline bool build_hierarchy(int64_t N, const std::vector<uint8_t>& node_free, const std::vector<int32_t>& rc1, const std::vector<int32_t>& rc2, const double* rmeas8 /* weight at [8 e + 7] */,
+inline bool build_hierarchy(int64_t N, const std::vector<uint8_t>& node_free, const std::vector<int32_t>& rc1, const std::vector<int32_t>& rc2, const double* rel_w, int rel_w_stride,
                             const std::vector<int32_t>& sc1, const std::vector<int32_t>& sc2, const double* sw_weight /* per switchable edge: s^2 of its switch at graph build, or nullptr = 1 */,
-                            int passes0, int passes, int dense_max, int tile_rows, int max_levels, Hierarchy& H, bool level0_follows_switchable = true, int level0_block = 0) {
+                            int passes0, int passes, int dense_max, int tile_rows, int max_levels, Hierarchy& H, bool level0_follows_switchable = true, int level0_block = 0,
+                            const LocalContrib* local = nullptr) {
     H = Hierarchy{};
     const int64_t Er = (int64_t)rc1.size(), Es = (int64_t)sc1.size();
     std::vector<WEdge> edges;
     edges.reserve((size_t)(Er + Es));
     for (int64_t e = 0; e < Er; ++e) if (node_free[rc1[e]] && node_free[rc2[e]]) {
-        const double w = rmeas8[8 * e + 7];
+        const double w = rel_w[(size_t)rel_w_stride * e];
         if (w * w > 1e-8) edges.push_back({rc1[e], rc2[e], w * w});       // an odometry edge the yaw policy has (all but) switched off ties nothing together
     }
     // the switchable functor ignores its edge weight (CeresResidues.h:198) and scales the whole block by its switch: a loop closure the
@@ -153,7 +166,7 @@ inline bool build_hierarchy(int64_t N, const std::vector<uint8_t>& node_free, co
         // switch off, and an aggregate held together by nothing else would stop being a rigid piece; the levels above match along the summed
         // couplings of whole groups, where a single dead edge no longer decides anything
         rel_only.reserve((size_t)Er);
-        for (int64_t e = 0; e < Er; ++e) if (node_free[rc1[e]] && node_free[rc2[e]]) { const double w = rmeas8[8 * e + 7]; if (w * w > 1e-8) rel_only.push_back({rc1[e], rc2[e], w * w}); }
+        for (int64_t e = 0; e < Er; ++e) if (node_free[rc1[e]] && node_free[rc2[e]]) { const double w = rel_w[(size_t)rel_w_stride * e]; if (w * w > 1e-8) rel_only.push_back({rc1[e], rc2[e], w * w}); }
     }
     H.agg0 = match_passes((int32_t)N, level0_follows_switchable ? edges : rel_only, passes0, &skip, n1);
     if (level0_block > 0 && n1 >= 1) {
@@ -242,15 +255,22 @@ inline bool build_hierarchy(int64_t N, const std::vector<uint8_t>& node_free, co
     {
         std::vector<std::pair<int64_t, int64_t>> trip;
         trip.reserve((size_t)N + 2 * (size_t)(Er + Es));
-        for (int64_t i = 0; i < N; ++i) if (H.agg0[i] >= 0) trip.push_back({(int64_t)H.agg0[i] * n1 + H.agg0[i], (i << 3) | 0});
+        // (entry -1: the block exists — its structure is the global one on every rank — but the contribution is another rank's)
+        for (int64_t i = 0; i < N; ++i) if (H.agg0[i] >= 0) trip.push_back({(int64_t)H.agg0[i] * n1 + H.agg0[i], local ? (int64_t)-1 : ((i << 3) | 0)});
         auto edge = [&](int64_t e, int32_t c1, int32_t c2, int kind_fwd) {
             const int32_t a = H.agg0[c1], b = H.agg0[c2];
             if (a < 0 || b < 0) return;                     // rows and columns of fixed keyframes are not part of the system
-            trip.push_back({(int64_t)a * n1 + b, (e << 3) | kind_fwd});
-            trip.push_back({(int64_t)b * n1 + a, (e << 3) | (kind_fwd + 1)});
+            trip.push_back({(int64_t)a * n1 + b, e < 0 ? (int64_t)-1 : ((e << 3) | kind_fwd)});
+            trip.push_back({(int64_t)b * n1 + a, e < 0 ? (int64_t)-1 : ((e << 3) | (kind_fwd + 1))});
         };
-        for (int64_t e = 0; e < Er; ++e) edge(e, rc1[e], rc2[e], 1);
-        for (int64_t e = 0; e < Es; ++e) edge(e, sc1[e], sc2[e], 3);
+        for (int64_t e = 0; e < Er; ++e) edge(local ? -1 : e, rc1[e], rc2[e], 1);
+        for (int64_t e = 0; e < Es; ++e) edge(local ? -1 : e, sc1[e], sc2[e], 3);
+        if (local) {
+            const int64_t Nl = (int64_t)local->l2g->size();
+            for (int64_t l = 0; l < Nl; ++l) { const int32_t a = H.agg0[(*local->l2g)[l]]; if (a >= 0 && (*local->own)[l] != 0.0) trip.push_back({(int64_t)a * n1 + a, (l << 3) | 0}); }
+            for (int64_t e = 0; e < (int64_t)local->rc1->size(); ++e) edge(e, (*local->rc1)[e], (*local->rc2)[e], 1);
+            for (int64_t e = 0; e < (int64_t)local->sc1->size(); ++e) edge(e, (*local->sc1)[e], (*local->sc2)[e], 3);
+        }
         build_blocks(n1, trip, H.L[0]);
     }
     for (size_t l = 0; l + 1 < H.L.size(); ++l) {

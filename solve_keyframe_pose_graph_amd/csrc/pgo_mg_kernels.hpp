@@ -122,6 +122,35 @@ void launch_mg_geometry(const GraphDev& G, const MgDev& M, const MgLevelDev* lev
     for (int l = 0; l + 1 < M.n_levels; ++l)
         hipLaunchKernelGGL(mg_geometry_kernel, dim3((unsigned)((levels[l].n_next + 255) / 256)), dim3(256), 0, st, levels[l], levels[l + 1].pos);
 }
+// several ranks: a level-1 node's members live on several ranks; every keyframe is counted by its owner
+__global__ __launch_bounds__(256) void mg_geometry0_sum_kernel(MgDev M, MgLevelDev A1, const double* __restrict__ pose8, const double* __restrict__ own) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= M.n1) return;
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    for (int m = M.mem0_ptr[a]; m < M.mem0_ptr[a + 1]; ++m) { const int i = M.mem0[m]; const double w = own[i]; const double* t = pose8 + (size_t)i * 8 + 4; sx += w * t[0]; sy += w * t[1]; sz += w * t[2]; }
+    A1.pos[a * 3] = sx; A1.pos[a * 3 + 1] = sy; A1.pos[a * 3 + 2] = sz;
+}
+__global__ __launch_bounds__(256) void mg_geometry0_finish_kernel(MgDev M, MgLevelDev A1, const double* __restrict__ pose8) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= M.n1) return;
+    const double inv = M.inv_cnt[a];
+    const double sx = A1.pos[a * 3] * inv, sy = A1.pos[a * 3 + 1] * inv, sz = A1.pos[a * 3 + 2] * inv;
+    A1.pos[a * 3] = sx; A1.pos[a * 3 + 1] = sy; A1.pos[a * 3 + 2] = sz;
+    for (int m = M.mem0_ptr[a]; m < M.mem0_ptr[a + 1]; ++m) {
+        const int i = M.mem0[m];
+        const double* t = pose8 + (size_t)i * 8 + 4;
+        M.d0[(size_t)i * 3] = t[0] - sx; M.d0[(size_t)i * 3 + 1] = t[1] - sy; M.d0[(size_t)i * 3 + 2] = t[2] - sz;
+    }
+}
+void launch_mg_geometry0_sum(const GraphDev& G, const MgDev& M, const MgLevelDev* levels, const double* pose8, hipStream_t st) {
+    hipLaunchKernelGGL(mg_geometry0_sum_kernel, dim3((unsigned)((M.n1 + 255) / 256)), dim3(256), 0, st, M, levels[0], pose8, G.own);
+}
+void launch_mg_geometry_finish(const GraphDev& G, const MgDev& M, const MgLevelDev* levels, const double* pose8, hipStream_t st) {
+    (void)G;
+    hipLaunchKernelGGL(mg_geometry0_finish_kernel, dim3((unsigned)((M.n1 + 255) / 256)), dim3(256), 0, st, M, levels[0], pose8);
+    for (int l = 0; l + 1 < M.n_levels; ++l)
+        hipLaunchKernelGGL(mg_geometry_kernel, dim3((unsigned)((levels[l].n_next + 255) / 256)), dim3(256), 0, st, levels[l], levels[l + 1].pos);
+}
 
 // ---- Galerkin products ----
 // level 1 from the keyframe system: one wavefront per block; contributions as in coarse_assemble_kernel (reduced diagonal blocks C.Dtot and,
@@ -265,8 +294,14 @@ __global__ __launch_bounds__(256) void mg_dense_scatter_kernel(MgLevelDev A, Coa
     for (int64_t k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k)
         K.Ac[(size_t)(i * 6 + row) * K.nc + (size_t)A.col[k] * 6 + col] = A.val[(size_t)k * 36 + l];
 }
-void launch_mg_assemble(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, double omega, int32_t* fail, hipStream_t st) {
+void launch_mg_galerkin0(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, const MgDev& M, const MgLevelDev* levels, hipStream_t st) {
     hipLaunchKernelGGL(mg_galerkin0_kernel, dim3((unsigned)((levels[0].nnzb + 3) / 4)), dim3(256), 0, st, G, L, Sc, C, M, levels[0]);
+}
+void launch_mg_assemble(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, double omega, int32_t* fail, hipStream_t st) {
+    launch_mg_galerkin0(G, L, Sc, C, M, levels, st);
+    launch_mg_assemble_rest(M, levels, K, omega, fail, st);
+}
+void launch_mg_assemble_rest(const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, double omega, int32_t* fail, hipStream_t st) {
     for (int l = 1; l < M.n_levels; ++l)
         hipLaunchKernelGGL(mg_galerkin_kernel, dim3((unsigned)((levels[l].nnzb + 3) / 4)), dim3(256), 0, st, levels[l - 1], levels[l]);
     for (int l = 0; l + 1 < M.n_levels; ++l)
@@ -282,7 +317,7 @@ void launch_mg_assemble(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, 
 // ---- the cycle ----
 // r_1 = P_0^T r over the keyframes of each level-1 aggregate; x_1 = Dinv_1 r_1 (skipped when level 1 is the dense level)
 __global__ __launch_bounds__(CG_BLOCK) void mg_restrict0_kernel(MgDev M, const double* __restrict__ rv, double* __restrict__ r_out, double* __restrict__ x_out,
-                                                                 const double* __restrict__ Dinv, const int32_t* __restrict__ stop) {
+                                                                 const double* __restrict__ Dinv, const int32_t* __restrict__ stop, const double* __restrict__ own = nullptr /* several ranks: owner weights */) {
     __shared__ double rb[CG_BLOCK];
     const int stopped = stop ? *stop : 0;        // requested together with the first data loads, tested when they are needed: no round trip of its own
     const int a = blockIdx.x * MG_TILE_ROWS + threadIdx.x / 6, k = threadIdx.x % 6;
@@ -292,7 +327,8 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_restrict0_kernel(MgDev M, const d
     if (stopped) return;
     double s = 0.0;
     if (live) {
-        for (int m = m0; m < m1; ++m) { const int i = M.mem0[m]; s += mg_restrict_comp(rv + (size_t)i * 6, M.d0 + (size_t)i * 3, k); }
+        if (own) for (int m = m0; m < m1; ++m) { const int i = M.mem0[m]; s += own[i] * mg_restrict_comp(rv + (size_t)i * 6, M.d0 + (size_t)i * 3, k); }
+        else for (int m = m0; m < m1; ++m) { const int i = M.mem0[m]; s += mg_restrict_comp(rv + (size_t)i * 6, M.d0 + (size_t)i * 3, k); }
         r_out[(size_t)a * 6 + k] = s;
     }
     if (!x_out) return;
@@ -532,7 +568,8 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_prolong0_kernel(GraphDev G, MgDev
         double2 z = *zp;
         z.x += a0; z.y += a1;
         *zp = z;
-        acc += r.x * a0 + r.y * a1;
+        const double w = G.own ? G.own[n] : 1.0;      // several ranks: a shared keyframe counts once, at its owner
+        acc += w * (r.x * a0 + r.y * a1);
     }
     const double s = block_sum(acc, red);
     if (threadIdx.x == 0) part_rz[blockIdx.x] += s;
@@ -659,6 +696,47 @@ void launch_cg_update_mg(const GraphDev& G, const CgDev& C, const MgDev& M, cons
     const int g = cg_grid(G);
     if (M.n_levels == 1) hipLaunchKernelGGL(cg_update_mg_kernel, dim3(g), dim3(CG_BLOCK), 0, st, G, C, M, K.rc, (double*)nullptr, (const double*)nullptr, k & 1, n_pq_partials, g);
     else hipLaunchKernelGGL(cg_update_mg_kernel, dim3(g), dim3(CG_BLOCK), 0, st, G, C, M, levels[0].r, levels[0].x, (const double*)levels[0].Dinv, k & 1, n_pq_partials, g);
+}
+void launch_mg_restrict0(const GraphDev& G, const MgDev& M, const double* v, double* out, bool own_weighted, hipStream_t st) {
+    const unsigned g1 = (unsigned)((M.n1 + MG_TILE_ROWS - 1) / MG_TILE_ROWS);
+    hipLaunchKernelGGL(mg_restrict0_kernel, dim3(g1), dim3(CG_BLOCK), 0, st, M, v, out, (double*)nullptr, (const double*)nullptr, (const int32_t*)nullptr, own_weighted ? G.own : (const double*)nullptr);
+}
+// Several ranks.  The level-1 residual follows the keyframes' residual through the Chronopoulos-Gear recurrence: q1 = P0^T (A u), summed over the ranks inside the
+// iteration's ONE exchange, gives s1 = q1 + beta s1 and r1 -= alpha s1 with the alpha, beta cgcg_update_kernel has just used — no second collective for P0^T r.
+// x1 = w D1^-1 r1 is the cycle's first smoothing step.  mode 1 (PCG start, r1 freshly all-reduced): s1 = 0.
+__global__ __launch_bounds__(CG_BLOCK) void mg_level1_update_kernel(CgDev C, MgDev M, double* __restrict__ r1, double* __restrict__ x1, const double* __restrict__ Dinv1, int parity, int first, int mode) {
+    __shared__ double rb[CG_BLOCK];
+    if (mode == 0 && C.flags[0]) return;            // a stopped PCG keeps its state (the flag was set by an earlier kernel: uniform)
+    const int a = blockIdx.x * MG_TILE_ROWS + threadIdx.x / 6, k = threadIdx.x % 6;
+    const bool live = a < M.n1;
+    double r = 0.0;
+    if (live) {
+        const size_t i = (size_t)a * 6 + k;
+        if (mode == 0) {
+            const double alpha = C.scal[9 + 2 * parity];
+            const double beta = first ? 0.0 : C.scal[8 + 2 * parity] / C.scal[8 + 2 * (parity ^ 1)];
+            const double s = M.q1[i] + beta * M.s1[i];
+            M.s1[i] = s;
+            r = r1[i] - alpha * s;
+            r1[i] = r;
+        } else { M.s1[i] = 0.0; r = r1[i]; }
+    }
+    if (!x1) return;
+    rb[threadIdx.x] = r;
+    __syncthreads();
+    if (live) {
+        const double* Dk = Dinv1 + (size_t)a * 36 + k * 6;
+        const double* ra = rb + (threadIdx.x - k);
+        double x = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) x += Dk[j] * ra[j];
+        x1[(size_t)a * 6 + k] = x;
+    }
+}
+void launch_mg_level1_update(const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, int k, int first, int mode, hipStream_t st) {
+    const unsigned g1 = (unsigned)((M.n1 + MG_TILE_ROWS - 1) / MG_TILE_ROWS);
+    if (M.n_levels == 1) hipLaunchKernelGGL(mg_level1_update_kernel, dim3(g1), dim3(CG_BLOCK), 0, st, C, M, K.rc, (double*)nullptr, (const double*)nullptr, k & 1, first, mode);
+    else hipLaunchKernelGGL(mg_level1_update_kernel, dim3(g1), dim3(CG_BLOCK), 0, st, C, M, levels[0].r, levels[0].x, (const double*)levels[0].Dinv, k & 1, first, mode);
 }
 void launch_mg_apply(const GraphDev& G, const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, const double* r, double* z, double* part_rz, double scale, bool inside_iteration, hipStream_t st,
                      bool restricted) {

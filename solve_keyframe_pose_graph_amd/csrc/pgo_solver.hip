@@ -13,6 +13,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -88,6 +89,7 @@ struct pgo_problem {
     std::vector<double> h_own;                // [N] 1.0 where this rank is the keyframe's owner (lowest rank touching it)
     std::vector<double> h_init_q, h_init_t;   // multi-GPU: the caller's state at solve_begin (keyframes no rank touches are returned as given)
     DBuf<int32_t> d_l2g, d_sh_loc, d_sh_pos;  // shared keyframes touched here: local id, position in the global shared list
+    DBuf<int32_t> d_sh_src, d_sh_of;          // the inverse maps: global shared position -> local keyframe or -1; local keyframe -> shared position or -1
     DBuf<double> d_own, d_xbuf;               // owner weights; exchange buffer
     int64_t n_sh_mine = 0, n_sh_global = 0;
     DBuf<int32_t> d_rc1, d_rc2, d_sc1, d_sc2, d_sidx, d_bsr_col;
@@ -239,6 +241,7 @@ int upload_class(pgo_problem* p, const HostClass& H, bool is_sw, DBuf<int32_t>& 
 }
 
 int allreduce(pgo_problem* p, double* buf, size_t n, int op);
+int host_allreduce(pgo_problem* p, std::vector<double>& v, int op);
 
 int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
     // ---- validate against the array sizes the caller solves with
@@ -301,6 +304,14 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
         if (p->n_sh_mine) {
             HIPCHK(p, hipMemcpyAsync(p->d_sh_loc.p, sh_loc.data(), p->n_sh_mine * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
             HIPCHK(p, hipMemcpyAsync(p->d_sh_pos.p, sh_pos.data(), p->n_sh_mine * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
+        }
+        {   // the PCG iteration packs and reads the exchange buffer without pack / unpack kernels of its own (cgcg_pack_kernel, cgcg_update_kernel)
+            std::vector<int32_t> sh_src((size_t)std::max<int64_t>(p->n_sh_global, 1), -1), sh_of((size_t)std::max<int64_t>(N, 1), -1);
+            for (int64_t j = 0; j < p->n_sh_mine; ++j) { sh_src[sh_pos[j]] = sh_loc[j]; sh_of[sh_loc[j]] = sh_pos[j]; }
+            HIPCHK(p, p->d_sh_src.ensure(sh_src.size())); HIPCHK(p, p->d_sh_of.ensure(sh_of.size()));
+            HIPCHK(p, hipMemcpyAsync(p->d_sh_src.p, sh_src.data(), sh_src.size() * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
+            HIPCHK(p, hipMemcpyAsync(p->d_sh_of.p, sh_of.data(), sh_of.size() * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
+            HIPCHK(p, hipStreamSynchronize(p->st));
         }
         HIPCHK(p, hipStreamSynchronize(p->st));
         G.own = p->d_own.p;
@@ -512,10 +523,158 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
     C.x = v; C.r = v + n6; C.r2 = v + 2 * n6; C.z = v + 3 * n6; C.p = v + 4 * n6; C.p2 = v + 5 * n6; C.q = v + 6 * n6;
     C.part_pq = p->d_cgpart.p; C.part_rz = p->d_cgpart.p + PQ_SLOTS; C.scal = p->d_cgpart.p + PQ_SLOTS + 2 * RZ_STRIDE; C.extra_rz = 0;
     C.flags = p->d_flags.p;
+    // ---- aggregation multigrid for large graphs (single GPU): hierarchy of graph-following rigid aggregates, pgo_mg_host.hpp
+    p->coarse_built = false; p->coarse_active = false; p->K = CoarseDev{};
+    p->mg_built = false; p->mg_active = false; p->M = MgDev{}; p->mg_geometry_epoch = 0;
+    if (p->opt.mg_min_keyframes > 0 && Ng >= p->opt.mg_min_keyframes) {      // (the caller's keyframe count decides: the same answer on every rank)
+        pgo_mg::Hierarchy H;
+        const int dense_max = std::max(1, std::min(p->opt.mg_dense_max_nodes, 512));
+        const int passes0 = std::max(1, std::min(p->opt.mg_first_passes, 3)), passes = std::max(1, std::min(p->opt.mg_passes, 3));
+        std::vector<double> sw_w;
+        if (sw_now && S > 0) { sw_w.resize((size_t)Es); for (int64_t e = 0; e < Es; ++e) { const double sv = sw_now[p->swe.sw[e]]; sw_w[e] = sv * sv; } }
+        bool ok;
+        std::vector<int32_t> agg0_l, mem0_ptr_l, mem0_l;      // several ranks: the keyframe-indexed arrays in the handle's local numbering
+        std::vector<double> inv_cnt;
+        if (!p->local_ids) {
+            ok = pgo_mg::build_hierarchy(N, p->h_node_free, p->rel.c1, p->rel.c2, p->rel.meas.data() + 7, 8, p->swe.c1, p->swe.c2, sw_w.empty() ? nullptr : sw_w.data(), passes0, passes, dense_max, MG_TILE_ROWS,
+                                         MG_MAX_LEVELS, H, false, MG_BLOCK0);
+        } else {
+            // Several ranks: every rank gathers the endpoints and weights of ALL edges (one all-reduce of a zero-padded buffer: 24 B per edge, once per graph build)
+            // and builds the same hierarchy from the global graph; its own edges and owned keyframes are what it contributes to level 1 (pgo_mg_host.hpp).
+            std::vector<double> cnt((size_t)2 * p->world, 0.0);
+            cnt[(size_t)2 * p->rank] = (double)Er; cnt[(size_t)2 * p->rank + 1] = (double)Es;
+            if ((rc = host_allreduce(p, cnt, 0)) != PGO_OK) return rc;
+            int64_t ErT = 0, EsT = 0, my_r = 0, my_s = 0;
+            for (int r = 0; r < p->world; ++r) { if (r == p->rank) { my_r = ErT; my_s = EsT; } ErT += (int64_t)(cnt[(size_t)2 * r] + 0.5); EsT += (int64_t)(cnt[(size_t)2 * r + 1] + 0.5); }
+            std::vector<double> buf((size_t)3 * (ErT + EsT), 0.0);
+            double* b_rc1 = buf.data(); double* b_rc2 = b_rc1 + ErT; double* b_rw = b_rc2 + ErT; double* b_sc1 = b_rw + ErT; double* b_sc2 = b_sc1 + EsT; double* b_sw = b_sc2 + EsT;
+            for (int64_t e = 0; e < Er; ++e) { b_rc1[my_r + e] = p->rel.c1[e]; b_rc2[my_r + e] = p->rel.c2[e]; b_rw[my_r + e] = p->rel.meas[(size_t)8 * e + 7]; }
+            for (int64_t e = 0; e < Es; ++e) { b_sc1[my_s + e] = p->swe.c1[e]; b_sc2[my_s + e] = p->swe.c2[e]; b_sw[my_s + e] = sw_w.empty() ? 1.0 : sw_w[e]; }
+            if ((rc = host_allreduce(p, buf, 0)) != PGO_OK) return rc;
+            std::vector<int32_t> grc1((size_t)ErT), grc2((size_t)ErT), gsc1((size_t)EsT), gsc2((size_t)EsT);
+            std::vector<double> grw(b_rw, b_rw + ErT), gsw(b_sw, b_sw + EsT);
+            for (int64_t e = 0; e < ErT; ++e) { grc1[e] = (int32_t)(b_rc1[e] + 0.5); grc2[e] = (int32_t)(b_rc2[e] + 0.5); }
+            for (int64_t e = 0; e < EsT; ++e) { gsc1[e] = (int32_t)(b_sc1[e] + 0.5); gsc2[e] = (int32_t)(b_sc2[e] + 0.5); }
+            std::vector<uint8_t> gfree((size_t)Ng);
+            for (int64_t g = 0; g < Ng; ++g) gfree[g] = p->h_touched_any[g];
+            for (int32_t c : p->constant_nodes) if (c >= 0 && c < Ng) gfree[c] = 0;
+            const pgo_mg::LocalContrib local{&p->l2g, &p->h_own, &p->rel.c1, &p->rel.c2, &p->swe.c1, &p->swe.c2};
+            ok = pgo_mg::build_hierarchy(Ng, gfree, grc1, grc2, grw.data(), 1, gsc1, gsc2, (sw_now && S > 0) ? gsw.data() : nullptr, passes0, passes, dense_max, MG_TILE_ROWS, MG_MAX_LEVELS, H, false, 0, &local);
+            if (ok) {
+                const int32_t n1g = (int32_t)H.mem0_ptr.size() - 1;
+                inv_cnt.resize((size_t)n1g);
+                for (int32_t a = 0; a < n1g; ++a) inv_cnt[a] = 1.0 / (double)std::max(1, H.mem0_ptr[a + 1] - H.mem0_ptr[a]);
+                agg0_l.resize((size_t)N); mem0_ptr_l.assign((size_t)n1g + 1, 0);
+                for (int64_t l = 0; l < N; ++l) { agg0_l[l] = p->h_node_free[l] ? H.agg0[p->l2g[l]] : -1; if (agg0_l[l] >= 0) mem0_ptr_l[(size_t)agg0_l[l] + 1]++; }
+                for (int32_t a = 0; a < n1g; ++a) mem0_ptr_l[(size_t)a + 1] += mem0_ptr_l[a];
+                mem0_l.resize((size_t)mem0_ptr_l[n1g]);
+                std::vector<int32_t> fillm(mem0_ptr_l.begin(), mem0_ptr_l.end() - 1);
+                for (int64_t l = 0; l < N; ++l) if (agg0_l[l] >= 0) mem0_l[(size_t)fillm[agg0_l[l]]++] = (int32_t)l;
+            }
+        }
+        const std::vector<int32_t>& A0 = p->local_ids ? agg0_l : H.agg0;
+        const std::vector<int32_t>& M0P = p->local_ids ? mem0_ptr_l : H.mem0_ptr;
+        const std::vector<int32_t>& M0 = p->local_ids ? mem0_l : H.mem0;
+        if (ok) {
+            const int nl = (int)H.L.size();
+            // pooled arrays: (offset, count) per array; doubles rounded up to even counts (16-B loads)
+            std::vector<int32_t> pi32; std::vector<int64_t> pi64;
+            auto put32 = [&](const std::vector<int32_t>& v) { const size_t o = pi32.size(); pi32.insert(pi32.end(), v.begin(), v.end()); return o; };
+            auto put64 = [&](const std::vector<int64_t>& v) { const size_t o = pi64.size(); pi64.insert(pi64.end(), v.begin(), v.end()); return o; };
+            size_t nf64 = 0;
+            auto take = [&](size_t cnt) { const size_t o = nf64; nf64 += (cnt + 1) & ~(size_t)1; return o; };
+            struct Off { size_t col, parent, agg_ptr, tile, tile_rows, rowptr, g_ptr, g_ent, val, Dinv, pos, d, r, x, xt, xf, valf; };
+            std::vector<Off> off((size_t)nl);
+            const size_t o_agg0 = put32(A0), o_mem0_ptr = put32(M0P), o_mem0 = put32(M0);
+            // slot table of the restriction inside the vector update: per run of MG_BLOCK0 keyframes its aggregates {id, 8 members as run-local bytes}
+            size_t o_blk_tab = 0; bool have_tab = !p->local_ids;
+            if (have_tab) {
+                const int64_t runs = (N + MG_BLOCK0 - 1) / MG_BLOCK0;
+                std::vector<int32_t> tab((size_t)runs * MG_BLOCK0 * 4);
+                for (size_t k = 0; k < tab.size(); k += 4) { tab[k] = -1; tab[k + 1] = -1; tab[k + 2] = -1; tab[k + 3] = 0; }
+                std::vector<int> fill((size_t)runs, 0);
+                const int32_t n1h = (int32_t)H.mem0_ptr.size() - 1;
+                for (int32_t a = 0; a < n1h && have_tab; ++a) {
+                    const int32_t m0 = H.mem0_ptr[a], m1 = H.mem0_ptr[a + 1];
+                    if (m1 <= m0) continue;
+                    const int64_t run = H.mem0[m0] / MG_BLOCK0;
+                    if (m1 - m0 > 8 || fill[run] >= MG_BLOCK0) { have_tab = false; break; }
+                    uint32_t w[2] = {0xffffffffu, 0xffffffffu};
+                    for (int32_t m = m0; m < m1; ++m) {
+                        if (H.mem0[m] / MG_BLOCK0 != run) { have_tab = false; break; }
+                        const int j = m - m0;
+                        w[j >> 2] = (w[j >> 2] & ~(0xffu << (8 * (j & 3)))) | ((uint32_t)(H.mem0[m] - run * MG_BLOCK0) << (8 * (j & 3)));
+                    }
+                    int32_t* e = &tab[((size_t)run * MG_BLOCK0 + fill[run]++) * 4];
+                    e[0] = a; e[1] = (int32_t)w[0]; e[2] = (int32_t)w[1];
+                }
+                if (have_tab) { while (pi32.size() % 4) pi32.push_back(0); o_blk_tab = put32(tab); }
+            }
+            const size_t o_d0 = take((size_t)N * 3);
+            const size_t n1_all = (size_t)H.L[0].n;
+            const size_t o_inv = p->local_ids ? take(n1_all) : 0, o_q1 = p->local_ids ? take(n1_all * 6) : 0, o_s1 = p->local_ids ? take(n1_all * 6) : 0;
+            for (int l = 0; l < nl; ++l) {
+                const pgo_mg::HostLevel& A = H.L[l];
+                Off& o = off[l];
+                o.col = put32(A.col); o.parent = put32(A.parent); o.agg_ptr = put32(A.agg_ptr);
+                {   // per tile {a0, a1, i0, i1}, 16-B aligned
+                    std::vector<int32_t> info;
+                    for (size_t tt = 0; tt + 1 < A.tile_agg0.size(); ++tt) { const int32_t a0 = A.tile_agg0[tt], a1 = A.tile_agg0[tt + 1]; info.insert(info.end(), {a0, a1, A.agg_ptr[a0], A.agg_ptr[a1]}); }
+                    while (pi32.size() % 4) pi32.push_back(0);
+                    o.tile = put32(info);
+                    std::vector<int32_t> rows;      // [tile][MG_TILE_ROWS] {first block, end block} of each row of the tile
+                    for (size_t tt = 0; tt + 1 < A.tile_agg0.size(); ++tt) {
+                        const int32_t i0 = A.agg_ptr[A.tile_agg0[tt]], i1 = A.agg_ptr[A.tile_agg0[tt + 1]];
+                        for (int li = 0; li < MG_TILE_ROWS; ++li) { const int32_t r = i0 + li; rows.push_back(r < i1 ? (int32_t)A.rowptr[r] : 0); rows.push_back(r < i1 ? (int32_t)A.rowptr[r + 1] : 0); }
+                    }
+                    o.tile_rows = put32(rows);
+                }
+                o.rowptr = put64(A.rowptr); o.g_ptr = put64(A.g_ptr); o.g_ent = put64(A.g_ent);
+                o.val = take(A.col.size() * 36); o.Dinv = take((size_t)A.n * 36); o.pos = take((size_t)A.n * 3); o.d = take((size_t)A.n * 3);
+                o.r = take((size_t)A.n * 6); o.x = take((size_t)A.n * 6); o.xt = take((size_t)A.n * 6); o.xf = take((size_t)A.n * 6);
+                o.valf = take((A.col.size() * 36 + 1) / 2);      // fp32 copy of the blocks, carved out of the fp64 pool
+            }
+            const int n_top = H.L[nl - 1].n;
+            const int nc = (6 * n_top + 63) / 64 * 64;
+            HIPCHK(p, p->d_mg_i32.ensure(std::max<size_t>(pi32.size(), 1))); HIPCHK(p, p->d_mg_i64.ensure(std::max<size_t>(pi64.size(), 1))); HIPCHK(p, p->d_mg_f64.ensure(std::max<size_t>(nf64, 2)));
+            HIPCHK(p, p->d_cAc.ensure((size_t)nc * nc)); HIPCHK(p, p->d_cAcf.ensure((size_t)nc * nc)); HIPCHK(p, p->d_crc.ensure((size_t)nc * 2)); HIPCHK(p, p->d_cscr.ensure((size_t)nc * 64 + 1024)); HIPCHK(p, p->d_cinfo.ensure(4));
+            HIPCHK(p, hipMemcpyAsync(p->d_mg_i32.p, pi32.data(), pi32.size() * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
+            HIPCHK(p, hipMemcpyAsync(p->d_mg_i64.p, pi64.data(), pi64.size() * sizeof(int64_t), hipMemcpyHostToDevice, p->st));
+            HIPCHK(p, hipMemsetAsync(p->d_mg_f64.p, 0, nf64 * sizeof(double), p->st));
+            HIPCHK(p, hipMemsetAsync(p->d_crc.p, 0, (size_t)nc * 2 * sizeof(double), p->st));
+            HIPCHK(p, hipStreamSynchronize(p->st));
+            const int32_t* b32 = p->d_mg_i32.p; const int64_t* b64 = p->d_mg_i64.p; double* bf = p->d_mg_f64.p;
+            p->M = MgDev{nl, H.L[0].n, b32 + o_agg0, b32 + o_mem0_ptr, b32 + o_mem0, bf + o_d0, have_tab ? reinterpret_cast<const int4*>(b32 + o_blk_tab) : nullptr, nullptr, nullptr, nullptr};
+            if (p->local_ids) {
+                HIPCHK(p, hipMemcpyAsync(bf + o_inv, inv_cnt.data(), inv_cnt.size() * sizeof(double), hipMemcpyHostToDevice, p->st));
+                HIPCHK(p, hipStreamSynchronize(p->st));
+                p->M.inv_cnt = bf + o_inv; p->M.q1 = bf + o_q1; p->M.s1 = bf + o_s1;
+            }
+            for (int l = 0; l < nl; ++l) {
+                const pgo_mg::HostLevel& A = H.L[l];
+                const Off& o = off[l];
+                MgLevelDev& D = p->mg_levels[l];
+                D = MgLevelDev{};
+                D.n = A.n; D.n_next = l + 1 < nl ? H.L[l + 1].n : 0; D.tiles = A.tile_agg0.empty() ? 0 : (int32_t)A.tile_agg0.size() - 1; D.nnzb = (int64_t)A.col.size();
+                D.rowptr = b64 + o.rowptr; D.col = b32 + o.col; D.val = bf + o.val; D.g_ptr = b64 + o.g_ptr; D.g_ent = b64 + o.g_ent;
+                D.Dinv = bf + o.Dinv; D.pos = bf + o.pos; D.d = bf + o.d; D.parent = b32 + o.parent; D.agg_ptr = b32 + o.agg_ptr; D.tile_info = reinterpret_cast<const int4*>(b32 + o.tile); D.tile_rows = reinterpret_cast<const int2*>(b32 + o.tile_rows);
+                D.r = bf + o.r; D.x = bf + o.x; D.xt = bf + o.xt; D.xf = bf + o.xf; D.valf = reinterpret_cast<float*>(bf + o.valf);
+            }
+            // the dense coarsest level shares the buffers of the two-level preconditioner, which the multigrid replaces on this graph
+            p->coarse_built = false;
+            p->K = CoarseDev{};
+            p->K.n_agg = n_top; p->K.nc = nc; p->K.Ac = p->d_cAc.p; p->K.Acf = p->d_cAcf.p; p->K.rc = p->d_crc.p; p->K.yc = p->d_crc.p + nc;
+            p->mg_built = true;
+            if (p->opt.verbosity > 0) {
+                std::fprintf(stderr, "[pgo] multigrid: %lld keyframes", (long long)N);
+                for (int l = 0; l < nl; ++l) std::fprintf(stderr, " -> %d (%lld blocks)", H.L[l].n, (long long)H.L[l].col.size());
+                std::fprintf(stderr, ", coarsest dense %d\n", nc);
+            }
+        } else if (p->opt.verbosity > 0) std::fprintf(stderr, "[pgo] multigrid: the graph does not coarsen (isolated keyframes?) -> off\n");
+    }
     // ---- two-level preconditioner: aggregates of consecutive keyframes and, per coarse 6x6 block (a <= b), the ordered list of fine
     // blocks that project onto it (single GPU; enough keyframes per aggregate to be worth it)
-    p->coarse_built = false; p->coarse_active = false; p->K = CoarseDev{};
-    {
+    if (!p->mg_built) {      // (a graph that got the multigrid never uses the two-level method: its dense operator would be built and uploaded for nothing)
         int n_agg = p->opt.coarse_aggregates;
         // a graph with no more keyframes than `half` (256 by default) gets one aggregate per keyframe: the coarse operator IS the reduced system and the "preconditioner"
         // its dense inverse (a direct solve; the PCG around it only refines); larger graphs: at least 8 keyframes per aggregate, but not fewer than `half` aggregates — the
@@ -566,104 +725,12 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
             p->coarse_built = true;
         }
     }
-    // ---- aggregation multigrid for large graphs (single GPU): hierarchy of graph-following rigid aggregates, pgo_mg_host.hpp
-    p->mg_built = false; p->mg_active = false; p->M = MgDev{}; p->mg_geometry_epoch = 0;
-    if (!p->local_ids && p->opt.mg_min_keyframes > 0 && N >= p->opt.mg_min_keyframes) {
-        pgo_mg::Hierarchy H;
-        const int dense_max = std::max(1, std::min(p->opt.mg_dense_max_nodes, 512));
-        std::vector<double> sw_w;
-        if (sw_now && S > 0) { sw_w.resize((size_t)Es); for (int64_t e = 0; e < Es; ++e) { const double sv = sw_now[p->swe.sw[e]]; sw_w[e] = sv * sv; } }
-        const bool ok = pgo_mg::build_hierarchy(N, p->h_node_free, p->rel.c1, p->rel.c2, p->rel.meas.data(), p->swe.c1, p->swe.c2, sw_w.empty() ? nullptr : sw_w.data(), std::max(1, std::min(p->opt.mg_first_passes, 3)),
-                                                std::max(1, std::min(p->opt.mg_passes, 3)), dense_max, MG_TILE_ROWS, MG_MAX_LEVELS, H, false, MG_BLOCK0);
-        if (ok) {
-            const int nl = (int)H.L.size();
-            // pooled arrays: (offset, count) per array; doubles rounded up to even counts (16-B loads)
-            std::vector<int32_t> pi32; std::vector<int64_t> pi64;
-            auto put32 = [&](const std::vector<int32_t>& v) { const size_t o = pi32.size(); pi32.insert(pi32.end(), v.begin(), v.end()); return o; };
-            auto put64 = [&](const std::vector<int64_t>& v) { const size_t o = pi64.size(); pi64.insert(pi64.end(), v.begin(), v.end()); return o; };
-            size_t nf64 = 0;
-            auto take = [&](size_t cnt) { const size_t o = nf64; nf64 += (cnt + 1) & ~(size_t)1; return o; };
-            struct Off { size_t col, parent, agg_ptr, tile, tile_rows, rowptr, g_ptr, g_ent, val, Dinv, pos, d, r, x, xt, xf, valf; };
-            std::vector<Off> off((size_t)nl);
-            const size_t o_agg0 = put32(H.agg0), o_mem0_ptr = put32(H.mem0_ptr), o_mem0 = put32(H.mem0);
-            // slot table of the restriction inside the vector update: per run of MG_BLOCK0 keyframes its aggregates {id, 8 members as run-local bytes}
-            size_t o_blk_tab = 0; bool have_tab = true;
-            {
-                const int64_t runs = (N + MG_BLOCK0 - 1) / MG_BLOCK0;
-                std::vector<int32_t> tab((size_t)runs * MG_BLOCK0 * 4);
-                for (size_t k = 0; k < tab.size(); k += 4) { tab[k] = -1; tab[k + 1] = -1; tab[k + 2] = -1; tab[k + 3] = 0; }
-                std::vector<int> fill((size_t)runs, 0);
-                const int32_t n1h = (int32_t)H.mem0_ptr.size() - 1;
-                for (int32_t a = 0; a < n1h && have_tab; ++a) {
-                    const int32_t m0 = H.mem0_ptr[a], m1 = H.mem0_ptr[a + 1];
-                    if (m1 <= m0) continue;
-                    const int64_t run = H.mem0[m0] / MG_BLOCK0;
-                    if (m1 - m0 > 8 || fill[run] >= MG_BLOCK0) { have_tab = false; break; }
-                    uint32_t w[2] = {0xffffffffu, 0xffffffffu};
-                    for (int32_t m = m0; m < m1; ++m) {
-                        if (H.mem0[m] / MG_BLOCK0 != run) { have_tab = false; break; }
-                        const int j = m - m0;
-                        w[j >> 2] = (w[j >> 2] & ~(0xffu << (8 * (j & 3)))) | ((uint32_t)(H.mem0[m] - run * MG_BLOCK0) << (8 * (j & 3)));
-                    }
-                    int32_t* e = &tab[((size_t)run * MG_BLOCK0 + fill[run]++) * 4];
-                    e[0] = a; e[1] = (int32_t)w[0]; e[2] = (int32_t)w[1];
-                }
-                if (have_tab) { while (pi32.size() % 4) pi32.push_back(0); o_blk_tab = put32(tab); }
-            }
-            const size_t o_d0 = take((size_t)N * 3);
-            for (int l = 0; l < nl; ++l) {
-                const pgo_mg::HostLevel& A = H.L[l];
-                Off& o = off[l];
-                o.col = put32(A.col); o.parent = put32(A.parent); o.agg_ptr = put32(A.agg_ptr);
-                {   // per tile {a0, a1, i0, i1}, 16-B aligned
-                    std::vector<int32_t> info;
-                    for (size_t tt = 0; tt + 1 < A.tile_agg0.size(); ++tt) { const int32_t a0 = A.tile_agg0[tt], a1 = A.tile_agg0[tt + 1]; info.insert(info.end(), {a0, a1, A.agg_ptr[a0], A.agg_ptr[a1]}); }
-                    while (pi32.size() % 4) pi32.push_back(0);
-                    o.tile = put32(info);
-                    std::vector<int32_t> rows;      // [tile][MG_TILE_ROWS] {first block, end block} of each row of the tile
-                    for (size_t tt = 0; tt + 1 < A.tile_agg0.size(); ++tt) {
-                        const int32_t i0 = A.agg_ptr[A.tile_agg0[tt]], i1 = A.agg_ptr[A.tile_agg0[tt + 1]];
-                        for (int li = 0; li < MG_TILE_ROWS; ++li) { const int32_t r = i0 + li; rows.push_back(r < i1 ? (int32_t)A.rowptr[r] : 0); rows.push_back(r < i1 ? (int32_t)A.rowptr[r + 1] : 0); }
-                    }
-                    o.tile_rows = put32(rows);
-                }
-                o.rowptr = put64(A.rowptr); o.g_ptr = put64(A.g_ptr); o.g_ent = put64(A.g_ent);
-                o.val = take(A.col.size() * 36); o.Dinv = take((size_t)A.n * 36); o.pos = take((size_t)A.n * 3); o.d = take((size_t)A.n * 3);
-                o.r = take((size_t)A.n * 6); o.x = take((size_t)A.n * 6); o.xt = take((size_t)A.n * 6); o.xf = take((size_t)A.n * 6);
-                o.valf = take((A.col.size() * 36 + 1) / 2);      // fp32 copy of the blocks, carved out of the fp64 pool
-            }
-            const int n_top = H.L[nl - 1].n;
-            const int nc = (6 * n_top + 63) / 64 * 64;
-            HIPCHK(p, p->d_mg_i32.ensure(std::max<size_t>(pi32.size(), 1))); HIPCHK(p, p->d_mg_i64.ensure(std::max<size_t>(pi64.size(), 1))); HIPCHK(p, p->d_mg_f64.ensure(std::max<size_t>(nf64, 2)));
-            HIPCHK(p, p->d_cAc.ensure((size_t)nc * nc)); HIPCHK(p, p->d_cAcf.ensure((size_t)nc * nc)); HIPCHK(p, p->d_crc.ensure((size_t)nc * 2)); HIPCHK(p, p->d_cscr.ensure((size_t)nc * 64 + 1024)); HIPCHK(p, p->d_cinfo.ensure(4));
-            HIPCHK(p, hipMemcpyAsync(p->d_mg_i32.p, pi32.data(), pi32.size() * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
-            HIPCHK(p, hipMemcpyAsync(p->d_mg_i64.p, pi64.data(), pi64.size() * sizeof(int64_t), hipMemcpyHostToDevice, p->st));
-            HIPCHK(p, hipMemsetAsync(p->d_mg_f64.p, 0, nf64 * sizeof(double), p->st));
-            HIPCHK(p, hipMemsetAsync(p->d_crc.p, 0, (size_t)nc * 2 * sizeof(double), p->st));
-            HIPCHK(p, hipStreamSynchronize(p->st));
-            const int32_t* b32 = p->d_mg_i32.p; const int64_t* b64 = p->d_mg_i64.p; double* bf = p->d_mg_f64.p;
-            p->M = MgDev{nl, H.L[0].n, b32 + o_agg0, b32 + o_mem0_ptr, b32 + o_mem0, bf + o_d0, have_tab ? reinterpret_cast<const int4*>(b32 + o_blk_tab) : nullptr};
-            for (int l = 0; l < nl; ++l) {
-                const pgo_mg::HostLevel& A = H.L[l];
-                const Off& o = off[l];
-                MgLevelDev& D = p->mg_levels[l];
-                D = MgLevelDev{};
-                D.n = A.n; D.n_next = l + 1 < nl ? H.L[l + 1].n : 0; D.tiles = A.tile_agg0.empty() ? 0 : (int32_t)A.tile_agg0.size() - 1; D.nnzb = (int64_t)A.col.size();
-                D.rowptr = b64 + o.rowptr; D.col = b32 + o.col; D.val = bf + o.val; D.g_ptr = b64 + o.g_ptr; D.g_ent = b64 + o.g_ent;
-                D.Dinv = bf + o.Dinv; D.pos = bf + o.pos; D.d = bf + o.d; D.parent = b32 + o.parent; D.agg_ptr = b32 + o.agg_ptr; D.tile_info = reinterpret_cast<const int4*>(b32 + o.tile); D.tile_rows = reinterpret_cast<const int2*>(b32 + o.tile_rows);
-                D.r = bf + o.r; D.x = bf + o.x; D.xt = bf + o.xt; D.xf = bf + o.xf; D.valf = reinterpret_cast<float*>(bf + o.valf);
-            }
-            // the dense coarsest level shares the buffers of the two-level preconditioner, which the multigrid replaces on this graph
-            p->coarse_built = false;
-            p->K = CoarseDev{};
-            p->K.n_agg = n_top; p->K.nc = nc; p->K.Ac = p->d_cAc.p; p->K.Acf = p->d_cAcf.p; p->K.rc = p->d_crc.p; p->K.yc = p->d_crc.p + nc;
-            p->mg_built = true;
-            if (p->opt.verbosity > 0) {
-                std::fprintf(stderr, "[pgo] multigrid: %lld keyframes", (long long)N);
-                for (int l = 0; l < nl; ++l) std::fprintf(stderr, " -> %d (%lld blocks)", H.L[l].n, (long long)H.L[l].col.size());
-                std::fprintf(stderr, ", coarsest dense %d\n", nc);
-            }
-        } else if (p->opt.verbosity > 0) std::fprintf(stderr, "[pgo] multigrid: the graph does not coarsen (isolated keyframes?) -> off\n");
+    if (p->local_ids) {
+        // the exchange buffer is sized here once for everything a solve sends (42 doubles per shared keyframe at linearisation; 6 + the level-1 vector in the PCG),
+        // so its address is stable: the multigrid's q1 = P0^T (A u) is produced straight into its tail
+        const size_t n1 = p->mg_built ? (size_t)p->M.n1 : 0;
+        HIPCHK(p, p->d_xbuf.ensure((size_t)p->n_sh_global * 42 + 2 + 6 * n1 + 64));
+        if (p->mg_built) p->M.q1 = p->d_xbuf.p + (size_t)p->n_sh_global * 6 + 2;
     }
     p->graph_dirty = false; p->priors_dirty = false;
     ++p->build_epoch;   // invalidates the captured PCG graph (kernel arguments hold device pointers / sizes)
@@ -686,21 +753,35 @@ int allreduce(pgo_problem* p, double* buf, size_t n, int op /*0 sum, 2 max*/) {
 // Multi-GPU exchange: sums, over the ranks sharing them, the rows of one or two keyframe-indexed device arrays (k1 + k2 doubles per
 // keyframe) and `n_extra` scalars (summed over ALL ranks, in place at `extra`) with ONE all-reduce of n_shared*(k1+k2) + n_extra doubles.
 // Keyframes touched by a single rank never travel.
-int exchange_rows(pgo_problem* p, double* a1, int k1, double* a2, int k2, double* extra, int n_extra, const int32_t* stop = nullptr) {
+// `extra2` / `n_extra2`: a second block summed over all ranks in the same all-reduce (the level-1 vector P0^T (A u) of the multigrid-preconditioned PCG).
+int exchange_rows(pgo_problem* p, double* a1, int k1, double* a2, int k2, double* extra, int n_extra, const int32_t* stop = nullptr, double* extra2 = nullptr, size_t n_extra2 = 0) {
     if (!p->local_ids) return PGO_OK;
     const int K = k1 + k2;
     const size_t n = (size_t)p->n_sh_global * K;
-    if (n + n_extra == 0) return PGO_OK;
-    HIPCHK(p, p->d_xbuf.ensure(n + n_extra));
+    if (n + n_extra + n_extra2 == 0) return PGO_OK;
+    HIPCHK(p, p->d_xbuf.ensure(n + n_extra + n_extra2));
     if (n) HIPCHK(p, hipMemsetAsync(p->d_xbuf.p, 0, n * sizeof(double), p->st));
     launch_pack_rows(p->d_xbuf.p, K, 0, a1, k1, p->n_sh_mine, p->d_sh_loc.p, p->d_sh_pos.p, p->st);
     if (a2) launch_pack_rows(p->d_xbuf.p, K, k1, a2, k2, p->n_sh_mine, p->d_sh_loc.p, p->d_sh_pos.p, p->st);
     if (n_extra) HIPCHK(p, hipMemcpyAsync(p->d_xbuf.p + n, extra, n_extra * sizeof(double), hipMemcpyDeviceToDevice, p->st));
+    if (n_extra2) HIPCHK(p, hipMemcpyAsync(p->d_xbuf.p + n + n_extra, extra2, n_extra2 * sizeof(double), hipMemcpyDeviceToDevice, p->st));
     int rc;
-    if ((rc = allreduce(p, p->d_xbuf.p, n + n_extra, 0)) != PGO_OK) return rc;
+    if ((rc = allreduce(p, p->d_xbuf.p, n + n_extra + n_extra2, 0)) != PGO_OK) return rc;
     launch_unpack_rows(p->d_xbuf.p, K, 0, a1, k1, p->n_sh_mine, p->d_sh_loc.p, p->d_sh_pos.p, stop, p->st);
     if (a2) launch_unpack_rows(p->d_xbuf.p, K, k1, a2, k2, p->n_sh_mine, p->d_sh_loc.p, p->d_sh_pos.p, stop, p->st);
     if (n_extra) HIPCHK(p, hipMemcpyAsync(extra, p->d_xbuf.p + n, n_extra * sizeof(double), hipMemcpyDeviceToDevice, p->st));
+    if (n_extra2) HIPCHK(p, hipMemcpyAsync(extra2, p->d_xbuf.p + n + n_extra, n_extra2 * sizeof(double), hipMemcpyDeviceToDevice, p->st));
+    return PGO_OK;
+}
+// all-reduce of a host vector (graph build: rare, sizes up to a few tens of MB)
+int host_allreduce(pgo_problem* p, std::vector<double>& v, int op) {
+    if (v.empty()) return PGO_OK;
+    HIPCHK(p, p->d_tmp.ensure(v.size()));
+    HIPCHK(p, hipMemcpyAsync(p->d_tmp.p, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice, p->st));
+    int rc;
+    if ((rc = allreduce(p, p->d_tmp.p, v.size(), op)) != PGO_OK) return rc;
+    HIPCHK(p, hipMemcpyAsync(v.data(), p->d_tmp.p, v.size() * sizeof(double), hipMemcpyDeviceToHost, p->st));
+    HIPCHK(p, hipStreamSynchronize(p->st));
     return PGO_OK;
 }
 
@@ -814,6 +895,25 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
     const int fused_parts = fused_coarse ? coarse_update_grid(p->G, p->K) : 0;
     if (fused_coarse) p->C.extra_rz = coarse_solve_grid(p->K);
     else if (!p->mg_active) p->C.extra_rz = 0;
+    // several ranks, PCG start: r = b (- A x), u = M^-1 r, p = s = 0; part_rz <- owner-weighted partials of gamma_0 (they travel with the first exchange),
+    // part_pq <- partials of b.D^-1 b, summed over ranks here once: the reference norm of the stopping test.  With the multigrid: r1 = P0^T r by one all-reduce
+    // of the owner-weighted partial restrictions (inside the iterations r1 follows by recurrence), the cycle on the replicated levels, z += P0 x1.
+    auto start_multi = [&](int warm_i) -> int {
+        int rcs;
+        const int g = launch_cg_init_vectors(p->G, p->C, warm_i, p->st);
+        if (p->mg_active) {
+            double* r1 = p->M.n_levels == 1 ? p->K.rc : p->mg_levels[0].r;
+            launch_mg_restrict0(p->G, p->M, p->C.r, r1, true, p->st);
+            if ((rcs = allreduce(p, r1, (size_t)p->M.n1 * 6, 0)) != PGO_OK) return rcs;
+            launch_mg_level1_update(p->C, p->M, p->mg_levels, p->K, 0, 1, 1, p->st);
+            launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz, mg_scale(p), false, p->st, true);
+        }
+        double* bb = p->C.scal + 12;
+        launch_reduce(p->C.part_pq, g, 0, bb, p->st);
+        if ((rcs = allreduce(p, bb, 1, 0)) != PGO_OK) return rcs;
+        launch_cgcg_scalars_init(p->C, bb, tol2, p->st);
+        return PGO_OK;
+    };
     if (resume_from < 0) {
         if (!multi && (p->coarse_active || p->mg_active)) {
             // z = D^-1 r + P Ac^-1 P^T r (or the multigrid cycle): the coarse term is added to z and to the r.z partials before the scalars are formed
@@ -826,15 +926,7 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
             }
             launch_cg_init_scalars(p->C, g, tol2, p->st);
         } else if (!multi) launch_cg_init(p->G, p->C, warm ? 1 : 0, tol2, p->st);
-        else {
-            // r = b (- A x), u = M^-1 r, p = s = 0; part_rz <- owner-weighted partials of gamma_0 (they travel with the first exchange),
-            // part_pq <- partials of b.M^-1 b, summed over ranks here once: the reference norm of the stopping test
-            const int g = launch_cg_init_vectors(p->G, p->C, warm ? 1 : 0, p->st);
-            double* bb = p->C.scal + 12;
-            launch_reduce(p->C.part_pq, g, 0, bb, p->st);
-            if ((rc0 = allreduce(p, bb, 1, 0)) != PGO_OK) return rc0;
-            launch_cgcg_scalars_init(p->C, bb, tol2, p->st);
-        }
+        else if ((rc0 = start_multi(warm ? 1 : 0)) != PGO_OK) return rc0;
     }
     int k = resume_from >= 0 ? resume_from : 0;
     int32_t hflags[3] = {0, 0, 0};
@@ -845,6 +937,7 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
         // captured chunks stay at <= 72 kernel nodes (rocprofv3 7.2 crashes while a graph of 120 nodes is captured under --kernel-trace; 80 are fine): five kernels
         // per iteration with the coarse space in its unfused form -> 12 iterations, three in the fused form -> 24
         if (p->coarse_active && !multi) e = std::min(e, fused_coarse ? 24 : 12);
+        if (p->mg_active && multi) e = std::min(e, std::max(2, (72 / (2 * p->M.n_levels + 7)) & ~1));
         if (p->mg_active && !multi) e = std::max(2, (72 / (2 * p->M.n_levels + 3)) & ~1);   // at most 2 n_levels + 1 cycle kernels + matvec + update per iteration (one less with the restriction inside the update)
         return e;
     };
@@ -856,11 +949,21 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
             int g_pq = g;
             if (p->built_mf) { launch_mf_apply_dot(p->G, p->F, p->Sc, p->C, p->C.z, p->C.q, p->st); g_pq = mf_grid_size(p->F); }   // w = A_r u and the partials of u.w in one kernel
             else { launch_apply_operator(p->G, p->C, p->C.z, p->C.q, p->st); launch_cgcg_dots(p->G, p->C, p->st); }
-            double* two = p->C.scal + 12;                                  // [delta, gamma]
-            launch_cg_reduce2_live(p->C, p->C.part_pq, g_pq, p->C.part_rz, g, two, p->st);
-            int r2 = exchange_rows(p, p->C.q, 6, nullptr, 0, two, 2, p->C.flags);   // the ONE exchange per CG iteration
+            // Four stream operations per iteration: matvec (+ dot partials), pack, all-reduce, update.  The exchange buffer is
+            //   [ 6 x n_shared rows of w | delta = u.Au | gamma = r.u | (multigrid) q1 = P0^T (A u), 6 x n1 ]
+            // packed by one kernel (zeros where this rank does not touch a shared keyframe), summed in place, and read in place by the update.
+            double* xb = p->d_xbuf.p;
+            const size_t nrow = (size_t)p->n_sh_global * 6;
+            // multigrid: this rank's part of q1 = P0^T (A u) (all its rows of A_r u, before the shared ones are summed) rides in the same exchange
+            if (p->mg_active) launch_mg_restrict0(p->G, p->M, p->C.q, p->M.q1, false, p->st);
+            launch_cgcg_pack(p->C, p->d_sh_src.p, p->n_sh_global, p->C.q, xb, p->C.part_pq, g_pq, p->C.part_rz, g, p->st);
+            int r2 = allreduce(p, xb, nrow + 2 + (p->mg_active ? (size_t)p->M.n1 * 6 : 0), 0);   // the ONE exchange per CG iteration
             if (r2 != PGO_OK) return r2;
-            launch_cgcg_update(p->G, p->C, kk, kk == 0 ? 1 : 0, p->st);   // also when a PCG that stopped before its first update is resumed: p = s = 0 still
+            launch_cgcg_update(p->G, p->C, kk, kk == 0 ? 1 : 0, p->st, xb, p->d_sh_of.p, xb + nrow);   // (first: also when a PCG that stopped before its first update is resumed: p = s = 0 still)
+            if (p->mg_active) {      // u = D^-1 r + P0 V(r1): r1 by the recurrence, the cycle on the replicated levels, the prolongation to this rank's keyframes
+                launch_mg_level1_update(p->C, p->M, p->mg_levels, p->K, kk, kk == 0 ? 1 : 0, 0, p->st);
+                launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz, mg_scale(p), true, p->st, true);
+            }
             return PGO_OK;
         }
         if (fused_coarse) {
@@ -882,7 +985,10 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
         return PGO_OK;
     };
     // hipGraph: capture one chunk (iterations 2 .. 2+every-1: no `first` kernel, even start) once per graph build and preconditioner, and replay it
-    const bool want_graph = o.cg_use_graph && !p->local_ids && !p->cg_graph_failed;
+    // Several ranks: a chunk holding RCCL's all-reduce can be captured as well (RCCL supports stream capture); not with a caller-supplied collective (a host callback).
+    // Opt-in (PGO_RCCL_GRAPH=1): it could only be tried with a 1-rank communicator on the 1-GPU development boxes.
+    static const bool rccl_graph = []() { const char* e = std::getenv("PGO_RCCL_GRAPH"); return e && e[0] == '1'; }();
+    const bool want_graph = o.cg_use_graph && !p->cg_graph_failed && (!p->local_ids || (p->comm != nullptr && p->custom_allreduce == nullptr && rccl_graph));
     // Capture + instantiation cost about a millisecond: a PCG pays it only once it has run `graph_after` iterations eagerly (a graph that is rebuilt for every
     // solve — the reference's sessions: one new loop edge, one solve — and converges in a few hundred iterations never does; eager launches keep up with
     // 5-8 us kernels: measured 18.5 vs 19.4 ms at 300 keyframes, 64.0 vs 64.6 ms at 3000)
@@ -908,7 +1014,7 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
     ensure_graph(k >= graph_after);
     // Chunks of `every` iterations; the convergence flag of chunk j is read (pinned memory + event) only AFTER chunk j+1 has been
     // enqueued, so the GPU never drains while the host polls.  A chunk enqueued after convergence is a string of early-exit kernels.
-    int n_chunks = 0, waited = -1;
+    int n_chunks = 0, waited = -1, r1_refreshed_at = k;
     bool done = false;
     auto enqueue_poll = [&](int slot) -> int {
         HIPCHK(p, hipMemcpyAsync(p->poll[slot].flags, p->C.flags, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, p->st));
@@ -918,6 +1024,16 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
     };
     while (k < o.cg_max_iterations && !done) {
         const int chunk = std::min(every, o.cg_max_iterations - k);
+        if (multi && p->mg_active && k - r1_refreshed_at >= every) {
+            // The level-1 residual follows a recurrence of its own (q1 rides in the exchange); while r falls by ten decades its absolute rounding drift does
+            // not, and a preconditioner fed with a residual that is not P0^T r any more breaks the PCG down near tight tolerances (measured at 1e-11).
+            // Once per chunk r1 is therefore taken from the keyframes' residual again: one small all-reduce every `every` iterations.
+            double* r1 = p->M.n_levels == 1 ? p->K.rc : p->mg_levels[0].r;
+            launch_mg_restrict0(p->G, p->M, p->C.r, p->M.q1, true, p->st);          // (q1 is free between exchanges)
+            if ((rc = allreduce(p, p->M.q1, (size_t)p->M.n1 * 6, 0)) != PGO_OK) return rc;
+            HIPCHK(p, hipMemcpyAsync(r1, p->M.q1, (size_t)p->M.n1 * 6 * sizeof(double), hipMemcpyDeviceToDevice, p->st));
+            r1_refreshed_at = k;
+        }
         if (want_graph && !p->cg_graph_failed && !p->cg_graph && k >= graph_after && (k & 1) == 0) ensure_graph(true);
         if (k >= 2 && chunk == every && want_graph && p->cg_graph && (k & 1) == 0) {
             HIPCHK(p, hipGraphLaunch(p->cg_graph, p->st));
@@ -941,7 +1057,7 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
         // Hybrid preconditioning: most LM systems (small trust regions, steps about to be rejected) are solved by block-Jacobi in a few
         // hundred cheap iterations; one that is not done after mg_switch_iterations is a hard one, and from there the multigrid (4x fewer
         // iterations or better at ~3x the price) takes over: operators built now, PCG restarted from the current iterate.
-        if (!done && !multi && p->mg_built && !p->mg_active && !p->mg_failed && k >= p->mg_switch_at && k < o.cg_max_iterations) {
+        if (!done && p->mg_built && !p->mg_active && !p->mg_failed && k >= p->mg_switch_at && k < o.cg_max_iterations) {     // (several ranks: every quantity tested here is the same on all of them)
             HIPCHK(p, hipMemcpyAsync(hflags, p->C.flags, sizeof(hflags), hipMemcpyDeviceToHost, p->st));
             HIPCHK(p, hipStreamSynchronize(p->st));
             if (hflags[0]) { done = true; (void)enqueue_poll(n_chunks & 1); ++n_chunks; break; }
@@ -950,10 +1066,15 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
             p->cg_extra += hflags[2];
             if (p->built_mf) launch_mf_apply(p->G, p->F, p->Sc, p->C, p->C.x, p->C.q, p->st);
             else launch_apply_operator(p->G, p->C, p->C.x, p->C.q, p->st);
-            const int g = launch_cg_init_vectors(p->G, p->C, 1, p->st);
-            launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz, mg_scale(p), false, p->st);
-            launch_cg_init_scalars(p->C, g, tol2, p->st);
-            k = 0; n_chunks = 0; waited = -1;
+            if (multi) {
+                if ((rc = exchange_rows(p, p->C.q, 6, nullptr, 0, nullptr, 0)) != PGO_OK) return rc;
+                if ((rc = start_multi(1)) != PGO_OK) return rc;
+            } else {
+                const int g = launch_cg_init_vectors(p->G, p->C, 1, p->st);
+                launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz, mg_scale(p), false, p->st);
+                launch_cg_init_scalars(p->C, g, tol2, p->st);
+            }
+            k = 0; n_chunks = 0; waited = -1; r1_refreshed_at = 0;
             every = chunk_length();
             ensure_graph(true);      // a system that needed the switch is a long one
         }
@@ -1019,13 +1140,23 @@ static int build_coarse(pgo_problem* p) {
 static int build_mg(pgo_problem* p) {
     p->mg_active = false;
     if (!p->mg_built) return PGO_OK;
+    int rcm;
     if (p->mg_geometry_epoch != p->lin_epoch) {              // the aggregates' centroids follow the poses of the current linearisation
-        launch_mg_geometry(p->G, p->M, p->mg_levels, p->d_pose[p->cur].p, p->st);
+        if (p->local_ids) {     // a level-1 node's keyframes live on several ranks: owner-weighted position sums, one all-reduce, then as on one GPU
+            launch_mg_geometry0_sum(p->G, p->M, p->mg_levels, p->d_pose[p->cur].p, p->st);
+            if ((rcm = allreduce(p, p->mg_levels[0].pos, (size_t)p->M.n1 * 3, 0)) != PGO_OK) return rcm;
+            launch_mg_geometry_finish(p->G, p->M, p->mg_levels, p->d_pose[p->cur].p, p->st);
+        } else launch_mg_geometry(p->G, p->M, p->mg_levels, p->d_pose[p->cur].p, p->st);
         p->mg_geometry_epoch = p->lin_epoch;
     }
     int32_t* fail = p->d_cinfo.p;
     HIPCHK(p, hipMemsetAsync(fail, 0, sizeof(int32_t), p->st));
-    launch_mg_assemble(p->G, p->L, p->Sc, p->C, p->M, p->mg_levels, p->K, p->opt.mg_omega > 0.0 && p->opt.mg_omega <= 1.0 ? p->opt.mg_omega : 0.9, fail, p->st);
+    const double omega = p->opt.mg_omega > 0.0 && p->opt.mg_omega <= 1.0 ? p->opt.mg_omega : 0.9;
+    if (p->local_ids) {         // level 1 = the sum of the ranks' Galerkin products (each edge lives on one rank, each diagonal block is its owner's); the levels above are replicated
+        launch_mg_galerkin0(p->G, p->L, p->Sc, p->C, p->M, p->mg_levels, p->st);
+        if ((rcm = allreduce(p, p->mg_levels[0].val, (size_t)p->mg_levels[0].nnzb * 36, 0)) != PGO_OK) return rcm;
+        launch_mg_assemble_rest(p->M, p->mg_levels, p->K, omega, fail, p->st);
+    } else launch_mg_assemble(p->G, p->L, p->Sc, p->C, p->M, p->mg_levels, p->K, omega, fail, p->st);
     launch_coarse_invert(p->K, p->d_cscr.p, fail, p->st);
     int32_t h = 1;
     HIPCHK(p, hipMemcpyAsync(&h, fail, sizeof(h), hipMemcpyDeviceToHost, p->st));
@@ -1034,7 +1165,7 @@ static int build_mg(pgo_problem* p) {
     // level 1's up-sweep kernel also prolongs to the keyframes; its workgroups (at most MAX_PARTIALS, each taking every gridDim-th tile) put their r.z partials behind the update kernel's
     // (measured: 1 114 tiles on 1 024 workgroups — C4 — lose 3 % to the ragged second trip against the separate prolongation kernel; 3 907 tiles — C5 — gain 3.5 %)
     const int t1 = p->mg_levels[0].tiles;
-    p->C.extra_rz = (p->mg_active && p->M.n_levels >= 2 && (t1 <= MAX_PARTIALS || t1 >= 2 * MAX_PARTIALS)) ? std::min<int>(t1, MAX_PARTIALS) : 0;
+    p->C.extra_rz = (p->mg_active && !p->local_ids && p->M.n_levels >= 2 && (t1 <= MAX_PARTIALS || t1 >= 2 * MAX_PARTIALS)) ? std::min<int>(t1, MAX_PARTIALS) : 0;
     if (p->opt.verbosity > 0 && h != 0) std::fprintf(stderr, "[pgo] multigrid: a coarse block is not positive definite at radius %.1e -> off for this iteration\n", p->radius);
     return PGO_OK;
 }
@@ -1048,6 +1179,11 @@ int build_system(pgo_problem* p, bool* ok) {
     int32_t fail = 0;
     HIPCHK(p, hipMemcpyAsync(&fail, p->d_flags.p + 4, sizeof(int32_t), hipMemcpyDeviceToHost, p->st));
     HIPCHK(p, hipStreamSynchronize(p->st));
+    if (p->local_ids) {      // a block that fails on one rank makes the step invalid on all of them (the ranks must take the same branch: collectives follow)
+        std::vector<double> f(1, fail ? 1.0 : 0.0);
+        if ((rc = host_allreduce(p, f, 2)) != PGO_OK) return rc;
+        fail = f[0] != 0.0;
+    }
     *ok = fail == 0;
     p->mg_active = false; p->mg_failed = false; p->C.extra_rz = 0;
     if (*ok && p->mg_built) {
@@ -1433,7 +1569,7 @@ int pgo_destroy(pgo_problem* p) {
     p->d_delta_s.release(); p->d_io.release(); p->d_tmp.release(); p->d_vio.release();
     p->d_mg_f64.release(); p->d_mg_i32.release(); p->d_mg_i64.release();
     p->d_ccen.release(); p->d_cd.release(); p->d_cAc.release(); p->d_crc.release(); p->d_cblk_ptr.release(); p->d_ccontrib.release(); p->d_cblk_ab.release(); p->d_cagg_free.release(); p->d_cinfo.release(); p->d_cscr.release(); p->d_cAcf.release();
-    p->d_l2g.release(); p->d_sh_loc.release(); p->d_sh_pos.release(); p->d_own.release(); p->d_xbuf.release();
+    p->d_l2g.release(); p->d_sh_loc.release(); p->d_sh_pos.release(); p->d_sh_src.release(); p->d_sh_of.release(); p->d_own.release(); p->d_xbuf.release();
     p->d_einc.release(); p->d_einc_slot.release(); p->d_node_rng.release(); p->d_tile_inc0.release(); p->d_einc_other.release();
     p->d_tile_node0.release(); p->d_tile_sw0.release(); p->d_node_prior.release(); p->d_rec.release(); p->d_lam.release();
     (void)hipStreamDestroy(p->st);
@@ -1779,6 +1915,65 @@ int pgo_comm_destroy(pgo_problem* p) {
     return PGO_OK;
 }
 
+// ---- edge sharding policies (host only) ----
+int pgo_partition_edges(int32_t policy, int32_t world, int64_t n_nodes, const double* t_xyz, int64_t n_rel, const int32_t* rel_c1, const int32_t* rel_c2,
+                        int64_t n_sw, const int32_t* sw_c1, const int32_t* sw_c2, int32_t* node_part, int32_t* rel_rank, int32_t* sw_rank) {
+    if (world < 1 || n_nodes < 0 || n_rel < 0 || n_sw < 0 || (n_rel > 0 && (!rel_c1 || !rel_c2 || !rel_rank)) || (n_sw > 0 && (!sw_c1 || !sw_c2 || !sw_rank))) return PGO_ERR_INVALID_ARG;
+    if (policy == PGO_PARTITION_CONTIGUOUS) {
+        // rank r holds the edges [n r / world, n (r+1) / world) of each class
+        for (int cls = 0; cls < 2; ++cls) {
+            const int64_t n = cls ? n_sw : n_rel; int32_t* out = cls ? sw_rank : rel_rank;
+            for (int r = 0; r < world; ++r) for (int64_t e = (n * r) / world; e < (n * (r + 1)) / world; ++e) out[e] = r;
+        }
+        return PGO_OK;
+    }
+    if (policy != PGO_PARTITION_CHAIN && policy != PGO_PARTITION_SPATIAL) return PGO_ERR_INVALID_ARG;
+    if (policy == PGO_PARTITION_SPATIAL && n_nodes > 0 && !t_xyz) return PGO_ERR_INVALID_ARG;
+    for (int64_t e = 0; e < n_rel; ++e) if (rel_c1[e] < 0 || rel_c1[e] >= n_nodes || rel_c2[e] < 0 || rel_c2[e] >= n_nodes) return PGO_ERR_INVALID_ARG;
+    for (int64_t e = 0; e < n_sw; ++e) if (sw_c1[e] < 0 || sw_c1[e] >= n_nodes || sw_c2[e] < 0 || sw_c2[e] >= n_nodes) return PGO_ERR_INVALID_ARG;
+    // parts are balanced by the edges they will receive (an edge goes with its later endpoint); keyframes without edges still spread evenly
+    std::vector<double> load((size_t)n_nodes, 0.0);
+    for (int64_t e = 0; e < n_rel; ++e) load[std::max(rel_c1[e], rel_c2[e])] += 1.0;
+    for (int64_t e = 0; e < n_sw; ++e) load[std::max(sw_c1[e], sw_c2[e])] += 1.0;
+    for (double& v : load) v += 1e-3;
+    std::vector<int32_t> part((size_t)n_nodes, 0);
+    if (policy == PGO_PARTITION_CHAIN) {
+        std::vector<double> c((size_t)n_nodes);
+        double acc = 0.0;
+        for (int64_t i = 0; i < n_nodes; ++i) { acc += load[i]; c[i] = acc; }
+        for (int64_t i = 0; i < n_nodes; ++i) part[i] = (int32_t)std::min((c[i] - load[i]) * (double)world / acc, (double)(world - 1));
+    } else {
+        // recursive coordinate bisection: cells [lo, hi) get the keyframes idx[b, e); split along the axis of largest extent at the load quantile
+        std::vector<int32_t> idx((size_t)n_nodes), tmp;
+        for (int64_t i = 0; i < n_nodes; ++i) idx[i] = (int32_t)i;
+        struct Job { int64_t b, e; int lo, hi; };
+        std::vector<Job> stack{{0, n_nodes, 0, world}};
+        while (!stack.empty()) {
+            const Job j = stack.back(); stack.pop_back();
+            if (j.hi - j.lo <= 1 || j.e - j.b <= 0) { for (int64_t k = j.b; k < j.e; ++k) part[idx[k]] = j.lo; continue; }
+            const int mid = (j.lo + j.hi) / 2;
+            double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+            for (int64_t k = j.b; k < j.e; ++k) for (int a = 0; a < 3; ++a) { const double v = t_xyz[(size_t)idx[k] * 3 + a]; mn[a] = std::min(mn[a], v); mx[a] = std::max(mx[a], v); }
+            int axis = 0;
+            for (int a = 1; a < 3; ++a) if (mx[a] - mn[a] > mx[axis] - mn[axis]) axis = a;
+            std::stable_sort(idx.begin() + j.b, idx.begin() + j.e, [&](int32_t x, int32_t y) { return t_xyz[(size_t)x * 3 + axis] < t_xyz[(size_t)y * 3 + axis]; });
+            const int64_t len = j.e - j.b;
+            std::vector<double> c((size_t)len);
+            double acc = 0.0;
+            for (int64_t k = 0; k < len; ++k) { acc += load[idx[j.b + k]]; c[k] = acc; }
+            const double target = acc * (double)(mid - j.lo) / (double)(j.hi - j.lo);
+            int64_t k = std::lower_bound(c.begin(), c.end(), target) - c.begin();
+            if (len > 1) k = std::min(std::max<int64_t>(k, 1), len - 1); else k = len;
+            stack.push_back({j.b + k, j.e, mid, j.hi});
+            stack.push_back({j.b, j.b + k, j.lo, mid});
+        }
+    }
+    for (int64_t e = 0; e < n_rel; ++e) rel_rank[e] = part[std::max(rel_c1[e], rel_c2[e])];
+    for (int64_t e = 0; e < n_sw; ++e) sw_rank[e] = part[std::max(sw_c1[e], sw_c2[e])];
+    if (node_part) std::copy(part.begin(), part.end(), node_part);
+    return PGO_OK;
+}
+
 // ---- measurement helpers ----
 int pgo_time_kernel(pgo_problem* p, int32_t which, int32_t launches, double* avg_ms, double* algorithmic_bytes) {
     if (!p || launches <= 0 || !avg_ms) return PGO_ERR_INVALID_ARG;
@@ -1792,7 +1987,7 @@ int pgo_time_kernel(pgo_problem* p, int32_t which, int32_t launches, double* avg
     const GraphDev& G = p->G;
     double bytes = 0;
     if (which == 6 || which == 7) {   // one multigrid-preconditioned PCG iteration (6) / its level kernels alone (7), on the current LM system
-        if (!p->mg_built || !p->built_mf) { p->err = "pgo_time_kernel: this graph has no multigrid hierarchy (mg_min_keyframes)"; (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return PGO_ERR_STATE; }
+        if (!p->mg_built || !p->built_mf || p->local_ids) { p->err = "pgo_time_kernel: this graph has no (single-GPU) multigrid hierarchy (mg_min_keyframes)"; (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return PGO_ERR_STATE; }
         const pgo_options& o = p->opt;
         if (!p->reuse_diagonal) launch_lm_diag(p->G, p->L, p->Sc, o.min_lm_diagonal, o.max_lm_diagonal, p->st);
         bool ok = true;

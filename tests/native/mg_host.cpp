@@ -11,7 +11,29 @@ void* mgh_build(long long N, const unsigned char* node_free, long long Er, const
     std::vector<double> meas((size_t)Er * 8, 0.0);
     for (long long e = 0; e < Er; ++e) meas[8 * e + 7] = rw[e];
     pgo_mg::Hierarchy* H = new pgo_mg::Hierarchy();
-    if (!pgo_mg::build_hierarchy(N, nf, a, b, meas.data(), c, d, nullptr, passes0, passes, dense_max, tile_rows, max_levels, *H, level0_follows_switchable != 0)) { delete H; return nullptr; }
+    if (!pgo_mg::build_hierarchy(N, nf, a, b, meas.data() + 7, 8, c, d, nullptr, passes0, passes, dense_max, tile_rows, max_levels, *H, level0_follows_switchable != 0)) { delete H; return nullptr; }
+    return H;
+}
+// Several ranks: the structure from the global graph, level 1's contribution lists from the edges dealt to `rank` (rank_rel / rank_sw: the rank holding each edge)
+// and the keyframes it owns (owner[]), in that rank's LOCAL numbering: keyframes touched by its edges in ascending global order, its edges in global order.
+// l2g_out [N] receives the local -> global keyframe map (n_local returned), rel_l2g_out / sw_l2g_out the local -> global edge maps.
+void* mgh_build_sharded(long long N, const unsigned char* node_free, long long Er, const int* rc1, const int* rc2, const double* rw, long long Es, const int* sc1, const int* sc2,
+                        int passes0, int passes, int dense_max, int tile_rows, int max_levels, const int* rank_rel, const int* rank_sw, const int* owner, int rank,
+                        int* l2g_out, long long* n_local, int* rel_l2g_out, long long* n_rel_local, int* sw_l2g_out, long long* n_sw_local) {
+    std::vector<uint8_t> nf(node_free, node_free + N);
+    std::vector<int32_t> a(rc1, rc1 + Er), b(rc2, rc2 + Er), c(sc1, sc1 + Es), d(sc2, sc2 + Es);
+    std::vector<double> w(rw, rw + Er);
+    std::vector<uint8_t> touched((size_t)N, 0);
+    std::vector<int32_t> la, lb, lc, ld;
+    long long nr = 0, ns = 0;
+    for (long long e = 0; e < Er; ++e) if (rank_rel[e] == rank) { la.push_back(a[e]); lb.push_back(b[e]); touched[a[e]] = touched[b[e]] = 1; rel_l2g_out[nr++] = (int)e; }
+    for (long long e = 0; e < Es; ++e) if (rank_sw[e] == rank) { lc.push_back(c[e]); ld.push_back(d[e]); touched[c[e]] = touched[d[e]] = 1; sw_l2g_out[ns++] = (int)e; }
+    std::vector<int32_t> l2g; std::vector<double> own;
+    for (long long g = 0; g < N; ++g) if (touched[g]) { l2g_out[l2g.size()] = (int)g; l2g.push_back((int32_t)g); own.push_back(owner[g] == rank ? 1.0 : 0.0); }
+    *n_local = (long long)l2g.size(); *n_rel_local = nr; *n_sw_local = ns;
+    pgo_mg::LocalContrib L{&l2g, &own, &la, &lb, &lc, &ld};
+    pgo_mg::Hierarchy* H = new pgo_mg::Hierarchy();
+    if (!pgo_mg::build_hierarchy(N, nf, a, b, w.data(), 1, c, d, nullptr, passes0, passes, dense_max, tile_rows, max_levels, *H, false, 0, &L)) { delete H; return nullptr; }
     return H;
 }
 void mgh_free(void* h) { delete (pgo_mg::Hierarchy*)h; }

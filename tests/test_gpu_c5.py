@@ -83,4 +83,6 @@ def test_c5_ranks_on_one_gpu_follow_the_single_rank_trajectory(c5, world):
             assert a.step_is_successful == b.step_is_successful, k
             assert abs(a.cost - b.cost) <= 1e-6 * a.cost, (k, a.cost, b.cost)
         assert np.abs(tr - t1).max() <= 1e-4 and np.abs(sr - s1).max() <= 1e-4
+        # library defaults on both sides: the ranks run the same hybrid block-Jacobi / multigrid PCG as the single handle (replicated coarse levels)
+        assert abs(sumr.cg_iterations - sum1.cg_iterations) <= 0.10 * sum1.cg_iterations, (sumr.cg_iterations, sum1.cg_iterations)
     assert np.array_equal(out[0][1], out[world - 1][1])          # every rank returns the complete, identical solution

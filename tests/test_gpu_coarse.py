@@ -50,12 +50,13 @@ def test_large_aggregates_switch_on_only_at_large_radius_and_the_headline_graph_
     """100k keyframes / 512 aggregates = 196 keyframes each (> 64): the coarse space waits for radius >= coarse_min_radius, which the
     10-iteration C3 trajectory never reaches — identical iteration counts with and without it."""
     g = graphgen.config("C3")
-    _, _, _, off = run(g, True, coarse_aggregates=0)
-    _, _, _, on = run(g, True)
+    # (mg_min_keyframes = 0: at this size the multigrid would replace the two-level method altogether and the comparison would be of a run with itself)
+    _, _, _, off = run(g, True, coarse_aggregates=0, mg_min_keyframes=0)
+    _, _, _, on = run(g, True, mg_min_keyframes=0)
     assert [on.iterations[k].cg_iterations for k in range(on.num_logged)] == [off.iterations[k].cg_iterations for k in range(off.num_logged)]
     assert on.final_cost == off.final_cost
     # forced on from the start (coarse_min_radius = 0) it still converges to the same trajectory
-    _, _, _, forced = run(g, True, coarse_min_radius=0.0)
+    _, _, _, forced = run(g, True, coarse_min_radius=0.0, mg_min_keyframes=0)
     assert [forced.iterations[k].step_is_successful for k in range(forced.num_logged)] == [off.iterations[k].step_is_successful for k in range(off.num_logged)]
     assert abs(forced.final_cost - off.final_cost) <= 1e-6 * off.final_cost
 

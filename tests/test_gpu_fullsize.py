@@ -124,20 +124,37 @@ def test_rccl_world_size_one_matches_single_gpu():
 def test_c3_early_rejection_does_not_change_the_iterates(c3):
     """A rejected LM step only shrinks the trust region (Ceres StepRejected), so libpgo pauses the PCG at cg_early_tolerance and
     cg_mid_tolerance and rejects a clearly bad step there.  The accepted iterates must be exactly those of the full-accuracy run,
-    with markedly fewer CG iterations."""
+    with markedly fewer CG iterations.  The preconditioner is PINNED in both runs (block-Jacobi: mg_min_keyframes = 0) so that the two
+    PCGs differ in nothing but the pauses and the tight bar holds; the library's default hybrid is compared separately below."""
+    g = c3
+    q, t, s = util.initial_state(g, True)
+    Pf = util.pgo_problem(g, True, cg_early_tolerance=0.0, cg_mid_tolerance=0.0, mg_min_keyframes=0)
+    _, tf, sf, sumf = Pf.solve(q, t, s)
+    Pf.close()
+    Pe = util.pgo_problem(g, True, mg_min_keyframes=0)           # pauses at 1e-2 (reject when relative_decrease < -0.5) and 1e-4 (< -0.05)
+    _, te, se, sume = Pe.solve(q, t, s)
+    Pe.close()
+    assert [sume.iterations[k].step_is_successful for k in range(sume.num_logged)] == [sumf.iterations[k].step_is_successful for k in range(sumf.num_logged)]
+    assert abs(sume.final_cost - sumf.final_cost) <= 1e-10 * sumf.final_cost
+    assert np.abs(te - tf).max() <= 1e-8 and np.abs(se - sf).max() <= 1e-8
+    assert sume.num_unsuccessful_steps >= 3 and sume.cg_iterations < 0.55 * sumf.cg_iterations
+
+
+def test_c3_early_rejection_with_the_default_hybrid_preconditioner(c3):
+    """The same comparison with the library defaults: the two runs pause at different points, so the hybrid block-Jacobi / multigrid PCG
+    switches preconditioner at different iterations and the iterates agree to the PCG tolerance only (inside BASELINE.json's 1e-6 bar)."""
     g = c3
     q, t, s = util.initial_state(g, True)
     Pf = util.pgo_problem(g, True, cg_early_tolerance=0.0, cg_mid_tolerance=0.0)
     _, tf, sf, sumf = Pf.solve(q, t, s)
     Pf.close()
-    Pe = util.pgo_problem(g, True)           # defaults: pauses at 1e-2 (reject when relative_decrease < -0.5) and 1e-4 (< -0.05)
+    Pe = util.pgo_problem(g, True)
     _, te, se, sume = Pe.solve(q, t, s)
     Pe.close()
     assert [sume.iterations[k].step_is_successful for k in range(sume.num_logged)] == [sumf.iterations[k].step_is_successful for k in range(sumf.num_logged)]
-    # (to the PCG tolerance: the two runs pause at different points, so the hybrid block-Jacobi / multigrid PCG switches at different ones)
     assert abs(sume.final_cost - sumf.final_cost) <= 1e-7 * sumf.final_cost
     assert np.abs(te - tf).max() <= 1e-5 and np.abs(se - sf).max() <= 1e-5
-    assert sume.num_unsuccessful_steps >= 3 and sume.cg_iterations < 0.55 * sumf.cg_iterations
+    assert sume.cg_iterations < 0.7 * sumf.cg_iterations
 
 
 def test_c3_structured_20k_ten_iterations_match_oracle_exact_cholesky():

@@ -156,3 +156,64 @@ def test_fixed_keyframes_stay_outside_and_isolated_graphs_are_refused(shim):
     e = E(); e.n_poses = 1000
     e.odom_c1 = e.odom_c2 = e.loop_c1 = e.loop_c2 = np.zeros(0, np.int32); e.odom_w = np.zeros(0)
     assert build(shim, e, np.ones(1000, np.uint8), 3, 2, 64) is None
+
+
+def test_sharded_build_has_the_global_structure_and_every_contribution_exactly_once(shim):
+    """Edge sharding (several ranks): every rank builds the hierarchy from the GLOBAL graph — identical structure on all of them — and lists only its own
+    contributions to level 1 (its edges, the diagonal blocks of the keyframes it owns), in its rank-local numbering.  The union of the ranks' lists must be
+    the single-handle list: every contribution exactly once."""
+    lib = shim
+    lib.mgh_build_sharded.restype = C.c_void_p
+    g = graphgen.generate(3000, 900, odom_f_max=2, seed=5)
+    N, world = g.n_poses, 3
+    ref = build(lib, g, passes0=3, passes=2, dense_max=64, level0_loops=False)
+    rng = np.random.default_rng(3)
+    rank_rel = I32(rng.integers(0, world, size=g.n_odom)); rank_sw = I32(rng.integers(0, world, size=g.n_loops))
+    touch = np.full((world, N), False)
+    for r in range(world):
+        for c, rk in ((g.odom_c1, rank_rel), (g.odom_c2, rank_rel), (g.loop_c1, rank_sw), (g.loop_c2, rank_sw)):
+            touch[r, np.asarray(c)[rk == r]] = True
+    owner = I32(np.argmax(touch, axis=0))                     # lowest touching rank (every keyframe is touched: the chain is complete)
+    assert touch.any(axis=0).all()
+    nf = np.ones(N, np.uint8)
+    rc1, rc2, sc1, sc2 = I32(g.odom_c1), I32(g.odom_c2), I32(g.loop_c1), I32(g.loop_c2)
+    rw = np.ascontiguousarray(g.odom_w, dtype=np.float64)
+    seen = {}
+    for rank in range(world):
+        l2g = np.zeros(N, np.int32); rl2g = np.zeros(g.n_odom, np.int32); sl2g = np.zeros(g.n_loops, np.int32)
+        nl, nr, ns = C.c_longlong(), C.c_longlong(), C.c_longlong()
+        h = lib.mgh_build_sharded(C.c_longlong(N), ptr(nf, C.c_ubyte), C.c_longlong(len(rc1)), ptr(rc1, C.c_int), ptr(rc2, C.c_int), ptr(rw, C.c_double), C.c_longlong(len(sc1)),
+                                  ptr(sc1, C.c_int), ptr(sc2, C.c_int), 3, 2, 64, 32, 12, ptr(rank_rel, C.c_int), ptr(rank_sw, C.c_int), ptr(owner, C.c_int), rank,
+                                  ptr(l2g, C.c_int), C.byref(nl), ptr(rl2g, C.c_int), C.byref(nr), ptr(sl2g, C.c_int), C.byref(ns))
+        assert h
+        h = C.c_void_p(h)
+        assert lib.mgh_levels(h) == len(ref["levels"])
+        for l, R in enumerate(ref["levels"]):
+            sz = np.zeros(6, np.int64); lib.mgh_sizes(h, l, ptr(sz, C.c_longlong))
+            n, nnzb, nent, npar, nagg, ntile = [int(x) for x in sz]
+            L = dict(rowptr=np.zeros(n + 1, np.int64), col=np.zeros(nnzb, np.int32), g_ptr=np.zeros(nnzb + 1, np.int64), g_ent=np.zeros(nent, np.int64),
+                     parent=np.zeros(npar, np.int32), agg_ptr=np.zeros(nagg, np.int32), tile_agg0=np.zeros(ntile, np.int32))
+            lib.mgh_level(h, l, ptr(L["rowptr"], C.c_longlong), ptr(L["col"], C.c_int), ptr(L["g_ptr"], C.c_longlong), ptr(L["g_ent"], C.c_longlong), ptr(L["parent"], C.c_int),
+                          ptr(L["agg_ptr"], C.c_int), ptr(L["tile_agg0"], C.c_int))
+            # the structure is the global one on every rank
+            assert n == R["n"] and np.array_equal(L["rowptr"], R["rowptr"]) and np.array_equal(L["col"], R["col"]) and np.array_equal(L["parent"], R["parent"])
+            if l >= 1:
+                assert np.array_equal(L["g_ent"], R["g_ent"])             # levels above 1 are replicated: the full lists
+                continue
+            for blk in range(nnzb):
+                for ent in L["g_ent"][L["g_ptr"][blk]:L["g_ptr"][blk + 1]]:
+                    kind, idx = int(ent & 7), int(ent >> 3)
+                    gidx = int(l2g[idx]) if kind == 0 else int(rl2g[idx]) if kind <= 2 else int(sl2g[idx])      # rank-local -> global
+                    key = (blk, kind, gidx)
+                    assert key not in seen, key
+                    seen[key] = rank
+        lib.mgh_free(h)
+    R = ref["levels"][0]
+    want = set()
+    for blk in range(len(R["col"])):
+        for ent in R["g_ent"][R["g_ptr"][blk]:R["g_ptr"][blk + 1]]:
+            want.add((blk, int(ent & 7), int(ent >> 3)))
+    assert set(seen) == want
+    # diagonal blocks come from the owner, edges from the rank that holds them
+    for (blk, kind, gidx), rank in seen.items():
+        assert rank == (owner[gidx] if kind == 0 else rank_rel[gidx] if kind <= 2 else rank_sw[gidx])
