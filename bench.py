@@ -31,11 +31,31 @@ C3_POSES, C3_LOOPS, C3_EDGES = 100000, 100003, 300000
 
 def probe_real_ceres():
     """The reference's real CPU path needs Ceres + Eigen (reference CMakeLists.txt:22-23).  If this host has them, oracle/ceres_bench.cpp (own
-    functors, real ceres::Solve) could be built; report what was found so that the baseline's kind is never mistaken."""
+    functors, real ceres::Solve) is built and run (run_real_ceres); report what was found so that the baseline's kind is never mistaken."""
     import glob
     hits = [p for pat in ("/usr/include/ceres/ceres.h", "/usr/local/include/ceres/ceres.h", "/opt/*/include/ceres/ceres.h") for p in glob.glob(pat)]
     eig = [p for pat in ("/usr/include/eigen3/Eigen/Core", "/usr/local/include/eigen3/Eigen/Core", "/usr/include/Eigen/Core") for p in glob.glob(pat)]
     return {"ceres_header": hits[0] if hits else None, "eigen_header": eig[0] if eig else None}
+
+
+def run_real_ceres(sample_poses, max_iters):
+    """Builds and runs oracle/ceres_bench (own functor restatement + the REAL ceres::Solve, SURVEY.md 8d) when this host has Ceres and Eigen3; None otherwise."""
+    import subprocess
+    pr = probe_real_ceres()
+    if not (pr["ceres_header"] and pr["eigen_header"]):
+        return None
+    try:
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "ceres_bench"], timeout=600)
+        exe = os.path.join(ROOT, "oracle", "ceres_bench")
+        if not os.path.exists(exe):
+            return {"error": "ceres_bench was not built"}
+        res = {}
+        for label, nt in (("one_thread", 1), ("all_cores", min(os.cpu_count() or 1, 32))):
+            out = subprocess.check_output([exe, str(sample_poses), str(sample_poses), "2", "3", str(max_iters), str(nt)], timeout=900)
+            res[label] = json.loads(out.decode().strip().splitlines()[-1])
+        return res
+    except Exception as e:
+        return {"error": repr(e)}
 
 
 def cpu_baseline(sample_poses, max_iters, budget_s):
@@ -61,6 +81,22 @@ def cpu_baseline(sample_poses, max_iters, budget_s):
         iters = max(1, sm.num_iterations)
         runs[label] = dict(ips=iters / sm.seconds_total, wall=wall, lin=sm.seconds_linear_solver, jac=sm.seconds_jacobian, fill=sm.chol_nnz_blocks, iters=iters)
     one, allc = runs["one_thread"], runs["all_cores"]
+    # How the 1-thread time grows with the graph: the same run on half the sample.  The sparse Cholesky's fill grows faster than the edge count on this mesh-like
+    # graph, so the LINEAR scaling to 300k edges used for `value` flatters the CPU; the measured exponent and the power-law extrapolation stand next to it.
+    growth = None
+    try:
+        gh = graphgen.generate(sample_poses // 2, sample_poses // 2, odom_f_max=2, seed=3)
+        Oh = util.oracle_problem(gh, True)
+        qh, th, sh = util.initial_state(gh, True)
+        opt = ob.default_options(max_num_iterations=max_iters, function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0, num_threads=1)
+        _, _, _, smh = Oh.solve(qh, th, sh, opt)
+        eh = gh.n_odom + gh.n_loops
+        per_it_full, per_it_half = 1.0 / one["ips"], smh.seconds_total / max(1, smh.num_iterations)
+        expo = float(np.log(per_it_full / per_it_half) / np.log(edges / eh))
+        growth = {"half_sample_edges": eh, "half_sample_s_per_iteration": per_it_half, "full_sample_s_per_iteration": per_it_full, "fill_blocks_half": int(smh.chol_nnz_blocks), "fill_blocks_full": int(one["fill"]),
+                  "time_exponent_vs_edges": expo, "power_law_value_at_300k_edges": 1.0 / (per_it_full * (C3_EDGES / edges) ** expo)}
+    except Exception as e:
+        growth = {"error": repr(e)}
     # kernel-level companion number on the FULL C3 graph: one residual + Jacobian evaluation of all 300k edges by the oracle's Jet
     # autodiff (what Ceres' evaluator does per linearisation) — the CPU counterpart of K1, no linear algebra involved
     g3 = graphgen.config("C3")
@@ -82,7 +118,9 @@ def cpu_baseline(sample_poses, max_iters, budget_s):
                       "note": "residual blocks / Jacobians on %d OpenMP threads of the host's %d cpus (%.2f s -> %.2f s), sparse Cholesky serial (%.2f s)" % (nthreads, ncpu, one["jac"], allc["jac"], allc["lin"])},
         "c3_jacobian_evaluation_ms": jac_ms,   # CPU (1 thread) residuals + autodiff Jacobians + J^T r of all 300k C3 edges; GPU: roofline.avg_launch_ms
         "host_cpus": ncpu,
+        "growth": growth,
         "real_ceres_probe": probe_real_ceres(),   # both null: the reference's own CPU path cannot be built on this host -> kind stays "port"
+        "real_ceres": run_real_ceres(sample_poses, max_iters),   # oracle/ceres_bench.cpp (functor restatement + real ceres::Solve) where Ceres + Eigen3 exist; null here
     }
 
 

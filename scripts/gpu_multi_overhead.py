@@ -10,8 +10,10 @@ from tests import util
 g = graphgen.config("C3")
 q, t, s = util.initial_state(g, True)
 out = {}
+import os
+mg = len(sys.argv) > 1 and sys.argv[1] == "mg"      # "mg": library defaults on both sides (hybrid block-Jacobi / multigrid); default: block-Jacobi on both sides
 for name in ("plain", "rccl_1rank"):
-    P = util.pgo_problem(g, True, mg_min_keyframes=0, coarse_aggregates=0)     # block-Jacobi on both sides: the multi-rank PCG has no coarse levels
+    P = util.pgo_problem(g, True) if mg else util.pgo_problem(g, True, mg_min_keyframes=0, coarse_aggregates=0)
     if name != "plain":
         P.comm_init(0, 1, capi.Problem.comm_unique_id())
     P.solve(q, t, s)                      # warm-up (graph build, hipGraph capture)
@@ -21,6 +23,7 @@ for name in ("plain", "rccl_1rank"):
     if name != "plain":
         P.comm_destroy()
     P.close()
+out["mode"] = ("defaults (hybrid multigrid)" if mg else "block-Jacobi") + (", RCCL chunks as hipGraphs" if os.environ.get("PGO_RCCL_GRAPH") == "1" else "")
 out["extra_us_per_cg_iteration"] = out["rccl_1rank"]["us_per_cg_iteration"] - out["plain"]["us_per_cg_iteration"]
 print(json.dumps(out, indent=1), flush=True)
-open('gpurun_out/multi_overhead.json', 'w').write(json.dumps(out, indent=1))
+open('gpurun_out/multi_overhead%s%s.json' % ('_mg' if mg else '', '_graph' if os.environ.get('PGO_RCCL_GRAPH') == '1' else ''), 'w').write(json.dumps(out, indent=1))
