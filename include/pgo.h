@@ -144,6 +144,12 @@ typedef struct pgo_options {
                                           *      solve, block-Jacobi iterations growing like sqrt(radius)) to need >= 2.25x this many starts with it, and one
                                           *      predicted easier than that switches only after twice its prediction.
                                           *      0: multigrid from the first iteration of every system. */
+    double mg_prolongation_damping;      /* 0.6: w_p of the smoothed prolongators Ps = (I - w_p D^-1 A) P (smoothed aggregation's 4 / (3 rho(D^-1 A)), rho ~ 2; from 0.9 on
+                                          *      I - w_p D^-1 A is singular inside the spectrum and the Galerkin product degenerates: measured, scripts/research/r3_cycle_probe.py) */
+    int32_t mg_smoothed_levels;          /* 1: the transitions level l -> l+1, l = 1 .. this many, use the SMOOTHED prolongator (the level above is Ps^T A Ps: denser, and each
+                                          *      such level costs two more row-product kernels per cycle); the keyframes -> level 1 transition stays the rigid one (its restriction and
+                                          *      prolongation ride in the PCG's own kernels).  0: plain aggregation on every level (round 2's cycle).  Measured on a C3-structured
+                                          *      20k-keyframe system with four levels, radius 1e6: 1237 PCG iterations without, 551 with the first transition smoothed, 487 with two */
     /* device selection */
     int32_t device_id;                   /* -1: use the current HIP device */
     int32_t verbosity;                   /* 0 silent (minimizer_progress_to_stdout=false, :1271), 1 per-iteration line on stderr */

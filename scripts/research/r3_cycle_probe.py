@@ -173,3 +173,13 @@ if __name__ == '__main__':
                 report('alpha0 %.1f alpha %.1f V add' % (a0, a), H, Cycle(H, alpha=a, alpha0=a0))
             for om in (0.7, 1.0):
                 report('omega %.1f V add' % om, H, Cycle(H, omega=om))
+    for w in which:
+        if w == 'which':
+            for sl in ((), (1,), (2,), (1, 2)):
+                H = Hier(A, t, agg_product(g, 3, 3), min_coarse=100, smooth_levels=sl)
+                report('4 levels, smoothed transitions %s, V add' % (sl,), H, Cycle(H))
+    for w in which:
+        if w == 'omegap':
+            for op in (0.5, 0.66, 0.9, 1.0):
+                H = Hier(A, t, agg_product(g, 3, 3), min_coarse=100, smooth_levels=(1,), omega_p=op, verbose=False)
+                report('4 levels, transition 1 smoothed, omega_p %.2f, V add' % op, H, Cycle(H))

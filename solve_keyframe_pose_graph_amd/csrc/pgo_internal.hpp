@@ -138,7 +138,7 @@ struct CoarseDev {
 constexpr int MG_MAX_LEVELS = 12;
 constexpr int MG_TILE_ROWS = 32;         // rows per workgroup tile of the level kernels (192 lanes = 32 rows x 6)
 struct MgLevelDev {
-    int32_t n, n_next, tiles, pad_;
+    int32_t n, n_next, tiles, n_ps;                              // n_ps: blocks of Ps (smoothed transition to the level above; else 0)
     int64_t nnzb;
     const int64_t* rowptr; const int32_t* col; double* val;      // block-CSR
     const int64_t* g_ptr; const int64_t* g_ent;                  // Galerkin contribution lists of the blocks
@@ -147,6 +147,13 @@ struct MgLevelDev {
     const int32_t* parent; const int32_t* agg_ptr; const int4* tile_info; const int2* tile_rows;   // tile_rows [tile][MG_TILE_ROWS]: block range of each row of the tile (no dependent tile_info -> rowptr load);   // nodes of level l+1: members contiguous; per workgroup tile {first aggregate, end aggregate, first row, end row}
     double* r; double* x; double* xt; double* xf;                // [n][6] restricted residual, pre-smoothed x, x + P x_next, final x
     float* valf;                                                 // the blocks rounded to fp32, exactly symmetric: what the cycle streams
+    // smoothed transition to the level above (pgo_mg_host.hpp): Ps = (I - c Dinv A) P and W = A Ps as explicit 6x6 blocks (row-major), needed only to FORM the
+    // level above (Ps^T W); inside the cycle Ps is applied implicitly — one more row product before the restriction and one after the prolongation
+    int32_t smoothed, n_w;                                       // n_w: blocks of W = A Ps
+    int32_t seg_shift, pad3_;                                    // log2 of the lane groups sharing a block row in the level kernels (tiles then hold <= 32 >> seg_shift rows)
+    const int32_t* ps_rowptr; const int32_t* ps_col; const int32_t* w_rowptr; const int32_t* w_col; const int64_t* psT_ptr; const int64_t* psT_ent;
+    double* ps_val; double* w_val;
+    double* t; double* u; double* y; const double* zero;         // [n][6] residual after pre-smoothing, c Dinv t, the smoothed correction; a vector of zeros
 };
 struct MgDev {
     int32_t n_levels;                    // levels 1..n_levels; the last one is dense (CoarseDev: Ac, rc = its residual, yc = its solution)
@@ -244,17 +251,17 @@ void launch_mg_geometry0_sum(const GraphDev& G, const MgDev& M, const MgLevelDev
 void launch_mg_geometry_finish(const GraphDev& G, const MgDev& M, const MgLevelDev* levels, const double* pose8, hipStream_t st);
 // numeric Galerkin products of the current LM system, level by level, block-Jacobi inverses of the sparse levels, the dense coarsest operator
 // into K.Ac (K.nc padded), which is then inverted by launch_coarse_invert; *fail != 0: some diagonal block was not positive definite
-void launch_mg_assemble(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, double omega, int32_t* fail, hipStream_t st);
+void launch_mg_assemble(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, double omega, int32_t* fail, hipStream_t st, double prolong_scale = 0.0);
 // its two halves: level 1 from the keyframe system (several ranks: this rank's contributions; the caller all-reduces levels[0].val), then everything above
 void launch_mg_galerkin0(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, const MgDev& M, const MgLevelDev* levels, hipStream_t st);
-void launch_mg_assemble_rest(const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, double omega, int32_t* fail, hipStream_t st);
+void launch_mg_assemble_rest(const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, double omega, int32_t* fail, hipStream_t st, double prolong_scale = 0.0 /* c = w_p / w of the smoothed transitions */);
 // out[n1][6] = P0^T v over the handle's keyframes (own_weighted: every keyframe counted by its owner only — several ranks)
 void launch_mg_restrict0(const GraphDev& G, const MgDev& M, const double* v, double* out, bool own_weighted, hipStream_t st);
 // several ranks: level-1 residual by the PCG's recurrence (mode 0: s1 = q1 + beta s1, r1 -= alpha s1 with the scalars cgcg_update left; mode 1, PCG start: s1 = 0) and x1 = w D1^-1 r1
 void launch_mg_level1_update(const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, int k, int first, int mode, hipStream_t st);
 // z += scale P V(P^T r) (every coarse correction inside V scaled alike), r.z partials updated in place (cg_update's workgroup -> slot mapping)
 void launch_mg_apply(const GraphDev& G, const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, const double* r, double* z, double* part_rz, double scale, bool inside_iteration, hipStream_t st,
-                     bool restricted = false /* r_1 (and x_1) already formed by launch_cg_update_mg */);
+                     bool restricted = false /* r_1 (and x_1) already formed by launch_cg_update_mg */, double prolong_scale = 0.0 /* c of the smoothed transitions */);
 // cg_update + r_1 = P_0^T r', x_1 = w D_1^-1 r_1 of the multigrid (M.blk_tab)
 void launch_cg_update_mg(const GraphDev& G, const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, int k, int n_pq_partials, hipStream_t st);
 

@@ -781,7 +781,8 @@ __global__ __launch_bounds__(CG_BLOCK) void cg_spmv_kernel(GraphDev G, CgDev C, 
         const bool breakdown = C.flags[1] != 0;
         // convergence on the preconditioned residual norm: every workgroup evaluates the same numbers -> uniform exit
         if (breakdown || !(rz_new > C.scal[3] * C.scal[0])) {
-            if (blockIdx.x == 0 && threadIdx.x == 0) { C.flags[0] = 1; if (!breakdown) C.scal[1] = rz_new; }
+            // (r.z clearly negative: the preconditioner is not positive definite — a breakdown, never convergence)
+            if (blockIdx.x == 0 && threadIdx.x == 0) { C.flags[0] = 1; if (!breakdown) { C.scal[1] = rz_new; if (rz_new < -C.scal[3] * C.scal[0]) C.flags[1] = 1; } }
             return;
         }
         beta = rz_new / rz_old;
@@ -1012,7 +1013,7 @@ __global__ __launch_bounds__(CG_BLOCK) void cgcg_update_kernel(GraphDev G, CgDev
     double beta = 0.0, den = delta;
     const bool breakdown = C.flags[1] != 0;
     if (breakdown || !(gamma > C.scal[3] * C.scal[0])) {   // converged (or broken down): the state stays that of the last completed update
-        if (blockIdx.x == 0 && threadIdx.x == 0) { C.flags[0] = 1; if (!breakdown) C.scal[1] = gamma; }
+        if (blockIdx.x == 0 && threadIdx.x == 0) { C.flags[0] = 1; if (!breakdown) { C.scal[1] = gamma; if (gamma < -C.scal[3] * C.scal[0]) C.flags[1] = 1; } }
         return;
     }
     if (!first) {
@@ -1198,7 +1199,7 @@ __global__ __launch_bounds__(MF_BLOCK) void mf_spmv_kernel(GraphDev G, MfDev F, 
             block_total2(C.part_rz + parity * RZ_STRIDE, nparts + C.extra_rz, C.part_rz + (parity ^ 1) * RZ_STRIDE, nparts + C.extra_rz, red, rz_new, rz_old);
             const bool breakdown = C.flags[1] != 0;
             if (breakdown || !(rz_new > C.scal[3] * C.scal[0])) {
-                if (blockIdx.x == 0 && threadIdx.x == 0) { C.flags[0] = 1; if (!breakdown) C.scal[1] = rz_new; }
+                if (blockIdx.x == 0 && threadIdx.x == 0) { C.flags[0] = 1; if (!breakdown) { C.scal[1] = rz_new; if (rz_new < -C.scal[3] * C.scal[0]) C.flags[1] = 1; } }
                 return;
             }
             beta = rz_new / rz_old;

@@ -30,7 +30,14 @@ struct HostLevel {                       // level l >= 1
                                          // level >= 2: (row << 32) | block slot of the level below
     std::vector<int32_t> parent;         // [n] node of level l+1 (empty on the coarsest level); members of a parent are CONTIGUOUS
     std::vector<int32_t> agg_ptr;        // [n_next+1] first member of each parent
-    std::vector<int32_t> tile_agg0;      // [tiles+1] workgroup tiles of whole aggregates, <= tile_rows rows
+    std::vector<int32_t> tile_agg0;      // [tiles+1] workgroup tiles of whole aggregates, <= tile_rows / seg rows
+    int seg = 1;                         // lanes-of-a-row groups that share one block row in the level kernels (1, 2 or 4): long rows (smoothed Galerkin products) are split
+    // SMOOTHED transition to the level above (smoothed aggregation): the prolongator is Ps = (I - w_p D^-1 A) P instead of the tentative P (rigid motion of the
+    // parent), the level above is the Galerkin product Ps^T A Ps.  Only its STRUCTURE is fixed here; the numbers follow the LM system (pgo_mg_kernels.hpp):
+    bool smoothed = false;
+    std::vector<int32_t> ps_rowptr, ps_col;     // Ps: row i holds the parents of the columns of A's row i, ascending
+    std::vector<int32_t> w_rowptr, w_col;       // W = A Ps: row i holds the union of the Ps rows of the columns of A's row i, ascending
+    std::vector<int64_t> psT_ptr, psT_ent;      // Ps by coarse column: [n_next+1], entries (row << 32) | block of Ps
 };
 
 struct Hierarchy {
@@ -142,7 +149,7 @@ struct LocalContrib {
 inline bool build_hierarchy(int64_t N, const std::vector<uint8_t>& node_free, const std::vector<int32_t>& rc1, const std::vector<int32_t>& rc2, const double* rel_w, int rel_w_stride,
                             const std::vector<int32_t>& sc1, const std::vector<int32_t>& sc2, const double* sw_weight /* per switchable edge: s^2 of its switch at graph build, or nullptr = 1 */,
                             int passes0, int passes, int dense_max, int tile_rows, int max_levels, Hierarchy& H, bool level0_follows_switchable = true, int level0_block = 0,
-                            const LocalContrib* local = nullptr) {
+                            const LocalContrib* local = nullptr, int smoothed_levels = 0 /* transitions level l -> l+1, l = 1 .. smoothed_levels, use the smoothed prolongator */) {
     H = Hierarchy{};
     const int64_t Er = (int64_t)rc1.size(), Es = (int64_t)sc1.size();
     std::vector<WEdge> edges;
@@ -231,15 +238,6 @@ inline bool build_hierarchy(int64_t N, const std::vector<uint8_t>& node_free, co
             Lv.agg_ptr.assign((size_t)n_next + 1, 0);
             for (int32_t k = 0; k < n; ++k) Lv.agg_ptr[(size_t)Lv.parent[k] + 1]++;
             for (int32_t a = 0; a < n_next; ++a) Lv.agg_ptr[(size_t)a + 1] += Lv.agg_ptr[a];
-            // workgroup tiles: whole aggregates, <= tile_rows rows
-            Lv.tile_agg0.push_back(0);
-            int rows = 0;
-            for (int32_t a = 0; a < n_next; ++a) {
-                const int sz = Lv.agg_ptr[(size_t)a + 1] - Lv.agg_ptr[a];
-                if (rows + sz > tile_rows) { Lv.tile_agg0.push_back(a); rows = 0; }
-                rows += sz;
-            }
-            Lv.tile_agg0.push_back(n_next);
         }
         newid_above.swap(newid);
     }
@@ -274,14 +272,74 @@ inline bool build_hierarchy(int64_t N, const std::vector<uint8_t>& node_free, co
         build_blocks(n1, trip, H.L[0]);
     }
     for (size_t l = 0; l + 1 < H.L.size(); ++l) {
-        const HostLevel& A = H.L[l];
+        HostLevel& A = H.L[l];
         HostLevel& B = H.L[l + 1];
+        if ((int)l < smoothed_levels) {
+            // structure of Ps, W = A Ps and B = Ps^T W (all by sorted unions; the numeric kernels search these short rows)
+            A.smoothed = true;
+            const int32_t n = A.n, nb = B.n;
+            A.ps_rowptr.assign((size_t)n + 1, 0);
+            std::vector<int32_t> tmp;
+            for (int32_t i = 0; i < n; ++i) {
+                tmp.clear();
+                for (int64_t k = A.rowptr[i]; k < A.rowptr[(size_t)i + 1]; ++k) tmp.push_back(A.parent[A.col[k]]);
+                std::sort(tmp.begin(), tmp.end()); tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+                A.ps_col.insert(A.ps_col.end(), tmp.begin(), tmp.end());
+                A.ps_rowptr[(size_t)i + 1] = (int32_t)A.ps_col.size();
+            }
+            A.w_rowptr.assign((size_t)n + 1, 0);
+            for (int32_t i = 0; i < n; ++i) {
+                tmp.clear();
+                for (int64_t k = A.rowptr[i]; k < A.rowptr[(size_t)i + 1]; ++k) { const int32_t j = A.col[k]; tmp.insert(tmp.end(), A.ps_col.begin() + A.ps_rowptr[j], A.ps_col.begin() + A.ps_rowptr[(size_t)j + 1]); }
+                std::sort(tmp.begin(), tmp.end()); tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+                A.w_col.insert(A.w_col.end(), tmp.begin(), tmp.end());
+                A.w_rowptr[(size_t)i + 1] = (int32_t)A.w_col.size();
+            }
+            A.psT_ptr.assign((size_t)nb + 1, 0);
+            for (int32_t c : A.ps_col) A.psT_ptr[(size_t)c + 1]++;
+            for (int32_t a = 0; a < nb; ++a) A.psT_ptr[(size_t)a + 1] += A.psT_ptr[a];
+            A.psT_ent.resize(A.ps_col.size());
+            { std::vector<int64_t> fill(A.psT_ptr.begin(), A.psT_ptr.end() - 1);
+              for (int32_t i = 0; i < n; ++i) for (int32_t sl = A.ps_rowptr[i]; sl < A.ps_rowptr[(size_t)i + 1]; ++sl) A.psT_ent[(size_t)fill[A.ps_col[sl]]++] = ((int64_t)i << 32) | (int64_t)sl; }
+            B.rowptr.assign((size_t)nb + 1, 0); B.col.clear();
+            for (int32_t a = 0; a < nb; ++a) {
+                tmp.clear();
+                for (int64_t e = A.psT_ptr[a]; e < A.psT_ptr[(size_t)a + 1]; ++e) { const int32_t i = (int32_t)(A.psT_ent[e] >> 32); tmp.insert(tmp.end(), A.w_col.begin() + A.w_rowptr[i], A.w_col.begin() + A.w_rowptr[(size_t)i + 1]); }
+                std::sort(tmp.begin(), tmp.end()); tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+                B.col.push_back(a);                                       // the diagonal block first, as everywhere
+                for (int32_t c : tmp) if (c != a) B.col.push_back(c);
+                B.rowptr[(size_t)a + 1] = (int64_t)B.col.size();
+            }
+            B.g_ptr.assign(B.col.size() + 1, 0); B.g_ent.clear();         // (no contribution lists: the product is formed from Ps and W)
+            continue;
+        }
         std::vector<std::pair<int64_t, int64_t>> trip;
         trip.reserve(A.col.size());
         for (int32_t r = 0; r < A.n; ++r)
             for (int64_t k = A.rowptr[r]; k < A.rowptr[(size_t)r + 1]; ++k)
                 trip.push_back({(int64_t)A.parent[r] * B.n + A.parent[A.col[k]], ((int64_t)r << 32) | k});
         build_blocks(B.n, trip, B);
+    }
+    // workgroup tiles of the level kernels: whole aggregates, <= tile_rows / seg rows; a level whose rows are long (the Galerkin product of a smoothed transition
+    // has ~40 blocks per row instead of ~8) lets seg groups of lanes share each row, so that a row's blocks are streamed by seg x 6 lanes instead of 6
+    for (size_t l = 0; l + 1 < H.L.size(); ++l) {
+        HostLevel& Lv = H.L[l];
+        const double mean_row = (double)Lv.col.size() / (double)std::max(1, Lv.n);
+        int max_agg = 1;
+        const int32_t n_next = H.L[l + 1].n;
+        for (int32_t a = 0; a < n_next; ++a) max_agg = std::max(max_agg, Lv.agg_ptr[(size_t)a + 1] - Lv.agg_ptr[a]);
+        Lv.seg = mean_row > 28.0 ? 4 : mean_row > 14.0 ? 2 : 1;
+        while (Lv.seg > 1 && tile_rows / Lv.seg < max_agg) Lv.seg /= 2;         // an aggregate never straddles tiles
+        const int cap = tile_rows / Lv.seg;
+        Lv.tile_agg0.clear();
+        Lv.tile_agg0.push_back(0);
+        int rows = 0;
+        for (int32_t a = 0; a < n_next; ++a) {
+            const int sz = Lv.agg_ptr[(size_t)a + 1] - Lv.agg_ptr[a];
+            if (rows + sz > cap) { Lv.tile_agg0.push_back(a); rows = 0; }
+            rows += sz;
+        }
+        Lv.tile_agg0.push_back(n_next);
     }
     return true;
 }

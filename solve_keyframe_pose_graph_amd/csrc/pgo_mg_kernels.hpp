@@ -54,6 +54,25 @@ __device__ __forceinline__ void mg_row_accumulate_f32(int64_t b, int64_t e, cons
     if (k + 2 <= e) { mg_chunk_f32<2>(col + k, val + (size_t)k * 36, c, x, acc); k += 2; }
     if (k < e) mg_chunk_f32<1>(col + k, val + (size_t)k * 36, c, x, acc);
 }
+// Row products of the level kernels.  192 lanes = 32 (row, lane-group) slots x 6 columns.  With seg_shift = 0 a slot is a row; with seg_shift = s the tile holds
+// R = 32 >> s rows and 2^s lane groups share each row, group g streaming the g-th part of its blocks (long rows: Galerkin products of smoothed transitions).
+// mg_split_row: this lane's part [b, e) of the row's block range.  mg_gather_row: the row's result for column-lane c, summed over the 6 column lanes and the groups
+// in a fixed order (valid for the lanes of group 0).
+__device__ __forceinline__ void mg_split_row(int2 rb, int sg, int seg_shift, int& b, int& e) {
+    const int len = rb.y - rb.x, part = (len + (1 << seg_shift) - 1) >> seg_shift;
+    b = rb.x + sg * part; e = b + part < rb.y ? b + part : rb.y;
+    if (b > e) b = e;
+}
+__device__ __forceinline__ double mg_gather_row(const double* __restrict__ xch, int li, int c, int seg_shift) {
+    const int R = MG_TILE_ROWS >> seg_shift;
+    double q = 0.0;
+    for (int g = 0; g < (1 << seg_shift); ++g) {
+        const double* grp = xch + (size_t)((g * R + li) * 6) * 7;
+#pragma unroll
+        for (int cc = 0; cc < 6; ++cc) q += grp[cc * 7 + c];
+    }
+    return q;
+}
 // valf <- val, EXACTLY symmetric: a block below the diagonal is the transpose of the rounded block above it, a diagonal block takes its upper
 // triangle.  One wavefront per block row, lane l < 36 owns element l of a block (column-pair-major: (row, col) at (row/2)*12 + col*2 + (row&1)).
 __global__ __launch_bounds__(256) void mg_val_f32_kernel(MgLevelDev A) {
@@ -66,11 +85,10 @@ __global__ __launch_bounds__(256) void mg_val_f32_kernel(MgLevelDev A) {
         double v;
         if (j > i) v = A.val[(size_t)k * 36 + lane];
         else if (j == i) v = row <= col ? A.val[(size_t)k * 36 + lane] : A.val[(size_t)k * 36 + tr];
-        else {
-            int64_t kt = A.rowptr[j];
-            const int64_t et = A.rowptr[j + 1];
-            while (kt < et && A.col[kt] != i) ++kt;
-            v = kt < et ? A.val[(size_t)kt * 36 + tr] : A.val[(size_t)k * 36 + lane];
+        else {      // the transposed block (j, i): row j holds its diagonal block first, the others by ascending column
+            int64_t lo = A.rowptr[j] + 1, hi = A.rowptr[j + 1];
+            while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (A.col[mid] < i) lo = mid + 1; else hi = mid; }
+            v = (lo < A.rowptr[j + 1] && A.col[lo] == i) ? A.val[(size_t)lo * 36 + tr] : A.val[(size_t)k * 36 + lane];
         }
         A.valf[(size_t)k * 36 + lane] = (float)v;
     }
@@ -294,20 +312,218 @@ __global__ __launch_bounds__(256) void mg_dense_scatter_kernel(MgLevelDev A, Coa
     for (int64_t k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k)
         K.Ac[(size_t)(i * 6 + row) * K.nc + (size_t)A.col[k] * 6 + col] = A.val[(size_t)k * 36 + l];
 }
+// ---- smoothed transitions (smoothed aggregation): Ps = (I - c Dinv A) P, W = A Ps, level above = Ps^T W ----
+// element (r, c) of B_k, the rigid prolongation block of node k with offset d to its parent: dtheta_k = y_theta ; dt_k = y_t - 2 d x y_theta
+__device__ __forceinline__ double mg_pblock(const double* __restrict__ d, int r, int c) {
+    if (r < 3 || c >= 3) return r == c ? 1.0 : 0.0;
+    const int a = r - 3;                              // X = -2 [d]x
+    if (a == c) return 0.0;
+    const int o = 3 - a - c;                          // the third axis
+    const double sgn = ((a + 1) % 3 == c) ? 1.0 : -1.0;     // X[a][a+1] = +2 d[a+2] ; X[a][a+2] = -2 d[a+1]
+    return sgn * 2.0 * d[o];
+}
+// one wavefront per block (i, a) of Ps; lane l < 36 owns element (l / 6, l % 6).  Row i of A is short: its blocks are scanned for columns whose parent is a.
+__global__ __launch_bounds__(256) void mg_ps_kernel(MgLevelDev A, double cs) {
+    __shared__ double acc_s[4][36];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t slot = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (slot >= A.n_ps) return;
+    const bool own = lane < 36;
+    const int r = own ? lane / 6 : 0, c = own ? lane % 6 : 0;
+    // the row of this block: ps_rowptr is ascending -> binary search
+    int lo = 0, hi = A.n;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int64_t)A.ps_rowptr[mid] <= slot) lo = mid; else hi = mid; }
+    const int i = lo, a = A.ps_col[slot];
+    double acc = 0.0;
+    for (int64_t k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k) {
+        const int j = A.col[k];
+        if (A.parent[j] != a) continue;
+        if (own) {
+            const double* dj = A.d + (size_t)j * 3;
+#pragma unroll
+            for (int m = 0; m < 6; ++m) acc += A.val[(size_t)k * 36 + bsr_idx(r, m)] * mg_pblock(dj, m, c);
+        }
+    }
+    if (own) acc_s[wv][lane] = acc;
+    __builtin_amdgcn_wave_barrier();
+    if (own) {
+        double v = A.parent[i] == a ? mg_pblock(A.d + (size_t)i * 3, r, c) : 0.0;
+        const double* Dk = A.Dinv + (size_t)i * 36 + r * 6;
+#pragma unroll
+        for (int m = 0; m < 6; ++m) v -= cs * Dk[m] * acc_s[wv][m * 6 + c];
+        A.ps_val[(size_t)slot * 36 + lane] = v;
+    }
+}
+// W = A Ps: one wavefront per block (i, b) of W: sum over the blocks k of A's row i whose column's Ps row holds b
+__global__ __launch_bounds__(256) void mg_w_kernel(MgLevelDev A) {
+    __shared__ double pb[4][36];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t slot = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (slot >= A.n_w) return;
+    const bool own = lane < 36;
+    const int r = own ? lane / 6 : 0, c = own ? lane % 6 : 0;
+    int lo = 0, hi = A.n;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int64_t)A.w_rowptr[mid] <= slot) lo = mid; else hi = mid; }
+    const int i = lo, b = A.w_col[slot];
+    double acc = 0.0;
+    for (int64_t k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k) {
+        const int j = A.col[k];
+        int ps = -1;
+        for (int sl = A.ps_rowptr[j]; sl < A.ps_rowptr[j + 1]; ++sl) if (A.ps_col[sl] == b) { ps = sl; break; }
+        if (ps < 0) continue;                         // (uniform over the wavefront)
+        if (own) pb[wv][lane] = A.ps_val[(size_t)ps * 36 + lane];
+        __builtin_amdgcn_wave_barrier();
+        if (own) {
+#pragma unroll
+            for (int m = 0; m < 6; ++m) acc += A.val[(size_t)k * 36 + bsr_idx(r, m)] * pb[wv][m * 6 + c];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (own) A.w_val[(size_t)slot * 36 + lane] = acc;
+}
+// level above: block (a, b) = sum over the rows i with Ps[i, a] != 0 of Ps[i, a]^T W[i, b]
+__global__ __launch_bounds__(256) void mg_psTw_kernel(MgLevelDev A, MgLevelDev B) {
+    __shared__ double pa[4][36], wb[4][36];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t slot = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (slot >= B.nnzb) return;
+    const bool own = lane < 36;
+    const int r = own ? lane / 6 : 0, c = own ? lane % 6 : 0;
+    int lo = 0, hi = B.n;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (B.rowptr[mid] <= slot) lo = mid; else hi = mid; }
+    const int a = lo, b = B.col[slot];
+    double acc = 0.0;
+    for (int64_t e = A.psT_ptr[a]; e < A.psT_ptr[a + 1]; ++e) {
+        const int64_t ent = A.psT_ent[e];
+        const int i = (int)(ent >> 32); const int64_t ps = ent & 0xffffffffll;
+        int ws = -1;
+        for (int sl = A.w_rowptr[i]; sl < A.w_rowptr[i + 1]; ++sl) if (A.w_col[sl] == b) { ws = sl; break; }
+        if (ws < 0) continue;
+        if (own) { pa[wv][lane] = A.ps_val[(size_t)ps * 36 + lane]; wb[wv][lane] = A.w_val[(size_t)ws * 36 + lane]; }
+        __builtin_amdgcn_wave_barrier();
+        if (own) {
+#pragma unroll
+            for (int m = 0; m < 6; ++m) acc += pa[wv][m * 6 + r] * wb[wv][m * 6 + c];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (own) B.val[(size_t)slot * 36 + bsr_idx(r, c)] = acc;
+}
+// The smoothed prolongator inside the cycle, implicitly: one row product with the level's own matrix.
+//   w = in_r - A in_x  (in_r null: 0) ;  out_w = w (optional) ;  out = add1 + add2 + cs Dinv w   (either add may be null; Dinv holds omega D^-1, cs = w_p / omega)
+// before the restriction:  t = r - A x_pre,  u = cs Dinv t,  then the restriction kernel forms P^T (t - A u) = Ps^T t
+// after the prolongation:  e = P x_next,  y = x_pre + e - cs Dinv (A e) = x_pre + Ps x_next,  then the post-smoothing kernel runs on y
+__global__ __launch_bounds__(CG_BLOCK) void mg_smooth_step_kernel(MgLevelDev A, const double* __restrict__ in_r, const double* __restrict__ in_x, double* __restrict__ out_w,
+                                                                   const double* __restrict__ add1, const double* __restrict__ add2, double* __restrict__ out, double cs, const int32_t* __restrict__ stop) {
+    __shared__ double xch[CG_BLOCK * 7];
+    __shared__ double tb[CG_BLOCK];
+    const int stopped = stop ? *stop : 0;
+    const int q6 = threadIdx.x / 6, c = threadIdx.x % 6;
+    const int li = q6 & ((MG_TILE_ROWS >> A.seg_shift) - 1), sg = q6 >> (5 - A.seg_shift);
+    const int4 ti = A.tile_info[blockIdx.x];
+    const int2 rb = A.tile_rows[blockIdx.x * MG_TILE_ROWS + li];
+    if (stopped) return;
+    const int i0 = ti.z, i1 = ti.w;
+    const int row = i0 + li;
+    const bool rowlive = row < i1;
+    const bool live = rowlive && sg == 0;
+    double rv = 0.0, av = 0.0;
+    double Dk[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (live) {
+        if (in_r) rv = in_r[(size_t)row * 6 + c];
+        if (add1) av += add1[(size_t)row * 6 + c];
+        if (add2) av += add2[(size_t)row * 6 + c];
+        const double2* Dp = reinterpret_cast<const double2*>(A.Dinv + (size_t)row * 36 + c * 6);
+        const double2 u0 = Dp[0], u1 = Dp[1], u2 = Dp[2];
+        Dk[0] = u0.x; Dk[1] = u0.y; Dk[2] = u1.x; Dk[3] = u1.y; Dk[4] = u2.x; Dk[5] = u2.y;
+    }
+    double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (rowlive) { int kb, ke; mg_split_row(rb, sg, A.seg_shift, kb, ke); mg_row_accumulate_f32(kb, ke, A.col, A.valf, in_x, c, acc); }
+    double* mine = xch + (size_t)threadIdx.x * 7;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) mine[q] = acc[q];
+    __syncthreads();
+    double w = 0.0;
+    if (live) {
+        w = rv - mg_gather_row(xch, li, c, A.seg_shift);
+        tb[threadIdx.x] = w;
+        if (out_w) out_w[(size_t)row * 6 + c] = w;
+    }
+    __syncthreads();
+    if (live) {
+        const double* ta = tb + (threadIdx.x - c);
+        double x = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) x += Dk[j] * ta[j];
+        out[(size_t)row * 6 + c] = av + cs * x;
+    }
+}
+
+// ---- smoother safety: the damped block-Jacobi smoother needs w lambda_max(D^-1 A) < 2 or the cycle is not positive definite any more (the PCG then "converges" on a
+// negative r.z: measured on a chain-like graph whose smoothed Galerkin level has lambda_max ~ 2.5).  lambda_max is estimated per level and per LM system by a few steps
+// of the power method (a lower bound: hence the margins) and a level whose w lambda exceeds `limit` gets its Dinv = w D^-1 scaled down to w lambda = `target`.
+__global__ void mg_power_init_kernel(double* __restrict__ v, int n6) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n6) v[i] = 1.0 + 0.5 * sin(0.7 * (double)i);          // fixed, not orthogonal to anything in particular
+}
+// one workgroup: lam = ||w|| / ||v_prev|| with v_prev normalised (first call: by its own norm, passed as w = v), v <- w / ||w||
+__global__ __launch_bounds__(1024) void mg_power_norm_kernel(const double* __restrict__ w, double* __restrict__ v, int n6, double* __restrict__ lam) {
+    __shared__ double red[16];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n6; i += blockDim.x) s += w[i] * w[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    double tot = 0.0;
+    for (int k = 0; k < 16; ++k) tot += red[k];
+    const double nrm = sqrt(tot), inv = nrm > 0.0 ? 1.0 / nrm : 0.0;
+    for (int i = threadIdx.x; i < n6; i += blockDim.x) v[i] = w[i] * inv;
+    if (threadIdx.x == 0) *lam = nrm;
+}
+__global__ __launch_bounds__(256) void mg_rescale_dinv_kernel(MgLevelDev A, const double* __restrict__ lam, double omega, double limit, double target) {
+    const double wl = omega * lam[0];
+    if (!(wl > limit)) return;
+    const double f = target / wl;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (int64_t)A.n * 36) A.Dinv[i] *= f;
+}
+static void mg_limit_smoother(const MgLevelDev& A, double omega, hipStream_t st) {
+    const int n6 = A.n * 6;
+    double* v = A.x; double* w = A.xt; double* lam = A.xf;              // the level's cycle vectors are free during the set-up
+    hipLaunchKernelGGL(mg_power_init_kernel, dim3((unsigned)((n6 + 255) / 256)), dim3(256), 0, st, w, n6);
+    hipLaunchKernelGGL(mg_power_norm_kernel, dim3(1), dim3(1024), 0, st, (const double*)w, v, n6, lam);
+    for (int it = 0; it < 10; ++it) {
+        // w = D^-1 A v  =  (-1 / omega) (omega D^-1) (0 - A v)
+        hipLaunchKernelGGL(mg_smooth_step_kernel, dim3((unsigned)A.tiles), dim3(CG_BLOCK), 0, st, A, (const double*)nullptr, (const double*)v, (double*)nullptr, (const double*)nullptr, (const double*)nullptr, w, -1.0 / omega, (const int32_t*)nullptr);
+        hipLaunchKernelGGL(mg_power_norm_kernel, dim3(1), dim3(1024), 0, st, (const double*)w, v, n6, lam);
+    }
+    hipLaunchKernelGGL(mg_rescale_dinv_kernel, dim3((unsigned)(((int64_t)A.n * 36 + 255) / 256)), dim3(256), 0, st, A, (const double*)lam, omega, 1.75, 1.5);
+}
+
 void launch_mg_galerkin0(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, const MgDev& M, const MgLevelDev* levels, hipStream_t st) {
     hipLaunchKernelGGL(mg_galerkin0_kernel, dim3((unsigned)((levels[0].nnzb + 3) / 4)), dim3(256), 0, st, G, L, Sc, C, M, levels[0]);
 }
-void launch_mg_assemble(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, double omega, int32_t* fail, hipStream_t st) {
+void launch_mg_assemble(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, double omega, int32_t* fail, hipStream_t st, double prolong_scale) {
     launch_mg_galerkin0(G, L, Sc, C, M, levels, st);
-    launch_mg_assemble_rest(M, levels, K, omega, fail, st);
+    launch_mg_assemble_rest(M, levels, K, omega, fail, st, prolong_scale);
 }
-void launch_mg_assemble_rest(const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, double omega, int32_t* fail, hipStream_t st) {
-    for (int l = 1; l < M.n_levels; ++l)
-        hipLaunchKernelGGL(mg_galerkin_kernel, dim3((unsigned)((levels[l].nnzb + 3) / 4)), dim3(256), 0, st, levels[l - 1], levels[l]);
-    for (int l = 0; l + 1 < M.n_levels; ++l)
-        hipLaunchKernelGGL(mg_dinv_kernel, dim3((unsigned)((levels[l].n + 255) / 256)), dim3(256), 0, st, levels[l], omega, fail);
-    for (int l = 0; l + 1 < M.n_levels; ++l)
-        hipLaunchKernelGGL(mg_val_f32_kernel, dim3((unsigned)((levels[l].n + 3) / 4)), dim3(256), 0, st, levels[l]);
+void launch_mg_assemble_rest(const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, double omega, int32_t* fail, hipStream_t st, double prolong_scale) {
+    // level by level: the block-Jacobi inverse of level l is needed by a smoothed transition to level l+1 (Ps = (I - c Dinv A) P)
+    for (int l = 0; l < M.n_levels; ++l) {
+        if (l > 0) {
+            const MgLevelDev& A = levels[l - 1];
+            if (A.smoothed) {
+                hipLaunchKernelGGL(mg_ps_kernel, dim3((unsigned)((A.n_ps + 3) / 4)), dim3(256), 0, st, A, prolong_scale);
+                hipLaunchKernelGGL(mg_w_kernel, dim3((unsigned)((A.n_w + 3) / 4)), dim3(256), 0, st, A);
+                hipLaunchKernelGGL(mg_psTw_kernel, dim3((unsigned)((levels[l].nnzb + 3) / 4)), dim3(256), 0, st, A, levels[l]);
+            } else hipLaunchKernelGGL(mg_galerkin_kernel, dim3((unsigned)((levels[l].nnzb + 3) / 4)), dim3(256), 0, st, A, levels[l]);
+        }
+        if (l + 1 < M.n_levels) {
+            hipLaunchKernelGGL(mg_dinv_kernel, dim3((unsigned)((levels[l].n + 255) / 256)), dim3(256), 0, st, levels[l], omega, fail);
+            hipLaunchKernelGGL(mg_val_f32_kernel, dim3((unsigned)((levels[l].n + 3) / 4)), dim3(256), 0, st, levels[l]);
+            mg_limit_smoother(levels[l], omega, st);
+        }
+    }
     const MgLevelDev& T = levels[M.n_levels - 1];
     (void)hipMemsetAsync(K.Ac, 0, (size_t)K.nc * K.nc * sizeof(double), st);
     if (K.nc > 6 * K.n_agg) hipLaunchKernelGGL(coarse_pad_identity_kernel, dim3((unsigned)((K.nc - 6 * K.n_agg + 63) / 64)), dim3(64), 0, st, K);
@@ -353,13 +569,15 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_down_kernel(MgLevelDev A, double*
     __shared__ double tb[CG_BLOCK];
     __shared__ double cb[CG_BLOCK];
     const int stopped = stop ? *stop : 0;
-    const int li = threadIdx.x / 6, c = threadIdx.x % 6;
+    const int q6 = threadIdx.x / 6, c = threadIdx.x % 6;
+    const int li = q6 & ((MG_TILE_ROWS >> A.seg_shift) - 1), sg = q6 >> (5 - A.seg_shift);      // row of the tile, lane group (0 unless the level's rows are split)
     const int4 ti = A.tile_info[blockIdx.x];          // {a0, a1, i0, i1}
     const int2 rb = A.tile_rows[blockIdx.x * MG_TILE_ROWS + li];   // this lane's row: its block range (independent of tile_info)
     if (stopped) return;
     const int a0 = ti.x, na = ti.y - ti.x, i0 = ti.z, i1 = ti.w;
     const int row = i0 + li;
-    const bool live = row < i1;
+    const bool rowlive = row < i1;
+    const bool live = rowlive && sg == 0;
     const bool lagg = threadIdx.x < na * 6;
     const int a = a0 + li;
     double rv = 0.0, d0 = 0.0, d1 = 0.0, d2 = 0.0;
@@ -375,18 +593,12 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_down_kernel(MgLevelDev A, double*
         }
     }
     double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    if (live) mg_row_accumulate_f32(rb.x, rb.y, A.col, A.valf, A.x, c, acc);
+    if (rowlive) { int kb, ke; mg_split_row(rb, sg, A.seg_shift, kb, ke); mg_row_accumulate_f32(kb, ke, A.col, A.valf, A.x, c, acc); }
     double* mine = xch + (size_t)threadIdx.x * 7;
 #pragma unroll
     for (int q = 0; q < 6; ++q) mine[q] = acc[q];
     __syncthreads();
-    if (live) {
-        const double* grp = xch + (size_t)(threadIdx.x - c) * 7;
-        double q = 0.0;
-#pragma unroll
-        for (int cc = 0; cc < 6; ++cc) q += grp[cc * 7 + c];
-        tb[threadIdx.x] = rv - q;
-    }
+    if (live) tb[threadIdx.x] = rv - mg_gather_row(xch, li, c, A.seg_shift);
     __syncthreads();
     if (live) {                                       // the row's own contribution (P_row^T t)[c]
         const double d[3] = {d0, d1, d2};
@@ -447,7 +659,8 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_up_kernel(MgLevelDev A, MgLevelDe
     __shared__ double tb[CG_BLOCK];
     __shared__ double xb[CG_BLOCK];
     const int stopped = stop ? *stop : 0;
-    const int li = threadIdx.x / 6, c = threadIdx.x % 6;
+    const int q6 = threadIdx.x / 6, c = threadIdx.x % 6;
+    const int li = q6 & ((MG_TILE_ROWS >> A.seg_shift) - 1), sg = q6 >> (5 - A.seg_shift);
     double acc2 = 0.0;      // FINE: this workgroup's share of r.(P x_1), over all its tiles
     // FINE: the grid is capped at MAX_PARTIALS workgroups (one r.z partial slot each), a workgroup takes every gridDim-th tile; otherwise one tile per workgroup
     for (int tile = blockIdx.x; tile < A.tiles; tile += gridDim.x) {
@@ -456,7 +669,8 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_up_kernel(MgLevelDev A, MgLevelDe
     if (stopped) return;
     const int i0 = ti.z, i1 = ti.w;
     const int row = i0 + li;
-    const bool live = row < i1;
+    const bool rowlive = row < i1;
+    const bool live = rowlive && sg == 0;
     double rv = 0.0, xv = 0.0;
     double Dk[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     int c0 = 0, c1 = 0;
@@ -497,18 +711,12 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_up_kernel(MgLevelDev A, MgLevelDe
         }
     }
     double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    if (live) mg_row_accumulate_f32(rb.x, rb.y, A.col, A.valf, A.xt, c, acc);
+    if (rowlive) { int kb, ke; mg_split_row(rb, sg, A.seg_shift, kb, ke); mg_row_accumulate_f32(kb, ke, A.col, A.valf, A.xt, c, acc); }
     double* mine = xch + (size_t)threadIdx.x * 7;
 #pragma unroll
     for (int q = 0; q < 6; ++q) mine[q] = acc[q];
     __syncthreads();
-    if (live) {
-        const double* grp = xch + (size_t)(threadIdx.x - c) * 7;
-        double q = 0.0;
-#pragma unroll
-        for (int cc = 0; cc < 6; ++cc) q += grp[cc * 7 + c];
-        tb[threadIdx.x] = rv - q;
-    }
+    if (live) tb[threadIdx.x] = rv - mg_gather_row(xch, li, c, A.seg_shift);
     __syncthreads();
     if (live) {
         const double* ta = tb + (threadIdx.x - c);
@@ -739,7 +947,7 @@ void launch_mg_level1_update(const CgDev& C, const MgDev& M, const MgLevelDev* l
     else hipLaunchKernelGGL(mg_level1_update_kernel, dim3(g1), dim3(CG_BLOCK), 0, st, C, M, levels[0].r, levels[0].x, (const double*)levels[0].Dinv, k & 1, first, mode);
 }
 void launch_mg_apply(const GraphDev& G, const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, const double* r, double* z, double* part_rz, double scale, bool inside_iteration, hipStream_t st,
-                     bool restricted) {
+                     bool restricted, double prolong_scale) {
     const int32_t* stop = inside_iteration ? C.flags : nullptr;     // at PCG start the flag still belongs to the previous solve
     const int nl = M.n_levels;
     const unsigned g1 = (unsigned)((M.n1 + MG_TILE_ROWS - 1) / MG_TILE_ROWS);
@@ -747,16 +955,29 @@ void launch_mg_apply(const GraphDev& G, const CgDev& C, const MgDev& M, const Mg
     else if (nl == 1) hipLaunchKernelGGL(mg_restrict0_kernel, dim3(g1), dim3(CG_BLOCK), 0, st, M, r, K.rc, (double*)nullptr, (const double*)nullptr, stop);
     else hipLaunchKernelGGL(mg_restrict0_kernel, dim3(g1), dim3(CG_BLOCK), 0, st, M, r, levels[0].r, levels[0].x, (const double*)levels[0].Dinv, stop);
     for (int l = 1; l < nl; ++l) {                     // sparse level l -> level l+1
-        const MgLevelDev& A = levels[l - 1];
+        MgLevelDev A = levels[l - 1];
+        if (A.smoothed) {
+            // smoothed prolongator: t = r - A x_pre, u = c Dinv t; the restriction kernel then forms P^T (t - A u) = Ps^T t
+            hipLaunchKernelGGL(mg_smooth_step_kernel, dim3((unsigned)A.tiles), dim3(CG_BLOCK), 0, st, A, (const double*)A.r, (const double*)A.x, A.t, (const double*)nullptr, (const double*)nullptr, A.u, prolong_scale, stop);
+            A.r = A.t; A.x = A.u;
+        }
         if (l + 1 == nl) hipLaunchKernelGGL(mg_down_kernel, dim3((unsigned)A.tiles), dim3(CG_BLOCK), 0, st, A, K.rc, (double*)nullptr, (const double*)nullptr, stop);
         else hipLaunchKernelGGL(mg_down_kernel, dim3((unsigned)A.tiles), dim3(CG_BLOCK), 0, st, A, levels[l].r, levels[l].x, (const double*)levels[l].Dinv, stop);
     }
-    hipLaunchKernelGGL(mg_dense_solve_kernel, dim3((unsigned)K.n_agg), dim3(384), 0, st, K, nl >= 2 ? levels[nl - 2] : levels[0], nl >= 2 ? 1 : 0, scale, stop);
+    // the level below a kernel that prolongs: with a smoothed transition it must receive the bare correction e = P x (xt = 0 + P x), smoothed afterwards
+    auto below_of = [&](int idx) { MgLevelDev B = levels[idx]; if (B.smoothed) B.x = const_cast<double*>(B.zero); return B; };
+    hipLaunchKernelGGL(mg_dense_solve_kernel, dim3((unsigned)K.n_agg), dim3(384), 0, st, K, nl >= 2 ? below_of(nl - 2) : levels[0], nl >= 2 ? 1 : 0, scale, stop);
     const bool fused = C.extra_rz > 0;     // level 1's kernel prolongs to the keyframes itself (the solver sets extra_rz = its tile count when that fits the partial-sum slots)
     const unsigned g0 = (unsigned)cg_grid(G);
     for (int l = nl - 1; l >= 1; --l) {
-        if (l == 1 && fused) hipLaunchKernelGGL(mg_up_kernel<true>, dim3((unsigned)(levels[0].tiles < MAX_PARTIALS ? levels[0].tiles : MAX_PARTIALS)), dim3(CG_BLOCK), 0, st, levels[0], levels[0], 0, scale, stop, M, r, z, part_rz + g0);
-        else hipLaunchKernelGGL(mg_up_kernel<false>, dim3((unsigned)levels[l - 1].tiles), dim3(CG_BLOCK), 0, st, levels[l - 1], l >= 2 ? levels[l - 2] : levels[0], l >= 2 ? 1 : 0, scale, stop, M, r, z, part_rz);
+        MgLevelDev A = levels[l - 1];
+        if (A.smoothed) {
+            // y = x_pre + e - c Dinv (A e) = x_pre + Ps x_next ; the post-smoothing kernel then works on y
+            hipLaunchKernelGGL(mg_smooth_step_kernel, dim3((unsigned)A.tiles), dim3(CG_BLOCK), 0, st, A, (const double*)nullptr, (const double*)A.xt, (double*)nullptr, (const double*)A.x, (const double*)A.xt, A.y, prolong_scale, stop);
+            A.xt = A.y;
+        }
+        if (l == 1 && fused) hipLaunchKernelGGL(mg_up_kernel<true>, dim3((unsigned)(A.tiles < MAX_PARTIALS ? A.tiles : MAX_PARTIALS)), dim3(CG_BLOCK), 0, st, A, A, 0, scale, stop, M, r, z, part_rz + g0);
+        else hipLaunchKernelGGL(mg_up_kernel<false>, dim3((unsigned)A.tiles), dim3(CG_BLOCK), 0, st, A, l >= 2 ? below_of(l - 2) : levels[0], l >= 2 ? 1 : 0, scale, stop, M, r, z, part_rz);
     }
     if (!fused) hipLaunchKernelGGL(mg_prolong0_kernel, dim3(g0), dim3(CG_BLOCK), 0, st, G, M, (const double*)(nl == 1 ? K.yc : levels[0].xf), r, z, part_rz, scale, stop);
 }

@@ -530,6 +530,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
         pgo_mg::Hierarchy H;
         const int dense_max = std::max(1, std::min(p->opt.mg_dense_max_nodes, 512));
         const int passes0 = std::max(1, std::min(p->opt.mg_first_passes, 3)), passes = std::max(1, std::min(p->opt.mg_passes, 3));
+        const int n_smoothed = std::max(0, std::min(p->opt.mg_smoothed_levels, MG_MAX_LEVELS));
         std::vector<double> sw_w;
         if (sw_now && S > 0) { sw_w.resize((size_t)Es); for (int64_t e = 0; e < Es; ++e) { const double sv = sw_now[p->swe.sw[e]]; sw_w[e] = sv * sv; } }
         bool ok;
@@ -537,7 +538,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
         std::vector<double> inv_cnt;
         if (!p->local_ids) {
             ok = pgo_mg::build_hierarchy(N, p->h_node_free, p->rel.c1, p->rel.c2, p->rel.meas.data() + 7, 8, p->swe.c1, p->swe.c2, sw_w.empty() ? nullptr : sw_w.data(), passes0, passes, dense_max, MG_TILE_ROWS,
-                                         MG_MAX_LEVELS, H, false, MG_BLOCK0);
+                                         MG_MAX_LEVELS, H, false, MG_BLOCK0, nullptr, n_smoothed);
         } else {
             // Several ranks: every rank gathers the endpoints and weights of ALL edges (one all-reduce of a zero-padded buffer: 24 B per edge, once per graph build)
             // and builds the same hierarchy from the global graph; its own edges and owned keyframes are what it contributes to level 1 (pgo_mg_host.hpp).
@@ -559,7 +560,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
             for (int64_t g = 0; g < Ng; ++g) gfree[g] = p->h_touched_any[g];
             for (int32_t c : p->constant_nodes) if (c >= 0 && c < Ng) gfree[c] = 0;
             const pgo_mg::LocalContrib local{&p->l2g, &p->h_own, &p->rel.c1, &p->rel.c2, &p->swe.c1, &p->swe.c2};
-            ok = pgo_mg::build_hierarchy(Ng, gfree, grc1, grc2, grw.data(), 1, gsc1, gsc2, (sw_now && S > 0) ? gsw.data() : nullptr, passes0, passes, dense_max, MG_TILE_ROWS, MG_MAX_LEVELS, H, false, 0, &local);
+            ok = pgo_mg::build_hierarchy(Ng, gfree, grc1, grc2, grw.data(), 1, gsc1, gsc2, (sw_now && S > 0) ? gsw.data() : nullptr, passes0, passes, dense_max, MG_TILE_ROWS, MG_MAX_LEVELS, H, false, 0, &local, n_smoothed);
             if (ok) {
                 const int32_t n1g = (int32_t)H.mem0_ptr.size() - 1;
                 inv_cnt.resize((size_t)n1g);
@@ -583,7 +584,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
             auto put64 = [&](const std::vector<int64_t>& v) { const size_t o = pi64.size(); pi64.insert(pi64.end(), v.begin(), v.end()); return o; };
             size_t nf64 = 0;
             auto take = [&](size_t cnt) { const size_t o = nf64; nf64 += (cnt + 1) & ~(size_t)1; return o; };
-            struct Off { size_t col, parent, agg_ptr, tile, tile_rows, rowptr, g_ptr, g_ent, val, Dinv, pos, d, r, x, xt, xf, valf; };
+            struct Off { size_t col, parent, agg_ptr, tile, tile_rows, rowptr, g_ptr, g_ent, val, Dinv, pos, d, r, x, xt, xf, valf, ps_rowptr, ps_col, w_rowptr, w_col, psT_ptr, psT_ent, ps_val, w_val, t, u, y, zero; };
             std::vector<Off> off((size_t)nl);
             const size_t o_agg0 = put32(A0), o_mem0_ptr = put32(M0P), o_mem0 = put32(M0);
             // slot table of the restriction inside the vector update: per run of MG_BLOCK0 keyframes its aggregates {id, 8 members as run-local bytes}
@@ -633,6 +634,12 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
                 o.val = take(A.col.size() * 36); o.Dinv = take((size_t)A.n * 36); o.pos = take((size_t)A.n * 3); o.d = take((size_t)A.n * 3);
                 o.r = take((size_t)A.n * 6); o.x = take((size_t)A.n * 6); o.xt = take((size_t)A.n * 6); o.xf = take((size_t)A.n * 6);
                 o.valf = take((A.col.size() * 36 + 1) / 2);      // fp32 copy of the blocks, carved out of the fp64 pool
+                if (A.smoothed) {
+                    o.ps_rowptr = put32(A.ps_rowptr); o.ps_col = put32(A.ps_col); o.w_rowptr = put32(A.w_rowptr); o.w_col = put32(A.w_col);
+                    o.psT_ptr = put64(A.psT_ptr); o.psT_ent = put64(A.psT_ent);
+                    o.ps_val = take(A.ps_col.size() * 36); o.w_val = take(A.w_col.size() * 36);
+                    o.t = take((size_t)A.n * 6); o.u = take((size_t)A.n * 6); o.y = take((size_t)A.n * 6); o.zero = take((size_t)A.n * 6);
+                }
             }
             const int n_top = H.L[nl - 1].n;
             const int nc = (6 * n_top + 63) / 64 * 64;
@@ -659,6 +666,12 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
                 D.rowptr = b64 + o.rowptr; D.col = b32 + o.col; D.val = bf + o.val; D.g_ptr = b64 + o.g_ptr; D.g_ent = b64 + o.g_ent;
                 D.Dinv = bf + o.Dinv; D.pos = bf + o.pos; D.d = bf + o.d; D.parent = b32 + o.parent; D.agg_ptr = b32 + o.agg_ptr; D.tile_info = reinterpret_cast<const int4*>(b32 + o.tile); D.tile_rows = reinterpret_cast<const int2*>(b32 + o.tile_rows);
                 D.r = bf + o.r; D.x = bf + o.x; D.xt = bf + o.xt; D.xf = bf + o.xf; D.valf = reinterpret_cast<float*>(bf + o.valf);
+                D.seg_shift = A.seg >= 4 ? 2 : A.seg >= 2 ? 1 : 0;
+                if (A.smoothed) {
+                    D.smoothed = 1; D.n_ps = (int32_t)A.ps_col.size(); D.n_w = (int32_t)A.w_col.size();
+                    D.ps_rowptr = b32 + o.ps_rowptr; D.ps_col = b32 + o.ps_col; D.w_rowptr = b32 + o.w_rowptr; D.w_col = b32 + o.w_col; D.psT_ptr = b64 + o.psT_ptr; D.psT_ent = b64 + o.psT_ent;
+                    D.ps_val = bf + o.ps_val; D.w_val = bf + o.w_val; D.t = bf + o.t; D.u = bf + o.u; D.y = bf + o.y; D.zero = bf + o.zero;
+                }
             }
             // the dense coarsest level shares the buffers of the two-level preconditioner, which the multigrid replaces on this graph
             p->coarse_built = false;
@@ -667,7 +680,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
             p->mg_built = true;
             if (p->opt.verbosity > 0) {
                 std::fprintf(stderr, "[pgo] multigrid: %lld keyframes", (long long)N);
-                for (int l = 0; l < nl; ++l) std::fprintf(stderr, " -> %d (%lld blocks)", H.L[l].n, (long long)H.L[l].col.size());
+                for (int l = 0; l < nl; ++l) std::fprintf(stderr, " -> %d (%lld blocks%s)", H.L[l].n, (long long)H.L[l].col.size(), H.L[l].smoothed ? ", smoothed prolongator above" : "");
                 std::fprintf(stderr, ", coarsest dense %d\n", nc);
             }
         } else if (p->opt.verbosity > 0) std::fprintf(stderr, "[pgo] multigrid: the graph does not coarsen (isolated keyframes?) -> off\n");
@@ -868,6 +881,12 @@ int linearize(pgo_problem* p, double* cost_out) {
 }
 
 static int build_mg(pgo_problem* p);
+// c = w_p / w of the smoothed prolongators (Dinv holds w D^-1)
+double mg_cs(const pgo_problem* p) {
+    const double om = p->opt.mg_omega > 0.0 && p->opt.mg_omega <= 1.0 ? p->opt.mg_omega : 0.9;
+    const double wp = p->opt.mg_prolongation_damping > 0.0 && p->opt.mg_prolongation_damping < 0.85 ? p->opt.mg_prolongation_damping : 0.6;
+    return wp / om;
+}
 double mg_scale(const pgo_problem* p) { return p->opt.mg_correction_scale >= 1.0 && p->opt.mg_correction_scale <= 4.0 ? p->opt.mg_correction_scale : 1.0; }
 
 struct CgResult { int iterations; bool breakdown; double rel_residual; bool converged; };
@@ -906,7 +925,7 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
             launch_mg_restrict0(p->G, p->M, p->C.r, r1, true, p->st);
             if ((rcs = allreduce(p, r1, (size_t)p->M.n1 * 6, 0)) != PGO_OK) return rcs;
             launch_mg_level1_update(p->C, p->M, p->mg_levels, p->K, 0, 1, 1, p->st);
-            launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz, mg_scale(p), false, p->st, true);
+            launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz, mg_scale(p), false, p->st, true, mg_cs(p));
         }
         double* bb = p->C.scal + 12;
         launch_reduce(p->C.part_pq, g, 0, bb, p->st);
@@ -918,7 +937,7 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
         if (!multi && (p->coarse_active || p->mg_active)) {
             // z = D^-1 r + P Ac^-1 P^T r (or the multigrid cycle): the coarse term is added to z and to the r.z partials before the scalars are formed
             int g = launch_cg_init_vectors(p->G, p->C, warm ? 1 : 0, p->st);
-            if (p->mg_active) launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz, mg_scale(p), false, p->st);
+            if (p->mg_active) launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz, mg_scale(p), false, p->st, false, mg_cs(p));
             else launch_coarse_apply(p->G, p->C, p->K, p->C.r, p->C.z, p->C.part_rz, false, p->st);
             if (fused_coarse) {    // z is complete here: the slots the fused kernels will use beyond the start-up kernels' stay zero for this parity
                 HIPCHK(p, hipMemsetAsync(p->C.part_rz + g, 0, (size_t)(fused_parts + p->C.extra_rz - g) * sizeof(double), p->st));
@@ -937,8 +956,10 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
         // captured chunks stay at <= 72 kernel nodes (rocprofv3 7.2 crashes while a graph of 120 nodes is captured under --kernel-trace; 80 are fine): five kernels
         // per iteration with the coarse space in its unfused form -> 12 iterations, three in the fused form -> 24
         if (p->coarse_active && !multi) e = std::min(e, fused_coarse ? 24 : 12);
-        if (p->mg_active && multi) e = std::min(e, std::max(2, (72 / (2 * p->M.n_levels + 7)) & ~1));
-        if (p->mg_active && !multi) e = std::max(2, (72 / (2 * p->M.n_levels + 3)) & ~1);   // at most 2 n_levels + 1 cycle kernels + matvec + update per iteration (one less with the restriction inside the update)
+        int n_sm = 0;
+        for (int l = 0; l < p->M.n_levels; ++l) n_sm += p->mg_levels[l].smoothed ? 1 : 0;      // two more kernels per cycle for every level with a smoothed prolongator above it
+        if (p->mg_active && multi) e = std::min(e, std::max(2, (72 / (2 * p->M.n_levels + 7 + 2 * n_sm)) & ~1));
+        if (p->mg_active && !multi) e = std::max(2, (72 / (2 * p->M.n_levels + 3 + 2 * n_sm)) & ~1);   // at most 2 n_levels + 1 cycle kernels + matvec + update per iteration (one less with the restriction inside the update)
         return e;
     };
     every = chunk_length();
@@ -962,7 +983,7 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
             launch_cgcg_update(p->G, p->C, kk, kk == 0 ? 1 : 0, p->st, xb, p->d_sh_of.p, xb + nrow);   // (first: also when a PCG that stopped before its first update is resumed: p = s = 0 still)
             if (p->mg_active) {      // u = D^-1 r + P0 V(r1): r1 by the recurrence, the cycle on the replicated levels, the prolongation to this rank's keyframes
                 launch_mg_level1_update(p->C, p->M, p->mg_levels, p->K, kk, kk == 0 ? 1 : 0, 0, p->st);
-                launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz, mg_scale(p), true, p->st, true);
+                launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz, mg_scale(p), true, p->st, true, mg_cs(p));
             }
             return PGO_OK;
         }
@@ -979,7 +1000,7 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
         if (mg_restrict_fused) launch_cg_update_mg(p->G, p->C, p->M, p->mg_levels, p->K, kk, n_pq, p->st);
         else launch_cg_update(p->G, p->C, kk, n_pq, p->st);
         // the new residual is in the OTHER r buffer, its r.z partials in the other parity's slots
-        if (p->mg_active) launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, (kk & 1) ? p->C.r : p->C.r2, p->C.z, p->C.part_rz + (size_t)((kk & 1) ^ 1) * RZ_STRIDE, mg_scale(p), true, p->st, mg_restrict_fused);
+        if (p->mg_active) launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, (kk & 1) ? p->C.r : p->C.r2, p->C.z, p->C.part_rz + (size_t)((kk & 1) ^ 1) * RZ_STRIDE, mg_scale(p), true, p->st, mg_restrict_fused, mg_cs(p));
         else if (p->coarse_active)
             launch_coarse_apply(p->G, p->C, p->K, (kk & 1) ? p->C.r : p->C.r2, p->C.z, p->C.part_rz + (size_t)((kk & 1) ^ 1) * RZ_STRIDE, true, p->st);
         return PGO_OK;
@@ -1071,7 +1092,7 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
                 if ((rc = start_multi(1)) != PGO_OK) return rc;
             } else {
                 const int g = launch_cg_init_vectors(p->G, p->C, 1, p->st);
-                launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz, mg_scale(p), false, p->st);
+                launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz, mg_scale(p), false, p->st, false, mg_cs(p));
                 launch_cg_init_scalars(p->C, g, tol2, p->st);
             }
             k = 0; n_chunks = 0; waited = -1; r1_refreshed_at = 0;
@@ -1155,8 +1176,8 @@ static int build_mg(pgo_problem* p) {
     if (p->local_ids) {         // level 1 = the sum of the ranks' Galerkin products (each edge lives on one rank, each diagonal block is its owner's); the levels above are replicated
         launch_mg_galerkin0(p->G, p->L, p->Sc, p->C, p->M, p->mg_levels, p->st);
         if ((rcm = allreduce(p, p->mg_levels[0].val, (size_t)p->mg_levels[0].nnzb * 36, 0)) != PGO_OK) return rcm;
-        launch_mg_assemble_rest(p->M, p->mg_levels, p->K, omega, fail, p->st);
-    } else launch_mg_assemble(p->G, p->L, p->Sc, p->C, p->M, p->mg_levels, p->K, omega, fail, p->st);
+        launch_mg_assemble_rest(p->M, p->mg_levels, p->K, omega, fail, p->st, mg_cs(p));
+    } else launch_mg_assemble(p->G, p->L, p->Sc, p->C, p->M, p->mg_levels, p->K, omega, fail, p->st, mg_cs(p));
     launch_coarse_invert(p->K, p->d_cscr.p, fail, p->st);
     int32_t h = 1;
     HIPCHK(p, hipMemcpyAsync(&h, fail, sizeof(h), hipMemcpyDeviceToHost, p->st));
@@ -1343,6 +1364,14 @@ int lm_step(pgo_problem* p, int ignore_termination, int* done) {
                 cg.iterations += plain.iterations;
             }
         }
+        // A breakdown under the multigrid (its cycle was not positive definite on this system — a smoother at its stability limit) is not the system's fault:
+        // the same system is solved again by plain block-Jacobi before the step may count as invalid.
+        if (cg.breakdown && p->mg_active && !evaluated) {
+            if (o.verbosity > 0) std::fprintf(stderr, "[pgo] multigrid: PCG breakdown at radius %.1e (cycle not positive definite) -> block-Jacobi for this system\n", p->radius);
+            p->mg_active = false; p->mg_failed = true; p->C.extra_rz = 0;
+            p->cg_extra += cg.iterations;
+            if ((rc = run_pcg(p, &cg, false, o.cg_rel_tolerance, -1)) != PGO_OK) return rc;
+        }
         p->have_prev_step = !cg.breakdown;
         if (cg.breakdown) ok = false;
         // block-Jacobi-equivalent work of this system, for the next system's choice of preconditioner (build_system)
@@ -1525,6 +1554,8 @@ void pgo_options_init(pgo_options* o) {
     o->mg_passes = 3;
     o->mg_dense_max_nodes = 512;
     o->mg_switch_iterations = 400;
+    o->mg_prolongation_damping = 0.6;
+    o->mg_smoothed_levels = 1;
     o->cg_rel_tolerance = 1e-9;     // loosest decade that keeps the 10-iteration chi^2 of C3 within 1e-8 of the 1e-13 solve
     o->device_id = -1;
     o->verbosity = 0;
@@ -1583,7 +1614,7 @@ int pgo_set_options(pgo_problem* p, const pgo_options* o) {
     if (o->linear_solver != p->opt.linear_solver) p->graph_dirty = true;
     // the preconditioner hierarchies are part of the device graph build
     if (o->mg_min_keyframes != p->opt.mg_min_keyframes || o->mg_first_passes != p->opt.mg_first_passes || o->mg_passes != p->opt.mg_passes ||
-        o->mg_dense_max_nodes != p->opt.mg_dense_max_nodes || o->coarse_aggregates != p->opt.coarse_aggregates) p->graph_dirty = true;
+        o->mg_dense_max_nodes != p->opt.mg_dense_max_nodes || o->coarse_aggregates != p->opt.coarse_aggregates || o->mg_smoothed_levels != p->opt.mg_smoothed_levels) p->graph_dirty = true;
     p->opt = *o;
     p->opt.device_id = dev;   // the device binding is fixed at create
     return PGO_OK;
@@ -1995,7 +2026,7 @@ int pgo_time_kernel(pgo_problem* p, int32_t which, int32_t launches, double* avg
         if (!p->mg_active && (rc = build_mg(p)) != PGO_OK) return rc;
         if (!p->mg_active) { p->err = "pgo_time_kernel: the multigrid operators of this system are not positive definite"; (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return PGO_ERR_NUMERIC; }
         const int g = launch_cg_init_vectors(p->G, p->C, 0, p->st);
-        launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz, mg_scale(p), false, p->st);
+        launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz, mg_scale(p), false, p->st, false, mg_cs(p));
         launch_cg_init_scalars(p->C, g, 0.0, p->st);
     }
     if (which == 2 || which == 4 || which == 5) {   // a live PCG state to iterate on (tolerance 0: never converges during the timed launches)
@@ -2039,7 +2070,7 @@ int pgo_time_kernel(pgo_problem* p, int32_t which, int32_t launches, double* avg
                               if (fused) launch_cg_update_mg(G, p->C, p->M, p->mg_levels, p->K, kk, mf_grid_size(p->F), p->st);
                               else launch_cg_update(G, p->C, kk, mf_grid_size(p->F), p->st);
                           }
-                          launch_mg_apply(G, p->C, p->M, p->mg_levels, p->K, (kk & 1) ? p->C.r : p->C.r2, p->C.z, p->C.part_rz + (size_t)((kk & 1) ^ 1) * RZ_STRIDE, mg_scale(p), true, p->st, which == 6 && fused);
+                          launch_mg_apply(G, p->C, p->M, p->mg_levels, p->K, (kk & 1) ? p->C.r : p->C.r2, p->C.z, p->C.part_rz + (size_t)((kk & 1) ^ 1) * RZ_STRIDE, mg_scale(p), true, p->st, which == 6 && fused, mg_cs(p));
                           // Bytes of this design, each array once per kernel that streams it.  Fine level as in case 2 (+ the restriction's per-keyframe offsets and slot table,
                           // the prolongation's read-modify-write of z, offsets and aggregate index); every sparse coarse level: its fp32 blocks and column indices twice
                           // (down- and up-sweep), Dinv, positions/offsets and its four vectors; the dense level: the fp32 inverse once.
@@ -2048,7 +2079,7 @@ int pgo_time_kernel(pgo_problem* p, int32_t which, int32_t launches, double* avg
                           double cyc = N * (24.0 + 16.0 / 8.0 * 8.0) /* d0 + slot table (restriction) */ + N * (2.0 * 48.0 + 24.0 + 4.0 + 4.0) /* z read + write, d0, agg0, member list (prolongation) */;
                           for (int l = 0; l + 1 < p->M.n_levels; ++l) {
                               const MgLevelDev& A = p->mg_levels[l];
-                              cyc += 2.0 * (double)A.nnzb * (144.0 + 4.0) + (double)A.n * (2.0 * 288.0 /* Dinv: pre- and post-smoothing */ + 24.0 + 10.0 * 48.0 + 16.0);
+                              cyc += (A.smoothed ? 4.0 : 2.0) * (double)A.nnzb * (144.0 + 4.0) + (double)A.n * ((A.smoothed ? 4.0 : 2.0) * 288.0 /* Dinv: smoothing steps */ + 24.0 + (A.smoothed ? 18.0 : 10.0) * 48.0 + 16.0);
                           }
                           cyc += (double)p->K.nc * (double)p->K.nc * 4.0 + (double)p->K.nc * 16.0;
                           bytes = which == 6 ? fine + cyc : cyc;

@@ -5,13 +5,13 @@
 
 extern "C" {
 void* mgh_build(long long N, const unsigned char* node_free, long long Er, const int* rc1, const int* rc2, const double* rw, long long Es, const int* sc1, const int* sc2,
-                int passes0, int passes, int dense_max, int tile_rows, int max_levels, int level0_follows_switchable) {
+                int passes0, int passes, int dense_max, int tile_rows, int max_levels, int level0_follows_switchable, int smoothed_levels) {
     std::vector<uint8_t> nf(node_free, node_free + N);
     std::vector<int32_t> a(rc1, rc1 + Er), b(rc2, rc2 + Er), c(sc1, sc1 + Es), d(sc2, sc2 + Es);
     std::vector<double> meas((size_t)Er * 8, 0.0);
     for (long long e = 0; e < Er; ++e) meas[8 * e + 7] = rw[e];
     pgo_mg::Hierarchy* H = new pgo_mg::Hierarchy();
-    if (!pgo_mg::build_hierarchy(N, nf, a, b, meas.data() + 7, 8, c, d, nullptr, passes0, passes, dense_max, tile_rows, max_levels, *H, level0_follows_switchable != 0)) { delete H; return nullptr; }
+    if (!pgo_mg::build_hierarchy(N, nf, a, b, meas.data() + 7, 8, c, d, nullptr, passes0, passes, dense_max, tile_rows, max_levels, *H, level0_follows_switchable != 0, 0, nullptr, smoothed_levels)) { delete H; return nullptr; }
     return H;
 }
 // Several ranks: the structure from the global graph, level 1's contribution lists from the edges dealt to `rank` (rank_rel / rank_sw: the rank holding each edge)
@@ -49,6 +49,17 @@ void mgh_level(void* h, int l, long long* rowptr, int* col, long long* g_ptr, lo
     if (!A.parent.empty()) std::memcpy(parent, A.parent.data(), A.parent.size() * 4);
     if (!A.agg_ptr.empty()) std::memcpy(agg_ptr, A.agg_ptr.data(), A.agg_ptr.size() * 4);
     if (!A.tile_agg0.empty()) std::memcpy(tile_agg0, A.tile_agg0.data(), A.tile_agg0.size() * 4);
+}
+// structure of a smoothed transition: sizes {n_ps, n_w, n_psT_ent}, then the arrays
+void mgh_smoothed_sizes(void* h, int l, long long* out) {
+    const pgo_mg::HostLevel& A = ((pgo_mg::Hierarchy*)h)->L[l];
+    out[0] = A.smoothed ? (long long)A.ps_col.size() : -1; out[1] = (long long)A.w_col.size(); out[2] = (long long)A.psT_ent.size();
+}
+void mgh_smoothed(void* h, int l, int* ps_rowptr, int* ps_col, int* w_rowptr, int* w_col, long long* psT_ptr, long long* psT_ent) {
+    const pgo_mg::HostLevel& A = ((pgo_mg::Hierarchy*)h)->L[l];
+    std::memcpy(ps_rowptr, A.ps_rowptr.data(), A.ps_rowptr.size() * 4); std::memcpy(ps_col, A.ps_col.data(), A.ps_col.size() * 4);
+    std::memcpy(w_rowptr, A.w_rowptr.data(), A.w_rowptr.size() * 4); std::memcpy(w_col, A.w_col.data(), A.w_col.size() * 4);
+    std::memcpy(psT_ptr, A.psT_ptr.data(), A.psT_ptr.size() * 8); std::memcpy(psT_ent, A.psT_ent.data(), A.psT_ent.size() * 8);
 }
 void mgh_level0(void* h, int* agg0, int* mem0_ptr, int* mem0) {
     const pgo_mg::Hierarchy& H = *(pgo_mg::Hierarchy*)h;

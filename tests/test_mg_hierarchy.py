@@ -30,13 +30,13 @@ def I32(x): return np.ascontiguousarray(x, dtype=np.int32)
 def ptr(a, t): return a.ctypes.data_as(C.POINTER(t))
 
 
-def build(lib, g, free=None, passes0=3, passes=2, dense_max=64, tile_rows=32, max_levels=12, level0_loops=True):
+def build(lib, g, free=None, passes0=3, passes=2, dense_max=64, tile_rows=32, max_levels=12, level0_loops=True, smoothed=0):
     N = g.n_poses
     nf = np.ones(N, np.uint8) if free is None else np.ascontiguousarray(free, dtype=np.uint8)
     rc1, rc2, sc1, sc2 = I32(g.odom_c1), I32(g.odom_c2), I32(g.loop_c1), I32(g.loop_c2)
     rw = np.ascontiguousarray(g.odom_w, dtype=np.float64)
     h = lib.mgh_build(C.c_longlong(N), ptr(nf, C.c_ubyte), C.c_longlong(len(rc1)), ptr(rc1, C.c_int), ptr(rc2, C.c_int), ptr(rw, C.c_double), C.c_longlong(len(sc1)), ptr(sc1, C.c_int),
-                      ptr(sc2, C.c_int), passes0, passes, dense_max, tile_rows, max_levels, 1 if level0_loops else 0)
+                      ptr(sc2, C.c_int), passes0, passes, dense_max, tile_rows, max_levels, 1 if level0_loops else 0, smoothed)
     if not h:
         return None
     h = C.c_void_p(h)
@@ -49,6 +49,13 @@ def build(lib, g, free=None, passes0=3, passes=2, dense_max=64, tile_rows=32, ma
                  parent=np.zeros(npar, np.int32), agg_ptr=np.zeros(nagg, np.int32), tile_agg0=np.zeros(ntile, np.int32))
         lib.mgh_level(h, l, ptr(L["rowptr"], C.c_longlong), ptr(L["col"], C.c_int), ptr(L["g_ptr"], C.c_longlong), ptr(L["g_ent"], C.c_longlong), ptr(L["parent"], C.c_int),
                       ptr(L["agg_ptr"], C.c_int), ptr(L["tile_agg0"], C.c_int))
+        ss = np.zeros(3, np.int64)
+        lib.mgh_smoothed_sizes(h, l, ptr(ss, C.c_longlong))
+        if ss[0] >= 0:
+            S = dict(ps_rowptr=np.zeros(n + 1, np.int32), ps_col=np.zeros(int(ss[0]), np.int32), w_rowptr=np.zeros(n + 1, np.int32), w_col=np.zeros(int(ss[1]), np.int32),
+                     psT_ptr=np.zeros(nagg, np.int64), psT_ent=np.zeros(int(ss[2]), np.int64))
+            lib.mgh_smoothed(h, l, ptr(S["ps_rowptr"], C.c_int), ptr(S["ps_col"], C.c_int), ptr(S["w_rowptr"], C.c_int), ptr(S["w_col"], C.c_int), ptr(S["psT_ptr"], C.c_longlong), ptr(S["psT_ent"], C.c_longlong))
+            L["smoothed"] = S
         levels.append(L)
     n1 = levels[0]["n"]
     agg0 = np.zeros(N, np.int32); mem0_ptr = np.zeros(n1 + 1, np.int32)
@@ -217,3 +224,44 @@ def test_sharded_build_has_the_global_structure_and_every_contribution_exactly_o
     # diagonal blocks come from the owner, edges from the rank that holds them
     for (blk, kind, gidx), rank in seen.items():
         assert rank == (owner[gidx] if kind == 0 else rank_rel[gidx] if kind <= 2 else rank_sw[gidx])
+
+
+def test_smoothed_transition_structures_are_the_sparse_products(shim):
+    """Smoothed aggregation on the transitions above level 1: Ps = (I - w D^-1 A) P has the pattern of A P, W = A Ps that of A A P, and the level above that of
+    Ps^T W — checked against scipy's boolean products; the column-wise view of Ps lists every block exactly once; the diagonal block stays first in every row."""
+    import scipy.sparse as sp
+    g = graphgen.generate(4000, 1500, odom_f_max=2, seed=11)
+    H = build(shim, g, passes0=3, passes=2, dense_max=40, level0_loops=False, smoothed=2)
+    Href = build(shim, g, passes0=3, passes=2, dense_max=40, level0_loops=False, smoothed=0)
+    assert len(H["levels"]) == len(Href["levels"]) >= 3
+    for l, L in enumerate(H["levels"][:-1]):
+        assert ("smoothed" in L) == (l < 2)
+        if "smoothed" not in L:
+            continue
+        n, S = L["n"], L["smoothed"]
+        nb = H["levels"][l + 1]["n"]
+        rows = np.repeat(np.arange(n), np.diff(L["rowptr"]))
+        A = sp.csr_matrix((np.ones(len(L["col"])), (rows, L["col"])), shape=(n, n))
+        P = sp.csr_matrix((np.ones(n), (np.arange(n), L["parent"])), shape=(n, nb))
+        def pattern(rowptr, col, shape):
+            r = np.repeat(np.arange(shape[0]), np.diff(rowptr))
+            return sp.csr_matrix((np.ones(len(col)), (r, col)), shape=shape)
+        Ps = pattern(S["ps_rowptr"], S["ps_col"], (n, nb)); W = pattern(S["w_rowptr"], S["w_col"], (n, nb))
+        assert ((A @ P) != 0).astype(int).toarray().tolist() == (Ps != 0).astype(int).toarray().tolist() if n <= 600 else (abs((A @ P).astype(bool).astype(int) - Ps.astype(bool).astype(int))).nnz == 0
+        assert (abs((A @ Ps).astype(bool).astype(int) - W.astype(bool).astype(int))).nnz == 0
+        B = H["levels"][l + 1]
+        Bp = pattern(B["rowptr"], B["col"], (nb, nb))
+        assert (abs((Ps.T @ W).astype(bool).astype(int) - Bp.astype(bool).astype(int))).nnz == 0
+        assert all(B["col"][B["rowptr"][a]] == a for a in range(nb))
+        # every row of Ps and W ascending (the numeric kernels search them), Ps by column complete
+        for a in range(n):
+            assert np.all(np.diff(S["ps_col"][S["ps_rowptr"][a]:S["ps_rowptr"][a + 1]]) > 0) and np.all(np.diff(S["w_col"][S["w_rowptr"][a]:S["w_rowptr"][a + 1]]) > 0)
+        seen = np.zeros(len(S["ps_col"]), int)
+        for a in range(nb):
+            for ent in S["psT_ent"][S["psT_ptr"][a]:S["psT_ptr"][a + 1]]:
+                i, sl = int(ent >> 32), int(ent & 0xffffffff)
+                assert S["ps_rowptr"][i] <= sl < S["ps_rowptr"][i + 1] and S["ps_col"][sl] == a
+                seen[sl] += 1
+        assert np.all(seen == 1)
+        # the level above is denser than with the tentative prolongator, the levels' sizes are the same
+        assert len(B["col"]) > len(Href["levels"][l + 1]["col"]) and B["n"] == Href["levels"][l + 1]["n"]
