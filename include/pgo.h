@@ -136,7 +136,7 @@ typedef struct pgo_options {
                                           *      positive definite, the PCG breaks down and the LM iterates leave the exact-solve path — so 1.0 has no margin and 0.9 stays) */
     double mg_correction_scale;          /* 1.0 (1.6 saves 15-25 % of the iterations on the first linearisation at radius >= 1e6 and costs 5-10 % on later ones) */
     int32_t mg_first_passes;             /* 3 */
-    int32_t mg_passes;                   /* 3; values 1..3 (measured with up to 5 on the final build, C3 / C4 20 steps: 3: 0.467 / 3.46 s, 4: 0.514 / 4.36 s, 5: 0.621 / 4.81 s) (one level less than with 2 at +6 % iterations: 3 % faster on C3 and C4, each level costs two ~10-us kernels) */
+    int32_t mg_passes;                   /* 0 = by the prolongator: 2 where the transition above level 1 is smoothed (round 3: C3 / C4, 20 steps: 3: 0.453 / 3.56 s, 2: 0.438 / 2.37 s, 1: 0.586 s / -), 3 with plain aggregation; values 1..3 (measured with up to 5 on the final build, C3 / C4 20 steps: 3: 0.467 / 3.46 s, 4: 0.514 / 4.36 s, 5: 0.621 / 4.81 s) (one level less than with 2 at +6 % iterations: 3 % faster on C3 and C4, each level costs two ~10-us kernels) */
     int32_t mg_dense_max_nodes;          /* 512 (dense coarsest operator of <= 3072 unknowns) */
     int32_t mg_switch_iterations;        /* 400: every PCG starts with plain block-Jacobi (most LM systems — small trust regions, steps about to be
                                           *      rejected — need a few hundred cheap iterations); one that has not converged after this many iterations
@@ -144,9 +144,15 @@ typedef struct pgo_options {
                                           *      solve, block-Jacobi iterations growing like sqrt(radius)) to need >= 2.25x this many starts with it, and one
                                           *      predicted easier than that switches only after twice its prediction.
                                           *      0: multigrid from the first iteration of every system. */
+    double mg_loop_discount;             /* 3.0: in the matching of the levels ABOVE level 1 the switchable loop closures between two level-1 nodes count as (their number - this).  A single
+                                          *      loop closure may be an outlier the solver switches off a few LM steps later, and an aggregate held together by nothing else then stops being a
+                                          *      rigid piece — the hierarchy is built once per graph, before the switches are known; several loop closures between the same two pieces (revisited
+                                          *      places) are not all outliers.  Measured, 20 LM steps: C3 (10 % outliers) 0.444 / 0.422 / 0.410 / 0.409 s and C4 2.38 / 1.72 / 1.47 / 1.60 s
+                                          *      with 0 / 2 / 3 / 5; a 60k-keyframe graph WITHOUT outliers 0.71 / 0.87 / - / 1.02 s.  Relative-pose loop edges (no switch) are not discounted. */
     double mg_prolongation_damping;      /* 0.6: w_p of the smoothed prolongators Ps = (I - w_p D^-1 A) P (smoothed aggregation's 4 / (3 rho(D^-1 A)), rho ~ 2; from 0.9 on
                                           *      I - w_p D^-1 A is singular inside the spectrum and the Galerkin product degenerates: measured, scripts/research/r3_cycle_probe.py) */
-    int32_t mg_smoothed_levels;          /* 1: the transitions level l -> l+1, l = 1 .. this many, use the SMOOTHED prolongator (the level above is Ps^T A Ps: denser, and each
+    int32_t mg_smoothed_levels;          /* -1 = by size: 1 up to 500 000 keyframes, 0 beyond (C5, 1M keyframes: its coarse levels are bandwidth-bound and the denser operators cost more than the
+                                          *      15 % of iterations they save: 8.5 -> 11.1 s).  n: the transitions level l -> l+1, l = 1 .. n, use the SMOOTHED prolongator (the level above is Ps^T A Ps: denser, and each
                                           *      such level costs two more row-product kernels per cycle); the keyframes -> level 1 transition stays the rigid one (its restriction and
                                           *      prolongation ride in the PCG's own kernels).  0: plain aggregation on every level (round 2's cycle).  Measured on a C3-structured
                                           *      20k-keyframe system with four levels, radius 1e6: 1237 PCG iterations without, 551 with the first transition smoothed, 487 with two */

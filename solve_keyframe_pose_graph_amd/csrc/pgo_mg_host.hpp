@@ -149,7 +149,8 @@ struct LocalContrib {
 inline bool build_hierarchy(int64_t N, const std::vector<uint8_t>& node_free, const std::vector<int32_t>& rc1, const std::vector<int32_t>& rc2, const double* rel_w, int rel_w_stride,
                             const std::vector<int32_t>& sc1, const std::vector<int32_t>& sc2, const double* sw_weight /* per switchable edge: s^2 of its switch at graph build, or nullptr = 1 */,
                             int passes0, int passes, int dense_max, int tile_rows, int max_levels, Hierarchy& H, bool level0_follows_switchable = true, int level0_block = 0,
-                            const LocalContrib* local = nullptr, int smoothed_levels = 0 /* transitions level l -> l+1, l = 1 .. smoothed_levels, use the smoothed prolongator */) {
+                            const LocalContrib* local = nullptr, int smoothed_levels = 0 /* transitions level l -> l+1, l = 1 .. smoothed_levels, use the smoothed prolongator */,
+                            double loop_discount = 0.0 /* loop closures of a pair of level-1 nodes that do not count in the matching above level 1 */) {
     H = Hierarchy{};
     const int64_t Er = (int64_t)rc1.size(), Es = (int64_t)sc1.size();
     std::vector<WEdge> edges;
@@ -203,6 +204,23 @@ inline bool build_hierarchy(int64_t N, const std::vector<uint8_t>& node_free, co
         return out;
     };
     std::vector<WEdge> cur = collapse(edges, H.agg0);
+    if (loop_discount > 0.0 && Es > 0) {
+        // A single loop closure between two level-1 nodes may be an outlier that the solver switches off a few LM steps later; an aggregate of the levels above held
+        // together by nothing else then stops being a rigid piece (the hierarchy is built once per graph, before the switches are known).  Two or more loop closures
+        // between the same two nodes — revisited places: parallel passes — are not all outliers: the matching above level 1 counts the loop closures of a pair minus one.
+        std::vector<WEdge> rel_part, sw_part;
+        { std::vector<WEdge> re, se;
+          for (int64_t e = 0; e < Er; ++e) if (node_free[rc1[e]] && node_free[rc2[e]]) { const double w = rel_w[(size_t)rel_w_stride * e]; if (w * w > 1e-8) re.push_back({rc1[e], rc2[e], w * w}); }
+          for (int64_t e = 0; e < Es; ++e) if (node_free[sc1[e]] && node_free[sc2[e]]) { const double w = sw_weight ? sw_weight[e] : 1.0; if (w > 1e-8) se.push_back({sc1[e], sc2[e], w}); }
+          rel_part = collapse(re, H.agg0); sw_part = collapse(se, H.agg0); }
+        for (WEdge& e : sw_part) if (e.u > e.v) std::swap(e.u, e.v);
+        std::sort(sw_part.begin(), sw_part.end(), [](const WEdge& a, const WEdge& b) { return a.u != b.u ? a.u < b.u : a.v < b.v; });
+        size_t m = 0;
+        for (size_t k = 0; k < sw_part.size(); ++k) { if (m > 0 && sw_part[m - 1].u == sw_part[k].u && sw_part[m - 1].v == sw_part[k].v) sw_part[m - 1].w += sw_part[k].w; else sw_part[m++] = sw_part[k]; }
+        sw_part.resize(m);
+        cur = rel_part;
+        for (const WEdge& e : sw_part) { const double w = e.w - loop_discount; if (w > 1e-8) cur.push_back({e.u, e.v, w}); }
+    }
     // pass 1: aggregate level by level in provisional numbering; par[l] maps level l+1 (index l) to the level above
     std::vector<std::vector<int32_t>> par;
     std::vector<int32_t> n_of{n1};

@@ -396,8 +396,12 @@ __global__ __launch_bounds__(256) void mg_psTw_kernel(MgLevelDev A, MgLevelDev B
     for (int64_t e = A.psT_ptr[a]; e < A.psT_ptr[a + 1]; ++e) {
         const int64_t ent = A.psT_ent[e];
         const int i = (int)(ent >> 32); const int64_t ps = ent & 0xffffffffll;
-        int ws = -1;
-        for (int sl = A.w_rowptr[i]; sl < A.w_rowptr[i + 1]; ++sl) if (A.w_col[sl] == b) { ws = sl; break; }
+        int ws = -1;       // the block (i, b) of W: row i is searched by the whole wavefront, 64 entries per step
+        for (int base = A.w_rowptr[i], end = A.w_rowptr[i + 1]; base < end && ws < 0; base += 64) {
+            const int sl = base + lane;
+            const unsigned long long hit = __ballot(sl < end && A.w_col[sl] == b);
+            if (hit) ws = base + __ffsll((long long)hit) - 1;
+        }
         if (ws < 0) continue;
         if (own) { pa[wv][lane] = A.ps_val[(size_t)ps * 36 + lane]; wb[wv][lane] = A.w_val[(size_t)ws * 36 + lane]; }
         __builtin_amdgcn_wave_barrier();
@@ -466,19 +470,19 @@ __global__ void mg_power_init_kernel(double* __restrict__ v, int n6) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n6) v[i] = 1.0 + 0.5 * sin(0.7 * (double)i);          // fixed, not orthogonal to anything in particular
 }
-// one workgroup: lam = ||w|| / ||v_prev|| with v_prev normalised (first call: by its own norm, passed as w = v), v <- w / ||w||
-__global__ __launch_bounds__(1024) void mg_power_norm_kernel(const double* __restrict__ w, double* __restrict__ v, int n6, double* __restrict__ lam) {
-    __shared__ double red[16];
-    double s = 0.0;
-    for (int i = threadIdx.x; i < n6; i += blockDim.x) s += w[i] * w[i];
-    s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+// one workgroup: lam = ||b|| / ||a||  (b = D^-1 A a after several un-normalised steps: lambda_max^8 ~ 10^3, far from overflow)
+__global__ __launch_bounds__(1024) void mg_power_ratio_kernel(const double* __restrict__ a, const double* __restrict__ b, int n6, double* __restrict__ lam) {
+    __shared__ double red[32];
+    double sa = 0.0, sb = 0.0;
+    for (int i = threadIdx.x; i < n6; i += blockDim.x) { sa += a[i] * a[i]; sb += b[i] * b[i]; }
+    sa = wave_sum(sa); sb = wave_sum(sb);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = sa; red[16 + (threadIdx.x >> 6)] = sb; }
     __syncthreads();
-    double tot = 0.0;
-    for (int k = 0; k < 16; ++k) tot += red[k];
-    const double nrm = sqrt(tot), inv = nrm > 0.0 ? 1.0 / nrm : 0.0;
-    for (int i = threadIdx.x; i < n6; i += blockDim.x) v[i] = w[i] * inv;
-    if (threadIdx.x == 0) *lam = nrm;
+    if (threadIdx.x == 0) {
+        double ta = 0.0, tb = 0.0;
+        for (int k = 0; k < 16; ++k) { ta += red[k]; tb += red[16 + k]; }
+        *lam = ta > 0.0 ? sqrt(tb / ta) : 0.0;
+    }
 }
 __global__ __launch_bounds__(256) void mg_rescale_dinv_kernel(MgLevelDev A, const double* __restrict__ lam, double omega, double limit, double target) {
     const double wl = omega * lam[0];
@@ -490,13 +494,13 @@ __global__ __launch_bounds__(256) void mg_rescale_dinv_kernel(MgLevelDev A, cons
 static void mg_limit_smoother(const MgLevelDev& A, double omega, hipStream_t st) {
     const int n6 = A.n * 6;
     double* v = A.x; double* w = A.xt; double* lam = A.xf;              // the level's cycle vectors are free during the set-up
-    hipLaunchKernelGGL(mg_power_init_kernel, dim3((unsigned)((n6 + 255) / 256)), dim3(256), 0, st, w, n6);
-    hipLaunchKernelGGL(mg_power_norm_kernel, dim3(1), dim3(1024), 0, st, (const double*)w, v, n6, lam);
-    for (int it = 0; it < 10; ++it) {
+    hipLaunchKernelGGL(mg_power_init_kernel, dim3((unsigned)((n6 + 255) / 256)), dim3(256), 0, st, v, n6);
+    for (int it = 0; it < 8; ++it) {
         // w = D^-1 A v  =  (-1 / omega) (omega D^-1) (0 - A v)
         hipLaunchKernelGGL(mg_smooth_step_kernel, dim3((unsigned)A.tiles), dim3(CG_BLOCK), 0, st, A, (const double*)nullptr, (const double*)v, (double*)nullptr, (const double*)nullptr, (const double*)nullptr, w, -1.0 / omega, (const int32_t*)nullptr);
-        hipLaunchKernelGGL(mg_power_norm_kernel, dim3(1), dim3(1024), 0, st, (const double*)w, v, n6, lam);
+        double* tmp = v; v = w; w = tmp;
     }
+    hipLaunchKernelGGL(mg_power_ratio_kernel, dim3(1), dim3(1024), 0, st, (const double*)w, (const double*)v, n6, lam);      // (v: 8 steps, w: 7 steps)
     hipLaunchKernelGGL(mg_rescale_dinv_kernel, dim3((unsigned)(((int64_t)A.n * 36 + 255) / 256)), dim3(256), 0, st, A, (const double*)lam, omega, 1.75, 1.5);
 }
 

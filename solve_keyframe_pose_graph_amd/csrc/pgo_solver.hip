@@ -529,8 +529,12 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
     if (p->opt.mg_min_keyframes > 0 && Ng >= p->opt.mg_min_keyframes) {      // (the caller's keyframe count decides: the same answer on every rank)
         pgo_mg::Hierarchy H;
         const int dense_max = std::max(1, std::min(p->opt.mg_dense_max_nodes, 512));
-        const int passes0 = std::max(1, std::min(p->opt.mg_first_passes, 3)), passes = std::max(1, std::min(p->opt.mg_passes, 3));
-        const int n_smoothed = std::max(0, std::min(p->opt.mg_smoothed_levels, MG_MAX_LEVELS));
+        // smoothed prolongators (denser coarse operators, two more row products per cycle on each such level) pay while the coarse levels are latency-bound: measured
+        // C4 (200k keyframes) 3.56 -> 2.37 s, C5 (1M keyframes, level 1 = 125k nodes: bandwidth-bound) 8.5 -> 11.1 s.  -1 = by size; with them aggregates of 4 above level 1, else of 8
+        static const double loop_discount_env = []() { const char* e = std::getenv("PGO_MG_LOOP_DISCOUNT"); return e ? std::atof(e) : -1.0; }();
+        const double loop_discount = loop_discount_env >= 0.0 ? loop_discount_env : std::max(0.0, p->opt.mg_loop_discount);
+        const int n_smoothed = p->opt.mg_smoothed_levels < 0 ? (Ng <= 500000 ? 1 : 0) : std::min(p->opt.mg_smoothed_levels, MG_MAX_LEVELS);
+        const int passes0 = std::max(1, std::min(p->opt.mg_first_passes, 3)), passes = p->opt.mg_passes <= 0 ? (n_smoothed > 0 ? 2 : 3) : std::min(p->opt.mg_passes, 3);
         std::vector<double> sw_w;
         if (sw_now && S > 0) { sw_w.resize((size_t)Es); for (int64_t e = 0; e < Es; ++e) { const double sv = sw_now[p->swe.sw[e]]; sw_w[e] = sv * sv; } }
         bool ok;
@@ -538,7 +542,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
         std::vector<double> inv_cnt;
         if (!p->local_ids) {
             ok = pgo_mg::build_hierarchy(N, p->h_node_free, p->rel.c1, p->rel.c2, p->rel.meas.data() + 7, 8, p->swe.c1, p->swe.c2, sw_w.empty() ? nullptr : sw_w.data(), passes0, passes, dense_max, MG_TILE_ROWS,
-                                         MG_MAX_LEVELS, H, false, MG_BLOCK0, nullptr, n_smoothed);
+                                         MG_MAX_LEVELS, H, false, MG_BLOCK0, nullptr, n_smoothed, loop_discount);
         } else {
             // Several ranks: every rank gathers the endpoints and weights of ALL edges (one all-reduce of a zero-padded buffer: 24 B per edge, once per graph build)
             // and builds the same hierarchy from the global graph; its own edges and owned keyframes are what it contributes to level 1 (pgo_mg_host.hpp).
@@ -560,7 +564,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
             for (int64_t g = 0; g < Ng; ++g) gfree[g] = p->h_touched_any[g];
             for (int32_t c : p->constant_nodes) if (c >= 0 && c < Ng) gfree[c] = 0;
             const pgo_mg::LocalContrib local{&p->l2g, &p->h_own, &p->rel.c1, &p->rel.c2, &p->swe.c1, &p->swe.c2};
-            ok = pgo_mg::build_hierarchy(Ng, gfree, grc1, grc2, grw.data(), 1, gsc1, gsc2, (sw_now && S > 0) ? gsw.data() : nullptr, passes0, passes, dense_max, MG_TILE_ROWS, MG_MAX_LEVELS, H, false, 0, &local, n_smoothed);
+            ok = pgo_mg::build_hierarchy(Ng, gfree, grc1, grc2, grw.data(), 1, gsc1, gsc2, (sw_now && S > 0) ? gsw.data() : nullptr, passes0, passes, dense_max, MG_TILE_ROWS, MG_MAX_LEVELS, H, false, 0, &local, n_smoothed, loop_discount);
             if (ok) {
                 const int32_t n1g = (int32_t)H.mem0_ptr.size() - 1;
                 inv_cnt.resize((size_t)n1g);
@@ -1215,10 +1219,12 @@ int build_system(pgo_problem* p, bool* ok) {
         // iterations into a system that needs 520 throws the work away); no prediction (first step, after a rejected one) -> block-Jacobi with
         // the switch at mg_switch_iterations.  Depends on this solve's own history only.
         double predicted = 0.0;
+        static const double start_factor = []() { const char* e = std::getenv("PGO_MG_START_FACTOR"); return e ? std::atof(e) : 2.25; }();
+        static const double wait_factor = []() { const char* e = std::getenv("PGO_MG_WAIT_FACTOR"); return e ? std::atof(e) : 2.0; }();
         if (p->cg_prev_radius > 0.0 && p->radius > 0.0) predicted = p->cg_prev_equiv * std::sqrt(p->radius / p->cg_prev_radius);
         p->mg_switch_at = p->opt.mg_switch_iterations;
-        if (predicted > 0.0 && predicted < 2.25 * (double)p->opt.mg_switch_iterations) p->mg_switch_at = std::max(p->opt.mg_switch_iterations, (int)(2.0 * predicted));
-        if ((p->opt.mg_switch_iterations <= 0 || predicted >= 2.25 * (double)p->opt.mg_switch_iterations) && (rc = build_mg(p)) != PGO_OK) return rc;
+        if (predicted > 0.0 && predicted < start_factor * (double)p->opt.mg_switch_iterations) p->mg_switch_at = std::max(p->opt.mg_switch_iterations, (int)(wait_factor * predicted));
+        if ((p->opt.mg_switch_iterations <= 0 || predicted >= start_factor * (double)p->opt.mg_switch_iterations) && (rc = build_mg(p)) != PGO_OK) return rc;
     }
     else if (*ok && (rc = build_coarse(p)) != PGO_OK) return rc;
     return PGO_OK;
@@ -1375,7 +1381,11 @@ int lm_step(pgo_problem* p, int ignore_termination, int* done) {
         p->have_prev_step = !cg.breakdown;
         if (cg.breakdown) ok = false;
         // block-Jacobi-equivalent work of this system, for the next system's choice of preconditioner (build_system)
-        if (!evaluated && !cg.breakdown) { p->cg_prev_equiv = (double)p->cg_extra + (p->mg_active ? 4.0 : 1.0) * (double)cg.iterations; p->cg_prev_radius = p->radius; }
+        if (!evaluated && !cg.breakdown) {
+            static const double equiv_env = []() { const char* e = std::getenv("PGO_MG_EQUIV"); return e ? std::atof(e) : 0.0; }();
+            const double equiv = equiv_env > 0.0 ? equiv_env : (p->mg_levels[0].smoothed ? 8.0 : 4.0);     // block-Jacobi iterations one multigrid iteration stands for on a hard system
+            p->cg_prev_equiv = (double)p->cg_extra + (p->mg_active ? equiv : 1.0) * (double)cg.iterations; p->cg_prev_radius = p->radius;
+        }
     }
     it.cg_iterations = cg.iterations + p->cg_extra; it.cg_residual = cg.rel_residual;
     p->sum.cg_iterations += cg.iterations + p->cg_extra;
@@ -1551,11 +1561,12 @@ void pgo_options_init(pgo_options* o) {
     o->mg_omega = 0.9;
     o->mg_correction_scale = 1.0;
     o->mg_first_passes = 3;
-    o->mg_passes = 3;
+    o->mg_passes = 0;
     o->mg_dense_max_nodes = 512;
     o->mg_switch_iterations = 400;
+    o->mg_loop_discount = 3.0;
     o->mg_prolongation_damping = 0.6;
-    o->mg_smoothed_levels = 1;
+    o->mg_smoothed_levels = -1;
     o->cg_rel_tolerance = 1e-9;     // loosest decade that keeps the 10-iteration chi^2 of C3 within 1e-8 of the 1e-13 solve
     o->device_id = -1;
     o->verbosity = 0;
@@ -1614,7 +1625,7 @@ int pgo_set_options(pgo_problem* p, const pgo_options* o) {
     if (o->linear_solver != p->opt.linear_solver) p->graph_dirty = true;
     // the preconditioner hierarchies are part of the device graph build
     if (o->mg_min_keyframes != p->opt.mg_min_keyframes || o->mg_first_passes != p->opt.mg_first_passes || o->mg_passes != p->opt.mg_passes ||
-        o->mg_dense_max_nodes != p->opt.mg_dense_max_nodes || o->coarse_aggregates != p->opt.coarse_aggregates || o->mg_smoothed_levels != p->opt.mg_smoothed_levels) p->graph_dirty = true;
+        o->mg_dense_max_nodes != p->opt.mg_dense_max_nodes || o->coarse_aggregates != p->opt.coarse_aggregates || o->mg_smoothed_levels != p->opt.mg_smoothed_levels || o->mg_loop_discount != p->opt.mg_loop_discount) p->graph_dirty = true;
     p->opt = *o;
     p->opt.device_id = dev;   // the device binding is fixed at create
     return PGO_OK;
