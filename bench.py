@@ -268,9 +268,12 @@ def main():
     # ---- roofline of the dominant data-parallel kernel (K1), measured live with HIP events on the library stream
     k1_ms, k1_bytes = P.time_kernel(0, 50)
     k2_ms, k2_bytes = P.time_kernel(1, 20)
-    cg_ms, cg_bytes = P.time_kernel(2, 50)
-    mv_ms, mv_bytes = P.time_kernel(4, 50)
-    up_ms, up_bytes = P.time_kernel(5, 50)
+    if world == 1:
+        cg_ms, cg_bytes = P.time_kernel(2, 50)
+        mv_ms, mv_bytes = P.time_kernel(4, 50)
+        up_ms, up_bytes = P.time_kernel(5, 50)
+    else:      # (the single-GPU form of the PCG iteration is not what several ranks run: no such figure for them)
+        cg_ms = cg_bytes = mv_ms = mv_bytes = up_ms = up_bytes = None
     k1c_ms, k1c_bytes = P.time_kernel(3, 50)
     mg_ms = mg_bytes = mgc_ms = mgc_bytes = None
     try:      # one multigrid-preconditioned PCG iteration on the current LM system (graphs with a hierarchy: >= mg_min_keyframes keyframes, one GPU)
@@ -328,23 +331,30 @@ def main():
             except Exception:
                 pass
 
-    traffic = None
-    try:
-        if not (scale == 1 and args.poses_per_gpu == C3_POSES):
-            raise KeyError("the PMC passes were taken on C3 x 1 only")   # HBM bytes per K1 launch from the rocprofv3 PMC passes (profiles/k1_pmc_rNN.json, written by scripts/profile_k1.sh)
-        with open(os.path.join(ROOT, "profiles", "k1_pmc_latest.json")) as f:
-            traffic = json.load(f).get("hbm_bytes_per_launch")
-    except Exception:
-        pass
+    # Static PMC traffic figures (rocprofv3 --pmc passes cannot run inside this process: scripts/profile_r03_final.sh -> profiles/*_pmc_latest.json) are reported only
+    # when they were measured on THIS build: every file carries the sha256 of the libpgo.so it profiled.
+    import hashlib
+    from solve_keyframe_pose_graph_amd import _build as _b
+    with open(os.environ.get("PGO_LIBPGO_OVERRIDE") or _b.LIBPGO, "rb") as f:
+        lib_sha = hashlib.sha256(f.read()).hexdigest()
+    traffic_note = {}
 
-    pcg_traffic = None
-    try:
-        if scale == 1 and args.poses_per_gpu == C3_POSES:
-            with open(os.path.join(ROOT, "profiles", "pcg_pmc_latest.json")) as f:
+    def static_traffic(name, getter):
+        if not (scale == 1 and args.poses_per_gpu == C3_POSES):
+            return None        # the PMC passes were taken on C3 x 1 only
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
                 pj = json.load(f)
-            pcg_traffic = pj["matvec"]["hbm_bytes_per_launch"] + pj["update"]["hbm_bytes_per_launch"]
-    except Exception:
-        pass
+            if pj.get("libpgo_sha256") != lib_sha:
+                traffic_note[name] = "refused: profiled on libpgo.so %s, this run loaded %s" % (str(pj.get("libpgo_sha256"))[:12], lib_sha[:12])
+                return None
+            return getter(pj)
+        except Exception as e:
+            traffic_note[name] = "unavailable: %r" % (e,)
+            return None
+    traffic = static_traffic("k1_pmc_latest.json", lambda pj: pj["hbm_bytes_per_launch"])
+    pcg_traffic = static_traffic("pcg_pmc_latest.json", lambda pj: pj["matvec"]["hbm_bytes_per_launch"] + pj["update"]["hbm_bytes_per_launch"])
+    mg_traffic = static_traffic("mg_pmc_latest.json", lambda pj: pj["hbm_bytes_per_iteration"])
     out = None
     if rank == 0:
         ips = args.steps / elapsed
@@ -359,11 +369,12 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "C3 x %d: synthetic 3D Manhattan graph, %d poses / %d edges (%d odometry f=1,2 + %d switchable loop closures, 10%% outliers) + %d regulariser(s)"
                                    % (scale, g.n_poses, n_edges, g.n_odom, g.n_loops, len(g.reg_node)),
-                       "poses": g.n_poses, "edges": n_edges, "sharding": ("edges by the '%s' policy (sharding.py): %d..%d edges and %d..%d keyframes per rank, %d of %d keyframes shared between ranks; one %s all-reduce of 6 x shared + 2 doubles per CG iteration"
+                       "poses": g.n_poses, "edges": n_edges, "sharding": ("edges by the '%s' policy (sharding.py): %d..%d edges and %d..%d keyframes per rank, %d of %d keyframes shared between ranks; one %s all-reduce of 6 x shared + 2 doubles per CG iteration (+ the multigrid's level-1 vector, 6 x level-1 nodes, in the same all-reduce; coarse levels replicated)"
                                                                        % (args.partition, min(shard_stats["edges_per_rank"]), max(shard_stats["edges_per_rank"]), min(shard_stats["keyframes_per_rank"]), max(shard_stats["keyframes_per_rank"]),
                                                                           shard_stats["shared_keyframes"], g.n_poses, args.collective)) if world > 1 else "single GPU",
-                       "linear_solver": "PCG, 6x6 block-Jacobi, Schur-reduced pose system, %s matvec" % ("matrix-free" if P_linear_solver == 1 else "block-CSR"), "cg_rel_tolerance": P_cg_tol,
+                       "linear_solver": "PCG on the Schur-reduced pose system, %s matvec; 6x6 block-Jacobi, hard LM systems by the aggregation multigrid (hybrid start)" % ("matrix-free" if P_linear_solver == 1 else "block-CSR"), "cg_rel_tolerance": P_cg_tol,
                        "cg_max_iterations": P_cg_max},
+            "libpgo_sha256": lib_sha, "static_traffic_notes": traffic_note or None,
             "lm_iters_per_s_raw": ips,
             "lm_iters_per_s_including_transfers": args.steps / elapsed_incl * scale,   # upload of the state, K iterations, write-back (rank 0's clock)
             "chi2_initial": 2.0 * summ.initial_cost, "chi2_final": 2.0 * summ.final_cost,
@@ -378,7 +389,7 @@ def main():
                          "note": "frac is the C3 figure (the benchmark workload); its 194 MB output fits the 256 MiB Infinity Cache — roofline_k1_out_of_cache is the HBM-only figure"},
             "roofline_k1_out_of_cache": k1_big,
             # where the solve spends its time: one block-Jacobi PCG iteration = matvec + vector update, bytes = what this design moves per iteration
-            "roofline_pcg": {"bound": "hbm", "kernel": "%s + cg_update_kernel (one PCG iteration)" % ("mf_spmv_kernel<true>" if P_linear_solver == 1 else "cg_spmv_kernel"),
+            "roofline_pcg": None if cg_ms is None else {"bound": "hbm", "kernel": "%s + cg_update_kernel (one PCG iteration)" % ("mf_spmv_kernel<true>" if P_linear_solver == 1 else "cg_spmv_kernel"),
                              "achieved": cg_bytes / (cg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cg_bytes / (cg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                              "algorithmic_bytes_per_iteration": cg_bytes, "avg_iteration_ms": cg_ms, "traffic": pcg_traffic,
                              "traffic_source": "static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the two kernels on C3 (profiles/pcg_pmc_latest.json), not measured in this run",
@@ -389,11 +400,12 @@ def main():
             "roofline_mg": None if mg_ms is None else {
                 "bound": "hbm", "kernel": "mf_spmv_kernel<true> + cg_update_mg_kernel + mg_down / mg_dense_solve / mg_up kernels (one multigrid-preconditioned PCG iteration)",
                 "achieved": mg_bytes / (mg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": mg_bytes / (mg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "algorithmic_bytes_per_iteration": mg_bytes, "avg_iteration_ms": mg_ms, "traffic": None,
+                "algorithmic_bytes_per_iteration": mg_bytes, "avg_iteration_ms": mg_ms, "traffic": mg_traffic,
+                "traffic_source": "static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of every kernel of the iteration on C3 (profiles/mg_pmc_latest.json, same libpgo.so sha256), not measured in this run",
                 "cycle_kernels": {"ms": mgc_ms, "bytes": mgc_bytes, "GBps": mgc_bytes / mgc_ms / 1e6},
                 "iterations_in_timed_region": summ_cg_mg, "share_of_timed_region": summ_cg_mg * mg_ms * 1e-3 / elapsed,
-                "note": "latency-bound: the coarse levels hold 12 %, 2 % and 0.4 % of the keyframes, every level kernel starts on cold L2s (DESIGN.md)"},
-            "other_kernels": {"k2_assembly": {"ms": k2_ms, "GBps": k2_bytes / k2_ms / 1e6}, "pcg_iteration": {"ms": cg_ms, "GBps": cg_bytes / cg_ms / 1e6},
+                "note": "latency-bound: the coarse levels hold 12 %, 4 %, 1 % and 0.4 % of the keyframes, every level kernel starts on cold L2s (DESIGN.md)"},
+            "other_kernels": {"k2_assembly": {"ms": k2_ms, "GBps": k2_bytes / k2_ms / 1e6}, "pcg_iteration": None if cg_ms is None else {"ms": cg_ms, "GBps": cg_bytes / cg_ms / 1e6},
                               "k1_cost_only": {"ms": k1c_ms, "GBps": k1c_bytes / k1c_ms / 1e6}},
         }
         if scale == 1 and not args.no_cpu_baseline:
