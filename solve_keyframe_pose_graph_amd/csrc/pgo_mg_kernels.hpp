@@ -74,24 +74,26 @@ __device__ __forceinline__ double mg_gather_row(const double* __restrict__ xch, 
     return q;
 }
 // valf <- val, EXACTLY symmetric: a block below the diagonal is the transpose of the rounded block above it, a diagonal block takes its upper
-// triangle.  One wavefront per block row, lane l < 36 owns element l of a block (column-pair-major: (row, col) at (row/2)*12 + col*2 + (row&1)).
+// triangle.  One wavefront per BLOCK (the smoothed Galerkin products have ~50 blocks per row: a wavefront per row ran 0.37 ms on C3's level 2); lane l < 36 owns
+// element l of the block (column-pair-major: (row, col) at (row/2)*12 + col*2 + (row&1)).
 __global__ __launch_bounds__(256) void mg_val_f32_kernel(MgLevelDev A) {
-    const int i = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
-    if (i >= A.n || lane >= 36) return;
+    const int64_t k = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (k >= A.nnzb || lane >= 36) return;
+    int lo = 0, hi = A.n;                            // the block's row: rowptr ascending
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (A.rowptr[mid] <= k) lo = mid; else hi = mid; }
+    const int i = lo, j = A.col[k];
     const int pr = lane / 12, rem = lane - pr * 12, col = rem >> 1, row = pr * 2 + (rem & 1);      // element (row, col) of the block
     const int tr = bsr_idx(col, row);                                                               // where (col, row) lives
-    for (int64_t k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k) {
-        const int j = A.col[k];
-        double v;
-        if (j > i) v = A.val[(size_t)k * 36 + lane];
-        else if (j == i) v = row <= col ? A.val[(size_t)k * 36 + lane] : A.val[(size_t)k * 36 + tr];
-        else {      // the transposed block (j, i): row j holds its diagonal block first, the others by ascending column
-            int64_t lo = A.rowptr[j] + 1, hi = A.rowptr[j + 1];
-            while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (A.col[mid] < i) lo = mid + 1; else hi = mid; }
-            v = (lo < A.rowptr[j + 1] && A.col[lo] == i) ? A.val[(size_t)lo * 36 + tr] : A.val[(size_t)k * 36 + lane];
-        }
-        A.valf[(size_t)k * 36 + lane] = (float)v;
+    double v;
+    if (j > i) v = A.val[(size_t)k * 36 + lane];
+    else if (j == i) v = row <= col ? A.val[(size_t)k * 36 + lane] : A.val[(size_t)k * 36 + tr];
+    else {      // the transposed block (j, i): row j holds its diagonal block first, the others by ascending column
+        int64_t l2 = A.rowptr[j] + 1, h2 = A.rowptr[j + 1];
+        while (l2 < h2) { const int64_t mid = (l2 + h2) >> 1; if (A.col[mid] < i) l2 = mid + 1; else h2 = mid; }
+        v = (l2 < A.rowptr[j + 1] && A.col[l2] == i) ? A.val[(size_t)l2 * 36 + tr] : A.val[(size_t)k * 36 + lane];
     }
+    A.valf[(size_t)k * 36 + lane] = (float)v;
 }
 
 // (P_i y)[k]:  dtheta_i = y_theta ; dt_i = y_t - 2 d_i x y_theta
@@ -524,7 +526,7 @@ void launch_mg_assemble_rest(const MgDev& M, const MgLevelDev* levels, const Coa
         }
         if (l + 1 < M.n_levels) {
             hipLaunchKernelGGL(mg_dinv_kernel, dim3((unsigned)((levels[l].n + 255) / 256)), dim3(256), 0, st, levels[l], omega, fail);
-            hipLaunchKernelGGL(mg_val_f32_kernel, dim3((unsigned)((levels[l].n + 3) / 4)), dim3(256), 0, st, levels[l]);
+            hipLaunchKernelGGL(mg_val_f32_kernel, dim3((unsigned)((levels[l].nnzb + 3) / 4)), dim3(256), 0, st, levels[l]);
             mg_limit_smoother(levels[l], omega, st);
         }
     }

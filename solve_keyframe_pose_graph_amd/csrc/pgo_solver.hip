@@ -531,8 +531,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
         const int dense_max = std::max(1, std::min(p->opt.mg_dense_max_nodes, 512));
         // smoothed prolongators (denser coarse operators, two more row products per cycle on each such level) pay while the coarse levels are latency-bound: measured
         // C4 (200k keyframes) 3.56 -> 2.37 s, C5 (1M keyframes, level 1 = 125k nodes: bandwidth-bound) 8.5 -> 11.1 s.  -1 = by size; with them aggregates of 4 above level 1, else of 8
-        static const double loop_discount_env = []() { const char* e = std::getenv("PGO_MG_LOOP_DISCOUNT"); return e ? std::atof(e) : -1.0; }();
-        const double loop_discount = loop_discount_env >= 0.0 ? loop_discount_env : std::max(0.0, p->opt.mg_loop_discount);
+        const double loop_discount = std::max(0.0, p->opt.mg_loop_discount);
         const int n_smoothed = p->opt.mg_smoothed_levels < 0 ? (Ng <= 500000 ? 1 : 0) : std::min(p->opt.mg_smoothed_levels, MG_MAX_LEVELS);
         const int passes0 = std::max(1, std::min(p->opt.mg_first_passes, 3)), passes = p->opt.mg_passes <= 0 ? (n_smoothed > 0 ? 2 : 3) : std::min(p->opt.mg_passes, 3);
         std::vector<double> sw_w;
@@ -1219,8 +1218,8 @@ int build_system(pgo_problem* p, bool* ok) {
         // iterations into a system that needs 520 throws the work away); no prediction (first step, after a rejected one) -> block-Jacobi with
         // the switch at mg_switch_iterations.  Depends on this solve's own history only.
         double predicted = 0.0;
-        static const double start_factor = []() { const char* e = std::getenv("PGO_MG_START_FACTOR"); return e ? std::atof(e) : 2.25; }();
-        static const double wait_factor = []() { const char* e = std::getenv("PGO_MG_WAIT_FACTOR"); return e ? std::atof(e) : 2.0; }();
+        // (round 3, with the smoothed cycle: start factors 1.0 - 2.25, waiting factors 1.5 - 2.0 and switch points 200 - 600 all within +-2 % on C3 and C4)
+        const double start_factor = 2.25, wait_factor = 2.0;
         if (p->cg_prev_radius > 0.0 && p->radius > 0.0) predicted = p->cg_prev_equiv * std::sqrt(p->radius / p->cg_prev_radius);
         p->mg_switch_at = p->opt.mg_switch_iterations;
         if (predicted > 0.0 && predicted < start_factor * (double)p->opt.mg_switch_iterations) p->mg_switch_at = std::max(p->opt.mg_switch_iterations, (int)(wait_factor * predicted));
@@ -1382,8 +1381,7 @@ int lm_step(pgo_problem* p, int ignore_termination, int* done) {
         if (cg.breakdown) ok = false;
         // block-Jacobi-equivalent work of this system, for the next system's choice of preconditioner (build_system)
         if (!evaluated && !cg.breakdown) {
-            static const double equiv_env = []() { const char* e = std::getenv("PGO_MG_EQUIV"); return e ? std::atof(e) : 0.0; }();
-            const double equiv = equiv_env > 0.0 ? equiv_env : (p->mg_levels[0].smoothed ? 8.0 : 4.0);     // block-Jacobi iterations one multigrid iteration stands for on a hard system
+            const double equiv = p->mg_levels[0].smoothed ? 8.0 : 4.0;     // block-Jacobi iterations one multigrid iteration stands for on a hard system
             p->cg_prev_equiv = (double)p->cg_extra + (p->mg_active ? equiv : 1.0) * (double)cg.iterations; p->cg_prev_radius = p->radius;
         }
     }
