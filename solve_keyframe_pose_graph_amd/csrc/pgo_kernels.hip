@@ -130,7 +130,7 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_edges_kernel(EdgeClassDev re
     if (active) {
         const int64_t e = (int64_t)tile * TILE + lane;
         const bool valid = e < C.E;
-        const int32_t c1 = C.c1[e], c2 = C.c2[e];          // padded entries are 0
+        const int32_t c1 = C.c1[e], c2 = C.c2[e];          // (padding lanes replicate the last edge: computed, never stored or counted)
         const Pose P1 = w.y > 0 ? load_pose_lds(win1, c1 - w.x) : load_pose_global(pose8, c1);
         const Pose P2 = w.w > 0 ? load_pose_lds(win2, c2 - w.z) : load_pose_global(pose8, c2);
         const double* mp = C.meas + e;
