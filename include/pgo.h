@@ -149,6 +149,11 @@ typedef struct pgo_options {
                                           *      rigid piece — the hierarchy is built once per graph, before the switches are known; several loop closures between the same two pieces (revisited
                                           *      places) are not all outliers.  Measured, 20 LM steps: C3 (10 % outliers) 0.444 / 0.422 / 0.410 / 0.409 s and C4 2.38 / 1.72 / 1.47 / 1.60 s
                                           *      with 0 / 2 / 3 / 5; a 60k-keyframe graph WITHOUT outliers 0.71 / 0.87 / - / 1.02 s.  Relative-pose loop edges (no switch) are not discounted. */
+    double mg_regroup_fraction;          /* 0.02: REGROUP — when multigrid operators are about to be built (not in the first three LM iterations) and the switchable edges that have moved by > 0.5
+                                          *      in s^2 since the hierarchy was built (outliers switched off) make up more than this fraction of ALL edges, the levels above level 1 are matched
+                                          *      again along the couplings alive now (at most twice per solve; the keyframes' level-1 aggregates follow relative-pose edges only and are kept, as is
+                                          *      level 1's structure: ~25 ms for C3).  0 disables.  Measured on C3: the late LM systems need 155 / 184 / 246 multigrid iterations after the
+                                          *      regroup against 305 / 367 / 454 without: 20 steps 0.406 -> 0.353 s */
     double mg_prolongation_damping;      /* 0.6: w_p of the smoothed prolongators Ps = (I - w_p D^-1 A) P (smoothed aggregation's 4 / (3 rho(D^-1 A)), rho ~ 2; from 0.9 on
                                           *      I - w_p D^-1 A is singular inside the spectrum and the Galerkin product degenerates: measured, scripts/research/r3_cycle_probe.py) */
     int32_t mg_smoothed_levels;          /* -1 = by size: 1 up to 500 000 keyframes, 0 beyond (C5, 1M keyframes: its coarse levels are bandwidth-bound and the denser operators cost more than the

@@ -30,10 +30,11 @@ out += ['## one multigrid-preconditioned PCG iteration (python scripts/gpu_mg_it
 tot = 0.0
 for k in sorted(fetch, key=lambda k: -fetch[k]['mean'] * fetch[k]['launches']):
     if not any(s in k for s in ('mf_spmv_kernel<true, false>', 'cg_update_mg', 'mg_down', 'mg_up', 'mg_dense_solve', 'mg_smooth_step')): continue
-    per_it = fetch[k]['launches'] / its
+    per_it = max(1, round(fetch[k]['launches'] / its))       # (the run's two LM steps and the set-up's power method add a few launches of the matvec and of mg_smooth_step: whole launches per iteration)
+    if 'mf_spmv_kernel' in k: per_it = 1
     b = (2 * fetch[k]['mean'] + write.get(k, {'mean': 0})['mean']) * 1024 * per_it
     tot += b
-    out.append('%-62s %.2f launches / iteration, %6.1f MB / iteration' % (k[:62], per_it, b / 1e6))
+    out.append('%-62s %d launches / iteration, %6.1f MB / iteration' % (k[:62], per_it, b / 1e6))
 out += ['total %.1f MB per iteration' % (tot / 1e6), '']
 open('profiles/r03_pcg_pmc.txt', 'w').write('\n'.join(out))
 corr = 'x2 (gfx950 FETCH_SIZE counts 128-B requests as 64 B for 16-B/lane streams, MI355X_MICROARCH.md)'

@@ -142,6 +142,43 @@ struct LocalContrib {
     const std::vector<int32_t>* sc1; const std::vector<int32_t>* sc2;     // the rank's switchable edges
 };
 
+// What build_hierarchy keeps between two builds of the SAME graph (same keyframes, edges, fixed keyframes, relative-pose weights, options) when only the SWITCH values
+// have changed — a regroup of the levels above level 1 inside a solve (pgo_solver.hip: regroup): the keyframes' level-1 aggregates (matched along relative-pose edges
+// only: they do not depend on the switches), the structure of level 1 in their provisional numbering, and the level-1 couplings with the switchable part kept per pair.
+// With a valid cache a rebuild skips the two expensive sorts (level-0 matching, level-1 block structure) and costs what the small upper levels cost.
+struct BuildCache {
+    bool valid = false;
+    std::vector<int32_t> agg0_prov; int32_t n1 = 0;     // level-1 node of each keyframe, provisional numbering (after the run cuts); -1: outside the system
+    HostLevel L1prov;                                     // rowptr / col / g_ptr / g_ent of level 1 in that numbering
+    std::vector<WEdge> rel1;                              // level-1 couplings through relative-pose edges (collapsed; match_passes merges parallel ones)
+    std::vector<int32_t> sw_u, sw_v;                      // level-1 pairs (u < v) coupled by switchable edges ...
+    std::vector<int64_t> sw_ptr; std::vector<int32_t> sw_edge;   // ... and the switchable edges of each pair
+};
+
+// level 1 in its FINAL numbering from the cached provisional structure: rows permuted, columns relabelled, every row again "diagonal block first, then ascending column",
+// every block with its contribution list as it was (the same lists, in the same order, as a direct build in the final numbering gives)
+inline void permute_level1(const HostLevel& P, int32_t n, const std::vector<int32_t>& newid, HostLevel& out) {
+    std::vector<int32_t> old_of((size_t)n);
+    for (int32_t i = 0; i < n; ++i) old_of[newid[i]] = i;
+    out.rowptr.assign((size_t)n + 1, 0); out.col.resize(P.col.size()); out.g_ptr.assign(P.col.size() + 1, 0); out.g_ent.resize(P.g_ent.size());
+    int64_t kb = 0, ge = 0;
+    std::vector<std::pair<int32_t, int64_t>> row;
+    for (int32_t r = 0; r < n; ++r) {
+        const int32_t o = old_of[r];
+        row.clear();
+        for (int64_t k = P.rowptr[o]; k < P.rowptr[(size_t)o + 1]; ++k) { const int32_t c = newid[P.col[k]]; row.push_back({c == r ? -1 : c, k}); }
+        std::sort(row.begin(), row.end());
+        for (const auto& ck : row) {
+            out.col[(size_t)kb] = ck.first < 0 ? r : ck.first;
+            out.g_ptr[(size_t)kb] = ge;
+            for (int64_t g = P.g_ptr[ck.second]; g < P.g_ptr[(size_t)ck.second + 1]; ++g) out.g_ent[(size_t)ge++] = P.g_ent[g];
+            ++kb;
+        }
+        out.rowptr[(size_t)r + 1] = kb;
+    }
+    out.g_ptr[(size_t)kb] = ge;
+}
+
 // N keyframes, node_free[N]; edge lists of both classes (endpoints in the handle's local numbering — the global one with several ranks —, weights of the
 // relative-pose class at rel_w[rel_w_stride * e]).
 // passes0: matching rounds keyframes -> level 1, passes: for the levels above.  Returns false when the graph does not coarsen down to
@@ -150,76 +187,126 @@ inline bool build_hierarchy(int64_t N, const std::vector<uint8_t>& node_free, co
                             const std::vector<int32_t>& sc1, const std::vector<int32_t>& sc2, const double* sw_weight /* per switchable edge: s^2 of its switch at graph build, or nullptr = 1 */,
                             int passes0, int passes, int dense_max, int tile_rows, int max_levels, Hierarchy& H, bool level0_follows_switchable = true, int level0_block = 0,
                             const LocalContrib* local = nullptr, int smoothed_levels = 0 /* transitions level l -> l+1, l = 1 .. smoothed_levels, use the smoothed prolongator */,
-                            double loop_discount = 0.0 /* loop closures of a pair of level-1 nodes that do not count in the matching above level 1 */) {
+                            double loop_discount = 0.0 /* loop closures of a pair of level-1 nodes that do not count in the matching above level 1 */,
+                            BuildCache* cache = nullptr /* kept by the caller across rebuilds of the same graph with other switch values (level0_follows_switchable must be false) */) {
     H = Hierarchy{};
     const int64_t Er = (int64_t)rc1.size(), Es = (int64_t)sc1.size();
-    std::vector<WEdge> edges;
-    edges.reserve((size_t)(Er + Es));
-    for (int64_t e = 0; e < Er; ++e) if (node_free[rc1[e]] && node_free[rc2[e]]) {
-        const double w = rel_w[(size_t)rel_w_stride * e];
-        if (w * w > 1e-8) edges.push_back({rc1[e], rc2[e], w * w});       // an odometry edge the yaw policy has (all but) switched off ties nothing together
-    }
-    // the switchable functor ignores its edge weight (CeresResidues.h:198) and scales the whole block by its switch: a loop closure the
-    // solver has switched off ties nothing together any more
-    for (int64_t e = 0; e < Es; ++e) if (node_free[sc1[e]] && node_free[sc2[e]]) {
-        const double w = sw_weight ? sw_weight[e] : 1.0;
-        if (w > 1e-8) edges.push_back({sc1[e], sc2[e], w});
-    }
-    std::vector<uint8_t> skip((size_t)N);
-    for (int64_t i = 0; i < N; ++i) skip[i] = node_free[i] ? 0 : 1;
-    int32_t n1 = 0;
-    std::vector<WEdge> rel_only;
-    if (!level0_follows_switchable) {
-        // keyframes are grouped along relative-pose (odometry) edges only: a switchable loop closure may be an outlier the solver is about to
-        // switch off, and an aggregate held together by nothing else would stop being a rigid piece; the levels above match along the summed
-        // couplings of whole groups, where a single dead edge no longer decides anything
-        rel_only.reserve((size_t)Er);
-        for (int64_t e = 0; e < Er; ++e) if (node_free[rc1[e]] && node_free[rc2[e]]) { const double w = rel_w[(size_t)rel_w_stride * e]; if (w * w > 1e-8) rel_only.push_back({rc1[e], rc2[e], w * w}); }
-    }
-    H.agg0 = match_passes((int32_t)N, level0_follows_switchable ? edges : rel_only, passes0, &skip, n1);
-    if (level0_block > 0 && n1 >= 1) {
-        // The PCG's vector-update kernel works on consecutive runs of level0_block keyframes and restricts the new residual to the level-1 aggregates a run
-        // holds COMPLETELY (no restriction kernel of its own: -5 us per iteration).  Regular odometry chains match into such aggregates by themselves; an
-        // aggregate that does straddle a run boundary is cut there (one more, smaller aggregate per boundary at most).  Matching restricted to the runs from the
-        // start was measured instead and dropped: on the 4-world benchmark graph it changed the whole greedy matching and cost 12 % more PCG iterations.
-        std::vector<int64_t> first_run((size_t)n1, -1);
-        std::vector<std::pair<int64_t, int32_t>> extra;       // (aggregate * runs + run) -> new id, for the parts beyond an aggregate's first run
-        const int64_t runs = (N + level0_block - 1) / level0_block;
-        std::vector<std::pair<int64_t, int64_t>> parts;       // (aggregate * runs + run, keyframe) of keyframes outside their aggregate's first run
-        for (int64_t i = 0; i < N; ++i) if (H.agg0[i] >= 0) {
-            const int64_t r = i / level0_block; const int32_t a = H.agg0[i];
-            if (first_run[a] < 0) first_run[a] = r;
-            else if (first_run[a] != r) parts.push_back({(int64_t)a * runs + r, i});
-        }
-        std::sort(parts.begin(), parts.end());
-        int64_t prev = -1;
-        for (const auto& pr : parts) { if (pr.first != prev) { prev = pr.first; ++n1; } H.agg0[pr.second] = n1 - 1; }
-    }
-    if (n1 < 1) return false;
-    // level-1 edge list
+    BuildCache own_cache;
+    BuildCache& Cc = (cache && !level0_follows_switchable) ? *cache : own_cache;
     auto collapse = [](const std::vector<WEdge>& in, const std::vector<int32_t>& par) {
         std::vector<WEdge> out;
         out.reserve(in.size());
         for (const WEdge& e : in) { const int32_t u = par[e.u], v = par[e.v]; if (u >= 0 && v >= 0 && u != v) out.push_back({u, v, e.w}); }
         return out;
     };
-    std::vector<WEdge> cur = collapse(edges, H.agg0);
-    if (loop_discount > 0.0 && Es > 0) {
-        // A single loop closure between two level-1 nodes may be an outlier that the solver switches off a few LM steps later; an aggregate of the levels above held
-        // together by nothing else then stops being a rigid piece (the hierarchy is built once per graph, before the switches are known).  Two or more loop closures
-        // between the same two nodes — revisited places: parallel passes — are not all outliers: the matching above level 1 counts the loop closures of a pair minus one.
-        std::vector<WEdge> rel_part, sw_part;
-        { std::vector<WEdge> re, se;
-          for (int64_t e = 0; e < Er; ++e) if (node_free[rc1[e]] && node_free[rc2[e]]) { const double w = rel_w[(size_t)rel_w_stride * e]; if (w * w > 1e-8) re.push_back({rc1[e], rc2[e], w * w}); }
-          for (int64_t e = 0; e < Es; ++e) if (node_free[sc1[e]] && node_free[sc2[e]]) { const double w = sw_weight ? sw_weight[e] : 1.0; if (w > 1e-8) se.push_back({sc1[e], sc2[e], w}); }
-          rel_part = collapse(re, H.agg0); sw_part = collapse(se, H.agg0); }
-        for (WEdge& e : sw_part) if (e.u > e.v) std::swap(e.u, e.v);
-        std::sort(sw_part.begin(), sw_part.end(), [](const WEdge& a, const WEdge& b) { return a.u != b.u ? a.u < b.u : a.v < b.v; });
-        size_t m = 0;
-        for (size_t k = 0; k < sw_part.size(); ++k) { if (m > 0 && sw_part[m - 1].u == sw_part[k].u && sw_part[m - 1].v == sw_part[k].v) sw_part[m - 1].w += sw_part[k].w; else sw_part[m++] = sw_part[k]; }
-        sw_part.resize(m);
-        cur = rel_part;
-        for (const WEdge& e : sw_part) { const double w = e.w - loop_discount; if (w > 1e-8) cur.push_back({e.u, e.v, w}); }
+    if (!Cc.valid) {
+        std::vector<WEdge> rel_edges;
+        rel_edges.reserve((size_t)Er);
+        for (int64_t e = 0; e < Er; ++e) if (node_free[rc1[e]] && node_free[rc2[e]]) {
+            const double w = rel_w[(size_t)rel_w_stride * e];
+            if (w * w > 1e-8) rel_edges.push_back({rc1[e], rc2[e], w * w});       // an odometry edge the yaw policy has (all but) switched off ties nothing together
+        }
+        std::vector<uint8_t> skip((size_t)N);
+        for (int64_t i = 0; i < N; ++i) skip[i] = node_free[i] ? 0 : 1;
+        int32_t n1 = 0;
+        if (level0_follows_switchable) {
+            // (research setting: keyframes matched across loop closures too — measured 2-3x the iterations once outliers are switched off; not cached)
+            std::vector<WEdge> edges = rel_edges;
+            for (int64_t e = 0; e < Es; ++e) if (node_free[sc1[e]] && node_free[sc2[e]]) { const double w = sw_weight ? sw_weight[e] : 1.0; if (w > 1e-8) edges.push_back({sc1[e], sc2[e], w}); }
+            Cc.agg0_prov = match_passes((int32_t)N, edges, passes0, &skip, n1);
+        } else {
+            // keyframes are grouped along relative-pose (odometry) edges only: a switchable loop closure may be an outlier the solver is about to
+            // switch off, and an aggregate held together by nothing else would stop being a rigid piece; the levels above match along the summed
+            // couplings of whole groups, where a single dead edge no longer decides anything
+            Cc.agg0_prov = match_passes((int32_t)N, rel_edges, passes0, &skip, n1);
+        }
+        if (level0_block > 0 && n1 >= 1) {
+            // The PCG's vector-update kernel works on consecutive runs of level0_block keyframes and restricts the new residual to the level-1 aggregates a run
+            // holds COMPLETELY (no restriction kernel of its own: -5 us per iteration).  Regular odometry chains match into such aggregates by themselves; an
+            // aggregate that does straddle a run boundary is cut there (one more, smaller aggregate per boundary at most).  Matching restricted to the runs from the
+            // start was measured instead and dropped: on the 4-world benchmark graph it changed the whole greedy matching and cost 12 % more PCG iterations.
+            std::vector<int64_t> first_run((size_t)n1, -1);
+            const int64_t runs = (N + level0_block - 1) / level0_block;
+            std::vector<std::pair<int64_t, int64_t>> parts;       // (aggregate * runs + run, keyframe) of keyframes outside their aggregate's first run
+            for (int64_t i = 0; i < N; ++i) if (Cc.agg0_prov[i] >= 0) {
+                const int64_t r = i / level0_block; const int32_t a = Cc.agg0_prov[i];
+                if (first_run[a] < 0) first_run[a] = r;
+                else if (first_run[a] != r) parts.push_back({(int64_t)a * runs + r, i});
+            }
+            std::sort(parts.begin(), parts.end());
+            int64_t prev = -1;
+            for (const auto& pr : parts) { if (pr.first != prev) { prev = pr.first; ++n1; } Cc.agg0_prov[pr.second] = n1 - 1; }
+        }
+        Cc.n1 = n1;
+        if (n1 < 1) return false;
+        // level-1 couplings: the relative-pose part as collapsed edges, the switchable part per pair of level-1 nodes with the list of its edges (their weights change)
+        Cc.rel1 = collapse(rel_edges, Cc.agg0_prov);
+        {   // parallel couplings merged once (match_passes would sort all of them again at every rebuild)
+            for (WEdge& e : Cc.rel1) if (e.u > e.v) std::swap(e.u, e.v);
+            std::sort(Cc.rel1.begin(), Cc.rel1.end(), [](const WEdge& a, const WEdge& b) { return a.u != b.u ? a.u < b.u : a.v < b.v; });
+            size_t m = 0;
+            for (size_t k = 0; k < Cc.rel1.size(); ++k) { if (m > 0 && Cc.rel1[m - 1].u == Cc.rel1[k].u && Cc.rel1[m - 1].v == Cc.rel1[k].v) Cc.rel1[m - 1].w += Cc.rel1[k].w; else Cc.rel1[m++] = Cc.rel1[k]; }
+            Cc.rel1.resize(m);
+        }
+        {
+            std::vector<std::pair<int64_t, int32_t>> pe;      // (u * n1 + v, edge), u < v
+            pe.reserve((size_t)Es);
+            for (int64_t e = 0; e < Es; ++e) if (node_free[sc1[e]] && node_free[sc2[e]]) {
+                int32_t u = Cc.agg0_prov[sc1[e]], v = Cc.agg0_prov[sc2[e]];
+                if (u < 0 || v < 0 || u == v) continue;
+                if (u > v) std::swap(u, v);
+                pe.push_back({(int64_t)u * n1 + v, (int32_t)e});
+            }
+            std::sort(pe.begin(), pe.end());
+            Cc.sw_u.clear(); Cc.sw_v.clear(); Cc.sw_ptr.clear(); Cc.sw_edge.clear();
+            int64_t prev = -1;
+            for (const auto& x : pe) {
+                if (x.first != prev) { Cc.sw_u.push_back((int32_t)(x.first / n1)); Cc.sw_v.push_back((int32_t)(x.first % n1)); Cc.sw_ptr.push_back((int64_t)Cc.sw_edge.size()); prev = x.first; }
+                Cc.sw_edge.push_back(x.second);
+            }
+            Cc.sw_ptr.push_back((int64_t)Cc.sw_edge.size());
+        }
+        // block structure and Galerkin contribution lists of level 1, in the provisional numbering
+        {
+            const std::vector<int32_t>& A0 = Cc.agg0_prov;
+            std::vector<std::pair<int64_t, int64_t>> trip;
+            trip.reserve((size_t)N + 2 * (size_t)(Er + Es));
+            // (entry -1: the block exists — its structure is the global one on every rank — but the contribution is another rank's)
+            for (int64_t i = 0; i < N; ++i) if (A0[i] >= 0) trip.push_back({(int64_t)A0[i] * n1 + A0[i], local ? (int64_t)-1 : ((i << 3) | 0)});
+            auto edge = [&](int64_t e, int32_t c1, int32_t c2, int kind_fwd) {
+                const int32_t a = A0[c1], b = A0[c2];
+                if (a < 0 || b < 0) return;                     // rows and columns of fixed keyframes are not part of the system
+                trip.push_back({(int64_t)a * n1 + b, e < 0 ? (int64_t)-1 : ((e << 3) | kind_fwd)});
+                trip.push_back({(int64_t)b * n1 + a, e < 0 ? (int64_t)-1 : ((e << 3) | (kind_fwd + 1))});
+            };
+            for (int64_t e = 0; e < Er; ++e) edge(local ? -1 : e, rc1[e], rc2[e], 1);
+            for (int64_t e = 0; e < Es; ++e) edge(local ? -1 : e, sc1[e], sc2[e], 3);
+            if (local) {
+                const int64_t Nl = (int64_t)local->l2g->size();
+                for (int64_t l = 0; l < Nl; ++l) { const int32_t a = A0[(*local->l2g)[l]]; if (a >= 0 && (*local->own)[l] != 0.0) trip.push_back({(int64_t)a * n1 + a, (l << 3) | 0}); }
+                for (int64_t e = 0; e < (int64_t)local->rc1->size(); ++e) edge(e, (*local->rc1)[e], (*local->rc2)[e], 1);
+                for (int64_t e = 0; e < (int64_t)local->sc1->size(); ++e) edge(e, (*local->sc1)[e], (*local->sc2)[e], 3);
+            }
+            Cc.L1prov = HostLevel{};
+            build_blocks(n1, trip, Cc.L1prov);
+            Cc.L1prov.n = n1;
+        }
+        Cc.valid = true;
+    }
+    const int32_t n1 = Cc.n1;
+    if (n1 < 1) return false;
+    // level-1 edge list with the CURRENT switch weights.  The switchable functor ignores its edge weight (CeresResidues.h:198) and scales the whole block by its switch:
+    // a loop closure the solver has switched off ties nothing together any more.
+    // A single loop closure between two level-1 nodes may be an outlier that the solver switches off a few LM steps later; an aggregate of the levels above held
+    // together by nothing else then stops being a rigid piece (the hierarchy is built before the switches are known, and regrouped at most a few times per solve).  Two or
+    // more loop closures between the same two nodes — revisited places: parallel passes — are not all outliers: the matching above level 1 counts a pair's loop closures
+    // minus `loop_discount`.
+    std::vector<WEdge> cur = Cc.rel1;
+    for (size_t pi = 0; pi < Cc.sw_u.size(); ++pi) {
+        double w = 0.0;
+        for (int64_t k = Cc.sw_ptr[pi]; k < Cc.sw_ptr[pi + 1]; ++k) { const double we = sw_weight ? sw_weight[Cc.sw_edge[(size_t)k]] : 1.0; if (we > 1e-8) w += we; }
+        w -= loop_discount;
+        if (w > 1e-8) cur.push_back({Cc.sw_u[pi], Cc.sw_v[pi], w});
     }
     // pass 1: aggregate level by level in provisional numbering; par[l] maps level l+1 (index l) to the level above
     std::vector<std::vector<int32_t>> par;
@@ -259,6 +346,7 @@ inline bool build_hierarchy(int64_t N, const std::vector<uint8_t>& node_free, co
         }
         newid_above.swap(newid);
     }
+    H.agg0 = Cc.agg0_prov;
     for (int32_t& a : H.agg0) if (a >= 0) a = newid_above[a];
     // level-1 membership lists (after the renumbering of level 1)
     H.mem0_ptr.assign((size_t)n1 + 1, 0);
@@ -267,28 +355,8 @@ inline bool build_hierarchy(int64_t N, const std::vector<uint8_t>& node_free, co
     H.mem0.resize((size_t)H.mem0_ptr[n1]);
     { std::vector<int32_t> fill(H.mem0_ptr.begin(), H.mem0_ptr.end() - 1);
       for (int64_t i = 0; i < N; ++i) if (H.agg0[i] >= 0) H.mem0[(size_t)fill[H.agg0[i]]++] = (int32_t)i; }
-    // block structures and Galerkin contribution lists, bottom up
-    {
-        std::vector<std::pair<int64_t, int64_t>> trip;
-        trip.reserve((size_t)N + 2 * (size_t)(Er + Es));
-        // (entry -1: the block exists — its structure is the global one on every rank — but the contribution is another rank's)
-        for (int64_t i = 0; i < N; ++i) if (H.agg0[i] >= 0) trip.push_back({(int64_t)H.agg0[i] * n1 + H.agg0[i], local ? (int64_t)-1 : ((i << 3) | 0)});
-        auto edge = [&](int64_t e, int32_t c1, int32_t c2, int kind_fwd) {
-            const int32_t a = H.agg0[c1], b = H.agg0[c2];
-            if (a < 0 || b < 0) return;                     // rows and columns of fixed keyframes are not part of the system
-            trip.push_back({(int64_t)a * n1 + b, e < 0 ? (int64_t)-1 : ((e << 3) | kind_fwd)});
-            trip.push_back({(int64_t)b * n1 + a, e < 0 ? (int64_t)-1 : ((e << 3) | (kind_fwd + 1))});
-        };
-        for (int64_t e = 0; e < Er; ++e) edge(local ? -1 : e, rc1[e], rc2[e], 1);
-        for (int64_t e = 0; e < Es; ++e) edge(local ? -1 : e, sc1[e], sc2[e], 3);
-        if (local) {
-            const int64_t Nl = (int64_t)local->l2g->size();
-            for (int64_t l = 0; l < Nl; ++l) { const int32_t a = H.agg0[(*local->l2g)[l]]; if (a >= 0 && (*local->own)[l] != 0.0) trip.push_back({(int64_t)a * n1 + a, (l << 3) | 0}); }
-            for (int64_t e = 0; e < (int64_t)local->rc1->size(); ++e) edge(e, (*local->rc1)[e], (*local->rc2)[e], 1);
-            for (int64_t e = 0; e < (int64_t)local->sc1->size(); ++e) edge(e, (*local->sc1)[e], (*local->sc2)[e], 3);
-        }
-        build_blocks(n1, trip, H.L[0]);
-    }
+    // block structure and Galerkin contribution lists of level 1: the cached provisional structure in the final numbering; the levels above bottom up
+    permute_level1(Cc.L1prov, n1, newid_above, H.L[0]);
     for (size_t l = 0; l + 1 < H.L.size(); ++l) {
         HostLevel& A = H.L[l];
         HostLevel& B = H.L[l + 1];
@@ -306,10 +374,14 @@ inline bool build_hierarchy(int64_t N, const std::vector<uint8_t>& node_free, co
                 A.ps_rowptr[(size_t)i + 1] = (int32_t)A.ps_col.size();
             }
             A.w_rowptr.assign((size_t)n + 1, 0);
+            std::vector<int32_t> stamp((size_t)nb, -1);              // unions by marking: each coarse column enters a row's list once
             for (int32_t i = 0; i < n; ++i) {
                 tmp.clear();
-                for (int64_t k = A.rowptr[i]; k < A.rowptr[(size_t)i + 1]; ++k) { const int32_t j = A.col[k]; tmp.insert(tmp.end(), A.ps_col.begin() + A.ps_rowptr[j], A.ps_col.begin() + A.ps_rowptr[(size_t)j + 1]); }
-                std::sort(tmp.begin(), tmp.end()); tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+                for (int64_t k = A.rowptr[i]; k < A.rowptr[(size_t)i + 1]; ++k) {
+                    const int32_t j = A.col[k];
+                    for (int32_t sl = A.ps_rowptr[j]; sl < A.ps_rowptr[(size_t)j + 1]; ++sl) { const int32_t c = A.ps_col[sl]; if (stamp[c] != i) { stamp[c] = i; tmp.push_back(c); } }
+                }
+                std::sort(tmp.begin(), tmp.end());
                 A.w_col.insert(A.w_col.end(), tmp.begin(), tmp.end());
                 A.w_rowptr[(size_t)i + 1] = (int32_t)A.w_col.size();
             }
@@ -320,10 +392,14 @@ inline bool build_hierarchy(int64_t N, const std::vector<uint8_t>& node_free, co
             { std::vector<int64_t> fill(A.psT_ptr.begin(), A.psT_ptr.end() - 1);
               for (int32_t i = 0; i < n; ++i) for (int32_t sl = A.ps_rowptr[i]; sl < A.ps_rowptr[(size_t)i + 1]; ++sl) A.psT_ent[(size_t)fill[A.ps_col[sl]]++] = ((int64_t)i << 32) | (int64_t)sl; }
             B.rowptr.assign((size_t)nb + 1, 0); B.col.clear();
+            std::fill(stamp.begin(), stamp.end(), -1);
             for (int32_t a = 0; a < nb; ++a) {
                 tmp.clear();
-                for (int64_t e = A.psT_ptr[a]; e < A.psT_ptr[(size_t)a + 1]; ++e) { const int32_t i = (int32_t)(A.psT_ent[e] >> 32); tmp.insert(tmp.end(), A.w_col.begin() + A.w_rowptr[i], A.w_col.begin() + A.w_rowptr[(size_t)i + 1]); }
-                std::sort(tmp.begin(), tmp.end()); tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+                for (int64_t e = A.psT_ptr[a]; e < A.psT_ptr[(size_t)a + 1]; ++e) {
+                    const int32_t i = (int32_t)(A.psT_ent[e] >> 32);
+                    for (int32_t sl = A.w_rowptr[i]; sl < A.w_rowptr[(size_t)i + 1]; ++sl) { const int32_t c = A.w_col[sl]; if (stamp[c] != a) { stamp[c] = a; tmp.push_back(c); } }
+                }
+                std::sort(tmp.begin(), tmp.end());
                 B.col.push_back(a);                                       // the diagonal block first, as everywhere
                 for (int32_t c : tmp) if (c != a) B.col.push_back(c);
                 B.rowptr[(size_t)a + 1] = (int64_t)B.col.size();

@@ -128,6 +128,9 @@ struct pgo_problem {
     DBuf<double> d_mg_f64; DBuf<int32_t> d_mg_i32; DBuf<int64_t> d_mg_i64;
     MgDev M{}; MgLevelDev mg_levels[MG_MAX_LEVELS];
     bool mg_built = false, mg_active = false;
+    pgo_mg::BuildCache mg_cache;           // what the hierarchy builder keeps for a regroup of the same graph
+    std::vector<double> mg_sw_built;       // [Es] s^2 of every switchable edge the current hierarchy was built with
+    int mg_regroups = 0;                   // regroups of this solve
     uint64_t mg_geometry_epoch = 0;
     int64_t n_vio = 0;
     // matrix-free operator
@@ -242,6 +245,193 @@ int upload_class(pgo_problem* p, const HostClass& H, bool is_sw, DBuf<int32_t>& 
 
 int allreduce(pgo_problem* p, double* buf, size_t n, int op);
 int host_allreduce(pgo_problem* p, std::vector<double>& v, int op);
+
+// The aggregation multigrid's hierarchy for the graph of this handle and the given switch values (host array over the caller's switches, or null): host-side structure
+// (pgo_mg_host.hpp), pooled device arrays, level descriptors.  Called by build_graph, and again inside a solve when the switch values have moved far from the ones the
+// hierarchy was built with (regroup): the levels above level 1 are matched along the couplings that are alive NOW.  p->mg_cache keeps what does not depend on the switches.
+int build_multigrid(pgo_problem* p, const double* sw_now) {
+    const int64_t N = p->N, Ng = p->N_global, S = p->S;
+    const int64_t Er = p->rel.size(), Es = p->swe.size();
+    int rc;
+    p->coarse_built = false; p->coarse_active = false; p->K = CoarseDev{};
+    p->mg_built = false; p->mg_active = false; p->M = MgDev{}; p->mg_geometry_epoch = 0;
+    if (p->opt.mg_min_keyframes > 0 && Ng >= p->opt.mg_min_keyframes) {      // (the caller's keyframe count decides: the same answer on every rank)
+        pgo_mg::Hierarchy H;
+        const int dense_max = std::max(1, std::min(p->opt.mg_dense_max_nodes, 512));
+        // smoothed prolongators (denser coarse operators, two more row products per cycle on each such level) pay while the coarse levels are latency-bound: measured
+        // C4 (200k keyframes) 3.56 -> 2.37 s, C5 (1M keyframes, level 1 = 125k nodes: bandwidth-bound) 8.5 -> 11.1 s.  -1 = by size; with them aggregates of 4 above level 1, else of 8
+        const double loop_discount = std::max(0.0, p->opt.mg_loop_discount);
+        const int n_smoothed = p->opt.mg_smoothed_levels < 0 ? (Ng <= 500000 ? 1 : 0) : std::min(p->opt.mg_smoothed_levels, MG_MAX_LEVELS);
+        const int passes0 = std::max(1, std::min(p->opt.mg_first_passes, 3)), passes = p->opt.mg_passes <= 0 ? (n_smoothed > 0 ? 2 : 3) : std::min(p->opt.mg_passes, 3);
+        std::vector<double> sw_w;
+        if (sw_now && S > 0) { sw_w.resize((size_t)Es); for (int64_t e = 0; e < Es; ++e) { const double sv = sw_now[p->swe.sw[e]]; sw_w[e] = sv * sv; } }
+        bool ok;
+        std::vector<int32_t> agg0_l, mem0_ptr_l, mem0_l;      // several ranks: the keyframe-indexed arrays in the handle's local numbering
+        std::vector<double> inv_cnt;
+        if (!p->local_ids) {
+            ok = pgo_mg::build_hierarchy(N, p->h_node_free, p->rel.c1, p->rel.c2, p->rel.meas.data() + 7, 8, p->swe.c1, p->swe.c2, sw_w.empty() ? nullptr : sw_w.data(), passes0, passes, dense_max, MG_TILE_ROWS,
+                                         MG_MAX_LEVELS, H, false, MG_BLOCK0, nullptr, n_smoothed, loop_discount, &p->mg_cache);
+        } else {
+            // Several ranks: every rank gathers the endpoints and weights of ALL edges (one all-reduce of a zero-padded buffer: 24 B per edge, once per graph build)
+            // and builds the same hierarchy from the global graph; its own edges and owned keyframes are what it contributes to level 1 (pgo_mg_host.hpp).
+            std::vector<double> cnt((size_t)2 * p->world, 0.0);
+            cnt[(size_t)2 * p->rank] = (double)Er; cnt[(size_t)2 * p->rank + 1] = (double)Es;
+            if ((rc = host_allreduce(p, cnt, 0)) != PGO_OK) return rc;
+            int64_t ErT = 0, EsT = 0, my_r = 0, my_s = 0;
+            for (int r = 0; r < p->world; ++r) { if (r == p->rank) { my_r = ErT; my_s = EsT; } ErT += (int64_t)(cnt[(size_t)2 * r] + 0.5); EsT += (int64_t)(cnt[(size_t)2 * r + 1] + 0.5); }
+            std::vector<double> buf((size_t)3 * (ErT + EsT), 0.0);
+            double* b_rc1 = buf.data(); double* b_rc2 = b_rc1 + ErT; double* b_rw = b_rc2 + ErT; double* b_sc1 = b_rw + ErT; double* b_sc2 = b_sc1 + EsT; double* b_sw = b_sc2 + EsT;
+            for (int64_t e = 0; e < Er; ++e) { b_rc1[my_r + e] = p->rel.c1[e]; b_rc2[my_r + e] = p->rel.c2[e]; b_rw[my_r + e] = p->rel.meas[(size_t)8 * e + 7]; }
+            for (int64_t e = 0; e < Es; ++e) { b_sc1[my_s + e] = p->swe.c1[e]; b_sc2[my_s + e] = p->swe.c2[e]; b_sw[my_s + e] = sw_w.empty() ? 1.0 : sw_w[e]; }
+            if ((rc = host_allreduce(p, buf, 0)) != PGO_OK) return rc;
+            std::vector<int32_t> grc1((size_t)ErT), grc2((size_t)ErT), gsc1((size_t)EsT), gsc2((size_t)EsT);
+            std::vector<double> grw(b_rw, b_rw + ErT), gsw(b_sw, b_sw + EsT);
+            for (int64_t e = 0; e < ErT; ++e) { grc1[e] = (int32_t)(b_rc1[e] + 0.5); grc2[e] = (int32_t)(b_rc2[e] + 0.5); }
+            for (int64_t e = 0; e < EsT; ++e) { gsc1[e] = (int32_t)(b_sc1[e] + 0.5); gsc2[e] = (int32_t)(b_sc2[e] + 0.5); }
+            std::vector<uint8_t> gfree((size_t)Ng);
+            for (int64_t g = 0; g < Ng; ++g) gfree[g] = p->h_touched_any[g];
+            for (int32_t c : p->constant_nodes) if (c >= 0 && c < Ng) gfree[c] = 0;
+            const pgo_mg::LocalContrib local{&p->l2g, &p->h_own, &p->rel.c1, &p->rel.c2, &p->swe.c1, &p->swe.c2};
+            ok = pgo_mg::build_hierarchy(Ng, gfree, grc1, grc2, grw.data(), 1, gsc1, gsc2, (sw_now && S > 0) ? gsw.data() : nullptr, passes0, passes, dense_max, MG_TILE_ROWS, MG_MAX_LEVELS, H, false, 0, &local, n_smoothed, loop_discount, &p->mg_cache);
+            if (ok) {
+                const int32_t n1g = (int32_t)H.mem0_ptr.size() - 1;
+                inv_cnt.resize((size_t)n1g);
+                for (int32_t a = 0; a < n1g; ++a) inv_cnt[a] = 1.0 / (double)std::max(1, H.mem0_ptr[a + 1] - H.mem0_ptr[a]);
+                agg0_l.resize((size_t)N); mem0_ptr_l.assign((size_t)n1g + 1, 0);
+                for (int64_t l = 0; l < N; ++l) { agg0_l[l] = p->h_node_free[l] ? H.agg0[p->l2g[l]] : -1; if (agg0_l[l] >= 0) mem0_ptr_l[(size_t)agg0_l[l] + 1]++; }
+                for (int32_t a = 0; a < n1g; ++a) mem0_ptr_l[(size_t)a + 1] += mem0_ptr_l[a];
+                mem0_l.resize((size_t)mem0_ptr_l[n1g]);
+                std::vector<int32_t> fillm(mem0_ptr_l.begin(), mem0_ptr_l.end() - 1);
+                for (int64_t l = 0; l < N; ++l) if (agg0_l[l] >= 0) mem0_l[(size_t)fillm[agg0_l[l]]++] = (int32_t)l;
+            }
+        }
+        const std::vector<int32_t>& A0 = p->local_ids ? agg0_l : H.agg0;
+        const std::vector<int32_t>& M0P = p->local_ids ? mem0_ptr_l : H.mem0_ptr;
+        const std::vector<int32_t>& M0 = p->local_ids ? mem0_l : H.mem0;
+        if (ok) {
+            const int nl = (int)H.L.size();
+            // pooled arrays: (offset, count) per array; doubles rounded up to even counts (16-B loads)
+            std::vector<int32_t> pi32; std::vector<int64_t> pi64;
+            auto put32 = [&](const std::vector<int32_t>& v) { const size_t o = pi32.size(); pi32.insert(pi32.end(), v.begin(), v.end()); return o; };
+            auto put64 = [&](const std::vector<int64_t>& v) { const size_t o = pi64.size(); pi64.insert(pi64.end(), v.begin(), v.end()); return o; };
+            size_t nf64 = 0;
+            auto take = [&](size_t cnt) { const size_t o = nf64; nf64 += (cnt + 1) & ~(size_t)1; return o; };
+            struct Off { size_t col, parent, agg_ptr, tile, tile_rows, rowptr, g_ptr, g_ent, val, Dinv, pos, d, r, x, xt, xf, valf, ps_rowptr, ps_col, w_rowptr, w_col, psT_ptr, psT_ent, ps_val, w_val, t, u, y, zero; };
+            std::vector<Off> off((size_t)nl);
+            const size_t o_agg0 = put32(A0), o_mem0_ptr = put32(M0P), o_mem0 = put32(M0);
+            // slot table of the restriction inside the vector update: per run of MG_BLOCK0 keyframes its aggregates {id, 8 members as run-local bytes}
+            size_t o_blk_tab = 0; bool have_tab = !p->local_ids;
+            if (have_tab) {
+                const int64_t runs = (N + MG_BLOCK0 - 1) / MG_BLOCK0;
+                std::vector<int32_t> tab((size_t)runs * MG_BLOCK0 * 4);
+                for (size_t k = 0; k < tab.size(); k += 4) { tab[k] = -1; tab[k + 1] = -1; tab[k + 2] = -1; tab[k + 3] = 0; }
+                std::vector<int> fill((size_t)runs, 0);
+                const int32_t n1h = (int32_t)H.mem0_ptr.size() - 1;
+                for (int32_t a = 0; a < n1h && have_tab; ++a) {
+                    const int32_t m0 = H.mem0_ptr[a], m1 = H.mem0_ptr[a + 1];
+                    if (m1 <= m0) continue;
+                    const int64_t run = H.mem0[m0] / MG_BLOCK0;
+                    if (m1 - m0 > 8 || fill[run] >= MG_BLOCK0) { have_tab = false; break; }
+                    uint32_t w[2] = {0xffffffffu, 0xffffffffu};
+                    for (int32_t m = m0; m < m1; ++m) {
+                        if (H.mem0[m] / MG_BLOCK0 != run) { have_tab = false; break; }
+                        const int j = m - m0;
+                        w[j >> 2] = (w[j >> 2] & ~(0xffu << (8 * (j & 3)))) | ((uint32_t)(H.mem0[m] - run * MG_BLOCK0) << (8 * (j & 3)));
+                    }
+                    int32_t* e = &tab[((size_t)run * MG_BLOCK0 + fill[run]++) * 4];
+                    e[0] = a; e[1] = (int32_t)w[0]; e[2] = (int32_t)w[1];
+                }
+                if (have_tab) { while (pi32.size() % 4) pi32.push_back(0); o_blk_tab = put32(tab); }
+            }
+            const size_t o_d0 = take((size_t)N * 3);
+            const size_t n1_all = (size_t)H.L[0].n;
+            const size_t o_inv = p->local_ids ? take(n1_all) : 0, o_q1 = p->local_ids ? take(n1_all * 6) : 0, o_s1 = p->local_ids ? take(n1_all * 6) : 0;
+            for (int l = 0; l < nl; ++l) {
+                const pgo_mg::HostLevel& A = H.L[l];
+                Off& o = off[l];
+                o.col = put32(A.col); o.parent = put32(A.parent); o.agg_ptr = put32(A.agg_ptr);
+                {   // per tile {a0, a1, i0, i1}, 16-B aligned
+                    std::vector<int32_t> info;
+                    for (size_t tt = 0; tt + 1 < A.tile_agg0.size(); ++tt) { const int32_t a0 = A.tile_agg0[tt], a1 = A.tile_agg0[tt + 1]; info.insert(info.end(), {a0, a1, A.agg_ptr[a0], A.agg_ptr[a1]}); }
+                    while (pi32.size() % 4) pi32.push_back(0);
+                    o.tile = put32(info);
+                    std::vector<int32_t> rows;      // [tile][MG_TILE_ROWS] {first block, end block} of each row of the tile
+                    for (size_t tt = 0; tt + 1 < A.tile_agg0.size(); ++tt) {
+                        const int32_t i0 = A.agg_ptr[A.tile_agg0[tt]], i1 = A.agg_ptr[A.tile_agg0[tt + 1]];
+                        for (int li = 0; li < MG_TILE_ROWS; ++li) { const int32_t r = i0 + li; rows.push_back(r < i1 ? (int32_t)A.rowptr[r] : 0); rows.push_back(r < i1 ? (int32_t)A.rowptr[r + 1] : 0); }
+                    }
+                    o.tile_rows = put32(rows);
+                }
+                o.rowptr = put64(A.rowptr); o.g_ptr = put64(A.g_ptr); o.g_ent = put64(A.g_ent);
+                o.val = take(A.col.size() * 36); o.Dinv = take((size_t)A.n * 36); o.pos = take((size_t)A.n * 3); o.d = take((size_t)A.n * 3);
+                o.r = take((size_t)A.n * 6); o.x = take((size_t)A.n * 6); o.xt = take((size_t)A.n * 6); o.xf = take((size_t)A.n * 6);
+                o.valf = take((A.col.size() * 36 + 1) / 2);      // fp32 copy of the blocks, carved out of the fp64 pool
+                if (A.smoothed) {
+                    o.ps_rowptr = put32(A.ps_rowptr); o.ps_col = put32(A.ps_col); o.w_rowptr = put32(A.w_rowptr); o.w_col = put32(A.w_col);
+                    o.psT_ptr = put64(A.psT_ptr); o.psT_ent = put64(A.psT_ent);
+                    o.ps_val = take(A.ps_col.size() * 36); o.w_val = take(A.w_col.size() * 36);
+                    o.t = take((size_t)A.n * 6); o.u = take((size_t)A.n * 6); o.y = take((size_t)A.n * 6); o.zero = take((size_t)A.n * 6);
+                }
+            }
+            const int n_top = H.L[nl - 1].n;
+            const int nc = (6 * n_top + 63) / 64 * 64;
+            HIPCHK(p, p->d_mg_i32.ensure(std::max<size_t>(pi32.size(), 1))); HIPCHK(p, p->d_mg_i64.ensure(std::max<size_t>(pi64.size(), 1))); HIPCHK(p, p->d_mg_f64.ensure(std::max<size_t>(nf64, 2)));
+            HIPCHK(p, p->d_cAc.ensure((size_t)nc * nc)); HIPCHK(p, p->d_cAcf.ensure((size_t)nc * nc)); HIPCHK(p, p->d_crc.ensure((size_t)nc * 2)); HIPCHK(p, p->d_cscr.ensure((size_t)nc * 64 + 1024)); HIPCHK(p, p->d_cinfo.ensure(4));
+            HIPCHK(p, hipMemcpyAsync(p->d_mg_i32.p, pi32.data(), pi32.size() * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
+            HIPCHK(p, hipMemcpyAsync(p->d_mg_i64.p, pi64.data(), pi64.size() * sizeof(int64_t), hipMemcpyHostToDevice, p->st));
+            HIPCHK(p, hipMemsetAsync(p->d_mg_f64.p, 0, nf64 * sizeof(double), p->st));
+            HIPCHK(p, hipMemsetAsync(p->d_crc.p, 0, (size_t)nc * 2 * sizeof(double), p->st));
+            HIPCHK(p, hipStreamSynchronize(p->st));
+            const int32_t* b32 = p->d_mg_i32.p; const int64_t* b64 = p->d_mg_i64.p; double* bf = p->d_mg_f64.p;
+            p->M = MgDev{nl, H.L[0].n, b32 + o_agg0, b32 + o_mem0_ptr, b32 + o_mem0, bf + o_d0, have_tab ? reinterpret_cast<const int4*>(b32 + o_blk_tab) : nullptr, nullptr, nullptr, nullptr};
+            if (p->local_ids) {
+                HIPCHK(p, hipMemcpyAsync(bf + o_inv, inv_cnt.data(), inv_cnt.size() * sizeof(double), hipMemcpyHostToDevice, p->st));
+                HIPCHK(p, hipStreamSynchronize(p->st));
+                p->M.inv_cnt = bf + o_inv; p->M.q1 = bf + o_q1; p->M.s1 = bf + o_s1;
+            }
+            for (int l = 0; l < nl; ++l) {
+                const pgo_mg::HostLevel& A = H.L[l];
+                const Off& o = off[l];
+                MgLevelDev& D = p->mg_levels[l];
+                D = MgLevelDev{};
+                D.n = A.n; D.n_next = l + 1 < nl ? H.L[l + 1].n : 0; D.tiles = A.tile_agg0.empty() ? 0 : (int32_t)A.tile_agg0.size() - 1; D.nnzb = (int64_t)A.col.size();
+                D.rowptr = b64 + o.rowptr; D.col = b32 + o.col; D.val = bf + o.val; D.g_ptr = b64 + o.g_ptr; D.g_ent = b64 + o.g_ent;
+                D.Dinv = bf + o.Dinv; D.pos = bf + o.pos; D.d = bf + o.d; D.parent = b32 + o.parent; D.agg_ptr = b32 + o.agg_ptr; D.tile_info = reinterpret_cast<const int4*>(b32 + o.tile); D.tile_rows = reinterpret_cast<const int2*>(b32 + o.tile_rows);
+                D.r = bf + o.r; D.x = bf + o.x; D.xt = bf + o.xt; D.xf = bf + o.xf; D.valf = reinterpret_cast<float*>(bf + o.valf);
+                D.seg_shift = A.seg >= 4 ? 2 : A.seg >= 2 ? 1 : 0;
+                if (A.smoothed) {
+                    D.smoothed = 1; D.n_ps = (int32_t)A.ps_col.size(); D.n_w = (int32_t)A.w_col.size();
+                    D.ps_rowptr = b32 + o.ps_rowptr; D.ps_col = b32 + o.ps_col; D.w_rowptr = b32 + o.w_rowptr; D.w_col = b32 + o.w_col; D.psT_ptr = b64 + o.psT_ptr; D.psT_ent = b64 + o.psT_ent;
+                    D.ps_val = bf + o.ps_val; D.w_val = bf + o.w_val; D.t = bf + o.t; D.u = bf + o.u; D.y = bf + o.y; D.zero = bf + o.zero;
+                }
+            }
+            // the dense coarsest level shares the buffers of the two-level preconditioner, which the multigrid replaces on this graph
+            p->coarse_built = false;
+            p->K = CoarseDev{};
+            p->K.n_agg = n_top; p->K.nc = nc; p->K.Ac = p->d_cAc.p; p->K.Acf = p->d_cAcf.p; p->K.rc = p->d_crc.p; p->K.yc = p->d_crc.p + nc;
+            p->mg_built = true;
+            if (p->opt.verbosity > 0) {
+                std::fprintf(stderr, "[pgo] multigrid: %lld keyframes", (long long)N);
+                for (int l = 0; l < nl; ++l) std::fprintf(stderr, " -> %d (%lld blocks%s)", H.L[l].n, (long long)H.L[l].col.size(), H.L[l].smoothed ? ", smoothed prolongator above" : "");
+                std::fprintf(stderr, ", coarsest dense %d\n", nc);
+            }
+        } else if (p->opt.verbosity > 0) std::fprintf(stderr, "[pgo] multigrid: the graph does not coarsen (isolated keyframes?) -> off\n");
+    }
+    // ---- two-level preconditioner: aggregates of consecutive keyframes and, per coarse 6x6 block (a <= b), the ordered list of fine
+    // blocks that project onto it (single GPU; enough keyframes per aggregate to be worth it)
+    if (p->mg_built) {
+        p->mg_sw_built.assign((size_t)Es, 1.0);
+        if (sw_now && S > 0) for (int64_t e = 0; e < Es; ++e) { const double sv = sw_now[p->swe.sw[e]]; p->mg_sw_built[e] = sv * sv; }
+    }
+    if (p->local_ids) {
+        // the exchange buffer is sized here once for everything a solve sends (42 doubles per shared keyframe at linearisation; 6 + the level-1 vector in the PCG),
+        // so its address is stable: the multigrid's q1 = P0^T (A u) is produced straight into its tail
+        const size_t n1 = p->mg_built ? (size_t)p->M.n1 : 0;
+        HIPCHK(p, p->d_xbuf.ensure((size_t)p->n_sh_global * 42 + 2 + 6 * n1 + 64));
+        if (p->mg_built) p->M.q1 = p->d_xbuf.p + (size_t)p->n_sh_global * 6 + 2;
+    }
+    return PGO_OK;
+}
 
 int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
     // ---- validate against the array sizes the caller solves with
@@ -523,173 +713,10 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
     C.x = v; C.r = v + n6; C.r2 = v + 2 * n6; C.z = v + 3 * n6; C.p = v + 4 * n6; C.p2 = v + 5 * n6; C.q = v + 6 * n6;
     C.part_pq = p->d_cgpart.p; C.part_rz = p->d_cgpart.p + PQ_SLOTS; C.scal = p->d_cgpart.p + PQ_SLOTS + 2 * RZ_STRIDE; C.extra_rz = 0;
     C.flags = p->d_flags.p;
-    // ---- aggregation multigrid for large graphs (single GPU): hierarchy of graph-following rigid aggregates, pgo_mg_host.hpp
-    p->coarse_built = false; p->coarse_active = false; p->K = CoarseDev{};
-    p->mg_built = false; p->mg_active = false; p->M = MgDev{}; p->mg_geometry_epoch = 0;
-    if (p->opt.mg_min_keyframes > 0 && Ng >= p->opt.mg_min_keyframes) {      // (the caller's keyframe count decides: the same answer on every rank)
-        pgo_mg::Hierarchy H;
-        const int dense_max = std::max(1, std::min(p->opt.mg_dense_max_nodes, 512));
-        // smoothed prolongators (denser coarse operators, two more row products per cycle on each such level) pay while the coarse levels are latency-bound: measured
-        // C4 (200k keyframes) 3.56 -> 2.37 s, C5 (1M keyframes, level 1 = 125k nodes: bandwidth-bound) 8.5 -> 11.1 s.  -1 = by size; with them aggregates of 4 above level 1, else of 8
-        const double loop_discount = std::max(0.0, p->opt.mg_loop_discount);
-        const int n_smoothed = p->opt.mg_smoothed_levels < 0 ? (Ng <= 500000 ? 1 : 0) : std::min(p->opt.mg_smoothed_levels, MG_MAX_LEVELS);
-        const int passes0 = std::max(1, std::min(p->opt.mg_first_passes, 3)), passes = p->opt.mg_passes <= 0 ? (n_smoothed > 0 ? 2 : 3) : std::min(p->opt.mg_passes, 3);
-        std::vector<double> sw_w;
-        if (sw_now && S > 0) { sw_w.resize((size_t)Es); for (int64_t e = 0; e < Es; ++e) { const double sv = sw_now[p->swe.sw[e]]; sw_w[e] = sv * sv; } }
-        bool ok;
-        std::vector<int32_t> agg0_l, mem0_ptr_l, mem0_l;      // several ranks: the keyframe-indexed arrays in the handle's local numbering
-        std::vector<double> inv_cnt;
-        if (!p->local_ids) {
-            ok = pgo_mg::build_hierarchy(N, p->h_node_free, p->rel.c1, p->rel.c2, p->rel.meas.data() + 7, 8, p->swe.c1, p->swe.c2, sw_w.empty() ? nullptr : sw_w.data(), passes0, passes, dense_max, MG_TILE_ROWS,
-                                         MG_MAX_LEVELS, H, false, MG_BLOCK0, nullptr, n_smoothed, loop_discount);
-        } else {
-            // Several ranks: every rank gathers the endpoints and weights of ALL edges (one all-reduce of a zero-padded buffer: 24 B per edge, once per graph build)
-            // and builds the same hierarchy from the global graph; its own edges and owned keyframes are what it contributes to level 1 (pgo_mg_host.hpp).
-            std::vector<double> cnt((size_t)2 * p->world, 0.0);
-            cnt[(size_t)2 * p->rank] = (double)Er; cnt[(size_t)2 * p->rank + 1] = (double)Es;
-            if ((rc = host_allreduce(p, cnt, 0)) != PGO_OK) return rc;
-            int64_t ErT = 0, EsT = 0, my_r = 0, my_s = 0;
-            for (int r = 0; r < p->world; ++r) { if (r == p->rank) { my_r = ErT; my_s = EsT; } ErT += (int64_t)(cnt[(size_t)2 * r] + 0.5); EsT += (int64_t)(cnt[(size_t)2 * r + 1] + 0.5); }
-            std::vector<double> buf((size_t)3 * (ErT + EsT), 0.0);
-            double* b_rc1 = buf.data(); double* b_rc2 = b_rc1 + ErT; double* b_rw = b_rc2 + ErT; double* b_sc1 = b_rw + ErT; double* b_sc2 = b_sc1 + EsT; double* b_sw = b_sc2 + EsT;
-            for (int64_t e = 0; e < Er; ++e) { b_rc1[my_r + e] = p->rel.c1[e]; b_rc2[my_r + e] = p->rel.c2[e]; b_rw[my_r + e] = p->rel.meas[(size_t)8 * e + 7]; }
-            for (int64_t e = 0; e < Es; ++e) { b_sc1[my_s + e] = p->swe.c1[e]; b_sc2[my_s + e] = p->swe.c2[e]; b_sw[my_s + e] = sw_w.empty() ? 1.0 : sw_w[e]; }
-            if ((rc = host_allreduce(p, buf, 0)) != PGO_OK) return rc;
-            std::vector<int32_t> grc1((size_t)ErT), grc2((size_t)ErT), gsc1((size_t)EsT), gsc2((size_t)EsT);
-            std::vector<double> grw(b_rw, b_rw + ErT), gsw(b_sw, b_sw + EsT);
-            for (int64_t e = 0; e < ErT; ++e) { grc1[e] = (int32_t)(b_rc1[e] + 0.5); grc2[e] = (int32_t)(b_rc2[e] + 0.5); }
-            for (int64_t e = 0; e < EsT; ++e) { gsc1[e] = (int32_t)(b_sc1[e] + 0.5); gsc2[e] = (int32_t)(b_sc2[e] + 0.5); }
-            std::vector<uint8_t> gfree((size_t)Ng);
-            for (int64_t g = 0; g < Ng; ++g) gfree[g] = p->h_touched_any[g];
-            for (int32_t c : p->constant_nodes) if (c >= 0 && c < Ng) gfree[c] = 0;
-            const pgo_mg::LocalContrib local{&p->l2g, &p->h_own, &p->rel.c1, &p->rel.c2, &p->swe.c1, &p->swe.c2};
-            ok = pgo_mg::build_hierarchy(Ng, gfree, grc1, grc2, grw.data(), 1, gsc1, gsc2, (sw_now && S > 0) ? gsw.data() : nullptr, passes0, passes, dense_max, MG_TILE_ROWS, MG_MAX_LEVELS, H, false, 0, &local, n_smoothed, loop_discount);
-            if (ok) {
-                const int32_t n1g = (int32_t)H.mem0_ptr.size() - 1;
-                inv_cnt.resize((size_t)n1g);
-                for (int32_t a = 0; a < n1g; ++a) inv_cnt[a] = 1.0 / (double)std::max(1, H.mem0_ptr[a + 1] - H.mem0_ptr[a]);
-                agg0_l.resize((size_t)N); mem0_ptr_l.assign((size_t)n1g + 1, 0);
-                for (int64_t l = 0; l < N; ++l) { agg0_l[l] = p->h_node_free[l] ? H.agg0[p->l2g[l]] : -1; if (agg0_l[l] >= 0) mem0_ptr_l[(size_t)agg0_l[l] + 1]++; }
-                for (int32_t a = 0; a < n1g; ++a) mem0_ptr_l[(size_t)a + 1] += mem0_ptr_l[a];
-                mem0_l.resize((size_t)mem0_ptr_l[n1g]);
-                std::vector<int32_t> fillm(mem0_ptr_l.begin(), mem0_ptr_l.end() - 1);
-                for (int64_t l = 0; l < N; ++l) if (agg0_l[l] >= 0) mem0_l[(size_t)fillm[agg0_l[l]]++] = (int32_t)l;
-            }
-        }
-        const std::vector<int32_t>& A0 = p->local_ids ? agg0_l : H.agg0;
-        const std::vector<int32_t>& M0P = p->local_ids ? mem0_ptr_l : H.mem0_ptr;
-        const std::vector<int32_t>& M0 = p->local_ids ? mem0_l : H.mem0;
-        if (ok) {
-            const int nl = (int)H.L.size();
-            // pooled arrays: (offset, count) per array; doubles rounded up to even counts (16-B loads)
-            std::vector<int32_t> pi32; std::vector<int64_t> pi64;
-            auto put32 = [&](const std::vector<int32_t>& v) { const size_t o = pi32.size(); pi32.insert(pi32.end(), v.begin(), v.end()); return o; };
-            auto put64 = [&](const std::vector<int64_t>& v) { const size_t o = pi64.size(); pi64.insert(pi64.end(), v.begin(), v.end()); return o; };
-            size_t nf64 = 0;
-            auto take = [&](size_t cnt) { const size_t o = nf64; nf64 += (cnt + 1) & ~(size_t)1; return o; };
-            struct Off { size_t col, parent, agg_ptr, tile, tile_rows, rowptr, g_ptr, g_ent, val, Dinv, pos, d, r, x, xt, xf, valf, ps_rowptr, ps_col, w_rowptr, w_col, psT_ptr, psT_ent, ps_val, w_val, t, u, y, zero; };
-            std::vector<Off> off((size_t)nl);
-            const size_t o_agg0 = put32(A0), o_mem0_ptr = put32(M0P), o_mem0 = put32(M0);
-            // slot table of the restriction inside the vector update: per run of MG_BLOCK0 keyframes its aggregates {id, 8 members as run-local bytes}
-            size_t o_blk_tab = 0; bool have_tab = !p->local_ids;
-            if (have_tab) {
-                const int64_t runs = (N + MG_BLOCK0 - 1) / MG_BLOCK0;
-                std::vector<int32_t> tab((size_t)runs * MG_BLOCK0 * 4);
-                for (size_t k = 0; k < tab.size(); k += 4) { tab[k] = -1; tab[k + 1] = -1; tab[k + 2] = -1; tab[k + 3] = 0; }
-                std::vector<int> fill((size_t)runs, 0);
-                const int32_t n1h = (int32_t)H.mem0_ptr.size() - 1;
-                for (int32_t a = 0; a < n1h && have_tab; ++a) {
-                    const int32_t m0 = H.mem0_ptr[a], m1 = H.mem0_ptr[a + 1];
-                    if (m1 <= m0) continue;
-                    const int64_t run = H.mem0[m0] / MG_BLOCK0;
-                    if (m1 - m0 > 8 || fill[run] >= MG_BLOCK0) { have_tab = false; break; }
-                    uint32_t w[2] = {0xffffffffu, 0xffffffffu};
-                    for (int32_t m = m0; m < m1; ++m) {
-                        if (H.mem0[m] / MG_BLOCK0 != run) { have_tab = false; break; }
-                        const int j = m - m0;
-                        w[j >> 2] = (w[j >> 2] & ~(0xffu << (8 * (j & 3)))) | ((uint32_t)(H.mem0[m] - run * MG_BLOCK0) << (8 * (j & 3)));
-                    }
-                    int32_t* e = &tab[((size_t)run * MG_BLOCK0 + fill[run]++) * 4];
-                    e[0] = a; e[1] = (int32_t)w[0]; e[2] = (int32_t)w[1];
-                }
-                if (have_tab) { while (pi32.size() % 4) pi32.push_back(0); o_blk_tab = put32(tab); }
-            }
-            const size_t o_d0 = take((size_t)N * 3);
-            const size_t n1_all = (size_t)H.L[0].n;
-            const size_t o_inv = p->local_ids ? take(n1_all) : 0, o_q1 = p->local_ids ? take(n1_all * 6) : 0, o_s1 = p->local_ids ? take(n1_all * 6) : 0;
-            for (int l = 0; l < nl; ++l) {
-                const pgo_mg::HostLevel& A = H.L[l];
-                Off& o = off[l];
-                o.col = put32(A.col); o.parent = put32(A.parent); o.agg_ptr = put32(A.agg_ptr);
-                {   // per tile {a0, a1, i0, i1}, 16-B aligned
-                    std::vector<int32_t> info;
-                    for (size_t tt = 0; tt + 1 < A.tile_agg0.size(); ++tt) { const int32_t a0 = A.tile_agg0[tt], a1 = A.tile_agg0[tt + 1]; info.insert(info.end(), {a0, a1, A.agg_ptr[a0], A.agg_ptr[a1]}); }
-                    while (pi32.size() % 4) pi32.push_back(0);
-                    o.tile = put32(info);
-                    std::vector<int32_t> rows;      // [tile][MG_TILE_ROWS] {first block, end block} of each row of the tile
-                    for (size_t tt = 0; tt + 1 < A.tile_agg0.size(); ++tt) {
-                        const int32_t i0 = A.agg_ptr[A.tile_agg0[tt]], i1 = A.agg_ptr[A.tile_agg0[tt + 1]];
-                        for (int li = 0; li < MG_TILE_ROWS; ++li) { const int32_t r = i0 + li; rows.push_back(r < i1 ? (int32_t)A.rowptr[r] : 0); rows.push_back(r < i1 ? (int32_t)A.rowptr[r + 1] : 0); }
-                    }
-                    o.tile_rows = put32(rows);
-                }
-                o.rowptr = put64(A.rowptr); o.g_ptr = put64(A.g_ptr); o.g_ent = put64(A.g_ent);
-                o.val = take(A.col.size() * 36); o.Dinv = take((size_t)A.n * 36); o.pos = take((size_t)A.n * 3); o.d = take((size_t)A.n * 3);
-                o.r = take((size_t)A.n * 6); o.x = take((size_t)A.n * 6); o.xt = take((size_t)A.n * 6); o.xf = take((size_t)A.n * 6);
-                o.valf = take((A.col.size() * 36 + 1) / 2);      // fp32 copy of the blocks, carved out of the fp64 pool
-                if (A.smoothed) {
-                    o.ps_rowptr = put32(A.ps_rowptr); o.ps_col = put32(A.ps_col); o.w_rowptr = put32(A.w_rowptr); o.w_col = put32(A.w_col);
-                    o.psT_ptr = put64(A.psT_ptr); o.psT_ent = put64(A.psT_ent);
-                    o.ps_val = take(A.ps_col.size() * 36); o.w_val = take(A.w_col.size() * 36);
-                    o.t = take((size_t)A.n * 6); o.u = take((size_t)A.n * 6); o.y = take((size_t)A.n * 6); o.zero = take((size_t)A.n * 6);
-                }
-            }
-            const int n_top = H.L[nl - 1].n;
-            const int nc = (6 * n_top + 63) / 64 * 64;
-            HIPCHK(p, p->d_mg_i32.ensure(std::max<size_t>(pi32.size(), 1))); HIPCHK(p, p->d_mg_i64.ensure(std::max<size_t>(pi64.size(), 1))); HIPCHK(p, p->d_mg_f64.ensure(std::max<size_t>(nf64, 2)));
-            HIPCHK(p, p->d_cAc.ensure((size_t)nc * nc)); HIPCHK(p, p->d_cAcf.ensure((size_t)nc * nc)); HIPCHK(p, p->d_crc.ensure((size_t)nc * 2)); HIPCHK(p, p->d_cscr.ensure((size_t)nc * 64 + 1024)); HIPCHK(p, p->d_cinfo.ensure(4));
-            HIPCHK(p, hipMemcpyAsync(p->d_mg_i32.p, pi32.data(), pi32.size() * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
-            HIPCHK(p, hipMemcpyAsync(p->d_mg_i64.p, pi64.data(), pi64.size() * sizeof(int64_t), hipMemcpyHostToDevice, p->st));
-            HIPCHK(p, hipMemsetAsync(p->d_mg_f64.p, 0, nf64 * sizeof(double), p->st));
-            HIPCHK(p, hipMemsetAsync(p->d_crc.p, 0, (size_t)nc * 2 * sizeof(double), p->st));
-            HIPCHK(p, hipStreamSynchronize(p->st));
-            const int32_t* b32 = p->d_mg_i32.p; const int64_t* b64 = p->d_mg_i64.p; double* bf = p->d_mg_f64.p;
-            p->M = MgDev{nl, H.L[0].n, b32 + o_agg0, b32 + o_mem0_ptr, b32 + o_mem0, bf + o_d0, have_tab ? reinterpret_cast<const int4*>(b32 + o_blk_tab) : nullptr, nullptr, nullptr, nullptr};
-            if (p->local_ids) {
-                HIPCHK(p, hipMemcpyAsync(bf + o_inv, inv_cnt.data(), inv_cnt.size() * sizeof(double), hipMemcpyHostToDevice, p->st));
-                HIPCHK(p, hipStreamSynchronize(p->st));
-                p->M.inv_cnt = bf + o_inv; p->M.q1 = bf + o_q1; p->M.s1 = bf + o_s1;
-            }
-            for (int l = 0; l < nl; ++l) {
-                const pgo_mg::HostLevel& A = H.L[l];
-                const Off& o = off[l];
-                MgLevelDev& D = p->mg_levels[l];
-                D = MgLevelDev{};
-                D.n = A.n; D.n_next = l + 1 < nl ? H.L[l + 1].n : 0; D.tiles = A.tile_agg0.empty() ? 0 : (int32_t)A.tile_agg0.size() - 1; D.nnzb = (int64_t)A.col.size();
-                D.rowptr = b64 + o.rowptr; D.col = b32 + o.col; D.val = bf + o.val; D.g_ptr = b64 + o.g_ptr; D.g_ent = b64 + o.g_ent;
-                D.Dinv = bf + o.Dinv; D.pos = bf + o.pos; D.d = bf + o.d; D.parent = b32 + o.parent; D.agg_ptr = b32 + o.agg_ptr; D.tile_info = reinterpret_cast<const int4*>(b32 + o.tile); D.tile_rows = reinterpret_cast<const int2*>(b32 + o.tile_rows);
-                D.r = bf + o.r; D.x = bf + o.x; D.xt = bf + o.xt; D.xf = bf + o.xf; D.valf = reinterpret_cast<float*>(bf + o.valf);
-                D.seg_shift = A.seg >= 4 ? 2 : A.seg >= 2 ? 1 : 0;
-                if (A.smoothed) {
-                    D.smoothed = 1; D.n_ps = (int32_t)A.ps_col.size(); D.n_w = (int32_t)A.w_col.size();
-                    D.ps_rowptr = b32 + o.ps_rowptr; D.ps_col = b32 + o.ps_col; D.w_rowptr = b32 + o.w_rowptr; D.w_col = b32 + o.w_col; D.psT_ptr = b64 + o.psT_ptr; D.psT_ent = b64 + o.psT_ent;
-                    D.ps_val = bf + o.ps_val; D.w_val = bf + o.w_val; D.t = bf + o.t; D.u = bf + o.u; D.y = bf + o.y; D.zero = bf + o.zero;
-                }
-            }
-            // the dense coarsest level shares the buffers of the two-level preconditioner, which the multigrid replaces on this graph
-            p->coarse_built = false;
-            p->K = CoarseDev{};
-            p->K.n_agg = n_top; p->K.nc = nc; p->K.Ac = p->d_cAc.p; p->K.Acf = p->d_cAcf.p; p->K.rc = p->d_crc.p; p->K.yc = p->d_crc.p + nc;
-            p->mg_built = true;
-            if (p->opt.verbosity > 0) {
-                std::fprintf(stderr, "[pgo] multigrid: %lld keyframes", (long long)N);
-                for (int l = 0; l < nl; ++l) std::fprintf(stderr, " -> %d (%lld blocks%s)", H.L[l].n, (long long)H.L[l].col.size(), H.L[l].smoothed ? ", smoothed prolongator above" : "");
-                std::fprintf(stderr, ", coarsest dense %d\n", nc);
-            }
-        } else if (p->opt.verbosity > 0) std::fprintf(stderr, "[pgo] multigrid: the graph does not coarsen (isolated keyframes?) -> off\n");
-    }
-    // ---- two-level preconditioner: aggregates of consecutive keyframes and, per coarse 6x6 block (a <= b), the ordered list of fine
-    // blocks that project onto it (single GPU; enough keyframes per aggregate to be worth it)
+    // ---- aggregation multigrid for large graphs: hierarchy of graph-following rigid aggregates (pgo_mg_host.hpp), built by build_multigrid() below — which a solve
+    // may call again with the current switch values (regroup)
+    p->mg_cache.valid = false;
+    if ((rc = build_multigrid(p, sw_now)) != PGO_OK) return rc;
     if (!p->mg_built) {      // (a graph that got the multigrid never uses the two-level method: its dense operator would be built and uploaded for nothing)
         int n_agg = p->opt.coarse_aggregates;
         // a graph with no more keyframes than `half` (256 by default) gets one aggregate per keyframe: the coarse operator IS the reduced system and the "preconditioner"
@@ -740,13 +767,6 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
             p->K = CoarseDev{n_agg, nc, m, n_blk, p->d_ccen.p, p->d_cd.p, p->d_cAc.p, p->d_crc.p, p->d_crc.p + nc, p->d_cblk_ptr.p, p->d_cblk_ab.p, p->d_ccontrib.p, p->d_cagg_free.p, p->d_cAcf.p};
             p->coarse_built = true;
         }
-    }
-    if (p->local_ids) {
-        // the exchange buffer is sized here once for everything a solve sends (42 doubles per shared keyframe at linearisation; 6 + the level-1 vector in the PCG),
-        // so its address is stable: the multigrid's q1 = P0^T (A u) is produced straight into its tail
-        const size_t n1 = p->mg_built ? (size_t)p->M.n1 : 0;
-        HIPCHK(p, p->d_xbuf.ensure((size_t)p->n_sh_global * 42 + 2 + 6 * n1 + 64));
-        if (p->mg_built) p->M.q1 = p->d_xbuf.p + (size_t)p->n_sh_global * 6 + 2;
     }
     p->graph_dirty = false; p->priors_dirty = false;
     ++p->build_epoch;   // invalidates the captured PCG graph (kernel arguments hold device pointers / sizes)
@@ -884,6 +904,7 @@ int linearize(pgo_problem* p, double* cost_out) {
 }
 
 static int build_mg(pgo_problem* p);
+static int regroup_if_moved(pgo_problem* p, const double* sv, bool in_solve);
 // c = w_p / w of the smoothed prolongators (Dinv holds w D^-1)
 double mg_cs(const pgo_problem* p) {
     const double om = p->opt.mg_omega > 0.0 && p->opt.mg_omega <= 1.0 ? p->opt.mg_omega : 0.9;
@@ -1161,8 +1182,42 @@ static int build_coarse(pgo_problem* p) {
 
 // Multigrid operators of the system just built: Galerkin products level by level, block-Jacobi inverses, dense inverse of the coarsest level.
 // A block that is not numerically positive definite leaves the multigrid off for this LM iteration (plain block-Jacobi).
+// Regroup: the hierarchy was built from the switch values of its time (0.99 everywhere at the first solve of a graph).  A few LM steps later the solver has
+// switched the outliers off, and aggregates of the levels above level 1 that such a loop closure held together are no rigid pieces any more: measured on C3, the
+// late systems need 305 / 367 / 454 multigrid iterations with the hierarchy of the start against 156 / 187 / 249 with one built from the final switch values.  So when
+// multigrid operators are about to be built and the switch values have moved far from the hierarchy's (switchable edges that moved by > 0.5 in s^2 make up more than mg_regroup_fraction of ALL
+// edges), the levels above level 1 are matched again along the couplings alive NOW (the keyframes' level-1 aggregates, matched along relative-pose edges only, and the
+// level-1 structure are cached: pgo_mg::BuildCache) — at most twice per solve.  Several ranks: the count is all-reduced, every rank regroups at the same LM step.
+static int regroup_if_moved(pgo_problem* p, const double* sv /* host: the caller's switch array */, bool in_solve) {
+    const int64_t Es = p->swe.size();
+    std::vector<double> cnt(2, 0.0);
+    for (int64_t e = 0; e < Es; ++e) { const double w = sv[p->swe.sw[e]] * sv[p->swe.sw[e]]; if (std::fabs(w - p->mg_sw_built[e]) > 0.5) cnt[0] += 1.0; }
+    cnt[1] = (double)(Es + p->rel.size());      // against ALL residual blocks: what counts is how much of the coupling structure changed (C4: 2 % of its edges are loop closures — no regroup pays there)
+    int rc;
+    if (p->local_ids && (rc = host_allreduce(p, cnt, 0)) != PGO_OK) return rc;
+    if (!(cnt[0] > p->opt.mg_regroup_fraction * cnt[1])) return PGO_OK;
+    const double t0 = now_s();
+    if ((rc = build_multigrid(p, sv)) != PGO_OK) return rc;
+    if (in_solve) ++p->mg_regroups;
+    ++p->build_epoch;      // captured PCG chunks hold pointers into the old pools
+    if (p->opt.verbosity > 0) std::fprintf(stderr, "[pgo] multigrid: regrouped %s (%.0f switchable edges of %.0f edges moved), %.1f ms\n", in_solve ? "inside the solve" : "for the new start", cnt[0], cnt[1], (now_s() - t0) * 1e3);
+    return PGO_OK;
+}
+static int maybe_regroup(pgo_problem* p) {
+    const int64_t Es = p->swe.size();
+    // (not during the first three LM iterations: the switches of outliers — and of inliers far from the odometry guess, which recover — are still falling then: measured on C3,
+    // 17 % of the switchable edges have moved after the first step, and a regroup there is paid twice)
+    if (!(p->opt.mg_regroup_fraction > 0.0) || !p->mg_built || p->S <= 0 || p->mg_regroups >= 2 || p->iteration <= 3 || (int64_t)p->mg_sw_built.size() != Es) return PGO_OK;
+    std::vector<double> sv((size_t)p->S);
+    HIPCHK(p, hipMemcpyAsync(sv.data(), p->d_swv[p->cur].p, sv.size() * sizeof(double), hipMemcpyDeviceToHost, p->st));
+    HIPCHK(p, hipStreamSynchronize(p->st));
+    return regroup_if_moved(p, sv.data(), true);
+}
+
 static int build_mg(pgo_problem* p) {
     p->mg_active = false;
+    if (!p->mg_built) return PGO_OK;
+    { int rcr; if ((rcr = maybe_regroup(p)) != PGO_OK) return rcr; }
     if (!p->mg_built) return PGO_OK;
     int rcm;
     if (p->mg_geometry_epoch != p->lin_epoch) {              // the aggregates' centroids follow the poses of the current linearisation
@@ -1247,7 +1302,13 @@ int solve_begin(pgo_problem* p, const double* quat, const double* t, const doubl
     int rc;
     if ((rc = set_device(p)) != PGO_OK) return rc;
     p->t_begin = now_s();
-    if (p->graph_dirty || p->priors_dirty || N != p->N_global || S != p->S) if ((rc = build_graph(p, N, S, sw)) != PGO_OK) return rc;
+    if (p->graph_dirty || p->priors_dirty || N != p->N_global || S != p->S) { if ((rc = build_graph(p, N, S, sw)) != PGO_OK) return rc; }
+    else if (p->opt.mg_regroup_fraction > 0.0 && p->mg_built && S > 0 && sw && (int64_t)p->mg_sw_built.size() == p->swe.size()) {
+        // the hierarchy of an unchanged graph was built (or regrouped inside the last solve) for other switch values than this solve starts from: the levels above level 1
+        // follow the start — a session's next trigger (switches as the last solve left them) keeps it, a re-solve from the original guess gets the original one back,
+        // so repeated solves from the same state stay bitwise identical
+        if ((rc = regroup_if_moved(p, sw, false)) != PGO_OK) return rc;
+    }
     // upload in the reference layout (multi-GPU: only this rank's keyframes), repack on the device
     double* io = p->d_io.p;
     const int64_t Nl = p->N;
@@ -1265,7 +1326,7 @@ int solve_begin(pgo_problem* p, const double* quat, const double* t, const doubl
     std::memset(&p->sum, 0, sizeof(p->sum));
     p->in_solve = true; p->terminated = false; p->scale_ready = false; p->have_prev_step = false;
     p->coarse_retests = 0; p->coarse_drop_radius = 0.0;
-    p->cg_prev_equiv = 0.0; p->cg_prev_radius = 0.0;
+    p->cg_prev_equiv = 0.0; p->cg_prev_radius = 0.0; p->mg_regroups = 0;
     if (p->coarse_skip > 0) { p->coarse_mode = 2; p->coarse_skip_all = true; --p->coarse_skip; }
     else { p->coarse_mode = (p->coarse_keep_streak % 4 != 0) ? 1 : 0; p->coarse_skip_all = false; }
     p->radius = p->opt.initial_trust_region_radius; p->decrease_factor = 2.0; p->reuse_diagonal = false; p->iteration = 0; p->invalid = 0;
@@ -1563,6 +1624,7 @@ void pgo_options_init(pgo_options* o) {
     o->mg_dense_max_nodes = 512;
     o->mg_switch_iterations = 400;
     o->mg_loop_discount = 3.0;
+    o->mg_regroup_fraction = 0.02;
     o->mg_prolongation_damping = 0.6;
     o->mg_smoothed_levels = -1;
     o->cg_rel_tolerance = 1e-9;     // loosest decade that keeps the 10-iteration chi^2 of C3 within 1e-8 of the 1e-13 solve

@@ -36,6 +36,25 @@ void* mgh_build_sharded(long long N, const unsigned char* node_free, long long E
     if (!pgo_mg::build_hierarchy(N, nf, a, b, w.data(), 1, c, d, nullptr, passes0, passes, dense_max, tile_rows, max_levels, *H, false, 0, &L)) { delete H; return nullptr; }
     return H;
 }
+// Regroup path: the hierarchy for switch weights `sw_w`; use_cache != 0: a first build with `sw_w_first` fills a BuildCache and the returned hierarchy is the REBUILD
+// with `sw_w` from that cache (what pgo_solver.hip's regroup does); use_cache == 0: a fresh build with `sw_w`.  The two must be identical.
+void* mgh_build_regroup(long long N, const unsigned char* node_free, long long Er, const int* rc1, const int* rc2, const double* rw, long long Es, const int* sc1, const int* sc2,
+                        const double* sw_w_first, const double* sw_w, int use_cache, int passes0, int passes, int dense_max, int tile_rows, int max_levels, int smoothed_levels, double loop_discount,
+                        int level0_block) {
+    std::vector<uint8_t> nf(node_free, node_free + N);
+    std::vector<int32_t> a(rc1, rc1 + Er), b(rc2, rc2 + Er), c(sc1, sc1 + Es), d(sc2, sc2 + Es);
+    std::vector<double> w(rw, rw + Er);
+    pgo_mg::Hierarchy* H = new pgo_mg::Hierarchy();
+    pgo_mg::BuildCache cache;
+    bool ok = true;
+    if (use_cache) {
+        pgo_mg::Hierarchy first;
+        ok = pgo_mg::build_hierarchy(N, nf, a, b, w.data(), 1, c, d, sw_w_first, passes0, passes, dense_max, tile_rows, max_levels, first, false, level0_block, nullptr, smoothed_levels, loop_discount, &cache) && cache.valid;
+    }
+    ok = ok && pgo_mg::build_hierarchy(N, nf, a, b, w.data(), 1, c, d, sw_w, passes0, passes, dense_max, tile_rows, max_levels, *H, false, level0_block, nullptr, smoothed_levels, loop_discount, use_cache ? &cache : nullptr);
+    if (!ok) { delete H; return nullptr; }
+    return H;
+}
 void mgh_free(void* h) { delete (pgo_mg::Hierarchy*)h; }
 int mgh_levels(void* h) { return (int)((pgo_mg::Hierarchy*)h)->L.size(); }
 void mgh_sizes(void* h, int l, long long* out /* n, nnzb, n_ent, n_parent, n_agg_ptr, n_tiles_plus_1 */) {

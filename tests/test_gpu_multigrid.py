@@ -106,3 +106,25 @@ def test_smoothed_prolongators_keep_the_trajectory_and_cut_the_iterations(smooth
     same_trajectory(base, sump, 1e-6)
     assert np.abs(tp - tb).max() <= 1e-4
     assert sump.cg_iterations * 1.15 < base.cg_iterations, (smoothed, sump.cg_iterations, base.cg_iterations)
+
+
+def test_regroup_follows_the_switches_and_keeps_the_trajectory():
+    """mg_regroup_fraction: once the solver has switched the outliers off, the levels above level 1 are matched again along the couplings that are alive (the keyframes'
+    level-1 aggregates and level 1's structure are cached).  Same LM trajectory with and without (the preconditioner changes, the steps do not), and a second solve of
+    the same handle from the same state is bitwise identical (the hierarchy follows the start again)."""
+    g = graphgen.generate(30000, 30000, odom_f_max=2, seed=3)
+    q, t, s = util.initial_state(g, True)
+    kw = dict(max_num_iterations=16, function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0, mg_switch_iterations=0)      # (multigrid on every system)
+    _, t0, s0, off = run(g, True, mg_regroup_fraction=0.0, **kw)
+    P = util.pgo_problem(g, True, mg_regroup_fraction=0.005, **kw)
+    _, t1, s1, on = P.solve(q, t, s)
+    _, t2, s2, on2 = P.solve(q, t, s)
+    P.close()
+    same_trajectory(off, on, 1e-6)
+    assert np.abs(t1 - t0).max() <= 1e-4 and np.abs(s1 - s0).max() <= 1e-4
+    its_on = [on.iterations[k].cg_iterations for k in range(1, on.num_logged)]
+    its_off = [off.iterations[k].cg_iterations for k in range(1, off.num_logged)]
+    assert its_on[:3] == its_off[:3] and its_on != its_off          # no regroup during the first three LM iterations; afterwards the upper levels are other ones
+    assert sum(its_on) <= 1.1 * sum(its_off)                         # (what it buys shows on harder late systems: C3's 305 / 367 / 454 -> 155 / 184 / 246, DESIGN.md)
+    assert on2.final_cost == on.final_cost and np.array_equal(t2, t1) and np.array_equal(s2, s1)
+    assert [on2.iterations[k].cg_iterations for k in range(on2.num_logged)] == [on.iterations[k].cg_iterations for k in range(on.num_logged)]

@@ -265,3 +265,54 @@ def test_smoothed_transition_structures_are_the_sparse_products(shim):
         assert np.all(seen == 1)
         # the level above is denser than with the tentative prolongator, the levels' sizes are the same
         assert len(B["col"]) > len(Href["levels"][l + 1]["col"]) and B["n"] == Href["levels"][l + 1]["n"]
+
+
+def _read_hierarchy(lib, h, N):
+    levels = []
+    for l in range(lib.mgh_levels(h)):
+        sz = np.zeros(6, np.int64)
+        lib.mgh_sizes(h, l, ptr(sz, C.c_longlong))
+        n, nnzb, nent, npar, nagg, ntile = [int(x) for x in sz]
+        L = dict(n=n, rowptr=np.zeros(n + 1, np.int64), col=np.zeros(nnzb, np.int32), g_ptr=np.zeros(nnzb + 1, np.int64), g_ent=np.zeros(nent, np.int64),
+                 parent=np.zeros(npar, np.int32), agg_ptr=np.zeros(nagg, np.int32), tile_agg0=np.zeros(ntile, np.int32))
+        lib.mgh_level(h, l, ptr(L["rowptr"], C.c_longlong), ptr(L["col"], C.c_int), ptr(L["g_ptr"], C.c_longlong), ptr(L["g_ent"], C.c_longlong), ptr(L["parent"], C.c_int),
+                      ptr(L["agg_ptr"], C.c_int), ptr(L["tile_agg0"], C.c_int))
+        levels.append(L)
+    n1 = levels[0]["n"]
+    agg0 = np.zeros(N, np.int32); mem0_ptr = np.zeros(n1 + 1, np.int32); mem0 = np.zeros(N, np.int32)
+    lib.mgh_level0(h, ptr(agg0, C.c_int), ptr(mem0_ptr, C.c_int), ptr(mem0, C.c_int))
+    return levels, agg0, mem0_ptr, mem0
+
+
+@pytest.mark.parametrize("smoothed,discount,block", [(0, 0.0, 0), (1, 3.0, 64)])
+def test_regroup_from_the_cache_equals_a_fresh_build(shim, smoothed, discount, block):
+    """A regroup inside a solve rebuilds the hierarchy from the CURRENT switch values with the cached level-1 aggregation and level-1 structure (BuildCache): it must
+    be exactly the hierarchy a fresh build with those switch values gives — and differ from the one built before the switches moved."""
+    lib = shim
+    lib.mgh_build_regroup.restype = C.c_void_p
+    g = graphgen.generate(5000, 3000, odom_f_max=2, seed=13)
+    N = g.n_poses
+    nf = np.ones(N, np.uint8)
+    rc1, rc2, sc1, sc2 = I32(g.odom_c1), I32(g.odom_c2), I32(g.loop_c1), I32(g.loop_c2)
+    rw = np.ascontiguousarray(g.odom_w, dtype=np.float64)
+    rng = np.random.default_rng(2)
+    w_first = np.full(g.n_loops, 0.99 ** 2)
+    w_now = np.where(rng.random(g.n_loops) < 0.2, 1e-6, rng.uniform(0.5, 1.0, g.n_loops))        # a fifth of the loop closures switched off
+    def call(use_cache, wa, wb):
+        h = lib.mgh_build_regroup(C.c_longlong(N), ptr(nf, C.c_ubyte), C.c_longlong(len(rc1)), ptr(rc1, C.c_int), ptr(rc2, C.c_int), ptr(rw, C.c_double), C.c_longlong(len(sc1)), ptr(sc1, C.c_int),
+                                  ptr(sc2, C.c_int), ptr(wa, C.c_double), ptr(wb, C.c_double), use_cache, 3, 2, 64, 32, 12, smoothed, C.c_double(discount), block)
+        assert h
+        h = C.c_void_p(h)
+        out = _read_hierarchy(lib, h, N)
+        lib.mgh_free(h)
+        return out
+    fresh = call(0, w_now, w_now)
+    regrouped = call(1, w_first, w_now)
+    before = call(0, w_first, w_first)
+    (La, a0, mpa, ma), (Lb, b0, mpb, mb) = fresh, regrouped
+    assert len(La) == len(Lb) and np.array_equal(a0, b0) and np.array_equal(mpa, mpb) and np.array_equal(ma, mb)
+    for A, B in zip(La, Lb):
+        for k in ("rowptr", "col", "g_ptr", "g_ent", "parent", "agg_ptr", "tile_agg0"):
+            assert np.array_equal(A[k], B[k]), k
+    # the switches mattered: the aggregates above level 1 changed
+    assert not np.array_equal(before[0][0]["parent"], La[0]["parent"])
