@@ -141,19 +141,22 @@ typedef struct pgo_options {
     int32_t mg_switch_iterations;        /* 400: every PCG starts with plain block-Jacobi (most LM systems — small trust regions, steps about to be
                                           *      rejected — need a few hundred cheap iterations); one that has not converged after this many iterations
                                           *      is restarted from its current iterate with the multigrid; a system predicted (from the previous LM step of the same
-                                          *      solve, block-Jacobi iterations growing like sqrt(radius)) to need >= 2.25x this many starts with it, and one
-                                          *      predicted easier than that switches only after twice its prediction.
-                                          *      0: multigrid from the first iteration of every system. */
+                                          *      solve, block-Jacobi iterations growing like sqrt(radius)) to need >= 1.75x this many gets the multigrid at once — or, while the
+                                          *      step can still be rejected early (cg_early_tolerance), after a block-Jacobi prelude of at most 72 iterations: a step rejected at
+                                          *      the first pause never pays for the operators (C3's step 4: 32 -> 2.6 ms); one predicted easier than that switches only after
+                                          *      twice its prediction.  0: multigrid from the first iteration of every system. */
     double mg_loop_discount;             /* 3.0: in the matching of the levels ABOVE level 1 the switchable loop closures between two level-1 nodes count as (their number - this).  A single
                                           *      loop closure may be an outlier the solver switches off a few LM steps later, and an aggregate held together by nothing else then stops being a
                                           *      rigid piece — the hierarchy is built once per graph, before the switches are known; several loop closures between the same two pieces (revisited
                                           *      places) are not all outliers.  Measured, 20 LM steps: C3 (10 % outliers) 0.444 / 0.422 / 0.410 / 0.409 s and C4 2.38 / 1.72 / 1.47 / 1.60 s
                                           *      with 0 / 2 / 3 / 5; a 60k-keyframe graph WITHOUT outliers 0.71 / 0.87 / - / 1.02 s.  Relative-pose loop edges (no switch) are not discounted. */
-    double mg_regroup_fraction;          /* 0.02: REGROUP — when multigrid operators are about to be built (not in the first three LM iterations) and the switchable edges that have moved by > 0.5
+    double mg_regroup_fraction;          /* 0.02: REGROUP — when, after an accepted step (not in the first three LM iterations), the switchable edges that have moved by > 0.5
                                           *      in s^2 since the hierarchy was built (outliers switched off) make up more than this fraction of ALL edges, the levels above level 1 are matched
                                           *      again along the couplings alive now (at most twice per solve; the keyframes' level-1 aggregates follow relative-pose edges only and are kept, as is
-                                          *      level 1's structure: ~25 ms for C3).  0 disables.  Measured on C3: the late LM systems need 155 / 184 / 246 multigrid iterations after the
-                                          *      regroup against 305 / 367 / 454 without: 20 steps 0.406 -> 0.353 s */
+                                          *      level 1's structure).  On one GPU the host half of the rebuild (~25-30 ms for C3) runs on a worker thread while the solve goes on and is
+                                          *      installed where multigrid operators are next built (both points depend on the solve's history only); with several ranks it happens there,
+                                          *      synchronously.  0 disables.  Measured on C3: the late LM systems need 155 / 184 / 246 multigrid iterations after the
+                                          *      regroup against 305 / 367 / 454 without */
     double mg_prolongation_damping;      /* 0.6: w_p of the smoothed prolongators Ps = (I - w_p D^-1 A) P (smoothed aggregation's 4 / (3 rho(D^-1 A)), rho ~ 2; from 0.9 on
                                           *      I - w_p D^-1 A is singular inside the spectrum and the Galerkin product degenerates: measured, scripts/research/r3_cycle_probe.py) */
     int32_t mg_smoothed_levels;          /* -1 = by size: 1 up to 500 000 keyframes, 0 beyond (C5, 1M keyframes: its coarse levels are bandwidth-bound and the denser operators cost more than the

@@ -15,7 +15,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "pgo.h"
@@ -65,6 +67,22 @@ struct Rccl {
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+};
+
+// Host half of a multigrid build (pgo_mg_host.hpp's hierarchy + the pooled index arrays and offsets of its device image): no HIP call, no collective in here when the handle is a
+// single rank's — that half can therefore run on a worker thread while the stream works on other LM steps (regroup, below); mg_install() uploads it.
+struct MgPrepared {
+    bool ok = false;
+    pgo_mg::Hierarchy H;
+    std::vector<int32_t> agg0_l, mem0_ptr_l, mem0_l;      // several ranks: the keyframe-indexed arrays in the handle's local numbering
+    std::vector<double> inv_cnt;
+    std::vector<int32_t> pi32; std::vector<int64_t> pi64; size_t nf64 = 0;
+    struct Off { size_t col, parent, agg_ptr, tile, tile_rows, rowptr, g_ptr, g_ent, val, Dinv, pos, d, r, x, xt, xf, valf, ps_rowptr, ps_col, w_rowptr, w_col, psT_ptr, psT_ent, ps_val, w_val, t, u, y, zero; };
+    std::vector<Off> off;
+    size_t o_agg0 = 0, o_mem0_ptr = 0, o_mem0 = 0, o_blk_tab = 0, o_d0 = 0, o_inv = 0, o_q1 = 0, o_s1 = 0;
+    bool have_tab = false;
+    std::vector<double> sw_built;          // [Es] s^2 of every switchable edge this hierarchy was matched with
+    double moved = 0.0, of_edges = 0.0, host_ms = 0.0;
 };
 
 }  // namespace
@@ -131,6 +149,10 @@ struct pgo_problem {
     pgo_mg::BuildCache mg_cache;           // what the hierarchy builder keeps for a regroup of the same graph
     std::vector<double> mg_sw_built;       // [Es] s^2 of every switchable edge the current hierarchy was built with
     int mg_regroups = 0;                   // regroups of this solve
+    // a regroup in flight: the host half of the rebuild runs on a worker thread from the LM iteration that found the switches moved (after an accepted step) and is
+    // installed where multigrid operators are next built — both points depend on the solve's own history only, never on timing
+    std::thread mg_job; std::unique_ptr<MgPrepared> mg_job_out, mg_job_old; bool mg_job_running = false;
+    int rc_job = 0;
     uint64_t mg_geometry_epoch = 0;
     int64_t n_vio = 0;
     // matrix-free operator
@@ -180,6 +202,7 @@ struct pgo_problem {
     int mg_switch_at = 400;              // in-flight switch point of the current LM system (build_system)
     int cg_extra = 0;                    // PCG iterations of the current LM step spent before a change of preconditioner
     bool mg_failed = false;              // the multigrid operators of the current system could not be built
+    bool mg_start_deferred = false;      // the current system is predicted hard, but its multigrid operators are built only once the step has survived the first early-rejection pause
 };
 
 namespace {
@@ -249,187 +272,216 @@ int host_allreduce(pgo_problem* p, std::vector<double>& v, int op);
 // The aggregation multigrid's hierarchy for the graph of this handle and the given switch values (host array over the caller's switches, or null): host-side structure
 // (pgo_mg_host.hpp), pooled device arrays, level descriptors.  Called by build_graph, and again inside a solve when the switch values have moved far from the ones the
 // hierarchy was built with (regroup): the levels above level 1 are matched along the couplings that are alive NOW.  p->mg_cache keeps what does not depend on the switches.
-int build_multigrid(pgo_problem* p, const double* sw_now) {
+// host half: hierarchy + pooled index arrays.  Reads the handle's edge lists, options and mg_cache only (single rank: no HIP, no collective -> may run on a worker thread)
+int mg_prepare(pgo_problem* p, const double* sw_now, MgPrepared& Q) {
     const int64_t N = p->N, Ng = p->N_global, S = p->S;
     const int64_t Er = p->rel.size(), Es = p->swe.size();
     int rc;
+    const double t0 = now_s();
+    pgo_mg::Hierarchy& H = Q.H;
+    const int dense_max = std::max(1, std::min(p->opt.mg_dense_max_nodes, 512));
+    // smoothed prolongators (denser coarse operators, two more row products per cycle on each such level) pay while the coarse levels are latency-bound: measured
+    // C4 (200k keyframes) 3.56 -> 2.37 s, C5 (1M keyframes, level 1 = 125k nodes: bandwidth-bound) 8.5 -> 11.1 s.  -1 = by size; with them aggregates of 4 above level 1, else of 8
+    const double loop_discount = std::max(0.0, p->opt.mg_loop_discount);
+    const int n_smoothed = p->opt.mg_smoothed_levels < 0 ? (Ng <= 500000 ? 1 : 0) : std::min(p->opt.mg_smoothed_levels, MG_MAX_LEVELS);
+    const int passes0 = std::max(1, std::min(p->opt.mg_first_passes, 3)), passes = p->opt.mg_passes <= 0 ? (n_smoothed > 0 ? 2 : 3) : std::min(p->opt.mg_passes, 3);
+    std::vector<double> sw_w;
+    if (sw_now && S > 0) { sw_w.resize((size_t)Es); for (int64_t e = 0; e < Es; ++e) { const double sv = sw_now[p->swe.sw[e]]; sw_w[e] = sv * sv; } }
+    Q.sw_built.assign((size_t)Es, 1.0);
+    if (!sw_w.empty()) Q.sw_built = sw_w;
+    bool ok;
+    std::vector<int32_t>& agg0_l = Q.agg0_l; std::vector<int32_t>& mem0_ptr_l = Q.mem0_ptr_l; std::vector<int32_t>& mem0_l = Q.mem0_l;
+    std::vector<double>& inv_cnt = Q.inv_cnt;
+    if (!p->local_ids) {
+        ok = pgo_mg::build_hierarchy(N, p->h_node_free, p->rel.c1, p->rel.c2, p->rel.meas.data() + 7, 8, p->swe.c1, p->swe.c2, sw_w.empty() ? nullptr : sw_w.data(), passes0, passes, dense_max, MG_TILE_ROWS,
+                                     MG_MAX_LEVELS, H, false, MG_BLOCK0, nullptr, n_smoothed, loop_discount, &p->mg_cache);
+    } else {
+        // Several ranks: every rank gathers the endpoints and weights of ALL edges (one all-reduce of a zero-padded buffer: 24 B per edge, once per graph build)
+        // and builds the same hierarchy from the global graph; its own edges and owned keyframes are what it contributes to level 1 (pgo_mg_host.hpp).
+        std::vector<double> cnt((size_t)2 * p->world, 0.0);
+        cnt[(size_t)2 * p->rank] = (double)Er; cnt[(size_t)2 * p->rank + 1] = (double)Es;
+        if ((rc = host_allreduce(p, cnt, 0)) != PGO_OK) return rc;
+        int64_t ErT = 0, EsT = 0, my_r = 0, my_s = 0;
+        for (int r = 0; r < p->world; ++r) { if (r == p->rank) { my_r = ErT; my_s = EsT; } ErT += (int64_t)(cnt[(size_t)2 * r] + 0.5); EsT += (int64_t)(cnt[(size_t)2 * r + 1] + 0.5); }
+        std::vector<double> buf((size_t)3 * (ErT + EsT), 0.0);
+        double* b_rc1 = buf.data(); double* b_rc2 = b_rc1 + ErT; double* b_rw = b_rc2 + ErT; double* b_sc1 = b_rw + ErT; double* b_sc2 = b_sc1 + EsT; double* b_sw = b_sc2 + EsT;
+        for (int64_t e = 0; e < Er; ++e) { b_rc1[my_r + e] = p->rel.c1[e]; b_rc2[my_r + e] = p->rel.c2[e]; b_rw[my_r + e] = p->rel.meas[(size_t)8 * e + 7]; }
+        for (int64_t e = 0; e < Es; ++e) { b_sc1[my_s + e] = p->swe.c1[e]; b_sc2[my_s + e] = p->swe.c2[e]; b_sw[my_s + e] = sw_w.empty() ? 1.0 : sw_w[e]; }
+        if ((rc = host_allreduce(p, buf, 0)) != PGO_OK) return rc;
+        std::vector<int32_t> grc1((size_t)ErT), grc2((size_t)ErT), gsc1((size_t)EsT), gsc2((size_t)EsT);
+        std::vector<double> grw(b_rw, b_rw + ErT), gsw(b_sw, b_sw + EsT);
+        for (int64_t e = 0; e < ErT; ++e) { grc1[e] = (int32_t)(b_rc1[e] + 0.5); grc2[e] = (int32_t)(b_rc2[e] + 0.5); }
+        for (int64_t e = 0; e < EsT; ++e) { gsc1[e] = (int32_t)(b_sc1[e] + 0.5); gsc2[e] = (int32_t)(b_sc2[e] + 0.5); }
+        std::vector<uint8_t> gfree((size_t)Ng);
+        for (int64_t g = 0; g < Ng; ++g) gfree[g] = p->h_touched_any[g];
+        for (int32_t c : p->constant_nodes) if (c >= 0 && c < Ng) gfree[c] = 0;
+        const pgo_mg::LocalContrib local{&p->l2g, &p->h_own, &p->rel.c1, &p->rel.c2, &p->swe.c1, &p->swe.c2};
+        ok = pgo_mg::build_hierarchy(Ng, gfree, grc1, grc2, grw.data(), 1, gsc1, gsc2, (sw_now && S > 0) ? gsw.data() : nullptr, passes0, passes, dense_max, MG_TILE_ROWS, MG_MAX_LEVELS, H, false, 0, &local, n_smoothed, loop_discount, &p->mg_cache);
+        if (ok) {
+            const int32_t n1g = (int32_t)H.mem0_ptr.size() - 1;
+            inv_cnt.resize((size_t)n1g);
+            for (int32_t a = 0; a < n1g; ++a) inv_cnt[a] = 1.0 / (double)std::max(1, H.mem0_ptr[a + 1] - H.mem0_ptr[a]);
+            agg0_l.resize((size_t)N); mem0_ptr_l.assign((size_t)n1g + 1, 0);
+            for (int64_t l = 0; l < N; ++l) { agg0_l[l] = p->h_node_free[l] ? H.agg0[p->l2g[l]] : -1; if (agg0_l[l] >= 0) mem0_ptr_l[(size_t)agg0_l[l] + 1]++; }
+            for (int32_t a = 0; a < n1g; ++a) mem0_ptr_l[(size_t)a + 1] += mem0_ptr_l[a];
+            mem0_l.resize((size_t)mem0_ptr_l[n1g]);
+            std::vector<int32_t> fillm(mem0_ptr_l.begin(), mem0_ptr_l.end() - 1);
+            for (int64_t l = 0; l < N; ++l) if (agg0_l[l] >= 0) mem0_l[(size_t)fillm[agg0_l[l]]++] = (int32_t)l;
+        }
+    }
+    Q.ok = ok;
+    if (!ok) return PGO_OK;
+    const std::vector<int32_t>& A0 = p->local_ids ? agg0_l : H.agg0;
+    const std::vector<int32_t>& M0P = p->local_ids ? mem0_ptr_l : H.mem0_ptr;
+    const std::vector<int32_t>& M0 = p->local_ids ? mem0_l : H.mem0;
+    const int nl = (int)H.L.size();
+    // pooled arrays: (offset, count) per array; doubles rounded up to even counts (16-B loads)
+    std::vector<int32_t>& pi32 = Q.pi32; std::vector<int64_t>& pi64 = Q.pi64;
+    auto put32 = [&](const std::vector<int32_t>& v) { const size_t o = pi32.size(); pi32.insert(pi32.end(), v.begin(), v.end()); return o; };
+    auto put64 = [&](const std::vector<int64_t>& v) { const size_t o = pi64.size(); pi64.insert(pi64.end(), v.begin(), v.end()); return o; };
+    size_t& nf64 = Q.nf64;
+    auto take = [&](size_t cnt) { const size_t o = nf64; nf64 += (cnt + 1) & ~(size_t)1; return o; };
+    Q.off.assign((size_t)nl, MgPrepared::Off{});
+    Q.o_agg0 = put32(A0); Q.o_mem0_ptr = put32(M0P); Q.o_mem0 = put32(M0);
+    // slot table of the restriction inside the vector update: per run of MG_BLOCK0 keyframes its aggregates {id, 8 members as run-local bytes}
+    bool have_tab = !p->local_ids;
+    if (have_tab) {
+        const int64_t runs = (N + MG_BLOCK0 - 1) / MG_BLOCK0;
+        std::vector<int32_t> tab((size_t)runs * MG_BLOCK0 * 4);
+        for (size_t k = 0; k < tab.size(); k += 4) { tab[k] = -1; tab[k + 1] = -1; tab[k + 2] = -1; tab[k + 3] = 0; }
+        std::vector<int> fill((size_t)runs, 0);
+        const int32_t n1h = (int32_t)H.mem0_ptr.size() - 1;
+        for (int32_t a = 0; a < n1h && have_tab; ++a) {
+            const int32_t m0 = H.mem0_ptr[a], m1 = H.mem0_ptr[a + 1];
+            if (m1 <= m0) continue;
+            const int64_t run = H.mem0[m0] / MG_BLOCK0;
+            if (m1 - m0 > 8 || fill[run] >= MG_BLOCK0) { have_tab = false; break; }
+            uint32_t w[2] = {0xffffffffu, 0xffffffffu};
+            for (int32_t m = m0; m < m1; ++m) {
+                if (H.mem0[m] / MG_BLOCK0 != run) { have_tab = false; break; }
+                const int j = m - m0;
+                w[j >> 2] = (w[j >> 2] & ~(0xffu << (8 * (j & 3)))) | ((uint32_t)(H.mem0[m] - run * MG_BLOCK0) << (8 * (j & 3)));
+            }
+            int32_t* e = &tab[((size_t)run * MG_BLOCK0 + fill[run]++) * 4];
+            e[0] = a; e[1] = (int32_t)w[0]; e[2] = (int32_t)w[1];
+        }
+        if (have_tab) { while (pi32.size() % 4) pi32.push_back(0); Q.o_blk_tab = put32(tab); }
+    }
+    Q.have_tab = have_tab;
+    Q.o_d0 = take((size_t)N * 3);
+    const size_t n1_all = (size_t)H.L[0].n;
+    Q.o_inv = p->local_ids ? take(n1_all) : 0; Q.o_q1 = p->local_ids ? take(n1_all * 6) : 0; Q.o_s1 = p->local_ids ? take(n1_all * 6) : 0;
+    for (int l = 0; l < nl; ++l) {
+        const pgo_mg::HostLevel& A = H.L[l];
+        MgPrepared::Off& o = Q.off[l];
+        o.col = put32(A.col); o.parent = put32(A.parent); o.agg_ptr = put32(A.agg_ptr);
+        {   // per tile {a0, a1, i0, i1}, 16-B aligned
+            std::vector<int32_t> info;
+            for (size_t tt = 0; tt + 1 < A.tile_agg0.size(); ++tt) { const int32_t a0 = A.tile_agg0[tt], a1 = A.tile_agg0[tt + 1]; info.insert(info.end(), {a0, a1, A.agg_ptr[a0], A.agg_ptr[a1]}); }
+            while (pi32.size() % 4) pi32.push_back(0);
+            o.tile = put32(info);
+            std::vector<int32_t> rows;      // [tile][MG_TILE_ROWS] {first block, end block} of each row of the tile
+            for (size_t tt = 0; tt + 1 < A.tile_agg0.size(); ++tt) {
+                const int32_t i0 = A.agg_ptr[A.tile_agg0[tt]], i1 = A.agg_ptr[A.tile_agg0[tt + 1]];
+                for (int li = 0; li < MG_TILE_ROWS; ++li) { const int32_t r = i0 + li; rows.push_back(r < i1 ? (int32_t)A.rowptr[r] : 0); rows.push_back(r < i1 ? (int32_t)A.rowptr[r + 1] : 0); }
+            }
+            o.tile_rows = put32(rows);
+        }
+        o.rowptr = put64(A.rowptr); o.g_ptr = put64(A.g_ptr); o.g_ent = put64(A.g_ent);
+        o.val = take(A.col.size() * 36); o.Dinv = take((size_t)A.n * 36); o.pos = take((size_t)A.n * 3); o.d = take((size_t)A.n * 3);
+        o.r = take((size_t)A.n * 6); o.x = take((size_t)A.n * 6); o.xt = take((size_t)A.n * 6); o.xf = take((size_t)A.n * 6);
+        o.valf = take((A.col.size() * 36 + 1) / 2);      // fp32 copy of the blocks, carved out of the fp64 pool
+        if (A.smoothed) {
+            o.ps_rowptr = put32(A.ps_rowptr); o.ps_col = put32(A.ps_col); o.w_rowptr = put32(A.w_rowptr); o.w_col = put32(A.w_col);
+            o.psT_ptr = put64(A.psT_ptr); o.psT_ent = put64(A.psT_ent);
+            o.ps_val = take(A.ps_col.size() * 36); o.w_val = take(A.w_col.size() * 36);
+            o.t = take((size_t)A.n * 6); o.u = take((size_t)A.n * 6); o.y = take((size_t)A.n * 6); o.zero = take((size_t)A.n * 6);
+        }
+    }
+    Q.host_ms = (now_s() - t0) * 1e3;
+    return PGO_OK;
+}
+
+// device half: pools (re)allocated, index arrays uploaded, level descriptors filled.  The stream must not be running multigrid kernels of the previous hierarchy.
+int mg_install(pgo_problem* p, MgPrepared& Q) {
+    const int64_t N = p->N;
     p->coarse_built = false; p->coarse_active = false; p->K = CoarseDev{};
     p->mg_built = false; p->mg_active = false; p->M = MgDev{}; p->mg_geometry_epoch = 0;
-    if (p->opt.mg_min_keyframes > 0 && Ng >= p->opt.mg_min_keyframes) {      // (the caller's keyframe count decides: the same answer on every rank)
-        pgo_mg::Hierarchy H;
-        const int dense_max = std::max(1, std::min(p->opt.mg_dense_max_nodes, 512));
-        // smoothed prolongators (denser coarse operators, two more row products per cycle on each such level) pay while the coarse levels are latency-bound: measured
-        // C4 (200k keyframes) 3.56 -> 2.37 s, C5 (1M keyframes, level 1 = 125k nodes: bandwidth-bound) 8.5 -> 11.1 s.  -1 = by size; with them aggregates of 4 above level 1, else of 8
-        const double loop_discount = std::max(0.0, p->opt.mg_loop_discount);
-        const int n_smoothed = p->opt.mg_smoothed_levels < 0 ? (Ng <= 500000 ? 1 : 0) : std::min(p->opt.mg_smoothed_levels, MG_MAX_LEVELS);
-        const int passes0 = std::max(1, std::min(p->opt.mg_first_passes, 3)), passes = p->opt.mg_passes <= 0 ? (n_smoothed > 0 ? 2 : 3) : std::min(p->opt.mg_passes, 3);
-        std::vector<double> sw_w;
-        if (sw_now && S > 0) { sw_w.resize((size_t)Es); for (int64_t e = 0; e < Es; ++e) { const double sv = sw_now[p->swe.sw[e]]; sw_w[e] = sv * sv; } }
-        bool ok;
-        std::vector<int32_t> agg0_l, mem0_ptr_l, mem0_l;      // several ranks: the keyframe-indexed arrays in the handle's local numbering
-        std::vector<double> inv_cnt;
-        if (!p->local_ids) {
-            ok = pgo_mg::build_hierarchy(N, p->h_node_free, p->rel.c1, p->rel.c2, p->rel.meas.data() + 7, 8, p->swe.c1, p->swe.c2, sw_w.empty() ? nullptr : sw_w.data(), passes0, passes, dense_max, MG_TILE_ROWS,
-                                         MG_MAX_LEVELS, H, false, MG_BLOCK0, nullptr, n_smoothed, loop_discount, &p->mg_cache);
-        } else {
-            // Several ranks: every rank gathers the endpoints and weights of ALL edges (one all-reduce of a zero-padded buffer: 24 B per edge, once per graph build)
-            // and builds the same hierarchy from the global graph; its own edges and owned keyframes are what it contributes to level 1 (pgo_mg_host.hpp).
-            std::vector<double> cnt((size_t)2 * p->world, 0.0);
-            cnt[(size_t)2 * p->rank] = (double)Er; cnt[(size_t)2 * p->rank + 1] = (double)Es;
-            if ((rc = host_allreduce(p, cnt, 0)) != PGO_OK) return rc;
-            int64_t ErT = 0, EsT = 0, my_r = 0, my_s = 0;
-            for (int r = 0; r < p->world; ++r) { if (r == p->rank) { my_r = ErT; my_s = EsT; } ErT += (int64_t)(cnt[(size_t)2 * r] + 0.5); EsT += (int64_t)(cnt[(size_t)2 * r + 1] + 0.5); }
-            std::vector<double> buf((size_t)3 * (ErT + EsT), 0.0);
-            double* b_rc1 = buf.data(); double* b_rc2 = b_rc1 + ErT; double* b_rw = b_rc2 + ErT; double* b_sc1 = b_rw + ErT; double* b_sc2 = b_sc1 + EsT; double* b_sw = b_sc2 + EsT;
-            for (int64_t e = 0; e < Er; ++e) { b_rc1[my_r + e] = p->rel.c1[e]; b_rc2[my_r + e] = p->rel.c2[e]; b_rw[my_r + e] = p->rel.meas[(size_t)8 * e + 7]; }
-            for (int64_t e = 0; e < Es; ++e) { b_sc1[my_s + e] = p->swe.c1[e]; b_sc2[my_s + e] = p->swe.c2[e]; b_sw[my_s + e] = sw_w.empty() ? 1.0 : sw_w[e]; }
-            if ((rc = host_allreduce(p, buf, 0)) != PGO_OK) return rc;
-            std::vector<int32_t> grc1((size_t)ErT), grc2((size_t)ErT), gsc1((size_t)EsT), gsc2((size_t)EsT);
-            std::vector<double> grw(b_rw, b_rw + ErT), gsw(b_sw, b_sw + EsT);
-            for (int64_t e = 0; e < ErT; ++e) { grc1[e] = (int32_t)(b_rc1[e] + 0.5); grc2[e] = (int32_t)(b_rc2[e] + 0.5); }
-            for (int64_t e = 0; e < EsT; ++e) { gsc1[e] = (int32_t)(b_sc1[e] + 0.5); gsc2[e] = (int32_t)(b_sc2[e] + 0.5); }
-            std::vector<uint8_t> gfree((size_t)Ng);
-            for (int64_t g = 0; g < Ng; ++g) gfree[g] = p->h_touched_any[g];
-            for (int32_t c : p->constant_nodes) if (c >= 0 && c < Ng) gfree[c] = 0;
-            const pgo_mg::LocalContrib local{&p->l2g, &p->h_own, &p->rel.c1, &p->rel.c2, &p->swe.c1, &p->swe.c2};
-            ok = pgo_mg::build_hierarchy(Ng, gfree, grc1, grc2, grw.data(), 1, gsc1, gsc2, (sw_now && S > 0) ? gsw.data() : nullptr, passes0, passes, dense_max, MG_TILE_ROWS, MG_MAX_LEVELS, H, false, 0, &local, n_smoothed, loop_discount, &p->mg_cache);
-            if (ok) {
-                const int32_t n1g = (int32_t)H.mem0_ptr.size() - 1;
-                inv_cnt.resize((size_t)n1g);
-                for (int32_t a = 0; a < n1g; ++a) inv_cnt[a] = 1.0 / (double)std::max(1, H.mem0_ptr[a + 1] - H.mem0_ptr[a]);
-                agg0_l.resize((size_t)N); mem0_ptr_l.assign((size_t)n1g + 1, 0);
-                for (int64_t l = 0; l < N; ++l) { agg0_l[l] = p->h_node_free[l] ? H.agg0[p->l2g[l]] : -1; if (agg0_l[l] >= 0) mem0_ptr_l[(size_t)agg0_l[l] + 1]++; }
-                for (int32_t a = 0; a < n1g; ++a) mem0_ptr_l[(size_t)a + 1] += mem0_ptr_l[a];
-                mem0_l.resize((size_t)mem0_ptr_l[n1g]);
-                std::vector<int32_t> fillm(mem0_ptr_l.begin(), mem0_ptr_l.end() - 1);
-                for (int64_t l = 0; l < N; ++l) if (agg0_l[l] >= 0) mem0_l[(size_t)fillm[agg0_l[l]]++] = (int32_t)l;
-            }
-        }
-        const std::vector<int32_t>& A0 = p->local_ids ? agg0_l : H.agg0;
-        const std::vector<int32_t>& M0P = p->local_ids ? mem0_ptr_l : H.mem0_ptr;
-        const std::vector<int32_t>& M0 = p->local_ids ? mem0_l : H.mem0;
-        if (ok) {
-            const int nl = (int)H.L.size();
-            // pooled arrays: (offset, count) per array; doubles rounded up to even counts (16-B loads)
-            std::vector<int32_t> pi32; std::vector<int64_t> pi64;
-            auto put32 = [&](const std::vector<int32_t>& v) { const size_t o = pi32.size(); pi32.insert(pi32.end(), v.begin(), v.end()); return o; };
-            auto put64 = [&](const std::vector<int64_t>& v) { const size_t o = pi64.size(); pi64.insert(pi64.end(), v.begin(), v.end()); return o; };
-            size_t nf64 = 0;
-            auto take = [&](size_t cnt) { const size_t o = nf64; nf64 += (cnt + 1) & ~(size_t)1; return o; };
-            struct Off { size_t col, parent, agg_ptr, tile, tile_rows, rowptr, g_ptr, g_ent, val, Dinv, pos, d, r, x, xt, xf, valf, ps_rowptr, ps_col, w_rowptr, w_col, psT_ptr, psT_ent, ps_val, w_val, t, u, y, zero; };
-            std::vector<Off> off((size_t)nl);
-            const size_t o_agg0 = put32(A0), o_mem0_ptr = put32(M0P), o_mem0 = put32(M0);
-            // slot table of the restriction inside the vector update: per run of MG_BLOCK0 keyframes its aggregates {id, 8 members as run-local bytes}
-            size_t o_blk_tab = 0; bool have_tab = !p->local_ids;
-            if (have_tab) {
-                const int64_t runs = (N + MG_BLOCK0 - 1) / MG_BLOCK0;
-                std::vector<int32_t> tab((size_t)runs * MG_BLOCK0 * 4);
-                for (size_t k = 0; k < tab.size(); k += 4) { tab[k] = -1; tab[k + 1] = -1; tab[k + 2] = -1; tab[k + 3] = 0; }
-                std::vector<int> fill((size_t)runs, 0);
-                const int32_t n1h = (int32_t)H.mem0_ptr.size() - 1;
-                for (int32_t a = 0; a < n1h && have_tab; ++a) {
-                    const int32_t m0 = H.mem0_ptr[a], m1 = H.mem0_ptr[a + 1];
-                    if (m1 <= m0) continue;
-                    const int64_t run = H.mem0[m0] / MG_BLOCK0;
-                    if (m1 - m0 > 8 || fill[run] >= MG_BLOCK0) { have_tab = false; break; }
-                    uint32_t w[2] = {0xffffffffu, 0xffffffffu};
-                    for (int32_t m = m0; m < m1; ++m) {
-                        if (H.mem0[m] / MG_BLOCK0 != run) { have_tab = false; break; }
-                        const int j = m - m0;
-                        w[j >> 2] = (w[j >> 2] & ~(0xffu << (8 * (j & 3)))) | ((uint32_t)(H.mem0[m] - run * MG_BLOCK0) << (8 * (j & 3)));
-                    }
-                    int32_t* e = &tab[((size_t)run * MG_BLOCK0 + fill[run]++) * 4];
-                    e[0] = a; e[1] = (int32_t)w[0]; e[2] = (int32_t)w[1];
-                }
-                if (have_tab) { while (pi32.size() % 4) pi32.push_back(0); o_blk_tab = put32(tab); }
-            }
-            const size_t o_d0 = take((size_t)N * 3);
-            const size_t n1_all = (size_t)H.L[0].n;
-            const size_t o_inv = p->local_ids ? take(n1_all) : 0, o_q1 = p->local_ids ? take(n1_all * 6) : 0, o_s1 = p->local_ids ? take(n1_all * 6) : 0;
-            for (int l = 0; l < nl; ++l) {
-                const pgo_mg::HostLevel& A = H.L[l];
-                Off& o = off[l];
-                o.col = put32(A.col); o.parent = put32(A.parent); o.agg_ptr = put32(A.agg_ptr);
-                {   // per tile {a0, a1, i0, i1}, 16-B aligned
-                    std::vector<int32_t> info;
-                    for (size_t tt = 0; tt + 1 < A.tile_agg0.size(); ++tt) { const int32_t a0 = A.tile_agg0[tt], a1 = A.tile_agg0[tt + 1]; info.insert(info.end(), {a0, a1, A.agg_ptr[a0], A.agg_ptr[a1]}); }
-                    while (pi32.size() % 4) pi32.push_back(0);
-                    o.tile = put32(info);
-                    std::vector<int32_t> rows;      // [tile][MG_TILE_ROWS] {first block, end block} of each row of the tile
-                    for (size_t tt = 0; tt + 1 < A.tile_agg0.size(); ++tt) {
-                        const int32_t i0 = A.agg_ptr[A.tile_agg0[tt]], i1 = A.agg_ptr[A.tile_agg0[tt + 1]];
-                        for (int li = 0; li < MG_TILE_ROWS; ++li) { const int32_t r = i0 + li; rows.push_back(r < i1 ? (int32_t)A.rowptr[r] : 0); rows.push_back(r < i1 ? (int32_t)A.rowptr[r + 1] : 0); }
-                    }
-                    o.tile_rows = put32(rows);
-                }
-                o.rowptr = put64(A.rowptr); o.g_ptr = put64(A.g_ptr); o.g_ent = put64(A.g_ent);
-                o.val = take(A.col.size() * 36); o.Dinv = take((size_t)A.n * 36); o.pos = take((size_t)A.n * 3); o.d = take((size_t)A.n * 3);
-                o.r = take((size_t)A.n * 6); o.x = take((size_t)A.n * 6); o.xt = take((size_t)A.n * 6); o.xf = take((size_t)A.n * 6);
-                o.valf = take((A.col.size() * 36 + 1) / 2);      // fp32 copy of the blocks, carved out of the fp64 pool
-                if (A.smoothed) {
-                    o.ps_rowptr = put32(A.ps_rowptr); o.ps_col = put32(A.ps_col); o.w_rowptr = put32(A.w_rowptr); o.w_col = put32(A.w_col);
-                    o.psT_ptr = put64(A.psT_ptr); o.psT_ent = put64(A.psT_ent);
-                    o.ps_val = take(A.ps_col.size() * 36); o.w_val = take(A.w_col.size() * 36);
-                    o.t = take((size_t)A.n * 6); o.u = take((size_t)A.n * 6); o.y = take((size_t)A.n * 6); o.zero = take((size_t)A.n * 6);
-                }
-            }
-            const int n_top = H.L[nl - 1].n;
-            const int nc = (6 * n_top + 63) / 64 * 64;
-            HIPCHK(p, p->d_mg_i32.ensure(std::max<size_t>(pi32.size(), 1))); HIPCHK(p, p->d_mg_i64.ensure(std::max<size_t>(pi64.size(), 1))); HIPCHK(p, p->d_mg_f64.ensure(std::max<size_t>(nf64, 2)));
-            HIPCHK(p, p->d_cAc.ensure((size_t)nc * nc)); HIPCHK(p, p->d_cAcf.ensure((size_t)nc * nc)); HIPCHK(p, p->d_crc.ensure((size_t)nc * 2)); HIPCHK(p, p->d_cscr.ensure((size_t)nc * 64 + 1024)); HIPCHK(p, p->d_cinfo.ensure(4));
-            HIPCHK(p, hipMemcpyAsync(p->d_mg_i32.p, pi32.data(), pi32.size() * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
-            HIPCHK(p, hipMemcpyAsync(p->d_mg_i64.p, pi64.data(), pi64.size() * sizeof(int64_t), hipMemcpyHostToDevice, p->st));
-            HIPCHK(p, hipMemsetAsync(p->d_mg_f64.p, 0, nf64 * sizeof(double), p->st));
-            HIPCHK(p, hipMemsetAsync(p->d_crc.p, 0, (size_t)nc * 2 * sizeof(double), p->st));
-            HIPCHK(p, hipStreamSynchronize(p->st));
-            const int32_t* b32 = p->d_mg_i32.p; const int64_t* b64 = p->d_mg_i64.p; double* bf = p->d_mg_f64.p;
-            p->M = MgDev{nl, H.L[0].n, b32 + o_agg0, b32 + o_mem0_ptr, b32 + o_mem0, bf + o_d0, have_tab ? reinterpret_cast<const int4*>(b32 + o_blk_tab) : nullptr, nullptr, nullptr, nullptr};
-            if (p->local_ids) {
-                HIPCHK(p, hipMemcpyAsync(bf + o_inv, inv_cnt.data(), inv_cnt.size() * sizeof(double), hipMemcpyHostToDevice, p->st));
-                HIPCHK(p, hipStreamSynchronize(p->st));
-                p->M.inv_cnt = bf + o_inv; p->M.q1 = bf + o_q1; p->M.s1 = bf + o_s1;
-            }
-            for (int l = 0; l < nl; ++l) {
-                const pgo_mg::HostLevel& A = H.L[l];
-                const Off& o = off[l];
-                MgLevelDev& D = p->mg_levels[l];
-                D = MgLevelDev{};
-                D.n = A.n; D.n_next = l + 1 < nl ? H.L[l + 1].n : 0; D.tiles = A.tile_agg0.empty() ? 0 : (int32_t)A.tile_agg0.size() - 1; D.nnzb = (int64_t)A.col.size();
-                D.rowptr = b64 + o.rowptr; D.col = b32 + o.col; D.val = bf + o.val; D.g_ptr = b64 + o.g_ptr; D.g_ent = b64 + o.g_ent;
-                D.Dinv = bf + o.Dinv; D.pos = bf + o.pos; D.d = bf + o.d; D.parent = b32 + o.parent; D.agg_ptr = b32 + o.agg_ptr; D.tile_info = reinterpret_cast<const int4*>(b32 + o.tile); D.tile_rows = reinterpret_cast<const int2*>(b32 + o.tile_rows);
-                D.r = bf + o.r; D.x = bf + o.x; D.xt = bf + o.xt; D.xf = bf + o.xf; D.valf = reinterpret_cast<float*>(bf + o.valf);
-                D.seg_shift = A.seg >= 4 ? 2 : A.seg >= 2 ? 1 : 0;
-                if (A.smoothed) {
-                    D.smoothed = 1; D.n_ps = (int32_t)A.ps_col.size(); D.n_w = (int32_t)A.w_col.size();
-                    D.ps_rowptr = b32 + o.ps_rowptr; D.ps_col = b32 + o.ps_col; D.w_rowptr = b32 + o.w_rowptr; D.w_col = b32 + o.w_col; D.psT_ptr = b64 + o.psT_ptr; D.psT_ent = b64 + o.psT_ent;
-                    D.ps_val = bf + o.ps_val; D.w_val = bf + o.w_val; D.t = bf + o.t; D.u = bf + o.u; D.y = bf + o.y; D.zero = bf + o.zero;
-                }
-            }
-            // the dense coarsest level shares the buffers of the two-level preconditioner, which the multigrid replaces on this graph
-            p->coarse_built = false;
-            p->K = CoarseDev{};
-            p->K.n_agg = n_top; p->K.nc = nc; p->K.Ac = p->d_cAc.p; p->K.Acf = p->d_cAcf.p; p->K.rc = p->d_crc.p; p->K.yc = p->d_crc.p + nc;
-            p->mg_built = true;
-            if (p->opt.verbosity > 0) {
-                std::fprintf(stderr, "[pgo] multigrid: %lld keyframes", (long long)N);
-                for (int l = 0; l < nl; ++l) std::fprintf(stderr, " -> %d (%lld blocks%s)", H.L[l].n, (long long)H.L[l].col.size(), H.L[l].smoothed ? ", smoothed prolongator above" : "");
-                std::fprintf(stderr, ", coarsest dense %d\n", nc);
-            }
-        } else if (p->opt.verbosity > 0) std::fprintf(stderr, "[pgo] multigrid: the graph does not coarsen (isolated keyframes?) -> off\n");
+    if (!Q.ok) { if (p->opt.verbosity > 0) std::fprintf(stderr, "[pgo] multigrid: the graph does not coarsen (isolated keyframes?) -> off\n"); return PGO_OK; }
+    const pgo_mg::Hierarchy& H = Q.H;
+    const int nl = (int)H.L.size();
+    const std::vector<int32_t>& pi32 = Q.pi32; const std::vector<int64_t>& pi64 = Q.pi64; const size_t nf64 = Q.nf64;
+    const int n_top = H.L[nl - 1].n;
+    const int nc = (6 * n_top + 63) / 64 * 64;
+    HIPCHK(p, p->d_mg_i32.ensure(std::max<size_t>(pi32.size(), 1))); HIPCHK(p, p->d_mg_i64.ensure(std::max<size_t>(pi64.size(), 1))); HIPCHK(p, p->d_mg_f64.ensure(std::max<size_t>(nf64, 2)));
+    HIPCHK(p, p->d_cAc.ensure((size_t)nc * nc)); HIPCHK(p, p->d_cAcf.ensure((size_t)nc * nc)); HIPCHK(p, p->d_crc.ensure((size_t)nc * 2)); HIPCHK(p, p->d_cscr.ensure((size_t)nc * 64 + 1024)); HIPCHK(p, p->d_cinfo.ensure(4));
+    HIPCHK(p, hipMemcpyAsync(p->d_mg_i32.p, pi32.data(), pi32.size() * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
+    HIPCHK(p, hipMemcpyAsync(p->d_mg_i64.p, pi64.data(), pi64.size() * sizeof(int64_t), hipMemcpyHostToDevice, p->st));
+    HIPCHK(p, hipMemsetAsync(p->d_mg_f64.p, 0, nf64 * sizeof(double), p->st));
+    HIPCHK(p, hipMemsetAsync(p->d_crc.p, 0, (size_t)nc * 2 * sizeof(double), p->st));
+    HIPCHK(p, hipStreamSynchronize(p->st));
+    const int32_t* b32 = p->d_mg_i32.p; const int64_t* b64 = p->d_mg_i64.p; double* bf = p->d_mg_f64.p;
+    p->M = MgDev{nl, H.L[0].n, b32 + Q.o_agg0, b32 + Q.o_mem0_ptr, b32 + Q.o_mem0, bf + Q.o_d0, Q.have_tab ? reinterpret_cast<const int4*>(b32 + Q.o_blk_tab) : nullptr, nullptr, nullptr, nullptr};
+    if (p->local_ids) {
+        HIPCHK(p, hipMemcpyAsync(bf + Q.o_inv, Q.inv_cnt.data(), Q.inv_cnt.size() * sizeof(double), hipMemcpyHostToDevice, p->st));
+        HIPCHK(p, hipStreamSynchronize(p->st));
+        p->M.inv_cnt = bf + Q.o_inv; p->M.q1 = bf + Q.o_q1; p->M.s1 = bf + Q.o_s1;
     }
-    // ---- two-level preconditioner: aggregates of consecutive keyframes and, per coarse 6x6 block (a <= b), the ordered list of fine
-    // blocks that project onto it (single GPU; enough keyframes per aggregate to be worth it)
-    if (p->mg_built) {
-        p->mg_sw_built.assign((size_t)Es, 1.0);
-        if (sw_now && S > 0) for (int64_t e = 0; e < Es; ++e) { const double sv = sw_now[p->swe.sw[e]]; p->mg_sw_built[e] = sv * sv; }
+    for (int l = 0; l < nl; ++l) {
+        const pgo_mg::HostLevel& A = H.L[l];
+        const MgPrepared::Off& o = Q.off[l];
+        MgLevelDev& D = p->mg_levels[l];
+        D = MgLevelDev{};
+        D.n = A.n; D.n_next = l + 1 < nl ? H.L[l + 1].n : 0; D.tiles = A.tile_agg0.empty() ? 0 : (int32_t)A.tile_agg0.size() - 1; D.nnzb = (int64_t)A.col.size();
+        D.rowptr = b64 + o.rowptr; D.col = b32 + o.col; D.val = bf + o.val; D.g_ptr = b64 + o.g_ptr; D.g_ent = b64 + o.g_ent;
+        D.Dinv = bf + o.Dinv; D.pos = bf + o.pos; D.d = bf + o.d; D.parent = b32 + o.parent; D.agg_ptr = b32 + o.agg_ptr; D.tile_info = reinterpret_cast<const int4*>(b32 + o.tile); D.tile_rows = reinterpret_cast<const int2*>(b32 + o.tile_rows);
+        D.r = bf + o.r; D.x = bf + o.x; D.xt = bf + o.xt; D.xf = bf + o.xf; D.valf = reinterpret_cast<float*>(bf + o.valf);
+        D.seg_shift = A.seg >= 4 ? 2 : A.seg >= 2 ? 1 : 0;
+        if (A.smoothed) {
+            D.smoothed = 1; D.n_ps = (int32_t)A.ps_col.size(); D.n_w = (int32_t)A.w_col.size();
+            D.ps_rowptr = b32 + o.ps_rowptr; D.ps_col = b32 + o.ps_col; D.w_rowptr = b32 + o.w_rowptr; D.w_col = b32 + o.w_col; D.psT_ptr = b64 + o.psT_ptr; D.psT_ent = b64 + o.psT_ent;
+            D.ps_val = bf + o.ps_val; D.w_val = bf + o.w_val; D.t = bf + o.t; D.u = bf + o.u; D.y = bf + o.y; D.zero = bf + o.zero;
+        }
+    }
+    // the dense coarsest level shares the buffers of the two-level preconditioner, which the multigrid replaces on this graph
+    p->K.n_agg = n_top; p->K.nc = nc; p->K.Ac = p->d_cAc.p; p->K.Acf = p->d_cAcf.p; p->K.rc = p->d_crc.p; p->K.yc = p->d_crc.p + nc;
+    p->mg_built = true;
+    p->mg_sw_built.swap(Q.sw_built);
+    if (p->opt.verbosity > 0) {
+        std::fprintf(stderr, "[pgo] multigrid: %lld keyframes", (long long)N);
+        for (int l = 0; l < nl; ++l) std::fprintf(stderr, " -> %d (%lld blocks%s)", H.L[l].n, (long long)H.L[l].col.size(), H.L[l].smoothed ? ", smoothed prolongator above" : "");
+        std::fprintf(stderr, ", coarsest dense %d (host %.1f ms)\n", nc, Q.host_ms);
     }
     if (p->local_ids) {
         // the exchange buffer is sized here once for everything a solve sends (42 doubles per shared keyframe at linearisation; 6 + the level-1 vector in the PCG),
         // so its address is stable: the multigrid's q1 = P0^T (A u) is produced straight into its tail
-        const size_t n1 = p->mg_built ? (size_t)p->M.n1 : 0;
+        const size_t n1 = (size_t)p->M.n1;
         HIPCHK(p, p->d_xbuf.ensure((size_t)p->n_sh_global * 42 + 2 + 6 * n1 + 64));
-        if (p->mg_built) p->M.q1 = p->d_xbuf.p + (size_t)p->n_sh_global * 6 + 2;
+        p->M.q1 = p->d_xbuf.p + (size_t)p->n_sh_global * 6 + 2;
     }
+    return PGO_OK;
+}
+
+// a regroup in flight is waited for and dropped (its result belongs to a solve state that is gone, or the graph is about to change)
+void mg_job_cancel(pgo_problem* p) {
+    if (p->mg_job.joinable()) p->mg_job.join();
+    p->mg_job_running = false; p->mg_job_out.reset();
+}
+
+// The aggregation multigrid's hierarchy for the graph of this handle and the given switch values (host array over the caller's switches, or null): host-side structure
+// (pgo_mg_host.hpp), pooled device arrays, level descriptors.  Called by build_graph, and again when the switch values have moved far from the ones the hierarchy was
+// built with (regroup): the levels above level 1 are matched along the couplings that are alive NOW.  p->mg_cache keeps what does not depend on the switches.
+int build_multigrid(pgo_problem* p, const double* sw_now) {
+    int rc;
+    mg_job_cancel(p);
+    p->coarse_built = false; p->coarse_active = false; p->K = CoarseDev{};
+    p->mg_built = false; p->mg_active = false; p->M = MgDev{}; p->mg_geometry_epoch = 0;
+    if (p->opt.mg_min_keyframes > 0 && p->N_global >= p->opt.mg_min_keyframes) {      // (the caller's keyframe count decides: the same answer on every rank)
+        MgPrepared Q;
+        if ((rc = mg_prepare(p, sw_now, Q)) != PGO_OK) return rc;
+        if ((rc = mg_install(p, Q)) != PGO_OK) return rc;
+    }
+    if (p->local_ids && !p->mg_built) HIPCHK(p, p->d_xbuf.ensure((size_t)p->n_sh_global * 42 + 2 + 64));
     return PGO_OK;
 }
 
@@ -905,6 +957,7 @@ int linearize(pgo_problem* p, double* cost_out) {
 
 static int build_mg(pgo_problem* p);
 static int regroup_if_moved(pgo_problem* p, const double* sv, bool in_solve);
+static int regroup_start(pgo_problem* p);
 // c = w_p / w of the smoothed prolongators (Dinv holds w D^-1)
 double mg_cs(const pgo_problem* p) {
     const double om = p->opt.mg_omega > 0.0 && p->opt.mg_omega <= 1.0 ? p->opt.mg_omega : 0.9;
@@ -917,7 +970,7 @@ struct CgResult { int iterations; bool breakdown; double rel_residual; bool conv
 
 // rel_tol: relative tolerance of this phase.  resume_from >= 0: continue the stopped PCG at that iteration index with the new tolerance
 // (device state x, r, z, p and the partial sums are those of `resume_from` completed iterations).
-int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume_from) {
+int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume_from, bool switch_now = false) {
     const pgo_options& o = p->opt;
     int rc0;
     const double tol2 = rel_tol * rel_tol;
@@ -1050,7 +1103,9 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
             for (int j = 0; j < every; ++j) (void)one_iteration(2 + j);
             ok = hipStreamEndCapture(p->st, &gr) == hipSuccess && gr != nullptr;
         }
+        const double t_inst = now_s();
         if (ok) ok = hipGraphInstantiate(&cc.exec, gr, nullptr, nullptr, 0) == hipSuccess;
+        if (o.verbosity > 1) std::fprintf(stderr, "[pgo] PCG chunk of %d iterations (preconditioner %d) captured, instantiated in %.2f ms\n", every, mode, (now_s() - t_inst) * 1e3);
         if (gr) (void)hipGraphDestroy(gr);
         if (!ok) { cc.exec = nullptr; p->cg_graph_failed = true; (void)hipGetLastError(); }
         else { cc.epoch = p->build_epoch; cc.len = every; cc.scale = mg_scale(p); }
@@ -1067,6 +1122,29 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
         HIPCHK(p, hipEventRecord(p->poll_ev[slot], p->st));
         return PGO_OK;
     };
+    // block-Jacobi -> multigrid inside one system: operators built now, PCG restarted from the current iterate (`so_far` iterations are booked as cg_extra)
+    auto switch_to_mg = [&](int so_far) -> int {
+        int rcs;
+        if ((rcs = build_mg(p)) != PGO_OK) return rcs;
+        if (!p->mg_active) { p->mg_failed = true; return PGO_OK; }
+        p->cg_extra += so_far;
+        if (p->built_mf) launch_mf_apply(p->G, p->F, p->Sc, p->C, p->C.x, p->C.q, p->st);
+        else launch_apply_operator(p->G, p->C, p->C.x, p->C.q, p->st);
+        if (multi) {
+            if ((rcs = exchange_rows(p, p->C.q, 6, nullptr, 0, nullptr, 0)) != PGO_OK) return rcs;
+            if ((rcs = start_multi(1)) != PGO_OK) return rcs;
+        } else {
+            const int g = launch_cg_init_vectors(p->G, p->C, 1, p->st);
+            launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz, mg_scale(p), false, p->st, false, mg_cs(p));
+            launch_cg_init_scalars(p->C, g, tol2, p->st);
+        }
+        k = 0; n_chunks = 0; waited = -1; r1_refreshed_at = 0;
+        every = chunk_length();
+        ensure_graph(true);      // a system that needed the switch is a long one
+        return PGO_OK;
+    };
+    // a system predicted hard whose step has survived the first early-rejection pause (lm_step): the multigrid takes over from the iterate the pause left
+    if (switch_now && resume_from >= 0 && p->mg_built && !p->mg_active && !p->mg_failed && (rc = switch_to_mg(resume_from)) != PGO_OK) return rc;
     while (k < o.cg_max_iterations && !done) {
         const int chunk = std::min(every, o.cg_max_iterations - k);
         if (multi && p->mg_active && k - r1_refreshed_at >= every) {
@@ -1106,22 +1184,7 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
             HIPCHK(p, hipMemcpyAsync(hflags, p->C.flags, sizeof(hflags), hipMemcpyDeviceToHost, p->st));
             HIPCHK(p, hipStreamSynchronize(p->st));
             if (hflags[0]) { done = true; (void)enqueue_poll(n_chunks & 1); ++n_chunks; break; }
-            if ((rc = build_mg(p)) != PGO_OK) return rc;
-            if (!p->mg_active) { p->mg_failed = true; continue; }
-            p->cg_extra += hflags[2];
-            if (p->built_mf) launch_mf_apply(p->G, p->F, p->Sc, p->C, p->C.x, p->C.q, p->st);
-            else launch_apply_operator(p->G, p->C, p->C.x, p->C.q, p->st);
-            if (multi) {
-                if ((rc = exchange_rows(p, p->C.q, 6, nullptr, 0, nullptr, 0)) != PGO_OK) return rc;
-                if ((rc = start_multi(1)) != PGO_OK) return rc;
-            } else {
-                const int g = launch_cg_init_vectors(p->G, p->C, 1, p->st);
-                launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz, mg_scale(p), false, p->st, false, mg_cs(p));
-                launch_cg_init_scalars(p->C, g, tol2, p->st);
-            }
-            k = 0; n_chunks = 0; waited = -1; r1_refreshed_at = 0;
-            every = chunk_length();
-            ensure_graph(true);      // a system that needed the switch is a long one
+            if ((rc = switch_to_mg(hflags[2])) != PGO_OK) return rc;
         }
     }
     if (n_chunks > 0) {   // the state after the LAST enqueued chunk is the final one (kernels past convergence do nothing)
@@ -1188,13 +1251,19 @@ static int build_coarse(pgo_problem* p) {
 // multigrid operators are about to be built and the switch values have moved far from the hierarchy's (switchable edges that moved by > 0.5 in s^2 make up more than mg_regroup_fraction of ALL
 // edges), the levels above level 1 are matched again along the couplings alive NOW (the keyframes' level-1 aggregates, matched along relative-pose edges only, and the
 // level-1 structure are cached: pgo_mg::BuildCache) — at most twice per solve.  Several ranks: the count is all-reduced, every rank regroups at the same LM step.
-static int regroup_if_moved(pgo_problem* p, const double* sv /* host: the caller's switch array */, bool in_solve) {
+// how many switchable edges have moved by > 0.5 in s^2 since the hierarchy was matched, against ALL residual blocks (what counts is how much of the coupling structure
+// changed: C4 has 2 % loop closures — no regroup pays there); summed over the ranks
+static int regroup_count(pgo_problem* p, const double* sv, std::vector<double>& cnt) {
     const int64_t Es = p->swe.size();
-    std::vector<double> cnt(2, 0.0);
+    cnt.assign(2, 0.0);
     for (int64_t e = 0; e < Es; ++e) { const double w = sv[p->swe.sw[e]] * sv[p->swe.sw[e]]; if (std::fabs(w - p->mg_sw_built[e]) > 0.5) cnt[0] += 1.0; }
-    cnt[1] = (double)(Es + p->rel.size());      // against ALL residual blocks: what counts is how much of the coupling structure changed (C4: 2 % of its edges are loop closures — no regroup pays there)
+    cnt[1] = (double)(Es + p->rel.size());
+    return p->local_ids ? host_allreduce(p, cnt, 0) : PGO_OK;
+}
+static int regroup_if_moved(pgo_problem* p, const double* sv /* host: the caller's switch array */, bool in_solve) {
+    std::vector<double> cnt;
     int rc;
-    if (p->local_ids && (rc = host_allreduce(p, cnt, 0)) != PGO_OK) return rc;
+    if ((rc = regroup_count(p, sv, cnt)) != PGO_OK) return rc;
     if (!(cnt[0] > p->opt.mg_regroup_fraction * cnt[1])) return PGO_OK;
     const double t0 = now_s();
     if ((rc = build_multigrid(p, sv)) != PGO_OK) return rc;
@@ -1203,22 +1272,69 @@ static int regroup_if_moved(pgo_problem* p, const double* sv /* host: the caller
     if (p->opt.verbosity > 0) std::fprintf(stderr, "[pgo] multigrid: regrouped %s (%.0f switchable edges of %.0f edges moved), %.1f ms\n", in_solve ? "inside the solve" : "for the new start", cnt[0], cnt[1], (now_s() - t0) * 1e3);
     return PGO_OK;
 }
-static int maybe_regroup(pgo_problem* p) {
-    const int64_t Es = p->swe.size();
+static bool regroup_allowed(const pgo_problem* p) {
     // (not during the first three LM iterations: the switches of outliers — and of inliers far from the odometry guess, which recover — are still falling then: measured on C3,
     // 17 % of the switchable edges have moved after the first step, and a regroup there is paid twice)
-    if (!(p->opt.mg_regroup_fraction > 0.0) || !p->mg_built || p->S <= 0 || p->mg_regroups >= 2 || p->iteration <= 3 || (int64_t)p->mg_sw_built.size() != Es) return PGO_OK;
+    return p->opt.mg_regroup_fraction > 0.0 && p->mg_built && p->S > 0 && p->mg_regroups < 2 && p->iteration >= 3 && (int64_t)p->mg_sw_built.size() == p->swe.size();
+}
+// several ranks: the regroup happens where multigrid operators are about to be built, synchronously (its host half holds collectives) — every rank at the same LM step
+static int maybe_regroup(pgo_problem* p) {
+    if (!regroup_allowed(p) || p->iteration <= 3) return PGO_OK;
     std::vector<double> sv((size_t)p->S);
     HIPCHK(p, hipMemcpyAsync(sv.data(), p->d_swv[p->cur].p, sv.size() * sizeof(double), hipMemcpyDeviceToHost, p->st));
     HIPCHK(p, hipStreamSynchronize(p->st));
     return regroup_if_moved(p, sv.data(), true);
 }
+// One GPU: the HOST half of a regroup (≈25 ms for C3: matching of the upper levels, structures of the smoothed transition, pooled arrays) starts on a worker thread right
+// after the accepted step that moved the switches far enough, and is installed where multigrid operators are next built (regroup_install) — on C3 that is a dozen cheap
+// block-Jacobi LM steps later, so the solve never waits for it.  Which step starts it and which step installs it depend on the solve's own history only.
+static int regroup_start(pgo_problem* p) {
+    if (p->local_ids || p->mg_job_running || !regroup_allowed(p)) return PGO_OK;
+    std::vector<double> sv((size_t)p->S);
+    HIPCHK(p, hipMemcpyAsync(sv.data(), p->d_swv[p->cur].p, sv.size() * sizeof(double), hipMemcpyDeviceToHost, p->st));
+    HIPCHK(p, hipStreamSynchronize(p->st));
+    std::vector<double> cnt;
+    int rc;
+    if ((rc = regroup_count(p, sv.data(), cnt)) != PGO_OK) return rc;
+    if (!(cnt[0] > p->opt.mg_regroup_fraction * cnt[1])) return PGO_OK;
+    ++p->mg_regroups;
+    p->mg_job_out.reset(new MgPrepared());
+    p->mg_job_out->moved = cnt[0]; p->mg_job_out->of_edges = cnt[1];
+    p->mg_job_running = true; p->rc_job = PGO_OK;
+    MgPrepared* Q = p->mg_job_out.get();
+    MgPrepared* old_image = p->mg_job_old.release();
+    p->mg_job = std::thread([p, Q, old_image, sv = std::move(sv)]() { delete old_image; p->rc_job = mg_prepare(p, sv.data(), *Q); });
+    return PGO_OK;
+}
+static int regroup_install(pgo_problem* p) {
+    if (!p->mg_job_running) return PGO_OK;
+    const double t0 = now_s();
+    if (p->mg_job.joinable()) p->mg_job.join();
+    p->mg_job_running = false;
+    std::unique_ptr<MgPrepared> Q = std::move(p->mg_job_out);
+    if (p->rc_job != PGO_OK || !Q) return p->rc_job;
+    const double waited = (now_s() - t0) * 1e3;
+    int rc;
+    HIPCHK(p, hipStreamSynchronize(p->st));
+    if ((rc = mg_install(p, *Q)) != PGO_OK) return rc;
+    ++p->build_epoch;      // captured PCG chunks hold pointers into the old pools
+    // The host image is NOT freed here: it was allocated by the worker thread (an mmap-backed malloc arena), and returning ~100 MB of it to the system from this thread
+    // costs 5 ms of munmap plus a ~10 ms stall of the next kernels (measured: MMU-notifier invalidations reach the GPU's address space).  It is kept until the next
+    // regroup's worker (or pgo_destroy) drops it, off the solve's critical path.
+    p->mg_job_old = std::move(Q);
+    MgPrepared* Qk = p->mg_job_old.get();
+    if (p->opt.verbosity > 0) std::fprintf(stderr, "[pgo] multigrid: regrouped inside the solve (%.0f switchable edges of %.0f edges moved): host half %.1f ms on a worker thread, waited %.1f ms, installed in %.1f ms\n",
+                                           Qk->moved, Qk->of_edges, Qk->host_ms, waited, (now_s() - t0) * 1e3 - waited);
+    return PGO_OK;
+}
 
 static int build_mg(pgo_problem* p) {
     p->mg_active = false;
     if (!p->mg_built) return PGO_OK;
-    { int rcr; if ((rcr = maybe_regroup(p)) != PGO_OK) return rcr; }
+    const double t_build0 = now_s();
+    { int rcr; if ((rcr = p->local_ids ? maybe_regroup(p) : regroup_install(p)) != PGO_OK) return rcr; }
     if (!p->mg_built) return PGO_OK;
+    if (p->opt.verbosity > 1) std::fprintf(stderr, "[pgo] multigrid: build_mg past the regroup at %.2f ms\n", (now_s() - t_build0) * 1e3);
     int rcm;
     if (p->mg_geometry_epoch != p->lin_epoch) {              // the aggregates' centroids follow the poses of the current linearisation
         if (p->local_ids) {     // a level-1 node's keyframes live on several ranks: owner-weighted position sums, one all-reduce, then as on one GPU
@@ -1235,7 +1351,13 @@ static int build_mg(pgo_problem* p) {
         launch_mg_galerkin0(p->G, p->L, p->Sc, p->C, p->M, p->mg_levels, p->st);
         if ((rcm = allreduce(p, p->mg_levels[0].val, (size_t)p->mg_levels[0].nnzb * 36, 0)) != PGO_OK) return rcm;
         launch_mg_assemble_rest(p->M, p->mg_levels, p->K, omega, fail, p->st, mg_cs(p));
+    } else if (p->opt.verbosity > 1) {
+        HIPCHK(p, hipStreamSynchronize(p->st)); std::fprintf(stderr, "[pgo] multigrid: geometry done at %.2f ms\n", (now_s() - t_build0) * 1e3);
+        launch_mg_galerkin0(p->G, p->L, p->Sc, p->C, p->M, p->mg_levels, p->st);
+        HIPCHK(p, hipStreamSynchronize(p->st)); std::fprintf(stderr, "[pgo] multigrid: galerkin0 done at %.2f ms\n", (now_s() - t_build0) * 1e3);
+        launch_mg_assemble_rest(p->M, p->mg_levels, p->K, omega, fail, p->st, mg_cs(p));
     } else launch_mg_assemble(p->G, p->L, p->Sc, p->C, p->M, p->mg_levels, p->K, omega, fail, p->st, mg_cs(p));
+    if (p->opt.verbosity > 1) { HIPCHK(p, hipStreamSynchronize(p->st)); std::fprintf(stderr, "[pgo] multigrid: level operators done at %.2f ms\n", (now_s() - t_build0) * 1e3); }
     launch_coarse_invert(p->K, p->d_cscr.p, fail, p->st);
     int32_t h = 1;
     HIPCHK(p, hipMemcpyAsync(&h, fail, sizeof(h), hipMemcpyDeviceToHost, p->st));
@@ -1246,6 +1368,7 @@ static int build_mg(pgo_problem* p) {
     const int t1 = p->mg_levels[0].tiles;
     p->C.extra_rz = (p->mg_active && !p->local_ids && p->M.n_levels >= 2 && (t1 <= MAX_PARTIALS || t1 >= 2 * MAX_PARTIALS)) ? std::min<int>(t1, MAX_PARTIALS) : 0;
     if (p->opt.verbosity > 0 && h != 0) std::fprintf(stderr, "[pgo] multigrid: a coarse block is not positive definite at radius %.1e -> off for this iteration\n", p->radius);
+    if (p->opt.verbosity > 1) std::fprintf(stderr, "[pgo] multigrid: operators of LM iteration %d built in %.2f ms\n", p->iteration, (now_s() - t_build0) * 1e3);
     return PGO_OK;
 }
 
@@ -1264,21 +1387,31 @@ int build_system(pgo_problem* p, bool* ok) {
         fail = f[0] != 0.0;
     }
     *ok = fail == 0;
-    p->mg_active = false; p->mg_failed = false; p->C.extra_rz = 0;
+    p->mg_active = false; p->mg_failed = false; p->C.extra_rz = 0; p->mg_start_deferred = false;
     if (*ok && p->mg_built) {
         // Which preconditioner the PCG of this LM system starts with.  Block-Jacobi iterations grow like sqrt(radius) from one accepted step
         // to the next, so the previous step of this solve predicts this one (a multigrid iteration counts as 4 block-Jacobi ones: it costs
-        // ~2.5x and saves 4x or more on hard systems):  predicted >= 2.25 x mg_switch_iterations -> multigrid from the first iteration;
+        // ~2.5x and saves 4x or more on hard systems):  predicted >= 1.75 x mg_switch_iterations -> multigrid (from the first iteration, or after the prelude below);
         // predicted easier than that -> block-Jacobi, and the in-flight switch of run_pcg waits for twice the prediction (switching 400
         // iterations into a system that needs 520 throws the work away); no prediction (first step, after a rejected one) -> block-Jacobi with
         // the switch at mg_switch_iterations.  Depends on this solve's own history only.
         double predicted = 0.0;
         // (round 3, with the smoothed cycle: start factors 1.0 - 2.25, waiting factors 1.5 - 2.0 and switch points 200 - 600 all within +-2 % on C3 and C4)
-        const double start_factor = 2.25, wait_factor = 2.0;
+        // (with the deferred start and the regroup off the critical path, session 2 of round 3: start 1.0 - 2.25 x wait 1.5 / 2.0 on C3 0.311 - 0.333 s, C4 1.498 - 1.542 s; 1.75 / 2.0 is the best pair on both)
+        const double start_factor = 1.75, wait_factor = 2.0;
         if (p->cg_prev_radius > 0.0 && p->radius > 0.0) predicted = p->cg_prev_equiv * std::sqrt(p->radius / p->cg_prev_radius);
         p->mg_switch_at = p->opt.mg_switch_iterations;
         if (predicted > 0.0 && predicted < start_factor * (double)p->opt.mg_switch_iterations) p->mg_switch_at = std::max(p->opt.mg_switch_iterations, (int)(wait_factor * predicted));
-        if ((p->opt.mg_switch_iterations <= 0 || predicted >= start_factor * (double)p->opt.mg_switch_iterations) && (rc = build_mg(p)) != PGO_OK) return rc;
+        // A system predicted hard gets the multigrid from the first iteration — unless the step can still be rejected early: most steps that ARE rejected follow a long
+        // accepted one at a large radius, i.e. exactly the systems predicted hard, and block-Jacobi reaches the first pause (cg_early_tolerance, a few dozen iterations)
+        // for a fraction of what the operators cost (C3, step 4: 32 ms for a step thrown away at 21 iterations).  Then the build waits for the pause (lm_step).
+        const bool hard = p->opt.mg_switch_iterations <= 0 || predicted >= start_factor * (double)p->opt.mg_switch_iterations;
+        p->mg_start_deferred = hard && p->opt.mg_switch_iterations > 0 && p->opt.cg_early_tolerance > p->opt.cg_rel_tolerance;
+        if (p->mg_start_deferred) {      // ... but not for long: a step that has not reached the pause within the prelude is a hard one that stays (late C3 systems need ~300 block-Jacobi iterations to 1e-2)
+            const int prelude = 72;      // three chunks (measured on C3 / C4, 20 steps: 48 -> 0.392 / 1.500 s — C3's rejected step 4 needs 53 —, 72 -> 0.322 / 1.515 s, 96 -> 0.324 / 1.524 s)
+            p->mg_switch_at = std::min(p->mg_switch_at, prelude);
+        }
+        if (hard && !p->mg_start_deferred && (rc = build_mg(p)) != PGO_OK) return rc;
     }
     else if (*ok && (rc = build_coarse(p)) != PGO_OK) return rc;
     return PGO_OK;
@@ -1302,6 +1435,7 @@ int solve_begin(pgo_problem* p, const double* quat, const double* t, const doubl
     int rc;
     if ((rc = set_device(p)) != PGO_OK) return rc;
     p->t_begin = now_s();
+    mg_job_cancel(p);
     if (p->graph_dirty || p->priors_dirty || N != p->N_global || S != p->S) { if ((rc = build_graph(p, N, S, sw)) != PGO_OK) return rc; }
     else if (p->opt.mg_regroup_fraction > 0.0 && p->mg_built && S > 0 && sw && (int64_t)p->mg_sw_built.size() == p->swe.size()) {
         // the hierarchy of an unchanged graph was built (or regrouped inside the last solve) for other switch values than this solve starts from: the levels above level 1
@@ -1400,7 +1534,11 @@ int lm_step(pgo_problem* p, int ignore_termination, int* done) {
             const bool clear_reject = mc > 0.0 && std::isfinite(mc) && std::isfinite(cand) && dc / mc < stages[sidx].reject_rho &&
                                       sn > o.parameter_tolerance * (p->x_norm + o.parameter_tolerance) && std::fabs(dc) > o.function_tolerance * p->x_cost;
             if (clear_reject) evaluated = true;
-            else if ((rc = run_pcg(p, &cg, false, sidx + 1 < n_stages ? stages[sidx + 1].tol : o.cg_rel_tolerance, cg.iterations)) != PGO_OK) return rc;
+            else {
+                const bool to_mg = p->mg_start_deferred && !p->mg_active;
+                p->mg_start_deferred = false;
+                if ((rc = run_pcg(p, &cg, false, sidx + 1 < n_stages ? stages[sidx + 1].tol : o.cg_rel_tolerance, cg.iterations, to_mg)) != PGO_OK) return rc;
+            }
         }
         // The coarse space pays by a large factor or not at all (it can even cost iterations on chains that odometry weights cut into
         // many loose pieces), so once per solve — at the first full-accuracy step that used it — plain block-Jacobi gets the SAME
@@ -1447,6 +1585,7 @@ int lm_step(pgo_problem* p, int ignore_termination, int* done) {
         }
     }
     it.cg_iterations = cg.iterations + p->cg_extra; it.cg_residual = cg.rel_residual;
+    if (o.verbosity > 1) std::fprintf(stderr, "[pgo] it %3d PCG: %d iterations%s after %d with block-Jacobi, linear solve %.2f ms so far\n", p->iteration, cg.iterations, p->mg_active ? " with the multigrid" : "", p->cg_extra, (now_s() - t0) * 1e3);
     p->sum.cg_iterations += cg.iterations + p->cg_extra;
     if (p->mg_active) p->sum.cg_iterations_multigrid += cg.iterations;     // iterations before an in-flight switch (cg_extra) ran with block-Jacobi
     if (ok) {
@@ -1496,6 +1635,7 @@ int lm_step(pgo_problem* p, int ignore_termination, int* done) {
         p->radius = std::min(o.max_trust_region_radius, p->radius);
         p->decrease_factor = 2.0; p->reuse_diagonal = false;
         ++p->sum.num_successful_steps;
+        if ((rc = regroup_start(p)) != PGO_OK) return rc;     // the switches have moved: does the hierarchy above level 1 still fit them?
     } else {
         p->radius = p->radius / p->decrease_factor; p->decrease_factor *= 2.0; p->reuse_diagonal = true;   // StepRejected
         ++p->sum.num_unsuccessful_steps;
@@ -1564,6 +1704,7 @@ int solve_end(pgo_problem* p, double* quat, double* t, double* sw, pgo_summary* 
     // of graph) skip it, 1, 3, 7, 15 solves at a time, before comparing again; one win resets the back-off
     if (p->coarse_mode == 2 && !p->coarse_skip_all) { p->coarse_backoff = std::min(2 * p->coarse_backoff + 1, 15); p->coarse_skip = p->coarse_backoff; }
     if (p->coarse_mode == 1) ++p->coarse_keep_streak; else if (p->coarse_mode == 2 && !p->coarse_skip_all) p->coarse_keep_streak = 0;
+    mg_job_cancel(p);      // a regroup nobody needed any more: dropped (the hierarchy in place keeps its own switch record)
     p->sum.seconds_total = now_s() - p->t_begin;
     if (out) *out = p->sum;
     p->in_solve = false;
@@ -1573,6 +1714,7 @@ int solve_end(pgo_problem* p, double* quat, double* t, double* sw, pgo_summary* 
 int add_edges(pgo_problem* p, HostClass& H, int64_t n, const int32_t* c1, const int32_t* c2, const double* T, const double* w, const int32_t* sw) {
     if (n < 0 || (n > 0 && (!c1 || !c2 || !T))) { p->err = "null edge array"; return PGO_ERR_INVALID_ARG; }
     for (int64_t k = 0; k < n; ++k) if (c1[k] < 0 || c2[k] < 0 || c1[k] == c2[k] || (sw && sw[k] < 0)) { p->err = "negative index or self edge"; return PGO_ERR_INVALID_ARG; }
+    mg_job_cancel(p);      // (the worker reads the edge lists)
     const size_t base = H.c1.size();
     H.c1.insert(H.c1.end(), c1, c1 + n);
     H.c2.insert(H.c2.end(), c2, c2 + n);
@@ -1655,6 +1797,7 @@ int pgo_create(pgo_problem** out, const pgo_options* opts) {
 
 int pgo_destroy(pgo_problem* p) {
     if (!p) return PGO_ERR_INVALID_ARG;
+    mg_job_cancel(p);
     (void)hipSetDevice(p->device);
     if (p->comm && p->nccl.CommDestroy) p->nccl.CommDestroy(p->comm);
     (void)hipStreamSynchronize(p->st);
@@ -1682,6 +1825,7 @@ int pgo_destroy(pgo_problem* p) {
 int pgo_set_options(pgo_problem* p, const pgo_options* o) {
     if (!p || !o) return PGO_ERR_INVALID_ARG;
     const int dev = p->opt.device_id;
+    mg_job_cancel(p);
     if (o->linear_solver != p->opt.linear_solver) p->graph_dirty = true;
     // the preconditioner hierarchies are part of the device graph build
     if (o->mg_min_keyframes != p->opt.mg_min_keyframes || o->mg_first_passes != p->opt.mg_first_passes || o->mg_passes != p->opt.mg_passes ||
