@@ -17,6 +17,7 @@
 #include <cstdint>
 #include <numeric>
 #include <utility>
+#include <cstdlib>
 #include <vector>
 
 namespace pgo_mg {
@@ -31,7 +32,7 @@ struct HostLevel {                       // level l >= 1
     std::vector<int32_t> parent;         // [n] node of level l+1 (empty on the coarsest level); members of a parent are CONTIGUOUS
     std::vector<int32_t> agg_ptr;        // [n_next+1] first member of each parent
     std::vector<int32_t> tile_agg0;      // [tiles+1] workgroup tiles of whole aggregates, <= tile_rows / seg rows
-    int seg = 1;                         // lanes-of-a-row groups that share one block row in the level kernels (1, 2 or 4): long rows (smoothed Galerkin products) are split
+    int seg = 1;                         // lanes-of-a-row groups that share one block row in the level kernels (1, 2, 4 or 8): long rows (smoothed Galerkin products) are split
     // SMOOTHED transition to the level above (smoothed aggregation): the prolongator is Ps = (I - w_p D^-1 A) P instead of the tentative P (rigid motion of the
     // parent), the level above is the Galerkin product Ps^T A Ps.  Only its STRUCTURE is fixed here; the numbers follow the LM system (pgo_mg_kernels.hpp):
     bool smoothed = false;
@@ -422,7 +423,11 @@ inline bool build_hierarchy(int64_t N, const std::vector<uint8_t>& node_free, co
         int max_agg = 1;
         const int32_t n_next = H.L[l + 1].n;
         for (int32_t a = 0; a < n_next; ++a) max_agg = std::max(max_agg, Lv.agg_ptr[(size_t)a + 1] - Lv.agg_ptr[a]);
-        Lv.seg = mean_row > 28.0 ? 4 : mean_row > 14.0 ? 2 : 1;
+        // at most ~5 blocks per lane group, up to 8 groups per row (tiles of 4 rows): the level kernels are latency-bound, so what counts is how many of a row's loads are in
+        // flight at once.  Measured, 20 LM steps, C3 / C4: <= 14 blocks per group and at most 4 groups (the first rule) 0.315 / 1.505 s; <= 10: 0.298 / 1.436; <= 7: 0.298 / 1.442;
+        // <= 5: 0.291 / 1.417; <= 3.5: 0.290 / 1.471; <= 2.5: 0.299 / 1.468
+        Lv.seg = 1;
+        while (Lv.seg < 8 && mean_row > 5.0 * Lv.seg) Lv.seg *= 2;
         while (Lv.seg > 1 && tile_rows / Lv.seg < max_agg) Lv.seg /= 2;         // an aggregate never straddles tiles
         const int cap = tile_rows / Lv.seg;
         Lv.tile_agg0.clear();
