@@ -911,10 +911,20 @@ __global__ __launch_bounds__(CG_BLOCK) void cg_update_kernel(GraphDev G, CgDev C
     const int64_t stride = (int64_t)gridDim.x * CG_BLOCK;
     const int64_t trips = (pairs + stride - 1) / stride;
     // the first trip's operands do not depend on alpha: issue their loads BEFORE the partial-sum re-reduction so that its ~2 us of
-    // dependent L2 round trips overlap with the streaming loads
-    const int64_t i_first = (int64_t)blockIdx.x * CG_BLOCK + threadIdx.x;
-    double2 r0 = make_double2(0.0, 0.0), q0 = r0, p0 = r0, x0 = r0;
-    if (i_first < pairs) { r0 = rin[i_first]; q0 = qv[i_first]; p0 = pcur[i_first]; x0 = xv[i_first]; }
+    // dependent L2 round trips overlap with the streaming loads.  The block-Jacobi factors of the trip's keyframes (two 16-B loads per lane) travel
+    // with them — staged through registers, not behind a barrier of their own — and a second trip's operands are requested while the first
+    // trip's z is being formed: per trip ONE round trip and one barrier on the critical path.
+    auto load_trip = [&](int64_t base, double2& r_, double2& q_, double2& p_, double2& x_, float4& l0, float4& l1) {
+        const int64_t i = base + threadIdx.x;
+        r_ = make_double2(0.0, 0.0); q_ = r_; p_ = r_; x_ = r_; l0 = make_float4(0.f, 0.f, 0.f, 0.f); l1 = l0;
+        if (i < pairs) { r_ = rin[i]; q_ = qv[i]; p_ = pcur[i]; x_ = xv[i]; }
+        const int64_t first_node = base / 3;
+        const float4* lp = reinterpret_cast<const float4*>(C.Lf + (size_t)first_node * LF_STRIDE);
+        if (first_node + threadIdx.x / 6 < G.N) l0 = lp[threadIdx.x];
+        if (first_node + (threadIdx.x + CG_BLOCK) / 6 < G.N) l1 = lp[threadIdx.x + CG_BLOCK];
+    };
+    double2 r0, q0, p0, x0; float4 lf0, lf1;
+    load_trip((int64_t)blockIdx.x * CG_BLOCK, r0, q0, p0, x0, lf0, lf1);
     if (cg_done(C)) return;     // after the first trip's loads are in flight: the flag's round trip overlaps with theirs
     double pq, rz;   // pq partials are produced by the matvec kernel (its own grid size)
     block_total2(C.part_pq, nparts_pq, C.part_rz + parity * RZ_STRIDE, nparts + C.extra_rz, red, pq, rz);
@@ -926,6 +936,7 @@ __global__ __launch_bounds__(CG_BLOCK) void cg_update_kernel(GraphDev G, CgDev C
     const double alpha = rz / pq;
     __shared__ double2 rnew[CG_BLOCK];
     __shared__ __attribute__((aligned(16))) float lfs[KF * LF_STRIDE];
+    static_assert(KF * LF_STRIDE / 4 == 2 * CG_BLOCK, "two 16-B loads per lane stage a trip's factors");
     double acc = 0.0;
     for (int64_t it = 0; it < trips; ++it) {
         const int64_t base = it * stride + (int64_t)blockIdx.x * CG_BLOCK;
@@ -933,15 +944,14 @@ __global__ __launch_bounds__(CG_BLOCK) void cg_update_kernel(GraphDev G, CgDev C
         const bool live = i < pairs;
         double2 rr = make_double2(0.0, 0.0);
         if (live) {
-            if (it > 0) { r0 = rin[i]; q0 = qv[i]; p0 = pcur[i]; x0 = xv[i]; }
             rr = make_double2(r0.x - alpha * q0.x, r0.y - alpha * q0.y);
             x0.x += alpha * p0.x; x0.y += alpha * p0.y;
             rout[i] = rr; xv[i] = x0;
         }
-        __syncthreads();
-        lf_stage<KF>(C.Lf, base / 3, G.N, lfs);
+        reinterpret_cast<float4*>(lfs)[threadIdx.x] = lf0; reinterpret_cast<float4*>(lfs)[threadIdx.x + CG_BLOCK] = lf1;
         rnew[threadIdx.x] = rr;
         __syncthreads();
+        if (it + 1 < trips) load_trip(base + stride, r0, q0, p0, x0, lf0, lf1);
         if (live) {
             const int j = (int)(i % 3);
             const double2 z = lf_apply_pair(lfs + (threadIdx.x / 3) * LF_STRIDE, reinterpret_cast<const double*>(rnew + (threadIdx.x - j)), j);
@@ -949,6 +959,7 @@ __global__ __launch_bounds__(CG_BLOCK) void cg_update_kernel(GraphDev G, CgDev C
             const double w = G.own ? G.own[i / 3] : 1.0;
             acc += w * (rr.x * z.x + rr.y * z.y);
         }
+        if (it + 1 < trips) __syncthreads();      // the LDS buffers are rewritten by the next trip
     }
     const double s = block_sum(acc, red);
     if (threadIdx.x == 0) C.part_rz[(parity ^ 1) * RZ_STRIDE + blockIdx.x] = s;

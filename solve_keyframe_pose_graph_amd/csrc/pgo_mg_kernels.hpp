@@ -808,18 +808,35 @@ __global__ __launch_bounds__(CG_BLOCK) void cg_update_mg_kernel(GraphDev G, CgDe
     const int64_t pairs = G.N * 3;
     const int64_t stride = (int64_t)gridDim.x * CG_BLOCK;
     const int64_t trips = (pairs + stride - 1) / stride;
-    const int64_t i_first = (int64_t)blockIdx.x * CG_BLOCK + t;
-    double2 r0 = make_double2(0.0, 0.0), q0 = r0, p0 = r0, x0 = r0;
-    double d0 = 0.0, d1 = 0.0, d2 = 0.0;
-    int4 tab0 = make_int4(-1, -1, -1, 0), tab1 = tab0;
-    if (i_first < pairs) {
-        r0 = rin[i_first]; q0 = qv[i_first]; p0 = pcur[i_first]; x0 = xv[i_first];
-        const double* d = M.d0 + (size_t)(i_first / 3) * 3; d0 = d[0]; d1 = d[1]; d2 = d[2];
-    }
-    if ((int64_t)blockIdx.x * CG_BLOCK < pairs) {     // the run exists: its slots are served by all lanes, also those beyond the last keyframe
-        tab0 = M.blk_tab[(size_t)blockIdx.x * MG_BLOCK0 + t / 6];
-        tab1 = M.blk_tab[(size_t)blockIdx.x * MG_BLOCK0 + (t + CG_BLOCK) / 6];
-    }
+    // Everything a trip reads from global memory is requested together — residual / direction / solution / offsets, the block-Jacobi factors (two 16-B loads per lane, staged
+    // through registers), the run's slot table and, once that has arrived, the Dinv rows of its aggregates — for the first trip before the partial-sum re-reduction:
+    // one round trip (+ the table -> Dinv hop) and three barriers per trip instead of three round trips and seven barriers.
+    const int c6 = t % 6;
+    double2 r0, q0, p0, x0; double d0, d1, d2; float4 lf0, lf1; int4 tab0, tab1; double Dk0[6], Dk1[6];
+    auto load_trip = [&](int64_t run) {
+        const int64_t base = run * CG_BLOCK, i = base + t;
+        r0 = make_double2(0.0, 0.0); q0 = r0; p0 = r0; x0 = r0; d0 = d1 = d2 = 0.0;
+        lf0 = make_float4(0.f, 0.f, 0.f, 0.f); lf1 = lf0; tab0 = make_int4(-1, -1, -1, 0); tab1 = tab0;
+        if (base < pairs) {     // the run exists: its slots are served by all lanes, also those beyond the last keyframe
+            tab0 = M.blk_tab[(size_t)run * MG_BLOCK0 + t / 6];
+            tab1 = M.blk_tab[(size_t)run * MG_BLOCK0 + (t + CG_BLOCK) / 6];
+        }
+        if (i < pairs) {
+            r0 = rin[i]; q0 = qv[i]; p0 = pcur[i]; x0 = xv[i];
+            const double* d = M.d0 + (size_t)(i / 3) * 3; d0 = d[0]; d1 = d[1]; d2 = d[2];
+        }
+        const int64_t first_node = base / 3;
+        const float4* lp = reinterpret_cast<const float4*>(C.Lf + (size_t)first_node * LF_STRIDE);
+        if (first_node + t / 6 < G.N) lf0 = lp[t];
+        if (first_node + (t + CG_BLOCK) / 6 < G.N) lf1 = lp[t + CG_BLOCK];
+#pragma unroll
+        for (int jj = 0; jj < 6; ++jj) { Dk0[jj] = 0.0; Dk1[jj] = 0.0; }
+        if (x1_out) {
+            if (tab0.x >= 0) { const double2* Dp = reinterpret_cast<const double2*>(Dinv1 + (size_t)tab0.x * 36 + c6 * 6); const double2 u0 = Dp[0], u1 = Dp[1], u2 = Dp[2]; Dk0[0] = u0.x; Dk0[1] = u0.y; Dk0[2] = u1.x; Dk0[3] = u1.y; Dk0[4] = u2.x; Dk0[5] = u2.y; }
+            if (tab1.x >= 0) { const double2* Dp = reinterpret_cast<const double2*>(Dinv1 + (size_t)tab1.x * 36 + c6 * 6); const double2 u0 = Dp[0], u1 = Dp[1], u2 = Dp[2]; Dk1[0] = u0.x; Dk1[1] = u0.y; Dk1[2] = u1.x; Dk1[3] = u1.y; Dk1[4] = u2.x; Dk1[5] = u2.y; }
+        }
+    };
+    load_trip((int64_t)blockIdx.x);
     if (cg_done(C)) return;
     double pq, rz;
     block_total2(C.part_pq, nparts_pq, C.part_rz + parity * RZ_STRIDE, nparts + C.extra_rz, red, pq, rz);
@@ -831,8 +848,9 @@ __global__ __launch_bounds__(CG_BLOCK) void cg_update_mg_kernel(GraphDev G, CgDe
     const double alpha = rz / pq;
     __shared__ double2 rnew[CG_BLOCK];
     __shared__ double2 btr[CG_BLOCK];
-    __shared__ double rs[CG_BLOCK];
+    __shared__ double rs[2 * CG_BLOCK];
     __shared__ __attribute__((aligned(16))) float lfs[KF * LF_STRIDE];
+    static_assert(KF * LF_STRIDE / 4 == 2 * CG_BLOCK, "two 16-B loads per lane stage a trip's factors");
     double acc = 0.0;
     for (int64_t it = 0; it < trips; ++it) {
         const int64_t run = it * gridDim.x + blockIdx.x;
@@ -841,28 +859,21 @@ __global__ __launch_bounds__(CG_BLOCK) void cg_update_mg_kernel(GraphDev G, CgDe
         const bool live = i < pairs;
         double2 rr = make_double2(0.0, 0.0);
         if (live) {
-            if (it > 0) {
-                r0 = rin[i]; q0 = qv[i]; p0 = pcur[i]; x0 = xv[i];
-                const double* d = M.d0 + (size_t)(i / 3) * 3; d0 = d[0]; d1 = d[1]; d2 = d[2];
-            }
             rr = make_double2(r0.x - alpha * q0.x, r0.y - alpha * q0.y);
             x0.x += alpha * p0.x; x0.y += alpha * p0.y;
             rout[i] = rr; xv[i] = x0;
         }
-        if (it > 0) {
-            tab0.x = -1; tab1.x = -1;
-            if (base < pairs) { tab0 = M.blk_tab[(size_t)run * MG_BLOCK0 + t / 6]; tab1 = M.blk_tab[(size_t)run * MG_BLOCK0 + (t + CG_BLOCK) / 6]; }
-        }
-        __syncthreads();
-        lf_stage<KF>(C.Lf, base / 3, G.N, lfs);
+        reinterpret_cast<float4*>(lfs)[t] = lf0; reinterpret_cast<float4*>(lfs)[t + CG_BLOCK] = lf1;
         rnew[t] = rr;
+        const double e0 = d0, e1 = d1, e2 = d2;
+        const int4 tb0 = tab0, tb1 = tab1;
         __syncthreads();
         {
             const int j = t % 3;
             const double* r6 = reinterpret_cast<const double*>(rnew + (t - j));
             double2 b;
-            if (j == 0) b = make_double2(r6[0] + 2.0 * (d1 * r6[5] - d2 * r6[4]), r6[1] + 2.0 * (d2 * r6[3] - d0 * r6[5]));
-            else if (j == 1) b = make_double2(r6[2] + 2.0 * (d0 * r6[4] - d1 * r6[3]), r6[3]);
+            if (j == 0) b = make_double2(r6[0] + 2.0 * (e1 * r6[5] - e2 * r6[4]), r6[1] + 2.0 * (e2 * r6[3] - e0 * r6[5]));
+            else if (j == 1) b = make_double2(r6[2] + 2.0 * (e0 * r6[4] - e1 * r6[3]), r6[3]);
             else b = make_double2(r6[4], r6[5]);
             btr[t] = b;
             if (live) {
@@ -873,35 +884,40 @@ __global__ __launch_bounds__(CG_BLOCK) void cg_update_mg_kernel(GraphDev G, CgDe
         }
         __syncthreads();
         // r_1 of the run's aggregates: slot u / 6, component u % 6 (two rounds of the workgroup cover the MG_BLOCK0 slots)
+        double sum2[2];
 #pragma unroll
         for (int round = 0; round < 2; ++round) {
-            const int4 tb = round ? tab1 : tab0;
-            const int c = (t + round * CG_BLOCK) % 6;
+            const int4 tb = round ? tb1 : tb0;
             double sum = 0.0;
             if (tb.x >= 0) {
-                const double* col = reinterpret_cast<const double*>(btr) + c;
+                const double* col = reinterpret_cast<const double*>(btr) + c6;
                 const uint32_t lo = (uint32_t)tb.y, hi = (uint32_t)tb.z;
 #pragma unroll
                 for (int m = 0; m < 8; ++m) {
                     const uint32_t kf = ((m < 4 ? lo >> (8 * m) : hi >> (8 * (m - 4))) & 0xffu);
                     if (kf != 0xffu) sum += col[kf * 6];
                 }
-                r1_out[(size_t)tb.x * 6 + c] = sum;
+                r1_out[(size_t)tb.x * 6 + c6] = sum;
             }
-            if (x1_out) {
-                rs[t] = sum;
-                __syncthreads();
+            sum2[round] = sum;
+            rs[round * CG_BLOCK + t] = sum;
+        }
+        if (x1_out) {
+            __syncthreads();
+#pragma unroll
+            for (int round = 0; round < 2; ++round) {
+                const int4 tb = round ? tb1 : tb0;
                 if (tb.x >= 0) {
-                    const double* Dk = Dinv1 + (size_t)tb.x * 36 + c * 6;
-                    const double* ra = rs + (t - c);
+                    const double* ra = rs + round * CG_BLOCK + (t - c6);
                     double x = 0.0;
 #pragma unroll
-                    for (int jj = 0; jj < 6; ++jj) x += Dk[jj] * ra[jj];
-                    x1_out[(size_t)tb.x * 6 + c] = x;
+                    for (int jj = 0; jj < 6; ++jj) x += (round ? Dk1[jj] : Dk0[jj]) * ra[jj];
+                    x1_out[(size_t)tb.x * 6 + c6] = x;
                 }
-                __syncthreads();
             }
         }
+        (void)sum2;
+        if (it + 1 < trips) { load_trip(run + gridDim.x); __syncthreads(); }      // (a prefetch during this trip's arithmetic costs 70 VGPRs: 196, two waves per SIMD); the LDS buffers are rewritten by the next trip
     }
     const double s = block_sum(acc, red);
     if (threadIdx.x == 0) C.part_rz[(parity ^ 1) * RZ_STRIDE + blockIdx.x] = s;
