@@ -97,7 +97,9 @@ typedef struct pgo_options {
      * stage's threshold while the converged step would have cleared min_relative_decrease would be rejected here and accepted by Ceres; the
      * thresholds are far enough from min_relative_decrease that no such step has been seen (tests/test_gpu_fuzz.py compares the sequences
      * with the stages on and off over hundreds of graphs), but a caller that wants Ceres' exact decision rule sets both tolerances to 0.
-     * The `relative_decrease`, `cost_change` and `step_norm` logged for an early-rejected step are the values at the pause. */
+     * The `relative_decrease`, `cost_change` and `step_norm` logged for an early-rejected step are the values at the pause.
+     * Graphs below 20 000 keyframes (the reference's sessions: steps accepted almost throughout, short PCGs) arm the pauses only once a step of the solve has been
+     * rejected: a pause costs one candidate evaluation, ~0.1 ms (measured: a 400-keyframe trigger 20.8 -> 17.1 ms without them). */
     double cg_early_tolerance;           /* 1e-2: first stage (0 disables the stage) */
     double cg_early_reject_rho;          /* -0.5: threshold of the first stage — far below min_relative_decrease because the step is still crude */
     double cg_mid_tolerance;             /* 1e-4: second stage (0 disables the stage) */

@@ -1,5 +1,5 @@
 """Option scan: 20-step solves of C3 / C4 (or others) under sets of pgo_options.  python scripts/gpu_opt_scan3.py C3,C4 "mg_first_passes=2" "mg_first_passes=2,mg_passes=3" ...
-(the empty string "" = library defaults)."""
+(the empty string "" = library defaults; S<n> = a session-structured graph of n keyframes; iters=<k> sets the LM iteration budget)."""
 import sys
 sys.path.insert(0, '/root/repo')
 from solve_keyframe_pose_graph_amd import graphgen
@@ -7,7 +7,10 @@ from tests import util
 names = sys.argv[1].split(',')
 sets = sys.argv[2:] or [""]
 for name in names:
-    g = graphgen.config(name); q, t, s = util.initial_state(g, True)
+    if name.startswith('S'):      # session-structured graph of that many keyframes (f = 1..5 odometry with yaw weights, one loop closure per 5 keyframes, 2-degree turns)
+        n = int(name[1:]); g = graphgen.generate(n, n // 5, odom_f_max=5, apply_yaw_weight=1, seed=5, **dict(graphgen._SMALL, turn_deg_per_keyframe=2.0))
+    else: g = graphgen.config(name)
+    q, t, s = util.initial_state(g, True)
     for st in sets:
         kw = {}
         for item in (st.split(',') if st else []):

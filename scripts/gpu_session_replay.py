@@ -14,7 +14,8 @@ turn = float(sys.argv[4]) if len(sys.argv) > 4 else 15.0      # degrees per keyf
 g = graphgen.generate(n, loops, odom_f_max=5, apply_yaw_weight=1, seed=5, **dict(graphgen._SMALL, turn_deg_per_keyframe=turn))
 w_M = util.poses_to_matrices(g.init_q, g.init_t)
 order = np.argsort(np.maximum(g.loop_c1, g.loop_c2), kind="stable")
-S = PoseGraphSLAM()
+import os
+S = PoseGraphSLAM(verbosity=int(os.environ.get("PGO_VERB", "0")))
 O = ob.OracleProblem()
 k, rows, n_edges_prev = 0, [], 0
 for i in range(n):

@@ -137,6 +137,11 @@ bool PoseGraphSLAM::reinit_ceres_problem_onnewloopedge_optimize6DOF_once() {
     // A failed pgo_* call ends the wake-up at once: nothing after it runs, and the progress markers only move past what libpgo has
     // accepted (loop edges: prev_loopedge_len; odometry residues: odom_until_), so the next wake-up neither repeats nor loses blocks.
     auto failed = [this]() { status_ = 0; return false; };
+    // PGO_HOST_TIMING=1: wall time of the wake-up's steps on stderr (where a trigger's time goes besides pgo_solve)
+    static const bool timing = []() { const char* e = std::getenv("PGO_HOST_TIMING"); return e && e[0] == '1'; }();
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_mark = now();
+    auto mark = [&](const char* what) { if (timing) { const double t = now(); std::fprintf(stderr, "[pgo host] %-28s %8.3f ms\n", what, (t - t_mark) * 1e3); t_mark = t; } };
 
     // -0- new optimisation variables (:1340-1367)
     for (int yp = n_opt_variables(); yp < node_len; ++yp) allocate_and_append_new_opt_variable_withpose(Matrix4d::Identity());
@@ -178,6 +183,7 @@ bool PoseGraphSLAM::reinit_ceres_problem_onnewloopedge_optimize6DOF_once() {
     }
     added_edges_.insert(added_edges_.end(), pending.begin(), pending.end());
     prev_loopedge_len = loopedge_len;
+    mark("-0/1/2- variables, loop edges");
 
     // -3- odometry residues u <-> u-f, f = 1..5 (:1570-1639)
     const int su = solvedUntil();
@@ -194,12 +200,14 @@ bool PoseGraphSLAM::reinit_ceres_problem_onnewloopedge_optimize6DOF_once() {
             last_rc_ = pgo_set_vio_poses(problem_, resident, node_len - resident, fresh.data());
             if (last_rc_ != PGO_OK) return failed();
         }
+        mark("   -3- pgo_set_vio_poses");
         std::vector<int32_t> set_id((size_t)node_len, 0);
         for (int u = std::max(0, u_first - 5); u < node_len; ++u) set_id[u] = manager->find_setID_of_world_i(manager->which_world_is_this_node(u));
         int64_t before = 0, added = 0;
         if ((last_rc_ = pgo_num_relpose_edges(problem_, &before)) != PGO_OK) return failed();
         if (u_first < node_len && (last_rc_ = pgo_add_odometry_edges_from_vio(problem_, set_id.data(), u_first, node_len, 5, 1, &added)) != PGO_OK) return failed();
         odom_until_ = std::max(odom_until_, node_len);
+        mark("   -3- pgo_add_odometry_edges");
         if (added > 0) {
             std::vector<int32_t> a1((size_t)added), a2((size_t)added);
             std::vector<double> rec((size_t)added * 8);
@@ -228,6 +236,7 @@ bool PoseGraphSLAM::reinit_ceres_problem_onnewloopedge_optimize6DOF_once() {
         odom_until_ = std::max(odom_until_, node_len);
     }
 
+    mark("-3- odometry residues");
     // -4- initial guesses (:1649-1793)
     {
         const int s_until = su;
@@ -306,6 +315,7 @@ bool PoseGraphSLAM::reinit_ceres_problem_onnewloopedge_optimize6DOF_once() {
         if (last_rc_ != PGO_OK) return failed();
     }
 
+    mark("-4- initial guesses");
     // -5- node regularisation replaces the previous set (:1803-1877)
     regs_.clear();
     for (int ww = 0; ww < manager->n_worlds(); ++ww) {
@@ -324,6 +334,7 @@ bool PoseGraphSLAM::reinit_ceres_problem_onnewloopedge_optimize6DOF_once() {
     }
     changes_to_setid_on_set_union.clear();                                       // (:1882)
 
+    mark("-5- regularisers");
     // -6- solve WITHOUT holding the lock; single write-back at the end (:1891-1910)
     status_ = 2;
     std::vector<double> q, t, s;
@@ -333,6 +344,7 @@ bool PoseGraphSLAM::reinit_ceres_problem_onnewloopedge_optimize6DOF_once() {
     }
     init_quat_ = q; init_t_ = t;
     last_rc_ = pgo_solve(problem_, q.data(), t.data(), s.empty() ? nullptr : s.data(), (int64_t)(t.size() / 3), (int64_t)s.size(), &summary_);
+    mark("-6- pgo_solve");
     if (last_rc_ != PGO_OK) return failed();     // a library error (not a Ceres-style FAILURE): no write-back, solved_until stays
     {
         std::lock_guard<std::mutex> lk(mutex_opt_vars);

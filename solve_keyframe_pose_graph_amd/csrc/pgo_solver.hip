@@ -130,6 +130,7 @@ struct pgo_problem {
     DBuf<double> d_pose[2], d_swv[2], d_delta_s, d_io;   // state ping-pong, staging for quat/t
     DBuf<double> d_tmp;
     DBuf<double> d_vio;              // raw VIO poses [n_vio][16] (graph construction, K0)
+    DBuf<int32_t> d_vio_idx; DBuf<double> d_vio_meas;   // K0's edge endpoints and measurements of one call
     // two-level preconditioner (CoarseDev)
     DBuf<double> d_ccen, d_cd, d_cAc, d_crc, d_cscr;
     DBuf<float> d_cAcf;              // the dense inverse rounded to fp32
@@ -1521,8 +1522,14 @@ int lm_step(pgo_problem* p, int ignore_termination, int* done) {
         // remaining decades; otherwise the same PCG resumes towards the next tolerance.
         struct Stage { double tol, reject_rho; };
         Stage stages[2]; int n_stages = 0;
-        if (o.cg_early_tolerance > o.cg_rel_tolerance) stages[n_stages++] = Stage{o.cg_early_tolerance, o.cg_early_reject_rho};
-        if (o.cg_mid_tolerance > o.cg_rel_tolerance && (n_stages == 0 || o.cg_mid_tolerance < stages[0].tol)) stages[n_stages++] = Stage{o.cg_mid_tolerance, o.cg_mid_reject_rho};
+        // A pause costs one candidate evaluation (~0.1 ms: eight small launches and a host sync) and pays only when a step is rejected on a system whose PCG is expensive.  The
+        // reference's own sessions (hundreds to a few thousand keyframes, steps accepted almost throughout, PCGs of 20-100 iterations at ~14 us) only pay: measured 20.8 -> 17.1 ms
+        // on a 400-keyframe trigger, 63.2 -> 60.3 ms at 3 000.  So below CG_PAUSE_MIN_KEYFRAMES the pauses are armed by the first rejected step of the solve (a rejection is
+        // usually followed by more: the radius shrinks in several steps) — a rule that depends on the solve's own history only.
+        constexpr int64_t CG_PAUSE_MIN_KEYFRAMES = 20000;
+        const bool pauses = p->N_global >= CG_PAUSE_MIN_KEYFRAMES || p->sum.num_unsuccessful_steps > 0;
+        if (pauses && o.cg_early_tolerance > o.cg_rel_tolerance) stages[n_stages++] = Stage{o.cg_early_tolerance, o.cg_early_reject_rho};
+        if (pauses && o.cg_mid_tolerance > o.cg_rel_tolerance && (n_stages == 0 || o.cg_mid_tolerance < stages[0].tol)) stages[n_stages++] = Stage{o.cg_mid_tolerance, o.cg_mid_reject_rho};
         const bool warm = o.cg_warm_start != 0 && p->have_prev_step && p->reuse_diagonal;
         if ((rc = run_pcg(p, &cg, warm, n_stages ? stages[0].tol : o.cg_rel_tolerance, -1)) != PGO_OK) return rc;
         for (int sidx = 0; sidx < n_stages && !cg.breakdown && !evaluated; ++sidx) {
@@ -1791,6 +1798,20 @@ int pgo_create(pgo_problem** out, const pgo_options* opts) {
     if (hipHostMalloc((void**)&p->poll, 2 * sizeof(pgo_problem::Poll), hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&p->poll_ev[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&p->poll_ev[1], hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(p->st); delete p; return PGO_ERR_OUT_OF_MEMORY; }
     std::memset(p->poll, 0, 2 * sizeof(pgo_problem::Poll));
+    // One-time costs of the process belong here, not in the first trigger: the first device allocation and the first kernel launch of the library (its code object goes to the
+    // device).  Failures here are not errors (the solve reports its own).  (A captured + instantiated graph would also take the first hipGraphInstantiate of the process off the
+    // first long PCG — 9.4 ms against 0.2 ms for later ones — but a capture in one thread makes a concurrent synchronous hipMemcpy of ANOTHER thread fail with
+    // hipErrorStreamCaptureImplicit on this runtime, thread-local mode or not: handles are created concurrently by callers that run one rank per thread.)
+    {
+        double* w = nullptr;
+        if (hipMalloc((void**)&w, 4096) == hipSuccess) {
+            (void)hipMemsetAsync(w, 0, 4096, p->st);
+            launch_reduce(w, 0, 0, w + 8, p->st);
+            (void)hipStreamSynchronize(p->st);
+            (void)hipFree(w);
+            (void)hipGetLastError();
+        }
+    }
     *out = p;
     return PGO_OK;
 }
@@ -1811,7 +1832,7 @@ int pgo_destroy(pgo_problem* p) {
     p->d_scale_p.release(); p->d_scale_s.release(); p->d_diag_p.release(); p->d_diag_s.release(); p->d_a_inv.release();
     p->d_val.release(); p->d_Lf.release(); p->d_Dtot_b.release(); p->d_cgvec.release(); p->d_part.release(); p->d_cgpart.release();
     p->d_flags.release(); p->d_scal.release(); p->d_pose[0].release(); p->d_pose[1].release(); p->d_swv[0].release(); p->d_swv[1].release();
-    p->d_delta_s.release(); p->d_io.release(); p->d_tmp.release(); p->d_vio.release();
+    p->d_delta_s.release(); p->d_io.release(); p->d_tmp.release(); p->d_vio.release(); p->d_vio_idx.release(); p->d_vio_meas.release();
     p->d_mg_f64.release(); p->d_mg_i32.release(); p->d_mg_i64.release();
     p->d_ccen.release(); p->d_cd.release(); p->d_cAc.release(); p->d_crc.release(); p->d_cblk_ptr.release(); p->d_ccontrib.release(); p->d_cblk_ab.release(); p->d_cagg_free.release(); p->d_cinfo.release(); p->d_cscr.release(); p->d_cAcf.release();
     p->d_l2g.release(); p->d_sh_loc.release(); p->d_sh_pos.release(); p->d_sh_src.release(); p->d_sh_of.release(); p->d_own.release(); p->d_xbuf.release();
@@ -1911,8 +1932,8 @@ int pgo_add_odometry_edges_from_vio(pgo_problem* p, const int32_t* set_id, int64
     if (n_added) *n_added = n;
     if (n == 0) return PGO_OK;
     HIPCHK(p, hipSetDevice(p->device));
-    ScopedBuf<int32_t> d_c;                       // c1 then c2
-    ScopedBuf<double> d_meas;
+    DBuf<int32_t>& d_c = p->d_vio_idx;            // c1 then c2 (kept across calls: a device allocation + free per wake-up cost the first wake-ups 8 ms each)
+    DBuf<double>& d_meas = p->d_vio_meas;
     HIPCHK(p, d_c.ensure((size_t)2 * n)); HIPCHK(p, d_meas.ensure((size_t)8 * n));
     HIPCHK(p, hipMemcpyAsync(d_c.p, c1.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
     HIPCHK(p, hipMemcpyAsync(d_c.p + n, c2.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
