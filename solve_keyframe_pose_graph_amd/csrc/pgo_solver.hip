@@ -203,6 +203,7 @@ struct pgo_problem {
     int mg_switch_at = 400;              // in-flight switch point of the current LM system (build_system)
     int cg_extra = 0;                    // PCG iterations of the current LM step spent before a change of preconditioner
     bool mg_failed = false;              // the multigrid operators of the current system could not be built
+    double last_rho = 1.0;               // relative decrease of the last accepted step of this solve
     bool mg_start_deferred = false;      // the current system is predicted hard, but its multigrid operators are built only once the step has survived the first early-rejection pause
 };
 
@@ -1407,7 +1408,11 @@ int build_system(pgo_problem* p, bool* ok) {
         // accepted one at a large radius, i.e. exactly the systems predicted hard, and block-Jacobi reaches the first pause (cg_early_tolerance, a few dozen iterations)
         // for a fraction of what the operators cost (C3, step 4: 32 ms for a step thrown away at 21 iterations).  Then the build waits for the pause (lm_step).
         const bool hard = p->opt.mg_switch_iterations <= 0 || predicted >= start_factor * (double)p->opt.mg_switch_iterations;
-        p->mg_start_deferred = hard && p->opt.mg_switch_iterations > 0 && p->opt.cg_early_tolerance > p->opt.cg_rel_tolerance;
+        // ... and only where a rejection is in the air: the previous step was rejected (rejections come in streaks: the radius shrinks over several steps), or the last accepted
+        // step's relative decrease fell below 0.8 — the quadratic model is losing its grip (C3's and C4's first rejected steps follow rho = 0.67 and 0.62; the accepted hard steps
+        // of both follow rho >= 0.89, and a prelude there is 74 block-Jacobi iterations the multigrid would not have needed: 3 ms x 5 on C3, 5 ms x 12 on C4)
+        const bool rejection_likely = p->reuse_diagonal || p->last_rho < 0.8;
+        p->mg_start_deferred = hard && rejection_likely && p->opt.mg_switch_iterations > 0 && p->opt.cg_early_tolerance > p->opt.cg_rel_tolerance;
         if (p->mg_start_deferred) {      // ... but not for long: a step that has not reached the pause within the prelude is a hard one that stays (late C3 systems need ~300 block-Jacobi iterations to 1e-2)
             const int prelude = 72;      // three chunks (measured on C3 / C4, 20 steps: 48 -> 0.392 / 1.500 s — C3's rejected step 4 needs 53 —, 72 -> 0.322 / 1.515 s, 96 -> 0.324 / 1.524 s)
             p->mg_switch_at = std::min(p->mg_switch_at, prelude);
@@ -1461,7 +1466,7 @@ int solve_begin(pgo_problem* p, const double* quat, const double* t, const doubl
     std::memset(&p->sum, 0, sizeof(p->sum));
     p->in_solve = true; p->terminated = false; p->scale_ready = false; p->have_prev_step = false;
     p->coarse_retests = 0; p->coarse_drop_radius = 0.0;
-    p->cg_prev_equiv = 0.0; p->cg_prev_radius = 0.0; p->mg_regroups = 0;
+    p->cg_prev_equiv = 0.0; p->cg_prev_radius = 0.0; p->mg_regroups = 0; p->last_rho = 1.0;
     if (p->coarse_skip > 0) { p->coarse_mode = 2; p->coarse_skip_all = true; --p->coarse_skip; }
     else { p->coarse_mode = (p->coarse_keep_streak % 4 != 0) ? 1 : 0; p->coarse_skip_all = false; }
     p->radius = p->opt.initial_trust_region_radius; p->decrease_factor = 2.0; p->reuse_diagonal = false; p->iteration = 0; p->invalid = 0;
@@ -1641,6 +1646,7 @@ int lm_step(pgo_problem* p, int ignore_termination, int* done) {
         p->radius = p->radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * it.relative_decrease - 1.0, 3));   // StepAccepted
         p->radius = std::min(o.max_trust_region_radius, p->radius);
         p->decrease_factor = 2.0; p->reuse_diagonal = false;
+        p->last_rho = it.relative_decrease;
         ++p->sum.num_successful_steps;
         if ((rc = regroup_start(p)) != PGO_OK) return rc;     // the switches have moved: does the hierarchy above level 1 still fit them?
     } else {
