@@ -1117,6 +1117,7 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
     // Chunks of `every` iterations; the convergence flag of chunk j is read (pinned memory + event) only AFTER chunk j+1 has been
     // enqueued, so the GPU never drains while the host polls.  A chunk enqueued after convergence is a string of early-exit kernels.
     int n_chunks = 0, waited = -1, r1_refreshed_at = k;
+    int ex_k0 = -1; double ex_rz0 = 0.0;      // first polled (iteration, r.z) of this run: base of the convergence-rate estimate
     bool done = false;
     auto enqueue_poll = [&](int slot) -> int {
         HIPCHK(p, hipMemcpyAsync(p->poll[slot].flags, p->C.flags, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, p->st));
@@ -1177,6 +1178,22 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
             HIPCHK(p, hipEventSynchronize(p->poll_ev[check & 1]));
             waited = check;
             if (p->poll[check & 1].flags[0]) done = true;
+            // A system without a prediction (the first of a solve, the first after rejected steps) need not burn mg_switch_iterations block-Jacobi iterations to be
+            // recognised as hard: the polled r.z values give its convergence rate, and a system that would need >= the start threshold in total at that rate (and at
+            // least twice what it has done) switches now.  One GPU only (the Chronopoulos-Gear form keeps its scalars elsewhere); depends on the solve's own data alone.
+            if (!done && !multi && p->mg_built && !p->mg_active && !p->mg_failed && !p->mg_start_deferred && o.mg_switch_iterations > 0 && k < p->mg_switch_at) {
+                const int kk = p->poll[check & 1].flags[2];
+                const double rz = p->poll[check & 1].scal[1], bb = p->poll[check & 1].scal[0];
+                if (rz > 0.0 && bb > 0.0) {
+                    if (ex_k0 < 0) { if (kk >= 24) { ex_k0 = kk; ex_rz0 = rz; } }
+                    else if (kk >= 96 && kk > ex_k0) {
+                        const double lr = std::log(rz / ex_rz0) / (double)(kk - ex_k0);                        // log reduction per iteration (negative while converging)
+                        const double need = std::log(o.cg_rel_tolerance * o.cg_rel_tolerance * bb / rz);      // what is left down to the final tolerance (negative)
+                        const double total = lr < 0.0 ? (double)kk + need / lr : 1e30;
+                        if (total >= 1.75 * (double)o.mg_switch_iterations && total >= 2.0 * (double)kk) p->mg_switch_at = std::min(p->mg_switch_at, k);
+                    }
+                }
+            }
         }
         ++n_chunks;
         // Hybrid preconditioning: most LM systems (small trust regions, steps about to be rejected) are solved by block-Jacobi in a few
