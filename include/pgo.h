@@ -86,8 +86,11 @@ typedef struct pgo_options {
     /* PCG controls (no Ceres counterpart: Ceres factorises exactly) */
     int32_t cg_max_iterations;           /* 50000: a safety net, not a budget — a capped PCG is an inexact LM step and leaves the exact-solve path */
     int32_t cg_check_every;              /* 25: host polls the device convergence flag every this many iterations (rounded down to even; 12 while the two-level preconditioner is on) */
-    double cg_rel_tolerance;             /* 1e-9: stop when ||r||_{M^-1} <= tol * ||b||_{D^-1} (D = block-Jacobi).  The block-Jacobi factors are stored rounded
-                                          *       to fp32 (a preconditioner may be anything symmetric positive definite; the arithmetic applying them is fp64). */
+    double cg_rel_tolerance;             /* 3e-10: stop when ||r||_{M^-1} <= tol * ||b||_{D^-1} (D = block-Jacobi).  The block-Jacobi factors are stored rounded
+                                          *       to fp32 (a preconditioner may be anything symmetric positive definite; the arithmetic applying them is fp64).
+                                          *       Measured on C3 against the independent CPU trajectory (tests/golden): chi^2 after 10 LM iterations within 9e-8 / 1.3e-7 (with / without the
+                                          *       early-rejection pauses: the two runs switch preconditioner at different points) at 1e-9, 3e-8 / 7e-8 at 5e-10, 8e-9 / 1.1e-8 at 3e-10,
+                                          *       1.1e-8 / 2.4e-8 at 2e-10; after 20 iterations 1.5e-9 at 1e-9, 1.8e-10 at 3e-10; 3e-10 costs 5 % more PCG iterations than 1e-9 */
     int32_t cg_warm_start;               /* 1: after a rejected step start the PCG from the previous step (same H, larger damping) */
     int32_t cg_use_graph;                /* 1: replay each `cg_check_every`-iteration chunk of the PCG loop as one hipGraph (single GPU) */
     /* Early rejection: a rejected LM step only shrinks the trust region, so the PCG pauses at up to two intermediate tolerances, the

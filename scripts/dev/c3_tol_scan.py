@@ -1,0 +1,16 @@
+import sys, json
+sys.path.insert(0, '/root/repo')
+from solve_keyframe_pose_graph_amd import graphgen
+from tests import util
+g = graphgen.config('C3'); q, t, s = util.initial_state(g, True)
+for iters, gold_file in ((10, 'c3_ten_iterations.json'), (20, 'c3_twenty_iterations.json')):
+    gold = json.load(open('/root/repo/tests/golden/' + gold_file))['iterations'][-1]['cost']
+    for tol in (1e-9, 5e-10, 3e-10, 2e-10):
+        for pauses in (True, False):
+            kw = dict(cg_rel_tolerance=tol, max_num_iterations=iters, function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0)
+            if not pauses: kw.update(cg_early_tolerance=0.0, cg_mid_tolerance=0.0)
+            best = None
+            for rep in range(2):
+                P = util.pgo_problem(g, True, **kw); _, _, _, sm = P.solve(q, t, s); P.close()
+                if best is None or sm.seconds_device < best.seconds_device: best = sm
+            print('%2d steps tol %.0e %-9s rel diff to golden %+.2e  cg %5d  %.4f s' % (iters, tol, 'pauses' if pauses else 'no pauses', (best.final_cost - gold) / gold, best.cg_iterations, best.seconds_device), flush=True)

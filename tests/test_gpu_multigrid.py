@@ -42,8 +42,8 @@ def test_oracle_trajectory_with_every_hierarchy_depth(dense_max, first, passes):
 def test_mid_size_graph_hybrid_start_and_multigrid_from_the_first_iteration():
     """20k keyframes: levels 20000 -> 2500 -> ~430 (dense).  From the first iteration the multigrid needs 3-8x fewer PCG iterations than
     block-Jacobi on the hard (large-radius) systems.  The default start is hybrid: block-Jacobi first, the multigrid takes over a system that
-    is not solved after mg_switch_iterations, and a system predicted hard from the previous step of the solve starts with it; easy systems
-    never build it.  Same LM trajectory either way."""
+    is not solved after mg_switch_iterations (or whose polled r.z values predict >= 1.75x that many iterations), and a system predicted hard from the
+    previous step of the solve starts with it; easy systems never build it.  Same LM trajectory either way."""
     g = graphgen.generate(20000, 20000, odom_f_max=2, seed=3)
     _, t0, s0, plain = run(g, True, mg_min_keyframes=0, coarse_aggregates=0)
     _, t1, s1, mg = run(g, True, mg_min_keyframes=1, mg_switch_iterations=0)
@@ -56,7 +56,8 @@ def test_mid_size_graph_hybrid_start_and_multigrid_from_the_first_iteration():
     for k in hard:
         assert mg.iterations[k].cg_iterations * 3 < plain.iterations[k].cg_iterations, (k, mg.iterations[k].cg_iterations, plain.iterations[k].cg_iterations)
         assert hyb.iterations[k].cg_iterations < plain.iterations[k].cg_iterations
-    assert 400 <= hyb.iterations[hard[0]].cg_iterations                       # first hard system: switched in flight after 400 block-Jacobi iterations
+    # first hard system (no prediction yet): switched in flight — by its measured convergence rate from 96 block-Jacobi iterations on, at the latest after mg_switch_iterations
+    assert 96 <= hyb.iterations[hard[0]].cg_iterations < 400 + mg.iterations[hard[0]].cg_iterations + 48
     assert any(hyb.iterations[k].cg_iterations < 400 for k in hard[1:])       # later ones: predicted hard, multigrid from the first iteration
     easy = [k for k in range(1, plain.num_logged) if plain.iterations[k].cg_iterations < 350 and (k == 1 or plain.iterations[k - 1].cg_iterations < 350)]
     # never switched: the same block-Jacobi PCG (its starting point differs from the plain run's within the PCG tolerance of the earlier multigrid steps: +-2 iterations)

@@ -80,7 +80,7 @@ def test_graph_built_on_the_device_solves_like_the_host_built_one():
     """C4-style graph (f = 1..5, yaw weights): odometry edges built by K0 from the VIO chain vs handed over as matrices."""
     g = graphgen.generate(4000, 400, odom_f_max=5, apply_yaw_weight=1, seed=9, **graphgen._SMALL)
     q, t, s = util.initial_state(g, True)
-    # the two routes hand over measurements that differ in the last bits; with the default PCG tolerance (1e-9) the linear solves of the two runs stop at
+    # the two routes hand over measurements that differ in the last bits; with the default PCG tolerance (3e-10) the linear solves of the two runs stop at
     # different points of a chain-like system and the 10-step costs drift apart by a few 1e-8 relative — a tighter PCG isolates what is tested here
     Pa = util.pgo_problem(g, True, cg_rel_tolerance=1e-11)
     qa, ta, sa, suma = Pa.solve(q, t, s)
