@@ -152,7 +152,7 @@ def test_c3_early_rejection_with_the_default_hybrid_preconditioner(c3):
     _, te, se, sume = Pe.solve(q, t, s)
     Pe.close()
     assert [sume.iterations[k].step_is_successful for k in range(sume.num_logged)] == [sumf.iterations[k].step_is_successful for k in range(sumf.num_logged)]
-    assert abs(sume.final_cost - sumf.final_cost) <= 1e-7 * sumf.final_cost
+    assert abs(sume.final_cost - sumf.final_cost) <= 5e-8 * sumf.final_cost      # (observed 1.9e-8 with the default cg_rel_tolerance 3e-10; 2.2e-7 at 1e-9)
     assert np.abs(te - tf).max() <= 1e-5 and np.abs(se - sf).max() <= 1e-5
     assert sume.cg_iterations < 0.7 * sumf.cg_iterations
 
