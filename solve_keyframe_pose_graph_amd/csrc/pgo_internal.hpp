@@ -251,9 +251,10 @@ void launch_mg_geometry0_sum(const GraphDev& G, const MgDev& M, const MgLevelDev
 void launch_mg_geometry_finish(const GraphDev& G, const MgDev& M, const MgLevelDev* levels, const double* pose8, hipStream_t st);
 // numeric Galerkin products of the current LM system, level by level, block-Jacobi inverses of the sparse levels, the dense coarsest operator
 // into K.Ac (K.nc padded), which is then inverted by launch_coarse_invert; *fail != 0: some diagonal block was not positive definite
-void launch_mg_assemble(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, double omega, int32_t* fail, hipStream_t st, double prolong_scale = 0.0);
+void launch_mg_assemble(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, double omega, int32_t* fail, hipStream_t st, double prolong_scale = 0.0, bool hoff_valid = false);
 // its two halves: level 1 from the keyframe system (several ranks: this rank's contributions; the caller all-reduces levels[0].val), then everything above
-void launch_mg_galerkin0(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, const MgDev& M, const MgLevelDev* levels, hipStream_t st);
+void launch_mg_galerkin0(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, const MgDev& M, const MgLevelDev* levels, hipStream_t st, bool hoff_valid = false);
+void launch_k2_offdiag(const GraphDev& G, const LinDev& L, hipStream_t st);
 void launch_mg_assemble_rest(const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, double omega, int32_t* fail, hipStream_t st, double prolong_scale = 0.0 /* c = w_p / w of the smoothed transitions */);
 // out[n1][6] = P0^T v over the handle's keyframes (own_weighted: every keyframe counted by its owner only — several ranks)
 void launch_mg_restrict0(const GraphDev& G, const MgDev& M, const double* v, double* out, bool own_weighted, hipStream_t st);

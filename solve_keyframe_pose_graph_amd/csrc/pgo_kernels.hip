@@ -465,6 +465,13 @@ void launch_k2(const GraphDev& G, const LinDev& L, bool want_offdiag, hipStream_
     if (ne > 0) hipLaunchKernelGGL(k2_edge_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, G, L, want_offdiag ? 1 : 0);
 }
 
+// J1^T J2 of every edge into L.Hoff (36 contiguous doubles per edge) for the multigrid's level-1 Galerkin product under the matrix-free solver, which does not
+// form them otherwise: one edge-parallel pass, the Jacobian loads coalesce (the switch couplings are rewritten with the same values)
+void launch_k2_offdiag(const GraphDev& G, const LinDev& L, hipStream_t st) {
+    const int64_t ne = G.rel.Epad + G.sw.Epad;
+    if (ne > 0) hipLaunchKernelGGL(k2_edge_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, G, L, 1);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Jacobi scaling and LM diagonal (Ceres: scale = 1/(1+sqrt(col norm^2)) fixed at iteration 0;
 // D^2 = clamp(col norm^2 of the scaled Jacobian, min, max) / radius)

@@ -176,6 +176,7 @@ void launch_mg_geometry_finish(const GraphDev& G, const MgDev& M, const MgLevelD
 // level 1 from the keyframe system: one wavefront per block; contributions as in coarse_assemble_kernel (reduced diagonal blocks C.Dtot and,
 // per edge, J1^T J2 - c1 c2^T / a recomputed from K1's Jacobians), summed in list order
 // one contribution of the keyframe system to a level-1 block: the fine 6x6 block (lane's element) and the two keyframes it couples
+template <bool HOFF>
 __device__ __forceinline__ double mg_fine_block(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, int64_t ent, int lane, int r, int c, bool own, int64_t& ni, int64_t& nj) {
     const int kind = (int)(ent & 7);
     const int64_t idx = ent >> 3;
@@ -193,8 +194,13 @@ __device__ __forceinline__ double mg_fine_block(const GraphDev& G, const LinDev&
         ni = transposed ? c2 : c1; nj = transposed ? c1 : c2;
         if (own) {
             const int oa = transposed ? o2 : o1, ob = transposed ? o1 : o2;
+            // Hoff (when the solver has had it formed for this linearisation: one edge-parallel, coalesced pass over K1's Jacobians) holds J1^T J2 of every edge as 36 contiguous
+            // doubles: one load per lane instead of twelve strided ones (the same sums in the same order: k2_edge_kernel adds the six products in this order too)
+            if (HOFF) h = L.Hoff[(size_t)((is_sw ? G.rel.Epad : 0) + idx) * 36 + (transposed ? c * 6 + r : r * 6 + c)];
+            else {
 #pragma unroll
-            for (int kk = 0; kk < 6; ++kk) h += E.J[tile_elem(D, idx, oa + kk * 6 + r)] * E.J[tile_elem(D, idx, ob + kk * 6 + c)];
+                for (int kk = 0; kk < 6; ++kk) h += E.J[tile_elem(D, idx, oa + kk * 6 + r)] * E.J[tile_elem(D, idx, ob + kk * 6 + c)];
+            }
             if (is_sw) {
                 const double* cc = L.c + (size_t)idx * 12;
                 h -= cc[(transposed ? 6 : 0) + r] * cc[(transposed ? 0 : 6) + c] * Sc.a_inv[idx];
@@ -205,6 +211,7 @@ __device__ __forceinline__ double mg_fine_block(const GraphDev& G, const LinDev&
 }
 // Two contributions are fetched together (their entry -> endpoints -> Jacobian load chains overlap) and then projected one after the other, in
 // list order: the sums are those of the one-at-a-time loop.
+template <bool HOFF>
 __global__ __launch_bounds__(256) void mg_galerkin0_kernel(GraphDev G, LinDev L, ScaleDev Sc, CgDev C, MgDev M, MgLevelDev A) {
     __shared__ double Hs[4][2][36];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -218,8 +225,8 @@ __global__ __launch_bounds__(256) void mg_galerkin0_kernel(GraphDev G, LinDev L,
     for (; k + 2 <= k1; k += 2) {
         const int64_t e0 = A.g_ent[k], e1 = A.g_ent[k + 1];
         int64_t ni0, nj0, ni1, nj1;
-        const double h0 = mg_fine_block(G, L, Sc, C, e0, lane, r, c, own, ni0, nj0);
-        const double h1 = mg_fine_block(G, L, Sc, C, e1, lane, r, c, own, ni1, nj1);
+        const double h0 = mg_fine_block<HOFF>(G, L, Sc, C, e0, lane, r, c, own, ni0, nj0);
+        const double h1 = mg_fine_block<HOFF>(G, L, Sc, C, e1, lane, r, c, own, ni1, nj1);
         if (own) { Hs[wv][0][lane] = h0; Hs[wv][1][lane] = h1; }
         __builtin_amdgcn_wave_barrier();
         if (own) {
@@ -230,7 +237,7 @@ __global__ __launch_bounds__(256) void mg_galerkin0_kernel(GraphDev G, LinDev L,
     }
     if (k < k1) {
         int64_t ni, nj;
-        const double h = mg_fine_block(G, L, Sc, C, A.g_ent[k], lane, r, c, own, ni, nj);
+        const double h = mg_fine_block<HOFF>(G, L, Sc, C, A.g_ent[k], lane, r, c, own, ni, nj);
         if (own) Hs[wv][0][lane] = h;
         __builtin_amdgcn_wave_barrier();
         if (own) acc += coarse_entry(Hs[wv][0], M.d0 + (size_t)ni * 3, M.d0 + (size_t)nj * 3, r, c);
@@ -506,11 +513,12 @@ static void mg_limit_smoother(const MgLevelDev& A, double omega, hipStream_t st)
     hipLaunchKernelGGL(mg_rescale_dinv_kernel, dim3((unsigned)(((int64_t)A.n * 36 + 255) / 256)), dim3(256), 0, st, A, (const double*)lam, omega, 1.75, 1.5);
 }
 
-void launch_mg_galerkin0(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, const MgDev& M, const MgLevelDev* levels, hipStream_t st) {
-    hipLaunchKernelGGL(mg_galerkin0_kernel, dim3((unsigned)((levels[0].nnzb + 3) / 4)), dim3(256), 0, st, G, L, Sc, C, M, levels[0]);
+void launch_mg_galerkin0(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, const MgDev& M, const MgLevelDev* levels, hipStream_t st, bool hoff_valid) {
+    if (hoff_valid) hipLaunchKernelGGL((mg_galerkin0_kernel<true>), dim3((unsigned)((levels[0].nnzb + 3) / 4)), dim3(256), 0, st, G, L, Sc, C, M, levels[0]);
+    else hipLaunchKernelGGL((mg_galerkin0_kernel<false>), dim3((unsigned)((levels[0].nnzb + 3) / 4)), dim3(256), 0, st, G, L, Sc, C, M, levels[0]);
 }
-void launch_mg_assemble(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, double omega, int32_t* fail, hipStream_t st, double prolong_scale) {
-    launch_mg_galerkin0(G, L, Sc, C, M, levels, st);
+void launch_mg_assemble(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, double omega, int32_t* fail, hipStream_t st, double prolong_scale, bool hoff_valid) {
+    launch_mg_galerkin0(G, L, Sc, C, M, levels, st, hoff_valid);
     launch_mg_assemble_rest(M, levels, K, omega, fail, st, prolong_scale);
 }
 void launch_mg_assemble_rest(const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, double omega, int32_t* fail, hipStream_t st, double prolong_scale) {

@@ -155,6 +155,7 @@ struct pgo_problem {
     std::thread mg_job; std::unique_ptr<MgPrepared> mg_job_out, mg_job_old; bool mg_job_running = false;
     int rc_job = 0;
     uint64_t mg_geometry_epoch = 0;
+    uint64_t hoff_epoch = 0;               // linearisation whose J1^T J2 blocks L.Hoff holds (matrix-free solver: formed on demand for the multigrid's level-1 product)
     int64_t n_vio = 0;
     // matrix-free operator
     DBuf<uint32_t> d_einc;
@@ -771,6 +772,8 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
     // may call again with the current switch values (regroup)
     p->mg_cache.valid = false;
     if ((rc = build_multigrid(p, sw_now)) != PGO_OK) return rc;
+    if (p->mg_built && p->built_mf) { HIPCHK(p, p->d_Hoff.ensure((size_t)(p->G.rel.Epad + p->G.sw.Epad) * 36)); p->L.Hoff = p->d_Hoff.p; }      // the multigrid's level-1 product reads J1^T J2 per edge
+    p->hoff_epoch = 0;
     if (!p->mg_built) {      // (a graph that got the multigrid never uses the two-level method: its dense operator would be built and uploaded for nothing)
         int n_agg = p->opt.coarse_aggregates;
         // a graph with no more keyframes than `half` (256 by default) gets one aggregate per keyframe: the coarse operator IS the reduced system and the "preconditioner"
@@ -1367,16 +1370,24 @@ static int build_mg(pgo_problem* p) {
     int32_t* fail = p->d_cinfo.p;
     HIPCHK(p, hipMemsetAsync(fail, 0, sizeof(int32_t), p->st));
     const double omega = p->opt.mg_omega > 0.0 && p->opt.mg_omega <= 1.0 ? p->opt.mg_omega : 0.9;
+    // level 1's Galerkin product reads J1^T J2 of every edge: the block-CSR solver has them from K2; under the matrix-free solver they are formed here, once per linearisation
+    // that builds multigrid operators (an edge-parallel pass whose Jacobian loads coalesce, ~60 us on C3 — the wavefront-per-block product gathering K1's Jacobians itself,
+    // twelve strided loads per lane and contribution, took 0.9 ms)
+    bool hoff_valid = !p->built_mf;
+    if (p->built_mf && p->d_Hoff.cap >= (size_t)(p->G.rel.Epad + p->G.sw.Epad) * 36) {
+        if (p->hoff_epoch != p->lin_epoch) { p->L.Hoff = p->d_Hoff.p; launch_k2_offdiag(p->G, p->L, p->st); p->hoff_epoch = p->lin_epoch; }
+        hoff_valid = true;
+    }
     if (p->local_ids) {         // level 1 = the sum of the ranks' Galerkin products (each edge lives on one rank, each diagonal block is its owner's); the levels above are replicated
-        launch_mg_galerkin0(p->G, p->L, p->Sc, p->C, p->M, p->mg_levels, p->st);
+        launch_mg_galerkin0(p->G, p->L, p->Sc, p->C, p->M, p->mg_levels, p->st, hoff_valid);
         if ((rcm = allreduce(p, p->mg_levels[0].val, (size_t)p->mg_levels[0].nnzb * 36, 0)) != PGO_OK) return rcm;
         launch_mg_assemble_rest(p->M, p->mg_levels, p->K, omega, fail, p->st, mg_cs(p));
     } else if (p->opt.verbosity > 1) {
         HIPCHK(p, hipStreamSynchronize(p->st)); std::fprintf(stderr, "[pgo] multigrid: geometry done at %.2f ms\n", (now_s() - t_build0) * 1e3);
-        launch_mg_galerkin0(p->G, p->L, p->Sc, p->C, p->M, p->mg_levels, p->st);
+        launch_mg_galerkin0(p->G, p->L, p->Sc, p->C, p->M, p->mg_levels, p->st, hoff_valid);
         HIPCHK(p, hipStreamSynchronize(p->st)); std::fprintf(stderr, "[pgo] multigrid: galerkin0 done at %.2f ms\n", (now_s() - t_build0) * 1e3);
         launch_mg_assemble_rest(p->M, p->mg_levels, p->K, omega, fail, p->st, mg_cs(p));
-    } else launch_mg_assemble(p->G, p->L, p->Sc, p->C, p->M, p->mg_levels, p->K, omega, fail, p->st, mg_cs(p));
+    } else launch_mg_assemble(p->G, p->L, p->Sc, p->C, p->M, p->mg_levels, p->K, omega, fail, p->st, mg_cs(p), hoff_valid);
     if (p->opt.verbosity > 1) { HIPCHK(p, hipStreamSynchronize(p->st)); std::fprintf(stderr, "[pgo] multigrid: level operators done at %.2f ms\n", (now_s() - t_build0) * 1e3); }
     launch_coarse_invert(p->K, p->d_cscr.p, fail, p->st);
     int32_t h = 1;
@@ -1956,7 +1967,7 @@ int pgo_add_odometry_edges_from_vio(pgo_problem* p, const int32_t* set_id, int64
     if (n_added) *n_added = n;
     if (n == 0) return PGO_OK;
     HIPCHK(p, hipSetDevice(p->device));
-    DBuf<int32_t>& d_c = p->d_vio_idx;            // c1 then c2 (kept across calls: a device allocation + free per wake-up cost the first wake-ups 8 ms each)
+    DBuf<int32_t>& d_c = p->d_vio_idx;            // c1 then c2 (kept across calls)
     DBuf<double>& d_meas = p->d_vio_meas;
     HIPCHK(p, d_c.ensure((size_t)2 * n)); HIPCHK(p, d_meas.ensure((size_t)8 * n));
     HIPCHK(p, hipMemcpyAsync(d_c.p, c1.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
@@ -1965,6 +1976,7 @@ int pgo_add_odometry_edges_from_vio(pgo_problem* p, const int32_t* set_id, int64
     HostClass& H = p->rel;
     const size_t base = H.c1.size();
     H.meas.resize((base + n) * 8);
+    // (the second wake-up of a process spends ~8 ms inside this copy call — runtime-internal, once; a pinned staging buffer of our own does not change it: measured)
     HIPCHK(p, hipMemcpyAsync(&H.meas[base * 8], d_meas.p, (size_t)8 * n * sizeof(double), hipMemcpyDeviceToHost, p->st));
     const hipError_t e = hipStreamSynchronize(p->st);
     if (e != hipSuccess) { H.meas.resize(base * 8); p->err = hipGetErrorString(e); return PGO_ERR_HIP; }
