@@ -129,3 +129,39 @@ def test_regroup_follows_the_switches_and_keeps_the_trajectory():
     assert sum(its_on) <= 1.1 * sum(its_off)                         # (what it buys shows on harder late systems: C3's 305 / 367 / 454 -> 155 / 184 / 246)
     assert on2.final_cost == on.final_cost and np.array_equal(t2, t1) and np.array_equal(s2, s1)
     assert [on2.iterations[k].cg_iterations for k in range(on2.num_logged)] == [on.iterations[k].cg_iterations for k in range(on.num_logged)]
+
+
+def test_hybrid_schedule_is_reproducible_and_survives_an_abandoned_regroup():
+    """The library defaults on a 30k-keyframe graph with outliers (hybrid start, rate-based switch, deferred start, regroup on a worker thread): every decision depends on
+    the solve's own history only, so a second handle reproduces iteration counts and state bit for bit.  A solve that is ended right after the step that started the
+    regroup's worker (its result is never installed), and a handle destroyed in that state, leave nothing behind: the next solve of the handle is again the same."""
+    g = graphgen.generate(30000, 30000, odom_f_max=2, seed=3)
+    q, t, s = util.initial_state(g, True)
+    kw = dict(max_num_iterations=14, function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0, mg_regroup_fraction=0.005)
+    qa, ta, sa, A = run(g, True, **kw)
+    its_a = [A.iterations[k].cg_iterations for k in range(A.num_logged)]
+    assert A.cg_iterations_multigrid > 0 and A.cg_iterations_multigrid < A.cg_iterations          # both preconditioners took part
+    P = util.pgo_problem(g, True, **kw)
+    P.solve_begin(q, t, s)
+    for _ in range(4):                     # the worker starts after the third accepted step at the earliest; nothing installs its result in these steps
+        P.lm_step(ignore_termination=True)
+    P.solve_end()
+    qb, tb, sb, B = P.solve(q, t, s)
+    assert [B.iterations[k].cg_iterations for k in range(B.num_logged)] == its_a
+    assert B.final_cost == A.final_cost and np.array_equal(tb, ta) and np.array_equal(qb, qa) and np.array_equal(sb, sa)
+    P.solve_begin(q, t, s)
+    for _ in range(4):
+        P.lm_step(ignore_termination=True)
+    P.close()                              # destroyed with a solve (and possibly a worker) in flight
+
+
+def test_small_graphs_arm_the_pauses_with_their_first_rejected_step():
+    """Below 20 000 keyframes the early-rejection pauses are armed by the solve's first rejected step: a solve whose steps are all accepted is the solve without pauses,
+    bit for bit and iteration for iteration."""
+    g = graphgen.generate(1500, 300, odom_f_max=5, apply_yaw_weight=1, seed=5, **dict(graphgen._SMALL, turn_deg_per_keyframe=2.0))
+    q, t, s = util.initial_state(g, True)
+    _, t0, s0, off = run(g, True, max_num_iterations=6, cg_early_tolerance=0.0, cg_mid_tolerance=0.0)
+    _, t1, s1, on = run(g, True, max_num_iterations=6)
+    assert off.num_unsuccessful_steps == 0
+    assert [on.iterations[k].cg_iterations for k in range(on.num_logged)] == [off.iterations[k].cg_iterations for k in range(off.num_logged)]
+    assert on.final_cost == off.final_cost and np.array_equal(t1, t0) and np.array_equal(s1, s0)
