@@ -489,6 +489,7 @@ int build_multigrid(pgo_problem* p, const double* sw_now) {
 }
 
 int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
+    mg_job_cancel(p);      // (a regroup's worker reads the host arrays rebuilt below)
     // ---- validate against the array sizes the caller solves with
     for (const HostClass* H : {&p->rel, &p->swe})
         for (int64_t e = 0; e < H->size(); ++e)
@@ -1326,7 +1327,12 @@ static int regroup_start(pgo_problem* p) {
     p->mg_job_running = true; p->rc_job = PGO_OK;
     MgPrepared* Q = p->mg_job_out.get();
     MgPrepared* old_image = p->mg_job_old.release();
-    p->mg_job = std::thread([p, Q, old_image, sv = std::move(sv)]() { delete old_image; p->rc_job = mg_prepare(p, sv.data(), *Q); });
+    try {
+        p->mg_job = std::thread([p, Q, old_image, sv]() { delete old_image; p->rc_job = mg_prepare(p, sv.data(), *Q); });
+    } catch (...) {      // no thread to be had (the C-ABI never throws): the same work on this one
+        delete old_image;
+        p->rc_job = mg_prepare(p, sv.data(), *Q);
+    }
     return PGO_OK;
 }
 static int regroup_install(pgo_problem* p) {
