@@ -363,9 +363,12 @@ __global__ __launch_bounds__(256) void mg_ps_kernel(MgLevelDev A, double cs) {
         A.ps_val[(size_t)slot * 36 + lane] = v;
     }
 }
-// W = A Ps: one wavefront per block (i, b) of W: sum over the blocks k of A's row i whose column's Ps row holds b
+// W = A Ps: one wavefront per block (i, b) of W: sum over the blocks k of A's row i whose column's Ps row holds b.  The row is taken MG_SETUP_CHUNK blocks at a time
+// and every hop of the chain column -> Ps row range -> Ps columns (searched by ballot) -> Ps block is issued for the whole chunk before the next one starts: four dependent
+// round trips per chunk instead of four per block of A (the kernel is nothing but these chains: 0.50 -> see DESIGN.md).  The products are added in the order of A's row, as before (same bits).
+constexpr int MG_SETUP_CHUNK = 8;
 __global__ __launch_bounds__(256) void mg_w_kernel(MgLevelDev A) {
-    __shared__ double pb[4][36];
+    __shared__ double pb[4][MG_SETUP_CHUNK][36], ab[4][MG_SETUP_CHUNK][36];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t slot = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (slot >= A.n_w) return;
@@ -375,24 +378,47 @@ __global__ __launch_bounds__(256) void mg_w_kernel(MgLevelDev A) {
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int64_t)A.w_rowptr[mid] <= slot) lo = mid; else hi = mid; }
     const int i = lo, b = A.w_col[slot];
     double acc = 0.0;
-    for (int64_t k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k) {
-        const int j = A.col[k];
-        int ps = -1;
-        for (int sl = A.ps_rowptr[j]; sl < A.ps_rowptr[j + 1]; ++sl) if (A.ps_col[sl] == b) { ps = sl; break; }
-        if (ps < 0) continue;                         // (uniform over the wavefront)
-        if (own) pb[wv][lane] = A.ps_val[(size_t)ps * 36 + lane];
-        __builtin_amdgcn_wave_barrier();
-        if (own) {
+    const int64_t kend = A.rowptr[i + 1];
+    for (int64_t k0 = A.rowptr[i]; k0 < kend; k0 += MG_SETUP_CHUNK) {
+        const int n = (int)(kend - k0 < MG_SETUP_CHUNK ? kend - k0 : MG_SETUP_CHUNK);
+        int j[MG_SETUP_CHUNK], p0[MG_SETUP_CHUNK], p1[MG_SETUP_CHUNK], ps[MG_SETUP_CHUNK];
 #pragma unroll
-            for (int m = 0; m < 6; ++m) acc += A.val[(size_t)k * 36 + bsr_idx(r, m)] * pb[wv][m * 6 + c];
+        for (int u = 0; u < MG_SETUP_CHUNK; ++u) j[u] = u < n ? A.col[k0 + u] : 0;
+#pragma unroll
+        for (int u = 0; u < MG_SETUP_CHUNK; ++u) { p0[u] = u < n ? A.ps_rowptr[j[u]] : 0; p1[u] = u < n ? A.ps_rowptr[j[u] + 1] : 0; }
+        // the Ps rows are short (the parents of one row's columns): one ballot per row finds b; a longer row takes further steps (uniform over the wavefront)
+        int cand[MG_SETUP_CHUNK];
+#pragma unroll
+        for (int u = 0; u < MG_SETUP_CHUNK; ++u) cand[u] = (p0[u] + lane < p1[u]) ? A.ps_col[p0[u] + lane] : -1;
+#pragma unroll
+        for (int u = 0; u < MG_SETUP_CHUNK; ++u) {
+            unsigned long long hit = __ballot(cand[u] == b);
+            ps[u] = hit ? p0[u] + __ffsll((long long)hit) - 1 : -1;
+            for (int base = p0[u] + 64; ps[u] < 0 && base < p1[u]; base += 64) {
+                hit = __ballot(base + lane < p1[u] && A.ps_col[base + lane] == b);
+                if (hit) ps[u] = base + __ffsll((long long)hit) - 1;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < MG_SETUP_CHUNK; ++u) if (ps[u] >= 0 && own) pb[wv][u][lane] = A.ps_val[(size_t)ps[u] * 36 + lane];
+#pragma unroll
+        for (int u = 0; u < MG_SETUP_CHUNK; ++u) if (ps[u] >= 0 && own) ab[wv][u][lane] = A.val[(size_t)(k0 + u) * 36 + lane];      // (storage order of the block-CSR blocks)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < MG_SETUP_CHUNK; ++u) {
+            if (ps[u] >= 0 && own) {
+#pragma unroll
+                for (int m = 0; m < 6; ++m) acc += ab[wv][u][bsr_idx(r, m)] * pb[wv][u][m * 6 + c];
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
     if (own) A.w_val[(size_t)slot * 36 + lane] = acc;
 }
-// level above: block (a, b) = sum over the rows i with Ps[i, a] != 0 of Ps[i, a]^T W[i, b]
+// level above: block (a, b) = sum over the rows i with Ps[i, a] != 0 of Ps[i, a]^T W[i, b] — the rows of Ps's column a in chunks, every hop (entry -> W row range -> W columns,
+// searched by ballot -> the two blocks) issued for the whole chunk at once, the products added in list order (same bits as the entry-at-a-time loop)
 __global__ __launch_bounds__(256) void mg_psTw_kernel(MgLevelDev A, MgLevelDev B) {
-    __shared__ double pa[4][36], wb[4][36];
+    __shared__ double pa[4][MG_SETUP_CHUNK][36], wb[4][MG_SETUP_CHUNK][36];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t slot = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (slot >= B.nnzb) return;
@@ -402,21 +428,36 @@ __global__ __launch_bounds__(256) void mg_psTw_kernel(MgLevelDev A, MgLevelDev B
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (B.rowptr[mid] <= slot) lo = mid; else hi = mid; }
     const int a = lo, b = B.col[slot];
     double acc = 0.0;
-    for (int64_t e = A.psT_ptr[a]; e < A.psT_ptr[a + 1]; ++e) {
-        const int64_t ent = A.psT_ent[e];
-        const int i = (int)(ent >> 32); const int64_t ps = ent & 0xffffffffll;
-        int ws = -1;       // the block (i, b) of W: row i is searched by the whole wavefront, 64 entries per step
-        for (int base = A.w_rowptr[i], end = A.w_rowptr[i + 1]; base < end && ws < 0; base += 64) {
-            const int sl = base + lane;
-            const unsigned long long hit = __ballot(sl < end && A.w_col[sl] == b);
-            if (hit) ws = base + __ffsll((long long)hit) - 1;
-        }
-        if (ws < 0) continue;
-        if (own) { pa[wv][lane] = A.ps_val[(size_t)ps * 36 + lane]; wb[wv][lane] = A.w_val[(size_t)ws * 36 + lane]; }
-        __builtin_amdgcn_wave_barrier();
-        if (own) {
+    const int64_t eend = A.psT_ptr[a + 1];
+    for (int64_t e0 = A.psT_ptr[a]; e0 < eend; e0 += MG_SETUP_CHUNK) {
+        const int n = (int)(eend - e0 < MG_SETUP_CHUNK ? eend - e0 : MG_SETUP_CHUNK);
+        int64_t ent[MG_SETUP_CHUNK];
+        int w0[MG_SETUP_CHUNK], w1[MG_SETUP_CHUNK], ws[MG_SETUP_CHUNK], cand[MG_SETUP_CHUNK];
 #pragma unroll
-            for (int m = 0; m < 6; ++m) acc += pa[wv][m * 6 + r] * wb[wv][m * 6 + c];
+        for (int u = 0; u < MG_SETUP_CHUNK; ++u) ent[u] = u < n ? A.psT_ent[e0 + u] : 0;
+#pragma unroll
+        for (int u = 0; u < MG_SETUP_CHUNK; ++u) { const int i = (int)(ent[u] >> 32); w0[u] = u < n ? A.w_rowptr[i] : 0; w1[u] = u < n ? A.w_rowptr[i + 1] : 0; }
+#pragma unroll
+        for (int u = 0; u < MG_SETUP_CHUNK; ++u) cand[u] = (w0[u] + lane < w1[u]) ? A.w_col[w0[u] + lane] : -1;
+#pragma unroll
+        for (int u = 0; u < MG_SETUP_CHUNK; ++u) {
+            unsigned long long hit = __ballot(cand[u] == b);
+            ws[u] = hit ? w0[u] + __ffsll((long long)hit) - 1 : -1;
+            for (int base = w0[u] + 64; ws[u] < 0 && base < w1[u]; base += 64) {      // rows of W longer than a wavefront
+                hit = __ballot(base + lane < w1[u] && A.w_col[base + lane] == b);
+                if (hit) ws[u] = base + __ffsll((long long)hit) - 1;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < MG_SETUP_CHUNK; ++u)
+            if (ws[u] >= 0 && own) { pa[wv][u][lane] = A.ps_val[(size_t)(ent[u] & 0xffffffffll) * 36 + lane]; wb[wv][u][lane] = A.w_val[(size_t)ws[u] * 36 + lane]; }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < MG_SETUP_CHUNK; ++u) {
+            if (ws[u] >= 0 && own) {
+#pragma unroll
+                for (int m = 0; m < 6; ++m) acc += pa[wv][u][m * 6 + r] * wb[wv][u][m * 6 + c];
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
