@@ -1850,6 +1850,18 @@ int pgo_create(pgo_problem** out, const pgo_options* opts) {
             launch_reduce(w, 0, 0, w + 8, p->st);
             (void)hipStreamSynchronize(p->st);
             (void)hipFree(w);
+            // the runtime's copy paths by size class (pageable host memory, both directions) set up their staging on first use: measured, the first wake-up of a session
+            // 27.3 -> 19.6 ms with these copies done here
+            double* big = nullptr;
+            if (hipMalloc((void**)&big, (size_t)4 << 20) == hipSuccess) {
+                std::vector<char> host((size_t)4 << 20, 0);
+                for (size_t bytes : {(size_t)1 << 10, (size_t)16 << 10, (size_t)32 << 10, (size_t)64 << 10, (size_t)256 << 10, (size_t)1 << 20, (size_t)4 << 20}) {
+                    (void)hipMemcpyAsync(big, host.data(), bytes, hipMemcpyHostToDevice, p->st);
+                    (void)hipMemcpyAsync(host.data(), big, bytes, hipMemcpyDeviceToHost, p->st);
+                    (void)hipStreamSynchronize(p->st);
+                }
+                (void)hipFree(big);
+            }
             (void)hipGetLastError();
         }
     }
