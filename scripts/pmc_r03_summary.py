@@ -50,7 +50,7 @@ k1 = {'round': 'r03', 'libpgo_sha256': sha, 'kernel': 'k1_edges_kernel<true, fal
 json.dump(k1, open('profiles/k1_pmc_r03.json', 'w'), indent=1); json.dump(k1, open('profiles/k1_pmc_latest.json', 'w'), indent=1)
 for name in ('r03_bench.json', 'r03_bench_under_rocprof.json', 'r03_bench_kernel_stats.txt', 'r03_mg_kernel_stats.txt', 'r03_k1_400k_kernel_stats.txt', 'r03_session_kernel_stats.txt', 'r03_all_configs.txt',
              'r03_mg_graph_types.txt', 'r03_smoothed_ab.txt', 'r03_session_replay_2deg.jsonl', 'r03_bench_gloo2.json', 'r03_multi_overhead.json', 'r03_multi_overhead_mg.json',
-             'r03_c5_tolerance.txt', 'r03_c3_tolerance_scan.txt', 'r03_session_step_times.txt'):
+             'r03_c5_tolerance.txt', 'r03_c3_tolerance_scan.txt', 'r03_session_step_times.txt', 'r03_mg_crossover.txt'):
     src = os.path.join(D, name)
     if os.path.exists(src): shutil.copy(src, os.path.join('profiles', name))
 print('\n'.join(out)); print(json.dumps(k1, indent=1))

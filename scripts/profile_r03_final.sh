@@ -48,6 +48,7 @@ python scripts/gpu_sa_ab.py c3,c4,types > $OUT/r03_smoothed_ab.txt 2>&1; stamp $
 python scripts/gpu_session_replay.py 3000 600 100 2 > $OUT/r03_session_replay_2deg.jsonl 2> $OUT/replay.err
 python scripts/gpu_c5_tolerance_check.py 2>&1 | grep -v "^\[pgo\]" > $OUT/r03_c5_tolerance.txt; stamp $OUT/r03_c5_tolerance.txt
 python scripts/gpu_c3_tolerance_scan.py 2>&1 | grep -v "^\[pgo\]" > $OUT/r03_c3_tolerance_scan.txt; stamp $OUT/r03_c3_tolerance_scan.txt
+python scripts/gpu_mg_crossover.py 4000,6000,8000,12000,18000 2>&1 | grep -v "^\[pgo\]" > $OUT/r03_mg_crossover.txt; stamp $OUT/r03_mg_crossover.txt
 python scripts/research/session_step_times.py 400,1000,3000 2>&1 | grep -v "^\[pgo\]" > $OUT/r03_session_step_times.txt; stamp $OUT/r03_session_step_times.txt
 python scripts/gpu_multi_overhead.py > $OUT/multi_overhead.log 2>&1
 python scripts/gpu_multi_overhead.py mg > $OUT/multi_overhead_mg.log 2>&1

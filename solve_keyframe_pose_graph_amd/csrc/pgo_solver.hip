@@ -479,7 +479,11 @@ int build_multigrid(pgo_problem* p, const double* sw_now) {
     mg_job_cancel(p);
     p->coarse_built = false; p->coarse_active = false; p->K = CoarseDev{};
     p->mg_built = false; p->mg_active = false; p->M = MgDev{}; p->mg_geometry_epoch = 0;
-    if (p->opt.mg_min_keyframes > 0 && p->N_global >= p->opt.mg_min_keyframes) {      // (the caller's keyframe count decides: the same answer on every rank)
+    // the caller's keyframe and switch counts decide (the same answer on every rank): graphs with switchable loop closures — all of the reference's — take the multigrid from
+    // mg_min_keyframes_switchable on, graphs without from mg_min_keyframes; mg_min_keyframes = 0 turns it off altogether
+    int64_t mg_from = p->opt.mg_min_keyframes;
+    if (mg_from > 0 && p->S > 0 && p->opt.mg_min_keyframes_switchable > 0) mg_from = std::min<int64_t>(mg_from, p->opt.mg_min_keyframes_switchable);
+    if (mg_from > 0 && p->N_global >= mg_from) {
         MgPrepared Q;
         if ((rc = mg_prepare(p, sw_now, Q)) != PGO_OK) return rc;
         if ((rc = mg_install(p, Q)) != PGO_OK) return rc;
@@ -1807,6 +1811,7 @@ void pgo_options_init(pgo_options* o) {
     o->coarse_aggregates = 768;
     o->coarse_min_radius = 1e7;
     o->mg_min_keyframes = 24000;
+    o->mg_min_keyframes_switchable = 8000;
     o->mg_omega = 0.9;
     o->mg_correction_scale = 1.0;
     o->mg_first_passes = 3;
@@ -1902,7 +1907,7 @@ int pgo_set_options(pgo_problem* p, const pgo_options* o) {
     mg_job_cancel(p);
     if (o->linear_solver != p->opt.linear_solver) p->graph_dirty = true;
     // the preconditioner hierarchies are part of the device graph build
-    if (o->mg_min_keyframes != p->opt.mg_min_keyframes || o->mg_first_passes != p->opt.mg_first_passes || o->mg_passes != p->opt.mg_passes ||
+    if (o->mg_min_keyframes != p->opt.mg_min_keyframes || o->mg_min_keyframes_switchable != p->opt.mg_min_keyframes_switchable || o->mg_first_passes != p->opt.mg_first_passes || o->mg_passes != p->opt.mg_passes ||
         o->mg_dense_max_nodes != p->opt.mg_dense_max_nodes || o->coarse_aggregates != p->opt.coarse_aggregates || o->mg_smoothed_levels != p->opt.mg_smoothed_levels || o->mg_loop_discount != p->opt.mg_loop_discount) p->graph_dirty = true;
     p->opt = *o;
     p->opt.device_id = dev;   // the device binding is fixed at create
