@@ -194,7 +194,23 @@ typedef struct pgo_iteration {
     double trust_region_radius;
     double cg_residual;        /* final relative preconditioned residual of the PCG solve */
     double seconds;            /* wall seconds of this iteration (device-synchronised) */
+    int32_t reason;            /* PGO_STEP_*: WHY the step ended the way step_is_valid / step_is_successful say */
+    int32_t preconditioner;    /* PGO_PRECOND_* of the PCG that produced the step | PGO_PRECOND_RETRIED when a breakdown under the two-level method / the
+                                * multigrid was answered by solving the same system again with plain block-Jacobi */
 } pgo_iteration;
+
+/* pgo_iteration.reason.  Ceres' IterationSummary only has step_is_valid / step_is_successful; an inexact linear solver adds ways for a step to fail that a log must
+ * be able to tell apart (trust_region_minimizer.cc: HandleInvalidStep / HandleUnsuccessfulStep / convergence tests). */
+enum {
+    PGO_STEP_ACCEPTED = 0,               /* relative_decrease > min_relative_decrease (iteration 0 carries this value too) */
+    PGO_STEP_REJECTED_RHO = 1,           /* full-accuracy step evaluated, relative_decrease <= min_relative_decrease (Ceres' unsuccessful step) */
+    PGO_STEP_REJECTED_AT_PAUSE = 2,      /* rejected at an early-rejection pause (cg_early_tolerance / cg_mid_tolerance): the logged values are those at the pause */
+    PGO_STEP_INVALID_FACTORIZATION = 3,  /* a damped 6x6 diagonal block was not positive definite (Ceres: linear solver failure) */
+    PGO_STEP_INVALID_BREAKDOWN = 4,      /* the PCG broke down (p.Ap <= 0, r.z < 0 or NaN) — also after the block-Jacobi retry */
+    PGO_STEP_INVALID_MODEL = 5,          /* model_cost_change <= 0 or not finite */
+    PGO_STEP_CONVERGED = 6               /* parameter or function tolerance fired on this step: the minimiser stopped, the step is not applied (Ceres) */
+};
+enum { PGO_PRECOND_BLOCK_JACOBI = 0, PGO_PRECOND_TWO_LEVEL = 1, PGO_PRECOND_MULTIGRID = 2, PGO_PRECOND_RETRIED = 16 };
 
 /* pgo_summary.iterations[] keeps the first PGO_MAX_ITERATION_LOG records (iteration 0 included); a stepping run that goes on longer
  * (pgo_lm_step with ignore_termination) still counts every iteration in num_iterations / cg_iterations — compare num_logged. */
@@ -216,7 +232,13 @@ typedef struct pgo_summary {
     pgo_iteration iterations[PGO_MAX_ITERATION_LOG];
     char message[256];
     int64_t cg_iterations_multigrid; /* of cg_iterations: those preconditioned by the aggregation multigrid (the rest: block-Jacobi / two-level) */
+    int32_t pcg_retries;             /* LM systems whose PCG broke down under the two-level method / the multigrid and were solved again by plain block-Jacobi */
+    int32_t reserved2_;
 } pgo_summary;
+
+/* sizeof(pgo_options), sizeof(pgo_iteration), sizeof(pgo_summary) as the LIBRARY was compiled: a caller built against another header version finds out at start-up
+ * instead of reading a shifted struct (which = 0, 1, 2; anything else: 0). */
+int64_t pgo_abi_sizeof(int32_t which);
 
 /* ------------------------------------------------------------------------------------------ */
 /* lifecycle                                                                                  */

@@ -35,19 +35,25 @@ class Iteration(C.Structure):
     _fields_ = [("iteration", C.c_int32), ("step_is_valid", C.c_int32), ("step_is_successful", C.c_int32), ("cg_iterations", C.c_int32),
                 ("cost", C.c_double), ("cost_change", C.c_double), ("model_cost_change", C.c_double), ("relative_decrease", C.c_double),
                 ("gradient_max_norm", C.c_double), ("step_norm", C.c_double), ("trust_region_radius", C.c_double), ("cg_residual", C.c_double),
-                ("seconds", C.c_double)]
+                ("seconds", C.c_double), ("reason", C.c_int32), ("preconditioner", C.c_int32)]
+
+
+# pgo_iteration.reason / .preconditioner (include/pgo.h)
+STEP_ACCEPTED, STEP_REJECTED_RHO, STEP_REJECTED_AT_PAUSE, STEP_INVALID_FACTORIZATION, STEP_INVALID_BREAKDOWN, STEP_INVALID_MODEL, STEP_CONVERGED = range(7)
+STEP_REASONS = ["accepted", "rejected-rho", "rejected-at-pause", "invalid-factorization", "invalid-breakdown", "invalid-model", "converged"]
+PRECOND_BLOCK_JACOBI, PRECOND_TWO_LEVEL, PRECOND_MULTIGRID, PRECOND_RETRIED = 0, 1, 2, 16
 
 
 class Summary(C.Structure):
     _fields_ = [("termination_type", C.c_int32), ("num_iterations", C.c_int32), ("num_successful_steps", C.c_int32), ("num_unsuccessful_steps", C.c_int32),
                 ("cg_iterations", C.c_int64), ("initial_cost", C.c_double), ("final_cost", C.c_double), ("seconds_total", C.c_double),
                 ("seconds_device", C.c_double), ("num_logged", C.c_int32), ("reserved_", C.c_int32),
-                ("iterations", Iteration * PGO_MAX_ITERATION_LOG), ("message", C.c_char * 256), ("cg_iterations_multigrid", C.c_int64)]
+                ("iterations", Iteration * PGO_MAX_ITERATION_LOG), ("message", C.c_char * 256), ("cg_iterations_multigrid", C.c_int64), ("pcg_retries", C.c_int32), ("reserved2_", C.c_int32)]
 
 
 # every symbol include/pgo.h declares (checked by tests/test_capi_symbols.py against the header text)
 EXPORTS = [
-    "pgo_options_init", "pgo_create", "pgo_destroy", "pgo_set_options", "pgo_reserve",
+    "pgo_abi_sizeof", "pgo_options_init", "pgo_create", "pgo_destroy", "pgo_set_options", "pgo_reserve",
     "pgo_add_relpose_edges", "pgo_add_switchable_edges", "pgo_set_node_regularizers", "pgo_set_nodes_constant",
     "pgo_num_relpose_edges", "pgo_num_switchable_edges", "pgo_num_regularizers",
     "pgo_set_vio_poses", "pgo_num_vio_poses", "pgo_add_odometry_edges_from_vio", "pgo_initial_guess_from_vio", "pgo_get_relpose_edge_records",
@@ -82,6 +88,11 @@ def load(build=True):
     for f in EXPORTS:
         if not hasattr(lib, f):
             raise RuntimeError("libpgo.so does not export %s" % f)
+    lib.pgo_abi_sizeof.restype = C.c_int64
+    lib.pgo_abi_sizeof.argtypes = [C.c_int32]
+    for which, T in enumerate((Options, Iteration, Summary)):
+        if lib.pgo_abi_sizeof(which) != C.sizeof(T):
+            raise RuntimeError("capi.%s is %d bytes, libpgo.so's struct %d: the ctypes view is out of date with include/pgo.h" % (T.__name__, C.sizeof(T), lib.pgo_abi_sizeof(which)))
     _lib = lib
     return lib
 

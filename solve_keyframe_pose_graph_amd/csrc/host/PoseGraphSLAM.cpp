@@ -2,6 +2,8 @@
 #include "PoseGraphSLAM.hpp"
 #include "GraphFormats.hpp"
 
+#include <chrono>
+#include <cstdlib>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>

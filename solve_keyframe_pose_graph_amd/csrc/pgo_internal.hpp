@@ -196,7 +196,7 @@ void launch_invert_rows(const GraphDev& G, const CgDev& C, int32_t* fail_flag, h
 void launch_cg_init(const GraphDev& G, const CgDev& C, int warm /*x holds a previous solution, q = A x*/, double tol2, hipStream_t st);
 // multi-GPU: the vector half of cg_init (owner-weighted partials of r.u in part_rz and of b.M^-1 b in part_pq); returns their count
 int launch_cg_init_vectors(const GraphDev& G, const CgDev& C, int warm, hipStream_t st);
-void launch_cg_init_scalars(const CgDev& C, int nparts, double tol2, hipStream_t st);   // scal[0] = b.M^-1 b, scal[1] = r.z from the partial sums; flags reset
+void launch_cg_init_scalars(const CgDev& C, int nparts, int nparts_bb, double tol2, hipStream_t st);   // scal[0] = b.M^-1 b, scal[1] = r.z from the partial sums; flags reset
 void launch_cg_set_tolerance(const CgDev& C, double tol2, hipStream_t st);
 void launch_cg_spmv(const GraphDev& G, const CgDev& C, int k, double tol2, hipStream_t st);   // iteration k: direction + matvec (+ convergence test)
 void launch_cg_update(const GraphDev& G, const CgDev& C, int k, int n_pq_partials, hipStream_t st);
@@ -222,6 +222,7 @@ void launch_coarse_assemble(const GraphDev& G, const LinDev& L, const ScaleDev& 
 void launch_coarse_symmetrize(const CoarseDev& K, hipStream_t st);                                             // mirror one triangle
 void launch_coarse_shift(const CoarseDev& K, double eps, hipStream_t st);   // Ac_ii *= 1 + eps
 void launch_coarse_invert(const CoarseDev& K, double* scratch /* 64 nc + 1024 doubles */, int32_t* fail, hipStream_t st);   // Ac -> Ac^-1 (blocked Gauss-Jordan)
+void launch_coarse_negate(const CoarseDev& K, hipStream_t st);   // debug aid (PGO_DEBUG_BREAK_COARSE): Ac^-1 <- -Ac^-1, a preconditioner that is NOT positive definite
 // z += P Ac^-1 P^T r for the vectors of the PCG (r of the given parity), r.z partials updated in place (same workgroup -> slot mapping as cg_update)
 void launch_coarse_apply(const GraphDev& G, const CgDev& C, const CoarseDev& K, const double* r, double* z, double* part_rz, bool inside_iteration, hipStream_t st);
 // the same preconditioner inside the PCG iteration in THREE kernels (matrix-free operator, aggregates of <= 64 keyframes; pgo_kernels.hip):

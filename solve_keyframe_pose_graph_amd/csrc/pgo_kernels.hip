@@ -67,6 +67,22 @@ __device__ __forceinline__ void block_total2(const double* __restrict__ pa, int 
     for (int i = 0; i < nw; ++i) { sa += buf[i]; sb += buf[nw + i]; }
 }
 
+// three totals in one pass: the two-level method's matvec keeps the block-Jacobi part and the coarse part of r.z apart (below)
+__device__ __forceinline__ void block_total3(const double* __restrict__ pa, int na, const double* __restrict__ pb, int nb, const double* __restrict__ pc, int nc, double* buf /*3 x nwaves*/,
+                                             double& sa, double& sb, double& sc) {
+    double va = 0.0, vb = 0.0, vc = 0.0;
+    for (int i = threadIdx.x; i < na; i += blockDim.x) va += pa[i];
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) vb += pb[i];
+    for (int i = threadIdx.x; i < nc; i += blockDim.x) vc += pc[i];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    va = wave_sum(va); vb = wave_sum(vb); vc = wave_sum(vc);
+    __syncthreads();
+    if (lane == 0) { buf[wave] = va; buf[nw + wave] = vb; buf[2 * nw + wave] = vc; }
+    __syncthreads();
+    sa = 0.0; sb = 0.0; sc = 0.0;
+    for (int i = 0; i < nw; ++i) { sa += buf[i]; sb += buf[nw + i]; sc += buf[2 * nw + i]; }
+}
+
 __device__ __forceinline__ size_t tile_elem(int doubles_per_edge, int64_t e, int k) {
     return (size_t)(e >> 6) * (size_t)(doubles_per_edge * TILE) + (size_t)(k >> 1) * (2 * TILE) + (size_t)(e & 63) * 2 + (k & 1);
 }
@@ -789,7 +805,7 @@ __global__ __launch_bounds__(CG_BLOCK) void cg_spmv_kernel(GraphDev G, CgDev C, 
         // convergence on the preconditioned residual norm: every workgroup evaluates the same numbers -> uniform exit
         if (breakdown || !(rz_new > C.scal[3] * C.scal[0])) {
             // (r.z clearly negative: the preconditioner is not positive definite — a breakdown, never convergence)
-            if (blockIdx.x == 0 && threadIdx.x == 0) { C.flags[0] = 1; if (!breakdown) { C.scal[1] = rz_new; if (rz_new < -C.scal[3] * C.scal[0]) C.flags[1] = 1; } }
+            if (blockIdx.x == 0 && threadIdx.x == 0) { C.flags[0] = 1; if (!breakdown) { C.scal[1] = rz_new; if (!(rz_new >= -C.scal[3] * C.scal[0])) C.flags[1] = 1; } }
             return;
         }
         beta = rz_new / rz_old;
@@ -892,13 +908,18 @@ __global__ __launch_bounds__(CG_BLOCK) void cg_init_kernel(GraphDev G, CgDev C, 
     const double sb = block_sum(bb, red);
     if (threadIdx.x == 0) { C.part_rz[blockIdx.x] = s; C.part_pq[blockIdx.x] = sb; }
 }
-__global__ void cg_scalars_init_kernel(CgDev C, int nparts, double tol2) {
+// nparts: r.z partial slots in use (the start-up kernels' — or, two-level method in its fused form, the update kernel's, the tail zeroed by the caller);
+// nparts_bb: slots of part_pq the start-up kernel (cg_init) filled with the partials of b.D^-1 b — ITS grid, whatever nparts is.  (Round 3 read `nparts` slots of both:
+// with aggregates whose size does not divide 64 the fused update kernel has more workgroups than cg_init, and the reference norm of the stopping test picked up
+// whatever the slots behind cg_init's held — stale p.q partials of an earlier PCG, or what the allocation contained: the box-dependent C2 result of GPUTEST_r03.)
+__global__ void cg_scalars_init_kernel(CgDev C, int nparts, int nparts_bb, double tol2) {
     __shared__ double red[4];
     const double rz0 = block_total(C.part_rz, nparts + C.extra_rz, red);
-    const double bb = block_total(C.part_pq, nparts, red);
+    const double bb = block_total(C.part_pq, nparts_bb, red);
     if (threadIdx.x == 0) {
         C.scal[0] = bb; C.scal[1] = rz0; C.scal[2] = 0.0; C.scal[3] = tol2;
-        C.flags[0] = (bb > 0.0 && rz0 > 0.0) ? 0 : 1; C.flags[1] = 0; C.flags[2] = 0;
+        // r0.z0 < 0: the preconditioner is not positive definite; NaN anywhere: both are breakdowns, never "converged at iteration 0"
+        C.flags[0] = (bb > 0.0 && rz0 > 0.0) ? 0 : 1; C.flags[1] = (bb >= 0.0 && rz0 >= 0.0) ? 0 : 1; C.flags[2] = 0;
     }
 }
 
@@ -1031,7 +1052,7 @@ __global__ __launch_bounds__(CG_BLOCK) void cgcg_update_kernel(GraphDev G, CgDev
     double beta = 0.0, den = delta;
     const bool breakdown = C.flags[1] != 0;
     if (breakdown || !(gamma > C.scal[3] * C.scal[0])) {   // converged (or broken down): the state stays that of the last completed update
-        if (blockIdx.x == 0 && threadIdx.x == 0) { C.flags[0] = 1; if (!breakdown) { C.scal[1] = gamma; if (gamma < -C.scal[3] * C.scal[0]) C.flags[1] = 1; } }
+        if (blockIdx.x == 0 && threadIdx.x == 0) { C.flags[0] = 1; if (!breakdown) { C.scal[1] = gamma; if (!(gamma >= -C.scal[3] * C.scal[0])) C.flags[1] = 1; } }
         return;
     }
     if (!first) {
@@ -1096,7 +1117,7 @@ __global__ void cgcg_scalars_init_kernel(CgDev C, const double* __restrict__ bb_
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         const double bb = bb_src[0];
         C.scal[0] = bb; C.scal[1] = 0.0; C.scal[2] = 0.0; C.scal[3] = tol2;
-        C.flags[0] = bb > 0.0 ? 0 : 1; C.flags[1] = 0; C.flags[2] = 0;
+        C.flags[0] = bb > 0.0 ? 0 : 1; C.flags[1] = bb >= 0.0 ? 0 : 1; C.flags[2] = 0;
     }
 }
 
@@ -1118,9 +1139,9 @@ void launch_cg_set_tolerance(const CgDev& C, double tol2, hipStream_t st) { hipL
 void launch_cg_init(const GraphDev& G, const CgDev& C, int warm, double tol2, hipStream_t st) {
     const int g = cg_grid(G);
     hipLaunchKernelGGL(cg_init_kernel, dim3(g), dim3(CG_BLOCK), 0, st, G, C, warm);
-    hipLaunchKernelGGL(cg_scalars_init_kernel, dim3(1), dim3(256), 0, st, C, g, tol2);
+    hipLaunchKernelGGL(cg_scalars_init_kernel, dim3(1), dim3(256), 0, st, C, g, g, tol2);
 }
-void launch_cg_init_scalars(const CgDev& C, int nparts, double tol2, hipStream_t st) { hipLaunchKernelGGL(cg_scalars_init_kernel, dim3(1), dim3(256), 0, st, C, nparts, tol2); }
+void launch_cg_init_scalars(const CgDev& C, int nparts, int nparts_bb, double tol2, hipStream_t st) { hipLaunchKernelGGL(cg_scalars_init_kernel, dim3(1), dim3(256), 0, st, C, nparts, nparts_bb, tol2); }
 int launch_cg_init_vectors(const GraphDev& G, const CgDev& C, int warm, hipStream_t st) {
     const int g = cg_grid(G);
     hipLaunchKernelGGL(cg_init_kernel, dim3(g), dim3(CG_BLOCK), 0, st, G, C, warm);
@@ -1190,7 +1211,7 @@ __global__ __launch_bounds__(MF_BLOCK) void mf_spmv_kernel(GraphDev G, MfDev F, 
                                                            int parity, int first, int nparts, double tol2, CoarseDev K = CoarseDev{}, int pending = 0) {
     __shared__ double contrib[MF_SLOTS * 7];
     __shared__ double pwin[MF_BLOCK];
-    __shared__ double red[2 * (MF_BLOCK / 64)];
+    __shared__ double red[3 * (MF_BLOCK / 64)];
     const int l = threadIdx.x;
     double beta = 0.0;
     const double* __restrict__ pprev = FUSED ? (parity ? C.p : C.p2) : xin;
@@ -1214,10 +1235,21 @@ __global__ __launch_bounds__(MF_BLOCK) void mf_spmv_kernel(GraphDev G, MfDev F, 
         if (cg_done(C)) return;
         if (!first) {
             double rz_new, rz_old;
-            block_total2(C.part_rz + parity * RZ_STRIDE, nparts + C.extra_rz, C.part_rz + (parity ^ 1) * RZ_STRIDE, nparts + C.extra_rz, red, rz_new, rz_old);
+            bool coarse_negative = false;
+            if (COARSE) {
+                // Two-level method: r.z = r.D^-1 r (the update kernel's partials) + rc.Ac^-1 rc (the dense solve's partials, behind them).  With the exact coarse inverse the
+                // second term is >= 0, so r.z <= tol^2 b.D^-1 b implies the same for the block-Jacobi part alone.  The inverse is applied rounded to fp32, and at large
+                // trust-region radii (coarse condition numbers beyond 2^24) it need not be positive definite any more: a negative coarse term can pull r.z below the
+                // tolerance — or through zero — while the residual is still large.  So convergence that the block-Jacobi part alone does not confirm is a BREAKDOWN
+                // (lm_step then finishes the system with plain block-Jacobi from the current iterate), never a converged step.  K.m == 1: z is the coarse term alone.
+                double rz_bj, rz_c;
+                block_total3(C.part_rz + parity * RZ_STRIDE, nparts, C.part_rz + parity * RZ_STRIDE + nparts, C.extra_rz, C.part_rz + (parity ^ 1) * RZ_STRIDE, nparts + C.extra_rz, red, rz_bj, rz_c, rz_old);
+                rz_new = rz_bj + rz_c;
+                coarse_negative = K.m != 1 && !(rz_new > C.scal[3] * C.scal[0]) && rz_bj > C.scal[3] * C.scal[0];
+            } else block_total2(C.part_rz + parity * RZ_STRIDE, nparts + C.extra_rz, C.part_rz + (parity ^ 1) * RZ_STRIDE, nparts + C.extra_rz, red, rz_new, rz_old);
             const bool breakdown = C.flags[1] != 0;
             if (breakdown || !(rz_new > C.scal[3] * C.scal[0])) {
-                if (blockIdx.x == 0 && threadIdx.x == 0) { C.flags[0] = 1; if (!breakdown) { C.scal[1] = rz_new; if (rz_new < -C.scal[3] * C.scal[0]) C.flags[1] = 1; } }
+                if (blockIdx.x == 0 && threadIdx.x == 0) { C.flags[0] = 1; if (!breakdown) { C.scal[1] = rz_new; if (coarse_negative || !(rz_new >= -C.scal[3] * C.scal[0])) C.flags[1] = 1; } }
                 return;
             }
             beta = rz_new / rz_old;
@@ -2261,6 +2293,17 @@ __global__ void coarse_shift_kernel(CoarseDev K, double eps) {
     if (i < K.nc) K.Ac[(size_t)i * K.nc + i] *= 1.0 + eps;
 }
 void launch_coarse_shift(const CoarseDev& K, double eps, hipStream_t st) { hipLaunchKernelGGL(coarse_shift_kernel, dim3((unsigned)((K.nc + 255) / 256)), dim3(256), 0, st, K, eps); }
+
+// debug aid: the dense inverse (and its fp32 image) with the sign flipped — the coarse part of the preconditioner becomes negative definite, r.z goes negative
+// within an iteration or two, and the PCG must report a breakdown (tests/test_gpu_breakdown_retry.py drives the block-Jacobi retry of lm_step through it)
+__global__ void coarse_negate_kernel(CoarseDev K) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (size_t)K.nc * K.nc) { K.Ac[i] = -K.Ac[i]; if (K.Acf) K.Acf[i] = -K.Acf[i]; }
+}
+void launch_coarse_negate(const CoarseDev& K, hipStream_t st) {
+    const size_t n = (size_t)K.nc * K.nc;
+    if (n) hipLaunchKernelGGL(coarse_negate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, K);
+}
 
 // Ac (assembled, padded) -> Ac^-1, exactly symmetric; *fail != 0 when a pivot was not positive
 void launch_coarse_invert(const CoarseDev& K, double* scratch /* 64 nc + 1024 doubles */, int32_t* fail, hipStream_t st) {

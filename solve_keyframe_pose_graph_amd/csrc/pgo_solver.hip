@@ -30,6 +30,15 @@ namespace {
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// PGO_DEBUG_POISON=1 (debug aid, read once per process): every new device allocation is filled with 0xFF bytes — a NaN in every double / float, -1 in every index —
+// so that a kernel reading memory nobody wrote fails the same way on every box instead of depending on what the allocation held before (tests/test_gpu_poison.py runs
+// the parity suite's solves under it and compares the results bit for bit with an unpoisoned run).
+bool debug_poison() { static const bool on = []() { const char* e = std::getenv("PGO_DEBUG_POISON"); return e && e[0] == '1'; }(); return on; }
+
+// PGO_DEBUG_BREAK_COARSE=1 (debug aid, read at every operator build so that a test can switch it inside one process): the dense coarse inverse of the two-level method /
+// of the multigrid's coarsest level is applied with the wrong sign — a preconditioner that is not positive definite, i.e. a forced PCG breakdown.
+bool debug_break_coarse() { const char* e = std::getenv("PGO_DEBUG_BREAK_COARSE"); return e && e[0] == '1'; }
+
 template <class T>
 struct DBuf {
     T* p = nullptr;
@@ -40,9 +49,17 @@ struct DBuf {
         const size_t want = n + n / 8 + 64;
         hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
         if (e == hipSuccess) cap = want;
+        if (e == hipSuccess && debug_poison()) { e = hipMemset(p, 0xFF, want * sizeof(T)); if (e == hipSuccess) e = hipDeviceSynchronize(); }
         return e;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+// a pair of timing events destroyed on EVERY exit of the function that holds it (the HIPCHK early returns included)
+struct EventPair {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t create() { hipError_t e = hipEventCreate(&e0); if (e == hipSuccess) e = hipEventCreate(&e1); return e; }
+    ~EventPair() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
 };
 
 // function-local device scratch (freed at scope exit; DBuf members of pgo_problem are released by pgo_destroy)
@@ -1024,13 +1041,14 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
         if (!multi && (p->coarse_active || p->mg_active)) {
             // z = D^-1 r + P Ac^-1 P^T r (or the multigrid cycle): the coarse term is added to z and to the r.z partials before the scalars are formed
             int g = launch_cg_init_vectors(p->G, p->C, warm ? 1 : 0, p->st);
+            const int g_bb = g;      // the slots of part_pq that hold the partials of b.D^-1 b
             if (p->mg_active) launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz, mg_scale(p), false, p->st, false, mg_cs(p));
             else launch_coarse_apply(p->G, p->C, p->K, p->C.r, p->C.z, p->C.part_rz, false, p->st);
             if (fused_coarse) {    // z is complete here: the slots the fused kernels will use beyond the start-up kernels' stay zero for this parity
                 HIPCHK(p, hipMemsetAsync(p->C.part_rz + g, 0, (size_t)(fused_parts + p->C.extra_rz - g) * sizeof(double), p->st));
                 g = fused_parts;
             }
-            launch_cg_init_scalars(p->C, g, tol2, p->st);
+            launch_cg_init_scalars(p->C, g, g_bb, tol2, p->st);
         } else if (!multi) launch_cg_init(p->G, p->C, warm ? 1 : 0, tol2, p->st);
         else if ((rc0 = start_multi(warm ? 1 : 0)) != PGO_OK) return rc0;
     }
@@ -1147,7 +1165,7 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
         } else {
             const int g = launch_cg_init_vectors(p->G, p->C, 1, p->st);
             launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz, mg_scale(p), false, p->st, false, mg_cs(p));
-            launch_cg_init_scalars(p->C, g, tol2, p->st);
+            launch_cg_init_scalars(p->C, g, g, tol2, p->st);
         }
         k = 0; n_chunks = 0; waited = -1; r1_refreshed_at = 0;
         every = chunk_length();
@@ -1263,6 +1281,7 @@ static int build_coarse(pgo_problem* p) {
     int32_t* fail = p->d_cinfo.p;
     HIPCHK(p, hipMemsetAsync(fail, 0, sizeof(int32_t), p->st));
     launch_coarse_invert(p->K, p->d_cscr.p, fail, p->st);
+    if (debug_break_coarse()) launch_coarse_negate(p->K, p->st);
     int32_t h = 1;
     HIPCHK(p, hipMemcpyAsync(&h, fail, sizeof(h), hipMemcpyDeviceToHost, p->st));
     HIPCHK(p, hipStreamSynchronize(p->st));
@@ -1281,22 +1300,42 @@ static int build_coarse(pgo_problem* p) {
 // level-1 structure are cached: pgo_mg::BuildCache) — at most twice per solve.  Several ranks: the count is all-reduced, every rank regroups at the same LM step.
 // how many switchable edges have moved by > 0.5 in s^2 since the hierarchy was matched, against ALL residual blocks (what counts is how much of the coupling structure
 // changed: C4 has 2 % loop closures — no regroup pays there); summed over the ranks
-static int regroup_count(pgo_problem* p, const double* sv, std::vector<double>& cnt) {
+static int regroup_count(pgo_problem* p, const double* sv, std::vector<double>& cnt, double moved_by = 0.5) {
     const int64_t Es = p->swe.size();
     cnt.assign(2, 0.0);
-    for (int64_t e = 0; e < Es; ++e) { const double w = sv[p->swe.sw[e]] * sv[p->swe.sw[e]]; if (std::fabs(w - p->mg_sw_built[e]) > 0.5) cnt[0] += 1.0; }
+    for (int64_t e = 0; e < Es; ++e) { const double w = sv[p->swe.sw[e]] * sv[p->swe.sw[e]]; if (std::fabs(w - p->mg_sw_built[e]) > moved_by) cnt[0] += 1.0; }
     cnt[1] = (double)(Es + p->rel.size());
     return p->local_ids ? host_allreduce(p, cnt, 0) : PGO_OK;
+}
+// A regroup is TRANSACTIONAL: the hierarchy in place is replaced only by one that coarsened; when the matching along the current couplings stalls (build_hierarchy
+// gives up above 0.85 nodes per node, or runs out of levels) the installed hierarchy stays — with the new switch record, so that the same failing attempt is not
+// repeated at every later check — instead of the handle silently falling back to plain block-Jacobi for the rest of its life.
+static int regroup_commit(pgo_problem* p, MgPrepared& Q) {
+    if (!Q.ok) {
+        if (p->opt.verbosity > 0) std::fprintf(stderr, "[pgo] multigrid: the regrouped hierarchy does not coarsen -> the one in place stays\n");
+        p->mg_sw_built.swap(Q.sw_built);
+        return PGO_OK;
+    }
+    int rc;
+    HIPCHK(p, hipStreamSynchronize(p->st));
+    if ((rc = mg_install(p, Q)) != PGO_OK) return rc;
+    ++p->build_epoch;      // captured PCG chunks hold pointers into the old pools
+    return PGO_OK;
 }
 static int regroup_if_moved(pgo_problem* p, const double* sv /* host: the caller's switch array */, bool in_solve) {
     std::vector<double> cnt;
     int rc;
-    if ((rc = regroup_count(p, sv, cnt)) != PGO_OK) return rc;
-    if (!(cnt[0] > p->opt.mg_regroup_fraction * cnt[1])) return PGO_OK;
+    if ((rc = regroup_count(p, sv, cnt, in_solve ? 0.5 : 0.0)) != PGO_OK) return rc;
+    // inside a solve: once the moved edges are a sizeable part of the coupling structure.  At the START of a solve: whenever ANY switch differs from the record — the
+    // hierarchy a solve starts with is then a function of the graph and of the solve's own start values alone, whatever earlier solves of the handle left behind
+    // (pgo.h: "no per-handle history"; tests/test_gpu_determinism.py solves from state A after a solve that regrouped and compares with a fresh handle, bit for bit).
+    if (in_solve ? !(cnt[0] > p->opt.mg_regroup_fraction * cnt[1]) : !(cnt[0] > 0.0)) return PGO_OK;
     const double t0 = now_s();
-    if ((rc = build_multigrid(p, sv)) != PGO_OK) return rc;
+    mg_job_cancel(p);
+    MgPrepared Q;
+    if ((rc = mg_prepare(p, sv, Q)) != PGO_OK) return rc;
+    if ((rc = regroup_commit(p, Q)) != PGO_OK) return rc;
     if (in_solve) ++p->mg_regroups;
-    ++p->build_epoch;      // captured PCG chunks hold pointers into the old pools
     if (p->opt.verbosity > 0) std::fprintf(stderr, "[pgo] multigrid: regrouped %s (%.0f switchable edges of %.0f edges moved), %.1f ms\n", in_solve ? "inside the solve" : "for the new start", cnt[0], cnt[1], (now_s() - t0) * 1e3);
     return PGO_OK;
 }
@@ -1348,9 +1387,7 @@ static int regroup_install(pgo_problem* p) {
     if (p->rc_job != PGO_OK || !Q) return p->rc_job;
     const double waited = (now_s() - t0) * 1e3;
     int rc;
-    HIPCHK(p, hipStreamSynchronize(p->st));
-    if ((rc = mg_install(p, *Q)) != PGO_OK) return rc;
-    ++p->build_epoch;      // captured PCG chunks hold pointers into the old pools
+    if ((rc = regroup_commit(p, *Q)) != PGO_OK) return rc;
     // The host image is NOT freed here: it was allocated by the worker thread (an mmap-backed malloc arena), and returning ~100 MB of it to the system from this thread
     // costs 5 ms of munmap plus a ~10 ms stall of the next kernels (measured: MMU-notifier invalidations reach the GPU's address space).  It is kept until the next
     // regroup's worker (or pgo_destroy) drops it, off the solve's critical path.
@@ -1400,6 +1437,7 @@ static int build_mg(pgo_problem* p) {
     } else launch_mg_assemble(p->G, p->L, p->Sc, p->C, p->M, p->mg_levels, p->K, omega, fail, p->st, mg_cs(p), hoff_valid);
     if (p->opt.verbosity > 1) { HIPCHK(p, hipStreamSynchronize(p->st)); std::fprintf(stderr, "[pgo] multigrid: level operators done at %.2f ms\n", (now_s() - t_build0) * 1e3); }
     launch_coarse_invert(p->K, p->d_cscr.p, fail, p->st);
+    if (debug_break_coarse()) launch_coarse_negate(p->K, p->st);
     int32_t h = 1;
     HIPCHK(p, hipMemcpyAsync(&h, fail, sizeof(h), hipMemcpyDeviceToHost, p->st));
     HIPCHK(p, hipStreamSynchronize(p->st));
@@ -1462,11 +1500,16 @@ int build_system(pgo_problem* p, bool* ok) {
     return PGO_OK;
 }
 
+const char* step_reason_text(int r) {
+    static const char* const t[] = {"ok", "REJ(rho)", "REJ(pause)", "INVALID(factorization)", "INVALID(breakdown)", "INVALID(model)", "CONVERGED"};
+    return r >= 0 && r < 7 ? t[r] : "?";
+}
+
 void log_iter(pgo_problem* p, const pgo_iteration& it) {
     if (p->sum.num_logged < PGO_MAX_ITERATION_LOG) p->sum.iterations[p->sum.num_logged++] = it;
     if (p->opt.verbosity > 0)
         std::fprintf(stderr, "[pgo] it %3d cost %.12e dcost %.3e rho %.3e |step| %.3e radius %.3e cg %d (%.1e) %s %.2f ms\n", it.iteration, it.cost, it.cost_change,
-                     it.relative_decrease, it.step_norm, it.trust_region_radius, it.cg_iterations, it.cg_residual, it.step_is_successful ? "ok" : (it.step_is_valid ? "REJ" : "INVALID"), it.seconds * 1e3);
+                     it.relative_decrease, it.step_norm, it.trust_region_radius, it.cg_iterations, it.cg_residual, step_reason_text(it.reason), it.seconds * 1e3);
 }
 
 void terminate(pgo_problem* p, int type, const char* msg) {
@@ -1541,6 +1584,8 @@ int lm_step(pgo_problem* p, int ignore_termination, int* done) {
     if (!p->reuse_diagonal) launch_lm_diag(p->G, p->L, p->Sc, o.min_lm_diagonal, o.max_lm_diagonal, p->st);
     bool ok = true;
     if ((rc = build_system(p, &ok)) != PGO_OK) return rc;
+    int why_invalid = ok ? PGO_STEP_ACCEPTED : PGO_STEP_INVALID_FACTORIZATION;      // pgo_iteration.reason of an invalid step
+    int precond_used = PGO_PRECOND_BLOCK_JACOBI;
     CgResult cg{0, false, 0.0, false};
     p->cg_extra = 0;
     const int nxt = p->cur ^ 1;
@@ -1619,16 +1664,27 @@ int lm_step(pgo_problem* p, int ignore_termination, int* done) {
                 cg.iterations += plain.iterations;
             }
         }
-        // A breakdown under the multigrid (its cycle was not positive definite on this system — a smoother at its stability limit) is not the system's fault:
-        // the same system is solved again by plain block-Jacobi before the step may count as invalid.
-        if (cg.breakdown && p->mg_active && !evaluated) {
-            if (o.verbosity > 0) std::fprintf(stderr, "[pgo] multigrid: PCG breakdown at radius %.1e (cycle not positive definite) -> block-Jacobi for this system\n", p->radius);
-            p->mg_active = false; p->mg_failed = true; p->C.extra_rz = 0;
+        // A breakdown under the multigrid (its cycle was not positive definite on this system — a smoother at its stability limit) or under the two-level method (its
+        // dense coarse inverse is applied rounded to fp32: at large trust-region radii the coarse operator's condition number exceeds what fp32 resolves, and the rounded
+        // inverse need not be positive definite) is not the system's fault: the same system is solved again by plain block-Jacobi before the step may count as invalid.
+        // Ceres' exact factorisation never turns a solvable step into an invalid one (reference src/PoseGraphSLAM.cpp:1903).
+        precond_used = p->mg_active ? PGO_PRECOND_MULTIGRID : (p->coarse_active ? PGO_PRECOND_TWO_LEVEL : PGO_PRECOND_BLOCK_JACOBI);
+        if (cg.breakdown && (p->mg_active || p->coarse_active) && !evaluated) {
+            if (o.verbosity > 0) std::fprintf(stderr, "[pgo] %s: PCG breakdown at radius %.1e after %d iterations (preconditioner not positive definite) -> block-Jacobi for this system\n",
+                                              p->mg_active ? "multigrid" : "two-level method", p->radius, cg.iterations);
+            if (p->mg_active) { p->mg_active = false; p->mg_failed = true; }
+            p->coarse_active = false;      // (this system only: build_coarse decides again for the next one)
+            p->C.extra_rz = 0;
             p->cg_extra += cg.iterations;
-            if ((rc = run_pcg(p, &cg, false, o.cg_rel_tolerance, -1)) != PGO_OK) return rc;
+            ++p->sum.pcg_retries;
+            precond_used = PGO_PRECOND_BLOCK_JACOBI | PGO_PRECOND_RETRIED;
+            // The iterate the broken-down PCG stopped at is a valid starting point (x_k with r_k = b - A x_k; a breakdown leaves x untouched): warm start.  Should that one
+            // break down as well (a NaN that reached x), the system is solved from zero.
+            if ((rc = run_pcg(p, &cg, true, o.cg_rel_tolerance, -1)) != PGO_OK) return rc;
+            if (cg.breakdown) { p->cg_extra += cg.iterations; if ((rc = run_pcg(p, &cg, false, o.cg_rel_tolerance, -1)) != PGO_OK) return rc; }
         }
         p->have_prev_step = !cg.breakdown;
-        if (cg.breakdown) ok = false;
+        if (cg.breakdown) { ok = false; why_invalid = PGO_STEP_INVALID_BREAKDOWN; }
         // block-Jacobi-equivalent work of this system, for the next system's choice of preconditioner (build_system)
         if (!evaluated && !cg.breakdown) {
             const double equiv = p->mg_levels[0].smoothed ? 8.0 : 4.0;     // block-Jacobi iterations one multigrid iteration stands for on a hard system
@@ -1642,11 +1698,12 @@ int lm_step(pgo_problem* p, int ignore_termination, int* done) {
     if (ok) {
         if (!evaluated && (rc = evaluate_candidate()) != PGO_OK) return rc;
         it.model_cost_change = -h[S_MODEL];
-        if (!(it.model_cost_change > 0.0) || !std::isfinite(it.model_cost_change)) ok = false;
+        if (!(it.model_cost_change > 0.0) || !std::isfinite(it.model_cost_change)) { ok = false; why_invalid = PGO_STEP_INVALID_MODEL; }
     }
+    it.preconditioner = precond_used;
     if (!ok) {
         // HandleInvalidStep
-        it.step_is_valid = 0; it.cost = p->x_cost; it.gradient_max_norm = p->gmax;
+        it.step_is_valid = 0; it.cost = p->x_cost; it.gradient_max_norm = p->gmax; it.reason = why_invalid;
         ++p->invalid; ++p->sum.num_unsuccessful_steps;
         if (p->invalid >= o.max_num_consecutive_invalid_steps && !ignore_termination) {
             terminate(p, PGO_FAILURE, "Number of consecutive invalid steps more than max_num_consecutive_invalid_steps.");
@@ -1671,6 +1728,7 @@ int lm_step(pgo_problem* p, int ignore_termination, int* done) {
         else if (std::fabs(it.cost_change) <= o.function_tolerance * p->x_cost) { terminate(p, PGO_CONVERGENCE, "Function tolerance reached."); stop = true; }
     }
     if (stop) {
+        it.reason = PGO_STEP_CONVERGED;
         it.cost = p->x_cost; it.gradient_max_norm = p->gmax; it.seconds = now_s() - t0; log_iter(p, it);
         if (done) *done = 1;
         return PGO_OK;
@@ -1686,10 +1744,12 @@ int lm_step(pgo_problem* p, int ignore_termination, int* done) {
         p->radius = std::min(o.max_trust_region_radius, p->radius);
         p->decrease_factor = 2.0; p->reuse_diagonal = false;
         p->last_rho = it.relative_decrease;
+        it.reason = PGO_STEP_ACCEPTED;
         ++p->sum.num_successful_steps;
         if ((rc = regroup_start(p)) != PGO_OK) return rc;     // the switches have moved: does the hierarchy above level 1 still fit them?
     } else {
         p->radius = p->radius / p->decrease_factor; p->decrease_factor *= 2.0; p->reuse_diagonal = true;   // StepRejected
+        it.reason = evaluated ? PGO_STEP_REJECTED_AT_PAUSE : PGO_STEP_REJECTED_RHO;
         ++p->sum.num_unsuccessful_steps;
     }
     it.cost = p->x_cost; it.gradient_max_norm = p->gmax; it.seconds = now_s() - t0;
@@ -1783,6 +1843,8 @@ int add_edges(pgo_problem* p, HostClass& H, int64_t n, const int32_t* c1, const 
 // C-ABI
 // ================================================================================================
 extern "C" {
+
+int64_t pgo_abi_sizeof(int32_t which) { return which == 0 ? (int64_t)sizeof(pgo_options) : which == 1 ? (int64_t)sizeof(pgo_iteration) : which == 2 ? (int64_t)sizeof(pgo_summary) : 0; }
 
 void pgo_options_init(pgo_options* o) {
     if (!o) return;
@@ -1942,6 +2004,7 @@ int pgo_set_node_regularizers(pgo_problem* p, int64_t n, const int32_t* node, co
         eigen_matrix_to_quat(P.Rf, P.qf);
         P.w = weight[k]; P.node = node[k]; P.pad_ = 0;
     }
+    mg_job_cancel(p);
     p->priors.swap(v);
     p->priors_dirty = true;
     return PGO_OK;
@@ -1949,6 +2012,7 @@ int pgo_set_node_regularizers(pgo_problem* p, int64_t n, const int32_t* node, co
 int pgo_set_nodes_constant(pgo_problem* p, int64_t n, const int32_t* node) {
     if (!p || n < 0 || (n > 0 && !node)) return PGO_ERR_INVALID_ARG;
     for (int64_t k = 0; k < n; ++k) if (node[k] < 0) return PGO_ERR_INVALID_ARG;
+    mg_job_cancel(p);      // (the worker reads h_node_free / constant_nodes)
     p->constant_nodes.insert(p->constant_nodes.end(), node, node + n);
     p->graph_dirty = true;
     return PGO_OK;
@@ -1978,6 +2042,7 @@ int pgo_add_odometry_edges_from_vio(pgo_problem* p, const int32_t* set_id, int64
     if (!p || u_begin < 0 || u_end < u_begin || f_max < 1) return PGO_ERR_INVALID_ARG;
     if (u_end > p->n_vio) { p->err = "odometry edges requested beyond the resident VIO poses"; return PGO_ERR_INVALID_ARG; }
     if (p->in_solve) { p->err = "graph construction inside a solve"; return PGO_ERR_STATE; }
+    mg_job_cancel(p);      // (a regroup's worker left behind by a failed solve reads the edge lists)
     std::vector<int32_t> c1, c2;
     c1.reserve((size_t)(u_end - u_begin) * f_max); c2.reserve(c1.capacity());
     for (int64_t u = u_begin; u < u_end; ++u)
@@ -2052,24 +2117,36 @@ int pgo_solve_begin(pgo_problem* p, const double* q, const double* t, const doub
     if (!p) return PGO_ERR_INVALID_ARG;
     return solve_begin(p, q, t, sw, N, S);
 }
+// a failed step or write-back: no regroup worker outlives it (it reads host arrays the caller may change next), and a stream capture a failing launch left open is ended
+static void after_failure(pgo_problem* p) {
+    mg_job_cancel(p);
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (p->st && hipStreamIsCapturing(p->st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(p->st, &g); if (g) (void)hipGraphDestroy(g); p->cg_graph_failed = true; }
+    (void)hipGetLastError();
+}
 int pgo_lm_step(pgo_problem* p, int32_t ignore_termination, int32_t* done) {
     if (!p) return PGO_ERR_INVALID_ARG;
     int d = 0;
     const int rc = lm_step(p, ignore_termination, &d);
+    if (rc != PGO_OK) after_failure(p);
     if (done) *done = d;
     return rc;
 }
 int pgo_solve_end(pgo_problem* p, double* q, double* t, double* sw, pgo_summary* s) {
     if (!p) return PGO_ERR_INVALID_ARG;
-    return solve_end(p, q, t, sw, s);
+    const int rc = solve_end(p, q, t, sw, s);
+    if (rc != PGO_OK) { after_failure(p); p->in_solve = false; }
+    return rc;
 }
 int pgo_solve(pgo_problem* p, double* q, double* t, double* sw, int64_t N, int64_t S, pgo_summary* s) {
     if (!p) return PGO_ERR_INVALID_ARG;
     int rc = solve_begin(p, q, t, sw, N, S);
     if (rc != PGO_OK) return rc;
     int done = p->terminated ? 1 : 0;
-    while (!done) { rc = lm_step(p, 0, &done); if (rc != PGO_OK) { p->in_solve = false; return rc; } }
-    return solve_end(p, q, t, sw, s);
+    while (!done) { rc = lm_step(p, 0, &done); if (rc != PGO_OK) { after_failure(p); p->in_solve = false; return rc; } }
+    rc = solve_end(p, q, t, sw, s);
+    if (rc != PGO_OK) { after_failure(p); p->in_solve = false; }
+    return rc;
 }
 
 int pgo_evaluate(pgo_problem* p, const double* q, const double* t, const double* sw, int64_t N, int64_t S, double* cost, double* residuals, double* gradient) {
@@ -2306,23 +2383,24 @@ int pgo_time_kernel(pgo_problem* p, int32_t which, int32_t launches, double* avg
     if (!p->in_solve) { p->err = "pgo_time_kernel needs an open solve (pgo_solve_begin)"; return PGO_ERR_STATE; }
     int rc;
     if ((rc = set_device(p)) != PGO_OK) return rc;
-    hipEvent_t e0, e1;
-    HIPCHK(p, hipEventCreate(&e0)); HIPCHK(p, hipEventCreate(&e1));
+    EventPair ev;
+    HIPCHK(p, ev.create());
+    const hipEvent_t e0 = ev.e0, e1 = ev.e1;
     int np = 0;
     const int nxt = p->cur ^ 1;
     const GraphDev& G = p->G;
     double bytes = 0;
     if (which == 6 || which == 7) {   // one multigrid-preconditioned PCG iteration (6) / its level kernels alone (7), on the current LM system
-        if (!p->mg_built || !p->built_mf || p->local_ids) { p->err = "pgo_time_kernel: this graph has no (single-GPU) multigrid hierarchy (mg_min_keyframes)"; (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return PGO_ERR_STATE; }
+        if (!p->mg_built || !p->built_mf || p->local_ids) { p->err = "pgo_time_kernel: this graph has no (single-GPU) multigrid hierarchy (mg_min_keyframes)"; return PGO_ERR_STATE; }
         const pgo_options& o = p->opt;
         if (!p->reuse_diagonal) launch_lm_diag(p->G, p->L, p->Sc, o.min_lm_diagonal, o.max_lm_diagonal, p->st);
         bool ok = true;
         if ((rc = build_system(p, &ok)) != PGO_OK) return rc;
         if (!p->mg_active && (rc = build_mg(p)) != PGO_OK) return rc;
-        if (!p->mg_active) { p->err = "pgo_time_kernel: the multigrid operators of this system are not positive definite"; (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return PGO_ERR_NUMERIC; }
+        if (!p->mg_active) { p->err = "pgo_time_kernel: the multigrid operators of this system are not positive definite"; return PGO_ERR_NUMERIC; }
         const int g = launch_cg_init_vectors(p->G, p->C, 0, p->st);
         launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz, mg_scale(p), false, p->st, false, mg_cs(p));
-        launch_cg_init_scalars(p->C, g, 0.0, p->st);
+        launch_cg_init_scalars(p->C, g, g, 0.0, p->st);
     }
     if (which == 2 || which == 4 || which == 5) {   // a live PCG state to iterate on (tolerance 0: never converges during the timed launches)
         const pgo_options& o = p->opt;
@@ -2379,7 +2457,7 @@ int pgo_time_kernel(pgo_problem* p, int32_t which, int32_t launches, double* avg
                           cyc += (double)p->K.nc * (double)p->K.nc * 4.0 + (double)p->K.nc * 16.0;
                           bytes = which == 6 ? fine + cyc : cyc;
                           break; }
-                default: (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return PGO_ERR_INVALID_ARG;
+                default: return PGO_ERR_INVALID_ARG;
             }
         }
         if (rep == 1) HIPCHK(p, hipEventRecord(e1, p->st));
@@ -2387,7 +2465,6 @@ int pgo_time_kernel(pgo_problem* p, int32_t which, int32_t launches, double* avg
     }
     float ms = 0;
     HIPCHK(p, hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     *avg_ms = (double)ms / launches;
     if (algorithmic_bytes) *algorithmic_bytes = bytes;
     return PGO_OK;
@@ -2406,8 +2483,9 @@ int pgo_time_vio_odometry_kernel(pgo_problem* p, int32_t f_max, int32_t launches
     ScopedBuf<int32_t> d_c; ScopedBuf<double> d_meas;
     HIPCHK(p, d_c.ensure((size_t)2 * n)); HIPCHK(p, d_meas.ensure((size_t)8 * n));
     HIPCHK(p, hipMemcpyAsync(d_c.p, c.data(), (size_t)2 * n * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
-    hipEvent_t e0, e1;
-    HIPCHK(p, hipEventCreate(&e0)); HIPCHK(p, hipEventCreate(&e1));
+    EventPair ev;
+    HIPCHK(p, ev.create());
+    const hipEvent_t e0 = ev.e0, e1 = ev.e1;
     launch_vio_odometry(n, d_c.p, d_c.p + n, p->d_vio.p, 1, d_meas.p, p->st);
     HIPCHK(p, hipEventRecord(e0, p->st));
     for (int i = 0; i < launches; ++i) launch_vio_odometry(n, d_c.p, d_c.p + n, p->d_vio.p, 1, d_meas.p, p->st);
@@ -2415,7 +2493,6 @@ int pgo_time_vio_odometry_kernel(pgo_problem* p, int32_t f_max, int32_t launches
     HIPCHK(p, hipStreamSynchronize(p->st));
     float ms = 0;
     HIPCHK(p, hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     *avg_ms = (double)ms / launches;
     if (algorithmic_bytes) *algorithmic_bytes = 128.0 * (double)p->n_vio + (8.0 + 64.0) * (double)n;   // each pose once + 2 indices + one record per edge
     return PGO_OK;
@@ -2434,8 +2511,9 @@ int pgo_dense_spd_inverse(pgo_problem* p, int32_t n, const double* a, double* a_
     ScopedBuf<double> d_a, d_scr; ScopedBuf<int32_t> d_fail;
     HIPCHK(p, d_a.ensure((size_t)nc * nc)); HIPCHK(p, d_scr.ensure((size_t)nc * 64 + 1024)); HIPCHK(p, d_fail.ensure(1));
     CoarseDev K{}; K.nc = nc; K.Ac = d_a.p;
-    hipEvent_t e0, e1;
-    HIPCHK(p, hipEventCreate(&e0)); HIPCHK(p, hipEventCreate(&e1));
+    EventPair ev;
+    HIPCHK(p, ev.create());
+    const hipEvent_t e0 = ev.e0, e1 = ev.e1;
     float total = 0;
     for (int l = 0; l < launches; ++l) {
         HIPCHK(p, hipMemcpyAsync(d_a.p, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, p->st));
@@ -2448,7 +2526,6 @@ int pgo_dense_spd_inverse(pgo_problem* p, int32_t n, const double* a, double* a_
         HIPCHK(p, hipEventElapsedTime(&ms, e0, e1));
         total += ms;
     }
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     int32_t fail = 1;
     HIPCHK(p, hipMemcpy(&fail, d_fail.p, sizeof(fail), hipMemcpyDeviceToHost));
     HIPCHK(p, hipMemcpy(h.data(), d_a.p, h.size() * sizeof(double), hipMemcpyDeviceToHost));

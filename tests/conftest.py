@@ -16,7 +16,44 @@ def _has_gpu():
     return os.path.exists("/dev/kfd")
 
 
+# Order of the GPU suite (the driver runs `pytest tests/ -x -q -m gpu`: with -x one red test hides everything collected after it).
+# 1. ANCHORS: one oracle- or golden-compared test per BASELINE.json config C1..C5, so that every config is exercised against the checker
+#    at the very start of the run;
+# 2. the oracle-parity files: functors / Plus / K2 / PCG operator / LM trajectories (SURVEY.md 8a a1-a7, row g), full sizes, the host
+#    shim (a5, a7, f1, f3), graph construction (f2), fuzz, the failure contract, forced breakdowns, determinism;
+# 3. only then the HIP-vs-HIP property tests of the preconditioners and the multi-rank machinery (f4, e).
+# Files not listed keep their alphabetical place after the listed ones.
+_GPU_ANCHORS = [
+    "test_gpu_parity.py::test_first_iterations_track_oracle",                                       # C1   vs oracle (exact Cholesky), 10 iterations
+    "test_gpu_fullsize.py::test_c2_ten_iterations_with_library_defaults_match_oracle",              # C2   vs oracle, library defaults
+    "test_gpu_fullsize.py::test_c3_iterations_match_the_independent_cpu_trajectory",                # C3   vs committed CPU goldens (10 and 20 iterations)
+    "test_gpu_fullsize.py::test_c4_multi_world_objective_and_solve",                                # C4   objective / gradient vs oracle at full size
+    "test_gpu_c5.py::test_c5_objective_gradient_and_three_lm_iterations_on_one_gpu",                # C5   objective / gradient vs oracle at full size
+]
+_GPU_FILE_ORDER = [
+    "test_gpu_parity.py", "test_gpu_fullsize.py", "test_gpu_host_shim.py", "test_gpu_vio_construction.py", "test_gpu_fuzz.py",
+    "test_gpu_failure_contract.py", "test_gpu_breakdown_retry.py", "test_gpu_determinism.py",
+    "test_gpu_two_ranks_one_gpu.py", "test_gpu_c5.py", "test_gpu_multigrid.py", "test_gpu_coarse.py",
+]
+
+
+def _gpu_rank(item):
+    nid = item.nodeid
+    for k, a in enumerate(_GPU_ANCHORS):
+        if a in nid:
+            return (0, k)
+    fname = nid.split("::")[0].rsplit("/", 1)[-1]
+    if fname in _GPU_FILE_ORDER:
+        return (1, _GPU_FILE_ORDER.index(fname))
+    return (2, 0)
+
+
 def pytest_collection_modifyitems(config, items):
+    gpu_pos = [i for i, it in enumerate(items) if "gpu" in it.keywords]
+    if gpu_pos:      # stable: tests of one file keep their order; CPU tests keep their places
+        ordered = sorted((items[i] for i in gpu_pos), key=_gpu_rank)
+        for i, it in zip(gpu_pos, ordered):
+            items[i] = it
     if _has_gpu():
         return
     skip = pytest.mark.skip(reason="no GPU in this container (/dev/kfd absent)")

@@ -7,7 +7,11 @@ are solved here with scipy's conjugate gradients to a relative residual of 1e-12
 to ~1e-12 — on a matrix assembled in scipy from the ORACLE's Jet-autodiff Jacobian blocks.  The trust-region logic is the Python
 restatement of oracle/pgo_oracle.cpp (Ceres trust_region_minimizer.cc / levenberg_marquardt_strategy.cc).  Nothing of libpgo is used.
 
-Run (about 30-60 min, one core):  python tests/golden/make_c3_trajectory.py [n_iterations] [config] [output name] [preconditioner]
+Run (about 30-60 min, one core):  python tests/golden/make_c3_trajectory.py [n_iterations] [config] [output name] [preconditioner] [converge]
+With a fifth argument "converge" the run does not stop at n_iterations but at Ceres' own convergence tests with the reference's options (src/PoseGraphSLAM.cpp:1268-1272 set
+none of them, so the defaults hold: function_tolerance 1e-6, parameter_tolerance 1e-8) — n_iterations is then only the safety cap — and the
+output (tests/golden/c3_converged.json) also carries every 100th keyframe's pose and all switches thresholded at 0.5: the converged-minimum anchor SURVEY.md 8d(ii) asks for.
+The state is checkpointed after every iteration (<output>.state.npz, not committed), so an interrupted run resumes where it stopped.
 The optional preconditioner "mg" (an aggregation-multigrid V-cycle in scipy, scripts/research/amg_probe.py) only shortens the CG runs of the
 long trajectories (20 iterations: the trust region grows to 1e6 and block-Jacobi needs ~10^4 iterations per step); the steps are the same
 to the CG tolerance of 1e-12.
@@ -107,19 +111,36 @@ def main():
     name = sys.argv[2] if len(sys.argv) > 2 else "C3"
     out_name = sys.argv[3] if len(sys.argv) > 3 else "%s_ten_iterations.json" % name.lower()
     precond = sys.argv[4] if len(sys.argv) > 4 else "bj"
+    converge = len(sys.argv) > 5 and sys.argv[5] == "converge"
+    function_tolerance, parameter_tolerance = 1e-6, 1e-8      # Ceres defaults
+    here = os.path.dirname(os.path.abspath(__file__))
+    state_path = os.path.join(here, out_name + '.state.npz')
     g = graphgen.config(name)
     O = util.oracle_problem(g, True)
     q, t, s = util.initial_state(g, True)
-    L = linearize(O, g, q, t, s)
     N, S = g.n_poses, g.n_loops
+    L = linearize(O, g, q, t, s)
     diagH = np.einsum('naa->na', L['Hd']).reshape(-1)
-    scale_p = 1.0 / (1.0 + np.sqrt(diagH)); scale_s = 1.0 / (1.0 + np.sqrt(L['hss']))
+    scale_p = 1.0 / (1.0 + np.sqrt(diagH)); scale_s = 1.0 / (1.0 + np.sqrt(L['hss']))     # Jacobi scaling: fixed at iteration 0
     radius, decrease = 1e4, 2.0
     x_cost = L['cost']
     log = [dict(iteration=0, cost=x_cost, successful=1, radius=radius)]
     reuse = False
+    first_it = 1
+    diag_p = diag_s = None
+    if converge and os.path.exists(state_path):      # resume an interrupted run
+        st = np.load(state_path, allow_pickle=True)
+        q, t, s = st['q'], st['t'], st['s']
+        radius, decrease, reuse, first_it = float(st['radius']), float(st['decrease']), bool(st['reuse']), int(st['next_it'])
+        log = json.loads(str(st['log']))
+        L = linearize(O, g, q, t, s)
+        x_cost = L['cost']
+        if reuse:
+            diag_p, diag_s = st['diag_p'], st['diag_s']
+        print('resumed at iteration %d, cost %.12e, radius %.3e' % (first_it, x_cost, radius), flush=True)
     t00 = time.time()
-    for it in range(1, n_iter + 1):
+    termination = "NO_CONVERGENCE: maximum number of iterations"
+    for it in range(first_it, n_iter + 1):
         if not reuse:
             diag_p = np.clip(scale_p ** 2 * np.einsum('naa->na', L['Hd']).reshape(-1), 1e-6, 1e32)
             diag_s = np.clip(scale_s ** 2 * L['hss'], 1e-6, 1e32)
@@ -130,6 +151,22 @@ def main():
         cand = O.evaluate(qc, tc, sc, want_residuals=False, want_gradient=False)[0]
         rho = (x_cost - cand) / mc
         rec = dict(iteration=it, radius=radius, model_cost_change=mc, candidate_cost=cand, relative_decrease=rho, cg_iterations=cgit)
+        if converge:
+            # trust_region_minimizer.cc: the parameter-tolerance test, then the function-tolerance test, both BEFORE the step is accepted or rejected
+            step_norm = np.sqrt(np.sum((qc - q) ** 2) + np.sum((tc - t) ** 2) + np.sum((sc - s) ** 2))
+            x_norm = np.sqrt(np.sum(q ** 2) + np.sum(t ** 2) + np.sum(s ** 2))
+            rec['step_norm'] = float(step_norm)
+            stop = None
+            if step_norm <= parameter_tolerance * (x_norm + parameter_tolerance):
+                stop = "CONVERGENCE: parameter tolerance"
+            elif abs(x_cost - cand) <= function_tolerance * x_cost:
+                stop = "CONVERGENCE: function tolerance"
+            if stop:
+                rec['successful'] = 0; rec['cost'] = x_cost; rec['terminated'] = stop
+                log.append(rec)
+                termination = stop
+                print('it %2d cost %.12e |dcost| %.3e -> %s' % (it, x_cost, abs(x_cost - cand), stop), flush=True)
+                break
         if rho > 1e-3:
             q, t, s = qc, tc, sc
             L = linearize(O, g, q, t, s)
@@ -144,9 +181,18 @@ def main():
         print('it %2d cost %.12e rho %.3e cg %d (%s) %.0fs' % (it, x_cost, rho, cgit, 'ok' if rec['successful'] else 'REJ', time.time() - t0), flush=True)
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), out_name + '.partial'), "w") as f:   # a long run survives an interruption
             json.dump(dict(config=name, iterations=log), f)
+        if converge:
+            np.savez(state_path, q=q, t=t, s=s, radius=radius, decrease=decrease, reuse=reuse, next_it=it + 1, log=json.dumps(log),
+                     diag_p=diag_p, diag_s=diag_s)
     out = dict(note="generated by tests/golden/make_c3_trajectory.py: oracle Jacobians + scipy CG (rtol 1e-12, preconditioner %s) + Python restatement of the Ceres LM loop" % precond,
                config=name, n_poses=N, n_edges=g.n_odom + g.n_loops, iterations=log, seconds=time.time() - t00,
                final_t_sample=t[::997].tolist(), final_s_sample=s[::997].tolist())
+    if converge:
+        on = (s > 0.5).astype(np.uint8)
+        out.update(termination=termination, function_tolerance=function_tolerance, parameter_tolerance=parameter_tolerance, final_cost=x_cost, final_chi2=2.0 * x_cost,
+                   pose_sample_stride=100, final_q_sample_100=q[::100].tolist(), final_t_sample_100=t[::100].tolist(),
+                   switches_on_hex=np.packbits(on).tobytes().hex(), n_switches=int(S), n_switches_on=int(on.sum()),
+                   switch_margin=float(np.abs(s - 0.5).min()))
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), out_name)
     with open(path, "w") as f:
         json.dump(out, f)

@@ -73,6 +73,31 @@ def test_c2_idempotence_at_the_converged_solution():
     assert np.abs(t2 - t1).max() <= 1e-3
 
 
+def test_c2_ten_iterations_with_library_defaults_match_oracle():
+    """BASELINE.json config 2 (10 000 poses, 9 999 odometry + 1 000 plain loop edges, no switches) with LIBRARY DEFAULTS — the two-level
+    preconditioner with its fp32 dense coarse inverse, the once-per-solve comparison, the default PCG tolerance — against the oracle's exact
+    block Cholesky for the reference's 10-iteration budget (src/PoseGraphSLAM.cpp:1272): same accept/reject sequence, every step valid, per-
+    iteration costs to 1e-6 relative (BASELINE.json's chi^2 bar), and every step carries a reason code."""
+    g = graphgen.config("C2")
+    O, P = util.oracle_problem(g, False), util.pgo_problem(g, False)
+    q, t, s = util.initial_state(g, False)
+    qo, to, so, sumo = O.solve(q, t, s)
+    qp, tp, sp, sump = P.solve(q, t, s)
+    P.close()
+    assert sump.num_iterations == sumo.num_iterations == 10
+    log = [(sump.iterations[k].step_is_valid, sump.iterations[k].step_is_successful, capi.STEP_REASONS[sump.iterations[k].reason], sump.iterations[k].preconditioner,
+            sump.iterations[k].cost, sump.iterations[k].relative_decrease, sump.iterations[k].cg_iterations) for k in range(sump.num_logged)]
+    for k in range(11):
+        a, b = sumo.iterations[k], sump.iterations[k]
+        assert b.step_is_valid == 1, (k, log)
+        assert a.step_is_successful == b.step_is_successful, (k, log)
+        assert b.reason == (capi.STEP_ACCEPTED if b.step_is_successful else capi.STEP_REJECTED_RHO), (k, log)
+        assert abs(a.cost - b.cost) <= 1e-6 * a.cost, (k, a.cost, b.cost, log)
+    assert abs(sump.final_cost - sumo.final_cost) <= 1e-6 * sumo.final_cost
+    # (C2 has nearly flat directions along the chain: the same 2e-2 m pose bar as test_solve_matches_oracle_at_convergence)
+    assert np.linalg.norm(tp.reshape(-1, 3) - to.reshape(-1, 3), axis=1).max() <= 2e-2
+
+
 def test_c4_multi_world_objective_and_solve():
     """Multi-world kidnap graph (4 worlds x 50k poses, f = 1..5 with yaw weights, inter-world loop edges, node regularisation)."""
     g = graphgen.config("C4")
