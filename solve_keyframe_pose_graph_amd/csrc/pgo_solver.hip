@@ -491,19 +491,23 @@ void mg_job_cancel(pgo_problem* p) {
 // The aggregation multigrid's hierarchy for the graph of this handle and the given switch values (host array over the caller's switches, or null): host-side structure
 // (pgo_mg_host.hpp), pooled device arrays, level descriptors.  Called by build_graph, and again when the switch values have moved far from the ones the hierarchy was
 // built with (regroup): the levels above level 1 are matched along the couplings that are alive NOW.  p->mg_cache keeps what does not depend on the switches.
-int build_multigrid(pgo_problem* p, const double* sw_now) {
+// the caller's keyframe and switch counts decide (the same answer on every rank): graphs with switchable loop closures — all of the reference's — take the multigrid from
+// mg_min_keyframes_switchable on, graphs without from mg_min_keyframes; mg_min_keyframes = 0 turns it off altogether
+bool wants_multigrid(const pgo_problem* p) {
+    int64_t mg_from = p->opt.mg_min_keyframes;
+    if (mg_from > 0 && p->S > 0 && p->opt.mg_min_keyframes_switchable > 0) mg_from = std::min<int64_t>(mg_from, p->opt.mg_min_keyframes_switchable);
+    return mg_from > 0 && p->N_global >= mg_from;
+}
+// `ready`: the host half prepared beforehand (build_graph runs it on a worker thread beside its own host work and uploads)
+int build_multigrid(pgo_problem* p, const double* sw_now, MgPrepared* ready = nullptr) {
     int rc;
     mg_job_cancel(p);
     p->coarse_built = false; p->coarse_active = false; p->K = CoarseDev{};
     p->mg_built = false; p->mg_active = false; p->M = MgDev{}; p->mg_geometry_epoch = 0;
-    // the caller's keyframe and switch counts decide (the same answer on every rank): graphs with switchable loop closures — all of the reference's — take the multigrid from
-    // mg_min_keyframes_switchable on, graphs without from mg_min_keyframes; mg_min_keyframes = 0 turns it off altogether
-    int64_t mg_from = p->opt.mg_min_keyframes;
-    if (mg_from > 0 && p->S > 0 && p->opt.mg_min_keyframes_switchable > 0) mg_from = std::min<int64_t>(mg_from, p->opt.mg_min_keyframes_switchable);
-    if (mg_from > 0 && p->N_global >= mg_from) {
+    if (wants_multigrid(p)) {
         MgPrepared Q;
-        if ((rc = mg_prepare(p, sw_now, Q)) != PGO_OK) return rc;
-        if ((rc = mg_install(p, Q)) != PGO_OK) return rc;
+        if (!ready && (rc = mg_prepare(p, sw_now, Q)) != PGO_OK) return rc;
+        if ((rc = mg_install(p, ready ? *ready : Q)) != PGO_OK) return rc;
     }
     if (p->local_ids && !p->mg_built) HIPCHK(p, p->d_xbuf.ensure((size_t)p->n_sh_global * 42 + 2 + 64));
     return PGO_OK;
@@ -511,6 +515,8 @@ int build_multigrid(pgo_problem* p, const double* sw_now) {
 
 int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
     mg_job_cancel(p);      // (a regroup's worker reads the host arrays rebuilt below)
+    double t_phase = now_s();
+    auto phase = [&](const char* what) { if (p->opt.verbosity > 1) { const double t = now_s(); std::fprintf(stderr, "[pgo] build_graph: %-34s %7.2f ms\n", what, (t - t_phase) * 1e3); t_phase = t; } };
     // ---- validate against the array sizes the caller solves with
     for (const HostClass* H : {&p->rel, &p->swe})
         for (int64_t e = 0; e < H->size(); ++e)
@@ -587,6 +593,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
         G.own = nullptr;
     }
     p->N = N;
+    phase("validation, rank-local numbering");
     const int32_t* g2l = p->local_ids ? p->g2l.data() : nullptr;
     auto L = [g2l](int32_t g) -> int32_t { return g2l ? g2l[g] : g; };
     G.N = N; G.S = S;
@@ -594,6 +601,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
     if ((rc = upload_class(p, p->rel, false, p->d_rc1, p->d_rc2, p->d_sidx /*unused*/, p->d_rmeas, p->d_rwin, G.rel)) != PGO_OK) return rc;
     if ((rc = upload_class(p, p->swe, true, p->d_sc1, p->d_sc2, p->d_sidx, p->d_smeas, p->d_swin, G.sw)) != PGO_OK) return rc;
     const int64_t Er = G.rel.E, Es = G.sw.E, Eg = (int64_t)p->priors.size();
+    phase("edge classes packed + uploaded");
     std::vector<PriorDev> pri = p->priors;
     for (PriorDev& x : pri) x.node = L(x.node);
     // ---- node -> incident list (edges in slot order, then regularisers), BSR structure
@@ -621,6 +629,21 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
     p->h_node_free.assign((size_t)N, 0);
     for (int64_t n = 0; n < N; ++n) p->h_node_free[n] = (rowptr[n + 1] > rowptr[n] || (p->local_ids && p->h_touched_any[p->l2g[n]])) ? 1 : 0;
     for (int32_t c : p->constant_nodes) if (c >= 0 && c < Ng && L(c) >= 0) p->h_node_free[L(c)] = 0;
+    // One GPU: the HOST half of the multigrid hierarchy (pgo_mg_host.hpp: ~0.1 s for C3, single-threaded sorts and matchings) needs the edge lists and the free flags
+    // only, so it runs on a worker thread beside the rest of this function — incident-list upload, matrix-free tile packing, buffer allocation — and is installed where
+    // build_multigrid used to compute it.  Nothing here depends on timing: the result is the same hierarchy.  (Several ranks: its host half holds collectives.)
+    std::thread mg_thread;
+    std::unique_ptr<MgPrepared> mg_ready;
+    int rc_mg_thread = PGO_OK;
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } mg_joiner{mg_thread};     // every early return below waits for the worker
+    p->mg_cache.valid = false;
+    if (!p->local_ids && wants_multigrid(p)) {
+        mg_ready.reset(new MgPrepared());
+        MgPrepared* Qp = mg_ready.get();
+        int* rcp = &rc_mg_thread;
+        try { mg_thread = std::thread([p, sw_now, Qp, rcp]() { *rcp = mg_prepare(p, sw_now, *Qp); }); }
+        catch (...) { rc_mg_thread = mg_prepare(p, sw_now, *Qp); }
+    }
 
     HIPCHK(p, p->d_inc_rowptr.ensure(N + 1)); HIPCHK(p, p->d_bsr_rowptr.ensure(N + 1)); HIPCHK(p, p->d_inc.ensure(std::max<int64_t>(ninc, 1)));
     HIPCHK(p, p->d_bsr_col.ensure(std::max<int64_t>(p->nnzb, 1))); HIPCHK(p, p->d_node_free.ensure(std::max<int64_t>(N, 1)));
@@ -633,6 +656,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
     if (Eg) HIPCHK(p, hipMemcpyAsync(p->d_prior.p, pri.data(), Eg * sizeof(PriorDev), hipMemcpyHostToDevice, p->st));
     HIPCHK(p, hipStreamSynchronize(p->st));
 
+    phase("incident lists + block-CSR structure");
     // ---- matrix-free operator: edge-sides in keyframe-major order, packed into workgroup tiles of whole keyframes
     bool mf = p->opt.linear_solver == PGO_LINEAR_PCG_MATRIX_FREE;
     if (mf) {
@@ -759,6 +783,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
         p->F = MfDev{p->d_einc.p, p->d_einc_other.p, p->d_einc_slot.p, p->d_tile_inc0.p, p->d_tile_sw0.p, p->d_tile_node0.p, p->d_node_rng.p, p->d_node_prior.p,
                      p->d_rec.p, p->d_lam.p, ninc_e, ninc_pad, tiles};
     }
+    phase("matrix-free tiles");
     // ---- work buffers
     const int64_t slots = G.rel.Epad + G.sw.Epad;
     HIPCHK(p, p->d_Jr.ensure(std::max<int64_t>((int64_t)G.rel.tiles * REL_DOUBLES * TILE, 1)));
@@ -792,8 +817,17 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
     C.flags = p->d_flags.p;
     // ---- aggregation multigrid for large graphs: hierarchy of graph-following rigid aggregates (pgo_mg_host.hpp), built by build_multigrid() below — which a solve
     // may call again with the current switch values (regroup)
-    p->mg_cache.valid = false;
-    if ((rc = build_multigrid(p, sw_now)) != PGO_OK) return rc;
+    phase("work buffers");
+    if (mg_thread.joinable()) mg_thread.join();
+    if (rc_mg_thread != PGO_OK) return rc_mg_thread;
+    phase("waited for the hierarchy worker");
+    if ((rc = build_multigrid(p, sw_now, mg_ready.get())) != PGO_OK) return rc;
+    if (mg_ready) {      // (freed off the solve's critical path: regroup_install's note on munmap and the GPU's address space)
+        std::unique_ptr<MgPrepared> old = std::move(p->mg_job_old);
+        p->mg_job_old = std::move(mg_ready);
+        if (p->opt.verbosity > 1) std::fprintf(stderr, "[pgo] build_graph: hierarchy host half %.2f ms on a worker thread\n", p->mg_job_old->host_ms);
+    }
+    phase("multigrid hierarchy (install)");
     if (p->mg_built && p->built_mf) { HIPCHK(p, p->d_Hoff.ensure((size_t)(p->G.rel.Epad + p->G.sw.Epad) * 36)); p->L.Hoff = p->d_Hoff.p; }      // the multigrid's level-1 product reads J1^T J2 per edge
     p->hoff_epoch = 0;
     if (!p->mg_built) {      // (a graph that got the multigrid never uses the two-level method: its dense operator would be built and uploaded for nothing)
@@ -847,6 +881,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
             p->coarse_built = true;
         }
     }
+    phase("two-level aggregates");
     p->graph_dirty = false; p->priors_dirty = false;
     ++p->build_epoch;   // invalidates the captured PCG graph (kernel arguments hold device pointers / sizes)
     return PGO_OK;
