@@ -140,6 +140,9 @@ def main():
                     help="rccl: libpgo's own RCCL communicator over xGMI (default).  gloo: torch.distributed gloo through pgo_comm_init_custom "
                          "(host staging; lets several ranks share one GPU to validate the multi-rank path on a 1-GPU box)")
     ap.add_argument("--partition", choices=["spatial", "chain", "contiguous"], default="spatial", help="how edges are dealt out to the ranks (solve_keyframe_pose_graph_amd/sharding.py)")
+    ap.add_argument("--config", choices=["C3", "C5"], default="C3",
+                    help="C3 (default): the headline workload, N x C3 on N GPUs = WEAK scaling (what the driver's `bench.py --gpus N` runs).  C5: BASELINE.json config 5 — 1M poses / "
+                         "3M edges, the SAME graph whatever N, edges sharded over the ranks = STRONG scaling; `value` is then LM iterations/s of that one graph")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -176,10 +179,14 @@ def main():
     capi.load()   # raises if libpgo.so is missing: no CPU fallback
 
     # ---- workload: N x C3, generated identically on every rank (deterministic); edges dealt out by the `--partition` policy
-    scale = args.gpus
-    n_poses = args.poses_per_gpu * scale
-    n_loops = int(round(C3_LOOPS * (args.poses_per_gpu / C3_POSES))) * scale if scale > 1 or args.poses_per_gpu != C3_POSES else C3_LOOPS
-    g = graphgen.generate(n_poses, n_loops, odom_f_max=2, seed=3)
+    strong = args.config == "C5"
+    scale = 1 if strong else args.gpus
+    if strong:
+        g = graphgen.config("C5")
+    else:
+        n_poses = args.poses_per_gpu * scale
+        n_loops = int(round(C3_LOOPS * (args.poses_per_gpu / C3_POSES))) * scale if scale > 1 or args.poses_per_gpu != C3_POSES else C3_LOOPS
+        g = graphgen.generate(n_poses, n_loops, odom_f_max=2, seed=3)
     n_edges = g.n_odom + g.n_loops
 
     from solve_keyframe_pose_graph_amd import sharding
@@ -306,7 +313,7 @@ def main():
     # ---- K1 once more where its output cannot sit in the 256 MiB Infinity Cache: C3's 194 MB of Jacobian blocks are absorbed by it (plain
     # stores), so the C3 figure is an HBM + cache number; 400k keyframes / 1.2M edges write 775 MB with non-temporal stores
     k1_big = None
-    if scale == 1 and rank == 0 and not args.no_k1_out_of_cache:
+    if scale == 1 and world == 1 and not strong and rank == 0 and not args.no_k1_out_of_cache:
         gb = graphgen.generate(400000, 400000, odom_f_max=2, seed=3)
         Pb = capi.problem_from_graph(gb, switchable=True, device_id=device_index)
         Pb.solve_begin(gb.init_q, gb.init_t, np.full(gb.n_loops, 0.99))
@@ -319,7 +326,7 @@ def main():
     # ---- final chi^2 against the independent CPU trajectory of the same K iterations (tests/golden/make_c3_trajectory.py: oracle Jacobians,
     # scipy CG to 1e-12, Python restatement of the Ceres LM loop; nothing of libpgo)
     chi2_ref = chi2_rel = None
-    if scale == 1 and args.poses_per_gpu == C3_POSES:
+    if scale == 1 and world == 1 and not strong and args.poses_per_gpu == C3_POSES:
         for name in ("c3_twenty_iterations.json", "c3_ten_iterations.json"):
             try:
                 with open(os.path.join(ROOT, "tests", "golden", name)) as f:
@@ -340,7 +347,7 @@ def main():
     traffic_note = {}
 
     def static_traffic(name, getter):
-        if not (scale == 1 and args.poses_per_gpu == C3_POSES):
+        if not (scale == 1 and world == 1 and not strong and args.poses_per_gpu == C3_POSES):
             return None        # the PMC passes were taken on C3 x 1 only
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
@@ -360,15 +367,15 @@ def main():
         ips = args.steps / elapsed
         its = [summ.iterations[k] for k in range(summ.num_logged)]
         out = {
-            "metric": "LM iters/sec + final chi2 vs Ceres, 100k-pose/300k-edge SE(3) graph",
+            "metric": "LM iters/sec + final chi2 vs Ceres, 100k-pose/300k-edge SE(3) graph" if not strong else "LM iters/sec, 1M-pose/3M-edge SE(3) graph (BASELINE.json config 5) edge-sharded over the ranks",
             "value": ips * scale,
             "unit": "LM iters/s" if scale == 1 else "LM iters/s x N (C3-sized graph-iterations/s)",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C3 x %d: synthetic 3D Manhattan graph, %d poses / %d edges (%d odometry f=1,2 + %d switchable loop closures, 10%% outliers) + %d regulariser(s)"
-                                   % (scale, g.n_poses, n_edges, g.n_odom, g.n_loops, len(g.reg_node)),
+            "config": {"workload": "%s: synthetic 3D Manhattan graph, %d poses / %d edges (%d odometry f=1,2 + %d switchable loop closures, 10%% outliers) + %d regulariser(s)"
+                                   % ("C5 (the same graph on every rank count)" if strong else "C3 x %d" % scale, g.n_poses, n_edges, g.n_odom, g.n_loops, len(g.reg_node)),
                        "poses": g.n_poses, "edges": n_edges, "sharding": ("edges by the '%s' policy (sharding.py): %d..%d edges and %d..%d keyframes per rank, %d of %d keyframes shared between ranks; one %s all-reduce of 6 x shared + 2 doubles per CG iteration (+ the multigrid's level-1 vector, 6 x level-1 nodes, in the same all-reduce; coarse levels replicated)"
                                                                        % (args.partition, min(shard_stats["edges_per_rank"]), max(shard_stats["edges_per_rank"]), min(shard_stats["keyframes_per_rank"]), max(shard_stats["keyframes_per_rank"]),
                                                                           shard_stats["shared_keyframes"], g.n_poses, args.collective)) if world > 1 else "single GPU",
@@ -408,7 +415,7 @@ def main():
             "other_kernels": {"k2_assembly": {"ms": k2_ms, "GBps": k2_bytes / k2_ms / 1e6}, "pcg_iteration": None if cg_ms is None else {"ms": cg_ms, "GBps": cg_bytes / cg_ms / 1e6},
                               "k1_cost_only": {"ms": k1c_ms, "GBps": k1c_bytes / k1c_ms / 1e6}},
         }
-        if scale == 1 and not args.no_cpu_baseline:
+        if scale == 1 and world == 1 and not strong and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_sample_poses, args.cpu_iters, 30.0)
             except Exception as e:   # the baseline is reported, never required for the GPU number

@@ -83,6 +83,46 @@ __device__ __forceinline__ void block_total3(const double* __restrict__ pa, int 
     for (int i = 0; i < nw; ++i) { sa += buf[i]; sb += buf[nw + i]; sc += buf[2 * nw + i]; }
 }
 
+// The head of every PCG kernel: "has the PCG stopped?" and the re-reduction of two (three) partial-sum arrays.  Measured with the timeline build (scripts/dev/mf_timeline.py, C3):
+// as two steps — flag -> barrier -> partial sums -> barrier — the head took 5 us of the matvec's 26, two dependent round trips to cold L2s.  Here ONE lane requests the flag
+// BEFORE the partial sums are requested and hands it over through the reduction's own LDS buffer: one round trip, one barrier pair.  (The flag may be raised by workgroup 0 of
+// a matvec while other workgroups of the same launch are starting: one lane reads, LDS broadcasts, nobody diverges around a barrier.)  buf: 2 (3) x nwaves + 1 doubles.
+__device__ __forceinline__ bool block_total2_done(const int32_t* __restrict__ flags, const double* __restrict__ pa, int na, const double* __restrict__ pb, int nb, double* buf,
+                                                  double& sa, double& sb) {
+    int f = 0;
+    if (threadIdx.x == 0) f = flags[0];
+    double va = 0.0, vb = 0.0;
+    for (int i = threadIdx.x; i < na; i += blockDim.x) va += pa[i];
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) vb += pb[i];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    va = wave_sum(va); vb = wave_sum(vb);
+    __syncthreads();
+    if (lane == 0) { buf[wave] = va; buf[nw + wave] = vb; }
+    if (threadIdx.x == 0) buf[2 * nw] = (double)f;
+    __syncthreads();
+    sa = 0.0; sb = 0.0;
+    for (int i = 0; i < nw; ++i) { sa += buf[i]; sb += buf[nw + i]; }
+    return buf[2 * nw] != 0.0;
+}
+__device__ __forceinline__ bool block_total3_done(const int32_t* __restrict__ flags, const double* __restrict__ pa, int na, const double* __restrict__ pb, int nb, const double* __restrict__ pc, int nc,
+                                                  double* buf, double& sa, double& sb, double& sc) {
+    int f = 0;
+    if (threadIdx.x == 0) f = flags[0];
+    double va = 0.0, vb = 0.0, vc = 0.0;
+    for (int i = threadIdx.x; i < na; i += blockDim.x) va += pa[i];
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) vb += pb[i];
+    for (int i = threadIdx.x; i < nc; i += blockDim.x) vc += pc[i];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    va = wave_sum(va); vb = wave_sum(vb); vc = wave_sum(vc);
+    __syncthreads();
+    if (lane == 0) { buf[wave] = va; buf[nw + wave] = vb; buf[2 * nw + wave] = vc; }
+    if (threadIdx.x == 0) buf[3 * nw] = (double)f;
+    __syncthreads();
+    sa = 0.0; sb = 0.0; sc = 0.0;
+    for (int i = 0; i < nw; ++i) { sa += buf[i]; sb += buf[nw + i]; sc += buf[2 * nw + i]; }
+    return buf[3 * nw] != 0.0;
+}
+
 __device__ __forceinline__ size_t tile_elem(int doubles_per_edge, int64_t e, int k) {
     return (size_t)(e >> 6) * (size_t)(doubles_per_edge * TILE) + (size_t)(k >> 1) * (2 * TILE) + (size_t)(e & 63) * 2 + (k & 1);
 }
@@ -794,13 +834,13 @@ __device__ __forceinline__ void bsr_row_accumulate(const GraphDev& G, const doub
 
 // q = A (z + beta p_prev), p_cur = z + beta p_prev
 __global__ __launch_bounds__(CG_BLOCK) void cg_spmv_kernel(GraphDev G, CgDev C, int parity, int first, int nparts, double tol2) {
-    __shared__ double red[2 * (CG_BLOCK / 64)];
+    __shared__ double red[2 * (CG_BLOCK / 64) + 1];
     __shared__ double xch[CG_BLOCK * 7];   // [keyframe-in-group][c][r], padded to 7 to spread LDS banks
-    if (cg_done(C)) return;
     double beta = 0.0;
-    if (!first) {
+    if (first) { if (cg_done(C)) return; }
+    else {
         double rz_new, rz_old;
-        block_total2(C.part_rz + parity * RZ_STRIDE, nparts + C.extra_rz, C.part_rz + (parity ^ 1) * RZ_STRIDE, nparts + C.extra_rz, red, rz_new, rz_old);
+        if (block_total2_done(C.flags, C.part_rz + parity * RZ_STRIDE, nparts + C.extra_rz, C.part_rz + (parity ^ 1) * RZ_STRIDE, nparts + C.extra_rz, red, rz_new, rz_old)) return;
         const bool breakdown = C.flags[1] != 0;
         // convergence on the preconditioned residual norm: every workgroup evaluates the same numbers -> uniform exit
         if (breakdown || !(rz_new > C.scal[3] * C.scal[0])) {
@@ -925,7 +965,7 @@ __global__ void cg_scalars_init_kernel(CgDev C, int nparts, int nparts_bb, doubl
 
 // alpha = rz/pq ; x += alpha p ; r' = r - alpha q ; z = Minv r' ; partial r'.z -> part_rz[parity^1]
 __global__ __launch_bounds__(CG_BLOCK) void cg_update_kernel(GraphDev G, CgDev C, int parity, int nparts_pq, int nparts) {
-    __shared__ double red[2 * (CG_BLOCK / 64)];
+    __shared__ double red[2 * (CG_BLOCK / 64) + 1];
     const double2* __restrict__ rin = reinterpret_cast<const double2*>(parity ? C.r2 : C.r);
     double2* __restrict__ rout = reinterpret_cast<double2*>(parity ? C.r : C.r2);
     const double2* __restrict__ pcur = reinterpret_cast<const double2*>(parity ? C.p2 : C.p);
@@ -953,9 +993,9 @@ __global__ __launch_bounds__(CG_BLOCK) void cg_update_kernel(GraphDev G, CgDev C
     };
     double2 r0, q0, p0, x0; float4 lf0, lf1;
     load_trip((int64_t)blockIdx.x * CG_BLOCK, r0, q0, p0, x0, lf0, lf1);
-    if (cg_done(C)) return;     // after the first trip's loads are in flight: the flag's round trip overlaps with theirs
     double pq, rz;   // pq partials are produced by the matvec kernel (its own grid size)
-    block_total2(C.part_pq, nparts_pq, C.part_rz + parity * RZ_STRIDE, nparts + C.extra_rz, red, pq, rz);
+    // (after the first trip's loads are in flight: the flag's and the partial sums' round trip overlaps with theirs)
+    if (block_total2_done(C.flags, C.part_pq, nparts_pq, C.part_rz + parity * RZ_STRIDE, nparts + C.extra_rz, red, pq, rz)) return;
     if (!(pq > 0.0)) {   // breakdown: matrix not positive definite along p (or NaN); x is left untouched, the next spmv raises done
         if (blockIdx.x == 0 && threadIdx.x == 0) C.flags[1] = 1;
         if (threadIdx.x == 0) C.part_rz[(parity ^ 1) * RZ_STRIDE + blockIdx.x] = 0.0;
@@ -1206,23 +1246,41 @@ __device__ __forceinline__ double coarse_pending(const CoarseDev& K, const uint8
 // COARSE (two-level preconditioner, fused form): the preconditioned residual is z = z_bj + P y with z_bj in C.z (block-Jacobi part, written by
 // cg_update_restrict_kernel) and y = Ac^-1 P^T r in K.yc (coarse_solve_dot_kernel): the prolongation happens HERE, where z is consumed, instead
 // of in a kernel of its own; `pending` = 0 right after the PCG start, when C.z is already complete.  K.m == 1: z = y alone (direct inverse).
+#ifdef PGO_MF_TIMELINE
+// Development aid (variant build only: scripts/dev/mf_timeline.py): thread 0 of every workgroup records the 100-MHz wall clock at the phase boundaries of the matvec — after a
+// full wait for the memory operations issued so far — so that one can see where a tile's ~12 us go.  [workgroup][16] ticks; slots 0-1 kernel entry / after the
+// re-reduction; per tile (first two tiles): bounds, phase 0 + barrier, record loads done, far gathers done, products + barrier, phase-B loads done, tile end.
+__device__ unsigned long long pgo_mf_tl[MF_MAX_GRID * 16];
+#define MF_TL(slot) do { __builtin_amdgcn_s_waitcnt(0); if (threadIdx.x == 0 && (slot) < 16) pgo_mf_tl[blockIdx.x * 16 + (slot)] = wall_clock64(); } while (0)
+extern "C" int pgo_debug_mf_timeline(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pgo_mf_tl), (size_t)n * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#else
+#define MF_TL(slot) do {} while (0)
+#endif
+
 template <bool FUSED, bool COARSE = false>
 __global__ __launch_bounds__(MF_BLOCK) void mf_spmv_kernel(GraphDev G, MfDev F, ScaleDev Sc, CgDev C, const double* __restrict__ xin, double* __restrict__ yout,
                                                            int parity, int first, int nparts, double tol2, CoarseDev K = CoarseDev{}, int pending = 0) {
     __shared__ double contrib[MF_SLOTS * 7];
     __shared__ double pwin[MF_BLOCK];
-    __shared__ double red[3 * (MF_BLOCK / 64)];
+    __shared__ double red[3 * (MF_BLOCK / 64) + 1];
     const int l = threadIdx.x;
+    MF_TL(0);
     double beta = 0.0;
     const double* __restrict__ pprev = FUSED ? (parity ? C.p : C.p2) : xin;
     const double* __restrict__ z = FUSED ? C.z : xin;
     // the first tile's bounds and phase-0 operands do not depend on beta: request them BEFORE the partial-sum re-reduction so that its
     // dependent L2 round trips overlap with theirs (two registers; the records stay behind the reduction — hoisting them spills)
     double v0_first = 0.0, v1_first = 0.0;
+    // (the first tile's bounds too: uniform loads whose round trip — 1.2 us behind the re-reduction in the timeline build — then runs beside it)
+    int64_t i0_first = 0, i1_first = 0; int32_t n0_first = 0, n1_first = 0, sw_first = 0;
     {
         const int tile = blockIdx.x;
         if (tile < F.tiles) {
+            i0_first = F.tile_inc0[tile]; i1_first = F.tile_inc0[tile + 1]; sw_first = F.tile_sw0[tile];
             const int32_t n0 = F.tile_node0[tile], n1 = F.tile_node0[tile + 1];
+            n0_first = n0; n1_first = n1;
             if (l < (n1 - n0) * 6) {
                 const size_t vi = (size_t)n0 * 6 + l;
                 v0_first = z[vi];
@@ -1232,10 +1290,11 @@ __global__ __launch_bounds__(MF_BLOCK) void mf_spmv_kernel(GraphDev G, MfDev F, 
         }
     }
     if (FUSED) {
-        if (cg_done(C)) return;
-        if (!first) {
+        if (first) { if (cg_done(C)) return; }
+        else {
             double rz_new, rz_old;
             bool coarse_negative = false;
+            bool stopped;
             if (COARSE) {
                 // Two-level method: r.z = r.D^-1 r (the update kernel's partials) + rc.Ac^-1 rc (the dense solve's partials, behind them).  With the exact coarse inverse the
                 // second term is >= 0, so r.z <= tol^2 b.D^-1 b implies the same for the block-Jacobi part alone.  The inverse is applied rounded to fp32, and at large
@@ -1243,10 +1302,11 @@ __global__ __launch_bounds__(MF_BLOCK) void mf_spmv_kernel(GraphDev G, MfDev F, 
                 // tolerance — or through zero — while the residual is still large.  So convergence that the block-Jacobi part alone does not confirm is a BREAKDOWN
                 // (lm_step then finishes the system with plain block-Jacobi from the current iterate), never a converged step.  K.m == 1: z is the coarse term alone.
                 double rz_bj, rz_c;
-                block_total3(C.part_rz + parity * RZ_STRIDE, nparts, C.part_rz + parity * RZ_STRIDE + nparts, C.extra_rz, C.part_rz + (parity ^ 1) * RZ_STRIDE, nparts + C.extra_rz, red, rz_bj, rz_c, rz_old);
+                stopped = block_total3_done(C.flags, C.part_rz + parity * RZ_STRIDE, nparts, C.part_rz + parity * RZ_STRIDE + nparts, C.extra_rz, C.part_rz + (parity ^ 1) * RZ_STRIDE, nparts + C.extra_rz, red, rz_bj, rz_c, rz_old);
                 rz_new = rz_bj + rz_c;
                 coarse_negative = K.m != 1 && !(rz_new > C.scal[3] * C.scal[0]) && rz_bj > C.scal[3] * C.scal[0];
-            } else block_total2(C.part_rz + parity * RZ_STRIDE, nparts + C.extra_rz, C.part_rz + (parity ^ 1) * RZ_STRIDE, nparts + C.extra_rz, red, rz_new, rz_old);
+            } else stopped = block_total2_done(C.flags, C.part_rz + parity * RZ_STRIDE, nparts + C.extra_rz, C.part_rz + (parity ^ 1) * RZ_STRIDE, nparts + C.extra_rz, red, rz_new, rz_old);
+            if (stopped) return;
             const bool breakdown = C.flags[1] != 0;
             if (breakdown || !(rz_new > C.scal[3] * C.scal[0])) {
                 if (blockIdx.x == 0 && threadIdx.x == 0) { C.flags[0] = 1; if (!breakdown) { C.scal[1] = rz_new; if (coarse_negative || !(rz_new >= -C.scal[3] * C.scal[0])) C.flags[1] = 1; } }
@@ -1257,14 +1317,21 @@ __global__ __launch_bounds__(MF_BLOCK) void mf_spmv_kernel(GraphDev G, MfDev F, 
         }
         if (blockIdx.x == 0 && threadIdx.x == 0) C.flags[2] += 1;
     }
+    MF_TL(1);
     double* __restrict__ pcur = parity ? C.p2 : C.p;
     double pq = 0.0;
+#ifdef PGO_MF_TIMELINE
+    int tl_base = 2;
+#endif
     for (int tile = blockIdx.x; tile < F.tiles; tile += gridDim.x) {
-        const int64_t i0 = F.tile_inc0[tile], i1 = F.tile_inc0[tile + 1];
-        const int32_t n0 = F.tile_node0[tile], n1 = F.tile_node0[tile + 1];
-        const int sw0 = F.tile_sw0[tile] & 0xffff, pair1 = (int)((uint32_t)F.tile_sw0[tile] >> 16);
+        const bool is_first = tile == (int)blockIdx.x;
+        const int64_t i0 = is_first ? i0_first : F.tile_inc0[tile], i1 = is_first ? i1_first : F.tile_inc0[tile + 1];
+        const int32_t n0 = is_first ? n0_first : F.tile_node0[tile], n1 = is_first ? n1_first : F.tile_node0[tile + 1];
+        const int32_t swp = is_first ? sw_first : F.tile_sw0[tile];
+        const int sw0 = swp & 0xffff, pair1 = (int)((uint32_t)swp >> 16);
         const int64_t i = i0 + l;
         const int nn = n1 - n0;
+        MF_TL(tl_base + 0);
         // phase 0: the tile's own keyframes' input vector p = z + beta p_prev, once, into LDS (every edge side of a keyframe needs it,
         // and odometry neighbours are inside the same window): only far endpoints of loop closures gather from global memory
         if (l < nn * 6) {
@@ -1286,6 +1353,7 @@ __global__ __launch_bounds__(MF_BLOCK) void mf_spmv_kernel(GraphDev G, MfDev F, 
             pwin[l] = v;
         }
         __syncthreads();
+        MF_TL(tl_base + 1);
         if (i < i1) {
             const uint32_t ent = F.einc[i];
             const bool is_sw = l >= sw0;
@@ -1305,6 +1373,7 @@ __global__ __launch_bounds__(MF_BLOCK) void mf_spmv_kernel(GraphDev G, MfDev F, 
 #pragma unroll
                 for (int k = 16; k < COMPACT_DOUBLES; ++k) rec[k] = 0.0;
             }
+            MF_TL(tl_base + 2);
             double po[6], pt[6];
             {
                 const double* a = pwin + ownl * 6;
@@ -1341,6 +1410,7 @@ __global__ __launch_bounds__(MF_BLOCK) void mf_spmv_kernel(GraphDev G, MfDev F, 
                     pt[0] += beta * c0.x; pt[1] += beta * c0.y; pt[2] += beta * c1.x; pt[3] += beta * c1.y; pt[4] += beta * c2.x; pt[5] += beta * c2.y;
                 }
             }
+            MF_TL(tl_base + 3);
             double y[6];
             if (l < pair1) {       // both keyframes of the edge are in this tile: the record is read once, the shared part computed once
                 double y2[6];
@@ -1352,12 +1422,14 @@ __global__ __launch_bounds__(MF_BLOCK) void mf_spmv_kernel(GraphDev G, MfDev F, 
             for (int r = 0; r < 6; ++r) contrib[slot_a * 7 + r] = y[r];
         }
         __syncthreads();
+        MF_TL(tl_base + 4);
         if (l < nn * 6) {
             const int nl = l / 6, r = l - nl * 6;
             const int64_t node = (int64_t)n0 + nl;
             const size_t vi = (size_t)node * 6 + r;
             const double pr = pwin[l];
             double acc = F.lam[vi] * pr;
+            MF_TL(tl_base + 5);
             if (G.node_free[node]) {
                 const ushort4 rg = F.node_rng[node];
                 for (int j = rg.x; j < rg.y; ++j) acc += contrib[j * 7 + r];    // relative-pose sides, then switchable sides: the same
@@ -1376,6 +1448,10 @@ __global__ __launch_bounds__(MF_BLOCK) void mf_spmv_kernel(GraphDev G, MfDev F, 
             else { yout[vi] = acc; pq += acc * pr; }
         }
         __syncthreads();
+        MF_TL(tl_base + 6);
+#ifdef PGO_MF_TIMELINE
+        tl_base += 7;
+#endif
     }
     if (FUSED || first == 2) {     // plain y = A x with first == 2: the partial sums of x.y as well (the multi-rank PCG's u.(A_r u))
         const double s = block_sum(pq, red);
@@ -1972,7 +2048,7 @@ __global__ __launch_bounds__(CG_BLOCK) void coarse_prolong_kernel(GraphDev G, Co
 //   cg_update_restrict_kernel     cg_update_kernel + rc = P^T r' : a workgroup trip covers `kft` keyframes = WHOLE aggregates (kft = (64 / m) m)
 //   coarse_solve_dot_kernel       y = Ac^-1 rc and the partial sums of rc.y = r'.(P y), the coarse part of r.z, behind the update kernel's partials
 __global__ __launch_bounds__(CG_BLOCK) void cg_update_restrict_kernel(GraphDev G, CgDev C, CoarseDev K, int parity, int nparts_pq, int nparts, int kft) {
-    __shared__ double red[2 * (CG_BLOCK / 64)];
+    __shared__ double red[2 * (CG_BLOCK / 64) + 1];
     const double2* __restrict__ rin = reinterpret_cast<const double2*>(parity ? C.r2 : C.r);
     double2* __restrict__ rout = reinterpret_cast<double2*>(parity ? C.r : C.r2);
     const double2* __restrict__ pcur = reinterpret_cast<const double2*>(parity ? C.p2 : C.p);
@@ -1990,9 +2066,8 @@ __global__ __launch_bounds__(CG_BLOCK) void cg_update_restrict_kernel(GraphDev G
         r0 = rin[i_first]; q0 = qv[i_first]; p0 = pcur[i_first]; x0 = xv[i_first];
         const double* d = K.d + (size_t)kf_first * 3; d0 = d[0]; d1 = d[1]; d2 = d[2]; fr = G.node_free[kf_first] ? 1.0 : 0.0;
     }
-    if (cg_done(C)) return;
     double pq, rz;
-    block_total2(C.part_pq, nparts_pq, C.part_rz + parity * RZ_STRIDE, nparts + C.extra_rz, red, pq, rz);
+    if (block_total2_done(C.flags, C.part_pq, nparts_pq, C.part_rz + parity * RZ_STRIDE, nparts + C.extra_rz, red, pq, rz)) return;
     if (!(pq > 0.0)) {
         if (blockIdx.x == 0 && threadIdx.x == 0) C.flags[1] = 1;
         if (threadIdx.x == 0) C.part_rz[(parity ^ 1) * RZ_STRIDE + blockIdx.x] = 0.0;

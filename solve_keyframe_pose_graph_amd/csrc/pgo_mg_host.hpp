@@ -19,6 +19,7 @@
 #include <utility>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 #ifdef PGO_MG_HOST_TIMING      // development aid (scripts/dev/time_hierarchy.py): phase times of build_hierarchy on stderr
 #include <chrono>
@@ -58,6 +59,26 @@ struct Hierarchy {
 };
 
 struct WEdge { int32_t u, v; double w; };
+
+// rows [0, n) in `parts` contiguous ranges, one thread each (the last one on the caller): fn(part, lo, hi).  The hierarchy build itself runs on a worker thread beside
+// build_graph's other host work; inside it the independent pieces — level 1's block structure beside the matching of the levels above, the rows of the smoothed
+// transition's sparsity patterns — are spread over a few more.  The results do not depend on the thread count: every part writes its own output, joined in order.
+template <class Fn>
+inline void parallel_ranges(int32_t n, int parts, Fn fn) {
+    if (parts < 1) parts = 1;
+    if (parts == 1 || n < 2048) { fn(0, 0, n); return; }
+    std::vector<std::thread> th;
+    const int32_t step = (n + parts - 1) / parts;
+    bool failed = false;
+    for (int k = 0; k + 1 < parts; ++k) {
+        const int32_t lo = std::min<int64_t>((int64_t)k * step, n), hi = std::min<int64_t>((int64_t)(k + 1) * step, n);
+        try { th.emplace_back([=, &fn]() { fn(k, lo, hi); }); } catch (...) { failed = true; fn(k, lo, hi); }
+    }
+    (void)failed;
+    fn(parts - 1, std::min<int64_t>((int64_t)(parts - 1) * step, n), n);
+    for (std::thread& t : th) t.join();
+}
+inline int host_threads() { const unsigned hc = std::thread::hardware_concurrency(); return hc >= 8 ? 4 : hc >= 4 ? 2 : 1; }
 
 // Stable bucket sort: elements of `v` ordered by bucket(v[i]) in [0, nb), the order inside a bucket kept; `start` [nb+1] receives the bucket bounds.  The big sorts of
 // the hierarchy build (700 000 block triples of C3's level 1, 200 000 couplings per matching pass) have keys "row, then column" with short rows: one linear pass by
@@ -291,6 +312,36 @@ inline bool build_hierarchy(int64_t N, const std::vector<uint8_t>& node_free, co
         Cc.n1 = n1;
         if (n1 < 1) return false;
         PGO_MG_T("level-0 matching + run cuts");
+        // block structure and Galerkin contribution lists of level 1, in the provisional numbering: needs the keyframes' aggregates only, so it runs on a thread of its own
+        // beside the level-1 couplings below (and, at a first build, its result is needed only after the levels above have been matched and numbered)
+        auto level1_structure = [&]() {
+            const std::vector<int32_t>& A0 = Cc.agg0_prov;
+            std::vector<std::pair<int64_t, int64_t>> trip;
+            trip.reserve((size_t)N + 2 * (size_t)(Er + Es));
+            // (entry -1: the block exists — its structure is the global one on every rank — but the contribution is another rank's)
+            for (int64_t i = 0; i < N; ++i) if (A0[i] >= 0) trip.push_back({(int64_t)A0[i] * n1 + A0[i], local ? (int64_t)-1 : ((i << 3) | 0)});
+            auto edge = [&](int64_t e, int32_t c1, int32_t c2, int kind_fwd) {
+                const int32_t a = A0[c1], b = A0[c2];
+                if (a < 0 || b < 0) return;                     // rows and columns of fixed keyframes are not part of the system
+                trip.push_back({(int64_t)a * n1 + b, e < 0 ? (int64_t)-1 : ((e << 3) | kind_fwd)});
+                trip.push_back({(int64_t)b * n1 + a, e < 0 ? (int64_t)-1 : ((e << 3) | (kind_fwd + 1))});
+            };
+            for (int64_t e = 0; e < Er; ++e) edge(local ? -1 : e, rc1[e], rc2[e], 1);
+            for (int64_t e = 0; e < Es; ++e) edge(local ? -1 : e, sc1[e], sc2[e], 3);
+            if (local) {
+                const int64_t Nl = (int64_t)local->l2g->size();
+                for (int64_t l = 0; l < Nl; ++l) { const int32_t a = A0[(*local->l2g)[l]]; if (a >= 0 && (*local->own)[l] != 0.0) trip.push_back({(int64_t)a * n1 + a, (l << 3) | 0}); }
+                for (int64_t e = 0; e < (int64_t)local->rc1->size(); ++e) edge(e, (*local->rc1)[e], (*local->rc2)[e], 1);
+                for (int64_t e = 0; e < (int64_t)local->sc1->size(); ++e) edge(e, (*local->sc1)[e], (*local->sc2)[e], 3);
+            }
+            Cc.L1prov = HostLevel{};
+            build_blocks(n1, trip, Cc.L1prov);
+            Cc.L1prov.n = n1;
+        };
+        std::thread l1_thread;
+        if (host_threads() > 1) { try { l1_thread = std::thread(level1_structure); } catch (...) {} }
+        struct Join { std::thread& t; ~Join() { if (t.joinable()) t.join(); } } l1_join{l1_thread};
+        const bool l1_async = l1_thread.joinable();
         // level-1 couplings: the relative-pose part as collapsed edges, the switchable part per pair of level-1 nodes with the list of its edges (their weights change)
         Cc.rel1 = collapse(rel_edges, Cc.agg0_prov);
         {   // parallel couplings merged once (match_passes would sort all of them again at every rebuild)
@@ -319,31 +370,8 @@ inline bool build_hierarchy(int64_t N, const std::vector<uint8_t>& node_free, co
             Cc.sw_ptr.push_back((int64_t)Cc.sw_edge.size());
         }
         PGO_MG_T("level-1 couplings");
-        // block structure and Galerkin contribution lists of level 1, in the provisional numbering
-        {
-            const std::vector<int32_t>& A0 = Cc.agg0_prov;
-            std::vector<std::pair<int64_t, int64_t>> trip;
-            trip.reserve((size_t)N + 2 * (size_t)(Er + Es));
-            // (entry -1: the block exists — its structure is the global one on every rank — but the contribution is another rank's)
-            for (int64_t i = 0; i < N; ++i) if (A0[i] >= 0) trip.push_back({(int64_t)A0[i] * n1 + A0[i], local ? (int64_t)-1 : ((i << 3) | 0)});
-            auto edge = [&](int64_t e, int32_t c1, int32_t c2, int kind_fwd) {
-                const int32_t a = A0[c1], b = A0[c2];
-                if (a < 0 || b < 0) return;                     // rows and columns of fixed keyframes are not part of the system
-                trip.push_back({(int64_t)a * n1 + b, e < 0 ? (int64_t)-1 : ((e << 3) | kind_fwd)});
-                trip.push_back({(int64_t)b * n1 + a, e < 0 ? (int64_t)-1 : ((e << 3) | (kind_fwd + 1))});
-            };
-            for (int64_t e = 0; e < Er; ++e) edge(local ? -1 : e, rc1[e], rc2[e], 1);
-            for (int64_t e = 0; e < Es; ++e) edge(local ? -1 : e, sc1[e], sc2[e], 3);
-            if (local) {
-                const int64_t Nl = (int64_t)local->l2g->size();
-                for (int64_t l = 0; l < Nl; ++l) { const int32_t a = A0[(*local->l2g)[l]]; if (a >= 0 && (*local->own)[l] != 0.0) trip.push_back({(int64_t)a * n1 + a, (l << 3) | 0}); }
-                for (int64_t e = 0; e < (int64_t)local->rc1->size(); ++e) edge(e, (*local->rc1)[e], (*local->rc2)[e], 1);
-                for (int64_t e = 0; e < (int64_t)local->sc1->size(); ++e) edge(e, (*local->sc1)[e], (*local->sc2)[e], 3);
-            }
-            Cc.L1prov = HostLevel{};
-            build_blocks(n1, trip, Cc.L1prov);
-            Cc.L1prov.n = n1;
-        }
+        if (!l1_async) level1_structure();
+        else l1_thread.join();      // (simple: joined here; the matching of the levels above is short next to it)
         Cc.valid = true;
         PGO_MG_T("level-1 block structure");
     }
@@ -421,45 +449,53 @@ inline bool build_hierarchy(int64_t N, const std::vector<uint8_t>& node_free, co
             // structure of Ps, W = A Ps and B = Ps^T W (all by sorted unions; the numeric kernels search these short rows)
             A.smoothed = true;
             const int32_t n = A.n, nb = B.n;
-            A.ps_rowptr.assign((size_t)n + 1, 0);
-            std::vector<int32_t> tmp;
-            for (int32_t i = 0; i < n; ++i) {
-                tmp.clear();
+            // rows are independent: contiguous row ranges on a few threads, each with its own output and marker array, joined in row order
+            const int nth = host_threads();
+            auto rows_in_parallel = [&](int32_t rows, std::vector<int32_t>& rowptr_out, std::vector<int32_t>& col_out, auto row_fn /* (row, tmp, stamp) -> fills tmp, sorted */) {
+                std::vector<std::vector<int32_t>> part_cols((size_t)nth), part_len((size_t)nth);
+                parallel_ranges(rows, nth, [&](int part, int32_t lo, int32_t hi) {
+                    std::vector<int32_t> tmp, stamp((size_t)nb, -1);
+                    std::vector<int32_t>& pc = part_cols[(size_t)part]; std::vector<int32_t>& pl = part_len[(size_t)part];
+                    pl.reserve((size_t)(hi - lo));
+                    for (int32_t i = lo; i < hi; ++i) { tmp.clear(); row_fn(i, tmp, stamp); pc.insert(pc.end(), tmp.begin(), tmp.end()); pl.push_back((int32_t)tmp.size()); }
+                });
+                rowptr_out.assign((size_t)rows + 1, 0); col_out.clear();
+                int32_t r = 0;
+                for (int k = 0; k < nth; ++k) {
+                    for (int32_t len : part_len[(size_t)k]) { rowptr_out[(size_t)r + 1] = rowptr_out[r] + len; ++r; }
+                    col_out.insert(col_out.end(), part_cols[(size_t)k].begin(), part_cols[(size_t)k].end());
+                }
+            };
+            rows_in_parallel(n, A.ps_rowptr, A.ps_col, [&](int32_t i, std::vector<int32_t>& tmp, std::vector<int32_t>&) {
                 for (int64_t k = A.rowptr[i]; k < A.rowptr[(size_t)i + 1]; ++k) tmp.push_back(A.parent[A.col[k]]);
                 std::sort(tmp.begin(), tmp.end()); tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
-                A.ps_col.insert(A.ps_col.end(), tmp.begin(), tmp.end());
-                A.ps_rowptr[(size_t)i + 1] = (int32_t)A.ps_col.size();
-            }
-            A.w_rowptr.assign((size_t)n + 1, 0);
-            std::vector<int32_t> stamp((size_t)nb, -1);              // unions by marking: each coarse column enters a row's list once
-            for (int32_t i = 0; i < n; ++i) {
-                tmp.clear();
+            });
+            rows_in_parallel(n, A.w_rowptr, A.w_col, [&](int32_t i, std::vector<int32_t>& tmp, std::vector<int32_t>& stamp) {      // unions by marking: each coarse column enters a row's list once
                 for (int64_t k = A.rowptr[i]; k < A.rowptr[(size_t)i + 1]; ++k) {
                     const int32_t j = A.col[k];
                     for (int32_t sl = A.ps_rowptr[j]; sl < A.ps_rowptr[(size_t)j + 1]; ++sl) { const int32_t c = A.ps_col[sl]; if (stamp[c] != i) { stamp[c] = i; tmp.push_back(c); } }
                 }
                 std::sort(tmp.begin(), tmp.end());
-                A.w_col.insert(A.w_col.end(), tmp.begin(), tmp.end());
-                A.w_rowptr[(size_t)i + 1] = (int32_t)A.w_col.size();
-            }
+            });
             A.psT_ptr.assign((size_t)nb + 1, 0);
             for (int32_t c : A.ps_col) A.psT_ptr[(size_t)c + 1]++;
             for (int32_t a = 0; a < nb; ++a) A.psT_ptr[(size_t)a + 1] += A.psT_ptr[a];
             A.psT_ent.resize(A.ps_col.size());
             { std::vector<int64_t> fill(A.psT_ptr.begin(), A.psT_ptr.end() - 1);
               for (int32_t i = 0; i < n; ++i) for (int32_t sl = A.ps_rowptr[i]; sl < A.ps_rowptr[(size_t)i + 1]; ++sl) A.psT_ent[(size_t)fill[A.ps_col[sl]]++] = ((int64_t)i << 32) | (int64_t)sl; }
-            B.rowptr.assign((size_t)nb + 1, 0); B.col.clear();
-            std::fill(stamp.begin(), stamp.end(), -1);
-            for (int32_t a = 0; a < nb; ++a) {
-                tmp.clear();
-                for (int64_t e = A.psT_ptr[a]; e < A.psT_ptr[(size_t)a + 1]; ++e) {
-                    const int32_t i = (int32_t)(A.psT_ent[e] >> 32);
-                    for (int32_t sl = A.w_rowptr[i]; sl < A.w_rowptr[(size_t)i + 1]; ++sl) { const int32_t c = A.w_col[sl]; if (stamp[c] != a) { stamp[c] = a; tmp.push_back(c); } }
-                }
-                std::sort(tmp.begin(), tmp.end());
-                B.col.push_back(a);                                       // the diagonal block first, as everywhere
-                for (int32_t c : tmp) if (c != a) B.col.push_back(c);
-                B.rowptr[(size_t)a + 1] = (int64_t)B.col.size();
+            {
+                std::vector<int32_t> brow, bcol;
+                rows_in_parallel(nb, brow, bcol, [&](int32_t a, std::vector<int32_t>& tmp, std::vector<int32_t>& stamp) {
+                    std::vector<int32_t> un;
+                    for (int64_t e = A.psT_ptr[a]; e < A.psT_ptr[(size_t)a + 1]; ++e) {
+                        const int32_t i = (int32_t)(A.psT_ent[e] >> 32);
+                        for (int32_t sl = A.w_rowptr[i]; sl < A.w_rowptr[(size_t)i + 1]; ++sl) { const int32_t c = A.w_col[sl]; if (stamp[c] != a) { stamp[c] = a; un.push_back(c); } }
+                    }
+                    std::sort(un.begin(), un.end());
+                    tmp.push_back(a);                                         // the diagonal block first, as everywhere
+                    for (int32_t c : un) if (c != a) tmp.push_back(c);
+                });
+                B.rowptr.assign(brow.begin(), brow.end()); B.col.swap(bcol);
             }
             B.g_ptr.assign(B.col.size() + 1, 0); B.g_ent.clear();         // (no contribution lists: the product is formed from Ps and W)
             continue;

@@ -845,7 +845,7 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_prolong0_kernel(GraphDev G, MgDev
 __global__ __launch_bounds__(CG_BLOCK) void cg_update_mg_kernel(GraphDev G, CgDev C, MgDev M, double* __restrict__ r1_out, double* __restrict__ x1_out, const double* __restrict__ Dinv1,
                                                                  int parity, int nparts_pq, int nparts) {
     static_assert(CG_BLOCK / 3 == MG_BLOCK0, "one workgroup trip of the vector update = one run of the slot table");
-    __shared__ double red[2 * (CG_BLOCK / 64)];
+    __shared__ double red[2 * (CG_BLOCK / 64) + 1];
     const double2* __restrict__ rin = reinterpret_cast<const double2*>(parity ? C.r2 : C.r);
     double2* __restrict__ rout = reinterpret_cast<double2*>(parity ? C.r : C.r2);
     const double2* __restrict__ pcur = reinterpret_cast<const double2*>(parity ? C.p2 : C.p);
@@ -886,9 +886,8 @@ __global__ __launch_bounds__(CG_BLOCK) void cg_update_mg_kernel(GraphDev G, CgDe
         }
     };
     load_trip((int64_t)blockIdx.x);
-    if (cg_done(C)) return;
     double pq, rz;
-    block_total2(C.part_pq, nparts_pq, C.part_rz + parity * RZ_STRIDE, nparts + C.extra_rz, red, pq, rz);
+    if (block_total2_done(C.flags, C.part_pq, nparts_pq, C.part_rz + parity * RZ_STRIDE, nparts + C.extra_rz, red, pq, rz)) return;
     if (!(pq > 0.0)) {
         if (blockIdx.x == 0 && threadIdx.x == 0) C.flags[1] = 1;
         if (threadIdx.x == 0) C.part_rz[(parity ^ 1) * RZ_STRIDE + blockIdx.x] = 0.0;
