@@ -21,15 +21,13 @@
 #include <cstring>
 #include <thread>
 #include <vector>
-#ifdef PGO_MG_HOST_TIMING      // development aid (scripts/dev/time_hierarchy.py): phase times of build_hierarchy on stderr
 #include <chrono>
 #include <cstdio>
+// phase times of build_hierarchy on stderr when pgo_mg::timing() is set (pgo_options.verbosity > 1)
 #define PGO_MG_T0() auto t_mg_ = std::chrono::steady_clock::now()
-#define PGO_MG_T(what) do { auto n_ = std::chrono::steady_clock::now(); std::fprintf(stderr, "[mg host] %-28s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(n_ - t_mg_).count()); t_mg_ = n_; } while (0)
-#else
-#define PGO_MG_T0() do {} while (0)
-#define PGO_MG_T(what) do {} while (0)
-#endif
+#define PGO_MG_T(what) do { if (pgo_mg::timing()) { auto n_ = std::chrono::steady_clock::now(); std::fprintf(stderr, "[pgo] hierarchy (host): %-28s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(n_ - t_mg_).count()); t_mg_ = n_; } } while (0)
+
+namespace pgo_mg { inline bool& timing() { static bool on = false; return on; } }
 
 namespace pgo_mg {
 

@@ -299,6 +299,7 @@ int mg_prepare(pgo_problem* p, const double* sw_now, MgPrepared& Q) {
     int rc;
     const double t0 = now_s();
     pgo_mg::Hierarchy& H = Q.H;
+    pgo_mg::timing() = p->opt.verbosity > 1;
     const int dense_max = std::max(1, std::min(p->opt.mg_dense_max_nodes, 512));
     // smoothed prolongators (denser coarse operators, two more row products per cycle on each such level) pay while the coarse levels are latency-bound: measured
     // C4 (200k keyframes) 3.56 -> 2.37 s, C5 (1M keyframes, level 1 = 125k nodes: bandwidth-bound) 8.5 -> 11.1 s.  -1 = by size; with them aggregates of 4 above level 1, else of 8
@@ -419,6 +420,7 @@ int mg_prepare(pgo_problem* p, const double* sw_now, MgPrepared& Q) {
         }
     }
     Q.host_ms = (now_s() - t0) * 1e3;
+    if (p->opt.verbosity > 1) std::fprintf(stderr, "[pgo] hierarchy (host): pooled arrays + descriptors      (total %.2f ms, %u hardware threads reported)\n", Q.host_ms, std::thread::hardware_concurrency());
     return PGO_OK;
 }
 
@@ -598,6 +600,31 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
     auto L = [g2l](int32_t g) -> int32_t { return g2l ? g2l[g] : g; };
     G.N = N; G.S = S;
     int rc;
+    // a keyframe is part of the program when a residual block touches it: on one GPU that is a non-empty incident list; in a rank-local
+    // subgraph every keyframe is touched by construction (by this rank or, for the stand-in keyframe of an idle rank, possibly by none)
+    p->h_node_free.assign((size_t)N, 0);
+    {
+        std::vector<uint8_t> touched_here((size_t)N, 0);      // (= a non-empty incident list, known before the lists are built: the hierarchy worker below starts at once)
+        for (const HostClass* H : {&p->rel, &p->swe}) for (int64_t e = 0; e < H->size(); ++e) { touched_here[L(H->c1[e])] = 1; touched_here[L(H->c2[e])] = 1; }
+        for (const PriorDev& pr : p->priors) touched_here[L(pr.node)] = 1;
+        for (int64_t n = 0; n < N; ++n) p->h_node_free[n] = (touched_here[n] || (p->local_ids && p->h_touched_any[p->l2g[n]])) ? 1 : 0;
+    }
+    for (int32_t c : p->constant_nodes) if (c >= 0 && c < Ng && L(c) >= 0) p->h_node_free[L(c)] = 0;
+    // One GPU: the HOST half of the multigrid hierarchy (pgo_mg_host.hpp: ~0.1 s for C3, single-threaded sorts and matchings) needs the edge lists and the free flags
+    // only, so it runs on a worker thread beside the rest of this function — incident-list upload, matrix-free tile packing, buffer allocation — and is installed where
+    // build_multigrid used to compute it.  Nothing here depends on timing: the result is the same hierarchy.  (Several ranks: its host half holds collectives.)
+    std::thread mg_thread;
+    std::unique_ptr<MgPrepared> mg_ready;
+    int rc_mg_thread = PGO_OK;
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } mg_joiner{mg_thread};     // every early return below waits for the worker
+    p->mg_cache.valid = false;
+    if (!p->local_ids && wants_multigrid(p)) {
+        mg_ready.reset(new MgPrepared());
+        MgPrepared* Qp = mg_ready.get();
+        int* rcp = &rc_mg_thread;
+        try { mg_thread = std::thread([p, sw_now, Qp, rcp]() { *rcp = mg_prepare(p, sw_now, *Qp); }); }
+        catch (...) { rc_mg_thread = mg_prepare(p, sw_now, *Qp); }
+    }
     if ((rc = upload_class(p, p->rel, false, p->d_rc1, p->d_rc2, p->d_sidx /*unused*/, p->d_rmeas, p->d_rwin, G.rel)) != PGO_OK) return rc;
     if ((rc = upload_class(p, p->swe, true, p->d_sc1, p->d_sc2, p->d_sidx, p->d_smeas, p->d_swin, G.sw)) != PGO_OK) return rc;
     const int64_t Er = G.rel.E, Es = G.sw.E, Eg = (int64_t)p->priors.size();
@@ -624,26 +651,6 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
     for (int64_t e = 0; e < Er; ++e) add_edge(e, L(p->rel.c1[e]), L(p->rel.c2[e]));
     for (int64_t e = 0; e < Es; ++e) add_edge(G.rel.Epad + e, L(p->swe.c1[e]), L(p->swe.c2[e]));
     for (int64_t k = 0; k < Eg; ++k) inc[fill[pri[k].node]++] = ((G.rel.Epad + G.sw.Epad + k) << 1);
-    // a keyframe is part of the program when a residual block touches it: on one GPU that is a non-empty incident list; in a rank-local
-    // subgraph every keyframe is touched by construction (by this rank or, for the stand-in keyframe of an idle rank, possibly by none)
-    p->h_node_free.assign((size_t)N, 0);
-    for (int64_t n = 0; n < N; ++n) p->h_node_free[n] = (rowptr[n + 1] > rowptr[n] || (p->local_ids && p->h_touched_any[p->l2g[n]])) ? 1 : 0;
-    for (int32_t c : p->constant_nodes) if (c >= 0 && c < Ng && L(c) >= 0) p->h_node_free[L(c)] = 0;
-    // One GPU: the HOST half of the multigrid hierarchy (pgo_mg_host.hpp: ~0.1 s for C3, single-threaded sorts and matchings) needs the edge lists and the free flags
-    // only, so it runs on a worker thread beside the rest of this function — incident-list upload, matrix-free tile packing, buffer allocation — and is installed where
-    // build_multigrid used to compute it.  Nothing here depends on timing: the result is the same hierarchy.  (Several ranks: its host half holds collectives.)
-    std::thread mg_thread;
-    std::unique_ptr<MgPrepared> mg_ready;
-    int rc_mg_thread = PGO_OK;
-    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } mg_joiner{mg_thread};     // every early return below waits for the worker
-    p->mg_cache.valid = false;
-    if (!p->local_ids && wants_multigrid(p)) {
-        mg_ready.reset(new MgPrepared());
-        MgPrepared* Qp = mg_ready.get();
-        int* rcp = &rc_mg_thread;
-        try { mg_thread = std::thread([p, sw_now, Qp, rcp]() { *rcp = mg_prepare(p, sw_now, *Qp); }); }
-        catch (...) { rc_mg_thread = mg_prepare(p, sw_now, *Qp); }
-    }
 
     HIPCHK(p, p->d_inc_rowptr.ensure(N + 1)); HIPCHK(p, p->d_bsr_rowptr.ensure(N + 1)); HIPCHK(p, p->d_inc.ensure(std::max<int64_t>(ninc, 1)));
     HIPCHK(p, p->d_bsr_col.ensure(std::max<int64_t>(p->nnzb, 1))); HIPCHK(p, p->d_node_free.ensure(std::max<int64_t>(N, 1)));
