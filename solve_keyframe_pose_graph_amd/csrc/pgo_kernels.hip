@@ -1356,10 +1356,10 @@ __global__ __launch_bounds__(MF_BLOCK) void mf_spmv_kernel(GraphDev G, MfDev F, 
         MF_TL(tl_base + 1);
         if (i < i1) {
             const uint32_t ent = F.einc[i];
+            const int32_t other = F.einc_other[i];      // (requesting the first tile's index words before the head, so that its far gathers go out with the records: measured, no change)
+            const uint32_t sl = F.einc_slot[i];
             const bool is_sw = l >= sw0;
             const int side = (int)(ent & 1u);
-            const int32_t other = F.einc_other[i];
-            const uint32_t sl = F.einc_slot[i];
             const int ownl = (int)(sl >> 18), slot_a = (int)(sl & 511u), slot_b = (int)((sl >> 9) & 511u);
             double rec[COMPACT_DOUBLES];
 #pragma unroll

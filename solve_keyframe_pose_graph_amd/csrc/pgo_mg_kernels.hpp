@@ -54,6 +54,10 @@ __device__ __forceinline__ void mg_row_accumulate_f32(int64_t b, int64_t e, cons
     if (k + 2 <= e) { mg_chunk_f32<2>(col + k, val + (size_t)k * 36, c, x, acc); k += 2; }
     if (k < e) mg_chunk_f32<1>(col + k, val + (size_t)k * 36, c, x, acc);
 }
+// (Measured and dropped in round 4: a 32-B slot descriptor carrying the block range AND the column indices of the group's first six blocks, so that the x gathers are issued with
+// the block loads — one dependent round trip less per level kernel on paper; on C3 the multigrid PCG iteration went 133 -> 142 us, with predicated and with branch-free loads alike:
+// six blocks' loads in flight per lane cost more than the round trip they save.)
+#define MG_ROW_PRODUCT(tile_, xvec_) do { if (rowlive) { int kb, ke; mg_split_row(rb, sg, A.seg_shift, kb, ke); mg_row_accumulate_f32(kb, ke, A.col, A.valf, xvec_, c, acc); } } while (0)
 // Row products of the level kernels.  192 lanes = 32 (row, lane-group) slots x 6 columns.  With seg_shift = 0 a slot is a row; with seg_shift = s the tile holds
 // R = 32 >> s rows and 2^s lane groups share each row, group g streaming the g-th part of its blocks (long rows: Galerkin products of smoothed transitions).
 // mg_split_row: this lane's part [b, e) of the row's block range.  mg_gather_row: the row's result for column-lane c, summed over the 6 column lanes and the groups
@@ -492,7 +496,7 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_smooth_step_kernel(MgLevelDev A, 
         Dk[0] = u0.x; Dk[1] = u0.y; Dk[2] = u1.x; Dk[3] = u1.y; Dk[4] = u2.x; Dk[5] = u2.y;
     }
     double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    if (rowlive) { int kb, ke; mg_split_row(rb, sg, A.seg_shift, kb, ke); mg_row_accumulate_f32(kb, ke, A.col, A.valf, in_x, c, acc); }
+    MG_ROW_PRODUCT(blockIdx.x, in_x);
     double* mine = xch + (size_t)threadIdx.x * 7;
 #pragma unroll
     for (int q = 0; q < 6; ++q) mine[q] = acc[q];
@@ -648,7 +652,7 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_down_kernel(MgLevelDev A, double*
         }
     }
     double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    if (rowlive) { int kb, ke; mg_split_row(rb, sg, A.seg_shift, kb, ke); mg_row_accumulate_f32(kb, ke, A.col, A.valf, A.x, c, acc); }
+    MG_ROW_PRODUCT(blockIdx.x, A.x);
     double* mine = xch + (size_t)threadIdx.x * 7;
 #pragma unroll
     for (int q = 0; q < 6; ++q) mine[q] = acc[q];
@@ -766,7 +770,7 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_up_kernel(MgLevelDev A, MgLevelDe
         }
     }
     double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    if (rowlive) { int kb, ke; mg_split_row(rb, sg, A.seg_shift, kb, ke); mg_row_accumulate_f32(kb, ke, A.col, A.valf, A.xt, c, acc); }
+    MG_ROW_PRODUCT(tile, A.xt);
     double* mine = xch + (size_t)threadIdx.x * 7;
 #pragma unroll
     for (int q = 0; q < 6; ++q) mine[q] = acc[q];
