@@ -24,6 +24,24 @@ __device__ __forceinline__ double wave_max(double v) {
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
     return v;
 }
+// This thread's share of a partial-sum array, p[threadIdx.x + k blockDim.x]: up to 12 entries per thread (2 048 partials on 192 lanes) REQUESTED TOGETHER — the loop form
+// `for (i = tid; i < n; i += blockDim) v += p[i]` has a run-time trip count, is not unrolled, and waits for every load before it issues the next: four to eleven dependent
+// round trips at the head of every PCG kernel, where the whole workgroup waits for alpha / beta (timeline build: 5 us of the matvec's 26).  Same summation order as the loop.
+#ifndef PGO_SERIAL_HEAD
+__device__ __forceinline__ double strided_share(const double* __restrict__ p, int n) {
+    constexpr int MAXK = 12;
+    double v[MAXK];
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) { const int i = (int)threadIdx.x + k * (int)blockDim.x; v[k] = i < n ? p[i] : 0.0; }
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) s += v[k];
+    for (int i = (int)threadIdx.x + MAXK * (int)blockDim.x; i < n; i += blockDim.x) s += p[i];
+    return s;
+}
+#else      // A/B aid (variant build): the loop form
+__device__ __forceinline__ double strided_share(const double* __restrict__ p, int n) { double s = 0.0; for (int i = threadIdx.x; i < n; i += blockDim.x) s += p[i]; return s; }
+#endif
 // sum over the workgroup; valid in thread 0.  `buf` holds blockDim/64 doubles of LDS.
 __device__ __forceinline__ double block_sum(double v, double* buf) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
@@ -37,8 +55,7 @@ __device__ __forceinline__ double block_sum(double v, double* buf) {
 }
 // every thread gets sum(partials[0..n)); n <= a few thousand, read through L2
 __device__ __forceinline__ double block_total(const double* __restrict__ partials, int n, double* buf) {
-    double v = 0.0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) v += partials[i];
+    double v = strided_share(partials, n);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
     v = wave_sum(v);
     __syncthreads();
@@ -55,9 +72,7 @@ __device__ __forceinline__ int pm(int r, int c) { return (c >> 1) * 12 + r * 2 +
 
 // two totals in one pass (one barrier pair instead of two): every PCG kernel starts by re-reducing two partial arrays
 __device__ __forceinline__ void block_total2(const double* __restrict__ pa, int na, const double* __restrict__ pb, int nb, double* buf /*2 x nwaves*/, double& sa, double& sb) {
-    double va = 0.0, vb = 0.0;
-    for (int i = threadIdx.x; i < na; i += blockDim.x) va += pa[i];
-    for (int i = threadIdx.x; i < nb; i += blockDim.x) vb += pb[i];
+    double va = strided_share(pa, na), vb = strided_share(pb, nb);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
     va = wave_sum(va); vb = wave_sum(vb);
     __syncthreads();
@@ -70,10 +85,7 @@ __device__ __forceinline__ void block_total2(const double* __restrict__ pa, int 
 // three totals in one pass: the two-level method's matvec keeps the block-Jacobi part and the coarse part of r.z apart (below)
 __device__ __forceinline__ void block_total3(const double* __restrict__ pa, int na, const double* __restrict__ pb, int nb, const double* __restrict__ pc, int nc, double* buf /*3 x nwaves*/,
                                              double& sa, double& sb, double& sc) {
-    double va = 0.0, vb = 0.0, vc = 0.0;
-    for (int i = threadIdx.x; i < na; i += blockDim.x) va += pa[i];
-    for (int i = threadIdx.x; i < nb; i += blockDim.x) vb += pb[i];
-    for (int i = threadIdx.x; i < nc; i += blockDim.x) vc += pc[i];
+    double va = strided_share(pa, na), vb = strided_share(pb, nb), vc = strided_share(pc, nc);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
     va = wave_sum(va); vb = wave_sum(vb); vc = wave_sum(vc);
     __syncthreads();
@@ -91,9 +103,7 @@ __device__ __forceinline__ bool block_total2_done(const int32_t* __restrict__ fl
                                                   double& sa, double& sb) {
     int f = 0;
     if (threadIdx.x == 0) f = flags[0];
-    double va = 0.0, vb = 0.0;
-    for (int i = threadIdx.x; i < na; i += blockDim.x) va += pa[i];
-    for (int i = threadIdx.x; i < nb; i += blockDim.x) vb += pb[i];
+    double va = strided_share(pa, na), vb = strided_share(pb, nb);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
     va = wave_sum(va); vb = wave_sum(vb);
     __syncthreads();
@@ -108,10 +118,7 @@ __device__ __forceinline__ bool block_total3_done(const int32_t* __restrict__ fl
                                                   double* buf, double& sa, double& sb, double& sc) {
     int f = 0;
     if (threadIdx.x == 0) f = flags[0];
-    double va = 0.0, vb = 0.0, vc = 0.0;
-    for (int i = threadIdx.x; i < na; i += blockDim.x) va += pa[i];
-    for (int i = threadIdx.x; i < nb; i += blockDim.x) vb += pb[i];
-    for (int i = threadIdx.x; i < nc; i += blockDim.x) vc += pc[i];
+    double va = strided_share(pa, na), vb = strided_share(pb, nb), vc = strided_share(pc, nc);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
     va = wave_sum(va); vb = wave_sum(vb); vc = wave_sum(vc);
     __syncthreads();

@@ -50,6 +50,32 @@ __device__ __forceinline__ void mg_chunk_f32(const int32_t* __restrict__ colp, c
 __device__ __forceinline__ void mg_row_accumulate_f32(int64_t b, int64_t e, const int32_t* __restrict__ col, const float* __restrict__ val,
                                                       const double* __restrict__ x, int c, double* acc) {
     int64_t k = b;
+#ifdef PGO_MG_ROW8      // experiment (variant builds): the first eight blocks of the part with ALL column indices requested first, then all blocks and x entries — two dependent
+                        // round trips for a part of <= 8 blocks instead of two per chunk of 4 / 2 / 1
+    {
+        const int n = (int)(e - b) < 8 ? (int)(e - b) : 8;
+        int32_t cc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cc[u] = u < n ? col[b + u] : 0;
+        float2 v[8][3]; double xx[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (u < n) {
+                const float2* vp = reinterpret_cast<const float2*>(val + (size_t)(b + u) * 36) + c;
+                v[u][0] = vp[0]; v[u][1] = vp[6]; v[u][2] = vp[12];
+                xx[u] = x[(size_t)cc[u] * 6 + c];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (u < n) {
+                acc[0] += (double)v[u][0].x * xx[u]; acc[1] += (double)v[u][0].y * xx[u]; acc[2] += (double)v[u][1].x * xx[u];
+                acc[3] += (double)v[u][1].y * xx[u]; acc[4] += (double)v[u][2].x * xx[u]; acc[5] += (double)v[u][2].y * xx[u];
+            }
+        }
+        k = b + n;
+    }
+#endif
     for (; k + 4 <= e; k += 4) mg_chunk_f32<4>(col + k, val + (size_t)k * 36, c, x, acc);
     if (k + 2 <= e) { mg_chunk_f32<2>(col + k, val + (size_t)k * 36, c, x, acc); k += 2; }
     if (k < e) mg_chunk_f32<1>(col + k, val + (size_t)k * 36, c, x, acc);
