@@ -1435,13 +1435,16 @@ __global__ __launch_bounds__(MF_BLOCK) void mf_spmv_kernel(GraphDev G, MfDev F, 
             const int64_t node = (int64_t)n0 + nl;
             const size_t vi = (size_t)node * 6 + r;
             const double pr = pwin[l];
-            double acc = F.lam[vi] * pr;
+            // (all four requested together: behind the free flag the slot ranges and the regulariser index were a second dependent round trip)
+            const double lam = F.lam[vi];
+            const uint8_t is_free = G.node_free[node];
+            const ushort4 rg = F.node_rng[node];
+            const int32_t pk = F.node_prior[node];
+            double acc = lam * pr;
             MF_TL(tl_base + 5);
-            if (G.node_free[node]) {
-                const ushort4 rg = F.node_rng[node];
+            if (is_free) {
                 for (int j = rg.x; j < rg.y; ++j) acc += contrib[j * 7 + r];    // relative-pose sides, then switchable sides: the same
                 for (int j = rg.z; j < rg.w; ++j) acc += contrib[j * 7 + r];    // fixed order as the incident list -> deterministic
-                const int32_t pk = F.node_prior[node];
                 if (pk >= 0) {   // regulariser: J^T J p of a unary block (a handful per graph)
                     const double* Jp = G.Jp + (size_t)pk * PRIOR_DOUBLES + 6;
                     double pn[6];

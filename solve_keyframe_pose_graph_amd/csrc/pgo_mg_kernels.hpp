@@ -50,32 +50,8 @@ __device__ __forceinline__ void mg_chunk_f32(const int32_t* __restrict__ colp, c
 __device__ __forceinline__ void mg_row_accumulate_f32(int64_t b, int64_t e, const int32_t* __restrict__ col, const float* __restrict__ val,
                                                       const double* __restrict__ x, int c, double* acc) {
     int64_t k = b;
-#ifdef PGO_MG_ROW8      // experiment (variant builds): the first eight blocks of the part with ALL column indices requested first, then all blocks and x entries — two dependent
-                        // round trips for a part of <= 8 blocks instead of two per chunk of 4 / 2 / 1
-    {
-        const int n = (int)(e - b) < 8 ? (int)(e - b) : 8;
-        int32_t cc[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) cc[u] = u < n ? col[b + u] : 0;
-        float2 v[8][3]; double xx[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (u < n) {
-                const float2* vp = reinterpret_cast<const float2*>(val + (size_t)(b + u) * 36) + c;
-                v[u][0] = vp[0]; v[u][1] = vp[6]; v[u][2] = vp[12];
-                xx[u] = x[(size_t)cc[u] * 6 + c];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (u < n) {
-                acc[0] += (double)v[u][0].x * xx[u]; acc[1] += (double)v[u][0].y * xx[u]; acc[2] += (double)v[u][1].x * xx[u];
-                acc[3] += (double)v[u][1].y * xx[u]; acc[4] += (double)v[u][2].x * xx[u]; acc[5] += (double)v[u][2].y * xx[u];
-            }
-        }
-        k = b + n;
-    }
-#endif
+// (Measured and dropped, round 4: the first eight blocks of a part with ALL their column indices requested first, then all blocks and x entries — 128 -> 157 us per multigrid
+    // iteration.  More loads in flight per lane means more registers, and these kernels need their 4 waves per SIMD: ~2 800 wavefronts of a level must be resident in one round.)
     for (; k + 4 <= e; k += 4) mg_chunk_f32<4>(col + k, val + (size_t)k * 36, c, x, acc);
     if (k + 2 <= e) { mg_chunk_f32<2>(col + k, val + (size_t)k * 36, c, x, acc); k += 2; }
     if (k < e) mg_chunk_f32<1>(col + k, val + (size_t)k * 36, c, x, acc);
@@ -644,6 +620,17 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_restrict0_kernel(MgDev M, const d
         x_out[(size_t)a * 6 + k] = x;
     }
 }
+#ifdef PGO_MG_TIMELINE
+// Development aid (variant build only: scripts/dev/mg_timeline.py): thread 0 of every workgroup of mg_down_kernel records the 100-MHz wall clock at its phase boundaries, after a
+// full wait for the memory operations issued so far; [level][workgroup][8] ticks (level = MgLevelDev::pad3_, set at install).
+__device__ unsigned long long pgo_mg_tl[4 * 1024 * 8];
+#define MG_TL(slot) do { __builtin_amdgcn_s_waitcnt(0); if (threadIdx.x == 0 && A.pad3_ < 4 && blockIdx.x < 1024) pgo_mg_tl[((size_t)A.pad3_ * 1024 + blockIdx.x) * 8 + (slot)] = wall_clock64(); } while (0)
+extern "C" int pgo_debug_mg_timeline(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pgo_mg_tl), (size_t)n * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#else
+#define MG_TL(slot) do {} while (0)
+#endif
 // t = r - A x on the rows of a tile of whole aggregates; r_next = P^T t; x_next = Dinv_next r_next (when the next level is a sparse one).
 // Every kernel of the cycle starts on cold L2s (kernel boundaries invalidate them), so what it costs is its chain of DEPENDENT loads:
 // tile_info -> rowptr -> col -> x is the only chain here; everything else a lane will need (its r entry, its row's offset d, the member
@@ -653,11 +640,13 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_down_kernel(MgLevelDev A, double*
     __shared__ double xch[CG_BLOCK * 7];
     __shared__ double tb[CG_BLOCK];
     __shared__ double cb[CG_BLOCK];
+    MG_TL(0);
     const int stopped = stop ? *stop : 0;
     const int q6 = threadIdx.x / 6, c = threadIdx.x % 6;
     const int li = q6 & ((MG_TILE_ROWS >> A.seg_shift) - 1), sg = q6 >> (5 - A.seg_shift);      // row of the tile, lane group (0 unless the level's rows are split)
     const int4 ti = A.tile_info[blockIdx.x];          // {a0, a1, i0, i1}
     const int2 rb = A.tile_rows[blockIdx.x * MG_TILE_ROWS + li];   // this lane's row: its block range (independent of tile_info)
+    MG_TL(1);
     if (stopped) return;
     const int a0 = ti.x, na = ti.y - ti.x, i0 = ti.z, i1 = ti.w;
     const int row = i0 + li;
@@ -677,14 +666,17 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_down_kernel(MgLevelDev A, double*
             Dk[0] = u0.x; Dk[1] = u0.y; Dk[2] = u1.x; Dk[3] = u1.y; Dk[4] = u2.x; Dk[5] = u2.y;
         }
     }
+    MG_TL(2);
     double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     MG_ROW_PRODUCT(blockIdx.x, A.x);
+    MG_TL(3);
     double* mine = xch + (size_t)threadIdx.x * 7;
 #pragma unroll
     for (int q = 0; q < 6; ++q) mine[q] = acc[q];
     __syncthreads();
     if (live) tb[threadIdx.x] = rv - mg_gather_row(xch, li, c, A.seg_shift);
     __syncthreads();
+    MG_TL(4);
     if (live) {                                       // the row's own contribution (P_row^T t)[c]
         const double d[3] = {d0, d1, d2};
         cb[threadIdx.x] = mg_restrict_comp(tb + (size_t)li * 6, d, c);
@@ -695,6 +687,7 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_down_kernel(MgLevelDev A, double*
         for (int m = m0; m < m1; ++m) s += cb[(m - i0) * 6 + c];
         r_next[(size_t)a * 6 + c] = s;
     }
+    MG_TL(5);
     if (!x_next) return;
     tb[threadIdx.x] = s;
     __syncthreads();
@@ -705,6 +698,7 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_down_kernel(MgLevelDev A, double*
         for (int j = 0; j < 6; ++j) x += Dk[j] * ra[j];
         x_next[(size_t)a * 6 + c] = x;
     }
+    MG_TL(6);
 }
 // dense level: one workgroup of 6 wavefronts per node — wavefront q takes row 6 a + q of the explicit inverse (one wavefront per node leaves
 // the 58 MB of a 2688-wide inverse to 440 wavefronts: 21 us; one per row: 2640 wavefronts) — then x + s P y on the node's members below
@@ -719,7 +713,11 @@ __global__ __launch_bounds__(384) void mg_dense_solve_kernel(CoarseDev K, MgLeve
     double s = 0.0;
     if (lane < n4) { const float4 u = Ar[lane]; const double2 v = x[2 * lane], w = x[2 * lane + 1]; s = (double)u.x * v.x + (double)u.y * v.y + (double)u.z * w.x + (double)u.w * w.y; }   // first trip issued before the flag is needed
     if (stopped) return;
+#ifdef PGO_DENSE_UNROLL8
+#pragma unroll 8
+#else
 #pragma unroll 4
+#endif
     for (int j = lane + 64; j < n4; j += 64) { const float4 u = Ar[j]; const double2 v = x[2 * j], w = x[2 * j + 1]; s += (double)u.x * v.x + (double)u.y * v.y + (double)u.z * w.x + (double)u.w * w.y; }
     s = wave_sum(s);
     if (lane == 0) { ys[q] = s; K.yc[a * 6 + q] = s; }

@@ -459,6 +459,7 @@ int mg_install(pgo_problem* p, MgPrepared& Q) {
         D.Dinv = bf + o.Dinv; D.pos = bf + o.pos; D.d = bf + o.d; D.parent = b32 + o.parent; D.agg_ptr = b32 + o.agg_ptr; D.tile_info = reinterpret_cast<const int4*>(b32 + o.tile); D.tile_rows = reinterpret_cast<const int2*>(b32 + o.tile_rows);
         D.r = bf + o.r; D.x = bf + o.x; D.xt = bf + o.xt; D.xf = bf + o.xf; D.valf = reinterpret_cast<float*>(bf + o.valf);
         D.seg_shift = A.seg >= 8 ? 3 : A.seg >= 4 ? 2 : A.seg >= 2 ? 1 : 0;
+        D.pad3_ = l;      // (the level's index: read by the timeline variant build only)
         if (A.smoothed) {
             D.smoothed = 1; D.n_ps = (int32_t)A.ps_col.size(); D.n_w = (int32_t)A.w_col.size();
             D.ps_rowptr = b32 + o.ps_rowptr; D.ps_col = b32 + o.ps_col; D.w_rowptr = b32 + o.w_rowptr; D.w_col = b32 + o.w_col; D.psT_ptr = b64 + o.psT_ptr; D.psT_ent = b64 + o.psT_ent;
