@@ -50,6 +50,8 @@ __device__ __forceinline__ void mg_chunk_f32(const int32_t* __restrict__ colp, c
 __device__ __forceinline__ void mg_row_accumulate_f32(int64_t b, int64_t e, const int32_t* __restrict__ col, const float* __restrict__ val,
                                                       const double* __restrict__ x, int c, double* acc) {
     int64_t k = b;
+// (Also measured and dropped: the part's column indices requested together ahead of the unchanged chunks — 127 -> 135 us per multigrid iteration on C3, 229 -> 237 on C4.  Every
+    // variant that puts more memory instructions in flight per lane loses: these kernels are bound by the issue rate of their scattered 8-byte gathers, not by the col -> x chain.)
 // (Measured and dropped, round 4: the first eight blocks of a part with ALL their column indices requested first, then all blocks and x entries — 128 -> 157 us per multigrid
     // iteration.  More loads in flight per lane means more registers, and these kernels need their 4 waves per SIMD: ~2 800 wavefronts of a level must be resident in one round.)
     for (; k + 4 <= e; k += 4) mg_chunk_f32<4>(col + k, val + (size_t)k * 36, c, x, acc);
@@ -713,11 +715,7 @@ __global__ __launch_bounds__(384) void mg_dense_solve_kernel(CoarseDev K, MgLeve
     double s = 0.0;
     if (lane < n4) { const float4 u = Ar[lane]; const double2 v = x[2 * lane], w = x[2 * lane + 1]; s = (double)u.x * v.x + (double)u.y * v.y + (double)u.z * w.x + (double)u.w * w.y; }   // first trip issued before the flag is needed
     if (stopped) return;
-#ifdef PGO_DENSE_UNROLL8
-#pragma unroll 8
-#else
-#pragma unroll 4
-#endif
+#pragma unroll 4      // (8: no change, measured)
     for (int j = lane + 64; j < n4; j += 64) { const float4 u = Ar[j]; const double2 v = x[2 * j], w = x[2 * j + 1]; s += (double)u.x * v.x + (double)u.y * v.y + (double)u.z * w.x + (double)u.w * w.y; }
     s = wave_sum(s);
     if (lane == 0) { ys[q] = s; K.yc[a * 6 + q] = s; }
