@@ -452,6 +452,8 @@ int pgo_time_vio_odometry_kernel(pgo_problem* p, int32_t f_max, int32_t launches
  * the result, *avg_ms (may be NULL) the HIP-event average of one inversion.  PGO_ERR_NUMERIC when a pivot is not positive. */
 int pgo_dense_spd_inverse(pgo_problem* p, int32_t n, const double* a, double* a_inv, int32_t launches, double* avg_ms);
 
+/* Waits for everything the handle has in flight: its stream and — after a pgo_solve_begin that (re)built the device graph — the worker thread that prepares the multigrid
+ * hierarchy's host half beside the build (otherwise installed where the solve first needs it).  bench.py calls it before its timed region starts. */
 int pgo_device_synchronize(pgo_problem* p);
 
 const char* pgo_strerror(int code);

@@ -171,6 +171,10 @@ struct pgo_problem {
     // installed where multigrid operators are next built — both points depend on the solve's own history only, never on timing
     std::thread mg_job; std::unique_ptr<MgPrepared> mg_job_out, mg_job_old; bool mg_job_running = false;
     int rc_job = 0;
+    // the hierarchy of a freshly built graph (one GPU): its host half is started on a worker thread at the top of build_graph and INSTALLED where it is first needed —
+    // build_mg (the first LM system that wants multigrid operators), the end of the solve, or the next solve_begin; until then mg_built is true ("this graph has a
+    // hierarchy") and the level descriptors are empty.  When it is needed is a property of the solve, how long the wait is not: results do not depend on timing.
+    std::thread mg_init_thread; std::unique_ptr<MgPrepared> mg_init_out; bool mg_init_pending = false; int rc_mg_init = 0;
     uint64_t mg_geometry_epoch = 0;
     uint64_t hoff_epoch = 0;               // linearisation whose J1^T J2 blocks L.Hoff holds (matrix-free solver: formed on demand for the multigrid's level-1 product)
     int64_t n_vio = 0;
@@ -358,6 +362,15 @@ int mg_prepare(pgo_problem* p, const double* sw_now, MgPrepared& Q) {
     const int nl = (int)H.L.size();
     // pooled arrays: (offset, count) per array; doubles rounded up to even counts (16-B loads)
     std::vector<int32_t>& pi32 = Q.pi32; std::vector<int64_t>& pi64 = Q.pi64;
+    {   // one allocation per pool (the arrays are appended one by one: without the reservation the 10-MB pools are reallocated and copied a dozen times)
+        size_t n32 = A0.size() + M0P.size() + M0.size() + (size_t)((N + MG_BLOCK0 - 1) / MG_BLOCK0) * MG_BLOCK0 * 4 + 64, n64 = 0;
+        for (const pgo_mg::HostLevel& A : H.L) {
+            const size_t tiles = A.tile_agg0.empty() ? 0 : A.tile_agg0.size() - 1;
+            n32 += A.col.size() + A.parent.size() + A.agg_ptr.size() + tiles * (4 + 2 * (size_t)MG_TILE_ROWS) + A.ps_rowptr.size() + A.ps_col.size() + A.w_rowptr.size() + A.w_col.size() + 16;
+            n64 += A.rowptr.size() + A.g_ptr.size() + A.g_ent.size() + A.psT_ptr.size() + A.psT_ent.size();
+        }
+        pi32.reserve(n32); pi64.reserve(n64);
+    }
     auto put32 = [&](const std::vector<int32_t>& v) { const size_t o = pi32.size(); pi32.insert(pi32.end(), v.begin(), v.end()); return o; };
     auto put64 = [&](const std::vector<int64_t>& v) { const size_t o = pi64.size(); pi64.insert(pi64.end(), v.begin(), v.end()); return o; };
     size_t& nf64 = Q.nf64;
@@ -491,6 +504,32 @@ void mg_job_cancel(pgo_problem* p) {
     p->mg_job_running = false; p->mg_job_out.reset();
 }
 
+// the pending hierarchy of a fresh graph build is not wanted any more (the graph is about to change, the handle to go): the worker is waited for, its result dropped, and the
+// graph marked for a rebuild (mg_built was an announcement, not a fact)
+void mg_init_drop(pgo_problem* p) {
+    if (p->mg_init_thread.joinable()) p->mg_init_thread.join();
+    if (p->mg_init_pending) { p->mg_init_pending = false; p->mg_init_out.reset(); p->mg_built = false; p->graph_dirty = true; }
+}
+int build_multigrid(pgo_problem* p, const double* sw_now, MgPrepared* ready);
+// ... or it is needed now: waited for and installed
+int mg_init_finish(pgo_problem* p) {
+    if (!p->mg_init_pending) return PGO_OK;
+    const double t0 = now_s();
+    if (p->mg_init_thread.joinable()) p->mg_init_thread.join();
+    p->mg_init_pending = false;
+    std::unique_ptr<MgPrepared> Q = std::move(p->mg_init_out);
+    if (p->rc_mg_init != PGO_OK || !Q) { p->mg_built = false; return p->rc_mg_init != PGO_OK ? p->rc_mg_init : PGO_ERR_STATE; }
+    const double waited = (now_s() - t0) * 1e3;
+    int rc;
+    HIPCHK(p, hipStreamSynchronize(p->st));
+    if ((rc = build_multigrid(p, nullptr, Q.get())) != PGO_OK) return rc;
+    ++p->build_epoch;
+    if (p->opt.verbosity > 1) std::fprintf(stderr, "[pgo] multigrid: hierarchy of the new graph installed at its first use: host half %.2f ms on a worker thread, waited %.2f ms, installed in %.2f ms%s\n",
+                                           Q->host_ms, waited, (now_s() - t0) * 1e3 - waited, p->mg_built ? "" : " — it does not coarsen: plain block-Jacobi on this graph");
+    p->mg_job_old = std::move(Q);      // (freed off the solve's critical path: regroup_install's note on munmap and the GPU's address space)
+    return PGO_OK;
+}
+
 // The aggregation multigrid's hierarchy for the graph of this handle and the given switch values (host array over the caller's switches, or null): host-side structure
 // (pgo_mg_host.hpp), pooled device arrays, level descriptors.  Called by build_graph, and again when the switch values have moved far from the ones the hierarchy was
 // built with (regroup): the levels above level 1 are matched along the couplings that are alive NOW.  p->mg_cache keeps what does not depend on the switches.
@@ -502,7 +541,7 @@ bool wants_multigrid(const pgo_problem* p) {
     return mg_from > 0 && p->N_global >= mg_from;
 }
 // `ready`: the host half prepared beforehand (build_graph runs it on a worker thread beside its own host work and uploads)
-int build_multigrid(pgo_problem* p, const double* sw_now, MgPrepared* ready = nullptr) {
+int build_multigrid(pgo_problem* p, const double* sw_now, MgPrepared* ready) {
     int rc;
     mg_job_cancel(p);
     p->coarse_built = false; p->coarse_active = false; p->K = CoarseDev{};
@@ -518,6 +557,7 @@ int build_multigrid(pgo_problem* p, const double* sw_now, MgPrepared* ready = nu
 
 int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
     mg_job_cancel(p);      // (a regroup's worker reads the host arrays rebuilt below)
+    mg_init_drop(p);
     double t_phase = now_s();
     auto phase = [&](const char* what) { if (p->opt.verbosity > 1) { const double t = now_s(); std::fprintf(stderr, "[pgo] build_graph: %-34s %7.2f ms\n", what, (t - t_phase) * 1e3); t_phase = t; } };
     // ---- validate against the array sizes the caller solves with
@@ -614,17 +654,17 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
     // One GPU: the HOST half of the multigrid hierarchy (pgo_mg_host.hpp: ~0.1 s for C3, single-threaded sorts and matchings) needs the edge lists and the free flags
     // only, so it runs on a worker thread beside the rest of this function — incident-list upload, matrix-free tile packing, buffer allocation — and is installed where
     // build_multigrid used to compute it.  Nothing here depends on timing: the result is the same hierarchy.  (Several ranks: its host half holds collectives.)
-    std::thread mg_thread;
-    std::unique_ptr<MgPrepared> mg_ready;
-    int rc_mg_thread = PGO_OK;
-    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } mg_joiner{mg_thread};     // every early return below waits for the worker
+    struct Guard { pgo_problem* p; bool committed = false; ~Guard() { if (!committed) mg_init_drop(p); } } mg_guard{p};     // an early return below waits for the worker and drops its result
     p->mg_cache.valid = false;
+    bool mg_async = false;
     if (!p->local_ids && wants_multigrid(p)) {
-        mg_ready.reset(new MgPrepared());
-        MgPrepared* Qp = mg_ready.get();
-        int* rcp = &rc_mg_thread;
-        try { mg_thread = std::thread([p, sw_now, Qp, rcp]() { *rcp = mg_prepare(p, sw_now, *Qp); }); }
-        catch (...) { rc_mg_thread = mg_prepare(p, sw_now, *Qp); }
+        p->mg_init_out.reset(new MgPrepared());
+        p->rc_mg_init = PGO_OK; p->mg_init_pending = true; mg_async = true;
+        MgPrepared* Qp = p->mg_init_out.get();
+        std::vector<double> sw_copy;      // the caller's switch array is only guaranteed to live as long as this call
+        if (sw_now && S > 0) sw_copy.assign(sw_now, sw_now + S);
+        try { p->mg_init_thread = std::thread([p, sw_copy, Qp]() { p->rc_mg_init = mg_prepare(p, sw_copy.empty() ? nullptr : sw_copy.data(), *Qp); }); }
+        catch (...) { p->rc_mg_init = mg_prepare(p, sw_now, *Qp); }
     }
     if ((rc = upload_class(p, p->rel, false, p->d_rc1, p->d_rc2, p->d_sidx /*unused*/, p->d_rmeas, p->d_rwin, G.rel)) != PGO_OK) return rc;
     if ((rc = upload_class(p, p->swe, true, p->d_sc1, p->d_sc2, p->d_sidx, p->d_smeas, p->d_swin, G.sw)) != PGO_OK) return rc;
@@ -826,16 +866,14 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
     // ---- aggregation multigrid for large graphs: hierarchy of graph-following rigid aggregates (pgo_mg_host.hpp), built by build_multigrid() below — which a solve
     // may call again with the current switch values (regroup)
     phase("work buffers");
-    if (mg_thread.joinable()) mg_thread.join();
-    if (rc_mg_thread != PGO_OK) return rc_mg_thread;
-    phase("waited for the hierarchy worker");
-    if ((rc = build_multigrid(p, sw_now, mg_ready.get())) != PGO_OK) return rc;
-    if (mg_ready) {      // (freed off the solve's critical path: regroup_install's note on munmap and the GPU's address space)
-        std::unique_ptr<MgPrepared> old = std::move(p->mg_job_old);
-        p->mg_job_old = std::move(mg_ready);
-        if (p->opt.verbosity > 1) std::fprintf(stderr, "[pgo] build_graph: hierarchy host half %.2f ms on a worker thread\n", p->mg_job_old->host_ms);
-    }
-    phase("multigrid hierarchy (install)");
+    if (mg_async) {
+        // not waited for here: installed where it is first needed (mg_init_finish).  What build_multigrid would have reset:
+        mg_job_cancel(p);
+        p->coarse_built = false; p->coarse_active = false; p->K = CoarseDev{};
+        p->mg_active = false; p->M = MgDev{}; p->mg_geometry_epoch = 0; p->mg_sw_built.clear();
+        p->mg_built = true;      // announced; mg_init_finish corrects it should the graph not coarsen
+    } else if ((rc = build_multigrid(p, sw_now, nullptr)) != PGO_OK) return rc;
+    phase("multigrid hierarchy");
     if (p->mg_built && p->built_mf) { HIPCHK(p, p->d_Hoff.ensure((size_t)(p->G.rel.Epad + p->G.sw.Epad) * 36)); p->L.Hoff = p->d_Hoff.p; }      // the multigrid's level-1 product reads J1^T J2 per edge
     p->hoff_epoch = 0;
     if (!p->mg_built) {      // (a graph that got the multigrid never uses the two-level method: its dense operator would be built and uploaded for nothing)
@@ -890,6 +928,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
         }
     }
     phase("two-level aggregates");
+    mg_guard.committed = true;
     p->graph_dirty = false; p->priors_dirty = false;
     ++p->build_epoch;   // invalidates the captured PCG graph (kernel arguments hold device pointers / sizes)
     return PGO_OK;
@@ -1444,6 +1483,8 @@ static int regroup_install(pgo_problem* p) {
 static int build_mg(pgo_problem* p) {
     p->mg_active = false;
     if (!p->mg_built) return PGO_OK;
+    { int rci; if ((rci = mg_init_finish(p)) != PGO_OK) return rci; }      // the hierarchy of a fresh graph build is installed where it is first needed
+    if (!p->mg_built) return PGO_OK;
     const double t_build0 = now_s();
     { int rcr; if ((rcr = p->local_ids ? maybe_regroup(p) : regroup_install(p)) != PGO_OK) return rcr; }
     if (!p->mg_built) return PGO_OK;
@@ -1567,8 +1608,10 @@ int solve_begin(pgo_problem* p, const double* quat, const double* t, const doubl
     if ((rc = set_device(p)) != PGO_OK) return rc;
     p->t_begin = now_s();
     mg_job_cancel(p);
-    if (p->graph_dirty || p->priors_dirty || N != p->N_global || S != p->S) { if ((rc = build_graph(p, N, S, sw)) != PGO_OK) return rc; }
-    else if (p->opt.mg_regroup_fraction > 0.0 && p->mg_built && S > 0 && sw && (int64_t)p->mg_sw_built.size() == p->swe.size()) {
+    const bool rebuild = p->graph_dirty || p->priors_dirty || N != p->N_global || S != p->S;
+    if (rebuild) { if ((rc = build_graph(p, N, S, sw)) != PGO_OK) return rc; }
+    else if ((rc = mg_init_finish(p)) != PGO_OK) return rc;      // (an unchanged graph whose hierarchy no solve has needed yet: installed, then compared with this solve's start values)
+    if (!rebuild && p->opt.mg_regroup_fraction > 0.0 && p->mg_built && S > 0 && sw && (int64_t)p->mg_sw_built.size() == p->swe.size()) {
         // the hierarchy of an unchanged graph was built (or regrouped inside the last solve) for other switch values than this solve starts from: the levels above level 1
         // follow the start — a session's next trigger (switches as the last solve left them) keeps it, a re-solve from the original guess gets the original one back,
         // so repeated solves from the same state stay bitwise identical
@@ -1860,6 +1903,7 @@ int solve_end(pgo_problem* p, double* quat, double* t, double* sw, pgo_summary* 
     if (p->coarse_mode == 2 && !p->coarse_skip_all) { p->coarse_backoff = std::min(2 * p->coarse_backoff + 1, 15); p->coarse_skip = p->coarse_backoff; }
     if (p->coarse_mode == 1) ++p->coarse_keep_streak; else if (p->coarse_mode == 2 && !p->coarse_skip_all) p->coarse_keep_streak = 0;
     mg_job_cancel(p);      // a regroup nobody needed any more: dropped (the hierarchy in place keeps its own switch record)
+    if ((rc = mg_init_finish(p)) != PGO_OK) return rc;      // a fresh graph's hierarchy that this solve never needed: installed now, for the handle's next solves
     p->sum.seconds_total = now_s() - p->t_begin;
     if (out) *out = p->sum;
     p->in_solve = false;
@@ -1870,6 +1914,7 @@ int add_edges(pgo_problem* p, HostClass& H, int64_t n, const int32_t* c1, const 
     if (n < 0 || (n > 0 && (!c1 || !c2 || !T))) { p->err = "null edge array"; return PGO_ERR_INVALID_ARG; }
     for (int64_t k = 0; k < n; ++k) if (c1[k] < 0 || c2[k] < 0 || c1[k] == c2[k] || (sw && sw[k] < 0)) { p->err = "negative index or self edge"; return PGO_ERR_INVALID_ARG; }
     mg_job_cancel(p);      // (the worker reads the edge lists)
+    mg_init_drop(p);
     const size_t base = H.c1.size();
     H.c1.insert(H.c1.end(), c1, c1 + n);
     H.c2.insert(H.c2.end(), c2, c2 + n);
@@ -1982,6 +2027,7 @@ int pgo_create(pgo_problem** out, const pgo_options* opts) {
 int pgo_destroy(pgo_problem* p) {
     if (!p) return PGO_ERR_INVALID_ARG;
     mg_job_cancel(p);
+    mg_init_drop(p);
     (void)hipSetDevice(p->device);
     if (p->comm && p->nccl.CommDestroy) p->nccl.CommDestroy(p->comm);
     (void)hipStreamSynchronize(p->st);
@@ -2010,6 +2056,7 @@ int pgo_set_options(pgo_problem* p, const pgo_options* o) {
     if (!p || !o) return PGO_ERR_INVALID_ARG;
     const int dev = p->opt.device_id;
     mg_job_cancel(p);
+    mg_init_drop(p);
     if (o->linear_solver != p->opt.linear_solver) p->graph_dirty = true;
     // the preconditioner hierarchies are part of the device graph build
     if (o->mg_min_keyframes != p->opt.mg_min_keyframes || o->mg_min_keyframes_switchable != p->opt.mg_min_keyframes_switchable || o->mg_first_passes != p->opt.mg_first_passes || o->mg_passes != p->opt.mg_passes ||
@@ -2048,6 +2095,7 @@ int pgo_set_node_regularizers(pgo_problem* p, int64_t n, const int32_t* node, co
         P.w = weight[k]; P.node = node[k]; P.pad_ = 0;
     }
     mg_job_cancel(p);
+    mg_init_drop(p);
     p->priors.swap(v);
     p->priors_dirty = true;
     return PGO_OK;
@@ -2056,6 +2104,7 @@ int pgo_set_nodes_constant(pgo_problem* p, int64_t n, const int32_t* node) {
     if (!p || n < 0 || (n > 0 && !node)) return PGO_ERR_INVALID_ARG;
     for (int64_t k = 0; k < n; ++k) if (node[k] < 0) return PGO_ERR_INVALID_ARG;
     mg_job_cancel(p);      // (the worker reads h_node_free / constant_nodes)
+    mg_init_drop(p);
     p->constant_nodes.insert(p->constant_nodes.end(), node, node + n);
     p->graph_dirty = true;
     return PGO_OK;
@@ -2086,6 +2135,7 @@ int pgo_add_odometry_edges_from_vio(pgo_problem* p, const int32_t* set_id, int64
     if (u_end > p->n_vio) { p->err = "odometry edges requested beyond the resident VIO poses"; return PGO_ERR_INVALID_ARG; }
     if (p->in_solve) { p->err = "graph construction inside a solve"; return PGO_ERR_STATE; }
     mg_job_cancel(p);      // (a regroup's worker left behind by a failed solve reads the edge lists)
+    mg_init_drop(p);
     std::vector<int32_t> c1, c2;
     c1.reserve((size_t)(u_end - u_begin) * f_max); c2.reserve(c1.capacity());
     for (int64_t u = u_begin; u < u_end; ++u)
@@ -2163,6 +2213,7 @@ int pgo_solve_begin(pgo_problem* p, const double* q, const double* t, const doub
 // a failed step or write-back: no regroup worker outlives it (it reads host arrays the caller may change next), and a stream capture a failing launch left open is ended
 static void after_failure(pgo_problem* p) {
     mg_job_cancel(p);
+    mg_init_drop(p);
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (p->st && hipStreamIsCapturing(p->st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(p->st, &g); if (g) (void)hipGraphDestroy(g); p->cg_graph_failed = true; }
     (void)hipGetLastError();
@@ -2342,12 +2393,14 @@ int pgo_comm_init(pgo_problem* p, int32_t rank, int32_t world, const uint8_t id[
     void* comm = nullptr;
     const int nrc = p->nccl.CommInitRank(&comm, world, u, rank);
     if (nrc != 0) { p->err = std::string("ncclCommInitRank: ") + (p->nccl.GetErrorString ? p->nccl.GetErrorString(nrc) : "error"); return PGO_ERR_COMM; }
+    mg_job_cancel(p); mg_init_drop(p);
     p->comm = comm; p->rank = rank; p->world = world;
     p->graph_dirty = true;   // keyframe participation is the union over ranks
     return PGO_OK;
 }
 int pgo_comm_init_custom(pgo_problem* p, int32_t rank, int32_t world, pgo_allreduce_fn fn, void* ctx) {
     if (!p || !fn || world < 1 || rank < 0 || rank >= world) return PGO_ERR_INVALID_ARG;
+    mg_job_cancel(p); mg_init_drop(p);
     p->custom_allreduce = fn; p->custom_ctx = ctx; p->rank = rank; p->world = world;
     p->graph_dirty = true;
     return PGO_OK;
@@ -2356,6 +2409,7 @@ int pgo_comm_destroy(pgo_problem* p) {
     if (!p) return PGO_ERR_INVALID_ARG;
     p->custom_allreduce = nullptr; p->custom_ctx = nullptr;
     if (p->comm && p->nccl.CommDestroy) { (void)hipStreamSynchronize(p->st); p->nccl.CommDestroy(p->comm); }
+    mg_job_cancel(p); mg_init_drop(p);
     p->comm = nullptr; p->rank = 0; p->world = 1;
     p->graph_dirty = true;
     return PGO_OK;
@@ -2582,6 +2636,7 @@ int pgo_device_synchronize(pgo_problem* p) {
     if (!p) return PGO_ERR_INVALID_ARG;
     int rc;
     if ((rc = set_device(p)) != PGO_OK) return rc;
+    if ((rc = mg_init_finish(p)) != PGO_OK) return rc;      // "everything this handle has in flight": the hierarchy worker of a fresh graph build too
     HIPCHK(p, hipStreamSynchronize(p->st));
     return PGO_OK;
 }
