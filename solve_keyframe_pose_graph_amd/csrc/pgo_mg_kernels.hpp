@@ -61,6 +61,8 @@ __device__ __forceinline__ void mg_row_accumulate_f32(int64_t b, int64_t e, cons
 // (Measured and dropped in round 4: a 32-B slot descriptor carrying the block range AND the column indices of the group's first six blocks, so that the x gathers are issued with
 // the block loads — one dependent round trip less per level kernel on paper; on C3 the multigrid PCG iteration went 133 -> 142 us, with predicated and with branch-free loads alike:
 // six blocks' loads in flight per lane cost more than the round trip they save.)
+// (A third variant — the first chunk's column indices requested before the kernel's other operands, so that the x gathers do not queue behind operand loads that miss to HBM —
+// lost the same 7 us per iteration as the two above.)
 #define MG_ROW_PRODUCT(tile_, xvec_) do { if (rowlive) { int kb, ke; mg_split_row(rb, sg, A.seg_shift, kb, ke); mg_row_accumulate_f32(kb, ke, A.col, A.valf, xvec_, c, acc); } } while (0)
 // Row products of the level kernels.  192 lanes = 32 (row, lane-group) slots x 6 columns.  With seg_shift = 0 a slot is a row; with seg_shift = s the tile holds
 // R = 32 >> s rows and 2^s lane groups share each row, group g streaming the g-th part of its blocks (long rows: Galerkin products of smoothed transitions).
