@@ -7,6 +7,7 @@ export TMPDIR=/tmp
 OUT=gpurun_out/r04_final
 PM=gpurun_out/r04_final/pmc
 mkdir -p gpurun_out/r04_final/pmc
+python -c "from solve_keyframe_pose_graph_amd import _build; _build.build_libpgo(); _build.build_host(); _build.build_graphgen()"   # (the snapshot's file times can make the shipped library look stale: whatever the loader would rebuild is rebuilt NOW, before the sha is taken)
 SHA=$(sha256sum solve_keyframe_pose_graph_amd/libpgo.so | cut -d' ' -f1)
 echo $SHA > $OUT/libpgo_sha256.txt
 stamp() { sed -i "1i # libpgo.so sha256 $SHA" "$1"; }

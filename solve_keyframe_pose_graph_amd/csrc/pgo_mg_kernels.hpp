@@ -47,8 +47,48 @@ __device__ __forceinline__ void mg_chunk_f32(const int32_t* __restrict__ colp, c
         acc[3] += (double)v[u][1].y * xx[u]; acc[4] += (double)v[u][2].x * xx[u]; acc[5] += (double)v[u][2].y * xx[u];
     }
 }
+#ifndef PGO_MG_NARROW
+// Round 4: the six lanes of a (row, lane group) slot split the part's blocks like this — lane (h, j) = (c / 3, c % 3) takes every second block (h) and
+// the column PAIR j of it: three 16-B loads of the fp32 block (in the row-pair-major layout the four entries (rows 2p, 2p+1) x (columns 2j, 2j+1) are one aligned float4) and one 16-B
+// load of x, instead of (before: -DPGO_MG_NARROW) one lane per column with three 8-B loads and one 8-B gather per block.  Same bytes, half the memory instructions per lane: the level
+// kernels are bound by the issue rate of their scattered loads (one texture-address unit per CU serves ~11 wavefronts of a level kernel), not by the col -> x dependency — three
+// variants that requested column indices earlier all LOST 7 us per iteration, this one gains: level kernels 93.3 -> 88.5 us per cycle on C3, 138.6 -> 127.4 us on C4 (20 LM steps
+// 1.37 -> 1.30 s), measured by A/B inside one call.  Every lane still ends with partial sums for all six rows, so the gather through LDS is unchanged.
+template <int U>
+__device__ __forceinline__ void mg_chunk_f32_wide(const int32_t* __restrict__ colp, const float* __restrict__ valp, int j, const double* __restrict__ x, double* acc) {
+    int32_t col[U];
+    float4 v[U][3];
+    double2 xx[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) col[u] = colp[2 * u];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const float4* vp = reinterpret_cast<const float4*>(valp + (size_t)(2 * u) * 36) + j;
+        v[u][0] = vp[0]; v[u][1] = vp[3]; v[u][2] = vp[6];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) xx[u] = reinterpret_cast<const double2*>(x + (size_t)col[u] * 6)[j];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            acc[2 * p] += (double)v[u][p].x * xx[u].x + (double)v[u][p].z * xx[u].y;
+            acc[2 * p + 1] += (double)v[u][p].y * xx[u].x + (double)v[u][p].w * xx[u].y;
+        }
+    }
+}
+#endif
 __device__ __forceinline__ void mg_row_accumulate_f32(int64_t b, int64_t e, const int32_t* __restrict__ col, const float* __restrict__ val,
                                                       const double* __restrict__ x, int c, double* acc) {
+#ifndef PGO_MG_NARROW
+    {
+        const int h = c >= 3 ? 1 : 0, j = c - 3 * h;
+        int64_t kw = b + h;                                         // this lane's blocks: b + h, b + h + 2, ...
+        for (; kw + 2 < e; kw += 4) mg_chunk_f32_wide<2>(col + kw, val + (size_t)kw * 36, j, x, acc);
+        if (kw < e) mg_chunk_f32_wide<1>(col + kw, val + (size_t)kw * 36, j, x, acc);
+        return;
+    }
+#endif
     int64_t k = b;
 // (Also measured and dropped: the part's column indices requested together ahead of the unchanged chunks — 127 -> 135 us per multigrid iteration on C3, 229 -> 237 on C4.  Every
     // variant that puts more memory instructions in flight per lane loses: these kernels are bound by the issue rate of their scattered 8-byte gathers, not by the col -> x chain.)
