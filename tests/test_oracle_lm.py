@@ -123,3 +123,20 @@ def test_ten_iteration_budget_and_termination_types():
     assert sm.termination_type == 0
     costs = [sm.iterations[k].cost for k in range(sm.num_logged)]
     assert all(b <= a * (1 + 1e-12) for a, b in zip(costs, costs[1:]))
+
+
+def test_the_full_size_exact_cholesky_run_agrees_with_the_c3_golden():
+    """Two independent CPU computations of the first LM iterations on the FULL C3 graph: the oracle with its exact block Cholesky (one measured run per round, 2.4 CPU-hours:
+    scripts/cpu_c3_full.py -> profiles/r04_cpu_c3_full.json) and the golden trajectory (oracle Jacobians, scipy CG to 1e-12, Python restatement of the Ceres loop:
+    tests/golden/c3_ten_iterations.json).  Same decisions, costs equal to 1e-9 relative: the anchor the GPU suite compares with is not an artefact of its iterative solver."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "profiles", "r04_cpu_c3_full.json")) as f:
+        full = json.load(f)
+    with open(os.path.join(root, "tests", "golden", "c3_ten_iterations.json")) as f:
+        gold = json.load(f)
+    assert full["n_poses"] == gold["n_poses"] and full["n_edges"] == gold["n_edges"] and full["lm_iterations"] >= 3
+    for a, b in zip(full["iterations"], gold["iterations"]):
+        assert a["successful"] == b["successful"]
+        assert abs(a["cost"] - b["cost"]) <= 1e-9 * b["cost"], (a, b)
