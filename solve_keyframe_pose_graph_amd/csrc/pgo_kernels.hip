@@ -11,6 +11,17 @@
 
 namespace pgo {
 
+// A wavefront's index in the grid / in its workgroup as a value the compiler KNOWS to be wave-uniform (an SGPR): everything indexed with it — list bounds, list entries, edge
+// endpoints, offsets — is then read by scalar loads instead of 64 identical vector loads.  The one-wavefront-per-block set-up kernels (Galerkin products, Ps / W / Ps^T W, the two-level
+// assembly) walk per-block lists whose every entry costs several such reads; as vector loads they queue in the CU's one texture-address unit (round 4: mg_galerkin0 637 us -> see DESIGN.md).
+#ifndef PGO_NO_UNIFORM
+__device__ __forceinline__ int wave_in_grid() { return __builtin_amdgcn_readfirstlane((int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6)); }
+__device__ __forceinline__ int wave_in_block() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+#else      // A/B aid (variant build): the plain expressions, which the compiler must treat as per-lane values
+__device__ __forceinline__ int wave_in_grid() { return (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6); }
+__device__ __forceinline__ int wave_in_block() { return (int)(threadIdx.x >> 6); }
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // reductions (fixed-shape trees: results are bitwise reproducible run to run)
 // ------------------------------------------------------------------------------------------------
@@ -174,7 +185,7 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_edges_kernel(EdgeClassDev re
                                                                   const double* __restrict__ swv, double* __restrict__ partials) {
     __shared__ __attribute__((aligned(16))) char lds_win[K1_WAVES * 2 * WIN_MAX * WIN_STRIDE];
     __shared__ double red[K1_WAVES];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;     // (NOT wave_in_block(): with a wave-uniform tile class the compiler keeps both residual paths' registers apart — 160 -> 200 VGPRs, 2 waves/SIMD)
     const int tile_g = blockIdx.x * K1_WAVES + wave;
     const bool active = tile_g < rel.tiles + sw.tiles;
     const bool is_sw = tile_g >= rel.tiles;
@@ -1843,7 +1854,7 @@ __device__ __forceinline__ double wave_bcast0(double v) { return __shfl(v, 0, 64
 
 // one wavefront per aggregate: centroid of its free keyframes, then d_i = t_i - centroid for every member
 __global__ __launch_bounds__(256) void coarse_geometry_kernel(GraphDev G, CoarseDev K, const double* __restrict__ pose8) {
-    const int a = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int a = wave_in_grid();
     const int lane = threadIdx.x & 63;
     if (a >= K.n_agg) return;
     const int64_t i0 = (int64_t)a * K.m, i1 = i0 + K.m < G.N ? i0 + K.m : G.N;
@@ -1896,8 +1907,8 @@ __device__ __forceinline__ double coarse_entry(const double* H, const double* di
 // (C.Dtot: J^T J + damping - switch Schur terms + regularisers) and, per edge, J1^T J2 - c1 c2^T / a recomputed from K1's Jacobians.
 __global__ __launch_bounds__(256) void coarse_assemble_kernel(GraphDev G, LinDev L, ScaleDev Sc, CgDev C, CoarseDev K) {
     __shared__ double Hs[4][36];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int blk = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int wv = wave_in_block(), lane = threadIdx.x & 63;
+    const int blk = wave_in_grid();
     if (blk >= K.n_blk) return;                       // whole wavefronts leave together; no workgroup barrier below
     const int a = K.blk_ab[blk * 2], b = K.blk_ab[blk * 2 + 1];
     const int r = lane / 6, c = lane - r * 6;
@@ -1995,7 +2006,7 @@ void launch_coarse_symmetrize(const CoarseDev& K, hipStream_t st) {
 // rc = P^T r: one wavefront per aggregate;  B_i^T r_i = [r_theta + 2 d_i x r_t ; r_t]
 __global__ __launch_bounds__(256) void coarse_restrict_kernel(GraphDev G, CoarseDev K, const double* __restrict__ rv, const int32_t* __restrict__ stop) {
     if (stop && *stop) return;   // a stopped PCG keeps z and its partial sums (it may be resumed)
-    const int a = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int a = wave_in_grid();
     const int lane = threadIdx.x & 63;
     if (a >= K.n_agg) return;
     const int64_t i0 = (int64_t)a * K.m, i1 = i0 + K.m < G.N ? i0 + K.m : G.N;
@@ -2019,7 +2030,7 @@ __global__ __launch_bounds__(256) void coarse_restrict_kernel(GraphDev G, Coarse
 // yc = Ac^-1 rc: one wavefront per row of the dense inverse
 __global__ __launch_bounds__(256) void coarse_solve_kernel(CoarseDev K, const int32_t* __restrict__ stop) {
     if (stop && *stop) return;
-    const int row = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int row = wave_in_grid();
     const int lane = threadIdx.x & 63;
     if (row >= K.nc) return;
     const double s = wave_sum(dense_row_dot(K.Acf + (size_t)row * K.nc, K.rc, K.nc, lane));

@@ -127,7 +127,7 @@ __device__ __forceinline__ double mg_gather_row(const double* __restrict__ xch, 
 // triangle.  One wavefront per BLOCK (the smoothed Galerkin products have ~50 blocks per row: a wavefront per row ran 0.37 ms on C3's level 2); lane l < 36 owns
 // element l of the block (column-pair-major: (row, col) at (row/2)*12 + col*2 + (row&1)).
 __global__ __launch_bounds__(256) void mg_val_f32_kernel(MgLevelDev A) {
-    const int64_t k = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t k = wave_in_grid();
     const int lane = threadIdx.x & 63;
     if (k >= A.nnzb || lane >= 36) return;
     int lo = 0, hi = A.n;                            // the block's row: rowptr ascending
@@ -264,8 +264,8 @@ __device__ __forceinline__ double mg_fine_block(const GraphDev& G, const LinDev&
 template <bool HOFF>
 __global__ __launch_bounds__(256) void mg_galerkin0_kernel(GraphDev G, LinDev L, ScaleDev Sc, CgDev C, MgDev M, MgLevelDev A) {
     __shared__ double Hs[4][2][36];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t slot = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int wv = wave_in_block(), lane = threadIdx.x & 63;
+    const int64_t slot = wave_in_grid();
     if (slot >= A.nnzb) return;
     const int r = lane / 6, c = lane - r * 6;
     const bool own = lane < 36;
@@ -297,8 +297,8 @@ __global__ __launch_bounds__(256) void mg_galerkin0_kernel(GraphDev G, LinDev L,
 // level l+1 (B) from level l (A): contributions are blocks of A, entry = (row << 32) | slot
 __global__ __launch_bounds__(256) void mg_galerkin_kernel(MgLevelDev A, MgLevelDev B) {
     __shared__ double Hs[4][36];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t slot = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int wv = wave_in_block(), lane = threadIdx.x & 63;
+    const int64_t slot = wave_in_grid();
     if (slot >= B.nnzb) return;
     const int r = lane / 6, c = lane - r * 6;
     const bool own = lane < 36;
@@ -384,8 +384,8 @@ __device__ __forceinline__ double mg_pblock(const double* __restrict__ d, int r,
 // one wavefront per block (i, a) of Ps; lane l < 36 owns element (l / 6, l % 6).  Row i of A is short: its blocks are scanned for columns whose parent is a.
 __global__ __launch_bounds__(256) void mg_ps_kernel(MgLevelDev A, double cs) {
     __shared__ double acc_s[4][36];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t slot = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int wv = wave_in_block(), lane = threadIdx.x & 63;
+    const int64_t slot = wave_in_grid();
     if (slot >= A.n_ps) return;
     const bool own = lane < 36;
     const int r = own ? lane / 6 : 0, c = own ? lane % 6 : 0;
@@ -419,8 +419,8 @@ __global__ __launch_bounds__(256) void mg_ps_kernel(MgLevelDev A, double cs) {
 constexpr int MG_SETUP_CHUNK = 8;
 __global__ __launch_bounds__(256) void mg_w_kernel(MgLevelDev A) {
     __shared__ double pb[4][MG_SETUP_CHUNK][36], ab[4][MG_SETUP_CHUNK][36];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t slot = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int wv = wave_in_block(), lane = threadIdx.x & 63;
+    const int64_t slot = wave_in_grid();
     if (slot >= A.n_w) return;
     const bool own = lane < 36;
     const int r = own ? lane / 6 : 0, c = own ? lane % 6 : 0;
@@ -469,8 +469,8 @@ __global__ __launch_bounds__(256) void mg_w_kernel(MgLevelDev A) {
 // searched by ballot -> the two blocks) issued for the whole chunk at once, the products added in list order (same bits as the entry-at-a-time loop)
 __global__ __launch_bounds__(256) void mg_psTw_kernel(MgLevelDev A, MgLevelDev B) {
     __shared__ double pa[4][MG_SETUP_CHUNK][36], wb[4][MG_SETUP_CHUNK][36];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t slot = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int wv = wave_in_block(), lane = threadIdx.x & 63;
+    const int64_t slot = wave_in_grid();
     if (slot >= B.nnzb) return;
     const bool own = lane < 36;
     const int r = own ? lane / 6 : 0, c = own ? lane % 6 : 0;
