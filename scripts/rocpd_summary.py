@@ -2,6 +2,7 @@
 """Summarises rocprofv3 rocpd (.db) outputs into the text/JSON files committed under profiles/.
   kernel stats:  python scripts/rocpd_summary.py stats  <trace.db>  > profiles/<name>_kernel_stats.txt
   PMC:           python scripts/rocpd_summary.py pmc <pmc.db> <COUNTER> [kernel-substring]
+  gaps:          python scripts/rocpd_summary.py gaps <trace.db>      (device idle time between consecutive kernels, by the kernel that follows the gap)
 """
 import json
 import sqlite3
@@ -42,8 +43,38 @@ def pmc(db, counter, sub=None):
     print(json.dumps(res, indent=1))
 
 
+def gaps(db):
+    con = sqlite3.connect(db)
+    cur = con.cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+    name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
+    rows = cur.execute("select %s, start, end from kernels order by start" % name_col).fetchall()
+    if not rows:
+        print("no kernels")
+        return
+    short = lambda n: n.replace("pgo::", "").replace("void ", "").split("(")[0][:44]
+    busy = sum(r[2] - r[1] for r in rows)
+    span = rows[-1][2] - rows[0][1]
+    by = {}
+    prev_end = rows[0][2]
+    for name, st, en in rows[1:]:
+        g = max(0, st - prev_end)
+        d = by.setdefault(short(name), [0, 0, 0, 0, 0, 0])
+        d[0] += 1; d[1] += g; d[2] = max(d[2], g); d[3] += en - st
+        if en - st < 3000:      # early exits of a stopped PCG (and other launches at the floor): what they hold the stream for
+            d[4] += 1; d[5] += (en - st) + min(g, 3000)
+        prev_end = max(prev_end, en)
+    print("%d kernels, first start to last end %.3f ms, busy %.3f ms, idle %.3f ms" % (len(rows), span / 1e6, busy / 1e6, (span - busy) / 1e6))
+    print("%-46s %7s %12s %10s %10s %12s %9s %14s" % ("kernel that follows the gap", "calls", "idle_total_us", "mean_us", "max_us", "busy_total_us", "under_3us", "their_span_us"))
+    for k, d in sorted(by.items(), key=lambda kv: -kv[1][1]):
+        print("%-46s %7d %12.1f %10.2f %10.1f %12.1f %9d %14.1f" % (k, d[0], d[1] / 1e3, d[1] / 1e3 / d[0], d[2] / 1e3, d[3] / 1e3, d[4], d[5] / 1e3))
+    print("launches under 3 us: %d, holding the stream for %.3f ms in all" % (sum(d[4] for d in by.values()), sum(d[5] for d in by.values()) / 1e6))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2])
+    elif sys.argv[1] == "gaps":
+        gaps(sys.argv[2])
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else None)

@@ -198,6 +198,7 @@ void launch_cg_init(const GraphDev& G, const CgDev& C, int warm /*x holds a prev
 int launch_cg_init_vectors(const GraphDev& G, const CgDev& C, int warm, hipStream_t st);
 void launch_cg_init_scalars(const CgDev& C, int nparts, int nparts_bb, double tol2, hipStream_t st);   // scal[0] = b.M^-1 b, scal[1] = r.z from the partial sums; flags reset
 void launch_cg_set_tolerance(const CgDev& C, double tol2, hipStream_t st);
+void launch_cg_poll(const CgDev& C, int32_t* host_flags, double* host_scal, hipStream_t st);      // host_*: pinned, device-accessible
 void launch_cg_spmv(const GraphDev& G, const CgDev& C, int k, double tol2, hipStream_t st);   // iteration k: direction + matvec (+ convergence test)
 void launch_cg_update(const GraphDev& G, const CgDev& C, int k, int n_pq_partials, hipStream_t st);
 int cg_grid_size(const GraphDev& G);

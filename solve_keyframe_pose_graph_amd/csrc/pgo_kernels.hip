@@ -1193,6 +1193,12 @@ __global__ void cg_set_tolerance_kernel(CgDev C, double tol2) {
     if (threadIdx.x == 0 && blockIdx.x == 0) { C.scal[3] = tol2; if (!C.flags[1]) C.flags[0] = 0; }
 }
 void launch_cg_set_tolerance(const CgDev& C, double tol2, hipStream_t st) { hipLaunchKernelGGL(cg_set_tolerance_kernel, dim3(1), dim3(64), 0, st, C, tol2); }
+// the host's view of a PCG chunk: {stopped, breakdown, iterations} and {reference norm, r.z, -} written straight into a pinned host slot (one launch at the
+// floor instead of two blit copies)
+__global__ void cg_poll_kernel(CgDev C, int32_t* __restrict__ hflags, double* __restrict__ hscal) {
+    if (threadIdx.x < 3) { hflags[threadIdx.x] = C.flags[threadIdx.x]; hscal[threadIdx.x] = C.scal[threadIdx.x]; }
+}
+void launch_cg_poll(const CgDev& C, int32_t* host_flags, double* host_scal, hipStream_t st) { hipLaunchKernelGGL(cg_poll_kernel, dim3(1), dim3(64), 0, st, C, host_flags, host_scal); }
 
 void launch_cg_init(const GraphDev& G, const CgDev& C, int warm, double tol2, hipStream_t st) {
     const int g = cg_grid(G);

@@ -518,7 +518,8 @@ inline bool build_hierarchy(int64_t N, const std::vector<uint8_t>& node_free, co
         // flight at once.  Measured, 20 LM steps, C3 / C4: <= 14 blocks per group and at most 4 groups (the first rule) 0.315 / 1.505 s; <= 10: 0.298 / 1.436; <= 7: 0.298 / 1.442;
         // <= 5: 0.291 / 1.417; <= 3.5: 0.290 / 1.471; <= 2.5: 0.299 / 1.468
         Lv.seg = 1;
-        while (Lv.seg < 8 && mean_row > 5.0 * Lv.seg) Lv.seg *= 2;
+        static const double blocks_per_group = []() { const char* e = std::getenv("PGO_DEBUG_SEG_BLOCKS"); const double v = e ? std::atof(e) : 0.0; return v > 0.0 ? v : 5.0; }();   // (debug override for scans)
+        while (Lv.seg < 8 && mean_row > blocks_per_group * Lv.seg) Lv.seg *= 2;
         while (Lv.seg > 1 && tile_rows / Lv.seg < max_agg) Lv.seg /= 2;         // an aggregate never straddles tiles
         const int cap = tile_rows / Lv.seg;
         Lv.tile_agg0.clear();

@@ -1200,7 +1200,7 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
     // Capture + instantiation cost about a millisecond: a PCG pays it only once it has run `graph_after` iterations eagerly (a graph that is rebuilt for every
     // solve — the reference's sessions: one new loop edge, one solve — and converges in a few hundred iterations never does; eager launches keep up with
     // 5-8 us kernels: measured 18.5 vs 19.4 ms at 300 keyframes, 64.0 vs 64.6 ms at 3000)
-    const int graph_after = 192;
+    static const int graph_after = []() { const char* e = std::getenv("PGO_DEBUG_GRAPH_AFTER"); return e ? std::atoi(e) : 192; }();
     auto ensure_graph = [&](bool may_capture) {
         const int mode = p->mg_active ? 2 : p->coarse_active ? 1 : 0;
         pgo_problem::CapturedChunk& cc = p->cg_chunk[mode];
@@ -1228,8 +1228,12 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
     int ex_k0 = -1; double ex_rz0 = 0.0;      // first polled (iteration, r.z) of this run: base of the convergence-rate estimate
     bool done = false;
     auto enqueue_poll = [&](int slot) -> int {
+#ifdef PGO_POLL_BY_COPY
         HIPCHK(p, hipMemcpyAsync(p->poll[slot].flags, p->C.flags, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, p->st));
         HIPCHK(p, hipMemcpyAsync(p->poll[slot].scal, p->C.scal, 3 * sizeof(double), hipMemcpyDeviceToHost, p->st));
+#else
+        launch_cg_poll(p->C, p->poll[slot].flags, p->poll[slot].scal, p->st);
+#endif
         HIPCHK(p, hipEventRecord(p->poll_ev[slot], p->st));
         return PGO_OK;
     };
@@ -1344,6 +1348,7 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
 // (blocked Gauss-Jordan kernels).  A coarse operator that is not numerically positive definite leaves the coarse space off for this iteration.
 static int build_coarse(pgo_problem* p) {
     p->coarse_active = false;
+    const double t_coarse0 = now_s();
     // Where it pays: always when the aggregates are small (the coarse space is then a sizeable fraction of the problem: graphs up to
     // ~64 x coarse_aggregates keyframes), otherwise only at large trust regions, where the slow modes are the long wavelengths
     // (measured: scripts/gpu_coarse_ab.py).
@@ -1368,6 +1373,7 @@ static int build_coarse(pgo_problem* p) {
     HIPCHK(p, hipMemcpyAsync(&h, fail, sizeof(h), hipMemcpyDeviceToHost, p->st));
     HIPCHK(p, hipStreamSynchronize(p->st));
     p->coarse_active = h == 0;
+    if (p->opt.verbosity > 1) std::fprintf(stderr, "[pgo] coarse operator assembled and inverted in %.3f ms (since the start of build_coarse)\n", (now_s() - t_coarse0) * 1e3);
     if (p->opt.verbosity > 0) std::fprintf(stderr, "[pgo] coarse space: %d aggregates of %d keyframes, %d blocks, radius %.1e: %s\n", p->K.n_agg, p->K.m, p->K.n_blk, p->radius, h == 0 ? "on" : "coarse operator not positive definite -> off");
     return PGO_OK;
 }
@@ -1670,6 +1676,7 @@ int lm_step(pgo_problem* p, int ignore_termination, int* done) {
     if (!p->reuse_diagonal) launch_lm_diag(p->G, p->L, p->Sc, o.min_lm_diagonal, o.max_lm_diagonal, p->st);
     bool ok = true;
     if ((rc = build_system(p, &ok)) != PGO_OK) return rc;
+    const double t_built = now_s();
     int why_invalid = ok ? PGO_STEP_ACCEPTED : PGO_STEP_INVALID_FACTORIZATION;      // pgo_iteration.reason of an invalid step
     int precond_used = PGO_PRECOND_BLOCK_JACOBI;
     CgResult cg{0, false, 0.0, false};
@@ -1778,11 +1785,13 @@ int lm_step(pgo_problem* p, int ignore_termination, int* done) {
         }
     }
     it.cg_iterations = cg.iterations + p->cg_extra; it.cg_residual = cg.rel_residual;
-    if (o.verbosity > 1) std::fprintf(stderr, "[pgo] it %3d PCG: %d iterations%s after %d with block-Jacobi, linear solve %.2f ms so far\n", p->iteration, cg.iterations, p->mg_active ? " with the multigrid" : "", p->cg_extra, (now_s() - t0) * 1e3);
+    const double t_solved = now_s();
+    if (o.verbosity > 1) std::fprintf(stderr, "[pgo] it %3d PCG: %d iterations%s after %d with block-Jacobi; system + preconditioner %.3f ms, PCG %.3f ms\n", p->iteration, cg.iterations, p->mg_active ? " with the multigrid" : "", p->cg_extra, (t_built - t0) * 1e3, (t_solved - t_built) * 1e3);
     p->sum.cg_iterations += cg.iterations + p->cg_extra;
     if (p->mg_active) p->sum.cg_iterations_multigrid += cg.iterations;     // iterations before an in-flight switch (cg_extra) ran with block-Jacobi
     if (ok) {
         if (!evaluated && (rc = evaluate_candidate()) != PGO_OK) return rc;
+        if (o.verbosity > 1) std::fprintf(stderr, "[pgo] it %3d candidate evaluated in %.3f ms\n", p->iteration, (now_s() - t_solved) * 1e3);
         it.model_cost_change = -h[S_MODEL];
         if (!(it.model_cost_change > 0.0) || !std::isfinite(it.model_cost_change)) { ok = false; why_invalid = PGO_STEP_INVALID_MODEL; }
     }
@@ -1823,7 +1832,9 @@ int lm_step(pgo_problem* p, int ignore_termination, int* done) {
         // HandleSuccessfulStep
         p->cur = nxt;
         double c = 0;
+        const double t_lin = now_s();
         if ((rc = linearize(p, &c)) != PGO_OK) return rc;
+        if (o.verbosity > 1) std::fprintf(stderr, "[pgo] it %3d linearised in %.3f ms\n", p->iteration, (now_s() - t_lin) * 1e3);
         p->x_cost = c;
         it.step_is_successful = 1;
         p->radius = p->radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * it.relative_decrease - 1.0, 3));   // StepAccepted
