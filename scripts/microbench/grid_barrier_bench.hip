@@ -1,5 +1,5 @@
 // Micro-benchmark (development aid, not product): what does a grid-wide barrier inside ONE launch cost on gfx950 against a kernel boundary inside a hipGraph?
-// Build: hipcc --offload-arch=gfx950 -O3 -o scripts/dev/micro/_grid_barrier_bench scripts/dev/micro/grid_barrier_bench.hip
+// Build: hipcc --offload-arch=gfx950 -O3 -o scripts/microbench/grid_barrier_bench scripts/microbench/grid_barrier_bench.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
