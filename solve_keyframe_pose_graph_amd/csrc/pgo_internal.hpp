@@ -154,6 +154,10 @@ struct MgLevelDev {
     const int32_t* ps_rowptr; const int32_t* ps_col; const int32_t* w_rowptr; const int32_t* w_col; const int64_t* psT_ptr; const int64_t* psT_ent;
     double* ps_val; double* w_val;
     double* t; double* u; double* y; const double* zero;         // [n][6] residual after pre-smoothing, c Dinv t, the smoothed correction; a vector of zeros
+    // set-up kernels run one wavefront per block: the block's row and the slot of its transposed block come from tables instead of a binary search over rowptr
+    // (14 dependent loads at the head of every wavefront of level 1)
+    const int32_t* row_of; const int32_t* tr_of;                 // [nnzb] row of block k; slot of block (col, row) (k itself on the diagonal or when absent)
+    const int32_t* ps_row; const int32_t* w_row;                 // [n_ps], [n_w] rows of the blocks of Ps and W
 };
 struct MgDev {
     int32_t n_levels;                    // levels 1..n_levels; the last one is dense (CoarseDev: Ac, rc = its residual, yc = its solution)

@@ -130,19 +130,14 @@ __global__ __launch_bounds__(256) void mg_val_f32_kernel(MgLevelDev A) {
     const int64_t k = wave_in_grid();
     const int lane = threadIdx.x & 63;
     if (k >= A.nnzb || lane >= 36) return;
-    int lo = 0, hi = A.n;                            // the block's row: rowptr ascending
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (A.rowptr[mid] <= k) lo = mid; else hi = mid; }
-    const int i = lo, j = A.col[k];
+    const int i = A.row_of[k], j = A.col[k];         // (tables: a binary search over rowptr was 14 dependent loads at the head of every wavefront)
+    const int64_t kt = A.tr_of[k];                   // the transposed block (j, i); k itself when the pattern does not hold it
     const int pr = lane / 12, rem = lane - pr * 12, col = rem >> 1, row = pr * 2 + (rem & 1);      // element (row, col) of the block
     const int tr = bsr_idx(col, row);                                                               // where (col, row) lives
     double v;
     if (j > i) v = A.val[(size_t)k * 36 + lane];
     else if (j == i) v = row <= col ? A.val[(size_t)k * 36 + lane] : A.val[(size_t)k * 36 + tr];
-    else {      // the transposed block (j, i): row j holds its diagonal block first, the others by ascending column
-        int64_t l2 = A.rowptr[j] + 1, h2 = A.rowptr[j + 1];
-        while (l2 < h2) { const int64_t mid = (l2 + h2) >> 1; if (A.col[mid] < i) l2 = mid + 1; else h2 = mid; }
-        v = (l2 < A.rowptr[j + 1] && A.col[l2] == i) ? A.val[(size_t)l2 * 36 + tr] : A.val[(size_t)k * 36 + lane];
-    }
+    else v = kt != k ? A.val[(size_t)kt * 36 + tr] : A.val[(size_t)k * 36 + lane];
     A.valf[(size_t)k * 36 + lane] = (float)v;
 }
 
@@ -224,79 +219,83 @@ void launch_mg_geometry_finish(const GraphDev& G, const MgDev& M, const MgLevelD
 
 // ---- Galerkin products ----
 // level 1 from the keyframe system: one wavefront per block; contributions as in coarse_assemble_kernel (reduced diagonal blocks C.Dtot and,
-// per edge, J1^T J2 - c1 c2^T / a recomputed from K1's Jacobians), summed in list order
-// one contribution of the keyframe system to a level-1 block: the fine 6x6 block (lane's element) and the two keyframes it couples
+// per edge, J1^T J2 - c1 c2^T / a — Hoff when the solver has had it formed for this linearisation (one edge-parallel, coalesced pass over K1's Jacobians: one load per
+// lane instead of twelve strided ones, the six products added in k2_edge_kernel's order), else recomputed from K1's Jacobians), summed in list order.
+// The value a lane owns of one contribution's fine block (mg_fine_block without the endpoint look-up).
 template <bool HOFF>
-__device__ __forceinline__ double mg_fine_block(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, int64_t ent, int lane, int r, int c, bool own, int64_t& ni, int64_t& nj) {
+__device__ __forceinline__ double mg_fine_value(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, int64_t ent, int lane, int r, int c, bool own) {
     const int kind = (int)(ent & 7);
     const int64_t idx = ent >> 3;
     double h = 0.0;
-    if (kind == 0) {
-        ni = nj = idx;
-        if (own) h = C.Dtot[(size_t)idx * 36 + lane];
-    } else {
-        const bool is_sw = kind >= 3;
-        const bool transposed = kind == 2 || kind == 4;
+    if (!own) return h;
+    if (kind == 0) return C.Dtot[(size_t)idx * 36 + lane];
+    const bool is_sw = kind >= 3;
+    const bool transposed = kind == 2 || kind == 4;
+    if (HOFF) h = L.Hoff[(size_t)((is_sw ? G.rel.Epad : 0) + idx) * 36 + (transposed ? c * 6 + r : r * 6 + c)];
+    else {
         const EdgeClassDev& E = is_sw ? G.sw : G.rel;
         const int D = is_sw ? SW_DOUBLES : REL_DOUBLES;
         const int o1 = is_sw ? 14 : 6, o2 = is_sw ? 50 : 42;
-        const int32_t c1 = E.c1[idx], c2 = E.c2[idx];
-        ni = transposed ? c2 : c1; nj = transposed ? c1 : c2;
-        if (own) {
-            const int oa = transposed ? o2 : o1, ob = transposed ? o1 : o2;
-            // Hoff (when the solver has had it formed for this linearisation: one edge-parallel, coalesced pass over K1's Jacobians) holds J1^T J2 of every edge as 36 contiguous
-            // doubles: one load per lane instead of twelve strided ones (the same sums in the same order: k2_edge_kernel adds the six products in this order too)
-            if (HOFF) h = L.Hoff[(size_t)((is_sw ? G.rel.Epad : 0) + idx) * 36 + (transposed ? c * 6 + r : r * 6 + c)];
-            else {
+        const int oa = transposed ? o2 : o1, ob = transposed ? o1 : o2;
 #pragma unroll
-                for (int kk = 0; kk < 6; ++kk) h += E.J[tile_elem(D, idx, oa + kk * 6 + r)] * E.J[tile_elem(D, idx, ob + kk * 6 + c)];
-            }
-            if (is_sw) {
-                const double* cc = L.c + (size_t)idx * 12;
-                h -= cc[(transposed ? 6 : 0) + r] * cc[(transposed ? 0 : 6) + c] * Sc.a_inv[idx];
-            }
-        }
+        for (int kk = 0; kk < 6; ++kk) h += E.J[tile_elem(D, idx, oa + kk * 6 + r)] * E.J[tile_elem(D, idx, ob + kk * 6 + c)];
+    }
+    if (is_sw) {
+        const double* cc = L.c + (size_t)idx * 12;
+        h -= cc[(transposed ? 6 : 0) + r] * cc[(transposed ? 0 : 6) + c] * Sc.a_inv[idx];
     }
     return h;
 }
-// Two contributions are fetched together (their entry -> endpoints -> Jacobian load chains overlap) and then projected one after the other, in
-// list order: the sums are those of the one-at-a-time loop.
+// The contribution list of a block is taken MG_G_CHUNK entries at a time, and every hop of a contribution's chain is issued for the whole chunk before anything waits:
+// the fine values (entry -> block) by the 36 owning lanes, the two keyframes' offsets to the aggregates' centroids (entry -> endpoint -> offset) by one lane per
+// (contribution, component) into LDS — three dependent round trips per chunk instead of four per pair of contributions.  The products are added in list order (same bits).
 template <bool HOFF>
 __global__ __launch_bounds__(256) void mg_galerkin0_kernel(GraphDev G, LinDev L, ScaleDev Sc, CgDev C, MgDev M, MgLevelDev A) {
-    __shared__ double Hs[4][2][36];
+    constexpr int CH = HOFF ? 8 : 2;      // (recomputing J1^T J2 from K1's Jacobians takes twelve strided loads per contribution: two at a time, as before)
+    __shared__ double Hs[4][CH][36];
+    __shared__ double ds[4][CH][6];
     const int wv = wave_in_block(), lane = threadIdx.x & 63;
     const int64_t slot = wave_in_grid();
     if (slot >= A.nnzb) return;
     const int r = lane / 6, c = lane - r * 6;
     const bool own = lane < 36;
+    const int du = lane / 6, dm = lane - du * 6;
     double acc = 0.0;
-    const int64_t k1 = A.g_ptr[slot + 1];
-    int64_t k = A.g_ptr[slot];
-    for (; k + 2 <= k1; k += 2) {
-        const int64_t e0 = A.g_ent[k], e1 = A.g_ent[k + 1];
-        int64_t ni0, nj0, ni1, nj1;
-        const double h0 = mg_fine_block<HOFF>(G, L, Sc, C, e0, lane, r, c, own, ni0, nj0);
-        const double h1 = mg_fine_block<HOFF>(G, L, Sc, C, e1, lane, r, c, own, ni1, nj1);
-        if (own) { Hs[wv][0][lane] = h0; Hs[wv][1][lane] = h1; }
+    const int64_t kend = A.g_ptr[slot + 1];
+    for (int64_t k0 = A.g_ptr[slot]; k0 < kend; k0 += CH) {
+        const int n = (int)(kend - k0 < CH ? kend - k0 : CH);
+        if (du < n) {       // lanes 0 .. 6 n - 1: component dm of contribution du's pair of offsets (dm < 3: the row keyframe)
+            const int64_t e = A.g_ent[k0 + du];
+            const int kind = (int)(e & 7);
+            int64_t node = e >> 3;
+            if (kind != 0) {
+                const bool is_sw = kind >= 3, first = (dm < 3) != (kind == 2 || kind == 4);
+                const int32_t* cp = is_sw ? (first ? G.sw.c1 : G.sw.c2) : (first ? G.rel.c1 : G.rel.c2);
+                node = cp[node];
+            }
+            ds[wv][du][dm] = M.d0[(size_t)node * 3 + (dm < 3 ? dm : dm - 3)];
+        }
+        double h[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) h[u] = mg_fine_value<HOFF>(G, L, Sc, C, A.g_ent[k0 + u < kend ? k0 + u : kend - 1], lane, r, c, own);
+        if (own) {
+#pragma unroll
+            for (int u = 0; u < CH; ++u) Hs[wv][u][lane] = h[u];
+        }
         __builtin_amdgcn_wave_barrier();
         if (own) {
-            acc += coarse_entry(Hs[wv][0], M.d0 + (size_t)ni0 * 3, M.d0 + (size_t)nj0 * 3, r, c);
-            acc += coarse_entry(Hs[wv][1], M.d0 + (size_t)ni1 * 3, M.d0 + (size_t)nj1 * 3, r, c);
+#pragma unroll
+            for (int u = 0; u < CH; ++u) if (u < n) acc += coarse_entry(Hs[wv][u], ds[wv][u], ds[wv][u] + 3, r, c);
         }
         __builtin_amdgcn_wave_barrier();
     }
-    if (k < k1) {
-        int64_t ni, nj;
-        const double h = mg_fine_block<HOFF>(G, L, Sc, C, A.g_ent[k], lane, r, c, own, ni, nj);
-        if (own) Hs[wv][0][lane] = h;
-        __builtin_amdgcn_wave_barrier();
-        if (own) acc += coarse_entry(Hs[wv][0], M.d0 + (size_t)ni * 3, M.d0 + (size_t)nj * 3, r, c);
-    }
     if (own) A.val[(size_t)slot * 36 + bsr_idx(r, c)] = acc;
 }
-// level l+1 (B) from level l (A): contributions are blocks of A, entry = (row << 32) | slot
+// level l+1 (B) from level l (A): contributions are blocks of A, entry = (row << 32) | slot; chunks as in mg_galerkin0_kernel
 __global__ __launch_bounds__(256) void mg_galerkin_kernel(MgLevelDev A, MgLevelDev B) {
-    __shared__ double Hs[4][36];
+    constexpr int CH = 8;
+    __shared__ double Hs[4][CH][36];
+    __shared__ double ds[4][CH][6];
     const int wv = wave_in_block(), lane = threadIdx.x & 63;
     const int64_t slot = wave_in_grid();
     if (slot >= B.nnzb) return;
@@ -304,14 +303,31 @@ __global__ __launch_bounds__(256) void mg_galerkin_kernel(MgLevelDev A, MgLevelD
     const bool own = lane < 36;
     // storage offset `lane` of a block holds element (row, col) with row = 2 (lane / 12) + (lane & 1), col = (lane % 12) / 2
     const int srow = 2 * (lane / 12) + (lane & 1), scol = (lane % 12) >> 1;
+    const int du = lane / 6, dm = lane - du * 6;
     double acc = 0.0;
-    for (int64_t k = B.g_ptr[slot]; k < B.g_ptr[slot + 1]; ++k) {
-        const int64_t ent = B.g_ent[k];
-        const int64_t fs = ent & 0xffffffffll;
-        const int64_t ni = ent >> 32, nj = A.col[fs];
-        if (own) Hs[wv][srow * 6 + scol] = A.val[(size_t)fs * 36 + lane];
+    const int64_t kend = B.g_ptr[slot + 1];
+    for (int64_t k0 = B.g_ptr[slot]; k0 < kend; k0 += CH) {
+        const int n = (int)(kend - k0 < CH ? kend - k0 : CH);
+        if (du < n) {
+            const int64_t e = B.g_ent[k0 + du];
+            const int64_t node = dm < 3 ? (e >> 32) : (int64_t)A.col[e & 0xffffffffll];
+            ds[wv][du][dm] = A.d[(size_t)node * 3 + (dm < 3 ? dm : dm - 3)];
+        }
+        double h[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int64_t fs = B.g_ent[k0 + u < kend ? k0 + u : kend - 1] & 0xffffffffll;
+            h[u] = own ? A.val[(size_t)fs * 36 + lane] : 0.0;
+        }
+        if (own) {
+#pragma unroll
+            for (int u = 0; u < CH; ++u) Hs[wv][u][srow * 6 + scol] = h[u];
+        }
         __builtin_amdgcn_wave_barrier();
-        if (own) acc += coarse_entry(Hs[wv], A.d + (size_t)ni * 3, A.d + (size_t)nj * 3, r, c);
+        if (own) {
+#pragma unroll
+            for (int u = 0; u < CH; ++u) if (u < n) acc += coarse_entry(Hs[wv][u], ds[wv][u], ds[wv][u] + 3, r, c);
+        }
         __builtin_amdgcn_wave_barrier();
     }
     if (own) B.val[(size_t)slot * 36 + bsr_idx(r, c)] = acc;
@@ -389,10 +405,7 @@ __global__ __launch_bounds__(256) void mg_ps_kernel(MgLevelDev A, double cs) {
     if (slot >= A.n_ps) return;
     const bool own = lane < 36;
     const int r = own ? lane / 6 : 0, c = own ? lane % 6 : 0;
-    // the row of this block: ps_rowptr is ascending -> binary search
-    int lo = 0, hi = A.n;
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int64_t)A.ps_rowptr[mid] <= slot) lo = mid; else hi = mid; }
-    const int i = lo, a = A.ps_col[slot];
+    const int i = A.ps_row[slot], a = A.ps_col[slot];
     double acc = 0.0;
     for (int64_t k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k) {
         const int j = A.col[k];
@@ -424,9 +437,7 @@ __global__ __launch_bounds__(256) void mg_w_kernel(MgLevelDev A) {
     if (slot >= A.n_w) return;
     const bool own = lane < 36;
     const int r = own ? lane / 6 : 0, c = own ? lane % 6 : 0;
-    int lo = 0, hi = A.n;
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int64_t)A.w_rowptr[mid] <= slot) lo = mid; else hi = mid; }
-    const int i = lo, b = A.w_col[slot];
+    const int i = A.w_row[slot], b = A.w_col[slot];
     double acc = 0.0;
     const int64_t kend = A.rowptr[i + 1];
     for (int64_t k0 = A.rowptr[i]; k0 < kend; k0 += MG_SETUP_CHUNK) {
@@ -474,9 +485,7 @@ __global__ __launch_bounds__(256) void mg_psTw_kernel(MgLevelDev A, MgLevelDev B
     if (slot >= B.nnzb) return;
     const bool own = lane < 36;
     const int r = own ? lane / 6 : 0, c = own ? lane % 6 : 0;
-    int lo = 0, hi = B.n;
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (B.rowptr[mid] <= slot) lo = mid; else hi = mid; }
-    const int a = lo, b = B.col[slot];
+    const int a = B.row_of[slot], b = B.col[slot];
     double acc = 0.0;
     const int64_t eend = A.psT_ptr[a + 1];
     for (int64_t e0 = A.psT_ptr[a]; e0 < eend; e0 += MG_SETUP_CHUNK) {

@@ -94,7 +94,7 @@ struct MgPrepared {
     std::vector<int32_t> agg0_l, mem0_ptr_l, mem0_l;      // several ranks: the keyframe-indexed arrays in the handle's local numbering
     std::vector<double> inv_cnt;
     std::vector<int32_t> pi32; std::vector<int64_t> pi64; size_t nf64 = 0;
-    struct Off { size_t col, parent, agg_ptr, tile, tile_rows, rowptr, g_ptr, g_ent, val, Dinv, pos, d, r, x, xt, xf, valf, ps_rowptr, ps_col, w_rowptr, w_col, psT_ptr, psT_ent, ps_val, w_val, t, u, y, zero; };
+    struct Off { size_t col, parent, agg_ptr, tile, tile_rows, rowptr, g_ptr, g_ent, val, Dinv, pos, d, r, x, xt, xf, valf, ps_rowptr, ps_col, w_rowptr, w_col, psT_ptr, psT_ent, ps_val, w_val, t, u, y, zero, row_of, tr_of, ps_row, w_row; };
     std::vector<Off> off;
     size_t o_agg0 = 0, o_mem0_ptr = 0, o_mem0 = 0, o_blk_tab = 0, o_d0 = 0, o_inv = 0, o_q1 = 0, o_s1 = 0;
     bool have_tab = false;
@@ -366,7 +366,7 @@ int mg_prepare(pgo_problem* p, const double* sw_now, MgPrepared& Q) {
         size_t n32 = A0.size() + M0P.size() + M0.size() + (size_t)((N + MG_BLOCK0 - 1) / MG_BLOCK0) * MG_BLOCK0 * 4 + 64, n64 = 0;
         for (const pgo_mg::HostLevel& A : H.L) {
             const size_t tiles = A.tile_agg0.empty() ? 0 : A.tile_agg0.size() - 1;
-            n32 += A.col.size() + A.parent.size() + A.agg_ptr.size() + tiles * (4 + 2 * (size_t)MG_TILE_ROWS) + A.ps_rowptr.size() + A.ps_col.size() + A.w_rowptr.size() + A.w_col.size() + 16;
+            n32 += 3 * A.col.size() + A.parent.size() + A.agg_ptr.size() + tiles * (4 + 2 * (size_t)MG_TILE_ROWS) + A.ps_rowptr.size() + 2 * A.ps_col.size() + A.w_rowptr.size() + 2 * A.w_col.size() + 16;
             n64 += A.rowptr.size() + A.g_ptr.size() + A.g_ent.size() + A.psT_ptr.size() + A.psT_ent.size();
         }
         pi32.reserve(n32); pi64.reserve(n64);
@@ -409,6 +409,22 @@ int mg_prepare(pgo_problem* p, const double* sw_now, MgPrepared& Q) {
         const pgo_mg::HostLevel& A = H.L[l];
         MgPrepared::Off& o = Q.off[l];
         o.col = put32(A.col); o.parent = put32(A.parent); o.agg_ptr = put32(A.agg_ptr);
+        {   // block -> row, block -> slot of the transposed block (rows hold the diagonal block first, the others by ascending column)
+            std::vector<int32_t> row_of(A.col.size()), tr_of(A.col.size());
+            for (int32_t i = 0; i < A.n; ++i) for (int64_t k = A.rowptr[i]; k < A.rowptr[(size_t)i + 1]; ++k) row_of[(size_t)k] = i;
+            for (int32_t i = 0; i < A.n; ++i)
+                for (int64_t k = A.rowptr[i]; k < A.rowptr[(size_t)i + 1]; ++k) {
+                    const int32_t j = A.col[(size_t)k];
+                    int64_t t = k;
+                    if (j != i) {
+                        const int32_t* b = A.col.data() + A.rowptr[j] + 1; const int32_t* e = A.col.data() + A.rowptr[(size_t)j + 1];
+                        const int32_t* f = std::lower_bound(b, e, i);
+                        if (f != e && *f == i) t = f - A.col.data();
+                    }
+                    tr_of[(size_t)k] = (int32_t)t;
+                }
+            o.row_of = put32(row_of); o.tr_of = put32(tr_of);
+        }
         {   // per tile {a0, a1, i0, i1}, 16-B aligned
             std::vector<int32_t> info;
             for (size_t tt = 0; tt + 1 < A.tile_agg0.size(); ++tt) { const int32_t a0 = A.tile_agg0[tt], a1 = A.tile_agg0[tt + 1]; info.insert(info.end(), {a0, a1, A.agg_ptr[a0], A.agg_ptr[a1]}); }
@@ -428,6 +444,14 @@ int mg_prepare(pgo_problem* p, const double* sw_now, MgPrepared& Q) {
         if (A.smoothed) {
             o.ps_rowptr = put32(A.ps_rowptr); o.ps_col = put32(A.ps_col); o.w_rowptr = put32(A.w_rowptr); o.w_col = put32(A.w_col);
             o.psT_ptr = put64(A.psT_ptr); o.psT_ent = put64(A.psT_ent);
+            {
+                std::vector<int32_t> ps_row(A.ps_col.size()), w_row(A.w_col.size());
+                for (int32_t i = 0; i < A.n; ++i) {
+                    for (int32_t k = A.ps_rowptr[i]; k < A.ps_rowptr[(size_t)i + 1]; ++k) ps_row[(size_t)k] = i;
+                    for (int32_t k = A.w_rowptr[i]; k < A.w_rowptr[(size_t)i + 1]; ++k) w_row[(size_t)k] = i;
+                }
+                o.ps_row = put32(ps_row); o.w_row = put32(w_row);
+            }
             o.ps_val = take(A.ps_col.size() * 36); o.w_val = take(A.w_col.size() * 36);
             o.t = take((size_t)A.n * 6); o.u = take((size_t)A.n * 6); o.y = take((size_t)A.n * 6); o.zero = take((size_t)A.n * 6);
         }
@@ -471,11 +495,13 @@ int mg_install(pgo_problem* p, MgPrepared& Q) {
         D.rowptr = b64 + o.rowptr; D.col = b32 + o.col; D.val = bf + o.val; D.g_ptr = b64 + o.g_ptr; D.g_ent = b64 + o.g_ent;
         D.Dinv = bf + o.Dinv; D.pos = bf + o.pos; D.d = bf + o.d; D.parent = b32 + o.parent; D.agg_ptr = b32 + o.agg_ptr; D.tile_info = reinterpret_cast<const int4*>(b32 + o.tile); D.tile_rows = reinterpret_cast<const int2*>(b32 + o.tile_rows);
         D.r = bf + o.r; D.x = bf + o.x; D.xt = bf + o.xt; D.xf = bf + o.xf; D.valf = reinterpret_cast<float*>(bf + o.valf);
+        D.row_of = b32 + o.row_of; D.tr_of = b32 + o.tr_of;
         D.seg_shift = A.seg >= 8 ? 3 : A.seg >= 4 ? 2 : A.seg >= 2 ? 1 : 0;
         D.pad3_ = l;      // (the level's index: read by the timeline variant build only)
         if (A.smoothed) {
             D.smoothed = 1; D.n_ps = (int32_t)A.ps_col.size(); D.n_w = (int32_t)A.w_col.size();
             D.ps_rowptr = b32 + o.ps_rowptr; D.ps_col = b32 + o.ps_col; D.w_rowptr = b32 + o.w_rowptr; D.w_col = b32 + o.w_col; D.psT_ptr = b64 + o.psT_ptr; D.psT_ent = b64 + o.psT_ent;
+            D.ps_row = b32 + o.ps_row; D.w_row = b32 + o.w_row;
             D.ps_val = bf + o.ps_val; D.w_val = bf + o.w_val; D.t = bf + o.t; D.u = bf + o.u; D.y = bf + o.y; D.zero = bf + o.zero;
         }
     }
