@@ -1908,48 +1908,74 @@ __device__ __forceinline__ double coarse_entry(const double* H, const double* di
     return v;
 }
 
+// The value a lane owns of one contribution's fine block of the keyframe system — kind 0: the reduced diagonal block C.Dtot; an edge: J1^T J2 - c1 c2^T / a (transposed for kinds 2 / 4), from Hoff where the solver has formed it, else recomputed from K1's Jacobians.
+template <bool HOFF>
+__device__ __forceinline__ double fine_block_value(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, int64_t ent, int lane, int r, int c, bool own) {
+    const int kind = (int)(ent & 7);
+    const int64_t idx = ent >> 3;
+    double h = 0.0;
+    if (!own) return h;
+    if (kind == 0) return C.Dtot[(size_t)idx * 36 + lane];
+    const bool is_sw = kind >= 3;
+    const bool transposed = kind == 2 || kind == 4;
+    if (HOFF) h = L.Hoff[(size_t)((is_sw ? G.rel.Epad : 0) + idx) * 36 + (transposed ? c * 6 + r : r * 6 + c)];
+    else {
+        const EdgeClassDev& E = is_sw ? G.sw : G.rel;
+        const int D = is_sw ? SW_DOUBLES : REL_DOUBLES;
+        const int o1 = is_sw ? 14 : 6, o2 = is_sw ? 50 : 42;
+        const int oa = transposed ? o2 : o1, ob = transposed ? o1 : o2;
+#pragma unroll
+        for (int kk = 0; kk < 6; ++kk) h += E.J[tile_elem(D, idx, oa + kk * 6 + r)] * E.J[tile_elem(D, idx, ob + kk * 6 + c)];
+    }
+    if (is_sw) {
+        const double* cc = L.c + (size_t)idx * 12;
+        h -= cc[(transposed ? 6 : 0) + r] * cc[(transposed ? 0 : 6) + c] * Sc.a_inv[idx];
+    }
+    return h;
+}
 // Ac = P^T A P: one wavefront per coarse block (a <= b), lane l < 36 owns entry (l / 6, l % 6); the block's contributions are summed in
 // list order (deterministic, no atomics).  Fine blocks come from the data the LM iteration already has: the reduced diagonal blocks
 // (C.Dtot: J^T J + damping - switch Schur terms + regularisers) and, per edge, J1^T J2 - c1 c2^T / a recomputed from K1's Jacobians.
+// The list (a diagonal block of 8 keyframes with 5 odometry neighbours each holds ~40 entries) is taken four entries at a time, every hop of their chains
+// (entry -> Jacobians; entry -> endpoint -> offset, by one lane per (contribution, component) into LDS) issued for the whole chunk before anything waits.
 __global__ __launch_bounds__(256) void coarse_assemble_kernel(GraphDev G, LinDev L, ScaleDev Sc, CgDev C, CoarseDev K) {
-    __shared__ double Hs[4][36];
+    constexpr int CH = 4;
+    __shared__ double Hs[4][CH][36];
+    __shared__ double ds[4][CH][6];
     const int wv = wave_in_block(), lane = threadIdx.x & 63;
     const int blk = wave_in_grid();
     if (blk >= K.n_blk) return;                       // whole wavefronts leave together; no workgroup barrier below
     const int a = K.blk_ab[blk * 2], b = K.blk_ab[blk * 2 + 1];
     const int r = lane / 6, c = lane - r * 6;
     const bool own = lane < 36;
+    const int du = lane / 6, dm = lane - du * 6;
     double acc = 0.0;
-    for (int64_t k = K.blk_ptr[blk]; k < K.blk_ptr[blk + 1]; ++k) {
-        const int64_t ent = K.contrib[k];
-        const int kind = (int)(ent & 7);
-        const int64_t idx = ent >> 3;
-        int64_t ni, nj;
-        double h = 0.0;
-        if (kind == 0) {
-            ni = nj = idx;
-            if (own) h = C.Dtot[(size_t)idx * 36 + lane];
-        } else {
-            const bool is_sw = kind >= 3;
-            const bool transposed = kind == 2 || kind == 4;
-            const EdgeClassDev& E = is_sw ? G.sw : G.rel;
-            const int D = is_sw ? SW_DOUBLES : REL_DOUBLES;
-            const int o1 = is_sw ? 14 : 6, o2 = is_sw ? 50 : 42;
-            const int32_t c1 = E.c1[idx], c2 = E.c2[idx];
-            ni = transposed ? c2 : c1; nj = transposed ? c1 : c2;
-            if (own) {
-                const int oa = transposed ? o2 : o1, ob = transposed ? o1 : o2;   // H[r][c] = sum_k Ja[k][r] Jb[k][c]
-#pragma unroll
-                for (int kk = 0; kk < 6; ++kk) h += E.J[tile_elem(D, idx, oa + kk * 6 + r)] * E.J[tile_elem(D, idx, ob + kk * 6 + c)];
-                if (is_sw) {
-                    const double* cc = L.c + (size_t)idx * 12;
-                    h -= cc[(transposed ? 6 : 0) + r] * cc[(transposed ? 0 : 6) + c] * Sc.a_inv[idx];
-                }
+    const int64_t kend = K.blk_ptr[blk + 1];
+    for (int64_t k0 = K.blk_ptr[blk]; k0 < kend; k0 += CH) {
+        const int n = (int)(kend - k0 < CH ? kend - k0 : CH);
+        if (du < n) {       // lanes 0 .. 6 n - 1: component dm of contribution du's pair of offsets (dm < 3: the row keyframe)
+            const int64_t e = K.contrib[k0 + du];
+            const int kind = (int)(e & 7);
+            int64_t node = e >> 3;
+            if (kind != 0) {
+                const bool is_sw = kind >= 3, first = (dm < 3) != (kind == 2 || kind == 4);
+                const int32_t* cp = is_sw ? (first ? G.sw.c1 : G.sw.c2) : (first ? G.rel.c1 : G.rel.c2);
+                node = cp[node];
             }
+            ds[wv][du][dm] = K.d[(size_t)node * 3 + (dm < 3 ? dm : dm - 3)];
         }
-        if (own) Hs[wv][lane] = h;
+        double h[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) h[u] = fine_block_value<false>(G, L, Sc, C, K.contrib[k0 + u < kend ? k0 + u : kend - 1], lane, r, c, own);
+        if (own) {
+#pragma unroll
+            for (int u = 0; u < CH; ++u) Hs[wv][u][lane] = h[u];
+        }
         __builtin_amdgcn_wave_barrier();
-        if (own) acc += coarse_entry(Hs[wv], K.d + (size_t)ni * 3, K.d + (size_t)nj * 3, r, c);
+        if (own) {
+#pragma unroll
+            for (int u = 0; u < CH; ++u) if (u < n) acc += coarse_entry(Hs[wv][u], ds[wv][u], ds[wv][u] + 3, r, c);
+        }
         __builtin_amdgcn_wave_barrier();
     }
     if (!own) return;

@@ -221,32 +221,7 @@ void launch_mg_geometry_finish(const GraphDev& G, const MgDev& M, const MgLevelD
 // level 1 from the keyframe system: one wavefront per block; contributions as in coarse_assemble_kernel (reduced diagonal blocks C.Dtot and,
 // per edge, J1^T J2 - c1 c2^T / a — Hoff when the solver has had it formed for this linearisation (one edge-parallel, coalesced pass over K1's Jacobians: one load per
 // lane instead of twelve strided ones, the six products added in k2_edge_kernel's order), else recomputed from K1's Jacobians), summed in list order.
-// The value a lane owns of one contribution's fine block (mg_fine_block without the endpoint look-up).
-template <bool HOFF>
-__device__ __forceinline__ double mg_fine_value(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, int64_t ent, int lane, int r, int c, bool own) {
-    const int kind = (int)(ent & 7);
-    const int64_t idx = ent >> 3;
-    double h = 0.0;
-    if (!own) return h;
-    if (kind == 0) return C.Dtot[(size_t)idx * 36 + lane];
-    const bool is_sw = kind >= 3;
-    const bool transposed = kind == 2 || kind == 4;
-    if (HOFF) h = L.Hoff[(size_t)((is_sw ? G.rel.Epad : 0) + idx) * 36 + (transposed ? c * 6 + r : r * 6 + c)];
-    else {
-        const EdgeClassDev& E = is_sw ? G.sw : G.rel;
-        const int D = is_sw ? SW_DOUBLES : REL_DOUBLES;
-        const int o1 = is_sw ? 14 : 6, o2 = is_sw ? 50 : 42;
-        const int oa = transposed ? o2 : o1, ob = transposed ? o1 : o2;
-#pragma unroll
-        for (int kk = 0; kk < 6; ++kk) h += E.J[tile_elem(D, idx, oa + kk * 6 + r)] * E.J[tile_elem(D, idx, ob + kk * 6 + c)];
-    }
-    if (is_sw) {
-        const double* cc = L.c + (size_t)idx * 12;
-        h -= cc[(transposed ? 6 : 0) + r] * cc[(transposed ? 0 : 6) + c] * Sc.a_inv[idx];
-    }
-    return h;
-}
-// The contribution list of a block is taken MG_G_CHUNK entries at a time, and every hop of a contribution's chain is issued for the whole chunk before anything waits:
+// The contribution list of a block is taken eight entries at a time, and every hop of a contribution's chain is issued for the whole chunk before anything waits:
 // the fine values (entry -> block) by the 36 owning lanes, the two keyframes' offsets to the aggregates' centroids (entry -> endpoint -> offset) by one lane per
 // (contribution, component) into LDS — three dependent round trips per chunk instead of four per pair of contributions.  The products are added in list order (same bits).
 template <bool HOFF>
@@ -277,7 +252,7 @@ __global__ __launch_bounds__(256) void mg_galerkin0_kernel(GraphDev G, LinDev L,
         }
         double h[CH];
 #pragma unroll
-        for (int u = 0; u < CH; ++u) h[u] = mg_fine_value<HOFF>(G, L, Sc, C, A.g_ent[k0 + u < kend ? k0 + u : kend - 1], lane, r, c, own);
+        for (int u = 0; u < CH; ++u) h[u] = fine_block_value<HOFF>(G, L, Sc, C, A.g_ent[k0 + u < kend ? k0 + u : kend - 1], lane, r, c, own);
         if (own) {
 #pragma unroll
             for (int u = 0; u < CH; ++u) Hs[wv][u][lane] = h[u];
