@@ -5,7 +5,7 @@ import numpy as np
 from solve_keyframe_pose_graph_amd import capi
 
 P = capi.Problem()
-for n in (384, 768, 1536, 3072):
+for n in [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "384,768,1216,1536,2048,2304,3072,4608".split(","))]:
     rng = np.random.default_rng(n)
     B = rng.standard_normal((n, n // 2))
     A = B @ B.T + np.diag(rng.uniform(1e-3, 1.0, n))

@@ -226,7 +226,7 @@ void launch_coarse_geometry(const GraphDev& G, const CoarseDev& K, const double*
 void launch_coarse_assemble(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, const CoarseDev& K, hipStream_t st);   // Ac = P^T A P (deterministic)
 void launch_coarse_symmetrize(const CoarseDev& K, hipStream_t st);                                             // mirror one triangle
 void launch_coarse_shift(const CoarseDev& K, double eps, hipStream_t st);   // Ac_ii *= 1 + eps
-void launch_coarse_invert(const CoarseDev& K, double* scratch /* 64 nc + 1024 doubles */, int32_t* fail, hipStream_t st);   // Ac -> Ac^-1 (blocked Gauss-Jordan)
+void launch_coarse_invert(const CoarseDev& K, double* scratch /* 64 nc + 4096 doubles */, int32_t* fail, hipStream_t st);   // Ac -> Ac^-1 (blocked Gauss-Jordan)
 void launch_coarse_negate(const CoarseDev& K, hipStream_t st);   // debug aid (PGO_DEBUG_BREAK_COARSE): Ac^-1 <- -Ac^-1, a preconditioner that is NOT positive definite
 // z += P Ac^-1 P^T r for the vectors of the PCG (r of the given parity), r.z partials updated in place (same workgroup -> slot mapping as cg_update)
 void launch_coarse_apply(const GraphDev& G, const CgDev& C, const CoarseDev& K, const double* r, double* z, double* part_rz, bool inside_iteration, hipStream_t st);

@@ -2411,6 +2411,148 @@ __global__ __launch_bounds__(256) void gj_update_kernel(double* __restrict__ A, 
     gj_block_inverse(a, Pinv, fail);
 }
 
+// ONE launch per block step (default; -DPGO_GJ_TWO_LAUNCHES keeps the panels + update pair).  What the panels kernel did is done by the update's own wavefronts:
+//   * the raw couplings u_x of ALL indices to this step's pivot block are in scratch already — UT, written by the PREVIOUS step's launch from the values it had just updated
+//     (two scratch copies alternate, as do two copies of the pivot inverse: every workgroup reads this step's while the owner of the next pivot block writes the next one's);
+//   * a wavefront forms s_j v_j = s_j P u_j for the 32 columns of its quadrant with the same eight MFMA per 16 columns the panels kernel issued — the D layout of
+//     v_mfma_f64_16x16x4 (row lk + 4 reg, column lr) IS the B layout the trailing update wants for k = reg + 4 h, so v goes from accumulator to operand without leaving registers;
+//   * quadrants on the pivot block's columns (rows before it) store -v_i instead of an update, quadrants on its rows (columns beyond it) store v_j, the pivot quadrant stores P;
+//   * quadrants on the NEXT pivot block's columns / rows also store their final values, transposed where needed, as the next step's UT.
+// Same MFMA sequences on the same operands as the two-launch form: the inverse is bit for bit the same.
+__global__ __launch_bounds__(256) void gj_first_panel_kernel(const double* __restrict__ A, int n, int ldu, double* __restrict__ UT) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= n) return;
+#pragma unroll 4
+    for (int k = 0; k < GJ_NB; ++k) UT[(size_t)k * ldu + x] = x < GJ_NB ? 0.0 : A[(size_t)k * n + x];
+}
+__global__ __launch_bounds__(256) void gj_step_kernel(double* __restrict__ A, int n, int ldu, int k0, const double* __restrict__ UT, double* __restrict__ UTn,
+                                                      const double* __restrict__ Pin, double* __restrict__ Pout, int32_t* __restrict__ fail) {
+    __shared__ double a[GJ_NB][GJ_NB + 1];
+    const int k1 = k0 + GJ_NB, kt = k1 < n ? k1 / 64 : 0;
+    int bi = blockIdx.y, bj = blockIdx.x;
+    if (bi == 0 && bj == 0) bi = bj = kt;                             // the tile of the next pivot block is dispatched first: its
+    else if (bi == kt && bj == kt) bi = bj = 0;                       // in-LDS inversion overlaps with the other tiles
+    if (bj < bi) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int i0 = bi * 64 + wr * 32, j0 = bj * 64 + wc * 32;
+    const bool ahead = k1 < n && bi == bj && bi == kt;                // this workgroup owns the next pivot block
+    if (!(bi == bj && wr == 1 && wc == 0)) {                          // (that quadrant lies below the diagonal)
+        const bool rows_pivot = i0 == k0, cols_pivot = j0 == k0;      // quadrants are 32-aligned, as is the pivot block
+        const bool next_cols = k1 < n && j0 == k1 && i0 < k1;         // final values = next step's couplings of the rows before the next pivot block
+        const bool next_rows = k1 < n && i0 == k1 && j0 > k1;         // ... of the columns beyond it
+        if (rows_pivot && cols_pivot) {                               // the pivot block becomes P (full block)
+#pragma unroll
+            for (int kk = 0; kk < GJ_NB / 4; ++kk) {
+                const int k = kk * 4 + lk;
+                A[(size_t)(k0 + lr) * n + k0 + k] = Pin[lr * GJ_NB + k];
+                A[(size_t)(k0 + 16 + lr) * n + k0 + k] = Pin[(16 + lr) * GJ_NB + k];
+            }
+        } else if (cols_pivot) {                                      // rows before the pivot block: A[x][k] = -v_x, v_x = P u_x
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                gj_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+                double u[GJ_NB / 4];
+#pragma unroll
+                for (int kk = 0; kk < GJ_NB / 4; ++kk) u[kk] = UT[(size_t)(kk * 4 + lk) * ldu + i0 + s * 16 + lr];
+#pragma unroll
+                for (int kk = 0; kk < GJ_NB / 4; ++kk) {
+                    const int k = kk * 4 + lk;
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Pin[lr * GJ_NB + k], u[kk], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Pin[(16 + lr) * GJ_NB + k], u[kk], acc1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int c = h * 16 + lk + 4 * reg;
+                        A[(size_t)(i0 + s * 16 + lr) * n + k0 + c] = -1.0 * (h == 0 ? acc0[reg] : acc1[reg]);
+                    }
+            }
+        } else {
+            // s_j v_j of this quadrant's columns: vj[t][h][reg] = row (h 16 + lk + 4 reg), column (j0 + 16 t + lr)
+            gj_d4 vj[2][2];
+            const double sgn = j0 < k0 ? -1.0 : 1.0;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                gj_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+                double u[GJ_NB / 4];
+#pragma unroll
+                for (int kk = 0; kk < GJ_NB / 4; ++kk) u[kk] = UT[(size_t)(kk * 4 + lk) * ldu + j0 + t * 16 + lr];
+#pragma unroll
+                for (int kk = 0; kk < GJ_NB / 4; ++kk) {
+                    const int k = kk * 4 + lk;
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Pin[lr * GJ_NB + k], u[kk], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Pin[(16 + lr) * GJ_NB + k], u[kk], acc1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) { vj[t][0][reg] = sgn * acc0[reg]; vj[t][1][reg] = sgn * acc1[reg]; }
+            }
+            if (rows_pivot) {                                         // columns beyond the pivot block: A[k][x] = v_x
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) {
+                            const int c = h * 16 + lk + 4 * reg;
+                            const double w = vj[t][h][reg];
+                            A[(size_t)(k0 + c) * n + j0 + t * 16 + lr] = w;
+                            if (next_cols) UTn[(size_t)(t * 16 + lr) * ldu + k0 + c] = w;      // (j0 == k1: these rows' couplings to the next pivot block)
+                        }
+            } else {
+                gj_d4 acc[2][2];
+                double old[2][2][4];                                  // the tile's current values: all 16 loads in flight before the first store
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        acc[s][t] = gj_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) old[s][t][reg] = A[(size_t)(i0 + s * 16 + lk + 4 * reg) * n + j0 + t * 16 + lr];
+                    }
+#pragma unroll
+                for (int kk = 0; kk < GJ_NB / 4; ++kk) {
+                    const size_t row = (size_t)(kk * 4 + lk) * ldu;
+                    const double a0 = UT[row + i0 + lr], a1 = UT[row + i0 + 16 + lr];
+                    const double b0 = vj[0][kk >> 2][kk & 3], b1 = vj[1][kk >> 2][kk & 3];
+                    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+                }
+                const bool mine = ahead && i0 == k1 && j0 == k1;
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) {
+                            const int i = i0 + s * 16 + lk + 4 * reg, j = j0 + t * 16 + lr;
+                            const double v = old[s][t][reg] - acc[s][t][reg];
+                            A[(size_t)i * n + j] = v;
+                            if (mine) a[i - k1][j - k1] = v;
+                            if (next_cols) UTn[(size_t)(j - k1) * ldu + i] = v;
+                            if (next_rows) UTn[(size_t)(i - k1) * ldu + j] = v;
+                        }
+            }
+        }
+    }
+    if (!ahead) return;
+    __syncthreads();
+    {   // only the upper triangle of the block is maintained: mirror it
+        const int r = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 4;
+        double m[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int c = c0 + q; m[q] = r <= c ? a[r][c] : a[c][r]; }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[r][c0 + q] = m[q];
+        __syncthreads();
+    }
+    gj_block_inverse(a, Pout, fail);
+}
+
 __global__ void coarse_pad_identity_kernel(CoarseDev K) {    // rows/columns beyond 6 n_agg: a decoupled identity block
     const int i = 6 * K.n_agg + blockIdx.x * blockDim.x + threadIdx.x;
     if (i < K.nc) K.Ac[(size_t)i * K.nc + i] = 1.0;
@@ -2434,15 +2576,34 @@ void launch_coarse_negate(const CoarseDev& K, hipStream_t st) {
 }
 
 // Ac (assembled, padded) -> Ac^-1, exactly symmetric; *fail != 0 when a pivot was not positive
-void launch_coarse_invert(const CoarseDev& K, double* scratch /* 64 nc + 1024 doubles */, int32_t* fail, hipStream_t st) {
+void launch_coarse_invert(const CoarseDev& K, double* scratch /* 64 nc + 4096 doubles */, int32_t* fail, hipStream_t st) {
     const int n = K.nc;
     double* UT = scratch;
     double* VT = scratch + (size_t)n * GJ_NB;
-    double* Pinv = scratch + (size_t)n * GJ_NB * 2;
+    double* Pinv = scratch + (size_t)(n + 16) * GJ_NB * 2;
     hipLaunchKernelGGL(gj_pivot_kernel, dim3(1), dim3(256), 0, st, K.Ac, n, 0, Pinv, fail);
-    for (int k0 = 0; k0 < n; k0 += GJ_NB) {
-        hipLaunchKernelGGL(gj_panels_kernel, dim3((unsigned)((n / 16 + 3) / 4)), dim3(256), 0, st, K.Ac, n, k0, Pinv, UT, VT);
-        hipLaunchKernelGGL(gj_update_kernel, dim3((unsigned)(n / 64), (unsigned)(n / 64)), dim3(256), 0, st, K.Ac, n, k0, UT, VT, Pinv, fail);
+    // One launch per block step where the launches are latency-bound; from n = 2 560 on every tile row's recomputation of P u_j costs more than the panels launch it
+    // saves (measured, ms, one launch vs two: n 384 0.181 / 0.206, 1 024 0.449 / 0.530, 1 216 0.55 / 0.66, 1 792 0.93 / 1.02, 2 304 1.31 / 1.42, 2 560 1.74 / 1.72, 3 072 2.84 / 2.27,
+    // 4 608 7.3 / 5.6; n = 2 048 — the multigrid's dense level on C3 — is the exception below 2 560: 1.28 / 1.15, with or without the padded scratch rows).  Same bits either way.
+#ifdef PGO_GJ_TWO_LAUNCHES
+    const bool fused = false;
+#else
+    const bool fused = n <= 2304 && n != 2048;
+#endif
+    if (!fused) {
+        for (int k0 = 0; k0 < n; k0 += GJ_NB) {
+            hipLaunchKernelGGL(gj_panels_kernel, dim3((unsigned)((n / 16 + 3) / 4)), dim3(256), 0, st, K.Ac, n, k0, Pinv, UT, VT);
+            hipLaunchKernelGGL(gj_update_kernel, dim3((unsigned)(n / 64), (unsigned)(n / 64)), dim3(256), 0, st, K.Ac, n, k0, UT, VT, Pinv, fail);
+        }
+    } else {
+        const int ldu = n + 16;                    // (rows of the scratch copies 128 B off a multiple of n: the transposed stores of a power-of-two n would all hit one channel)
+        double* U0 = scratch; double* U1 = scratch + (size_t)ldu * GJ_NB;
+        double* Pinv2 = Pinv + GJ_NB * GJ_NB;      // (the scratch ends with 2 x 1024 doubles behind 64 (n + 16))
+        hipLaunchKernelGGL(gj_first_panel_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)K.Ac, n, ldu, U0);
+        int step = 0;
+        for (int k0 = 0; k0 < n; k0 += GJ_NB, ++step)
+            hipLaunchKernelGGL(gj_step_kernel, dim3((unsigned)(n / 64), (unsigned)(n / 64)), dim3(256), 0, st, K.Ac, n, ldu, k0, (const double*)((step & 1) ? U1 : U0), (step & 1) ? U0 : U1,
+                               (const double*)((step & 1) ? Pinv2 : Pinv), (step & 1) ? Pinv : Pinv2, fail);
     }
     launch_coarse_symmetrize(K, st);     // lower <- upper
 }

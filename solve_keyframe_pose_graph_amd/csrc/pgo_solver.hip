@@ -473,7 +473,7 @@ int mg_install(pgo_problem* p, MgPrepared& Q) {
     const int n_top = H.L[nl - 1].n;
     const int nc = (6 * n_top + 63) / 64 * 64;
     HIPCHK(p, p->d_mg_i32.ensure(std::max<size_t>(pi32.size(), 1))); HIPCHK(p, p->d_mg_i64.ensure(std::max<size_t>(pi64.size(), 1))); HIPCHK(p, p->d_mg_f64.ensure(std::max<size_t>(nf64, 2)));
-    HIPCHK(p, p->d_cAc.ensure((size_t)nc * nc)); HIPCHK(p, p->d_cAcf.ensure((size_t)nc * nc)); HIPCHK(p, p->d_crc.ensure((size_t)nc * 2)); HIPCHK(p, p->d_cscr.ensure((size_t)nc * 64 + 1024)); HIPCHK(p, p->d_cinfo.ensure(4));
+    HIPCHK(p, p->d_cAc.ensure((size_t)nc * nc)); HIPCHK(p, p->d_cAcf.ensure((size_t)nc * nc)); HIPCHK(p, p->d_crc.ensure((size_t)nc * 2)); HIPCHK(p, p->d_cscr.ensure((size_t)nc * 64 + 4096)); HIPCHK(p, p->d_cinfo.ensure(4));
     HIPCHK(p, hipMemcpyAsync(p->d_mg_i32.p, pi32.data(), pi32.size() * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
     HIPCHK(p, hipMemcpyAsync(p->d_mg_i64.p, pi64.data(), pi64.size() * sizeof(int64_t), hipMemcpyHostToDevice, p->st));
     HIPCHK(p, hipMemsetAsync(p->d_mg_f64.p, 0, nf64 * sizeof(double), p->st));
@@ -942,7 +942,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
             const int n_blk = (int)blk_ab.size() / 2;
             const int nc = (6 * n_agg + 63) / 64 * 64;      // padded with a decoupled identity block (the dense kernels work on 64-wide tiles)
             HIPCHK(p, p->d_ccen.ensure((size_t)n_agg * 3)); HIPCHK(p, p->d_cd.ensure((size_t)N * 3)); HIPCHK(p, p->d_cAc.ensure((size_t)nc * nc)); HIPCHK(p, p->d_cAcf.ensure((size_t)nc * nc));
-            HIPCHK(p, p->d_crc.ensure((size_t)nc * 2)); HIPCHK(p, p->d_cscr.ensure((size_t)nc * 64 + 1024)); HIPCHK(p, hipMemsetAsync(p->d_crc.p, 0, (size_t)nc * 2 * sizeof(double), p->st)); HIPCHK(p, p->d_cblk_ptr.ensure(blk_ptr.size())); HIPCHK(p, p->d_ccontrib.ensure(std::max<size_t>(contrib.size(), 1)));
+            HIPCHK(p, p->d_crc.ensure((size_t)nc * 2)); HIPCHK(p, p->d_cscr.ensure((size_t)nc * 64 + 4096)); HIPCHK(p, hipMemsetAsync(p->d_crc.p, 0, (size_t)nc * 2 * sizeof(double), p->st)); HIPCHK(p, p->d_cblk_ptr.ensure(blk_ptr.size())); HIPCHK(p, p->d_ccontrib.ensure(std::max<size_t>(contrib.size(), 1)));
             HIPCHK(p, p->d_cblk_ab.ensure(blk_ab.size())); HIPCHK(p, p->d_cagg_free.ensure(n_agg)); HIPCHK(p, p->d_cinfo.ensure(4));
             HIPCHK(p, hipMemcpyAsync(p->d_cblk_ptr.p, blk_ptr.data(), blk_ptr.size() * sizeof(int64_t), hipMemcpyHostToDevice, p->st));
             if (!contrib.empty()) HIPCHK(p, hipMemcpyAsync(p->d_ccontrib.p, contrib.data(), contrib.size() * sizeof(int64_t), hipMemcpyHostToDevice, p->st));
@@ -2643,7 +2643,7 @@ int pgo_dense_spd_inverse(pgo_problem* p, int32_t n, const double* a, double* a_
         else h[(size_t)i * nc + i] = 1.0;
     }
     ScopedBuf<double> d_a, d_scr; ScopedBuf<int32_t> d_fail;
-    HIPCHK(p, d_a.ensure((size_t)nc * nc)); HIPCHK(p, d_scr.ensure((size_t)nc * 64 + 1024)); HIPCHK(p, d_fail.ensure(1));
+    HIPCHK(p, d_a.ensure((size_t)nc * nc)); HIPCHK(p, d_scr.ensure((size_t)nc * 64 + 4096)); HIPCHK(p, d_fail.ensure(1));
     CoarseDev K{}; K.nc = nc; K.Ac = d_a.p;
     EventPair ev;
     HIPCHK(p, ev.create());
