@@ -124,10 +124,11 @@ def test_a_handle_that_kept_it_skips_the_comparison_in_its_next_solves():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [64, 96, 200, 1024, 3072])
+@pytest.mark.parametrize("n", [64, 96, 200, 1024, 2048, 2304, 3072])
 def test_dense_inverse_against_numpy(n):
     """K6's blocked Gauss-Jordan (upper triangle, fp64 MFMA) against numpy on symmetric positive definite matrices whose conditioning
-    resembles a coarse operator's (a graph Laplacian-like stiff part plus a small damping on the diagonal)."""
+    resembles a coarse operator's (a graph Laplacian-like stiff part plus a small damping on the diagonal).  Sizes up to 2 304 except 2 048 run the
+    one-launch-per-block-step form, 2 048 and 3 072 the panels + update pair (launch_coarse_invert)."""
     rng = np.random.default_rng(n)
     B = rng.standard_normal((n, max(8, n // 2)))
     A = B @ B.T + np.diag(rng.uniform(1e-3, 1.0, n))
