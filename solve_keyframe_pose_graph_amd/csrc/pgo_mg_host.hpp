@@ -76,7 +76,7 @@ inline void parallel_ranges(int32_t n, int parts, Fn fn) {
     fn(parts - 1, std::min<int64_t>((int64_t)(parts - 1) * step, n), n);
     for (std::thread& t : th) t.join();
 }
-inline int host_threads() { const unsigned hc = std::thread::hardware_concurrency(); return hc >= 8 ? 4 : hc >= 4 ? 2 : 1; }
+inline int host_threads() { const unsigned hc = std::thread::hardware_concurrency(); return hc >= 32 ? 8 : hc >= 8 ? 4 : hc >= 4 ? 2 : 1; }      // (row ranges are joined in row order: the result does not depend on the count)
 
 // Stable bucket sort: elements of `v` ordered by bucket(v[i]) in [0, nb), the order inside a bucket kept; `start` [nb+1] receives the bucket bounds.  The big sorts of
 // the hierarchy build (700 000 block triples of C3's level 1, 200 000 couplings per matching pass) have keys "row, then column" with short rows: one linear pass by
