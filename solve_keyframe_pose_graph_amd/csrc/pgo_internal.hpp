@@ -42,7 +42,7 @@ constexpr int MF_MAX_NODES = 42;   // keyframes per tile (42 * 6 rows <= 256 lan
 constexpr int MF_SLOTS = 384;      // edge SIDES per tile (LDS contribution slots): a lane that serves both sides of an in-tile edge fills two
 constexpr int MF_MAX_GRID = 1024;  // cap on matvec workgroups = p.q partial sums = what 256 CUs hold at 4 workgroups each (measured per matvec on C3 / C4 with the round-2 lanes:
                                    // 512: 34.1 / 57.2 us, 768: 29.2 / 49.4, 896: 28.9 / 49.5, 1024: 27.3 / 45.3, 1536: 30.4 / 52.1, 2560: 34.6 / 51.8)
-constexpr int MF_PLANES = 11;      // COMPACT_DOUBLES / 2 double2 planes
+constexpr int MF_PLANES = 8;       // stored double2 planes of the compact record: q2 b a' dt (w|s, -); r6 (rec[16..21]) is recomputed by the matvec
 
 struct PriorDev {        // NodePoseRegularization target (rigid), see prior_residual()
     double Rf[9];
@@ -95,7 +95,7 @@ struct MfDev {
     const int32_t* tile_node0;   // [tiles+1]
     const ushort4* node_rng;     // [N] tile-local SLOT ranges {rel_begin, rel_end, sw_begin, sw_end} of the keyframe's sides
     const int32_t* node_prior;   // [N] regulariser index or -1
-    double2* rec;                // [MF_PLANES][ninc_pad]: planes 0-6 q2 b a' dt, plane 7 (w|s, -), planes 8-10 r6 (switchable only)
+    double2* rec;                // [MF_PLANES][ninc_pad]: planes 0-6 q2 b a' dt, plane 7 (w|s, -)
     double* lam;                 // [N][6] LM damping in the unscaled space (identity rows for fixed keyframes)
     int64_t ninc, ninc_pad;
     int32_t tiles;

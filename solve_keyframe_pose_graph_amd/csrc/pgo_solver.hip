@@ -2565,7 +2565,7 @@ int pgo_time_kernel(pgo_problem* p, int32_t which, int32_t launches, double* avg
                           // damping 48, side ranges / regulariser index / free flag 13.  Update: r, q, p, x read, r, x, z written (7 x 48), the fp32
                           // block-Jacobi factor 96.  Block-CSR matvec: SURVEY.md 8d's assembled form.
                           const double lanes_rel = (double)(p->mf_pair_lanes + p->mf_rel_side_lanes), lanes_sw = (double)p->mf_sw_lanes;
-                          const double mv = p->built_mf ? lanes_rel * (128.0 + 12.0) + lanes_sw * (176.0 + 12.0 + 8.0) + N * (4.0 * 48.0 + 48.0 + 13.0)
+                          const double mv = p->built_mf ? lanes_rel * (128.0 + 12.0) + lanes_sw * (128.0 + 12.0 + 8.0) + N * (4.0 * 48.0 + 48.0 + 13.0)
                                                         : 288.0 * (N + 2.0 * E) + 4.0 * (N + 2.0 * E) + N * 4.0 * 48.0;
                           const double up = N * (7.0 * 48.0 + 96.0);
                           bytes = which == 2 ? mv + up : which == 4 ? mv : up;
@@ -2584,7 +2584,7 @@ int pgo_time_kernel(pgo_problem* p, int32_t which, int32_t launches, double* avg
                           // the prolongation's read-modify-write of z, offsets and aggregate index); every sparse coarse level: its fp32 blocks and column indices twice
                           // (down- and up-sweep), Dinv, positions/offsets and its four vectors; the dense level: the fp32 inverse once.
                           const double lanes_rel = (double)(p->mf_pair_lanes + p->mf_rel_side_lanes), lanes_sw = (double)p->mf_sw_lanes;
-                          const double fine = lanes_rel * (128.0 + 12.0) + lanes_sw * (176.0 + 12.0 + 8.0) + N * (4.0 * 48.0 + 48.0 + 13.0) + N * (7.0 * 48.0 + 96.0);
+                          const double fine = lanes_rel * (128.0 + 12.0) + lanes_sw * (128.0 + 12.0 + 8.0) + N * (4.0 * 48.0 + 48.0 + 13.0) + N * (7.0 * 48.0 + 96.0);
                           double cyc = N * (24.0 + 16.0 / 8.0 * 8.0) /* d0 + slot table (restriction) */ + N * (2.0 * 48.0 + 24.0 + 4.0 + 4.0) /* z read + write, d0, agg0, member list (prolongation) */;
                           for (int l = 0; l + 1 < p->M.n_levels; ++l) {
                               const MgLevelDev& A = p->mg_levels[l];
