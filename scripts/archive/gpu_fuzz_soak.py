@@ -6,7 +6,7 @@ import numpy as np
 from tests import util
 
 n_graphs = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-rng = np.random.default_rng(2024)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
 bad, rejected_total, early = [], 0, 0
 t0 = time.time()
 for k in range(n_graphs):

@@ -7,7 +7,7 @@ import numpy as np
 from solve_keyframe_pose_graph_amd import graphgen
 from tests import util
 
-rng = np.random.default_rng(31)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 31)
 bad = 0
 for k in range(int(sys.argv[1]) if len(sys.argv) > 1 else 10):
     n = int(rng.integers(25000, 70000)); loops = int(n * rng.uniform(0.1, 1.2)); f = int(rng.integers(1, 4)); out = float(rng.choice([0.0, 0.1, 0.3])); seed = int(rng.integers(1, 10**6))
