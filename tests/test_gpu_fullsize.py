@@ -209,12 +209,15 @@ def test_c3_iterations_match_the_independent_cpu_trajectory(c3, n_iter, name):
     trajectories computed without libpgo (oracle Jet Jacobians, scipy CG to 1e-12, Python restatement of the Ceres LM loop; generator:
     tests/golden/make_c3_trajectory.py).  Ten iterations = the reference's budget per trigger; twenty = what bench.py times by default in
     the driver's run (the trust region grows to 1e5 and the multigrid takes over the late systems)."""
+    _check_trajectory_against_golden(c3, n_iter, name)
+
+
+def _check_trajectory_against_golden(g, n_iter, name):
     import json
     import os
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name)
     with open(path) as f:
         gold = json.load(f)
-    g = c3
     assert gold["n_poses"] == g.n_poses and gold["n_edges"] == g.n_odom + g.n_loops
     P = util.pgo_problem(g, True, max_num_iterations=n_iter)
     q, t, s = util.initial_state(g, True)
@@ -227,11 +230,21 @@ def test_c3_iterations_match_the_independent_cpu_trajectory(c3, n_iter, name):
         assert abs(mine.cost - rec["cost"]) <= 1e-6 * rec["cost"], (k, mine.cost, rec["cost"])     # chi^2 within 1e-6 relative at EVERY iteration
         if k > 0 and rec["successful"]:
             assert abs(mine.relative_decrease - rec["relative_decrease"]) <= 1e-3 * max(1.0, abs(rec["relative_decrease"]))
-        elif k > 0:   # a step rejected at an early-rejection pause reports the relative decrease of the truncated step: clearly bad too
+        elif k > 0 and mine.reason == capi.STEP_REJECTED_AT_PAUSE:   # reports the relative decrease of the truncated step: clearly bad too
             assert mine.relative_decrease < -0.05 and rec["relative_decrease"] < 1e-3
+        elif k > 0:   # rejected on the fully solved step: the same relative decrease as the golden's
+            assert mine.reason == capi.STEP_REJECTED_RHO and rec["relative_decrease"] < 1e-3
+            assert abs(mine.relative_decrease - rec["relative_decrease"]) <= 1e-3 * max(1.0, abs(rec["relative_decrease"]))
     tt = tp.reshape(-1, 3)[::997]
     assert np.abs(tt - np.array(gold["final_t_sample"])).max() <= 1e-3
     assert np.abs(sp[::997] - np.array(gold["final_s_sample"])).max() <= 1e-3
+
+
+def test_c4_ten_iterations_match_the_independent_cpu_trajectory():
+    """BASELINE config C4 (4 worlds x 50 000 keyframes, f = 1..5 with yaw weights, 1.02 M edges) at full size: the reference's 10-iteration budget with library defaults against
+    tests/golden/c4_ten_iterations.json — the CPU trajectory of tests/golden/make_c3_trajectory.py (oracle Jet Jacobians, scipy CG to 1e-12, Python restatement of the Ceres loop;
+    nothing of libpgo): every accept / reject decision, every cost within 1e-6 relative, a sample of the final positions and switches."""
+    _check_trajectory_against_golden(graphgen.config("C4"), 10, "c4_ten_iterations.json")
 
 
 def test_c3_converged_minimum_matches_the_independent_cpu_run(c3):

@@ -140,3 +140,19 @@ def test_the_full_size_exact_cholesky_run_agrees_with_the_c3_golden():
     for a, b in zip(full["iterations"], gold["iterations"]):
         assert a["successful"] == b["successful"]
         assert abs(a["cost"] - b["cost"]) <= 1e-9 * b["cost"], (a, b)
+
+
+def test_the_c4_golden_starts_at_the_oracles_objective():
+    """tests/golden/c4_ten_iterations.json (the full-size CPU trajectory of BASELINE config C4 the GPU suite compares with) begins at the cost the oracle's line-by-line
+    restatement of the reference functors gives for the odometry initial guess of the same graph — the golden's generator, graph and initial state are the ones the tests use."""
+    import json
+    import os
+    from solve_keyframe_pose_graph_amd import graphgen
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c4_ten_iterations.json")) as f:
+        gold = json.load(f)
+    g = graphgen.config("C4")
+    assert gold["n_poses"] == g.n_poses and gold["n_edges"] == g.n_odom + g.n_loops and len(gold["iterations"]) == 11
+    q, t, s = util.initial_state(g, True)
+    cost = util.oracle_problem(g, True).evaluate(q, t, s, want_residuals=False, want_gradient=False)[0]
+    assert abs(cost - gold["iterations"][0]["cost"]) <= 1e-12 * cost
+    assert [it["successful"] for it in gold["iterations"]] == [1, 1, 1, 1, 0, 0, 0, 0, 1, 1, 1]
