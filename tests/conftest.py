@@ -28,7 +28,7 @@ _GPU_ANCHORS = [
     "test_gpu_fullsize.py::test_c2_ten_iterations_with_library_defaults_match_oracle",              # C2   vs oracle, library defaults
     "test_gpu_fullsize.py::test_c3_iterations_match_the_independent_cpu_trajectory",                # C3   vs committed CPU goldens (10 and 20 iterations)
     "test_gpu_fullsize.py::test_c3_converged_minimum_matches_the_independent_cpu_run",              # C3   to Ceres' own convergence vs the committed CPU run
-    "test_gpu_fullsize.py::test_c4_ten_iterations_match_the_independent_cpu_trajectory",            # C4   vs the committed CPU golden (10 iterations, full size)
+    "test_gpu_fullsize.py::test_c4_iterations_match_the_independent_cpu_trajectory",                # C4   vs the committed CPU goldens (10 and 20 iterations, full size)
     "test_gpu_fullsize.py::test_c4_multi_world_objective_and_solve",                                # C4   objective / gradient vs oracle at full size
     "test_gpu_c5.py::test_c5_objective_gradient_and_three_lm_iterations_on_one_gpu",                # C5   objective / gradient vs oracle at full size
 ]

@@ -240,11 +240,13 @@ def _check_trajectory_against_golden(g, n_iter, name):
     assert np.abs(sp[::997] - np.array(gold["final_s_sample"])).max() <= 1e-3
 
 
-def test_c4_ten_iterations_match_the_independent_cpu_trajectory():
-    """BASELINE config C4 (4 worlds x 50 000 keyframes, f = 1..5 with yaw weights, 1.02 M edges) at full size: the reference's 10-iteration budget with library defaults against
-    tests/golden/c4_ten_iterations.json — the CPU trajectory of tests/golden/make_c3_trajectory.py (oracle Jet Jacobians, scipy CG to 1e-12, Python restatement of the Ceres loop;
-    nothing of libpgo): every accept / reject decision, every cost within 1e-6 relative, a sample of the final positions and switches."""
-    _check_trajectory_against_golden(graphgen.config("C4"), 10, "c4_ten_iterations.json")
+@pytest.mark.parametrize("n_iter,name", [(10, "c4_ten_iterations.json"), (20, "c4_twenty_iterations.json")])
+def test_c4_iterations_match_the_independent_cpu_trajectory(n_iter, name):
+    """BASELINE config C4 (4 worlds x 50 000 keyframes, f = 1..5 with yaw weights, 1.02 M edges) at full size: the reference's 10-iteration budget, and 20 iterations (the
+    multigrid has taken over by then), with library defaults against tests/golden/c4_{ten,twenty}_iterations.json — CPU trajectories of tests/golden/make_c3_trajectory.py (oracle
+    Jet Jacobians, scipy CG to 1e-12, Python restatement of the Ceres loop; nothing of libpgo; the 20-iteration one written from the checkpoint of a run to convergence by
+    tests/golden/make_trajectory_from_checkpoint.py): every accept / reject decision, every cost within 1e-6 relative, a sample of the final positions and switches."""
+    _check_trajectory_against_golden(graphgen.config("C4"), n_iter, name)
 
 
 def test_c3_converged_minimum_matches_the_independent_cpu_run(c3):
