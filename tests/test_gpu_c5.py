@@ -37,6 +37,21 @@ def test_c5_objective_gradient_and_three_lm_iterations_on_one_gpu(c5):
     assert abs(P.evaluate(q2, t2, s2)[0] - c2) <= 1e-10 * c2
     qf, tf, sf, summ = P.solve(q, t, s)
     assert summ.num_iterations == 3 and summ.num_successful_steps >= 2
+    # the three LM iterations against tests/golden/c5_three_iterations.json: the CPU trajectory of tests/golden/make_c3_trajectory.py on the full graph (oracle Jet Jacobians, scipy CG
+    # to 1e-12, Python restatement of the Ceres loop; 1.4 CPU-hours, nothing of libpgo) — decisions, costs within 1e-6 relative (observed 5e-11), relative decreases
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c5_three_iterations.json")) as f:
+        gold = json.load(f)
+    assert gold["n_poses"] == g.n_poses and gold["n_edges"] == g.n_odom + g.n_loops and len(gold["iterations"]) == 4
+    for k, rec in enumerate(gold["iterations"]):
+        mine = summ.iterations[k]
+        assert mine.step_is_successful == rec["successful"], k
+        assert abs(mine.cost - rec["cost"]) <= 1e-6 * rec["cost"], (k, mine.cost, rec["cost"])
+        if k > 0:
+            assert abs(mine.relative_decrease - rec["relative_decrease"]) <= 1e-3 * max(1.0, abs(rec["relative_decrease"]))
+    assert np.abs(tf.reshape(-1, 3)[::997] - np.array(gold["final_t_sample"])).max() <= 1e-3
+    assert np.abs(sf[::997] - np.array(gold["final_s_sample"])).max() <= 1e-3
     costs = [summ.iterations[k].cost for k in range(summ.num_logged)]
     assert all(b <= a for a, b in zip(costs, costs[1:])) and costs[-1] < 0.1 * costs[0]
     c1 = O.evaluate(qf, tf, sf, want_residuals=False, want_gradient=False)[0]
