@@ -24,6 +24,7 @@ def _has_gpu():
 # 3. only then the HIP-vs-HIP property tests of the preconditioners and the multi-rank machinery (f4, e).
 # Files not listed keep their alphabetical place after the listed ones.
 _GPU_ANCHORS = [
+    "test_gpu_parity.py::test_functor_goldens_through_the_kernels_as_gfx950_compiles_them",         # a1-a3: the 267 adversarial 50-digit functor cases through K1 / prior_kernel on the device
     "test_gpu_parity.py::test_first_iterations_track_oracle",                                       # C1   vs oracle (exact Cholesky), 10 iterations
     "test_gpu_fullsize.py::test_c2_ten_iterations_with_library_defaults_match_oracle",              # C2   vs oracle, library defaults
     "test_gpu_fullsize.py::test_c3_iterations_match_the_independent_cpu_trajectory",                # C3   vs committed CPU goldens (10 and 20 iterations)

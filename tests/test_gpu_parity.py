@@ -232,6 +232,80 @@ def test_full_graph_cost_and_gradient_match_the_independent_goldens():
             assert abs(grad[6 * g.n_poses + k] - v) <= 1e-12 * scale, (c["config"], k)
 
 
+def test_functor_goldens_through_the_kernels_as_gfx950_compiles_them():
+    """The 267 adversarial cases of tests/golden/functor_goldens.json (50-digit closed forms; identity, 90 / 180 degree rotations that hit every branch of Eigen's
+    matrix -> quaternion rule used at reference src/CeresResidues.h:24,119,150, antipodal quaternion signs, s in {0, 0.5, 0.99, 1, 1.3, < 0}) as ONE graph through
+    k1_edges_kernel / prior_kernel on the device: two keyframes per case, the case's edge between them (relative-pose, switchable with the case's s, or a
+    regulariser on the first keyframe), pgo_evaluate residuals and pgo_get_jacobian_blocks against the golden values.  The CPU suite feeds the same cases to the
+    device header compiled by g++ with -ffp-contract=off (tests/test_device_math_host.py); here hipcc's -ffp-contract=on code runs them."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "functor_goldens.json")) as f:
+        cases = json.load(f)["cases"]
+    rel = [c for c in cases if c["kind"] == "relpose"]
+    sw = [c for c in cases if c["kind"] == "switch"]
+    pri = [c for c in cases if c["kind"] == "prior"]
+    assert len(rel) >= 100 and len(sw) >= 80 and len(pri) >= 40
+    order = rel + sw + pri
+    N = 2 * len(order)
+    q = np.zeros((N, 4)); t = np.zeros((N, 3))
+    for i, c in enumerate(order):
+        q[2 * i], t[2 * i] = c["q1"], c["t1"]
+        q[2 * i + 1], t[2 * i + 1] = (c["q2"], c["t2"]) if "q2" in c else (c["q1"], c["t1"])
+    first = lambda k: 2 * np.arange(k, dtype=np.int32)
+    nr, ns, npri = len(rel), len(sw), len(pri)
+    P = capi.Problem()
+    ident = np.eye(4).flatten(order="F")
+    # relative-pose cases, then one filler edge per regulariser case (identity observation between two equal poses: keeps those keyframe pairs connected; not compared)
+    c1 = np.concatenate([first(nr), 2 * (nr + ns) + first(npri)]).astype(np.int32)
+    P.add_relpose_edges(c1, c1 + 1, np.array([c["T"] for c in rel] + [ident] * npri), np.array([c["w"] for c in rel] + [1.0] * npri))
+    c1s = (2 * nr + first(ns)).astype(np.int32)
+    P.add_switchable_edges(c1s, c1s + 1, np.array([c["T"] for c in sw]), np.array([c["w"] for c in sw]), np.arange(ns, dtype=np.int32))
+    P.set_node_regularizers((2 * (nr + ns) + first(npri)).astype(np.int32), np.array([c["T"] for c in pri]), np.array([c["w"] for c in pri]))
+    s = np.array([c["s"] for c in sw])
+    cost, res, grad = P.evaluate(q, t, s)
+    want_r = np.concatenate([np.array(c["r"]) for c in rel] + [np.zeros(6)] * npri + [np.array(c["r"]) for c in sw] + [np.array(c["r"]) for c in pri])
+    assert res.shape == want_r.shape
+    filler = slice(6 * nr, 6 * (nr + npri))
+    assert np.abs(res[filler]).max() <= 1e-15                      # identity observation between equal poses
+    assert np.abs(res - want_r).max() <= 1e-12 * max(1.0, np.abs(want_r).max())
+    assert abs(cost - 0.5 * np.sum(want_r ** 2)) <= 1e-12 * max(1.0, cost)
+    worst = 0.0
+    J1, J2, _ = P.jacobian_blocks(0, 0, nr)
+    for k, c in enumerate(rel):
+        for got, want in ((J1[k], np.array(c["J1"])), (J2[k], np.array(c["J2"]))):
+            err = np.abs(got - want).max() / max(1.0, np.abs(want).max()); worst = max(worst, err)
+            assert err <= 1e-12, ("relpose", k, err)
+    J1, J2, ds = P.jacobian_blocks(1)
+    for k, c in enumerate(sw):
+        G1, G2 = np.array(c["J1"]), np.array(c["J2"])
+        assert np.abs(G1[6]).max() == 0.0 and np.abs(G2[6]).max() == 0.0      # the 7th row w.r.t. the poses is identically zero (the kernels store 6 rows)
+        for got, want in ((J1[k], G1[:6]), (J2[k], G2[:6]), (ds[k], np.array(c["Js"]))):
+            err = np.abs(got - want).max() / max(1.0, np.abs(want).max()); worst = max(worst, err)
+            assert err <= 1e-12, ("switch", k, c["s"], err)
+    J1, _, _ = P.jacobian_blocks(2)
+    for k, c in enumerate(pri):
+        want = np.array(c["J1"])
+        err = np.abs(J1[k] - want).max() / max(1.0, np.abs(want).max()); worst = max(worst, err)
+        assert err <= 1e-12, ("prior", k, err)
+    # the gradient rows J^T r of every case's keyframes (K2 on the same adversarial inputs)
+    g6 = grad[:6 * N].reshape(N, 6)
+    for i, c in enumerate(order):
+        r = np.array(c["r"]); A1 = np.array(c["J1"])
+        w1 = A1.T @ r
+        if c["kind"] == "prior":
+            continue      # (its first keyframe also carries the filler edge's zero-residual block: J^T 0 = 0, so the row is the regulariser's alone)
+        w2 = np.array(c["J2"]).T @ r
+        sc = max(1.0, np.abs(w1).max(), np.abs(w2).max())
+        assert np.abs(g6[2 * i] - w1).max() <= 1e-11 * sc and np.abs(g6[2 * i + 1] - w2).max() <= 1e-11 * sc, (c["kind"], i)
+    for k, c in enumerate(pri):
+        w1 = np.array(c["J1"]).T @ np.array(c["r"])
+        assert np.abs(g6[2 * (nr + ns + k)] - w1).max() <= 1e-11 * max(1.0, np.abs(w1).max())
+    for k, c in enumerate(sw):
+        assert abs(grad[6 * N + k] - float(np.array(c["Js"]) @ np.array(c["r"]))) <= 1e-11 * max(1.0, abs(grad[6 * N + k]))
+    P.close()
+
+
 def test_manifold_plus_on_the_device_matches_the_oracle_parameterization():
     """a4: ceres::EigenQuaternionParameterization::Plus (reference src/PoseGraphSLAM.cpp:1276,1352) — the device function behind every
     candidate step against the oracle's restatement, including zero, tiny, half-turn and beyond-a-turn increments."""
