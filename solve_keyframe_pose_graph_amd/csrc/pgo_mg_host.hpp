@@ -518,7 +518,9 @@ inline bool build_hierarchy(int64_t N, const std::vector<uint8_t>& node_free, co
         // flight at once.  Measured, 20 LM steps, C3 / C4: <= 14 blocks per group and at most 4 groups (the first rule) 0.315 / 1.505 s; <= 10: 0.298 / 1.436; <= 7: 0.298 / 1.442;
         // <= 5: 0.291 / 1.417; <= 3.5: 0.290 / 1.471; <= 2.5: 0.299 / 1.468
         Lv.seg = 1;
-        static const double blocks_per_group = []() { const char* e = std::getenv("PGO_DEBUG_SEG_BLOCKS"); const double v = e ? std::atof(e) : 0.0; return v > 0.0 ? v : 5.0; }();   // (debug override for scans)
+        static const double blocks_per_group = []() {      // (debug override for scans: honoured only with PGO_ENABLE_DEBUG_HOOKS=1, values outside [1, 64] ignored)
+            const char* m = std::getenv("PGO_ENABLE_DEBUG_HOOKS"); const char* e = std::getenv("PGO_DEBUG_SEG_BLOCKS");
+            const double v = (m && m[0] == '1' && m[1] == 0 && e) ? std::atof(e) : 0.0; return v >= 1.0 && v <= 64.0 ? v : 5.0; }();
         while (Lv.seg < 8 && mean_row > blocks_per_group * Lv.seg) Lv.seg *= 2;
         while (Lv.seg > 1 && tile_rows / Lv.seg < max_agg) Lv.seg /= 2;         // an aggregate never straddles tiles
         const int cap = tile_rows / Lv.seg;

@@ -30,14 +30,27 @@ namespace {
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-// PGO_DEBUG_POISON=1 (debug aid, read once per process): every new device allocation is filled with 0xFF bytes — a NaN in every double / float, -1 in every index —
-// so that a kernel reading memory nobody wrote fails the same way on every box instead of depending on what the allocation held before (tests/test_gpu_poison.py runs
-// the parity suite's solves under it and compares the results bit for bit with an unpoisoned run).
-bool debug_poison() { static const bool on = []() { const char* e = std::getenv("PGO_DEBUG_POISON"); return e && e[0] == '1'; }(); return on; }
+// Debug hooks.  None of them is honoured unless the process ALSO sets PGO_ENABLE_DEBUG_HOOKS=1 (read once per process): a PGO_DEBUG_* variable that leaks into a production
+// environment on its own does nothing.  The test suite sets the master switch in tests/conftest.py.
+bool debug_hooks_enabled() { static const bool on = []() { const char* e = std::getenv("PGO_ENABLE_DEBUG_HOOKS"); return e && e[0] == '1' && e[1] == 0; }(); return on; }
+// PGO_DEBUG_POISON=1 (read once per process): every new device allocation is filled with 0xFF bytes — a NaN in every double / float, -1 in every index —
+// so that a kernel reading memory nobody wrote fails the same way on every box instead of depending on what the allocation held before (tests/test_gpu_determinism.py runs
+// its solves under it and compares the results bit for bit with an unpoisoned run).
+bool debug_poison() { static const bool on = []() { const char* e = std::getenv("PGO_DEBUG_POISON"); return debug_hooks_enabled() && e && e[0] == '1' && e[1] == 0; }(); return on; }
 
-// PGO_DEBUG_BREAK_COARSE=1 (debug aid, read at every operator build so that a test can switch it inside one process): the dense coarse inverse of the two-level method /
+// PGO_DEBUG_BREAK_COARSE=1 (read at every operator build so that a test can switch it inside one process): the dense coarse inverse of the two-level method /
 // of the multigrid's coarsest level is applied with the wrong sign — a preconditioner that is not positive definite, i.e. a forced PCG breakdown.
-bool debug_break_coarse() { const char* e = std::getenv("PGO_DEBUG_BREAK_COARSE"); return e && e[0] == '1'; }
+bool debug_break_coarse() { if (!debug_hooks_enabled()) return false; const char* e = std::getenv("PGO_DEBUG_BREAK_COARSE"); return e && e[0] == '1' && e[1] == 0; }
+// PGO_DEBUG_GRAPH_AFTER=<n> (read once): the PCG captures its chunk as a hipGraph after n eager iterations instead of 192; values that are not an even number in [2, 10^6] are ignored
+int debug_graph_after() {
+    static const int v = []() {
+        const char* e = std::getenv("PGO_DEBUG_GRAPH_AFTER");
+        if (!debug_hooks_enabled() || !e) return 192;
+        char* end = nullptr; const long n = std::strtol(e, &end, 10);
+        return (end && *end == 0 && n >= 2 && n <= 1000000 && (n & 1) == 0) ? (int)n : 192;
+    }();
+    return v;
+}
 
 template <class T>
 struct DBuf {
@@ -539,6 +552,7 @@ void mg_init_drop(pgo_problem* p) {
     if (p->mg_init_pending) { p->mg_init_pending = false; p->mg_init_out.reset(); p->mg_built = false; p->graph_dirty = true; }
 }
 int build_multigrid(pgo_problem* p, const double* sw_now, MgPrepared* ready);
+int build_two_level_aggregates(pgo_problem* p);
 // ... or it is needed now: waited for and installed
 int mg_init_finish(pgo_problem* p) {
     if (!p->mg_init_pending) return PGO_OK;
@@ -546,14 +560,23 @@ int mg_init_finish(pgo_problem* p) {
     if (p->mg_init_thread.joinable()) p->mg_init_thread.join();
     p->mg_init_pending = false;
     std::unique_ptr<MgPrepared> Q = std::move(p->mg_init_out);
-    if (p->rc_mg_init != PGO_OK || !Q) { p->mg_built = false; return p->rc_mg_init != PGO_OK ? p->rc_mg_init : PGO_ERR_STATE; }
+    if (p->rc_mg_init != PGO_OK || !Q) {      // the worker failed: the handle keeps working with what a graph without a hierarchy gets (build_graph's synchronous path does the same)
+        p->mg_built = false;
+        const int rc_worker = p->rc_mg_init != PGO_OK ? p->rc_mg_init : PGO_ERR_STATE;
+        HIPCHK(p, hipStreamSynchronize(p->st));
+        const int rc2 = build_two_level_aggregates(p);
+        ++p->build_epoch;
+        return rc2 != PGO_OK ? rc2 : rc_worker;
+    }
     const double waited = (now_s() - t0) * 1e3;
     int rc;
     HIPCHK(p, hipStreamSynchronize(p->st));
     if ((rc = build_multigrid(p, nullptr, Q.get())) != PGO_OK) return rc;
+    // a hierarchy that does not coarsen: the graph falls back to the two-level method — exactly what build_graph's synchronous path (several ranks) gives the same graph
+    if (!p->mg_built && (rc = build_two_level_aggregates(p)) != PGO_OK) return rc;
     ++p->build_epoch;
     if (p->opt.verbosity > 1) std::fprintf(stderr, "[pgo] multigrid: hierarchy of the new graph installed at its first use: host half %.2f ms on a worker thread, waited %.2f ms, installed in %.2f ms%s\n",
-                                           Q->host_ms, waited, (now_s() - t0) * 1e3 - waited, p->mg_built ? "" : " — it does not coarsen: plain block-Jacobi on this graph");
+                                           Q->host_ms, waited, (now_s() - t0) * 1e3 - waited, p->mg_built ? "" : " — it does not coarsen: the two-level method on this graph");
     p->mg_job_old = std::move(Q);      // (freed off the solve's critical path: regroup_install's note on munmap and the GPU's address space)
     return PGO_OK;
 }
@@ -580,6 +603,65 @@ int build_multigrid(pgo_problem* p, const double* sw_now, MgPrepared* ready) {
         if ((rc = mg_install(p, ready ? *ready : Q)) != PGO_OK) return rc;
     }
     if (p->local_ids && !p->mg_built) HIPCHK(p, p->d_xbuf.ensure((size_t)p->n_sh_global * 42 + 2 + 64));
+    return PGO_OK;
+}
+
+// The two-level method's aggregates (consecutive keyframes) and the contribution lists of its dense coarse operator, for the graph as built: what a graph WITHOUT a multigrid
+// hierarchy preconditions with.  Called by build_graph, and by mg_init_finish when the hierarchy a worker thread prepared turns out not to coarsen (the synchronous path —
+// several ranks — decides that inside build_graph; one GPU only learns it where the hierarchy is first needed: both end up with the same preconditioner).
+int build_two_level_aggregates(pgo_problem* p) {
+    const int64_t N = p->N, Er = p->rel.size(), Es = p->swe.size();
+    const int32_t* g2l = p->local_ids ? p->g2l.data() : nullptr;
+    auto L = [g2l](int32_t g) -> int32_t { return g2l ? g2l[g] : g; };
+    int n_agg = p->opt.coarse_aggregates;
+    // a graph with no more keyframes than `half` (256 by default) gets one aggregate per keyframe: the coarse operator IS the reduced system and the "preconditioner"
+    // its dense inverse (a direct solve; the PCG around it only refines); larger graphs: at least 8 keyframes per aggregate, but not fewer than `half` aggregates — the
+    // dense inverse (cubic in the aggregates) is what small graphs pay for (scripts/gpu_small_graphs.py) — and at most coarse_aggregates (768: measured on
+    // chain-like session graphs of 6 000 - 23 000 keyframes, scripts/gpu_session_aggregates.py: 768 beats 512 by 3 - 45 %, 1024 and 1536 lose to the cubic inverse)
+    const int half = std::min(n_agg / 2, 256);
+    if (N <= half) n_agg = (int)N;
+    else n_agg = (int)std::min<int64_t>(n_agg, std::max<int64_t>(N / 8, half));
+    if (n_agg >= 2 && !p->local_ids && (N + n_agg - 1) / n_agg <= 1024) {    // aggregates of thousands of keyframes are never used (build_coarse)
+        const int m = (int)((N + n_agg - 1) / n_agg);
+        n_agg = (int)((N + m - 1) / m);
+        std::vector<int32_t> agg_free((size_t)n_agg, 0);
+        for (int64_t n = 0; n < N; ++n) if (p->h_node_free[n]) agg_free[n / m]++;
+        // (block key, entry) pairs; key = a * n_agg + b with a <= b
+        std::vector<std::pair<int64_t, int64_t>> ent;
+        ent.reserve((size_t)N + 2 * (size_t)(Er + Es));
+        for (int64_t n = 0; n < N; ++n) if (p->h_node_free[n]) ent.push_back({(int64_t)(n / m) * n_agg + n / m, (n << 3) | 0});
+        auto edge = [&](int64_t e, int32_t c1, int32_t c2, int kind_fwd) {
+            if (!p->h_node_free[c1] || !p->h_node_free[c2]) return;       // rows and columns of fixed keyframes are not part of the system
+            const int64_t a = c1 / m, b = c2 / m;
+            if (a < b) ent.push_back({a * n_agg + b, (e << 3) | kind_fwd});
+            else if (a > b) ent.push_back({b * n_agg + a, (e << 3) | (kind_fwd + 1)});
+            else { ent.push_back({a * n_agg + a, (e << 3) | kind_fwd}); ent.push_back({a * n_agg + a, (e << 3) | (kind_fwd + 1)}); }
+        };
+        for (int64_t e = 0; e < Er; ++e) edge(e, L(p->rel.c1[e]), L(p->rel.c2[e]), 1);
+        for (int64_t e = 0; e < Es; ++e) edge(e, L(p->swe.c1[e]), L(p->swe.c2[e]), 3);
+        for (int a = 0; a < n_agg; ++a) if (agg_free[a] == 0) ent.push_back({(int64_t)a * n_agg + a, -1});   // identity block: listed, no contribution
+        std::stable_sort(ent.begin(), ent.end(), [](const std::pair<int64_t, int64_t>& x, const std::pair<int64_t, int64_t>& y) { return x.first < y.first; });
+        std::vector<int64_t> blk_ptr, contrib;
+        std::vector<int32_t> blk_ab;
+        int64_t prev = -1;
+        for (const auto& kv : ent) {
+            if (kv.first != prev) { blk_ptr.push_back((int64_t)contrib.size()); blk_ab.push_back((int32_t)(kv.first / n_agg)); blk_ab.push_back((int32_t)(kv.first % n_agg)); prev = kv.first; }
+            if (kv.second >= 0) contrib.push_back(kv.second);
+        }
+        blk_ptr.push_back((int64_t)contrib.size());
+        const int n_blk = (int)blk_ab.size() / 2;
+        const int nc = (6 * n_agg + 63) / 64 * 64;      // padded with a decoupled identity block (the dense kernels work on 64-wide tiles)
+        HIPCHK(p, p->d_ccen.ensure((size_t)n_agg * 3)); HIPCHK(p, p->d_cd.ensure((size_t)N * 3)); HIPCHK(p, p->d_cAc.ensure((size_t)nc * nc)); HIPCHK(p, p->d_cAcf.ensure((size_t)nc * nc));
+        HIPCHK(p, p->d_crc.ensure((size_t)nc * 2)); HIPCHK(p, p->d_cscr.ensure((size_t)nc * 64 + 4096)); HIPCHK(p, hipMemsetAsync(p->d_crc.p, 0, (size_t)nc * 2 * sizeof(double), p->st)); HIPCHK(p, p->d_cblk_ptr.ensure(blk_ptr.size())); HIPCHK(p, p->d_ccontrib.ensure(std::max<size_t>(contrib.size(), 1)));
+        HIPCHK(p, p->d_cblk_ab.ensure(blk_ab.size())); HIPCHK(p, p->d_cagg_free.ensure(n_agg)); HIPCHK(p, p->d_cinfo.ensure(4));
+        HIPCHK(p, hipMemcpyAsync(p->d_cblk_ptr.p, blk_ptr.data(), blk_ptr.size() * sizeof(int64_t), hipMemcpyHostToDevice, p->st));
+        if (!contrib.empty()) HIPCHK(p, hipMemcpyAsync(p->d_ccontrib.p, contrib.data(), contrib.size() * sizeof(int64_t), hipMemcpyHostToDevice, p->st));
+        HIPCHK(p, hipMemcpyAsync(p->d_cblk_ab.p, blk_ab.data(), blk_ab.size() * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
+        HIPCHK(p, hipMemcpyAsync(p->d_cagg_free.p, agg_free.data(), n_agg * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
+        HIPCHK(p, hipStreamSynchronize(p->st));
+        p->K = CoarseDev{n_agg, nc, m, n_blk, p->d_ccen.p, p->d_cd.p, p->d_cAc.p, p->d_crc.p, p->d_crc.p + nc, p->d_cblk_ptr.p, p->d_cblk_ab.p, p->d_ccontrib.p, p->d_cagg_free.p, p->d_cAcf.p};
+        p->coarse_built = true;
+    }
     return PGO_OK;
 }
 
@@ -904,57 +986,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
     phase("multigrid hierarchy");
     if (p->mg_built && p->built_mf) { HIPCHK(p, p->d_Hoff.ensure((size_t)(p->G.rel.Epad + p->G.sw.Epad) * 36)); p->L.Hoff = p->d_Hoff.p; }      // the multigrid's level-1 product reads J1^T J2 per edge
     p->hoff_epoch = 0;
-    if (!p->mg_built) {      // (a graph that got the multigrid never uses the two-level method: its dense operator would be built and uploaded for nothing)
-        int n_agg = p->opt.coarse_aggregates;
-        // a graph with no more keyframes than `half` (256 by default) gets one aggregate per keyframe: the coarse operator IS the reduced system and the "preconditioner"
-        // its dense inverse (a direct solve; the PCG around it only refines); larger graphs: at least 8 keyframes per aggregate, but not fewer than `half` aggregates — the
-        // dense inverse (cubic in the aggregates) is what small graphs pay for (scripts/gpu_small_graphs.py) — and at most coarse_aggregates (768: measured on
-        // chain-like session graphs of 6 000 - 23 000 keyframes, scripts/gpu_session_aggregates.py: 768 beats 512 by 3 - 45 %, 1024 and 1536 lose to the cubic inverse)
-        const int half = std::min(n_agg / 2, 256);
-        if (N <= half) n_agg = (int)N;
-        else n_agg = (int)std::min<int64_t>(n_agg, std::max<int64_t>(N / 8, half));
-        if (n_agg >= 2 && !p->local_ids && (N + n_agg - 1) / n_agg <= 1024) {    // aggregates of thousands of keyframes are never used (build_coarse)
-            const int m = (int)((N + n_agg - 1) / n_agg);
-            n_agg = (int)((N + m - 1) / m);
-            std::vector<int32_t> agg_free((size_t)n_agg, 0);
-            for (int64_t n = 0; n < N; ++n) if (p->h_node_free[n]) agg_free[n / m]++;
-            // (block key, entry) pairs; key = a * n_agg + b with a <= b
-            std::vector<std::pair<int64_t, int64_t>> ent;
-            ent.reserve((size_t)N + 2 * (size_t)(Er + Es));
-            for (int64_t n = 0; n < N; ++n) if (p->h_node_free[n]) ent.push_back({(int64_t)(n / m) * n_agg + n / m, (n << 3) | 0});
-            auto edge = [&](int64_t e, int32_t c1, int32_t c2, int kind_fwd) {
-                if (!p->h_node_free[c1] || !p->h_node_free[c2]) return;       // rows and columns of fixed keyframes are not part of the system
-                const int64_t a = c1 / m, b = c2 / m;
-                if (a < b) ent.push_back({a * n_agg + b, (e << 3) | kind_fwd});
-                else if (a > b) ent.push_back({b * n_agg + a, (e << 3) | (kind_fwd + 1)});
-                else { ent.push_back({a * n_agg + a, (e << 3) | kind_fwd}); ent.push_back({a * n_agg + a, (e << 3) | (kind_fwd + 1)}); }
-            };
-            for (int64_t e = 0; e < Er; ++e) edge(e, L(p->rel.c1[e]), L(p->rel.c2[e]), 1);
-            for (int64_t e = 0; e < Es; ++e) edge(e, L(p->swe.c1[e]), L(p->swe.c2[e]), 3);
-            for (int a = 0; a < n_agg; ++a) if (agg_free[a] == 0) ent.push_back({(int64_t)a * n_agg + a, -1});   // identity block: listed, no contribution
-            std::stable_sort(ent.begin(), ent.end(), [](const std::pair<int64_t, int64_t>& x, const std::pair<int64_t, int64_t>& y) { return x.first < y.first; });
-            std::vector<int64_t> blk_ptr, contrib;
-            std::vector<int32_t> blk_ab;
-            int64_t prev = -1;
-            for (const auto& kv : ent) {
-                if (kv.first != prev) { blk_ptr.push_back((int64_t)contrib.size()); blk_ab.push_back((int32_t)(kv.first / n_agg)); blk_ab.push_back((int32_t)(kv.first % n_agg)); prev = kv.first; }
-                if (kv.second >= 0) contrib.push_back(kv.second);
-            }
-            blk_ptr.push_back((int64_t)contrib.size());
-            const int n_blk = (int)blk_ab.size() / 2;
-            const int nc = (6 * n_agg + 63) / 64 * 64;      // padded with a decoupled identity block (the dense kernels work on 64-wide tiles)
-            HIPCHK(p, p->d_ccen.ensure((size_t)n_agg * 3)); HIPCHK(p, p->d_cd.ensure((size_t)N * 3)); HIPCHK(p, p->d_cAc.ensure((size_t)nc * nc)); HIPCHK(p, p->d_cAcf.ensure((size_t)nc * nc));
-            HIPCHK(p, p->d_crc.ensure((size_t)nc * 2)); HIPCHK(p, p->d_cscr.ensure((size_t)nc * 64 + 4096)); HIPCHK(p, hipMemsetAsync(p->d_crc.p, 0, (size_t)nc * 2 * sizeof(double), p->st)); HIPCHK(p, p->d_cblk_ptr.ensure(blk_ptr.size())); HIPCHK(p, p->d_ccontrib.ensure(std::max<size_t>(contrib.size(), 1)));
-            HIPCHK(p, p->d_cblk_ab.ensure(blk_ab.size())); HIPCHK(p, p->d_cagg_free.ensure(n_agg)); HIPCHK(p, p->d_cinfo.ensure(4));
-            HIPCHK(p, hipMemcpyAsync(p->d_cblk_ptr.p, blk_ptr.data(), blk_ptr.size() * sizeof(int64_t), hipMemcpyHostToDevice, p->st));
-            if (!contrib.empty()) HIPCHK(p, hipMemcpyAsync(p->d_ccontrib.p, contrib.data(), contrib.size() * sizeof(int64_t), hipMemcpyHostToDevice, p->st));
-            HIPCHK(p, hipMemcpyAsync(p->d_cblk_ab.p, blk_ab.data(), blk_ab.size() * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
-            HIPCHK(p, hipMemcpyAsync(p->d_cagg_free.p, agg_free.data(), n_agg * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
-            HIPCHK(p, hipStreamSynchronize(p->st));
-            p->K = CoarseDev{n_agg, nc, m, n_blk, p->d_ccen.p, p->d_cd.p, p->d_cAc.p, p->d_crc.p, p->d_crc.p + nc, p->d_cblk_ptr.p, p->d_cblk_ab.p, p->d_ccontrib.p, p->d_cagg_free.p, p->d_cAcf.p};
-            p->coarse_built = true;
-        }
-    }
+    if (!p->mg_built && (rc = build_two_level_aggregates(p)) != PGO_OK) return rc;      // (a graph that got the multigrid never uses the two-level method: its dense operator would be built and uploaded for nothing)
     phase("two-level aggregates");
     mg_guard.committed = true;
     p->graph_dirty = false; p->priors_dirty = false;
@@ -1228,7 +1260,7 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
     // Capture + instantiation cost about a millisecond: a PCG pays it only once it has run `graph_after` iterations eagerly (a graph that is rebuilt for every
     // solve — the reference's sessions: one new loop edge, one solve — and converges in a few hundred iterations never does; eager launches keep up with
     // 5-8 us kernels: measured 18.5 vs 19.4 ms at 300 keyframes, 64.0 vs 64.6 ms at 3000)
-    static const int graph_after = []() { const char* e = std::getenv("PGO_DEBUG_GRAPH_AFTER"); return e ? std::atoi(e) : 192; }();
+    const int graph_after = debug_graph_after();
     auto ensure_graph = [&](bool may_capture) {
         const int mode = p->mg_active ? 2 : p->coarse_active ? 1 : 0;
         pgo_problem::CapturedChunk& cc = p->cg_chunk[mode];
@@ -2107,6 +2139,11 @@ int pgo_set_options(pgo_problem* p, const pgo_options* o) {
 
 int pgo_reserve(pgo_problem* p, int64_t n_nodes, int64_t n_edges) {
     if (!p || n_nodes < 0 || n_edges < 0) return PGO_ERR_INVALID_ARG;
+    if ((size_t)n_edges <= p->rel.c1.capacity() && (size_t)n_edges <= p->rel.c2.capacity() && (size_t)n_edges * 8 <= p->rel.meas.capacity()) return PGO_OK;      // nothing moves
+    // the edge arrays are about to be reallocated: the hierarchy workers (a fresh graph's, a regroup's) read them — same rule as every other mutating entry point
+    if (p->in_solve) { p->err = "pgo_reserve inside a solve (between pgo_solve_begin and pgo_solve_end)"; return PGO_ERR_STATE; }
+    mg_job_cancel(p);
+    mg_init_drop(p);
     p->rel.c1.reserve(n_edges); p->rel.c2.reserve(n_edges); p->rel.meas.reserve((size_t)n_edges * 8);
     return PGO_OK;
 }

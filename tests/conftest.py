@@ -3,6 +3,8 @@ import sys
 
 import pytest
 
+# libpgo honours its PGO_DEBUG_* hooks (forced breakdowns, NaN-poisoned allocations) only under this master switch; the tests that use them run in this process or its children
+os.environ.setdefault("PGO_ENABLE_DEBUG_HOOKS", "1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

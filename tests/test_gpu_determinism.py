@@ -26,7 +26,7 @@ def digest_in_a_new_process(name, poison=False, **opt):
     env = dict(os.environ)
     env.pop("PGO_DEBUG_POISON", None)
     if poison:
-        env["PGO_DEBUG_POISON"] = "1"
+        env["PGO_DEBUG_POISON"] = "1"; env["PGO_ENABLE_DEBUG_HOOKS"] = "1"      # (the hooks need the master switch: csrc/pgo_solver.hip)
     cmd = [sys.executable, "-m", "tests.solve_digest", name] + ["%s=%r" % kv for kv in opt.items()]
     out = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
