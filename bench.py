@@ -421,6 +421,8 @@ def main():
                        "linear_solver": "PCG on the Schur-reduced pose system, %s matvec; 6x6 block-Jacobi, hard LM systems by the aggregation multigrid (hybrid start)" % ("matrix-free" if P_linear_solver == 1 else "block-CSR"), "cg_rel_tolerance": P_cg_tol,
                        "cg_max_iterations": P_cg_max},
             "libpgo_sha256": lib_sha, "static_traffic_notes": traffic_note or None,
+            # the hash of the sources the loaded library was built from (compiled in by _build.py) next to the hash of this checkout's sources: equal = built from this tree
+            "libpgo_sources_sha256": capi.build_info()[0], "checkout_sources_sha256": capi.build_info()[1],
             "lm_iters_per_s_raw": ips,
             "lm_iters_per_s_including_transfers": args.steps / elapsed_incl * scale,   # upload of the state, K iterations, write-back (rank 0's clock)
             "chi2_initial": 2.0 * summ.initial_cost, "chi2_final": 2.0 * summ.final_cost,
@@ -428,6 +430,21 @@ def main():
             "chi2_converged_rel_diff": None if not chi2_conv or "error" in chi2_conv else chi2_conv["chi2_converged_rel_diff"], "converged": chi2_conv,
             "lm_successful_steps": summ.num_successful_steps, "cg_iterations_total": int(summ.cg_iterations),
             "cg_iterations_per_step": [it.cg_iterations for it in its[1:]],
+            # what the K counted LM iterations were: a step rejected at an early-rejection pause costs a fraction of a fully solved one (Ceres pays a full factorisation for each)
+            "lm_iterations_fully_solved": sum(1 for it in its[1:] if it.reason != capi.STEP_REJECTED_AT_PAUSE),
+            "lm_iterations_rejected_at_pause": sum(1 for it in its[1:] if it.reason == capi.STEP_REJECTED_AT_PAUSE),
+            "pcg_form": "single-reduction (Chronopoulos-Gear)" if any(it.single_reduction for it in its[1:]) else "classic (two reductions per iteration)",
+            # where the timed region went, from the library's own host clock around its device-synchronised phases (pgo_iteration.seconds_*)
+            "timed_region_breakdown": (lambda steps: {
+                "system_and_preconditioner_setup_s": sum(it.seconds_system for it in steps),
+                "pcg_s_steps_ending_under_the_multigrid": sum(it.seconds_pcg for it in steps if (it.preconditioner & 15) == capi.PRECOND_MULTIGRID),
+                "pcg_s_other_steps": sum(it.seconds_pcg for it in steps if (it.preconditioner & 15) != capi.PRECOND_MULTIGRID),
+                "candidate_evaluation_s": sum(it.seconds_evaluate for it in steps),
+                "linearisation_s": sum(it.seconds_linearize for it in steps),
+                "unaccounted_s": elapsed - sum(it.seconds for it in steps),
+                "pcg_s_beyond_iterations_x_iteration_time": None if cg_ms is None or mg_ms is None else
+                    sum(it.seconds_pcg for it in steps) - 1e-3 * (summ_cg_mg * mg_ms + (summ_cg_total - summ_cg_mg) * cg_ms),
+                "note": "pcg_s includes the early-rejection pauses' candidate evaluations, the drain of the chunk in flight when a PCG stops, and multigrid operators built after a PCG has started (in-flight switch)"})(its[1:args.steps + 1]),
             "roofline": {"bound": "hbm", "kernel": "k1_edges_kernel<true> (residual + Jacobian blocks, all edges, one launch)",
                          "achieved": k1_bytes / (k1_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": k1_bytes / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,

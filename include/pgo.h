@@ -177,6 +177,13 @@ typedef struct pgo_options {
     /* device selection */
     int32_t device_id;                   /* -1: use the current HIP device */
     int32_t verbosity;                   /* 0 silent (minimizer_progress_to_stdout=false, :1271), 1 per-iteration line on stderr */
+    /* round 5 (appended: the layout of everything above is unchanged) */
+    int32_t cg_single_reduction;         /* 1: one GPU runs the PCG in its single-reduction (Chronopoulos-Gear) form — w = A u, both dot products r.u and u.w known right after the matvec,
+                                          *    ONE partial-sum re-reduction per iteration (in the vector update) instead of two — whenever cg_rel_tolerance >= 1e-11; the same iterates in exact
+                                          *    arithmetic, its attainable accuracy is a little lower, so tighter tolerances (the 1e-12 / 1e-13 parity settings) keep the classic two-reduction
+                                          *    form, and so does the two-level method's fused three-kernel iteration.  0: classic form everywhere.  Several ranks always run the single-reduction form. */
+    int32_t cg_pause_always;             /* 0: the early-rejection pauses are armed only where a rejection is in the air (previous step rejected, or the last accepted step's relative decrease
+                                          *    below 0.8); 1: at every LM system of graphs >= 20 000 keyframes / after the solve's first rejection (round 4's rule) */
 } pgo_options;
 
 /* Per-iteration record; mirrors ceres::IterationSummary fields the BriefReport is built from. */
@@ -197,6 +204,13 @@ typedef struct pgo_iteration {
     int32_t reason;            /* PGO_STEP_*: WHY the step ended the way step_is_valid / step_is_successful say */
     int32_t preconditioner;    /* PGO_PRECOND_* of the PCG that produced the step | PGO_PRECOND_RETRIED when a breakdown under the two-level method / the
                                 * multigrid was answered by solving the same system again with plain block-Jacobi */
+    /* round 5 (appended): where `seconds` went, from the library's host clock around its own (device-synchronised) phases */
+    double seconds_system;     /* LM diagonal, Schur-reduced system, block-Jacobi factors, and the operators of the preconditioner built BEFORE the PCG starts */
+    double seconds_pcg;        /* the PCG, its early-rejection pauses (candidate evaluations there) and operators built while it runs (in-flight switch to the multigrid) */
+    double seconds_evaluate;   /* candidate point, its cost, model cost change (the full-accuracy evaluation; 0 for a step rejected at a pause) */
+    double seconds_linearize;  /* K1 + K2 at the accepted point (0 for rejected steps) */
+    int32_t cg_iterations_multigrid; /* of cg_iterations: those preconditioned by the aggregation multigrid */
+    int32_t single_reduction;  /* 1: the PCG ran in its single-reduction form (pgo_options.cg_single_reduction) */
 } pgo_iteration;
 
 /* pgo_iteration.reason.  Ceres' IterationSummary only has step_is_valid / step_is_successful; an inexact linear solver adds ways for a step to fail that a log must
@@ -457,6 +471,9 @@ int pgo_dense_spd_inverse(pgo_problem* p, int32_t n, const double* a, double* a_
 int pgo_device_synchronize(pgo_problem* p);
 
 const char* pgo_strerror(int code);
+/* "libpgo sources sha256:<64 hex digits>": the hash the build recipe (solve_keyframe_pose_graph_amd/_build.py: source_tree_hash) computed over the HIP sources, their headers,
+ * this header and the compiler flags the library was built from — a caller (bench.py) recomputes it from its checkout to tell whether the binary it loaded was built from it. */
+const char* pgo_build_info(void);
 /* Text of the last error on this handle (HIP/RCCL error string); never NULL. */
 const char* pgo_last_error(const pgo_problem* p);
 

@@ -13,8 +13,7 @@ name, macros, reps = sys.argv[1], sys.argv[2].split(), int(sys.argv[3])
 cmd = sys.argv[sys.argv.index("--") + 1:]
 variant = os.path.join(ROOT, "build", "variants", "libpgo_%s.so" % name)
 os.makedirs(os.path.dirname(variant), exist_ok=True)
-srcs = [os.path.join(_build.CSRC, s) for s in _build.HIP_SOURCES]
-subprocess.check_call([_build.hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=on"] + macros + ["-I", _build.INCLUDE, "-I", _build.CSRC, "-x", "hip"] + srcs + ["-o", variant, "-ldl"])
+_build.compile_libpgo(variant, extra_flags=macros, obj_dir=os.path.join(ROOT, "build", "variants", "obj_" + name))
 _build.build_libpgo()
 for r in range(reps):
     for label, lib in (("product", None), (name, variant)):

@@ -35,15 +35,55 @@ def build_graphgen(force=False):
     return LIBGEN
 
 
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on"]
+_ROOT = os.path.dirname(_HERE)
+OBJ_DIR = os.path.join(_ROOT, "build", "obj")
+
+
+def source_tree_hash(extra_flags=()):
+    """sha256 over the sources libpgo.so is built from (names relative to the repo root, then contents, in a fixed order) and the compiler flags: what pgo_build_info()
+    reports for a library built by build_libpgo(), recomputable from a checkout (bench.py prints both)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(CSRC, f) for f in HIP_SOURCES + HIP_HEADERS] + [os.path.join(INCLUDE, "pgo.h")]
+    for f in files:
+        h.update(os.path.relpath(f, _ROOT).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+        h.update(b"\0")
+    h.update(" ".join(HIP_FLAGS + list(extra_flags)).encode())
+    return h.hexdigest()
+
+
+def compile_libpgo(target, extra_flags=(), verbose=False, obj_dir=None):
+    """Reproducible build: every translation unit to an object of its own with a FIXED compilation-unit id (clang otherwise draws a random one per run: two builds of the
+    same sources differed in a few hundred bytes), source paths mapped relative to the repo root, no linker build-id — the same sources and flags give the same bytes whatever
+    the checkout's path.  The two objects are compiled side by side."""
+    obj_dir = obj_dir or OBJ_DIR
+    os.makedirs(obj_dir, exist_ok=True)
+    sha = source_tree_hash(extra_flags)
+    procs, objs = [], []
+    for src in HIP_SOURCES:
+        stem = os.path.splitext(src)[0]
+        obj = os.path.join(obj_dir, stem + ".o")
+        cmd = [hipcc_path()] + HIP_FLAGS + list(extra_flags) + ["-ffile-prefix-map=%s=." % _ROOT, "-cuid=" + stem, '-DPGO_SOURCE_SHA256="%s"' % sha,
+                                                                "-I", INCLUDE, "-I", CSRC, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+        procs.append((cmd, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    subprocess.check_call([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", target, "-ldl", "-Wl,--build-id=none"])
+    return target
+
+
 def build_libpgo(force=False, verbose=False):
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
     deps = srcs + [os.path.join(CSRC, h) for h in HIP_HEADERS] + [os.path.join(INCLUDE, "pgo.h")]
     if force or _stale(LIBPGO, deps):
-        cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=on",
-               "-I", INCLUDE, "-I", CSRC, "-x", "hip"] + srcs + ["-o", LIBPGO, "-ldl"]
-        if verbose:
-            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-        subprocess.check_call(cmd)
+        compile_libpgo(LIBPGO, verbose=verbose)
     return LIBPGO
 
 

@@ -28,14 +28,16 @@ class Options(C.Structure):
                 ("cg_warm_start", C.c_int32), ("cg_use_graph", C.c_int32), ("cg_early_tolerance", C.c_double), ("cg_early_reject_rho", C.c_double), ("cg_mid_tolerance", C.c_double), ("cg_mid_reject_rho", C.c_double), ("coarse_aggregates", C.c_int32), ("mg_min_keyframes", C.c_int32), ("coarse_min_radius", C.c_double),
                 ("mg_omega", C.c_double), ("mg_correction_scale", C.c_double), ("mg_first_passes", C.c_int32), ("mg_passes", C.c_int32), ("mg_dense_max_nodes", C.c_int32), ("mg_switch_iterations", C.c_int32),
                 ("mg_loop_discount", C.c_double), ("mg_regroup_fraction", C.c_double), ("mg_prolongation_damping", C.c_double), ("mg_smoothed_levels", C.c_int32), ("mg_min_keyframes_switchable", C.c_int32),
-                ("device_id", C.c_int32), ("verbosity", C.c_int32)]
+                ("device_id", C.c_int32), ("verbosity", C.c_int32), ("cg_single_reduction", C.c_int32), ("cg_pause_always", C.c_int32)]
 
 
 class Iteration(C.Structure):
     _fields_ = [("iteration", C.c_int32), ("step_is_valid", C.c_int32), ("step_is_successful", C.c_int32), ("cg_iterations", C.c_int32),
                 ("cost", C.c_double), ("cost_change", C.c_double), ("model_cost_change", C.c_double), ("relative_decrease", C.c_double),
                 ("gradient_max_norm", C.c_double), ("step_norm", C.c_double), ("trust_region_radius", C.c_double), ("cg_residual", C.c_double),
-                ("seconds", C.c_double), ("reason", C.c_int32), ("preconditioner", C.c_int32)]
+                ("seconds", C.c_double), ("reason", C.c_int32), ("preconditioner", C.c_int32),
+                ("seconds_system", C.c_double), ("seconds_pcg", C.c_double), ("seconds_evaluate", C.c_double), ("seconds_linearize", C.c_double),
+                ("cg_iterations_multigrid", C.c_int32), ("single_reduction", C.c_int32)]
 
 
 # pgo_iteration.reason / .preconditioner (include/pgo.h)
@@ -60,7 +62,7 @@ EXPORTS = [
     "pgo_solve", "pgo_solve_begin", "pgo_lm_step", "pgo_solve_end", "pgo_evaluate",
     "pgo_get_jacobian_blocks", "pgo_get_normal_blocks", "pgo_apply_normal_operator", "pgo_manifold_plus",
     "pgo_comm_get_unique_id", "pgo_comm_init", "pgo_comm_destroy", "pgo_comm_init_custom", "pgo_partition_edges",
-    "pgo_time_linearize_kernel", "pgo_time_kernel", "pgo_time_vio_odometry_kernel", "pgo_dense_spd_inverse", "pgo_device_synchronize", "pgo_strerror", "pgo_last_error",
+    "pgo_time_linearize_kernel", "pgo_time_kernel", "pgo_time_vio_odometry_kernel", "pgo_dense_spd_inverse", "pgo_device_synchronize", "pgo_strerror", "pgo_last_error", "pgo_build_info",
 ]
 
 _lib = None
@@ -85,6 +87,9 @@ def load(build=True):
     lib.pgo_last_error.restype = C.c_char_p
     lib.pgo_last_error.argtypes = [C.c_void_p]
     lib.pgo_strerror.argtypes = [C.c_int]
+    if hasattr(lib, "pgo_build_info"):
+        lib.pgo_build_info.restype = C.c_char_p
+        lib.pgo_build_info.argtypes = []
     for f in EXPORTS:
         if not hasattr(lib, f):
             raise RuntimeError("libpgo.so does not export %s" % f)
@@ -95,6 +100,12 @@ def load(build=True):
             raise RuntimeError("capi.%s is %d bytes, libpgo.so's struct %d: the ctypes view is out of date with include/pgo.h" % (T.__name__, C.sizeof(T), lib.pgo_abi_sizeof(which)))
     _lib = lib
     return lib
+
+
+def build_info():
+    """(sha256 the loaded library says its sources had, sha256 of the sources in this checkout): equal when the library was built from this tree by _build.py."""
+    txt = load().pgo_build_info().decode()
+    return txt.rsplit(":", 1)[-1], _build.source_tree_hash()
 
 
 def default_options(**kw):

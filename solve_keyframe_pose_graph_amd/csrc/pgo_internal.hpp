@@ -205,6 +205,9 @@ void launch_cg_set_tolerance(const CgDev& C, double tol2, hipStream_t st);
 void launch_cg_poll(const CgDev& C, int32_t* host_flags, double* host_scal, hipStream_t st);      // host_*: pinned, device-accessible
 void launch_cg_spmv(const GraphDev& G, const CgDev& C, int k, double tol2, hipStream_t st);   // iteration k: direction + matvec (+ convergence test)
 void launch_cg_update(const GraphDev& G, const CgDev& C, int k, int n_pq_partials, hipStream_t st);
+// single-reduction (Chronopoulos-Gear) form on one GPU: w = A u with the partials of u.w (stops with the PCG), then ONE update kernel that re-reduces both dot products
+void launch_mf_apply_dot_live(const GraphDev& G, const MfDev& F, const ScaleDev& Sc, const CgDev& C, hipStream_t st);
+void launch_cg_update_sr(const GraphDev& G, const CgDev& C, int k, int first, int n_pq_partials, hipStream_t st);
 int cg_grid_size(const GraphDev& G);
 int mf_grid_size(const MfDev& F);
 void launch_apply_operator(const GraphDev& G, const CgDev& C, const double* x, double* y, hipStream_t st);
@@ -271,6 +274,7 @@ void launch_mg_apply(const GraphDev& G, const CgDev& C, const MgDev& M, const Mg
                      bool restricted = false /* r_1 (and x_1) already formed by launch_cg_update_mg */, double prolong_scale = 0.0 /* c of the smoothed transitions */);
 // cg_update + r_1 = P_0^T r', x_1 = w D_1^-1 r_1 of the multigrid (M.blk_tab)
 void launch_cg_update_mg(const GraphDev& G, const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, int k, int n_pq_partials, hipStream_t st);
+void launch_cg_update_mg_sr(const GraphDev& G, const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, int k, int first, int n_pq_partials, hipStream_t st);      // single-reduction form (cg_update_kernel<true>) with the same restriction
 
 double k1_algorithmic_bytes(const GraphDev& G, bool want_jacobian);
 

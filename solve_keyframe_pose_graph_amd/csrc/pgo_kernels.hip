@@ -981,15 +981,47 @@ __global__ void cg_scalars_init_kernel(CgDev C, int nparts, int nparts_bb, doubl
     }
 }
 
-// alpha = rz/pq ; x += alpha p ; r' = r - alpha q ; z = Minv r' ; partial r'.z -> part_rz[parity^1]
-__global__ __launch_bounds__(CG_BLOCK) void cg_update_kernel(GraphDev G, CgDev C, int parity, int nparts_pq, int nparts) {
+// The head of the single-reduction (Chronopoulos-Gear) update on one GPU: delta = u.w (the matvec's partials) and gamma = r.u (the previous update's) are re-reduced
+// TOGETHER — the iteration's only reduction point — then the convergence test the classic form runs at the head of its matvec, beta = gamma / gamma_prev,
+// alpha = gamma / (delta - beta gamma / alpha_prev).  Scalars in C.scal[8 + 2 parity] (gamma), [9 + 2 parity] (alpha) of the iteration with that parity (as the multi-rank
+// kernel keeps them).  Returns false when the workgroup has nothing to do (stopped, converged, broken down).
+__device__ __forceinline__ bool sr_head(const CgDev& C, int parity, int first, int nparts_pq, int nparts, double* red, double& alpha, double& beta) {
+    double delta, gamma;
+    if (block_total2_done(C.flags, C.part_pq, nparts_pq, C.part_rz + parity * RZ_STRIDE, nparts + C.extra_rz, red, delta, gamma)) return false;
+    const bool breakdown = C.flags[1] != 0;
+    if (breakdown || !(gamma > C.scal[3] * C.scal[0])) {      // converged (or broken down): the state stays that of the last completed update
+        if (blockIdx.x == 0 && threadIdx.x == 0) { C.flags[0] = 1; if (!breakdown) { C.scal[1] = gamma; if (!(gamma >= -C.scal[3] * C.scal[0])) C.flags[1] = 1; } }
+        return false;
+    }
+    beta = 0.0;
+    double den = delta;
+    if (!first) {
+        const double gamma_prev = C.scal[8 + 2 * (parity ^ 1)], alpha_prev = C.scal[9 + 2 * (parity ^ 1)];
+        beta = gamma / gamma_prev;
+        den = delta - beta * gamma / alpha_prev;
+    }
+    if (!(den > 0.0)) {      // not positive definite along the direction (or NaN): x is left untouched
+        if (blockIdx.x == 0 && threadIdx.x == 0) { C.flags[1] = 1; C.flags[0] = 1; }
+        return false;
+    }
+    alpha = gamma / den;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { C.scal[8 + 2 * parity] = gamma; C.scal[9 + 2 * parity] = alpha; C.scal[1] = gamma; C.flags[2] += 1; }
+    return true;
+}
+
+// classic form (SR = false):   alpha = rz/pq ; x += alpha p ; r' = r - alpha q ; z = Minv r' ; partial r'.z -> part_rz[parity^1]
+// single-reduction form (SR):  p = u + beta p ; s = w + beta s ; x += alpha p ; r -= alpha s ; u = Minv r ; partial r.u -> part_rz[parity^1]     (u in C.z, w in C.q, s in C.p2, r in place)
+template <bool SR>
+__global__ __launch_bounds__(CG_BLOCK) void cg_update_kernel(GraphDev G, CgDev C, int parity, int nparts_pq, int nparts, int first) {
     __shared__ double red[2 * (CG_BLOCK / 64) + 1];
-    const double2* __restrict__ rin = reinterpret_cast<const double2*>(parity ? C.r2 : C.r);
-    double2* __restrict__ rout = reinterpret_cast<double2*>(parity ? C.r : C.r2);
-    const double2* __restrict__ pcur = reinterpret_cast<const double2*>(parity ? C.p2 : C.p);
+    const double2* __restrict__ rin = reinterpret_cast<const double2*>(SR ? C.r : (parity ? C.r2 : C.r));
+    double2* __restrict__ rout = reinterpret_cast<double2*>(SR ? C.r : (parity ? C.r : C.r2));
+    const double2* __restrict__ pcur = reinterpret_cast<const double2*>(SR ? C.p : (parity ? C.p2 : C.p));
     const double2* __restrict__ qv = reinterpret_cast<const double2*>(C.q);
     double2* __restrict__ xv = reinterpret_cast<double2*>(C.x);
     double2* __restrict__ zv = reinterpret_cast<double2*>(C.z);
+    double2* __restrict__ pout = reinterpret_cast<double2*>(C.p);      // (SR only)
+    double2* __restrict__ sv = reinterpret_cast<double2*>(C.p2);       // (SR only) s = A p
     // one lane per (keyframe, ROW PAIR): every vector access is 16 B/lane (8-B accesses reach only ~0.6x of the streaming rate);
     // a workgroup covers CG_BLOCK/3 = 64 keyframes per trip
     constexpr int KF = CG_BLOCK / 3;
@@ -1000,10 +1032,12 @@ __global__ __launch_bounds__(CG_BLOCK) void cg_update_kernel(GraphDev G, CgDev C
     // dependent L2 round trips overlap with the streaming loads.  The block-Jacobi factors of the trip's keyframes (two 16-B loads per lane) travel
     // with them — staged through registers, not behind a barrier of their own — and a second trip's operands are requested while the first
     // trip's z is being formed: per trip ONE round trip and one barrier on the critical path.
+    double2 u0 = make_double2(0.0, 0.0), s0 = u0;      // (SR) the preconditioned residual u and s = A p of the trip
     auto load_trip = [&](int64_t base, double2& r_, double2& q_, double2& p_, double2& x_, float4& l0, float4& l1) {
         const int64_t i = base + threadIdx.x;
         r_ = make_double2(0.0, 0.0); q_ = r_; p_ = r_; x_ = r_; l0 = make_float4(0.f, 0.f, 0.f, 0.f); l1 = l0;
-        if (i < pairs) { r_ = rin[i]; q_ = qv[i]; p_ = pcur[i]; x_ = xv[i]; }
+        if (SR) { u0 = r_; s0 = r_; }
+        if (i < pairs) { r_ = rin[i]; q_ = qv[i]; p_ = pcur[i]; x_ = xv[i]; if (SR) { u0 = zv[i]; s0 = sv[i]; } }
         const int64_t first_node = base / 3;
         const float4* lp = reinterpret_cast<const float4*>(C.Lf + (size_t)first_node * LF_STRIDE);
         if (first_node + threadIdx.x / 6 < G.N) l0 = lp[threadIdx.x];
@@ -1011,15 +1045,19 @@ __global__ __launch_bounds__(CG_BLOCK) void cg_update_kernel(GraphDev G, CgDev C
     };
     double2 r0, q0, p0, x0; float4 lf0, lf1;
     load_trip((int64_t)blockIdx.x * CG_BLOCK, r0, q0, p0, x0, lf0, lf1);
-    double pq, rz;   // pq partials are produced by the matvec kernel (its own grid size)
+    double alpha = 0.0, beta = 0.0;
     // (after the first trip's loads are in flight: the flag's and the partial sums' round trip overlaps with theirs)
-    if (block_total2_done(C.flags, C.part_pq, nparts_pq, C.part_rz + parity * RZ_STRIDE, nparts + C.extra_rz, red, pq, rz)) return;
-    if (!(pq > 0.0)) {   // breakdown: matrix not positive definite along p (or NaN); x is left untouched, the next spmv raises done
-        if (blockIdx.x == 0 && threadIdx.x == 0) C.flags[1] = 1;
-        if (threadIdx.x == 0) C.part_rz[(parity ^ 1) * RZ_STRIDE + blockIdx.x] = 0.0;
-        return;
+    if (SR) { if (!sr_head(C, parity, first, nparts_pq, nparts, red, alpha, beta)) return; }
+    else {
+        double pq, rz;   // pq partials are produced by the matvec kernel (its own grid size)
+        if (block_total2_done(C.flags, C.part_pq, nparts_pq, C.part_rz + parity * RZ_STRIDE, nparts + C.extra_rz, red, pq, rz)) return;
+        if (!(pq > 0.0)) {   // breakdown: matrix not positive definite along p (or NaN); x is left untouched, the next spmv raises done
+            if (blockIdx.x == 0 && threadIdx.x == 0) C.flags[1] = 1;
+            if (threadIdx.x == 0) C.part_rz[(parity ^ 1) * RZ_STRIDE + blockIdx.x] = 0.0;
+            return;
+        }
+        alpha = rz / pq;
     }
-    const double alpha = rz / pq;
     __shared__ double2 rnew[CG_BLOCK];
     __shared__ __attribute__((aligned(16))) float lfs[KF * LF_STRIDE];
     static_assert(KF * LF_STRIDE / 4 == 2 * CG_BLOCK, "two 16-B loads per lane stage a trip's factors");
@@ -1030,8 +1068,16 @@ __global__ __launch_bounds__(CG_BLOCK) void cg_update_kernel(GraphDev G, CgDev C
         const bool live = i < pairs;
         double2 rr = make_double2(0.0, 0.0);
         if (live) {
-            rr = make_double2(r0.x - alpha * q0.x, r0.y - alpha * q0.y);
-            x0.x += alpha * p0.x; x0.y += alpha * p0.y;
+            if (SR) {
+                p0.x = u0.x + beta * p0.x; p0.y = u0.y + beta * p0.y;
+                s0.x = q0.x + beta * s0.x; s0.y = q0.y + beta * s0.y;
+                rr = make_double2(r0.x - alpha * s0.x, r0.y - alpha * s0.y);
+                x0.x += alpha * p0.x; x0.y += alpha * p0.y;
+                pout[i] = p0; sv[i] = s0;
+            } else {
+                rr = make_double2(r0.x - alpha * q0.x, r0.y - alpha * q0.y);
+                x0.x += alpha * p0.x; x0.y += alpha * p0.y;
+            }
             rout[i] = rr; xv[i] = x0;
         }
         reinterpret_cast<float4*>(lfs)[threadIdx.x] = lf0; reinterpret_cast<float4*>(lfs)[threadIdx.x + CG_BLOCK] = lf1;
@@ -1217,7 +1263,12 @@ void launch_cg_spmv(const GraphDev& G, const CgDev& C, int k, double tol2, hipSt
 }
 void launch_cg_update(const GraphDev& G, const CgDev& C, int k, int n_pq_partials, hipStream_t st) {
     const int g = cg_grid(G);
-    hipLaunchKernelGGL(cg_update_kernel, dim3(g), dim3(CG_BLOCK), 0, st, G, C, k & 1, n_pq_partials, g);
+    hipLaunchKernelGGL(cg_update_kernel<false>, dim3(g), dim3(CG_BLOCK), 0, st, G, C, k & 1, n_pq_partials, g, 0);
+}
+// single-reduction form: `first` = the PCG's first update (p = s = 0: also when a PCG that stopped before its first update is resumed)
+void launch_cg_update_sr(const GraphDev& G, const CgDev& C, int k, int first, int n_pq_partials, hipStream_t st) {
+    const int g = cg_grid(G);
+    hipLaunchKernelGGL(cg_update_kernel<true>, dim3(g), dim3(CG_BLOCK), 0, st, G, C, k & 1, n_pq_partials, g, first);
 }
 void launch_cgcg_dots(const GraphDev& G, const CgDev& C, hipStream_t st) { hipLaunchKernelGGL(cgcg_dots_kernel, dim3(cg_grid(G)), dim3(CG_BLOCK), 0, st, G, C); }
 void launch_cg_reduce2_live(const CgDev& C, const double* pa, int na, const double* pb, int nb, double* out, hipStream_t st) {
@@ -1312,6 +1363,7 @@ __global__ __launch_bounds__(MF_BLOCK) void mf_spmv_kernel(GraphDev G, MfDev F, 
             }
         }
     }
+    if (!FUSED && first == 3) { if (cg_done(C)) return; }      // the single-reduction PCG's matvec w = A u: nothing but "has the PCG stopped?" stands before the tiles
     if (FUSED) {
         if (first) { if (cg_done(C)) return; }
         else {
@@ -1486,7 +1538,7 @@ __global__ __launch_bounds__(MF_BLOCK) void mf_spmv_kernel(GraphDev G, MfDev F, 
         tl_base += 7;
 #endif
     }
-    if (FUSED || first == 2) {     // plain y = A x with first == 2: the partial sums of x.y as well (the multi-rank PCG's u.(A_r u))
+    if (FUSED || first >= 2) {     // plain y = A x with first == 2 / 3: the partial sums of x.y as well (the multi-rank PCG's u.(A_r u); the one-GPU single-reduction PCG's u.w)
         const double s = block_sum(pq, red);
         if (threadIdx.x == 0) C.part_pq[blockIdx.x] = s;
     }
@@ -1510,6 +1562,10 @@ void launch_mf_spmv_coarse(const GraphDev& G, const MfDev& F, const ScaleDev& Sc
 // y = A x and the per-workgroup partial sums of x.y in C.part_pq[0 .. mf_grid_size): the multi-rank PCG's matvec and its u.(A_r u) in one kernel
 void launch_mf_apply_dot(const GraphDev& G, const MfDev& F, const ScaleDev& Sc, const CgDev& C, const double* x, double* y, hipStream_t st) {
     hipLaunchKernelGGL((mf_spmv_kernel<false, false>), dim3(mf_grid(F)), dim3(MF_BLOCK), 0, st, G, F, Sc, C, x, y, 0, 2, 0, 0.0);
+}
+// the single-reduction PCG on one GPU: w = A u (u in C.z, w in C.q), partial sums of u.w in C.part_pq[0 .. mf_grid_size), nothing once the PCG has stopped
+void launch_mf_apply_dot_live(const GraphDev& G, const MfDev& F, const ScaleDev& Sc, const CgDev& C, hipStream_t st) {
+    hipLaunchKernelGGL((mf_spmv_kernel<false, false>), dim3(mf_grid(F)), dim3(MF_BLOCK), 0, st, G, F, Sc, C, (const double*)C.z, C.q, 0, 3, 0, 0.0);
 }
 void launch_mf_apply(const GraphDev& G, const MfDev& F, const ScaleDev& Sc, const CgDev& C, const double* x, double* y, hipStream_t st) {
     hipLaunchKernelGGL((mf_spmv_kernel<false, false>), dim3(mf_grid(F)), dim3(MF_BLOCK), 0, st, G, F, Sc, C, x, y, 0, 1, 0, 0.0);

@@ -894,16 +894,21 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_prolong0_kernel(GraphDev G, MgDev
 // a run boundary, so r_1 = P_0^T r' of the run's aggregates is formed from the new residual while it is still in LDS (members in list order, the
 // same sums as mg_restrict0_kernel) — and with it x_1 = w D_1^-1 r_1.  The slot table entries a lane needs are requested before the partial-sum
 // re-reduction, together with the vector operands.
-__global__ __launch_bounds__(CG_BLOCK) void cg_update_mg_kernel(GraphDev G, CgDev C, MgDev M, double* __restrict__ r1_out, double* __restrict__ x1_out, const double* __restrict__ Dinv1,
-                                                                 int parity, int nparts_pq, int nparts) {
+// SR: the single-reduction form of the update (cg_update_kernel<true>: p = u + beta p, s = w + beta s, x += alpha p, r -= alpha s in place) with the same restriction.
+template <bool SR>
+__global__ __launch_bounds__(CG_BLOCK, SR ? 3 : 1) void cg_update_mg_kernel(GraphDev G, CgDev C, MgDev M, double* __restrict__ r1_out, double* __restrict__ x1_out, const double* __restrict__ Dinv1,
+                                                                 int parity, int nparts_pq, int nparts, int first) {
     static_assert(CG_BLOCK / 3 == MG_BLOCK0, "one workgroup trip of the vector update = one run of the slot table");
     __shared__ double red[2 * (CG_BLOCK / 64) + 1];
-    const double2* __restrict__ rin = reinterpret_cast<const double2*>(parity ? C.r2 : C.r);
-    double2* __restrict__ rout = reinterpret_cast<double2*>(parity ? C.r : C.r2);
-    const double2* __restrict__ pcur = reinterpret_cast<const double2*>(parity ? C.p2 : C.p);
+    const double2* __restrict__ rin = reinterpret_cast<const double2*>(SR ? C.r : (parity ? C.r2 : C.r));
+    double2* __restrict__ rout = reinterpret_cast<double2*>(SR ? C.r : (parity ? C.r : C.r2));
+    const double2* __restrict__ pcur = reinterpret_cast<const double2*>(SR ? C.p : (parity ? C.p2 : C.p));
     const double2* __restrict__ qv = reinterpret_cast<const double2*>(C.q);
     double2* __restrict__ xv = reinterpret_cast<double2*>(C.x);
     double2* __restrict__ zv = reinterpret_cast<double2*>(C.z);
+    double2* __restrict__ pout = reinterpret_cast<double2*>(C.p);      // (SR only)
+    double2* __restrict__ sv = reinterpret_cast<double2*>(C.p2);       // (SR only) s = A p
+    double2 u0 = make_double2(0.0, 0.0), s0 = u0;
     constexpr int KF = CG_BLOCK / 3;
     const int t = threadIdx.x;
     const int64_t pairs = G.N * 3;
@@ -917,6 +922,7 @@ __global__ __launch_bounds__(CG_BLOCK) void cg_update_mg_kernel(GraphDev G, CgDe
     auto load_trip = [&](int64_t run) {
         const int64_t base = run * CG_BLOCK, i = base + t;
         r0 = make_double2(0.0, 0.0); q0 = r0; p0 = r0; x0 = r0; d0 = d1 = d2 = 0.0;
+        if (SR) { u0 = r0; s0 = r0; }
         lf0 = make_float4(0.f, 0.f, 0.f, 0.f); lf1 = lf0; tab0 = make_int4(-1, -1, -1, 0); tab1 = tab0;
         if (base < pairs) {     // the run exists: its slots are served by all lanes, also those beyond the last keyframe
             tab0 = M.blk_tab[(size_t)run * MG_BLOCK0 + t / 6];
@@ -924,6 +930,7 @@ __global__ __launch_bounds__(CG_BLOCK) void cg_update_mg_kernel(GraphDev G, CgDe
         }
         if (i < pairs) {
             r0 = rin[i]; q0 = qv[i]; p0 = pcur[i]; x0 = xv[i];
+            if (SR) { u0 = zv[i]; s0 = sv[i]; }
             const double* d = M.d0 + (size_t)(i / 3) * 3; d0 = d[0]; d1 = d[1]; d2 = d[2];
         }
         const int64_t first_node = base / 3;
@@ -938,14 +945,18 @@ __global__ __launch_bounds__(CG_BLOCK) void cg_update_mg_kernel(GraphDev G, CgDe
         }
     };
     load_trip((int64_t)blockIdx.x);
-    double pq, rz;
-    if (block_total2_done(C.flags, C.part_pq, nparts_pq, C.part_rz + parity * RZ_STRIDE, nparts + C.extra_rz, red, pq, rz)) return;
-    if (!(pq > 0.0)) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) C.flags[1] = 1;
-        if (threadIdx.x == 0) C.part_rz[(parity ^ 1) * RZ_STRIDE + blockIdx.x] = 0.0;
-        return;
+    double alpha = 0.0, beta = 0.0;
+    if (SR) { if (!sr_head(C, parity, first, nparts_pq, nparts, red, alpha, beta)) return; }
+    else {
+        double pq, rz;
+        if (block_total2_done(C.flags, C.part_pq, nparts_pq, C.part_rz + parity * RZ_STRIDE, nparts + C.extra_rz, red, pq, rz)) return;
+        if (!(pq > 0.0)) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) C.flags[1] = 1;
+            if (threadIdx.x == 0) C.part_rz[(parity ^ 1) * RZ_STRIDE + blockIdx.x] = 0.0;
+            return;
+        }
+        alpha = rz / pq;
     }
-    const double alpha = rz / pq;
     __shared__ double2 rnew[CG_BLOCK];
     __shared__ double2 btr[CG_BLOCK];
     __shared__ double rs[2 * CG_BLOCK];
@@ -959,8 +970,16 @@ __global__ __launch_bounds__(CG_BLOCK) void cg_update_mg_kernel(GraphDev G, CgDe
         const bool live = i < pairs;
         double2 rr = make_double2(0.0, 0.0);
         if (live) {
-            rr = make_double2(r0.x - alpha * q0.x, r0.y - alpha * q0.y);
-            x0.x += alpha * p0.x; x0.y += alpha * p0.y;
+            if (SR) {
+                p0.x = u0.x + beta * p0.x; p0.y = u0.y + beta * p0.y;
+                s0.x = q0.x + beta * s0.x; s0.y = q0.y + beta * s0.y;
+                rr = make_double2(r0.x - alpha * s0.x, r0.y - alpha * s0.y);
+                x0.x += alpha * p0.x; x0.y += alpha * p0.y;
+                pout[i] = p0; sv[i] = s0;
+            } else {
+                rr = make_double2(r0.x - alpha * q0.x, r0.y - alpha * q0.y);
+                x0.x += alpha * p0.x; x0.y += alpha * p0.y;
+            }
             rout[i] = rr; xv[i] = x0;
         }
         reinterpret_cast<float4*>(lfs)[t] = lf0; reinterpret_cast<float4*>(lfs)[t + CG_BLOCK] = lf1;
@@ -1024,8 +1043,13 @@ __global__ __launch_bounds__(CG_BLOCK) void cg_update_mg_kernel(GraphDev G, CgDe
 }
 void launch_cg_update_mg(const GraphDev& G, const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, int k, int n_pq_partials, hipStream_t st) {
     const int g = cg_grid(G);
-    if (M.n_levels == 1) hipLaunchKernelGGL(cg_update_mg_kernel, dim3(g), dim3(CG_BLOCK), 0, st, G, C, M, K.rc, (double*)nullptr, (const double*)nullptr, k & 1, n_pq_partials, g);
-    else hipLaunchKernelGGL(cg_update_mg_kernel, dim3(g), dim3(CG_BLOCK), 0, st, G, C, M, levels[0].r, levels[0].x, (const double*)levels[0].Dinv, k & 1, n_pq_partials, g);
+    if (M.n_levels == 1) hipLaunchKernelGGL(cg_update_mg_kernel<false>, dim3(g), dim3(CG_BLOCK), 0, st, G, C, M, K.rc, (double*)nullptr, (const double*)nullptr, k & 1, n_pq_partials, g, 0);
+    else hipLaunchKernelGGL(cg_update_mg_kernel<false>, dim3(g), dim3(CG_BLOCK), 0, st, G, C, M, levels[0].r, levels[0].x, (const double*)levels[0].Dinv, k & 1, n_pq_partials, g, 0);
+}
+void launch_cg_update_mg_sr(const GraphDev& G, const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, int k, int first, int n_pq_partials, hipStream_t st) {
+    const int g = cg_grid(G);
+    if (M.n_levels == 1) hipLaunchKernelGGL(cg_update_mg_kernel<true>, dim3(g), dim3(CG_BLOCK), 0, st, G, C, M, K.rc, (double*)nullptr, (const double*)nullptr, k & 1, n_pq_partials, g, first);
+    else hipLaunchKernelGGL(cg_update_mg_kernel<true>, dim3(g), dim3(CG_BLOCK), 0, st, G, C, M, levels[0].r, levels[0].x, (const double*)levels[0].Dinv, k & 1, n_pq_partials, g, first);
 }
 void launch_mg_restrict0(const GraphDev& G, const MgDev& M, const double* v, double* out, bool own_weighted, hipStream_t st) {
     const unsigned g1 = (unsigned)((M.n1 + MG_TILE_ROWS - 1) / MG_TILE_ROWS);

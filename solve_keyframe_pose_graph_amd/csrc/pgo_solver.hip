@@ -230,7 +230,7 @@ struct pgo_problem {
 
     // hipGraph of one PCG chunk (launch-bound inner loop); valid for (graph build epoch, tolerance, chunk length, solver)
     // one captured chunk per preconditioner (0 block-Jacobi, 1 two-level, 2 multigrid): the hybrid policy changes between them inside a solve
-    struct CapturedChunk { hipGraphExec_t exec = nullptr; int len = 0; uint64_t epoch = 0; double scale = 0.0; };   // scale: mg_correction_scale is a by-value kernel argument of the captured cycle
+    struct CapturedChunk { hipGraphExec_t exec = nullptr; int len = 0; uint64_t epoch = 0; double scale = 0.0; bool sr = false; };   // scale: mg_correction_scale is a by-value kernel argument of the captured cycle
     CapturedChunk cg_chunk[3];
     hipGraphExec_t cg_graph = nullptr;   // the one in use (not owned)
     uint64_t build_epoch = 1; bool cg_graph_failed = false;
@@ -1137,6 +1137,13 @@ double mg_scale(const pgo_problem* p) { return p->opt.mg_correction_scale >= 1.0
 
 struct CgResult { int iterations; bool breakdown; double rel_residual; bool converged; };
 
+// One GPU, matrix-free matvec, tolerance not below 1e-11: the PCG runs in its single-reduction (Chronopoulos-Gear) form — matvec w = A u with the partials of u.w, then ONE
+// vector kernel whose head re-reduces u.w and r.u together (pgo_kernels.hip: sr_head).  Decided by the options alone, so every phase of a paused PCG runs the same form.
+// The two-level method keeps the classic form (its fused three-kernel iteration folds the prolongation into the direction update of the classic matvec).
+bool single_reduction(const pgo_problem* p) {
+    return p->opt.cg_single_reduction != 0 && !p->local_ids && p->built_mf && p->opt.cg_rel_tolerance >= 1e-11 && !(p->coarse_active && !p->mg_active);
+}
+
 // rel_tol: relative tolerance of this phase.  resume_from >= 0: continue the stopped PCG at that iteration index with the new tolerance
 // (device state x, r, z, p and the partial sums are those of `resume_from` completed iterations).
 int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume_from, bool switch_now = false) {
@@ -1211,7 +1218,17 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
     };
     every = chunk_length();
     int rc;
+    const bool sr = single_reduction(p);
     auto one_iteration = [&](int kk) -> int {
+        if (sr) {      // matvec (no head: it only asks whether the PCG has stopped), update with the iteration's one reduction point, [the multigrid cycle]
+            launch_mf_apply_dot_live(p->G, p->F, p->Sc, p->C, p->st);
+            const int n_pq = mf_grid_size(p->F), first = kk == 0 ? 1 : 0;      // (first: also when a PCG that stopped before its first update is resumed — p = s = 0 still)
+            const bool mg_restrict_fused = p->mg_active && p->M.blk_tab != nullptr;
+            if (mg_restrict_fused) launch_cg_update_mg_sr(p->G, p->C, p->M, p->mg_levels, p->K, kk, first, n_pq, p->st);
+            else launch_cg_update_sr(p->G, p->C, kk, first, n_pq, p->st);
+            if (p->mg_active) launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz + (size_t)((kk & 1) ^ 1) * RZ_STRIDE, mg_scale(p), true, p->st, mg_restrict_fused, mg_cs(p));
+            return PGO_OK;
+        }
         if (multi) {
             const int g = cg_grid_size(p->G);
             int g_pq = g;
@@ -1264,7 +1281,7 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
     auto ensure_graph = [&](bool may_capture) {
         const int mode = p->mg_active ? 2 : p->coarse_active ? 1 : 0;
         pgo_problem::CapturedChunk& cc = p->cg_chunk[mode];
-        if (!want_graph || p->cg_graph_failed || (cc.exec != nullptr && cc.epoch == p->build_epoch && cc.len == every && cc.scale == mg_scale(p))) { p->cg_graph = want_graph && !p->cg_graph_failed ? cc.exec : nullptr; return; }
+        if (!want_graph || p->cg_graph_failed || (cc.exec != nullptr && cc.epoch == p->build_epoch && cc.len == every && cc.scale == mg_scale(p) && cc.sr == sr)) { p->cg_graph = want_graph && !p->cg_graph_failed ? cc.exec : nullptr; return; }
         if (!may_capture) { p->cg_graph = nullptr; return; }
         if (cc.exec) { (void)hipGraphExecDestroy(cc.exec); cc.exec = nullptr; }
         hipGraph_t gr = nullptr;
@@ -1278,7 +1295,7 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
         if (o.verbosity > 1) std::fprintf(stderr, "[pgo] PCG chunk of %d iterations (preconditioner %d) captured, instantiated in %.2f ms\n", every, mode, (now_s() - t_inst) * 1e3);
         if (gr) (void)hipGraphDestroy(gr);
         if (!ok) { cc.exec = nullptr; p->cg_graph_failed = true; (void)hipGetLastError(); }
-        else { cc.epoch = p->build_epoch; cc.len = every; cc.scale = mg_scale(p); }
+        else { cc.epoch = p->build_epoch; cc.len = every; cc.scale = mg_scale(p); cc.sr = sr; }
         p->cg_graph = cc.exec;
     };
     ensure_graph(k >= graph_after);
@@ -1391,7 +1408,8 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
     res->converged = hflags[0] != 0 && hflags[1] == 0;
     if (!hflags[0] && !multi) {   // iteration cap reached: one more convergence test so that scal[1] holds the last r.z (x is already final)
         launch_cg_set_tolerance(p->C, 1e300, p->st);
-        if (fused_coarse) launch_mf_spmv_coarse(p->G, p->F, p->Sc, p->C, p->K, k, 1e300, fused_parts, k > 0 ? 1 : 0, p->st);
+        if (sr) { if ((rc = one_iteration(k)) != PGO_OK) return rc; }      // (its update's head finds r.u below the tolerance: scal[1] <- r.u, nothing else moves)
+        else if (fused_coarse) launch_mf_spmv_coarse(p->G, p->F, p->Sc, p->C, p->K, k, 1e300, fused_parts, k > 0 ? 1 : 0, p->st);
         else if (p->built_mf) launch_mf_spmv(p->G, p->F, p->Sc, p->C, k, 1e300, p->st);
         else launch_cg_spmv(p->G, p->C, k, 1e300, p->st);
         HIPCHK(p, hipMemcpyAsync(hflags, p->C.flags, sizeof(hflags), hipMemcpyDeviceToHost, p->st));
@@ -1769,7 +1787,12 @@ int lm_step(pgo_problem* p, int ignore_termination, int* done) {
         // on a 400-keyframe trigger, 63.2 -> 60.3 ms at 3 000.  So below CG_PAUSE_MIN_KEYFRAMES the pauses are armed by the first rejected step of the solve (a rejection is
         // usually followed by more: the radius shrinks in several steps) — a rule that depends on the solve's own history only.
         constexpr int64_t CG_PAUSE_MIN_KEYFRAMES = 20000;
-        const bool pauses = p->N_global >= CG_PAUSE_MIN_KEYFRAMES || p->sum.num_unsuccessful_steps > 0;
+        // ... and (round 5) only where a rejection is in the air — the rule build_system defers the multigrid by: the previous step was rejected (rejections come in streaks) or
+        // the last accepted step's relative decrease fell below 0.8 (C3's and C4's first rejected steps follow rho = 0.67 and 0.62, their long runs of accepted steps
+        // rho >= 0.89).  A system whose step is accepted pays ~0.25 ms per pause for nothing (candidate evaluation, the drain of the chunk in flight, a host round trip):
+        // 13 of C3's 20 steps.  The PCG's own iterates do not depend on where it pauses.
+        const bool rejection_likely = p->reuse_diagonal || p->last_rho < 0.8;
+        const bool pauses = (p->N_global >= CG_PAUSE_MIN_KEYFRAMES || p->sum.num_unsuccessful_steps > 0) && (rejection_likely || p->opt.cg_pause_always != 0);
         if (pauses && o.cg_early_tolerance > o.cg_rel_tolerance) stages[n_stages++] = Stage{o.cg_early_tolerance, o.cg_early_reject_rho};
         if (pauses && o.cg_mid_tolerance > o.cg_rel_tolerance && (n_stages == 0 || o.cg_mid_tolerance < stages[0].tol)) stages[n_stages++] = Stage{o.cg_mid_tolerance, o.cg_mid_reject_rho};
         const bool warm = o.cg_warm_start != 0 && p->have_prev_step && p->reuse_diagonal;
@@ -1846,12 +1869,15 @@ int lm_step(pgo_problem* p, int ignore_termination, int* done) {
     }
     it.cg_iterations = cg.iterations + p->cg_extra; it.cg_residual = cg.rel_residual;
     const double t_solved = now_s();
+    it.seconds_system = t_built - t0; it.seconds_pcg = t_solved - t_built;
+    it.cg_iterations_multigrid = p->mg_active ? cg.iterations : 0; it.single_reduction = ok && single_reduction(p) ? 1 : 0;
     if (o.verbosity > 1) std::fprintf(stderr, "[pgo] it %3d PCG: %d iterations%s after %d with block-Jacobi; system + preconditioner %.3f ms, PCG %.3f ms\n", p->iteration, cg.iterations, p->mg_active ? " with the multigrid" : "", p->cg_extra, (t_built - t0) * 1e3, (t_solved - t_built) * 1e3);
     p->sum.cg_iterations += cg.iterations + p->cg_extra;
     if (p->mg_active) p->sum.cg_iterations_multigrid += cg.iterations;     // iterations before an in-flight switch (cg_extra) ran with block-Jacobi
     if (ok) {
         if (!evaluated && (rc = evaluate_candidate()) != PGO_OK) return rc;
-        if (o.verbosity > 1) std::fprintf(stderr, "[pgo] it %3d candidate evaluated in %.3f ms\n", p->iteration, (now_s() - t_solved) * 1e3);
+        it.seconds_evaluate = now_s() - t_solved;
+        if (o.verbosity > 1) std::fprintf(stderr, "[pgo] it %3d candidate evaluated in %.3f ms\n", p->iteration, it.seconds_evaluate * 1e3);
         it.model_cost_change = -h[S_MODEL];
         if (!(it.model_cost_change > 0.0) || !std::isfinite(it.model_cost_change)) { ok = false; why_invalid = PGO_STEP_INVALID_MODEL; }
     }
@@ -1894,7 +1920,8 @@ int lm_step(pgo_problem* p, int ignore_termination, int* done) {
         double c = 0;
         const double t_lin = now_s();
         if ((rc = linearize(p, &c)) != PGO_OK) return rc;
-        if (o.verbosity > 1) std::fprintf(stderr, "[pgo] it %3d linearised in %.3f ms\n", p->iteration, (now_s() - t_lin) * 1e3);
+        it.seconds_linearize = now_s() - t_lin;
+        if (o.verbosity > 1) std::fprintf(stderr, "[pgo] it %3d linearised in %.3f ms\n", p->iteration, it.seconds_linearize * 1e3);
         p->x_cost = c;
         it.step_is_successful = 1;
         p->radius = p->radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * it.relative_decrease - 1.0, 3));   // StepAccepted
@@ -2046,6 +2073,8 @@ void pgo_options_init(pgo_options* o) {
     o->cg_rel_tolerance = 3e-10;    // keeps the 10-iteration chi^2 of C3 within 1e-8 of the independent CPU trajectory whatever the preconditioner schedule (1e-9: 1e-7)
     o->device_id = -1;
     o->verbosity = 0;
+    o->cg_single_reduction = 1;
+    o->cg_pause_always = 0;
 }
 
 int pgo_create(pgo_problem** out, const pgo_options* opts) {
@@ -2594,34 +2623,46 @@ int pgo_time_kernel(pgo_problem* p, int32_t which, int32_t launches, double* avg
                 case 1: launch_k2(G, p->L, !p->built_mf, p->st, p->built_mf ? &p->F : nullptr); bytes = (624.0 * G.rel.E + 688.0 * Es) + 288.0 * E + 336.0 * N + 112.0 * Es; break;
                 case 2: case 4: case 5: {   // one PCG iteration (2), its matvec alone (4), its vector update alone (5)
                           const int kk = rep == 0 ? 0 : i + 1;
-                          if (which != 5) { if (p->built_mf) launch_mf_spmv(G, p->F, p->Sc, p->C, kk, 0.0, p->st); else launch_cg_spmv(G, p->C, kk, 0.0, p->st); }
-                          if (which != 4) launch_cg_update(G, p->C, kk, p->built_mf ? mf_grid_size(p->F) : cg_grid_size(G), p->st);
+                          const bool sr = single_reduction(p);      // the form the solver runs on this handle
+                          if (sr) {
+                              if (which != 5) launch_mf_apply_dot_live(G, p->F, p->Sc, p->C, p->st);
+                              if (which != 4) launch_cg_update_sr(G, p->C, kk, kk == 0 ? 1 : 0, mf_grid_size(p->F), p->st);
+                          } else {
+                              if (which != 5) { if (p->built_mf) launch_mf_spmv(G, p->F, p->Sc, p->C, kk, 0.0, p->st); else launch_cg_spmv(G, p->C, kk, 0.0, p->st); }
+                              if (which != 4) launch_cg_update(G, p->C, kk, p->built_mf ? mf_grid_size(p->F) : cg_grid_size(G), p->st);
+                          }
                           // Bytes this design moves per iteration, each array once.  Matrix-free matvec: per LANE (a relative-pose edge with both
                           // keyframes in one tile is one lane, every other edge side its own) the compact record (8 double2 planes; 11 for switchable
                           // sides) + 12 B of index data (+ a_inv for switchable sides); per keyframe z and p_prev read, p and q written (4 x 48),
                           // damping 48, side ranges / regulariser index / free flag 13.  Update: r, q, p, x read, r, x, z written (7 x 48), the fp32
                           // block-Jacobi factor 96.  Block-CSR matvec: SURVEY.md 8d's assembled form.
                           const double lanes_rel = (double)(p->mf_pair_lanes + p->mf_rel_side_lanes), lanes_sw = (double)p->mf_sw_lanes;
-                          const double mv = p->built_mf ? lanes_rel * (128.0 + 12.0) + lanes_sw * (128.0 + 12.0 + 8.0) + N * (4.0 * 48.0 + 48.0 + 13.0)
+                          // Single-reduction form: the matvec reads u and writes w (2 x 48 per keyframe instead of 4 x 48); the update reads u, w, p, s, x, r and writes p, s, x, r, u (11 x 48).
+                          const double mv = p->built_mf ? lanes_rel * (128.0 + 12.0) + lanes_sw * (128.0 + 12.0 + 8.0) + N * ((sr ? 2.0 : 4.0) * 48.0 + 48.0 + 13.0)
                                                         : 288.0 * (N + 2.0 * E) + 4.0 * (N + 2.0 * E) + N * 4.0 * 48.0;
-                          const double up = N * (7.0 * 48.0 + 96.0);
+                          const double up = N * ((sr ? 11.0 : 7.0) * 48.0 + 96.0);
                           bytes = which == 2 ? mv + up : which == 4 ? mv : up;
                           break; }
                 case 3: launch_k1(G, p->d_pose[nxt].p, p->d_swv[nxt].p, false, part(p, 5), &np, p->st); bytes = k1_algorithmic_bytes(G, false); break;
                 case 6: case 7: {
                           const int kk = rep == 0 ? 0 : i + 1;
                           const bool fused = p->M.blk_tab != nullptr;
-                          if (which == 6) {
+                          const bool sr = single_reduction(p);
+                          if (which == 6 && sr) {
+                              launch_mf_apply_dot_live(G, p->F, p->Sc, p->C, p->st);
+                              if (fused) launch_cg_update_mg_sr(G, p->C, p->M, p->mg_levels, p->K, kk, kk == 0 ? 1 : 0, mf_grid_size(p->F), p->st);
+                              else launch_cg_update_sr(G, p->C, kk, kk == 0 ? 1 : 0, mf_grid_size(p->F), p->st);
+                          } else if (which == 6) {
                               launch_mf_spmv(G, p->F, p->Sc, p->C, kk, 0.0, p->st);
                               if (fused) launch_cg_update_mg(G, p->C, p->M, p->mg_levels, p->K, kk, mf_grid_size(p->F), p->st);
                               else launch_cg_update(G, p->C, kk, mf_grid_size(p->F), p->st);
                           }
-                          launch_mg_apply(G, p->C, p->M, p->mg_levels, p->K, (kk & 1) ? p->C.r : p->C.r2, p->C.z, p->C.part_rz + (size_t)((kk & 1) ^ 1) * RZ_STRIDE, mg_scale(p), true, p->st, which == 6 && fused, mg_cs(p));
+                          launch_mg_apply(G, p->C, p->M, p->mg_levels, p->K, sr ? p->C.r : ((kk & 1) ? p->C.r : p->C.r2), p->C.z, p->C.part_rz + (size_t)((kk & 1) ^ 1) * RZ_STRIDE, mg_scale(p), true, p->st, which == 6 && fused, mg_cs(p));
                           // Bytes of this design, each array once per kernel that streams it.  Fine level as in case 2 (+ the restriction's per-keyframe offsets and slot table,
                           // the prolongation's read-modify-write of z, offsets and aggregate index); every sparse coarse level: its fp32 blocks and column indices twice
                           // (down- and up-sweep), Dinv, positions/offsets and its four vectors; the dense level: the fp32 inverse once.
                           const double lanes_rel = (double)(p->mf_pair_lanes + p->mf_rel_side_lanes), lanes_sw = (double)p->mf_sw_lanes;
-                          const double fine = lanes_rel * (128.0 + 12.0) + lanes_sw * (128.0 + 12.0 + 8.0) + N * (4.0 * 48.0 + 48.0 + 13.0) + N * (7.0 * 48.0 + 96.0);
+                          const double fine = lanes_rel * (128.0 + 12.0) + lanes_sw * (128.0 + 12.0 + 8.0) + N * ((sr ? 2.0 : 4.0) * 48.0 + 48.0 + 13.0) + N * ((sr ? 11.0 : 7.0) * 48.0 + 96.0);
                           double cyc = N * (24.0 + 16.0 / 8.0 * 8.0) /* d0 + slot table (restriction) */ + N * (2.0 * 48.0 + 24.0 + 4.0 + 4.0) /* z read + write, d0, agg0, member list (prolongation) */;
                           for (int l = 0; l + 1 < p->M.n_levels; ++l) {
                               const MgLevelDev& A = p->mg_levels[l];
@@ -2731,5 +2772,9 @@ const char* pgo_strerror(int code) {
     }
 }
 const char* pgo_last_error(const pgo_problem* p) { return p ? p->err.c_str() : ""; }
+#ifndef PGO_SOURCE_SHA256
+#define PGO_SOURCE_SHA256 "unknown (not built by _build.py)"
+#endif
+const char* pgo_build_info(void) { return "libpgo sources sha256:" PGO_SOURCE_SHA256; }
 
 }  // extern "C"

@@ -37,7 +37,7 @@ _GPU_ANCHORS = [
 ]
 _GPU_FILE_ORDER = [
     "test_gpu_parity.py", "test_gpu_fullsize.py", "test_gpu_host_shim.py", "test_gpu_vio_construction.py", "test_gpu_fuzz.py",
-    "test_gpu_failure_contract.py", "test_gpu_breakdown_retry.py", "test_gpu_determinism.py",
+    "test_gpu_failure_contract.py", "test_gpu_breakdown_retry.py", "test_gpu_determinism.py", "test_gpu_single_reduction.py",
     "test_gpu_two_ranks_one_gpu.py", "test_gpu_c5.py", "test_gpu_multigrid.py", "test_gpu_coarse.py",
 ]
 

@@ -26,6 +26,14 @@ def test_library_exports_every_declared_symbol():
     assert sorted(capi.EXPORTS) == names
 
 
+def test_library_records_the_hash_of_the_sources_it_was_built_from():
+    """pgo_build_info(): the source-tree hash the build recipe compiled in equals the hash recomputed from this checkout (include/pgo.h; the recipe also makes the build
+    reproducible byte for byte: fixed compilation-unit ids, paths relative to the repo root, no linker build-id)."""
+    capi._lib = None
+    in_lib, in_tree = capi.build_info()
+    assert len(in_tree) == 64 and in_lib == in_tree, (in_lib, in_tree)
+
+
 def test_graphgen_exports_every_declared_symbol():
     lib = C.CDLL(_build.build_graphgen())
     for n in header_functions(os.path.join(ROOT, "include", "pgo_graphgen.h")):

@@ -1,0 +1,79 @@
+"""GPU: the single-reduction (Chronopoulos-Gear) form of the PCG on one GPU (pgo_options.cg_single_reduction, default on for cg_rel_tolerance >= 1e-11) against the classic
+two-reduction form: in exact arithmetic the same iterates, so the LM trajectory must be the classic one to the PCG tolerance, with (nearly) the same iteration counts — under
+block-Jacobi, under the multigrid (restriction inside the update, coarse part of r.u from the level-1 kernel), through early-rejection pauses (stop / resume), the in-flight
+switch to the multigrid and warm starts after rejected steps.  And against the oracle's exact solve where that is affordable."""
+import numpy as np
+import pytest
+
+from solve_keyframe_pose_graph_amd import capi, graphgen
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def solve(g, switchable, **kw):
+    q, t, s = util.initial_state(g, switchable)
+    P = util.pgo_problem(g, switchable, **kw)
+    out = P.solve(q, t, s)
+    P.close()
+    return out
+
+
+def same_trajectory(a, b, rel=1e-7):
+    assert a.num_logged == b.num_logged
+    for k in range(a.num_logged):
+        x, y = a.iterations[k], b.iterations[k]
+        assert (x.step_is_valid, x.step_is_successful) == (y.step_is_valid, y.step_is_successful), k
+        assert abs(x.cost - y.cost) <= rel * max(x.cost, 1e-12), (k, x.cost, y.cost)
+
+
+@pytest.mark.parametrize("name", ["P9000", "G12000", "G30000", "C2"])
+def test_same_trajectory_and_iteration_counts_as_the_classic_form(name):
+    if name == "P9000":        # plain loops below mg_min_keyframes: two-level method -> classic form on both sides unless the comparison drops it (then block-Jacobi: single reduction)
+        g, sw, kw = graphgen.generate(9000, 900, odom_f_max=1, seed=4, outlier_frac=0.0), False, dict(max_num_iterations=12)
+    elif name == "G12000":     # switchable, multigrid hierarchy, hybrid start
+        g, sw, kw = graphgen.generate(12000, 12000, odom_f_max=2, seed=3), True, dict(max_num_iterations=14)
+    elif name == "G30000":     # rejected steps, pauses, warm starts, the multigrid from the first iteration of hard systems
+        g, sw, kw = graphgen.generate(30000, 30000, odom_f_max=2, seed=5), True, dict(max_num_iterations=16)
+    else:
+        g, sw, kw = graphgen.config("C2"), False, dict(coarse_aggregates=0)       # plain block-Jacobi, thousands of iterations per system
+    _, t0, s0, classic = solve(g, sw, cg_single_reduction=0, **kw)
+    _, t1, s1, single = solve(g, sw, cg_single_reduction=1, **kw)
+    same_trajectory(classic, single)
+    assert abs(single.cg_iterations - classic.cg_iterations) <= 0.05 * classic.cg_iterations + 8, (single.cg_iterations, classic.cg_iterations)
+    assert np.abs(t1 - t0).max() <= 1e-5
+    if sw:
+        assert np.abs(s1 - s0).max() <= 1e-5
+
+
+def test_mid_size_graph_against_the_oracle_in_the_single_reduction_form():
+    """6 000 keyframes / 3 000 switchable closures with the two-level method and the multigrid both off: every system is solved by the single-reduction block-Jacobi PCG
+    (up to a few thousand iterations at the large radii); per-iteration costs against the oracle's exact Cholesky."""
+    g = graphgen.generate(6000, 3000, odom_f_max=2, seed=21, outlier_frac=0.1)
+    q, t, s = util.initial_state(g, True)
+    _, to, so, sumo = util.oracle_problem(g, True).solve(q, t, s)
+    _, tp, sp, sump = solve(g, True, coarse_aggregates=0, mg_min_keyframes=0, cg_single_reduction=1)
+    assert [sump.iterations[k].step_is_successful for k in range(sump.num_logged)] == [sumo.iterations[k].step_is_successful for k in range(sumo.num_logged)]
+    for k in range(sumo.num_logged):
+        assert abs(sumo.iterations[k].cost - sump.iterations[k].cost) <= 1e-6 * sumo.iterations[k].cost, k
+    assert np.abs(sp - so).max() <= 1e-3
+
+
+def test_tight_tolerances_keep_the_classic_form():
+    """cg_rel_tolerance < 1e-11 (the parity settings of the other test files): the option is ignored, the result is bit for bit the one of cg_single_reduction = 0."""
+    g = graphgen.generate(9000, 9000, odom_f_max=2, seed=3)
+    _, t0, s0, a = solve(g, True, cg_rel_tolerance=1e-12, cg_single_reduction=0, max_num_iterations=6)
+    _, t1, s1, b = solve(g, True, cg_rel_tolerance=1e-12, cg_single_reduction=1, max_num_iterations=6)
+    assert np.array_equal(t0, t1) and np.array_equal(s0, s1)
+    assert [a.iterations[k].cg_iterations for k in range(a.num_logged)] == [b.iterations[k].cg_iterations for k in range(b.num_logged)]
+
+
+def test_iteration_cap_and_breakdown_paths_in_the_single_reduction_form():
+    """A capped PCG (cg_max_iterations) reports its iteration count and residual and the solve goes on with the inexact step, as in the classic form."""
+    g = graphgen.generate(9000, 9000, odom_f_max=2, seed=3)
+    _, _, _, a = solve(g, True, cg_max_iterations=40, mg_min_keyframes=0, coarse_aggregates=0, cg_single_reduction=1, max_num_iterations=4)
+    _, _, _, b = solve(g, True, cg_max_iterations=40, mg_min_keyframes=0, coarse_aggregates=0, cg_single_reduction=0, max_num_iterations=4)
+    for k in range(1, a.num_logged):
+        assert a.iterations[k].cg_iterations <= 40 and a.iterations[k].cg_iterations == b.iterations[k].cg_iterations
+        assert a.iterations[k].cg_residual > 0 and abs(a.iterations[k].cg_residual - b.iterations[k].cg_residual) <= 1e-6 * b.iterations[k].cg_residual + 1e-300
+    same_trajectory(a, b, rel=1e-8)
