@@ -232,11 +232,11 @@ def main():
             hip.hipMemcpy(buf, host.data_ptr(), count * 8, 1)
             return 0
 
-    def make_problem():
+    def make_problem(graph=None, graph_shard=None):
         """A FRESH handle: the library keeps per-handle history between solves (which preconditioner paid last time, for the incremental
         triggers of a session), so every leg of the benchmark — warm-up, timed, including-transfers — gets its own handle and the timed
         region is a function of (graph, options) alone."""
-        P = capi.problem_from_graph(g, switchable=True, edge_slice=shard if world > 1 else None, device_id=device_index, max_num_iterations=10 ** 6, **opt)
+        P = capi.problem_from_graph(graph if graph is not None else g, switchable=True, edge_slice=(graph_shard if graph is not None else shard) if world > 1 else None, device_id=device_index, max_num_iterations=10 ** 6, **opt)
         if world > 1 and args.collective == "rccl":
             uid = [capi.Problem.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(uid, src=0)
@@ -324,6 +324,41 @@ def main():
     elapsed_incl = time.perf_counter() - t_incl
 
     drop_problem(P)
+
+    # ---- several ranks, default (weak) run: BASELINE.json config 5 as well — the SAME 1M-pose / 3M-edge graph whatever N, its edges sharded over the ranks (strong scaling) —
+    # so that a scaling run carries the configured multi-GPU workload next to the weak N x C3 `value`.  A bounded leg: at most 5 LM iterations after 1 warm-up iteration.
+    c5_strong = None
+    if world > 1 and not strong:
+        try:
+            g5 = graphgen.config("C5")
+            parts5 = sharding.partition(g5, world, args.partition)
+            stats5 = sharding.partition_stats(g5, parts5) if rank == 0 else None
+            k5 = max(1, min(args.steps, 5))
+            P5 = make_problem(g5, parts5[rank])
+            q5, t5, s5 = g5.init_q, g5.init_t, np.full(g5.n_loops, 0.99)
+            P5.solve_begin(q5, t5, s5)
+            P5.lm_step(ignore_termination=True)
+            P5.solve_end()
+            P5.solve_begin(q5, t5, s5)
+            barrier(); P5.synchronize()
+            t5_0 = time.perf_counter()
+            for _ in range(k5):
+                P5.lm_step(ignore_termination=True)
+            P5.synchronize(); barrier()
+            el5 = time.perf_counter() - t5_0
+            tt = torch.tensor([el5], dtype=torch.float64, device="cuda" if args.collective == "rccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el5 = float(tt.item())
+            _, _, _, sum5 = P5.solve_end()
+            drop_problem(P5)
+            if rank == 0:
+                c5_strong = {"workload": "C5: synthetic 3D Manhattan graph, %d poses / %d edges, the same graph on every rank count (BASELINE.json config 5), edges sharded by the '%s' policy" % (g5.n_poses, g5.n_odom + g5.n_loops, args.partition),
+                             "scaling": "strong", "steps": k5, "seconds": el5, "lm_iters_per_s": k5 / el5, "chi2_final": 2.0 * sum5.final_cost, "cg_iterations_total": int(sum5.cg_iterations),
+                             "cg_iterations_multigrid": int(sum5.cg_iterations_multigrid), "shared_keyframes": stats5["shared_keyframes"], "edges_per_rank": [min(stats5["edges_per_rank"]), max(stats5["edges_per_rank"])],
+                             "note": "one all-reduce per CG iteration over the union of shared keyframes (+ the multigrid's level-1 vector); the coarse levels are replicated on every rank (DESIGN.md §8): what limits this figure"}
+            del g5, parts5
+        except Exception as e:      # the weak figure above is the contract; this leg is reported when it runs
+            c5_strong = {"error": repr(e)}
 
     # ---- K1 once more where its output cannot sit in the 256 MiB Infinity Cache: C3's 194 MB of Jacobian blocks are absorbed by it (plain
     # stores), so the C3 figure is an HBM + cache number; 400k keyframes / 1.2M edges write 775 MB with non-temporal stores
@@ -423,7 +458,7 @@ def main():
             "libpgo_sha256": lib_sha, "static_traffic_notes": traffic_note or None,
             # the hash of the sources the loaded library was built from (compiled in by _build.py) next to the hash of this checkout's sources: equal = built from this tree
             "libpgo_sources_sha256": capi.build_info()[0], "checkout_sources_sha256": capi.build_info()[1],
-            "lm_iters_per_s_raw": ips,
+            "lm_iters_per_s_raw": ips, "c5_strong": c5_strong,
             "lm_iters_per_s_including_transfers": args.steps / elapsed_incl * scale,   # upload of the state, K iterations, write-back (rank 0's clock)
             "chi2_initial": 2.0 * summ.initial_cost, "chi2_final": 2.0 * summ.final_cost,
             "chi2_ref": chi2_ref, "chi2_rel_diff": chi2_rel,   # reference = the CPU trajectory after the same number of LM iterations (null: no golden for this workload / step count)

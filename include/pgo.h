@@ -182,6 +182,10 @@ typedef struct pgo_options {
                                           *    ONE partial-sum re-reduction per iteration (in the vector update) instead of two — whenever cg_rel_tolerance >= 1e-11; the same iterates in exact
                                           *    arithmetic, its attainable accuracy is a little lower, so tighter tolerances (the 1e-12 / 1e-13 parity settings) keep the classic two-reduction
                                           *    form, and so does the two-level method's fused three-kernel iteration.  0: classic form everywhere.  Several ranks always run the single-reduction form. */
+    int32_t mg_explicit_transfer;        /* 1: a multigrid level with a smoothed transition above it applies that transition through the EXPLICIT operator R^T = Ps - Dinv W (fp32 blocks on the
+                                          *    pattern of W = A Ps, formed once per LM system): pre-smoothing step + smoothed restriction and smoothed prolongation + post-smoothing step
+                                          *    become  v = x + Dinv (r - A x), r_next = R r  and  x = v + R^T x_next — two row products on that level per cycle, two launches fewer per
+                                          *    PCG iteration; algebraically the same V(1,1) cycle.  0: the implicit form of rounds 3-4 (four row products with the level's own matrix) */
     int32_t cg_pause_always;             /* 0: the early-rejection pauses are armed only where a rejection is in the air (previous step rejected, or the last accepted step's relative decrease
                                           *    below 0.8); 1: at every LM system of graphs >= 20 000 keyframes / after the solve's first rejection (round 4's rule) */
 } pgo_options;

@@ -158,6 +158,12 @@ struct MgLevelDev {
     // (14 dependent loads at the head of every wavefront of level 1)
     const int32_t* row_of; const int32_t* tr_of;                 // [nnzb] row of block k; slot of block (col, row) (k itself on the diagonal or when absent)
     const int32_t* ps_row; const int32_t* w_row;                 // [n_ps], [n_w] rows of the blocks of Ps and W
+    // explicit transfer operator of the smoothed transition (pgo_mg_host.hpp; null / 0 when off: the cycle then applies Ps implicitly, four row products on this level):
+    // R^T = Ps - Dinv W as fp32 blocks on W's pattern (w_rowptr / w_col; per tile of THIS level the block range of each row: rt_rows), R by coarse row (rT_col = fine row,
+    // r_valf = the transposed fp32 blocks — the same rounded numbers; tiles of (MG_TILE_ROWS >> rT_seg_shift) consecutive coarse rows, block ranges in rT_rows)
+    float* rt_valf; float* r_valf;
+    const int2* rt_rows; const int2* rT_rows; const int32_t* rT_col; const int32_t* rT_of_w; const int32_t* ps_of_w;
+    int32_t rT_tiles, rT_seg_shift;
 };
 struct MgDev {
     int32_t n_levels;                    // levels 1..n_levels; the last one is dense (CoarseDev: Ac, rc = its residual, yc = its solution)

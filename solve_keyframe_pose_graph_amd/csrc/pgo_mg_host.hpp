@@ -48,6 +48,13 @@ struct HostLevel {                       // level l >= 1
     std::vector<int32_t> ps_rowptr, ps_col;     // Ps: row i holds the parents of the columns of A's row i, ascending
     std::vector<int32_t> w_rowptr, w_col;       // W = A Ps: row i holds the union of the Ps rows of the columns of A's row i, ascending
     std::vector<int64_t> psT_ptr, psT_ent;      // Ps by coarse column: [n_next+1], entries (row << 32) | block of Ps
+    // EXPLICIT transfer operator of the smoothed transition (round 5): inside the cycle the pre-smoothing step, the smoothed restriction, the smoothed prolongation and the
+    // post-smoothing step of this level collapse into  v = x_pre + Dinv (r - A x_pre),  r_next = R r,  x = v + R^T x_next  with  R^T = Ps - Dinv W  on the pattern of W
+    // (pattern(Ps) is a subset of it) — two row products per cycle on this level instead of four.  R^T lives on W's block-CSR (w_rowptr / w_col); R = its transpose by coarse row:
+    std::vector<int32_t> ps_of_w;               // [n_w] block of Ps at the same (row, column) as block k of W, or -1
+    std::vector<int32_t> rT_rowptr, rT_col;     // R by coarse row: [n_next+1]; fine rows ascending
+    std::vector<int32_t> rT_of_w;               // [n_w] slot of block (column, row) in R's arrays for block k = (row, column) of W
+    int rT_seg = 1;                             // lane groups sharing a row of R in the level kernel (tiles of tile_rows / rT_seg consecutive coarse rows)
 };
 
 struct Hierarchy {
@@ -496,6 +503,23 @@ inline bool build_hierarchy(int64_t N, const std::vector<uint8_t>& node_free, co
                 B.rowptr.assign(brow.begin(), brow.end()); B.col.swap(bcol);
             }
             B.g_ptr.assign(B.col.size() + 1, 0); B.g_ent.clear();         // (no contribution lists: the product is formed from Ps and W)
+            // explicit transfer operator: Ps slot of every W block (both rows ascend by column: one merge per row), and W's pattern by coarse column
+            A.ps_of_w.assign(A.w_col.size(), -1);
+            for (int32_t i = 0; i < n; ++i) {
+                int32_t ps = A.ps_rowptr[i]; const int32_t pe = A.ps_rowptr[(size_t)i + 1];
+                for (int32_t k = A.w_rowptr[i]; k < A.w_rowptr[(size_t)i + 1] && ps < pe; ++k) if (A.w_col[k] == A.ps_col[ps]) A.ps_of_w[(size_t)k] = ps++;
+            }
+            A.rT_rowptr.assign((size_t)nb + 1, 0);
+            for (int32_t c : A.w_col) A.rT_rowptr[(size_t)c + 1]++;
+            for (int32_t a = 0; a < nb; ++a) A.rT_rowptr[(size_t)a + 1] += A.rT_rowptr[a];
+            A.rT_col.resize(A.w_col.size()); A.rT_of_w.resize(A.w_col.size());
+            { std::vector<int32_t> fill(A.rT_rowptr.begin(), A.rT_rowptr.end() - 1);
+              for (int32_t i = 0; i < n; ++i) for (int32_t k = A.w_rowptr[i]; k < A.w_rowptr[(size_t)i + 1]; ++k) { const int32_t sl = fill[A.w_col[k]]++; A.rT_col[(size_t)sl] = i; A.rT_of_w[(size_t)k] = sl; } }
+            {   // lane groups per coarse row, by the rule of the level kernels below (<= ~5 blocks per group, up to 8 groups)
+                const double mean_row = (double)A.w_col.size() / (double)std::max(1, nb);
+                A.rT_seg = 1;
+                while (A.rT_seg < 8 && mean_row > 5.0 * A.rT_seg) A.rT_seg *= 2;
+            }
             continue;
         }
         std::vector<std::pair<int64_t, int64_t>> trip;

@@ -451,6 +451,26 @@ __global__ __launch_bounds__(256) void mg_w_kernel(MgLevelDev A) {
     }
     if (own) A.w_val[(size_t)slot * 36 + lane] = acc;
 }
+// Explicit transfer operator of a smoothed transition: R^T[i, b] = Ps[i, b] - Dinv_i W[i, b] for every block of W (Ps[i, b] = 0 outside its own, smaller pattern), rounded to
+// fp32 ONCE and stored twice — on W's block-CSR for the prolongation x = v + R^T x_next, transposed by coarse row for the restriction r_next = R r: the two are exact
+// transposes of each other, so the cycle stays symmetric.  One wavefront per block, lane l < 36 owns element (l / 6, l % 6); both copies in the level kernels' block layout (bsr_idx).
+__global__ __launch_bounds__(256) void mg_rt_kernel(MgLevelDev A) {
+    const int lane = threadIdx.x & 63;
+    const int64_t k = wave_in_grid();
+    if (k >= A.n_w || lane >= 36) return;
+    const int r = lane / 6, c = lane % 6;
+    const int i = A.w_row[k];
+    const int32_t ps = A.ps_of_w[k];
+    const int32_t tr = A.rT_of_w[k];
+    double v = ps >= 0 ? A.ps_val[(size_t)ps * 36 + lane] : 0.0;
+    const double* Dk = A.Dinv + (size_t)i * 36 + r * 6;
+    const double* W = A.w_val + (size_t)k * 36;
+#pragma unroll
+    for (int m = 0; m < 6; ++m) v -= Dk[m] * W[m * 6 + c];
+    const float f = (float)v;
+    A.rt_valf[(size_t)k * 36 + bsr_idx(r, c)] = f;
+    A.r_valf[(size_t)tr * 36 + bsr_idx(c, r)] = f;
+}
 // level above: block (a, b) = sum over the rows i with Ps[i, a] != 0 of Ps[i, a]^T W[i, b] — the rows of Ps's column a in chunks, every hop (entry -> W row range -> W columns,
 // searched by ballot -> the two blocks) issued for the whole chunk at once, the products added in list order (same bits as the entry-at-a-time loop)
 __global__ __launch_bounds__(256) void mg_psTw_kernel(MgLevelDev A, MgLevelDev B) {
@@ -501,15 +521,14 @@ __global__ __launch_bounds__(256) void mg_psTw_kernel(MgLevelDev A, MgLevelDev B
 //   w = in_r - A in_x  (in_r null: 0) ;  out_w = w (optional) ;  out = add1 + add2 + cs Dinv w   (either add may be null; Dinv holds omega D^-1, cs = w_p / omega)
 // before the restriction:  t = r - A x_pre,  u = cs Dinv t,  then the restriction kernel forms P^T (t - A u) = Ps^T t
 // after the prolongation:  e = P x_next,  y = x_pre + e - cs Dinv (A e) = x_pre + Ps x_next,  then the post-smoothing kernel runs on y
-__global__ __launch_bounds__(CG_BLOCK) void mg_smooth_step_kernel(MgLevelDev A, const double* __restrict__ in_r, const double* __restrict__ in_x, double* __restrict__ out_w,
-                                                                   const double* __restrict__ add1, const double* __restrict__ add2, double* __restrict__ out, double cs, const int32_t* __restrict__ stop) {
-    __shared__ double xch[CG_BLOCK * 7];
-    __shared__ double tb[CG_BLOCK];
+__device__ __forceinline__ void mg_smooth_step_tile(const MgLevelDev& A, int tile, const double* __restrict__ in_r, const double* __restrict__ in_x, double* __restrict__ out_w,
+                                                    const double* __restrict__ add1, const double* __restrict__ add2, double* __restrict__ out, double cs, const int32_t* __restrict__ stop,
+                                                    double* xch /* CG_BLOCK x 7 */, double* tb /* CG_BLOCK */) {
     const int stopped = stop ? *stop : 0;
     const int q6 = threadIdx.x / 6, c = threadIdx.x % 6;
     const int li = q6 & ((MG_TILE_ROWS >> A.seg_shift) - 1), sg = q6 >> (5 - A.seg_shift);
-    const int4 ti = A.tile_info[blockIdx.x];
-    const int2 rb = A.tile_rows[blockIdx.x * MG_TILE_ROWS + li];
+    const int4 ti = A.tile_info[tile];
+    const int2 rb = A.tile_rows[tile * MG_TILE_ROWS + li];
     if (stopped) return;
     const int i0 = ti.z, i1 = ti.w;
     const int row = i0 + li;
@@ -526,7 +545,7 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_smooth_step_kernel(MgLevelDev A, 
         Dk[0] = u0.x; Dk[1] = u0.y; Dk[2] = u1.x; Dk[3] = u1.y; Dk[4] = u2.x; Dk[5] = u2.y;
     }
     double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    MG_ROW_PRODUCT(blockIdx.x, in_x);
+    MG_ROW_PRODUCT(tile, in_x);
     double* mine = xch + (size_t)threadIdx.x * 7;
 #pragma unroll
     for (int q = 0; q < 6; ++q) mine[q] = acc[q];
@@ -544,6 +563,54 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_smooth_step_kernel(MgLevelDev A, 
 #pragma unroll
         for (int j = 0; j < 6; ++j) x += Dk[j] * ta[j];
         out[(size_t)row * 6 + c] = av + cs * x;
+    }
+}
+__global__ __launch_bounds__(CG_BLOCK) void mg_smooth_step_kernel(MgLevelDev A, const double* __restrict__ in_r, const double* __restrict__ in_x, double* __restrict__ out_w,
+                                                                   const double* __restrict__ add1, const double* __restrict__ add2, double* __restrict__ out, double cs, const int32_t* __restrict__ stop) {
+    __shared__ double xch[CG_BLOCK * 7];
+    __shared__ double tb[CG_BLOCK];
+    mg_smooth_step_tile(A, (int)blockIdx.x, in_r, in_x, out_w, add1, add2, out, cs, stop, xch, tb);
+}
+// Down-sweep of a level with a smoothed transition above it, explicit form (MgLevelDev::rt_valf; pgo_mg_host.hpp) — ONE launch, two independent kinds of workgroups:
+//   the level's own tiles:           v = x_pre + Dinv (r - A x_pre)                                  -> A.y   (the smoothing step; the up-sweep only adds R^T x_next to it)
+//   tiles of consecutive coarse rows: r_next = R r  (R = (Ps - Dinv W)^T, fp32 blocks by coarse row)  -> r_next, and x_next = Dinv_next r_next when the level above is a sparse one
+// instead of the implicit form's two dependent launches (t = r - A x_pre, u = c Dinv t;  r_next = P^T (t - A u)): the same r_next = Ps^T (r - A x_pre) algebraically.
+__global__ __launch_bounds__(CG_BLOCK) void mg_sdown_kernel(MgLevelDev A, double* __restrict__ r_next, double* __restrict__ x_next, const double* __restrict__ Dinv_next, const int32_t* __restrict__ stop) {
+    __shared__ double xch[CG_BLOCK * 7];
+    __shared__ double tb[CG_BLOCK];
+    if ((int)blockIdx.x < A.tiles) { mg_smooth_step_tile(A, (int)blockIdx.x, A.r, A.x, nullptr, A.x, nullptr, A.y, 1.0, stop, xch, tb); return; }
+    const int stopped = stop ? *stop : 0;
+    const int tile = (int)blockIdx.x - A.tiles;
+    const int ss = A.rT_seg_shift, rpt = MG_TILE_ROWS >> ss;
+    const int q6 = threadIdx.x / 6, c = threadIdx.x % 6;
+    const int li = q6 & (rpt - 1), sg = q6 >> (5 - ss);
+    const int2 rb = A.rT_rows[tile * MG_TILE_ROWS + li];
+    const int row = tile * rpt + li;
+    const bool live = row < A.n_next && sg == 0;
+    double Dk[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (live && x_next) {
+        const double2* Dp = reinterpret_cast<const double2*>(Dinv_next + (size_t)row * 36 + c * 6);
+        const double2 u0 = Dp[0], u1 = Dp[1], u2 = Dp[2];
+        Dk[0] = u0.x; Dk[1] = u0.y; Dk[2] = u1.x; Dk[3] = u1.y; Dk[4] = u2.x; Dk[5] = u2.y;
+    }
+    if (stopped) return;
+    double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (row < A.n_next) { int kb, ke; mg_split_row(rb, sg, ss, kb, ke); mg_row_accumulate_f32(kb, ke, A.rT_col, A.r_valf, A.r, c, acc); }
+    double* mine = xch + (size_t)threadIdx.x * 7;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) mine[q] = acc[q];
+    __syncthreads();
+    double sum = 0.0;
+    if (live) { sum = mg_gather_row(xch, li, c, ss); r_next[(size_t)row * 6 + c] = sum; }
+    if (!x_next) return;
+    tb[threadIdx.x] = sum;
+    __syncthreads();
+    if (live) {
+        const double* ra = tb + (threadIdx.x - c);
+        double x = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) x += Dk[j] * ra[j];
+        x_next[(size_t)row * 6 + c] = x;
     }
 }
 
@@ -604,6 +671,7 @@ void launch_mg_assemble_rest(const MgDev& M, const MgLevelDev* levels, const Coa
             if (A.smoothed) {
                 hipLaunchKernelGGL(mg_ps_kernel, dim3((unsigned)((A.n_ps + 3) / 4)), dim3(256), 0, st, A, prolong_scale);
                 hipLaunchKernelGGL(mg_w_kernel, dim3((unsigned)((A.n_w + 3) / 4)), dim3(256), 0, st, A);
+                if (A.rt_valf) hipLaunchKernelGGL(mg_rt_kernel, dim3((unsigned)((A.n_w + 3) / 4)), dim3(256), 0, st, A);
                 hipLaunchKernelGGL(mg_psTw_kernel, dim3((unsigned)((levels[l].nnzb + 3) / 4)), dim3(256), 0, st, A, levels[l]);
             } else hipLaunchKernelGGL(mg_galerkin_kernel, dim3((unsigned)((levels[l].nnzb + 3) / 4)), dim3(256), 0, st, A, levels[l]);
         }
@@ -759,9 +827,12 @@ __global__ __launch_bounds__(384) void mg_dense_solve_kernel(CoarseDev K, MgLeve
 // x = xt + Dinv (r - A xt) on a tile; then xt = x + s P x on the members (level below) of the tile's rows.  Loads hoisted as in mg_down.
 // FINE (level 1 only): the prolongation to the KEYFRAMES is done here too — z_i += s P_i x_1[agg0(i)] over the keyframes of the tile's rows
 // (mem0 lists) with this workgroup's share of r.(P x_1) going to its own partial-sum slot after the update kernel's (CgDev::extra_rz).
+// EXPLICIT (xnext != null; levels with MgLevelDev::rt_valf): x = v + s R^T x_next with v = x_pre + Dinv (r - A x_pre) left in A.y by mg_sdown_kernel — the smoothed
+// prolongation and the post-smoothing step in ONE row product over the fp32 blocks of R^T (W's pattern), no Dinv, no second pass over the level's own matrix.
 template <bool FINE>
 __global__ __launch_bounds__(CG_BLOCK) void mg_up_kernel(MgLevelDev A, MgLevelDev Below, int has_below, double scale, const int32_t* __restrict__ stop,
-                                                          MgDev M, const double* __restrict__ rfine, double* __restrict__ zfine, double* __restrict__ part_extra) {
+                                                          MgDev M, const double* __restrict__ rfine, double* __restrict__ zfine, double* __restrict__ part_extra,
+                                                          const double* __restrict__ xnext = nullptr) {
     __shared__ double xch[CG_BLOCK * 7];
     __shared__ double tb[CG_BLOCK];
     __shared__ double xb[CG_BLOCK];
@@ -772,7 +843,8 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_up_kernel(MgLevelDev A, MgLevelDe
     // FINE: the grid is capped at MAX_PARTIALS workgroups (one r.z partial slot each), a workgroup takes every gridDim-th tile; otherwise one tile per workgroup
     for (int tile = blockIdx.x; tile < A.tiles; tile += gridDim.x) {
     const int4 ti = A.tile_info[tile];
-    const int2 rb = A.tile_rows[tile * MG_TILE_ROWS + li];
+    const bool expl = xnext != nullptr;
+    const int2 rb = expl ? A.rt_rows[tile * MG_TILE_ROWS + li] : A.tile_rows[tile * MG_TILE_ROWS + li];
     if (stopped) return;
     const int i0 = ti.z, i1 = ti.w;
     const int row = i0 + li;
@@ -782,10 +854,12 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_up_kernel(MgLevelDev A, MgLevelDe
     double Dk[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     int c0 = 0, c1 = 0;
     if (live) {
-        rv = A.r[(size_t)row * 6 + c]; xv = A.xt[(size_t)row * 6 + c];
-        const double2* Dp = reinterpret_cast<const double2*>(A.Dinv + (size_t)row * 36 + c * 6);
-        const double2 u0 = Dp[0], u1 = Dp[1], u2 = Dp[2];
-        Dk[0] = u0.x; Dk[1] = u0.y; Dk[2] = u1.x; Dk[3] = u1.y; Dk[4] = u2.x; Dk[5] = u2.y;
+        rv = A.r[(size_t)row * 6 + c]; xv = expl ? A.y[(size_t)row * 6 + c] : A.xt[(size_t)row * 6 + c];
+        if (!expl) {
+            const double2* Dp = reinterpret_cast<const double2*>(A.Dinv + (size_t)row * 36 + c * 6);
+            const double2 u0 = Dp[0], u1 = Dp[1], u2 = Dp[2];
+            Dk[0] = u0.x; Dk[1] = u0.y; Dk[2] = u1.x; Dk[3] = u1.y; Dk[4] = u2.x; Dk[5] = u2.y;
+        }
     }
     if (has_below) { c0 = Below.agg_ptr[i0]; c1 = Below.agg_ptr[i1]; }
     // the first trip of the prolongation loop: child row, its parent, its pre-smoothed x and offset d
@@ -818,20 +892,29 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_up_kernel(MgLevelDev A, MgLevelDe
         }
     }
     double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    MG_ROW_PRODUCT(tile, A.xt);
+    if (expl) { if (rowlive) { int kb, ke; mg_split_row(rb, sg, A.seg_shift, kb, ke); mg_row_accumulate_f32(kb, ke, A.w_col, A.rt_valf, xnext, c, acc); } }
+    else MG_ROW_PRODUCT(tile, A.xt);
     double* mine = xch + (size_t)threadIdx.x * 7;
 #pragma unroll
     for (int q = 0; q < 6; ++q) mine[q] = acc[q];
     __syncthreads();
-    if (live) tb[threadIdx.x] = rv - mg_gather_row(xch, li, c, A.seg_shift);
-    __syncthreads();
-    if (live) {
-        const double* ta = tb + (threadIdx.x - c);
-        double x = xv;
+    if (expl) {
+        if (live) {
+            const double x = xv + scale * mg_gather_row(xch, li, c, A.seg_shift);
+            A.xf[(size_t)row * 6 + c] = x;
+            xb[threadIdx.x] = x;
+        }
+    } else {
+        if (live) tb[threadIdx.x] = rv - mg_gather_row(xch, li, c, A.seg_shift);
+        __syncthreads();
+        if (live) {
+            const double* ta = tb + (threadIdx.x - c);
+            double x = xv;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) x += Dk[j] * ta[j];
-        A.xf[(size_t)row * 6 + c] = x;
-        xb[threadIdx.x] = x;
+            for (int j = 0; j < 6; ++j) x += Dk[j] * ta[j];
+            A.xf[(size_t)row * 6 + c] = x;
+            xb[threadIdx.x] = x;
+        }
     }
     if (FINE) {
         __syncthreads();
@@ -1102,6 +1185,11 @@ void launch_mg_apply(const GraphDev& G, const CgDev& C, const MgDev& M, const Mg
     else hipLaunchKernelGGL(mg_restrict0_kernel, dim3(g1), dim3(CG_BLOCK), 0, st, M, r, levels[0].r, levels[0].x, (const double*)levels[0].Dinv, stop);
     for (int l = 1; l < nl; ++l) {                     // sparse level l -> level l+1
         MgLevelDev A = levels[l - 1];
+        if (A.smoothed && A.rt_valf) {      // explicit transfer operator: smoothing step and restriction in one launch (two kinds of workgroups)
+            if (l + 1 == nl) hipLaunchKernelGGL(mg_sdown_kernel, dim3((unsigned)(A.tiles + A.rT_tiles)), dim3(CG_BLOCK), 0, st, A, K.rc, (double*)nullptr, (const double*)nullptr, stop);
+            else hipLaunchKernelGGL(mg_sdown_kernel, dim3((unsigned)(A.tiles + A.rT_tiles)), dim3(CG_BLOCK), 0, st, A, levels[l].r, levels[l].x, (const double*)levels[l].Dinv, stop);
+            continue;
+        }
         if (A.smoothed) {
             // smoothed prolongator: t = r - A x_pre, u = c Dinv t; the restriction kernel then forms P^T (t - A u) = Ps^T t
             hipLaunchKernelGGL(mg_smooth_step_kernel, dim3((unsigned)A.tiles), dim3(CG_BLOCK), 0, st, A, (const double*)A.r, (const double*)A.x, A.t, (const double*)nullptr, (const double*)nullptr, A.u, prolong_scale, stop);
@@ -1112,18 +1200,25 @@ void launch_mg_apply(const GraphDev& G, const CgDev& C, const MgDev& M, const Mg
     }
     // the level below a kernel that prolongs: with a smoothed transition it must receive the bare correction e = P x (xt = 0 + P x), smoothed afterwards
     auto below_of = [&](int idx) { MgLevelDev B = levels[idx]; if (B.smoothed) B.x = const_cast<double*>(B.zero); return B; };
-    hipLaunchKernelGGL(mg_dense_solve_kernel, dim3((unsigned)K.n_agg), dim3(384), 0, st, K, nl >= 2 ? below_of(nl - 2) : levels[0], nl >= 2 ? 1 : 0, scale, stop);
+    auto expl_at = [&](int idx) { return idx >= 0 && levels[idx].smoothed && levels[idx].rt_valf != nullptr; };      // that level's up-sweep reads x_next itself: nothing is prolonged into it
+    hipLaunchKernelGGL(mg_dense_solve_kernel, dim3((unsigned)K.n_agg), dim3(384), 0, st, K, nl >= 2 ? below_of(nl - 2) : levels[0], nl >= 2 && !expl_at(nl - 2) ? 1 : 0, scale, stop);
     const bool fused = C.extra_rz > 0;     // level 1's kernel prolongs to the keyframes itself (the solver sets extra_rz = its tile count when that fits the partial-sum slots)
     const unsigned g0 = (unsigned)cg_grid(G);
     for (int l = nl - 1; l >= 1; --l) {
         MgLevelDev A = levels[l - 1];
+        if (expl_at(l - 1)) {      // x = v + s R^T x_next: prolongation and post-smoothing in one launch
+            const double* xn = l + 1 == nl ? (const double*)K.yc : (const double*)levels[l].xf;
+            if (l == 1 && fused) hipLaunchKernelGGL(mg_up_kernel<true>, dim3((unsigned)(A.tiles < MAX_PARTIALS ? A.tiles : MAX_PARTIALS)), dim3(CG_BLOCK), 0, st, A, A, 0, scale, stop, M, r, z, part_rz + g0, xn);
+            else hipLaunchKernelGGL(mg_up_kernel<false>, dim3((unsigned)A.tiles), dim3(CG_BLOCK), 0, st, A, l >= 2 ? below_of(l - 2) : levels[0], l >= 2 && !expl_at(l - 2) ? 1 : 0, scale, stop, M, r, z, part_rz, xn);
+            continue;
+        }
         if (A.smoothed) {
             // y = x_pre + e - c Dinv (A e) = x_pre + Ps x_next ; the post-smoothing kernel then works on y
             hipLaunchKernelGGL(mg_smooth_step_kernel, dim3((unsigned)A.tiles), dim3(CG_BLOCK), 0, st, A, (const double*)nullptr, (const double*)A.xt, (double*)nullptr, (const double*)A.x, (const double*)A.xt, A.y, prolong_scale, stop);
             A.xt = A.y;
         }
-        if (l == 1 && fused) hipLaunchKernelGGL(mg_up_kernel<true>, dim3((unsigned)(A.tiles < MAX_PARTIALS ? A.tiles : MAX_PARTIALS)), dim3(CG_BLOCK), 0, st, A, A, 0, scale, stop, M, r, z, part_rz + g0);
-        else hipLaunchKernelGGL(mg_up_kernel<false>, dim3((unsigned)A.tiles), dim3(CG_BLOCK), 0, st, A, l >= 2 ? below_of(l - 2) : levels[0], l >= 2 ? 1 : 0, scale, stop, M, r, z, part_rz);
+        if (l == 1 && fused) hipLaunchKernelGGL(mg_up_kernel<true>, dim3((unsigned)(A.tiles < MAX_PARTIALS ? A.tiles : MAX_PARTIALS)), dim3(CG_BLOCK), 0, st, A, A, 0, scale, stop, M, r, z, part_rz + g0, (const double*)nullptr);
+        else hipLaunchKernelGGL(mg_up_kernel<false>, dim3((unsigned)A.tiles), dim3(CG_BLOCK), 0, st, A, l >= 2 ? below_of(l - 2) : levels[0], l >= 2 && !expl_at(l - 2) ? 1 : 0, scale, stop, M, r, z, part_rz, (const double*)nullptr);
     }
     if (!fused) hipLaunchKernelGGL(mg_prolong0_kernel, dim3(g0), dim3(CG_BLOCK), 0, st, G, M, (const double*)(nl == 1 ? K.yc : levels[0].xf), r, z, part_rz, scale, stop);
 }

@@ -107,7 +107,8 @@ struct MgPrepared {
     std::vector<int32_t> agg0_l, mem0_ptr_l, mem0_l;      // several ranks: the keyframe-indexed arrays in the handle's local numbering
     std::vector<double> inv_cnt;
     std::vector<int32_t> pi32; std::vector<int64_t> pi64; size_t nf64 = 0;
-    struct Off { size_t col, parent, agg_ptr, tile, tile_rows, rowptr, g_ptr, g_ent, val, Dinv, pos, d, r, x, xt, xf, valf, ps_rowptr, ps_col, w_rowptr, w_col, psT_ptr, psT_ent, ps_val, w_val, t, u, y, zero, row_of, tr_of, ps_row, w_row; };
+    struct Off { size_t col, parent, agg_ptr, tile, tile_rows, rowptr, g_ptr, g_ent, val, Dinv, pos, d, r, x, xt, xf, valf, ps_rowptr, ps_col, w_rowptr, w_col, psT_ptr, psT_ent, ps_val, w_val, t, u, y, zero, row_of, tr_of, ps_row, w_row,
+                        rt_rows, rT_rows, rT_col, rT_of_w, ps_of_w, rt_valf, r_valf; int rT_tiles, rT_seg_shift; };
     std::vector<Off> off;
     size_t o_agg0 = 0, o_mem0_ptr = 0, o_mem0 = 0, o_blk_tab = 0, o_d0 = 0, o_inv = 0, o_q1 = 0, o_s1 = 0;
     bool have_tab = false;
@@ -379,7 +380,7 @@ int mg_prepare(pgo_problem* p, const double* sw_now, MgPrepared& Q) {
         size_t n32 = A0.size() + M0P.size() + M0.size() + (size_t)((N + MG_BLOCK0 - 1) / MG_BLOCK0) * MG_BLOCK0 * 4 + 64, n64 = 0;
         for (const pgo_mg::HostLevel& A : H.L) {
             const size_t tiles = A.tile_agg0.empty() ? 0 : A.tile_agg0.size() - 1;
-            n32 += 3 * A.col.size() + A.parent.size() + A.agg_ptr.size() + tiles * (4 + 2 * (size_t)MG_TILE_ROWS) + A.ps_rowptr.size() + 2 * A.ps_col.size() + A.w_rowptr.size() + 2 * A.w_col.size() + 16;
+            n32 += 3 * A.col.size() + A.parent.size() + A.agg_ptr.size() + tiles * (4 + 2 * (size_t)MG_TILE_ROWS) + A.ps_rowptr.size() + 2 * A.ps_col.size() + A.w_rowptr.size() + 5 * A.w_col.size() + (A.smoothed ? tiles * 2 * (size_t)MG_TILE_ROWS + ((size_t)A.rT_rowptr.size() / 4 + 2) * 2 * (size_t)MG_TILE_ROWS : 0) + 16;
             n64 += A.rowptr.size() + A.g_ptr.size() + A.g_ent.size() + A.psT_ptr.size() + A.psT_ent.size();
         }
         pi32.reserve(n32); pi64.reserve(n64);
@@ -469,6 +470,25 @@ int mg_prepare(pgo_problem* p, const double* sw_now, MgPrepared& Q) {
             }
             o.ps_val = take(A.ps_col.size() * 36); o.w_val = take(A.w_col.size() * 36);
             o.t = take((size_t)A.n * 6); o.u = take((size_t)A.n * 6); o.y = take((size_t)A.n * 6); o.zero = take((size_t)A.n * 6);
+            {   // explicit transfer operator: index arrays, per-tile block ranges of R^T (this level's tiles) and of R (tiles of consecutive coarse rows), fp32 block arrays
+                o.rT_col = put32(A.rT_col); o.rT_of_w = put32(A.rT_of_w); o.ps_of_w = put32(A.ps_of_w);
+                std::vector<int32_t> rows;
+                for (size_t tt = 0; tt + 1 < A.tile_agg0.size(); ++tt) {
+                    const int32_t i0 = A.agg_ptr[A.tile_agg0[tt]], i1 = A.agg_ptr[A.tile_agg0[tt + 1]];
+                    for (int li = 0; li < MG_TILE_ROWS; ++li) { const int32_t r = i0 + li; rows.push_back(r < i1 ? A.w_rowptr[r] : 0); rows.push_back(r < i1 ? A.w_rowptr[(size_t)r + 1] : 0); }
+                }
+                while (pi32.size() % 2) pi32.push_back(0);
+                o.rt_rows = put32(rows);
+                o.rT_seg_shift = A.rT_seg >= 8 ? 3 : A.rT_seg >= 4 ? 2 : A.rT_seg >= 2 ? 1 : 0;
+                const int rpt = MG_TILE_ROWS >> o.rT_seg_shift;
+                const int32_t nb = (int32_t)A.rT_rowptr.size() - 1;
+                o.rT_tiles = (nb + rpt - 1) / rpt;
+                rows.clear();
+                for (int tt = 0; tt < o.rT_tiles; ++tt)
+                    for (int li = 0; li < MG_TILE_ROWS; ++li) { const int32_t r = tt * rpt + li; const bool in = li < rpt && r < nb; rows.push_back(in ? A.rT_rowptr[r] : 0); rows.push_back(in ? A.rT_rowptr[(size_t)r + 1] : 0); }
+                o.rT_rows = put32(rows);
+                o.rt_valf = take((A.w_col.size() * 36 + 1) / 2); o.r_valf = take((A.w_col.size() * 36 + 1) / 2);
+            }
         }
     }
     Q.host_ms = (now_s() - t0) * 1e3;
@@ -518,6 +538,12 @@ int mg_install(pgo_problem* p, MgPrepared& Q) {
             D.ps_rowptr = b32 + o.ps_rowptr; D.ps_col = b32 + o.ps_col; D.w_rowptr = b32 + o.w_rowptr; D.w_col = b32 + o.w_col; D.psT_ptr = b64 + o.psT_ptr; D.psT_ent = b64 + o.psT_ent;
             D.ps_row = b32 + o.ps_row; D.w_row = b32 + o.w_row;
             D.ps_val = bf + o.ps_val; D.w_val = bf + o.w_val; D.t = bf + o.t; D.u = bf + o.u; D.y = bf + o.y; D.zero = bf + o.zero;
+            if (p->opt.mg_explicit_transfer != 0) {
+                D.rt_valf = reinterpret_cast<float*>(bf + o.rt_valf); D.r_valf = reinterpret_cast<float*>(bf + o.r_valf);
+                D.rt_rows = reinterpret_cast<const int2*>(b32 + o.rt_rows); D.rT_rows = reinterpret_cast<const int2*>(b32 + o.rT_rows);
+                D.rT_col = b32 + o.rT_col; D.rT_of_w = b32 + o.rT_of_w; D.ps_of_w = b32 + o.ps_of_w;
+                D.rT_tiles = o.rT_tiles; D.rT_seg_shift = o.rT_seg_shift;
+            }
         }
     }
     // the dense coarsest level shares the buffers of the two-level preconditioner, which the multigrid replaces on this graph
@@ -2075,6 +2101,7 @@ void pgo_options_init(pgo_options* o) {
     o->verbosity = 0;
     o->cg_single_reduction = 1;
     o->cg_pause_always = 0;
+    o->mg_explicit_transfer = 1;
 }
 
 int pgo_create(pgo_problem** out, const pgo_options* opts) {
@@ -2160,7 +2187,8 @@ int pgo_set_options(pgo_problem* p, const pgo_options* o) {
     if (o->linear_solver != p->opt.linear_solver) p->graph_dirty = true;
     // the preconditioner hierarchies are part of the device graph build
     if (o->mg_min_keyframes != p->opt.mg_min_keyframes || o->mg_min_keyframes_switchable != p->opt.mg_min_keyframes_switchable || o->mg_first_passes != p->opt.mg_first_passes || o->mg_passes != p->opt.mg_passes ||
-        o->mg_dense_max_nodes != p->opt.mg_dense_max_nodes || o->coarse_aggregates != p->opt.coarse_aggregates || o->mg_smoothed_levels != p->opt.mg_smoothed_levels || o->mg_loop_discount != p->opt.mg_loop_discount) p->graph_dirty = true;
+        o->mg_dense_max_nodes != p->opt.mg_dense_max_nodes || o->coarse_aggregates != p->opt.coarse_aggregates || o->mg_smoothed_levels != p->opt.mg_smoothed_levels || o->mg_loop_discount != p->opt.mg_loop_discount ||
+        o->mg_explicit_transfer != p->opt.mg_explicit_transfer) p->graph_dirty = true;
     p->opt = *o;
     p->opt.device_id = dev;   // the device binding is fixed at create
     return PGO_OK;
@@ -2666,6 +2694,9 @@ int pgo_time_kernel(pgo_problem* p, int32_t which, int32_t launches, double* avg
                           double cyc = N * (24.0 + 16.0 / 8.0 * 8.0) /* d0 + slot table (restriction) */ + N * (2.0 * 48.0 + 24.0 + 4.0 + 4.0) /* z read + write, d0, agg0, member list (prolongation) */;
                           for (int l = 0; l + 1 < p->M.n_levels; ++l) {
                               const MgLevelDev& A = p->mg_levels[l];
+                              if (A.smoothed && A.rt_valf)      // explicit transfer operator: the level's own blocks once (smoothing step), R and R^T once each, Dinv once, r / x / y / xf and the level above's r, x
+                                  cyc += (double)A.nnzb * (144.0 + 4.0) + 2.0 * (double)A.n_w * (144.0 + 4.0) + (double)A.n * (288.0 + 24.0 + 8.0 * 48.0 + 16.0) + (double)A.n_next * (288.0 + 2.0 * 48.0 + 8.0);
+                              else
                               cyc += (A.smoothed ? 4.0 : 2.0) * (double)A.nnzb * (144.0 + 4.0) + (double)A.n * ((A.smoothed ? 4.0 : 2.0) * 288.0 /* Dinv: smoothing steps */ + 24.0 + (A.smoothed ? 18.0 : 10.0) * 48.0 + 16.0);
                           }
                           cyc += (double)p->K.nc * (double)p->K.nc * 4.0 + (double)p->K.nc * 16.0;

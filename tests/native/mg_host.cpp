@@ -80,6 +80,13 @@ void mgh_smoothed(void* h, int l, int* ps_rowptr, int* ps_col, int* w_rowptr, in
     std::memcpy(w_rowptr, A.w_rowptr.data(), A.w_rowptr.size() * 4); std::memcpy(w_col, A.w_col.data(), A.w_col.size() * 4);
     std::memcpy(psT_ptr, A.psT_ptr.data(), A.psT_ptr.size() * 8); std::memcpy(psT_ent, A.psT_ent.data(), A.psT_ent.size() * 8);
 }
+// explicit transfer operator of a smoothed transition (R^T on W's pattern): Ps slot of every W block, W's pattern by coarse row, slot of every W block there, lane groups
+void mgh_explicit(void* h, int l, int* ps_of_w, int* rT_rowptr, int* rT_col, int* rT_of_w, int* rT_seg) {
+    const pgo_mg::HostLevel& A = ((pgo_mg::Hierarchy*)h)->L[l];
+    std::memcpy(ps_of_w, A.ps_of_w.data(), A.ps_of_w.size() * 4); std::memcpy(rT_rowptr, A.rT_rowptr.data(), A.rT_rowptr.size() * 4);
+    std::memcpy(rT_col, A.rT_col.data(), A.rT_col.size() * 4); std::memcpy(rT_of_w, A.rT_of_w.data(), A.rT_of_w.size() * 4);
+    *rT_seg = A.rT_seg;
+}
 void mgh_level0(void* h, int* agg0, int* mem0_ptr, int* mem0) {
     const pgo_mg::Hierarchy& H = *(pgo_mg::Hierarchy*)h;
     std::memcpy(agg0, H.agg0.data(), H.agg0.size() * 4); std::memcpy(mem0_ptr, H.mem0_ptr.data(), H.mem0_ptr.size() * 4); std::memcpy(mem0, H.mem0.data(), H.mem0.size() * 4);

@@ -152,57 +152,62 @@ def test_dense_inverse_reports_an_indefinite_matrix():
 
 
 def test_a_graph_whose_hierarchy_does_not_coarsen_falls_back_to_the_two_level_method():
-    """9 600 keyframes in 1 200 separate chains of 8 (each its own level-1 aggregate: nothing ties two level-1 nodes together, the matching above level 1 stalls) with one
-    switchable closure and one regulariser per chain: large enough for the multigrid (mg_min_keyframes_switchable), but its hierarchy cannot be built.  One GPU prepares the
-    hierarchy on a worker thread and only learns this where it is first needed (mg_init_finish): the handle must then work with the two-level method — what the same graph gets
-    when the multigrid is switched off — not with plain block-Jacobi for the rest of its life (round-4 advisor finding).  Checked: a step preconditioned by the two-level method
-    appears in the log of the handle's next solve, and both trajectories are the oracle's (block-diagonal exact Cholesky)."""
+    """One 9 600-keyframe trajectory whose every 8th link is a SWITCHABLE closure instead of an odometry edge: level 1 groups keyframes along odometry edges only (1 200
+    aggregates of 8), and above level 1 a SINGLE switchable closure between two aggregates counts for nothing (mg_loop_discount) — the matching stalls, the hierarchy cannot be
+    built, although the graph is large enough for the multigrid (mg_min_keyframes_switchable) and, being one long chain, hard for plain block-Jacobi.  One GPU prepares the
+    hierarchy on a worker thread and only learns this where it is first needed (mg_init_finish): from there on the handle must work with the two-level method — what the same
+    graph gets when the multigrid is switched off — not with plain block-Jacobi for the rest of its life (round-4 advisor finding).  Checked: steps preconditioned by the
+    two-level method appear in the log (never the multigrid), and the trajectory is the oracle's (banded exact Cholesky)."""
     rng = np.random.default_rng(12)
-    chains, m = 1200, 8
-    N = chains * m
-    # ground truth: every chain a short random walk somewhere in a 200 m box
-    q = rng.normal(size=(N, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
-    t = np.repeat(rng.uniform(-100, 100, size=(chains, 3)), m, axis=0) + np.cumsum(rng.normal(size=(N, 3)) * 0.5, axis=0) * 0.0
-    t += np.tile(np.cumsum(rng.normal(size=(m, 3)), axis=0), (chains, 1)) * 0.7
+    N, m = 9600, 8
+    q = np.zeros((N, 4)); t = np.zeros((N, 3))
+    q[0] = [0, 0, 0, 1]
+    for k in range(1, N):      # a random walk with gentle turns
+        a = rng.normal(size=3) * 0.05
+        dq = np.array([a[0] / 2, a[1] / 2, a[2] / 2, 1.0]); dq /= np.linalg.norm(dq)
+        x1, y1, z1, w1 = q[k - 1]; x2, y2, z2, w2 = dq
+        q[k] = [w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2, w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2, w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2]
+        q[k] /= np.linalg.norm(q[k])
+    M = util.poses_to_matrices(q, np.zeros((N, 3))).reshape(N, 4, 4).transpose(0, 2, 1)
+    for k in range(1, N):
+        t[k] = t[k - 1] + M[k - 1][:3, :3] @ np.array([1.0, 0.0, 0.0])
     M = util.poses_to_matrices(q, t).reshape(N, 4, 4).transpose(0, 2, 1)          # row-major 4x4 per keyframe
 
     def rel(a, b, sig):
         T = np.linalg.inv(M[a]) @ M[b]
         T[:, :3, 3] += rng.normal(size=(len(a), 3)) * sig
         return np.ascontiguousarray(T.transpose(0, 2, 1)).reshape(len(a), 16)       # column-major, the reference's layout
-    first = np.arange(chains, dtype=np.int32) * m
-    oc1 = np.concatenate([first + k for k in range(m - 1)]).astype(np.int32); oc2 = oc1 + 1
-    lc1 = first.copy(); lc2 = (first + m - 1).astype(np.int32)
-    oT, lT = rel(oc1, oc2, 0.02), rel(lc1, lc2, 0.05)
-    regT = util.poses_to_matrices(q[first], t[first])
+    links = np.arange(N - 1, dtype=np.int32)
+    is_sw = (links % m) == m - 1
+    skip2 = np.arange(N - 2, dtype=np.int32); skip2 = skip2[(skip2 % m) <= m - 3]      # k -> k + 2 inside a run of 8 (redundancy: the minimum is not a zero-cost tree fit)
+    oc1 = np.concatenate([links[~is_sw], skip2]); oc2 = np.concatenate([links[~is_sw] + 1, skip2 + 2])
+    lc1 = links[is_sw]; lc2 = lc1 + 1
+    oT, lT = rel(oc1, oc2, 0.02), rel(lc1, lc2, 0.02)
+    S = len(lc1)
+    reg_node = np.zeros(1, np.int32); regT = util.poses_to_matrices(q[:1], t[:1])
 
-    def build(**kw):
-        P = capi.Problem(**kw)
+    def build(cls, **kw):
+        P = cls(**kw)
         P.add_relpose_edges(oc1, oc2, oT, np.ones(len(oc1)))
-        P.add_switchable_edges(lc1, lc2, lT, np.ones(chains), np.arange(chains, dtype=np.int32))
-        P.set_node_regularizers(first, regT, np.full(chains, 1.1))
+        P.add_switchable_edges(lc1, lc2, lT, np.ones(S), np.arange(S, dtype=np.int32))
+        P.set_node_regularizers(reg_node, regT, np.full(1, 4.0))
         return P
-    q0 = q + rng.normal(size=q.shape) * 0.02; q0 /= np.linalg.norm(q0, axis=1, keepdims=True)
-    t0 = t + rng.normal(size=t.shape) * 0.1
-    s0 = np.full(chains, 0.99)
-    # The first solve of the handle may never need the hierarchy (its PCGs are short): it runs on block-Jacobi and the pending hierarchy is resolved at pgo_solve_end.  From
-    # then on the handle is a two-level one: the second solve from the same start shows steps preconditioned by the two-level method and never the multigrid.
-    P = build()
-    _, t1, s1, with_mg = P.solve(q0, t0, s0)
+    q0 = q + rng.normal(size=q.shape) * 0.01; q0 /= np.linalg.norm(q0, axis=1, keepdims=True)
+    t0 = t + rng.normal(size=t.shape) * 0.05
+    s0 = np.full(S, 0.99)
+    P = build(capi.Problem)
+    _, t1, s1, first = P.solve(q0, t0, s0)
     _, t2, s2, again = P.solve(q0, t0, s0)
     P.close()
-    pre = [again.iterations[k].preconditioner & 15 for k in range(1, again.num_logged)]
-    assert capi.PRECOND_TWO_LEVEL in pre and capi.PRECOND_MULTIGRID not in pre, pre
-    assert capi.PRECOND_MULTIGRID not in [with_mg.iterations[k].preconditioner & 15 for k in range(1, with_mg.num_logged)]
-    assert again.num_logged == with_mg.num_logged and np.abs(t1 - t2).max() <= 1e-6 and np.abs(s1 - s2).max() <= 1e-6
-    for k in range(with_mg.num_logged):
-        assert abs(again.iterations[k].cost - with_mg.iterations[k].cost) <= 1e-7 * max(with_mg.iterations[k].cost, 1e-12), k
+    pre1 = [first.iterations[k].preconditioner & 15 for k in range(1, first.num_logged)]
+    pre2 = [again.iterations[k].preconditioner & 15 for k in range(1, again.num_logged)]
+    assert capi.PRECOND_MULTIGRID not in pre1 + pre2, (pre1, pre2)
+    assert capi.PRECOND_TWO_LEVEL in pre2, (pre1, pre2)              # at the latest from the handle's second solve on (the first may never have needed the hierarchy)
     from oracle import binding as ob
-    O = ob.OracleProblem()
-    O.add_relpose_edges(oc1, oc2, oT, np.ones(len(oc1)))
-    O.add_switchable_edges(lc1, lc2, lT, np.ones(chains), np.arange(chains))
-    O.set_node_regularizers(first, regT, np.full(chains, 1.1))
+    O = build(ob.OracleProblem)
     _, to, so, sumo = O.solve(q0, t0, s0)
-    assert [with_mg.iterations[k].step_is_successful for k in range(with_mg.num_logged)] == [sumo.iterations[k].step_is_successful for k in range(sumo.num_logged)]
-    for k in range(sumo.num_logged):
-        assert abs(sumo.iterations[k].cost - with_mg.iterations[k].cost) <= 1e-6 * max(sumo.iterations[k].cost, 1e-12), k
+    for got in (first, again):
+        assert [got.iterations[k].step_is_successful for k in range(got.num_logged)] == [sumo.iterations[k].step_is_successful for k in range(sumo.num_logged)]
+        for k in range(sumo.num_logged):
+            assert abs(sumo.iterations[k].cost - got.iterations[k].cost) <= 1e-6 * max(sumo.iterations[k].cost, 1e-12), k
+    assert np.abs(t1 - to).max() <= 2e-2 and np.abs(t2 - to).max() <= 2e-2      # (a 9 600-keyframe chain: the valley is flat along its long wavelengths, as on C2)

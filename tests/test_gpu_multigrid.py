@@ -109,6 +109,35 @@ def test_smoothed_prolongators_keep_the_trajectory_and_cut_the_iterations(smooth
     assert sump.cg_iterations * 1.15 < base.cg_iterations, (smoothed, sump.cg_iterations, base.cg_iterations)
 
 
+@pytest.mark.parametrize("shape", ["two_smoothed_deep", "smoothed_below_dense", "default_20k", "multi_world_30k"])
+def test_explicit_transfer_operator_is_the_same_cycle(shape):
+    """mg_explicit_transfer (round 5): on a level with a smoothed transition above, pre-smoothing + smoothed restriction and smoothed prolongation + post-smoothing are applied
+    through R = (Ps - Dinv W)^T (fp32 blocks on W's pattern) — v = x + Dinv (r - A x), r_next = R r, x = v + R^T x_next: two row products on that level instead of four, two
+    launches fewer per PCG iteration.  Algebraically the same V(1,1) cycle as the implicit form: same LM trajectory, PCG iteration counts within a few per cent (the operator
+    is rounded to fp32 once instead of the level matrix being applied twice in fp32), and the oracle's trajectory where the oracle is affordable.  Shapes: two smoothed
+    transitions in a deep hierarchy (a smoothed level below another explicit level: nothing is prolonged into it), a smoothed level directly below the dense one (its restriction
+    writes the dense right-hand side, its prolongation reads the dense solution), library defaults on a 20 000-keyframe graph, a multi-world graph with f = 1..5 odometry."""
+    oracle = False
+    if shape == "two_smoothed_deep":
+        g, kw, oracle = graphgen.generate(2500, 2500, odom_f_max=2, seed=17, outlier_frac=0.1), dict(mg_min_keyframes=1, mg_switch_iterations=0, mg_dense_max_nodes=24, mg_first_passes=2, mg_smoothed_levels=2), True
+    elif shape == "smoothed_below_dense":
+        g, kw, oracle = graphgen.generate(2500, 2500, odom_f_max=2, seed=17, outlier_frac=0.1), dict(mg_min_keyframes=1, mg_switch_iterations=0, mg_dense_max_nodes=96, mg_first_passes=3, mg_smoothed_levels=1), True
+    elif shape == "default_20k":
+        g, kw = graphgen.generate(20000, 20000, odom_f_max=2, seed=3), dict(mg_switch_iterations=0)
+    else:
+        g, kw = graphgen.generate(30000, 6000, odom_f_max=5, apply_yaw_weight=True, n_worlds=3, seed=8), dict(mg_switch_iterations=0)
+    _, t0, s0, implicit = run(g, True, mg_explicit_transfer=0, **kw)
+    _, t1, s1, explicit = run(g, True, mg_explicit_transfer=1, **kw)
+    same_trajectory(implicit, explicit, 1e-7)
+    assert np.abs(t1 - t0).max() <= 1e-5 and np.abs(s1 - s0).max() <= 1e-5
+    assert explicit.cg_iterations_multigrid > 0 and abs(explicit.cg_iterations - implicit.cg_iterations) <= 0.05 * implicit.cg_iterations + 10, (explicit.cg_iterations, implicit.cg_iterations)
+    if oracle:
+        q, t, s = util.initial_state(g, True)
+        _, to, so, sumo = util.oracle_problem(g, True).solve(q, t, s)
+        same_trajectory(sumo, explicit, 1e-6)
+        assert np.abs(t1 - to).max() <= 1e-3 and np.abs(s1 - so).max() <= 1e-3
+
+
 def test_regroup_follows_the_switches_and_keeps_the_trajectory():
     """mg_regroup_fraction: once the solver has switched the outliers off, the levels above level 1 are matched again along the couplings that are alive (the keyframes'
     level-1 aggregates and level 1's structure are cached).  Same LM trajectory with and without (the preconditioner changes, the steps do not), and a second solve of

@@ -55,6 +55,10 @@ def build(lib, g, free=None, passes0=3, passes=2, dense_max=64, tile_rows=32, ma
             S = dict(ps_rowptr=np.zeros(n + 1, np.int32), ps_col=np.zeros(int(ss[0]), np.int32), w_rowptr=np.zeros(n + 1, np.int32), w_col=np.zeros(int(ss[1]), np.int32),
                      psT_ptr=np.zeros(nagg, np.int64), psT_ent=np.zeros(int(ss[2]), np.int64))
             lib.mgh_smoothed(h, l, ptr(S["ps_rowptr"], C.c_int), ptr(S["ps_col"], C.c_int), ptr(S["w_rowptr"], C.c_int), ptr(S["w_col"], C.c_int), ptr(S["psT_ptr"], C.c_longlong), ptr(S["psT_ent"], C.c_longlong))
+            S.update(ps_of_w=np.zeros(int(ss[1]), np.int32), rT_rowptr=np.zeros(nagg, np.int32), rT_col=np.zeros(int(ss[1]), np.int32), rT_of_w=np.zeros(int(ss[1]), np.int32))
+            seg = C.c_int(0)
+            lib.mgh_explicit(h, l, ptr(S["ps_of_w"], C.c_int), ptr(S["rT_rowptr"], C.c_int), ptr(S["rT_col"], C.c_int), ptr(S["rT_of_w"], C.c_int), C.byref(seg))
+            S["rT_seg"] = seg.value
             L["smoothed"] = S
         levels.append(L)
     n1 = levels[0]["n"]
@@ -263,6 +267,20 @@ def test_smoothed_transition_structures_are_the_sparse_products(shim):
                 assert S["ps_rowptr"][i] <= sl < S["ps_rowptr"][i + 1] and S["ps_col"][sl] == a
                 seen[sl] += 1
         assert np.all(seen == 1)
+        # explicit transfer operator R^T = Ps - Dinv W on W's pattern: every W block knows its Ps block (same row, same column) or -1 — and every Ps block is found;
+        # W's pattern by coarse row is a permutation of it (rT_of_w), rows of R ascend by fine row; the lane groups of the restriction kernel follow the row lengths
+        w_rows = np.repeat(np.arange(n), np.diff(S["w_rowptr"]))
+        hit = S["ps_of_w"] >= 0
+        assert hit.sum() == len(S["ps_col"]) and len(set(S["ps_of_w"][hit].tolist())) == hit.sum()
+        ps_rows = np.repeat(np.arange(n), np.diff(S["ps_rowptr"]))
+        assert np.array_equal(ps_rows[S["ps_of_w"][hit]], w_rows[hit]) and np.array_equal(S["ps_col"][S["ps_of_w"][hit]], S["w_col"][hit])
+        assert sorted(S["rT_of_w"].tolist()) == list(range(len(S["w_col"])))
+        assert S["rT_rowptr"][0] == 0 and S["rT_rowptr"][-1] == len(S["w_col"]) and len(S["rT_rowptr"]) == nb + 1
+        r_rows = np.repeat(np.arange(nb), np.diff(S["rT_rowptr"]))
+        assert np.array_equal(r_rows[S["rT_of_w"]], S["w_col"]) and np.array_equal(S["rT_col"][S["rT_of_w"]], w_rows)
+        for a in range(nb):
+            assert np.all(np.diff(S["rT_col"][S["rT_rowptr"][a]:S["rT_rowptr"][a + 1]]) > 0)
+        assert S["rT_seg"] in (1, 2, 4, 8) and (S["rT_seg"] == 8 or len(S["w_col"]) / nb <= 5.0 * S["rT_seg"])
         # the level above is denser than with the tentative prolongator, the levels' sizes are the same
         assert len(B["col"]) > len(Href["levels"][l + 1]["col"]) and B["n"] == Href["levels"][l + 1]["n"]
 
