@@ -155,6 +155,8 @@ def main():
                     help="rccl: libpgo's own RCCL communicator over xGMI (default).  gloo: torch.distributed gloo through pgo_comm_init_custom "
                          "(host staging; lets several ranks share one GPU to validate the multi-rank path on a 1-GPU box)")
     ap.add_argument("--partition", choices=["spatial", "chain", "contiguous"], default="spatial", help="how edges are dealt out to the ranks (solve_keyframe_pose_graph_amd/sharding.py)")
+    ap.add_argument("--no-c5-strong", action="store_true", help="several ranks, default config: skip the extra BASELINE-config-5 leg (1M poses / 3M edges sharded over the ranks) that is appended as `c5_strong`")
+    ap.add_argument("--c5-timeout", type=int, default=300, help="watchdog of that leg, seconds")
     ap.add_argument("--config", choices=["C3", "C5"], default="C3",
                     help="C3 (default): the headline workload, N x C3 on N GPUs = WEAK scaling (what the driver's `bench.py --gpus N` runs).  C5: BASELINE.json config 5 — 1M poses / "
                          "3M edges, the SAME graph whatever N, edges sharded over the ranks = STRONG scaling; `value` is then LM iterations/s of that one graph")
@@ -325,41 +327,6 @@ def main():
 
     drop_problem(P)
 
-    # ---- several ranks, default (weak) run: BASELINE.json config 5 as well — the SAME 1M-pose / 3M-edge graph whatever N, its edges sharded over the ranks (strong scaling) —
-    # so that a scaling run carries the configured multi-GPU workload next to the weak N x C3 `value`.  A bounded leg: at most 5 LM iterations after 1 warm-up iteration.
-    c5_strong = None
-    if world > 1 and not strong:
-        try:
-            g5 = graphgen.config("C5")
-            parts5 = sharding.partition(g5, world, args.partition)
-            stats5 = sharding.partition_stats(g5, parts5) if rank == 0 else None
-            k5 = max(1, min(args.steps, 5))
-            P5 = make_problem(g5, parts5[rank])
-            q5, t5, s5 = g5.init_q, g5.init_t, np.full(g5.n_loops, 0.99)
-            P5.solve_begin(q5, t5, s5)
-            P5.lm_step(ignore_termination=True)
-            P5.solve_end()
-            P5.solve_begin(q5, t5, s5)
-            barrier(); P5.synchronize()
-            t5_0 = time.perf_counter()
-            for _ in range(k5):
-                P5.lm_step(ignore_termination=True)
-            P5.synchronize(); barrier()
-            el5 = time.perf_counter() - t5_0
-            tt = torch.tensor([el5], dtype=torch.float64, device="cuda" if args.collective == "rccl" else "cpu")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el5 = float(tt.item())
-            _, _, _, sum5 = P5.solve_end()
-            drop_problem(P5)
-            if rank == 0:
-                c5_strong = {"workload": "C5: synthetic 3D Manhattan graph, %d poses / %d edges, the same graph on every rank count (BASELINE.json config 5), edges sharded by the '%s' policy" % (g5.n_poses, g5.n_odom + g5.n_loops, args.partition),
-                             "scaling": "strong", "steps": k5, "seconds": el5, "lm_iters_per_s": k5 / el5, "chi2_final": 2.0 * sum5.final_cost, "cg_iterations_total": int(sum5.cg_iterations),
-                             "cg_iterations_multigrid": int(sum5.cg_iterations_multigrid), "shared_keyframes": stats5["shared_keyframes"], "edges_per_rank": [min(stats5["edges_per_rank"]), max(stats5["edges_per_rank"])],
-                             "note": "one all-reduce per CG iteration over the union of shared keyframes (+ the multigrid's level-1 vector); the coarse levels are replicated on every rank (DESIGN.md §8): what limits this figure"}
-            del g5, parts5
-        except Exception as e:      # the weak figure above is the contract; this leg is reported when it runs
-            c5_strong = {"error": repr(e)}
-
     # ---- K1 once more where its output cannot sit in the 256 MiB Infinity Cache: C3's 194 MB of Jacobian blocks are absorbed by it (plain
     # stores), so the C3 figure is an HBM + cache number; 400k keyframes / 1.2M edges write 775 MB with non-temporal stores
     k1_big = None
@@ -436,6 +403,40 @@ def main():
     traffic = static_traffic("k1_pmc_latest.json", lambda pj: pj["hbm_bytes_per_launch"])
     pcg_traffic = static_traffic("pcg_pmc_latest.json", lambda pj: pj["matvec"]["hbm_bytes_per_launch"] + pj["update"]["hbm_bytes_per_launch"])
     mg_traffic = static_traffic("mg_pmc_latest.json", lambda pj: pj["hbm_bytes_per_iteration"])
+    # ---- several ranks, default (weak) run: BASELINE.json config 5 as well — the SAME 1M-pose / 3M-edge graph whatever N, its edges sharded over the ranks (strong scaling) —
+    # so that a scaling run carries the configured multi-GPU workload next to the weak N x C3 `value`.  A bounded leg: at most 5 LM iterations after 1 warm-up iteration.
+    def run_c5_strong():
+        try:
+            g5 = graphgen.config("C5")
+            parts5 = sharding.partition(g5, world, args.partition)
+            stats5 = sharding.partition_stats(g5, parts5) if rank == 0 else None
+            k5 = max(1, min(args.steps, 5))
+            P5 = make_problem(g5, parts5[rank])
+            q5, t5, s5 = g5.init_q, g5.init_t, np.full(g5.n_loops, 0.99)
+            P5.solve_begin(q5, t5, s5)
+            P5.lm_step(ignore_termination=True)
+            P5.solve_end()
+            P5.solve_begin(q5, t5, s5)
+            barrier(); P5.synchronize()
+            t5_0 = time.perf_counter()
+            for _ in range(k5):
+                P5.lm_step(ignore_termination=True)
+            P5.synchronize(); barrier()
+            el5 = time.perf_counter() - t5_0
+            tt = torch.tensor([el5], dtype=torch.float64, device="cuda" if args.collective == "rccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el5 = float(tt.item())
+            _, _, _, sum5 = P5.solve_end()
+            drop_problem(P5)
+            if rank == 0:
+                return {"workload": "C5: synthetic 3D Manhattan graph, %d poses / %d edges, the same graph on every rank count (BASELINE.json config 5), edges sharded by the '%s' policy" % (g5.n_poses, g5.n_odom + g5.n_loops, args.partition),
+                             "scaling": "strong", "steps": k5, "seconds": el5, "lm_iters_per_s": k5 / el5, "chi2_final": 2.0 * sum5.final_cost, "cg_iterations_total": int(sum5.cg_iterations),
+                             "cg_iterations_multigrid": int(sum5.cg_iterations_multigrid), "shared_keyframes": stats5["shared_keyframes"], "edges_per_rank": [min(stats5["edges_per_rank"]), max(stats5["edges_per_rank"])],
+                             "note": "one all-reduce per CG iteration over the union of shared keyframes (+ the multigrid's level-1 vector); the coarse levels are replicated on every rank (DESIGN.md §8): what limits this figure"}
+            return None
+        except Exception as e:      # the weak figure above is the contract; this leg is reported when it runs
+            return {"error": repr(e)}
+
     out = None
     if rank == 0:
         ips = args.steps / elapsed
@@ -458,7 +459,7 @@ def main():
             "libpgo_sha256": lib_sha, "static_traffic_notes": traffic_note or None,
             # the hash of the sources the loaded library was built from (compiled in by _build.py) next to the hash of this checkout's sources: equal = built from this tree
             "libpgo_sources_sha256": capi.build_info()[0], "checkout_sources_sha256": capi.build_info()[1],
-            "lm_iters_per_s_raw": ips, "c5_strong": c5_strong,
+            "lm_iters_per_s_raw": ips, "c5_strong": None,
             "lm_iters_per_s_including_transfers": args.steps / elapsed_incl * scale,   # upload of the state, K iterations, write-back (rank 0's clock)
             "chi2_initial": 2.0 * summ.initial_cost, "chi2_final": 2.0 * summ.final_cost,
             "chi2_ref": chi2_ref, "chi2_rel_diff": chi2_rel,   # reference = the CPU trajectory after the same number of LM iterations (null: no golden for this workload / step count)
@@ -512,6 +513,24 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args.cpu_sample_poses, args.cpu_iters, 30.0)
             except Exception as e:   # the baseline is reported, never required for the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "LM iters/s (C3-equivalent)", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
+    if world > 1 and not strong and not args.no_c5_strong:
+        # The C5 leg runs LAST, after everything the contract asks for has been measured, under a watchdog on every rank: a collective that does not come back on some
+        # multi-GPU box must cost this leg, not the bench line — after --c5-timeout seconds rank 0 prints the line without it and every rank leaves.
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out["c5_strong"] = {"error": "timed out after %d s (the weak-scaling figures above are complete)" % args.c5_timeout}
+                os.write(result_fd, (json.dumps(out) + "\n").encode())
+            os._exit(0)
+        dog = threading.Timer(args.c5_timeout, give_up)
+        dog.daemon = True
+        dog.start()
+        c5 = run_c5_strong()
+        dog.cancel()
+        if rank == 0:
+            out["c5_strong"] = c5
+    if rank == 0:
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
