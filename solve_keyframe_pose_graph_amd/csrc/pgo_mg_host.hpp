@@ -20,6 +20,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <thread>
+#include <atomic>
+#include <new>
 #include <vector>
 #include <chrono>
 #include <cstdio>
@@ -27,7 +29,7 @@
 #define PGO_MG_T0() auto t_mg_ = std::chrono::steady_clock::now()
 #define PGO_MG_T(what) do { if (pgo_mg::timing()) { auto n_ = std::chrono::steady_clock::now(); std::fprintf(stderr, "[pgo] hierarchy (host): %-28s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(n_ - t_mg_).count()); t_mg_ = n_; } } while (0)
 
-namespace pgo_mg { inline bool& timing() { static bool on = false; return on; } }
+namespace pgo_mg { inline bool& timing() { static thread_local bool on = false; return on; } }      // per thread: every handle's hierarchy build (worker thread or caller) sets its own
 
 namespace pgo_mg {
 
@@ -72,16 +74,20 @@ template <class Fn>
 inline void parallel_ranges(int32_t n, int parts, Fn fn) {
     if (parts < 1) parts = 1;
     if (parts == 1 || n < 2048) { fn(0, 0, n); return; }
-    std::vector<std::thread> th;
+    // exception safety (the C-ABI above never throws; an allocation failure inside fn must not reach std::terminate): the helper threads are joined on EVERY exit of this
+    // function — also while an exception thrown by fn on the calling thread unwinds — and an exception inside a helper thread is caught there and re-thrown here as bad_alloc
+    struct Joiner { std::vector<std::thread> th; ~Joiner() { for (std::thread& t : th) if (t.joinable()) t.join(); } } j;
+    std::atomic<bool> helper_failed{false};
     const int32_t step = (n + parts - 1) / parts;
-    bool failed = false;
     for (int k = 0; k + 1 < parts; ++k) {
         const int32_t lo = std::min<int64_t>((int64_t)k * step, n), hi = std::min<int64_t>((int64_t)(k + 1) * step, n);
-        try { th.emplace_back([=, &fn]() { fn(k, lo, hi); }); } catch (...) { failed = true; fn(k, lo, hi); }
+        bool started = false;
+        try { j.th.emplace_back([=, &fn, &helper_failed]() { try { fn(k, lo, hi); } catch (...) { helper_failed.store(true); } }); started = true; } catch (...) {}
+        if (!started) fn(k, lo, hi);      // no thread to be had: the same range on this one
     }
-    (void)failed;
     fn(parts - 1, std::min<int64_t>((int64_t)(parts - 1) * step, n), n);
-    for (std::thread& t : th) t.join();
+    for (std::thread& t : j.th) t.join();
+    if (helper_failed.load()) throw std::bad_alloc();
 }
 inline int host_threads() { const unsigned hc = std::thread::hardware_concurrency(); return hc >= 32 ? 8 : hc >= 8 ? 4 : hc >= 4 ? 2 : 1; }      // (row ranges are joined in row order: the result does not depend on the count)
 
@@ -344,7 +350,8 @@ inline bool build_hierarchy(int64_t N, const std::vector<uint8_t>& node_free, co
             Cc.L1prov.n = n1;
         };
         std::thread l1_thread;
-        if (host_threads() > 1) { try { l1_thread = std::thread(level1_structure); } catch (...) {} }
+        std::atomic<bool> l1_failed{false};
+        if (host_threads() > 1) { try { l1_thread = std::thread([&]() { try { level1_structure(); } catch (...) { l1_failed.store(true); } }); } catch (...) {} }
         struct Join { std::thread& t; ~Join() { if (t.joinable()) t.join(); } } l1_join{l1_thread};
         const bool l1_async = l1_thread.joinable();
         // level-1 couplings: the relative-pose part as collapsed edges, the switchable part per pair of level-1 nodes with the list of its edges (their weights change)
@@ -376,7 +383,7 @@ inline bool build_hierarchy(int64_t N, const std::vector<uint8_t>& node_free, co
         }
         PGO_MG_T("level-1 couplings");
         if (!l1_async) level1_structure();
-        else l1_thread.join();      // (simple: joined here; the matching of the levels above is short next to it)
+        else { l1_thread.join(); if (l1_failed.load()) throw std::bad_alloc(); }      // (simple: joined here; the matching of the levels above is short next to it)
         Cc.valid = true;
         PGO_MG_T("level-1 block structure");
     }
@@ -517,8 +524,11 @@ inline bool build_hierarchy(int64_t N, const std::vector<uint8_t>& node_free, co
               for (int32_t i = 0; i < n; ++i) for (int32_t k = A.w_rowptr[i]; k < A.w_rowptr[(size_t)i + 1]; ++k) { const int32_t sl = fill[A.w_col[k]]++; A.rT_col[(size_t)sl] = i; A.rT_of_w[(size_t)k] = sl; } }
             {   // lane groups per coarse row, by the rule of the level kernels below (<= ~5 blocks per group, up to 8 groups)
                 const double mean_row = (double)A.w_col.size() / (double)std::max(1, nb);
+                static const double rt_blocks_per_group = []() {      // (debug override for scans, as below: PGO_ENABLE_DEBUG_HOOKS=1 and a value in [1, 64])
+                    const char* m = std::getenv("PGO_ENABLE_DEBUG_HOOKS"); const char* e = std::getenv("PGO_DEBUG_RT_SEG_BLOCKS");
+                    const double v = (m && m[0] == '1' && m[1] == 0 && e) ? std::atof(e) : 0.0; return v >= 1.0 && v <= 64.0 ? v : 5.0; }();
                 A.rT_seg = 1;
-                while (A.rT_seg < 8 && mean_row > 5.0 * A.rT_seg) A.rT_seg *= 2;
+                while (A.rT_seg < 8 && mean_row > rt_blocks_per_group * A.rT_seg) A.rT_seg *= 2;
             }
             continue;
         }

@@ -978,8 +978,13 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_prolong0_kernel(GraphDev G, MgDev
 // same sums as mg_restrict0_kernel) — and with it x_1 = w D_1^-1 r_1.  The slot table entries a lane needs are requested before the partial-sum
 // re-reduction, together with the vector operands.
 // SR: the single-reduction form of the update (cg_update_kernel<true>: p = u + beta p, s = w + beta s, x += alpha p, r -= alpha s in place) with the same restriction.
+#ifdef PGO_SR_MG_NO_BOUNDS      // A/B aid (variant build): 174 VGPRs, two waves per SIMD, no spills
+#define PGO_SR_MG_WAVES 1
+#else
+#define PGO_SR_MG_WAVES 3
+#endif
 template <bool SR>
-__global__ __launch_bounds__(CG_BLOCK, SR ? 3 : 1) void cg_update_mg_kernel(GraphDev G, CgDev C, MgDev M, double* __restrict__ r1_out, double* __restrict__ x1_out, const double* __restrict__ Dinv1,
+__global__ __launch_bounds__(CG_BLOCK, SR ? PGO_SR_MG_WAVES : 1) void cg_update_mg_kernel(GraphDev G, CgDev C, MgDev M, double* __restrict__ r1_out, double* __restrict__ x1_out, const double* __restrict__ Dinv1,
                                                                  int parity, int nparts_pq, int nparts, int first) {
     static_assert(CG_BLOCK / 3 == MG_BLOCK0, "one workgroup trip of the vector update = one run of the slot table");
     __shared__ double red[2 * (CG_BLOCK / 64) + 1];

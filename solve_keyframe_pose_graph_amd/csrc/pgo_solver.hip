@@ -311,7 +311,14 @@ int host_allreduce(pgo_problem* p, std::vector<double>& v, int op);
 // (pgo_mg_host.hpp), pooled device arrays, level descriptors.  Called by build_graph, and again inside a solve when the switch values have moved far from the ones the
 // hierarchy was built with (regroup): the levels above level 1 are matched along the couplings that are alive NOW.  p->mg_cache keeps what does not depend on the switches.
 // host half: hierarchy + pooled index arrays.  Reads the handle's edge lists, options and mg_cache only (single rank: no HIP, no collective -> may run on a worker thread)
+int mg_prepare_impl(pgo_problem* p, const double* sw_now, MgPrepared& Q);
+// (runs on worker threads as well: nothing may escape — the C-ABI never throws, and an exception leaving a std::thread is std::terminate)
 int mg_prepare(pgo_problem* p, const double* sw_now, MgPrepared& Q) {
+    try { return mg_prepare_impl(p, sw_now, Q); }
+    catch (const std::bad_alloc&) { Q.ok = false; return PGO_ERR_OUT_OF_MEMORY; }
+    catch (...) { Q.ok = false; return PGO_ERR_OUT_OF_MEMORY; }
+}
+int mg_prepare_impl(pgo_problem* p, const double* sw_now, MgPrepared& Q) {
     const int64_t N = p->N, Ng = p->N_global, S = p->S;
     const int64_t Er = p->rel.size(), Es = p->swe.size();
     int rc;
@@ -1723,8 +1730,12 @@ int solve_begin(pgo_problem* p, const double* quat, const double* t, const doubl
     else if ((rc = mg_init_finish(p)) != PGO_OK) return rc;      // (an unchanged graph whose hierarchy no solve has needed yet: installed, then compared with this solve's start values)
     if (!rebuild && p->opt.mg_regroup_fraction > 0.0 && p->mg_built && S > 0 && sw && (int64_t)p->mg_sw_built.size() == p->swe.size()) {
         // the hierarchy of an unchanged graph was built (or regrouped inside the last solve) for other switch values than this solve starts from: the levels above level 1
-        // follow the start — a session's next trigger (switches as the last solve left them) keeps it, a re-solve from the original guess gets the original one back,
-        // so repeated solves from the same state stay bitwise identical
+        // are rebuilt for the start values whenever ANY switch differs from the record (regroup_if_moved, moved_by = 0) — a synchronous mg_prepare + mg_install, tens of
+        // milliseconds on C3 — so that repeated solves from the same state stay bitwise identical whatever the handle solved before.  What this costs in practice: a session's
+        // next trigger has a NEW graph (one more loop edge: full rebuild anyway); only a re-solve of an unchanged graph from other switch values pays it.  (The matching
+        // depends on the switch values continuously — coupling strengths order the heavy-edge matching — so "nearly the same switches" is not a safe reason to keep a hierarchy.)
+        // Exception, stated: when the rebuilt hierarchy does not coarsen the one in place stays (regroup_commit) with the new switch record; the starting hierarchy then
+        // depends on the handle's history.  No graph of the test suite or of profiles/ reaches that branch at a solve's start.
         if ((rc = regroup_if_moved(p, sw, false)) != PGO_OK) return rc;
     }
     // upload in the reference layout (multi-GPU: only this rank's keyframes), repack on the device
