@@ -60,13 +60,13 @@ def run_real_ceres(sample_poses, max_iters):
 
 def measured_c3():
     """The one full-size measurement of the CPU port on C3 (hours of CPU: not repeated inside the driver's bench run)"""
-    for name in ("r04_cpu_c3_full.json",):
+    for name in ("r05_cpu_c3_full_gpubox.json", "r04_cpu_c3_full.json"):      # round 5: the first LM iteration on a GPU box's own host (EPYC 9575F); round 4: three iterations in the build container
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)
             return {"value": d["lm_iterations_per_second"], "unit": "LM iters/s", "cores": 1, "kind": "port", "seconds_per_lm_iteration": d["seconds_per_lm_iteration"], "lm_iterations": d["lm_iterations"],
                     "seconds_linear_solver": d["seconds_linear_solver"], "cholesky_fill_blocks": d["cholesky_fill_blocks"], "host_cpu": d.get("host_cpu"), "file": "profiles/" + name,
-                    "note": "measured at full size on %s; static (not re-measured in this run)" % (d.get("machine") or "the GPU box's host")}
+                    "note": "measured at full size on %s (%s); static (not re-measured in this run)" % (d.get("machine") or "the GPU box's host", d.get("host_cpu") or "?")}
         except Exception:
             continue
     return None

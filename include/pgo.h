@@ -186,6 +186,9 @@ typedef struct pgo_options {
                                           *    pattern of W = A Ps, formed once per LM system): pre-smoothing step + smoothed restriction and smoothed prolongation + post-smoothing step
                                           *    become  v = x + Dinv (r - A x), r_next = R r  and  x = v + R^T x_next — two row products on that level per cycle, two launches fewer per
                                           *    PCG iteration; algebraically the same V(1,1) cycle.  0: the implicit form of rounds 3-4 (four row products with the level's own matrix) */
+    int32_t cg_end_game;                 /* 1: once the polled r.z values predict fewer than two chunks of PCG iterations to go, the host stops running a chunk ahead and enqueues what the
+                                          *    prediction asks for (one GPU); 0: always one full chunk in flight, as in rounds 1-4.  Changes how many early-exit kernels follow a stopped PCG,
+                                          *    never its iterates. */
     int32_t cg_pause_always;             /* 0: the early-rejection pauses are armed only where a rejection is in the air (previous step rejected, or the last accepted step's relative decrease
                                           *    below 0.8); 1: at every LM system of graphs >= 20 000 keyframes / after the solve's first rejection (round 4's rule) */
 } pgo_options;

@@ -7,7 +7,12 @@ import numpy as np
 from solve_keyframe_pose_graph_amd import capi, graphgen
 name, steps, reps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 sets = sys.argv[4:] or [""]
-g = graphgen.config(name) if not name.startswith('N') else graphgen.generate(int(name[1:]), int(name[1:]), odom_f_max=2, seed=3)
+if name.startswith('N'):
+    g = graphgen.generate(int(name[1:]), int(name[1:]), odom_f_max=2, seed=3)
+elif name.startswith('S'):      # session structure (scripts/research/session_step_times.py)
+    g = graphgen.generate(int(name[1:]), int(name[1:]) // 5, odom_f_max=5, apply_yaw_weight=1, seed=5, **dict(graphgen._SMALL, turn_deg_per_keyframe=2.0))
+else:
+    g = graphgen.config(name)
 q0, t0, s0 = g.init_q, g.init_t, np.full(g.n_loops, 0.99)
 
 
@@ -30,13 +35,15 @@ for r in range(reps + 1):      # round 0 = warm-up, not printed
         P.synchronize()
         el = time.perf_counter() - t
         ms = {}
-        for which, label in ((2, 'bj_it'), (4, 'matvec'), (5, 'update'), (6, 'mg_it'), (7, 'mg_cycle')):
+        for which, label in ((2, 'bj_it'), (4, 'matvec'), (5, 'update'), (6, 'mg_it'), (7, 'mg_cycle')) if not name.startswith('S') else ():
             try:
                 ms[label] = P.time_kernel(which, 50)[0] * 1e3
             except capi.PgoError:
                 ms[label] = float('nan')
         _, _, _, sm = P.solve_end()
         P.close()
+        for label in ('bj_it', 'matvec', 'update', 'mg_it', 'mg_cycle'):
+            ms.setdefault(label, float('nan'))
         if r:
             print("%-44s #%d  %.4f s  %.2f it/s  cg %d (mg %d)  final cost %.12e | us: bj %.2f (mv %.2f up %.2f) mg %.2f (cycle %.2f)" %
                   (txt or "(defaults)", r, el, steps / el, sm.cg_iterations, sm.cg_iterations_multigrid, sm.final_cost, ms['bj_it'], ms['matvec'], ms['update'], ms['mg_it'], ms['mg_cycle']), flush=True)

@@ -214,6 +214,8 @@ void launch_cg_update(const GraphDev& G, const CgDev& C, int k, int n_pq_partial
 // single-reduction (Chronopoulos-Gear) form on one GPU: w = A u with the partials of u.w (stops with the PCG), then ONE update kernel that re-reduces both dot products
 void launch_mf_apply_dot_live(const GraphDev& G, const MfDev& F, const ScaleDev& Sc, const CgDev& C, hipStream_t st);
 void launch_cg_update_sr(const GraphDev& G, const CgDev& C, int k, int first, int n_pq_partials, hipStream_t st);
+void launch_mf_apply_dot_live_coarse(const GraphDev& G, const MfDev& F, const ScaleDev& Sc, const CgDev& C, const CoarseDev& K, int pending, hipStream_t st);      // two-level method, fused form
+void launch_cg_update_restrict_sr(const GraphDev& G, const CgDev& C, const CoarseDev& K, int k, int first, int pending, int n_pq_partials, hipStream_t st);
 int cg_grid_size(const GraphDev& G);
 int mf_grid_size(const MfDev& F);
 void launch_apply_operator(const GraphDev& G, const CgDev& C, const double* x, double* y, hipStream_t st);

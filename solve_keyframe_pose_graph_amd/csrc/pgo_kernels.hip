@@ -985,12 +985,21 @@ __global__ void cg_scalars_init_kernel(CgDev C, int nparts, int nparts_bb, doubl
 // TOGETHER — the iteration's only reduction point — then the convergence test the classic form runs at the head of its matvec, beta = gamma / gamma_prev,
 // alpha = gamma / (delta - beta gamma / alpha_prev).  Scalars in C.scal[8 + 2 parity] (gamma), [9 + 2 parity] (alpha) of the iteration with that parity (as the multi-rank
 // kernel keeps them).  Returns false when the workgroup has nothing to do (stopped, converged, broken down).
-__device__ __forceinline__ bool sr_head(const CgDev& C, int parity, int first, int nparts_pq, int nparts, double* red, double& alpha, double& beta) {
+// split_coarse (the two-level method's fused iteration): the slots behind the update kernel's `nparts` hold the coarse part rc.Ac^-1 rc of r.u (coarse_solve_dot_kernel); a
+// convergence that the block-Jacobi part alone does not confirm is a breakdown of the fp32-rounded coarse inverse, never a converged step (the classic form runs the same
+// test at the head of its matvec: mf_spmv_kernel<true, true>); coarse_only: one aggregate per keyframe, u is the coarse term alone.  red: 3 x waves + 1 doubles then.
+__device__ __forceinline__ bool sr_head(const CgDev& C, int parity, int first, int nparts_pq, int nparts, double* red, double& alpha, double& beta, bool split_coarse = false, bool coarse_only = false) {
     double delta, gamma;
-    if (block_total2_done(C.flags, C.part_pq, nparts_pq, C.part_rz + parity * RZ_STRIDE, nparts + C.extra_rz, red, delta, gamma)) return false;
+    bool coarse_negative = false;
+    if (split_coarse) {
+        double g_bj, g_c;
+        if (block_total3_done(C.flags, C.part_pq, nparts_pq, C.part_rz + parity * RZ_STRIDE, nparts, C.part_rz + parity * RZ_STRIDE + nparts, C.extra_rz, red, delta, g_bj, g_c)) return false;
+        gamma = g_bj + g_c;
+        coarse_negative = !coarse_only && !(gamma > C.scal[3] * C.scal[0]) && g_bj > C.scal[3] * C.scal[0];
+    } else if (block_total2_done(C.flags, C.part_pq, nparts_pq, C.part_rz + parity * RZ_STRIDE, nparts + C.extra_rz, red, delta, gamma)) return false;
     const bool breakdown = C.flags[1] != 0;
     if (breakdown || !(gamma > C.scal[3] * C.scal[0])) {      // converged (or broken down): the state stays that of the last completed update
-        if (blockIdx.x == 0 && threadIdx.x == 0) { C.flags[0] = 1; if (!breakdown) { C.scal[1] = gamma; if (!(gamma >= -C.scal[3] * C.scal[0])) C.flags[1] = 1; } }
+        if (blockIdx.x == 0 && threadIdx.x == 0) { C.flags[0] = 1; if (!breakdown) { C.scal[1] = gamma; if (coarse_negative || !(gamma >= -C.scal[3] * C.scal[0])) C.flags[1] = 1; } }
         return false;
     }
     beta = 0.0;
@@ -2162,14 +2171,31 @@ __global__ __launch_bounds__(CG_BLOCK) void coarse_prolong_kernel(GraphDev G, Co
 //   mf_spmv_kernel<true, true>    prolongs the pending coarse correction while it forms p (above)
 //   cg_update_restrict_kernel     cg_update_kernel + rc = P^T r' : a workgroup trip covers `kft` keyframes = WHOLE aggregates (kft = (64 / m) m)
 //   coarse_solve_dot_kernel       y = Ac^-1 rc and the partial sums of rc.y = r'.(P y), the coarse part of r.z, behind the update kernel's partials
-__global__ __launch_bounds__(CG_BLOCK) void cg_update_restrict_kernel(GraphDev G, CgDev C, CoarseDev K, int parity, int nparts_pq, int nparts, int kft) {
-    __shared__ double red[2 * (CG_BLOCK / 64) + 1];
-    const double2* __restrict__ rin = reinterpret_cast<const double2*>(parity ? C.r2 : C.r);
-    double2* __restrict__ rout = reinterpret_cast<double2*>(parity ? C.r : C.r2);
-    const double2* __restrict__ pcur = reinterpret_cast<const double2*>(parity ? C.p2 : C.p);
+// SR: the single-reduction form (cg_update_kernel<true>) of the same kernel.  The preconditioned residual it needs in full, u = z_bj + P y (y = Ac^-1 rc of the previous dense
+// solve, still "pending": the classic form folds it into the next matvec's direction update), is completed here per lane from K.yc and the keyframe's offset.
+template <bool SR>
+__global__ __launch_bounds__(CG_BLOCK) void cg_update_restrict_kernel(GraphDev G, CgDev C, CoarseDev K, int parity, int nparts_pq, int nparts, int kft, int first, int pending) {
+    __shared__ double red[3 * (CG_BLOCK / 64) + 1];
+    const double2* __restrict__ rin = reinterpret_cast<const double2*>(SR ? C.r : (parity ? C.r2 : C.r));
+    double2* __restrict__ rout = reinterpret_cast<double2*>(SR ? C.r : (parity ? C.r : C.r2));
+    const double2* __restrict__ pcur = reinterpret_cast<const double2*>(SR ? C.p : (parity ? C.p2 : C.p));
     const double2* __restrict__ qv = reinterpret_cast<const double2*>(C.q);
     double2* __restrict__ xv = reinterpret_cast<double2*>(C.x);
     double2* __restrict__ zv = reinterpret_cast<double2*>(C.z);
+    double2* __restrict__ pout = reinterpret_cast<double2*>(C.p);      // (SR only)
+    double2* __restrict__ sv = reinterpret_cast<double2*>(C.p2);       // (SR only) s = A p
+    double2 u0 = make_double2(0.0, 0.0), s0 = u0;
+    // the lane's row pair of the pending coarse correction P y: dtheta_i = dtheta_a ; dt_i = dt_a - 2 d_i x dtheta_a (0 for fixed keyframes)
+    auto pending_pair = [&](int64_t node, int j, double e0, double e1, double e2, double free_) -> double2 {
+        const double* y = K.yc + (size_t)(node / K.m) * 6;
+        const double y0 = y[0], y1 = y[1], y2 = y[2], y3 = y[3], y4 = y[4], y5 = y[5];
+        double2 c;
+        if (j == 0) c = make_double2(y0, y1);
+        else if (j == 1) c = make_double2(y2, y3 - 2.0 * (e1 * y2 - e2 * y1));
+        else c = make_double2(y4 - 2.0 * (e2 * y0 - e0 * y2), y5 - 2.0 * (e0 * y1 - e1 * y0));
+        c.x *= free_; c.y *= free_;
+        return c;
+    };
     const int t = threadIdx.x;
     const int64_t groups = (G.N + kft - 1) / kft;
     const int64_t kf_first = (int64_t)blockIdx.x * kft + t / 3;
@@ -2177,19 +2203,28 @@ __global__ __launch_bounds__(CG_BLOCK) void cg_update_restrict_kernel(GraphDev G
     const int64_t i_first = (int64_t)blockIdx.x * kft * 3 + t;
     double2 r0 = make_double2(0.0, 0.0), q0 = r0, p0 = r0, x0 = r0;
     double d0 = 0.0, d1 = 0.0, d2 = 0.0, fr = 0.0;      // the lane's keyframe: offset from its aggregate's centroid, free flag
+    const bool direct = K.m == 1;
+    auto load_u = [&](int64_t i, int64_t node, int j) {      // (SR) u = z_bj + P y (direct: the coarse term alone), s
+        u0 = zv[i]; s0 = sv[i];
+        if (pending) { const double2 c = pending_pair(node, j, d0, d1, d2, fr); if (direct) u0 = c; else { u0.x += c.x; u0.y += c.y; } }
+    };
     if (live_first) {
         r0 = rin[i_first]; q0 = qv[i_first]; p0 = pcur[i_first]; x0 = xv[i_first];
         const double* d = K.d + (size_t)kf_first * 3; d0 = d[0]; d1 = d[1]; d2 = d[2]; fr = G.node_free[kf_first] ? 1.0 : 0.0;
+        if (SR) load_u(i_first, kf_first, t % 3);
     }
-    double pq, rz;
-    if (block_total2_done(C.flags, C.part_pq, nparts_pq, C.part_rz + parity * RZ_STRIDE, nparts + C.extra_rz, red, pq, rz)) return;
-    if (!(pq > 0.0)) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) C.flags[1] = 1;
-        if (threadIdx.x == 0) C.part_rz[(parity ^ 1) * RZ_STRIDE + blockIdx.x] = 0.0;
-        return;
+    double alpha = 0.0, beta = 0.0;
+    if (SR) { if (!sr_head(C, parity, first, nparts_pq, nparts, red, alpha, beta, true, direct)) return; }
+    else {
+        double pq, rz;
+        if (block_total2_done(C.flags, C.part_pq, nparts_pq, C.part_rz + parity * RZ_STRIDE, nparts + C.extra_rz, red, pq, rz)) return;
+        if (!(pq > 0.0)) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) C.flags[1] = 1;
+            if (threadIdx.x == 0) C.part_rz[(parity ^ 1) * RZ_STRIDE + blockIdx.x] = 0.0;
+            return;
+        }
+        alpha = rz / pq;
     }
-    const double alpha = rz / pq;
-    const bool direct = K.m == 1;
     __shared__ double2 btr[CG_BLOCK];       // B_i^T r'_i, row pair j of keyframe t / 3 at [t]
     __shared__ double2 rnew[CG_BLOCK];
     __shared__ __attribute__((aligned(16))) float lfs[(CG_BLOCK / 3) * LF_STRIDE];
@@ -2203,9 +2238,18 @@ __global__ __launch_bounds__(CG_BLOCK) void cg_update_restrict_kernel(GraphDev G
             if (g != (int64_t)blockIdx.x) {
                 r0 = rin[i]; q0 = qv[i]; p0 = pcur[i]; x0 = xv[i];
                 const double* d = K.d + (size_t)(base + t / 3) * 3; d0 = d[0]; d1 = d[1]; d2 = d[2]; fr = G.node_free[base + t / 3] ? 1.0 : 0.0;
+                if (SR) load_u(i, base + t / 3, t % 3);
             }
-            rr = make_double2(r0.x - alpha * q0.x, r0.y - alpha * q0.y);
-            x0.x += alpha * p0.x; x0.y += alpha * p0.y;
+            if (SR) {
+                p0.x = u0.x + beta * p0.x; p0.y = u0.y + beta * p0.y;
+                s0.x = q0.x + beta * s0.x; s0.y = q0.y + beta * s0.y;
+                rr = make_double2(r0.x - alpha * s0.x, r0.y - alpha * s0.y);
+                x0.x += alpha * p0.x; x0.y += alpha * p0.y;
+                pout[i] = p0; sv[i] = s0;
+            } else {
+                rr = make_double2(r0.x - alpha * q0.x, r0.y - alpha * q0.y);
+                x0.x += alpha * p0.x; x0.y += alpha * p0.y;
+            }
             rout[i] = rr; xv[i] = x0;
         }
         __syncthreads();
@@ -2278,7 +2322,15 @@ int coarse_update_grid(const GraphDev& G, const CoarseDev& K) {
 int coarse_solve_grid(const CoarseDev& K) { return (K.nc + CSOLVE_ROWS - 1) / CSOLVE_ROWS; }
 void launch_cg_update_restrict(const GraphDev& G, const CgDev& C, const CoarseDev& K, int k, int n_pq_partials, hipStream_t st) {
     const int g = coarse_update_grid(G, K);
-    hipLaunchKernelGGL(cg_update_restrict_kernel, dim3(g), dim3(CG_BLOCK), 0, st, G, C, K, k & 1, n_pq_partials, g, coarse_group_keyframes(K));
+    hipLaunchKernelGGL(cg_update_restrict_kernel<false>, dim3(g), dim3(CG_BLOCK), 0, st, G, C, K, k & 1, n_pq_partials, g, coarse_group_keyframes(K), 0, 0);
+}
+// single-reduction form of the two-level method's fused iteration: w = A (z_bj + P y) with the partials of u.w (stops with the PCG), then the update that re-reduces both dot products
+void launch_mf_apply_dot_live_coarse(const GraphDev& G, const MfDev& F, const ScaleDev& Sc, const CgDev& C, const CoarseDev& K, int pending, hipStream_t st) {
+    hipLaunchKernelGGL((mf_spmv_kernel<false, true>), dim3(mf_grid(F)), dim3(MF_BLOCK), 0, st, G, F, Sc, C, (const double*)C.z, C.q, 0, 3, 0, 0.0, K, pending);
+}
+void launch_cg_update_restrict_sr(const GraphDev& G, const CgDev& C, const CoarseDev& K, int k, int first, int pending, int n_pq_partials, hipStream_t st) {
+    const int g = coarse_update_grid(G, K);
+    hipLaunchKernelGGL(cg_update_restrict_kernel<true>, dim3(g), dim3(CG_BLOCK), 0, st, G, C, K, k & 1, n_pq_partials, g, coarse_group_keyframes(K), first, pending);
 }
 void launch_coarse_solve_dot(const CoarseDev& K, const int32_t* stop, double* part, hipStream_t st) {
     hipLaunchKernelGGL(coarse_solve_dot_kernel, dim3(coarse_solve_grid(K)), dim3(CSOLVE_ROWS * 64), 0, st, K, stop, part);

@@ -227,7 +227,7 @@ struct pgo_problem {
 
     // pipelined convergence polling: pinned host copies of {flags[4], scal[4]} for two chunks in flight
     struct Poll { int32_t flags[4]; double scal[4]; };
-    Poll* poll = nullptr; hipEvent_t poll_ev[2] = {nullptr, nullptr};
+    Poll* poll = nullptr; hipEvent_t poll_ev[2] = {nullptr, nullptr};      // poll[2]: snapshot at the start of a PCG phase (base point of the convergence-rate estimate)
 
     // hipGraph of one PCG chunk (launch-bound inner loop); valid for (graph build epoch, tolerance, chunk length, solver)
     // one captured chunk per preconditioner (0 block-Jacobi, 1 two-level, 2 multigrid): the hybrid policy changes between them inside a solve
@@ -1174,7 +1174,9 @@ struct CgResult { int iterations; bool breakdown; double rel_residual; bool conv
 // vector kernel whose head re-reduces u.w and r.u together (pgo_kernels.hip: sr_head).  Decided by the options alone, so every phase of a paused PCG runs the same form.
 // The two-level method keeps the classic form (its fused three-kernel iteration folds the prolongation into the direction update of the classic matvec).
 bool single_reduction(const pgo_problem* p) {
-    return p->opt.cg_single_reduction != 0 && !p->local_ids && p->built_mf && p->opt.cg_rel_tolerance >= 1e-11 && !(p->coarse_active && !p->mg_active);
+    // (the two-level method: only its fused three-kernel iteration has a single-reduction form; its unfused form — aggregates too large for the update kernel's groups — stays classic)
+    const bool two_level = p->coarse_active && !p->mg_active;
+    return p->opt.cg_single_reduction != 0 && !p->local_ids && p->built_mf && p->opt.cg_rel_tolerance >= 1e-11 && (!two_level || coarse_group_keyframes(p->K) > 0);
 }
 
 // rel_tol: relative tolerance of this phase.  resume_from >= 0: continue the stopped PCG at that iteration index with the new tolerance
@@ -1253,6 +1255,13 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
     int rc;
     const bool sr = single_reduction(p);
     auto one_iteration = [&](int kk) -> int {
+        if (sr && fused_coarse) {      // two-level method: w = A (z_bj + P y), update + restriction with the one reduction point, dense solve (y, coarse part of r.u)
+            const int pending = kk > 0 ? 1 : 0;      // (iteration 0: the PCG start has left the complete u in C.z)
+            launch_mf_apply_dot_live_coarse(p->G, p->F, p->Sc, p->C, p->K, pending, p->st);
+            launch_cg_update_restrict_sr(p->G, p->C, p->K, kk, kk == 0 ? 1 : 0, pending, mf_grid_size(p->F), p->st);
+            launch_coarse_solve_dot(p->K, p->C.flags, p->C.part_rz + (size_t)((kk & 1) ^ 1) * RZ_STRIDE + fused_parts, p->st);
+            return PGO_OK;
+        }
         if (sr) {      // matvec (no head: it only asks whether the PCG has stopped), update with the iteration's one reduction point, [the multigrid cycle]
             launch_mf_apply_dot_live(p->G, p->F, p->Sc, p->C, p->st);
             const int n_pq = mf_grid_size(p->F), first = kk == 0 ? 1 : 0;      // (first: also when a PCG that stopped before its first update is resumed — p = s = 0 still)
@@ -1337,6 +1346,31 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
     int n_chunks = 0, waited = -1, r1_refreshed_at = k;
     int ex_k0 = -1; double ex_rz0 = 0.0;      // first polled (iteration, r.z) of this run: base of the convergence-rate estimate
     bool done = false;
+    // END GAME (round 5, one GPU).  A chunk enqueued past convergence is a string of early-exit kernels (~2 us each: 100-150 us per stopped PCG with a chunk in flight, more
+    // than a tenth of a session-sized PCG).  The polled r.z values give the convergence rate; once the predicted remaining iterations fall below two chunks the host stops
+    // running ahead: it enqueues what the prediction asks for (+15 % + 4 iterations: an early-exit iteration costs a quarter of a host round trip), eagerly, and polls at once.
+    // Chunk lengths depend on the device's own r.z values alone — the PCG's iterates do not depend on how its iterations are cut into chunks.
+    const bool end_game = o.cg_end_game != 0 && !multi;
+    bool eg_tight = false, eg_have = false; int eg_next = every; int eg_k = 0; double eg_rz = 0.0;
+    auto eg_snapshot = [&]() { if (end_game) launch_cg_poll(p->C, p->poll[2].flags, p->poll[2].scal, p->st); eg_have = false; };      // (read only after a later poll's event: stream order)
+    auto eg_update = [&](int slot) {      // a completed poll: new rate estimate from the last two points, length of the next chunk
+        if (!end_game) return;
+        const int kk = p->poll[slot].flags[2];
+        const double rz = p->poll[slot].scal[1], bb = p->poll[slot].scal[0];
+        if (!eg_have) { eg_k = p->poll[2].flags[2]; eg_rz = p->poll[2].scal[1]; eg_have = true; }
+        eg_tight = false; eg_next = every;
+        if (rz > 0.0 && bb > 0.0 && eg_rz > 0.0 && kk > eg_k && rz < eg_rz) {
+            const double lr = std::log(rz / eg_rz) / (double)(kk - eg_k);
+            const double need = std::log(tol2 * bb / rz);
+            const double left = need < 0.0 ? need / lr - (double)(k - kk) : 0.0;      // iterations still to run beyond what is already enqueued
+            if (left < 2.0 * (double)every) {
+                eg_tight = true;
+                const int want = (int)std::ceil(std::max(left, 0.0) * 1.15 + 4.0);
+                eg_next = std::max(2, std::min(every, (want + 1) & ~1));
+            }
+        }
+        if (kk > eg_k) { eg_k = kk; eg_rz = rz; }
+    };
     auto enqueue_poll = [&](int slot) -> int {
 #ifdef PGO_POLL_BY_COPY
         HIPCHK(p, hipMemcpyAsync(p->poll[slot].flags, p->C.flags, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, p->st));
@@ -1365,13 +1399,24 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
         }
         k = 0; n_chunks = 0; waited = -1; r1_refreshed_at = 0;
         every = chunk_length();
+        eg_tight = false; eg_next = every; eg_have = false; eg_snapshot();
         ensure_graph(true);      // a system that needed the switch is a long one
         return PGO_OK;
     };
     // a system predicted hard whose step has survived the first early-rejection pause (lm_step): the multigrid takes over from the iterate the pause left
     if (switch_now && resume_from >= 0 && p->mg_built && !p->mg_active && !p->mg_failed && (rc = switch_to_mg(resume_from)) != PGO_OK) return rc;
+    eg_next = every;
+    if (end_game && (resume_from >= 0 || k == 0)) eg_snapshot();
     while (k < o.cg_max_iterations && !done) {
-        const int chunk = std::min(every, o.cg_max_iterations - k);
+        if (eg_tight && n_chunks > 0 && waited < n_chunks - 1) {      // end game: the chunk in flight is waited for before anything else is enqueued
+            HIPCHK(p, hipEventSynchronize(p->poll_ev[(n_chunks - 1) & 1]));
+            waited = n_chunks - 1;
+            if (p->poll[waited & 1].flags[0]) { done = true; break; }
+            eg_update(waited & 1);
+        }
+        // (a phase that only has to reach an early-rejection pause's loose tolerance is a matter of a few iterations: its first chunk is short, the rate estimate takes over from there)
+        const int first_short = end_game && n_chunks == 0 && rel_tol >= 5e-3 ? std::min(every, 8) : every;
+        const int chunk = std::min(eg_tight ? eg_next : first_short, o.cg_max_iterations - k);
         if (multi && p->mg_active && k - r1_refreshed_at >= every) {
             // The level-1 residual follows a recurrence of its own (q1 rides in the exchange); while r falls by ten decades its absolute rounding drift does
             // not, and a preconditioner fed with a residual that is not P0^T r any more breaks the PCG down near tight tolerances (measured at 1e-11).
@@ -1395,11 +1440,12 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
         }
         if ((rc = enqueue_poll(n_chunks & 1)) != PGO_OK) return rc;
         // the first two chunks are polled immediately (short solves finish there); afterwards one chunk stays in flight
-        const int check = n_chunks < 2 ? n_chunks : n_chunks - 1;
+        const int check = (n_chunks < 2 || eg_tight) ? n_chunks : n_chunks - 1;
         if (check > waited) {
             HIPCHK(p, hipEventSynchronize(p->poll_ev[check & 1]));
             waited = check;
             if (p->poll[check & 1].flags[0]) done = true;
+            else eg_update(check & 1);
             // A system without a prediction (the first of a solve, the first after rejected steps) need not burn mg_switch_iterations block-Jacobi iterations to be
             // recognised as hard: the polled r.z values give its convergence rate, and a system that would need >= the start threshold in total at that rate (and at
             // least twice what it has done) switches now.  Depends on the solve's own data alone; several ranks: r.z and the reference norm are all-reduced values, every
@@ -2113,6 +2159,7 @@ void pgo_options_init(pgo_options* o) {
     o->cg_single_reduction = 1;
     o->cg_pause_always = 0;
     o->mg_explicit_transfer = 1;
+    o->cg_end_game = 1;
 }
 
 int pgo_create(pgo_problem** out, const pgo_options* opts) {
@@ -2129,9 +2176,9 @@ int pgo_create(pgo_problem** out, const pgo_options* opts) {
     p->device = dev;
     if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&p->st, hipStreamNonBlocking) != hipSuccess) { delete p; return PGO_ERR_NO_DEVICE; }
     std::memset(&p->sum, 0, sizeof(p->sum));
-    if (hipHostMalloc((void**)&p->poll, 2 * sizeof(pgo_problem::Poll), hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&p->poll_ev[0], hipEventDisableTiming) != hipSuccess ||
+    if (hipHostMalloc((void**)&p->poll, 3 * sizeof(pgo_problem::Poll), hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&p->poll_ev[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&p->poll_ev[1], hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(p->st); delete p; return PGO_ERR_OUT_OF_MEMORY; }
-    std::memset(p->poll, 0, 2 * sizeof(pgo_problem::Poll));
+    std::memset(p->poll, 0, 3 * sizeof(pgo_problem::Poll));
     // One-time costs of the process belong here, not in the first trigger: the first device allocation and the first kernel launch of the library (its code object goes to the
     // device).  Failures here are not errors (the solve reports its own).  (A captured + instantiated graph would also take the first hipGraphInstantiate of the process off the
     // first long PCG — 9.4 ms against 0.2 ms for later ones — but a capture in one thread makes a concurrent synchronous hipMemcpy of ANOTHER thread fail with

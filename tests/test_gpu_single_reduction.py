@@ -1,6 +1,7 @@
 """GPU: the single-reduction (Chronopoulos-Gear) form of the PCG on one GPU (pgo_options.cg_single_reduction, default on for cg_rel_tolerance >= 1e-11) against the classic
 two-reduction form: in exact arithmetic the same iterates, so the LM trajectory must be the classic one to the PCG tolerance, with (nearly) the same iteration counts — under
-block-Jacobi, under the multigrid (restriction inside the update, coarse part of r.u from the level-1 kernel), through early-rejection pauses (stop / resume), the in-flight
+block-Jacobi, under the two-level method's fused three-kernel iteration (pending coarse correction completed inside the update, coarse part of r.u from the dense solve), under
+the multigrid (restriction inside the update, coarse part of r.u from the level-1 kernel), through early-rejection pauses (stop / resume), the in-flight
 switch to the multigrid and warm starts after rejected steps.  And against the oracle's exact solve where that is affordable."""
 import numpy as np
 import pytest
@@ -27,9 +28,15 @@ def same_trajectory(a, b, rel=1e-7):
         assert abs(x.cost - y.cost) <= rel * max(x.cost, 1e-12), (k, x.cost, y.cost)
 
 
-@pytest.mark.parametrize("name", ["P9000", "G12000", "G30000", "C2"])
+@pytest.mark.parametrize("name", ["C1", "C1F5", "S3000", "G6000", "P9000", "G12000", "G30000", "C2"])
 def test_same_trajectory_and_iteration_counts_as_the_classic_form(name):
-    if name == "P9000":        # plain loops below mg_min_keyframes: two-level method -> classic form on both sides unless the comparison drops it (then block-Jacobi: single reduction)
+    if name in ("C1", "C1F5"):     # the two-level method's fused iteration: one aggregate per keyframe (the coarse inverse IS the solve: u is the coarse term alone) / aggregates of 2
+        g, sw, kw = graphgen.config(name), True, dict()
+    elif name == "S3000":      # session-structured (f = 1..5 odometry with yaw weights, 2 degrees per keyframe): two-level method, 384 aggregates, pending coarse correction in every kernel
+        g, sw, kw = graphgen.generate(3000, 600, odom_f_max=5, apply_yaw_weight=1, seed=5, **dict(graphgen._SMALL, turn_deg_per_keyframe=2.0)), True, dict()
+    elif name == "G6000":      # switchable, below mg_min_keyframes_switchable: two-level method, rejected steps and pauses
+        g, sw, kw = graphgen.generate(6000, 6000, odom_f_max=2, seed=3), True, dict(max_num_iterations=14)
+    elif name == "P9000":      # plain loops below mg_min_keyframes: two-level method unless the once-per-solve comparison drops it (then block-Jacobi)
         g, sw, kw = graphgen.generate(9000, 900, odom_f_max=1, seed=4, outlier_frac=0.0), False, dict(max_num_iterations=12)
     elif name == "G12000":     # switchable, multigrid hierarchy, hybrid start
         g, sw, kw = graphgen.generate(12000, 12000, odom_f_max=2, seed=3), True, dict(max_num_iterations=14)
