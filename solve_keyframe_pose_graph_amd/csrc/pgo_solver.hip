@@ -1246,7 +1246,7 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
         // per iteration with the coarse space in its unfused form -> 12 iterations, three in the fused form -> 24
         if (p->coarse_active && !multi) e = std::min(e, fused_coarse ? 24 : 12);
         int n_sm = 0;
-        for (int l = 0; l < p->M.n_levels; ++l) n_sm += p->mg_levels[l].smoothed ? 1 : 0;      // two more kernels per cycle for every level with a smoothed prolongator above it
+        for (int l = 0; l < p->M.n_levels; ++l) n_sm += (p->mg_levels[l].smoothed && !p->mg_levels[l].rt_valf) ? 1 : 0;      // two more kernels per cycle for every level whose smoothed prolongator is applied implicitly (none with the explicit transfer operator)
         if (p->mg_active && multi) e = std::min(e, std::max(2, (72 / (2 * p->M.n_levels + 7 + 2 * n_sm)) & ~1));
         if (p->mg_active && !multi) e = std::max(2, (72 / (2 * p->M.n_levels + 3 + 2 * n_sm)) & ~1);   // at most 2 n_levels + 1 cycle kernels + matvec + update per iteration (one less with the restriction inside the update)
         return e;
@@ -2689,6 +2689,9 @@ int pgo_time_kernel(pgo_problem* p, int32_t which, int32_t launches, double* avg
         const int g = launch_cg_init_vectors(p->G, p->C, 0, p->st);
         launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz, mg_scale(p), false, p->st, false, mg_cs(p));
         launch_cg_init_scalars(p->C, g, g, 0.0, p->st);
+    }
+    if (which == 5 && single_reduction(p)) {      // (its head needs the u.w partials of a matvec on the CURRENT u: launched back to back it sees stale ones, breaks down and returns early)
+        p->err = "pgo_time_kernel(5): the single-reduction update cannot be timed without its matvec; time the iteration (2) and the matvec (4) and subtract"; return PGO_ERR_STATE;
     }
     if (which == 2 || which == 4 || which == 5) {   // a live PCG state to iterate on (tolerance 0: never converges during the timed launches)
         const pgo_options& o = p->opt;
