@@ -189,8 +189,9 @@ typedef struct pgo_options {
     int32_t cg_end_game;                 /* 1: once the polled r.z values predict fewer than two chunks of PCG iterations to go, the host stops running a chunk ahead and enqueues what the
                                           *    prediction asks for (one GPU); 0: always one full chunk in flight, as in rounds 1-4.  Changes how many early-exit kernels follow a stopped PCG,
                                           *    never its iterates. */
-    int32_t cg_pause_always;             /* 0: the early-rejection pauses are armed only where a rejection is in the air (previous step rejected, or the last accepted step's relative decrease
-                                          *    below 0.8); 1: at every LM system of graphs >= 20 000 keyframes / after the solve's first rejection (round 4's rule) */
+    int32_t cg_pause_always;             /* 0: both early-rejection pauses where a rejection is in the air (previous step rejected, or the last accepted step's relative decrease below 0.8), the
+                                          *    first pause alone where the system is expensive (predicted block-Jacobi-equivalent iterations x keyframes >= 5.6e7: one wasted solve outweighs dozens
+                                          *    of pauses), none elsewhere; 1: both at every LM system of graphs >= 20 000 keyframes / after the solve's first rejection (round 4's rule) */
 } pgo_options;
 
 /* Per-iteration record; mirrors ceres::IterationSummary fields the BriefReport is built from. */

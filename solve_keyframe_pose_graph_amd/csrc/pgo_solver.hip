@@ -235,6 +235,7 @@ struct pgo_problem {
     CapturedChunk cg_chunk[3];
     hipGraphExec_t cg_graph = nullptr;   // the one in use (not owned)
     uint64_t build_epoch = 1; bool cg_graph_failed = false;
+    double cg_predicted = 0.0;      // block-Jacobi-equivalent iterations predicted for the current LM system (build_system); 0: none
     double cg_prev_equiv = 0.0, cg_prev_radius = 0.0;   // block-Jacobi-equivalent PCG iterations and radius of the last fully solved LM system of this solve
     int mg_switch_at = 400;              // in-flight switch point of the current LM system (build_system)
     int cg_extra = 0;                    // PCG iterations of the current LM step spent before a change of preconditioner
@@ -1714,6 +1715,8 @@ int build_system(pgo_problem* p, bool* ok) {
     }
     *ok = fail == 0;
     p->mg_active = false; p->mg_failed = false; p->C.extra_rz = 0; p->mg_start_deferred = false;
+    // block-Jacobi-equivalent iterations this system is expected to need: those of the last fully solved system of this solve x sqrt(radius ratio); 0 = no prediction
+    p->cg_predicted = (p->cg_prev_radius > 0.0 && p->radius > 0.0) ? p->cg_prev_equiv * std::sqrt(p->radius / p->cg_prev_radius) : 0.0;
     if (*ok && p->mg_built) {
         // Which preconditioner the PCG of this LM system starts with.  Block-Jacobi iterations grow like sqrt(radius) from one accepted step
         // to the next, so the previous step of this solve predicts this one (a multigrid iteration counts as 4 block-Jacobi ones: it costs
@@ -1870,13 +1873,22 @@ int lm_step(pgo_problem* p, int ignore_termination, int* done) {
         // on a 400-keyframe trigger, 63.2 -> 60.3 ms at 3 000.  So below CG_PAUSE_MIN_KEYFRAMES the pauses are armed by the first rejected step of the solve (a rejection is
         // usually followed by more: the radius shrinks in several steps) — a rule that depends on the solve's own history only.
         constexpr int64_t CG_PAUSE_MIN_KEYFRAMES = 20000;
-        // ... and (round 5) only where a rejection is in the air — the rule build_system defers the multigrid by: the previous step was rejected (rejections come in streaks) or
-        // the last accepted step's relative decrease fell below 0.8 (C3's and C4's first rejected steps follow rho = 0.67 and 0.62, their long runs of accepted steps
-        // rho >= 0.89).  A system whose step is accepted pays ~0.25 ms per pause for nothing (candidate evaluation, the drain of the chunk in flight, a host round trip):
-        // 13 of C3's 20 steps.  The PCG's own iterates do not depend on where it pauses.
+        // ... and (round 5) in proportion to what they can save.  A pause costs ~0.25 ms (candidate evaluation, host round trips, the PCG's restart out of its hipGraph), and a
+        // system whose step is ACCEPTED pays it for nothing: 13 of C3's 20 steps, 2.8 % of its headline.
+        //   * both pauses where a rejection is in the air — the rule build_system defers the multigrid by: the previous step was rejected (rejections come in streaks) or the last
+        //     accepted step's relative decrease fell below 0.8 (C3's and C4's first rejected steps follow rho = 0.67 and 0.62);
+        //   * the FIRST pause alone, as cheap insurance, where the system is expensive enough for one wasted solve to outweigh dozens of pauses: predicted block-Jacobi-equivalent
+        //     iterations x keyframes >= 5.6e7, i.e. a solve of >= ~20 ms (a pause pair is 0.5 ms; a block-Jacobi iteration costs ~36 us per 100 000 keyframes).  rho does NOT
+        //     predict every rejection: C5's step 8 follows rho = 0.97 and is rejected with rho = -2.0 — 1.87 s of PCG thrown away against 0.25 s with the pause
+        //     (gpurun_out/r05_s8/c5_verbose.txt); a system without a prediction counts as mg_switch_iterations iterations;
+        //   * none elsewhere.  The PCG's own iterates do not depend on where it pauses.
         const bool rejection_likely = p->reuse_diagonal || p->last_rho < 0.8;
-        const bool pauses = (p->N_global >= CG_PAUSE_MIN_KEYFRAMES || p->sum.num_unsuccessful_steps > 0) && (rejection_likely || p->opt.cg_pause_always != 0);
-        if (pauses && o.cg_early_tolerance > o.cg_rel_tolerance) stages[n_stages++] = Stage{o.cg_early_tolerance, o.cg_early_reject_rho};
+        const double predicted_its = p->cg_predicted > 0.0 ? p->cg_predicted : (double)(o.mg_switch_iterations > 0 ? o.mg_switch_iterations : 400);
+        const bool expensive = predicted_its * (double)p->N_global >= 5.6e7;
+        const bool armed = p->N_global >= CG_PAUSE_MIN_KEYFRAMES || p->sum.num_unsuccessful_steps > 0;
+        const bool pauses = armed && (rejection_likely || p->opt.cg_pause_always != 0);
+        const bool early_only = armed && !pauses && expensive;
+        if ((pauses || early_only) && o.cg_early_tolerance > o.cg_rel_tolerance) stages[n_stages++] = Stage{o.cg_early_tolerance, o.cg_early_reject_rho};
         if (pauses && o.cg_mid_tolerance > o.cg_rel_tolerance && (n_stages == 0 || o.cg_mid_tolerance < stages[0].tol)) stages[n_stages++] = Stage{o.cg_mid_tolerance, o.cg_mid_reject_rho};
         const bool warm = o.cg_warm_start != 0 && p->have_prev_step && p->reuse_diagonal;
         if ((rc = run_pcg(p, &cg, warm, n_stages ? stages[0].tol : o.cg_rel_tolerance, -1)) != PGO_OK) return rc;

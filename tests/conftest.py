@@ -32,7 +32,9 @@ _GPU_ANCHORS = [
     "test_gpu_fullsize.py::test_c3_iterations_match_the_independent_cpu_trajectory",                # C3   vs committed CPU goldens (10 and 20 iterations)
     "test_gpu_fullsize.py::test_c3_converged_minimum_matches_the_independent_cpu_run",              # C3   to Ceres' own convergence vs the committed CPU run
     "test_gpu_fullsize.py::test_c4_iterations_match_the_independent_cpu_trajectory",                # C4   vs the committed CPU goldens (10 and 20 iterations, full size)
+    "test_gpu_fullsize.py::test_c4_converged_minimum_matches_the_independent_cpu_run",              # C4   to Ceres' own convergence vs the committed CPU run (full size)
     "test_gpu_fullsize.py::test_c4_multi_world_objective_and_solve",                                # C4   objective / gradient vs oracle at full size
+    "test_gpu_c5.py::test_c5_reference_budget_of_iterations_matches_the_independent_cpu_trajectory",  # C5   the reference's 10-iteration budget vs the committed CPU trajectory (full size)
     "test_gpu_c5.py::test_c5_objective_gradient_and_three_lm_iterations_on_one_gpu",                # C5   objective / gradient vs oracle + 3 LM iterations vs the committed CPU golden, full size
 ]
 _GPU_FILE_ORDER = [

@@ -61,6 +61,36 @@ def test_c5_objective_gradient_and_three_lm_iterations_on_one_gpu(c5):
     P.close()
 
 
+def test_c5_reference_budget_of_iterations_matches_the_independent_cpu_trajectory(c5):
+    """BASELINE config 5 with the reference's own LM budget (max_num_iterations = 10, src/PoseGraphSLAM.cpp:1272; Ceres' default tolerances), library defaults, against the
+    independent CPU trajectory tests/golden/c5_ten_iterations.json (tests/golden/make_c3_trajectory.py 10 C5 ... mg converge: oracle Jet Jacobians, scipy CG to 1e-12, Python
+    restatement of the Ceres loop incl. its convergence tests; about five CPU-hours, nothing of libpgo) — or, when that run was cut short, its first N iterations written from the
+    run's checkpoint (tests/golden/make_trajectory_from_checkpoint.py): every decision, every cost within 1e-6 relative, sampled positions and switches."""
+    import glob
+    import json
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    names = [n for n in ("c5_ten_iterations.json",) + tuple(sorted(glob.glob(os.path.join(here, "c5_first_*_iterations.json")), reverse=True)) if os.path.exists(os.path.join(here, os.path.basename(n)))]
+    if not names:
+        pytest.skip("tests/golden/c5_ten_iterations.json has not been generated (five CPU-hours: tests/golden/make_c3_trajectory.py 10 C5 c5_ten_iterations.json mg converge)")
+    with open(os.path.join(here, os.path.basename(names[0]))) as f:
+        gold = json.load(f)
+    g = c5
+    n_iter = len(gold["iterations"]) - 1
+    assert gold["n_poses"] == g.n_poses and gold["n_edges"] == g.n_odom + g.n_loops and n_iter >= 4
+    P = util.pgo_problem(g, True, max_num_iterations=n_iter)
+    q, t, s = util.initial_state(g, True)
+    qf, tf, sf, summ = P.solve(q, t, s)
+    P.close()
+    assert summ.num_iterations == n_iter
+    for k, rec in enumerate(gold["iterations"]):
+        mine = summ.iterations[k]
+        assert mine.step_is_successful == rec["successful"], k
+        assert abs(mine.cost - rec["cost"]) <= 1e-6 * rec["cost"], (k, mine.cost, rec["cost"])
+    assert np.abs(tf.reshape(-1, 3)[::997] - np.array(gold["final_t_sample"])).max() <= 1e-3
+    assert np.abs(sf[::997] - np.array(gold["final_s_sample"])).max() <= 1e-3
+
+
 @pytest.mark.parametrize("world", [4, 8])
 def test_c5_ranks_on_one_gpu_follow_the_single_rank_trajectory(c5, world):
     g = c5

@@ -283,6 +283,41 @@ def test_c3_converged_minimum_matches_the_independent_cpu_run(c3):
     assert np.abs(sp - 0.5).min() > 0.1      # (and none of them anywhere near the threshold: the golden's own margin is 0.41)
 
 
+def test_c4_converged_minimum_matches_the_independent_cpu_run():
+    """The multi-world config at full size TO CONVERGENCE (BASELINE.json "final chi^2 within 1e-6 relative"): library defaults, Ceres' default tolerances,
+    against tests/golden/c4_converged.json — the independent CPU run of tests/golden/make_c3_trajectory.py 60 C4 c4_converged.json mg converge (oracle Jet Jacobians, scipy CG to
+    1e-12 with up to 4 000+ iterations per step, Python restatement of the Ceres loop; about seven CPU-hours, nothing of libpgo): every accept / reject decision, every cost to 1e-6
+    relative, the same terminating iteration and reason, final chi^2, every 100th keyframe, all 20 000 switches on the same side of 0.5."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c4_converged.json")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/c4_converged.json has not been generated (seven CPU-hours: tests/golden/make_c3_trajectory.py 60 C4 c4_converged.json mg converge)")
+    with open(path) as f:
+        gold = json.load(f)
+    g = graphgen.config("C4")
+    assert gold["n_poses"] == g.n_poses and gold["n_edges"] == g.n_odom + g.n_loops and gold["termination"].startswith("CONVERGENCE")
+    P = util.pgo_problem(g, True, max_num_iterations=400)
+    q, t, s = util.initial_state(g, True)
+    qp, tp, sp, summ = P.solve(q, t, s)
+    P.close()
+    its = gold["iterations"]
+    assert summ.termination_type == capi.CONVERGENCE, summ.message
+    assert summ.num_iterations == len(its) - 1, (summ.num_iterations, len(its) - 1)
+    for k, rec in enumerate(its):
+        mine = summ.iterations[k]
+        assert mine.step_is_successful == rec["successful"], k
+        assert abs(mine.cost - rec["cost"]) <= 1e-6 * rec["cost"], (k, mine.cost, rec["cost"])
+    assert summ.iterations[summ.num_logged - 1].reason == capi.STEP_CONVERGED
+    assert abs(2.0 * summ.final_cost - gold["final_chi2"]) <= 1e-6 * gold["final_chi2"], (2.0 * summ.final_cost, gold["final_chi2"])
+    stride = gold["pose_sample_stride"]
+    dt = np.abs(tp.reshape(-1, 3)[::stride] - np.array(gold["final_t_sample_100"])).max()
+    dq = util.rot_angle(qp.reshape(-1, 4)[::stride], np.array(gold["final_q_sample_100"])).max()
+    assert dt <= 2e-2 and dq <= 2e-3, (dt, dq)      # (four worlds of 50 000 keyframes tied by 5 000 inter-world closures: long, flat valleys — the chi^2 bar above is the tight one)
+    on_ref = np.unpackbits(np.frombuffer(bytes.fromhex(gold["switches_on_hex"]), dtype=np.uint8))[:gold["n_switches"]]
+    assert np.count_nonzero((sp > 0.5).astype(np.uint8) != on_ref) == 0
+
+
 def test_c3_structured_5k_to_convergence_matches_oracle():
     """final chi^2 against the CPU oracle run TO CONVERGENCE (not the 10-iteration budget) on a C3-structured graph
     the oracle's exact Cholesky handles quickly.  With Ceres' function_tolerance 1e-6 both minimisers stop after the same 10 iterations
