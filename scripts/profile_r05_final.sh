@@ -58,9 +58,9 @@ rocprofv3 --kernel-trace --stats -d gpurun_out/r05_final/trace_bench -o t -- pyt
 python scripts/rocpd_summary.py stats $(find gpurun_out/r05_final/trace_bench -name "*.db" | head -1) > $OUT/r05_bench_kernel_stats.txt; stamp $OUT/r05_bench_kernel_stats.txt
 rm -rf gpurun_out/r05_final/trace_bench
 # idle gaps of the timed region (bench.py's K LM steps, the device idle for 0.3 s on both sides) and of a 400-keyframe trigger
-{ for t in "C3 20" "S400 10"; do set -- $t
-    rocprofv3 --kernel-trace -d gpurun_out/r05_final/trace_gaps_$1 -o t -- python scripts/dev/timed_region.py $1 $2 > $OUT/timed_$1.log 2>&1
-    echo "## python scripts/dev/timed_region.py $1 $2   (segment 1 = warm-up leg, the LAST segment = the timed leg; under rocprofv3 --kernel-trace every kernel boundary costs more than in a plain run)"
+{ for t in "C3 20 0 cg_use_graph=0" "S400 10"; do set -- $t
+    rocprofv3 --kernel-trace -d gpurun_out/r05_final/trace_gaps_$1 -o t -- python scripts/dev/timed_region.py $1 $2 $3 $4 > $OUT/timed_$1.log 2>&1
+    echo "## python scripts/dev/timed_region.py $1 $2 $3 $4   (C3: PCG chunks launched eagerly, not as hipGraphs — rocprofv3 7.2 --kernel-trace segfaults in hipGraphLaunch of this run once the end game interleaves eager chunks and graph replays; plain runs and the other traces are unaffected; segment 1 = warm-up leg, the LAST segment = the timed leg; under rocprofv3 --kernel-trace every kernel boundary costs more than in a plain run)"
     python scripts/rocpd_summary.py segments $(find gpurun_out/r05_final/trace_gaps_$1 -name "*.db" | head -1) 50 200
     tail -1 $OUT/timed_$1.log; rm -rf gpurun_out/r05_final/trace_gaps_$1; done; } > $OUT/r05_idle_gaps.txt 2>&1; stamp $OUT/r05_idle_gaps.txt
 python scripts/dev/r05/ab_options.py C3 20 3 "" "cg_single_reduction=0" "mg_explicit_transfer=0" "cg_pause_always=1" "cg_end_game=0" "cg_single_reduction=0,mg_explicit_transfer=0,cg_pause_always=1,cg_end_game=0" > $OUT/r05_option_ab_c3.txt 2>&1; stamp $OUT/r05_option_ab_c3.txt
