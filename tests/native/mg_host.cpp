@@ -55,6 +55,7 @@ void* mgh_build_regroup(long long N, const unsigned char* node_free, long long E
     if (!ok) { delete H; return nullptr; }
     return H;
 }
+void mgh_set_timing(int on) { pgo_mg::timing() = on != 0; }      // phase times of build_hierarchy on stderr (this thread's builds)
 void mgh_free(void* h) { delete (pgo_mg::Hierarchy*)h; }
 int mgh_levels(void* h) { return (int)((pgo_mg::Hierarchy*)h)->L.size(); }
 void mgh_sizes(void* h, int l, long long* out /* n, nnzb, n_ent, n_parent, n_agg_ptr, n_tiles_plus_1 */) {
