@@ -179,7 +179,8 @@ typedef struct pgo_options {
     int32_t verbosity;                   /* 0 silent (minimizer_progress_to_stdout=false, :1271), 1 per-iteration line on stderr */
     /* round 5 (appended: the layout of everything above is unchanged) */
     int32_t cg_single_reduction;         /* 1: one GPU runs the PCG in its single-reduction (Chronopoulos-Gear) form — w = A u, both dot products r.u and u.w known right after the matvec,
-                                          *    ONE partial-sum re-reduction per iteration (in the vector update) instead of two — whenever cg_rel_tolerance >= 1e-11; the same iterates in exact
+                                          *    ONE partial-sum re-reduction per iteration (in the vector update) instead of two — whenever cg_rel_tolerance >= 1e-11 and the graph has at most 150 000
+                                          *    keyframes (beyond that the four more vectors its update moves cost more than the head it saves: measured); the same iterates in exact
                                           *    arithmetic, its attainable accuracy is a little lower, so tighter tolerances (the 1e-12 / 1e-13 parity settings) keep the classic two-reduction
                                           *    form, and so does the two-level method's fused three-kernel iteration.  0: classic form everywhere.  Several ranks always run the single-reduction form. */
     int32_t mg_explicit_transfer;        /* 1: a multigrid level with a smoothed transition above it applies that transition through the EXPLICIT operator R^T = Ps - Dinv W (fp32 blocks on the

@@ -1177,7 +1177,12 @@ struct CgResult { int iterations; bool breakdown; double rel_residual; bool conv
 bool single_reduction(const pgo_problem* p) {
     // (the two-level method: only its fused three-kernel iteration has a single-reduction form; its unfused form — aggregates too large for the update kernel's groups — stays classic)
     const bool two_level = p->coarse_active && !p->mg_active;
-    return p->opt.cg_single_reduction != 0 && !p->local_ids && p->built_mf && p->opt.cg_rel_tolerance >= 1e-11 && (!two_level || coarse_group_keyframes(p->K) > 0);
+    // ... and only where the iteration is latency-bound: the form trades one partial-sum head (~4.5 us) for 96 more bytes per keyframe and iteration, which costs more than the
+    // head from ~130 000 keyframes on — measured +1.4 % on C3 (100k) and +2...+7 % on 12k-60k-keyframe graphs, but -1.2 % on C4 (200k) and -1.7 % on C5 (1M)
+    // (profiles/r05_single_reduction_graph_types.txt, r05_option_ab_c4_c5.txt)
+    constexpr int64_t SINGLE_REDUCTION_MAX_KEYFRAMES = 150000;
+    return p->opt.cg_single_reduction != 0 && !p->local_ids && p->built_mf && p->opt.cg_rel_tolerance >= 1e-11 && p->N_global <= SINGLE_REDUCTION_MAX_KEYFRAMES &&
+           (!two_level || coarse_group_keyframes(p->K) > 0);
 }
 
 // rel_tol: relative tolerance of this phase.  resume_from >= 0: continue the stopped PCG at that iteration index with the new tolerance
@@ -1880,7 +1885,7 @@ int lm_step(pgo_problem* p, int ignore_termination, int* done) {
         //   * the FIRST pause alone, as cheap insurance, where the system is expensive enough for one wasted solve to outweigh dozens of pauses: predicted block-Jacobi-equivalent
         //     iterations x keyframes >= 5.6e7, i.e. a solve of >= ~20 ms (a pause pair is 0.5 ms; a block-Jacobi iteration costs ~36 us per 100 000 keyframes).  rho does NOT
         //     predict every rejection: C5's step 8 follows rho = 0.97 and is rejected with rho = -2.0 — 1.87 s of PCG thrown away against 0.25 s with the pause
-        //     (gpurun_out/r05_s8/c5_verbose.txt); a system without a prediction counts as mg_switch_iterations iterations;
+        //     (profiles/r05_pause_rule.txt); a system without a prediction counts as mg_switch_iterations iterations;
         //   * none elsewhere.  The PCG's own iterates do not depend on where it pauses.
         const bool rejection_likely = p->reuse_diagonal || p->last_rho < 0.8;
         const double predicted_its = p->cg_predicted > 0.0 ? p->cg_predicted : (double)(o.mg_switch_iterations > 0 ? o.mg_switch_iterations : 400);
