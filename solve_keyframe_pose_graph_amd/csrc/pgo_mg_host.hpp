@@ -61,6 +61,11 @@ struct HostLevel {                       // level l >= 1
 
 struct Hierarchy {
     std::vector<HostLevel> L;            // L[0] = level 1
+    // SMOOTHED transition keyframes -> level 1 (round 6): F is the keyframe level as a block-CSR level of its own — rowptr / col = the solver's block pattern (diagonal block first,
+    // then one block per incident edge; parallel edges repeat a column), parent = agg0 (-1: fixed keyframe, outside the system: its rows of Ps and W are empty) — with the
+    // structures of Ps, W = A Ps and the explicit operator R^T; L[0]'s pattern is then that of Ps^T W and carries no contribution lists.
+    bool fine_smoothed = false;
+    HostLevel F;
     std::vector<int32_t> agg0;           // [N] level-1 node of each keyframe, -1 for keyframes outside the system (fixed)
     std::vector<int32_t> mem0_ptr, mem0; // level-1 node -> its keyframes
 };
@@ -261,6 +266,86 @@ inline void permute_level1(const HostLevel& P, int32_t n, const std::vector<int3
     out.g_ptr[(size_t)kb] = ge;
 }
 
+// Structure of a SMOOTHED transition from level A to the level above, B (n and the parents of A's nodes known): Ps, W = A Ps, Ps by coarse column, B = Ps^T W (diagonal block
+// first), and the explicit operator's tables.  Nodes of A with parent -1 (fixed keyframes on the keyframe level) are outside the system: their rows of Ps and W are empty and
+// they appear in no row as a column.
+inline void smoothed_structure(HostLevel& A, HostLevel& B) {
+    // structure of Ps, W = A Ps and B = Ps^T W (all by sorted unions; the numeric kernels search these short rows)
+    A.smoothed = true;
+    const int32_t n = A.n, nb = B.n;
+    // rows are independent: contiguous row ranges on a few threads, each with its own output and marker array, joined in row order
+    const int nth = host_threads();
+    auto rows_in_parallel = [&](int32_t rows, std::vector<int32_t>& rowptr_out, std::vector<int32_t>& col_out, auto row_fn /* (row, tmp, stamp) -> fills tmp, sorted */) {
+        std::vector<std::vector<int32_t>> part_cols((size_t)nth), part_len((size_t)nth);
+        parallel_ranges(rows, nth, [&](int part, int32_t lo, int32_t hi) {
+            std::vector<int32_t> tmp, stamp((size_t)nb, -1);
+            std::vector<int32_t>& pc = part_cols[(size_t)part]; std::vector<int32_t>& pl = part_len[(size_t)part];
+            pl.reserve((size_t)(hi - lo));
+            for (int32_t i = lo; i < hi; ++i) { tmp.clear(); row_fn(i, tmp, stamp); pc.insert(pc.end(), tmp.begin(), tmp.end()); pl.push_back((int32_t)tmp.size()); }
+        });
+        rowptr_out.assign((size_t)rows + 1, 0); col_out.clear();
+        int32_t r = 0;
+        for (int k = 0; k < nth; ++k) {
+            for (int32_t len : part_len[(size_t)k]) { rowptr_out[(size_t)r + 1] = rowptr_out[r] + len; ++r; }
+            col_out.insert(col_out.end(), part_cols[(size_t)k].begin(), part_cols[(size_t)k].end());
+        }
+    };
+    rows_in_parallel(n, A.ps_rowptr, A.ps_col, [&](int32_t i, std::vector<int32_t>& tmp, std::vector<int32_t>&) {
+        if (A.parent[i] < 0) return;
+        for (int64_t k = A.rowptr[i]; k < A.rowptr[(size_t)i + 1]; ++k) { const int32_t a = A.parent[A.col[k]]; if (a >= 0) tmp.push_back(a); }
+        std::sort(tmp.begin(), tmp.end()); tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+    });
+    rows_in_parallel(n, A.w_rowptr, A.w_col, [&](int32_t i, std::vector<int32_t>& tmp, std::vector<int32_t>& stamp) {      // unions by marking: each coarse column enters a row's list once
+        if (A.parent[i] < 0) return;
+        for (int64_t k = A.rowptr[i]; k < A.rowptr[(size_t)i + 1]; ++k) {
+            const int32_t j = A.col[k];
+            for (int32_t sl = A.ps_rowptr[j]; sl < A.ps_rowptr[(size_t)j + 1]; ++sl) { const int32_t c = A.ps_col[sl]; if (stamp[c] != i) { stamp[c] = i; tmp.push_back(c); } }
+        }
+        std::sort(tmp.begin(), tmp.end());
+    });
+    A.psT_ptr.assign((size_t)nb + 1, 0);
+    for (int32_t c : A.ps_col) A.psT_ptr[(size_t)c + 1]++;
+    for (int32_t a = 0; a < nb; ++a) A.psT_ptr[(size_t)a + 1] += A.psT_ptr[a];
+    A.psT_ent.resize(A.ps_col.size());
+    { std::vector<int64_t> fill(A.psT_ptr.begin(), A.psT_ptr.end() - 1);
+      for (int32_t i = 0; i < n; ++i) for (int32_t sl = A.ps_rowptr[i]; sl < A.ps_rowptr[(size_t)i + 1]; ++sl) A.psT_ent[(size_t)fill[A.ps_col[sl]]++] = ((int64_t)i << 32) | (int64_t)sl; }
+    {
+        std::vector<int32_t> brow, bcol;
+        rows_in_parallel(nb, brow, bcol, [&](int32_t a, std::vector<int32_t>& tmp, std::vector<int32_t>& stamp) {
+            std::vector<int32_t> un;
+            for (int64_t e = A.psT_ptr[a]; e < A.psT_ptr[(size_t)a + 1]; ++e) {
+                const int32_t i = (int32_t)(A.psT_ent[e] >> 32);
+                for (int32_t sl = A.w_rowptr[i]; sl < A.w_rowptr[(size_t)i + 1]; ++sl) { const int32_t c = A.w_col[sl]; if (stamp[c] != a) { stamp[c] = a; un.push_back(c); } }
+            }
+            std::sort(un.begin(), un.end());
+            tmp.push_back(a);                                         // the diagonal block first, as everywhere
+            for (int32_t c : un) if (c != a) tmp.push_back(c);
+        });
+        B.rowptr.assign(brow.begin(), brow.end()); B.col.swap(bcol);
+    }
+    B.g_ptr.assign(B.col.size() + 1, 0); B.g_ent.clear();         // (no contribution lists: the product is formed from Ps and W)
+    // explicit transfer operator: Ps slot of every W block (both rows ascend by column: one merge per row), and W's pattern by coarse column
+    A.ps_of_w.assign(A.w_col.size(), -1);
+    for (int32_t i = 0; i < n; ++i) {
+        int32_t ps = A.ps_rowptr[i]; const int32_t pe = A.ps_rowptr[(size_t)i + 1];
+        for (int32_t k = A.w_rowptr[i]; k < A.w_rowptr[(size_t)i + 1] && ps < pe; ++k) if (A.w_col[k] == A.ps_col[ps]) A.ps_of_w[(size_t)k] = ps++;
+    }
+    A.rT_rowptr.assign((size_t)nb + 1, 0);
+    for (int32_t c : A.w_col) A.rT_rowptr[(size_t)c + 1]++;
+    for (int32_t a = 0; a < nb; ++a) A.rT_rowptr[(size_t)a + 1] += A.rT_rowptr[a];
+    A.rT_col.resize(A.w_col.size()); A.rT_of_w.resize(A.w_col.size());
+    { std::vector<int32_t> fill(A.rT_rowptr.begin(), A.rT_rowptr.end() - 1);
+      for (int32_t i = 0; i < n; ++i) for (int32_t k = A.w_rowptr[i]; k < A.w_rowptr[(size_t)i + 1]; ++k) { const int32_t sl = fill[A.w_col[k]]++; A.rT_col[(size_t)sl] = i; A.rT_of_w[(size_t)k] = sl; } }
+    {   // lane groups per coarse row, by the rule of the level kernels below (<= ~5 blocks per group, up to 8 groups)
+        const double mean_row = (double)A.w_col.size() / (double)std::max(1, nb);
+        static const double rt_blocks_per_group = []() {      // (debug override for scans, as below: PGO_ENABLE_DEBUG_HOOKS=1 and a value in [1, 64])
+            const char* m = std::getenv("PGO_ENABLE_DEBUG_HOOKS"); const char* e = std::getenv("PGO_DEBUG_RT_SEG_BLOCKS");
+            const double v = (m && m[0] == '1' && m[1] == 0 && e) ? std::atof(e) : 0.0; return v >= 1.0 && v <= 64.0 ? v : 5.0; }();
+        A.rT_seg = 1;
+        while (A.rT_seg < 8 && mean_row > rt_blocks_per_group * A.rT_seg) A.rT_seg *= 2;
+    }
+}
+
 // N keyframes, node_free[N]; edge lists of both classes (endpoints in the handle's local numbering — the global one with several ranks —, weights of the
 // relative-pose class at rel_w[rel_w_stride * e]).
 // passes0: matching rounds keyframes -> level 1, passes: for the levels above.  Returns false when the graph does not coarsen down to
@@ -270,7 +355,9 @@ inline bool build_hierarchy(int64_t N, const std::vector<uint8_t>& node_free, co
                             int passes0, int passes, int dense_max, int tile_rows, int max_levels, Hierarchy& H, bool level0_follows_switchable = true, int level0_block = 0,
                             const LocalContrib* local = nullptr, int smoothed_levels = 0 /* transitions level l -> l+1, l = 1 .. smoothed_levels, use the smoothed prolongator */,
                             double loop_discount = 0.0 /* loop closures of a pair of level-1 nodes that do not count in the matching above level 1 */,
-                            BuildCache* cache = nullptr /* kept by the caller across rebuilds of the same graph with other switch values (level0_follows_switchable must be false) */) {
+                            BuildCache* cache = nullptr /* kept by the caller across rebuilds of the same graph with other switch values (level0_follows_switchable must be false) */,
+                            const std::vector<int64_t>* fine_rowptr = nullptr, const std::vector<int32_t>* fine_col = nullptr /* both given: the transition keyframes -> level 1 is SMOOTHED
+                            too; the keyframe level's block pattern as the solver holds it (row i: block (i, i) first, then one block per incident edge) */) {
     H = Hierarchy{};
     PGO_MG_T0();
     const int64_t Er = (int64_t)rc1.size(), Es = (int64_t)sc1.size();
@@ -454,84 +541,20 @@ inline bool build_hierarchy(int64_t N, const std::vector<uint8_t>& node_free, co
     PGO_MG_T("numbering + member lists");
     permute_level1(Cc.L1prov, n1, newid_above, H.L[0]);
     PGO_MG_T("permute level 1");
+    if (fine_rowptr && fine_col && !local) {
+        // smoothed transition keyframes -> level 1: level 1's pattern is that of Ps^T W (one hop wider than the aggregated edges), without contribution lists
+        H.fine_smoothed = true;
+        H.F = HostLevel{};
+        H.F.n = (int32_t)N; H.F.rowptr = *fine_rowptr; H.F.col = *fine_col; H.F.parent = H.agg0;
+        HostLevel B1; B1.n = n1;
+        smoothed_structure(H.F, B1);
+        H.L[0].rowptr.swap(B1.rowptr); H.L[0].col.swap(B1.col); H.L[0].g_ptr.swap(B1.g_ptr); H.L[0].g_ent.clear();
+        PGO_MG_T("fine-level smoothed structure");
+    }
     for (size_t l = 0; l + 1 < H.L.size(); ++l) {
         HostLevel& A = H.L[l];
         HostLevel& B = H.L[l + 1];
-        if ((int)l < smoothed_levels) {
-            // structure of Ps, W = A Ps and B = Ps^T W (all by sorted unions; the numeric kernels search these short rows)
-            A.smoothed = true;
-            const int32_t n = A.n, nb = B.n;
-            // rows are independent: contiguous row ranges on a few threads, each with its own output and marker array, joined in row order
-            const int nth = host_threads();
-            auto rows_in_parallel = [&](int32_t rows, std::vector<int32_t>& rowptr_out, std::vector<int32_t>& col_out, auto row_fn /* (row, tmp, stamp) -> fills tmp, sorted */) {
-                std::vector<std::vector<int32_t>> part_cols((size_t)nth), part_len((size_t)nth);
-                parallel_ranges(rows, nth, [&](int part, int32_t lo, int32_t hi) {
-                    std::vector<int32_t> tmp, stamp((size_t)nb, -1);
-                    std::vector<int32_t>& pc = part_cols[(size_t)part]; std::vector<int32_t>& pl = part_len[(size_t)part];
-                    pl.reserve((size_t)(hi - lo));
-                    for (int32_t i = lo; i < hi; ++i) { tmp.clear(); row_fn(i, tmp, stamp); pc.insert(pc.end(), tmp.begin(), tmp.end()); pl.push_back((int32_t)tmp.size()); }
-                });
-                rowptr_out.assign((size_t)rows + 1, 0); col_out.clear();
-                int32_t r = 0;
-                for (int k = 0; k < nth; ++k) {
-                    for (int32_t len : part_len[(size_t)k]) { rowptr_out[(size_t)r + 1] = rowptr_out[r] + len; ++r; }
-                    col_out.insert(col_out.end(), part_cols[(size_t)k].begin(), part_cols[(size_t)k].end());
-                }
-            };
-            rows_in_parallel(n, A.ps_rowptr, A.ps_col, [&](int32_t i, std::vector<int32_t>& tmp, std::vector<int32_t>&) {
-                for (int64_t k = A.rowptr[i]; k < A.rowptr[(size_t)i + 1]; ++k) tmp.push_back(A.parent[A.col[k]]);
-                std::sort(tmp.begin(), tmp.end()); tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
-            });
-            rows_in_parallel(n, A.w_rowptr, A.w_col, [&](int32_t i, std::vector<int32_t>& tmp, std::vector<int32_t>& stamp) {      // unions by marking: each coarse column enters a row's list once
-                for (int64_t k = A.rowptr[i]; k < A.rowptr[(size_t)i + 1]; ++k) {
-                    const int32_t j = A.col[k];
-                    for (int32_t sl = A.ps_rowptr[j]; sl < A.ps_rowptr[(size_t)j + 1]; ++sl) { const int32_t c = A.ps_col[sl]; if (stamp[c] != i) { stamp[c] = i; tmp.push_back(c); } }
-                }
-                std::sort(tmp.begin(), tmp.end());
-            });
-            A.psT_ptr.assign((size_t)nb + 1, 0);
-            for (int32_t c : A.ps_col) A.psT_ptr[(size_t)c + 1]++;
-            for (int32_t a = 0; a < nb; ++a) A.psT_ptr[(size_t)a + 1] += A.psT_ptr[a];
-            A.psT_ent.resize(A.ps_col.size());
-            { std::vector<int64_t> fill(A.psT_ptr.begin(), A.psT_ptr.end() - 1);
-              for (int32_t i = 0; i < n; ++i) for (int32_t sl = A.ps_rowptr[i]; sl < A.ps_rowptr[(size_t)i + 1]; ++sl) A.psT_ent[(size_t)fill[A.ps_col[sl]]++] = ((int64_t)i << 32) | (int64_t)sl; }
-            {
-                std::vector<int32_t> brow, bcol;
-                rows_in_parallel(nb, brow, bcol, [&](int32_t a, std::vector<int32_t>& tmp, std::vector<int32_t>& stamp) {
-                    std::vector<int32_t> un;
-                    for (int64_t e = A.psT_ptr[a]; e < A.psT_ptr[(size_t)a + 1]; ++e) {
-                        const int32_t i = (int32_t)(A.psT_ent[e] >> 32);
-                        for (int32_t sl = A.w_rowptr[i]; sl < A.w_rowptr[(size_t)i + 1]; ++sl) { const int32_t c = A.w_col[sl]; if (stamp[c] != a) { stamp[c] = a; un.push_back(c); } }
-                    }
-                    std::sort(un.begin(), un.end());
-                    tmp.push_back(a);                                         // the diagonal block first, as everywhere
-                    for (int32_t c : un) if (c != a) tmp.push_back(c);
-                });
-                B.rowptr.assign(brow.begin(), brow.end()); B.col.swap(bcol);
-            }
-            B.g_ptr.assign(B.col.size() + 1, 0); B.g_ent.clear();         // (no contribution lists: the product is formed from Ps and W)
-            // explicit transfer operator: Ps slot of every W block (both rows ascend by column: one merge per row), and W's pattern by coarse column
-            A.ps_of_w.assign(A.w_col.size(), -1);
-            for (int32_t i = 0; i < n; ++i) {
-                int32_t ps = A.ps_rowptr[i]; const int32_t pe = A.ps_rowptr[(size_t)i + 1];
-                for (int32_t k = A.w_rowptr[i]; k < A.w_rowptr[(size_t)i + 1] && ps < pe; ++k) if (A.w_col[k] == A.ps_col[ps]) A.ps_of_w[(size_t)k] = ps++;
-            }
-            A.rT_rowptr.assign((size_t)nb + 1, 0);
-            for (int32_t c : A.w_col) A.rT_rowptr[(size_t)c + 1]++;
-            for (int32_t a = 0; a < nb; ++a) A.rT_rowptr[(size_t)a + 1] += A.rT_rowptr[a];
-            A.rT_col.resize(A.w_col.size()); A.rT_of_w.resize(A.w_col.size());
-            { std::vector<int32_t> fill(A.rT_rowptr.begin(), A.rT_rowptr.end() - 1);
-              for (int32_t i = 0; i < n; ++i) for (int32_t k = A.w_rowptr[i]; k < A.w_rowptr[(size_t)i + 1]; ++k) { const int32_t sl = fill[A.w_col[k]]++; A.rT_col[(size_t)sl] = i; A.rT_of_w[(size_t)k] = sl; } }
-            {   // lane groups per coarse row, by the rule of the level kernels below (<= ~5 blocks per group, up to 8 groups)
-                const double mean_row = (double)A.w_col.size() / (double)std::max(1, nb);
-                static const double rt_blocks_per_group = []() {      // (debug override for scans, as below: PGO_ENABLE_DEBUG_HOOKS=1 and a value in [1, 64])
-                    const char* m = std::getenv("PGO_ENABLE_DEBUG_HOOKS"); const char* e = std::getenv("PGO_DEBUG_RT_SEG_BLOCKS");
-                    const double v = (m && m[0] == '1' && m[1] == 0 && e) ? std::atof(e) : 0.0; return v >= 1.0 && v <= 64.0 ? v : 5.0; }();
-                A.rT_seg = 1;
-                while (A.rT_seg < 8 && mean_row > rt_blocks_per_group * A.rT_seg) A.rT_seg *= 2;
-            }
-            continue;
-        }
+        if ((int)l < smoothed_levels) { smoothed_structure(A, B); continue; }
         std::vector<std::pair<int64_t, int64_t>> trip;
         trip.reserve(A.col.size());
         for (int32_t r = 0; r < A.n; ++r)

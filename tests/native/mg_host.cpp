@@ -55,6 +55,30 @@ void* mgh_build_regroup(long long N, const unsigned char* node_free, long long E
     if (!ok) { delete H; return nullptr; }
     return H;
 }
+// Smoothed transition keyframes -> level 1: the keyframe level's block pattern built as pgo_solver.hip's build_graph builds it (row i: block (i, i), then one block per incident
+// edge — relative-pose edges first, in edge order —, parallel edges repeating a column), handed to build_hierarchy with level0_block as the solver does.
+void* mgh_build_fine(long long N, const unsigned char* node_free, long long Er, const int* rc1, const int* rc2, const double* rw, long long Es, const int* sc1, const int* sc2,
+                     int passes0, int passes, int dense_max, int tile_rows, int max_levels, int smoothed_levels, int level0_block) {
+    std::vector<uint8_t> nf(node_free, node_free + N);
+    std::vector<int32_t> a(rc1, rc1 + Er), b(rc2, rc2 + Er), c(sc1, sc1 + Es), d(sc2, sc2 + Es);
+    std::vector<double> w(rw, rw + Er);
+    std::vector<int64_t> rowptr((size_t)N + 1, 0);
+    for (long long e = 0; e < Er; ++e) { rowptr[a[e] + 1]++; rowptr[b[e] + 1]++; }
+    for (long long e = 0; e < Es; ++e) { rowptr[c[e] + 1]++; rowptr[d[e] + 1]++; }
+    for (long long n = 0; n < N; ++n) rowptr[n + 1] += rowptr[n] + 1;
+    std::vector<int32_t> col((size_t)rowptr[N]);
+    std::vector<int64_t> fill((size_t)N);
+    for (long long n = 0; n < N; ++n) { col[rowptr[n]] = (int32_t)n; fill[n] = rowptr[n] + 1; }
+    for (long long e = 0; e < Er; ++e) { col[fill[a[e]]++] = b[e]; col[fill[b[e]]++] = a[e]; }
+    for (long long e = 0; e < Es; ++e) { col[fill[c[e]]++] = d[e]; col[fill[d[e]]++] = c[e]; }
+    pgo_mg::Hierarchy* H = new pgo_mg::Hierarchy();
+    if (!pgo_mg::build_hierarchy(N, nf, a, b, w.data(), 1, c, d, nullptr, passes0, passes, dense_max, tile_rows, max_levels, *H, false, level0_block, nullptr, smoothed_levels, 0.0, nullptr, &rowptr, &col)) { delete H; return nullptr; }
+    return H;
+}
+// (level -1 in the accessors below = the keyframe level F of a hierarchy built with the smoothed keyframe transition)
+static const pgo_mg::HostLevel& level_of(void* h, int l) { pgo_mg::Hierarchy* H = (pgo_mg::Hierarchy*)h; return l < 0 ? H->F : H->L[l]; }
+long long mgh_fine_nnzb(void* h) { return ((pgo_mg::Hierarchy*)h)->fine_smoothed ? (long long)((pgo_mg::Hierarchy*)h)->F.col.size() : -1; }
+void mgh_fine_pattern(void* h, long long* rowptr, int* col) { const pgo_mg::HostLevel& F = ((pgo_mg::Hierarchy*)h)->F; std::memcpy(rowptr, F.rowptr.data(), F.rowptr.size() * 8); std::memcpy(col, F.col.data(), F.col.size() * 4); }
 void mgh_set_timing(int on) { pgo_mg::timing() = on != 0; }      // phase times of build_hierarchy on stderr (this thread's builds)
 void mgh_free(void* h) { delete (pgo_mg::Hierarchy*)h; }
 int mgh_levels(void* h) { return (int)((pgo_mg::Hierarchy*)h)->L.size(); }
@@ -72,18 +96,18 @@ void mgh_level(void* h, int l, long long* rowptr, int* col, long long* g_ptr, lo
 }
 // structure of a smoothed transition: sizes {n_ps, n_w, n_psT_ent}, then the arrays
 void mgh_smoothed_sizes(void* h, int l, long long* out) {
-    const pgo_mg::HostLevel& A = ((pgo_mg::Hierarchy*)h)->L[l];
+    const pgo_mg::HostLevel& A = level_of(h, l);
     out[0] = A.smoothed ? (long long)A.ps_col.size() : -1; out[1] = (long long)A.w_col.size(); out[2] = (long long)A.psT_ent.size();
 }
 void mgh_smoothed(void* h, int l, int* ps_rowptr, int* ps_col, int* w_rowptr, int* w_col, long long* psT_ptr, long long* psT_ent) {
-    const pgo_mg::HostLevel& A = ((pgo_mg::Hierarchy*)h)->L[l];
+    const pgo_mg::HostLevel& A = level_of(h, l);
     std::memcpy(ps_rowptr, A.ps_rowptr.data(), A.ps_rowptr.size() * 4); std::memcpy(ps_col, A.ps_col.data(), A.ps_col.size() * 4);
     std::memcpy(w_rowptr, A.w_rowptr.data(), A.w_rowptr.size() * 4); std::memcpy(w_col, A.w_col.data(), A.w_col.size() * 4);
     std::memcpy(psT_ptr, A.psT_ptr.data(), A.psT_ptr.size() * 8); std::memcpy(psT_ent, A.psT_ent.data(), A.psT_ent.size() * 8);
 }
 // explicit transfer operator of a smoothed transition (R^T on W's pattern): Ps slot of every W block, W's pattern by coarse row, slot of every W block there, lane groups
 void mgh_explicit(void* h, int l, int* ps_of_w, int* rT_rowptr, int* rT_col, int* rT_of_w, int* rT_seg) {
-    const pgo_mg::HostLevel& A = ((pgo_mg::Hierarchy*)h)->L[l];
+    const pgo_mg::HostLevel& A = level_of(h, l);
     std::memcpy(ps_of_w, A.ps_of_w.data(), A.ps_of_w.size() * 4); std::memcpy(rT_rowptr, A.rT_rowptr.data(), A.rT_rowptr.size() * 4);
     std::memcpy(rT_col, A.rT_col.data(), A.rT_col.size() * 4); std::memcpy(rT_of_w, A.rT_of_w.data(), A.rT_of_w.size() * 4);
     *rT_seg = A.rT_seg;

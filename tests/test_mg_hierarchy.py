@@ -285,6 +285,78 @@ def test_smoothed_transition_structures_are_the_sparse_products(shim):
         assert len(B["col"]) > len(Href["levels"][l + 1]["col"]) and B["n"] == Href["levels"][l + 1]["n"]
 
 
+def test_smoothed_keyframe_transition_structures_are_the_sparse_products(shim):
+    """Smoothed transition keyframes -> level 1: on the keyframe level's own block pattern (parallel edges repeat a column, fixed keyframes are outside the system) Ps has the
+    pattern of A P, W that of A Ps, level 1 that of Ps^T W — without contribution lists, one hop wider than the aggregated edges —, the explicit operator's tables are consistent,
+    and everything above level 1 is built from that wider pattern."""
+    import scipy.sparse as sp
+    g = graphgen.generate(3000, 1200, odom_f_max=2, seed=13)
+    N = g.n_poses
+    free = np.ones(N, np.uint8); free[0] = 0; free[1700] = 0
+    rc1, rc2, sc1, sc2 = I32(g.odom_c1), I32(g.odom_c2), I32(g.loop_c1), I32(g.loop_c2)
+    rw = np.ascontiguousarray(g.odom_w, dtype=np.float64)
+    shim.mgh_build_fine.restype = C.c_void_p
+    shim.mgh_fine_nnzb.restype = C.c_longlong
+    h = C.c_void_p(shim.mgh_build_fine(C.c_longlong(N), ptr(free, C.c_ubyte), C.c_longlong(len(rc1)), ptr(rc1, C.c_int), ptr(rc2, C.c_int), ptr(rw, C.c_double), C.c_longlong(len(sc1)),
+                                       ptr(sc1, C.c_int), ptr(sc2, C.c_int), 3, 2, 40, 32, 12, 1, 64))
+    assert h.value
+    levels, agg0, mem0_ptr, mem0 = _read_hierarchy(shim, h, N)
+    nnzb = shim.mgh_fine_nnzb(h)
+    assert nnzb == N + 2 * (len(rc1) + len(sc1))
+    rowptr = np.zeros(N + 1, np.int64); col = np.zeros(nnzb, np.int32)
+    shim.mgh_fine_pattern(h, ptr(rowptr, C.c_longlong), ptr(col, C.c_int))
+    ss = np.zeros(3, np.int64)
+    shim.mgh_smoothed_sizes(h, -1, ptr(ss, C.c_longlong))
+    n1 = levels[0]["n"]
+    S = dict(ps_rowptr=np.zeros(N + 1, np.int32), ps_col=np.zeros(int(ss[0]), np.int32), w_rowptr=np.zeros(N + 1, np.int32), w_col=np.zeros(int(ss[1]), np.int32),
+             psT_ptr=np.zeros(n1 + 1, np.int64), psT_ent=np.zeros(int(ss[2]), np.int64), ps_of_w=np.zeros(int(ss[1]), np.int32), rT_rowptr=np.zeros(n1 + 1, np.int32),
+             rT_col=np.zeros(int(ss[1]), np.int32), rT_of_w=np.zeros(int(ss[1]), np.int32))
+    shim.mgh_smoothed(h, -1, ptr(S["ps_rowptr"], C.c_int), ptr(S["ps_col"], C.c_int), ptr(S["w_rowptr"], C.c_int), ptr(S["w_col"], C.c_int), ptr(S["psT_ptr"], C.c_longlong), ptr(S["psT_ent"], C.c_longlong))
+    seg = C.c_int(0)
+    shim.mgh_explicit(h, -1, ptr(S["ps_of_w"], C.c_int), ptr(S["rT_rowptr"], C.c_int), ptr(S["rT_col"], C.c_int), ptr(S["rT_of_w"], C.c_int), C.byref(seg))
+    shim.mgh_free(h)
+    assert np.array_equal(agg0 >= 0, free.astype(bool))
+    fr = np.nonzero(free)[0]
+    rows = np.repeat(np.arange(N), np.diff(rowptr))
+    keep = (free[rows] != 0) & (free[col] != 0)                      # the system: rows and columns of the free keyframes
+    A = sp.csr_matrix((np.ones(int(keep.sum())), (rows[keep], col[keep])), shape=(N, N))
+    P = sp.csr_matrix((np.ones(len(fr)), (fr, agg0[fr])), shape=(N, n1))
+    def pattern(rp, cl, shape):
+        r = np.repeat(np.arange(shape[0]), np.diff(rp))
+        return sp.csr_matrix((np.ones(len(cl)), (r, cl)), shape=shape)
+    def same(X, Y): return (abs(X.astype(bool).astype(int) - Y.astype(bool).astype(int))).nnz == 0
+    Ps = pattern(S["ps_rowptr"], S["ps_col"], (N, n1)); W = pattern(S["w_rowptr"], S["w_col"], (N, n1))
+    assert same(A @ P, Ps) and same(A @ Ps, W)
+    for i in np.nonzero(free == 0)[0]:
+        assert S["ps_rowptr"][i] == S["ps_rowptr"][i + 1] and S["w_rowptr"][i] == S["w_rowptr"][i + 1]
+    B = levels[0]
+    assert same(Ps.T @ W, pattern(B["rowptr"], B["col"], (n1, n1))) and all(B["col"][B["rowptr"][a]] == a for a in range(n1)) and len(B["g_ent"]) == 0
+    for i in range(N):
+        assert np.all(np.diff(S["ps_col"][S["ps_rowptr"][i]:S["ps_rowptr"][i + 1]]) > 0) and np.all(np.diff(S["w_col"][S["w_rowptr"][i]:S["w_rowptr"][i + 1]]) > 0)
+    seen = np.zeros(len(S["ps_col"]), int)
+    for a in range(n1):
+        for ent in S["psT_ent"][S["psT_ptr"][a]:S["psT_ptr"][a + 1]]:
+            i, sl = int(ent >> 32), int(ent & 0xffffffff)
+            assert S["ps_rowptr"][i] <= sl < S["ps_rowptr"][i + 1] and S["ps_col"][sl] == a
+            seen[sl] += 1
+    assert np.all(seen == 1)
+    w_rows = np.repeat(np.arange(N), np.diff(S["w_rowptr"])); ps_rows = np.repeat(np.arange(N), np.diff(S["ps_rowptr"]))
+    hit = S["ps_of_w"] >= 0
+    assert hit.sum() == len(S["ps_col"]) and np.array_equal(ps_rows[S["ps_of_w"][hit]], w_rows[hit]) and np.array_equal(S["ps_col"][S["ps_of_w"][hit]], S["w_col"][hit])
+    assert sorted(S["rT_of_w"].tolist()) == list(range(len(S["w_col"])))
+    r_rows = np.repeat(np.arange(n1), np.diff(S["rT_rowptr"]))
+    assert np.array_equal(r_rows[S["rT_of_w"]], S["w_col"]) and np.array_equal(S["rT_col"][S["rT_of_w"]], w_rows)
+    assert seg.value in (1, 2, 4, 8)
+    # level 2 is the smoothed product of the WIDER level 1 (smoothed_levels = 1)
+    L1 = levels[0]
+    rows1 = np.repeat(np.arange(n1), np.diff(L1["rowptr"]))
+    A1 = sp.csr_matrix((np.ones(len(L1["col"])), (rows1, L1["col"])), shape=(n1, n1))
+    n2 = levels[1]["n"]
+    P1 = sp.csr_matrix((np.ones(n1), (np.arange(n1), L1["parent"])), shape=(n1, n2))
+    assert same(P1.T @ A1 @ A1 @ A1 @ P1, pattern(levels[1]["rowptr"], levels[1]["col"], (n2, n2)))
+    print("blocks per keyframe: Ps %.2f  W %.2f ; level 1: %d nodes, %.1f blocks per row" % (len(S["ps_col"]) / N, len(S["w_col"]) / N, n1, len(B["col"]) / n1))
+
+
 def _read_hierarchy(lib, h, N):
     levels = []
     for l in range(lib.mgh_levels(h)):
