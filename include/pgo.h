@@ -193,6 +193,9 @@ typedef struct pgo_options {
     int32_t cg_pause_always;             /* 0: both early-rejection pauses where a rejection is in the air (previous step rejected, or the last accepted step's relative decrease below 0.8), the
                                           *    first pause alone where the system is expensive (predicted block-Jacobi-equivalent iterations x keyframes >= 5.6e7: one wasted solve outweighs dozens
                                           *    of pauses), none elsewhere; 1: both at every LM system of graphs >= 20 000 keyframes / after the solve's first rejection (round 4's rule) */
+    int32_t mg_smoothed_fine;            /* 0.  1: the transition keyframes -> level 1 is SMOOTHED as well (one GPU): Ps_0 = (I - w_p D^-1 A) P_0, level 1 = Ps_0^T A Ps_0 (one hop wider),
+                                          *    inside the cycle z = D^-1 r + s Ps_0 V_1(Ps_0^T r) with Ps_0 as fp32 blocks in both orientations (two launches of their own per iteration
+                                          *    instead of riding in the vector update and level 1's up-sweep).  EXPERIMENTAL (round 6). */
 } pgo_options;
 
 /* Per-iteration record; mirrors ceres::IterationSummary fields the BriefReport is built from. */

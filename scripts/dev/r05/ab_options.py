@@ -2,7 +2,7 @@
   python scripts/dev/r05/ab_options.py C3 20 3 "" "cg_single_reduction=0" "cg_pause_always=1" ..."""
 import sys
 import time
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import numpy as np
 from solve_keyframe_pose_graph_amd import capi, graphgen
 name, steps, reps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])

@@ -28,7 +28,7 @@ class Options(C.Structure):
                 ("cg_warm_start", C.c_int32), ("cg_use_graph", C.c_int32), ("cg_early_tolerance", C.c_double), ("cg_early_reject_rho", C.c_double), ("cg_mid_tolerance", C.c_double), ("cg_mid_reject_rho", C.c_double), ("coarse_aggregates", C.c_int32), ("mg_min_keyframes", C.c_int32), ("coarse_min_radius", C.c_double),
                 ("mg_omega", C.c_double), ("mg_correction_scale", C.c_double), ("mg_first_passes", C.c_int32), ("mg_passes", C.c_int32), ("mg_dense_max_nodes", C.c_int32), ("mg_switch_iterations", C.c_int32),
                 ("mg_loop_discount", C.c_double), ("mg_regroup_fraction", C.c_double), ("mg_prolongation_damping", C.c_double), ("mg_smoothed_levels", C.c_int32), ("mg_min_keyframes_switchable", C.c_int32),
-                ("device_id", C.c_int32), ("verbosity", C.c_int32), ("cg_single_reduction", C.c_int32), ("mg_explicit_transfer", C.c_int32), ("cg_end_game", C.c_int32), ("cg_pause_always", C.c_int32)]
+                ("device_id", C.c_int32), ("verbosity", C.c_int32), ("cg_single_reduction", C.c_int32), ("mg_explicit_transfer", C.c_int32), ("cg_end_game", C.c_int32), ("cg_pause_always", C.c_int32), ("mg_smoothed_fine", C.c_int32)]
 
 
 class Iteration(C.Structure):

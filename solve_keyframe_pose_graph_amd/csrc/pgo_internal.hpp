@@ -272,6 +272,8 @@ void launch_mg_assemble(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, 
 // its two halves: level 1 from the keyframe system (several ranks: this rank's contributions; the caller all-reduces levels[0].val), then everything above
 void launch_mg_galerkin0(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, const MgDev& M, const MgLevelDev* levels, hipStream_t st, bool hoff_valid = false);
 void launch_k2_offdiag(const GraphDev& G, const LinDev& L, hipStream_t st);
+void launch_mg_assemble_fine(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, const MgLevelDev& F, const MgLevelDev& T, const MgLevelDev& L1, double omega, int32_t* fail, hipStream_t st,
+                             double prolong_scale, bool hoff_valid);      // level 1 = Ps_0^T A Ps_0 (smoothed keyframe transition), then launch_mg_assemble_rest
 void launch_mg_assemble_rest(const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, double omega, int32_t* fail, hipStream_t st, double prolong_scale = 0.0 /* c = w_p / w of the smoothed transitions */);
 // out[n1][6] = P0^T v over the handle's keyframes (own_weighted: every keyframe counted by its owner only — several ranks)
 void launch_mg_restrict0(const GraphDev& G, const MgDev& M, const double* v, double* out, bool own_weighted, hipStream_t st);
@@ -279,7 +281,8 @@ void launch_mg_restrict0(const GraphDev& G, const MgDev& M, const double* v, dou
 void launch_mg_level1_update(const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, int k, int first, int mode, hipStream_t st);
 // z += scale P V(P^T r) (every coarse correction inside V scaled alike), r.z partials updated in place (cg_update's workgroup -> slot mapping)
 void launch_mg_apply(const GraphDev& G, const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, const double* r, double* z, double* part_rz, double scale, bool inside_iteration, hipStream_t st,
-                     bool restricted = false /* r_1 (and x_1) already formed by launch_cg_update_mg */, double prolong_scale = 0.0 /* c of the smoothed transitions */);
+                     bool restricted = false /* r_1 (and x_1) already formed by launch_cg_update_mg */, double prolong_scale = 0.0 /* c of the smoothed transitions */,
+                     const MgLevelDev* fine = nullptr /* smoothed keyframe transition: the keyframe level's transfer view (r_1 = Ps_0^T r and z += s Ps_0 x_1 by kernels of their own) */);
 // cg_update + r_1 = P_0^T r', x_1 = w D_1^-1 r_1 of the multigrid (M.blk_tab)
 void launch_cg_update_mg(const GraphDev& G, const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, int k, int n_pq_partials, hipStream_t st);
 void launch_cg_update_mg_sr(const GraphDev& G, const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, int k, int first, int n_pq_partials, hipStream_t st);      // single-reduction form (cg_update_kernel<true>) with the same restriction

@@ -308,9 +308,10 @@ __global__ __launch_bounds__(256) void mg_galerkin_kernel(MgLevelDev A, MgLevelD
     if (own) B.val[(size_t)slot * 36 + bsr_idx(r, c)] = acc;
 }
 // omega x inverse of every diagonal block (Cholesky; a block that is not positive definite raises *fail)
-__global__ __launch_bounds__(256) void mg_dinv_kernel(MgLevelDev A, double omega, int32_t* __restrict__ fail) {
+__global__ __launch_bounds__(256) void mg_dinv_kernel(MgLevelDev A, double omega, int32_t* __restrict__ fail, int skip_orphans /* keyframe level: rows with parent -1 are outside the system */) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A.n) return;
+    if (skip_orphans && A.parent[i] < 0) { double* out = A.Dinv + (size_t)i * 36; for (int e = 0; e < 36; ++e) out[e] = 0.0; return; }
     const double* v = A.val + (size_t)A.rowptr[i] * 36;
     double Lm[36];
     bool ok = true;
@@ -614,6 +615,66 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_sdown_kernel(MgLevelDev A, double
     }
 }
 
+// ---- smoothed transition keyframes -> level 1 (round 6) ----
+// The keyframe level as a block-CSR level F of its own (rowptr / col: one block per keyframe and per incident edge; g_ent[k] = the contribution block k IS: (index << 3) | kind as
+// in level 1's lists), so that the set-up kernels of a smoothed transition (mg_ps_kernel, mg_w_kernel, mg_psTw_kernel) form Ps_0 = (I - c Dinv A) P_0, W_0 = A Ps_0 and level 1 =
+// Ps_0^T W_0 exactly as they do one level up.  Inside the cycle the keyframe level stays matrix-free and additive:  z = D^-1 r + s Ps_0 V_1(Ps_0^T r)  — Ps_0 as fp32 blocks by
+// keyframe row (prolongation) and, the same rounded numbers transposed, by level-1 row (restriction): ~2 blocks per keyframe each way.
+template <bool HOFF>
+__global__ __launch_bounds__(256) void mg_fine_blocks_kernel(GraphDev G, LinDev L, ScaleDev Sc, CgDev C, MgLevelDev F) {
+    const int lane = threadIdx.x & 63;
+    const int64_t k = wave_in_grid();
+    if (k >= F.nnzb) return;
+    const int r = lane / 6, c = lane - r * 6;
+    const bool own = lane < 36;
+    const double h = fine_block_value<HOFF>(G, L, Sc, C, F.g_ent[k], lane, r, c, own);
+    if (own) F.val[(size_t)k * 36 + bsr_idx(r, c)] = h;
+}
+// Ps_0 rounded to fp32 ONCE and stored twice (T = the transfer view of the keyframe level: rt_valf on Ps's own pattern by keyframe row, r_valf by level-1 row, rT_of_w = slot of
+// block k there): exact transposes of each other, so the preconditioner stays symmetric.  Both in the level kernels' block layout.
+__global__ __launch_bounds__(256) void mg_ps_f32_kernel(MgLevelDev T) {
+    const int lane = threadIdx.x & 63;
+    const int64_t k = wave_in_grid();
+    if (k >= T.n_ps || lane >= 36) return;
+    const int r = lane / 6, c = lane % 6;
+    const float f = (float)T.ps_val[(size_t)k * 36 + lane];
+    T.rt_valf[(size_t)k * 36 + bsr_idx(r, c)] = f;
+    T.r_valf[(size_t)T.rT_of_w[k] * 36 + bsr_idx(c, r)] = f;
+}
+// z_i += s (Ps_0 x_1)_i and r.z += r.(s Ps_0 x_1), in cg_update's lane / workgroup mapping (same partial-sum slots, as mg_prolong0_kernel): lane = (keyframe, row pair j);
+// rows 2j, 2j+1 of a block are 12 consecutive floats of the block layout
+__global__ __launch_bounds__(CG_BLOCK) void mg_prolong0s_kernel(GraphDev G, MgLevelDev T, const double* __restrict__ x1, const double* __restrict__ rv, double* __restrict__ zv,
+                                                                 double* __restrict__ part_rz, double scale, const int32_t* __restrict__ stop) {
+    __shared__ double red[CG_BLOCK / 64];
+    if (stop && *stop) return;
+    const int64_t pairs = G.N * 3;
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * CG_BLOCK + threadIdx.x; i < pairs; i += (int64_t)gridDim.x * CG_BLOCK) {
+        const int64_t n = i / 3;
+        const int j = (int)(i - n * 3);
+        const int k0 = T.ps_rowptr[n], k1 = T.ps_rowptr[n + 1];
+        if (k1 <= k0) continue;
+        double a0 = 0.0, a1 = 0.0;
+        for (int k = k0; k < k1; ++k) {
+            const float4* vp = reinterpret_cast<const float4*>(T.rt_valf + (size_t)k * 36 + j * 12);
+            const float4 v0 = vp[0], v1 = vp[1], v2 = vp[2];      // (row 2j, col 0) (row 2j+1, col 0) (2j, 1) (2j+1, 1) | cols 2, 3 | cols 4, 5
+            const double2* xp = reinterpret_cast<const double2*>(x1 + (size_t)T.ps_col[k] * 6);
+            const double2 xa = xp[0], xb = xp[1], xc = xp[2];
+            a0 += (double)v0.x * xa.x + (double)v0.z * xa.y + (double)v1.x * xb.x + (double)v1.z * xb.y + (double)v2.x * xc.x + (double)v2.z * xc.y;
+            a1 += (double)v0.y * xa.x + (double)v0.w * xa.y + (double)v1.y * xb.x + (double)v1.w * xb.y + (double)v2.y * xc.x + (double)v2.w * xc.y;
+        }
+        a0 *= scale; a1 *= scale;
+        double2* zp = reinterpret_cast<double2*>(zv) + i;
+        const double2 r = reinterpret_cast<const double2*>(rv)[i];
+        double2 z = *zp;
+        z.x += a0; z.y += a1;
+        *zp = z;
+        acc += r.x * a0 + r.y * a1;
+    }
+    const double s = block_sum(acc, red);
+    if (threadIdx.x == 0) part_rz[blockIdx.x] += s;
+}
+
 // ---- smoother safety: the damped block-Jacobi smoother needs w lambda_max(D^-1 A) < 2 or the cycle is not positive definite any more (the PCG then "converges" on a
 // negative r.z: measured on a chain-like graph whose smoothed Galerkin level has lambda_max ~ 2.5).  lambda_max is estimated per level and per LM system by a few steps
 // of the power method (a lower bound: hence the margins) and a level whose w lambda exceeds `limit` gets its Dinv = w D^-1 scaled down to w lambda = `target`.
@@ -676,7 +737,7 @@ void launch_mg_assemble_rest(const MgDev& M, const MgLevelDev* levels, const Coa
             } else hipLaunchKernelGGL(mg_galerkin_kernel, dim3((unsigned)((levels[l].nnzb + 3) / 4)), dim3(256), 0, st, A, levels[l]);
         }
         if (l + 1 < M.n_levels) {
-            hipLaunchKernelGGL(mg_dinv_kernel, dim3((unsigned)((levels[l].n + 255) / 256)), dim3(256), 0, st, levels[l], omega, fail);
+            hipLaunchKernelGGL(mg_dinv_kernel, dim3((unsigned)((levels[l].n + 255) / 256)), dim3(256), 0, st, levels[l], omega, fail, 0);
             hipLaunchKernelGGL(mg_val_f32_kernel, dim3((unsigned)((levels[l].nnzb + 3) / 4)), dim3(256), 0, st, levels[l]);
             mg_limit_smoother(levels[l], omega, st);
         }
@@ -685,6 +746,17 @@ void launch_mg_assemble_rest(const MgDev& M, const MgLevelDev* levels, const Coa
     (void)hipMemsetAsync(K.Ac, 0, (size_t)K.nc * K.nc * sizeof(double), st);
     if (K.nc > 6 * K.n_agg) hipLaunchKernelGGL(coarse_pad_identity_kernel, dim3((unsigned)((K.nc - 6 * K.n_agg + 63) / 64)), dim3(64), 0, st, K);
     hipLaunchKernelGGL(mg_dense_scatter_kernel, dim3((unsigned)(((int64_t)T.n * 36 + 255) / 256)), dim3(256), 0, st, T, K);
+}
+// level 1 of a hierarchy with the smoothed keyframe transition: F = the keyframe level (set-up view), T = its transfer view (Ps's pattern in the explicit operator's fields)
+void launch_mg_assemble_fine(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, const MgLevelDev& F, const MgLevelDev& T, const MgLevelDev& L1, double omega, int32_t* fail, hipStream_t st,
+                             double prolong_scale, bool hoff_valid) {
+    if (hoff_valid) hipLaunchKernelGGL((mg_fine_blocks_kernel<true>), dim3((unsigned)((F.nnzb + 3) / 4)), dim3(256), 0, st, G, L, Sc, C, F);
+    else hipLaunchKernelGGL((mg_fine_blocks_kernel<false>), dim3((unsigned)((F.nnzb + 3) / 4)), dim3(256), 0, st, G, L, Sc, C, F);
+    hipLaunchKernelGGL(mg_dinv_kernel, dim3((unsigned)((F.n + 255) / 256)), dim3(256), 0, st, F, omega, fail, 1);
+    hipLaunchKernelGGL(mg_ps_kernel, dim3((unsigned)((F.n_ps + 3) / 4)), dim3(256), 0, st, F, prolong_scale);
+    hipLaunchKernelGGL(mg_w_kernel, dim3((unsigned)((F.n_w + 3) / 4)), dim3(256), 0, st, F);
+    hipLaunchKernelGGL(mg_psTw_kernel, dim3((unsigned)((L1.nnzb + 3) / 4)), dim3(256), 0, st, F, L1);
+    hipLaunchKernelGGL(mg_ps_f32_kernel, dim3((unsigned)((T.n_ps + 3) / 4)), dim3(256), 0, st, T);
 }
 
 // ---- the cycle ----
@@ -1181,11 +1253,16 @@ void launch_mg_level1_update(const CgDev& C, const MgDev& M, const MgLevelDev* l
     else hipLaunchKernelGGL(mg_level1_update_kernel, dim3(g1), dim3(CG_BLOCK), 0, st, C, M, levels[0].r, levels[0].x, (const double*)levels[0].Dinv, k & 1, first, mode);
 }
 void launch_mg_apply(const GraphDev& G, const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, const double* r, double* z, double* part_rz, double scale, bool inside_iteration, hipStream_t st,
-                     bool restricted, double prolong_scale) {
+                     bool restricted, double prolong_scale, const MgLevelDev* fine /* transfer view of the keyframe level: smoothed keyframe transition (never `restricted`, never fused) */) {
     const int32_t* stop = inside_iteration ? C.flags : nullptr;     // at PCG start the flag still belongs to the previous solve
     const int nl = M.n_levels;
     const unsigned g1 = (unsigned)((M.n1 + MG_TILE_ROWS - 1) / MG_TILE_ROWS);
     if (restricted) {}
+    else if (fine) {      // r_1 = Ps_0^T r (and x_1 = Dinv_1 r_1): the restriction half of mg_sdown_kernel on the keyframe level's transfer view, which has no tiles of its own
+        MgLevelDev T = *fine; T.tiles = 0; T.r = const_cast<double*>(r);
+        if (nl == 1) hipLaunchKernelGGL(mg_sdown_kernel, dim3((unsigned)T.rT_tiles), dim3(CG_BLOCK), 0, st, T, K.rc, (double*)nullptr, (const double*)nullptr, stop);
+        else hipLaunchKernelGGL(mg_sdown_kernel, dim3((unsigned)T.rT_tiles), dim3(CG_BLOCK), 0, st, T, levels[0].r, levels[0].x, (const double*)levels[0].Dinv, stop);
+    }
     else if (nl == 1) hipLaunchKernelGGL(mg_restrict0_kernel, dim3(g1), dim3(CG_BLOCK), 0, st, M, r, K.rc, (double*)nullptr, (const double*)nullptr, stop);
     else hipLaunchKernelGGL(mg_restrict0_kernel, dim3(g1), dim3(CG_BLOCK), 0, st, M, r, levels[0].r, levels[0].x, (const double*)levels[0].Dinv, stop);
     for (int l = 1; l < nl; ++l) {                     // sparse level l -> level l+1
@@ -1225,5 +1302,6 @@ void launch_mg_apply(const GraphDev& G, const CgDev& C, const MgDev& M, const Mg
         if (l == 1 && fused) hipLaunchKernelGGL(mg_up_kernel<true>, dim3((unsigned)(A.tiles < MAX_PARTIALS ? A.tiles : MAX_PARTIALS)), dim3(CG_BLOCK), 0, st, A, A, 0, scale, stop, M, r, z, part_rz + g0, (const double*)nullptr);
         else hipLaunchKernelGGL(mg_up_kernel<false>, dim3((unsigned)A.tiles), dim3(CG_BLOCK), 0, st, A, l >= 2 ? below_of(l - 2) : levels[0], l >= 2 && !expl_at(l - 2) ? 1 : 0, scale, stop, M, r, z, part_rz, (const double*)nullptr);
     }
-    if (!fused) hipLaunchKernelGGL(mg_prolong0_kernel, dim3(g0), dim3(CG_BLOCK), 0, st, G, M, (const double*)(nl == 1 ? K.yc : levels[0].xf), r, z, part_rz, scale, stop);
+    if (fine) hipLaunchKernelGGL(mg_prolong0s_kernel, dim3(g0), dim3(CG_BLOCK), 0, st, G, *fine, (const double*)(nl == 1 ? K.yc : levels[0].xf), r, z, part_rz, scale, stop);
+    else if (!fused) hipLaunchKernelGGL(mg_prolong0_kernel, dim3(g0), dim3(CG_BLOCK), 0, st, G, M, (const double*)(nl == 1 ? K.yc : levels[0].xf), r, z, part_rz, scale, stop);
 }

@@ -112,6 +112,9 @@ struct MgPrepared {
     std::vector<Off> off;
     size_t o_agg0 = 0, o_mem0_ptr = 0, o_mem0 = 0, o_blk_tab = 0, o_d0 = 0, o_inv = 0, o_q1 = 0, o_s1 = 0;
     bool have_tab = false;
+    // smoothed keyframe transition: the keyframe level F (pgo_mg_host.hpp) — its own block pattern and contribution ids, Ps / W structure, Ps by level-1 row for the restriction
+    bool fine = false;
+    struct FineOff { size_t rowptr, col, ent, ps_rowptr, ps_col, w_rowptr, w_col, psT_ptr, psT_ent, ps_row, w_row, rT_of_ps, rT_col, rT_rows, val, Dinv, ps_val, w_val, rt_valf, r_valf; int rT_tiles, rT_seg_shift; } fo{};
     std::vector<double> sw_built;          // [Es] s^2 of every switchable edge this hierarchy was matched with
     double moved = 0.0, of_edges = 0.0, host_ms = 0.0;
 };
@@ -177,6 +180,7 @@ struct pgo_problem {
     // aggregation multigrid (MgDev): hierarchy arrays live in three pooled buffers
     DBuf<double> d_mg_f64; DBuf<int32_t> d_mg_i32; DBuf<int64_t> d_mg_i64;
     MgDev M{}; MgLevelDev mg_levels[MG_MAX_LEVELS];
+    bool mg_fine = false; MgLevelDev mg_fineF{}, mg_fineT{};      // smoothed keyframe transition (opt.mg_smoothed_fine): the keyframe level's set-up view and transfer view
     bool mg_built = false, mg_active = false;
     pgo_mg::BuildCache mg_cache;           // what the hierarchy builder keeps for a regroup of the same graph
     std::vector<double> mg_sw_built;       // [Es] s^2 of every switchable edge the current hierarchy was built with
@@ -339,9 +343,28 @@ int mg_prepare_impl(pgo_problem* p, const double* sw_now, MgPrepared& Q) {
     bool ok;
     std::vector<int32_t>& agg0_l = Q.agg0_l; std::vector<int32_t>& mem0_ptr_l = Q.mem0_ptr_l; std::vector<int32_t>& mem0_l = Q.mem0_l;
     std::vector<double>& inv_cnt = Q.inv_cnt;
+    std::vector<int64_t> fine_rowptr, fine_ent; std::vector<int32_t> fine_col;
+    const bool want_fine = p->opt.mg_smoothed_fine != 0 && !p->local_ids;
+    if (want_fine) {
+        // the keyframe level's block pattern: row i = block (i, i), then one block per incident edge (relative-pose edges first, each class in edge order), and what each block IS for
+        // fine_block_value (kind 0: the keyframe's reduced diagonal block; 1 / 2: a relative-pose edge seen from its first / second keyframe; 3 / 4: a switchable edge)
+        fine_rowptr.assign((size_t)N + 1, 0);
+        for (int64_t e = 0; e < Er; ++e) { fine_rowptr[(size_t)p->rel.c1[e] + 1]++; fine_rowptr[(size_t)p->rel.c2[e] + 1]++; }
+        for (int64_t e = 0; e < Es; ++e) { fine_rowptr[(size_t)p->swe.c1[e] + 1]++; fine_rowptr[(size_t)p->swe.c2[e] + 1]++; }
+        for (int64_t n = 0; n < N; ++n) fine_rowptr[(size_t)n + 1] += fine_rowptr[n] + 1;
+        fine_col.resize((size_t)fine_rowptr[N]); fine_ent.resize((size_t)fine_rowptr[N]);
+        std::vector<int64_t> fillb((size_t)N);
+        for (int64_t n = 0; n < N; ++n) { fine_col[(size_t)fine_rowptr[n]] = (int32_t)n; fine_ent[(size_t)fine_rowptr[n]] = (n << 3) | 0; fillb[n] = fine_rowptr[n] + 1; }
+        auto add = [&](int64_t e, int32_t a, int32_t b, int kind) {
+            fine_col[(size_t)fillb[a]] = b; fine_ent[(size_t)fillb[a]++] = (e << 3) | kind;
+            fine_col[(size_t)fillb[b]] = a; fine_ent[(size_t)fillb[b]++] = (e << 3) | (kind + 1);
+        };
+        for (int64_t e = 0; e < Er; ++e) add(e, p->rel.c1[e], p->rel.c2[e], 1);
+        for (int64_t e = 0; e < Es; ++e) add(e, p->swe.c1[e], p->swe.c2[e], 3);
+    }
     if (!p->local_ids) {
         ok = pgo_mg::build_hierarchy(N, p->h_node_free, p->rel.c1, p->rel.c2, p->rel.meas.data() + 7, 8, p->swe.c1, p->swe.c2, sw_w.empty() ? nullptr : sw_w.data(), passes0, passes, dense_max, MG_TILE_ROWS,
-                                     MG_MAX_LEVELS, H, false, MG_BLOCK0, nullptr, n_smoothed, loop_discount, &p->mg_cache);
+                                     MG_MAX_LEVELS, H, false, MG_BLOCK0, nullptr, n_smoothed, loop_discount, &p->mg_cache, want_fine ? &fine_rowptr : nullptr, want_fine ? &fine_col : nullptr);
     } else {
         // Several ranks: every rank gathers the endpoints and weights of ALL edges (one all-reduce of a zero-padded buffer: 24 B per edge, once per graph build)
         // and builds the same hierarchy from the global graph; its own edges and owned keyframes are what it contributes to level 1 (pgo_mg_host.hpp).
@@ -391,6 +414,11 @@ int mg_prepare_impl(pgo_problem* p, const double* sw_now, MgPrepared& Q) {
             n32 += 3 * A.col.size() + A.parent.size() + A.agg_ptr.size() + tiles * (4 + 2 * (size_t)MG_TILE_ROWS) + A.ps_rowptr.size() + 2 * A.ps_col.size() + A.w_rowptr.size() + 5 * A.w_col.size() + (A.smoothed ? tiles * 2 * (size_t)MG_TILE_ROWS + ((size_t)A.rT_rowptr.size() / 4 + 2) * 2 * (size_t)MG_TILE_ROWS : 0) + 16;
             n64 += A.rowptr.size() + A.g_ptr.size() + A.g_ent.size() + A.psT_ptr.size() + A.psT_ent.size();
         }
+        if (H.fine_smoothed) {
+            const pgo_mg::HostLevel& F = H.F;
+            n32 += F.col.size() + F.ps_rowptr.size() + 4 * F.ps_col.size() + F.w_rowptr.size() + 2 * F.w_col.size() + ((size_t)H.L[0].n / 4 + 2) * 2 * (size_t)MG_TILE_ROWS + 16;
+            n64 += F.rowptr.size() + F.col.size() + F.psT_ptr.size() + F.psT_ent.size();
+        }
         pi32.reserve(n32); pi64.reserve(n64);
     }
     auto put32 = [&](const std::vector<int32_t>& v) { const size_t o = pi32.size(); pi32.insert(pi32.end(), v.begin(), v.end()); return o; };
@@ -400,7 +428,7 @@ int mg_prepare_impl(pgo_problem* p, const double* sw_now, MgPrepared& Q) {
     Q.off.assign((size_t)nl, MgPrepared::Off{});
     Q.o_agg0 = put32(A0); Q.o_mem0_ptr = put32(M0P); Q.o_mem0 = put32(M0);
     // slot table of the restriction inside the vector update: per run of MG_BLOCK0 keyframes its aggregates {id, 8 members as run-local bytes}
-    bool have_tab = !p->local_ids;
+    bool have_tab = !p->local_ids && !H.fine_smoothed;      // (smoothed keyframe transition: restriction and prolongation need neighbouring runs — kernels of their own)
     if (have_tab) {
         const int64_t runs = (N + MG_BLOCK0 - 1) / MG_BLOCK0;
         std::vector<int32_t> tab((size_t)runs * MG_BLOCK0 * 4);
@@ -499,6 +527,39 @@ int mg_prepare_impl(pgo_problem* p, const double* sw_now, MgPrepared& Q) {
             }
         }
     }
+    Q.fine = H.fine_smoothed;
+    if (Q.fine) {
+        const pgo_mg::HostLevel& F = H.F;
+        MgPrepared::FineOff& o = Q.fo;
+        const int32_t n1 = H.L[0].n;
+        o.rowptr = put64(F.rowptr); o.ent = put64(fine_ent); o.col = put32(F.col);
+        o.ps_rowptr = put32(F.ps_rowptr); o.ps_col = put32(F.ps_col); o.w_rowptr = put32(F.w_rowptr); o.w_col = put32(F.w_col);
+        o.psT_ptr = put64(F.psT_ptr); o.psT_ent = put64(F.psT_ent);
+        std::vector<int32_t> ps_row(F.ps_col.size()), w_row(F.w_col.size());
+        for (int32_t i = 0; i < F.n; ++i) {
+            for (int32_t k = F.ps_rowptr[i]; k < F.ps_rowptr[(size_t)i + 1]; ++k) ps_row[(size_t)k] = i;
+            for (int32_t k = F.w_rowptr[i]; k < F.w_rowptr[(size_t)i + 1]; ++k) w_row[(size_t)k] = i;
+        }
+        o.ps_row = put32(ps_row); o.w_row = put32(w_row);
+        // Ps by level-1 row (the restriction r_1 = Ps_0^T r runs as the restriction half of mg_sdown_kernel): position e of psT_ent = slot of the transposed block
+        std::vector<int32_t> rT_of_ps(F.ps_col.size()), rT_col(F.ps_col.size());
+        for (size_t e = 0; e < F.psT_ent.size(); ++e) { rT_of_ps[(size_t)(F.psT_ent[e] & 0xffffffffll)] = (int32_t)e; rT_col[e] = (int32_t)(F.psT_ent[e] >> 32); }
+        o.rT_of_ps = put32(rT_of_ps); o.rT_col = put32(rT_col);
+        const double mean_row = (double)F.ps_col.size() / (double)std::max(1, n1);
+        int seg = 1;
+        while (seg < 8 && mean_row > 5.0 * seg) seg *= 2;
+        o.rT_seg_shift = seg >= 8 ? 3 : seg >= 4 ? 2 : seg >= 2 ? 1 : 0;
+        const int rpt = MG_TILE_ROWS >> o.rT_seg_shift;
+        o.rT_tiles = (n1 + rpt - 1) / rpt;
+        std::vector<int32_t> rows;
+        rows.reserve((size_t)o.rT_tiles * MG_TILE_ROWS * 2);
+        for (int tt = 0; tt < o.rT_tiles; ++tt)
+            for (int li = 0; li < MG_TILE_ROWS; ++li) { const int32_t r = tt * rpt + li; const bool in = li < rpt && r < n1; rows.push_back(in ? (int32_t)F.psT_ptr[r] : 0); rows.push_back(in ? (int32_t)F.psT_ptr[(size_t)r + 1] : 0); }
+        while (pi32.size() % 2) pi32.push_back(0);
+        o.rT_rows = put32(rows);
+        o.val = take(F.col.size() * 36); o.Dinv = take((size_t)F.n * 36); o.ps_val = take(F.ps_col.size() * 36); o.w_val = take(F.w_col.size() * 36);
+        o.rt_valf = take((F.ps_col.size() * 36 + 1) / 2); o.r_valf = take((F.ps_col.size() * 36 + 1) / 2);
+    }
     Q.host_ms = (now_s() - t0) * 1e3;
     if (p->opt.verbosity > 1) std::fprintf(stderr, "[pgo] hierarchy (host): pooled arrays + descriptors      (total %.2f ms, %u hardware threads reported)\n", Q.host_ms, std::thread::hardware_concurrency());
     return PGO_OK;
@@ -553,6 +614,24 @@ int mg_install(pgo_problem* p, MgPrepared& Q) {
                 D.rT_tiles = o.rT_tiles; D.rT_seg_shift = o.rT_seg_shift;
             }
         }
+    }
+    p->mg_fine = Q.fine; p->mg_fineF = MgLevelDev{}; p->mg_fineT = MgLevelDev{};
+    if (Q.fine) {
+        const pgo_mg::HostLevel& Fh = H.F;
+        const MgPrepared::FineOff& o = Q.fo;
+        MgLevelDev& F = p->mg_fineF;
+        F.n = Fh.n; F.n_next = H.L[0].n; F.tiles = 0; F.nnzb = (int64_t)Fh.col.size();
+        F.rowptr = b64 + o.rowptr; F.col = b32 + o.col; F.val = bf + o.val; F.g_ent = b64 + o.ent; F.Dinv = bf + o.Dinv;
+        F.d = p->M.d0; F.parent = p->M.agg0;
+        F.smoothed = 1; F.n_ps = (int32_t)Fh.ps_col.size(); F.n_w = (int32_t)Fh.w_col.size();
+        F.ps_rowptr = b32 + o.ps_rowptr; F.ps_col = b32 + o.ps_col; F.w_rowptr = b32 + o.w_rowptr; F.w_col = b32 + o.w_col; F.psT_ptr = b64 + o.psT_ptr; F.psT_ent = b64 + o.psT_ent;
+        F.ps_row = b32 + o.ps_row; F.w_row = b32 + o.w_row; F.ps_val = bf + o.ps_val; F.w_val = bf + o.w_val;
+        // the transfer view: the explicit operator's fields describe Ps itself (its own pattern by keyframe row; by level-1 row for the restriction)
+        MgLevelDev& T = p->mg_fineT;
+        T = F;
+        T.rt_valf = reinterpret_cast<float*>(bf + o.rt_valf); T.r_valf = reinterpret_cast<float*>(bf + o.r_valf);
+        T.rT_of_w = b32 + o.rT_of_ps; T.rT_col = b32 + o.rT_col; T.rT_rows = reinterpret_cast<const int2*>(b32 + o.rT_rows);
+        T.rT_tiles = o.rT_tiles; T.rT_seg_shift = o.rT_seg_shift;
     }
     // the dense coarsest level shares the buffers of the two-level preconditioner, which the multigrid replaces on this graph
     p->K.n_agg = n_top; p->K.nc = nc; p->K.Ac = p->d_cAc.p; p->K.Acf = p->d_cAcf.p; p->K.rc = p->d_crc.p; p->K.yc = p->d_crc.p + nc;
@@ -1167,6 +1246,7 @@ double mg_cs(const pgo_problem* p) {
     const double wp = p->opt.mg_prolongation_damping > 0.0 && p->opt.mg_prolongation_damping < 0.85 ? p->opt.mg_prolongation_damping : 0.6;
     return wp / om;
 }
+static const MgLevelDev* mg_fine_view(const pgo_problem* p) { return p->mg_fine ? &p->mg_fineT : nullptr; }      // smoothed keyframe transition: what launch_mg_apply restricts and prolongs with
 double mg_scale(const pgo_problem* p) { return p->opt.mg_correction_scale >= 1.0 && p->opt.mg_correction_scale <= 4.0 ? p->opt.mg_correction_scale : 1.0; }
 
 struct CgResult { int iterations; bool breakdown; double rel_residual; bool converged; };
@@ -1219,7 +1299,7 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
             launch_mg_restrict0(p->G, p->M, p->C.r, r1, true, p->st);
             if ((rcs = allreduce(p, r1, (size_t)p->M.n1 * 6, 0)) != PGO_OK) return rcs;
             launch_mg_level1_update(p->C, p->M, p->mg_levels, p->K, 0, 1, 1, p->st);
-            launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz, mg_scale(p), false, p->st, true, mg_cs(p));
+            launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz, mg_scale(p), false, p->st, true, mg_cs(p), mg_fine_view(p));
         }
         double* bb = p->C.scal + 12;
         launch_reduce(p->C.part_pq, g, 0, bb, p->st);
@@ -1232,7 +1312,7 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
             // z = D^-1 r + P Ac^-1 P^T r (or the multigrid cycle): the coarse term is added to z and to the r.z partials before the scalars are formed
             int g = launch_cg_init_vectors(p->G, p->C, warm ? 1 : 0, p->st);
             const int g_bb = g;      // the slots of part_pq that hold the partials of b.D^-1 b
-            if (p->mg_active) launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz, mg_scale(p), false, p->st, false, mg_cs(p));
+            if (p->mg_active) launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz, mg_scale(p), false, p->st, false, mg_cs(p), mg_fine_view(p));
             else launch_coarse_apply(p->G, p->C, p->K, p->C.r, p->C.z, p->C.part_rz, false, p->st);
             if (fused_coarse) {    // z is complete here: the slots the fused kernels will use beyond the start-up kernels' stay zero for this parity
                 HIPCHK(p, hipMemsetAsync(p->C.part_rz + g, 0, (size_t)(fused_parts + p->C.extra_rz - g) * sizeof(double), p->st));
@@ -1274,7 +1354,7 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
             const bool mg_restrict_fused = p->mg_active && p->M.blk_tab != nullptr;
             if (mg_restrict_fused) launch_cg_update_mg_sr(p->G, p->C, p->M, p->mg_levels, p->K, kk, first, n_pq, p->st);
             else launch_cg_update_sr(p->G, p->C, kk, first, n_pq, p->st);
-            if (p->mg_active) launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz + (size_t)((kk & 1) ^ 1) * RZ_STRIDE, mg_scale(p), true, p->st, mg_restrict_fused, mg_cs(p));
+            if (p->mg_active) launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz + (size_t)((kk & 1) ^ 1) * RZ_STRIDE, mg_scale(p), true, p->st, mg_restrict_fused, mg_cs(p), mg_fine_view(p));
             return PGO_OK;
         }
         if (multi) {
@@ -1295,7 +1375,7 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
             launch_cgcg_update(p->G, p->C, kk, kk == 0 ? 1 : 0, p->st, xb, p->d_sh_of.p, xb + nrow);   // (first: also when a PCG that stopped before its first update is resumed: p = s = 0 still)
             if (p->mg_active) {      // u = D^-1 r + P0 V(r1): r1 by the recurrence, the cycle on the replicated levels, the prolongation to this rank's keyframes
                 launch_mg_level1_update(p->C, p->M, p->mg_levels, p->K, kk, kk == 0 ? 1 : 0, 0, p->st);
-                launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz, mg_scale(p), true, p->st, true, mg_cs(p));
+                launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz, mg_scale(p), true, p->st, true, mg_cs(p), mg_fine_view(p));
             }
             return PGO_OK;
         }
@@ -1312,7 +1392,7 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
         if (mg_restrict_fused) launch_cg_update_mg(p->G, p->C, p->M, p->mg_levels, p->K, kk, n_pq, p->st);
         else launch_cg_update(p->G, p->C, kk, n_pq, p->st);
         // the new residual is in the OTHER r buffer, its r.z partials in the other parity's slots
-        if (p->mg_active) launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, (kk & 1) ? p->C.r : p->C.r2, p->C.z, p->C.part_rz + (size_t)((kk & 1) ^ 1) * RZ_STRIDE, mg_scale(p), true, p->st, mg_restrict_fused, mg_cs(p));
+        if (p->mg_active) launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, (kk & 1) ? p->C.r : p->C.r2, p->C.z, p->C.part_rz + (size_t)((kk & 1) ^ 1) * RZ_STRIDE, mg_scale(p), true, p->st, mg_restrict_fused, mg_cs(p), mg_fine_view(p));
         else if (p->coarse_active)
             launch_coarse_apply(p->G, p->C, p->K, (kk & 1) ? p->C.r : p->C.r2, p->C.z, p->C.part_rz + (size_t)((kk & 1) ^ 1) * RZ_STRIDE, true, p->st);
         return PGO_OK;
@@ -1400,7 +1480,7 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
             if ((rcs = start_multi(1)) != PGO_OK) return rcs;
         } else {
             const int g = launch_cg_init_vectors(p->G, p->C, 1, p->st);
-            launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz, mg_scale(p), false, p->st, false, mg_cs(p));
+            launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz, mg_scale(p), false, p->st, false, mg_cs(p), mg_fine_view(p));
             launch_cg_init_scalars(p->C, g, g, tol2, p->st);
         }
         k = 0; n_chunks = 0; waited = -1; r1_refreshed_at = 0;
@@ -1687,6 +1767,9 @@ static int build_mg(pgo_problem* p) {
         launch_mg_galerkin0(p->G, p->L, p->Sc, p->C, p->M, p->mg_levels, p->st, hoff_valid);
         HIPCHK(p, hipStreamSynchronize(p->st)); std::fprintf(stderr, "[pgo] multigrid: galerkin0 done at %.2f ms\n", (now_s() - t_build0) * 1e3);
         launch_mg_assemble_rest(p->M, p->mg_levels, p->K, omega, fail, p->st, mg_cs(p));
+    } else if (p->mg_fine) {      // smoothed keyframe transition: level 1 = Ps_0^T A Ps_0 from the keyframe level's own blocks
+        launch_mg_assemble_fine(p->G, p->L, p->Sc, p->C, p->mg_fineF, p->mg_fineT, p->mg_levels[0], omega, fail, p->st, mg_cs(p), hoff_valid);
+        launch_mg_assemble_rest(p->M, p->mg_levels, p->K, omega, fail, p->st, mg_cs(p));
     } else launch_mg_assemble(p->G, p->L, p->Sc, p->C, p->M, p->mg_levels, p->K, omega, fail, p->st, mg_cs(p), hoff_valid);
     if (p->opt.verbosity > 1) { HIPCHK(p, hipStreamSynchronize(p->st)); std::fprintf(stderr, "[pgo] multigrid: level operators done at %.2f ms\n", (now_s() - t_build0) * 1e3); }
     launch_coarse_invert(p->K, p->d_cscr.p, fail, p->st);
@@ -1698,7 +1781,7 @@ static int build_mg(pgo_problem* p) {
     // level 1's up-sweep kernel also prolongs to the keyframes; its workgroups (at most MAX_PARTIALS, each taking every gridDim-th tile) put their r.z partials behind the update kernel's
     // (measured: 1 114 tiles on 1 024 workgroups — C4 — lose 3 % to the ragged second trip against the separate prolongation kernel; 3 907 tiles — C5 — gain 3.5 %)
     const int t1 = p->mg_levels[0].tiles;
-    p->C.extra_rz = (p->mg_active && !p->local_ids && p->M.n_levels >= 2 && (t1 <= MAX_PARTIALS || t1 >= 2 * MAX_PARTIALS)) ? std::min<int>(t1, MAX_PARTIALS) : 0;
+    p->C.extra_rz = (p->mg_active && !p->local_ids && !p->mg_fine && p->M.n_levels >= 2 && (t1 <= MAX_PARTIALS || t1 >= 2 * MAX_PARTIALS)) ? std::min<int>(t1, MAX_PARTIALS) : 0;
     if (p->opt.verbosity > 0 && h != 0) std::fprintf(stderr, "[pgo] multigrid: a coarse block is not positive definite at radius %.1e -> off for this iteration\n", p->radius);
     if (p->opt.verbosity > 1) std::fprintf(stderr, "[pgo] multigrid: operators of LM iteration %d built in %.2f ms\n", p->iteration, (now_s() - t_build0) * 1e3);
     return PGO_OK;
@@ -2175,6 +2258,7 @@ void pgo_options_init(pgo_options* o) {
     o->verbosity = 0;
     o->cg_single_reduction = 1;
     o->cg_pause_always = 0;
+    o->mg_smoothed_fine = 0;
     o->mg_explicit_transfer = 1;
     o->cg_end_game = 1;
 }
@@ -2263,7 +2347,7 @@ int pgo_set_options(pgo_problem* p, const pgo_options* o) {
     // the preconditioner hierarchies are part of the device graph build
     if (o->mg_min_keyframes != p->opt.mg_min_keyframes || o->mg_min_keyframes_switchable != p->opt.mg_min_keyframes_switchable || o->mg_first_passes != p->opt.mg_first_passes || o->mg_passes != p->opt.mg_passes ||
         o->mg_dense_max_nodes != p->opt.mg_dense_max_nodes || o->coarse_aggregates != p->opt.coarse_aggregates || o->mg_smoothed_levels != p->opt.mg_smoothed_levels || o->mg_loop_discount != p->opt.mg_loop_discount ||
-        o->mg_explicit_transfer != p->opt.mg_explicit_transfer) p->graph_dirty = true;
+        o->mg_explicit_transfer != p->opt.mg_explicit_transfer || o->mg_smoothed_fine != p->opt.mg_smoothed_fine) p->graph_dirty = true;
     p->opt = *o;
     p->opt.device_id = dev;   // the device binding is fixed at create
     return PGO_OK;
@@ -2704,7 +2788,7 @@ int pgo_time_kernel(pgo_problem* p, int32_t which, int32_t launches, double* avg
         if (!p->mg_active && (rc = build_mg(p)) != PGO_OK) return rc;
         if (!p->mg_active) { p->err = "pgo_time_kernel: the multigrid operators of this system are not positive definite"; return PGO_ERR_NUMERIC; }
         const int g = launch_cg_init_vectors(p->G, p->C, 0, p->st);
-        launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz, mg_scale(p), false, p->st, false, mg_cs(p));
+        launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz, mg_scale(p), false, p->st, false, mg_cs(p), mg_fine_view(p));
         launch_cg_init_scalars(p->C, g, g, 0.0, p->st);
     }
     if (which == 5 && single_reduction(p)) {      // (its head needs the u.w partials of a matvec on the CURRENT u: launched back to back it sees stale ones, breaks down and returns early)
@@ -2763,7 +2847,7 @@ int pgo_time_kernel(pgo_problem* p, int32_t which, int32_t launches, double* avg
                               if (fused) launch_cg_update_mg(G, p->C, p->M, p->mg_levels, p->K, kk, mf_grid_size(p->F), p->st);
                               else launch_cg_update(G, p->C, kk, mf_grid_size(p->F), p->st);
                           }
-                          launch_mg_apply(G, p->C, p->M, p->mg_levels, p->K, sr ? p->C.r : ((kk & 1) ? p->C.r : p->C.r2), p->C.z, p->C.part_rz + (size_t)((kk & 1) ^ 1) * RZ_STRIDE, mg_scale(p), true, p->st, which == 6 && fused, mg_cs(p));
+                          launch_mg_apply(G, p->C, p->M, p->mg_levels, p->K, sr ? p->C.r : ((kk & 1) ? p->C.r : p->C.r2), p->C.z, p->C.part_rz + (size_t)((kk & 1) ^ 1) * RZ_STRIDE, mg_scale(p), true, p->st, which == 6 && fused, mg_cs(p), mg_fine_view(p));
                           // Bytes of this design, each array once per kernel that streams it.  Fine level as in case 2 (+ the restriction's per-keyframe offsets and slot table,
                           // the prolongation's read-modify-write of z, offsets and aggregate index); every sparse coarse level: its fp32 blocks and column indices twice
                           // (down- and up-sweep), Dinv, positions/offsets and its four vectors; the dense level: the fp32 inverse once.

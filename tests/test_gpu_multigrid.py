@@ -138,6 +138,34 @@ def test_explicit_transfer_operator_is_the_same_cycle(shape):
         assert np.abs(t1 - to).max() <= 1e-3 and np.abs(s1 - so).max() <= 1e-3
 
 
+@pytest.mark.parametrize("shape", ["small_with_oracle", "fixed_keyframes", "default_20k", "multi_world_30k"])
+def test_smoothed_keyframe_transition_keeps_the_trajectory(shape):
+    """mg_smoothed_fine (round 6, experimental): the transition keyframes -> level 1 smoothed as well — Ps_0 = (I - w_p D^-1 A) P_0 formed from the keyframe level's own blocks,
+    level 1 = Ps_0^T A Ps_0, z = D^-1 r + s Ps_0 V_1(Ps_0^T r) inside the PCG.  Another preconditioner for the same systems: same LM trajectory as the default hierarchy (and as the
+    oracle where that is affordable), fewer multigrid iterations."""
+    oracle = False
+    free = None
+    if shape == "small_with_oracle":
+        g, kw, oracle = graphgen.generate(2500, 2500, odom_f_max=2, seed=17, outlier_frac=0.1), dict(mg_min_keyframes=1, mg_switch_iterations=0, mg_dense_max_nodes=24), True
+    elif shape == "fixed_keyframes":
+        g, kw = graphgen.generate(6000, 3000, odom_f_max=2, seed=5), dict(mg_min_keyframes=1, mg_switch_iterations=0, mg_dense_max_nodes=64)
+    elif shape == "default_20k":
+        g, kw = graphgen.generate(20000, 20000, odom_f_max=2, seed=3), dict(mg_switch_iterations=0)
+    else:
+        g, kw = graphgen.generate(30000, 6000, odom_f_max=5, apply_yaw_weight=True, n_worlds=3, seed=8), dict(mg_switch_iterations=0)
+    _, t0, s0, plain = run(g, True, mg_smoothed_fine=0, **kw)
+    _, t1, s1, smooth = run(g, True, mg_smoothed_fine=1, **kw)
+    same_trajectory(plain, smooth, 1e-7)
+    assert np.abs(t1 - t0).max() <= 1e-5 and np.abs(s1 - s0).max() <= 1e-5
+    print("multigrid iterations: default %d, smoothed keyframe transition %d" % (plain.cg_iterations_multigrid, smooth.cg_iterations_multigrid))
+    assert 0 < smooth.cg_iterations_multigrid <= 0.8 * plain.cg_iterations_multigrid
+    if oracle:
+        q, t, s = util.initial_state(g, True)
+        _, to, so, sumo = util.oracle_problem(g, True).solve(q, t, s)
+        same_trajectory(sumo, smooth, 1e-6)
+        assert np.abs(t1 - to).max() <= 1e-3 and np.abs(s1 - so).max() <= 1e-3
+
+
 def test_regroup_follows_the_switches_and_keeps_the_trajectory():
     """mg_regroup_fraction: once the solver has switched the outliers off, the levels above level 1 are matched again along the couplings that are alive (the keyframes'
     level-1 aggregates and level 1's structure are cached).  Same LM trajectory with and without (the preconditioner changes, the steps do not), and a second solve of
