@@ -2,7 +2,7 @@
   python scripts/dev/r05/opt_types.py "types,C4,C5" "" "mg_first_passes=2" ..."""
 import sys
 import time
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import numpy as np
 from solve_keyframe_pose_graph_amd import capi, graphgen
 from tests import util

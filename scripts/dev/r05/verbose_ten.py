@@ -1,5 +1,5 @@
 import sys
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 from solve_keyframe_pose_graph_amd import graphgen
 from tests import util
 name = sys.argv[1]

@@ -1,0 +1,14 @@
+#!/bin/bash
+# round-6 branch: first hardware run of the smoothed keyframe transition (mg_smoothed_fine).  Run from the repo root of the MAIN checkout through gpurun: the branch lives in build/r6.
+export TMPDIR=/tmp PGO_ENABLE_DEBUG_HOOKS=1
+OUT=$PWD/gpurun_out/r06_fine
+mkdir -p $OUT
+cd build/r6
+python -c "from solve_keyframe_pose_graph_amd import _build; _build.build_libpgo(); _build.build_host(); _build.build_graphgen()" > $OUT/build.log 2>&1
+PARTS=${1:-test,c3}
+if [[ $PARTS == *test* ]]; then timeout 900 python -m pytest tests/test_gpu_multigrid.py -q -m gpu -k "smoothed_keyframe" -s -p no:cacheprovider 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -40 > $OUT/test.txt; fi
+if [[ $PARTS == *c3* ]]; then timeout 600 python scripts/dev/r05/ab_options.py C3 20 2 "" "mg_smoothed_fine=1" > $OUT/ab_c3.txt 2>&1; fi
+if [[ $PARTS == *c4* ]]; then timeout 600 python scripts/dev/r05/ab_options.py C4 20 1 "" "mg_smoothed_fine=1" > $OUT/ab_c4.txt 2>&1; fi
+if [[ $PARTS == *verbose* ]]; then timeout 300 python scripts/dev/r05/verbose_ten.py C3 "mg_smoothed_fine=1,verbosity=2" > $OUT/verbose.txt 2>&1; fi
+if [[ $PARTS == *types* ]]; then timeout 900 python scripts/dev/r05/opt_types.py "types,C4" "" "mg_smoothed_fine=1" > $OUT/types.txt 2>&1; fi
+tail -30 $OUT/*.txt
