@@ -8,6 +8,7 @@ for item in (sys.argv[2].split(',') if len(sys.argv) > 2 and sys.argv[2] else []
     k, x = item.split('='); kw[k] = float(x) if ('.' in x or 'e' in x) else int(x)
 g = graphgen.config(name)
 q, t, s = util.initial_state(g, True)
-P = util.pgo_problem(g, True, max_num_iterations=10, verbosity=1, **kw)
+kw.setdefault('verbosity', 1)
+P = util.pgo_problem(g, True, max_num_iterations=10, **kw)
 _, _, _, sm = P.solve(q, t, s); P.close()
 print(name, kw, 'device s', sm.seconds_device, 'cg', sm.cg_iterations, 'mg', sm.cg_iterations_multigrid)
