@@ -11,4 +11,9 @@ if [[ $PARTS == *c3* ]]; then timeout 600 python scripts/dev/r05/ab_options.py C
 if [[ $PARTS == *c4* ]]; then timeout 600 python scripts/dev/r05/ab_options.py C4 20 1 "" "mg_smoothed_fine=1" > $OUT/ab_c4.txt 2>&1; fi
 if [[ $PARTS == *verbose* ]]; then timeout 300 python scripts/dev/r05/verbose_ten.py C3 "mg_smoothed_fine=1,verbosity=2" > $OUT/verbose.txt 2>&1; fi
 if [[ $PARTS == *types* ]]; then timeout 900 python scripts/dev/r05/opt_types.py "types,C4" "" "mg_smoothed_fine=1" > $OUT/types.txt 2>&1; fi
-tail -30 $OUT/*.txt
+if [[ $PARTS == *prof* ]]; then
+  rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python scripts/dev/r06/fine_iteration_profile.py "mg_smoothed_fine=1,verbosity=1" > $OUT/prof.log 2>&1
+  python scripts/rocpd_summary.py stats $(find $OUT/trace -name "*.db" | head -1) > $OUT/prof_kernel_stats.txt; rm -rf $OUT/trace
+  grep "multigrid:" $OUT/prof.log | head -3 >> $OUT/prof_kernel_stats.txt
+fi
+for f in $OUT/*.txt; do echo "== $f"; tail -n 30 $f; done
