@@ -8,6 +8,8 @@ python -c "from solve_keyframe_pose_graph_amd import _build; _build.build_libpgo
 PARTS=${1:-test,c3}
 if [[ $PARTS == *test* ]]; then timeout 900 python -m pytest tests/test_gpu_multigrid.py -q -m gpu -k "smoothed_keyframe" -s -p no:cacheprovider 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -40 > $OUT/test.txt; fi
 if [[ $PARTS == *c3* ]]; then timeout 600 python scripts/dev/r05/ab_options.py C3 20 2 "" "mg_smoothed_fine=1" > $OUT/ab_c3.txt 2>&1; fi
+if [[ $PARTS == *poison* ]]; then PGO_DEBUG_POISON=1 timeout 900 python -m pytest tests/test_gpu_multigrid.py -q -m gpu -k "smoothed_keyframe" -p no:cacheprovider 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -5 > $OUT/test_poison.txt; fi
+if [[ $PARTS == *variants* ]]; then timeout 600 python scripts/dev/r05/ab_options.py C3 20 1 "" "mg_smoothed_fine=1" "mg_smoothed_fine=1,mg_passes=3" "mg_smoothed_fine=1,mg_passes=1" > $OUT/ab_c3_variants.txt 2>&1; fi
 if [[ $PARTS == *c4* ]]; then timeout 600 python scripts/dev/r05/ab_options.py C4 20 1 "" "mg_smoothed_fine=1" > $OUT/ab_c4.txt 2>&1; fi
 if [[ $PARTS == *verbose* ]]; then timeout 300 python scripts/dev/r05/verbose_ten.py C3 "mg_smoothed_fine=1,verbosity=2" > $OUT/verbose.txt 2>&1; fi
 if [[ $PARTS == *types* ]]; then timeout 900 python scripts/dev/r05/opt_types.py "types,C4" "" "mg_smoothed_fine=1" > $OUT/types.txt 2>&1; fi
