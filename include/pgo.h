@@ -195,7 +195,10 @@ typedef struct pgo_options {
                                           *    of pauses), none elsewhere; 1: both at every LM system of graphs >= 20 000 keyframes / after the solve's first rejection (round 4's rule) */
     int32_t mg_smoothed_fine;            /* 0.  1: the transition keyframes -> level 1 is SMOOTHED as well (one GPU): Ps_0 = (I - w_p D^-1 A) P_0, level 1 = Ps_0^T A Ps_0 (one hop wider),
                                           *    inside the cycle z = D^-1 r + s Ps_0 V_1(Ps_0^T r) with Ps_0 as fp32 blocks in both orientations (two launches of their own per iteration
-                                          *    instead of riding in the vector update and level 1's up-sweep).  EXPERIMENTAL (round 6). */
+                                          *    instead of riding in the vector update and level 1's up-sweep).  EXPERIMENTAL, off: measured on C3 (profiles/r05_smoothed_fine_measured.txt) the
+                                          *    multigrid iterations halve (1 291 -> 612 over 20 LM steps, as the CPU probe predicted) but an iteration costs 258 instead of 122 us — on the real graph
+                                          *    level 1 comes out 2.4x and level 2 2.9x denser (77 784 -> 184 098 and 189 201 -> 549 975 blocks) — and the operators 6.7 instead of 2.6 ms per
+                                          *    system: 65.5 against 81.1 LM iterations/s. */
 } pgo_options;
 
 /* Per-iteration record; mirrors ceres::IterationSummary fields the BriefReport is built from. */

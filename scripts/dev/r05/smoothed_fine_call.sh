@@ -1,9 +1,8 @@
 #!/bin/bash
-# round-6 branch: first hardware run of the smoothed keyframe transition (mg_smoothed_fine).  Run from the repo root of the MAIN checkout through gpurun: the branch lives in build/r6.
+# Hardware runs of the smoothed keyframe transition (pgo_options::mg_smoothed_fine), through gpurun from the repo root: parts test,c3,poison,variants,c4,verbose,types,prof.
 export TMPDIR=/tmp PGO_ENABLE_DEBUG_HOOKS=1
-OUT=$PWD/gpurun_out/r06_fine
+OUT=$PWD/gpurun_out/r05_smoothed_fine
 mkdir -p $OUT
-cd build/r6
 python -c "from solve_keyframe_pose_graph_amd import _build; _build.build_libpgo(); _build.build_host(); _build.build_graphgen()" > $OUT/build.log 2>&1
 PARTS=${1:-test,c3}
 if [[ $PARTS == *test* ]]; then timeout 900 python -m pytest tests/test_gpu_multigrid.py -q -m gpu -k "smoothed_keyframe" -s -p no:cacheprovider 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -40 > $OUT/test.txt; fi
@@ -14,7 +13,7 @@ if [[ $PARTS == *c4* ]]; then timeout 600 python scripts/dev/r05/ab_options.py C
 if [[ $PARTS == *verbose* ]]; then timeout 300 python scripts/dev/r05/verbose_ten.py C3 "mg_smoothed_fine=1,verbosity=2" > $OUT/verbose.txt 2>&1; fi
 if [[ $PARTS == *types* ]]; then timeout 900 python scripts/dev/r05/opt_types.py "types,C4" "" "mg_smoothed_fine=1" > $OUT/types.txt 2>&1; fi
 if [[ $PARTS == *prof* ]]; then
-  rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python scripts/dev/r06/fine_iteration_profile.py "mg_smoothed_fine=1,verbosity=1" > $OUT/prof.log 2>&1
+  rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python scripts/dev/r05/smoothed_fine_iteration_profile.py "mg_smoothed_fine=1,verbosity=1" > $OUT/prof.log 2>&1
   python scripts/rocpd_summary.py stats $(find $OUT/trace -name "*.db" | head -1) > $OUT/prof_kernel_stats.txt; rm -rf $OUT/trace
   grep "multigrid:" $OUT/prof.log | head -3 >> $OUT/prof_kernel_stats.txt
 fi

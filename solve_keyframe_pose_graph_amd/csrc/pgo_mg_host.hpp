@@ -61,7 +61,7 @@ struct HostLevel {                       // level l >= 1
 
 struct Hierarchy {
     std::vector<HostLevel> L;            // L[0] = level 1
-    // SMOOTHED transition keyframes -> level 1 (round 6): F is the keyframe level as a block-CSR level of its own — rowptr / col = the solver's block pattern (diagonal block first,
+    // SMOOTHED transition keyframes -> level 1 (round 5, pgo_options::mg_smoothed_fine): F is the keyframe level as a block-CSR level of its own — rowptr / col = the solver's block pattern (diagonal block first,
     // then one block per incident edge; parallel edges repeat a column), parent = agg0 (-1: fixed keyframe, outside the system: its rows of Ps and W are empty) — with the
     // structures of Ps, W = A Ps and the explicit operator R^T; L[0]'s pattern is then that of Ps^T W and carries no contribution lists.
     bool fine_smoothed = false;

@@ -615,7 +615,7 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_sdown_kernel(MgLevelDev A, double
     }
 }
 
-// ---- smoothed transition keyframes -> level 1 (round 6) ----
+// ---- smoothed transition keyframes -> level 1 (round 5, experimental: pgo_options::mg_smoothed_fine) ----
 // The keyframe level as a block-CSR level F of its own (rowptr / col: one block per keyframe and per incident edge; g_ent[k] = the contribution block k IS: (index << 3) | kind as
 // in level 1's lists), so that the set-up kernels of a smoothed transition (mg_ps_kernel, mg_w_kernel, mg_psTw_kernel) form Ps_0 = (I - c Dinv A) P_0, W_0 = A Ps_0 and level 1 =
 // Ps_0^T W_0 exactly as they do one level up.  Inside the cycle the keyframe level stays matrix-free and additive:  z = D^-1 r + s Ps_0 V_1(Ps_0^T r)  — Ps_0 as fp32 blocks by
