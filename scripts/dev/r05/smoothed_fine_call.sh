@@ -17,4 +17,12 @@ if [[ $PARTS == *prof* ]]; then
   python scripts/rocpd_summary.py stats $(find $OUT/trace -name "*.db" | head -1) > $OUT/prof_kernel_stats.txt; rm -rf $OUT/trace
   grep "multigrid:" $OUT/prof.log | head -3 >> $OUT/prof_kernel_stats.txt
 fi
+if [[ $PARTS == *typeprof* ]]; then
+  for w in plain40k noout60k; do for o in "" "mg_smoothed_fine=1"; do
+    n=${w}_${o:+fine}; n=${n%_}
+    rocprofv3 --kernel-trace --stats -d $OUT/trace_$n -o t -- python scripts/dev/r05/smoothed_fine_type_profile.py $w "$o" > $OUT/typeprof_$n.log 2>&1
+    { echo "## $w  options: ${o:-defaults}"; grep "multigrid: [0-9]* keyframes" $OUT/typeprof_$n.log | head -1; tail -1 $OUT/typeprof_$n.log; python scripts/rocpd_summary.py stats $(find $OUT/trace_$n -name "*.db" | head -1) | head -16 | cut -c1-170; } >> $OUT/typeprof.txt
+    rm -rf $OUT/trace_$n
+  done; done
+fi
 for f in $OUT/*.txt; do echo "== $f"; tail -n 30 $f; done
