@@ -193,14 +193,12 @@ typedef struct pgo_options {
     int32_t cg_pause_always;             /* 0: both early-rejection pauses where a rejection is in the air (previous step rejected, or the last accepted step's relative decrease below 0.8), the
                                           *    first pause alone where the system is expensive (predicted block-Jacobi-equivalent iterations x keyframes >= 5.6e7: one wasted solve outweighs dozens
                                           *    of pauses), none elsewhere; 1: both at every LM system of graphs >= 20 000 keyframes / after the solve's first rejection (round 4's rule) */
-    int32_t mg_smoothed_fine;            /* -1 = by size: on for graphs of up to 30 000 keyframes on one GPU, off beyond; 0 off; 1 on.  The transition keyframes -> level 1 SMOOTHED as well:
-                                          *    Ps_0 = (I - w_p D^-1 A) P_0, level 1 = Ps_0^T A Ps_0 (one hop wider), inside the cycle z = D^-1 r + s Ps_0 V_1(Ps_0^T r) with Ps_0 as fp32 blocks in
-                                          *    both orientations (two launches of their own per iteration instead of riding in the vector update and level 1's up-sweep).  Halves the multigrid
-                                          *    iterations on every graph measured; what it costs depends on how dense it makes the levels (profiles/r05_smoothed_fine_measured.txt, one MI355X):
-                                          *    BASELINE config 2 (10 000 keyframes, 10 iterations) 0.107 -> 0.0705 s (+52 %), 12 000 / 20 000 / 30 000 keyframes +9 / +25 / +5 %, 60 000 keyframes
-                                          *    with <= 1 loop per keyframe +18..28 % — but 40 000 keyframes with plain loops -25 %, 50 000 with f = 1..5 odometry -37 %, C3 -20 % (multigrid
-                                          *    iterations 1 291 -> 612 over 20 LM steps, an iteration 258 instead of 122 us: level 1 comes out 2.4x, level 2 2.9x denser; operators 6.7 instead of
-                                          *    2.6 ms per system), C4 -43 %: beyond 30 000 keyframes it is a per-graph decision (a rule by the block count of the smoothed levels is the next step). */
+    int32_t mg_smoothed_fine;            /* 0.  1: the transition keyframes -> level 1 is SMOOTHED as well (one GPU): Ps_0 = (I - w_p D^-1 A) P_0, level 1 = Ps_0^T A Ps_0 (one hop wider),
+                                          *    inside the cycle z = D^-1 r + s Ps_0 V_1(Ps_0^T r) with Ps_0 as fp32 blocks in both orientations (two launches of their own per iteration
+                                          *    instead of riding in the vector update and level 1's up-sweep).  EXPERIMENTAL, off: measured on C3 (profiles/r05_smoothed_fine_measured.txt) the
+                                          *    multigrid iterations halve (1 291 -> 612 over 20 LM steps, as the CPU probe predicted) but an iteration costs 258 instead of 122 us — on the real graph
+                                          *    level 1 comes out 2.4x and level 2 2.9x denser (77 784 -> 184 098 and 189 201 -> 549 975 blocks) — and the operators 6.7 instead of 2.6 ms per
+                                          *    system: 65.5 against 81.1 LM iterations/s. */
 } pgo_options;
 
 /* Per-iteration record; mirrors ceres::IterationSummary fields the BriefReport is built from. */

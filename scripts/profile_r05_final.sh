@@ -17,10 +17,8 @@ if [[ $PARTS == *gate* ]]; then
   {
     echo "## python -m pytest tests/ -x -q -m gpu      (the driver's command)"
     timeout 1500 python -m pytest tests/ -x -q -m gpu -p no:cacheprovider 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -6
-    if [[ $PARTS == *nopoison* ]]; then echo "## (the NaN-poisoned run of the whole suite was NOT repeated on this build: GPU budget; last full poisoned run: the previous build, see DESIGN.md)"; else
     echo "## PGO_DEBUG_POISON=1 python -m pytest tests/ -q -m gpu      (every new device allocation NaN-filled)"
     PGO_DEBUG_POISON=1 timeout 1500 python -m pytest tests/ -q -m gpu -p no:cacheprovider 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -6
-    fi
     echo "## python -m pytest tests -m gpu --collect-only -q | head -12      (oracle anchors of C1..C5 first)"
     python -m pytest tests -m gpu --collect-only -q -p no:cacheprovider 2>/dev/null | head -12
   } > $OUT/r05_gate.txt 2>&1
@@ -72,7 +70,6 @@ python scripts/gpu_all_configs.py > $OUT/r05_all_configs.txt 2>&1; stamp $OUT/r0
 python scripts/gpu_mg_graph_types.py 20 > $OUT/r05_mg_graph_types.txt 2>&1; stamp $OUT/r05_mg_graph_types.txt
 python scripts/gpu_session_replay.py 3000 600 100 2 > $OUT/r05_session_replay_2deg.jsonl 2> $OUT/replay.err
 python scripts/research/session_step_times.py 400,1000,3000 2>&1 | grep -v "^\[pgo\]" > $OUT/r05_session_step_times.txt; stamp $OUT/r05_session_step_times.txt
-if [[ $PARTS == *slim* ]]; then python scripts/pmc_r05_summary.py $OUT > $OUT/pmc_summary.log 2>&1; ls -la $OUT; exit 0; fi      # (slim: without the multi-rank and C5 legs, whose paths a change of single-GPU defaults at small sizes does not touch)
 python scripts/gpu_multi_overhead.py > $OUT/multi_overhead.log 2>&1
 python scripts/gpu_multi_overhead.py mg > $OUT/multi_overhead_mg.log 2>&1
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 10 --warmup 2 --collective gloo > $OUT/r05_bench_gloo2.json 2> $OUT/bench_gloo2.err

@@ -344,9 +344,7 @@ int mg_prepare_impl(pgo_problem* p, const double* sw_now, MgPrepared& Q) {
     std::vector<int32_t>& agg0_l = Q.agg0_l; std::vector<int32_t>& mem0_ptr_l = Q.mem0_ptr_l; std::vector<int32_t>& mem0_l = Q.mem0_l;
     std::vector<double>& inv_cnt = Q.inv_cnt;
     std::vector<int64_t> fine_rowptr, fine_ent; std::vector<int32_t> fine_col;
-    // smoothed keyframe transition: 1 = on, 0 = off, < 0 = by size — on up to SMOOTHED_FINE_MAX_KEYFRAMES keyframes, where the denser levels it makes are still latency-sized (one GPU only)
-    constexpr int64_t SMOOTHED_FINE_MAX_KEYFRAMES = 30000;
-    const bool want_fine = !p->local_ids && (p->opt.mg_smoothed_fine > 0 || (p->opt.mg_smoothed_fine < 0 && Ng <= SMOOTHED_FINE_MAX_KEYFRAMES));
+    const bool want_fine = p->opt.mg_smoothed_fine != 0 && !p->local_ids;
     if (want_fine) {
         // the keyframe level's block pattern: row i = block (i, i), then one block per incident edge (relative-pose edges first, each class in edge order), and what each block IS for
         // fine_block_value (kind 0: the keyframe's reduced diagonal block; 1 / 2: a relative-pose edge seen from its first / second keyframe; 3 / 4: a switchable edge)
@@ -2260,7 +2258,7 @@ void pgo_options_init(pgo_options* o) {
     o->verbosity = 0;
     o->cg_single_reduction = 1;
     o->cg_pause_always = 0;
-    o->mg_smoothed_fine = -1;
+    o->mg_smoothed_fine = 0;
     o->mg_explicit_transfer = 1;
     o->cg_end_game = 1;
 }
