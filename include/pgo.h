@@ -199,6 +199,11 @@ typedef struct pgo_options {
                                           *    multigrid iterations halve (1 291 -> 612 over 20 LM steps, as the CPU probe predicted) but an iteration costs 258 instead of 122 us — on the real graph
                                           *    level 1 comes out 2.4x and level 2 2.9x denser (77 784 -> 184 098 and 189 201 -> 549 975 blocks) — and the operators 6.7 instead of 2.6 ms per
                                           *    system: 65.5 against 81.1 LM iterations/s. */
+    /* round 6 (appended) */
+    int32_t mg_dist_min_rows;            /* 8192.  Several ranks: a multigrid level with at least this many rows is DISTRIBUTED — every rank runs the cycle's kernels on the rows it owns and
+                                          *    receives the rows of other ranks its kernels read by neighbour send/receive; a smaller level is run completely by every rank from gathered vectors
+                                          *    (a level kernel stays at its 8-10 us latency floor up to ~10 000 rows, so distributing a smaller level buys no kernel time and costs two exchanges).  The hierarchy is the same on every rank, its aggregates never mix owners. */
+    int32_t reserved_r6_;
 } pgo_options;
 
 /* Per-iteration record; mirrors ceres::IterationSummary fields the BriefReport is built from. */
@@ -395,12 +400,20 @@ int pgo_apply_normal_operator(pgo_problem* p, const double* x, double* y);
  * `spatial`) to keep the shared set small.  The contract on every rank: the same n_nodes / n_switch,
  * the same initial arrays, the same constant keyframes, every switch index on exactly one rank; a
  * rank without edges is fine.  pgo_solve returns the COMPLETE solution on every rank (each
- * keyframe from its owner, each switch from the rank holding its edge).  Calls that issue
+ * keyframe from its owner, each switch from the rank holding its edge).  At most 52 ranks.  Calls that issue
  * collectives (solve*, evaluate, get_normal_blocks, apply_normal_operator, time_kernel) must be
  * made by all ranks in the same order. */
 int pgo_comm_get_unique_id(uint8_t id[PGO_COMM_ID_BYTES]);
 int pgo_comm_init(pgo_problem* p, int32_t rank, int32_t world_size, const uint8_t id[PGO_COMM_ID_BYTES]);
 int pgo_comm_destroy(pgo_problem* p);
+
+/* What travels (round 6).  Every data-path exchange is a NEIGHBOUR exchange: a rank sends another rank exactly the rows that one reads and does not own —
+ *   per CG iteration   the partial rows of w = A u of the keyframes two ranks share, to the ranks sharing them (ncclSend / ncclRecv in one group), the parts summed in
+ *                      ascending rank order on every rank (same bits everywhere), plus ONE all-reduce of the iteration's two dot products (2 doubles);
+ *   per multigrid cycle  the halo rows of the level vectors: the hierarchy's aggregates never mix owners, every level is numbered owner-major, and a rank runs the level
+ *                      kernels on its own rows only (pgo_options.mg_dist_min_rows; smaller levels are run completely by every rank from gathered vectors);
+ *   per linearisation / LM system  diagonal blocks, gradient, reduced diagonal and right-hand side of the shared keyframes, the same way.
+ * The multigrid's SET-UP (Galerkin products, dense inverse) is still formed by every rank for all levels (level 1 through one all-reduce of its blocks per LM system). */
 
 /* Bring-your-own collective (e.g. torch.distributed, MPI, or an in-process test harness): `fn` must all-reduce `count` doubles in
  * DEVICE memory in place across the `world_size` ranks (op 0 = sum, 2 = max; work enqueued before the call on `hip_stream` must be
@@ -408,6 +421,42 @@ int pgo_comm_destroy(pgo_problem* p);
  * communicator of pgo_comm_init; same sharding contract. */
 typedef int (*pgo_allreduce_fn)(void* ctx, double* device_buf, int64_t count, int32_t op, void* hip_stream);
 int pgo_comm_init_custom(pgo_problem* p, int32_t rank, int32_t world_size, pgo_allreduce_fn fn, void* ctx);
+/* ... and its neighbour exchange (optional; without it the library emulates the exchange through `fn`: an all-reduce of a zero-padded buffer holding every pair's segment —
+ * correct, but it moves world x the bytes).  `fn` must deliver, for every peer q, the doubles send_buf[send_off[q] .. send_off[q+1]) of this rank to
+ * recv_buf[recv_off[r] .. recv_off[r+1]) of rank q's call (r = this rank) — MPI_Alltoallv in doubles on DEVICE buffers, offsets as HOST arrays of world_size + 1 entries,
+ * same stream contract as pgo_allreduce_fn.  The segment sizes agree on both sides by construction. */
+typedef int (*pgo_exchange_fn)(void* ctx, const double* send_buf, const int64_t* send_off, double* recv_buf, const int64_t* recv_off, void* hip_stream);
+int pgo_comm_set_exchange(pgo_problem* p, pgo_exchange_fn fn);
+
+/* In-process communicator: the ranks are `world_size` handles of ONE process, each driven by its own thread (on one GPU, or on several GPUs of one node with peer access).
+ * A collective is then a kernel that reads the peers' device buffers directly, ordered by events between the handles' streams — no host staging, no RCCL.  Create one group,
+ * hand it to every rank's pgo_comm_init_local, destroy it after the last pgo_comm_destroy.  Same sharding contract; at most 16 ranks.  Every rank must make the same
+ * collective-issuing calls in the same order, each from its own thread (a rank blocks at a host barrier until all have arrived). */
+int pgo_local_group_create(int32_t world_size, void** group);
+int pgo_local_group_abort(void* group);      /* a rank failed outside the library: releases the ranks waiting at a barrier (their calls return PGO_ERR_COMM) */
+int pgo_local_group_destroy(void* group);
+int pgo_comm_init_local(pgo_problem* p, int32_t rank, int32_t world_size, void* group);
+
+/* What the rank-local handle looks like and what its exchanges moved (several ranks; zeros on one GPU).  Counters are reset by pgo_solve_begin. */
+typedef struct pgo_sharding_stats {
+    int32_t world, rank;
+    int64_t keyframes_local, keyframes_owned, keyframes_shared;      /* keyframes the rank's edges touch; of them owned; of them touched by other ranks too */
+    int64_t shared_global;                                           /* keyframes touched by >= 2 ranks, over all ranks (rows of round 5's union all-reduce) */
+    int32_t mg_levels, mg_levels_distributed;                        /* sparse + dense levels of the hierarchy; sparse levels whose kernels run on the owner's rows only */
+    int64_t mg_rows_total, mg_rows_own;                              /* rows of all sparse levels; rows this rank's level kernels work on (its own on distributed levels, all on the others) */
+    int64_t mg_blocks_total, mg_blocks_own;                          /* the same in 6x6 blocks of the level matrices (+ transfer operators): what the level kernels stream */
+    int64_t pcg_iterations;                                          /* PCG iterations of this solve so far */
+    int64_t exchanges;                                               /* neighbour exchanges issued */
+    int64_t allreduces;                                              /* all-reduces issued (any size) */
+    double bytes_sent_neighbour;                                     /* payload this rank sent in neighbour exchanges */
+    double bytes_allreduce;                                          /* payload of its all-reduces (buffer sizes) */
+    double bytes_sent_per_mg_iteration;                              /* by the plans: rows this rank sends in ONE multigrid-preconditioned PCG iteration x 48 B (+ 16 B of scalars) */
+    double bytes_sent_per_bj_iteration;                              /* ... in one block-Jacobi iteration */
+    double bytes_round5_per_mg_iteration;                            /* what round 5's design all-reduced per multigrid iteration on the same graph: (6 shared_global + 2 + 6 n_1) x 8 B */
+    double bytes_round5_per_bj_iteration;                            /* (6 shared_global + 2) x 8 B */
+    int32_t exchanges_per_mg_iteration, exchanges_per_bj_iteration;  /* neighbour exchanges on the critical path of one iteration */
+} pgo_sharding_stats;
+int pgo_get_sharding_stats(pgo_problem* p, pgo_sharding_stats* out);
 
 /* ------------------------------------------------------------------------------------------ */
 /* graph construction on the device from the raw VIO poses                   */
@@ -467,7 +516,8 @@ int pgo_time_linearize_kernel(pgo_problem* p, int32_t launches, double* avg_ms, 
 
 /* Same for one PCG iteration (K3+K4) and the assembly (K2). which: 0 = K1, 1 = K2, 2 = one block-Jacobi PCG iteration (matvec + update),
  * 3 = K1 cost-only, 4 = the matvec of the iteration alone, 5 = its vector update alone, 6 = one MULTIGRID-preconditioned PCG iteration (matvec + update with
- * the restriction + every level kernel; graphs with a hierarchy only), 7 = its level kernels alone.  algorithmic_bytes of 2/4/5/6/7: what THIS design moves
+ * the restriction + every level kernel; graphs with a hierarchy only), 7 = its level kernels alone (several ranks: THIS rank's share of them, without the exchanges —
+ * what the rank's GPU computes per cycle; call it rank by rank).  algorithmic_bytes of 2/4/5/6/7: what THIS design moves
  * per iteration with every array counted once (matrix-free: compact edge-side records + index data + vectors + the fp32 block-Jacobi
  * factors; block-CSR: SURVEY.md 8d's assembled form). */
 int pgo_time_kernel(pgo_problem* p, int32_t which, int32_t launches, double* avg_ms, double* algorithmic_bytes);

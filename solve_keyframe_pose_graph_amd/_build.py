@@ -11,7 +11,7 @@ LIBPGO = os.path.join(_HERE, "libpgo.so")
 LIBGEN = os.path.join(_HERE, "libpgo_graphgen.so")
 
 HIP_SOURCES = ["pgo_kernels.hip", "pgo_solver.hip"]
-HIP_HEADERS = ["pgo_internal.hpp", "pgo_device_math.hpp", "pgo_mg_kernels.hpp", "pgo_mg_host.hpp"]
+HIP_HEADERS = ["pgo_internal.hpp", "pgo_device_math.hpp", "pgo_mg_kernels.hpp", "pgo_mg_host.hpp", "pgo_comm_local.hpp"]
 
 
 def _stale(target, deps):

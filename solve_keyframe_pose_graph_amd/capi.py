@@ -28,7 +28,8 @@ class Options(C.Structure):
                 ("cg_warm_start", C.c_int32), ("cg_use_graph", C.c_int32), ("cg_early_tolerance", C.c_double), ("cg_early_reject_rho", C.c_double), ("cg_mid_tolerance", C.c_double), ("cg_mid_reject_rho", C.c_double), ("coarse_aggregates", C.c_int32), ("mg_min_keyframes", C.c_int32), ("coarse_min_radius", C.c_double),
                 ("mg_omega", C.c_double), ("mg_correction_scale", C.c_double), ("mg_first_passes", C.c_int32), ("mg_passes", C.c_int32), ("mg_dense_max_nodes", C.c_int32), ("mg_switch_iterations", C.c_int32),
                 ("mg_loop_discount", C.c_double), ("mg_regroup_fraction", C.c_double), ("mg_prolongation_damping", C.c_double), ("mg_smoothed_levels", C.c_int32), ("mg_min_keyframes_switchable", C.c_int32),
-                ("device_id", C.c_int32), ("verbosity", C.c_int32), ("cg_single_reduction", C.c_int32), ("mg_explicit_transfer", C.c_int32), ("cg_end_game", C.c_int32), ("cg_pause_always", C.c_int32), ("mg_smoothed_fine", C.c_int32)]
+                ("device_id", C.c_int32), ("verbosity", C.c_int32), ("cg_single_reduction", C.c_int32), ("mg_explicit_transfer", C.c_int32), ("cg_end_game", C.c_int32), ("cg_pause_always", C.c_int32), ("mg_smoothed_fine", C.c_int32),
+                ("mg_dist_min_rows", C.c_int32), ("reserved_r6_", C.c_int32)]
 
 
 class Iteration(C.Structure):
@@ -53,6 +54,18 @@ class Summary(C.Structure):
                 ("iterations", Iteration * PGO_MAX_ITERATION_LOG), ("message", C.c_char * 256), ("cg_iterations_multigrid", C.c_int64), ("pcg_retries", C.c_int32), ("reserved2_", C.c_int32)]
 
 
+class ShardingStats(C.Structure):
+    """pgo_sharding_stats (include/pgo.h): the rank-local handle and what its exchanges moved"""
+    _fields_ = [("world", C.c_int32), ("rank", C.c_int32), ("keyframes_local", C.c_int64), ("keyframes_owned", C.c_int64), ("keyframes_shared", C.c_int64), ("shared_global", C.c_int64),
+                ("mg_levels", C.c_int32), ("mg_levels_distributed", C.c_int32), ("mg_rows_total", C.c_int64), ("mg_rows_own", C.c_int64), ("mg_blocks_total", C.c_int64), ("mg_blocks_own", C.c_int64),
+                ("pcg_iterations", C.c_int64), ("exchanges", C.c_int64), ("allreduces", C.c_int64), ("bytes_sent_neighbour", C.c_double), ("bytes_allreduce", C.c_double),
+                ("bytes_sent_per_mg_iteration", C.c_double), ("bytes_sent_per_bj_iteration", C.c_double), ("bytes_round5_per_mg_iteration", C.c_double), ("bytes_round5_per_bj_iteration", C.c_double),
+                ("exchanges_per_mg_iteration", C.c_int32), ("exchanges_per_bj_iteration", C.c_int32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
 # every symbol include/pgo.h declares (checked by tests/test_capi_symbols.py against the header text)
 EXPORTS = [
     "pgo_abi_sizeof", "pgo_options_init", "pgo_create", "pgo_destroy", "pgo_set_options", "pgo_reserve",
@@ -61,7 +74,8 @@ EXPORTS = [
     "pgo_set_vio_poses", "pgo_num_vio_poses", "pgo_add_odometry_edges_from_vio", "pgo_initial_guess_from_vio", "pgo_get_relpose_edge_records",
     "pgo_solve", "pgo_solve_begin", "pgo_lm_step", "pgo_solve_end", "pgo_evaluate",
     "pgo_get_jacobian_blocks", "pgo_get_normal_blocks", "pgo_apply_normal_operator", "pgo_manifold_plus",
-    "pgo_comm_get_unique_id", "pgo_comm_init", "pgo_comm_destroy", "pgo_comm_init_custom", "pgo_partition_edges",
+    "pgo_comm_get_unique_id", "pgo_comm_init", "pgo_comm_destroy", "pgo_comm_init_custom", "pgo_comm_set_exchange", "pgo_local_group_create", "pgo_local_group_abort", "pgo_local_group_destroy", "pgo_comm_init_local",
+    "pgo_get_sharding_stats", "pgo_partition_edges",
     "pgo_time_linearize_kernel", "pgo_time_kernel", "pgo_time_vio_odometry_kernel", "pgo_dense_spd_inverse", "pgo_device_synchronize", "pgo_strerror", "pgo_last_error", "pgo_build_info",
 ]
 
@@ -344,10 +358,51 @@ class Problem:
                 traceback.print_exc()
                 return 1
         self._custom_cb = CB(tramp)   # keep alive
+        self._world = world_size
         self._check(self.lib.pgo_comm_init_custom(self.h, C.c_int32(rank), C.c_int32(world_size), self._custom_cb, None))
+
+    def comm_set_exchange(self, fn):
+        """fn(send_ptr:int, send_off:list, recv_ptr:int, recv_off:list, stream:int) -> 0: the neighbour exchange of a caller-supplied collective (MPI_Alltoallv in doubles on device buffers)."""
+        CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_int64), C.c_void_p)
+        world = self._world
+
+        def tramp(ctx, sbuf, soff, rbuf, roff, stream):
+            try:
+                return int(fn(sbuf, [soff[i] for i in range(world + 1)], rbuf, [roff[i] for i in range(world + 1)], stream))
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._custom_xcb = CB(tramp)
+        self._check(self.lib.pgo_comm_set_exchange(self.h, self._custom_xcb))
+
+    def comm_init_local(self, rank, world_size, group):
+        """in-process communicator: `group` from local_group_create(world_size); every rank from its own thread"""
+        self._check(self.lib.pgo_comm_init_local(self.h, C.c_int32(rank), C.c_int32(world_size), group))
+
+    def sharding_stats(self):
+        st = ShardingStats()
+        self._check(self.lib.pgo_get_sharding_stats(self.h, C.byref(st)))
+        return st
 
     def comm_destroy(self):
         self._check(self.lib.pgo_comm_destroy(self.h))
+
+
+def local_group_create(world_size):
+    g = C.c_void_p()
+    rc = load().pgo_local_group_create(C.c_int32(world_size), C.byref(g))
+    if rc != 0:
+        raise PgoError(rc, load().pgo_strerror(rc).decode())
+    return g
+
+
+def local_group_abort(group):
+    load().pgo_local_group_abort(group)
+
+
+def local_group_destroy(group):
+    load().pgo_local_group_destroy(group)
 
 
 PARTITION = {"contiguous": 0, "chain": 1, "spatial": 2}

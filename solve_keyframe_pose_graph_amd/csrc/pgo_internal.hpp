@@ -164,6 +164,10 @@ struct MgLevelDev {
     float* rt_valf; float* r_valf;
     const int2* rt_rows; const int2* rT_rows; const int32_t* rT_col; const int32_t* rT_of_w; const int32_t* ps_of_w;
     int32_t rT_tiles, rT_seg_shift;
+    // several ranks, distributed cycle (round 6): the CYCLE's kernels run on this rank's share of the level — its tiles [tile0, tile0 + tiles_own) and, for the restriction half of
+    // mg_sdown_kernel, the coarse rows [rT_row0, rT_row1) (rT_rows / rT_tiles describe THAT range) — from vectors whose other entries the exchanges have brought in.  One GPU, and
+    // levels every rank runs completely: tile0 = 0, tiles_own = tiles, rT_row0 = 0, rT_row1 = n_next.  The set-up kernels always work on the whole level.
+    int32_t tile0, tiles_own, rT_row0, rT_row1;
 };
 struct MgDev {
     int32_t n_levels;                    // levels 1..n_levels; the last one is dense (CoarseDev: Ac, rc = its residual, yc = its solution)
@@ -174,9 +178,9 @@ struct MgDev {
     // restriction inside the PCG's vector update: per run of MG_BLOCK0 consecutive keyframes (one workgroup trip of cg_update) the level-1 aggregates it holds,
     // MG_BLOCK0 slots of {aggregate or -1, 8 member keyframes as run-local bytes (0xff: none)} — aggregates never cross a run boundary (pgo_mg_host.hpp)
     const int4* blk_tab;                 // [runs][MG_BLOCK0] {aggregate, members 0-3, members 4-7, unused}; null: restriction by its own kernel
-    // several ranks (edge sharding): the keyframe arrays above are the rank's LOCAL keyframes, the level-1 ids GLOBAL (levels 1.. are replicated on every rank)
+    // several ranks (edge sharding): the keyframe arrays above are the rank's LOCAL keyframes, the level-1 ids GLOBAL (the hierarchy is the same on every rank)
     const double* inv_cnt;               // [n1] 1 / (members of the level-1 node over all ranks); null on one GPU
-    double* q1; double* s1;              // [n1][6] level-1 companions of the Chronopoulos-Gear recurrence: q1 = P0^T (A u) as exchanged, s1 = P0^T s
+    int32_t a0, a1;                      // the level-1 aggregates this rank restricts to (its own: all their keyframes are local); one GPU: [0, n1)
 };
 constexpr int MG_BLOCK0 = 64;
 
@@ -229,9 +233,16 @@ void launch_manifold_plus(int64_t n, const double* quat, const double* t, const 
 void launch_pack_pose(const double* quat, const double* t, double* pose8, int64_t N, hipStream_t st);
 void launch_unpack_pose(const double* pose8, double* quat, double* t, int64_t N, hipStream_t st);
 void launch_unpack_k1(const GraphDev& G, int kind, int64_t first, int64_t count, double* r, double* J1, double* J2, double* Js, hipStream_t st);
-// multi-GPU exchange of the keyframes shared between ranks: buf[pos[j]*K + off + c] <-> src[loc[j]*k + c], c < k
-void launch_pack_rows(double* buf, int K, int off, const double* src, int k, int64_t n, const int32_t* loc, const int32_t* pos, hipStream_t st);
-void launch_unpack_rows(const double* buf, int K, int off, double* dst, int k, int64_t n, const int32_t* loc, const int32_t* pos, const int32_t* stop /*nullable device flag: skip when set*/, hipStream_t st);
+// neighbour exchanges (round 6).  Gather: buf[j][K] <- (a1[idx[j]][k1], a2[idx[j]][k2]) for the rows listed; scatter: the reverse; sum: for every shared keyframe the parts of
+// its row in ascending rank order (src -1: the rank's own row in a1 / a2, else row `src` of the receive buffer) — the same bits on every rank.  `stop`: skip when the flag is set.
+void launch_gather_rows(double* buf, const double* a1, int k1, const double* a2, int k2, int64_t n, const int32_t* idx, const int32_t* stop, hipStream_t st);
+void launch_scatter_rows(const double* buf, double* a1, int k1, double* a2, int k2, int64_t n, const int32_t* idx, const int32_t* stop, hipStream_t st);
+void launch_scatter_rows_dinv(const double* buf, double* r, double* x, const double* Dinv, int64_t n, const int32_t* idx, const int32_t* stop, hipStream_t st);      // r rows in, x = Dinv r formed on the spot
+void launch_sum_rows(const double* buf, double* a1, int k1, double* a2, int k2, int64_t n_sh, const int32_t* sh_loc, const int32_t* sum_ptr, const int32_t* sum_src, const int32_t* stop, hipStream_t st);
+// in-process communicator (pgo_comm_init_local): out[i] = sum / max over the ranks' staged buffers in rank order; peers' segments copied into the receive buffer
+struct LocalPeers { const double* src[16]; int64_t off[16]; int64_t cnt[16]; int n; };      // off: destination offset (copy) — unused by the reduction
+void launch_local_reduce(double* out, const LocalPeers& P, int64_t n, int op, hipStream_t st);
+void launch_local_copy(double* recv, const LocalPeers& P, hipStream_t st);
 // two-level preconditioner (CoarseDev)
 void launch_coarse_geometry(const GraphDev& G, const CoarseDev& K, const double* pose8, hipStream_t st);       // centroids + d
 void launch_coarse_assemble(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, const CoarseDev& K, hipStream_t st);   // Ac = P^T A P (deterministic)
@@ -252,8 +263,6 @@ void launch_coarse_solve_dot(const CoarseDev& K, const int32_t* stop, double* pa
 void launch_cgcg_dots(const GraphDev& G, const CgDev& C, hipStream_t st);                                     // part_pq[block] = partial of u.w
 void launch_cg_reduce2_live(const CgDev& C, const double* pa, int na, const double* pb, int nb, double* out, hipStream_t st);
 void launch_cgcg_update(const GraphDev& G, const CgDev& C, int k, int first, hipStream_t st, const double* xq = nullptr, const int32_t* sh_of = nullptr, const double* two = nullptr);
-// the iteration's exchange buffer in one kernel: [rows of w of the global shared list (zeros where this rank does not touch the keyframe) | sum pa | sum pb]
-void launch_cgcg_pack(const CgDev& C, const int32_t* sh_src, int64_t n_sh, const double* w, double* buf, const double* pa, int na, const double* pb, int nb, hipStream_t st);
 void launch_cgcg_scalars_init(const CgDev& C, const double* bb_src, double tol2, hipStream_t st);
 // write-back: owned keyframes of the rank-local (quat[n][4], t[n][3]) into zero-initialised global arrays
 void launch_scatter_owned_pose(const double* quat, const double* t, int64_t n, const int32_t* l2g, const double* own, double* gquat, double* gt, hipStream_t st);
@@ -275,14 +284,15 @@ void launch_k2_offdiag(const GraphDev& G, const LinDev& L, hipStream_t st);
 void launch_mg_assemble_fine(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, const MgLevelDev& F, const MgLevelDev& T, const MgLevelDev& L1, double omega, int32_t* fail, hipStream_t st,
                              double prolong_scale, bool hoff_valid);      // level 1 = Ps_0^T A Ps_0 (smoothed keyframe transition), then launch_mg_assemble_rest
 void launch_mg_assemble_rest(const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, double omega, int32_t* fail, hipStream_t st, double prolong_scale = 0.0 /* c = w_p / w of the smoothed transitions */);
-// out[n1][6] = P0^T v over the handle's keyframes (own_weighted: every keyframe counted by its owner only — several ranks)
-void launch_mg_restrict0(const GraphDev& G, const MgDev& M, const double* v, double* out, bool own_weighted, hipStream_t st);
-// several ranks: level-1 residual by the PCG's recurrence (mode 0: s1 = q1 + beta s1, r1 -= alpha s1 with the scalars cgcg_update left; mode 1, PCG start: s1 = 0) and x1 = w D1^-1 r1
-void launch_mg_level1_update(const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, int k, int first, int mode, hipStream_t st);
+// Several ranks: the cycle is cut into segments by the exchanges its kernels need (pgo_solver.hip issues them); launch_mg_apply calls the hook BEFORE the kernel that reads the
+// exchanged vectors.  point: 0 = down-sweep of `level` (1-based; n_levels = the dense solve) is about to read x (and r) of that level, 1 = the up-sweep of `level` is about to
+// read xt of that level (plain transition) or xf of level + 1 (explicit transfer operator), 2 = the prolongation to the keyframes is about to read xf of level 1.
+struct MgExchangeHook { void* ctx; int (*fn)(void* ctx, int point, int level); };
 // z += scale P V(P^T r) (every coarse correction inside V scaled alike), r.z partials updated in place (cg_update's workgroup -> slot mapping)
 void launch_mg_apply(const GraphDev& G, const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, const double* r, double* z, double* part_rz, double scale, bool inside_iteration, hipStream_t st,
                      bool restricted = false /* r_1 (and x_1) already formed by launch_cg_update_mg */, double prolong_scale = 0.0 /* c of the smoothed transitions */,
-                     const MgLevelDev* fine = nullptr /* smoothed keyframe transition: the keyframe level's transfer view (r_1 = Ps_0^T r and z += s Ps_0 x_1 by kernels of their own) */);
+                     const MgLevelDev* fine = nullptr /* smoothed keyframe transition: the keyframe level's transfer view (r_1 = Ps_0^T r and z += s Ps_0 x_1 by kernels of their own) */,
+                     const MgExchangeHook* hook = nullptr /* several ranks: called where the cycle needs rows of other ranks */, int* hook_rc = nullptr);
 // cg_update + r_1 = P_0^T r', x_1 = w D_1^-1 r_1 of the multigrid (M.blk_tab)
 void launch_cg_update_mg(const GraphDev& G, const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, int k, int n_pq_partials, hipStream_t st);
 void launch_cg_update_mg_sr(const GraphDev& G, const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, int k, int first, int n_pq_partials, hipStream_t st);      // single-reduction form (cg_update_kernel<true>) with the same restriction

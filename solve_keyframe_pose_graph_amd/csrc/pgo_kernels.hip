@@ -7,6 +7,8 @@
 //   K3  cg_spmv_kernel         block-CSR (6x6) SpMV of the Schur-reduced damped normal matrix
 //   K4  cg_update/direction    fused PCG vector updates, block-Jacobi apply and dot products
 //   K5  plus_kernel            manifold Plus + step norms; k1 (J = false) evaluates the candidate cost
+#include <algorithm>
+
 #include "pgo_internal.hpp"
 
 namespace pgo {
@@ -1135,27 +1137,6 @@ __global__ void cg_reduce2_live_kernel(CgDev C, const double* __restrict__ pa, i
     if (!stopped) block_total2(pa, na, pb, nb, red, a, b);
     if (threadIdx.x == 0) { out[0] = a; out[1] = b; }
 }
-// Packs the iteration's exchange buffer in ONE kernel (no memset, no copies): workgroup 0 reduces the two dot products' partial sums into buf[6 n_sh], buf[6 n_sh + 1]
-// (zeros once the PCG has stopped); the others write, for every keyframe of the GLOBAL shared list, this rank's row of w = A_r u or zeros when it does not touch the keyframe.
-__global__ __launch_bounds__(256) void cgcg_pack_kernel(CgDev C, const int32_t* __restrict__ sh_src, int64_t n_sh, const double* __restrict__ w, double* __restrict__ buf,
-                                                         const double* __restrict__ pa, int na, const double* __restrict__ pb, int nb) {
-    if (blockIdx.x == 0) {
-        __shared__ double red[8];
-        const bool stopped = C.flags[0] != 0;
-        double a = 0.0, b = 0.0;
-        if (!stopped) block_total2(pa, na, pb, nb, red, a, b);
-        if (threadIdx.x == 0) { buf[n_sh * 6] = a; buf[n_sh * 6 + 1] = b; }
-        return;
-    }
-    const int64_t i = (int64_t)(blockIdx.x - 1) * blockDim.x + threadIdx.x;
-    if (i >= n_sh * 6) return;
-    const int64_t j = i / 6; const int c = (int)(i - j * 6);
-    const int32_t src = sh_src[j];
-    buf[i] = src >= 0 ? w[(size_t)src * 6 + c] : 0.0;
-}
-void launch_cgcg_pack(const CgDev& C, const int32_t* sh_src, int64_t n_sh, const double* w, double* buf, const double* pa, int na, const double* pb, int nb, hipStream_t st) {
-    hipLaunchKernelGGL(cgcg_pack_kernel, dim3((unsigned)((n_sh * 6 + 255) / 256 + 1)), dim3(256), 0, st, C, sh_src, n_sh, w, buf, pa, na, pb, nb);
-}
 // xq / sh_of / two (fused exchange): the summed rows of w for shared keyframes are read straight from the exchange buffer (sh_of[keyframe] = its position there, or -1)
 // and [delta, gamma] from its tail — no unpack kernel, no copies; null: w complete in C.q, scalars in C.scal[12..13]
 __global__ __launch_bounds__(CG_BLOCK) void cgcg_update_kernel(GraphDev G, CgDev C, int parity, int first, const double* __restrict__ xq = nullptr, const int32_t* __restrict__ sh_of = nullptr,
@@ -1888,29 +1869,91 @@ void launch_vio_initial_guess(int64_t u_begin, int64_t count, const double* left
     if (count > 0) hipLaunchKernelGGL(vio_initial_guess_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, u_begin, count, left, left_of_node, vio, quat, t);
 }
 
-// ---- multi-GPU: exchange of the keyframes shared between ranks ----
-// All ranks hold the same ordered list of shared keyframes (touched by >= 2 ranks); the exchange buffer has one row of K doubles per
-// list entry.  A rank packs the rows of the shared keyframes IT touches (the rest of the zero-initialised buffer stays 0), the
-// buffer is all-reduced, and the rank reads its rows back.
-__global__ void pack_rows_kernel(double* __restrict__ buf, int K, int off, const double* __restrict__ src, int k, int64_t n, const int32_t* __restrict__ loc,
-                                 const int32_t* __restrict__ pos) {
+// ---- several ranks: neighbour exchanges (round 6) ----
+// A rank sends another rank exactly the rows that one reads and does not own (plans: pgo_mg_host.hpp).  Send and receive buffers hold one row of K = k1 + k2 doubles per listed
+// node, segment by segment in peer order.  The keyframes' own exchange SUMS: a keyframe touched by several ranks holds a partial row on each; every rank adds the parts in ascending
+// rank order (its own row where its rank comes), so that all of them end up with the same bits.
+__global__ void gather_rows_kernel(double* __restrict__ buf, const double* __restrict__ a1, int k1, const double* __restrict__ a2, int k2, int64_t n, const int32_t* __restrict__ idx,
+                                   const int32_t* __restrict__ stop) {
+    const int K = k1 + k2;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n * k) return;
-    const int64_t j = i / k; const int c = (int)(i - j * k);
-    buf[(size_t)pos[j] * K + off + c] = src[(size_t)loc[j] * k + c];
+    if (i >= n * K) return;
+    const int64_t j = i / K; const int c = (int)(i - j * K);
+    const bool stopped = stop && *stop;      // (a stopped PCG still takes part in every exchange: it sends zeros)
+    const int64_t node = idx[j];
+    buf[i] = stopped ? 0.0 : (c < k1 ? a1[(size_t)node * k1 + c] : a2[(size_t)node * k2 + (c - k1)]);
 }
-__global__ void unpack_rows_kernel(const double* __restrict__ buf, int K, int off, double* __restrict__ dst, int k, int64_t n, const int32_t* __restrict__ loc,
-                                   const int32_t* __restrict__ pos, const int32_t* __restrict__ stop) {
+__global__ void scatter_rows_kernel(const double* __restrict__ buf, double* __restrict__ a1, int k1, double* __restrict__ a2, int k2, int64_t n, const int32_t* __restrict__ idx,
+                                    const int32_t* __restrict__ stop) {
+    const int K = k1 + k2;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n * k || (stop && *stop)) return;   // a stopped PCG keeps its state bit for bit (it may be resumed with a tighter tolerance)
-    const int64_t j = i / k; const int c = (int)(i - j * k);
-    dst[(size_t)loc[j] * k + c] = buf[(size_t)pos[j] * K + off + c];
+    if (i >= n * K || (stop && *stop)) return;   // a stopped PCG keeps its state bit for bit (it may be resumed with a tighter tolerance)
+    const int64_t j = i / K; const int c = (int)(i - j * K);
+    const int64_t node = idx[j];
+    if (c < k1) a1[(size_t)node * k1 + c] = buf[i]; else a2[(size_t)node * k2 + (c - k1)] = buf[i];
 }
-void launch_pack_rows(double* buf, int K, int off, const double* src, int k, int64_t n, const int32_t* loc, const int32_t* pos, hipStream_t st) {
-    if (n > 0) hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((n * k + 255) / 256)), dim3(256), 0, st, buf, K, off, src, k, n, loc, pos);
+__global__ void sum_rows_kernel(const double* __restrict__ buf, double* __restrict__ a1, int k1, double* __restrict__ a2, int k2, int64_t n_sh, const int32_t* __restrict__ sh_loc,
+                                const int32_t* __restrict__ sum_ptr, const int32_t* __restrict__ sum_src, const int32_t* __restrict__ stop) {
+    const int K = k1 + k2;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_sh * K || (stop && *stop)) return;
+    const int64_t j = i / K; const int c = (int)(i - j * K);
+    double* mine = c < k1 ? a1 + (size_t)sh_loc[j] * k1 + c : a2 + (size_t)sh_loc[j] * k2 + (c - k1);
+    double s = 0.0;
+    for (int e = sum_ptr[j]; e < sum_ptr[j + 1]; ++e) { const int32_t src = sum_src[e]; s += src < 0 ? *mine : buf[(size_t)src * K + c]; }
+    *mine = s;
 }
-void launch_unpack_rows(const double* buf, int K, int off, double* dst, int k, int64_t n, const int32_t* loc, const int32_t* pos, const int32_t* stop, hipStream_t st) {
-    if (n > 0) hipLaunchKernelGGL(unpack_rows_kernel, dim3((unsigned)((n * k + 255) / 256)), dim3(256), 0, st, buf, K, off, dst, k, n, loc, pos, stop);
+// scatter of a level's residual rows with the pre-smoothed x of the same rows formed on the spot: x = (omega D^-1) r is pointwise, and every rank holds every level's Dinv
+// (the set-up is the same on all ranks) — so only r travels (half the bytes of sending both); the same six products in the same order as the kernel that owns the row
+__global__ void scatter_rows_dinv_kernel(const double* __restrict__ buf, double* __restrict__ r, double* __restrict__ x, const double* __restrict__ Dinv, int64_t n,
+                                         const int32_t* __restrict__ idx, const int32_t* __restrict__ stop) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * 6 || (stop && *stop)) return;
+    const int64_t j = i / 6; const int c = (int)(i - j * 6);
+    const int64_t node = idx[j];
+    const double* rv = buf + j * 6;
+    const double* Dk = Dinv + (size_t)node * 36 + c * 6;
+    double xv = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) xv += Dk[k] * rv[k];
+    r[(size_t)node * 6 + c] = rv[c];
+    x[(size_t)node * 6 + c] = xv;
+}
+void launch_scatter_rows_dinv(const double* buf, double* r, double* x, const double* Dinv, int64_t n, const int32_t* idx, const int32_t* stop, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(scatter_rows_dinv_kernel, dim3((unsigned)((n * 6 + 255) / 256)), dim3(256), 0, st, buf, r, x, Dinv, n, idx, stop);
+}
+void launch_gather_rows(double* buf, const double* a1, int k1, const double* a2, int k2, int64_t n, const int32_t* idx, const int32_t* stop, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n * (k1 + k2) + 255) / 256)), dim3(256), 0, st, buf, a1, k1, a2, k2, n, idx, stop);
+}
+void launch_scatter_rows(const double* buf, double* a1, int k1, double* a2, int k2, int64_t n, const int32_t* idx, const int32_t* stop, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)((n * (k1 + k2) + 255) / 256)), dim3(256), 0, st, buf, a1, k1, a2, k2, n, idx, stop);
+}
+void launch_sum_rows(const double* buf, double* a1, int k1, double* a2, int k2, int64_t n_sh, const int32_t* sh_loc, const int32_t* sum_ptr, const int32_t* sum_src, const int32_t* stop, hipStream_t st) {
+    if (n_sh > 0) hipLaunchKernelGGL(sum_rows_kernel, dim3((unsigned)((n_sh * (k1 + k2) + 255) / 256)), dim3(256), 0, st, buf, a1, k1, a2, k2, n_sh, sh_loc, sum_ptr, sum_src, stop);
+}
+// in-process communicator: the ranks are handles of ONE process (threads), so a "collective" is a kernel that reads the peers' device buffers directly — on one GPU, or over
+// xGMI with peer access between the GPUs of one process
+__global__ void local_reduce_kernel(double* __restrict__ out, LocalPeers P, int64_t n, int op) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = P.src[0][i];
+    for (int q = 1; q < P.n; ++q) { const double v = P.src[q][i]; s = op == 0 ? s + v : (v > s ? v : s); }      // rank order: the same bits on every rank
+    out[i] = s;
+}
+__global__ void local_copy_kernel(double* __restrict__ recv, LocalPeers P) {
+    const int q = blockIdx.y;
+    const int64_t n = P.cnt[q];
+    const double* __restrict__ src = P.src[q];
+    double* __restrict__ dst = recv + P.off[q];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+void launch_local_reduce(double* out, const LocalPeers& P, int64_t n, int op, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(local_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, P, n, op);
+}
+void launch_local_copy(double* recv, const LocalPeers& P, hipStream_t st) {
+    int64_t mx = 0;
+    for (int q = 0; q < P.n; ++q) mx = std::max(mx, P.cnt[q]);
+    if (mx > 0) hipLaunchKernelGGL(local_copy_kernel, dim3((unsigned)std::min<int64_t>((mx + 255) / 256, 256), (unsigned)P.n), dim3(256), 0, st, recv, P);
 }
 __global__ void scatter_owned_pose_kernel(const double* __restrict__ quat, const double* __restrict__ t, int64_t n, const int32_t* __restrict__ l2g,
                                           const double* __restrict__ own, double* __restrict__ gquat, double* __restrict__ gt) {

@@ -57,6 +57,11 @@ struct HostLevel {                       // level l >= 1
     std::vector<int32_t> rT_rowptr, rT_col;     // R by coarse row: [n_next+1]; fine rows ascending
     std::vector<int32_t> rT_of_w;               // [n_w] slot of block (column, row) in R's arrays for block k = (row, column) of W
     int rT_seg = 1;                             // lane groups sharing a row of R in the level kernel (tiles of tile_rows / rT_seg consecutive coarse rows)
+    // SEVERAL RANKS, distributed cycle (round 6; build_hierarchy with an Owners argument): every aggregate of every level holds nodes of ONE rank, the levels are numbered
+    // owner-major (rank 0's nodes first), tiles never mix ranks — so the rows a rank works on are one contiguous range of rows and of tiles on every level:
+    std::vector<int32_t> own_ptr;               // [world+1] rows [own_ptr[r], own_ptr[r+1]) belong to rank r; empty on one GPU
+    std::vector<int32_t> tile_ptr;              // [world+1] the rank's tiles (empty on the coarsest level)
+    bool distributed = false;                   // the cycle's kernels of this level run on the owner's rows only (else: every rank runs all of it from gathered vectors)
 };
 
 struct Hierarchy {
@@ -68,6 +73,19 @@ struct Hierarchy {
     HostLevel F;
     std::vector<int32_t> agg0;           // [N] level-1 node of each keyframe, -1 for keyframes outside the system (fixed)
     std::vector<int32_t> mem0_ptr, mem0; // level-1 node -> its keyframes
+    int world = 1;                       // > 1: built with Owners (owner-pure aggregates, owner-major numbering, own_ptr / tile_ptr on every level)
+};
+
+// Several ranks (edge sharding), distributed cycle: which ranks hold a residual block on each keyframe (bit r of touch_mask[g]) and which of them OWNS it — the one holding most
+// of its residual blocks (the lowest such rank): under a partition by place that is the rank of the keyframe's own cell, so that owners follow the partition and aggregates of
+// one owner are whole pieces of trajectory (with "the lowest touching rank" every loop closure into a lower cell moved its far keyframe there: measured on config 5 with 8
+// ranks, the owner-pure matching then stalled at 7 360 nodes where the single handle reaches 518).  Both are known on every rank after two all-reduces at graph build
+// (the sum of 2^rank over the touching ranks is exact in a double up to 52 ranks; the maximum of (blocks + 1) * 64 + 63 - rank picks the owner).
+struct Owners {
+    const std::vector<uint64_t>* touch_mask = nullptr;   // [N] in the numbering the hierarchy is built in (the caller's global one)
+    const std::vector<int32_t>* owner = nullptr;         // [N] owning rank, -1: no rank touches the keyframe
+    int world = 1;
+    int32_t dist_min_rows = 8192;                        // levels with fewer rows than this are not distributed: every rank runs all their rows from gathered vectors
 };
 
 struct WEdge { int32_t u, v; double w; };
@@ -240,6 +258,7 @@ struct BuildCache {
     std::vector<WEdge> rel1;                              // level-1 couplings through relative-pose edges (collapsed; match_passes merges parallel ones)
     std::vector<int32_t> sw_u, sw_v;                      // level-1 pairs (u < v) coupled by switchable edges ...
     std::vector<int64_t> sw_ptr; std::vector<int32_t> sw_edge;   // ... and the switchable edges of each pair
+    std::vector<int32_t> own1_prov;                       // several ranks: owner of each provisional level-1 node (its keyframes all have that owner)
 };
 
 // level 1 in its FINAL numbering from the cached provisional structure: rows permuted, columns relabelled, every row again "diagonal block first, then ascending column",
@@ -357,8 +376,13 @@ inline bool build_hierarchy(int64_t N, const std::vector<uint8_t>& node_free, co
                             double loop_discount = 0.0 /* loop closures of a pair of level-1 nodes that do not count in the matching above level 1 */,
                             BuildCache* cache = nullptr /* kept by the caller across rebuilds of the same graph with other switch values (level0_follows_switchable must be false) */,
                             const std::vector<int64_t>* fine_rowptr = nullptr, const std::vector<int32_t>* fine_col = nullptr /* both given: the transition keyframes -> level 1 is SMOOTHED
-                            too; the keyframe level's block pattern as the solver holds it (row i: block (i, i) first, then one block per incident edge) */) {
+                            too; the keyframe level's block pattern as the solver holds it (row i: block (i, i) first, then one block per incident edge) */,
+                            const Owners* owners = nullptr /* several ranks, distributed cycle: aggregates never mix owners, levels numbered owner-major (HostLevel::own_ptr) */) {
     H = Hierarchy{};
+    const bool owned = owners && owners->touch_mask && owners->owner && owners->world > 1;
+    const int world = owned ? owners->world : 1;
+    H.world = world;
+    auto kf_owner = [&](int64_t g) { return (*owners->owner)[(size_t)g]; };
     PGO_MG_T0();
     const int64_t Er = (int64_t)rc1.size(), Es = (int64_t)sc1.size();
     BuildCache own_cache;
@@ -374,6 +398,7 @@ inline bool build_hierarchy(int64_t N, const std::vector<uint8_t>& node_free, co
         rel_edges.reserve((size_t)Er);
         for (int64_t e = 0; e < Er; ++e) if (node_free[rc1[e]] && node_free[rc2[e]]) {
             const double w = rel_w[(size_t)rel_w_stride * e];
+            if (owned && kf_owner(rc1[e]) != kf_owner(rc2[e])) continue;          // several ranks: an aggregate holds keyframes of ONE owner
             if (w * w > 1e-8) rel_edges.push_back({rc1[e], rc2[e], w * w});       // an odometry edge the yaw policy has (all but) switched off ties nothing together
         }
         std::vector<uint8_t> skip((size_t)N);
@@ -382,7 +407,7 @@ inline bool build_hierarchy(int64_t N, const std::vector<uint8_t>& node_free, co
         if (level0_follows_switchable) {
             // (research setting: keyframes matched across loop closures too — measured 2-3x the iterations once outliers are switched off; not cached)
             std::vector<WEdge> edges = rel_edges;
-            for (int64_t e = 0; e < Es; ++e) if (node_free[sc1[e]] && node_free[sc2[e]]) { const double w = sw_weight ? sw_weight[e] : 1.0; if (w > 1e-8) edges.push_back({sc1[e], sc2[e], w}); }
+            for (int64_t e = 0; e < Es; ++e) if (node_free[sc1[e]] && node_free[sc2[e]] && !(owned && kf_owner(sc1[e]) != kf_owner(sc2[e]))) { const double w = sw_weight ? sw_weight[e] : 1.0; if (w > 1e-8) edges.push_back({sc1[e], sc2[e], w}); }
             Cc.agg0_prov = match_passes((int32_t)N, edges, passes0, &skip, n1);
         } else {
             // keyframes are grouped along relative-pose (odometry) edges only: a switchable loop closure may be an outlier the solver is about to
@@ -409,6 +434,8 @@ inline bool build_hierarchy(int64_t N, const std::vector<uint8_t>& node_free, co
         }
         Cc.n1 = n1;
         if (n1 < 1) return false;
+        Cc.own1_prov.clear();
+        if (owned) { Cc.own1_prov.assign((size_t)n1, 0); for (int64_t i = 0; i < N; ++i) if (Cc.agg0_prov[i] >= 0) Cc.own1_prov[(size_t)Cc.agg0_prov[i]] = std::max(0, kf_owner(i)); }
         PGO_MG_T("level-0 matching + run cuts");
         // block structure and Galerkin contribution lists of level 1, in the provisional numbering: needs the keyframes' aggregates only, so it runs on a thread of its own
         // beside the level-1 couplings below (and, at a first build, its result is needed only after the levels above have been matched and numbered)
@@ -489,18 +516,66 @@ inline bool build_hierarchy(int64_t N, const std::vector<uint8_t>& node_free, co
         w -= loop_discount;
         if (w > 1e-8) cur.push_back({Cc.sw_u[pi], Cc.sw_v[pi], w});
     }
+    // several ranks: couplings between nodes of different owners never match (every aggregate of every level stays with one rank); parents inherit the owner, so the
+    // filter is needed once
+    std::vector<int32_t> own_cur;                      // owner of each node of the level being matched (provisional numbering)
+    if (owned) {
+        own_cur = Cc.own1_prov;
+        size_t m = 0;
+        for (size_t k = 0; k < cur.size(); ++k) if (own_cur[(size_t)cur[k].u] == own_cur[(size_t)cur[k].v]) cur[m++] = cur[k];
+        cur.resize(m);
+    }
     // pass 1: aggregate level by level in provisional numbering; par[l] maps level l+1 (index l) to the level above
     std::vector<std::vector<int32_t>> par;
     std::vector<int32_t> n_of{n1};
+    std::vector<std::vector<int32_t>> own_of;          // owned: own_of[l][i] = owner of provisional node i of level l+1
+    if (owned) own_of.push_back(own_cur);
     for (int lvl = 1;; ++lvl) {
         const int32_t n = n_of.back();
-        if (n <= dense_max) break;                     // coarsest level: solved densely
-        if (lvl >= max_levels) return false;
+        if (n <= std::max(dense_max, owned ? world : 0)) break;       // coarsest level: solved densely
+        if (lvl >= max_levels) { if (timing()) std::fprintf(stderr, "[pgo] hierarchy (host): more than %d levels\n", max_levels); return false; }
         int32_t n_next = 0;
         par.push_back(match_passes(n, cur, passes, nullptr, n_next));      // (8-node aggregates from level 2 up, one level less: measured slower on C3 and C4 with the smoothed transition, 0.424 vs 0.411 s / 1.60 vs 1.47 s)
-        if ((double)n_next > 0.85 * (double)n) return false;          // coarsening stalls
+        if (owned && (double)n_next > 0.85 * (double)n) {
+            // Several ranks: aggregates stay inside one owner, and a rank's part of the graph falls into pieces that nothing of the SAME rank ties together (a trajectory
+            // crosses a cell of the partition many times) — once every piece is one node the matching has no partners left although thousands of nodes remain (config 5 on 8
+            // ranks: 1 364 nodes at level 4, the single handle is at 518 there).  The nodes the matching left single are then grouped by owner in node order, up to
+            // 2^passes per aggregate: a rigid aggregate of pieces that do not touch is a weaker coarse mode than a matched one, never a wrong one (the Galerkin product of any
+            // aggregation is symmetric positive definite), and it only happens on the small top levels.
+            std::vector<int32_t>& pr = par.back();
+            std::vector<int32_t> cnt((size_t)n_next, 0);
+            for (int32_t i = 0; i < n; ++i) cnt[(size_t)pr[(size_t)i]]++;
+            const int group = 1 << std::max(1, passes);
+            std::vector<int32_t> open_agg((size_t)world, -1), open_cnt((size_t)world, 0), target((size_t)n_next, -1);
+            for (int32_t i = 0; i < n; ++i) {
+                const int32_t a = pr[(size_t)i];
+                if (cnt[(size_t)a] != 1) continue;
+                const int o = own_of.back()[(size_t)i];
+                if (open_agg[(size_t)o] < 0 || open_cnt[(size_t)o] >= group) { open_agg[(size_t)o] = a; open_cnt[(size_t)o] = 1; }
+                else { target[(size_t)a] = open_agg[(size_t)o]; ++open_cnt[(size_t)o]; }
+            }
+            std::vector<int32_t> remap((size_t)n_next, -1);
+            int32_t na = 0;
+            for (int32_t i = 0; i < n; ++i) {
+                int32_t a = pr[(size_t)i];
+                if (target[(size_t)a] >= 0) a = target[(size_t)a];
+                if (remap[(size_t)a] < 0) remap[(size_t)a] = na++;
+                pr[(size_t)i] = remap[(size_t)a];
+            }
+            n_next = na;
+        }
+        if ((double)n_next > 0.85 * (double)n) {          // coarsening stalls
+            if (owned && n <= 512) { par.pop_back(); break; }      // (several ranks: a level the dense solver can take then simply becomes the coarsest one)
+            if (timing()) std::fprintf(stderr, "[pgo] hierarchy (host): coarsening stalls at level %d: %d -> %d nodes\n", lvl, n, n_next);
+            return false;
+        }
         cur = collapse(cur, par.back());
         n_of.push_back(n_next);
+        if (owned) {
+            std::vector<int32_t> on((size_t)n_next, 0);
+            for (int32_t i = 0; i < n; ++i) on[(size_t)par.back()[(size_t)i]] = own_of.back()[(size_t)i];
+            own_of.push_back(std::move(on));
+        }
     }
     PGO_MG_T("upper-level matching");
     // pass 2, top down: number every level so that the members of a parent are contiguous and parents ascend
@@ -512,7 +587,14 @@ inline bool build_hierarchy(int64_t N, const std::vector<uint8_t>& node_free, co
         const int32_t n = n_of[l];
         Lv.n = n;
         std::vector<int32_t> newid(n);
-        if (l == nl - 1) std::iota(newid.begin(), newid.end(), 0);
+        if (l == nl - 1 && owned) {      // owner-major on the coarsest level; "children by parent" then makes every level below owner-major as well
+            std::vector<int32_t> order(n);
+            std::iota(order.begin(), order.end(), 0);
+            const std::vector<int32_t>& ow = own_of[(size_t)l];
+            std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return ow[(size_t)a] < ow[(size_t)b]; });
+            for (int32_t k = 0; k < n; ++k) newid[order[(size_t)k]] = k;
+        }
+        else if (l == nl - 1) std::iota(newid.begin(), newid.end(), 0);
         else {
             const std::vector<int32_t>& pr = par[l];
             std::vector<int32_t> fpar(n), order(n);
@@ -526,7 +608,23 @@ inline bool build_hierarchy(int64_t N, const std::vector<uint8_t>& node_free, co
             for (int32_t k = 0; k < n; ++k) Lv.agg_ptr[(size_t)Lv.parent[k] + 1]++;
             for (int32_t a = 0; a < n_next; ++a) Lv.agg_ptr[(size_t)a + 1] += Lv.agg_ptr[a];
         }
+        if (owned) {      // rows of each rank: the numbering is owner-major by construction
+            Lv.own_ptr.assign((size_t)world + 1, 0);
+            for (int32_t i = 0; i < n; ++i) Lv.own_ptr[(size_t)own_of[(size_t)l][(size_t)i] + 1]++;
+            for (int r = 0; r < world; ++r) Lv.own_ptr[(size_t)r + 1] += Lv.own_ptr[(size_t)r];
+            Lv.distributed = l + 1 < nl && n >= owners->dist_min_rows;
+        }
         newid_above.swap(newid);
+    }
+    if (owned) for (int l = 0; l < nl; ++l) {      // (checked, not assumed: a rank's rows are one range)
+        const HostLevel& Lv = H.L[(size_t)l];
+        if (l + 1 < nl) for (int32_t k = 0; k < Lv.n; ++k) {
+            const HostLevel& Up = H.L[(size_t)l + 1];
+            const int32_t pa = Lv.parent[(size_t)k];
+            const int ro = (int)(std::upper_bound(Lv.own_ptr.begin(), Lv.own_ptr.end(), k) - Lv.own_ptr.begin()) - 1;
+            const int po = (int)(std::upper_bound(Up.own_ptr.begin(), Up.own_ptr.end(), pa) - Up.own_ptr.begin()) - 1;
+            if (ro != po) { if (timing()) std::fprintf(stderr, "[pgo] hierarchy (host): level %d row %d: owner %d, its parent's %d\n", l + 1, k, ro, po); return false; }
+        }
     }
     H.agg0 = Cc.agg0_prov;
     for (int32_t& a : H.agg0) if (a >= 0) a = newid_above[a];
@@ -584,14 +682,123 @@ inline bool build_hierarchy(int64_t N, const std::vector<uint8_t>& node_free, co
         Lv.tile_agg0.clear();
         Lv.tile_agg0.push_back(0);
         int rows = 0;
+        const std::vector<int32_t>& up_own = H.L[l + 1].own_ptr;      // several ranks: a tile never mixes owners (aggregate a belongs to the rank whose range of the level above holds it)
+        int r_cur = 0;                      // rank whose range of the level above holds the aggregates being packed
         for (int32_t a = 0; a < n_next; ++a) {
             const int sz = Lv.agg_ptr[(size_t)a + 1] - Lv.agg_ptr[a];
-            if (rows + sz > cap) { Lv.tile_agg0.push_back(a); rows = 0; }
+            bool owner_change = false;
+            if (owned) while (r_cur + 1 < world && a >= up_own[(size_t)r_cur + 1]) { ++r_cur; owner_change = true; }
+            if (rows > 0 && (rows + sz > cap || owner_change)) { Lv.tile_agg0.push_back(a); rows = 0; }
             rows += sz;
         }
         Lv.tile_agg0.push_back(n_next);
+        if (owned) {      // tile ranges from the aggregates' owners (simple and checked: recomputed from the finished tile list)
+            const int32_t nt = (int32_t)Lv.tile_agg0.size() - 1;
+            Lv.tile_ptr.assign((size_t)world + 1, nt);
+            Lv.tile_ptr[0] = 0;
+            int32_t t = 0;
+            for (int r = 0; r < world; ++r) {
+                while (t < nt && Lv.tile_agg0[(size_t)t] < up_own[(size_t)r]) ++t;
+                Lv.tile_ptr[(size_t)r] = t;
+            }
+            Lv.tile_ptr[(size_t)world] = nt;
+            for (int r = 0; r < world; ++r) for (int32_t tt = Lv.tile_ptr[(size_t)r]; tt < Lv.tile_ptr[(size_t)r + 1]; ++tt)
+                if (Lv.tile_agg0[(size_t)tt] < up_own[(size_t)r] || Lv.tile_agg0[(size_t)tt + 1] > up_own[(size_t)r + 1]) return false;      // a tile that straddles two ranks: never (guard)
+        }
     }
     return true;
+}
+
+// ---- several ranks: who sends which rows to whom (round 6) ----
+// Every exchange of the distributed solver is a NEIGHBOUR exchange: a rank sends the rows another rank reads and does not own, nothing else travels.  The plans are built on
+// every rank from data all ranks hold (the keyframes' touch masks, the hierarchy built from the gathered graph, its ownership ranges), so sender and receiver agree on the
+// contents and order of every segment without a handshake: segment (src -> dst) lists node ids in ascending order.
+struct ExchangePlan {
+    std::vector<int32_t> send_idx, recv_idx;       // concatenated per peer (peer 0 first), ascending inside a segment
+    std::vector<int64_t> send_off, recv_off;       // [world+1] segment bounds, in rows
+    std::vector<int64_t> pair_cnt;                 // [world*world] rows rank src sends to rank dst at [src * world + dst] — the layout of the all-reduce fallback and the byte counters
+    int64_t n_send() const { return send_off.empty() ? 0 : send_off.back(); }
+    int64_t n_recv() const { return recv_off.empty() ? 0 : recv_off.back(); }
+};
+inline void plan_from_keys(std::vector<uint64_t>& keys /* ((needer * world + provider) << 32) | node */, int world, int rank, ExchangePlan& P) {
+    std::sort(keys.begin(), keys.end());
+    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+    P = ExchangePlan{};
+    P.pair_cnt.assign((size_t)world * world, 0);
+    P.send_off.assign((size_t)world + 1, 0); P.recv_off.assign((size_t)world + 1, 0);
+    for (uint64_t k : keys) { const int np = (int)(k >> 32), needer = np / world, provider = np % world; P.pair_cnt[(size_t)provider * world + needer]++; }
+    for (int q = 0; q < world; ++q) { P.send_off[(size_t)q + 1] = P.send_off[(size_t)q] + P.pair_cnt[(size_t)rank * world + q]; P.recv_off[(size_t)q + 1] = P.recv_off[(size_t)q] + P.pair_cnt[(size_t)q * world + rank]; }
+    P.send_idx.resize((size_t)P.send_off[(size_t)world]); P.recv_idx.resize((size_t)P.recv_off[(size_t)world]);
+    std::vector<int64_t> fs(P.send_off.begin(), P.send_off.end() - 1), fr(P.recv_off.begin(), P.recv_off.end() - 1);
+    for (uint64_t k : keys) {      // keys ascend by (needer, provider, node): every segment comes out ascending
+        const int np = (int)(k >> 32), needer = np / world, provider = np % world; const int32_t node = (int32_t)(k & 0xffffffffull);
+        if (provider == rank) P.send_idx[(size_t)fs[(size_t)needer]++] = node;
+        if (needer == rank) P.recv_idx[(size_t)fr[(size_t)provider]++] = node;
+    }
+}
+// plans[l], l < n_levels = exchange of the vectors of level l+1 (the last one: the dense level's residual); plans[n_levels] = the prolongation to the keyframes (x of level 1 at
+// the aggregates of every keyframe the rank touches — a subset of level 1's halo, sent on its own).  What a rank reads on a level it does not own there:
+//   a distributed level:  the columns of its rows (row products of the down- and the up-sweep), with an explicit transfer operator above also the rows of R (restriction of its
+//                         coarse rows) and, one level up, the columns of R^T (x_next in the up-sweep); on level 1 the aggregates of every keyframe the rank touches (prolongation)
+//   any other level:      everything (its kernels run all rows on every rank from gathered vectors)
+inline void build_level_plans(const Hierarchy& H, const Owners& O, int rank, std::vector<ExchangePlan>& plans) {
+    const int world = O.world, nl = (int)H.L.size();
+    plans.assign((size_t)nl + 1, ExchangePlan{});
+    std::vector<std::vector<int32_t>> own((size_t)nl);
+    for (int l = 0; l < nl; ++l) {
+        const HostLevel& A = H.L[(size_t)l];
+        own[(size_t)l].resize((size_t)A.n);
+        for (int r = 0; r < world; ++r) for (int32_t i = A.own_ptr[(size_t)r]; i < A.own_ptr[(size_t)r + 1]; ++i) own[(size_t)l][(size_t)i] = r;
+    }
+    std::vector<std::vector<uint64_t>> keys((size_t)nl + 1);
+    auto need_in = [&](int slot, int l, int needer, int32_t node) { const int prov = own[(size_t)l][(size_t)node]; if (prov != needer) keys[(size_t)slot].push_back(((uint64_t)(needer * world + prov) << 32) | (uint32_t)node); };
+    auto need = [&](int l, int needer, int32_t node) { need_in(l, l, needer, node); };
+    for (int l = 0; l < nl; ++l) {
+        const HostLevel& A = H.L[(size_t)l];
+        if (!A.distributed) { for (int32_t i = 0; i < A.n; ++i) for (int q = 0; q < world; ++q) need(l, q, i); continue; }
+        for (int32_t i = 0; i < A.n; ++i) { const int o = own[(size_t)l][(size_t)i]; for (int64_t k = A.rowptr[(size_t)i]; k < A.rowptr[(size_t)i + 1]; ++k) need(l, o, A.col[(size_t)k]); }
+        if (A.smoothed) {
+            const int32_t nb = (int32_t)A.rT_rowptr.size() - 1;
+            for (int32_t c = 0; c < nb; ++c) { const int oc = own[(size_t)l + 1][(size_t)c]; for (int32_t k = A.rT_rowptr[(size_t)c]; k < A.rT_rowptr[(size_t)c + 1]; ++k) need(l, oc, A.rT_col[(size_t)k]); }
+            if (H.L[(size_t)l + 1].distributed)
+                for (int32_t i = 0; i < A.n; ++i) { const int o = own[(size_t)l][(size_t)i]; for (int32_t k = A.w_rowptr[(size_t)i]; k < A.w_rowptr[(size_t)i + 1]; ++k) need(l + 1, o, A.w_col[(size_t)k]); }
+        }
+        if (l == 0) for (size_t g = 0; g < H.agg0.size(); ++g) if (H.agg0[g] >= 0) { uint64_t m = (*O.touch_mask)[g]; while (m) { const int q = __builtin_ctzll(m); m &= m - 1; need_in(nl, 0, q, H.agg0[g]); } }
+    }
+    for (int l = 0; l <= nl; ++l) plan_from_keys(keys[(size_t)l], world, rank, plans[(size_t)l]);
+}
+// The keyframes' own exchange (rows of the matvec output, of the diagonal blocks, of the gradient ...): a keyframe touched by several ranks holds a PARTIAL row on each of them; every
+// touching rank sends its part to every other one and sums what it has and what it gets in ascending rank order — the same bits on every rank.  Local ids (l2g ascending).
+struct FinePlan {
+    ExchangePlan x;                                // send_idx: LOCAL keyframes whose rows go to each peer (recv_idx unused: the segment from peer q lists the same keyframes in the same order)
+    std::vector<int32_t> sh_loc;                   // the rank's shared keyframes (local ids, ascending)
+    std::vector<int32_t> sum_ptr, sum_src;         // per shared keyframe its parts in ascending rank order: -1 = the rank's own row, else the row of the receive buffer
+};
+inline void build_fine_plan(const std::vector<uint64_t>& touch_mask, const std::vector<int32_t>& l2g, int rank, int world, FinePlan& F) {
+    F = FinePlan{};
+    ExchangePlan& P = F.x;
+    P.pair_cnt.assign((size_t)world * world, 0);
+    for (uint64_t m0 : touch_mask) {
+        if (!(m0 & (m0 - 1))) continue;            // one rank (or none): nothing travels
+        for (uint64_t a = m0; a; a &= a - 1) for (uint64_t b = m0; b; b &= b - 1) { const int ra = __builtin_ctzll(a), rb = __builtin_ctzll(b); if (ra != rb) P.pair_cnt[(size_t)ra * world + rb]++; }
+    }
+    P.send_off.assign((size_t)world + 1, 0); P.recv_off.assign((size_t)world + 1, 0);
+    for (int q = 0; q < world; ++q) { P.send_off[(size_t)q + 1] = P.send_off[(size_t)q] + P.pair_cnt[(size_t)rank * world + q]; P.recv_off[(size_t)q + 1] = P.recv_off[(size_t)q] + P.pair_cnt[(size_t)q * world + rank]; }
+    P.send_idx.resize((size_t)P.send_off[(size_t)world]);
+    std::vector<int64_t> fill(P.send_off.begin(), P.send_off.end() - 1);
+    F.sum_ptr.push_back(0);
+    for (size_t l = 0; l < l2g.size(); ++l) {
+        const uint64_t m0 = touch_mask[(size_t)l2g[l]];
+        if (!(m0 & (m0 - 1)) || !((m0 >> rank) & 1)) continue;
+        F.sh_loc.push_back((int32_t)l);
+        for (uint64_t a = m0; a; a &= a - 1) {
+            const int q = __builtin_ctzll(a);
+            if (q == rank) { F.sum_src.push_back(-1); continue; }
+            F.sum_src.push_back((int32_t)(P.recv_off[(size_t)q] + (fill[(size_t)q] - P.send_off[(size_t)q])));      // (segment q -> rank lists the same keyframes in the same order as rank -> q)
+            P.send_idx[(size_t)fill[(size_t)q]++] = (int32_t)l;
+        }
+        F.sum_ptr.push_back((int32_t)F.sum_src.size());
+    }
 }
 
 }  // namespace pgo_mg

@@ -570,7 +570,7 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_smooth_step_kernel(MgLevelDev A, 
                                                                    const double* __restrict__ add1, const double* __restrict__ add2, double* __restrict__ out, double cs, const int32_t* __restrict__ stop) {
     __shared__ double xch[CG_BLOCK * 7];
     __shared__ double tb[CG_BLOCK];
-    mg_smooth_step_tile(A, (int)blockIdx.x, in_r, in_x, out_w, add1, add2, out, cs, stop, xch, tb);
+    mg_smooth_step_tile(A, (int)blockIdx.x + A.tile0, in_r, in_x, out_w, add1, add2, out, cs, stop, xch, tb);
 }
 // Down-sweep of a level with a smoothed transition above it, explicit form (MgLevelDev::rt_valf; pgo_mg_host.hpp) — ONE launch, two independent kinds of workgroups:
 //   the level's own tiles:           v = x_pre + Dinv (r - A x_pre)                                  -> A.y   (the smoothing step; the up-sweep only adds R^T x_next to it)
@@ -579,15 +579,15 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_smooth_step_kernel(MgLevelDev A, 
 __global__ __launch_bounds__(CG_BLOCK) void mg_sdown_kernel(MgLevelDev A, double* __restrict__ r_next, double* __restrict__ x_next, const double* __restrict__ Dinv_next, const int32_t* __restrict__ stop) {
     __shared__ double xch[CG_BLOCK * 7];
     __shared__ double tb[CG_BLOCK];
-    if ((int)blockIdx.x < A.tiles) { mg_smooth_step_tile(A, (int)blockIdx.x, A.r, A.x, nullptr, A.x, nullptr, A.y, 1.0, stop, xch, tb); return; }
+    if ((int)blockIdx.x < A.tiles_own) { mg_smooth_step_tile(A, (int)blockIdx.x + A.tile0, A.r, A.x, nullptr, A.x, nullptr, A.y, 1.0, stop, xch, tb); return; }
     const int stopped = stop ? *stop : 0;
-    const int tile = (int)blockIdx.x - A.tiles;
+    const int tile = (int)blockIdx.x - A.tiles_own;
     const int ss = A.rT_seg_shift, rpt = MG_TILE_ROWS >> ss;
     const int q6 = threadIdx.x / 6, c = threadIdx.x % 6;
     const int li = q6 & (rpt - 1), sg = q6 >> (5 - ss);
     const int2 rb = A.rT_rows[tile * MG_TILE_ROWS + li];
-    const int row = tile * rpt + li;
-    const bool live = row < A.n_next && sg == 0;
+    const int row = A.rT_row0 + tile * rpt + li;      // (several ranks: the rank's own coarse rows; rT_rows is the table of that range)
+    const bool live = row < A.rT_row1 && sg == 0;
     double Dk[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     if (live && x_next) {
         const double2* Dp = reinterpret_cast<const double2*>(Dinv_next + (size_t)row * 36 + c * 6);
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_sdown_kernel(MgLevelDev A, double
     }
     if (stopped) return;
     double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    if (row < A.n_next) { int kb, ke; mg_split_row(rb, sg, ss, kb, ke); mg_row_accumulate_f32(kb, ke, A.rT_col, A.r_valf, A.r, c, acc); }
+    if (row < A.rT_row1) { int kb, ke; mg_split_row(rb, sg, ss, kb, ke); mg_row_accumulate_f32(kb, ke, A.rT_col, A.r_valf, A.r, c, acc); }
     double* mine = xch + (size_t)threadIdx.x * 7;
 #pragma unroll
     for (int q = 0; q < 6; ++q) mine[q] = acc[q];
@@ -706,10 +706,11 @@ __global__ __launch_bounds__(256) void mg_rescale_dinv_kernel(MgLevelDev A, cons
 static void mg_limit_smoother(const MgLevelDev& A, double omega, hipStream_t st) {
     const int n6 = A.n * 6;
     double* v = A.x; double* w = A.xt; double* lam = A.xf;              // the level's cycle vectors are free during the set-up
+    MgLevelDev whole = A; whole.tile0 = 0; whole.tiles_own = A.tiles;     // (the set-up is the same on every rank: all rows)
     hipLaunchKernelGGL(mg_power_init_kernel, dim3((unsigned)((n6 + 255) / 256)), dim3(256), 0, st, v, n6);
     for (int it = 0; it < 8; ++it) {
         // w = D^-1 A v  =  (-1 / omega) (omega D^-1) (0 - A v)
-        hipLaunchKernelGGL(mg_smooth_step_kernel, dim3((unsigned)A.tiles), dim3(CG_BLOCK), 0, st, A, (const double*)nullptr, (const double*)v, (double*)nullptr, (const double*)nullptr, (const double*)nullptr, w, -1.0 / omega, (const int32_t*)nullptr);
+        hipLaunchKernelGGL(mg_smooth_step_kernel, dim3((unsigned)A.tiles), dim3(CG_BLOCK), 0, st, whole, (const double*)nullptr, (const double*)v, (double*)nullptr, (const double*)nullptr, (const double*)nullptr, w, -1.0 / omega, (const int32_t*)nullptr);
         double* tmp = v; v = w; w = tmp;
     }
     hipLaunchKernelGGL(mg_power_ratio_kernel, dim3(1), dim3(1024), 0, st, (const double*)w, (const double*)v, n6, lam);      // (v: 8 steps, w: 7 steps)
@@ -765,8 +766,8 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_restrict0_kernel(MgDev M, const d
                                                                  const double* __restrict__ Dinv, const int32_t* __restrict__ stop, const double* __restrict__ own = nullptr /* several ranks: owner weights */) {
     __shared__ double rb[CG_BLOCK];
     const int stopped = stop ? *stop : 0;        // requested together with the first data loads, tested when they are needed: no round trip of its own
-    const int a = blockIdx.x * MG_TILE_ROWS + threadIdx.x / 6, k = threadIdx.x % 6;
-    const bool live = a < M.n1;
+    const int a = M.a0 + blockIdx.x * MG_TILE_ROWS + threadIdx.x / 6, k = threadIdx.x % 6;
+    const bool live = a < M.a1;
     int m0 = 0, m1 = 0;
     if (live) { m0 = M.mem0_ptr[a]; m1 = M.mem0_ptr[a + 1]; }
     if (stopped) return;
@@ -812,8 +813,9 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_down_kernel(MgLevelDev A, double*
     const int stopped = stop ? *stop : 0;
     const int q6 = threadIdx.x / 6, c = threadIdx.x % 6;
     const int li = q6 & ((MG_TILE_ROWS >> A.seg_shift) - 1), sg = q6 >> (5 - A.seg_shift);      // row of the tile, lane group (0 unless the level's rows are split)
-    const int4 ti = A.tile_info[blockIdx.x];          // {a0, a1, i0, i1}
-    const int2 rb = A.tile_rows[blockIdx.x * MG_TILE_ROWS + li];   // this lane's row: its block range (independent of tile_info)
+    const int tile_d = (int)blockIdx.x + A.tile0;
+    const int4 ti = A.tile_info[tile_d];          // {a0, a1, i0, i1}
+    const int2 rb = A.tile_rows[tile_d * MG_TILE_ROWS + li];   // this lane's row: its block range (independent of tile_info)
     MG_TL(1);
     if (stopped) return;
     const int a0 = ti.x, na = ti.y - ti.x, i0 = ti.z, i1 = ti.w;
@@ -913,7 +915,7 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_up_kernel(MgLevelDev A, MgLevelDe
     const int li = q6 & ((MG_TILE_ROWS >> A.seg_shift) - 1), sg = q6 >> (5 - A.seg_shift);
     double acc2 = 0.0;      // FINE: this workgroup's share of r.(P x_1), over all its tiles
     // FINE: the grid is capped at MAX_PARTIALS workgroups (one r.z partial slot each), a workgroup takes every gridDim-th tile; otherwise one tile per workgroup
-    for (int tile = blockIdx.x; tile < A.tiles; tile += gridDim.x) {
+    for (int tile = A.tile0 + (int)blockIdx.x; tile < A.tile0 + A.tiles_own; tile += gridDim.x) {
     const int4 ti = A.tile_info[tile];
     const bool expl = xnext != nullptr;
     const int2 rb = expl ? A.rt_rows[tile * MG_TILE_ROWS + li] : A.tile_rows[tile * MG_TILE_ROWS + li];
@@ -1211,97 +1213,73 @@ void launch_cg_update_mg_sr(const GraphDev& G, const CgDev& C, const MgDev& M, c
     if (M.n_levels == 1) hipLaunchKernelGGL(cg_update_mg_kernel<true>, dim3(g), dim3(CG_BLOCK), 0, st, G, C, M, K.rc, (double*)nullptr, (const double*)nullptr, k & 1, n_pq_partials, g, first);
     else hipLaunchKernelGGL(cg_update_mg_kernel<true>, dim3(g), dim3(CG_BLOCK), 0, st, G, C, M, levels[0].r, levels[0].x, (const double*)levels[0].Dinv, k & 1, n_pq_partials, g, first);
 }
-void launch_mg_restrict0(const GraphDev& G, const MgDev& M, const double* v, double* out, bool own_weighted, hipStream_t st) {
-    const unsigned g1 = (unsigned)((M.n1 + MG_TILE_ROWS - 1) / MG_TILE_ROWS);
-    hipLaunchKernelGGL(mg_restrict0_kernel, dim3(g1), dim3(CG_BLOCK), 0, st, M, v, out, (double*)nullptr, (const double*)nullptr, (const int32_t*)nullptr, own_weighted ? G.own : (const double*)nullptr);
-}
-// Several ranks.  The level-1 residual follows the keyframes' residual through the Chronopoulos-Gear recurrence: q1 = P0^T (A u), summed over the ranks inside the
-// iteration's ONE exchange, gives s1 = q1 + beta s1 and r1 -= alpha s1 with the alpha, beta cgcg_update_kernel has just used — no second collective for P0^T r.
-// x1 = w D1^-1 r1 is the cycle's first smoothing step.  mode 1 (PCG start, r1 freshly all-reduced): s1 = 0.
-__global__ __launch_bounds__(CG_BLOCK) void mg_level1_update_kernel(CgDev C, MgDev M, double* __restrict__ r1, double* __restrict__ x1, const double* __restrict__ Dinv1, int parity, int first, int mode) {
-    __shared__ double rb[CG_BLOCK];
-    if (mode == 0 && C.flags[0]) return;            // a stopped PCG keeps its state (the flag was set by an earlier kernel: uniform)
-    const int a = blockIdx.x * MG_TILE_ROWS + threadIdx.x / 6, k = threadIdx.x % 6;
-    const bool live = a < M.n1;
-    double r = 0.0;
-    if (live) {
-        const size_t i = (size_t)a * 6 + k;
-        if (mode == 0) {
-            const double alpha = C.scal[9 + 2 * parity];
-            const double beta = first ? 0.0 : C.scal[8 + 2 * parity] / C.scal[8 + 2 * (parity ^ 1)];
-            const double s = M.q1[i] + beta * M.s1[i];
-            M.s1[i] = s;
-            r = r1[i] - alpha * s;
-            r1[i] = r;
-        } else { M.s1[i] = 0.0; r = r1[i]; }
-    }
-    if (!x1) return;
-    rb[threadIdx.x] = r;
-    __syncthreads();
-    if (live) {
-        const double* Dk = Dinv1 + (size_t)a * 36 + k * 6;
-        const double* ra = rb + (threadIdx.x - k);
-        double x = 0.0;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) x += Dk[j] * ra[j];
-        x1[(size_t)a * 6 + k] = x;
-    }
-}
-void launch_mg_level1_update(const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, int k, int first, int mode, hipStream_t st) {
-    const unsigned g1 = (unsigned)((M.n1 + MG_TILE_ROWS - 1) / MG_TILE_ROWS);
-    if (M.n_levels == 1) hipLaunchKernelGGL(mg_level1_update_kernel, dim3(g1), dim3(CG_BLOCK), 0, st, C, M, K.rc, (double*)nullptr, (const double*)nullptr, k & 1, first, mode);
-    else hipLaunchKernelGGL(mg_level1_update_kernel, dim3(g1), dim3(CG_BLOCK), 0, st, C, M, levels[0].r, levels[0].x, (const double*)levels[0].Dinv, k & 1, first, mode);
-}
 void launch_mg_apply(const GraphDev& G, const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, const double* r, double* z, double* part_rz, double scale, bool inside_iteration, hipStream_t st,
-                     bool restricted, double prolong_scale, const MgLevelDev* fine /* transfer view of the keyframe level: smoothed keyframe transition (never `restricted`, never fused) */) {
+                     bool restricted, double prolong_scale, const MgLevelDev* fine /* transfer view of the keyframe level: smoothed keyframe transition (never `restricted`, never fused) */,
+                     const MgExchangeHook* hook, int* hook_rc) {
     const int32_t* stop = inside_iteration ? C.flags : nullptr;     // at PCG start the flag still belongs to the previous solve
     const int nl = M.n_levels;
-    const unsigned g1 = (unsigned)((M.n1 + MG_TILE_ROWS - 1) / MG_TILE_ROWS);
+    const unsigned g1 = (unsigned)((std::max(M.a1 - M.a0, 0) + MG_TILE_ROWS - 1) / MG_TILE_ROWS);      // (several ranks: the rank's own aggregates)
+    // several ranks: the exchange a kernel's reads need is issued right before it (pgo_solver.hip); a failing exchange ends the cycle (the caller sees *hook_rc)
+    bool hook_failed = false;
+    auto xchg = [&](int point, int level) { if (hook && !hook_failed) { const int rc = hook->fn(hook->ctx, point, level); if (rc != 0) { hook_failed = true; if (hook_rc) *hook_rc = rc; } } };
     if (restricted) {}
     else if (fine) {      // r_1 = Ps_0^T r (and x_1 = Dinv_1 r_1): the restriction half of mg_sdown_kernel on the keyframe level's transfer view, which has no tiles of its own
-        MgLevelDev T = *fine; T.tiles = 0; T.r = const_cast<double*>(r);
+        MgLevelDev T = *fine; T.tiles = 0; T.tiles_own = 0; T.r = const_cast<double*>(r);
         if (nl == 1) hipLaunchKernelGGL(mg_sdown_kernel, dim3((unsigned)T.rT_tiles), dim3(CG_BLOCK), 0, st, T, K.rc, (double*)nullptr, (const double*)nullptr, stop);
         else hipLaunchKernelGGL(mg_sdown_kernel, dim3((unsigned)T.rT_tiles), dim3(CG_BLOCK), 0, st, T, levels[0].r, levels[0].x, (const double*)levels[0].Dinv, stop);
     }
+    else if (g1 == 0) {}
     else if (nl == 1) hipLaunchKernelGGL(mg_restrict0_kernel, dim3(g1), dim3(CG_BLOCK), 0, st, M, r, K.rc, (double*)nullptr, (const double*)nullptr, stop);
     else hipLaunchKernelGGL(mg_restrict0_kernel, dim3(g1), dim3(CG_BLOCK), 0, st, M, r, levels[0].r, levels[0].x, (const double*)levels[0].Dinv, stop);
     for (int l = 1; l < nl; ++l) {                     // sparse level l -> level l+1
         MgLevelDev A = levels[l - 1];
+        xchg(0, l);
+        if (hook_failed) return;
         if (A.smoothed && A.rt_valf) {      // explicit transfer operator: smoothing step and restriction in one launch (two kinds of workgroups)
-            if (l + 1 == nl) hipLaunchKernelGGL(mg_sdown_kernel, dim3((unsigned)(A.tiles + A.rT_tiles)), dim3(CG_BLOCK), 0, st, A, K.rc, (double*)nullptr, (const double*)nullptr, stop);
-            else hipLaunchKernelGGL(mg_sdown_kernel, dim3((unsigned)(A.tiles + A.rT_tiles)), dim3(CG_BLOCK), 0, st, A, levels[l].r, levels[l].x, (const double*)levels[l].Dinv, stop);
+            const unsigned g = (unsigned)(A.tiles_own + A.rT_tiles);
+            if (g == 0) continue;
+            if (l + 1 == nl) hipLaunchKernelGGL(mg_sdown_kernel, dim3(g), dim3(CG_BLOCK), 0, st, A, K.rc, (double*)nullptr, (const double*)nullptr, stop);
+            else hipLaunchKernelGGL(mg_sdown_kernel, dim3(g), dim3(CG_BLOCK), 0, st, A, levels[l].r, levels[l].x, (const double*)levels[l].Dinv, stop);
             continue;
         }
+        if (A.tiles_own == 0) continue;
         if (A.smoothed) {
             // smoothed prolongator: t = r - A x_pre, u = c Dinv t; the restriction kernel then forms P^T (t - A u) = Ps^T t
-            hipLaunchKernelGGL(mg_smooth_step_kernel, dim3((unsigned)A.tiles), dim3(CG_BLOCK), 0, st, A, (const double*)A.r, (const double*)A.x, A.t, (const double*)nullptr, (const double*)nullptr, A.u, prolong_scale, stop);
+            hipLaunchKernelGGL(mg_smooth_step_kernel, dim3((unsigned)A.tiles_own), dim3(CG_BLOCK), 0, st, A, (const double*)A.r, (const double*)A.x, A.t, (const double*)nullptr, (const double*)nullptr, A.u, prolong_scale, stop);
             A.r = A.t; A.x = A.u;
         }
-        if (l + 1 == nl) hipLaunchKernelGGL(mg_down_kernel, dim3((unsigned)A.tiles), dim3(CG_BLOCK), 0, st, A, K.rc, (double*)nullptr, (const double*)nullptr, stop);
-        else hipLaunchKernelGGL(mg_down_kernel, dim3((unsigned)A.tiles), dim3(CG_BLOCK), 0, st, A, levels[l].r, levels[l].x, (const double*)levels[l].Dinv, stop);
+        if (l + 1 == nl) hipLaunchKernelGGL(mg_down_kernel, dim3((unsigned)A.tiles_own), dim3(CG_BLOCK), 0, st, A, K.rc, (double*)nullptr, (const double*)nullptr, stop);
+        else hipLaunchKernelGGL(mg_down_kernel, dim3((unsigned)A.tiles_own), dim3(CG_BLOCK), 0, st, A, levels[l].r, levels[l].x, (const double*)levels[l].Dinv, stop);
     }
     // the level below a kernel that prolongs: with a smoothed transition it must receive the bare correction e = P x (xt = 0 + P x), smoothed afterwards
     auto below_of = [&](int idx) { MgLevelDev B = levels[idx]; if (B.smoothed) B.x = const_cast<double*>(B.zero); return B; };
     auto expl_at = [&](int idx) { return idx >= 0 && levels[idx].smoothed && levels[idx].rt_valf != nullptr; };      // that level's up-sweep reads x_next itself: nothing is prolonged into it
+    xchg(0, nl);
+    if (hook_failed) return;
     hipLaunchKernelGGL(mg_dense_solve_kernel, dim3((unsigned)K.n_agg), dim3(384), 0, st, K, nl >= 2 ? below_of(nl - 2) : levels[0], nl >= 2 && !expl_at(nl - 2) ? 1 : 0, scale, stop);
     const bool fused = C.extra_rz > 0;     // level 1's kernel prolongs to the keyframes itself (the solver sets extra_rz = its tile count when that fits the partial-sum slots)
     const unsigned g0 = (unsigned)cg_grid(G);
     for (int l = nl - 1; l >= 1; --l) {
         MgLevelDev A = levels[l - 1];
+        xchg(1, l);
+        if (hook_failed) return;
+        if (A.tiles_own == 0) continue;
         if (expl_at(l - 1)) {      // x = v + s R^T x_next: prolongation and post-smoothing in one launch
             const double* xn = l + 1 == nl ? (const double*)K.yc : (const double*)levels[l].xf;
-            if (l == 1 && fused) hipLaunchKernelGGL(mg_up_kernel<true>, dim3((unsigned)(A.tiles < MAX_PARTIALS ? A.tiles : MAX_PARTIALS)), dim3(CG_BLOCK), 0, st, A, A, 0, scale, stop, M, r, z, part_rz + g0, xn);
-            else hipLaunchKernelGGL(mg_up_kernel<false>, dim3((unsigned)A.tiles), dim3(CG_BLOCK), 0, st, A, l >= 2 ? below_of(l - 2) : levels[0], l >= 2 && !expl_at(l - 2) ? 1 : 0, scale, stop, M, r, z, part_rz, xn);
+            if (l == 1 && fused) hipLaunchKernelGGL(mg_up_kernel<true>, dim3((unsigned)(A.tiles_own < MAX_PARTIALS ? A.tiles_own : MAX_PARTIALS)), dim3(CG_BLOCK), 0, st, A, A, 0, scale, stop, M, r, z, part_rz + g0, xn);
+            else hipLaunchKernelGGL(mg_up_kernel<false>, dim3((unsigned)A.tiles_own), dim3(CG_BLOCK), 0, st, A, l >= 2 ? below_of(l - 2) : levels[0], l >= 2 && !expl_at(l - 2) ? 1 : 0, scale, stop, M, r, z, part_rz, xn);
             continue;
         }
         if (A.smoothed) {
             // y = x_pre + e - c Dinv (A e) = x_pre + Ps x_next ; the post-smoothing kernel then works on y
-            hipLaunchKernelGGL(mg_smooth_step_kernel, dim3((unsigned)A.tiles), dim3(CG_BLOCK), 0, st, A, (const double*)nullptr, (const double*)A.xt, (double*)nullptr, (const double*)A.x, (const double*)A.xt, A.y, prolong_scale, stop);
+            hipLaunchKernelGGL(mg_smooth_step_kernel, dim3((unsigned)A.tiles_own), dim3(CG_BLOCK), 0, st, A, (const double*)nullptr, (const double*)A.xt, (double*)nullptr, (const double*)A.x, (const double*)A.xt, A.y, prolong_scale, stop);
             A.xt = A.y;
         }
-        if (l == 1 && fused) hipLaunchKernelGGL(mg_up_kernel<true>, dim3((unsigned)(A.tiles < MAX_PARTIALS ? A.tiles : MAX_PARTIALS)), dim3(CG_BLOCK), 0, st, A, A, 0, scale, stop, M, r, z, part_rz + g0, (const double*)nullptr);
-        else hipLaunchKernelGGL(mg_up_kernel<false>, dim3((unsigned)A.tiles), dim3(CG_BLOCK), 0, st, A, l >= 2 ? below_of(l - 2) : levels[0], l >= 2 && !expl_at(l - 2) ? 1 : 0, scale, stop, M, r, z, part_rz, (const double*)nullptr);
+        if (l == 1 && fused) hipLaunchKernelGGL(mg_up_kernel<true>, dim3((unsigned)(A.tiles_own < MAX_PARTIALS ? A.tiles_own : MAX_PARTIALS)), dim3(CG_BLOCK), 0, st, A, A, 0, scale, stop, M, r, z, part_rz + g0, (const double*)nullptr);
+        else hipLaunchKernelGGL(mg_up_kernel<false>, dim3((unsigned)A.tiles_own), dim3(CG_BLOCK), 0, st, A, l >= 2 ? below_of(l - 2) : levels[0], l >= 2 && !expl_at(l - 2) ? 1 : 0, scale, stop, M, r, z, part_rz, (const double*)nullptr);
     }
+    xchg(2, 1);
+    if (hook_failed) return;
     if (fine) hipLaunchKernelGGL(mg_prolong0s_kernel, dim3(g0), dim3(CG_BLOCK), 0, st, G, *fine, (const double*)(nl == 1 ? K.yc : levels[0].xf), r, z, part_rz, scale, stop);
     else if (!fused) hipLaunchKernelGGL(mg_prolong0_kernel, dim3(g0), dim3(CG_BLOCK), 0, st, G, M, (const double*)(nl == 1 ? K.yc : levels[0].xf), r, z, part_rz, scale, stop);
 }

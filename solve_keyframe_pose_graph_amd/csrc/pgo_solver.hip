@@ -23,6 +23,7 @@
 #include "pgo.h"
 #include "pgo_internal.hpp"
 #include "pgo_mg_host.hpp"
+#include "pgo_comm_local.hpp"
 
 using namespace pgo;
 
@@ -95,6 +96,10 @@ struct Rccl {
     int (*GetUniqueId)(void*) = nullptr;
     int (*CommInitRank)(void**, int, Uid, int) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;      // ncclSend(buf, count, type, peer, comm, stream)
+    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
     int (*CommDestroy)(void*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
@@ -110,11 +115,17 @@ struct MgPrepared {
     struct Off { size_t col, parent, agg_ptr, tile, tile_rows, rowptr, g_ptr, g_ent, val, Dinv, pos, d, r, x, xt, xf, valf, ps_rowptr, ps_col, w_rowptr, w_col, psT_ptr, psT_ent, ps_val, w_val, t, u, y, zero, row_of, tr_of, ps_row, w_row,
                         rt_rows, rT_rows, rT_col, rT_of_w, ps_of_w, rt_valf, r_valf; int rT_tiles, rT_seg_shift; };
     std::vector<Off> off;
-    size_t o_agg0 = 0, o_mem0_ptr = 0, o_mem0 = 0, o_blk_tab = 0, o_d0 = 0, o_inv = 0, o_q1 = 0, o_s1 = 0;
+    size_t o_agg0 = 0, o_mem0_ptr = 0, o_mem0 = 0, o_blk_tab = 0, o_d0 = 0, o_inv = 0;
     bool have_tab = false;
     // smoothed keyframe transition: the keyframe level F (pgo_mg_host.hpp) — its own block pattern and contribution ids, Ps / W structure, Ps by level-1 row for the restriction
     bool fine = false;
     struct FineOff { size_t rowptr, col, ent, ps_rowptr, ps_col, w_rowptr, w_col, psT_ptr, psT_ent, ps_row, w_row, rT_of_ps, rT_col, rT_rows, val, Dinv, ps_val, w_val, rt_valf, r_valf; int rT_tiles, rT_seg_shift; } fo{};
+    // several ranks: who sends which rows of the level vectors to whom (plans[l]: level l+1; the last: the dense level's residual), and this rank's share of every level
+    std::vector<pgo_mg::ExchangePlan> plans;
+    std::vector<size_t> o_plan_send, o_plan_recv;      // offsets of the plans' index lists in the int32 pool
+    struct Share { int32_t tile0 = 0, tiles_own = 0, rT_row0 = 0, rT_row1 = 0; bool distributed = false; };
+    std::vector<Share> share;
+    int32_t a0 = 0, a1 = 0;                            // the rank's own level-1 aggregates
     std::vector<double> sw_built;          // [Es] s^2 of every switchable edge this hierarchy was matched with
     double moved = 0.0, of_edges = 0.0, host_ms = 0.0;
 };
@@ -140,10 +151,20 @@ struct pgo_problem {
     std::vector<uint8_t> h_touched_any;       // [N_global] some rank holds a residual block on the keyframe
     std::vector<double> h_own;                // [N] 1.0 where this rank is the keyframe's owner (lowest rank touching it)
     std::vector<double> h_init_q, h_init_t;   // multi-GPU: the caller's state at solve_begin (keyframes no rank touches are returned as given)
-    DBuf<int32_t> d_l2g, d_sh_loc, d_sh_pos;  // shared keyframes touched here: local id, position in the global shared list
-    DBuf<int32_t> d_sh_src, d_sh_of;          // the inverse maps: global shared position -> local keyframe or -1; local keyframe -> shared position or -1
-    DBuf<double> d_own, d_xbuf;               // owner weights; exchange buffer
+    std::vector<uint64_t> h_touch_mask;       // [N_global] bit r: rank r holds a residual block on the keyframe (one all-reduce at graph build)
+    std::vector<int32_t> h_owner;             // [N_global] the rank that owns the keyframe: the one holding most of its residual blocks (a second all-reduce), -1: nobody touches it
+    pgo_mg::FinePlan fine_plan;               // the keyframes' neighbour exchange: who shares which keyframes with this rank, and the order their parts are summed in
+    DBuf<int32_t> d_l2g, d_fp_send, d_fp_shloc, d_fp_sumptr, d_fp_sumsrc;
+    DBuf<double> d_own, d_xsend[2], d_xrecv, d_xscal;   // owner weights; send buffers (by collective parity), receive buffer, the iteration's two scalars
     int64_t n_sh_mine = 0, n_sh_global = 0;
+    // multigrid level exchanges (installed with the hierarchy)
+    struct LevelPlanDev { const int32_t* send_idx = nullptr; const int32_t* recv_idx = nullptr; const pgo_mg::ExchangePlan* plan = nullptr; };
+    std::vector<LevelPlanDev> lvl_plan;
+    std::vector<pgo_mg::ExchangePlan> mg_plans;   // several ranks: the installed hierarchy's level plans (their segment bounds are read at every exchange)
+    std::vector<uint8_t> mg_dist;             // per sparse level: its kernels run on the owner's rows only
+    int mg_levels_distributed = 0; int64_t mg_rows_total = 0, mg_rows_own = 0, mg_blocks_total = 0, mg_blocks_own = 0;
+    // exchange accounting (pgo_get_sharding_stats)
+    int64_t st_exchanges = 0, st_allreduces = 0, st_pcg_iterations = 0; double st_bytes_neighbour = 0.0, st_bytes_allreduce = 0.0;
     DBuf<int32_t> d_rc1, d_rc2, d_sc1, d_sc2, d_sidx, d_bsr_col;
     DBuf<double> d_rmeas, d_smeas;
     DBuf<int4> d_rwin, d_swin;
@@ -228,6 +249,9 @@ struct pgo_problem {
     // comm
     Rccl nccl; void* comm = nullptr; int rank = 0, world = 1;
     pgo_allreduce_fn custom_allreduce = nullptr; void* custom_ctx = nullptr;
+    pgo_exchange_fn custom_exchange = nullptr;
+    pgo_local::Group* local_group = nullptr; uint64_t lc_count = 0;      // in-process communicator: collectives issued so far (parity = count & 1)
+    std::vector<int64_t> x_off_send, x_off_recv;                          // scratch: segment bounds in doubles of the exchange in flight
 
     // pipelined convergence polling: pinned host copies of {flags[4], scal[4]} for two chunks in flight
     struct Poll { int32_t flags[4]; double scal[4]; };
@@ -386,7 +410,11 @@ int mg_prepare_impl(pgo_problem* p, const double* sw_now, MgPrepared& Q) {
         for (int64_t g = 0; g < Ng; ++g) gfree[g] = p->h_touched_any[g];
         for (int32_t c : p->constant_nodes) if (c >= 0 && c < Ng) gfree[c] = 0;
         const pgo_mg::LocalContrib local{&p->l2g, &p->h_own, &p->rel.c1, &p->rel.c2, &p->swe.c1, &p->swe.c2};
-        ok = pgo_mg::build_hierarchy(Ng, gfree, grc1, grc2, grw.data(), 1, gsc1, gsc2, (sw_now && S > 0) ? gsw.data() : nullptr, passes0, passes, dense_max, MG_TILE_ROWS, MG_MAX_LEVELS, H, false, 0, &local, n_smoothed, loop_discount, &p->mg_cache);
+        // distributed cycle: aggregates never mix owners, every level is numbered owner-major (pgo_mg_host.hpp: Owners)
+        pgo_mg::Owners OW; OW.touch_mask = &p->h_touch_mask; OW.owner = &p->h_owner; OW.world = p->world; OW.dist_min_rows = p->opt.mg_dist_min_rows > 0 ? p->opt.mg_dist_min_rows : 8192;
+        ok = pgo_mg::build_hierarchy(Ng, gfree, grc1, grc2, grw.data(), 1, gsc1, gsc2, (sw_now && S > 0) ? gsw.data() : nullptr, passes0, passes, dense_max, MG_TILE_ROWS, MG_MAX_LEVELS, H, false, 0, &local, n_smoothed, loop_discount, &p->mg_cache,
+                                     nullptr, nullptr, p->world > 1 ? &OW : nullptr);
+        if (ok && p->world > 1) pgo_mg::build_level_plans(H, OW, p->rank, Q.plans);
         if (ok) {
             const int32_t n1g = (int32_t)H.mem0_ptr.size() - 1;
             inv_cnt.resize((size_t)n1g);
@@ -405,6 +433,18 @@ int mg_prepare_impl(pgo_problem* p, const double* sw_now, MgPrepared& Q) {
     const std::vector<int32_t>& M0P = p->local_ids ? mem0_ptr_l : H.mem0_ptr;
     const std::vector<int32_t>& M0 = p->local_ids ? mem0_l : H.mem0;
     const int nl = (int)H.L.size();
+    // this rank's share of every sparse level (one GPU, and levels every rank runs completely: all of it)
+    const bool dist = H.world > 1;
+    Q.share.assign((size_t)nl, MgPrepared::Share{});
+    for (int l = 0; l + 1 < nl; ++l) {
+        const pgo_mg::HostLevel& A = H.L[(size_t)l];
+        MgPrepared::Share& sh = Q.share[(size_t)l];
+        const int32_t tiles = A.tile_agg0.empty() ? 0 : (int32_t)A.tile_agg0.size() - 1;
+        sh.distributed = dist && A.distributed;
+        if (sh.distributed) { sh.tile0 = A.tile_ptr[(size_t)p->rank]; sh.tiles_own = A.tile_ptr[(size_t)p->rank + 1] - sh.tile0; sh.rT_row0 = H.L[(size_t)l + 1].own_ptr[(size_t)p->rank]; sh.rT_row1 = H.L[(size_t)l + 1].own_ptr[(size_t)p->rank + 1]; }
+        else { sh.tile0 = 0; sh.tiles_own = tiles; sh.rT_row0 = 0; sh.rT_row1 = H.L[(size_t)l + 1].n; }
+    }
+    Q.a0 = dist ? H.L[0].own_ptr[(size_t)p->rank] : 0; Q.a1 = dist ? H.L[0].own_ptr[(size_t)p->rank + 1] : H.L[0].n;
     // pooled arrays: (offset, count) per array; doubles rounded up to even counts (16-B loads)
     std::vector<int32_t>& pi32 = Q.pi32; std::vector<int64_t>& pi64 = Q.pi64;
     {   // one allocation per pool (the arrays are appended one by one: without the reservation the 10-MB pools are reallocated and copied a dozen times)
@@ -454,7 +494,7 @@ int mg_prepare_impl(pgo_problem* p, const double* sw_now, MgPrepared& Q) {
     Q.have_tab = have_tab;
     Q.o_d0 = take((size_t)N * 3);
     const size_t n1_all = (size_t)H.L[0].n;
-    Q.o_inv = p->local_ids ? take(n1_all) : 0; Q.o_q1 = p->local_ids ? take(n1_all * 6) : 0; Q.o_s1 = p->local_ids ? take(n1_all * 6) : 0;
+    Q.o_inv = p->local_ids ? take(n1_all) : 0;
     for (int l = 0; l < nl; ++l) {
         const pgo_mg::HostLevel& A = H.L[l];
         MgPrepared::Off& o = Q.off[l];
@@ -517,16 +557,18 @@ int mg_prepare_impl(pgo_problem* p, const double* sw_now, MgPrepared& Q) {
                 o.rt_rows = put32(rows);
                 o.rT_seg_shift = A.rT_seg >= 8 ? 3 : A.rT_seg >= 4 ? 2 : A.rT_seg >= 2 ? 1 : 0;
                 const int rpt = MG_TILE_ROWS >> o.rT_seg_shift;
-                const int32_t nb = (int32_t)A.rT_rowptr.size() - 1;
-                o.rT_tiles = (nb + rpt - 1) / rpt;
+                const int32_t nb0 = Q.share[(size_t)l].rT_row0, nb = Q.share[(size_t)l].rT_row1;      // (several ranks: the restriction's tiles cover the rank's own coarse rows)
+                o.rT_tiles = (nb - nb0 + rpt - 1) / rpt;
                 rows.clear();
                 for (int tt = 0; tt < o.rT_tiles; ++tt)
-                    for (int li = 0; li < MG_TILE_ROWS; ++li) { const int32_t r = tt * rpt + li; const bool in = li < rpt && r < nb; rows.push_back(in ? A.rT_rowptr[r] : 0); rows.push_back(in ? A.rT_rowptr[(size_t)r + 1] : 0); }
+                    for (int li = 0; li < MG_TILE_ROWS; ++li) { const int32_t r = nb0 + tt * rpt + li; const bool in = li < rpt && r < nb; rows.push_back(in ? A.rT_rowptr[r] : 0); rows.push_back(in ? A.rT_rowptr[(size_t)r + 1] : 0); }
                 o.rT_rows = put32(rows);
                 o.rt_valf = take((A.w_col.size() * 36 + 1) / 2); o.r_valf = take((A.w_col.size() * 36 + 1) / 2);
             }
         }
     }
+    Q.o_plan_send.assign(Q.plans.size(), 0); Q.o_plan_recv.assign(Q.plans.size(), 0);
+    for (size_t l = 0; l < Q.plans.size(); ++l) { Q.o_plan_send[l] = put32(Q.plans[l].send_idx); Q.o_plan_recv[l] = put32(Q.plans[l].recv_idx); }
     Q.fine = H.fine_smoothed;
     if (Q.fine) {
         const pgo_mg::HostLevel& F = H.F;
@@ -565,11 +607,21 @@ int mg_prepare_impl(pgo_problem* p, const double* sw_now, MgPrepared& Q) {
     return PGO_OK;
 }
 
+// several ranks: send / receive buffers for the largest exchange of the handle — 42 doubles per row of the keyframes' plan (diagonal block + gradient), 12 per row of a
+// level plan (x and r of a level travel together).  Two send buffers: the in-process communicator double-buffers by collective parity.
+int ensure_exchange_buffers(pgo_problem* p) {
+    if (!p->local_ids) return PGO_OK;
+    size_t ns = (size_t)p->fine_plan.x.n_send() * 42, nr = (size_t)p->fine_plan.x.n_recv() * 42;
+    for (const pgo_problem::LevelPlanDev& L : p->lvl_plan) if (L.plan) { ns = std::max(ns, (size_t)L.plan->n_send() * 12); nr = std::max(nr, (size_t)L.plan->n_recv() * 12); }
+    HIPCHK(p, p->d_xsend[0].ensure(ns + 64)); HIPCHK(p, p->d_xsend[1].ensure(ns + 64)); HIPCHK(p, p->d_xrecv.ensure(nr + 64)); HIPCHK(p, p->d_xscal.ensure(16));
+    return PGO_OK;
+}
+
 // device half: pools (re)allocated, index arrays uploaded, level descriptors filled.  The stream must not be running multigrid kernels of the previous hierarchy.
 int mg_install(pgo_problem* p, MgPrepared& Q) {
     const int64_t N = p->N;
     p->coarse_built = false; p->coarse_active = false; p->K = CoarseDev{};
-    p->mg_built = false; p->mg_active = false; p->M = MgDev{}; p->mg_geometry_epoch = 0;
+    p->mg_built = false; p->mg_active = false; p->M = MgDev{}; p->mg_geometry_epoch = 0; p->lvl_plan.clear();
     if (!Q.ok) { if (p->opt.verbosity > 0) std::fprintf(stderr, "[pgo] multigrid: the graph does not coarsen (isolated keyframes?) -> off\n"); return PGO_OK; }
     const pgo_mg::Hierarchy& H = Q.H;
     const int nl = (int)H.L.size();
@@ -584,12 +636,15 @@ int mg_install(pgo_problem* p, MgPrepared& Q) {
     HIPCHK(p, hipMemsetAsync(p->d_crc.p, 0, (size_t)nc * 2 * sizeof(double), p->st));
     HIPCHK(p, hipStreamSynchronize(p->st));
     const int32_t* b32 = p->d_mg_i32.p; const int64_t* b64 = p->d_mg_i64.p; double* bf = p->d_mg_f64.p;
-    p->M = MgDev{nl, H.L[0].n, b32 + Q.o_agg0, b32 + Q.o_mem0_ptr, b32 + Q.o_mem0, bf + Q.o_d0, Q.have_tab ? reinterpret_cast<const int4*>(b32 + Q.o_blk_tab) : nullptr, nullptr, nullptr, nullptr};
+    p->M = MgDev{nl, H.L[0].n, b32 + Q.o_agg0, b32 + Q.o_mem0_ptr, b32 + Q.o_mem0, bf + Q.o_d0, Q.have_tab ? reinterpret_cast<const int4*>(b32 + Q.o_blk_tab) : nullptr, nullptr, Q.a0, Q.a1};
     if (p->local_ids) {
         HIPCHK(p, hipMemcpyAsync(bf + Q.o_inv, Q.inv_cnt.data(), Q.inv_cnt.size() * sizeof(double), hipMemcpyHostToDevice, p->st));
         HIPCHK(p, hipStreamSynchronize(p->st));
-        p->M.inv_cnt = bf + Q.o_inv; p->M.q1 = bf + Q.o_q1; p->M.s1 = bf + Q.o_s1;
+        p->M.inv_cnt = bf + Q.o_inv;
     }
+    p->mg_levels_distributed = 0; p->mg_rows_total = p->mg_rows_own = p->mg_blocks_total = p->mg_blocks_own = 0;
+    p->mg_dist.assign((size_t)nl, 0);
+    for (int l = 0; l + 1 < nl; ++l) p->mg_dist[(size_t)l] = Q.share[(size_t)l].distributed ? 1 : 0;
     for (int l = 0; l < nl; ++l) {
         const pgo_mg::HostLevel& A = H.L[l];
         const MgPrepared::Off& o = Q.off[l];
@@ -602,12 +657,28 @@ int mg_install(pgo_problem* p, MgPrepared& Q) {
         D.row_of = b32 + o.row_of; D.tr_of = b32 + o.tr_of;
         D.seg_shift = A.seg >= 8 ? 3 : A.seg >= 4 ? 2 : A.seg >= 2 ? 1 : 0;
         D.pad3_ = l;      // (the level's index: read by the timeline variant build only)
+        {   // the cycle's share of the level (several ranks: the owner's rows; else all of it)
+            const MgPrepared::Share& sh = Q.share[(size_t)l];
+            D.tile0 = sh.tile0; D.tiles_own = l + 1 < nl ? sh.tiles_own : 0; D.rT_row0 = sh.rT_row0; D.rT_row1 = l + 1 < nl ? sh.rT_row1 : 0;
+            if (l + 1 < nl) {
+                if (sh.distributed) ++p->mg_levels_distributed;
+                const int64_t blocks = (int64_t)A.col.size() + (A.smoothed ? 2 * (int64_t)A.w_col.size() : 0);
+                int64_t own_rows = A.n, own_blocks = blocks;
+                if (sh.distributed) {
+                    const int32_t r0 = A.own_ptr[(size_t)p->rank], r1 = A.own_ptr[(size_t)p->rank + 1];
+                    own_rows = r1 - r0;
+                    own_blocks = A.rowptr[(size_t)r1] - A.rowptr[(size_t)r0];
+                    if (A.smoothed) own_blocks += (int64_t)(A.w_rowptr[(size_t)r1] - A.w_rowptr[(size_t)r0]) + (int64_t)(A.rT_rowptr[(size_t)sh.rT_row1] - A.rT_rowptr[(size_t)sh.rT_row0]);
+                }
+                p->mg_rows_total += A.n; p->mg_rows_own += own_rows; p->mg_blocks_total += blocks; p->mg_blocks_own += own_blocks;
+            }
+        }
         if (A.smoothed) {
             D.smoothed = 1; D.n_ps = (int32_t)A.ps_col.size(); D.n_w = (int32_t)A.w_col.size();
             D.ps_rowptr = b32 + o.ps_rowptr; D.ps_col = b32 + o.ps_col; D.w_rowptr = b32 + o.w_rowptr; D.w_col = b32 + o.w_col; D.psT_ptr = b64 + o.psT_ptr; D.psT_ent = b64 + o.psT_ent;
             D.ps_row = b32 + o.ps_row; D.w_row = b32 + o.w_row;
             D.ps_val = bf + o.ps_val; D.w_val = bf + o.w_val; D.t = bf + o.t; D.u = bf + o.u; D.y = bf + o.y; D.zero = bf + o.zero;
-            if (p->opt.mg_explicit_transfer != 0) {
+            if (p->opt.mg_explicit_transfer != 0 || p->local_ids) {      // (several ranks: always the explicit form — the implicit one would need two more exchanges per level)
                 D.rt_valf = reinterpret_cast<float*>(bf + o.rt_valf); D.r_valf = reinterpret_cast<float*>(bf + o.r_valf);
                 D.rt_rows = reinterpret_cast<const int2*>(b32 + o.rt_rows); D.rT_rows = reinterpret_cast<const int2*>(b32 + o.rT_rows);
                 D.rT_col = b32 + o.rT_col; D.rT_of_w = b32 + o.rT_of_w; D.ps_of_w = b32 + o.ps_of_w;
@@ -621,6 +692,7 @@ int mg_install(pgo_problem* p, MgPrepared& Q) {
         const MgPrepared::FineOff& o = Q.fo;
         MgLevelDev& F = p->mg_fineF;
         F.n = Fh.n; F.n_next = H.L[0].n; F.tiles = 0; F.nnzb = (int64_t)Fh.col.size();
+        F.tile0 = 0; F.tiles_own = 0; F.rT_row0 = 0; F.rT_row1 = H.L[0].n;      // (one GPU: the restriction covers every level-1 row)
         F.rowptr = b64 + o.rowptr; F.col = b32 + o.col; F.val = bf + o.val; F.g_ent = b64 + o.ent; F.Dinv = bf + o.Dinv;
         F.d = p->M.d0; F.parent = p->M.agg0;
         F.smoothed = 1; F.n_ps = (int32_t)Fh.ps_col.size(); F.n_w = (int32_t)Fh.w_col.size();
@@ -642,13 +714,12 @@ int mg_install(pgo_problem* p, MgPrepared& Q) {
         for (int l = 0; l < nl; ++l) std::fprintf(stderr, " -> %d (%lld blocks%s)", H.L[l].n, (long long)H.L[l].col.size(), H.L[l].smoothed ? ", smoothed prolongator above" : "");
         std::fprintf(stderr, ", coarsest dense %d (host %.1f ms)\n", nc, Q.host_ms);
     }
-    if (p->local_ids) {
-        // the exchange buffer is sized here once for everything a solve sends (42 doubles per shared keyframe at linearisation; 6 + the level-1 vector in the PCG),
-        // so its address is stable: the multigrid's q1 = P0^T (A u) is produced straight into its tail
-        const size_t n1 = (size_t)p->M.n1;
-        HIPCHK(p, p->d_xbuf.ensure((size_t)p->n_sh_global * 42 + 2 + 6 * n1 + 64));
-        p->M.q1 = p->d_xbuf.p + (size_t)p->n_sh_global * 6 + 2;
-    }
+    // several ranks: the level exchanges' index lists live in the int32 pool; the segment bounds stay on the host (p->mg_plans)
+    p->mg_plans.swap(Q.plans);
+    p->lvl_plan.assign(p->mg_plans.size(), pgo_problem::LevelPlanDev{});
+    for (size_t l = 0; l < p->mg_plans.size(); ++l) p->lvl_plan[l] = pgo_problem::LevelPlanDev{b32 + Q.o_plan_send[l], b32 + Q.o_plan_recv[l], &p->mg_plans[l]};
+    int rcx;
+    if ((rcx = ensure_exchange_buffers(p)) != PGO_OK) return rcx;
     return PGO_OK;
 }
 
@@ -709,13 +780,13 @@ int build_multigrid(pgo_problem* p, const double* sw_now, MgPrepared* ready) {
     int rc;
     mg_job_cancel(p);
     p->coarse_built = false; p->coarse_active = false; p->K = CoarseDev{};
-    p->mg_built = false; p->mg_active = false; p->M = MgDev{}; p->mg_geometry_epoch = 0;
+    p->mg_built = false; p->mg_active = false; p->M = MgDev{}; p->mg_geometry_epoch = 0; p->lvl_plan.clear();
     if (wants_multigrid(p)) {
         MgPrepared Q;
         if (!ready && (rc = mg_prepare(p, sw_now, Q)) != PGO_OK) return rc;
         if ((rc = mg_install(p, ready ? *ready : Q)) != PGO_OK) return rc;
     }
-    if (p->local_ids && !p->mg_built) HIPCHK(p, p->d_xbuf.ensure((size_t)p->n_sh_global * 42 + 2 + 64));
+    if (p->local_ids && !p->mg_built) { p->lvl_plan.clear(); if ((rc = ensure_exchange_buffers(p)) != PGO_OK) return rc; }
     return PGO_OK;
 }
 
@@ -801,56 +872,59 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
     // ---- multi-GPU: rank-local subgraph.  This rank works on the keyframes its own residual blocks touch, renumbered densely; keyframes
     // touched by >= 2 ranks are "shared" (their rows are summed over ranks by exchange_rows), the lowest touching rank is the owner.
     const int64_t Ng = N;
-    p->local_ids = p->comm != nullptr || p->custom_allreduce != nullptr;   // also with a 1-rank communicator: the same code path, every collective issued
+    p->local_ids = p->comm != nullptr || p->custom_allreduce != nullptr || p->local_group != nullptr;   // also with a 1-rank communicator: the same code path, every collective issued
     p->n_sh_mine = p->n_sh_global = 0;
     if (p->local_ids) {
         std::vector<uint8_t> touched((size_t)Ng, 0);
-        for (const HostClass* H : {&p->rel, &p->swe}) for (int64_t e = 0; e < H->size(); ++e) { touched[H->c1[e]] = 1; touched[H->c2[e]] = 1; }
-        for (const PriorDev& pr : p->priors) touched[pr.node] = 1;
+        std::vector<int32_t> deg((size_t)Ng, 0);      // residual blocks of THIS rank on each keyframe
+        for (const HostClass* H : {&p->rel, &p->swe}) for (int64_t e = 0; e < H->size(); ++e) { touched[H->c1[e]] = 1; touched[H->c2[e]] = 1; ++deg[H->c1[e]]; ++deg[H->c2[e]]; }
+        for (const PriorDev& pr : p->priors) { touched[pr.node] = 1; ++deg[pr.node]; }
         bool any = false;
         for (int64_t g = 0; g < Ng && !any; ++g) any = touched[g] != 0;
         if (!any) touched[0] = 1;   // a rank without residual blocks still takes part in every collective: give it one (zero-contribution) keyframe
-        // two all-reduces of Ng doubles, once per graph build: how many ranks touch each keyframe, and the lowest of them
-        std::vector<double> buf((size_t)2 * Ng);
-        for (int64_t g = 0; g < Ng; ++g) { buf[g] = touched[g] ? 1.0 : 0.0; buf[Ng + g] = touched[g] ? (double)(p->world - p->rank) : 0.0; }
-        HIPCHK(p, p->d_tmp.ensure((size_t)2 * Ng));
-        HIPCHK(p, hipMemcpyAsync(p->d_tmp.p, buf.data(), (size_t)2 * Ng * sizeof(double), hipMemcpyHostToDevice, p->st));
+        // Two all-reduces of Ng doubles, once per graph build.  Sum: every rank adds 2^rank for the keyframes it touches — the set of touching ranks (exact in a double up to
+        // 52 ranks): how many they are, and who exchanges the keyframe's rows with whom.  Max of (blocks + 1) * 64 + 63 - rank: the OWNER — the rank holding most of the
+        // keyframe's residual blocks, the lowest of them on a tie (pgo_mg_host.hpp: Owners).
+        if (p->world > 52) { p->err = "more than 52 ranks"; return PGO_ERR_INVALID_ARG; }
+        std::vector<double> buf((size_t)Ng), obuf((size_t)Ng);
+        for (int64_t g = 0; g < Ng; ++g) { buf[g] = touched[g] ? std::ldexp(1.0, p->rank) : 0.0; obuf[g] = touched[g] ? (double)(((int64_t)deg[g] + 1) * 64 + 63 - p->rank) : 0.0; }
         int rc2;
-        if ((rc2 = allreduce(p, p->d_tmp.p, (size_t)Ng, 0)) != PGO_OK) return rc2;
-        if ((rc2 = allreduce(p, p->d_tmp.p + Ng, (size_t)Ng, 2 /*max*/)) != PGO_OK) return rc2;
-        HIPCHK(p, hipMemcpyAsync(buf.data(), p->d_tmp.p, (size_t)2 * Ng * sizeof(double), hipMemcpyDeviceToHost, p->st));
-        HIPCHK(p, hipStreamSynchronize(p->st));
+        if ((rc2 = host_allreduce(p, buf, 0)) != PGO_OK) return rc2;
+        if ((rc2 = host_allreduce(p, obuf, 2)) != PGO_OK) return rc2;
+        p->h_touch_mask.assign((size_t)Ng, 0); p->h_owner.assign((size_t)Ng, -1);
         p->l2g.clear(); p->g2l.assign((size_t)Ng, -1); p->h_own.clear(); p->h_touched_any.assign((size_t)Ng, 0);
-        std::vector<int32_t> sh_loc, sh_pos;
-        int64_t pos = 0;
+        int64_t pos = 0, n_mine = 0;
         for (int64_t g = 0; g < Ng; ++g) {
-            const int cnt = (int)(buf[g] + 0.5);
+            const uint64_t m = (uint64_t)(buf[g] + 0.5);
+            p->h_touch_mask[g] = m;
+            const int cnt = __builtin_popcountll(m);
+            if (m) { p->h_owner[g] = 63 - (int32_t)((int64_t)(obuf[g] + 0.5) % 64); if (!((m >> p->h_owner[g]) & 1)) { p->err = "graph build: a keyframe's owner does not touch it (the ranks' all-reduces disagree)"; return PGO_ERR_COMM; } }
             p->h_touched_any[g] = cnt > 0;
             if (touched[g]) {
-                const int owner = p->world - (int)(buf[Ng + g] + 0.5);
+                if (!((m >> p->rank) & 1)) { p->err = "touch masks: the all-reduce did not return this rank's own bit"; return PGO_ERR_COMM; }
                 p->g2l[g] = (int32_t)p->l2g.size();
-                if (cnt >= 2) { sh_loc.push_back((int32_t)p->l2g.size()); sh_pos.push_back((int32_t)pos); }
+                if (cnt >= 2) ++n_mine;
                 p->l2g.push_back((int32_t)g);
-                p->h_own.push_back(owner == p->rank ? 1.0 : 0.0);
+                p->h_own.push_back(p->h_owner[g] == p->rank ? 1.0 : 0.0);
             }
             if (cnt >= 2) ++pos;
         }
-        p->n_sh_global = pos; p->n_sh_mine = (int64_t)sh_loc.size();
+        p->n_sh_global = pos; p->n_sh_mine = n_mine;
         N = (int64_t)p->l2g.size();
-        HIPCHK(p, p->d_l2g.ensure(N)); HIPCHK(p, p->d_own.ensure(N)); HIPCHK(p, p->d_sh_loc.ensure(std::max<int64_t>(p->n_sh_mine, 1))); HIPCHK(p, p->d_sh_pos.ensure(std::max<int64_t>(p->n_sh_mine, 1)));
+        HIPCHK(p, p->d_l2g.ensure(N)); HIPCHK(p, p->d_own.ensure(N));
         HIPCHK(p, hipMemcpyAsync(p->d_l2g.p, p->l2g.data(), N * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
         HIPCHK(p, hipMemcpyAsync(p->d_own.p, p->h_own.data(), N * sizeof(double), hipMemcpyHostToDevice, p->st));
-        if (p->n_sh_mine) {
-            HIPCHK(p, hipMemcpyAsync(p->d_sh_loc.p, sh_loc.data(), p->n_sh_mine * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
-            HIPCHK(p, hipMemcpyAsync(p->d_sh_pos.p, sh_pos.data(), p->n_sh_mine * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
-        }
-        {   // the PCG iteration packs and reads the exchange buffer without pack / unpack kernels of its own (cgcg_pack_kernel, cgcg_update_kernel)
-            std::vector<int32_t> sh_src((size_t)std::max<int64_t>(p->n_sh_global, 1), -1), sh_of((size_t)std::max<int64_t>(N, 1), -1);
-            for (int64_t j = 0; j < p->n_sh_mine; ++j) { sh_src[sh_pos[j]] = sh_loc[j]; sh_of[sh_loc[j]] = sh_pos[j]; }
-            HIPCHK(p, p->d_sh_src.ensure(sh_src.size())); HIPCHK(p, p->d_sh_of.ensure(sh_of.size()));
-            HIPCHK(p, hipMemcpyAsync(p->d_sh_src.p, sh_src.data(), sh_src.size() * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
-            HIPCHK(p, hipMemcpyAsync(p->d_sh_of.p, sh_of.data(), sh_of.size() * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
-            HIPCHK(p, hipStreamSynchronize(p->st));
+        {   // the keyframes' neighbour exchange: segments per peer, and for every shared keyframe the order its parts are summed in (pgo_mg_host.hpp: build_fine_plan)
+            pgo_mg::build_fine_plan(p->h_touch_mask, p->l2g, p->rank, p->world, p->fine_plan);
+            const pgo_mg::FinePlan& F = p->fine_plan;
+            auto up = [&](DBuf<int32_t>& d, const std::vector<int32_t>& v) -> int {
+                HIPCHK(p, d.ensure(std::max<size_t>(v.size(), 1)));
+                if (!v.empty()) HIPCHK(p, hipMemcpyAsync(d.p, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice, p->st));
+                return PGO_OK;
+            };
+            if ((rc2 = up(p->d_fp_send, F.x.send_idx)) != PGO_OK || (rc2 = up(p->d_fp_shloc, F.sh_loc)) != PGO_OK || (rc2 = up(p->d_fp_sumptr, F.sum_ptr)) != PGO_OK || (rc2 = up(p->d_fp_sumsrc, F.sum_src)) != PGO_OK) return rc2;
+            p->lvl_plan.clear();
+            if ((rc2 = ensure_exchange_buffers(p)) != PGO_OK) return rc2;
         }
         HIPCHK(p, hipStreamSynchronize(p->st));
         G.own = p->d_own.p;
@@ -1108,7 +1182,45 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
 }
 
 // ---- collectives (no-ops without a communicator; a 1-rank communicator still issues every call) ----
+// in-process communicator (pgo_comm_local.hpp): step 1 of its protocol — the parity buffers of this collective may be overwritten once the peers' reads of two collectives ago are done
+int local_pre(pgo_problem* p) {
+    pgo_local::Group* G = p->local_group;
+    const int par = (int)(p->lc_count & 1);
+    for (int q = 0; q < G->world; ++q) if (q != p->rank && G->slot[q].done[par]) HIPCHK(p, hipStreamWaitEvent(p->st, G->slot[q].done[par], 0));
+    return PGO_OK;
+}
+int local_allreduce(pgo_problem* p, double* buf, size_t n, int op) {
+    pgo_local::Group* G = p->local_group;
+    pgo_local::Group::Slot& me = G->slot[p->rank];
+    const int par = (int)(p->lc_count & 1);
+    int rc;
+    if ((rc = local_pre(p)) != PGO_OK) return rc;
+    if (me.stage_cap[par] < n) {
+        HIPCHK(p, hipStreamSynchronize(p->st));
+        if (me.stage[par]) (void)hipFree(me.stage[par]);
+        me.stage[par] = nullptr; me.stage_cap[par] = 0;
+        const size_t want = n + n / 4 + 64;
+        HIPCHK(p, hipMalloc((void**)&me.stage[par], want * sizeof(double)));
+        me.stage_cap[par] = want;
+    }
+    HIPCHK(p, hipMemcpyAsync(me.stage[par], buf, n * sizeof(double), hipMemcpyDeviceToDevice, p->st));
+    HIPCHK(p, hipEventRecord(me.ready[par], p->st));
+    me.ptr[par] = me.stage[par];
+    if (!G->barrier()) { p->err = "in-process communicator: a rank did not reach the collective (failed, left, or out of step)"; return PGO_ERR_COMM; }
+    LocalPeers P{};
+    P.n = G->world;
+    for (int q = 0; q < G->world; ++q) {
+        P.src[q] = G->slot[q].ptr[par]; P.off[q] = 0; P.cnt[q] = (int64_t)n;
+        if (q != p->rank) HIPCHK(p, hipStreamWaitEvent(p->st, G->slot[q].ready[par], 0));
+    }
+    launch_local_reduce(buf, P, (int64_t)n, op, p->st);
+    HIPCHK(p, hipEventRecord(me.done[par], p->st));
+    ++p->lc_count;
+    return PGO_OK;
+}
 int allreduce(pgo_problem* p, double* buf, size_t n, int op /*0 sum, 2 max*/) {
+    if (p->local_ids || p->comm || p->custom_allreduce || p->local_group) { ++p->st_allreduces; p->st_bytes_allreduce += (double)n * sizeof(double); }
+    if (p->local_group) return local_allreduce(p, buf, n, op);
     if (p->custom_allreduce) {
         const int rc = p->custom_allreduce(p->custom_ctx, buf, (int64_t)n, op, (void*)p->st);
         if (rc != 0) { p->err = "custom all-reduce callback failed"; return PGO_ERR_COMM; }
@@ -1120,27 +1232,110 @@ int allreduce(pgo_problem* p, double* buf, size_t n, int op /*0 sum, 2 max*/) {
     return PGO_OK;
 }
 
-// Multi-GPU exchange: sums, over the ranks sharing them, the rows of one or two keyframe-indexed device arrays (k1 + k2 doubles per
-// keyframe) and `n_extra` scalars (summed over ALL ranks, in place at `extra`) with ONE all-reduce of n_shared*(k1+k2) + n_extra doubles.
-// Keyframes touched by a single rank never travel.
-// `extra2` / `n_extra2`: a second block summed over all ranks in the same all-reduce (the level-1 vector P0^T (A u) of the multigrid-preconditioned PCG).
-int exchange_rows(pgo_problem* p, double* a1, int k1, double* a2, int k2, double* extra, int n_extra, const int32_t* stop = nullptr, double* extra2 = nullptr, size_t n_extra2 = 0) {
-    if (!p->local_ids) return PGO_OK;
-    const int K = k1 + k2;
-    const size_t n = (size_t)p->n_sh_global * K;
-    if (n + n_extra + n_extra2 == 0) return PGO_OK;
-    HIPCHK(p, p->d_xbuf.ensure(n + n_extra + n_extra2));
-    if (n) HIPCHK(p, hipMemsetAsync(p->d_xbuf.p, 0, n * sizeof(double), p->st));
-    launch_pack_rows(p->d_xbuf.p, K, 0, a1, k1, p->n_sh_mine, p->d_sh_loc.p, p->d_sh_pos.p, p->st);
-    if (a2) launch_pack_rows(p->d_xbuf.p, K, k1, a2, k2, p->n_sh_mine, p->d_sh_loc.p, p->d_sh_pos.p, p->st);
-    if (n_extra) HIPCHK(p, hipMemcpyAsync(p->d_xbuf.p + n, extra, n_extra * sizeof(double), hipMemcpyDeviceToDevice, p->st));
-    if (n_extra2) HIPCHK(p, hipMemcpyAsync(p->d_xbuf.p + n + n_extra, extra2, n_extra2 * sizeof(double), hipMemcpyDeviceToDevice, p->st));
+// The send buffer of the exchange about to be packed (the in-process communicator double-buffers by collective parity and first waits for the peers' reads of that buffer)
+int exchange_send_buffer(pgo_problem* p, double** out) {
     int rc;
-    if ((rc = allreduce(p, p->d_xbuf.p, n + n_extra + n_extra2, 0)) != PGO_OK) return rc;
-    launch_unpack_rows(p->d_xbuf.p, K, 0, a1, k1, p->n_sh_mine, p->d_sh_loc.p, p->d_sh_pos.p, stop, p->st);
-    if (a2) launch_unpack_rows(p->d_xbuf.p, K, k1, a2, k2, p->n_sh_mine, p->d_sh_loc.p, p->d_sh_pos.p, stop, p->st);
-    if (n_extra) HIPCHK(p, hipMemcpyAsync(extra, p->d_xbuf.p + n, n_extra * sizeof(double), hipMemcpyDeviceToDevice, p->st));
-    if (n_extra2) HIPCHK(p, hipMemcpyAsync(extra2, p->d_xbuf.p + n + n_extra, n_extra2 * sizeof(double), hipMemcpyDeviceToDevice, p->st));
+    if (p->local_group && (rc = local_pre(p)) != PGO_OK) return rc;
+    *out = p->d_xsend[p->local_group ? (p->lc_count & 1) : 0].p;
+    return PGO_OK;
+}
+// Neighbour exchange of `K` doubles per row: rows [plan.send_off[q], plan.send_off[q+1]) of `sendbuf` go to rank q, rows [recv_off[q], recv_off[q+1]) of `recvbuf` come from it.
+// RCCL: one group of ncclSend / ncclRecv pairs (point-to-point over the xGMI link of each pair).  In-process communicator: one kernel reading the peers' send buffers.
+// Caller-supplied collective: its exchange callback, or — without one — an all-reduce of a zero-padded buffer that holds every pair's segment (correct, world x the bytes).
+int neighbor_exchange(pgo_problem* p, const pgo_mg::ExchangePlan& X, int K, const double* sendbuf, double* recvbuf) {
+    const int W = p->world, r = p->rank;
+    ++p->st_exchanges; p->st_bytes_neighbour += (double)X.n_send() * K * sizeof(double);
+    if (p->local_group) {
+        pgo_local::Group* G = p->local_group;
+        pgo_local::Group::Slot& me = G->slot[r];
+        const int par = (int)(p->lc_count & 1);
+        HIPCHK(p, hipEventRecord(me.ready[par], p->st));
+        me.ptr[par] = sendbuf; me.send_off[par] = X.send_off.data();
+        if (!G->barrier()) { p->err = "in-process communicator: a rank did not reach the exchange (failed, left, or out of step)"; return PGO_ERR_COMM; }
+        LocalPeers P{};
+        int np = 0;
+        for (int q = 0; q < W; ++q) {
+            const int64_t cnt = (X.recv_off[(size_t)q + 1] - X.recv_off[(size_t)q]) * K;
+            if (q == r || cnt == 0) continue;
+            const int64_t* so = G->slot[q].send_off[par];
+            if ((so[r + 1] - so[r]) * K != cnt) { G->abort(); p->err = "in-process communicator: the ranks' exchange plans disagree"; return PGO_ERR_COMM; }
+            HIPCHK(p, hipStreamWaitEvent(p->st, G->slot[q].ready[par], 0));
+            P.src[np] = G->slot[q].ptr[par] + so[r] * K; P.off[np] = X.recv_off[(size_t)q] * K; P.cnt[np] = cnt; ++np;
+        }
+        P.n = np;
+        if (np > 0) launch_local_copy(recvbuf, P, p->st);
+        HIPCHK(p, hipEventRecord(me.done[par], p->st));
+        ++p->lc_count;
+        return PGO_OK;
+    }
+    if (p->custom_allreduce && p->custom_exchange) {
+        p->x_off_send.resize((size_t)W + 1); p->x_off_recv.resize((size_t)W + 1);
+        for (int q = 0; q <= W; ++q) { p->x_off_send[(size_t)q] = X.send_off[(size_t)q] * K; p->x_off_recv[(size_t)q] = X.recv_off[(size_t)q] * K; }
+        const int rc = p->custom_exchange(p->custom_ctx, sendbuf, p->x_off_send.data(), recvbuf, p->x_off_recv.data(), (void*)p->st);
+        if (rc != 0) { p->err = "custom exchange callback failed"; return PGO_ERR_COMM; }
+        return PGO_OK;
+    }
+    if (p->custom_allreduce) {
+        // emulation: [src][dst] segments in one buffer; this rank fills row `r`, the all-reduce fills the rest, column `r` is what it receives
+        std::vector<int64_t> off((size_t)W * W + 1, 0);
+        for (int i = 0; i < W * W; ++i) off[(size_t)i + 1] = off[(size_t)i] + X.pair_cnt[(size_t)i] * K;
+        const size_t total = (size_t)off[(size_t)W * W];
+        if (total == 0) return PGO_OK;
+        HIPCHK(p, p->d_tmp.ensure(total));
+        HIPCHK(p, hipMemsetAsync(p->d_tmp.p, 0, total * sizeof(double), p->st));
+        for (int q = 0; q < W; ++q) { const int64_t cnt = (X.send_off[(size_t)q + 1] - X.send_off[(size_t)q]) * K; if (cnt > 0) HIPCHK(p, hipMemcpyAsync(p->d_tmp.p + off[(size_t)r * W + q], sendbuf + X.send_off[(size_t)q] * K, (size_t)cnt * sizeof(double), hipMemcpyDeviceToDevice, p->st)); }
+        const int rc = p->custom_allreduce(p->custom_ctx, p->d_tmp.p, (int64_t)total, 0, (void*)p->st);
+        if (rc != 0) { p->err = "custom all-reduce callback failed"; return PGO_ERR_COMM; }
+        for (int q = 0; q < W; ++q) { const int64_t cnt = (X.recv_off[(size_t)q + 1] - X.recv_off[(size_t)q]) * K; if (cnt > 0) HIPCHK(p, hipMemcpyAsync(recvbuf + X.recv_off[(size_t)q] * K, p->d_tmp.p + off[(size_t)q * W + r], (size_t)cnt * sizeof(double), hipMemcpyDeviceToDevice, p->st)); }
+        return PGO_OK;
+    }
+    if (!p->comm) return PGO_OK;
+    if (!p->nccl.Send || !p->nccl.Recv || !p->nccl.GroupStart || !p->nccl.GroupEnd) { p->err = "librccl lacks ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd"; return PGO_ERR_COMM; }
+    int rc = p->nccl.GroupStart();
+    for (int q = 0; q < W && rc == 0; ++q) {
+        if (q == r) continue;
+        const int64_t ns = (X.send_off[(size_t)q + 1] - X.send_off[(size_t)q]) * K, nr = (X.recv_off[(size_t)q + 1] - X.recv_off[(size_t)q]) * K;
+        if (ns > 0) rc = p->nccl.Send(sendbuf + X.send_off[(size_t)q] * K, (size_t)ns, /*ncclDouble*/ 8, q, p->comm, p->st);
+        if (rc == 0 && nr > 0) rc = p->nccl.Recv(recvbuf + X.recv_off[(size_t)q] * K, (size_t)nr, 8, q, p->comm, p->st);
+    }
+    const int rc_end = p->nccl.GroupEnd();
+    if (rc == 0) rc = rc_end;
+    if (rc != 0) { p->err = std::string("ncclSend / ncclRecv: ") + (p->nccl.GetErrorString ? p->nccl.GetErrorString(rc) : "error"); return PGO_ERR_COMM; }
+    return PGO_OK;
+}
+
+// Multi-GPU exchange of the keyframes' rows: sums, over the ranks sharing them, the rows of one or two keyframe-indexed device arrays (k1 + k2 doubles per keyframe).  Every rank
+// sends its partial rows of the keyframes it shares with a peer to that peer and adds what it receives in ascending rank order (pgo_mg_host.hpp: build_fine_plan): all ranks
+// end up with the same bits.  Keyframes touched by a single rank never travel.  `stop` (device flag): a stopped PCG sends zeros and keeps its rows.
+int exchange_rows(pgo_problem* p, double* a1, int k1, double* a2, int k2, const int32_t* stop = nullptr) {
+    if (!p->local_ids) return PGO_OK;
+    const pgo_mg::FinePlan& F = p->fine_plan;
+    const int K = k1 + k2;
+    int rc;
+    double* sb = nullptr;
+    if ((rc = exchange_send_buffer(p, &sb)) != PGO_OK) return rc;
+    launch_gather_rows(sb, a1, k1, a2, k2, F.x.n_send(), p->d_fp_send.p, stop, p->st);
+    if ((rc = neighbor_exchange(p, F.x, K, sb, p->d_xrecv.p)) != PGO_OK) return rc;
+    launch_sum_rows(p->d_xrecv.p, a1, k1, a2, k2, (int64_t)F.sh_loc.size(), p->d_fp_shloc.p, p->d_fp_sumptr.p, p->d_fp_sumsrc.p, stop, p->st);
+    return PGO_OK;
+}
+// ... and of the multigrid's level vectors: the rows of one or two vectors of level `l + 1` this rank owns and a peer reads go to that peer, the rows it reads come in
+int exchange_level(pgo_problem* p, int l, double* v1, double* v2, const int32_t* stop, const double* dinv) {
+    if (!p->local_ids || (size_t)l >= p->lvl_plan.size() || !p->lvl_plan[(size_t)l].plan) return PGO_OK;
+    const pgo_problem::LevelPlanDev& L = p->lvl_plan[(size_t)l];
+    int rc;
+    double* sb = nullptr;
+    if ((rc = exchange_send_buffer(p, &sb)) != PGO_OK) return rc;
+    if (dinv) {      // x = v1, r = v2: only r travels, x = Dinv r is formed on receipt (pointwise; every rank holds the level's Dinv)
+        launch_gather_rows(sb, v2, 6, nullptr, 0, L.plan->n_send(), L.send_idx, stop, p->st);
+        if ((rc = neighbor_exchange(p, *L.plan, 6, sb, p->d_xrecv.p)) != PGO_OK) return rc;
+        launch_scatter_rows_dinv(p->d_xrecv.p, v2, v1, dinv, L.plan->n_recv(), L.recv_idx, stop, p->st);
+        return PGO_OK;
+    }
+    const int K = v2 ? 12 : 6;
+    launch_gather_rows(sb, v1, 6, v2, v2 ? 6 : 0, L.plan->n_send(), L.send_idx, stop, p->st);
+    if ((rc = neighbor_exchange(p, *L.plan, K, sb, p->d_xrecv.p)) != PGO_OK) return rc;
+    launch_scatter_rows(p->d_xrecv.p, v1, 6, v2, v2 ? 6 : 0, L.plan->n_recv(), L.recv_idx, stop, p->st);
     return PGO_OK;
 }
 // all-reduce of a host vector (graph build: rare, sizes up to a few tens of MB)
@@ -1220,7 +1415,7 @@ int linearize(pgo_problem* p, double* cost_out) {
     launch_k2(p->G, p->L, !p->built_mf, p->st, p->built_mf ? &p->F : nullptr);
     ++p->lin_epoch;
     if (p->built_mf) launch_mf_compact(p->G, p->F, p->d_pose[p->cur].p, p->d_swv[p->cur].p, p->st);
-    if ((rc = exchange_rows(p, p->L.Hd, 36, p->L.g, 6, nullptr, 0)) != PGO_OK) return rc;   // diagonal blocks + gradient of shared keyframes
+    if ((rc = exchange_rows(p, p->L.Hd, 36, p->L.g, 6)) != PGO_OK) return rc;   // diagonal blocks + gradient of shared keyframes
     if (!p->scale_ready) { launch_scale_init(p->G, p->L, p->Sc, p->opt.jacobi_scaling, p->st); p->scale_ready = true; }
     int np = 0;
     launch_state_norms(p->G, p->L, p->d_pose[p->cur].p, p->d_swv[p->cur].p, part(p, 1), part(p, 2), part(p, 3), &np, p->st);
@@ -1251,6 +1446,53 @@ double mg_scale(const pgo_problem* p) { return p->opt.mg_correction_scale >= 1.0
 
 struct CgResult { int iterations; bool breakdown; double rel_residual; bool converged; };
 
+// Several ranks: which exchange the multigrid cycle needs at one of launch_mg_apply's hook points (pgo_internal.hpp: MgExchangeHook) — the plan (index of the level whose vectors
+// travel) and the one or two vectors; false: none.  Level `lv` (1-based) is "distributed" when its kernels run on the owner's rows only; otherwise every rank runs all its rows.
+//   point 0, down-sweep of lv (lv = n_levels: the dense solve):  a distributed level reads x (with an explicit transfer operator also r) on the halo of its rows; a level every
+//            rank runs completely needs r and x complete — a gather — when what produced them ran on owned rows only (the level below is distributed, or lv = 1: the restriction
+//            from the keyframes covers the rank's own aggregates)
+//   point 1, up-sweep of a distributed lv:  plain transition: xt of lv on the halo, unless the level above wrote all of it (a level every rank runs completely, or the dense
+//            solve, prolongs into every child it holds a valid x for: own rows + halo); explicit operator: xf of lv + 1 on the columns of R^T, when that level is distributed
+//   point 2, prolongation to the keyframes:  xf of level 1 at the aggregates of every keyframe the rank touches, when level 1 is distributed
+bool mg_exchange_at(pgo_problem* p, int point, int lv, int* plan, double** v1, double** v2, const double** dinv /* non-null result: only r (*v2) travels, x (*v1) = Dinv r is formed on receipt */) {
+    const int nl = p->M.n_levels;
+    auto dist = [&](int level) { return level >= 1 && level < nl && (size_t)(level - 1) < p->mg_dist.size() && p->mg_dist[(size_t)level - 1] != 0; };
+    auto expl = [&](int level) { return level >= 1 && level < nl && p->mg_levels[level - 1].smoothed && p->mg_levels[level - 1].rt_valf != nullptr; };
+    *v1 = nullptr; *v2 = nullptr; *plan = -1; *dinv = nullptr;
+    if (p->world <= 1 || p->lvl_plan.empty()) return false;
+    if (point == 0) {
+        if (lv == nl) { if (nl == 1 || dist(nl - 1)) { *plan = nl - 1; *v1 = p->K.rc; return true; } return false; }
+        MgLevelDev& A = p->mg_levels[lv - 1];
+        if (dist(lv)) { *plan = lv - 1; *v1 = A.x; if (expl(lv)) { *v2 = A.r; *dinv = A.Dinv; } return true; }
+        if (lv == 1 || dist(lv - 1)) { *plan = lv - 1; *v1 = A.x; *v2 = A.r; *dinv = A.Dinv; return true; }
+        return false;
+    }
+    if (point == 1) {
+        if (!dist(lv)) return false;
+        if (expl(lv)) { if (dist(lv + 1)) { *plan = lv; *v1 = p->mg_levels[lv].xf; return true; } return false; }
+        if (dist(lv + 1)) { *plan = lv - 1; *v1 = p->mg_levels[lv - 1].xt; return true; }
+        return false;
+    }
+    if (point == 2) { if (nl >= 2 && dist(1)) { *plan = nl; *v1 = p->mg_levels[0].xf; return true; } return false; }      // (the prolongation's own plan: a subset of level 1's halo)
+    return false;
+}
+struct MgHookCtx { pgo_problem* p; const int32_t* stop; };
+int mg_exchange_hook(void* ctx, int point, int level) {
+    MgHookCtx* c = static_cast<MgHookCtx*>(ctx);
+    int plan; double* v1; double* v2; const double* dinv;
+    if (!mg_exchange_at(c->p, point, level, &plan, &v1, &v2, &dinv)) return PGO_OK;
+    return exchange_level(c->p, plan, v1, v2, c->stop, dinv);
+}
+// z += s P V(P^T r) on several ranks: the cycle's kernels on this rank's share of every level, the exchanges their reads need in between
+int mg_apply_ranks(pgo_problem* p, bool inside_iteration) {
+    MgHookCtx hc{p, inside_iteration ? p->C.flags : nullptr};
+    MgExchangeHook hook{&hc, mg_exchange_hook};
+    int hrc = PGO_OK;
+    launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz, mg_scale(p), inside_iteration, p->st, false, mg_cs(p), nullptr, &hook, &hrc);
+    return hrc;
+}
+
+
 // One GPU, matrix-free matvec, tolerance not below 1e-11: the PCG runs in its single-reduction (Chronopoulos-Gear) form — matvec w = A u with the partials of u.w, then ONE
 // vector kernel whose head re-reduces u.w and r.u together (pgo_kernels.hip: sr_head).  Decided by the options alone, so every phase of a paused PCG runs the same form.
 // The two-level method keeps the classic form (its fused three-kernel iteration folds the prolongation into the direction update of the classic matvec).
@@ -1277,10 +1519,10 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
         // after a rejected step the system keeps H and only the damping grows: start from the previous solution (q = A x first)
         if (p->built_mf) launch_mf_apply(p->G, p->F, p->Sc, p->C, p->C.x, p->C.q, p->st);
         else launch_apply_operator(p->G, p->C, p->C.x, p->C.q, p->st);
-        if ((rc0 = exchange_rows(p, p->C.q, 6, nullptr, 0, nullptr, 0)) != PGO_OK) return rc0;
+        if ((rc0 = exchange_rows(p, p->C.q, 6, nullptr, 0)) != PGO_OK) return rc0;
     }
-    // Multi-GPU: the PCG runs in Chronopoulos-Gear form (pgo_kernels.hip): per iteration ONE all-reduce carries the shared rows of
-    // w = A u together with gamma = r.u (owner-weighted partials of the previous update) and delta = u.A u (rank-local partials).
+    // Multi-GPU: the PCG runs in Chronopoulos-Gear form (pgo_kernels.hip): both dot products of an iteration — gamma = r.u (owner-weighted partials of the previous update) and
+    // delta = u.A u (rank-local partials) — are known right after the matvec: ONE 2-double all-reduce per iteration, beside the neighbour exchange of the shared rows of w = A u.
     const bool multi = p->local_ids;
     // two-level preconditioner in three kernels per iteration (prolongation inside the matvec, restriction inside the update, r.(P y) from the dense solve):
     // the update kernel's r.z partials take `fused_parts` slots, the solve's C.extra_rz slots behind them
@@ -1288,19 +1530,12 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
     const int fused_parts = fused_coarse ? coarse_update_grid(p->G, p->K) : 0;
     if (fused_coarse) p->C.extra_rz = coarse_solve_grid(p->K);
     else if (!p->mg_active) p->C.extra_rz = 0;
-    // several ranks, PCG start: r = b (- A x), u = M^-1 r, p = s = 0; part_rz <- owner-weighted partials of gamma_0 (they travel with the first exchange),
-    // part_pq <- partials of b.D^-1 b, summed over ranks here once: the reference norm of the stopping test.  With the multigrid: r1 = P0^T r by one all-reduce
-    // of the owner-weighted partial restrictions (inside the iterations r1 follows by recurrence), the cycle on the replicated levels, z += P0 x1.
+    // several ranks, PCG start: r = b (- A x), u = M^-1 r, p = s = 0; part_rz <- owner-weighted partials of gamma_0 (summed over ranks with the first iteration's scalars),
+    // part_pq <- partials of b.D^-1 b, summed over ranks here once: the reference norm of the stopping test.  With the multigrid: the distributed cycle (mg_apply_ranks).
     auto start_multi = [&](int warm_i) -> int {
         int rcs;
         const int g = launch_cg_init_vectors(p->G, p->C, warm_i, p->st);
-        if (p->mg_active) {
-            double* r1 = p->M.n_levels == 1 ? p->K.rc : p->mg_levels[0].r;
-            launch_mg_restrict0(p->G, p->M, p->C.r, r1, true, p->st);
-            if ((rcs = allreduce(p, r1, (size_t)p->M.n1 * 6, 0)) != PGO_OK) return rcs;
-            launch_mg_level1_update(p->C, p->M, p->mg_levels, p->K, 0, 1, 1, p->st);
-            launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz, mg_scale(p), false, p->st, true, mg_cs(p), mg_fine_view(p));
-        }
+        if (p->mg_active && (rcs = mg_apply_ranks(p, false)) != PGO_OK) return rcs;      // z += P0 V(P0^T r): the restriction covers the rank's own aggregates (all their keyframes are local)
         double* bb = p->C.scal + 12;
         launch_reduce(p->C.part_pq, g, 0, bb, p->st);
         if ((rcs = allreduce(p, bb, 1, 0)) != PGO_OK) return rcs;
@@ -1333,7 +1568,7 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
         if (p->coarse_active && !multi) e = std::min(e, fused_coarse ? 24 : 12);
         int n_sm = 0;
         for (int l = 0; l < p->M.n_levels; ++l) n_sm += (p->mg_levels[l].smoothed && !p->mg_levels[l].rt_valf) ? 1 : 0;      // two more kernels per cycle for every level whose smoothed prolongator is applied implicitly (none with the explicit transfer operator)
-        if (p->mg_active && multi) e = std::min(e, std::max(2, (72 / (2 * p->M.n_levels + 7 + 2 * n_sm)) & ~1));
+        if (p->mg_active && multi) e = std::min(e, std::max(2, (72 / (6 * p->M.n_levels + 12)) & ~1));      // (every exchange is a pack kernel, the transfer and an unpack kernel)
         if (p->mg_active && !multi) e = std::max(2, (72 / (2 * p->M.n_levels + 3 + 2 * n_sm)) & ~1);   // at most 2 n_levels + 1 cycle kernels + matvec + update per iteration (one less with the restriction inside the update)
         return e;
     };
@@ -1362,21 +1597,15 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
             int g_pq = g;
             if (p->built_mf) { launch_mf_apply_dot(p->G, p->F, p->Sc, p->C, p->C.z, p->C.q, p->st); g_pq = mf_grid_size(p->F); }   // w = A_r u and the partials of u.w in one kernel
             else { launch_apply_operator(p->G, p->C, p->C.z, p->C.q, p->st); launch_cgcg_dots(p->G, p->C, p->st); }
-            // Four stream operations per iteration: matvec (+ dot partials), pack, all-reduce, update.  The exchange buffer is
-            //   [ 6 x n_shared rows of w | delta = u.Au | gamma = r.u | (multigrid) q1 = P0^T (A u), 6 x n1 ]
-            // packed by one kernel (zeros where this rank does not touch a shared keyframe), summed in place, and read in place by the update.
-            double* xb = p->d_xbuf.p;
-            const size_t nrow = (size_t)p->n_sh_global * 6;
-            // multigrid: this rank's part of q1 = P0^T (A u) (all its rows of A_r u, before the shared ones are summed) rides in the same exchange
-            if (p->mg_active) launch_mg_restrict0(p->G, p->M, p->C.q, p->M.q1, false, p->st);
-            launch_cgcg_pack(p->C, p->d_sh_src.p, p->n_sh_global, p->C.q, xb, p->C.part_pq, g_pq, p->C.part_rz, g, p->st);
-            int r2 = allreduce(p, xb, nrow + 2 + (p->mg_active ? (size_t)p->M.n1 * 6 : 0), 0);   // the ONE exchange per CG iteration
-            if (r2 != PGO_OK) return r2;
-            launch_cgcg_update(p->G, p->C, kk, kk == 0 ? 1 : 0, p->st, xb, p->d_sh_of.p, xb + nrow);   // (first: also when a PCG that stopped before its first update is resumed: p = s = 0 still)
-            if (p->mg_active) {      // u = D^-1 r + P0 V(r1): r1 by the recurrence, the cycle on the replicated levels, the prolongation to this rank's keyframes
-                launch_mg_level1_update(p->C, p->M, p->mg_levels, p->K, kk, kk == 0 ? 1 : 0, 0, p->st);
-                launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz, mg_scale(p), true, p->st, true, mg_cs(p), mg_fine_view(p));
-            }
+            // The iteration's exchanges: the partial rows of w of the keyframes this rank shares go to the ranks sharing them (one group of sends / receives), the parts are
+            // summed in ascending rank order; [delta, gamma] by ONE all-reduce of two doubles.  Then the update; with the multigrid the distributed cycle.
+            int r2;
+            launch_cg_reduce2_live(p->C, p->C.part_pq, g_pq, p->C.part_rz, g, p->d_xscal.p, p->st);
+            if ((r2 = exchange_rows(p, p->C.q, 6, nullptr, 0, p->C.flags)) != PGO_OK) return r2;
+            if ((r2 = allreduce(p, p->d_xscal.p, 2, 0)) != PGO_OK) return r2;
+            launch_cgcg_update(p->G, p->C, kk, kk == 0 ? 1 : 0, p->st, nullptr, nullptr, p->d_xscal.p);   // (first: also when a PCG that stopped before its first update is resumed: p = s = 0 still)
+            ++p->st_pcg_iterations;
+            if (p->mg_active && (r2 = mg_apply_ranks(p, true)) != PGO_OK) return r2;      // u = D^-1 r + P0 V(P0^T r)
             return PGO_OK;
         }
         if (fused_coarse) {
@@ -1429,7 +1658,7 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
     ensure_graph(k >= graph_after);
     // Chunks of `every` iterations; the convergence flag of chunk j is read (pinned memory + event) only AFTER chunk j+1 has been
     // enqueued, so the GPU never drains while the host polls.  A chunk enqueued after convergence is a string of early-exit kernels.
-    int n_chunks = 0, waited = -1, r1_refreshed_at = k;
+    int n_chunks = 0, waited = -1;
     int ex_k0 = -1; double ex_rz0 = 0.0;      // first polled (iteration, r.z) of this run: base of the convergence-rate estimate
     bool done = false;
     // END GAME (round 5, one GPU).  A chunk enqueued past convergence is a string of early-exit kernels (~2 us each: 100-150 us per stopped PCG with a chunk in flight, more
@@ -1476,14 +1705,14 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
         if (p->built_mf) launch_mf_apply(p->G, p->F, p->Sc, p->C, p->C.x, p->C.q, p->st);
         else launch_apply_operator(p->G, p->C, p->C.x, p->C.q, p->st);
         if (multi) {
-            if ((rcs = exchange_rows(p, p->C.q, 6, nullptr, 0, nullptr, 0)) != PGO_OK) return rcs;
+            if ((rcs = exchange_rows(p, p->C.q, 6, nullptr, 0)) != PGO_OK) return rcs;
             if ((rcs = start_multi(1)) != PGO_OK) return rcs;
         } else {
             const int g = launch_cg_init_vectors(p->G, p->C, 1, p->st);
             launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz, mg_scale(p), false, p->st, false, mg_cs(p), mg_fine_view(p));
             launch_cg_init_scalars(p->C, g, g, tol2, p->st);
         }
-        k = 0; n_chunks = 0; waited = -1; r1_refreshed_at = 0;
+        k = 0; n_chunks = 0; waited = -1;
         every = chunk_length();
         eg_tight = false; eg_next = every; eg_have = false; eg_snapshot();
         ensure_graph(true);      // a system that needed the switch is a long one
@@ -1503,16 +1732,6 @@ int run_pcg(pgo_problem* p, CgResult* res, bool warm, double rel_tol, int resume
         // (a phase that only has to reach an early-rejection pause's loose tolerance is a matter of a few iterations: its first chunk is short, the rate estimate takes over from there)
         const int first_short = end_game && n_chunks == 0 && rel_tol >= 5e-3 ? std::min(every, 8) : every;
         const int chunk = std::min(eg_tight ? eg_next : first_short, o.cg_max_iterations - k);
-        if (multi && p->mg_active && k - r1_refreshed_at >= every) {
-            // The level-1 residual follows a recurrence of its own (q1 rides in the exchange); while r falls by ten decades its absolute rounding drift does
-            // not, and a preconditioner fed with a residual that is not P0^T r any more breaks the PCG down near tight tolerances (measured at 1e-11).
-            // Once per chunk r1 is therefore taken from the keyframes' residual again: one small all-reduce every `every` iterations.
-            double* r1 = p->M.n_levels == 1 ? p->K.rc : p->mg_levels[0].r;
-            launch_mg_restrict0(p->G, p->M, p->C.r, p->M.q1, true, p->st);          // (q1 is free between exchanges)
-            if ((rc = allreduce(p, p->M.q1, (size_t)p->M.n1 * 6, 0)) != PGO_OK) return rc;
-            HIPCHK(p, hipMemcpyAsync(r1, p->M.q1, (size_t)p->M.n1 * 6 * sizeof(double), hipMemcpyDeviceToDevice, p->st));
-            r1_refreshed_at = k;
-        }
         if (want_graph && !p->cg_graph_failed && !p->cg_graph && k >= graph_after && (k & 1) == 0) ensure_graph(true);
         if (k >= 2 && chunk == every && want_graph && p->cg_graph && (k & 1) == 0) {
             HIPCHK(p, hipGraphLaunch(p->cg_graph, p->st));
@@ -1791,7 +2010,7 @@ int build_system(pgo_problem* p, bool* ok) {
     int rc;
     HIPCHK(p, hipMemsetAsync(p->d_flags.p + 4, 0, sizeof(int32_t), p->st));
     launch_build_rows(p->G, p->L, p->Sc, p->C, p->radius, 1 /*one GPU: this handle adds Hd, g and the damping; multi-GPU: the keyframe's owner (G.own)*/, p->built_mf ? p->d_lam.p : nullptr, p->st);
-    if ((rc = exchange_rows(p, p->C.Dtot, 36, p->C.b, 6, nullptr, 0)) != PGO_OK) return rc;   // reduced diagonal + rhs of shared keyframes
+    if ((rc = exchange_rows(p, p->C.Dtot, 36, p->C.b, 6)) != PGO_OK) return rc;   // reduced diagonal + rhs of shared keyframes
     launch_invert_rows(p->G, p->C, p->d_flags.p + 4, p->st);
     int32_t fail = 0;
     HIPCHK(p, hipMemcpyAsync(&fail, p->d_flags.p + 4, sizeof(int32_t), hipMemcpyDeviceToHost, p->st));
@@ -1891,6 +2110,7 @@ int solve_begin(pgo_problem* p, const double* quat, const double* t, const doubl
     p->t_device0 = now_s();
     std::memset(&p->sum, 0, sizeof(p->sum));
     p->in_solve = true; p->terminated = false; p->scale_ready = false; p->have_prev_step = false;
+    p->st_exchanges = p->st_allreduces = p->st_pcg_iterations = 0; p->st_bytes_neighbour = p->st_bytes_allreduce = 0.0;
     p->coarse_retests = 0; p->coarse_drop_radius = 0.0;
     p->cg_prev_equiv = 0.0; p->cg_prev_radius = 0.0; p->mg_regroups = 0; p->last_rho = 1.0;
     if (p->coarse_skip > 0) { p->coarse_mode = 2; p->coarse_skip_all = true; --p->coarse_skip; }
@@ -2218,6 +2438,7 @@ int64_t pgo_abi_sizeof(int32_t which) { return which == 0 ? (int64_t)sizeof(pgo_
 void pgo_options_init(pgo_options* o) {
     if (!o) return;
     std::memset(o, 0, sizeof(*o));
+    o->mg_dist_min_rows = 8192;
     o->max_num_iterations = 10;          // src/PoseGraphSLAM.cpp:1272
     o->linear_solver = PGO_LINEAR_PCG_MATRIX_FREE;
     o->jacobi_scaling = 1;
@@ -2330,7 +2551,7 @@ int pgo_destroy(pgo_problem* p) {
     p->d_delta_s.release(); p->d_io.release(); p->d_tmp.release(); p->d_vio.release(); p->d_vio_idx.release(); p->d_vio_meas.release();
     p->d_mg_f64.release(); p->d_mg_i32.release(); p->d_mg_i64.release();
     p->d_ccen.release(); p->d_cd.release(); p->d_cAc.release(); p->d_crc.release(); p->d_cblk_ptr.release(); p->d_ccontrib.release(); p->d_cblk_ab.release(); p->d_cagg_free.release(); p->d_cinfo.release(); p->d_cscr.release(); p->d_cAcf.release();
-    p->d_l2g.release(); p->d_sh_loc.release(); p->d_sh_pos.release(); p->d_sh_src.release(); p->d_sh_of.release(); p->d_own.release(); p->d_xbuf.release();
+    p->d_l2g.release(); p->d_fp_send.release(); p->d_fp_shloc.release(); p->d_fp_sumptr.release(); p->d_fp_sumsrc.release(); p->d_own.release(); p->d_xsend[0].release(); p->d_xsend[1].release(); p->d_xrecv.release(); p->d_xscal.release();
     p->d_einc.release(); p->d_einc_slot.release(); p->d_node_rng.release(); p->d_tile_inc0.release(); p->d_einc_other.release();
     p->d_tile_node0.release(); p->d_tile_sw0.release(); p->d_node_prior.release(); p->d_rec.release(); p->d_lam.release();
     (void)hipStreamDestroy(p->st);
@@ -2646,7 +2867,7 @@ int pgo_apply_normal_operator(pgo_problem* p, const double* x, double* y) {
     if ((rc = nodes_from_global(p, x, 6, xin)) != PGO_OK) return rc;
     if (p->built_mf) launch_mf_apply(p->G, p->F, p->Sc, p->C, xin, yout, p->st);
     else launch_apply_operator(p->G, p->C, xin, yout, p->st);
-    if ((rc = exchange_rows(p, yout, 6, nullptr, 0, nullptr, 0)) != PGO_OK) return rc;
+    if ((rc = exchange_rows(p, yout, 6, nullptr, 0)) != PGO_OK) return rc;
     return nodes_to_global(p, yout, 6, y);
 }
 
@@ -2660,6 +2881,10 @@ static int load_rccl(Rccl& r, std::string& err) {
     r.CommInitRank = (int (*)(void**, int, Rccl::Uid, int))dlsym(r.h, "ncclCommInitRank");
     r.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(r.h, "ncclAllReduce");
     r.CommDestroy = (int (*)(void*))dlsym(r.h, "ncclCommDestroy");
+    r.Send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))dlsym(r.h, "ncclSend");
+    r.Recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))dlsym(r.h, "ncclRecv");
+    r.GroupStart = (int (*)())dlsym(r.h, "ncclGroupStart");
+    r.GroupEnd = (int (*)())dlsym(r.h, "ncclGroupEnd");
     r.GetErrorString = (const char* (*)(int))dlsym(r.h, "ncclGetErrorString");
     if (!r.GetUniqueId || !r.CommInitRank || !r.AllReduce || !r.CommDestroy) { err = "librccl: missing symbols"; return PGO_ERR_COMM; }
     return PGO_OK;
@@ -2697,9 +2922,93 @@ int pgo_comm_init_custom(pgo_problem* p, int32_t rank, int32_t world, pgo_allred
     p->graph_dirty = true;
     return PGO_OK;
 }
+int pgo_comm_set_exchange(pgo_problem* p, pgo_exchange_fn fn) {
+    if (!p || !p->custom_allreduce) return PGO_ERR_INVALID_ARG;      // (belongs to a communicator set up by pgo_comm_init_custom)
+    p->custom_exchange = fn;
+    return PGO_OK;
+}
+int pgo_local_group_create(int32_t world, void** group) {
+    if (!group || world < 1 || world > pgo_local::MAX_RANKS) return PGO_ERR_INVALID_ARG;
+    pgo_local::Group* G = new (std::nothrow) pgo_local::Group();
+    if (!G) return PGO_ERR_OUT_OF_MEMORY;
+    G->world = world;
+    *group = G;
+    return PGO_OK;
+}
+int pgo_local_group_abort(void* group) {
+    if (!group) return PGO_ERR_INVALID_ARG;
+    static_cast<pgo_local::Group*>(group)->abort();
+    return PGO_OK;
+}
+int pgo_local_group_destroy(void* group) {
+    if (!group) return PGO_ERR_INVALID_ARG;
+    delete static_cast<pgo_local::Group*>(group);
+    return PGO_OK;
+}
+int pgo_comm_init_local(pgo_problem* p, int32_t rank, int32_t world, void* group) {
+    pgo_local::Group* G = static_cast<pgo_local::Group*>(group);
+    if (!p || !G || world != G->world || rank < 0 || rank >= world) return PGO_ERR_INVALID_ARG;
+    int rc;
+    if ((rc = set_device(p)) != PGO_OK) return rc;
+    pgo_local::Group::Slot& me = G->slot[rank];
+    if (me.joined) { p->err = "in-process communicator: the rank is taken"; return PGO_ERR_INVALID_ARG; }
+    for (int k = 0; k < 2; ++k) {
+        HIPCHK(p, hipEventCreateWithFlags(&me.ready[k], hipEventDisableTiming));
+        HIPCHK(p, hipEventCreateWithFlags(&me.done[k], hipEventDisableTiming));
+    }
+    me.device = p->device; me.joined = true;
+    mg_job_cancel(p); mg_init_drop(p);
+    p->local_group = G; p->lc_count = 0; p->rank = rank; p->world = world;
+    p->graph_dirty = true;
+    // ranks on other GPUs of this process: their buffers are read over xGMI (peer access); every rank has joined once all have passed this barrier
+    if (!G->barrier()) { p->err = "in-process communicator: not all ranks joined"; return PGO_ERR_COMM; }
+    for (int q = 0; q < world; ++q) if (q != rank && G->slot[q].device != p->device) { const hipError_t e = hipDeviceEnablePeerAccess(G->slot[q].device, 0); if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); p->err = "in-process communicator: no peer access between the ranks' GPUs"; G->abort(); return PGO_ERR_COMM; } (void)hipGetLastError(); }
+    return PGO_OK;
+}
+int pgo_get_sharding_stats(pgo_problem* p, pgo_sharding_stats* out) {
+    if (!p || !out) return PGO_ERR_INVALID_ARG;
+    std::memset(out, 0, sizeof(*out));
+    out->world = p->world; out->rank = p->rank;
+    if (!p->local_ids || p->graph_dirty) return PGO_OK;
+    out->keyframes_local = p->N;
+    for (double w : p->h_own) if (w != 0.0) ++out->keyframes_owned;
+    out->keyframes_shared = p->n_sh_mine; out->shared_global = p->n_sh_global;
+    out->pcg_iterations = p->st_pcg_iterations; out->exchanges = p->st_exchanges; out->allreduces = p->st_allreduces;
+    out->bytes_sent_neighbour = p->st_bytes_neighbour; out->bytes_allreduce = p->st_bytes_allreduce;
+    const double fine = (double)p->fine_plan.x.n_send() * 48.0 + 16.0;
+    out->bytes_sent_per_bj_iteration = fine; out->exchanges_per_bj_iteration = 1;
+    out->bytes_round5_per_bj_iteration = (6.0 * (double)p->n_sh_global + 2.0) * 8.0;
+    if (p->mg_built && !p->mg_init_pending && p->M.n_levels >= 1) {
+        const int nl = p->M.n_levels;
+        out->mg_levels = nl; out->mg_levels_distributed = p->mg_levels_distributed;
+        out->mg_rows_total = p->mg_rows_total; out->mg_rows_own = p->mg_rows_own; out->mg_blocks_total = p->mg_blocks_total; out->mg_blocks_own = p->mg_blocks_own;
+        double bytes = fine; int nx = 1;
+        auto count = [&](int point, int lv) { int plan; double* v1; double* v2; const double* dinv; if (mg_exchange_at(p, point, lv, &plan, &v1, &v2, &dinv) && p->lvl_plan[(size_t)plan].plan) { bytes += (double)p->lvl_plan[(size_t)plan].plan->n_send() * (v2 && !dinv ? 96.0 : 48.0); ++nx; } };
+        for (int l = 1; l <= nl; ++l) count(0, l);
+        for (int l = nl - 1; l >= 1; --l) count(1, l);
+        count(2, 1);
+        out->bytes_sent_per_mg_iteration = bytes; out->exchanges_per_mg_iteration = nx;
+        out->bytes_round5_per_mg_iteration = (6.0 * (double)p->n_sh_global + 2.0 + 6.0 * (double)p->M.n1) * 8.0;
+    }
+    return PGO_OK;
+}
 int pgo_comm_destroy(pgo_problem* p) {
     if (!p) return PGO_ERR_INVALID_ARG;
-    p->custom_allreduce = nullptr; p->custom_ctx = nullptr;
+    p->custom_allreduce = nullptr; p->custom_ctx = nullptr; p->custom_exchange = nullptr;
+    if (p->local_group) {      // every rank's stream has drained before any event or staging buffer goes (a peer's kernel may still be reading them)
+        pgo_local::Group* G = p->local_group;
+        (void)hipStreamSynchronize(p->st);
+        (void)G->barrier();
+        pgo_local::Group::Slot& me = G->slot[p->rank];
+        for (int k = 0; k < 2; ++k) {
+            if (me.ready[k]) (void)hipEventDestroy(me.ready[k]);
+            if (me.done[k]) (void)hipEventDestroy(me.done[k]);
+            if (me.stage[k]) (void)hipFree(me.stage[k]);
+            me.ready[k] = me.done[k] = nullptr; me.stage[k] = nullptr; me.stage_cap[k] = 0; me.ptr[k] = nullptr; me.send_off[k] = nullptr;
+        }
+        me.joined = false;
+        p->local_group = nullptr;
+    }
     if (p->comm && p->nccl.CommDestroy) { (void)hipStreamSynchronize(p->st); p->nccl.CommDestroy(p->comm); }
     mg_job_cancel(p); mg_init_drop(p);
     p->comm = nullptr; p->rank = 0; p->world = 1;
@@ -2780,7 +3089,7 @@ int pgo_time_kernel(pgo_problem* p, int32_t which, int32_t launches, double* avg
     const GraphDev& G = p->G;
     double bytes = 0;
     if (which == 6 || which == 7) {   // one multigrid-preconditioned PCG iteration (6) / its level kernels alone (7), on the current LM system
-        if (!p->mg_built || !p->built_mf || p->local_ids) { p->err = "pgo_time_kernel: this graph has no (single-GPU) multigrid hierarchy (mg_min_keyframes)"; return PGO_ERR_STATE; }
+        if (!p->mg_built || !p->built_mf || (p->local_ids && which == 6)) { p->err = "pgo_time_kernel: this graph has no multigrid hierarchy (mg_min_keyframes) / several ranks: only the level kernels (7) can be timed"; return PGO_ERR_STATE; }
         const pgo_options& o = p->opt;
         if (!p->reuse_diagonal) launch_lm_diag(p->G, p->L, p->Sc, o.min_lm_diagonal, o.max_lm_diagonal, p->st);
         bool ok = true;
@@ -2788,9 +3097,16 @@ int pgo_time_kernel(pgo_problem* p, int32_t which, int32_t launches, double* avg
         if (!p->mg_active && (rc = build_mg(p)) != PGO_OK) return rc;
         if (!p->mg_active) { p->err = "pgo_time_kernel: the multigrid operators of this system are not positive definite"; return PGO_ERR_NUMERIC; }
         const int g = launch_cg_init_vectors(p->G, p->C, 0, p->st);
-        launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz, mg_scale(p), false, p->st, false, mg_cs(p), mg_fine_view(p));
-        launch_cg_init_scalars(p->C, g, g, 0.0, p->st);
+        if (p->local_ids) { if ((rc = mg_apply_ranks(p, false)) != PGO_OK) return rc; launch_cg_set_tolerance(p->C, 0.0, p->st); }      // (one full distributed cycle: every level vector holds finite numbers)
+        else {
+            launch_mg_apply(p->G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz, mg_scale(p), false, p->st, false, mg_cs(p), mg_fine_view(p));
+            launch_cg_init_scalars(p->C, g, g, 0.0, p->st);
+        }
     }
+    // in-process ranks share the GPU(s) of one process: the timed launches of the ranks take turns (every rank's figure is what its GPU would need on its own)
+    const int turns = (p->local_group && (which == 7)) ? p->world : 1;
+    for (int turn = 0; turn < turns; ++turn) {
+    if (turns > 1) { HIPCHK(p, hipStreamSynchronize(p->st)); if (!p->local_group->barrier()) { p->err = "in-process communicator: a rank left during pgo_time_kernel"; return PGO_ERR_COMM; } if (turn != p->rank) continue; }
     if (which == 5 && single_reduction(p)) {      // (its head needs the u.w partials of a matvec on the CURRENT u: launched back to back it sees stale ones, breaks down and returns early)
         p->err = "pgo_time_kernel(5): the single-reduction update cannot be timed without its matvec; time the iteration (2) and the matvec (4) and subtract"; return PGO_ERR_STATE;
     }
@@ -2847,6 +3163,11 @@ int pgo_time_kernel(pgo_problem* p, int32_t which, int32_t launches, double* avg
                               if (fused) launch_cg_update_mg(G, p->C, p->M, p->mg_levels, p->K, kk, mf_grid_size(p->F), p->st);
                               else launch_cg_update(G, p->C, kk, mf_grid_size(p->F), p->st);
                           }
+                          if (p->local_ids) {      // several ranks: this rank's share of the cycle's kernels, no exchanges (what its GPU computes per cycle)
+                              launch_mg_apply(G, p->C, p->M, p->mg_levels, p->K, p->C.r, p->C.z, p->C.part_rz, mg_scale(p), false, p->st, false, mg_cs(p), nullptr);
+                              bytes = (double)p->mg_blocks_own * 148.0 + (double)p->mg_rows_own * (288.0 + 24.0 + 8.0 * 48.0 + 16.0) + (double)p->K.nc * (double)p->K.nc * 4.0 + (double)p->K.nc * 16.0;
+                              break;
+                          }
                           launch_mg_apply(G, p->C, p->M, p->mg_levels, p->K, sr ? p->C.r : ((kk & 1) ? p->C.r : p->C.r2), p->C.z, p->C.part_rz + (size_t)((kk & 1) ^ 1) * RZ_STRIDE, mg_scale(p), true, p->st, which == 6 && fused, mg_cs(p), mg_fine_view(p));
                           // Bytes of this design, each array once per kernel that streams it.  Fine level as in case 2 (+ the restriction's per-keyframe offsets and slot table,
                           // the prolongation's read-modify-write of z, offsets and aggregate index); every sparse coarse level: its fp32 blocks and column indices twice
@@ -2870,6 +3191,8 @@ int pgo_time_kernel(pgo_problem* p, int32_t which, int32_t launches, double* avg
         if (rep == 1) HIPCHK(p, hipEventRecord(e1, p->st));
         HIPCHK(p, hipStreamSynchronize(p->st));
     }
+    }
+    if (turns > 1 && !p->local_group->barrier()) { p->err = "in-process communicator: a rank left during pgo_time_kernel"; return PGO_ERR_COMM; }
     float ms = 0;
     HIPCHK(p, hipEventElapsedTime(&ms, e0, e1));
     *avg_ms = (double)ms / launches;

@@ -116,4 +116,54 @@ void mgh_level0(void* h, int* agg0, int* mem0_ptr, int* mem0) {
     const pgo_mg::Hierarchy& H = *(pgo_mg::Hierarchy*)h;
     std::memcpy(agg0, H.agg0.data(), H.agg0.size() * 4); std::memcpy(mem0_ptr, H.mem0_ptr.data(), H.mem0_ptr.size() * 4); std::memcpy(mem0, H.mem0.data(), H.mem0.size() * 4);
 }
+
+// ---- several ranks, distributed cycle (round 6): owner-pure aggregates, owner-major numbering, exchange plans ----
+// masks [N]: bit r = rank r holds a residual block on the keyframe (what libpgo's build_graph all-reduces).  Built from the GLOBAL graph, as every rank does.
+void* mgh_build_owned(long long N, const unsigned char* node_free, long long Er, const int* rc1, const int* rc2, const double* rw, long long Es, const int* sc1, const int* sc2,
+                      int passes0, int passes, int dense_max, int tile_rows, int max_levels, int smoothed_levels, const unsigned long long* masks, const int* owner, int world, int dist_min_rows) {
+    std::vector<uint8_t> nf(node_free, node_free + N);
+    std::vector<int32_t> a(rc1, rc1 + Er), b(rc2, rc2 + Er), c(sc1, sc1 + Es), d(sc2, sc2 + Es);
+    std::vector<double> w(rw, rw + Er);
+    std::vector<uint64_t> m(masks, masks + N);
+    std::vector<int32_t> ow(owner, owner + N);
+    pgo_mg::Owners O; O.touch_mask = &m; O.owner = &ow; O.world = world; O.dist_min_rows = dist_min_rows;
+    pgo_mg::Hierarchy* H = new pgo_mg::Hierarchy();
+    if (!pgo_mg::build_hierarchy(N, nf, a, b, w.data(), 1, c, d, nullptr, passes0, passes, dense_max, tile_rows, max_levels, *H, false, 0, nullptr, smoothed_levels, 0.0, nullptr, nullptr, nullptr, &O)) { delete H; return nullptr; }
+    return H;
+}
+int mgh_world(void* h) { return ((pgo_mg::Hierarchy*)h)->world; }
+void mgh_ownership(void* h, int l, int* own_ptr /* world+1 */, int* tile_ptr /* world+1; zeros on the coarsest level */, int* distributed) {
+    const pgo_mg::Hierarchy& H = *(pgo_mg::Hierarchy*)h; const pgo_mg::HostLevel& A = H.L[l];
+    for (int r = 0; r <= H.world; ++r) { own_ptr[r] = A.own_ptr.empty() ? 0 : A.own_ptr[r]; tile_ptr[r] = A.tile_ptr.empty() ? 0 : A.tile_ptr[r]; }
+    *distributed = A.distributed ? 1 : 0;
+}
+struct PlanSet { std::vector<pgo_mg::ExchangePlan> plans; pgo_mg::FinePlan fine; };
+void* mgh_plans(void* h, const unsigned long long* masks, long long N, int world, int dist_min_rows, int rank) {
+    const pgo_mg::Hierarchy& H = *(pgo_mg::Hierarchy*)h;
+    std::vector<uint64_t> m(masks, masks + N);
+    pgo_mg::Owners O; O.touch_mask = &m; O.world = world; O.dist_min_rows = dist_min_rows;      // (the plans read the ownership ranges of the hierarchy, not the owner array)
+    PlanSet* P = new PlanSet();
+    pgo_mg::build_level_plans(H, O, rank, P->plans);
+    std::vector<int32_t> l2g;
+    for (long long g = 0; g < N; ++g) if ((m[g] >> rank) & 1) l2g.push_back((int32_t)g);
+    pgo_mg::build_fine_plan(m, l2g, rank, world, P->fine);
+    return P;
+}
+void mgh_plans_free(void* ps) { delete (PlanSet*)ps; }
+static const pgo_mg::ExchangePlan& plan_of(void* ps, int l) { PlanSet* P = (PlanSet*)ps; return l < 0 ? P->fine.x : P->plans[l]; }      // l = -1: the keyframes' plan
+void mgh_plan_sizes(void* ps, int l, long long* n_send, long long* n_recv) { const pgo_mg::ExchangePlan& X = plan_of(ps, l); *n_send = X.n_send(); *n_recv = X.n_recv(); }
+void mgh_plan_get(void* ps, int l, int* send_idx, long long* send_off, int* recv_idx, long long* recv_off, long long* pair_cnt) {
+    const pgo_mg::ExchangePlan& X = plan_of(ps, l);
+    if (!X.send_idx.empty()) std::memcpy(send_idx, X.send_idx.data(), X.send_idx.size() * 4);
+    if (!X.recv_idx.empty()) std::memcpy(recv_idx, X.recv_idx.data(), X.recv_idx.size() * 4);
+    std::memcpy(send_off, X.send_off.data(), X.send_off.size() * 8); std::memcpy(recv_off, X.recv_off.data(), X.recv_off.size() * 8);
+    std::memcpy(pair_cnt, X.pair_cnt.data(), X.pair_cnt.size() * 8);
+}
+void mgh_fine_sizes(void* ps, long long* n_shared, long long* n_src) { PlanSet* P = (PlanSet*)ps; *n_shared = (long long)P->fine.sh_loc.size(); *n_src = (long long)P->fine.sum_src.size(); }
+void mgh_fine_get(void* ps, int* sh_loc, int* sum_ptr, int* sum_src) {
+    PlanSet* P = (PlanSet*)ps;
+    if (!P->fine.sh_loc.empty()) std::memcpy(sh_loc, P->fine.sh_loc.data(), P->fine.sh_loc.size() * 4);
+    std::memcpy(sum_ptr, P->fine.sum_ptr.data(), P->fine.sum_ptr.size() * 4);
+    if (!P->fine.sum_src.empty()) std::memcpy(sum_src, P->fine.sum_src.data(), P->fine.sum_src.size() * 4);
+}
 }

@@ -102,13 +102,14 @@ def test_c5_ranks_on_one_gpu_follow_the_single_rank_trajectory(c5, world):
     st = sharding.partition_stats(g, parts)
     assert 1000 < st["shared_keyframes"] < 0.2 * g.n_poses
     ar = InProcessAllReduce(world)
-    out, err = [None] * world, []
+    out, err, stats = [None] * world, [], [None] * world
 
     def run(rank):
         try:
             Pr = capi.problem_from_graph(g, switchable=True, edge_slice=parts[rank], max_num_iterations=2)
-            Pr.comm_init_custom(rank, world, ar.make(rank))
+            ar.attach(Pr, rank)
             out[rank] = Pr.solve(q, t, s)
+            stats[rank] = Pr.sharding_stats().as_dict()
             Pr.comm_destroy()
             Pr.close()
         except Exception as e:
@@ -120,8 +121,14 @@ def test_c5_ranks_on_one_gpu_follow_the_single_rank_trajectory(c5, world):
     for x in th:
         x.join(timeout=1200)
     assert not err, err
+    ar.close()
     for r in range(world):
         qr, tr, sr, sumr = out[r]
+        # round 6, distributed multigrid: a rank's level kernels work on its own rows, and it sends less than a third of what round 5's union all-reduce carried
+        print("rank %d: %s" % (r, {k: stats[r][k] for k in ("mg_levels", "mg_levels_distributed", "mg_blocks_own", "mg_blocks_total", "bytes_sent_per_mg_iteration", "bytes_round5_per_mg_iteration", "exchanges_per_mg_iteration")}))
+        assert stats[r]["mg_levels_distributed"] >= 2
+        assert stats[r]["mg_blocks_own"] <= (1.0 / world + 0.25) * stats[r]["mg_blocks_total"]      # its own rows of the distributed levels + all of the small ones
+        assert stats[r]["bytes_sent_per_mg_iteration"] <= stats[r]["bytes_round5_per_mg_iteration"] * (1.0 / 3.0 if world == 8 else 0.45)      # (measured: 0.23-0.27 on 8 ranks, 0.40 on 4)
         assert sumr.num_iterations == sum1.num_iterations == 2
         for k in range(sum1.num_logged):
             a, b = sum1.iterations[k], sumr.iterations[k]

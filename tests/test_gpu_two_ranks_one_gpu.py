@@ -19,14 +19,46 @@ pytestmark = pytest.mark.gpu
 
 
 class InProcessAllReduce:
-    def __init__(self, world):
+    """`world` ranks as threads of this process.  transport "local": libpgo's own in-process communicator (pgo_comm_init_local: collectives are kernels reading the peers' device
+    buffers); "custom": a caller-supplied all-reduce staged through the host (pgo_comm_init_custom) — the neighbour exchanges are then emulated through it by the library;
+    "custom+exchange": the same with a caller-supplied exchange (pgo_comm_set_exchange: MPI_Alltoallv semantics)."""
+
+    def __init__(self, world, transport="local"):
         self.world = world
+        self.transport = transport
         self.barrier = threading.Barrier(world)
         self.slots = [None] * world
+        self.xslots = [None] * world
         self.hip = C.CDLL("libamdhip64.so")
         self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         self.hip.hipStreamSynchronize.argtypes = [C.c_void_p]
         self.calls = 0
+        self.group = capi.local_group_create(world) if transport == "local" else None
+        outer = self
+
+        class _Abort:      # the tests call ar.barrier.abort() when a rank fails: release the ranks waiting inside the library too
+            def abort(self_inner):
+                if outer.group is not None:
+                    capi.local_group_abort(outer.group)
+                outer._barrier.abort()
+
+            def wait(self_inner, timeout=None):
+                return outer._barrier.wait(timeout=timeout)
+        self._barrier = self.barrier
+        self.barrier = _Abort()
+
+    def attach(self, P, rank):
+        if self.transport == "local":
+            P.comm_init_local(rank, self.world, self.group)
+        else:
+            P.comm_init_custom(rank, self.world, self.make(rank))
+            if self.transport == "custom+exchange":
+                P.comm_set_exchange(self.make_exchange(rank))
+
+    def close(self):
+        if self.group is not None:
+            capi.local_group_destroy(self.group)
+            self.group = None
 
     def make(self, rank):
         def fn(buf, count, op, stream):
@@ -43,14 +75,35 @@ class InProcessAllReduce:
             return 0
         return fn
 
+    def make_exchange(self, rank):
+        def fn(sbuf, soff, rbuf, roff, stream):
+            assert self.hip.hipStreamSynchronize(stream) == 0
+            host = np.empty(max(soff[-1], 1), dtype=np.float64)
+            if soff[-1]:
+                assert self.hip.hipMemcpy(host.ctypes.data, sbuf, soff[-1] * 8, 2) == 0
+            self.xslots[rank] = (host, soff)
+            self.barrier.wait(timeout=120)
+            got = np.empty(max(roff[-1], 1), dtype=np.float64)
+            for q in range(self.world):
+                hq, sq = self.xslots[q]
+                n = roff[q + 1] - roff[q]
+                assert sq[rank + 1] - sq[rank] == n, (rank, q, n, sq[rank + 1] - sq[rank])
+                got[roff[q]:roff[q + 1]] = hq[sq[rank]:sq[rank + 1]]
+            self.barrier.wait(timeout=120)
+            if roff[-1]:
+                assert self.hip.hipMemcpy(rbuf, got.ctypes.data, roff[-1] * 8, 1) == 0
+            return 0
+        return fn
+
 
 def idle_last_rank(g, world):
     """world-1 working ranks (spatial cells) + one rank without a single residual block"""
     return sharding.partition(g, world - 1, "spatial") + [lambda kind, n: np.arange(0)]
 
 
-@pytest.mark.parametrize("world,policy,linear_solver", [(2, "contiguous", 1), (2, "contiguous", 0), (3, "spatial", 1), (3, "chain", 0), (4, "spatial", 1), (3, "idle", 1)])
-def test_ranks_reproduce_the_single_rank_solve(world, policy, linear_solver):
+@pytest.mark.parametrize("world,policy,linear_solver,transport", [(2, "contiguous", 1, "custom"), (2, "contiguous", 0, "local"), (3, "spatial", 1, "custom+exchange"), (3, "chain", 0, "local"),
+                                                                  (4, "spatial", 1, "local"), (3, "idle", 1, "local")])
+def test_ranks_reproduce_the_single_rank_solve(world, policy, linear_solver, transport):
     g = util.small_graph(500, 70, f=2, seed=17)
     q, t, s = util.initial_state(g, True)
     opts = dict(cg_rel_tolerance=1e-12, cg_max_iterations=20000, linear_solver=linear_solver)
@@ -62,18 +115,20 @@ def test_ranks_reproduce_the_single_rank_solve(world, policy, linear_solver):
     parts = idle_last_rank(g, world) if policy == "idle" else sharding.partition(g, world, policy)
     st = sharding.partition_stats(g, parts)
     assert sum(st["edges_per_rank"]) == g.n_odom + g.n_loops and 0 < st["shared_keyframes"] < g.n_poses
-    ar = InProcessAllReduce(world)
+    ar = InProcessAllReduce(world, transport)
     out = [None] * world
     grads = [None] * world
+    stats = [None] * world
     err = []
 
     def run(rank):
         try:
             Pr = capi.problem_from_graph(g, switchable=True, edge_slice=parts[rank], **opts)
-            Pr.comm_init_custom(rank, world, ar.make(rank))
+            ar.attach(Pr, rank)
             c, _, gr = Pr.evaluate(q, t, s)                                  # parity hook through the exchange: cost + full gradient
             grads[rank] = (c, gr)
             out[rank] = Pr.solve(q, t, s)
+            stats[rank] = Pr.sharding_stats().as_dict()
             Pr.comm_destroy()
             Pr.close()
         except Exception as e:   # make a failing rank release the others
@@ -85,7 +140,12 @@ def test_ranks_reproduce_the_single_rank_solve(world, policy, linear_solver):
     for x in th:
         x.join(timeout=600)
     assert not err, err
-    assert ar.calls > 100                                        # one exchange per CG matvec happened
+    ar.close()
+    for r in range(world):                                       # one neighbour exchange of the shared rows and one 2-scalar all-reduce per CG matvec happened
+        assert stats[r]["exchanges"] > 100 and stats[r]["allreduces"] > 100 and stats[r]["pcg_iterations"] > 100, stats[r]
+        assert stats[r]["bytes_sent_per_bj_iteration"] <= stats[r]["bytes_round5_per_bj_iteration"] + 16
+    if transport != "local":
+        assert ar.calls > 100
     # gradient over ALL keyframes on every rank; the switch part holds the rank's own switches
     for r in range(world):
         c, gr = grads[r]
@@ -123,7 +183,7 @@ def test_default_tolerances_with_early_rejection_across_ranks():
     def run(rank):
         try:
             Pr = capi.problem_from_graph(g, switchable=True, edge_slice=parts[rank])
-            Pr.comm_init_custom(rank, world, ar.make(rank))
+            ar.attach(Pr, rank)
             out[rank] = Pr.solve(q, t, s)
             Pr.comm_destroy()
             Pr.close()
@@ -163,7 +223,7 @@ def test_keyframes_without_residual_blocks_come_back_as_given_on_every_rank():
     def run(rank):
         try:
             Pr = capi.problem_from_graph(g, switchable=True, edge_slice=parts[rank], **opts)
-            Pr.comm_init_custom(rank, world, ar.make(rank))
+            ar.attach(Pr, rank)
             out[rank] = Pr.solve(q, t, s)
             Pr.comm_destroy()
             Pr.close()
@@ -189,7 +249,7 @@ def test_c3_four_ranks_on_one_gpu_follow_the_single_rank_trajectory():
     from solve_keyframe_pose_graph_amd import graphgen
     g = graphgen.config("C3")
     q, t, s = util.initial_state(g, True)
-    P = util.pgo_problem(g, True)     # library defaults on BOTH sides: hybrid block-Jacobi / multigrid PCG (the ranks run it in Chronopoulos-Gear form on replicated coarse levels)
+    P = util.pgo_problem(g, True)     # library defaults on BOTH sides: hybrid block-Jacobi / multigrid PCG (the ranks run it in Chronopoulos-Gear form, the cycle distributed)
     q1, t1, s1, sum1 = P.solve(q, t, s)
     P.close()
     world = 4
@@ -203,21 +263,32 @@ def test_c3_four_ranks_on_one_gpu_follow_the_single_rank_trajectory():
     def run(rank):
         try:
             Pr = capi.problem_from_graph(g, switchable=True, edge_slice=parts[rank])
-            Pr.comm_init_custom(rank, world, ar.make(rank))
+            ar.attach(Pr, rank)
             out[rank] = Pr.solve(q, t, s)
+            stats[rank] = Pr.sharding_stats().as_dict()
             Pr.comm_destroy()
             Pr.close()
         except Exception as e:
             err.append(e)
             ar.barrier.abort()
+    stats = [None] * world
     th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
     for x in th:
         x.start()
     for x in th:
         x.join(timeout=1200)
     assert not err, err
+    ar.close()
     for r in range(world):
         qr, tr, sr, sumr = out[r]
+        # round 6: the multigrid is distributed — a rank's level kernels stream about a quarter of the hierarchy's blocks, and what it sends per multigrid iteration is
+        # less than a third of what round 5's union all-reduce carried on the same graph
+        print("rank %d: %s" % (r, {k: stats[r][k] for k in ("mg_levels", "mg_levels_distributed", "mg_blocks_own", "mg_blocks_total", "bytes_sent_per_mg_iteration", "bytes_round5_per_mg_iteration", "exchanges_per_mg_iteration")}))
+        # (C3 on 4 ranks: level 1 — 13 000 rows — is distributed, the smaller levels are run completely by every rank: at these sizes a level kernel sits at its latency floor
+        # whatever its share.  Round 5's all-reduce was dominated by the 6 n_1 level-1 vector here; config 5 on 8 ranks, where the shared keyframes dominate: tests/test_gpu_c5.py)
+        assert stats[r]["mg_levels_distributed"] >= 1
+        assert stats[r]["mg_blocks_own"] <= 0.80 * stats[r]["mg_blocks_total"]
+        assert stats[r]["bytes_sent_per_mg_iteration"] <= 0.65 * stats[r]["bytes_round5_per_mg_iteration"]
         assert sumr.num_iterations == sum1.num_iterations == 10
         for k in range(sum1.num_logged):
             a, b = sum1.iterations[k], sumr.iterations[k]
@@ -253,7 +324,7 @@ def test_constant_keyframes_and_unused_switches_across_ranks(switchable):
         try:
             Pr = capi.problem_from_graph(g, switchable=switchable, edge_slice=parts[rank], **opts)
             Pr.set_nodes_constant(const)                       # the same list on every rank
-            Pr.comm_init_custom(rank, world, ar.make(rank))
+            ar.attach(Pr, rank)
             out[rank] = Pr.solve(q, t, s)
             Pr.comm_destroy()
             Pr.close()
@@ -278,10 +349,10 @@ def test_constant_keyframes_and_unused_switches_across_ranks(switchable):
 
 @pytest.mark.parametrize("world,policy,switch_at,linear_solver", [(2, "spatial", 0, 1), (3, "chain", 0, 1), (3, "spatial", 60, 1), (2, "contiguous", 0, 0)])
 def test_multigrid_across_ranks_follows_the_single_rank_multigrid(world, policy, switch_at, linear_solver):
-    """The aggregation multigrid with several ranks: the hierarchy is built from the gathered global graph (identical on every rank), level 1's Galerkin
-    product is the all-reduced sum of the ranks' parts, the levels above are replicated, and the level-1 residual follows the Chronopoulos-Gear recurrence
-    with P0^T (A u) riding in the iteration's ONE exchange.  Same preconditioner as on one handle up to the tie-breaks of the matching (the gathered edge
-    order differs from the single handle's), so: same accept/reject sequence, costs to the PCG tolerance, iteration counts within 15 %.
+    """The aggregation multigrid with several ranks (round 6: DISTRIBUTED): the hierarchy is built from the gathered global graph (identical on every rank) with aggregates that
+    never mix owners and owner-major numbering; every rank runs the cycle's kernels on the rows it owns and gets the halo rows its kernels read by neighbour exchanges
+    (mg_dist_min_rows = 64 here so that the small test levels ARE distributed; the "chain" / "contiguous" cases keep the default and run every level completely on every rank
+    from gathered vectors).  Level 1's Galerkin product is still the all-reduced sum of the ranks' parts.  Same accept/reject sequence, costs to the PCG tolerance.
     switch_at > 0: the hybrid start (block-Jacobi first, multigrid operators built in flight) on every rank at the same iteration."""
     from solve_keyframe_pose_graph_amd import graphgen
     g = graphgen.generate(6000, 3000, odom_f_max=2, seed=7)
@@ -300,29 +371,37 @@ def test_multigrid_across_ranks_follows_the_single_rank_multigrid(world, policy,
 
     def run(rank):
         try:
-            Pr = capi.problem_from_graph(g, switchable=True, edge_slice=parts[rank], **opts)
-            Pr.comm_init_custom(rank, world, ar.make(rank))
+            Pr = capi.problem_from_graph(g, switchable=True, edge_slice=parts[rank], **dict(opts, mg_dist_min_rows=64 if policy == "spatial" else 8192))
+            ar.attach(Pr, rank)
             out[rank] = Pr.solve(q, t, s)
+            stats[rank] = Pr.sharding_stats().as_dict()
             Pr.comm_destroy()
             Pr.close()
         except Exception as e:
             err.append(e)
             ar.barrier.abort()
+    stats = [None] * world
     th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
     for x in th:
         x.start()
     for x in th:
         x.join(timeout=900)
     assert not err, err
+    ar.close()
     for r in range(world):
         qr, tr, sr, sumr = out[r]
+        assert (stats[r]["mg_levels_distributed"] >= 1) == (policy == "spatial"), stats[r]
+        if policy == "spatial":
+            assert stats[r]["mg_rows_own"] < 0.8 * stats[r]["mg_rows_total"]
         assert sumr.num_iterations == sum1.num_iterations
         assert [sumr.iterations[k].step_is_successful for k in range(sumr.num_logged)] == [sum1.iterations[k].step_is_successful for k in range(sum1.num_logged)]
         for k in range(sum1.num_logged):
             assert abs(sumr.iterations[k].cost - sum1.iterations[k].cost) <= 1e-8 * sum1.iterations[k].cost, k
         assert np.abs(tr - t1).max() <= 1e-6 and np.abs(sr - s1).max() <= 1e-6
         assert sumr.cg_iterations_multigrid > 0.5 * sumr.cg_iterations
-        assert abs(sumr.cg_iterations - sum1.cg_iterations) <= 0.15 * sum1.cg_iterations, (sumr.cg_iterations, sum1.cg_iterations)
+        # (round 6: aggregates never mix owners.  Dealt out by place — the policy to use — that costs nothing; dealt out by index ranges, loop closures cross ranks and
+        # the levels above level 1 can no longer follow them: +27 % iterations measured on this graph with 3 index ranges)
+        assert abs(sumr.cg_iterations - sum1.cg_iterations) <= (0.15 if policy == "spatial" else 0.35) * sum1.cg_iterations, (sumr.cg_iterations, sum1.cg_iterations)
         assert sumr.cg_iterations < 0.5 * sumb.cg_iterations          # and it is the multigrid that runs: far fewer iterations than block-Jacobi
     for r in range(1, world):
         assert np.array_equal(out[0][1], out[r][1]) and np.array_equal(out[0][2], out[r][2])

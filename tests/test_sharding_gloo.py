@@ -1,10 +1,12 @@
 """CPU, world_size 2 and 3 over gloo: the construction of the N > 1 path.  Each rank owns the edges a sharding.partition policy deals
 it and works on the keyframes those edges touch (rank-local subgraph); keyframes touched by >= 2 ranks are shared and ONLY their rows
-travel.  With the oracle standing in for the kernels (no GPU in this container) the test replays the collectives libpgo issues —
-touch counts (sum) and lowest touching rank (max) at graph build, shared rows of diagonal + gradient per linearisation, shared rows
-of the CG matvec output with BOTH dot products of the iteration riding along (the rank-local partial of u.Au and the owner-weighted
-partial of r.u: the Chronopoulos-Gear form needs no other collective), owner-wise write-back — and checks every rank ends up with the
-single-rank numbers on ITS keyframes."""
+travel.  With the oracle standing in for the kernels (no GPU in this container) the test replays the exchanges libpgo issues (round 6:
+NEIGHBOUR exchanges) — the touch masks at graph build (ONE all-reduce of sum 2^rank: who touches a keyframe, the lowest of them owns it), the
+partial rows of diagonal + gradient per linearisation and of the CG matvec output sent between the ranks that share a keyframe (send / recv)
+and summed in ascending rank order, BOTH dot products of the iteration in one 2-double all-reduce (the rank-local partial of u.Au and the
+owner-weighted partial of r.u: the Chronopoulos-Gear form needs no other collective), owner-wise write-back — and checks every rank ends up
+with the single-rank numbers on ITS keyframes.  test_level_halo_protocol_over_gloo replays the distributed multigrid's level exchanges with the
+plans csrc/pgo_mg_host.hpp builds (through tests/native/mg_host.cpp): after the sends / receives a rank holds every row its level kernels read."""
 import os
 import socket
 
@@ -53,16 +55,33 @@ def _reduced_operator(H, N, owned_sw, radius, x):
     return y
 
 
-def _exchange_rows(rows_mine, shared_pos_of_mine, n_shared, k, extra=None):
-    """libpgo's exchange_rows: zero buffer of n_shared x k (+ scalars), this rank's shared rows packed in, ONE all-reduce, rows read back"""
-    n_extra = 0 if extra is None else len(extra)
-    buf = torch.zeros(n_shared * k + n_extra, dtype=torch.float64)
-    view = buf[:n_shared * k].view(n_shared, k)
-    view[shared_pos_of_mine] = torch.from_numpy(np.ascontiguousarray(rows_mine))
-    if n_extra:
-        buf[n_shared * k:] = torch.from_numpy(np.asarray(extra, dtype=np.float64))
-    dist.all_reduce(buf)
-    return view[shared_pos_of_mine].numpy().copy(), buf[n_shared * k:].numpy().copy()
+def _exchange_rows(rows_mine, mine_shared, masks, rank, world, extra=None):
+    """libpgo's exchange_rows (round 6): this rank's partial rows of the keyframes it shares with peer q go to q (the keyframes both touch, ascending — both ends derive the same
+    list from the touch masks), the parts are summed in ascending rank order; the iteration's scalars by one small all-reduce"""
+    rows_mine = np.ascontiguousarray(rows_mine)
+    segs, reqs, bufs = {}, [], {}
+    for q in range(world):
+        if q == rank:
+            continue
+        sel = np.nonzero((masks[mine_shared] >> np.uint64(q)) & np.uint64(1))[0]
+        segs[q] = sel
+        if len(sel) == 0:
+            continue
+        bufs[q] = torch.zeros(len(sel), rows_mine.shape[1], dtype=torch.float64)
+        reqs.append(dist.isend(torch.from_numpy(rows_mine[sel].copy()), dst=q))
+        reqs.append(dist.irecv(bufs[q], src=q))
+    for r in reqs:
+        r.wait()
+    total = np.zeros_like(rows_mine)
+    for q in range(world):                                          # ascending rank order, the rank's own part where its rank comes: the same bits on every rank
+        if q == rank:
+            total += rows_mine
+        elif len(segs[q]):
+            total[segs[q]] += bufs[q].numpy()
+    if extra is None:
+        return total, None
+    ex = torch.from_numpy(np.asarray(extra, dtype=np.float64).copy()); dist.all_reduce(ex)
+    return total, ex.numpy()
 
 
 def _worker(rank, world, port, policy, out):
@@ -74,10 +93,11 @@ def _worker(rank, world, port, policy, out):
     P, owned_sw, touched = _local_problem(g, sharding.partition(g, world, policy)[rank])
     cost, _, grad = P.evaluate(q, t, s, want_residuals=False)
     H = P.dense_normal_matrix(q, t, s)
-    # ---- graph build: how many ranks touch each keyframe (sum) and the lowest of them (max of world - rank)
-    cnt = torch.from_numpy(touched.astype(np.float64)); dist.all_reduce(cnt)
-    low = torch.from_numpy(np.where(touched, float(world - rank), 0.0)); dist.all_reduce(low, op=dist.ReduceOp.MAX)
-    cnt = cnt.numpy().astype(int); owner = world - low.numpy().astype(int)
+    # ---- graph build: ONE all-reduce of sum 2^rank over the touching ranks: who they are, how many, the lowest of them (the owner)
+    mk = torch.from_numpy(np.where(touched, float(1 << rank), 0.0)); dist.all_reduce(mk)
+    masks = mk.numpy().astype(np.uint64)
+    cnt = np.array([bin(int(m)).count("1") for m in masks])
+    owner = np.array([(int(m) & -int(m)).bit_length() - 1 for m in masks])
     assert cnt.min() >= 1 and not touched.all()                  # every keyframe is somebody's, nobody holds them all
     shared = np.nonzero(cnt >= 2)[0]                              # the same ordered list on every rank
     pos_of = -np.ones(N, int); pos_of[shared] = np.arange(len(shared))
@@ -88,7 +108,7 @@ def _worker(rank, world, port, policy, out):
     # ---- linearisation: cost (scalar sum), diagonal + gradient rows of the SHARED keyframes only
     tc = torch.tensor([cost], dtype=torch.float64); dist.all_reduce(tc)
     dg = np.concatenate([rows(np.diag(H)[:6 * N].copy(), 6), rows(grad[:6 * N].copy(), 6)], axis=1)    # [N][12]
-    got, _ = _exchange_rows(dg[mine_shared], pos_of[mine_shared], len(shared), 12)
+    got, _ = _exchange_rows(dg[mine_shared], mine_shared, masks, rank, world)
     dg[mine_shared] = got
     diag_l, grad_l = dg[mine, :6], dg[mine, 6:]                   # complete on this rank's keyframes
     # ---- damped operator: the OWNER adds the damping once; shared rows of y summed, x.(A_r x) rides along
@@ -103,7 +123,7 @@ def _worker(rank, world, port, policy, out):
     assert np.abs(np.delete(y, mine, axis=0)).max(initial=0.0) == 0.0     # A_r only reaches the rank's own keyframes
     pAp_local = float((rows(x, 6)[mine] * y[mine]).sum())                       # rank-local partial: sum over ranks = x.Ax
     xx_local = float((own_w[:, None] * rows(x, 6)[mine] ** 2).sum())           # owner-weighted partial: every keyframe counted once
-    got, extra = _exchange_rows(y[mine_shared], pos_of[mine_shared], len(shared), 6, [pAp_local, xx_local])   # ONE all-reduce
+    got, extra = _exchange_rows(y[mine_shared], mine_shared, masks, rank, world, [pAp_local, xx_local])   # neighbour sends / receives + ONE 2-double all-reduce
     y[mine_shared] = got
     # ---- write-back: owners scatter their keyframes into a zeroed global array, one all-reduce replicates it
     wb = torch.zeros(N, 6, dtype=torch.float64)
@@ -142,6 +162,75 @@ def test_rank_local_subgraphs_reproduce_the_full_system(tmp_path, world, policy)
         assert abs(r["pAp"][0] - x @ (A @ x)) <= 1e-10 * abs(x @ (A @ x))           # sum over ranks of the rank-local partials
         assert abs(r["xx"][0] - x @ x) <= 1e-12 * (x @ x)                             # every keyframe counted once
         assert np.abs(r["y_all"] - Ax).max() <= 1e-10 * np.abs(Ax).max()             # owner-wise write-back
+
+
+def _halo_worker(rank, world, port, policy, out):
+    import ctypes as C
+    from solve_keyframe_pose_graph_amd import graphgen
+    from tests import test_mg_distributed as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "native", "libmg_host.so"))
+    lib.mgh_build.restype = C.c_void_p
+    g = graphgen.generate(4000, 2000, odom_f_max=2, seed=9)
+    sel = sharding.partition(g, world, policy)[rank]
+    touched = np.zeros(g.n_poses, bool)
+    for a in (g.odom_c1[sel("odom", g.n_odom)], g.odom_c2[sel("odom", g.n_odom)], g.loop_c1[sel("loop", g.n_loops)], g.loop_c2[sel("loop", g.n_loops)], g.reg_node[sel("reg", len(g.reg_node))]):
+        touched[a] = True
+    mk = torch.from_numpy(np.where(touched, float(1 << rank), 0.0)); dist.all_reduce(mk)          # the graph build's one all-reduce
+    masks = mk.numpy().astype(np.uint64)
+    # every rank builds the SAME hierarchy from the global graph + the masks, and its own plans
+    h = D.build_owned(lib, g, masks, world, dist_min_rows=64, smoothed=1, policy=policy)      # (the owners: libpgo's second all-reduce, computed here from the partition)
+    L = D.levels_of(lib, h, world)
+    P = D.plans_of(lib, h, masks, world, 64, rank, len(L))
+    ok = []
+    for l, A in enumerate(L):
+        own = D.owner_of_rows(A, world)
+        truth = np.stack([np.arange(A["n"]) * 1.5 + 7.0 + 100.0 * l + c for c in range(6)], axis=1)       # 6 doubles per node, like a level vector
+        vec = np.where((own == rank)[:, None], truth, np.nan)
+        X = P[l]
+        reqs, rb = [], {}
+        for q in range(world):
+            if q == rank:
+                continue
+            s_idx = X["send_idx"][X["send_off"][q]:X["send_off"][q + 1]]
+            n_r = int(X["recv_off"][q + 1] - X["recv_off"][q])
+            if len(s_idx):
+                reqs.append(dist.isend(torch.from_numpy(vec[s_idx].copy()), dst=q))
+            if n_r:
+                rb[q] = torch.zeros(n_r, 6, dtype=torch.float64)
+                reqs.append(dist.irecv(rb[q], src=q))
+        for r in reqs:
+            r.wait()
+        for q, b in rb.items():
+            vec[X["recv_idx"][X["recv_off"][q]:X["recv_off"][q + 1]]] = b.numpy()
+        rows = np.nonzero(own == rank)[0]
+        if A["distributed"]:
+            cols = np.unique(np.concatenate([A["col"][A["rowptr"][i]:A["rowptr"][i + 1]] for i in rows])) if len(rows) else np.zeros(0, int)
+            ok.append(bool(np.array_equal(vec[cols], truth[cols])) and bool(np.isnan(vec).any()))        # the halo is there, and it is a halo, not a gather
+        else:
+            ok.append(bool(np.array_equal(vec, truth)))
+    np.savez(out % rank, ok=np.array(ok), n_levels=len(L), distributed=np.array([A["distributed"] for A in L]))
+    lib.mgh_free(h)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world,policy", [(2, "spatial"), (3, "spatial")])
+def test_level_halo_protocol_over_gloo(tmp_path, world, policy):
+    from tests.test_mg_hierarchy import shim as _shim_fixture  # noqa: F401  (the native library is built by that module's fixture; build it here when missing)
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    so, src = os.path.join(here, "native", "libmg_host.so"), os.path.join(here, "native", "mg_host.cpp")
+    hdr = os.path.join(os.path.dirname(here), "solve_keyframe_pose_graph_amd", "csrc", "pgo_mg_host.hpp")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", os.path.dirname(hdr), "-o", so, src])
+    out = str(tmp_path / "halo%d.npz")
+    mp.spawn(_halo_worker, args=(world, _free_port(), policy, out), nprocs=world, join=True)
+    for rank in range(world):
+        r = np.load(out % rank)
+        assert r["ok"].all(), (rank, r["ok"])
+        assert r["distributed"][:-1].any() and not r["distributed"][-1]
 
 
 def test_policies_deal_out_every_edge_exactly_once():
