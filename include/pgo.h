@@ -182,7 +182,8 @@ typedef struct pgo_options {
                                           *    ONE partial-sum re-reduction per iteration (in the vector update) instead of two — whenever cg_rel_tolerance >= 1e-11 and the graph has at most 150 000
                                           *    keyframes (beyond that the four more vectors its update moves cost more than the head it saves: measured); the same iterates in exact
                                           *    arithmetic, its attainable accuracy is a little lower, so tighter tolerances (the 1e-12 / 1e-13 parity settings) keep the classic two-reduction
-                                          *    form, and so does the two-level method's fused three-kernel iteration.  0: classic form everywhere.  Several ranks always run the single-reduction form. */
+                                          *    form.  The two-level method: its FUSED three-kernel iteration (aggregates small enough for the update kernel's groups: every session-sized graph) runs the
+     *    single-reduction form under the same two gates; its unfused form stays classic.  0: classic form everywhere.  Several ranks always run the single-reduction form. */
     int32_t mg_explicit_transfer;        /* 1: a multigrid level with a smoothed transition above it applies that transition through the EXPLICIT operator R^T = Ps - Dinv W (fp32 blocks on the
                                           *    pattern of W = A Ps, formed once per LM system): pre-smoothing step + smoothed restriction and smoothed prolongation + post-smoothing step
                                           *    become  v = x + Dinv (r - A x), r_next = R r  and  x = v + R^T x_next — two row products on that level per cycle, two launches fewer per
@@ -270,6 +271,11 @@ typedef struct pgo_summary {
     int32_t reserved2_;
 } pgo_summary;
 
+/* ABI contract: pgo_options, pgo_iteration, pgo_summary and pgo_sharding_stats carry no size field — fields are only ever APPENDED, and the library copies the struct at ITS
+ * size.  A caller must therefore be compiled against the header of the library it loads: check pgo_abi_version() == PGO_ABI_VERSION (bumped whenever a struct grows) or the
+ * sizes below at start-up; never pass a struct compiled against an older header (the library would read past it).  INTEGRATION.md §2. */
+#define PGO_ABI_VERSION 6
+int32_t pgo_abi_version(void);
 /* sizeof(pgo_options), sizeof(pgo_iteration), sizeof(pgo_summary) as the LIBRARY was compiled: a caller built against another header version finds out at start-up
  * instead of reading a shifted struct (which = 0, 1, 2; anything else: 0). */
 int64_t pgo_abi_sizeof(int32_t which);

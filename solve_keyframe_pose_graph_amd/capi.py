@@ -67,8 +67,9 @@ class ShardingStats(C.Structure):
 
 
 # every symbol include/pgo.h declares (checked by tests/test_capi_symbols.py against the header text)
+ABI_VERSION = 6      # PGO_ABI_VERSION of the include/pgo.h this view mirrors
 EXPORTS = [
-    "pgo_abi_sizeof", "pgo_options_init", "pgo_create", "pgo_destroy", "pgo_set_options", "pgo_reserve",
+    "pgo_abi_version", "pgo_abi_sizeof", "pgo_options_init", "pgo_create", "pgo_destroy", "pgo_set_options", "pgo_reserve",
     "pgo_add_relpose_edges", "pgo_add_switchable_edges", "pgo_set_node_regularizers", "pgo_set_nodes_constant",
     "pgo_num_relpose_edges", "pgo_num_switchable_edges", "pgo_num_regularizers",
     "pgo_set_vio_poses", "pgo_num_vio_poses", "pgo_add_odometry_edges_from_vio", "pgo_initial_guess_from_vio", "pgo_get_relpose_edge_records",
@@ -107,6 +108,9 @@ def load(build=True):
     for f in EXPORTS:
         if not hasattr(lib, f):
             raise RuntimeError("libpgo.so does not export %s" % f)
+    lib.pgo_abi_version.restype = C.c_int32
+    if lib.pgo_abi_version() != ABI_VERSION:
+        raise RuntimeError("libpgo.so speaks ABI %d, this ctypes view %d: rebuild the library from this tree" % (lib.pgo_abi_version(), ABI_VERSION))
     lib.pgo_abi_sizeof.restype = C.c_int64
     lib.pgo_abi_sizeof.argtypes = [C.c_int32]
     for which, T in enumerate((Options, Iteration, Summary)):

@@ -99,8 +99,8 @@ inline void parallel_ranges(int32_t n, int parts, Fn fn) {
     if (parts == 1 || n < 2048) { fn(0, 0, n); return; }
     // exception safety (the C-ABI above never throws; an allocation failure inside fn must not reach std::terminate): the helper threads are joined on EVERY exit of this
     // function — also while an exception thrown by fn on the calling thread unwinds — and an exception inside a helper thread is caught there and re-thrown here as bad_alloc
+    std::atomic<bool> helper_failed{false};      // (declared BEFORE the joiner: destroyed after it, i.e. after the helper threads that may still store to it have been joined)
     struct Joiner { std::vector<std::thread> th; ~Joiner() { for (std::thread& t : th) if (t.joinable()) t.join(); } } j;
-    std::atomic<bool> helper_failed{false};
     const int32_t step = (n + parts - 1) / parts;
     for (int k = 0; k + 1 < parts; ++k) {
         const int32_t lo = std::min<int64_t>((int64_t)k * step, n), hi = std::min<int64_t>((int64_t)(k + 1) * step, n);

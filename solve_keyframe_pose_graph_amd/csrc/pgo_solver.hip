@@ -1495,7 +1495,8 @@ int mg_apply_ranks(pgo_problem* p, bool inside_iteration) {
 
 // One GPU, matrix-free matvec, tolerance not below 1e-11: the PCG runs in its single-reduction (Chronopoulos-Gear) form — matvec w = A u with the partials of u.w, then ONE
 // vector kernel whose head re-reduces u.w and r.u together (pgo_kernels.hip: sr_head).  Decided by the options alone, so every phase of a paused PCG runs the same form.
-// The two-level method keeps the classic form (its fused three-kernel iteration folds the prolongation into the direction update of the classic matvec).
+// The two-level method: its FUSED three-kernel iteration has a single-reduction form of its own (launch_mf_apply_dot_live_coarse + launch_cg_update_restrict_sr) and runs it under the
+// same gates (tolerance >= 1e-11, <= 150 000 keyframes); only its unfused form — aggregates too large for the update kernel's groups — stays classic.
 bool single_reduction(const pgo_problem* p) {
     // (the two-level method: only its fused three-kernel iteration has a single-reduction form; its unfused form — aggregates too large for the update kernel's groups — stays classic)
     const bool two_level = p->coarse_active && !p->mg_active;
@@ -2433,6 +2434,7 @@ int add_edges(pgo_problem* p, HostClass& H, int64_t n, const int32_t* c1, const 
 // ================================================================================================
 extern "C" {
 
+int32_t pgo_abi_version(void) { return PGO_ABI_VERSION; }
 int64_t pgo_abi_sizeof(int32_t which) { return which == 0 ? (int64_t)sizeof(pgo_options) : which == 1 ? (int64_t)sizeof(pgo_iteration) : which == 2 ? (int64_t)sizeof(pgo_summary) : 0; }
 
 void pgo_options_init(pgo_options* o) {
