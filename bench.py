@@ -93,7 +93,8 @@ def cpu_baseline(sample_poses, max_iters, budget_s):
         _, _, _, sm = O.solve(q, t, s, opt)
         wall = time.time() - t0
         iters = max(1, sm.num_iterations)
-        runs[label] = dict(ips=iters / sm.seconds_total, wall=wall, lin=sm.seconds_linear_solver, jac=sm.seconds_jacobian, fill=sm.chol_nnz_blocks, iters=iters)
+        runs[label] = dict(ips=iters / sm.seconds_total, wall=wall, lin=sm.seconds_linear_solver, jac=sm.seconds_jacobian, fill=sm.chol_nnz_blocks, iters=iters,
+                           chol_gflops=float(ob.lib().orc_last_cholesky_flops()) * 1e-9)
     one, allc = runs["one_thread"], runs["all_cores"]
     # How the 1-thread time grows with the graph: the same run on half the sample.  The sparse Cholesky's fill grows faster than the edge count on this mesh-like
     # graph, so the LINEAR scaling to 300k edges used for `value` flatters the CPU; the measured exponent and the power-law extrapolation stand next to it.
@@ -119,15 +120,26 @@ def cpu_baseline(sample_poses, max_iters, budget_s):
     tj = time.time()
     O3.evaluate(q3, t3, s3, want_residuals=False, want_gradient=True)
     jac_ms = 1e3 * (time.time() - tj)
+    full = measured_c3()      # the port on the FULL C3 graph, measured on a GPU box's host (static file of an earlier round: 30 minutes of CPU per iteration do not fit this run)
+    linear_value = one["ips"] * edges / C3_EDGES
+    port_rate = one["chol_gflops"] * one["iters"] / max(one["lin"], 1e-9)      # GFLOP/s of the port's factorisations on the sample
     return {
-        "value": one["ips"] * edges / C3_EDGES,   # LINEAR edge scaling to C3 size: optimistic for the CPU (sparse Cholesky is super-linear)
-        "unit": "LM iters/s (C3-equivalent)",
+        # round 6: `value` is the MEASURED full-size figure where one exists; the sample scaled linearly by edges — optimistic for the CPU by two orders of
+        # magnitude, the sparse Cholesky being super-linear — stays as a labelled extra
+        "value": full["value"] if full and full.get("value") else linear_value,
+        "value_is": ("MEASURED on the full C3 graph: %s" % full["note"] + " (" + full["file"] + ")") if full and full.get("value") else "the sample of this run scaled linearly by edges (no full-size measurement on file)",
+        "unit": "LM iters/s (C3)",
         "cores": 1,
         "kind": "port",
-        "sample": "%d LM iterations of the oracle on a C3-structured %d-pose / %d-edge graph (same generator, seed 3): %.3f LM iters/s on the sample "
-                  "(%.2f s, linear solver %.2f s, Jacobians %.2f s, Cholesky fill %d blocks), scaled linearly by edge count to 300k edges"
-                  % (one["iters"], g.n_poses, edges, one["ips"], one["wall"], one["lin"], one["jac"], one["fill"]),
+        "sample": "%d LM iterations of the oracle on a C3-structured %d-pose / %d-edge graph (same generator, seed 3), timed in this run: %.3f LM iters/s on the sample "
+                  "(%.2f s, linear solver %.2f s, Jacobians %.2f s, Cholesky fill %d blocks, %.1f GFLOP per factorisation = %.2f GFLOP/s)"
+                  % (one["iters"], g.n_poses, edges, one["ips"], one["wall"], one["lin"], one["jac"], one["fill"], one["chol_gflops"], port_rate),
         "sample_iters_per_s": one["ips"],
+        "sample_scaled_linearly_by_edges": linear_value,
+        "port_cholesky_gflops_per_s": port_rate,
+        "what_a_supernodal_solver_would_change": "the port's up-looking 6x6-block Cholesky runs at the rate above; a supernodal code (CHOLMOD: BLAS-3 panels) reaches 10-30x that on one core at C3's "
+                                                 "fill (21.9 M blocks) — scipy's SuperLU, the one supernodal solver in this image, is 4.7x SLOWER than the port on the 24 000-pose sample "
+                                                 "(profiles/r06_cpu_supernodal_crosscheck.json), so it is no better baseline; Ceres + CHOLMOD cannot be built here (reference CMakeLists.txt:22-23)",
         "all_cores": {"value": allc["ips"] * edges / C3_EDGES, "cores": nthreads, "sample_iters_per_s": allc["ips"],
                       "note": "residual blocks / Jacobians on %d OpenMP threads of the host's %d cpus (%.2f s -> %.2f s), sparse Cholesky serial (%.2f s)" % (nthreads, ncpu, one["jac"], allc["jac"], allc["lin"])},
         "c3_jacobian_evaluation_ms": jac_ms,   # CPU (1 thread) residuals + autodiff Jacobians + J^T r of all 300k C3 edges; GPU: roofline.avg_launch_ms

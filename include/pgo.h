@@ -194,12 +194,14 @@ typedef struct pgo_options {
     int32_t cg_pause_always;             /* 0: both early-rejection pauses where a rejection is in the air (previous step rejected, or the last accepted step's relative decrease below 0.8), the
                                           *    first pause alone where the system is expensive (predicted block-Jacobi-equivalent iterations x keyframes >= 5.6e7: one wasted solve outweighs dozens
                                           *    of pauses), none elsewhere; 1: both at every LM system of graphs >= 20 000 keyframes / after the solve's first rejection (round 4's rule) */
-    int32_t mg_smoothed_fine;            /* 0.  1: the transition keyframes -> level 1 is SMOOTHED as well (one GPU): Ps_0 = (I - w_p D^-1 A) P_0, level 1 = Ps_0^T A Ps_0 (one hop wider),
+    int32_t mg_smoothed_fine;            /* -1.  1: the transition keyframes -> level 1 is SMOOTHED as well (one GPU): Ps_0 = (I - w_p D^-1 A) P_0, level 1 = Ps_0^T A Ps_0 (one hop wider),
                                           *    inside the cycle z = D^-1 r + s Ps_0 V_1(Ps_0^T r) with Ps_0 as fp32 blocks in both orientations (two launches of their own per iteration
-                                          *    instead of riding in the vector update and level 1's up-sweep).  EXPERIMENTAL, off: measured on C3 (profiles/r05_smoothed_fine_measured.txt) the
-                                          *    multigrid iterations halve (1 291 -> 612 over 20 LM steps, as the CPU probe predicted) but an iteration costs 258 instead of 122 us — on the real graph
-                                          *    level 1 comes out 2.4x and level 2 2.9x denser (77 784 -> 184 098 and 189 201 -> 549 975 blocks) — and the operators 6.7 instead of 2.6 ms per
-                                          *    system: 65.5 against 81.1 LM iterations/s. */
+                                          *    instead of riding in the vector update and level 1's up-sweep).  It halves the multigrid iterations on every graph measured and costs denser
+                                          *    levels: it pays while those are latency-sized.  -1 (default, round 6): BY THE DENSITY OF THE LEVELS IT MAKES — graphs of up to 80 000
+                                          *    keyframes build the hierarchy with it, and it is kept when the sparse levels hold at most 450 000 blocks (round 5's measurements: +9 ... +52 %
+                                          *    on graphs of 10 000 - 60 000 keyframes whose smoothed levels hold 43 000 - 375 000 blocks — config 2's graph with switchable loop closures
+                                          *    0.107 -> 0.071 s — against -19 ... -43 % on C3, C4 and the f = 1..5 / plain-loop types at 714 000 - 3.9 M blocks,
+                                          *    profiles/r05_smoothed_fine_measured.txt; C3, the benchmark graph: 734 000 blocks, not used).  0: never.  Several ranks: never. */
     /* round 6 (appended) */
     int32_t mg_dist_min_rows;            /* 8192.  Several ranks: a multigrid level with at least this many rows is DISTRIBUTED — every rank runs the cycle's kernels on the rows it owns and
                                           *    receives the rows of other ranks its kernels read by neighbour send/receive; a smaller level is run completely by every rank from gathered vectors

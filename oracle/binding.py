@@ -56,6 +56,7 @@ def lib():
         _lib = C.CDLL(_LIB)
         _lib.orc_create.restype = C.c_void_p
         _lib.orc_destroy.argtypes = [C.c_void_p]
+        _lib.orc_last_cholesky_flops.restype = C.c_double
         _lib.orc_sizeof_summary.restype = C.c_size_t
         _lib.orc_sizeof_options.restype = C.c_size_t
         _lib.orc_odometry_edges_from_vio.restype = C.c_int64

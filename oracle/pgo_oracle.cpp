@@ -237,6 +237,7 @@ struct Summary {
     char message[256];
 };
 
+static double g_last_chol_flops = 0.0;      // floating-point operations of the last Cholesky factorisation (orc_last_cholesky_flops: bench.py reports the port's rate)
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // The LM normal equations in the Jacobi-scaled space:  (S H S + D^2) y = S J^T r,  step = -y.
@@ -416,6 +417,7 @@ static int solve(const Problem& P, const Options& opt, State& x, int N, int S, S
         bool ok = ns.solve(P, N, S, rel, swe, pri, node_free, sw_free, scale, D2, g, step);
         sum.seconds_linear_solver += now_s() - tl;
         sum.chol_nnz_blocks = ns.chol.nnz_blocks;
+        g_last_chol_flops = ns.chol.flops;
         double model_cost_change = 0;
         if (ok) {
             for (double v : step) if (!std::isfinite(v)) { ok = false; break; }
@@ -499,6 +501,9 @@ static int solve(const Problem& P, const Options& opt, State& x, int N, int S, S
 using namespace orc;
 
 extern "C" {
+
+// flops of the most recent block Cholesky factorisation of this process (2 * 216 per 6x6 block update, oracle/sparse_chol.hpp)
+double orc_last_cholesky_flops(void) { return g_last_chol_flops; }
 
 // --- single-block evaluation (golden-vector checks) ---
 // ambient Jacobians are what AutoDiffCostFunction::Evaluate returns (row-major rows x {14,15,7});

@@ -201,6 +201,7 @@ struct pgo_problem {
     // aggregation multigrid (MgDev): hierarchy arrays live in three pooled buffers
     DBuf<double> d_mg_f64; DBuf<int32_t> d_mg_i32; DBuf<int64_t> d_mg_i64;
     MgDev M{}; MgLevelDev mg_levels[MG_MAX_LEVELS];
+    int mg_fine_auto = -1;                 // mg_smoothed_fine < 0: the decision of this graph build (-1 not taken yet, 0 / 1), written by the hierarchy's worker before it is joined
     bool mg_fine = false; MgLevelDev mg_fineF{}, mg_fineT{};      // smoothed keyframe transition (opt.mg_smoothed_fine): the keyframe level's set-up view and transfer view
     bool mg_built = false, mg_active = false;
     pgo_mg::BuildCache mg_cache;           // what the hierarchy builder keeps for a regroup of the same graph
@@ -368,8 +369,15 @@ int mg_prepare_impl(pgo_problem* p, const double* sw_now, MgPrepared& Q) {
     std::vector<int32_t>& agg0_l = Q.agg0_l; std::vector<int32_t>& mem0_ptr_l = Q.mem0_ptr_l; std::vector<int32_t>& mem0_l = Q.mem0_l;
     std::vector<double>& inv_cnt = Q.inv_cnt;
     std::vector<int64_t> fine_rowptr, fine_ent; std::vector<int32_t> fine_col;
-    const bool want_fine = p->opt.mg_smoothed_fine != 0 && !p->local_ids;
-    if (want_fine) {
+    // smoothed keyframe transition (one GPU): 1 = on, 0 = off, < 0 = BY THE DENSITY OF THE LEVELS IT MAKES (round 6).  It halves the multigrid iterations everywhere and pays
+    // while its denser levels are still latency-sized: over the eight graph types measured in round 5 the sparse levels of the smoothed hierarchy hold 43 000 - 375 000 blocks where
+    // it wins (+9 ... +52 %) and 714 000 - 3.9 M where it loses (-19 ... -43 %).  So the hierarchy is built WITH it (graphs beyond 80 000 keyframes are not tried: C3's 100 000 give
+    // 734 000 blocks), its blocks are counted, and above SMOOTHED_FINE_MAX_BLOCKS it is built again without (level-0 matching and level-1 structure come from the cache; all of
+    // this runs on the worker thread beside build_graph).  Decided once per graph build — a regroup keeps the decision.
+    constexpr int64_t SMOOTHED_FINE_MAX_BLOCKS = 450000, SMOOTHED_FINE_TRY_MAX_KEYFRAMES = 80000;
+    bool want_fine = !p->local_ids && (p->opt.mg_smoothed_fine > 0 || (p->opt.mg_smoothed_fine < 0 && (p->mg_fine_auto == 1 || (p->mg_fine_auto < 0 && Ng <= SMOOTHED_FINE_TRY_MAX_KEYFRAMES))));
+    const bool fine_on_trial = want_fine && p->opt.mg_smoothed_fine < 0 && p->mg_fine_auto < 0;
+    auto fine_pattern = [&]() {
         // the keyframe level's block pattern: row i = block (i, i), then one block per incident edge (relative-pose edges first, each class in edge order), and what each block IS for
         // fine_block_value (kind 0: the keyframe's reduced diagonal block; 1 / 2: a relative-pose edge seen from its first / second keyframe; 3 / 4: a switchable edge)
         fine_rowptr.assign((size_t)N + 1, 0);
@@ -385,10 +393,23 @@ int mg_prepare_impl(pgo_problem* p, const double* sw_now, MgPrepared& Q) {
         };
         for (int64_t e = 0; e < Er; ++e) add(e, p->rel.c1[e], p->rel.c2[e], 1);
         for (int64_t e = 0; e < Es; ++e) add(e, p->swe.c1[e], p->swe.c2[e], 3);
-    }
+    };
+    if (want_fine) fine_pattern();
     if (!p->local_ids) {
         ok = pgo_mg::build_hierarchy(N, p->h_node_free, p->rel.c1, p->rel.c2, p->rel.meas.data() + 7, 8, p->swe.c1, p->swe.c2, sw_w.empty() ? nullptr : sw_w.data(), passes0, passes, dense_max, MG_TILE_ROWS,
                                      MG_MAX_LEVELS, H, false, MG_BLOCK0, nullptr, n_smoothed, loop_discount, &p->mg_cache, want_fine ? &fine_rowptr : nullptr, want_fine ? &fine_col : nullptr);
+        if (fine_on_trial) {
+            int64_t blocks = 0;
+            if (ok) for (size_t l = 0; l + 1 < H.L.size(); ++l) blocks += (int64_t)H.L[l].col.size();
+            const bool keep = ok && blocks <= SMOOTHED_FINE_MAX_BLOCKS;
+            if (p->opt.verbosity > 0) std::fprintf(stderr, "[pgo] multigrid: smoothed keyframe transition on trial: its sparse levels hold %lld blocks (limit %lld) -> %s\n", (long long)blocks, (long long)SMOOTHED_FINE_MAX_BLOCKS, keep ? "kept" : "not used");
+            p->mg_fine_auto = keep ? 1 : 0;
+            if (!keep) {
+                want_fine = false;
+                ok = pgo_mg::build_hierarchy(N, p->h_node_free, p->rel.c1, p->rel.c2, p->rel.meas.data() + 7, 8, p->swe.c1, p->swe.c2, sw_w.empty() ? nullptr : sw_w.data(), passes0, passes, dense_max, MG_TILE_ROWS,
+                                             MG_MAX_LEVELS, H, false, MG_BLOCK0, nullptr, n_smoothed, loop_discount, &p->mg_cache, nullptr, nullptr);
+            }
+        }
     } else {
         // Several ranks: every rank gathers the endpoints and weights of ALL edges (one all-reduce of a zero-padded buffer: 24 B per edge, once per graph build)
         // and builds the same hierarchy from the global graph; its own edges and owned keyframes are what it contributes to level 1 (pgo_mg_host.hpp).
@@ -952,7 +973,7 @@ int build_graph(pgo_problem* p, int64_t N, int64_t S, const double* sw_now) {
     // only, so it runs on a worker thread beside the rest of this function — incident-list upload, matrix-free tile packing, buffer allocation — and is installed where
     // build_multigrid used to compute it.  Nothing here depends on timing: the result is the same hierarchy.  (Several ranks: its host half holds collectives.)
     struct Guard { pgo_problem* p; bool committed = false; ~Guard() { if (!committed) mg_init_drop(p); } } mg_guard{p};     // an early return below waits for the worker and drops its result
-    p->mg_cache.valid = false;
+    p->mg_cache.valid = false; p->mg_fine_auto = -1;
     bool mg_async = false;
     if (!p->local_ids && wants_multigrid(p)) {
         p->mg_init_out.reset(new MgPrepared());
@@ -2481,7 +2502,7 @@ void pgo_options_init(pgo_options* o) {
     o->verbosity = 0;
     o->cg_single_reduction = 1;
     o->cg_pause_always = 0;
-    o->mg_smoothed_fine = 0;
+    o->mg_smoothed_fine = -1;
     o->mg_explicit_transfer = 1;
     o->cg_end_game = 1;
 }

@@ -142,7 +142,7 @@ def test_explicit_transfer_operator_is_the_same_cycle(shape):
 
 @pytest.mark.parametrize("shape", ["small_with_oracle", "fixed_keyframes", "default_20k", "multi_world_30k"])
 def test_smoothed_keyframe_transition_keeps_the_trajectory(shape):
-    """mg_smoothed_fine (round 5, experimental, off by default): the transition keyframes -> level 1 smoothed as well — Ps_0 = (I - w_p D^-1 A) P_0 formed from the keyframe level's own blocks,
+    """mg_smoothed_fine (round 5; round 6: by default where the levels it makes stay below 450 000 blocks, one GPU): the transition keyframes -> level 1 smoothed as well — Ps_0 = (I - w_p D^-1 A) P_0 formed from the keyframe level's own blocks,
     level 1 = Ps_0^T A Ps_0, z = D^-1 r + s Ps_0 V_1(Ps_0^T r) inside the PCG.  Another preconditioner for the same systems: same LM trajectory as the default hierarchy (and as the
     oracle where that is affordable), fewer multigrid iterations."""
     oracle = False
