@@ -206,7 +206,13 @@ typedef struct pgo_options {
     int32_t mg_dist_min_rows;            /* 8192.  Several ranks: a multigrid level with at least this many rows is DISTRIBUTED — every rank runs the cycle's kernels on the rows it owns and
                                           *    receives the rows of other ranks its kernels read by neighbour send/receive; a smaller level is run completely by every rank from gathered vectors
                                           *    (a level kernel stays at its 8-10 us latency floor up to ~10 000 rows, so distributing a smaller level buys no kernel time and costs two exchanges).  The hierarchy is the same on every rank, its aggregates never mix owners. */
-    int32_t reserved_r6_;
+    int32_t mg_fine_filter;              /* 0.  1: the smoothed keyframe transition (mg_smoothed_fine) forms its prolongator with a FILTERED matrix: Ps_0 = (I - w_p D_f^-1 A_f) P_0 where A_f keeps the
+                                          *    odometry blocks and drops the switchable loop closures, the dropped blocks LUMPED into the diagonal so that A_f acts on the rigid-body modes as A
+                                          *    does (A_f,ii = A_ii + sym(sum_dropped A_ij T_ji)); W_0 = A Ps_0 and level 1 = Ps_0^T A Ps_0 use the whole matrix.  Level 1 then does not take every
+                                          *    loop closure of a neighbouring keyframe along.  Built and measured in round 6 (profiles/r06_fine_filter_measured.txt), OFF: on C3 the levels come out
+                                          *    1.46x / 1.87x as dense as the plain hierarchy's instead of 2.4x / 2.9x, but the multigrid iterations only fall to 899 (unfiltered: 612, plain: 1 291;
+                                          *    the 20 000-keyframe CPU probe had said 146 : 127 : 265) — 0.272 s against 0.247 s plain on C3, and slower than the unfiltered form on all four
+                                          *    smaller graph types where the smoothed transition pays. */
 } pgo_options;
 
 /* Per-iteration record; mirrors ceres::IterationSummary fields the BriefReport is built from. */

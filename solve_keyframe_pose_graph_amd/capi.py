@@ -29,7 +29,7 @@ class Options(C.Structure):
                 ("mg_omega", C.c_double), ("mg_correction_scale", C.c_double), ("mg_first_passes", C.c_int32), ("mg_passes", C.c_int32), ("mg_dense_max_nodes", C.c_int32), ("mg_switch_iterations", C.c_int32),
                 ("mg_loop_discount", C.c_double), ("mg_regroup_fraction", C.c_double), ("mg_prolongation_damping", C.c_double), ("mg_smoothed_levels", C.c_int32), ("mg_min_keyframes_switchable", C.c_int32),
                 ("device_id", C.c_int32), ("verbosity", C.c_int32), ("cg_single_reduction", C.c_int32), ("mg_explicit_transfer", C.c_int32), ("cg_end_game", C.c_int32), ("cg_pause_always", C.c_int32), ("mg_smoothed_fine", C.c_int32),
-                ("mg_dist_min_rows", C.c_int32), ("reserved_r6_", C.c_int32)]
+                ("mg_dist_min_rows", C.c_int32), ("mg_fine_filter", C.c_int32)]
 
 
 class Iteration(C.Structure):

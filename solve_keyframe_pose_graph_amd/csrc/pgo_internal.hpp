@@ -154,6 +154,7 @@ struct MgLevelDev {
     const int32_t* ps_rowptr; const int32_t* ps_col; const int32_t* w_rowptr; const int32_t* w_col; const int64_t* psT_ptr; const int64_t* psT_ent;
     double* ps_val; double* w_val;
     double* t; double* u; double* y; const double* zero;         // [n][6] residual after pre-smoothing, c Dinv t, the smoothed correction; a vector of zeros
+    double* dlump;                                               // keyframe level, filtered smoothed transition (round 6): [n][36] the diagonal blocks with the dropped blocks lumped in; else null
     // set-up kernels run one wavefront per block: the block's row and the slot of its transposed block come from tables instead of a binary search over rowptr
     // (14 dependent loads at the head of every wavefront of level 1)
     const int32_t* row_of; const int32_t* tr_of;                 // [nnzb] row of block k; slot of block (col, row) (k itself on the diagonal or when absent)
@@ -282,7 +283,7 @@ void launch_mg_assemble(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, 
 void launch_mg_galerkin0(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, const MgDev& M, const MgLevelDev* levels, hipStream_t st, bool hoff_valid = false);
 void launch_k2_offdiag(const GraphDev& G, const LinDev& L, hipStream_t st);
 void launch_mg_assemble_fine(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, const MgLevelDev& F, const MgLevelDev& T, const MgLevelDev& L1, double omega, int32_t* fail, hipStream_t st,
-                             double prolong_scale, bool hoff_valid);      // level 1 = Ps_0^T A Ps_0 (smoothed keyframe transition), then launch_mg_assemble_rest
+                             double prolong_scale, bool hoff_valid, const double* pose8 = nullptr /* filtered form (F.dlump): the keyframes' positions of the current linearisation */);      // level 1 = Ps_0^T A Ps_0 (smoothed keyframe transition), then launch_mg_assemble_rest
 void launch_mg_assemble_rest(const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, double omega, int32_t* fail, hipStream_t st, double prolong_scale = 0.0 /* c = w_p / w of the smoothed transitions */);
 // Several ranks: the cycle is cut into segments by the exchanges its kernels need (pgo_solver.hip issues them); launch_mg_apply calls the hook BEFORE the kernel that reads the
 // exchanged vectors.  point: 0 = down-sweep of `level` (1-based; n_levels = the dense solve) is about to read x (and r) of that level, 1 = the up-sweep of `level` is about to

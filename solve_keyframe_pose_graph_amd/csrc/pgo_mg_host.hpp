@@ -288,7 +288,10 @@ inline void permute_level1(const HostLevel& P, int32_t n, const std::vector<int3
 // Structure of a SMOOTHED transition from level A to the level above, B (n and the parents of A's nodes known): Ps, W = A Ps, Ps by coarse column, B = Ps^T W (diagonal block
 // first), and the explicit operator's tables.  Nodes of A with parent -1 (fixed keyframes on the keyframe level) are outside the system: their rows of Ps and W are empty and
 // they appear in no row as a column.
-inline void smoothed_structure(HostLevel& A, HostLevel& B) {
+// ps_keep (keyframe level only, round 6): Ps is formed with a FILTERED matrix — blocks k of A with ps_keep[k] == 0 (switchable loop closures) do not enter (I - w D_f^-1 A_f) P, so a row
+// of Ps holds the parents of the row's ODOMETRY neighbours only and level 1 does not take every loop closure of a neighbouring keyframe along; W = A Ps and the level above
+// = Ps^T W are formed with the whole matrix (a Galerkin product of the true operator, whatever Ps is).
+inline void smoothed_structure(HostLevel& A, HostLevel& B, const std::vector<uint8_t>* ps_keep = nullptr) {
     // structure of Ps, W = A Ps and B = Ps^T W (all by sorted unions; the numeric kernels search these short rows)
     A.smoothed = true;
     const int32_t n = A.n, nb = B.n;
@@ -311,7 +314,7 @@ inline void smoothed_structure(HostLevel& A, HostLevel& B) {
     };
     rows_in_parallel(n, A.ps_rowptr, A.ps_col, [&](int32_t i, std::vector<int32_t>& tmp, std::vector<int32_t>&) {
         if (A.parent[i] < 0) return;
-        for (int64_t k = A.rowptr[i]; k < A.rowptr[(size_t)i + 1]; ++k) { const int32_t a = A.parent[A.col[k]]; if (a >= 0) tmp.push_back(a); }
+        for (int64_t k = A.rowptr[i]; k < A.rowptr[(size_t)i + 1]; ++k) { if (ps_keep && !(*ps_keep)[(size_t)k]) continue; const int32_t a = A.parent[A.col[k]]; if (a >= 0) tmp.push_back(a); }
         std::sort(tmp.begin(), tmp.end()); tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
     });
     rows_in_parallel(n, A.w_rowptr, A.w_col, [&](int32_t i, std::vector<int32_t>& tmp, std::vector<int32_t>& stamp) {      // unions by marking: each coarse column enters a row's list once
@@ -377,7 +380,8 @@ inline bool build_hierarchy(int64_t N, const std::vector<uint8_t>& node_free, co
                             BuildCache* cache = nullptr /* kept by the caller across rebuilds of the same graph with other switch values (level0_follows_switchable must be false) */,
                             const std::vector<int64_t>* fine_rowptr = nullptr, const std::vector<int32_t>* fine_col = nullptr /* both given: the transition keyframes -> level 1 is SMOOTHED
                             too; the keyframe level's block pattern as the solver holds it (row i: block (i, i) first, then one block per incident edge) */,
-                            const Owners* owners = nullptr /* several ranks, distributed cycle: aggregates never mix owners, levels numbered owner-major (HostLevel::own_ptr) */) {
+                            const Owners* owners = nullptr /* several ranks, distributed cycle: aggregates never mix owners, levels numbered owner-major (HostLevel::own_ptr) */,
+                            const std::vector<uint8_t>* fine_keep = nullptr /* with fine_rowptr / fine_col: blocks of the keyframe level that enter the smoothed prolongator (smoothed_structure) */) {
     H = Hierarchy{};
     const bool owned = owners && owners->touch_mask && owners->owner && owners->world > 1;
     const int world = owned ? owners->world : 1;
@@ -645,7 +649,7 @@ inline bool build_hierarchy(int64_t N, const std::vector<uint8_t>& node_free, co
         H.F = HostLevel{};
         H.F.n = (int32_t)N; H.F.rowptr = *fine_rowptr; H.F.col = *fine_col; H.F.parent = H.agg0;
         HostLevel B1; B1.n = n1;
-        smoothed_structure(H.F, B1);
+        smoothed_structure(H.F, B1, fine_keep);
         H.L[0].rowptr.swap(B1.rowptr); H.L[0].col.swap(B1.col); H.L[0].g_ptr.swap(B1.g_ptr); H.L[0].g_ent.clear();
         PGO_MG_T("fine-level smoothed structure");
     }

@@ -308,13 +308,18 @@ __global__ __launch_bounds__(256) void mg_galerkin_kernel(MgLevelDev A, MgLevelD
     if (own) B.val[(size_t)slot * 36 + bsr_idx(r, c)] = acc;
 }
 // omega x inverse of every diagonal block (Cholesky; a block that is not positive definite raises *fail)
-__global__ __launch_bounds__(256) void mg_dinv_kernel(MgLevelDev A, double omega, int32_t* __restrict__ fail, int skip_orphans /* keyframe level: rows with parent -1 are outside the system */) {
+// `diag` (keyframe level, filtered smoothed transition): the blocks to invert instead of the level's own diagonal blocks — the lumped ones; a lumped block that is not positive
+// definite falls back to the level's own block (the lumping keeps A's action on the rigid modes, it does not have to keep every block definite)
+__global__ __launch_bounds__(256) void mg_dinv_kernel(MgLevelDev A, double omega, int32_t* __restrict__ fail, int skip_orphans /* keyframe level: rows with parent -1 are outside the system */,
+                                                      const double* __restrict__ diag = nullptr) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A.n) return;
     if (skip_orphans && A.parent[i] < 0) { double* out = A.Dinv + (size_t)i * 36; for (int e = 0; e < 36; ++e) out[e] = 0.0; return; }
-    const double* v = A.val + (size_t)A.rowptr[i] * 36;
+    const double* v = diag ? diag + (size_t)i * 36 : A.val + (size_t)A.rowptr[i] * 36;
     double Lm[36];
     bool ok = true;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+    ok = true;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
         double d = v[bsr_idx(j, j)];
@@ -330,6 +335,9 @@ __global__ __launch_bounds__(256) void mg_dinv_kernel(MgLevelDev A, double omega
             for (int k = 0; k < 6; ++k) if (k < j) s -= Lm[r * 6 + k] * Lm[j * 6 + k];
             Lm[r * 6 + j] = s * Lm[j * 6 + j];
         }
+    }
+    if (ok || !diag || attempt == 1) break;
+    v = A.val + (size_t)A.rowptr[i] * 36;      // the lumped block is not positive definite: the level's own
     }
     if (!ok) atomicOr(fail, 1);
     double* out = A.Dinv + (size_t)i * 36;
@@ -374,6 +382,8 @@ __device__ __forceinline__ double mg_pblock(const double* __restrict__ d, int r,
     return sgn * 2.0 * d[o];
 }
 // one wavefront per block (i, a) of Ps; lane l < 36 owns element (l / 6, l % 6).  Row i of A is short: its blocks are scanned for columns whose parent is a.
+// FILT (keyframe level, round 6): the FILTERED matrix — blocks of switchable loop closures (kind 3 / 4 in g_ent) do not enter, the diagonal block is the lumped one (A.dlump)
+template <bool FILT>
 __global__ __launch_bounds__(256) void mg_ps_kernel(MgLevelDev A, double cs) {
     __shared__ double acc_s[4][36];
     const int wv = wave_in_block(), lane = threadIdx.x & 63;
@@ -386,10 +396,12 @@ __global__ __launch_bounds__(256) void mg_ps_kernel(MgLevelDev A, double cs) {
     for (int64_t k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k) {
         const int j = A.col[k];
         if (A.parent[j] != a) continue;
+        if (FILT && (A.g_ent[k] & 7) >= 3) continue;
         if (own) {
             const double* dj = A.d + (size_t)j * 3;
+            const double* blk = (FILT && k == A.rowptr[i]) ? A.dlump + (size_t)i * 36 : A.val + (size_t)k * 36;
 #pragma unroll
-            for (int m = 0; m < 6; ++m) acc += A.val[(size_t)k * 36 + bsr_idx(r, m)] * mg_pblock(dj, m, c);
+            for (int m = 0; m < 6; ++m) acc += blk[bsr_idx(r, m)] * mg_pblock(dj, m, c);
         }
     }
     if (own) acc_s[wv][lane] = acc;
@@ -630,6 +642,38 @@ __global__ __launch_bounds__(256) void mg_fine_blocks_kernel(GraphDev G, LinDev 
     const double h = fine_block_value<HOFF>(G, L, Sc, C, F.g_ent[k], lane, r, c, own);
     if (own) F.val[(size_t)k * 36 + bsr_idx(r, c)] = h;
 }
+// Filtered smoothed keyframe transition (round 6): the diagonal blocks of the filtered matrix A_f (odometry blocks kept, switchable loop closures dropped) with the dropped blocks
+// LUMPED in so that A_f keeps A's action on the rigid-body modes:  A_f,ii = A_ii + sym( sum over dropped j of A_ij T_ji ),  T_ji = the rigid motion seen at keyframe j for a
+// motion of keyframe i (dtheta_j = dtheta_i, dt_j = dt_i - 2 [t_j - t_i]x dtheta_i).  Without the lumping the filtered prolongator is useless (CPU probe
+// scripts/research/r5_filtered_fine_probe.py: 1 878 PCG iterations against 146 with it, 127 unfiltered, 265 with the plain transition).  One wavefront per keyframe, lane l < 36 owns
+// element (l / 6, l % 6); blocks in the level's layout (bsr_idx).
+__global__ __launch_bounds__(256) void mg_fine_lump_kernel(MgLevelDev F, const double* __restrict__ pose8) {
+    __shared__ double cs_[4][36];
+    const int wv = wave_in_block(), lane = threadIdx.x & 63;
+    const int64_t i = wave_in_grid();
+    if (i >= F.n) return;
+    const bool own = lane < 36;
+    const int r = own ? lane / 6 : 0, c = own ? lane % 6 : 0;
+    const int64_t k0 = F.rowptr[i], k1 = F.rowptr[i + 1];
+    double acc = 0.0;
+    if (F.parent[i] >= 0) {
+        const double* ti = pose8 + (size_t)i * 8 + 4;
+        for (int64_t k = k0 + 1; k < k1; ++k) {
+            if ((F.g_ent[k] & 7) < 3) continue;
+            const int j = F.col[k];
+            if (F.parent[j] < 0 || j == (int)i) continue;
+            if (own) {
+                const double* tj = pose8 + (size_t)j * 8 + 4;
+                const double d[3] = {tj[0] - ti[0], tj[1] - ti[1], tj[2] - ti[2]};
+#pragma unroll
+                for (int m = 0; m < 6; ++m) acc += F.val[(size_t)k * 36 + bsr_idx(r, m)] * mg_pblock(d, m, c);
+            }
+        }
+    }
+    if (own) cs_[wv][lane] = acc;
+    __builtin_amdgcn_wave_barrier();
+    if (own) F.dlump[(size_t)i * 36 + bsr_idx(r, c)] = F.val[(size_t)k0 * 36 + bsr_idx(r, c)] + 0.5 * (cs_[wv][r * 6 + c] + cs_[wv][c * 6 + r]);
+}
 // Ps_0 rounded to fp32 ONCE and stored twice (T = the transfer view of the keyframe level: rt_valf on Ps's own pattern by keyframe row, r_valf by level-1 row, rT_of_w = slot of
 // block k there): exact transposes of each other, so the preconditioner stays symmetric.  Both in the level kernels' block layout.
 __global__ __launch_bounds__(256) void mg_ps_f32_kernel(MgLevelDev T) {
@@ -731,14 +775,14 @@ void launch_mg_assemble_rest(const MgDev& M, const MgLevelDev* levels, const Coa
         if (l > 0) {
             const MgLevelDev& A = levels[l - 1];
             if (A.smoothed) {
-                hipLaunchKernelGGL(mg_ps_kernel, dim3((unsigned)((A.n_ps + 3) / 4)), dim3(256), 0, st, A, prolong_scale);
+                hipLaunchKernelGGL(mg_ps_kernel<false>, dim3((unsigned)((A.n_ps + 3) / 4)), dim3(256), 0, st, A, prolong_scale);
                 hipLaunchKernelGGL(mg_w_kernel, dim3((unsigned)((A.n_w + 3) / 4)), dim3(256), 0, st, A);
                 if (A.rt_valf) hipLaunchKernelGGL(mg_rt_kernel, dim3((unsigned)((A.n_w + 3) / 4)), dim3(256), 0, st, A);
                 hipLaunchKernelGGL(mg_psTw_kernel, dim3((unsigned)((levels[l].nnzb + 3) / 4)), dim3(256), 0, st, A, levels[l]);
             } else hipLaunchKernelGGL(mg_galerkin_kernel, dim3((unsigned)((levels[l].nnzb + 3) / 4)), dim3(256), 0, st, A, levels[l]);
         }
         if (l + 1 < M.n_levels) {
-            hipLaunchKernelGGL(mg_dinv_kernel, dim3((unsigned)((levels[l].n + 255) / 256)), dim3(256), 0, st, levels[l], omega, fail, 0);
+            hipLaunchKernelGGL(mg_dinv_kernel, dim3((unsigned)((levels[l].n + 255) / 256)), dim3(256), 0, st, levels[l], omega, fail, 0, (const double*)nullptr);
             hipLaunchKernelGGL(mg_val_f32_kernel, dim3((unsigned)((levels[l].nnzb + 3) / 4)), dim3(256), 0, st, levels[l]);
             mg_limit_smoother(levels[l], omega, st);
         }
@@ -750,11 +794,17 @@ void launch_mg_assemble_rest(const MgDev& M, const MgLevelDev* levels, const Coa
 }
 // level 1 of a hierarchy with the smoothed keyframe transition: F = the keyframe level (set-up view), T = its transfer view (Ps's pattern in the explicit operator's fields)
 void launch_mg_assemble_fine(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, const MgLevelDev& F, const MgLevelDev& T, const MgLevelDev& L1, double omega, int32_t* fail, hipStream_t st,
-                             double prolong_scale, bool hoff_valid) {
+                             double prolong_scale, bool hoff_valid, const double* pose8) {
     if (hoff_valid) hipLaunchKernelGGL((mg_fine_blocks_kernel<true>), dim3((unsigned)((F.nnzb + 3) / 4)), dim3(256), 0, st, G, L, Sc, C, F);
     else hipLaunchKernelGGL((mg_fine_blocks_kernel<false>), dim3((unsigned)((F.nnzb + 3) / 4)), dim3(256), 0, st, G, L, Sc, C, F);
-    hipLaunchKernelGGL(mg_dinv_kernel, dim3((unsigned)((F.n + 255) / 256)), dim3(256), 0, st, F, omega, fail, 1);
-    hipLaunchKernelGGL(mg_ps_kernel, dim3((unsigned)((F.n_ps + 3) / 4)), dim3(256), 0, st, F, prolong_scale);
+    if (F.dlump && pose8) {      // filtered form: Ps_0 = (I - c D_f^-1 A_f) P_0 with the lumped diagonal
+        hipLaunchKernelGGL(mg_fine_lump_kernel, dim3((unsigned)((F.n + 3) / 4)), dim3(256), 0, st, F, pose8);
+        hipLaunchKernelGGL(mg_dinv_kernel, dim3((unsigned)((F.n + 255) / 256)), dim3(256), 0, st, F, omega, fail, 1, (const double*)F.dlump);
+        hipLaunchKernelGGL(mg_ps_kernel<true>, dim3((unsigned)((F.n_ps + 3) / 4)), dim3(256), 0, st, F, prolong_scale);
+    } else {
+        hipLaunchKernelGGL(mg_dinv_kernel, dim3((unsigned)((F.n + 255) / 256)), dim3(256), 0, st, F, omega, fail, 1, (const double*)nullptr);
+        hipLaunchKernelGGL(mg_ps_kernel<false>, dim3((unsigned)((F.n_ps + 3) / 4)), dim3(256), 0, st, F, prolong_scale);
+    }
     hipLaunchKernelGGL(mg_w_kernel, dim3((unsigned)((F.n_w + 3) / 4)), dim3(256), 0, st, F);
     hipLaunchKernelGGL(mg_psTw_kernel, dim3((unsigned)((L1.nnzb + 3) / 4)), dim3(256), 0, st, F, L1);
     hipLaunchKernelGGL(mg_ps_f32_kernel, dim3((unsigned)((T.n_ps + 3) / 4)), dim3(256), 0, st, T);

@@ -119,7 +119,7 @@ struct MgPrepared {
     bool have_tab = false;
     // smoothed keyframe transition: the keyframe level F (pgo_mg_host.hpp) — its own block pattern and contribution ids, Ps / W structure, Ps by level-1 row for the restriction
     bool fine = false;
-    struct FineOff { size_t rowptr, col, ent, ps_rowptr, ps_col, w_rowptr, w_col, psT_ptr, psT_ent, ps_row, w_row, rT_of_ps, rT_col, rT_rows, val, Dinv, ps_val, w_val, rt_valf, r_valf; int rT_tiles, rT_seg_shift; } fo{};
+    struct FineOff { size_t rowptr, col, ent, ps_rowptr, ps_col, w_rowptr, w_col, psT_ptr, psT_ent, ps_row, w_row, rT_of_ps, rT_col, rT_rows, val, Dinv, ps_val, w_val, rt_valf, r_valf, lump; int rT_tiles, rT_seg_shift; bool filtered; } fo{};
     // several ranks: who sends which rows of the level vectors to whom (plans[l]: level l+1; the last: the dense level's residual), and this rank's share of every level
     std::vector<pgo_mg::ExchangePlan> plans;
     std::vector<size_t> o_plan_send, o_plan_recv;      // offsets of the plans' index lists in the int32 pool
@@ -395,9 +395,14 @@ int mg_prepare_impl(pgo_problem* p, const double* sw_now, MgPrepared& Q) {
         for (int64_t e = 0; e < Es; ++e) add(e, p->swe.c1[e], p->swe.c2[e], 3);
     };
     if (want_fine) fine_pattern();
+    // filtered smoothed keyframe transition: the blocks that enter the prolongator — the keyframe's own block and its relative-pose (odometry) edges; switchable loop closures do not
+    std::vector<uint8_t> fine_keep;
+    const bool filtered = want_fine && p->opt.mg_fine_filter != 0 && Es > 0;
+    if (filtered) { fine_keep.resize(fine_ent.size()); for (size_t k = 0; k < fine_ent.size(); ++k) fine_keep[k] = (fine_ent[k] & 7) <= 2 ? 1 : 0; }
     if (!p->local_ids) {
         ok = pgo_mg::build_hierarchy(N, p->h_node_free, p->rel.c1, p->rel.c2, p->rel.meas.data() + 7, 8, p->swe.c1, p->swe.c2, sw_w.empty() ? nullptr : sw_w.data(), passes0, passes, dense_max, MG_TILE_ROWS,
-                                     MG_MAX_LEVELS, H, false, MG_BLOCK0, nullptr, n_smoothed, loop_discount, &p->mg_cache, want_fine ? &fine_rowptr : nullptr, want_fine ? &fine_col : nullptr);
+                                     MG_MAX_LEVELS, H, false, MG_BLOCK0, nullptr, n_smoothed, loop_discount, &p->mg_cache, want_fine ? &fine_rowptr : nullptr, want_fine ? &fine_col : nullptr,
+                                     nullptr, filtered ? &fine_keep : nullptr);
         if (fine_on_trial) {
             int64_t blocks = 0;
             if (ok) for (size_t l = 0; l + 1 < H.L.size(); ++l) blocks += (int64_t)H.L[l].col.size();
@@ -622,6 +627,8 @@ int mg_prepare_impl(pgo_problem* p, const double* sw_now, MgPrepared& Q) {
         o.rT_rows = put32(rows);
         o.val = take(F.col.size() * 36); o.Dinv = take((size_t)F.n * 36); o.ps_val = take(F.ps_col.size() * 36); o.w_val = take(F.w_col.size() * 36);
         o.rt_valf = take((F.ps_col.size() * 36 + 1) / 2); o.r_valf = take((F.ps_col.size() * 36 + 1) / 2);
+        o.filtered = filtered && want_fine;
+        o.lump = o.filtered ? take((size_t)F.n * 36) : 0;
     }
     Q.host_ms = (now_s() - t0) * 1e3;
     if (p->opt.verbosity > 1) std::fprintf(stderr, "[pgo] hierarchy (host): pooled arrays + descriptors      (total %.2f ms, %u hardware threads reported)\n", Q.host_ms, std::thread::hardware_concurrency());
@@ -714,6 +721,7 @@ int mg_install(pgo_problem* p, MgPrepared& Q) {
         MgLevelDev& F = p->mg_fineF;
         F.n = Fh.n; F.n_next = H.L[0].n; F.tiles = 0; F.nnzb = (int64_t)Fh.col.size();
         F.tile0 = 0; F.tiles_own = 0; F.rT_row0 = 0; F.rT_row1 = H.L[0].n;      // (one GPU: the restriction covers every level-1 row)
+        F.dlump = o.filtered ? bf + o.lump : nullptr;
         F.rowptr = b64 + o.rowptr; F.col = b32 + o.col; F.val = bf + o.val; F.g_ent = b64 + o.ent; F.Dinv = bf + o.Dinv;
         F.d = p->M.d0; F.parent = p->M.agg0;
         F.smoothed = 1; F.n_ps = (int32_t)Fh.ps_col.size(); F.n_w = (int32_t)Fh.w_col.size();
@@ -2009,7 +2017,7 @@ static int build_mg(pgo_problem* p) {
         HIPCHK(p, hipStreamSynchronize(p->st)); std::fprintf(stderr, "[pgo] multigrid: galerkin0 done at %.2f ms\n", (now_s() - t_build0) * 1e3);
         launch_mg_assemble_rest(p->M, p->mg_levels, p->K, omega, fail, p->st, mg_cs(p));
     } else if (p->mg_fine) {      // smoothed keyframe transition: level 1 = Ps_0^T A Ps_0 from the keyframe level's own blocks
-        launch_mg_assemble_fine(p->G, p->L, p->Sc, p->C, p->mg_fineF, p->mg_fineT, p->mg_levels[0], omega, fail, p->st, mg_cs(p), hoff_valid);
+        launch_mg_assemble_fine(p->G, p->L, p->Sc, p->C, p->mg_fineF, p->mg_fineT, p->mg_levels[0], omega, fail, p->st, mg_cs(p), hoff_valid, p->d_pose[p->cur].p);
         launch_mg_assemble_rest(p->M, p->mg_levels, p->K, omega, fail, p->st, mg_cs(p));
     } else launch_mg_assemble(p->G, p->L, p->Sc, p->C, p->M, p->mg_levels, p->K, omega, fail, p->st, mg_cs(p), hoff_valid);
     if (p->opt.verbosity > 1) { HIPCHK(p, hipStreamSynchronize(p->st)); std::fprintf(stderr, "[pgo] multigrid: level operators done at %.2f ms\n", (now_s() - t_build0) * 1e3); }
@@ -2462,6 +2470,7 @@ void pgo_options_init(pgo_options* o) {
     if (!o) return;
     std::memset(o, 0, sizeof(*o));
     o->mg_dist_min_rows = 8192;
+    o->mg_fine_filter = 0;
     o->max_num_iterations = 10;          // src/PoseGraphSLAM.cpp:1272
     o->linear_solver = PGO_LINEAR_PCG_MATRIX_FREE;
     o->jacobi_scaling = 1;
