@@ -130,7 +130,11 @@ typedef struct pgo_options {
      * rebuilt for every LM system that uses them.  Replaces the two-level preconditioner above on graphs of at least mg_min_keyframes
      * keyframes (0 disables).  No comparison runs and no per-handle history: what runs depends on the solve alone (mg_switch_iterations).
      * Like every preconditioner it changes the iteration count of the PCG, not the solution of a step beyond cg_rel_tolerance. */
-    int32_t mg_min_keyframes;            /* 24000 (graphs without switchable edges; see mg_min_keyframes_switchable).  0 turns the multigrid off for every graph.  Measured in round 2 (20 LM steps) on four graph types at 8k / 15k / 25k keyframes the two-level method wins 3:1 / 3:1 / 1:3
+    int32_t mg_min_keyframes;            /* 5000 (graphs without switchable edges; see mg_min_keyframes_switchable).  0 turns the multigrid off for every graph.  ROUND 6: with the smoothed keyframe
+                                          *      transition (mg_smoothed_fine, by default wherever its levels stay small) the multigrid beats the two-level method from ~4 000 keyframes on, on plain and
+                                          *      switchable loops alike — 10 LM iterations, two-level / multigrid time: 2 000 keyframes 0.60-0.81, 3 000 0.85-0.97, 4 000 0.89-1.08, 6 000 1.45-2.2,
+                                          *      8 000 1.13-2.1, 12 000 1.4-2.4; BASELINE config 2 (10 000 keyframes, plain loops) 0.163 -> 0.111 s (profiles/r06_mg_crossover.txt) — rounds 2-5 had 24 000 here.
+                                          *      Measured in round 2 (20 LM steps) on four graph types at 8k / 15k / 25k keyframes the two-level method wins 3:1 / 3:1 / 1:3
                                           *      against the multigrid (which costs ~3x per iteration); C3-structured 20k keyframes
                                           *      0.66 -> 0.50 s, 100k (C3) 0.70 -> 0.54 s, 200k (C4) 8.8 -> 4.6 s, 1M (C5, 10 steps) 15.8 -> 10.9 s; a 10k-keyframe
                                           *      chain with few loops (C2) is better off with the two-level method (0.32 vs 0.42 s) */
@@ -169,7 +173,7 @@ typedef struct pgo_options {
                                           *      such level costs two more row-product kernels per cycle); the keyframes -> level 1 transition stays the rigid one (its restriction and
                                           *      prolongation ride in the PCG's own kernels).  0: plain aggregation on every level (round 2's cycle).  Measured on a C3-structured
                                           *      20k-keyframe system with four levels, radius 1e6: 1237 PCG iterations without, 551 with the first transition smoothed, 487 with two */
-    int32_t mg_min_keyframes_switchable; /* 8000: graphs WITH switchable loop closures (every graph the reference builds) take the multigrid already from this many keyframes (0: mg_min_keyframes for all).
+    int32_t mg_min_keyframes_switchable; /* 5000 (round 6, see mg_min_keyframes; rounds 3-5: 8000): graphs WITH switchable loop closures (every graph the reference builds) take the multigrid already from this many keyframes (0: mg_min_keyframes for all).
                                           *      Round 3, after the cycle got cheaper (smoothed transition, 8-group rows, regroup): 10 LM iterations, two-level method vs multigrid, time ratio at
                                           *      4 000 / 6 000 / 8 000 / 12 000 / 18 000 keyframes — chain-like 0.93 / 0.97 / 2.05 / 1.30 / 1.03, no outliers 0.98 / 1.04 / 1.09 / 1.41 / 1.25,
                                           *      f = 1..5 + yaw weights 0.99 / 1.20 / 1.35 / 1.40 / 3.18, session-structured 1.41 / 1.20 / 1.43 / 1.13 / 1.70; PLAIN loops (no switches:

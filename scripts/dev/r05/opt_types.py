@@ -26,6 +26,19 @@ if 'types' in which:
               ("40k keyframes, 40k PLAIN loops (no switches)", lambda: graphgen.generate(40000, 40000, odom_f_max=2, seed=10, outlier_frac=0.0), False, 20),
               ("20k keyframes, 20k loops", lambda: graphgen.generate(20000, 20000, odom_f_max=2, seed=3), True, 20),
               ("12k keyframes, 12k loops", lambda: graphgen.generate(12000, 12000, odom_f_max=2, seed=3), True, 20)]
+if 'C2' in which:      # BASELINE config 2 (plain loops, no switch variables) with the reference's 10-iteration budget
+    cases.append(("C2 (10k keyframes, 1k PLAIN loops)", lambda: graphgen.config("C2"), False, 10))
+if 'C2S' in which:     # the same graph with its loop closures switchable (what the reference's trigger builds)
+    cases.append(("C2 graph, loops SWITCHABLE", lambda: graphgen.config("C2"), True, 10))
+if 'mid' in which:     # graphs between the reference's sessions and the benchmark sizes
+    cases += [("8k keyframes, 2k loops", lambda: graphgen.generate(8000, 2000, odom_f_max=2, seed=21), True, 10),
+              ("16k keyframes, 4k loops, f=1..5 + yaw", lambda: graphgen.generate(16000, 4000, odom_f_max=5, apply_yaw_weight=True, seed=22), True, 10),
+              ("30k keyframes, 6k PLAIN loops", lambda: graphgen.generate(30000, 6000, odom_f_max=2, seed=23, outlier_frac=0.0), False, 10)]
+if 'scan' in which:    # where the multigrid (with the smoothed keyframe transition) takes over from the two-level method: plain and switchable loops, 10 LM iterations
+    for n in (2000, 3000, 4000, 6000, 8000, 12000):
+        cases.append(("%d keyframes, %d PLAIN loops" % (n, n // 5), (lambda n=n: graphgen.generate(n, n // 5, odom_f_max=2, seed=30 + n // 1000, outlier_frac=0.0)), False, 10))
+        cases.append(("%d keyframes, %d switchable loops" % (n, n // 5), (lambda n=n: graphgen.generate(n, n // 5, odom_f_max=2, seed=30 + n // 1000)), True, 10))
+        cases.append(("%d keyframes, %d switchable loops, f=1..5 + yaw" % (n, n // 2), (lambda n=n: graphgen.generate(n, n // 2, odom_f_max=5, apply_yaw_weight=True, seed=60 + n // 1000)), True, 10))
 for c in ('C3', 'C4', 'C5'):
     if c in which:
         cases.append((c, (lambda c=c: graphgen.config(c)), True, 10 if c == 'C5' else 20))

@@ -1324,7 +1324,10 @@ extern "C" int pgo_debug_mf_timeline(unsigned long long* out, int n) {
 #endif
 
 template <bool FUSED, bool COARSE = false>
-__global__ __launch_bounds__(MF_BLOCK) void mf_spmv_kernel(GraphDev G, MfDev F, ScaleDev Sc, CgDev C, const double* __restrict__ xin, double* __restrict__ yout,
+#ifndef PGO_MF_WAVES      // A/B aid (variant builds, scripts/dev/ab_variant.py): minimum waves per SIMD the matvec is compiled for (1 = the compiler's choice: 122 VGPRs, 4 waves)
+#define PGO_MF_WAVES 1
+#endif
+__global__ __launch_bounds__(MF_BLOCK, PGO_MF_WAVES) void mf_spmv_kernel(GraphDev G, MfDev F, ScaleDev Sc, CgDev C, const double* __restrict__ xin, double* __restrict__ yout,
                                                            int parity, int first, int nparts, double tol2, CoarseDev K = CoarseDev{}, int pending = 0) {
     __shared__ double contrib[MF_SLOTS * 7];
     __shared__ double pwin[MF_BLOCK];

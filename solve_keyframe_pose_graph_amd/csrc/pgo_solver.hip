@@ -2494,8 +2494,8 @@ void pgo_options_init(pgo_options* o) {
     o->cg_mid_reject_rho = -0.05;
     o->coarse_aggregates = 768;
     o->coarse_min_radius = 1e7;
-    o->mg_min_keyframes = 24000;
-    o->mg_min_keyframes_switchable = 8000;
+    o->mg_min_keyframes = 5000;
+    o->mg_min_keyframes_switchable = 5000;
     o->mg_omega = 0.9;
     o->mg_correction_scale = 1.0;
     o->mg_first_passes = 3;

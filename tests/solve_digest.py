@@ -12,11 +12,13 @@ def graph(name):
     from solve_keyframe_pose_graph_amd import graphgen
     if name in ("C1", "C1F5", "C2", "C3", "C4"):
         return graphgen.config(name), name != "C2"
-    if name == "G6000":          # two-level method, switchable loop closures with outliers
+    if name == "G4000":          # below mg_min_keyframes_switchable (5 000 since round 6): the two-level method, switchable loop closures with outliers
+        return graphgen.generate(4000, 2000, odom_f_max=2, seed=21, outlier_frac=0.1), True
+    if name == "G6000":          # (rounds 3-5: two-level method; round 6: multigrid with the smoothed keyframe transition decided by the density of its levels)
         return graphgen.generate(6000, 3000, odom_f_max=2, seed=21, outlier_frac=0.1), True
     if name == "G12000":         # above mg_min_keyframes_switchable: the hybrid block-Jacobi / multigrid schedule with its regroup worker
         return graphgen.generate(12000, 12000, odom_f_max=2, seed=3), True
-    if name == "P9000":          # plain loops, chain-like: two-level method at large trust-region radii (C2's regime)
+    if name == "P9000":          # plain loops, chain-like (C2's regime): the multigrid since round 6 (two-level method before)
         return graphgen.generate(9000, 900, odom_f_max=1, seed=2, outlier_frac=0.0), False
     raise SystemExit("unknown graph %r" % name)
 

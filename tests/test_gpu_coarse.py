@@ -21,8 +21,9 @@ def run(g, switchable=True, **kw):
 @pytest.mark.parametrize("name,switchable", [("C1", True), ("C1F5", True), ("C2", False)])
 def test_same_trajectory_far_fewer_iterations_on_the_small_configs(name, switchable):
     g = graphgen.config(name)
-    _, t0, s0, off = run(g, switchable, coarse_aggregates=0, cg_max_iterations=200000)
-    _, t1, s1, on = run(g, switchable)
+    # (mg_min_keyframes = 0 on both sides: since round 6 C2's 10 000 keyframes would take the multigrid, and the comparison would be of a run with itself)
+    _, t0, s0, off = run(g, switchable, coarse_aggregates=0, cg_max_iterations=200000, mg_min_keyframes=0)
+    _, t1, s1, on = run(g, switchable, mg_min_keyframes=0)
     assert on.num_iterations == off.num_iterations
     for k in range(off.num_logged):
         a, b = off.iterations[k], on.iterations[k]
@@ -38,7 +39,7 @@ def test_mid_size_graph_matches_the_oracle_with_the_coarse_space_on_at_every_rad
     g = graphgen.generate(8000, 5000, odom_f_max=2, seed=21, outlier_frac=0.1)
     q, t, s = util.initial_state(g, True)
     qo, to, so, sumo = util.oracle_problem(g, True).solve(q, t, s)
-    _, tp, sp, sump = run(g, True)
+    _, tp, sp, sump = run(g, True, mg_min_keyframes=0)      # (the two-level method: since round 6 the multigrid would take this graph)
     assert [sump.iterations[k].step_is_successful for k in range(sump.num_logged)] == [sumo.iterations[k].step_is_successful for k in range(sumo.num_logged)]
     for k in range(sumo.num_logged):
         assert abs(sumo.iterations[k].cost - sump.iterations[k].cost) <= 1e-6 * sumo.iterations[k].cost, k
@@ -100,7 +101,7 @@ def test_two_runs_are_bitwise_identical_with_the_coarse_space():
     q, t, s = util.initial_state(g, True)
     outs = []
     for _ in range(2):
-        P = util.pgo_problem(g, True)
+        P = util.pgo_problem(g, True, mg_min_keyframes=0)      # (the two-level method)
         outs.append(P.solve(q, t, s))
         P.close()
     (qa, ta, sa, suma), (qb, tb, sb, sumb) = outs
@@ -114,7 +115,7 @@ def test_a_handle_that_kept_it_skips_the_comparison_in_its_next_solves():
     next three solves of the handle use it without paying for the plain block-Jacobi run; the fifth compares again."""
     g = graphgen.generate(6918, 1382, odom_f_max=3, seed=12, outlier_frac=0.3)
     q, t, s = util.initial_state(g, True)
-    P = util.pgo_problem(g, True)
+    P = util.pgo_problem(g, True, mg_min_keyframes=0)      # (the two-level method and its once-per-solve comparison: since round 6 the multigrid would take a graph of this size)
     runs = [P.solve(q, t, s)[3] for _ in range(5)]
     P.close()
     cg = [r.cg_iterations for r in runs]

@@ -34,7 +34,7 @@ def digest_in_a_new_process(name, poison=False, **opt):
     return json.loads(line[len("DIGEST "):])
 
 
-@pytest.mark.parametrize("name", ["C1F5", "C2", "P9000", "G6000", "G12000"])
+@pytest.mark.parametrize("name", ["C1F5", "C2", "P9000", "G4000", "G6000", "G12000"])
 def test_two_processes_and_a_poisoned_one_produce_the_same_bits(name):
     a = digest_in_a_new_process(name)
     b = digest_in_a_new_process(name)

@@ -35,9 +35,9 @@ def test_same_trajectory_and_iteration_counts_as_the_classic_form(name):
     elif name == "S3000":      # session-structured (f = 1..5 odometry with yaw weights, 2 degrees per keyframe): two-level method, 384 aggregates, pending coarse correction in every kernel
         g, sw, kw = graphgen.generate(3000, 600, odom_f_max=5, apply_yaw_weight=1, seed=5, **dict(graphgen._SMALL, turn_deg_per_keyframe=2.0)), True, dict()
     elif name == "G6000":      # switchable, below mg_min_keyframes_switchable: two-level method, rejected steps and pauses
-        g, sw, kw = graphgen.generate(6000, 6000, odom_f_max=2, seed=3), True, dict(max_num_iterations=14)
+        g, sw, kw = graphgen.generate(6000, 6000, odom_f_max=2, seed=3), True, dict(max_num_iterations=14, mg_min_keyframes_switchable=8000)      # (pinned: round 6 takes the multigrid from 5 000 keyframes)
     elif name == "P9000":      # plain loops below mg_min_keyframes: two-level method unless the once-per-solve comparison drops it (then block-Jacobi)
-        g, sw, kw = graphgen.generate(9000, 900, odom_f_max=1, seed=4, outlier_frac=0.0), False, dict(max_num_iterations=12)
+        g, sw, kw = graphgen.generate(9000, 900, odom_f_max=1, seed=4, outlier_frac=0.0), False, dict(max_num_iterations=12, mg_min_keyframes=24000)      # (pinned to the two-level method)
     elif name == "G12000":     # switchable, multigrid hierarchy, hybrid start
         g, sw, kw = graphgen.generate(12000, 12000, odom_f_max=2, seed=3), True, dict(max_num_iterations=14)
     elif name == "G30000":     # rejected steps, pauses, warm starts, the multigrid from the first iteration of hard systems
