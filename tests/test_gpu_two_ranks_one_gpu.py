@@ -406,3 +406,59 @@ def test_multigrid_across_ranks_follows_the_single_rank_multigrid(world, policy,
         assert sumr.cg_iterations < 0.5 * sumb.cg_iterations          # and it is the multigrid that runs: far fewer iterations than block-Jacobi
     for r in range(1, world):
         assert np.array_equal(out[0][1], out[r][1]) and np.array_equal(out[0][2], out[r][2])
+
+
+@pytest.mark.parametrize("world,n,loops,policy,opts", [
+    (5, 4000, 2000, "idle", dict(mg_smoothed_levels=1)),                     # an idle rank (no residual blocks): empty row and tile ranges on every level
+    (8, 3000, 1500, "spatial", dict(mg_smoothed_levels=0)),                  # many ranks, few rows each: ranks that own nothing on the small levels; plain aggregation on every level
+    (3, 5000, 5000, "spatial", dict(mg_smoothed_levels=2)),                  # two stacked smoothed transitions, both distributed: explicit operators on consecutive levels
+    (2, 4000, 400, "chain", dict(mg_smoothed_levels=1, mg_dense_max_nodes=16)),   # a deep hierarchy (tiny dense level) on index ranges
+    (4, 6000, 3000, "spatial", dict(mg_smoothed_levels=1, mg_dist_min_rows=300)),  # distributed and completely-run levels mixed
+])
+def test_distributed_multigrid_shapes_follow_the_single_handle(world, n, loops, policy, opts):
+    """The distributed cycle on hierarchy shapes the benchmark configs do not produce (round 6): empty ranges, ranks without rows on a level, consecutive explicit operators, deep
+    hierarchies, distributed and completely-run levels mixed — every level distributed unless the case says otherwise (mg_dist_min_rows = 1).  Same accept/reject sequence and costs
+    as the single handle with the same options, identical results on every rank."""
+    from solve_keyframe_pose_graph_amd import graphgen
+    g = graphgen.generate(n, loops, odom_f_max=2, seed=n // 100 + world)
+    q, t, s = util.initial_state(g, True)
+    base = dict(mg_min_keyframes=1000, mg_min_keyframes_switchable=1000, mg_switch_iterations=0, cg_rel_tolerance=1e-11, max_num_iterations=6, mg_dense_max_nodes=48, mg_smoothed_fine=0)
+    base.update(opts)
+    P = util.pgo_problem(g, True, **base)
+    q1, t1, s1, sum1 = P.solve(q, t, s)
+    P.close()
+    assert sum1.cg_iterations_multigrid > 0
+    parts = idle_last_rank(g, world) if policy == "idle" else sharding.partition(g, world, policy)
+    ar = InProcessAllReduce(world)
+    out, err, stats = [None] * world, [], [None] * world
+
+    def run(rank):
+        try:
+            Pr = capi.problem_from_graph(g, switchable=True, edge_slice=parts[rank], **dict(dict(mg_dist_min_rows=1), **base))
+            ar.attach(Pr, rank)
+            out[rank] = Pr.solve(q, t, s)
+            stats[rank] = Pr.sharding_stats().as_dict()
+            Pr.comm_destroy()
+            Pr.close()
+        except Exception as e:
+            err.append(e)
+            ar.barrier.abort()
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join(timeout=900)
+    assert not err, err
+    ar.close()
+    for r in range(world):
+        qr, tr, sr, sumr = out[r]
+        assert stats[r]["mg_levels_distributed"] >= 1 and sumr.cg_iterations_multigrid > 0, stats[r]
+        assert sumr.num_iterations == sum1.num_iterations
+        assert [sumr.iterations[k].step_is_successful for k in range(sumr.num_logged)] == [sum1.iterations[k].step_is_successful for k in range(sum1.num_logged)]
+        for k in range(sum1.num_logged):
+            assert abs(sumr.iterations[k].cost - sum1.iterations[k].cost) <= 1e-8 * sum1.iterations[k].cost, k
+        assert np.abs(tr - t1).max() <= 1e-6 and np.abs(sr - s1).max() <= 1e-6
+        assert sumr.pcg_retries == 0                                          # the distributed cycle is a positive definite preconditioner: no breakdown, no retry
+        assert sumr.cg_iterations <= 1.6 * sum1.cg_iterations, (sumr.cg_iterations, sum1.cg_iterations)
+    for r in range(1, world):
+        assert np.array_equal(out[0][1], out[r][1]) and np.array_equal(out[0][2], out[r][2])
