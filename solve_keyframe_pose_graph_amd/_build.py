@@ -114,8 +114,21 @@ def build_examples(force=False):
     return EXAMPLE_REPLAY
 
 
+EXAMPLE_RANKS = os.path.join(os.path.dirname(_HERE), "examples", "ranks_in_process")
+
+
+def build_example_ranks(force=False):
+    """examples/ranks_in_process.cpp: N ranks of the sharded solver from one C++ process through the C-ABI alone (in-process communicator)."""
+    build_libpgo(force); build_graphgen(force)
+    src = EXAMPLE_RANKS + ".cpp"
+    if force or _stale(EXAMPLE_RANKS, [src, LIBPGO, LIBGEN, os.path.join(INCLUDE, "pgo.h"), os.path.join(INCLUDE, "pgo_graphgen.h")]):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-I", INCLUDE, "-o", EXAMPLE_RANKS, src, "-L", _HERE, "-l:libpgo.so", "-l:libpgo_graphgen.so", "-Wl,-rpath," + _HERE])
+    return EXAMPLE_RANKS
+
+
 def build_all(force=False):
     build_graphgen(force)
     build_libpgo(force)
     build_host(force)
     build_examples(force)
+    build_example_ranks(force)

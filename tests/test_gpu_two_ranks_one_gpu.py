@@ -462,3 +462,15 @@ def test_distributed_multigrid_shapes_follow_the_single_handle(world, n, loops, 
         assert sumr.cg_iterations <= 1.6 * sum1.cg_iterations, (sumr.cg_iterations, sum1.cg_iterations)
     for r in range(1, world):
         assert np.array_equal(out[0][1], out[r][1]) and np.array_equal(out[0][2], out[r][2])
+
+
+def test_cpp_example_runs_four_ranks_from_one_process():
+    """examples/ranks_in_process.cpp: the sharded solver through the C-ABI alone — pgo_partition_edges, one handle per rank on its own thread, pgo_comm_init_local — against the
+    single handle (the program exits non-zero when decisions or the final cost differ)."""
+    import subprocess
+    from solve_keyframe_pose_graph_amd import _build
+    exe = _build.build_example_ranks()
+    r = subprocess.run([exe, "12000", "4"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    assert "decisions equal" in r.stdout and "4 ranks" in r.stdout, r.stdout
+    print(r.stdout)
