@@ -166,15 +166,20 @@ def main():
     ap.add_argument("--collective", choices=["rccl", "gloo"], default="rccl",
                     help="rccl: libpgo's own RCCL communicator over xGMI (default).  gloo: torch.distributed gloo through pgo_comm_init_custom "
                          "(host staging; lets several ranks share one GPU to validate the multi-rank path on a 1-GPU box)")
+    ap.add_argument("--exchange-via-allreduce", action="store_true", help="several ranks: route the neighbour exchanges through all-reduces of zero-padded buffers instead of ncclSend / ncclRecv (PGO_EXCHANGE_VIA_ALLREDUCE=1: the safety net for a node where RCCL's point-to-point path misbehaves; moves world x the bytes)")
     ap.add_argument("--no-ceres-rule", action="store_true", help="skip the untimed leg that repeats the K iterations with the early-rejection pauses off (Ceres' exact decision rule)")
     ap.add_argument("--partition", choices=["spatial", "chain", "contiguous"], default="spatial", help="how edges are dealt out to the ranks (solve_keyframe_pose_graph_amd/sharding.py)")
     ap.add_argument("--no-c5-strong", action="store_true", help="several ranks, default config: skip the extra BASELINE-config-5 leg (1M poses / 3M edges sharded over the ranks) that is appended as `c5_strong`")
     ap.add_argument("--c5-timeout", type=int, default=300, help="watchdog of that leg, seconds")
+    ap.add_argument("--multi-timeout", type=int, default=900, help="several ranks: watchdog of the WHOLE run up to the bench line, seconds — a collective that never comes back (RCCL's point-to-point path has "
+                    "never run between two physical GPUs in this repo) ends the run with an error line instead of hanging; retry with --exchange-via-allreduce")
     ap.add_argument("--config", choices=["C3", "C5"], default="C3",
                     help="C3 (default): the headline workload, N x C3 on N GPUs = WEAK scaling (what the driver's `bench.py --gpus N` runs).  C5: BASELINE.json config 5 — 1M poses / "
                          "3M edges, the SAME graph whatever N, edges sharded over the ranks = STRONG scaling; `value` is then LM iterations/s of that one graph")
     args = ap.parse_args()
 
+    if args.exchange_via_allreduce:
+        os.environ["PGO_EXCHANGE_VIA_ALLREDUCE"] = "1"      # (read by libpgo once, at its first exchange)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -287,6 +292,18 @@ def main():
             P.comm_destroy()
         P.close()
 
+    main_dog = None
+    if world > 1 and args.multi_timeout > 0:
+        import threading
+
+        def main_give_up():
+            if rank == 0:
+                os.write(result_fd, (json.dumps({"metric": "LM iters/sec + final chi2 vs Ceres, 100k-pose/300k-edge SE(3) graph", "value": None, "unit": "LM iters/s", "n_gpus": args.gpus, "steps": args.steps,
+                                                 "warmup": args.warmup, "error": "no result after %d s with %d ranks over '%s' (a collective did not come back?); retry with --exchange-via-allreduce" % (args.multi_timeout, world, args.collective)}) + "\n").encode())
+            os._exit(3)
+        main_dog = threading.Timer(args.multi_timeout, main_give_up)
+        main_dog.daemon = True
+        main_dog.start()
     P = make_problem()
     q0, t0_, s0 = g.init_q, g.init_t, np.full(g.n_loops, 0.99)
 
@@ -501,6 +518,8 @@ def main():
         except Exception as e:      # the weak figure above is the contract; this leg is reported when it runs
             return {"error": repr(e)}
 
+    if main_dog is not None:
+        main_dog.cancel()      # (everything the contract asks for has been measured; the C5 leg below has a watchdog of its own)
     out = None
     written = [False]
     if rank == 0:

@@ -1304,7 +1304,10 @@ int neighbor_exchange(pgo_problem* p, const pgo_mg::ExchangePlan& X, int K, cons
         if (rc != 0) { p->err = "custom exchange callback failed"; return PGO_ERR_COMM; }
         return PGO_OK;
     }
-    if (p->custom_allreduce) {
+    // PGO_EXCHANGE_VIA_ALLREDUCE=1 (read once; a production switch, not a debug hook): RCCL's point-to-point path is bypassed as well — the safety net for a node where
+    // ncclSend / ncclRecv misbehave (this repo's send / receive path has never run between two physical GPUs)
+    static const bool via_allreduce = []() { const char* e = std::getenv("PGO_EXCHANGE_VIA_ALLREDUCE"); return e && e[0] == '1' && e[1] == 0; }();
+    if (p->custom_allreduce || (p->comm && via_allreduce)) {
         // emulation: [src][dst] segments in one buffer; this rank fills row `r`, the all-reduce fills the rest, column `r` is what it receives
         std::vector<int64_t> off((size_t)W * W + 1, 0);
         for (int i = 0; i < W * W; ++i) off[(size_t)i + 1] = off[(size_t)i] + X.pair_cnt[(size_t)i] * K;
@@ -1313,8 +1316,8 @@ int neighbor_exchange(pgo_problem* p, const pgo_mg::ExchangePlan& X, int K, cons
         HIPCHK(p, p->d_tmp.ensure(total));
         HIPCHK(p, hipMemsetAsync(p->d_tmp.p, 0, total * sizeof(double), p->st));
         for (int q = 0; q < W; ++q) { const int64_t cnt = (X.send_off[(size_t)q + 1] - X.send_off[(size_t)q]) * K; if (cnt > 0) HIPCHK(p, hipMemcpyAsync(p->d_tmp.p + off[(size_t)r * W + q], sendbuf + X.send_off[(size_t)q] * K, (size_t)cnt * sizeof(double), hipMemcpyDeviceToDevice, p->st)); }
-        const int rc = p->custom_allreduce(p->custom_ctx, p->d_tmp.p, (int64_t)total, 0, (void*)p->st);
-        if (rc != 0) { p->err = "custom all-reduce callback failed"; return PGO_ERR_COMM; }
+        int rca;
+        if ((rca = allreduce(p, p->d_tmp.p, total, 0)) != PGO_OK) return rca;
         for (int q = 0; q < W; ++q) { const int64_t cnt = (X.recv_off[(size_t)q + 1] - X.recv_off[(size_t)q]) * K; if (cnt > 0) HIPCHK(p, hipMemcpyAsync(recvbuf + X.recv_off[(size_t)q] * K, p->d_tmp.p + off[(size_t)q * W + r], (size_t)cnt * sizeof(double), hipMemcpyDeviceToDevice, p->st)); }
         return PGO_OK;
     }
