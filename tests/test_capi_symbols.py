@@ -79,3 +79,20 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.lower() or f == "capi.py" and "oracle" not in txt.lower(), os.path.join(dirpath, f)
+
+
+def test_abi_version_and_the_host_only_entry_points_of_round_6():
+    """No GPU needed: the ABI version the ctypes view was written against, the sizes of the structs it mirrors (pgo_sharding_stats has no size query: its layout is pinned here by
+    the field the library would write last), and the in-process communicator's group object — created, aborted, destroyed; refused for worlds the kernels cannot take."""
+    lib = capi.load()
+    assert lib.pgo_abi_version() == capi.ABI_VERSION == 6
+    assert C.sizeof(capi.ShardingStats) == 160 and capi.ShardingStats.exchanges_per_bj_iteration.offset == 156
+    o = capi.default_options()
+    assert o.mg_min_keyframes == 5000 and o.mg_min_keyframes_switchable == 5000 and o.mg_smoothed_fine == -1 and o.mg_dist_min_rows == 8192 and o.mg_fine_filter == 0
+    g = capi.local_group_create(4)
+    assert g.value
+    capi.local_group_abort(g)
+    capi.local_group_destroy(g)
+    for bad in (0, 17):
+        with pytest.raises(capi.PgoError):
+            capi.local_group_create(bad)
