@@ -72,6 +72,24 @@ def measured_c3():
     return None
 
 
+def c3_direct_solve_estimate(full):
+    try:
+        with open(os.path.join(ROOT, "profiles", "r06_cpu_cholesky_flops.json")) as f:
+            c3 = json.load(f)["C3"]
+        tf = c3["cholesky_flops"] * 1e-12
+        out = {"cholesky_tflop_per_lm_iteration": tf, "cholesky_fill_blocks": c3["cholesky_fill_blocks"], "ordering": "approximate minimum degree (oracle/sparse_chol.hpp); a nested-dissection ordering typically needs 2-3x fewer flops on mesh-like graphs",
+               "source": "profiles/r06_cpu_cholesky_flops.json (symbolic factorisation of the full C3 normal matrix, exact)"}
+        if full and full.get("seconds_linear_solver"):
+            out["port_measured_gflops_per_s"] = c3["cholesky_flops"] * 1e-9 / full["seconds_linear_solver"]
+        out["estimates_not_measurements"] = {
+            "one_core_supernodal_at_30_to_60_gflops": {"seconds_per_lm_iteration": [tf * 1e3 / 60.0, tf * 1e3 / 30.0], "lm_iters_per_s": [30.0 / (tf * 1e3), 60.0 / (tf * 1e3)]},
+            "64_cores_at_2_tflops_aggregate": {"seconds_per_lm_iteration": tf / 2.0, "lm_iters_per_s": 2.0 / tf},
+            "note": "what Ceres + CHOLMOD (supernodal, BLAS-3) would need for the factorisation alone at plausible rates on this host; neither can be built here, so these are arithmetic on an exact flop count, not runs"}
+        return out
+    except Exception as e:
+        return {"error": repr(e)}
+
+
 def cpu_baseline(sample_poses, max_iters, budget_s):
     """Times the oracle (oracle/pgo_oracle.cpp: Jet autodiff + Ceres-style LM + exact block-sparse Cholesky) on a C3-structured sample that fits
     the time budget: once with 1 thread (faithful: the reference never sets num_threads, Ceres default 1) and once with the residual blocks
@@ -137,6 +155,9 @@ def cpu_baseline(sample_poses, max_iters, budget_s):
         "sample_iters_per_s": one["ips"],
         "sample_scaled_linearly_by_edges": linear_value,
         "port_cholesky_gflops_per_s": port_rate,
+        # the work ANY direct solver with this ordering has to do per LM iteration on the full C3 graph — exact, from the symbolic factorisation (profiles/r06_cpu_cholesky_flops.json,
+        # oracle orc_cholesky_symbolic: the fill equals the measured run's 21 857 781 blocks) — and what it means at the rates a supernodal code reaches (ESTIMATES, labelled as such)
+        "c3_direct_solve": c3_direct_solve_estimate(full),
         "what_a_supernodal_solver_would_change": "the port's up-looking 6x6-block Cholesky runs at the rate above; a supernodal code (CHOLMOD: BLAS-3 panels) reaches 10-30x that on one core at C3's "
                                                  "fill (21.9 M blocks) — scipy's SuperLU, the one supernodal solver in this image, is 4.7x SLOWER than the port on the 24 000-pose sample "
                                                  "(profiles/r06_cpu_supernodal_crosscheck.json), so it is no better baseline; Ceres + CHOLMOD cannot be built here (reference CMakeLists.txt:22-23)",

@@ -57,6 +57,7 @@ def lib():
         _lib.orc_create.restype = C.c_void_p
         _lib.orc_destroy.argtypes = [C.c_void_p]
         _lib.orc_last_cholesky_flops.restype = C.c_double
+        _lib.orc_cholesky_symbolic.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_longlong), C.POINTER(C.c_double)]
         _lib.orc_sizeof_summary.restype = C.c_size_t
         _lib.orc_sizeof_options.restype = C.c_size_t
         _lib.orc_odometry_edges_from_vio.restype = C.c_int64
@@ -186,6 +187,13 @@ class OracleProblem:
     def set_nodes_constant(self, node):
         na, np_ = _i(node)
         lib().orc_set_nodes_constant(self.h, C.c_int64(len(na)), np_)
+
+    def cholesky_symbolic(self, n_nodes):
+        """(fill in 6x6 blocks, flops) of the exact block Cholesky of this problem's Schur-reduced normal matrix under the port's AMD ordering — symbolic phase only, nothing factorised"""
+        nnz = C.c_longlong(0); fl = C.c_double(0)
+        rc = lib().orc_cholesky_symbolic(self.h, C.c_int64(n_nodes), C.byref(nnz), C.byref(fl))
+        assert rc == 0
+        return int(nnz.value), float(fl.value)
 
     def evaluate(self, q, t, s, want_residuals=True, want_gradient=True):
         qa, qp = _d(q); ta, tp = _d(t); sa, sp = _d(s)

@@ -695,6 +695,34 @@ int orc_dense_normal_matrix(void* h, const double* q, const double* t, const dou
 void orc_options_init(Options* o) { *o = Options(); }
 
 // = ceres::Solve (src/PoseGraphSLAM.cpp:1903).  In/out arrays like pgo_solve.
+// Symbolic Cholesky of the problem's Schur-reduced normal matrix (pattern only: one block row per free keyframe touched by a residual block, one off-diagonal block per edge between two
+// of them), with the port's own AMD ordering: fill in 6x6 blocks and the floating-point operations its numeric factorisation takes — without factorising.  bench.py reports it
+// for the full C3 graph beside the measured time: what any direct solver with this ordering has to do per LM iteration.
+int orc_cholesky_symbolic(void* h, int64_t N, long long* nnz_blocks, double* flops) {
+    const Problem& P = *(Problem*)h;
+    std::vector<char> used((size_t)N, 0);
+    for (const RelEdge& e : P.rel) { used[e.c1] = 1; used[e.c2] = 1; }
+    for (const SwEdge& e : P.swe) { used[e.c1] = 1; used[e.c2] = 1; }
+    for (const Prior& pr : P.pri) used[pr.node] = 1;
+    for (int c : P.constant_nodes) if (c >= 0 && c < N) used[c] = 0;
+    std::vector<int> cid((size_t)N, -1);
+    int na = 0;
+    for (int64_t i = 0; i < N; ++i) if (used[i]) cid[i] = na++;
+    BlockSPD A;
+    A.n = na;
+    A.diag.assign((size_t)na * 36, 0.0);
+    auto off = [&](int a, int b) { if (a != b && cid[a] >= 0 && cid[b] >= 0) { A.oi.push_back(cid[a]); A.oj.push_back(cid[b]); } };
+    for (const RelEdge& e : P.rel) off(e.c1, e.c2);
+    for (const SwEdge& e : P.swe) off(e.c1, e.c2);
+    A.oval.assign(A.oi.size() * 36, 0.0);
+    BlockCholesky chol;
+    chol.symbolic_only = true;
+    if (!chol.analyze_and_factor(A, nullptr)) return 1;
+    if (nnz_blocks) *nnz_blocks = chol.nnz_blocks;
+    if (flops) *flops = chol.flops;
+    return 0;
+}
+
 int orc_solve(void* h, const Options* opt, double* q, double* t, double* s, int64_t N, int64_t S, Summary* sum) {
     Problem* P = (Problem*)h;
     State x = make_state(q, t, s, N, S);

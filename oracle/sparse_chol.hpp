@@ -164,6 +164,7 @@ struct BlockCholesky {
     std::vector<double> val;           // 36 per block
     int64_t nnz_blocks = 0;
     double flops = 0;
+    bool symbolic_only = false;        // analyze_and_factor stops after the symbolic phase: ordering, elimination tree, column counts (nnz_blocks) and the flop count of the numeric phase
 
     // upper-triangular permuted A in block CSC: column k holds rows i<=k
     std::vector<int64_t> acolptr; std::vector<int> arow; std::vector<double> aval;
@@ -246,6 +247,16 @@ struct BlockCholesky {
         colptr.assign(n + 1, 0);
         for (int c = 0; c < n; ++c) colptr[c + 1] = colptr[c] + colcount[c];
         nnz_blocks = colptr[n];
+        if (symbolic_only) {      // the flops the numeric loop below would spend (its own count: 2 * 216 per block update), without touching a value
+            std::fill(flag.begin(), flag.end(), -1);
+            std::vector<int64_t> cnt(n, 1);      // blocks of column i so far (the diagonal block is there from the start)
+            flops = 0;
+            for (int k = 0; k < n; ++k) {
+                const int top = ereach(k, s.data());
+                for (int q = top; q < n; ++q) { const int i = s[q]; flops += 2.0 * 216.0 * (double)cnt[i]; ++cnt[i]; }
+            }
+            return true;
+        }
         rowind.assign(nnz_blocks, 0);
         val.assign((size_t)nnz_blocks * 36, 0.0);
         // ---- numeric, up-looking

@@ -156,3 +156,16 @@ def test_the_c4_golden_starts_at_the_oracles_objective():
     cost = util.oracle_problem(g, True).evaluate(q, t, s, want_residuals=False, want_gradient=False)[0]
     assert abs(cost - gold["iterations"][0]["cost"]) <= 1e-12 * cost
     assert [it["successful"] for it in gold["iterations"]] == [1, 1, 1, 1, 0, 0, 0, 0, 1, 1, 1]
+
+
+def test_symbolic_cholesky_counts_what_the_numeric_factorisation_does():
+    """orc_cholesky_symbolic (bench.py's cpu_baseline.c3_direct_solve: the exact work of a direct solve on the full C3 graph, without running it): fill and flops of the symbolic phase
+    equal those of the numeric factorisation the LM loop runs on the same graph."""
+    from oracle import binding as ob
+    g = util.small_graph(600, 120, f=2, seed=9)
+    O = util.oracle_problem(g, True)
+    fill, flops = O.cholesky_symbolic(g.n_poses)
+    q, t, s = util.initial_state(g, True)
+    _, _, _, sm = O.solve(q, t, s, ob.default_options(max_num_iterations=1))
+    assert fill == sm.chol_nnz_blocks and fill >= g.n_poses
+    assert flops == ob.lib().orc_last_cholesky_flops() and flops > 0
