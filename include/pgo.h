@@ -202,10 +202,11 @@ typedef struct pgo_options {
                                           *    inside the cycle z = D^-1 r + s Ps_0 V_1(Ps_0^T r) with Ps_0 as fp32 blocks in both orientations (two launches of their own per iteration
                                           *    instead of riding in the vector update and level 1's up-sweep).  It halves the multigrid iterations on every graph measured and costs denser
                                           *    levels: it pays while those are latency-sized.  -1 (default, round 6): BY THE DENSITY OF THE LEVELS IT MAKES — graphs of up to 80 000
-                                          *    keyframes build the hierarchy with it, and it is kept when the sparse levels hold at most 450 000 blocks (round 5's measurements: +9 ... +52 %
+                                          *    keyframes build the hierarchy with it, and it is kept when the sparse levels hold at most 280 000 blocks (round 5's measurements: +9 ... +52 %
                                           *    on graphs of 10 000 - 60 000 keyframes whose smoothed levels hold 43 000 - 375 000 blocks — config 2's graph with switchable loop closures
                                           *    0.107 -> 0.071 s — against -19 ... -43 % on C3, C4 and the f = 1..5 / plain-loop types at 714 000 - 3.9 M blocks,
-                                          *    profiles/r05_smoothed_fine_measured.txt; C3, the benchmark graph: 734 000 blocks, not used).  0: never.  Several ranks: never. */
+                                          *    profiles/r05_smoothed_fine_measured.txt; round 6's soak of 36 random graphs found 300 000 - 375 000 blocks a mixed zone, -28 ... +18 %, and no loss below:
+                                          *    profiles/r06_mid_soak.txt; C3, the benchmark graph: 734 000 blocks, not used).  0: never.  Several ranks: never. */
     /* round 6 (appended) */
     int32_t mg_dist_min_rows;            /* 8192.  Several ranks: a multigrid level with at least this many rows is DISTRIBUTED — every rank runs the cycle's kernels on the rows it owns and
                                           *    receives the rows of other ranks its kernels read by neighbour send/receive; a smaller level is run completely by every rank from gathered vectors

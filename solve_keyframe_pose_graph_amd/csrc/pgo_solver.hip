@@ -374,7 +374,10 @@ int mg_prepare_impl(pgo_problem* p, const double* sw_now, MgPrepared& Q) {
     // it wins (+9 ... +52 %) and 714 000 - 3.9 M where it loses (-19 ... -43 %).  So the hierarchy is built WITH it (graphs beyond 80 000 keyframes are not tried: C3's 100 000 give
     // 734 000 blocks), its blocks are counted, and above SMOOTHED_FINE_MAX_BLOCKS it is built again without (level-0 matching and level-1 structure come from the cache; all of
     // this runs on the worker thread beside build_graph).  Decided once per graph build — a regroup keeps the decision.
-    constexpr int64_t SMOOTHED_FINE_MAX_BLOCKS = 450000, SMOOTHED_FINE_TRY_MAX_KEYFRAMES = 80000;
+    // The limit: round 5's eight graph types are separated by anything between 375 000 and 714 000; round 6's soak of 36 random graphs of 5 000 - 80 000 keyframes
+    // (scripts/gpu_mid_soak.py, profiles/r06_mid_soak.txt) found the zone in between mixed — 300 000 blocks -28 % (10 000 keyframes, f = 1..5 + yaw, plain loops), 351 000 +4.5 %,
+    // 371 000 -24 %, 375 000 +18 % — and nothing below 280 000 that loses: a missed gain costs less than a regression, so the limit sits under the mixed zone.
+    constexpr int64_t SMOOTHED_FINE_MAX_BLOCKS = 280000, SMOOTHED_FINE_TRY_MAX_KEYFRAMES = 80000;
     bool want_fine = !p->local_ids && (p->opt.mg_smoothed_fine > 0 || (p->opt.mg_smoothed_fine < 0 && (p->mg_fine_auto == 1 || (p->mg_fine_auto < 0 && Ng <= SMOOTHED_FINE_TRY_MAX_KEYFRAMES))));
     const bool fine_on_trial = want_fine && p->opt.mg_smoothed_fine < 0 && p->mg_fine_auto < 0;
     auto fine_pattern = [&]() {
