@@ -218,6 +218,11 @@ typedef struct pgo_options {
                                           *    1.46x / 1.87x as dense as the plain hierarchy's instead of 2.4x / 2.9x, but the multigrid iterations only fall to 899 (unfiltered: 612, plain: 1 291;
                                           *    the 20 000-keyframe CPU probe had said 146 : 127 : 265) — 0.272 s against 0.247 s plain on C3, and slower than the unfiltered form on all four
                                           *    smaller graph types where the smoothed transition pays. */
+    int32_t mg_dist_setup;               /* 1.  Several ranks: the multigrid's SET-UP (Galerkin products, block-Jacobi inverses, smoothed prolongators and transfer operators of every LM system) is
+                                          *    distributed like its cycle — every rank forms the numbers of its OWN rows of every distributed level; the blocks two ranks share travel by neighbour
+                                          *    send/receive (the parts of a block formed on several ranks are summed, in ascending rank order, where the block is needed), the first level every rank
+                                          *    runs completely is gathered, the small levels above it and the dense inverse are formed by every rank.  0: rounds 3-5's set-up — level 1's blocks
+                                          *    all-reduced (288 B per block), every level above formed by every rank. */
 } pgo_options;
 
 /* Per-iteration record; mirrors ceres::IterationSummary fields the BriefReport is built from. */
@@ -287,7 +292,7 @@ typedef struct pgo_summary {
 /* ABI contract: pgo_options, pgo_iteration, pgo_summary and pgo_sharding_stats carry no size field — fields are only ever APPENDED, and the library copies the struct at ITS
  * size.  A caller must therefore be compiled against the header of the library it loads: check pgo_abi_version() == PGO_ABI_VERSION (bumped whenever a struct grows) or the
  * sizes below at start-up; never pass a struct compiled against an older header (the library would read past it).  INTEGRATION.md §2. */
-#define PGO_ABI_VERSION 6
+#define PGO_ABI_VERSION 7
 int32_t pgo_abi_version(void);
 /* sizeof(pgo_options), sizeof(pgo_iteration), sizeof(pgo_summary) as the LIBRARY was compiled: a caller built against another header version finds out at start-up
  * instead of reading a shifted struct (which = 0, 1, 2; anything else: 0). */
@@ -474,8 +479,18 @@ typedef struct pgo_sharding_stats {
     double bytes_round5_per_mg_iteration;                            /* what round 5's design all-reduced per multigrid iteration on the same graph: (6 shared_global + 2 + 6 n_1) x 8 B */
     double bytes_round5_per_bj_iteration;                            /* (6 shared_global + 2) x 8 B */
     int32_t exchanges_per_mg_iteration, exchanges_per_bj_iteration;  /* neighbour exchanges on the critical path of one iteration */
+    /* the multigrid's set-up (pgo_options.mg_dist_setup; appended in ABI 7) */
+    int32_t mg_setup_levels_own_rows;                                /* sparse levels whose operators this rank forms for its own rows only (0: the set-up is replicated) */
+    int32_t mg_setup_exchanges;                                      /* collectives of one set-up: block exchanges + one 2-double all-reduce per such level (replicated: 1 all-reduce) */
+    int64_t mg_setup_blocks_total, mg_setup_blocks_own;              /* 6x6 blocks one set-up forms (level matrices, Ps, W, R^T of every sparse level): in all, and by THIS rank (replicated: all of them on every rank) */
+    double bytes_sent_per_mg_setup;                                  /* by the plans: what this rank sends in the block exchanges of one set-up */
+    double bytes_allreduce_replicated_setup;                         /* what the replicated set-up all-reduces per LM system on the same graph: level 1's blocks x 288 B */
 } pgo_sharding_stats;
 int pgo_get_sharding_stats(pgo_problem* p, pgo_sharding_stats* out);
+/* Diagnostic for tests of the distributed set-up: sums of squares of what THIS rank's cycle kernels read of multigrid level `level` (1-based) after the last set-up —
+ * out8 = {its rows' fp64 blocks, their fp32 copy, its rows' block-Jacobi inverses, its rows of R^T, its coarse rows of R (smoothed transition above; else 0), the dense
+ * inverse (coarsest level only), 0, 0}.  The same numbers whichever way the set-up ran (pgo_options.mg_dist_setup), up to the order of the sums. */
+int pgo_mg_level_norms(pgo_problem* p, int32_t level, double* out8);
 
 /* ------------------------------------------------------------------------------------------ */
 /* graph construction on the device from the raw VIO poses                   */
@@ -536,7 +551,8 @@ int pgo_time_linearize_kernel(pgo_problem* p, int32_t launches, double* avg_ms, 
 /* Same for one PCG iteration (K3+K4) and the assembly (K2). which: 0 = K1, 1 = K2, 2 = one block-Jacobi PCG iteration (matvec + update),
  * 3 = K1 cost-only, 4 = the matvec of the iteration alone, 5 = its vector update alone, 6 = one MULTIGRID-preconditioned PCG iteration (matvec + update with
  * the restriction + every level kernel; graphs with a hierarchy only), 7 = its level kernels alone (several ranks: THIS rank's share of them, without the exchanges —
- * what the rank's GPU computes per cycle; call it rank by rank).  algorithmic_bytes of 2/4/5/6/7: what THIS design moves
+ * what the rank's GPU computes per cycle; call it rank by rank), 8 = the kernels of ONE multigrid set-up (the level operators of an LM system and the dense inverse;
+ * several ranks: THIS rank's kernels without the block exchanges between them, every rank must call it; algorithmic_bytes 0).  algorithmic_bytes of 2/4/5/6/7: what THIS design moves
  * per iteration with every array counted once (matrix-free: compact edge-side records + index data + vectors + the fp32 block-Jacobi
  * factors; block-CSR: SURVEY.md 8d's assembled form). */
 int pgo_time_kernel(pgo_problem* p, int32_t which, int32_t launches, double* avg_ms, double* algorithmic_bytes);

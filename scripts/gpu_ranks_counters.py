@@ -5,7 +5,9 @@
   * decisions and PCG iteration counts of the N-rank solve against the single-handle solve of the same graph;
   * per rank: level-kernel time of one multigrid cycle (pgo_time_kernel(7): the rank's share of every level, no exchanges, the ranks taking turns on the GPU) against the
     single handle's full cycle = what round 5's replicated levels cost on EVERY rank;
-  * per rank: bytes sent per PCG iteration by the exchange plans against what round 5's union all-reduce carried on the same graph; exchanges per iteration.
+  * per rank: bytes sent per PCG iteration by the exchange plans against what round 5's union all-reduce carried on the same graph; exchanges per iteration;
+  * per rank: the kernels of ONE multigrid set-up (pgo_time_kernel(8): level operators + dense inverse, no exchanges, ranks taking turns) with the distributed set-up
+    (mg_dist_setup = 1) and with the replicated one (= 0: every rank forms every level), the blocks it forms and the bytes its block exchanges send per set-up.
 
   python scripts/gpu_ranks_counters.py C3 4 [lm_iterations] [policy]      ->  one JSON line on stdout (and on stderr the library's hierarchy log of rank 0)"""
 import json
@@ -36,6 +38,7 @@ def main():
     P.solve_begin(q1, t1, s1)                      # a late linearisation: the hard systems are the ones the multigrid runs on
     cyc_ms, cyc_bytes = P.time_kernel(7, 50)
     it_ms, _ = P.time_kernel(6, 50)
+    setup_ms, _ = P.time_kernel(8, 10)
     P.solve_end()
     P.close()
     # ---- the ranks
@@ -44,6 +47,20 @@ def main():
     group = capi.local_group_create(world)
     out, stats, lvl, err = [None] * world, [None] * world, [None] * world, []
     wall = [0.0] * world
+    su, su_rep = [None] * world, [None] * world
+
+    def run_replicated(rank):      # the same ranks with rounds 3-5's replicated set-up: only its kernel time is wanted
+        try:
+            Pr = capi.problem_from_graph(g, switchable=True, edge_slice=parts[rank], mg_dist_setup=0, **opts)
+            Pr.comm_init_local(rank, world, group)
+            Pr.solve_begin(out[rank][0], out[rank][1], out[rank][2])
+            su_rep[rank] = Pr.time_kernel(8, 10)
+            Pr.solve_end()
+            Pr.comm_destroy()
+            Pr.close()
+        except Exception as e:   # noqa: BLE001
+            err.append(repr(e))
+            capi.local_group_abort(group)
 
     def run(rank):
         try:
@@ -56,6 +73,7 @@ def main():
             Pr.set_options(verbosity=0)
             Pr.solve_begin(out[rank][0], out[rank][1], out[rank][2])
             lvl[rank] = Pr.time_kernel(7, 50)     # the ranks take turns inside the library
+            su[rank] = Pr.time_kernel(8, 10)
             Pr.solve_end()
             Pr.comm_destroy()
             Pr.close()
@@ -68,6 +86,14 @@ def main():
     for x in th:
         x.join()
     capi.local_group_destroy(group)
+    if not err:
+        group = capi.local_group_create(world)
+        th = [threading.Thread(target=run_replicated, args=(r,)) for r in range(world)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        capi.local_group_destroy(group)
     if err:
         print(json.dumps({"config": name, "world": world, "error": err}))
         sys.exit(1)
@@ -82,13 +108,17 @@ def main():
         "pcg_multigrid_single": int(sum1.cg_iterations_multigrid), "pcg_multigrid_ranks": int(sumr.cg_iterations_multigrid),
         "all_ranks_identical": all(np.array_equal(out[0][1], out[r][1]) and np.array_equal(out[0][2], out[r][2]) for r in range(world)),
         "t_max_abs_diff": float(np.abs(out[0][1] - t1).max()),
-        "single_handle": {"level_kernels_per_cycle_ms": cyc_ms, "multigrid_iteration_ms": it_ms, "solve_s": single_s},
+        "single_handle": {"level_kernels_per_cycle_ms": cyc_ms, "multigrid_iteration_ms": it_ms, "setup_kernels_ms": setup_ms, "solve_s": single_s},
         "ranks": [{"rank": r, "level_kernels_per_cycle_ms": lvl[r][0], "level_kernel_time_vs_replicated": lvl[r][0] / cyc_ms,
                    "bytes_sent_per_mg_iteration": stats[r]["bytes_sent_per_mg_iteration"], "bytes_round5_per_mg_iteration": stats[r]["bytes_round5_per_mg_iteration"],
                    "bytes_vs_round5": stats[r]["bytes_sent_per_mg_iteration"] / max(1.0, stats[r]["bytes_round5_per_mg_iteration"]),
                    "bytes_sent_per_bj_iteration": stats[r]["bytes_sent_per_bj_iteration"], "bytes_round5_per_bj_iteration": stats[r]["bytes_round5_per_bj_iteration"],
                    "exchanges_per_mg_iteration": stats[r]["exchanges_per_mg_iteration"], "mg_levels": stats[r]["mg_levels"], "mg_levels_distributed": stats[r]["mg_levels_distributed"],
                    "mg_rows_own": stats[r]["mg_rows_own"], "mg_rows_total": stats[r]["mg_rows_total"], "mg_blocks_own": stats[r]["mg_blocks_own"], "mg_blocks_total": stats[r]["mg_blocks_total"],
+                   "setup_kernels_ms": su[r][0], "setup_kernels_replicated_ms": su_rep[r][0], "setup_kernel_time_vs_replicated": su[r][0] / su_rep[r][0],
+                   "mg_setup_levels_own_rows": stats[r]["mg_setup_levels_own_rows"], "mg_setup_exchanges": stats[r]["mg_setup_exchanges"], "mg_setup_blocks_own": stats[r]["mg_setup_blocks_own"],
+                   "mg_setup_blocks_total": stats[r]["mg_setup_blocks_total"], "bytes_sent_per_mg_setup": stats[r]["bytes_sent_per_mg_setup"],
+                   "bytes_allreduce_replicated_setup": stats[r]["bytes_allreduce_replicated_setup"],
                    "keyframes_local": stats[r]["keyframes_local"], "keyframes_shared": stats[r]["keyframes_shared"], "solve_wall_s_sharing_one_gpu": wall[r]} for r in range(world)],
     }
     print(json.dumps(rec))

@@ -29,7 +29,7 @@ class Options(C.Structure):
                 ("mg_omega", C.c_double), ("mg_correction_scale", C.c_double), ("mg_first_passes", C.c_int32), ("mg_passes", C.c_int32), ("mg_dense_max_nodes", C.c_int32), ("mg_switch_iterations", C.c_int32),
                 ("mg_loop_discount", C.c_double), ("mg_regroup_fraction", C.c_double), ("mg_prolongation_damping", C.c_double), ("mg_smoothed_levels", C.c_int32), ("mg_min_keyframes_switchable", C.c_int32),
                 ("device_id", C.c_int32), ("verbosity", C.c_int32), ("cg_single_reduction", C.c_int32), ("mg_explicit_transfer", C.c_int32), ("cg_end_game", C.c_int32), ("cg_pause_always", C.c_int32), ("mg_smoothed_fine", C.c_int32),
-                ("mg_dist_min_rows", C.c_int32), ("mg_fine_filter", C.c_int32)]
+                ("mg_dist_min_rows", C.c_int32), ("mg_fine_filter", C.c_int32), ("mg_dist_setup", C.c_int32)]
 
 
 class Iteration(C.Structure):
@@ -60,14 +60,16 @@ class ShardingStats(C.Structure):
                 ("mg_levels", C.c_int32), ("mg_levels_distributed", C.c_int32), ("mg_rows_total", C.c_int64), ("mg_rows_own", C.c_int64), ("mg_blocks_total", C.c_int64), ("mg_blocks_own", C.c_int64),
                 ("pcg_iterations", C.c_int64), ("exchanges", C.c_int64), ("allreduces", C.c_int64), ("bytes_sent_neighbour", C.c_double), ("bytes_allreduce", C.c_double),
                 ("bytes_sent_per_mg_iteration", C.c_double), ("bytes_sent_per_bj_iteration", C.c_double), ("bytes_round5_per_mg_iteration", C.c_double), ("bytes_round5_per_bj_iteration", C.c_double),
-                ("exchanges_per_mg_iteration", C.c_int32), ("exchanges_per_bj_iteration", C.c_int32)]
+                ("exchanges_per_mg_iteration", C.c_int32), ("exchanges_per_bj_iteration", C.c_int32),
+                ("mg_setup_levels_own_rows", C.c_int32), ("mg_setup_exchanges", C.c_int32), ("mg_setup_blocks_total", C.c_int64), ("mg_setup_blocks_own", C.c_int64),
+                ("bytes_sent_per_mg_setup", C.c_double), ("bytes_allreduce_replicated_setup", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 # every symbol include/pgo.h declares (checked by tests/test_capi_symbols.py against the header text)
-ABI_VERSION = 6      # PGO_ABI_VERSION of the include/pgo.h this view mirrors
+ABI_VERSION = 7      # PGO_ABI_VERSION of the include/pgo.h this view mirrors
 EXPORTS = [
     "pgo_abi_version", "pgo_abi_sizeof", "pgo_options_init", "pgo_create", "pgo_destroy", "pgo_set_options", "pgo_reserve",
     "pgo_add_relpose_edges", "pgo_add_switchable_edges", "pgo_set_node_regularizers", "pgo_set_nodes_constant",
@@ -76,7 +78,7 @@ EXPORTS = [
     "pgo_solve", "pgo_solve_begin", "pgo_lm_step", "pgo_solve_end", "pgo_evaluate",
     "pgo_get_jacobian_blocks", "pgo_get_normal_blocks", "pgo_apply_normal_operator", "pgo_manifold_plus",
     "pgo_comm_get_unique_id", "pgo_comm_init", "pgo_comm_destroy", "pgo_comm_init_custom", "pgo_comm_set_exchange", "pgo_local_group_create", "pgo_local_group_abort", "pgo_local_group_destroy", "pgo_comm_init_local",
-    "pgo_get_sharding_stats", "pgo_partition_edges",
+    "pgo_get_sharding_stats", "pgo_mg_level_norms", "pgo_partition_edges",
     "pgo_time_linearize_kernel", "pgo_time_kernel", "pgo_time_vio_odometry_kernel", "pgo_dense_spd_inverse", "pgo_device_synchronize", "pgo_strerror", "pgo_last_error", "pgo_build_info",
 ]
 
@@ -388,6 +390,12 @@ class Problem:
         st = ShardingStats()
         self._check(self.lib.pgo_get_sharding_stats(self.h, C.byref(st)))
         return st
+
+    def mg_level_norms(self, level):
+        """diagnostic: sums of squares of what this rank's cycle kernels read of multigrid level `level` (1-based) after the last set-up"""
+        out = np.zeros(8)
+        self._check(self.lib.pgo_mg_level_norms(self.h, C.c_int32(level), out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
 
     def comm_destroy(self):
         self._check(self.lib.pgo_comm_destroy(self.h))

@@ -167,8 +167,14 @@ struct MgLevelDev {
     int32_t rT_tiles, rT_seg_shift;
     // several ranks, distributed cycle (round 6): the CYCLE's kernels run on this rank's share of the level — its tiles [tile0, tile0 + tiles_own) and, for the restriction half of
     // mg_sdown_kernel, the coarse rows [rT_row0, rT_row1) (rT_rows / rT_tiles describe THAT range) — from vectors whose other entries the exchanges have brought in.  One GPU, and
-    // levels every rank runs completely: tile0 = 0, tiles_own = tiles, rT_row0 = 0, rT_row1 = n_next.  The set-up kernels always work on the whole level.
+    // levels every rank runs completely: tile0 = 0, tiles_own = tiles, rT_row0 = 0, rT_row1 = n_next.
     int32_t tile0, tiles_own, rT_row0, rT_row1;
+    // several ranks, distributed SET-UP (round 6): the set-up kernels of a distributed level work on this rank's rows [su_row0, su_row1) — its blocks [su_blk0, su_blk1), its blocks
+    // of Ps [su_ps0, su_ps1) and of W [su_w0, su_w1) — and the product Ps^T W on the blocks of the level above its rows contribute to (su_prod, ascending; null: every block, the
+    // whole sum); what they read of other ranks' rows the block exchanges of pgo_solver.hip bring in.  One GPU, and levels every rank sets up completely: the whole level.
+    int32_t su_row0, su_row1, su_ps0, su_ps1, su_w0, su_w1, n_su_prod, pad4_;
+    int64_t su_blk0, su_blk1;
+    const int32_t* su_prod;
 };
 struct MgDev {
     int32_t n_levels;                    // levels 1..n_levels; the last one is dense (CoarseDev: Ac, rc = its residual, yc = its solution)
@@ -182,6 +188,7 @@ struct MgDev {
     // several ranks (edge sharding): the keyframe arrays above are the rank's LOCAL keyframes, the level-1 ids GLOBAL (the hierarchy is the same on every rank)
     const double* inv_cnt;               // [n1] 1 / (members of the level-1 node over all ranks); null on one GPU
     int32_t a0, a1;                      // the level-1 aggregates this rank restricts to (its own: all their keyframes are local); one GPU: [0, n1)
+    const int32_t* g0_slots; int32_t n_g0, pad_;      // several ranks, distributed set-up: the level-1 blocks this rank's edges and owned keyframes contribute to (ascending); null: every block
 };
 constexpr int MG_BLOCK0 = 64;
 
@@ -284,7 +291,19 @@ void launch_mg_galerkin0(const GraphDev& G, const LinDev& L, const ScaleDev& Sc,
 void launch_k2_offdiag(const GraphDev& G, const LinDev& L, hipStream_t st);
 void launch_mg_assemble_fine(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, const MgLevelDev& F, const MgLevelDev& T, const MgLevelDev& L1, double omega, int32_t* fail, hipStream_t st,
                              double prolong_scale, bool hoff_valid, const double* pose8 = nullptr /* filtered form (F.dlump): the keyframes' positions of the current linearisation */);      // level 1 = Ps_0^T A Ps_0 (smoothed keyframe transition), then launch_mg_assemble_rest
-void launch_mg_assemble_rest(const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, double omega, int32_t* fail, hipStream_t st, double prolong_scale = 0.0 /* c = w_p / w of the smoothed transitions */);
+void launch_mg_assemble_rest(const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, double omega, int32_t* fail, hipStream_t st, double prolong_scale = 0.0 /* c = w_p / w of the smoothed transitions */,
+                             int first_level = 0 /* levels[first_level].val is complete already: its inverses and everything above */);
+// ... and the pieces it is made of, each on the level's set-up share (MgLevelDev::su_*): several ranks run them with block exchanges in between (pgo_solver.hip: build_mg_ranks)
+void launch_mg_level_inverses(const MgLevelDev& A, double omega, int32_t* fail, hipStream_t st);       // Dinv = omega D^-1 and the fp32 copy of the blocks
+void launch_mg_level_power(const MgLevelDev& A, double omega, hipStream_t st);                        // lambda_max(D^-1 A) estimate -> A.xf[0] (a distributed level: of the rank's own diagonal part, a lower bound as well)
+void launch_mg_level_rescale(const MgLevelDev& A, const double* lam, double omega, hipStream_t st);    // Dinv scaled down where omega lambda > 1.75
+void launch_mg_transition_ps(const MgLevelDev& A, double prolong_scale, hipStream_t st);              // Ps = (I - c Dinv A) P
+void launch_mg_transition_w(const MgLevelDev& A, hipStream_t st);                                     // W = A Ps, R^T = Ps - Dinv W (both orientations)
+void launch_mg_transition_product(const MgLevelDev& A, const MgLevelDev& B, hipStream_t st);          // B = Ps^T W (several ranks: this rank's rows' part of it)
+void launch_mg_level_galerkin(const MgLevelDev& A, const MgLevelDev& B, hipStream_t st);              // B = P^T A P (plain transition)
+void launch_mg_dense_top(const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, hipStream_t st);
+void launch_mg_pack_flags(const int32_t* fail, const double* lam, double* out2, hipStream_t st);       // out2 = {fail != 0, lambda}: what a distributed level all-reduces (max)
+void launch_mg_unpack_flags(const double* in2, int32_t* fail, double* lam, hipStream_t st);
 // Several ranks: the cycle is cut into segments by the exchanges its kernels need (pgo_solver.hip issues them); launch_mg_apply calls the hook BEFORE the kernel that reads the
 // exchanged vectors.  point: 0 = down-sweep of `level` (1-based; n_levels = the dense solve) is about to read x (and r) of that level, 1 = the up-sweep of `level` is about to
 // read xt of that level (plain transition) or xf of level + 1 (explicit transfer operator), 2 = the prolongation to the keyframes is about to read xf of level 1.

@@ -805,4 +805,134 @@ inline void build_fine_plan(const std::vector<uint64_t>& touch_mask, const std::
     }
 }
 
+// ---- several ranks: the multigrid's SET-UP distributed like its cycle (round 6) ----
+// Every rank forms the numbers of its OWN rows of every distributed level (Galerkin products, block-Jacobi inverses, smoothed prolongators, transfer operators); what a kernel
+// reads of another rank's rows arrives by a neighbour exchange of 6x6 BLOCKS, listed by slot.  Two kinds:
+//   BlockPlan   — blocks with several CONTRIBUTORS (level 1: every rank holding an edge between two aggregates adds to their block; the product Ps^T W of a smoothed transition:
+//                 every rank owning a row of Ps's column) go to the ranks that NEED them and are summed there in ascending rank order (the same bits on every needer).  A block is
+//                 needed by the owner of its row and, above the diagonal, by the owner of its column too (the cycle streams an exactly symmetric fp32 copy: the block below the
+//                 diagonal is the transpose of the rounded block above it); on the first level every rank runs completely, by everybody.
+//   ExchangePlan over slots — blocks with ONE producer copied to their readers: the rows of Ps a rank's rows of W = A Ps multiply (the columns of its rows of A), the blocks of
+//                 R = (Ps - Dinv W)^T whose coarse row belongs to another rank than their fine row.
+// All of it derived on every rank from what all ranks hold (hierarchy, ownership ranges, the gathered edge list with the rank of every edge): no handshake.
+struct BlockPlan {
+    ExchangePlan x;                                // send_idx: slots whose blocks go to each peer (ascending inside a segment); recv_idx unused
+    std::vector<int32_t> dst;                      // slots this rank needs and does not produce alone, ascending
+    std::vector<int32_t> sum_ptr, sum_src;         // per dst its parts in ascending rank order: -1 = this rank's own values, else the row of the receive buffer
+};
+// entries (slot ascending, contributors, needers as rank bit masks)
+inline void block_plan(const std::vector<int32_t>& slot, const std::vector<uint64_t>& contrib, const std::vector<uint64_t>& need, int rank, int world, BlockPlan& B) {
+    B = BlockPlan{};
+    ExchangePlan& P = B.x;
+    P.pair_cnt.assign((size_t)world * world, 0);
+    for (size_t k = 0; k < slot.size(); ++k)
+        for (uint64_t c = contrib[k]; c; c &= c - 1) { const int rc = __builtin_ctzll(c); for (uint64_t n = need[k] & ~(1ull << rc); n; n &= n - 1) P.pair_cnt[(size_t)rc * world + (size_t)__builtin_ctzll(n)]++; }
+    P.send_off.assign((size_t)world + 1, 0); P.recv_off.assign((size_t)world + 1, 0);
+    for (int q = 0; q < world; ++q) { P.send_off[(size_t)q + 1] = P.send_off[(size_t)q] + P.pair_cnt[(size_t)rank * world + q]; P.recv_off[(size_t)q + 1] = P.recv_off[(size_t)q] + P.pair_cnt[(size_t)q * world + rank]; }
+    P.send_idx.resize((size_t)P.send_off[(size_t)world]);
+    std::vector<int64_t> fs(P.send_off.begin(), P.send_off.end() - 1), fr(P.recv_off.begin(), P.recv_off.end() - 1);
+    const uint64_t me = 1ull << rank;
+    B.sum_ptr.push_back(0);
+    for (size_t k = 0; k < slot.size(); ++k) {
+        if (contrib[k] & me) for (uint64_t n = need[k] & ~me; n; n &= n - 1) P.send_idx[(size_t)fs[(size_t)__builtin_ctzll(n)]++] = slot[k];
+        if ((need[k] & me) && (contrib[k] & ~me)) {
+            B.dst.push_back(slot[k]);
+            for (uint64_t c = contrib[k]; c; c &= c - 1) { const int rc = __builtin_ctzll(c); B.sum_src.push_back(rc == rank ? -1 : (int32_t)fr[(size_t)rc]++); }
+            B.sum_ptr.push_back((int32_t)B.sum_src.size());
+        }
+    }
+}
+struct SetupPlans {
+    int first_whole = 0;                           // index of the first level every rank sets up (and runs) completely; levels below it are distributed.  0: nothing is (the set-up stays replicated)
+    std::vector<BlockPlan> val;                    // [first_whole + 1] the level's own blocks
+    std::vector<ExchangePlan> ps, rv;              // [first_whole] smoothed transition above level l: blocks of Ps (slots of ps_val), blocks of R (slots of r_valf)
+    std::vector<std::vector<int32_t>> prod;        // [first_whole] smoothed transition above level l: the blocks of level l + 1 this rank's rows contribute to (ascending)
+};
+// rel / sw: the GATHERED edge lists (every rank's edges, rank by rank: edges [rel_off[r], rel_off[r+1]) are rank r's)
+inline void build_setup_plans(const Hierarchy& H, int rank, int world, const std::vector<int32_t>& rc1, const std::vector<int32_t>& rc2, const std::vector<int64_t>& rel_off,
+                              const std::vector<int32_t>& sc1, const std::vector<int32_t>& sc2, const std::vector<int64_t>& sw_off, SetupPlans& S) {
+    S = SetupPlans{};
+    const int nl = (int)H.L.size();
+    if (world <= 1 || H.world != world || nl < 2 || !H.L[0].distributed) return;
+    int fw = 0;
+    while (fw < nl && H.L[(size_t)fw].distributed) ++fw;
+    S.first_whole = fw;
+    S.val.assign((size_t)fw + 1, BlockPlan{}); S.ps.assign((size_t)fw, ExchangePlan{}); S.rv.assign((size_t)fw, ExchangePlan{}); S.prod.assign((size_t)fw, std::vector<int32_t>{});
+    std::vector<std::vector<int32_t>> own((size_t)fw + 1);
+    for (int l = 0; l <= fw; ++l) {
+        const HostLevel& A = H.L[(size_t)l];
+        own[(size_t)l].resize((size_t)A.n);
+        for (int r = 0; r < world; ++r) for (int32_t i = A.own_ptr[(size_t)r]; i < A.own_ptr[(size_t)r + 1]; ++i) own[(size_t)l][(size_t)i] = r;
+    }
+    const uint64_t all = world >= 64 ? ~0ull : ((1ull << world) - 1);
+    auto find_block = [](const HostLevel& A, int32_t a, int32_t b) -> int64_t {      // rows hold the diagonal block first, the others by ascending column
+        if (a == b) return A.rowptr[(size_t)a];
+        const int32_t* lo = A.col.data() + A.rowptr[(size_t)a] + 1; const int32_t* hi = A.col.data() + A.rowptr[(size_t)a + 1];
+        const int32_t* f = std::lower_bound(lo, hi, b);
+        return (f != hi && *f == b) ? (int64_t)(f - A.col.data()) : -1;
+    };
+    std::vector<uint64_t> cm;                      // contributors of every block of the level in hand
+    for (int l = 0; l <= fw; ++l) {
+        const HostLevel& A = H.L[(size_t)l];
+        const std::vector<int32_t>& ow = own[(size_t)l];
+        cm.assign(A.col.size(), 0);
+        if (l == 0) {
+            for (int32_t a = 0; a < A.n; ++a) cm[(size_t)A.rowptr[(size_t)a]] |= 1ull << ow[(size_t)a];      // the keyframes' own (summed) diagonal blocks: their owner
+            auto edges = [&](const std::vector<int32_t>& c1, const std::vector<int32_t>& c2, const std::vector<int64_t>& off) {
+                for (int r = 0; r < world; ++r) for (int64_t e = off[(size_t)r]; e < off[(size_t)r + 1]; ++e) {
+                    const int32_t a = H.agg0[(size_t)c1[(size_t)e]], b = H.agg0[(size_t)c2[(size_t)e]];
+                    if (a < 0 || b < 0) continue;
+                    const int64_t k1 = find_block(A, a, b), k2 = find_block(A, b, a);
+                    if (k1 >= 0) cm[(size_t)k1] |= 1ull << r;
+                    if (k2 >= 0) cm[(size_t)k2] |= 1ull << r;
+                }
+            };
+            edges(rc1, rc2, rel_off); edges(sc1, sc2, sw_off);
+        } else {
+            const HostLevel& Lo = H.L[(size_t)l - 1];
+            const std::vector<int32_t>& olo = own[(size_t)l - 1];
+            if (!Lo.smoothed) { for (int32_t a = 0; a < A.n; ++a) for (int64_t k = A.rowptr[(size_t)a]; k < A.rowptr[(size_t)a + 1]; ++k) cm[(size_t)k] = 1ull << ow[(size_t)a]; }
+            else {
+                std::vector<uint8_t> mine(A.col.size(), 0);
+                for (int32_t i = 0; i < Lo.n; ++i) {
+                    const uint64_t bit = 1ull << olo[(size_t)i];
+                    for (int32_t pk = Lo.ps_rowptr[(size_t)i]; pk < Lo.ps_rowptr[(size_t)i + 1]; ++pk)
+                        for (int32_t wk = Lo.w_rowptr[(size_t)i]; wk < Lo.w_rowptr[(size_t)i + 1]; ++wk) {
+                            const int64_t k = find_block(A, Lo.ps_col[(size_t)pk], Lo.w_col[(size_t)wk]);
+                            if (k >= 0) { cm[(size_t)k] |= bit; if (olo[(size_t)i] == rank) mine[(size_t)k] = 1; }
+                        }
+                }
+                for (size_t k = 0; k < mine.size(); ++k) if (mine[k]) S.prod[(size_t)l - 1].push_back((int32_t)k);
+            }
+        }
+        std::vector<int32_t> slot; std::vector<uint64_t> cb, nd;
+        for (int32_t a = 0; a < A.n; ++a) for (int64_t k = A.rowptr[(size_t)a]; k < A.rowptr[(size_t)a + 1]; ++k) {
+            const int32_t b = A.col[(size_t)k];
+            uint64_t need = l == fw ? all : (1ull << ow[(size_t)a]) | (b > a ? 1ull << ow[(size_t)b] : 0ull);
+            const uint64_t c = cm[(size_t)k];
+            if (!c) continue;
+            if (!(c & (c - 1)) && need == c) continue;          // produced and read by one and the same rank: nothing travels
+            slot.push_back((int32_t)k); cb.push_back(c); nd.push_back(need);
+        }
+        block_plan(slot, cb, nd, rank, world, S.val[(size_t)l]);
+        if (l == fw || !A.smoothed) continue;
+        // smoothed transition above level l: rows of Ps the rank's rows of W read; blocks of R whose coarse row is another rank's
+        std::vector<uint64_t> need_row((size_t)A.n, 0);
+        for (int32_t r = 0; r < A.n; ++r) for (int64_t k = A.rowptr[(size_t)r]; k < A.rowptr[(size_t)r + 1]; ++k) need_row[(size_t)A.col[(size_t)k]] |= 1ull << ow[(size_t)r];
+        std::vector<uint64_t> keys;
+        for (int32_t j = 0; j < A.n; ++j) {
+            const int prov = ow[(size_t)j];
+            for (uint64_t n = need_row[(size_t)j] & ~(1ull << prov); n; n &= n - 1) { const int q = __builtin_ctzll(n); for (int32_t pk = A.ps_rowptr[(size_t)j]; pk < A.ps_rowptr[(size_t)j + 1]; ++pk) keys.push_back(((uint64_t)(q * world + prov) << 32) | (uint32_t)pk); }
+        }
+        plan_from_keys(keys, world, rank, S.ps[(size_t)l]);
+        keys.clear();
+        const std::vector<int32_t>& oup = own[(size_t)l + 1];
+        for (int32_t i = 0; i < A.n; ++i) for (int32_t wk = A.w_rowptr[(size_t)i]; wk < A.w_rowptr[(size_t)i + 1]; ++wk) {
+            const int prov = ow[(size_t)i], q = oup[(size_t)A.w_col[(size_t)wk]];
+            if (prov != q) keys.push_back(((uint64_t)(q * world + prov) << 32) | (uint32_t)A.rT_of_w[(size_t)wk]);
+        }
+        plan_from_keys(keys, world, rank, S.rv[(size_t)l]);
+    }
+}
+
 }  // namespace pgo_mg

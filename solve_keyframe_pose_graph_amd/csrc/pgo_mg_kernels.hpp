@@ -127,9 +127,9 @@ __device__ __forceinline__ double mg_gather_row(const double* __restrict__ xch, 
 // triangle.  One wavefront per BLOCK (the smoothed Galerkin products have ~50 blocks per row: a wavefront per row ran 0.37 ms on C3's level 2); lane l < 36 owns
 // element l of the block (column-pair-major: (row, col) at (row/2)*12 + col*2 + (row&1)).
 __global__ __launch_bounds__(256) void mg_val_f32_kernel(MgLevelDev A) {
-    const int64_t k = wave_in_grid();
+    const int64_t k = wave_in_grid() + A.su_blk0;    // (the level's set-up share: all of it on one GPU)
     const int lane = threadIdx.x & 63;
-    if (k >= A.nnzb || lane >= 36) return;
+    if (k >= A.su_blk1 || lane >= 36) return;
     const int i = A.row_of[k], j = A.col[k];         // (tables: a binary search over rowptr was 14 dependent loads at the head of every wavefront)
     const int64_t kt = A.tr_of[k];                   // the transposed block (j, i); k itself when the pattern does not hold it
     const int pr = lane / 12, rem = lane - pr * 12, col = rem >> 1, row = pr * 2 + (rem & 1);      // element (row, col) of the block
@@ -230,8 +230,9 @@ __global__ __launch_bounds__(256) void mg_galerkin0_kernel(GraphDev G, LinDev L,
     __shared__ double Hs[4][CH][36];
     __shared__ double ds[4][CH][6];
     const int wv = wave_in_block(), lane = threadIdx.x & 63;
-    const int64_t slot = wave_in_grid();
-    if (slot >= A.nnzb) return;
+    int64_t slot = wave_in_grid();
+    if (slot >= (M.g0_slots ? (int64_t)M.n_g0 : A.nnzb)) return;
+    if (M.g0_slots) slot = M.g0_slots[slot];      // several ranks, distributed set-up: the blocks this rank has contributions for (the others are never read here: their parts arrive by the block exchange)
     const int r = lane / 6, c = lane - r * 6;
     const bool own = lane < 36;
     const int du = lane / 6, dm = lane - du * 6;
@@ -272,8 +273,8 @@ __global__ __launch_bounds__(256) void mg_galerkin_kernel(MgLevelDev A, MgLevelD
     __shared__ double Hs[4][CH][36];
     __shared__ double ds[4][CH][6];
     const int wv = wave_in_block(), lane = threadIdx.x & 63;
-    const int64_t slot = wave_in_grid();
-    if (slot >= B.nnzb) return;
+    const int64_t slot = wave_in_grid() + B.su_blk0;      // (several ranks: the blocks of the rank's own rows of B — their contributions are blocks of its own rows of A)
+    if (slot >= B.su_blk1) return;
     const int r = lane / 6, c = lane - r * 6;
     const bool own = lane < 36;
     // storage offset `lane` of a block holds element (row, col) with row = 2 (lane / 12) + (lane & 1), col = (lane % 12) / 2
@@ -312,8 +313,8 @@ __global__ __launch_bounds__(256) void mg_galerkin_kernel(MgLevelDev A, MgLevelD
 // definite falls back to the level's own block (the lumping keeps A's action on the rigid modes, it does not have to keep every block definite)
 __global__ __launch_bounds__(256) void mg_dinv_kernel(MgLevelDev A, double omega, int32_t* __restrict__ fail, int skip_orphans /* keyframe level: rows with parent -1 are outside the system */,
                                                       const double* __restrict__ diag = nullptr) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= A.n) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x + A.su_row0;
+    if (i >= A.su_row1) return;
     if (skip_orphans && A.parent[i] < 0) { double* out = A.Dinv + (size_t)i * 36; for (int e = 0; e < 36; ++e) out[e] = 0.0; return; }
     const double* v = diag ? diag + (size_t)i * 36 : A.val + (size_t)A.rowptr[i] * 36;
     double Lm[36];
@@ -387,8 +388,8 @@ template <bool FILT>
 __global__ __launch_bounds__(256) void mg_ps_kernel(MgLevelDev A, double cs) {
     __shared__ double acc_s[4][36];
     const int wv = wave_in_block(), lane = threadIdx.x & 63;
-    const int64_t slot = wave_in_grid();
-    if (slot >= A.n_ps) return;
+    const int64_t slot = wave_in_grid() + A.su_ps0;
+    if (slot >= A.su_ps1) return;
     const bool own = lane < 36;
     const int r = own ? lane / 6 : 0, c = own ? lane % 6 : 0;
     const int i = A.ps_row[slot], a = A.ps_col[slot];
@@ -421,8 +422,8 @@ constexpr int MG_SETUP_CHUNK = 8;
 __global__ __launch_bounds__(256) void mg_w_kernel(MgLevelDev A) {
     __shared__ double pb[4][MG_SETUP_CHUNK][36], ab[4][MG_SETUP_CHUNK][36];
     const int wv = wave_in_block(), lane = threadIdx.x & 63;
-    const int64_t slot = wave_in_grid();
-    if (slot >= A.n_w) return;
+    const int64_t slot = wave_in_grid() + A.su_w0;
+    if (slot >= A.su_w1) return;
     const bool own = lane < 36;
     const int r = own ? lane / 6 : 0, c = own ? lane % 6 : 0;
     const int i = A.w_row[slot], b = A.w_col[slot];
@@ -469,8 +470,8 @@ __global__ __launch_bounds__(256) void mg_w_kernel(MgLevelDev A) {
 // transposes of each other, so the cycle stays symmetric.  One wavefront per block, lane l < 36 owns element (l / 6, l % 6); both copies in the level kernels' block layout (bsr_idx).
 __global__ __launch_bounds__(256) void mg_rt_kernel(MgLevelDev A) {
     const int lane = threadIdx.x & 63;
-    const int64_t k = wave_in_grid();
-    if (k >= A.n_w || lane >= 36) return;
+    const int64_t k = wave_in_grid() + A.su_w0;
+    if (k >= A.su_w1 || lane >= 36) return;
     const int r = lane / 6, c = lane % 6;
     const int i = A.w_row[k];
     const int32_t ps = A.ps_of_w[k];
@@ -489,8 +490,10 @@ __global__ __launch_bounds__(256) void mg_rt_kernel(MgLevelDev A) {
 __global__ __launch_bounds__(256) void mg_psTw_kernel(MgLevelDev A, MgLevelDev B) {
     __shared__ double pa[4][MG_SETUP_CHUNK][36], wb[4][MG_SETUP_CHUNK][36];
     const int wv = wave_in_block(), lane = threadIdx.x & 63;
-    const int64_t slot = wave_in_grid();
-    if (slot >= B.nnzb) return;
+    // several ranks (A.su_prod): the blocks this rank's rows of Ps / W contribute to, and only those rows' part of the sum — the parts are added where the block is needed
+    int64_t slot = wave_in_grid();
+    if (slot >= (A.su_prod ? (int64_t)A.n_su_prod : B.nnzb)) return;
+    if (A.su_prod) slot = A.su_prod[slot];
     const bool own = lane < 36;
     const int r = own ? lane / 6 : 0, c = own ? lane % 6 : 0;
     const int a = B.row_of[slot], b = B.col[slot];
@@ -503,7 +506,7 @@ __global__ __launch_bounds__(256) void mg_psTw_kernel(MgLevelDev A, MgLevelDev B
 #pragma unroll
         for (int u = 0; u < MG_SETUP_CHUNK; ++u) ent[u] = u < n ? A.psT_ent[e0 + u] : 0;
 #pragma unroll
-        for (int u = 0; u < MG_SETUP_CHUNK; ++u) { const int i = (int)(ent[u] >> 32); w0[u] = u < n ? A.w_rowptr[i] : 0; w1[u] = u < n ? A.w_rowptr[i + 1] : 0; }
+        for (int u = 0; u < MG_SETUP_CHUNK; ++u) { const int i = (int)(ent[u] >> 32); const bool in = u < n && i >= A.su_row0 && i < A.su_row1; w0[u] = in ? A.w_rowptr[i] : 0; w1[u] = in ? A.w_rowptr[i + 1] : 0; }
 #pragma unroll
         for (int u = 0; u < MG_SETUP_CHUNK; ++u) cand[u] = (w0[u] + lane < w1[u]) ? A.w_col[w0[u] + lane] : -1;
 #pragma unroll
@@ -722,15 +725,17 @@ __global__ __launch_bounds__(CG_BLOCK) void mg_prolong0s_kernel(GraphDev G, MgLe
 // ---- smoother safety: the damped block-Jacobi smoother needs w lambda_max(D^-1 A) < 2 or the cycle is not positive definite any more (the PCG then "converges" on a
 // negative r.z: measured on a chain-like graph whose smoothed Galerkin level has lambda_max ~ 2.5).  lambda_max is estimated per level and per LM system by a few steps
 // of the power method (a lower bound: hence the margins) and a level whose w lambda exceeds `limit` gets its Dinv = w D^-1 scaled down to w lambda = `target`.
-__global__ void mg_power_init_kernel(double* __restrict__ v, int n6) {
+__global__ void mg_power_init_kernel(double* __restrict__ v, double* __restrict__ w, int n6, int lo6, int hi6) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n6) v[i] = 1.0 + 0.5 * sin(0.7 * (double)i);          // fixed, not orthogonal to anything in particular
+    if (i >= n6) return;
+    v[i] = (i >= lo6 && i < hi6) ? 1.0 + 0.5 * sin(0.7 * (double)i) : 0.0;          // fixed, not orthogonal to anything in particular; zero outside the rank's own rows (and they stay zero)
+    w[i] = 0.0;
 }
 // one workgroup: lam = ||b|| / ||a||  (b = D^-1 A a after several un-normalised steps: lambda_max^8 ~ 10^3, far from overflow)
-__global__ __launch_bounds__(1024) void mg_power_ratio_kernel(const double* __restrict__ a, const double* __restrict__ b, int n6, double* __restrict__ lam) {
+__global__ __launch_bounds__(1024) void mg_power_ratio_kernel(const double* __restrict__ a, const double* __restrict__ b, int lo6, int hi6, double* __restrict__ lam) {
     __shared__ double red[32];
     double sa = 0.0, sb = 0.0;
-    for (int i = threadIdx.x; i < n6; i += blockDim.x) { sa += a[i] * a[i]; sb += b[i] * b[i]; }
+    for (int i = lo6 + threadIdx.x; i < hi6; i += blockDim.x) { sa += a[i] * a[i]; sb += b[i] * b[i]; }      // (the set-up's rows: outside them both vectors are zero)
     sa = wave_sum(sa); sb = wave_sum(sb);
     if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = sa; red[16 + (threadIdx.x >> 6)] = sb; }
     __syncthreads();
@@ -744,53 +749,90 @@ __global__ __launch_bounds__(256) void mg_rescale_dinv_kernel(MgLevelDev A, cons
     const double wl = omega * lam[0];
     if (!(wl > limit)) return;
     const double f = target / wl;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < (int64_t)A.n * 36) A.Dinv[i] *= f;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + (int64_t)A.su_row0 * 36;
+    if (i < (int64_t)A.su_row1 * 36) A.Dinv[i] *= f;
 }
-static void mg_limit_smoother(const MgLevelDev& A, double omega, hipStream_t st) {
+// The level's set-up share: on one GPU (and on levels every rank sets up completely) all rows.  A distributed level: the power method runs on the rank's own DIAGONAL part of
+// D^-1 A (entries outside its rows start at zero and stay there) — the largest eigenvalue of a principal part of D^-1/2 A D^-1/2 is a lower bound of the whole matrix's, as the
+// power method's own estimate is; the ranks' estimates are then maximised (pgo_solver.hip) so that all of them rescale alike.
+void launch_mg_level_power(const MgLevelDev& A, double omega, hipStream_t st) {
     const int n6 = A.n * 6;
     double* v = A.x; double* w = A.xt; double* lam = A.xf;              // the level's cycle vectors are free during the set-up
-    MgLevelDev whole = A; whole.tile0 = 0; whole.tiles_own = A.tiles;     // (the set-up is the same on every rank: all rows)
-    hipLaunchKernelGGL(mg_power_init_kernel, dim3((unsigned)((n6 + 255) / 256)), dim3(256), 0, st, v, n6);
+    MgLevelDev S = A;                                                   // the rows the set-up works on, as tiles: the cycle's share on a distributed level, else every tile
+    const bool part = A.su_row0 != 0 || A.su_row1 != A.n;
+    if (!part) { S.tile0 = 0; S.tiles_own = A.tiles; }
+    hipLaunchKernelGGL(mg_power_init_kernel, dim3((unsigned)((n6 + 255) / 256)), dim3(256), 0, st, v, w, n6, A.su_row0 * 6, A.su_row1 * 6);
     for (int it = 0; it < 8; ++it) {
         // w = D^-1 A v  =  (-1 / omega) (omega D^-1) (0 - A v)
-        hipLaunchKernelGGL(mg_smooth_step_kernel, dim3((unsigned)A.tiles), dim3(CG_BLOCK), 0, st, whole, (const double*)nullptr, (const double*)v, (double*)nullptr, (const double*)nullptr, (const double*)nullptr, w, -1.0 / omega, (const int32_t*)nullptr);
+        if (S.tiles_own > 0) hipLaunchKernelGGL(mg_smooth_step_kernel, dim3((unsigned)S.tiles_own), dim3(CG_BLOCK), 0, st, S, (const double*)nullptr, (const double*)v, (double*)nullptr, (const double*)nullptr, (const double*)nullptr, w, -1.0 / omega, (const int32_t*)nullptr);
         double* tmp = v; v = w; w = tmp;
     }
-    hipLaunchKernelGGL(mg_power_ratio_kernel, dim3(1), dim3(1024), 0, st, (const double*)w, (const double*)v, n6, lam);      // (v: 8 steps, w: 7 steps)
-    hipLaunchKernelGGL(mg_rescale_dinv_kernel, dim3((unsigned)(((int64_t)A.n * 36 + 255) / 256)), dim3(256), 0, st, A, (const double*)lam, omega, 1.75, 1.5);
+    hipLaunchKernelGGL(mg_power_ratio_kernel, dim3(1), dim3(1024), 0, st, (const double*)w, (const double*)v, A.su_row0 * 6, A.su_row1 * 6, lam);      // (v: 8 steps, w: 7 steps)
 }
+void launch_mg_level_rescale(const MgLevelDev& A, const double* lam, double omega, hipStream_t st) {
+    const int64_t cnt = (int64_t)(A.su_row1 - A.su_row0) * 36;
+    if (cnt > 0) hipLaunchKernelGGL(mg_rescale_dinv_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, A, lam, omega, 1.75, 1.5);
+}
+void launch_mg_level_inverses(const MgLevelDev& A, double omega, int32_t* fail, hipStream_t st) {
+    const int rows = A.su_row1 - A.su_row0;
+    const int64_t blocks = A.su_blk1 - A.su_blk0;
+    if (rows > 0) hipLaunchKernelGGL(mg_dinv_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, A, omega, fail, 0, (const double*)nullptr);
+    if (blocks > 0) hipLaunchKernelGGL(mg_val_f32_kernel, dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, st, A);
+}
+void launch_mg_transition_ps(const MgLevelDev& A, double prolong_scale, hipStream_t st) {
+    const int cnt = A.su_ps1 - A.su_ps0;
+    if (cnt > 0) hipLaunchKernelGGL(mg_ps_kernel<false>, dim3((unsigned)((cnt + 3) / 4)), dim3(256), 0, st, A, prolong_scale);
+}
+void launch_mg_transition_w(const MgLevelDev& A, hipStream_t st) {
+    const int cnt = A.su_w1 - A.su_w0;
+    if (cnt <= 0) return;
+    hipLaunchKernelGGL(mg_w_kernel, dim3((unsigned)((cnt + 3) / 4)), dim3(256), 0, st, A);
+    if (A.rt_valf) hipLaunchKernelGGL(mg_rt_kernel, dim3((unsigned)((cnt + 3) / 4)), dim3(256), 0, st, A);
+}
+void launch_mg_transition_product(const MgLevelDev& A, const MgLevelDev& B, hipStream_t st) {
+    const int64_t cnt = A.su_prod ? (int64_t)A.n_su_prod : B.nnzb;
+    if (cnt > 0) hipLaunchKernelGGL(mg_psTw_kernel, dim3((unsigned)((cnt + 3) / 4)), dim3(256), 0, st, A, B);
+}
+void launch_mg_level_galerkin(const MgLevelDev& A, const MgLevelDev& B, hipStream_t st) {
+    const int64_t cnt = B.su_blk1 - B.su_blk0;
+    if (cnt > 0) hipLaunchKernelGGL(mg_galerkin_kernel, dim3((unsigned)((cnt + 3) / 4)), dim3(256), 0, st, A, B);
+}
+__global__ void mg_pack_flags_kernel(const int32_t* __restrict__ fail, const double* __restrict__ lam, double* __restrict__ out2) { out2[0] = *fail != 0 ? 1.0 : 0.0; out2[1] = *lam; }
+__global__ void mg_unpack_flags_kernel(const double* __restrict__ in2, int32_t* __restrict__ fail, double* __restrict__ lam) { if (in2[0] != 0.0) *fail = 1; *lam = in2[1]; }
+void launch_mg_pack_flags(const int32_t* fail, const double* lam, double* out2, hipStream_t st) { hipLaunchKernelGGL(mg_pack_flags_kernel, dim3(1), dim3(1), 0, st, fail, lam, out2); }
+void launch_mg_unpack_flags(const double* in2, int32_t* fail, double* lam, hipStream_t st) { hipLaunchKernelGGL(mg_unpack_flags_kernel, dim3(1), dim3(1), 0, st, in2, fail, lam); }
 
 void launch_mg_galerkin0(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, const MgDev& M, const MgLevelDev* levels, hipStream_t st, bool hoff_valid) {
-    if (hoff_valid) hipLaunchKernelGGL((mg_galerkin0_kernel<true>), dim3((unsigned)((levels[0].nnzb + 3) / 4)), dim3(256), 0, st, G, L, Sc, C, M, levels[0]);
-    else hipLaunchKernelGGL((mg_galerkin0_kernel<false>), dim3((unsigned)((levels[0].nnzb + 3) / 4)), dim3(256), 0, st, G, L, Sc, C, M, levels[0]);
+    const int64_t cnt = M.g0_slots ? (int64_t)M.n_g0 : levels[0].nnzb;
+    if (cnt <= 0) return;
+    if (hoff_valid) hipLaunchKernelGGL((mg_galerkin0_kernel<true>), dim3((unsigned)((cnt + 3) / 4)), dim3(256), 0, st, G, L, Sc, C, M, levels[0]);
+    else hipLaunchKernelGGL((mg_galerkin0_kernel<false>), dim3((unsigned)((cnt + 3) / 4)), dim3(256), 0, st, G, L, Sc, C, M, levels[0]);
 }
 void launch_mg_assemble(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, double omega, int32_t* fail, hipStream_t st, double prolong_scale, bool hoff_valid) {
     launch_mg_galerkin0(G, L, Sc, C, M, levels, st, hoff_valid);
     launch_mg_assemble_rest(M, levels, K, omega, fail, st, prolong_scale);
 }
-void launch_mg_assemble_rest(const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, double omega, int32_t* fail, hipStream_t st, double prolong_scale) {
-    // level by level: the block-Jacobi inverse of level l is needed by a smoothed transition to level l+1 (Ps = (I - c Dinv A) P)
-    for (int l = 0; l < M.n_levels; ++l) {
-        if (l > 0) {
-            const MgLevelDev& A = levels[l - 1];
-            if (A.smoothed) {
-                hipLaunchKernelGGL(mg_ps_kernel<false>, dim3((unsigned)((A.n_ps + 3) / 4)), dim3(256), 0, st, A, prolong_scale);
-                hipLaunchKernelGGL(mg_w_kernel, dim3((unsigned)((A.n_w + 3) / 4)), dim3(256), 0, st, A);
-                if (A.rt_valf) hipLaunchKernelGGL(mg_rt_kernel, dim3((unsigned)((A.n_w + 3) / 4)), dim3(256), 0, st, A);
-                hipLaunchKernelGGL(mg_psTw_kernel, dim3((unsigned)((levels[l].nnzb + 3) / 4)), dim3(256), 0, st, A, levels[l]);
-            } else hipLaunchKernelGGL(mg_galerkin_kernel, dim3((unsigned)((levels[l].nnzb + 3) / 4)), dim3(256), 0, st, A, levels[l]);
-        }
-        if (l + 1 < M.n_levels) {
-            hipLaunchKernelGGL(mg_dinv_kernel, dim3((unsigned)((levels[l].n + 255) / 256)), dim3(256), 0, st, levels[l], omega, fail, 0, (const double*)nullptr);
-            hipLaunchKernelGGL(mg_val_f32_kernel, dim3((unsigned)((levels[l].nnzb + 3) / 4)), dim3(256), 0, st, levels[l]);
-            mg_limit_smoother(levels[l], omega, st);
-        }
-    }
+void launch_mg_dense_top(const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, hipStream_t st) {
     const MgLevelDev& T = levels[M.n_levels - 1];
     (void)hipMemsetAsync(K.Ac, 0, (size_t)K.nc * K.nc * sizeof(double), st);
     if (K.nc > 6 * K.n_agg) hipLaunchKernelGGL(coarse_pad_identity_kernel, dim3((unsigned)((K.nc - 6 * K.n_agg + 63) / 64)), dim3(64), 0, st, K);
     hipLaunchKernelGGL(mg_dense_scatter_kernel, dim3((unsigned)(((int64_t)T.n * 36 + 255) / 256)), dim3(256), 0, st, T, K);
+}
+void launch_mg_assemble_rest(const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, double omega, int32_t* fail, hipStream_t st, double prolong_scale, int first_level) {
+    // level by level: the block-Jacobi inverse of level l is needed by a smoothed transition to level l+1 (Ps = (I - c Dinv A) P)
+    for (int l = first_level; l < M.n_levels; ++l) {
+        if (l > first_level) {
+            const MgLevelDev& A = levels[l - 1];
+            if (A.smoothed) { launch_mg_transition_ps(A, prolong_scale, st); launch_mg_transition_w(A, st); launch_mg_transition_product(A, levels[l], st); }
+            else launch_mg_level_galerkin(A, levels[l], st);
+        }
+        if (l + 1 < M.n_levels) {
+            launch_mg_level_inverses(levels[l], omega, fail, st);
+            launch_mg_level_power(levels[l], omega, st);
+            launch_mg_level_rescale(levels[l], levels[l].xf, omega, st);
+        }
+    }
+    launch_mg_dense_top(M, levels, K, st);
 }
 // level 1 of a hierarchy with the smoothed keyframe transition: F = the keyframe level (set-up view), T = its transfer view (Ps's pattern in the explicit operator's fields)
 void launch_mg_assemble_fine(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, const MgLevelDev& F, const MgLevelDev& T, const MgLevelDev& L1, double omega, int32_t* fail, hipStream_t st,

@@ -166,4 +166,37 @@ void mgh_fine_get(void* ps, int* sh_loc, int* sum_ptr, int* sum_src) {
     std::memcpy(sum_ptr, P->fine.sum_ptr.data(), P->fine.sum_ptr.size() * 4);
     if (!P->fine.sum_src.empty()) std::memcpy(sum_src, P->fine.sum_src.data(), P->fine.sum_src.size() * 4);
 }
+
+// ---- the distributed set-up's block plans (pgo_mg_host.hpp: build_setup_plans) ----
+void* mgh_setup_plans(void* h, int rank, int world, long long Er, const int* rc1, const int* rc2, const long long* rel_off, long long Es, const int* sc1, const int* sc2, const long long* sw_off) {
+    const pgo_mg::Hierarchy& H = *(pgo_mg::Hierarchy*)h;
+    std::vector<int32_t> a(rc1, rc1 + Er), b(rc2, rc2 + Er), c(sc1, sc1 + Es), d(sc2, sc2 + Es);
+    std::vector<int64_t> ro(rel_off, rel_off + world + 1), so(sw_off, sw_off + world + 1);
+    pgo_mg::SetupPlans* S = new pgo_mg::SetupPlans();
+    pgo_mg::build_setup_plans(H, rank, world, a, b, ro, c, d, so, *S);
+    return S;
+}
+void mgh_setup_free(void* sp) { delete (pgo_mg::SetupPlans*)sp; }
+int mgh_setup_first_whole(void* sp) { return ((pgo_mg::SetupPlans*)sp)->first_whole; }
+static const pgo_mg::ExchangePlan& setup_plan(void* sp, int kind, int l) { pgo_mg::SetupPlans* S = (pgo_mg::SetupPlans*)sp; return kind == 0 ? S->val[l].x : kind == 1 ? S->ps[l] : S->rv[l]; }
+void mgh_setup_sizes(void* sp, int kind /* 0 the level's blocks (sum), 1 Ps, 2 R */, int l, long long* n_send, long long* n_recv, long long* n_dst, long long* n_src) {
+    const pgo_mg::ExchangePlan& X = setup_plan(sp, kind, l);
+    *n_send = X.n_send(); *n_recv = X.n_recv(); *n_dst = 0; *n_src = 0;
+    if (kind == 0) { const pgo_mg::BlockPlan& B = ((pgo_mg::SetupPlans*)sp)->val[l]; *n_dst = (long long)B.dst.size(); *n_src = (long long)B.sum_src.size(); }
+}
+void mgh_setup_get(void* sp, int kind, int l, int* send_idx, long long* send_off, int* recv_idx, long long* recv_off, long long* pair_cnt, int* dst, int* sum_ptr, int* sum_src) {
+    const pgo_mg::ExchangePlan& X = setup_plan(sp, kind, l);
+    if (!X.send_idx.empty()) std::memcpy(send_idx, X.send_idx.data(), X.send_idx.size() * 4);
+    if (!X.recv_idx.empty()) std::memcpy(recv_idx, X.recv_idx.data(), X.recv_idx.size() * 4);
+    std::memcpy(send_off, X.send_off.data(), X.send_off.size() * 8); std::memcpy(recv_off, X.recv_off.data(), X.recv_off.size() * 8);
+    std::memcpy(pair_cnt, X.pair_cnt.data(), X.pair_cnt.size() * 8);
+    if (kind == 0) {
+        const pgo_mg::BlockPlan& B = ((pgo_mg::SetupPlans*)sp)->val[l];
+        if (!B.dst.empty()) std::memcpy(dst, B.dst.data(), B.dst.size() * 4);
+        std::memcpy(sum_ptr, B.sum_ptr.data(), B.sum_ptr.size() * 4);
+        if (!B.sum_src.empty()) std::memcpy(sum_src, B.sum_src.data(), B.sum_src.size() * 4);
+    }
+}
+long long mgh_setup_prod_size(void* sp, int l) { return (long long)((pgo_mg::SetupPlans*)sp)->prod[l].size(); }
+void mgh_setup_prod_get(void* sp, int l, int* out) { const std::vector<int32_t>& v = ((pgo_mg::SetupPlans*)sp)->prod[l]; if (!v.empty()) std::memcpy(out, v.data(), v.size() * 4); }
 }

@@ -85,10 +85,10 @@ def test_abi_version_and_the_host_only_entry_points_of_round_6():
     """No GPU needed: the ABI version the ctypes view was written against, the sizes of the structs it mirrors (pgo_sharding_stats has no size query: its layout is pinned here by
     the field the library would write last), and the in-process communicator's group object — created, aborted, destroyed; refused for worlds the kernels cannot take."""
     lib = capi.load()
-    assert lib.pgo_abi_version() == capi.ABI_VERSION == 6
-    assert C.sizeof(capi.ShardingStats) == 160 and capi.ShardingStats.exchanges_per_bj_iteration.offset == 156
+    assert lib.pgo_abi_version() == capi.ABI_VERSION == 7
+    assert C.sizeof(capi.ShardingStats) == 200 and capi.ShardingStats.exchanges_per_bj_iteration.offset == 156 and capi.ShardingStats.bytes_allreduce_replicated_setup.offset == 192
     o = capi.default_options()
-    assert o.mg_min_keyframes == 5000 and o.mg_min_keyframes_switchable == 5000 and o.mg_smoothed_fine == -1 and o.mg_dist_min_rows == 8192 and o.mg_fine_filter == 0
+    assert o.mg_min_keyframes == 5000 and o.mg_min_keyframes_switchable == 5000 and o.mg_smoothed_fine == -1 and o.mg_dist_min_rows == 8192 and o.mg_fine_filter == 0 and o.mg_dist_setup == 1
     g = capi.local_group_create(4)
     assert g.value
     capi.local_group_abort(g)

@@ -243,3 +243,227 @@ def test_keyframe_plan_sums_the_partial_rows_in_rank_order(shim, world, policy):
             total.setdefault(k, s)
             assert total[k] == s
     shim.mgh_free(h)
+
+
+def setup_plans_of(lib, h, g, world, policy, rank, L):
+    """pgo_mg_host.hpp: build_setup_plans for one rank, from the edge lists gathered rank by rank (as libpgo's graph build gathers them)"""
+    parts = sharding.partition(g, world, policy)
+    io = [sel("odom", g.n_odom) for sel in parts]; il = [sel("loop", g.n_loops) for sel in parts]
+    rc1, rc2 = I32(np.concatenate([g.odom_c1[i] for i in io])), I32(np.concatenate([g.odom_c2[i] for i in io]))
+    sc1, sc2 = I32(np.concatenate([g.loop_c1[i] for i in il])), I32(np.concatenate([g.loop_c2[i] for i in il]))
+    ro = np.concatenate([[0], np.cumsum([len(i) for i in io])]).astype(np.int64); so = np.concatenate([[0], np.cumsum([len(i) for i in il])]).astype(np.int64)
+    lib.mgh_setup_plans.restype = C.c_void_p
+    sp = C.c_void_p(lib.mgh_setup_plans(h, rank, world, C.c_longlong(len(rc1)), ptr(rc1, C.c_int), ptr(rc2, C.c_int), ptr(ro, C.c_longlong), C.c_longlong(len(sc1)), ptr(sc1, C.c_int), ptr(sc2, C.c_int),
+                                        ptr(so, C.c_longlong)))
+    fw = lib.mgh_setup_first_whole(sp)
+    out = dict(first_whole=fw, val=[], ps=[], rv=[], prod=[])
+    lib.mgh_setup_prod_size.restype = C.c_longlong
+
+    def get(kind, l):
+        ns, nr, nd, nsrc = C.c_longlong(0), C.c_longlong(0), C.c_longlong(0), C.c_longlong(0)
+        lib.mgh_setup_sizes(sp, kind, l, C.byref(ns), C.byref(nr), C.byref(nd), C.byref(nsrc))
+        P = dict(send_idx=np.zeros(ns.value, np.int32), recv_idx=np.zeros(nr.value if kind else 0, np.int32), send_off=np.zeros(world + 1, np.int64), recv_off=np.zeros(world + 1, np.int64),
+                 pair_cnt=np.zeros(world * world, np.int64), dst=np.zeros(nd.value, np.int32), sum_ptr=np.zeros(nd.value + 1, np.int32), sum_src=np.zeros(nsrc.value, np.int32))
+        lib.mgh_setup_get(sp, kind, l, ptr(P["send_idx"], C.c_int), ptr(P["send_off"], C.c_longlong), ptr(P["recv_idx"], C.c_int), ptr(P["recv_off"], C.c_longlong), ptr(P["pair_cnt"], C.c_longlong),
+                          ptr(P["dst"], C.c_int), ptr(P["sum_ptr"], C.c_int), ptr(P["sum_src"], C.c_int))
+        return P
+    for l in range(fw + 1 if fw > 0 else 0):
+        out["val"].append(get(0, l))
+    for l in range(fw):
+        sm = "smoothed" in L[l]
+        out["ps"].append(get(1, l) if sm else None); out["rv"].append(get(2, l) if sm else None)
+        n = lib.mgh_setup_prod_size(sp, l)
+        pr = np.zeros(int(n), np.int32)
+        lib.mgh_setup_prod_get(sp, l, ptr(pr, C.c_int))
+        out["prod"].append(pr)
+    lib.mgh_setup_free(sp)
+    return out, (rc1, rc2, ro, sc1, sc2, so)
+
+
+def exchange_copy(world, plans, arrays):
+    """neighbour exchange with ONE producer per entry: plans[r] / arrays[r] of every rank; segment (r -> q) must be the same list on both ends"""
+    for r in range(world):
+        assert np.array_equal(plans[r]["pair_cnt"], plans[0]["pair_cnt"])
+    staged = [[arrays[r][plans[r]["send_idx"][plans[r]["send_off"][q]:plans[r]["send_off"][q + 1]]].copy() for q in range(world)] for r in range(world)]
+    for r in range(world):
+        for q in range(world):
+            seg = plans[r]["send_idx"][plans[r]["send_off"][q]:plans[r]["send_off"][q + 1]]
+            dst = plans[q]["recv_idx"][plans[q]["recv_off"][r]:plans[q]["recv_off"][r + 1]]
+            assert np.array_equal(seg, dst) and len(seg) == plans[0]["pair_cnt"][r * world + q]
+            arrays[q][dst] = staged[r][q]
+
+
+def exchange_sum(world, plans, arrays):
+    """... with several contributors per entry: every needer adds the parts in ascending rank order (its own where its rank comes)"""
+    for r in range(world):
+        assert np.array_equal(plans[r]["pair_cnt"], plans[0]["pair_cnt"])
+    recv = []
+    for q in range(world):
+        buf = np.full(int(plans[q]["recv_off"][-1]), np.nan)
+        for r in range(world):
+            seg = plans[r]["send_idx"][plans[r]["send_off"][q]:plans[r]["send_off"][q + 1]]
+            assert len(seg) == plans[q]["recv_off"][r + 1] - plans[q]["recv_off"][r] == plans[0]["pair_cnt"][r * world + q] and np.all(np.diff(seg) > 0)
+            buf[plans[q]["recv_off"][r]:plans[q]["recv_off"][r + 1]] = arrays[r][seg]
+        recv.append(buf)
+    for q in range(world):
+        P = plans[q]
+        for j, k in enumerate(P["dst"]):
+            src = P["sum_src"][P["sum_ptr"][j]:P["sum_ptr"][j + 1]]
+            tot = 0.0
+            for s_ in src:
+                tot += arrays[q][k] if s_ < 0 else recv[q][s_]
+            arrays[q][k] = tot
+
+
+@pytest.mark.parametrize("world,policy,smoothed,dist_min", [(2, "chain", 1, 64), (4, "spatial", 1, 64), (3, "spatial", 0, 64), (4, "spatial", 2, 32), (8, "spatial", 0, 16), (3, "spatial", 1, 100000)])
+def test_distributed_setup_replayed_with_scalar_blocks(shim, world, policy, smoothed, dist_min):
+    """The distributed SET-UP (pgo_solver.hip: build_mg_ranks) replayed with numpy, every 6x6 block a scalar: each rank holds arrays that are NaN wherever it has not formed or
+    received a number, forms what libpgo's kernels form on its own rows — level 1 from its own edges and owned keyframes, Dinv, Ps, W, R, the Galerkin products — from exactly the
+    entries those kernels read, and exchanges blocks by the plans of pgo_mg_host.hpp: build_setup_plans.  Every entry its cycle kernels read must then equal the single-process
+    result: its rows' blocks (and the transposed upper blocks of other owners: the fp32 copy is symmetrised), Dinv on its rows and their halo, R^T on its rows, R on its coarse
+    rows, everything of the first level every rank runs completely."""
+    g = graphgen.generate(2500, 1500, odom_f_max=2, seed=11)
+    masks, kf_owner = touch_masks(g, world, policy, with_owner=True)
+    h = build_owned(shim, g, masks, world, dist_min_rows=dist_min, smoothed=smoothed, owner=kf_owner, policy=policy)
+    L = levels_of(shim, h, world)
+    nl = len(L)
+    agg0 = np.zeros(g.n_poses, np.int32); mem0_ptr = np.zeros(L[0]["n"] + 1, np.int32); mem0 = np.zeros(int((masks != 0).sum()), np.int32)
+    shim.mgh_level0(h, ptr(agg0, C.c_int), ptr(mem0_ptr, C.c_int), ptr(mem0, C.c_int))
+    SP, edges = zip(*[setup_plans_of(shim, h, g, world, policy, r, L) for r in range(world)])
+    rc1, rc2, ro, sc1, sc2, so = edges[0]
+    fw = SP[0]["first_whole"]
+    assert all(S["first_whole"] == fw for S in SP)
+    if not L[0]["distributed"]:
+        assert fw == 0      # level 1 not distributed: the set-up stays replicated
+        shim.mgh_free(h)
+        return
+    assert fw >= 1 and all(L[l]["distributed"] for l in range(fw)) and not L[fw]["distributed"]
+    LP = [plans_of(shim, h, masks, world, dist_min, r, nl) for r in range(world)]
+    own = [owner_of_rows(A, world) for A in L]
+    rng = np.random.default_rng(5)
+
+    def slot_of(A, a, b):
+        if a == b:
+            return int(A["rowptr"][a])
+        lo, hi = int(A["rowptr"][a]) + 1, int(A["rowptr"][a + 1])
+        k = lo + int(np.searchsorted(A["col"][lo:hi], b))
+        assert k < hi and A["col"][k] == b
+        return k
+    row_of = [np.repeat(np.arange(A["n"]), np.diff(A["rowptr"])) for A in L]
+    # ---- level 1: the truth and every rank's part (a keyframe's diagonal block by its owner, an edge's two blocks by the rank holding the edge)
+    A0 = L[0]
+    truth = [np.zeros(len(A["col"])) for A in L]
+    part = [np.full(len(A0["col"]), np.nan) for _ in range(world)]
+
+    def add(r, k, v):
+        truth[0][k] += v
+        part[r][k] = v if np.isnan(part[r][k]) else part[r][k] + v
+    dk = 5.0 + rng.random(g.n_poses)
+    for i in range(g.n_poses):
+        if agg0[i] >= 0:
+            add(int(kf_owner[i]), slot_of(A0, agg0[i], agg0[i]), dk[i])
+    for (c1, c2, off) in ((rc1, rc2, ro), (sc1, sc2, so)):
+        he = -0.3 * rng.random(len(c1))
+        for r in range(world):
+            for e in range(int(off[r]), int(off[r + 1])):
+                a, b = agg0[c1[e]], agg0[c2[e]]
+                if a < 0 or b < 0:
+                    continue
+                add(r, slot_of(A0, a, b), he[e]); add(r, slot_of(A0, b, a), he[e])
+    val = [part]      # val[l][r]: rank r's array of level l
+    exchange_sum(world, [S["val"][0] for S in SP], val[0])
+    cs = 0.6
+    Dinv_t, Ps_t, W_t, R_t = {}, {}, {}, {}
+    for l in range(fw + 1):
+        A = L[l]
+        # what a rank's kernels read of this level's blocks: its rows; the blocks above the diagonal whose column it owns (transposed into its fp32 copy); the first whole level: all
+        for r in range(world):
+            blocks = np.arange(len(A["col"]))
+            need = blocks if l == fw else blocks[(own[l][row_of[l]] == r) | ((A["col"] > row_of[l]) & (own[l][A["col"]] == r))]
+            assert np.allclose(val[l][r][need], truth[l][need], rtol=1e-13, atol=0), (l, r)
+        if l == fw:
+            break
+        B = L[l + 1]
+        diag = A["rowptr"][:-1]
+        Dinv_t[l] = 1.0 / truth[l][diag]
+        Dinv = [np.where(own[l] == r, 1.0 / val[l][r][diag], np.nan) for r in range(world)]
+        nxt = [np.full(len(B["col"]), np.nan) for _ in range(world)]
+        if "smoothed" in A:
+            S = A["smoothed"]
+            exchange_copy(world, [LP[r][l] for r in range(world)], Dinv)       # the halo's Dinv (the cycle forms x = Dinv r on receipt): the level's own plan
+            ps_row = np.repeat(np.arange(A["n"]), np.diff(S["ps_rowptr"])); w_row = np.repeat(np.arange(A["n"]), np.diff(S["w_rowptr"]))
+
+            def form_ps(valA, Dv, rows):
+                out = {}
+                for i in rows:
+                    for pk in range(S["ps_rowptr"][i], S["ps_rowptr"][i + 1]):
+                        a = S["ps_col"][pk]
+                        acc = sum(valA[k] for k in range(A["rowptr"][i], A["rowptr"][i + 1]) if A["parent"][A["col"][k]] == a)
+                        out[pk] = (1.0 if A["parent"][i] == a else 0.0) - cs * Dv[i] * acc
+                return out
+
+            def form_w(valA, Ps, rows):
+                out = {}
+                for i in rows:
+                    for wk in range(S["w_rowptr"][i], S["w_rowptr"][i + 1]):
+                        b = S["w_col"][wk]
+                        acc = 0.0
+                        for k in range(A["rowptr"][i], A["rowptr"][i + 1]):
+                            j = A["col"][k]
+                            for pk in range(S["ps_rowptr"][j], S["ps_rowptr"][j + 1]):
+                                if S["ps_col"][pk] == b:
+                                    acc += valA[k] * Ps[pk]
+                        out[wk] = acc
+                return out
+            allrows = range(A["n"])
+            pst = form_ps(truth[l], Dinv_t[l], allrows); Ps_t[l] = np.array([pst[k] for k in range(len(S["ps_col"]))])
+            wt = form_w(truth[l], Ps_t[l], allrows); W_t[l] = np.array([wt[k] for k in range(len(S["w_col"]))])
+            Ps = [np.full(len(S["ps_col"]), np.nan) for _ in range(world)]
+            for r in range(world):
+                for k, v in form_ps(val[l][r], Dinv[r], np.nonzero(own[l] == r)[0]).items():
+                    Ps[r][k] = v
+            exchange_copy(world, [SP[r]["ps"][l] for r in range(world)], Ps)
+            W = [np.full(len(S["w_col"]), np.nan) for _ in range(world)]
+            Rv = [np.full(len(S["w_col"]), np.nan) for _ in range(world)]      # R by coarse row (slot rT_of_w[k] for block k of W)
+            R_t[l] = np.zeros(len(S["w_col"]))
+            for k in range(len(S["w_col"])):
+                ps = S["ps_of_w"][k]
+                R_t[l][S["rT_of_w"][k]] = (Ps_t[l][ps] if ps >= 0 else 0.0) - Dinv_t[l][w_row[k]] * W_t[l][k]
+            for r in range(world):
+                for k, v in form_w(val[l][r], Ps[r], np.nonzero(own[l] == r)[0]).items():
+                    W[r][k] = v
+                    ps = S["ps_of_w"][k]
+                    Rv[r][S["rT_of_w"][k]] = (Ps[r][ps] if ps >= 0 else 0.0) - Dinv[r][w_row[k]] * v
+                assert not np.isnan(W[r][own[l][w_row] == r]).any()                                   # every entry the W kernel read was there
+            exchange_copy(world, [SP[r]["rv"][l] for r in range(world)], Rv)
+            for r in range(world):
+                c0, c1_ = L[l + 1]["own_ptr"][r], L[l + 1]["own_ptr"][r + 1]
+                mine = np.arange(S["rT_rowptr"][c0], S["rT_rowptr"][c1_])
+                assert np.allclose(Rv[r][mine], R_t[l][mine], rtol=1e-12, atol=1e-15), (l, r)          # R on the rank's coarse rows
+                halo = np.unique(np.concatenate([A["col"][A["rowptr"][i]:A["rowptr"][i + 1]] for i in np.nonzero(own[l] == r)[0]] + [S["rT_col"][mine]]))
+                assert np.allclose(Dinv[r][halo], Dinv_t[l][halo], rtol=1e-13), (l, r)                 # Dinv wherever the cycle forms x = Dinv r on receipt
+            # the product Ps^T W: the truth, and every rank's rows' part on the blocks it contributes to
+            for i in range(A["n"]):
+                for pk in range(S["ps_rowptr"][i], S["ps_rowptr"][i + 1]):
+                    for wk in range(S["w_rowptr"][i], S["w_rowptr"][i + 1]):
+                        kb = slot_of(B, S["ps_col"][pk], S["w_col"][wk])
+                        truth[l + 1][kb] += Ps_t[l][pk] * W_t[l][wk]
+                        r = own[l][i]
+                        v = Ps[r][pk] * W[r][wk]
+                        nxt[r][kb] = v if np.isnan(nxt[r][kb]) else nxt[r][kb] + v
+            for r in range(world):
+                assert np.array_equal(np.nonzero(~np.isnan(nxt[r]))[0], SP[r]["prod"][l])              # exactly the blocks the library launches the product on
+        else:
+            for kb in range(len(B["col"])):
+                ent = B["g_ent"][B["g_ptr"][kb]:B["g_ptr"][kb + 1]]
+                truth[l + 1][kb] = sum(truth[l][int(e) & 0xffffffff] for e in ent)
+                r = own[l + 1][row_of[l + 1][kb]]
+                rows = (ent >> 32).astype(np.int64)
+                assert np.all(own[l][rows] == r)                                                       # a coarse row's contributions are blocks of its own rank's rows
+                nxt[r][kb] = sum(val[l][r][int(e) & 0xffffffff] for e in ent)
+        val.append(nxt)
+        exchange_sum(world, [S_["val"][l + 1] for S_ in SP], val[l + 1])
+    # what travels: far less than level 1's all-reduce (every block, from every rank)
+    sent = sum(int(S["val"][0]["pair_cnt"].sum()) for S in SP[:1])
+    assert sent < 0.5 * len(A0["col"]) * world
+    shim.mgh_free(h)
