@@ -534,7 +534,7 @@ def main():
                              "scaling": "strong", "steps": k5, "seconds": el5, "lm_iters_per_s": k5 / el5, "chi2_final": 2.0 * sum5.final_cost, "cg_iterations_total": int(sum5.cg_iterations),
                              "cg_iterations_multigrid": int(sum5.cg_iterations_multigrid), "shared_keyframes": stats5["shared_keyframes"], "edges_per_rank": [min(stats5["edges_per_rank"]), max(stats5["edges_per_rank"])],
                              "sharding_counters": counters5,
-                             "note": "per CG iteration: neighbour exchange of the shared keyframes' rows + one 2-double all-reduce; multigrid cycle distributed (levels >= mg_dist_min_rows rows run on their owners' rows, halo rows by neighbour exchange, smaller levels by every rank from gathered vectors); the multigrid's SET-UP is still formed by every rank for all levels (DESIGN.md §8)"}
+                             "note": "per CG iteration: neighbour exchange of the shared keyframes' rows + one 2-double all-reduce; multigrid cycle distributed (levels >= mg_dist_min_rows rows run on their owners' rows, halo rows by neighbour exchange, smaller levels by every rank from gathered vectors); the multigrid's SET-UP distributed the same way (every rank forms the operators of its own rows, shared blocks by neighbour exchange, the first completely-run level gathered, the dense inverse on every rank: DESIGN.md §8)"}
             return None
         except Exception as e:      # the weak figure above is the contract; this leg is reported when it runs
             return {"error": repr(e)}
@@ -556,7 +556,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: synthetic 3D Manhattan graph, %d poses / %d edges (%d odometry f=1,2 + %d switchable loop closures, 10%% outliers) + %d regulariser(s)"
                                    % ("C5 (the same graph on every rank count)" if strong else "C3 x %d" % scale, g.n_poses, n_edges, g.n_odom, g.n_loops, len(g.reg_node)),
-                       "poses": g.n_poses, "edges": n_edges, "sharding": ("edges by the '%s' policy (sharding.py): %d..%d edges and %d..%d keyframes per rank, %d of %d keyframes shared between ranks; per CG iteration the partial rows of the matvec output go to the ranks sharing a keyframe (neighbour send / receive, summed in rank order) + one %s all-reduce of 2 doubles; the multigrid's cycle is distributed (every rank runs the level kernels on the rows it owns, halo rows by neighbour exchange: sharding_counters)"
+                       "poses": g.n_poses, "edges": n_edges, "sharding": ("edges by the '%s' policy (sharding.py): %d..%d edges and %d..%d keyframes per rank, %d of %d keyframes shared between ranks; per CG iteration the partial rows of the matvec output go to the ranks sharing a keyframe (neighbour send / receive, summed in rank order) + one %s all-reduce of 2 doubles; the multigrid's cycle AND set-up are distributed (every rank runs the level kernels and forms the level operators on the rows it owns; halo rows, and the blocks two ranks share, by neighbour exchange: sharding_counters)"
                                                                        % (args.partition, min(shard_stats["edges_per_rank"]), max(shard_stats["edges_per_rank"]), min(shard_stats["keyframes_per_rank"]), max(shard_stats["keyframes_per_rank"]),
                                                                           shard_stats["shared_keyframes"], g.n_poses, args.collective)) if world > 1 else "single GPU",
                        "linear_solver": "PCG on the Schur-reduced pose system, %s matvec; 6x6 block-Jacobi, hard LM systems by the aggregation multigrid (hybrid start)" % ("matrix-free" if P_linear_solver == 1 else "block-CSR"), "cg_rel_tolerance": P_cg_tol,

@@ -437,7 +437,8 @@ int pgo_comm_destroy(pgo_problem* p);
  *   per multigrid cycle  the halo rows of the level vectors: the hierarchy's aggregates never mix owners, every level is numbered owner-major, and a rank runs the level
  *                      kernels on its own rows only (pgo_options.mg_dist_min_rows; smaller levels are run completely by every rank from gathered vectors);
  *   per linearisation / LM system  diagonal blocks, gradient, reduced diagonal and right-hand side of the shared keyframes, the same way.
- * The multigrid's SET-UP (Galerkin products, dense inverse) is still formed by every rank for all levels (level 1 through one all-reduce of its blocks per LM system). */
+ * The multigrid's SET-UP is distributed the same way (pgo_options.mg_dist_setup): every rank forms the operators of its own rows of a distributed level, the blocks two ranks share
+ * travel by neighbour send/receive, the first level every rank runs completely is gathered; the small levels above it and the dense inverse are formed by every rank. */
 
 /* Bring-your-own collective (e.g. torch.distributed, MPI, or an in-process test harness): `fn` must all-reduce `count` doubles in
  * DEVICE memory in place across the `world_size` ranks (op 0 = sum, 2 = max; work enqueued before the call on `hip_stream` must be

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Round 6 soak of the distributed multi-rank solver: random graphs (1 500 - 9 000 keyframes, loop density, odometry policy, outliers), 2 - 7 in-process ranks on ONE GPU, the three
-partition policies (+ an idle rank now and then), 0 - 2 smoothed transitions, every level distributed or the library's threshold — each solved by the ranks and by a single handle with
+partition policies (+ an idle rank now and then), 0 - 2 smoothed transitions, every level distributed or the library's threshold, the set-up distributed (3 of 4) or replicated — each solved by the ranks and by a single handle with
 the same options: same accept/reject sequence, costs within 1e-7, no PCG retry, identical results on every rank.  Prints one line per case and a summary; exit code 1 on any mismatch.
   python scripts/gpu_ranks_soak.py [cases] [seed]"""
 import sys
@@ -25,6 +25,7 @@ for case in range(n_cases):
     opts = dict(mg_min_keyframes=1000, mg_min_keyframes_switchable=1000, mg_switch_iterations=int(rng.choice([0, 0, 60])), max_num_iterations=int(rng.integers(4, 9)), mg_smoothed_fine=0,
                 mg_smoothed_levels=int(rng.choice([0, 1, 1, 2])), mg_dense_max_nodes=int(rng.choice([16, 48, 128])), cg_rel_tolerance=1e-11)
     dist_min = int(rng.choice([1, 1, 200, 8192]))
+    dist_setup = int(rng.choice([1, 1, 1, 0]))      # (the multigrid's set-up distributed like its cycle — the default — or rounds 3-5's replicated one)
     g = graphgen.generate(n, loops, odom_f_max=f, apply_yaw_weight=bool(f == 5), seed=int(rng.integers(1, 10 ** 6)), outlier_frac=float(rng.choice([0.0, 0.1, 0.3])))
     q, t, s = util.initial_state(g, True)
     P = util.pgo_problem(g, True, **opts)
@@ -36,7 +37,7 @@ for case in range(n_cases):
 
     def run(rank):
         try:
-            Pr = capi.problem_from_graph(g, switchable=True, edge_slice=parts[rank], mg_dist_min_rows=dist_min, **opts)
+            Pr = capi.problem_from_graph(g, switchable=True, edge_slice=parts[rank], mg_dist_min_rows=dist_min, mg_dist_setup=dist_setup, **opts)
             Pr.comm_init_local(rank, world, group)
             out[rank] = Pr.solve(q, t, s) + (Pr.sharding_stats().as_dict(),)
             Pr.comm_destroy()
@@ -69,8 +70,8 @@ for case in range(n_cases):
             why.append("positions deviate by %.1e" % np.abs(out[0][1] - t1).max())
     bad += bool(why)
     st = out[0][4] if out[0] else {}
-    print("case %2d: %5d keyframes %5d loops f=%d outliers | %d ranks %-10s%s smoothed %d dense<=%3d dist_min %4d | single cg %6d (mg %6d)  ranks cg %6d  levels %s/%s  exchanges/it %s | %s" % (
-        case, n, loops, f, world, policy, " +idle" if idle else "", opts["mg_smoothed_levels"], opts["mg_dense_max_nodes"], dist_min, sum1.cg_iterations, sum1.cg_iterations_multigrid,
+    print("case %2d: %5d keyframes %5d loops f=%d outliers | %d ranks %-10s%s smoothed %d dense<=%3d dist_min %4d set-up %s | single cg %6d (mg %6d)  ranks cg %6d  levels %s/%s  exchanges/it %s | %s" % (
+        case, n, loops, f, world, policy, " +idle" if idle else "", opts["mg_smoothed_levels"], opts["mg_dense_max_nodes"], dist_min, "distributed" if dist_setup else "replicated ", sum1.cg_iterations, sum1.cg_iterations_multigrid,
         out[0][3].cg_iterations if out[0] else -1, st.get("mg_levels_distributed"), st.get("mg_levels"), st.get("exchanges_per_mg_iteration"), "ok" if not why else "MISMATCH: " + "; ".join(why)), flush=True)
 print("%d cases, %d mismatches" % (n_cases, bad))
 sys.exit(1 if bad else 0)

@@ -18,7 +18,8 @@ if [[ $PARTS == *gate* ]]; then
     echo "## python -m pytest tests/ -x -q -m gpu      (the driver's command)"
     timeout 1500 python -m pytest tests/ -x -q -m gpu -p no:cacheprovider 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -6
     echo "## PGO_DEBUG_POISON=1 python -m pytest tests/ -q -m gpu      (every new device allocation NaN-filled)"
-    PGO_DEBUG_POISON=1 timeout 1500 python -m pytest tests/ -q -m gpu -p no:cacheprovider 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -6
+    PGO_DEBUG_POISON=1 timeout 1500 python -X faulthandler -m pytest tests/ -v -m gpu -p no:cacheprovider > $OUT/gate_poison_full.log 2>&1 < /dev/null; prc=$?
+    grep -v "PASSED\|^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl\|^Extension modules\|^tests/.*::\|^$" $OUT/gate_poison_full.log | tail -$([ $prc -eq 0 ] && echo 6 || echo 80)      # (a crash keeps its whole traceback)
     echo "## python -m pytest tests -m gpu --collect-only -q | head -12      (oracle anchors of C1..C5 first)"
     python -m pytest tests -m gpu --collect-only -q -p no:cacheprovider 2>/dev/null | head -12
   } > $OUT/r06_gate.txt 2>&1
@@ -69,6 +70,8 @@ python scripts/dev/r05/opt_types.py "scan" "mg_min_keyframes=0" "" > $OUT/r06_mg
 python scripts/gpu_ranks_counters.py C3 4 10 > $OUT/r06_ranks_c3x4.json 2> $OUT/ranks_c3x4.err
 python scripts/gpu_ranks_counters.py C5 8 2 > $OUT/r06_ranks_c5x8.json 2> $OUT/ranks_c5x8.err
 python scripts/gpu_ranks_counters.py C3 8 10 > $OUT/r06_ranks_c3x8.json 2> $OUT/ranks_c3x8.err
+python scripts/gpu_ranks_counters.py C5 8 6 > $OUT/r06_ranks_c5x8_after_regroup.json 2> $OUT/ranks_c5x8_after_regroup.err      # (6 LM iterations: past the regroup inside the solve — another hierarchy: 4 distributed levels)
+timeout 900 python scripts/gpu_dist_setup_check.py > $OUT/r06_dist_setup_check.txt 2>&1 < /dev/null; stamp $OUT/r06_dist_setup_check.txt
 python scripts/dev/verbose_solve.py C3 2 2>&1 | grep "build_graph\|hierarchy (host)" > $OUT/r06_build_phases.txt; stamp $OUT/r06_build_phases.txt
 python scripts/gpu_all_configs.py > $OUT/r06_all_configs.txt 2>&1; stamp $OUT/r06_all_configs.txt
 python scripts/gpu_mg_graph_types.py 20 > $OUT/r06_mg_graph_types.txt 2>&1; stamp $OUT/r06_mg_graph_types.txt

@@ -1,0 +1,58 @@
+"""GPU: the multigrid's DISTRIBUTED SET-UP (pgo_options.mg_dist_setup = 1, pgo_solver.hip: build_mg_ranks) against the replicated one (= 0: level 1's blocks all-reduced, every
+level above formed by every rank) with in-process ranks on one GPU.  After ONE LM iteration from the same state with the multigrid from the first PCG iteration — one set-up on
+identical inputs — what every rank's cycle kernels read of every level (its rows' fp64 blocks, their fp32 copy, block-Jacobi inverses, R^T, R, the dense inverse:
+pgo_mg_level_norms) agrees to the order of the sums; full solves take the same decisions with the same costs.  (Host side of the same thing, replayed on the CPU:
+tests/test_mg_distributed.py::test_distributed_setup_replayed_with_scalar_blocks.)"""
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,world,dist_min,smoothed,policy,f", [
+    (6000, 3, 300, 1, "spatial", 2),      # one distributed level with a smoothed transition above it, the level above gathered
+    (12000, 5, 64, 2, "spatial", 2),      # two distributed levels, both transitions smoothed
+    (6000, 4, 1, 0, "spatial", 2),        # plain transitions only (what graphs beyond 500 000 keyframes get: BASELINE config 5)
+    (12000, 5, 64, 1, "spatial", 5),      # f = 1..5 + yaw weights: the smoother's safety rescaling triggers (estimated per rank, maximised: a few percent off the replicated estimate)
+    (6000, 3, 300, 1, "chain", 2),        # a partition by index ranges: loop closures cross ranks
+])
+def test_distributed_setup_forms_the_same_operators(n, world, dist_min, smoothed, policy, f):
+    import gpu_dist_setup_check as chk
+    assert chk.check(n, world, dist_min, smoothed, policy, f=f, verbose=False)
+
+
+def test_setup_counters_on_a_sharded_graph():
+    """what the set-up sends and forms, from the library's own counters: a rank forms its share of the blocks, its block exchanges carry less than the all-reduce of level 1 did"""
+    import threading
+
+    from solve_keyframe_pose_graph_amd import capi, graphgen, sharding
+    from tests import util
+    g = graphgen.generate(30000, 30000, odom_f_max=2, seed=3)
+    q, t, s = util.initial_state(g, True)
+    world = 4
+    parts = sharding.partition(g, world, "spatial")
+    group = capi.local_group_create(world)
+    out, err = [None] * world, []
+
+    def run(rank):
+        try:
+            P = capi.problem_from_graph(g, switchable=True, edge_slice=parts[rank], mg_dist_min_rows=500, max_num_iterations=3, mg_switch_iterations=0)
+            P.comm_init_local(rank, world, group)
+            P.solve(q, t, s)
+            out[rank] = P.sharding_stats().as_dict()
+            P.comm_destroy(); P.close()
+        except Exception as e:   # noqa: BLE001
+            err.append(repr(e)); capi.local_group_abort(group)
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [x.start() for x in th]; [x.join() for x in th]
+    capi.local_group_destroy(group)
+    assert not err, err
+    for st in out:
+        assert st["mg_setup_levels_own_rows"] >= 1 and st["mg_setup_levels_own_rows"] == st["mg_levels_distributed"]
+        assert st["mg_setup_blocks_own"] < 0.6 * st["mg_setup_blocks_total"]
+        assert 0 < st["bytes_sent_per_mg_setup"] < st["bytes_allreduce_replicated_setup"]
+        assert st["mg_setup_exchanges"] >= 3

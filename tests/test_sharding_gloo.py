@@ -259,3 +259,98 @@ def test_slices_partition_every_edge_class():
             got = np.concatenate([edge_slice(r, world)("odom", n) for r in range(world)])
             assert np.array_equal(got, np.arange(n))
         assert sum(len(edge_slice(r, world)("reg", 3)) for r in range(world)) == 3
+
+
+def _setup_worker(rank, world, port, policy, out):
+    """the distributed set-up's first exchange between independent processes: every rank forms ITS part of level 1's blocks (scalar blocks: its own edges, its owned keyframes), sends
+    the parts of the blocks it shares by the BlockPlan it derived on its own, and sums what it gets in ascending rank order — no handshake, the same bits on every needer"""
+    import ctypes as C
+    from solve_keyframe_pose_graph_amd import graphgen
+    from tests import test_mg_distributed as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "native", "libmg_host.so"))
+    lib.mgh_build.restype = C.c_void_p
+    g = graphgen.generate(4000, 2000, odom_f_max=2, seed=9)
+    masks, kf_owner = D.touch_masks(g, world, policy, with_owner=True)
+    h = D.build_owned(lib, g, masks, world, dist_min_rows=64, smoothed=1, owner=kf_owner, policy=policy)
+    L = D.levels_of(lib, h, world)
+    SP, (rc1, rc2, ro, sc1, sc2, so) = D.setup_plans_of(lib, h, g, world, policy, rank, L)
+    A0 = L[0]
+    agg0 = np.zeros(g.n_poses, np.int32); mem0_ptr = np.zeros(A0["n"] + 1, np.int32); mem0 = np.zeros(int((masks != 0).sum()), np.int32)
+    lib.mgh_level0(h, D.ptr(agg0, C.c_int), D.ptr(mem0_ptr, C.c_int), D.ptr(mem0, C.c_int))
+
+    def slot(a, b):
+        if a == b:
+            return int(A0["rowptr"][a])
+        lo, hi = int(A0["rowptr"][a]) + 1, int(A0["rowptr"][a + 1])
+        return lo + int(np.searchsorted(A0["col"][lo:hi], b))
+    rng = np.random.default_rng(5)      # (the same stream on every rank: the truth is computable everywhere)
+    dk = 5.0 + rng.random(g.n_poses)
+    he = [-0.3 * rng.random(len(rc1)), -0.3 * rng.random(len(sc1))]
+    truth = np.zeros(len(A0["col"])); mine = np.full(len(A0["col"]), np.nan)
+
+    def add(r, k, v):
+        truth[k] += v
+        if r == rank:
+            mine[k] = v if np.isnan(mine[k]) else mine[k] + v
+    for i in range(g.n_poses):
+        if agg0[i] >= 0:
+            add(int(kf_owner[i]), slot(agg0[i], agg0[i]), dk[i])
+    for cls, (c1, c2, off) in enumerate(((rc1, rc2, ro), (sc1, sc2, so))):
+        for r in range(world):
+            for e in range(int(off[r]), int(off[r + 1])):
+                a, b = agg0[c1[e]], agg0[c2[e]]
+                if a >= 0 and b >= 0:
+                    add(r, slot(a, b), he[cls][e]); add(r, slot(b, a), he[cls][e])
+    X = SP["val"][0]
+    reqs, rb = [], {}
+    recv = np.full(int(X["recv_off"][-1]), np.nan)
+    for q in range(world):
+        if q == rank:
+            continue
+        s_idx = X["send_idx"][X["send_off"][q]:X["send_off"][q + 1]]
+        n_r = int(X["recv_off"][q + 1] - X["recv_off"][q])
+        if len(s_idx):
+            reqs.append(dist.isend(torch.from_numpy(mine[s_idx].copy()), dst=q))
+        if n_r:
+            rb[q] = torch.zeros(n_r, dtype=torch.float64)
+            reqs.append(dist.irecv(rb[q], src=q))
+    for r in reqs:
+        r.wait()
+    for q, b in rb.items():
+        recv[X["recv_off"][q]:X["recv_off"][q + 1]] = b.numpy()
+    for j, k in enumerate(X["dst"]):
+        tot = 0.0
+        for s_ in X["sum_src"][X["sum_ptr"][j]:X["sum_ptr"][j + 1]]:
+            tot += mine[k] if s_ < 0 else recv[s_]
+        mine[k] = tot
+    own = D.owner_of_rows(A0, world)
+    row_of = np.repeat(np.arange(A0["n"]), np.diff(A0["rowptr"]))
+    need = np.nonzero((own[row_of] == rank) | ((A0["col"] > row_of) & (own[A0["col"]] == rank)))[0]
+    # the blocks above the diagonal that two owners share: both needers must hold the SAME bits — gathered and compared on rank 0 by the test
+    np.savez(out % rank, ok=bool(np.allclose(mine[need], truth[need], rtol=1e-13, atol=0)), first_whole=SP["first_whole"], sent=len(X["send_idx"]), blocks=len(A0["col"]),
+             need=need, got=mine[need])
+    lib.mgh_free(h)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world,policy", [(2, "spatial"), (3, "spatial")])
+def test_setup_block_sums_over_gloo(tmp_path, world, policy):
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    so, src = os.path.join(here, "native", "libmg_host.so"), os.path.join(here, "native", "mg_host.cpp")
+    hdr = os.path.join(os.path.dirname(here), "solve_keyframe_pose_graph_amd", "csrc", "pgo_mg_host.hpp")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", os.path.dirname(hdr), "-o", so, src])
+    out = str(tmp_path / "setup%d.npz")
+    mp.spawn(_setup_worker, args=(world, _free_port(), policy, out), nprocs=world, join=True)
+    R = [np.load(out % rank) for rank in range(world)]
+    for rank, r in enumerate(R):
+        assert bool(r["ok"]), rank
+        assert int(r["first_whole"]) >= 1 and 0 < int(r["sent"]) < 0.2 * int(r["blocks"])      # only the blocks two ranks share travel
+    for a in range(world):                                                                        # a block two ranks need holds the same bits on both
+        for b in range(a + 1, world):
+            common, ia, ib = np.intersect1d(R[a]["need"], R[b]["need"], return_indices=True)
+            assert len(common) > 0 and np.array_equal(R[a]["got"][ia], R[b]["got"][ib])
