@@ -482,7 +482,7 @@ typedef struct pgo_sharding_stats {
     int32_t exchanges_per_mg_iteration, exchanges_per_bj_iteration;  /* neighbour exchanges on the critical path of one iteration */
     /* the multigrid's set-up (pgo_options.mg_dist_setup; appended in ABI 7) */
     int32_t mg_setup_levels_own_rows;                                /* sparse levels whose operators this rank forms for its own rows only (0: the set-up is replicated) */
-    int32_t mg_setup_exchanges;                                      /* collectives of one set-up: block exchanges + one 2-double all-reduce per such level (replicated: 1 all-reduce) */
+    int32_t mg_setup_exchanges;                                      /* collectives of one set-up: block exchanges + per such level the smoother's safety estimate (8 halo exchanges of its power method's iterate, one 3-double all-reduce); replicated: 1 all-reduce */
     int64_t mg_setup_blocks_total, mg_setup_blocks_own;              /* 6x6 blocks one set-up forms (level matrices, Ps, W, R^T of every sparse level): in all, and by THIS rank (replicated: all of them on every rank) */
     double bytes_sent_per_mg_setup;                                  /* by the plans: what this rank sends in the block exchanges of one set-up */
     double bytes_allreduce_replicated_setup;                         /* what the replicated set-up all-reduces per LM system on the same graph: level 1's blocks x 288 B */

@@ -50,10 +50,8 @@ def check(n, world, dist_min, smoothed, policy="spatial", loops=None, f=2, verbo
     q, t, s = util.initial_state(g, True)
     base = dict(mg_min_keyframes=1000, mg_min_keyframes_switchable=1000, mg_switch_iterations=0, mg_smoothed_fine=0, mg_smoothed_levels=smoothed, mg_dist_min_rows=dist_min, cg_rel_tolerance=1e-11)
     worst = 0.0
-    # (mg_omega = 0.5 here: the smoother's safety rescaling — omega lambda_max > 1.75 — never triggers; the distributed set-up estimates lambda_max on each rank's own diagonal
-    # part and takes the maximum, the replicated one on the whole level: both lower bounds, not the same number, and a triggered rescaling then differs by a few percent)
-    A = run_ranks(g, world, policy, q, t, s, dict(base, max_num_iterations=1, mg_dist_setup=1, mg_omega=0.5), norms=True)
-    B = run_ranks(g, world, policy, q, t, s, dict(base, max_num_iterations=1, mg_dist_setup=0, mg_omega=0.5), norms=True)
+    A = run_ranks(g, world, policy, q, t, s, dict(base, max_num_iterations=1, mg_dist_setup=1), norms=True)
+    B = run_ranks(g, world, policy, q, t, s, dict(base, max_num_iterations=1, mg_dist_setup=0), norms=True)
     names = ["blocks", "fp32 blocks", "Dinv", "R^T", "R", "dense inverse"]
     for r in range(world):
         for l, (na, nb) in enumerate(zip(A[r][5], B[r][5])):

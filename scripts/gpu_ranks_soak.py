@@ -2,7 +2,7 @@
 """Round 6 soak of the distributed multi-rank solver: random graphs (1 500 - 9 000 keyframes, loop density, odometry policy, outliers), 2 - 7 in-process ranks on ONE GPU, the three
 partition policies (+ an idle rank now and then), 0 - 2 smoothed transitions, every level distributed or the library's threshold, the set-up distributed (3 of 4) or replicated — each solved by the ranks and by a single handle with
 the same options: same accept/reject sequence, costs within 1e-7, no PCG retry, identical results on every rank.  Prints one line per case and a summary; exit code 1 on any mismatch.
-  python scripts/gpu_ranks_soak.py [cases] [seed]"""
+  python scripts/gpu_ranks_soak.py [cases] [seed] [only this case] [its set-up forced: 0 replicated / 1 distributed]"""
 import sys
 import threading
 
@@ -14,6 +14,8 @@ from tests import util  # noqa: E402
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 6)
+only = int(sys.argv[3]) if len(sys.argv) > 3 else -1
+force_setup = int(sys.argv[4]) if len(sys.argv) > 4 else -1
 bad = 0
 for case in range(n_cases):
     n = int(rng.integers(1500, 9000))
@@ -26,7 +28,12 @@ for case in range(n_cases):
                 mg_smoothed_levels=int(rng.choice([0, 1, 1, 2])), mg_dense_max_nodes=int(rng.choice([16, 48, 128])), cg_rel_tolerance=1e-11)
     dist_min = int(rng.choice([1, 1, 200, 8192]))
     dist_setup = int(rng.choice([1, 1, 1, 0]))      # (the multigrid's set-up distributed like its cycle — the default — or rounds 3-5's replicated one)
-    g = graphgen.generate(n, loops, odom_f_max=f, apply_yaw_weight=bool(f == 5), seed=int(rng.integers(1, 10 ** 6)), outlier_frac=float(rng.choice([0.0, 0.1, 0.3])))
+    gseed, gout = int(rng.integers(1, 10 ** 6)), float(rng.choice([0.0, 0.1, 0.3]))
+    if only >= 0 and case != only:      # (python scripts/gpu_ranks_soak.py <cases> <seed> <case> [0|1]: that one case again, the set-up's mode forced)
+        continue
+    if only >= 0 and force_setup >= 0:
+        dist_setup = force_setup
+    g = graphgen.generate(n, loops, odom_f_max=f, apply_yaw_weight=bool(f == 5), seed=gseed, outlier_frac=gout)
     q, t, s = util.initial_state(g, True)
     P = util.pgo_problem(g, True, **opts)
     q1, t1, s1, sum1 = P.solve(q, t, s)

@@ -295,15 +295,19 @@ void launch_mg_assemble_rest(const MgDev& M, const MgLevelDev* levels, const Coa
                              int first_level = 0 /* levels[first_level].val is complete already: its inverses and everything above */);
 // ... and the pieces it is made of, each on the level's set-up share (MgLevelDev::su_*): several ranks run them with block exchanges in between (pgo_solver.hip: build_mg_ranks)
 void launch_mg_level_inverses(const MgLevelDev& A, double omega, int32_t* fail, hipStream_t st);       // Dinv = omega D^-1 and the fp32 copy of the blocks
-void launch_mg_level_power(const MgLevelDev& A, double omega, hipStream_t st);                        // lambda_max(D^-1 A) estimate -> A.xf[0] (a distributed level: of the rank's own diagonal part, a lower bound as well)
+void launch_mg_level_power(const MgLevelDev& A, double omega, hipStream_t st);                        // lambda_max(D^-1 A) estimate of a whole level -> A.xf[0]
+// ... of a distributed level, step by step (the caller exchanges the iterate's halo before every step and all-reduces the sums): start vector on the own rows of A.x (A.xt zeroed),
+// w = D^-1 A v on the own tiles, {|a|^2, |b|^2 over the own rows, failure flag} -> out3, lambda = sqrt(in3[1] / in3[0]) and the flag back
+void launch_mg_power_init(const MgLevelDev& A, hipStream_t st);
+void launch_mg_power_step(const MgLevelDev& A, const double* v, double* w, double omega, hipStream_t st);
+void launch_mg_power_sums(const MgLevelDev& A, const double* a, const double* b, const int32_t* fail, double* out3, hipStream_t st);
+void launch_mg_power_finish(const double* in3, int32_t* fail, double* lam, hipStream_t st);
 void launch_mg_level_rescale(const MgLevelDev& A, const double* lam, double omega, hipStream_t st);    // Dinv scaled down where omega lambda > 1.75
 void launch_mg_transition_ps(const MgLevelDev& A, double prolong_scale, hipStream_t st);              // Ps = (I - c Dinv A) P
 void launch_mg_transition_w(const MgLevelDev& A, hipStream_t st);                                     // W = A Ps, R^T = Ps - Dinv W (both orientations)
 void launch_mg_transition_product(const MgLevelDev& A, const MgLevelDev& B, hipStream_t st);          // B = Ps^T W (several ranks: this rank's rows' part of it)
 void launch_mg_level_galerkin(const MgLevelDev& A, const MgLevelDev& B, hipStream_t st);              // B = P^T A P (plain transition)
 void launch_mg_dense_top(const MgDev& M, const MgLevelDev* levels, const CoarseDev& K, hipStream_t st);
-void launch_mg_pack_flags(const int32_t* fail, const double* lam, double* out2, hipStream_t st);       // out2 = {fail != 0, lambda}: what a distributed level all-reduces (max)
-void launch_mg_unpack_flags(const double* in2, int32_t* fail, double* lam, hipStream_t st);
 // Several ranks: the cycle is cut into segments by the exchanges its kernels need (pgo_solver.hip issues them); launch_mg_apply calls the hook BEFORE the kernel that reads the
 // exchanged vectors.  point: 0 = down-sweep of `level` (1-based; n_levels = the dense solve) is about to read x (and r) of that level, 1 = the up-sweep of `level` is about to
 // read xt of that level (plain transition) or xf of level + 1 (explicit transfer operator), 2 = the prolongation to the keyframes is about to read xf of level 1.

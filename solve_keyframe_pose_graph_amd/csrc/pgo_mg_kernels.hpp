@@ -752,9 +752,10 @@ __global__ __launch_bounds__(256) void mg_rescale_dinv_kernel(MgLevelDev A, cons
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + (int64_t)A.su_row0 * 36;
     if (i < (int64_t)A.su_row1 * 36) A.Dinv[i] *= f;
 }
-// The level's set-up share: on one GPU (and on levels every rank sets up completely) all rows.  A distributed level: the power method runs on the rank's own DIAGONAL part of
-// D^-1 A (entries outside its rows start at zero and stay there) — the largest eigenvalue of a principal part of D^-1/2 A D^-1/2 is a lower bound of the whole matrix's, as the
-// power method's own estimate is; the ranks' estimates are then maximised (pgo_solver.hip) so that all of them rescale alike.
+// The whole level (one GPU, and levels every rank sets up completely).  A distributed level runs the same eight steps on the owners' rows with the halo of the iterate exchanged
+// before every step and the two norms all-reduced (pgo_solver.hip: build_mg_ranks, through the pieces below) — the same estimate up to the order of the sums.  (First tried: every
+// rank on its own diagonal part of D^-1 A, the estimates maximised — a lower bound as well, no exchanges; scripts/gpu_ranks_soak.py case 36 — 6 010 keyframes on 3 ranks by index
+// ranges, two smoothed transitions — then missed a rescaling the whole-level estimate triggers and the PCG broke down on a preconditioner that was not positive definite.)
 void launch_mg_level_power(const MgLevelDev& A, double omega, hipStream_t st) {
     const int n6 = A.n * 6;
     double* v = A.x; double* w = A.xt; double* lam = A.xf;              // the level's cycle vectors are free during the set-up
@@ -797,10 +798,33 @@ void launch_mg_level_galerkin(const MgLevelDev& A, const MgLevelDev& B, hipStrea
     const int64_t cnt = B.su_blk1 - B.su_blk0;
     if (cnt > 0) hipLaunchKernelGGL(mg_galerkin_kernel, dim3((unsigned)((cnt + 3) / 4)), dim3(256), 0, st, A, B);
 }
-__global__ void mg_pack_flags_kernel(const int32_t* __restrict__ fail, const double* __restrict__ lam, double* __restrict__ out2) { out2[0] = *fail != 0 ? 1.0 : 0.0; out2[1] = *lam; }
-__global__ void mg_unpack_flags_kernel(const double* __restrict__ in2, int32_t* __restrict__ fail, double* __restrict__ lam) { if (in2[0] != 0.0) *fail = 1; *lam = in2[1]; }
-void launch_mg_pack_flags(const int32_t* fail, const double* lam, double* out2, hipStream_t st) { hipLaunchKernelGGL(mg_pack_flags_kernel, dim3(1), dim3(1), 0, st, fail, lam, out2); }
-void launch_mg_unpack_flags(const double* in2, int32_t* fail, double* lam, hipStream_t st) { hipLaunchKernelGGL(mg_unpack_flags_kernel, dim3(1), dim3(1), 0, st, in2, fail, lam); }
+// ... step by step, for a distributed level: v = the fixed start vector on the rank's own rows (the formula of the whole-level run: the owners' rows of the same vector), one step
+// w = D^-1 A v on its own tiles (the halo of v exchanged by the caller), this rank's part of the two norms and the level's failure flag, lambda from the all-reduced sums
+void launch_mg_power_init(const MgLevelDev& A, hipStream_t st) {
+    const int n6 = A.n * 6;
+    hipLaunchKernelGGL(mg_power_init_kernel, dim3((unsigned)((n6 + 255) / 256)), dim3(256), 0, st, A.x, A.xt, n6, A.su_row0 * 6, A.su_row1 * 6);
+}
+void launch_mg_power_step(const MgLevelDev& A, const double* v, double* w, double omega, hipStream_t st) {
+    if (A.tiles_own > 0) hipLaunchKernelGGL(mg_smooth_step_kernel, dim3((unsigned)A.tiles_own), dim3(CG_BLOCK), 0, st, A, (const double*)nullptr, v, (double*)nullptr, (const double*)nullptr, (const double*)nullptr, w, -1.0 / omega, (const int32_t*)nullptr);
+}
+__global__ __launch_bounds__(1024) void mg_power_sums_kernel(const double* __restrict__ a, const double* __restrict__ b, int lo6, int hi6, const int32_t* __restrict__ fail, double* __restrict__ out3) {
+    __shared__ double red[32];
+    double sa = 0.0, sb = 0.0;
+    for (int i = lo6 + threadIdx.x; i < hi6; i += blockDim.x) { sa += a[i] * a[i]; sb += b[i] * b[i]; }
+    sa = wave_sum(sa); sb = wave_sum(sb);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = sa; red[16 + (threadIdx.x >> 6)] = sb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ta = 0.0, tb = 0.0;
+        for (int k = 0; k < 16; ++k) { ta += red[k]; tb += red[16 + k]; }
+        out3[0] = ta; out3[1] = tb; out3[2] = *fail != 0 ? 1.0 : 0.0;
+    }
+}
+__global__ void mg_power_finish_kernel(const double* __restrict__ in3, int32_t* __restrict__ fail, double* __restrict__ lam) { if (in3[2] != 0.0) *fail = 1; *lam = in3[0] > 0.0 ? sqrt(in3[1] / in3[0]) : 0.0; }
+void launch_mg_power_sums(const MgLevelDev& A, const double* a, const double* b, const int32_t* fail, double* out3, hipStream_t st) {
+    hipLaunchKernelGGL(mg_power_sums_kernel, dim3(1), dim3(1024), 0, st, a, b, A.su_row0 * 6, A.su_row1 * 6, fail, out3);
+}
+void launch_mg_power_finish(const double* in3, int32_t* fail, double* lam, hipStream_t st) { hipLaunchKernelGGL(mg_power_finish_kernel, dim3(1), dim3(1), 0, st, in3, fail, lam); }
 
 void launch_mg_galerkin0(const GraphDev& G, const LinDev& L, const ScaleDev& Sc, const CgDev& C, const MgDev& M, const MgLevelDev* levels, hipStream_t st, bool hoff_valid) {
     const int64_t cnt = M.g0_slots ? (int64_t)M.n_g0 : levels[0].nnzb;

@@ -2093,8 +2093,8 @@ static int regroup_install(pgo_problem* p) {
 // Several ranks, distributed set-up (round 6): the operators of the current LM system with every DISTRIBUTED level formed by its rows' owners.
 //   level 1:  every rank's part of the Galerkin product from its own edges and owned keyframes (as before), then — instead of the all-reduce of ALL of level 1's blocks — the
 //             parts of the blocks two ranks share go to the ranks that need them (BlockPlan: summed in ascending rank order)
-//   level l distributed:  block-Jacobi inverses, the fp32 copy, the smoother's safety estimate on its own rows (one 2-double max all-reduce: a failed block and the estimate count
-//             for all ranks); a smoothed transition above it: Dinv of the halo rows (the cycle forms x = Dinv r on receipt), Ps on its own rows, the rows of Ps its rows of W = A Ps
+//   level l distributed:  block-Jacobi inverses, the fp32 copy, the smoother's safety estimate (the whole level's eight power steps on the owners' rows: the iterate's halo before
+//             every step, one 3-double all-reduce of the norms and the failure flag — a failed block counts for all ranks); a smoothed transition above it: Dinv of the halo rows (the cycle forms x = Dinv r on receipt), Ps on its own rows, the rows of Ps its rows of W = A Ps
 //             multiply from their owners, W and R^T = Ps - Dinv W on its own rows, the blocks of R whose coarse row is another rank's to that rank, its rows' part of Ps^T W to
 //             the needers; a plain transition: P^T A P on its own rows (children are the parent's rank's), the blocks above the diagonal also to the column's owner
 //   the first level every rank runs completely:  formed like that by its rows' owners, gathered by all; from there on every rank forms the same small levels and the dense inverse
@@ -2109,11 +2109,19 @@ static int build_mg_ranks(pgo_problem* p, double omega, int32_t* fail, bool hoff
         MgLevelDev& A = p->mg_levels[l];
         MgLevelDev& B = p->mg_levels[l + 1];
         launch_mg_level_inverses(A, omega, fail, p->st);
-        launch_mg_level_power(A, omega, p->st);
-        launch_mg_pack_flags(fail, A.xf, p->d_xscal.p + 8, p->st);
-        if (!kernels_only && (rc = allreduce(p, p->d_xscal.p + 8, 2, 2)) != PGO_OK) return rc;
-        launch_mg_unpack_flags(p->d_xscal.p + 8, fail, A.xf, p->st);
-        launch_mg_level_rescale(A, A.xf, omega, p->st);
+        {   // the smoother's safety estimate: the whole level's power method, the iterate's halo exchanged before every step, the norms (and the failure flag) summed over the ranks
+            launch_mg_power_init(A, p->st);
+            double* v = A.x; double* w = A.xt;
+            for (int it = 0; it < 8; ++it) {
+                if (!kernels_only && (rc = exchange_level(p, l, v, nullptr, nullptr, nullptr)) != PGO_OK) return rc;
+                launch_mg_power_step(A, v, w, omega, p->st);
+                std::swap(v, w);
+            }
+            launch_mg_power_sums(A, w, v, fail, p->d_xscal.p + 8, p->st);      // (v: 8 steps, w: 7 steps)
+            if (!kernels_only && (rc = allreduce(p, p->d_xscal.p + 8, 3, 0)) != PGO_OK) return rc;
+            launch_mg_power_finish(p->d_xscal.p + 8, fail, A.xf, p->st);
+            launch_mg_level_rescale(A, A.xf, omega, p->st);
+        }
         if (A.smoothed) {
             const pgo_problem::LevelPlanDev& LP = p->lvl_plan[(size_t)l];
             if (!kernels_only && LP.plan && (rc = exchange_blocks_copy(p, *LP.plan, LP.send_idx, LP.recv_idx, A.Dinv, 36)) != PGO_OK) return rc;
@@ -3195,7 +3203,8 @@ int pgo_get_sharding_stats(pgo_problem* p, pgo_sharding_stats* out) {
             auto add = [&](const pgo_mg::ExchangePlan& X, double bytes_per_row) { if (!plan_is_empty(X)) { sb += (double)X.n_send() * bytes_per_row; ++nx; } };
             for (const pgo_mg::BlockPlan& B : p->mg_setup.val) add(B.x, 288.0);
             for (int l = 0; l < fw; ++l) {
-                ++nx; sb += 16.0;      // the level's 2-double all-reduce
+                nx += 9; sb += 24.0;      // the level's power method: eight halo exchanges of the iterate + the 3-double all-reduce
+                if ((size_t)l < p->lvl_plan.size() && p->lvl_plan[(size_t)l].plan) sb += 8.0 * (double)p->lvl_plan[(size_t)l].plan->n_send() * 48.0;
                 if (!p->mg_levels[l].smoothed) continue;
                 if ((size_t)l < p->lvl_plan.size() && p->lvl_plan[(size_t)l].plan) add(*p->lvl_plan[(size_t)l].plan, 288.0);
                 add(p->mg_setup.ps[(size_t)l], 288.0); add(p->mg_setup.rv[(size_t)l], 144.0);

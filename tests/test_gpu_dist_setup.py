@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
     (6000, 3, 300, 1, "spatial", 2),      # one distributed level with a smoothed transition above it, the level above gathered
     (12000, 5, 64, 2, "spatial", 2),      # two distributed levels, both transitions smoothed
     (6000, 4, 1, 0, "spatial", 2),        # plain transitions only (what graphs beyond 500 000 keyframes get: BASELINE config 5)
-    (12000, 5, 64, 1, "spatial", 5),      # f = 1..5 + yaw weights: the smoother's safety rescaling triggers (estimated per rank, maximised: a few percent off the replicated estimate)
+    (12000, 5, 64, 1, "spatial", 5),      # f = 1..5 + yaw weights: the smoother's safety rescaling triggers (the distributed power method: the iterate's halo exchanged before every step)
     (6000, 3, 300, 1, "chain", 2),        # a partition by index ranges: loop closures cross ranks
 ])
 def test_distributed_setup_forms_the_same_operators(n, world, dist_min, smoothed, policy, f):
