@@ -109,9 +109,11 @@ int main(int argc, char** argv) {
     for (int k = 0; k < one.num_logged && same; ++k) same = one.iterations[k].step_is_successful == many.iterations[k].step_is_successful;
     std::printf("%lld keyframes / %lld edges: single handle %d LM iterations, cost %.9e, %lld PCG iterations | %d ranks: %d LM iterations, cost %.9e, %lld PCG iterations, decisions %s, "
                 "max position difference %.2e m | rank 0: %lld of %lld keyframes local, %lld shared; %d of %d multigrid levels distributed; %.0f B sent per multigrid iteration "
-                "(the union all-reduce of earlier rounds: %.0f B), %d exchanges per iteration\n",
+                "(the union all-reduce of earlier rounds: %.0f B), %d exchanges per iteration; multigrid set-up: %d level(s) formed by their rows' owners, this rank forms %lld of %lld blocks "
+                "and sends %.0f B per set-up (the replicated set-up all-reduces %.0f B)\n",
                 (long long)g.n, (long long)(g.n_odom + g.n_loops), one.num_iterations, one.final_cost, (long long)one.cg_iterations, world, many.num_iterations, many.final_cost,
                 (long long)many.cg_iterations, same ? "equal" : "DIFFERENT", dt, (long long)st.keyframes_local, (long long)g.n, (long long)st.keyframes_shared, st.mg_levels_distributed, st.mg_levels,
-                st.bytes_sent_per_mg_iteration, st.bytes_round5_per_mg_iteration, st.exchanges_per_mg_iteration);
+                st.bytes_sent_per_mg_iteration, st.bytes_round5_per_mg_iteration, st.exchanges_per_mg_iteration, st.mg_setup_levels_own_rows, (long long)st.mg_setup_blocks_own,
+                (long long)st.mg_setup_blocks_total, st.bytes_sent_per_mg_setup, st.bytes_allreduce_replicated_setup);
     return same && std::fabs(many.final_cost - one.final_cost) <= 1e-6 * one.final_cost ? 0 : 1;
 }

@@ -56,3 +56,49 @@ def test_setup_counters_on_a_sharded_graph():
         assert st["mg_setup_blocks_own"] < 0.6 * st["mg_setup_blocks_total"]
         assert 0 < st["bytes_sent_per_mg_setup"] < st["bytes_allreduce_replicated_setup"]
         assert st["mg_setup_exchanges"] >= 3
+
+
+def test_setup_kernels_can_be_timed_alone_on_one_handle_and_on_ranks():
+    """pgo_time_kernel(8): the kernels of one multigrid set-up — on ranks every rank's own, without the exchanges (the ranks take turns on the GPU), after which the operators are
+    formed again properly: the solve that follows takes the decisions of the single handle"""
+    import threading
+
+    from solve_keyframe_pose_graph_amd import capi, graphgen, sharding
+    from tests import util
+    g = graphgen.generate(12000, 12000, odom_f_max=2, seed=3)
+    q, t, s = util.initial_state(g, True)
+    opts = dict(mg_min_keyframes=1000, mg_min_keyframes_switchable=1000, mg_switch_iterations=0, mg_smoothed_fine=0, max_num_iterations=4)
+    P = util.pgo_problem(g, True, **opts)
+    P.solve_begin(q, t, s)
+    ms1, _ = P.time_kernel(8, 5)
+    P.solve_end()
+    _, _, _, sum1 = P.solve(q, t, s)
+    with pytest.raises(capi.PgoError):
+        P.mg_level_norms(99)
+    P.close()
+    assert 0.05 < ms1 < 50.0
+    world = 3
+    parts = sharding.partition(g, world, "spatial")
+    group = capi.local_group_create(world)
+    out, err = [None] * world, []
+
+    def run(rank):
+        try:
+            Pr = capi.problem_from_graph(g, switchable=True, edge_slice=parts[rank], mg_dist_min_rows=200, **opts)
+            Pr.comm_init_local(rank, world, group)
+            Pr.solve_begin(q, t, s)
+            ms, _ = Pr.time_kernel(8, 5)
+            Pr.solve_end()
+            res = Pr.solve(q, t, s)
+            out[rank] = (ms, res[3], Pr.sharding_stats().as_dict())
+            Pr.comm_destroy(); Pr.close()
+        except Exception as e:   # noqa: BLE001
+            err.append(repr(e)); capi.local_group_abort(group)
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [x.start() for x in th]; [x.join() for x in th]
+    capi.local_group_destroy(group)
+    assert not err, err
+    for ms, summ, st in out:
+        assert 0.05 < ms < 50.0 and st["mg_setup_levels_own_rows"] >= 1
+        assert [summ.iterations[k].step_is_successful for k in range(summ.num_logged)] == [sum1.iterations[k].step_is_successful for k in range(sum1.num_logged)]
+        assert abs(summ.final_cost - sum1.final_cost) <= 1e-7 * sum1.final_cost
