@@ -854,6 +854,7 @@ inline void build_setup_plans(const Hierarchy& H, int rank, int world, const std
     S = SetupPlans{};
     const int nl = (int)H.L.size();
     if (world <= 1 || H.world != world || nl < 2 || !H.L[0].distributed) return;
+    PGO_MG_T0();
     int fw = 0;
     while (fw < nl && H.L[(size_t)fw].distributed) ++fw;
     S.first_whole = fw;
@@ -878,30 +879,44 @@ inline void build_setup_plans(const Hierarchy& H, int rank, int world, const std
         cm.assign(A.col.size(), 0);
         if (l == 0) {
             for (int32_t a = 0; a < A.n; ++a) cm[(size_t)A.rowptr[(size_t)a]] |= 1ull << ow[(size_t)a];      // the keyframes' own (summed) diagonal blocks: their owner
+            // (config 5: 3 M edges, two block look-ups each — spread over the host threads; the masks are OR-ed atomically, the result does not depend on the thread count)
             auto edges = [&](const std::vector<int32_t>& c1, const std::vector<int32_t>& c2, const std::vector<int64_t>& off) {
-                for (int r = 0; r < world; ++r) for (int64_t e = off[(size_t)r]; e < off[(size_t)r + 1]; ++e) {
-                    const int32_t a = H.agg0[(size_t)c1[(size_t)e]], b = H.agg0[(size_t)c2[(size_t)e]];
-                    if (a < 0 || b < 0) continue;
-                    const int64_t k1 = find_block(A, a, b), k2 = find_block(A, b, a);
-                    if (k1 >= 0) cm[(size_t)k1] |= 1ull << r;
-                    if (k2 >= 0) cm[(size_t)k2] |= 1ull << r;
-                }
+                const int64_t E = off[(size_t)world];
+                if (E > 0x7fffffffll) return;
+                parallel_ranges((int32_t)E, host_threads(), [&](int, int32_t lo, int32_t hi) {
+                    int r = (int)(std::upper_bound(off.begin(), off.end(), (int64_t)lo) - off.begin()) - 1;
+                    for (int64_t e = lo; e < hi; ++e) {
+                        while (r + 1 < world && e >= off[(size_t)r + 1]) ++r;
+                        const int32_t a = H.agg0[(size_t)c1[(size_t)e]], b = H.agg0[(size_t)c2[(size_t)e]];
+                        if (a < 0 || b < 0) continue;
+                        const int64_t k1 = find_block(A, a, b), k2 = find_block(A, b, a);
+                        if (k1 >= 0) __atomic_fetch_or(&cm[(size_t)k1], 1ull << r, __ATOMIC_RELAXED);
+                        if (k2 >= 0) __atomic_fetch_or(&cm[(size_t)k2], 1ull << r, __ATOMIC_RELAXED);
+                    }
+                });
             };
             edges(rc1, rc2, rel_off); edges(sc1, sc2, sw_off);
+            PGO_MG_T("set-up plans: level-1 contributors");
         } else {
             const HostLevel& Lo = H.L[(size_t)l - 1];
             const std::vector<int32_t>& olo = own[(size_t)l - 1];
             if (!Lo.smoothed) { for (int32_t a = 0; a < A.n; ++a) for (int64_t k = A.rowptr[(size_t)a]; k < A.rowptr[(size_t)a + 1]; ++k) cm[(size_t)k] = 1ull << ow[(size_t)a]; }
             else {
+                // the symbolic product Ps^T W row by row (C3 on 4 ranks: 1.3 M block look-ups in rows of ~50), spread over the host threads; atomic ORs: the same masks whatever the thread count
                 std::vector<uint8_t> mine(A.col.size(), 0);
-                for (int32_t i = 0; i < Lo.n; ++i) {
-                    const uint64_t bit = 1ull << olo[(size_t)i];
-                    for (int32_t pk = Lo.ps_rowptr[(size_t)i]; pk < Lo.ps_rowptr[(size_t)i + 1]; ++pk)
-                        for (int32_t wk = Lo.w_rowptr[(size_t)i]; wk < Lo.w_rowptr[(size_t)i + 1]; ++wk) {
-                            const int64_t k = find_block(A, Lo.ps_col[(size_t)pk], Lo.w_col[(size_t)wk]);
-                            if (k >= 0) { cm[(size_t)k] |= bit; if (olo[(size_t)i] == rank) mine[(size_t)k] = 1; }
-                        }
-                }
+                parallel_ranges(Lo.n, host_threads(), [&](int, int32_t lo, int32_t hi) {
+                    for (int32_t i = lo; i < hi; ++i) {
+                        const uint64_t bit = 1ull << olo[(size_t)i];
+                        const bool me = olo[(size_t)i] == rank;
+                        for (int32_t pk = Lo.ps_rowptr[(size_t)i]; pk < Lo.ps_rowptr[(size_t)i + 1]; ++pk)
+                            for (int32_t wk = Lo.w_rowptr[(size_t)i]; wk < Lo.w_rowptr[(size_t)i + 1]; ++wk) {
+                                const int64_t k = find_block(A, Lo.ps_col[(size_t)pk], Lo.w_col[(size_t)wk]);
+                                if (k < 0) continue;
+                                if (!(__atomic_load_n(&cm[(size_t)k], __ATOMIC_RELAXED) & bit)) __atomic_fetch_or(&cm[(size_t)k], bit, __ATOMIC_RELAXED);
+                                if (me) __atomic_store_n(&mine[(size_t)k], (uint8_t)1, __ATOMIC_RELAXED);
+                            }
+                    }
+                });
                 for (size_t k = 0; k < mine.size(); ++k) if (mine[k]) S.prod[(size_t)l - 1].push_back((int32_t)k);
             }
         }
@@ -915,6 +930,7 @@ inline void build_setup_plans(const Hierarchy& H, int rank, int world, const std
             slot.push_back((int32_t)k); cb.push_back(c); nd.push_back(need);
         }
         block_plan(slot, cb, nd, rank, world, S.val[(size_t)l]);
+        PGO_MG_T("set-up plans: a level's blocks");
         if (l == fw || !A.smoothed) continue;
         // smoothed transition above level l: rows of Ps the rank's rows of W read; blocks of R whose coarse row is another rank's
         std::vector<uint64_t> need_row((size_t)A.n, 0);
@@ -932,6 +948,7 @@ inline void build_setup_plans(const Hierarchy& H, int rank, int world, const std
             if (prov != q) keys.push_back(((uint64_t)(q * world + prov) << 32) | (uint32_t)A.rT_of_w[(size_t)wk]);
         }
         plan_from_keys(keys, world, rank, S.rv[(size_t)l]);
+        PGO_MG_T("set-up plans: Ps and R of a level");
     }
 }
 
