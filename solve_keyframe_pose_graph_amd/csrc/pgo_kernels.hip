@@ -1907,7 +1907,7 @@ __global__ void sum_rows_kernel(const double* __restrict__ buf, double* __restri
     *mine = s;
 }
 // scatter of a level's residual rows with the pre-smoothed x of the same rows formed on the spot: x = (omega D^-1) r is pointwise, and every rank holds every level's Dinv
-// (the set-up is the same on all ranks) — so only r travels (half the bytes of sending both); the same six products in the same order as the kernel that owns the row
+// (the set-up has brought the halo rows' Dinv in: pgo_solver.hip, build_mg_ranks) — so only r travels (half the bytes of sending both); the same six products in the same order as the kernel that owns the row
 __global__ void scatter_rows_dinv_kernel(const double* __restrict__ buf, double* __restrict__ r, double* __restrict__ x, const double* __restrict__ Dinv, int64_t n,
                                          const int32_t* __restrict__ idx, const int32_t* __restrict__ stop) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -238,8 +238,8 @@ inline void build_blocks(int32_t n, std::vector<std::pair<int64_t, int64_t>>& tr
 
 // Several ranks (edge sharding): the hierarchy is built from the GLOBAL graph — every rank gathers the endpoints and weights of all edges and builds the
 // same levels — while the contributions a rank adds to level 1's Galerkin product are its OWN: the diagonal blocks of the keyframes it owns and its own
-// edges, both in the handle's rank-local numbering (the device kernel indexes the rank-local arrays).  The ranks' partial level-1 blocks are summed by an
-// all-reduce; everything above level 1 is replicated.
+// edges, both in the handle's rank-local numbering (the device kernel indexes the rank-local arrays).  The ranks' parts of a level-1 block are summed where the
+// block is needed (build_setup_plans below: the distributed set-up; with pgo_options.mg_dist_setup = 0 by an all-reduce of all blocks, everything above level 1 then formed by every rank).
 struct LocalContrib {
     const std::vector<int32_t>* l2g;          // local keyframe -> global keyframe
     const std::vector<double>* own;           // [N_local] 1.0 where this rank contributes the keyframe's (already summed) diagonal block

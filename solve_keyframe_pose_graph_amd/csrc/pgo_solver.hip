@@ -174,7 +174,6 @@ struct pgo_problem {
     struct SetupPlanDev { const int32_t* val_send = nullptr; const int32_t* val_dst = nullptr; const int32_t* val_sum_ptr = nullptr; const int32_t* val_sum_src = nullptr;
                           const int32_t* ps_send = nullptr; const int32_t* ps_recv = nullptr; const int32_t* rv_send = nullptr; const int32_t* rv_recv = nullptr; };
     std::vector<SetupPlanDev> su_plan;
-    double st_setup_bytes = 0.0; int64_t st_setup_exchanges = 0, st_setups = 0;      // (accounting: block exchanges of the set-ups)
     struct OwnRange { int64_t row0 = 0, row1 = 0, blk0 = 0, blk1 = 0, ps0 = 0, ps1 = 0, w0 = 0, w1 = 0, rT0 = 0, rT1 = 0; };      // this rank's rows of every level and the block ranges they span (one GPU, and levels every rank runs completely: everything)
     std::vector<OwnRange> mg_own;
     int mg_levels_distributed = 0; int64_t mg_rows_total = 0, mg_rows_own = 0, mg_blocks_total = 0, mg_blocks_own = 0;
@@ -458,11 +457,26 @@ int mg_prepare_impl(pgo_problem* p, const double* sw_now, MgPrepared& Q) {
         pgo_mg::Owners OW; OW.touch_mask = &p->h_touch_mask; OW.owner = &p->h_owner; OW.world = p->world; OW.dist_min_rows = p->opt.mg_dist_min_rows > 0 ? p->opt.mg_dist_min_rows : 8192;
         ok = pgo_mg::build_hierarchy(Ng, gfree, grc1, grc2, grw.data(), 1, gsc1, gsc2, (sw_now && S > 0) ? gsw.data() : nullptr, passes0, passes, dense_max, MG_TILE_ROWS, MG_MAX_LEVELS, H, false, 0, &local, n_smoothed, loop_discount, &p->mg_cache,
                                      nullptr, nullptr, p->world > 1 ? &OW : nullptr);
-        if (ok && p->world > 1) pgo_mg::build_level_plans(H, OW, p->rank, Q.plans);
-        if (ok && p->world > 1 && p->opt.mg_dist_setup != 0) {      // the set-up distributed like the cycle: who contributes to / needs which blocks (the gathered edge lists are rank by rank)
+        if (ok && p->world > 1) {
+            // the cycle's plans, and beside them on a thread of its own — the two read the finished hierarchy and write their own results — the set-up's (the set-up distributed
+            // like the cycle: who contributes to / needs which blocks; the gathered edge lists are rank by rank)
+            const bool want_setup = p->opt.mg_dist_setup != 0;
             std::vector<int64_t> rel_off((size_t)p->world + 1, 0), sw_off((size_t)p->world + 1, 0);
             for (int r = 0; r < p->world; ++r) { rel_off[(size_t)r + 1] = rel_off[(size_t)r] + (int64_t)(cnt[(size_t)2 * r] + 0.5); sw_off[(size_t)r + 1] = sw_off[(size_t)r] + (int64_t)(cnt[(size_t)2 * r + 1] + 0.5); }
-            pgo_mg::build_setup_plans(H, p->rank, p->world, grc1, grc2, rel_off, gsc1, gsc2, sw_off, Q.setup);
+            const bool tm = pgo_mg::timing();
+            std::atomic<bool> worker_failed{false};      // (declared before the thread and its joiner: destroyed after them)
+            std::thread worker;
+            struct Join { std::thread& t; ~Join() { if (t.joinable()) t.join(); } } join_worker{worker};
+            bool started = false;
+            if (want_setup && pgo_mg::host_threads() > 1) {
+                try {
+                    worker = std::thread([&]() { try { pgo_mg::timing() = tm; pgo_mg::build_setup_plans(H, p->rank, p->world, grc1, grc2, rel_off, gsc1, gsc2, sw_off, Q.setup); } catch (...) { worker_failed.store(true); } });
+                    started = true;
+                } catch (...) {}
+            }
+            pgo_mg::build_level_plans(H, OW, p->rank, Q.plans);
+            if (started) { worker.join(); if (worker_failed.load()) throw std::bad_alloc(); }
+            else if (want_setup) pgo_mg::build_setup_plans(H, p->rank, p->world, grc1, grc2, rel_off, gsc1, gsc2, sw_off, Q.setup);
         }
         if (ok) {
             const int32_t n1g = (int32_t)H.mem0_ptr.size() - 1;
@@ -1465,7 +1479,6 @@ int exchange_blocks_copy(pgo_problem* p, const pgo_mg::ExchangePlan& X, const in
     launch_gather_rows(sb, arr, K, nullptr, 0, X.n_send(), send_idx, nullptr, p->st);
     if ((rc = neighbor_exchange(p, X, K, sb, p->d_xrecv.p)) != PGO_OK) return rc;
     launch_scatter_rows(p->d_xrecv.p, arr, K, nullptr, 0, X.n_recv(), recv_idx, nullptr, p->st);
-    ++p->st_setup_exchanges; p->st_setup_bytes += (double)X.n_send() * K * sizeof(double);
     return PGO_OK;
 }
 int exchange_blocks_sum(pgo_problem* p, const pgo_mg::BlockPlan& B, const pgo_problem::SetupPlanDev& D, double* arr) {
@@ -1476,7 +1489,6 @@ int exchange_blocks_sum(pgo_problem* p, const pgo_mg::BlockPlan& B, const pgo_pr
     launch_gather_rows(sb, arr, 36, nullptr, 0, B.x.n_send(), D.val_send, nullptr, p->st);
     if ((rc = neighbor_exchange(p, B.x, 36, sb, p->d_xrecv.p)) != PGO_OK) return rc;
     launch_sum_rows(p->d_xrecv.p, arr, 36, nullptr, 0, (int64_t)B.dst.size(), D.val_dst, D.val_sum_ptr, D.val_sum_src, nullptr, p->st);
-    ++p->st_setup_exchanges; p->st_setup_bytes += (double)B.x.n_send() * 36 * sizeof(double);
     return PGO_OK;
 }
 // all-reduce of a host vector (graph build: rare, sizes up to a few tens of MB)
@@ -2102,7 +2114,6 @@ static int regroup_install(pgo_problem* p) {
 static int build_mg_ranks(pgo_problem* p, double omega, int32_t* fail, bool hoff_valid, bool kernels_only = false /* pgo_time_kernel(8): this rank's kernels without the exchanges (the numbers are then meaningless) */) {
     const int fw = p->mg_first_whole;
     int rc;
-    if (!kernels_only) ++p->st_setups;
     launch_mg_galerkin0(p->G, p->L, p->Sc, p->C, p->M, p->mg_levels, p->st, hoff_valid);
     if (!kernels_only && (rc = exchange_blocks_sum(p, p->mg_setup.val[0], p->su_plan[0], p->mg_levels[0].val)) != PGO_OK) return rc;
     for (int l = 0; l < fw; ++l) {
