@@ -102,3 +102,46 @@ def test_setup_kernels_can_be_timed_alone_on_one_handle_and_on_ranks():
         assert 0.05 < ms < 50.0 and st["mg_setup_levels_own_rows"] >= 1
         assert [summ.iterations[k].step_is_successful for k in range(summ.num_logged)] == [sum1.iterations[k].step_is_successful for k in range(sum1.num_logged)]
         assert abs(summ.final_cost - sum1.final_cost) <= 1e-7 * sum1.final_cost
+
+
+@pytest.mark.parametrize("transport", ["custom", "custom+exchange"])
+def test_distributed_setup_through_a_caller_supplied_collective(transport):
+    """the set-up's block exchanges through pgo_comm_init_custom: with an exchange callback (all-to-all-v semantics), and without one — the library then emulates every exchange by an
+    all-reduce of a zero-padded buffer (also the fp32 blocks of R, which travel as raw bytes: adding zeros to a finite double changes nothing).  Same bits as the in-process
+    communicator's solve: the parts of a block are added in rank order on the device whatever carried them."""
+    import threading
+
+    import numpy as np
+
+    from solve_keyframe_pose_graph_amd import capi, graphgen, sharding
+    from tests import util
+    from tests.test_gpu_two_ranks_one_gpu import InProcessAllReduce
+    g = graphgen.generate(6000, 3000, odom_f_max=2, seed=5)
+    q, t, s = util.initial_state(g, True)
+    world = 3
+    parts = sharding.partition(g, world, "spatial")
+    opts = dict(mg_min_keyframes=1000, mg_min_keyframes_switchable=1000, mg_switch_iterations=0, mg_smoothed_fine=0, mg_smoothed_levels=1, mg_dist_min_rows=100, max_num_iterations=5)
+
+    def solve(tr):
+        ar = InProcessAllReduce(world, tr)
+        out, err = [None] * world, []
+
+        def run(rank):
+            try:
+                P = capi.problem_from_graph(g, switchable=True, edge_slice=parts[rank], **opts)
+                ar.attach(P, rank)
+                res = P.solve(q, t, s)
+                out[rank] = (res, P.sharding_stats().as_dict())
+                P.comm_destroy(); P.close()
+            except Exception as e:   # noqa: BLE001
+                err.append(repr(e)); ar.barrier.abort()
+        th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        [x.start() for x in th]; [x.join() for x in th]
+        ar.close()
+        assert not err, err
+        return out
+    A, B = solve(transport), solve("local")
+    assert A[0][1]["mg_setup_levels_own_rows"] >= 1 and A[0][1]["mg_setup_exchanges"] >= 10
+    for r in range(world):
+        assert np.array_equal(A[r][0][1], B[0][0][1]) and np.array_equal(A[r][0][2], B[0][0][2]) and np.array_equal(A[r][0][0], B[0][0][0])
+        assert A[r][0][3].cg_iterations == B[0][0][3].cg_iterations and A[r][0][3].pcg_retries == 0
