@@ -5,7 +5,9 @@
 // the GPUs of a node without MPI / torch.distributed.  (One process per GPU over RCCL: pgo_comm_get_unique_id + pgo_comm_init, same calls otherwise.)
 // Build: solve_keyframe_pose_graph_amd/_build.py::build_examples (g++, links libpgo.so + libpgo_graphgen.so).
 //
-//   ranks_in_process [n_poses = 20000] [ranks = 4] [n_gpus = 1]
+//   ranks_in_process [n_poses = 20000] [ranks = 4] [n_gpus = 1] [mg_dist_min_rows = 1000]
+// (mg_dist_min_rows: the library's default, 8 192, distributes multigrid levels of graphs from ~70 000 keyframes on; the smaller value lets this 20 000-keyframe demonstration run the
+// distributed cycle and set-up — every rank its own rows of level 1 — instead of every level completely on every rank)
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -21,7 +23,7 @@ struct Graph {
     std::vector<int32_t> oc1, oc2, lc1, lc2, reg_node;
 };
 
-static int solve_ranks(const Graph& g, int world, int n_gpus, std::vector<double>& q, std::vector<double>& t, std::vector<double>& s, pgo_summary* summary, pgo_sharding_stats* stats) {
+static int solve_ranks(const Graph& g, int world, int n_gpus, int dist_min_rows, std::vector<double>& q, std::vector<double>& t, std::vector<double>& s, pgo_summary* summary, pgo_sharding_stats* stats) {
     // which rank gets which residual block: recursive coordinate bisection of the keyframe positions, an edge follows its later endpoint
     std::vector<int32_t> part((size_t)g.n), orank((size_t)g.n_odom), lrank((size_t)g.n_loops);
     if (pgo_partition_edges(PGO_PARTITION_SPATIAL, world, g.n, g.t.data(), g.n_odom, g.oc1.data(), g.oc2.data(), g.n_loops, g.lc1.data(), g.lc2.data(), part.data(), orank.data(), lrank.data()) != PGO_OK) return 1;
@@ -35,6 +37,7 @@ static int solve_ranks(const Graph& g, int world, int n_gpus, std::vector<double
         pgo_options o;
         pgo_options_init(&o);
         o.device_id = n_gpus > 1 ? r % n_gpus : -1;
+        o.mg_dist_min_rows = dist_min_rows;
         pgo_problem* p = nullptr;
         if ((rc[(size_t)r] = pgo_create(&p, &o)) != PGO_OK) { pgo_local_group_abort(group); return; }
         auto fail = [&](int code) { rc[(size_t)r] = code; std::fprintf(stderr, "rank %d: %s — %s\n", r, pgo_strerror(code), pgo_last_error(p)); pgo_local_group_abort(group); };
@@ -69,6 +72,7 @@ int main(int argc, char** argv) {
     const int64_t n_poses = argc > 1 ? std::atoll(argv[1]) : 20000;
     const int world = argc > 2 ? std::atoi(argv[2]) : 4;
     const int n_gpus = argc > 3 ? std::atoi(argv[3]) : 1;
+    const int dist_min_rows = argc > 4 ? std::atoi(argv[4]) : 1000;
     if (pgo_abi_version() != PGO_ABI_VERSION) { std::fprintf(stderr, "libpgo.so speaks ABI %d, this program was compiled against %d\n", pgo_abi_version(), PGO_ABI_VERSION); return 1; }
     pgo_gen_config c;
     pgo_gen_config_init(&c);
@@ -102,7 +106,7 @@ int main(int argc, char** argv) {
 
     std::vector<double> qr, tr, sr;
     pgo_summary many; pgo_sharding_stats st;
-    if (solve_ranks(g, world, n_gpus, qr, tr, sr, &many, &st) != 0) return 1;
+    if (solve_ranks(g, world, n_gpus, dist_min_rows, qr, tr, sr, &many, &st) != 0) return 1;
     double dt = 0.0;
     for (size_t i = 0; i < tr.size(); ++i) dt = std::fmax(dt, std::fabs(tr[i] - t1[i]));
     bool same = one.num_iterations == many.num_iterations;
