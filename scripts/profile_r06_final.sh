@@ -72,6 +72,7 @@ python scripts/gpu_ranks_counters.py C5 8 2 > $OUT/r06_ranks_c5x8.json 2> $OUT/r
 python scripts/gpu_ranks_counters.py C3 8 10 > $OUT/r06_ranks_c3x8.json 2> $OUT/ranks_c3x8.err
 python scripts/gpu_ranks_counters.py C5 8 6 > $OUT/r06_ranks_c5x8_after_regroup.json 2> $OUT/ranks_c5x8_after_regroup.err      # (6 LM iterations: past the regroup inside the solve — another hierarchy: 4 distributed levels)
 timeout 900 python scripts/gpu_dist_setup_check.py > $OUT/r06_dist_setup_check.txt 2>&1 < /dev/null; stamp $OUT/r06_dist_setup_check.txt
+trace setup_ranks r06_dist_setup_kernel_stats.txt python scripts/dev/setup_kernels_ranks.py C5 8 1      # the set-up's kernels per rank (config 5 on 8 in-process ranks)
 python scripts/dev/verbose_solve.py C3 2 2>&1 | grep "build_graph\|hierarchy (host)" > $OUT/r06_build_phases.txt; stamp $OUT/r06_build_phases.txt
 python scripts/gpu_all_configs.py > $OUT/r06_all_configs.txt 2>&1; stamp $OUT/r06_all_configs.txt
 python scripts/gpu_mg_graph_types.py 20 > $OUT/r06_mg_graph_types.txt 2>&1; stamp $OUT/r06_mg_graph_types.txt
