@@ -9,7 +9,7 @@
   * per rank: the kernels of ONE multigrid set-up (pgo_time_kernel(8): level operators + dense inverse, no exchanges, ranks taking turns) with the distributed set-up
     (mg_dist_setup = 1) and with the replicated one (= 0: every rank forms every level), the blocks it forms and the bytes its block exchanges send per set-up.
 
-  python scripts/gpu_ranks_counters.py C3 4 [lm_iterations] [policy]      ->  one JSON line on stdout (and on stderr the library's hierarchy log of rank 0)"""
+  python scripts/gpu_ranks_counters.py C3 4 [lm_iterations] [policy] [option=value,...]      ->  one JSON line on stdout (and on stderr the library's hierarchy log of rank 0)"""
 import json
 import sys
 import threading
@@ -27,9 +27,10 @@ def main():
     world = int(sys.argv[2]) if len(sys.argv) > 2 else 4
     n_it = int(sys.argv[3]) if len(sys.argv) > 3 else 10
     policy = sys.argv[4] if len(sys.argv) > 4 else "spatial"
+    extra = dict((k, int(v)) for k, v in (kv.split("=") for kv in sys.argv[5].split(","))) if len(sys.argv) > 5 and sys.argv[5] else {}      # e.g. mg_dist_min_rows=16384 (integer options)
     g = graphgen.config(name)
     q, t, s = util.initial_state(g, True)
-    opts = dict(max_num_iterations=n_it)
+    opts = dict(max_num_iterations=n_it, **extra)
     # ---- the single handle
     P = util.pgo_problem(g, True, **opts)
     t0 = time.time()
@@ -101,7 +102,7 @@ def main():
     seq1 = [sum1.iterations[k].step_is_successful for k in range(sum1.num_logged)]
     seqr = [sumr.iterations[k].step_is_successful for k in range(sumr.num_logged)]
     rec = {
-        "what": "in-process ranks on ONE MI355X (pgo_comm_init_local); nothing here is a multi-GPU timing", "config": name, "world": world, "policy": policy, "lm_iterations": n_it,
+        "what": "in-process ranks on ONE MI355X (pgo_comm_init_local); nothing here is a multi-GPU timing", "config": name, "world": world, "policy": policy, "lm_iterations": n_it, "options": extra,
         "partition": pst,
         "decisions_equal": seq1 == seqr, "cost_rel_diff_max": max(abs(sumr.iterations[k].cost - sum1.iterations[k].cost) / sum1.iterations[k].cost for k in range(sum1.num_logged)),
         "pcg_iterations_single": int(sum1.cg_iterations), "pcg_iterations_ranks": int(sumr.cg_iterations), "pcg_ratio": sumr.cg_iterations / max(1, sum1.cg_iterations),
