@@ -189,6 +189,8 @@ def main():
                          "(host staging; lets several ranks share one GPU to validate the multi-rank path on a 1-GPU box)")
     ap.add_argument("--exchange-via-allreduce", action="store_true", help="several ranks: route the neighbour exchanges through all-reduces of zero-padded buffers instead of ncclSend / ncclRecv (PGO_EXCHANGE_VIA_ALLREDUCE=1: the safety net for a node where RCCL's point-to-point path misbehaves; moves world x the bytes)")
     ap.add_argument("--no-ceres-rule", action="store_true", help="skip the untimed leg that repeats the K iterations with the early-rejection pauses off (Ceres' exact decision rule)")
+    ap.add_argument("--mg-dist-min-rows", type=int, default=None, help="several ranks: pgo_options.mg_dist_min_rows (library default 8192) — multigrid levels with at least this many rows are distributed; the knob to tune on a real node (DESIGN.md section 8)")
+    ap.add_argument("--mg-dist-setup", type=int, default=None, choices=[0, 1], help="several ranks: pgo_options.mg_dist_setup (library default 1: the multigrid's set-up distributed like its cycle; 0: rounds 3-5's replicated set-up)")
     ap.add_argument("--partition", choices=["spatial", "chain", "contiguous"], default="spatial", help="how edges are dealt out to the ranks (solve_keyframe_pose_graph_amd/sharding.py)")
     ap.add_argument("--no-c5-strong", action="store_true", help="several ranks, default config: skip the extra BASELINE-config-5 leg (1M poses / 3M edges sharded over the ranks) that is appended as `c5_strong`")
     ap.add_argument("--c5-timeout", type=int, default=300, help="watchdog of that leg, seconds")
@@ -254,6 +256,10 @@ def main():
             shard_stats = sharding.partition_stats(g, parts)
 
     opt = {}
+    if args.mg_dist_min_rows is not None:
+        opt["mg_dist_min_rows"] = args.mg_dist_min_rows
+    if args.mg_dist_setup is not None:
+        opt["mg_dist_setup"] = args.mg_dist_setup
     if args.cg_tol is not None:
         opt["cg_rel_tolerance"] = args.cg_tol
     if args.cg_max is not None:
@@ -560,7 +566,7 @@ def main():
                                                                        % (args.partition, min(shard_stats["edges_per_rank"]), max(shard_stats["edges_per_rank"]), min(shard_stats["keyframes_per_rank"]), max(shard_stats["keyframes_per_rank"]),
                                                                           shard_stats["shared_keyframes"], g.n_poses, args.collective)) if world > 1 else "single GPU",
                        "linear_solver": "PCG on the Schur-reduced pose system, %s matvec; 6x6 block-Jacobi, hard LM systems by the aggregation multigrid (hybrid start)" % ("matrix-free" if P_linear_solver == 1 else "block-CSR"), "cg_rel_tolerance": P_cg_tol,
-                       "cg_max_iterations": P_cg_max},
+                       "cg_max_iterations": P_cg_max, "library_options_set_on_the_command_line": opt or None},
             # several ranks: what THIS rank's exchanges moved and what its level kernels work on (pgo_get_sharding_stats, rank 0's view; bytes_round5_*: what round 5's union
             # all-reduce carried on the same graph).  Nothing multi-GPU in this repo has been timed on hardware before this run.
             "sharding_counters": shard_counters,
