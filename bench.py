@@ -570,6 +570,11 @@ def main():
             # several ranks: what THIS rank's exchanges moved and what its level kernels work on (pgo_get_sharding_stats, rank 0's view; bytes_round5_*: what round 5's union
             # all-reduce carried on the same graph).  Nothing multi-GPU in this repo has been timed on hardware before this run.
             "sharding_counters": shard_counters,
+            # (several ranks) what the weak leg's graph costs on ONE GPU as it grows — measured in round 6 (profiles/r06_weak_graph_growth.txt), quoted here so that an efficiency computed
+            # from the values of N = 1, 2, 4, 8 is read with the problem's own growth beside it
+            "weak_graph_note": ("N x C3 as ONE graph is a harder problem at every N: 10 LM iterations on one MI355X take 0.092 / 0.43 / 0.98 / 2.25 / 10.7 s at N = 1 / 2 / 4 / 6 / 8 "
+                                "(every step of the 800 000-keyframe graph is accepted, the trust region opens to 2.4e7, 20 441 PCG iterations instead of 798); the c5_strong leg — the same "
+                                "graph at every N — isolates the solver's scaling") if world > 1 and not strong else None,
             "libpgo_sha256": lib_sha, "static_traffic_notes": traffic_note or None,
             # the hash of the sources the loaded library was built from (compiled in by _build.py) next to the hash of this checkout's sources: equal = built from this tree
             "libpgo_sources_sha256": capi.build_info()[0], "checkout_sources_sha256": capi.build_info()[1],
