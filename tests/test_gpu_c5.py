@@ -96,7 +96,7 @@ def test_c5_reference_budget_of_iterations_matches_the_independent_cpu_trajector
 
 def test_c5_early_rejection_rule_takes_the_decisions_of_the_full_solves(c5):
     """The one decision rule Ceres does not have — a step rejected at an early-rejection pause, on an unconverged linear solve (pgo.h: cg_early_tolerance / cg_mid_tolerance) — on
-    config 5's full 10-iteration budget, where the independent CPU golden stops at iteration 8 — the first of the rejected ones, 8-10 —: the same solve with both pauses
+    config 5's full 10-iteration budget, where the independent CPU golden stops at iteration 9 — the first two of the rejected ones, 8-10 —: the same solve with both pauses
     OFF (Ceres' exact rule: every step's system solved to cg_rel_tolerance before it is judged) takes the same ten decisions and ends at the same cost.  HIP against HIP — evidence
     that the rule does not flip a decision here, not a substitute for the golden."""
     g = c5
