@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The graph of `bench.py --gpus N` (N x C3 as one graph: N x 100 000 poses, N x 100 003 switchable loops) solved by N in-process ranks on ONE GPU and by a single handle: a functional check
 of the weak-scaling leg at its real size (decisions, costs, PCG counts, the hierarchy's shape, the counters) — the timings mean nothing (the ranks share one GPU).
-  python scripts/dev/weak8_inprocess.py [N = 8] [lm_iterations = 10]"""
+  python scripts/dev/weak8_inprocess.py [N = 8] [lm_iterations = 10] [policy = spatial] [ranks-only]"""
 import json
 import sys
 import threading
@@ -15,12 +15,14 @@ from tests import util  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 n_it = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+policy = sys.argv[3] if len(sys.argv) > 3 else "spatial"
+skip_single = len(sys.argv) > 4 and sys.argv[4] == "ranks-only"
 g = graphgen.generate(100000 * N, 100003 * N, odom_f_max=2, seed=3)
 q, t, s = util.initial_state(g, True)
 P = util.pgo_problem(g, True, max_num_iterations=n_it)
 t0 = time.time(); _, t1, s1, sum1 = P.solve(q, t, s); single_s = time.time() - t0
 P.close()
-parts = sharding.partition(g, N, "spatial")
+parts = sharding.partition(g, N, policy)
 group = capi.local_group_create(N)
 out, err = [None] * N, []
 
@@ -46,7 +48,7 @@ d1 = [sum1.iterations[k].step_is_successful for k in range(sum1.num_logged)]
 dr = [sr.iterations[k].step_is_successful for k in range(sr.num_logged)]
 st = out[0][1]
 print(json.dumps({"what": "bench.py's weak-scaling graph at N = %d (%d poses / %d edges) on %d in-process ranks of ONE GPU against the single handle: functional, not a timing" % (N, g.n_poses, g.n_odom + g.n_loops, N),
-                  "decisions_equal": d1 == dr, "decisions": dr, "cost_rel_diff_max": max(abs(sr.iterations[k].cost - sum1.iterations[k].cost) / sum1.iterations[k].cost for k in range(sum1.num_logged)),
+                  "policy": policy, "decisions_equal": d1 == dr, "decisions": dr, "cost_rel_diff_max": max(abs(sr.iterations[k].cost - sum1.iterations[k].cost) / sum1.iterations[k].cost for k in range(sum1.num_logged)),
                   "pcg_single": int(sum1.cg_iterations), "pcg_ranks": int(sr.cg_iterations), "pcg_retries": int(sr.pcg_retries),
                   "all_ranks_identical": all(np.array_equal(out[0][0][1], o[0][1]) and np.array_equal(out[0][0][2], o[0][2]) for o in out),
                   "t_max_abs_diff": float(np.abs(out[0][0][1] - t1).max()), "single_handle_s": single_s, "ranks_wall_s_sharing_one_gpu": max(o[2] for o in out),
